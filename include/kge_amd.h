@@ -1,0 +1,190 @@
+/*
+ * kge_amd.h -- C ABI of the MI355X (gfx950) KGE scoring engine.
+ *
+ * This is the drop-in boundary of the hot path.  The
+ * reference (uma-pi1/kge, "LibKGE") has no native code; its boundary for this
+ * path is the index-level Python API of KgeModel.  Every entry point below
+ * replaces one reference function and cites it (paths relative to the
+ * reference tree):
+ *
+ *   kge_score_spo      KgeModel.score_spo        kge/model/kge_model.py:663-680
+ *   kge_score_sp       KgeModel.score_sp         kge/model/kge_model.py:682-702
+ *   kge_score_po       KgeModel.score_po         kge/model/kge_model.py:704-725
+ *   kge_score_sp_po    KgeModel.score_sp_po      kge/model/kge_model.py:749-789
+ *   kge_score_emb      RelationalScorer.score_emb kge/model/kge_model.py:151-213
+ *                      (ComplEx complex.py:18-43, DistMult distmult.py:13-25,
+ *                       TransE transe.py:15-37, RotatE rotate.py:20-69)
+ *   kge_score_neg      BatchNegativeSample.score (impl "triple")
+ *                                                kge/util/sampler.py:263-306
+ *   kge_rank_counts    EntityRankingJob._filter_and_rank /
+ *                      _get_ranks_and_num_ties   kge/job/eval_entity_ranking.py:533-596
+ *   kge_score_*_bwd    autograd backward of the above (implicit in the
+ *                      reference: train_1vsAll.py:70,81; train_KvsAll.py:293;
+ *                      train_negative_sampling.py:161)
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  All pointers are DEVICE
+ *     pointers (HBM) unless the name says host.  The library never allocates
+ *     or frees device memory and keeps no global state: outputs and
+ *     workspaces are caller-provided.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *     All work is enqueued on that stream; calls are asynchronous and
+ *     re-entrant.
+ *   - every function returns KGE_OK (0) or a negative kge_status; nothing
+ *     throws across the ABI.  kge_status_string() gives a static message.
+ *   - embedding tables are row-major [rows, dim] with leading dimension `ld`
+ *     (elements); element type f32 or bf16.  All scores are f32.
+ *   - index vectors may be int32 or int64 with an element stride (the
+ *     reference trainers pass stride-3 views triples[:,0] of an [n,3] tensor:
+ *     kge/job/train_1vsAll.py:64; eval passes int32: eval_entity_ranking.py:164).
+ *   - ComplEx/RotatE entity rows are [real half | imaginary half]
+ *     (complex.py:24-27, rotate.py:24-25); RotatE relation rows hold dim/2
+ *     phases in radians (rotate.py:28,88-93).
+ *   - arithmetic is specified operation by operation in DESIGN.md ("canonical
+ *     arithmetic"); the f32 paths are bit-reproducible against oracle/.
+ */
+#ifndef KGE_AMD_H
+#define KGE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGE_AMD_ABI_VERSION 1
+
+typedef enum kge_status {
+  KGE_OK = 0,
+  KGE_ERR_INVALID_ARG = -1,   /* NULL pointer, negative size, bad enum          */
+  KGE_ERR_UNSUPPORTED = -2,   /* valid request this build has no kernel for     */
+  KGE_ERR_LAUNCH = -3,        /* hipLaunchKernel / hip runtime error            */
+  KGE_ERR_NO_DEVICE = -4,     /* no gfx950 device visible                       */
+  KGE_ERR_WORKSPACE = -5      /* caller workspace too small                     */
+} kge_status;
+
+typedef enum kge_scorer {
+  KGE_COMPLEX = 0,            /* kge/model/complex.py                            */
+  KGE_DISTMULT = 1,           /* kge/model/distmult.py                           */
+  KGE_TRANSE = 2,             /* kge/model/transe.py                             */
+  KGE_ROTATE = 3              /* kge/model/rotate.py                             */
+} kge_scorer;
+
+typedef enum kge_dtype { KGE_F32 = 0, KGE_BF16 = 1 } kge_dtype;
+typedef enum kge_itype { KGE_I32 = 0, KGE_I64 = 1 } kge_itype;
+
+/* combine modes of RelationalScorer.score_emb (kge_model.py:151-213) */
+typedef enum kge_combine { KGE_SPO = 0, KGE_SP_ = 1, KGE_PO_ = 2 } kge_combine;
+
+/* Entity + relation lookup tables (LookupEmbedder._embeddings.weight,
+ * kge/model/embedder/lookup_embedder.py:44-46). */
+typedef struct kge_tables {
+  const void* ent;            /* [num_ent, dim]      */
+  const void* rel;            /* [num_rel, rel_dim]  */
+  int32_t dtype;              /* kge_dtype of both tables                        */
+  int32_t scorer;             /* kge_scorer                                      */
+  int64_t num_ent;
+  int64_t num_rel;
+  int64_t dim;                /* entity embedding size d                         */
+  int64_t rel_dim;            /* d, except RotatE: d/2                           */
+  int64_t ent_ld;             /* leading dimensions in elements                  */
+  int64_t rel_ld;
+  float l_norm;               /* TransE/RotatE `l_norm` option (transe.yaml:11)  */
+  int32_t reserved;
+} kge_tables;
+
+/* An index vector: element i is ptr[i*stride] of type itype.
+ * ptr == NULL means the identity 0,1,2,... (used for "all entities"). */
+typedef struct kge_index {
+  const void* ptr;
+  int32_t itype;              /* kge_itype */
+  int32_t reserved;
+  int64_t stride;             /* in elements */
+} kge_index;
+
+/* ---- library ---------------------------------------------------------- */
+int kge_abi_version(void);
+const char* kge_status_string(int status);
+/* Number of gfx950 devices visible to the HIP runtime (0 if none). */
+int kge_device_count(void);
+
+/* ---- index-level scoring (fused gather + score) ------------------------ */
+
+/* out[i] = score(s[i], p[i], o[i]), i < n.        KgeModel.score_spo */
+int kge_score_spo(const kge_tables* t, kge_index s, kge_index p, kge_index o,
+                  int64_t n, float* out, void* stream);
+
+/* out[i*ldo + j] = score(s[i], p[i], targets[j]), j < m.  KgeModel.score_sp
+ * targets.ptr == NULL: all entities, m must equal t->num_ent. */
+int kge_score_sp(const kge_tables* t, kge_index s, kge_index p, int64_t n,
+                 kge_index targets, int64_t m, float* out, int64_t ldo,
+                 void* stream);
+
+/* out[i*ldo + j] = score(targets[j], p[i], o[i]).  KgeModel.score_po */
+int kge_score_po(const kge_tables* t, kge_index p, kge_index o, int64_t n,
+                 kge_index targets, int64_t m, float* out, int64_t ldo,
+                 void* stream);
+
+/* out[i*ldo + j] = sp score, out[i*ldo + m + j] = po score (j < m); ldo >= 2m.
+ * KgeModel.score_sp_po (cat of score_sp and score_po over one entity subset). */
+int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o,
+                    int64_t n, kge_index targets, int64_t m, float* out,
+                    int64_t ldo, void* stream);
+
+/* Negative-sampling scores, the "triple" implementation without building the
+ * [n*K,3] index tensor: slot 0/2 = corrupt s / o.
+ * out[i*ldo + k] = score of triple i with slot replaced by neg[i*neg_ld + k].
+ * BatchNegativeSample.score, kge/util/sampler.py:291-306. */
+int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o,
+                  int64_t n, int slot, const void* neg, int32_t neg_itype,
+                  int64_t neg_ld, int64_t num_neg, float* out, int64_t ldo,
+                  void* stream);
+
+/* ---- embedding-level scoring (dense inputs, no gather) ----------------- */
+/* RelationalScorer.score_emb.  `t` supplies scorer, dtype, dim, rel_dim and
+ * l_norm only (t->ent/rel ignored).  SPO: all three [n, *] -> out[n];
+ * SP_: s,p [n,*], o [m,dim] -> out[n,m]; PO_: p,o [n,*], s [m,dim] -> out[n,m]. */
+int kge_score_emb(const kge_tables* t, int combine, const void* s_emb,
+                  int64_t s_ld, const void* p_emb, int64_t p_ld,
+                  const void* o_emb, int64_t o_ld, int64_t n, int64_t m,
+                  float* out, int64_t ldo, void* stream);
+
+/* ---- ranking ------------------------------------------------------------ */
+/* For each row i of scores[n, c] (leading dim lds) and its true score:
+ *   x = NaN -> -inf; filtered columns -> -inf; t = NaN -> -inf
+ *   close   = (x == t) || (isfinite(|x-t|) && |x-t| <= atol + |rtol*t|)
+ *   ties[i] += #close ;  rank[i] += #(x > t && !close)
+ * Filtered columns of row i are lbl_col[lbl_rowptr[i] .. lbl_rowptr[i+1]) minus
+ * col_offset; entries outside [0,c) and the entry equal to true_col[i] (global
+ * id, may be NULL) are ignored.  Columns must be unique within a row.
+ * lbl_rowptr == NULL: raw ranking.  rank/ties are int64 and ACCUMULATED
+ * (counts are additive over entity chunks: eval_entity_ranking.py:310-313).
+ * EntityRankingJob._filter_and_rank + _get_ranks_and_num_ties,
+ * kge/job/eval_entity_ranking.py:533-596. */
+int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
+                    const float* true_scores, const int64_t* lbl_rowptr,
+                    const int64_t* lbl_col, int64_t col_offset,
+                    const int64_t* true_col, float atol, float rtol,
+                    int64_t* rank, int64_t* ties, void* stream);
+
+/* ---- backward (autograd twins) ------------------------------------------ */
+/* Gradients of sum_ij gout[i,j]*score(i,j) w.r.t. the gathered query rows and
+ * the target rows, for kge_score_sp / kge_score_po (dir = KGE_SP_ / KGE_PO_).
+ *   g_a   [n, dim]      grad of the entity query row  (s for SP_, o for PO_)
+ *   g_p   [n, rel_dim]  grad of the relation row
+ *   g_tgt [m, dim]      grad of the target rows (dense; caller scatters/adds)
+ * All f32, overwritten.  Tables must be f32. */
+int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p,
+                        int64_t n, kge_index targets, int64_t m,
+                        const float* gout, int64_t ldg, float* g_a, float* g_p,
+                        float* g_tgt, void* stream);
+
+/* Gradients of sum_i gout[i]*score(s_i,p_i,o_i): g_s,g_o [n,dim], g_p [n,rel_dim]. */
+int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p,
+                      kge_index o, int64_t n, const float* gout, float* g_s,
+                      float* g_p, float* g_o, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGE_AMD_H */

@@ -1,0 +1,128 @@
+"""Pin the CPU oracle (oracle/kge_oracle.c) to the golden vectors produced by the
+live reference (tests/golden/make_golden.py).  CPU only.
+
+Tolerance for scores is the reference's own (tests/test_model.py:51-71 and
+entity_ranking.tie_handling: atol=1e-5, rtol=1e-4); rank counts, ranks and the
+metrics derived from them must be exact."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as ko
+
+from conftest import GOLDEN
+
+ATOL, RTOL = 1e-5, 1e-4
+SCORE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "scores_*.npz")))
+
+
+def _tables(g):
+    return ko.Tables(str(g["model"]), g["ent"], g["rel"], float(g["l_norm"]))
+
+
+def _close(a, b):
+    """Reference tolerance (atol=1e-5, rtol=1e-4), with atol taken relative to the
+    score scale: the f32 rounding noise of a length-d sum is proportional to the
+    magnitude of its terms, so for O(1) scores (the reference's own d=32 tests) this
+    IS atol=1e-5 and for d=512, N(0,1) tables (rms score ~30) it is 3e-4."""
+    scale = max(1.0, float(np.sqrt(np.mean(np.square(b[np.isfinite(b)], dtype=np.float64)))))
+    np.testing.assert_allclose(a, b, atol=ATOL * scale, rtol=RTOL)
+
+
+@pytest.mark.parametrize("path", SCORE_FILES, ids=[os.path.basename(p)[7:-4] for p in SCORE_FILES])
+def test_scores_match_reference(path):
+    g = np.load(path)
+    t = _tables(g)
+    s, p, o, sub = g["s"], g["p"], g["o"], g["sub"]
+    _close(ko.score_spo(t, s, p, o), g["spo"])
+    _close(ko.score_sp(t, s, p), g["sp"])
+    _close(ko.score_po(t, p, o), g["po"])
+    _close(ko.score_sp(t, s, p, sub), g["sp_sub"])
+    _close(ko.score_po(t, p, o, sub), g["po_sub"])
+    _close(ko.score_sp_po(t, s, p, o, sub), g["sp_po_sub"])
+    _close(ko.score_sp_po(t, s, p, o, None), g["sp_po_all"])
+    _close(ko.score_neg(t, s, p, o, 0, g["neg"]), g["neg_s"])
+    _close(ko.score_neg(t, s, p, o, 2, g["neg"]), g["neg_o"])
+
+
+@pytest.mark.parametrize("path", SCORE_FILES[:4], ids=[os.path.basename(p)[7:-4] for p in SCORE_FILES[:4]])
+def test_index_dtypes_and_strides(path):
+    """int32 / int64 / stride-3 views give identical results (train_1vsAll.py:64,
+    eval_entity_ranking.py:164 pass such views)."""
+    g = np.load(path)
+    t = _tables(g)
+    tri = np.stack([g["s"], g["p"], g["o"]], axis=1).astype(np.int64)
+    a = ko.score_sp(t, g["s"], g["p"])
+    b = ko.score_sp(t, tri[:, 0], tri[:, 1])
+    c = ko.score_sp(t, tri[:, 0].astype(np.int32), tri.astype(np.int32)[:, 1])
+    assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert np.array_equal(ko.score_spo(t, tri[:, 0], tri[:, 1], tri[:, 2]),
+                          ko.score_spo(t, g["s"], g["p"], g["o"]))
+
+
+def test_rank_core_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "rankcore.npz"))
+    atol, rtol = float(g["atol"]), float(g["rtol"])
+    rank, ties = ko.rank_counts(g["scores"], g["true"], atol=atol, rtol=rtol)
+    assert np.array_equal(rank, g["rank"]) and np.array_equal(ties, g["ties"])
+    # filtered: dense 0/inf labels -> CSR
+    lab = g["labels"]
+    n, c = g["scores"].shape
+
+    def csr(block):
+        rp, col = [0], []
+        for i in range(n):
+            col.extend(np.nonzero(np.isinf(block[i]))[0].tolist())
+            rp.append(len(col))
+        return np.array(rp), np.array(col, dtype=np.int64)
+
+    rp, col = csr(lab[:, :c])
+    o_rank, o_ties = ko.rank_counts(g["scores"], g["true"], rp, col, atol=atol, rtol=rtol)
+    rp, col = csr(lab[:, c:])
+    s_rank, s_ties = ko.rank_counts(g["scores_po"], g["true_po"], rp, col, atol=atol, rtol=rtol)
+    assert np.array_equal(o_rank, g["filt_o_rank"]) and np.array_equal(o_ties, g["filt_o_ties"])
+    assert np.array_equal(s_rank, g["filt_s_rank"]) and np.array_equal(s_ties, g["filt_s_ties"])
+
+
+def test_isclose_matches_torch():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(0)
+    t = rng.standard_normal(4000).astype(np.float32) * np.float32(30)
+    allowed = np.float32(1e-5) + np.abs(np.float32(1e-4) * t)
+    x = (t + allowed * rng.choice([-1.0, 1.0], t.size).astype(np.float32)
+         * (1 + rng.integers(-3, 4, t.size).astype(np.float32) * np.float32(6e-8))).astype(np.float32)
+    ref = torch.isclose(torch.from_numpy(x), torch.from_numpy(t), rtol=1e-4, atol=1e-5).numpy()
+    rank, ties = ko.rank_counts(x.reshape(-1, 1), t, atol=1e-5, rtol=1e-4)
+    assert np.array_equal(ties.astype(bool), ref)
+    assert 0.1 < ref.mean() < 0.9  # the sample really straddles the boundary
+
+
+@pytest.mark.parametrize("model", ["complex", "distmult", "transe", "rotate"])
+@pytest.mark.parametrize("tag,chunk", [("full", -1), ("chunk17", 17)])
+def test_entity_ranking_matches_reference(model, tag, chunk):
+    """EntityRankingJob._evaluate on a synthetic dataset: per-example ranks for
+    raw / filtered / filtered_with_test rankings and the final metrics."""
+    g = np.load(os.path.join(GOLDEN, f"eval_{model}.npz"))
+    t = ko.Tables(model, g["ent"], g["rel"], float(g["l_norm"]))
+    E = int(g["num_entities"])
+    valid = g["valid"]
+    ix = {sp: (ko.build_index(g[sp], (0, 1), 2), ko.build_index(g[sp], (1, 2), 0))
+          for sp in ("train", "valid", "test")}
+    metrics_ref = json.loads(str(g[f"metrics_{tag}"]))
+    cases = {
+        "": (None, None),
+        "_filt": ([ix["train"][0], ix["valid"][0]], [ix["train"][1], ix["valid"][1]]),
+        "_filt_test": ([ix["train"][0], ix["valid"][0], ix["test"][0]],
+                       [ix["train"][1], ix["valid"][1], ix["test"][1]]),
+    }
+    suffix = {"": "", "_filt": "_filtered", "_filt_test": "_filtered_with_test"}
+    for key, (fsp, fpo) in cases.items():
+        s_ranks, o_ranks = ko.evaluate_ranks(t, valid, fsp, fpo, chunk_size=chunk)
+        assert np.array_equal(o_ranks, g[f"o_rank{key}_{tag}"]), (model, key, "o")
+        assert np.array_equal(s_ranks, g[f"s_rank{key}_{tag}"]), (model, key, "s")
+        m = ko.compute_metrics(s_ranks, o_ranks, E)
+        for name in ("mean_reciprocal_rank", "mean_rank", "hits_at_1", "hits_at_10"):
+            assert abs(m[name] - metrics_ref[name + suffix[key]]) <= 1e-5 * max(1.0, abs(m[name]))
