@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Benchmark of the KGE scoring hot path on MI355X (contract: see the task prompt / DESIGN.md 7).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): scored triples / s, 1vsAll ComplEx d=512.
+Workload at N=1 = BASELINE configs[1]: FB15k-237 shape (E=14,541, R=237), ComplEx d=512,
+bf16 tables, batch n=512.  One STEP = the two scoring calls of a 1vsAll batch
+(kge/job/train_1vsAll.py:64,75): score_sp(s,p) and score_po(p,o), each an [n, E] f32 score
+matrix -> 2*n*E scored triples per step.  Inputs (tables, index vectors) are resident in
+HBM before the timed region.  Data is synthetic (no datasets/network here): N(0, 0.1)
+tables (examples/toy-complex-train.yaml:18-22), uniform random queries.
+
+N > 1 (weak scaling): the entity table is row-sharded, every rank owns an FB15k-237-sized
+shard (global E = N * 14,541) and scores the same n queries against its shard; the query
+rows live on their owner shards and are exchanged with ONE all-gather per step (RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+E_FB, R_FB, DIM, BATCH = 14541, 237, 512, 512
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_inputs(rank, device, n):
+    g = torch.Generator().manual_seed(0 + rank)
+    ent = torch.empty(E_FB, DIM).normal_(0, 0.1, generator=g)
+    rel = torch.empty(R_FB, DIM).normal_(0, 0.1, generator=torch.Generator().manual_seed(1234))
+    q = torch.Generator().manual_seed(1)
+    s = torch.randint(E_FB, (n,), generator=q)
+    p = torch.randint(R_FB, (n,), generator=q)
+    o = torch.randint(E_FB, (n,), generator=q)
+    return (ent.to(torch.bfloat16).to(device), rel.to(torch.bfloat16).to(device),
+            s.to(device), p.to(device), o.to(device))
+
+
+def algorithmic_bytes(n, m, d, elt=2):
+    """target rows once + query rows (s and r) + f32 scores out + indices."""
+    return m * d * elt + n * (d + d) * elt + n * m * 4 + 2 * n * 8
+
+
+def cpu_baseline(n, seconds):
+    """Reference CPU path restated op-for-op in torch (oracle/torch_port.py, bit-identical to
+    the live reference in the build container), fp32, all host cores, on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_port as tp
+
+    g = torch.Generator().manual_seed(0)
+    ent = torch.empty(E_FB, DIM).normal_(0, 0.1, generator=g)
+    rel = torch.empty(R_FB, DIM).normal_(0, 0.1, generator=g)
+    s = torch.randint(E_FB, (n,), generator=g)
+    p = torch.randint(R_FB, (n,), generator=g)
+    o = torch.randint(E_FB, (n,), generator=g)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        tp.score_sp("complex", ent, rel, s, p)  # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            tp.score_sp("complex", ent, rel, s, p)
+            tp.score_po("complex", ent, rel, p, o)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > seconds or reps >= 200:
+                break
+    return {"value": 2.0 * n * E_FB * reps / el, "unit": "scored triples/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{reps} 1vsAll steps (score_sp+score_po, n={n}, E={E_FB}, d={DIM}, fp32) "
+                      f"of oracle/torch_port.py (reference torch op sequence) in {el:.1f}s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=device)
+
+    from kge_amd import engine
+
+    n = a.batch
+    ent, rel, s, p, o = make_inputs(rank, device, n)
+    T = engine.Tables("complex", ent, rel)
+
+    if dist:
+        import torch.distributed as td
+        # query rows live on their owner shard: rank r owns rows [r*n/world, (r+1)*n/world)
+        per = (n + world - 1) // world
+        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
+        loc = torch.zeros(2, per, DIM, dtype=torch.bfloat16, device=device)
+        gath = torch.empty(world, 2, per, DIM, dtype=torch.bfloat16, device=device)
+
+        def step():
+            loc[0, : hi - lo] = ent[s[lo:hi]]
+            loc[1, : hi - lo] = ent[o[lo:hi]]
+            td.all_gather_into_tensor(gath.view(-1), loc.view(-1))
+            gs = gath[:, 0].reshape(world * per, DIM)[:n]
+            go = gath[:, 1].reshape(world * per, DIM)[:n]
+            pe = rel[p]
+            engine.score_emb("complex", gs, pe, ent, "sp_")
+            engine.score_emb("complex", ent, pe, go, "_po")
+    else:
+        def step():
+            engine.score_sp(T, s, p)
+            engine.score_po(T, p, o)
+
+    def sync():
+        if dist:
+            import torch.distributed as td
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    el = time.perf_counter() - t0
+    if dist:
+        import torch.distributed as td
+        tt = torch.tensor([el], device=device, dtype=torch.float64)
+        td.all_reduce(tt, op=td.ReduceOp.MAX)
+        el = float(tt.item())
+
+    # per-launch duration of the dominant kernel, HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(2 * a.steps)]
+    for k in range(a.steps):
+        ev[2 * k][0].record()
+        engine.score_sp(T, s, p)
+        ev[2 * k][1].record()
+        ev[2 * k + 1][0].record()
+        engine.score_po(T, p, o)
+        ev[2 * k + 1][1].record()
+    torch.cuda.synchronize()
+    kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    avg_ms = sum(kern_ms) / len(kern_ms)
+
+    if rank == 0:
+        total = 2.0 * n * E_FB * world * a.steps
+        ab = algorithmic_bytes(n, E_FB, DIM)
+        achieved = ab / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "scored triples/sec (1vsAll, ComplEx d=512)",
+            "value": total / el,
+            "unit": "scored triples/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": "FB15k-237 shape ComplEx d=512 1vsAll scoring, bf16 tables, f32 scores: "
+                            "score_sp + score_po per step",
+                "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n,
+                "parallelism": f"entity-shard x{world}" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "pairs_bf16_kernel<ComplEx> (one score_sp / score_po launch)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": ab,
+                "avg_launch_us": avg_ms * 1e3,
+                "median_launch_us": kern_ms[len(kern_ms) // 2] * 1e3,
+                "traffic": None,
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
+        print(json.dumps(out))
+    if dist:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,8 +90,16 @@ typedef struct kge_tables {
   int64_t ent_ld;             /* leading dimensions in elements                  */
   int64_t rel_ld;
   float l_norm;               /* TransE/RotatE `l_norm` option (transe.yaml:11)  */
-  int32_t reserved;
+  int32_t flags;              /* kge_flags, 0 = default                           */
 } kge_tables;
+
+/* Per-call kernel selection (no global state).  Default: fastest kernel.        */
+typedef enum kge_flags {
+  KGE_FLAG_EXACT = 1,         /* ComplEx/DistMult on bf16 tables: use the bit-reproducible
+                                 f32-chain kernel instead of the bf16 MFMA kernel            */
+  KGE_FLAG_NO_MFMA = 2        /* f32 ComplEx/DistMult: VALU fmaf chain instead of the f32
+                                 MFMA (same bits; used to cross-check the MFMA mapping)      */
+} kge_flags;
 
 /* An index vector: element i is ptr[i*stride] of type itype.
  * ptr == NULL means the identity 0,1,2,... (used for "all entities"). */

@@ -1,0 +1,101 @@
+"""ctypes binding of libkge_amd.so (C ABI: include/kge_amd.h).
+
+The product path has NO fallback: if the library is missing or cannot be loaded this
+module raises, and every op in kge_amd.engine raises on non-GPU tensors.  torch is
+imported first so that the HIP runtime already mapped by torch (torch/lib/libamdhip64.so,
+SONAME libamdhip64.so.7) is the one our library binds to -- torch's streams and device
+pointers must belong to the same runtime instance.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must be loaded before libkge_amd.so, see above)
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libkge_amd.so")
+
+KGE_OK = 0
+COMPLEX, DISTMULT, TRANSE, ROTATE = 0, 1, 2, 3
+SCORERS = {"complex": COMPLEX, "distmult": DISTMULT, "transe": TRANSE, "rotate": ROTATE}
+F32, BF16 = 0, 1
+I32, I64 = 0, 1
+SPO, SP_, PO_ = 0, 1, 2
+FLAG_EXACT, FLAG_NO_MFMA = 1, 2
+
+c_i64 = ctypes.c_int64
+c_vp = ctypes.c_void_p
+
+
+class KgeTables(ctypes.Structure):
+    _fields_ = [
+        ("ent", c_vp), ("rel", c_vp), ("dtype", ctypes.c_int32), ("scorer", ctypes.c_int32),
+        ("num_ent", c_i64), ("num_rel", c_i64), ("dim", c_i64), ("rel_dim", c_i64),
+        ("ent_ld", c_i64), ("rel_ld", c_i64), ("l_norm", ctypes.c_float),
+        ("flags", ctypes.c_int32),
+    ]
+
+
+class KgeIndex(ctypes.Structure):
+    _fields_ = [("ptr", c_vp), ("itype", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("stride", c_i64)]
+
+
+# every symbol include/kge_amd.h declares: name -> (restype, argtypes)
+_PT = ctypes.POINTER(KgeTables)
+PROTOTYPES = {
+    "kge_abi_version": (ctypes.c_int, []),
+    "kge_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "kge_device_count": (ctypes.c_int, []),
+    "kge_score_spo": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp]),
+    "kge_score_sp": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_sp_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_neg": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int, c_vp,
+                                     ctypes.c_int32, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_emb": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                     c_i64, c_i64, c_vp, c_i64, c_vp]),
+    "kge_rank_counts": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                       ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
+    "kge_score_pairs_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, KgeIndex,
+                                           c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "kge_score_spo_bwd": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp,
+                                         c_vp, c_vp, c_vp]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1))]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libkge_amd.so (raises if it has not been built: no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (make -C kge_amd/csrc). kge_amd has no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.kge_abi_version() != 1:
+            raise RuntimeError("libkge_amd.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != KGE_OK:
+        msg = lib().kge_status_string(status).decode()
+        raise RuntimeError(f"{what} failed: {msg} (kge_status {status})")

@@ -1,0 +1,234 @@
+// api.hip -- the C ABI of libkge_amd.so (include/kge_amd.h): argument validation and
+// kernel selection.  No torch, no allocation, no global state; every call enqueues on the
+// caller's hipStream_t and returns a kge_status.
+#include "common.hpp"
+
+namespace kge {
+int run_spo(int scorer, int dtype, bool neg_mode, const Operand& S, const Operand& R,
+            const Operand& O, int d, int dr, long long n, int slot, const void* neg,
+            int neg_itype, long long neg_ld, long long K, float lp, float* out,
+            long long ldo, hipStream_t st);
+int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, const Operand& R,
+                    const Operand& TG, int dir, int d, int dr, long long n, long long m,
+                    float lp, float* out, long long ldo, hipStream_t st);
+bool pairs_bf16_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
+                          const Operand& TG);
+int run_pairs_bf16(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
+                   int d, long long n, long long m, float* out, long long ldo, hipStream_t st);
+int run_rank(const float* scores, long long lds, long long n, long long c,
+             const float* true_scores, const long long* rowptr, const long long* lcol,
+             long long col_offset, const long long* true_col, float atol, float rtol,
+             long long* rank, long long* ties, hipStream_t st);
+int run_pairs_bwd(const kge_tables* t, int dir, const Operand& A, const Operand& R,
+                  const Operand& TG, long long n, long long m, const float* gout, long long ldg,
+                  float* g_a, float* g_p, float* g_tgt, hipStream_t st);
+int run_spo_bwd(const kge_tables* t, const Operand& S, const Operand& R, const Operand& O,
+                long long n, const float* gout, float* g_s, float* g_p, float* g_o,
+                hipStream_t st);
+}  // namespace kge
+
+using namespace kge;
+
+namespace {
+
+int check_tables(const kge_tables* t, bool need_ptrs) {
+  if (!t) return KGE_ERR_INVALID_ARG;
+  if (t->scorer < KGE_COMPLEX || t->scorer > KGE_ROTATE) return KGE_ERR_INVALID_ARG;
+  if (t->dtype != KGE_F32 && t->dtype != KGE_BF16) return KGE_ERR_INVALID_ARG;
+  if (t->dim <= 0 || t->rel_dim <= 0 || t->dim > (1 << 20)) return KGE_ERR_INVALID_ARG;
+  const bool cplx = t->scorer == KGE_COMPLEX || t->scorer == KGE_ROTATE;
+  if (cplx && (t->dim % 2)) return KGE_ERR_INVALID_ARG;  // rotate.py:82-86
+  if (t->scorer == KGE_ROTATE) {
+    if (t->rel_dim != t->dim / 2) return KGE_ERR_INVALID_ARG;  // rotate.py:87-93
+  } else if (t->rel_dim != t->dim) {
+    return KGE_ERR_INVALID_ARG;
+  }
+  if ((t->scorer == KGE_TRANSE || t->scorer == KGE_ROTATE) && !(t->l_norm > 0.0f))
+    return KGE_ERR_INVALID_ARG;
+  if (need_ptrs) {
+    if (!t->ent || !t->rel) return KGE_ERR_INVALID_ARG;
+    if (t->num_ent <= 0 || t->num_rel <= 0) return KGE_ERR_INVALID_ARG;
+    if (t->ent_ld < t->dim || t->rel_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
+  }
+  return KGE_OK;
+}
+
+int check_index(const kge_index& ix, bool allow_null) {
+  if (!ix.ptr) return allow_null ? KGE_OK : KGE_ERR_INVALID_ARG;
+  if (ix.itype != KGE_I32 && ix.itype != KGE_I64) return KGE_ERR_INVALID_ARG;
+  if (ix.stride < 1) return KGE_ERR_INVALID_ARG;
+  return KGE_OK;
+}
+
+Operand ent_op(const kge_tables* t, const kge_index& ix) {
+  return Operand{t->ent, t->ent_ld, make_index(ix)};
+}
+Operand rel_op(const kge_tables* t, const kge_index& ix) {
+  return Operand{t->rel, t->rel_ld, make_index(ix)};
+}
+
+int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand& R,
+                   const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo,
+                   hipStream_t st) {
+  const int d = (int)t->dim, dr = (int)t->rel_dim;
+  if (!(t->flags & KGE_FLAG_EXACT) && pairs_bf16_supported(t->scorer, t->dtype, d, A, R, TG))
+    return run_pairs_bf16(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
+  const bool mfma = !(t->flags & KGE_FLAG_NO_MFMA);
+  return run_pairs_exact(t->scorer, t->dtype, mfma, A, R, TG, dir, d, dr, n, m, t->l_norm, out,
+                         ldo, st);
+}
+
+int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+                kge_index targets, int64_t m, float* out, int64_t ldo, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (n < 0 || m < 0 || (!out && n * m > 0) || ldo < m) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(a, false)) || (rc = check_index(p, false)) ||
+      (rc = check_index(targets, true)))
+    return rc;
+  if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
+  return pairs_dispatch(t, dir, ent_op(t, a), rel_op(t, p), ent_op(t, targets), n, m, out, ldo,
+                        (hipStream_t)stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int kge_abi_version(void) { return KGE_AMD_ABI_VERSION; }
+
+const char* kge_status_string(int status) {
+  switch (status) {
+    case KGE_OK: return "ok";
+    case KGE_ERR_INVALID_ARG: return "invalid argument";
+    case KGE_ERR_UNSUPPORTED: return "unsupported configuration";
+    case KGE_ERR_LAUNCH: return "HIP launch/runtime error";
+    case KGE_ERR_NO_DEVICE: return "no gfx950 device";
+    case KGE_ERR_WORKSPACE: return "workspace too small";
+  }
+  return "unknown status";
+}
+
+int kge_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int kge_score_spo(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                  float* out, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (n < 0 || (!out && n > 0)) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s, false)) || (rc = check_index(p, false)) ||
+      (rc = check_index(o, false)))
+    return rc;
+  return run_spo(t->scorer, t->dtype, false, ent_op(t, s), rel_op(t, p), ent_op(t, o),
+                 (int)t->dim, (int)t->rel_dim, n, 2, nullptr, 0, 0, 0, t->l_norm, out, 0,
+                 (hipStream_t)stream);
+}
+
+int kge_score_sp(const kge_tables* t, kge_index s, kge_index p, int64_t n, kge_index targets,
+                 int64_t m, float* out, int64_t ldo, void* stream) {
+  return pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, stream);
+}
+
+int kge_score_po(const kge_tables* t, kge_index p, kge_index o, int64_t n, kge_index targets,
+                 int64_t m, float* out, int64_t ldo, void* stream) {
+  return pairs_entry(t, KGE_PO_, o, p, n, targets, m, out, ldo, stream);
+}
+
+int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                    kge_index targets, int64_t m, float* out, int64_t ldo, void* stream) {
+  if (ldo < 2 * m) return KGE_ERR_INVALID_ARG;
+  int rc = pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, stream);
+  if (rc) return rc;
+  return pairs_entry(t, KGE_PO_, o, p, n, targets, m, out ? out + m : out, ldo, stream);
+}
+
+int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                  int slot, const void* neg, int32_t neg_itype, int64_t neg_ld,
+                  int64_t num_neg, float* out, int64_t ldo, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (n < 0 || num_neg < 0 || (slot != 0 && slot != 2)) return KGE_ERR_INVALID_ARG;
+  if (n * num_neg > 0 && (!out || !neg)) return KGE_ERR_INVALID_ARG;
+  if (neg_ld < num_neg || ldo < num_neg) return KGE_ERR_INVALID_ARG;
+  if (neg_itype != KGE_I32 && neg_itype != KGE_I64) return KGE_ERR_INVALID_ARG;
+  if (n > 65535) return KGE_ERR_UNSUPPORTED;  // grid.y; callers sub-batch far below this
+  if ((rc = check_index(s, false)) || (rc = check_index(p, false)) ||
+      (rc = check_index(o, false)))
+    return rc;
+  return run_spo(t->scorer, t->dtype, true, ent_op(t, s), rel_op(t, p), ent_op(t, o),
+                 (int)t->dim, (int)t->rel_dim, n, slot, neg, neg_itype, neg_ld, num_neg,
+                 t->l_norm, out, ldo, (hipStream_t)stream);
+}
+
+int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s_ld,
+                  const void* p_emb, int64_t p_ld, const void* o_emb, int64_t o_ld, int64_t n,
+                  int64_t m, float* out, int64_t ldo, void* stream) {
+  int rc = check_tables(t, false);
+  if (rc) return rc;
+  if (!s_emb || !p_emb || !o_emb || n < 0 || m < 0) return KGE_ERR_INVALID_ARG;
+  if (s_ld < t->dim || o_ld < t->dim || p_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
+  const Index ident{nullptr, 1, KGE_I64};
+  Operand S{s_emb, s_ld, ident}, P{p_emb, p_ld, ident}, O{o_emb, o_ld, ident};
+  hipStream_t st = (hipStream_t)stream;
+  if (combine == KGE_SPO) {
+    if (!out && n > 0) return KGE_ERR_INVALID_ARG;
+    return run_spo(t->scorer, t->dtype, false, S, P, O, (int)t->dim, (int)t->rel_dim, n, 2,
+                   nullptr, 0, 0, 0, t->l_norm, out, 0, st);
+  }
+  if ((!out && n * m > 0) || ldo < m) return KGE_ERR_INVALID_ARG;
+  if (combine == KGE_SP_) return pairs_dispatch(t, KGE_SP_, S, P, O, n, m, out, ldo, st);
+  if (combine == KGE_PO_) return pairs_dispatch(t, KGE_PO_, O, P, S, n, m, out, ldo, st);
+  return KGE_ERR_INVALID_ARG;
+}
+
+int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
+                    const float* true_scores, const int64_t* lbl_rowptr,
+                    const int64_t* lbl_col, int64_t col_offset, const int64_t* true_col,
+                    float atol, float rtol, int64_t* rank, int64_t* ties, void* stream) {
+  if (n < 0 || c < 0 || lds < c) return KGE_ERR_INVALID_ARG;
+  if (n * c > 0 && (!scores || !true_scores || !rank || !ties)) return KGE_ERR_INVALID_ARG;
+  if (lbl_rowptr && !lbl_col) return KGE_ERR_INVALID_ARG;
+  if (n > 65535) return KGE_ERR_UNSUPPORTED;
+  return run_rank(scores, lds, n, c, true_scores, (const long long*)lbl_rowptr,
+                  (const long long*)lbl_col, col_offset, (const long long*)true_col, atol, rtol,
+                  (long long*)rank, (long long*)ties, (hipStream_t)stream);
+}
+
+int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+                        kge_index targets, int64_t m, const float* gout, int64_t ldg,
+                        float* g_a, float* g_p, float* g_tgt, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
+  if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || m < 0 || ldg < m) return KGE_ERR_INVALID_ARG;
+  if (n * m > 0 && (!gout || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(a, false)) || (rc = check_index(p, false)) ||
+      (rc = check_index(targets, true)))
+    return rc;
+  if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
+  return run_pairs_bwd(t, dir, ent_op(t, a), rel_op(t, p), ent_op(t, targets), n, m, gout, ldg,
+                       g_a, g_p, g_tgt, (hipStream_t)stream);
+}
+
+int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                      const float* gout, float* g_s, float* g_p, float* g_o, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
+  if (n < 0 || (n > 0 && (!gout || !g_s || !g_p || !g_o))) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s, false)) || (rc = check_index(p, false)) ||
+      (rc = check_index(o, false)))
+    return rc;
+  return run_spo_bwd(t, ent_op(t, s), rel_op(t, p), ent_op(t, o), n, gout, g_s, g_p, g_o,
+                     (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+// common.hpp -- device helpers shared by the gfx950 kernels of the KGE scoring engine.
+//
+// Canonical arithmetic: every f32 operation sequence below is
+// specified so that oracle/kge_oracle.c reproduces it bit for bit.  The translation
+// unit is compiled with -ffp-contract=off; fused multiply-adds appear only where
+// __builtin_fmaf is written.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/kge_amd.h"
+
+namespace kge {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Index vector as passed over the C ABI, flattened for kernel arguments.
+struct Index {
+  const void* ptr;   // NULL = identity
+  long long stride;  // elements
+  int itype;         // 0 = int32, 1 = int64
+};
+
+__host__ inline Index make_index(const kge_index& k) {
+  Index r;
+  r.ptr = k.ptr;
+  r.stride = k.stride;
+  r.itype = k.itype;
+  return r;
+}
+
+__device__ __forceinline__ long long index_at(const Index& ix, long long i) {
+  if (ix.ptr == nullptr) return i;
+  if (ix.itype) return ((const long long*)ix.ptr)[i * ix.stride];
+  return (long long)((const int*)ix.ptr)[i * ix.stride];
+}
+
+// One kernel operand: rows `idx[i]` of a row-major matrix (table or dense embeddings).
+struct Operand {
+  const void* base;
+  long long ld;  // elements
+  Index idx;
+};
+
+// Flattened table descriptor for kernels.
+struct Tables {
+  const void* ent;
+  const void* rel;
+  long long num_ent, num_rel;
+  int dim, rel_dim;
+  long long ent_ld, rel_ld;
+  float l_norm;
+};
+
+__host__ inline Tables make_tables(const kge_tables* t) {
+  Tables r;
+  r.ent = t->ent;
+  r.rel = t->rel;
+  r.num_ent = t->num_ent;
+  r.num_rel = t->num_rel;
+  r.dim = (int)t->dim;
+  r.rel_dim = (int)t->rel_dim;
+  r.ent_ld = t->ent_ld;
+  r.rel_ld = t->rel_ld;
+  r.l_norm = t->l_norm;
+  return r;
+}
+
+// ---- bf16 ---------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __uint_as_float(((unsigned int)h) << 16);
+}
+// round-to-nearest-even, NaN -> quiet NaN (same bit recipe as the oracle)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+// ---- element loads (T = float or unsigned short(bf16)) --------------------------
+template <typename T>
+__device__ __forceinline__ float ld1(const T* p);
+template <>
+__device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld1<unsigned short>(const unsigned short* p) {
+  return bf16_to_f32(*p);
+}
+
+// 4 consecutive elements -> 4 floats (pointer must be 16 B (f32) / 8 B (bf16) aligned)
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* p);
+template <>
+__device__ __forceinline__ f32x4 ld4<float>(const float* p) {
+  return *reinterpret_cast<const f32x4*>(p);
+}
+template <>
+__device__ __forceinline__ f32x4 ld4<unsigned short>(const unsigned short* p) {
+  u32x2 v = *reinterpret_cast<const u32x2*>(p);
+  f32x4 r;
+  r[0] = __uint_as_float(v[0] << 16);
+  r[1] = __uint_as_float(v[0] & 0xffff0000u);
+  r[2] = __uint_as_float(v[1] << 16);
+  r[3] = __uint_as_float(v[1] & 0xffff0000u);
+  return r;
+}
+
+// 8 consecutive elements -> 8 floats (32 B (f32) / 16 B (bf16) aligned)
+struct f32x8 {
+  float v[8];
+};
+template <typename T>
+__device__ __forceinline__ f32x8 ld8(const T* p);
+template <>
+__device__ __forceinline__ f32x8 ld8<float>(const float* p) {
+  f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[i] = a[i];
+    r.v[4 + i] = b[i];
+  }
+  return r;
+}
+template <>
+__device__ __forceinline__ f32x8 ld8<unsigned short>(const unsigned short* p) {
+  u32x4 v = *reinterpret_cast<const u32x4*>(p);
+  f32x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[2 * i] = __uint_as_float(v[i] << 16);
+    r.v[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u);
+  }
+  return r;
+}
+
+// ---- canonical sin/cos (oracle: ko_sincosf) ---------------------------------------
+__device__ __forceinline__ void sincos_canon(float x, float& sn, float& cs) {
+  const float TWO_OVER_PI = 0.63661977236758134308f;
+  const float P1 = 1.5707855224609375f;
+  const float P2 = 1.0804334124e-5f;
+  const float P3 = 6.0770999344e-11f;
+  float j = __builtin_rintf(x * TWO_OVER_PI);
+  float r = __builtin_fmaf(-j, P1, x);
+  r = __builtin_fmaf(-j, P2, r);
+  r = __builtin_fmaf(-j, P3, r);
+  float z = r * r;
+  float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+  float s = __builtin_fmaf(ps * z, r, r);
+  float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+  float c = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  int q = ((int)j) & 3;
+  float so = (q & 1) ? c : s;
+  float co = (q & 1) ? s : c;
+  so = (q & 2) ? -so : so;
+  co = ((q + 1) & 2) ? -co : co;
+  sn = so;
+  cs = co;
+}
+
+// IEEE-correct sqrt (the oracle uses glibc sqrtf, correctly rounded).
+__device__ __forceinline__ float sqrt_rn(float x) { return __fsqrt_rn(x); }
+
+enum { NORM_L1 = 1, NORM_L2 = 2, NORM_LP = 3 };
+__host__ inline int norm_mode(float p) { return p == 1.0f ? NORM_L1 : (p == 2.0f ? NORM_L2 : NORM_LP); }
+
+// accumulate one non-negative distance component
+template <int NORM>
+__device__ __forceinline__ float norm_acc(float acc, float a, float p) {
+  if (NORM == NORM_L1) return acc + a;
+  if (NORM == NORM_L2) return __builtin_fmaf(a, a, acc);
+  return acc + powf(a, p);  // general p: libm pow, tolerance-level only
+}
+
+}  // namespace kge

@@ -1,0 +1,126 @@
+// rank.hip -- filter-and-rank counts of EntityRankingJob on gfx950:
+// _filter_and_rank + _get_ranks_and_num_ties (kge/job/eval_entity_ranking.py:533-596).
+//
+// The reference makes ~10 full passes over the [n, 2c] score matrix per ranking (clone,
+// isnan, subtract dense 0/inf labels, isclose, gt, and, two sums) plus a sparse->dense
+// label scatter.  Here: ONE streaming pass over the scores (HBM scan bound, n*c*4 bytes)
+// counting `close` and `greater & !close` against the row's true score, then a sparse
+// correction over the row's CSR filter labels: a filtered column becomes -inf
+// (x - inf = -inf, NaN -> -inf, :565-566,583-586), so its raw contribution is taken out
+// and the contribution of -inf is put in.  Integer work: bit-exact vs oracle/.
+#include "common.hpp"
+
+namespace kge {
+
+__device__ __forceinline__ bool is_close(float x, float t, float atol, float rtol) {
+  // torch.isclose in f32: (x == t) | (isfinite(|x-t|) & (|x-t| <= atol + |rtol*t|))
+  if (x == t) return true;
+  float err = __builtin_fabsf(x - t);
+  float allowed = atol + __builtin_fabsf(rtol * t);
+  return __builtin_isfinite(err) && err <= allowed;
+}
+
+__device__ __forceinline__ void count_one(float x, float t, float atol, float rtol, int& gt,
+                                          int& cl) {
+  if (x != x) x = -__builtin_inff();
+  bool c = is_close(x, t, atol, rtol);
+  cl += c ? 1 : 0;
+  gt += (x > t && !c) ? 1 : 0;
+}
+
+constexpr int RK_THREADS = 256;
+
+__global__ __launch_bounds__(RK_THREADS) void rank_kernel(
+    const float* __restrict__ scores, long long lds, long long n, long long c,
+    const float* __restrict__ true_scores, const long long* __restrict__ rowptr,
+    const long long* __restrict__ lcol, long long col_offset,
+    const long long* __restrict__ true_col, float atol, float rtol,
+    unsigned long long* __restrict__ rank, unsigned long long* __restrict__ ties,
+    long long cols_per_block) {
+  const long long i = blockIdx.y;
+  const long long jb = (long long)blockIdx.x * cols_per_block;
+  long long je = jb + cols_per_block;
+  if (je > c) je = c;
+  float t = true_scores[i];
+  if (t != t) t = -__builtin_inff();
+  const float* row = scores + i * lds;
+  int gt = 0, cl = 0;
+
+  // scalar head up to 16-byte alignment, float4 body, scalar tail
+  long long j0 = jb;
+  const uintptr_t addr = (uintptr_t)(row + jb);
+  long long head = ((16 - (addr & 15)) & 15) >> 2;
+  if (head > je - jb) head = je - jb;
+  if ((long long)threadIdx.x < head) count_one(row[jb + threadIdx.x], t, atol, rtol, gt, cl);
+  j0 = jb + head;
+  const long long nvec = (je - j0) >> 2;
+  const f32x4* vrow = reinterpret_cast<const f32x4*>(row + j0);
+  for (long long v = threadIdx.x; v < nvec; v += RK_THREADS) {
+    f32x4 x = vrow[v];
+    count_one(x[0], t, atol, rtol, gt, cl);
+    count_one(x[1], t, atol, rtol, gt, cl);
+    count_one(x[2], t, atol, rtol, gt, cl);
+    count_one(x[3], t, atol, rtol, gt, cl);
+  }
+  const long long jt = j0 + (nvec << 2);
+  if (jt + (long long)threadIdx.x < je) count_one(row[jt + threadIdx.x], t, atol, rtol, gt, cl);
+
+  // sparse filter correction (labels of this row that fall into this block's columns)
+  if (rowptr != nullptr) {
+    const long long tc = true_col ? true_col[i] : -1;
+    for (long long e = rowptr[i] + threadIdx.x; e < rowptr[i + 1]; e += RK_THREADS) {
+      const long long g = lcol[e];
+      if (true_col && g == tc) continue;  // the positive itself stays (:288-290)
+      const long long j = g - col_offset;
+      if (j < jb || j >= je) continue;
+      int rg = 0, rc = 0;
+      count_one(row[j], t, atol, rtol, rg, rc);
+      const bool fc = is_close(-__builtin_inff(), t, atol, rtol);
+      gt -= rg;  // -inf is never greater
+      cl += (fc ? 1 : 0) - rc;
+    }
+  }
+
+  // block reduction
+  __shared__ int sg[RK_THREADS / 64], sc[RK_THREADS / 64];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    gt += __shfl_xor(gt, off, 64);
+    cl += __shfl_xor(cl, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sg[threadIdx.x >> 6] = gt;
+    sc[threadIdx.x >> 6] = cl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long G = 0, C = 0;
+#pragma unroll
+    for (int w = 0; w < RK_THREADS / 64; ++w) {
+      G += sg[w];
+      C += sc[w];
+    }
+    if (G != 0) atomicAdd(&rank[i], (unsigned long long)G);
+    if (C != 0) atomicAdd(&ties[i], (unsigned long long)C);
+  }
+}
+
+int run_rank(const float* scores, long long lds, long long n, long long c,
+             const float* true_scores, const long long* rowptr, const long long* lcol,
+             long long col_offset, const long long* true_col, float atol, float rtol,
+             long long* rank, long long* ties, hipStream_t st) {
+  if (n == 0 || c == 0) return KGE_OK;
+  // enough blocks to fill the chip: ~2048 blocks, at least 4096 columns per block
+  long long splits = (2048 + n - 1) / n;
+  long long cpb = (c + splits - 1) / splits;
+  if (cpb < 4096) cpb = 4096;
+  cpb = (cpb + 3) & ~3LL;
+  splits = (c + cpb - 1) / cpb;
+  dim3 grid((unsigned)splits, (unsigned)n);
+  hipLaunchKernelGGL(rank_kernel, grid, dim3(RK_THREADS), 0, st, scores, lds, n, c, true_scores,
+                     rowptr, lcol, col_offset, true_col, atol, rtol,
+                     (unsigned long long*)rank, (unsigned long long*)ties, cpb);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+}  // namespace kge

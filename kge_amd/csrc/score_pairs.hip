@@ -1,0 +1,299 @@
+// score_pairs.hip -- "one query row vs many target rows" scoring, gfx950:
+// KgeModel.score_sp / score_po (kge_model.py:682-725) and the sp_/_po branches of the
+// four scorers (complex.py:36-39, distmult.py:17-21, transe.py:19-34, rotate.py:43-64),
+// with the embedding gather (lookup_embedder.py:96-112) fused in.
+//
+// This is the exact f32 path: every output element is ONE sequential chain over the
+// coordinate pairs c = 0..ceil(d/2)-1 (first-half element c, then second-half element
+// ceil(d/2)+c), identical to pair_score() in oracle/kge_oracle.c, so results are
+// bit-reproducible for f32 AND bf16 tables (bf16 values are widened exactly; for
+// ComplEx/DistMult on bf16 tables the query vector q is rounded to bf16 first, like a
+// bf16 GEMM operand).
+//
+//   tile      64 query rows x 64 target rows per 256-thread workgroup
+//   staging   gather + query build (q = s(x)r, s+r, s*e^{i th}, ...) into LDS as
+//             Qs[half][c][row], Ts[half][c][row] (row fastest: conflict-free reads)
+//   compute   ComplEx/DistMult: v_mfma_f32_32x32x2_f32 -- k=0 is the first-half element,
+//             k=1 the second-half element of coordinate c; the f32 MFMA is an exact
+//             k-ordered fmaf chain (cdna guide section 3), i.e. the canonical order.
+//             TransE/RotatE: 4x4 register micro-tile per thread on the VALU.
+#include "common.hpp"
+
+namespace kge {
+
+constexpr int PT_BM = 64, PT_BN = 64, PT_KC = 16, PT_LD = 68;
+
+template <typename T, bool VEC>
+__device__ __forceinline__ f32x4 load4(const T* row, int c, int limit) {
+  if (VEC) return ld4<T>(row + c);
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (c + i < limit) ? ld1<T>(row + c + i) : 0.0f;
+  return r;
+}
+
+// q halves for 4 coordinates.  a0/a1: entity row halves, r0/r1: relation row halves
+// (RotatE: r0 = phases).  dir: KGE_SP_ or KGE_PO_.
+template <int SCORER>
+__device__ __forceinline__ void build_q4(int dir, const f32x4& a0, const f32x4& a1,
+                                         const f32x4& r0, const f32x4& r1, f32x4& q0,
+                                         f32x4& q1) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (SCORER == KGE_DISTMULT) {
+      q0[i] = a0[i] * r0[i];
+      q1[i] = a1[i] * r1[i];
+    } else if (SCORER == KGE_TRANSE) {
+      q0[i] = (dir == KGE_SP_) ? (a0[i] + r0[i]) : (a0[i] - r0[i]);
+      q1[i] = (dir == KGE_SP_) ? (a1[i] + r1[i]) : (a1[i] - r1[i]);
+    } else if (SCORER == KGE_COMPLEX) {
+      if (dir == KGE_SP_) {
+        q0[i] = a0[i] * r0[i] - a1[i] * r1[i];
+        q1[i] = a1[i] * r0[i] + a0[i] * r1[i];
+      } else {
+        q0[i] = r0[i] * a0[i] + r1[i] * a1[i];
+        q1[i] = r0[i] * a1[i] - r1[i] * a0[i];
+      }
+    } else {  // ROTATE
+      float sn, cs;
+      sincos_canon(r0[i], sn, cs);
+      if (dir == KGE_SP_) {
+        q0[i] = a0[i] * cs - a1[i] * sn;
+        q1[i] = a0[i] * sn + a1[i] * cs;
+      } else {
+        q0[i] = cs * a0[i] + sn * a1[i];
+        q1[i] = cs * a1[i] - sn * a0[i];
+      }
+    }
+  }
+}
+
+template <int SCORER, typename T, int NORM, bool VEC, bool MFMA>
+__global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operand TG, int dir,
+                                                    int d, int dr, long long n, long long m,
+                                                    float lp, int round_q,
+                                                    float* __restrict__ out, long long ldo) {
+  constexpr bool DOT = (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT);
+  __shared__ __attribute__((aligned(16))) float Qs[2][PT_KC][PT_LD];
+  __shared__ __attribute__((aligned(16))) float Ts[2][PT_KC][PT_LD];
+
+  const int tid = threadIdx.x;
+  const long long col0 = (long long)blockIdx.x * PT_BN;
+  const long long row0 = (long long)blockIdx.y * PT_BM;
+  const int hh = (d + 1) / 2;  // coordinate pairs
+  const int lim1 = d - hh;     // valid second-half elements
+  const int nchunk = (hh + PT_KC - 1) / PT_KC;
+
+  // staging role: row sr, coordinates 4*scq .. +3 of the chunk
+  const int sr = tid >> 2, scq = tid & 3;
+  long long qrow = row0 + sr;
+  if (qrow >= n) qrow = n - 1;  // clamp: rows beyond n are computed but never stored
+  long long trow = col0 + sr;
+  if (trow >= m) trow = m - 1;
+  const T* arow = (const T*)A.base + index_at(A.idx, qrow) * A.ld;
+  const T* rrow = (const T*)R.base + index_at(R.idx, qrow) * R.ld;
+  const T* tgrow = (const T*)TG.base + index_at(TG.idx, trow) * TG.ld;
+  const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;  // valid relation first-half elements
+  const int rl1 = (SCORER == KGE_ROTATE) ? 0 : lim1;
+
+  f32x4 a0, a1, r0, r1, t0, t1;
+  auto gload = [&](int ch) {
+    const int c = ch * PT_KC + scq * 4;
+    if (VEC && c >= hh) {  // chunk tail beyond the row (hh % 4 == 0 on this path): zeros
+      a0 = a1 = r0 = r1 = t0 = t1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+    a0 = load4<T, VEC>(arow, c, hh);
+    a1 = load4<T, VEC>(arow + hh, c, lim1);
+    r0 = load4<T, VEC>(rrow, c, rl0);
+    if (SCORER != KGE_ROTATE) r1 = load4<T, VEC>(rrow + hh, c, rl1);
+    else r1 = r0;
+    t0 = load4<T, VEC>(tgrow, c, hh);
+    t1 = load4<T, VEC>(tgrow + hh, c, lim1);
+  };
+  auto sstore = [&]() {
+    f32x4 q0, q1;
+    build_q4<SCORER>(dir, a0, a1, r0, r1, q0, q1);
+    if (round_q) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        q0[i] = round_bf16(q0[i]);
+        q1[i] = round_bf16(q1[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Qs[0][scq * 4 + i][sr] = q0[i];
+      Qs[1][scq * 4 + i][sr] = q1[i];
+      Ts[0][scq * 4 + i][sr] = t0[i];
+      Ts[1][scq * 4 + i][sr] = t1[i];
+    }
+  };
+
+  const int lane = tid & 63, wave = tid >> 6;
+  f32x16 macc;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) macc[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+
+  const int tx = tid & 15, ty = tid >> 4;
+  const int mrow = 32 * (wave >> 1) + (lane & 31), mcol = 32 * (wave & 1) + (lane & 31);
+  const int mh = lane >> 5;
+
+  gload(0);
+  sstore();
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    if (ch + 1 < nchunk) gload(ch + 1);
+    if (DOT && MFMA) {
+#pragma unroll
+      for (int cc = 0; cc < PT_KC; ++cc) {
+        float av = Qs[mh][cc][mrow];
+        float bv = Ts[mh][cc][mcol];
+        macc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, macc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int cc = 0; cc < PT_KC; ++cc) {
+        f32x4 q0 = *reinterpret_cast<const f32x4*>(&Qs[0][cc][ty * 4]);
+        f32x4 q1 = *reinterpret_cast<const f32x4*>(&Qs[1][cc][ty * 4]);
+        f32x4 t0v = *reinterpret_cast<const f32x4*>(&Ts[0][cc][tx * 4]);
+        f32x4 t1v = *reinterpret_cast<const f32x4*>(&Ts[1][cc][tx * 4]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (DOT) {
+              acc[i][j] = __builtin_fmaf(q0[i], t0v[j], acc[i][j]);
+              acc[i][j] = __builtin_fmaf(q1[i], t1v[j], acc[i][j]);
+            } else if (SCORER == KGE_TRANSE) {
+              acc[i][j] = norm_acc<NORM>(acc[i][j], __builtin_fabsf(q0[i] - t0v[j]), lp);
+              acc[i][j] = norm_acc<NORM>(acc[i][j], __builtin_fabsf(q1[i] - t1v[j]), lp);
+            } else {
+              float dre = q0[i] - t0v[j], dim_ = q1[i] - t1v[j];
+              float ab = __builtin_sqrtf(__builtin_fmaf(dim_, dim_, dre * dre));
+              acc[i][j] = norm_acc<NORM>(acc[i][j], ab, lp);
+            }
+          }
+      }
+    }
+    __syncthreads();
+    if (ch + 1 < nchunk) sstore();
+    __syncthreads();
+  }
+
+  if (DOT && MFMA) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      long long orow = row0 + 32 * (wave >> 1) + (r & 3) + 8 * (r >> 2) + 4 * mh;
+      long long ocol = col0 + 32 * (wave & 1) + (lane & 31);
+      if (orow < n && ocol < m) out[orow * ldo + ocol] = macc[r];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long long orow = row0 + ty * 4 + i;
+      if (orow >= n) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        long long ocol = col0 + tx * 4 + j;
+        if (ocol >= m) continue;
+        float v = acc[i][j];
+        if (!DOT) {
+          if (NORM == NORM_L1) v = -v;
+          else if (NORM == NORM_L2) v = -__builtin_sqrtf(v);
+          else v = -powf(v, 1.0f / lp);
+        }
+        out[orow * ldo + ocol] = v;
+      }
+    }
+  }
+}
+
+// ---- host dispatch ------------------------------------------------------------------------
+static inline bool aligned16p(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static bool pairs_vec_ok(int dtype, int d, int dr, int scorer, const Operand& A,
+                         const Operand& R, const Operand& TG) {
+  if (d % 8) return false;  // hh % 4 == 0 and d even
+  if (scorer == KGE_ROTATE && dr != d / 2) return false;
+  const int es = dtype == KGE_BF16 ? 2 : 4;
+  const int al = dtype == KGE_BF16 ? 8 : 16;  // bytes per 4-element load
+  if (!aligned16p(A.base) || !aligned16p(R.base) || !aligned16p(TG.base)) return false;
+  if ((A.ld * es) % al || (R.ld * es) % al || (TG.ld * es) % al) return false;
+  return true;
+}
+
+template <int SCORER, typename T, int NORM>
+static int launch_pairs(bool vec, bool mfma, const Operand& A, const Operand& R,
+                        const Operand& TG, int dir, int d, int dr, long long n, long long m,
+                        float lp, int round_q, float* out, long long ldo, hipStream_t st) {
+  dim3 grid((unsigned)((m + PT_BN - 1) / PT_BN), (unsigned)((n + PT_BM - 1) / PT_BM));
+  constexpr bool DOT = (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT);
+#define KGE_PL(VEC, MF)                                                                       \
+  hipLaunchKernelGGL((pairs_kernel<SCORER, T, NORM, VEC, MF>), grid, dim3(256), 0, st, A, R, \
+                     TG, dir, d, dr, n, m, lp, round_q, out, ldo)
+  if constexpr (DOT) {
+    if (mfma) {
+      if (vec) KGE_PL(true, true); else KGE_PL(false, true);
+    } else {
+      if (vec) KGE_PL(true, false); else KGE_PL(false, false);
+    }
+  } else {
+    if (vec) KGE_PL(true, false); else KGE_PL(false, false);
+  }
+#undef KGE_PL
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+template <int SCORER, typename T>
+static int pairs_norm(int norm, bool vec, bool mfma, const Operand& A, const Operand& R,
+                      const Operand& TG, int dir, int d, int dr, long long n, long long m,
+                      float lp, int round_q, float* out, long long ldo, hipStream_t st) {
+  if constexpr (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT) {
+    return launch_pairs<SCORER, T, NORM_L1>(vec, mfma, A, R, TG, dir, d, dr, n, m, lp, round_q,
+                                            out, ldo, st);
+  } else {
+    if (norm == NORM_L1)
+      return launch_pairs<SCORER, T, NORM_L1>(vec, mfma, A, R, TG, dir, d, dr, n, m, lp, 0, out,
+                                              ldo, st);
+    if (norm == NORM_L2)
+      return launch_pairs<SCORER, T, NORM_L2>(vec, mfma, A, R, TG, dir, d, dr, n, m, lp, 0, out,
+                                              ldo, st);
+    return launch_pairs<SCORER, T, NORM_LP>(vec, mfma, A, R, TG, dir, d, dr, n, m, lp, 0, out,
+                                            ldo, st);
+  }
+}
+
+// exact (canonical f32) pair scoring for every scorer / dtype / dimension
+int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, const Operand& R,
+                    const Operand& TG, int dir, int d, int dr, long long n, long long m,
+                    float lp, float* out, long long ldo, hipStream_t st) {
+  if (n == 0 || m == 0) return KGE_OK;
+  const bool cplx = scorer == KGE_COMPLEX || scorer == KGE_ROTATE;
+  if (cplx && (d % 2)) return KGE_ERR_INVALID_ARG;
+  const bool vec = pairs_vec_ok(dtype, d, dr, scorer, A, R, TG);
+  const int norm = norm_mode(lp);
+  const int round_q =
+      (dtype == KGE_BF16 && (scorer == KGE_COMPLEX || scorer == KGE_DISTMULT)) ? 1 : 0;
+#define KGE_DT(SC)                                                                            \
+  return dtype == KGE_BF16                                                                    \
+             ? pairs_norm<SC, unsigned short>(norm, vec, use_mfma, A, R, TG, dir, d, dr, n, m, \
+                                              lp, round_q, out, ldo, st)                       \
+             : pairs_norm<SC, float>(norm, vec, use_mfma, A, R, TG, dir, d, dr, n, m, lp,      \
+                                     round_q, out, ldo, st)
+  switch (scorer) {
+    case KGE_COMPLEX: KGE_DT(KGE_COMPLEX);
+    case KGE_DISTMULT: KGE_DT(KGE_DISTMULT);
+    case KGE_TRANSE: KGE_DT(KGE_TRANSE);
+    case KGE_ROTATE: KGE_DT(KGE_ROTATE);
+  }
+#undef KGE_DT
+  return KGE_ERR_INVALID_ARG;
+}
+
+}  // namespace kge

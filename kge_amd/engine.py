@@ -1,0 +1,240 @@
+"""Tensor-level front end of the gfx950 scoring kernels (C ABI in include/kge_amd.h).
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and
+dtype/stride bookkeeping.  Every function launches hand-written HIP kernels from
+libkge_amd.so; there is no torch/CPU fallback -- tensors that are not on a GPU raise.
+
+Function <-> reference map (paths relative to the reference tree):
+  score_spo / score_sp / score_po / score_sp_po   KgeModel.score_*     kge/model/kge_model.py:663-789
+  score_emb                                        RelationalScorer.score_emb  kge_model.py:151-213
+  score_neg                                        BatchNegativeSample.score   kge/util/sampler.py:263-306
+  rank_counts                                      EntityRankingJob._filter_and_rank  kge/job/eval_entity_ranking.py:533-596
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (BF16, F32, FLAG_EXACT, FLAG_NO_MFMA, I32, I64, PO_, SCORERS, SP_, SPO, KgeIndex,
+                   KgeTables)
+
+__all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
+           "score_emb", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA"]
+
+
+def _require_gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"kge_amd: {what} is on '{t.device}'. The MI355X engine has no CPU path "
+            "(use the reference implementation for job.device=cpu).")
+
+
+def _empty(shape, device, dtype=torch.float32):
+    """Allocate through torch's caching allocator.  LibKGE's sub-batch auto-tuner string-
+    matches 'CUDA out of memory' (kge/job/train.py:384-391); ROCm says 'HIP out of memory'."""
+    try:
+        return torch.empty(shape, device=device, dtype=dtype)
+    except torch.OutOfMemoryError as e:  # pragma: no cover - needs a full GPU
+        raise RuntimeError("CUDA out of memory (kge_amd: " + str(e) + ")") from e
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"kge_amd: embedding tables must be float32 or bfloat16, got {t.dtype}")
+
+
+def _index(ix, device, keep):
+    """1-D int32/int64 tensor (any stride, e.g. triples[:, 0]) -> KgeIndex.  None -> identity."""
+    if ix is None:
+        return KgeIndex(None, I64, 0, 1)
+    if not torch.is_tensor(ix):
+        ix = torch.as_tensor(ix, device=device)
+    if ix.device != device:
+        raise RuntimeError(f"kge_amd: index tensor on {ix.device}, tables on {device}")
+    if ix.dim() != 1:
+        ix = ix.reshape(-1)
+    if ix.dtype not in (torch.int32, torch.int64):
+        ix = ix.long()
+    stride = ix.stride(0) if ix.numel() > 1 else 1
+    if stride < 1:
+        ix = ix.contiguous()
+        stride = 1
+    keep.append(ix)
+    return KgeIndex(ix.data_ptr(), I32 if ix.dtype == torch.int32 else I64, 0, stride)
+
+
+class Tables:
+    """Entity and relation lookup tables of one model (LookupEmbedder weights,
+    kge/model/embedder/lookup_embedder.py:44-46) as the kernels see them."""
+
+    def __init__(self, scorer, ent: torch.Tensor, rel: torch.Tensor, l_norm: float = 1.0,
+                 flags: int = 0):
+        self.scorer = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
+        _require_gpu(ent, "entity table")
+        _require_gpu(rel, "relation table")
+        if ent.dim() != 2 or rel.dim() != 2 or ent.stride(1) != 1 or rel.stride(1) != 1:
+            raise ValueError("kge_amd: tables must be 2-D with unit inner stride")
+        if ent.dtype != rel.dtype:
+            raise TypeError("kge_amd: entity and relation tables must share a dtype")
+        self.ent, self.rel = ent, rel
+        self.l_norm, self.flags = float(l_norm), int(flags)
+        self.device = ent.device
+
+    def c(self, flags=None) -> KgeTables:
+        e, r = self.ent, self.rel
+        return KgeTables(e.data_ptr(), r.data_ptr(), _dtype_code(e), self.scorer, e.shape[0],
+                         r.shape[0], e.shape[1], r.shape[1], e.stride(0), r.stride(0),
+                         self.l_norm, self.flags if flags is None else flags)
+
+    @property
+    def num_ent(self):
+        return self.ent.shape[0]
+
+
+def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = keep[0].numel()
+    out = _empty((n,), t.device)
+    with torch.cuda.device(t.device):
+        tc = t.c(flags)
+        _lib.check(_lib.lib().kge_score_spo(ctypes.byref(tc), si, pi, oi, n, out.data_ptr(),
+                                            _stream(t.device)), "kge_score_spo")
+    return out
+
+
+def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
+    keep = []
+    ai, pi = _index(a, t.device, keep), _index(p, t.device, keep)
+    n = keep[0].numel()
+    ti = _index(targets, t.device, keep)
+    m = t.num_ent if targets is None else keep[-1].numel()
+    if out is None:
+        out = _empty((n, m), t.device)
+        ldo = m
+    with torch.cuda.device(t.device):
+        tc = t.c(flags)
+        fn = getattr(_lib.lib(), fn_name)
+        _lib.check(fn(ctypes.byref(tc), ai, pi, n, ti, m, out.data_ptr(), ldo,
+                      _stream(t.device)), fn_name)
+    return out
+
+
+def score_sp(t: Tables, s, p, o=None, flags=None) -> torch.Tensor:
+    """[n, E|m] scores of (s_i, p_i, ·) against all / the listed objects."""
+    return _pairs("kge_score_sp", t, s, p, o, flags)
+
+
+def score_po(t: Tables, p, o, s=None, flags=None) -> torch.Tensor:
+    """[n, E|m] scores of (·, p_i, o_i) against all / the listed subjects."""
+    return _pairs("kge_score_po", t, o, p, s, flags)
+
+
+def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Tensor:
+    """[n, 2m]: score_sp and score_po against one shared entity subset, written directly
+    into the two halves of the output (no torch.cat copy, kge_model.py:789)."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = keep[0].numel()
+    ti = _index(entity_subset, t.device, keep)
+    m = t.num_ent if entity_subset is None else keep[-1].numel()
+    out = _empty((n, 2 * m), t.device)
+    with torch.cuda.device(t.device):
+        tc = t.c(flags)
+        _lib.check(_lib.lib().kge_score_sp_po(ctypes.byref(tc), si, pi, oi, n, ti, m,
+                                              out.data_ptr(), 2 * m, _stream(t.device)),
+                   "kge_score_sp_po")
+    return out
+
+
+def score_neg(t: Tables, s, p, o, slot: int, neg: torch.Tensor, flags=None) -> torch.Tensor:
+    """[n, K] scores of triple i with `slot` (0 = s, 2 = o) replaced by neg[i, k]."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = keep[0].numel()
+    _require_gpu(neg, "negative samples")
+    if neg.dtype not in (torch.int32, torch.int64):
+        neg = neg.long()
+    if neg.dim() != 2 or neg.shape[0] != n:
+        raise ValueError("kge_amd: neg must be [n, K]")
+    if neg.stride(1) != 1:
+        neg = neg.contiguous()
+    K = neg.shape[1]
+    out = _empty((n, K), t.device)
+    with torch.cuda.device(t.device):
+        tc = t.c(flags)
+        _lib.check(_lib.lib().kge_score_neg(
+            ctypes.byref(tc), si, pi, oi, n, int(slot), neg.data_ptr(),
+            I32 if neg.dtype == torch.int32 else I64, neg.stride(0) if n > 1 else K, K,
+            out.data_ptr(), K, _stream(t.device)), "kge_score_neg")
+    return out
+
+
+def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, flags: int = 0):
+    """RelationalScorer.score_emb on dense embeddings (no gather)."""
+    code = {"spo": SPO, "sp_": SP_, "_po": PO_}.get(combine)
+    if code is None:
+        raise ValueError('cannot handle combine="{}"'.format(combine))
+    for x in (s_emb, p_emb, o_emb):
+        _require_gpu(x, "embedding")
+    dt = {s_emb.dtype, p_emb.dtype, o_emb.dtype}
+    if len(dt) != 1:
+        raise TypeError("kge_amd: embeddings must share a dtype")
+    s_emb, p_emb, o_emb = (x if x.stride(-1) == 1 else x.contiguous() for x in (s_emb, p_emb, o_emb))
+    sc = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
+    n = p_emb.shape[0]
+    d, dr = s_emb.shape[1], p_emb.shape[1]
+    if code == SPO:
+        m, out = 0, _empty((n,), s_emb.device)
+    else:
+        m = o_emb.shape[0] if code == SP_ else s_emb.shape[0]
+        out = _empty((n, m), s_emb.device)
+    tc = KgeTables(None, None, _dtype_code(s_emb), sc, 0, 0, d, dr, d, dr, float(l_norm), int(flags))
+    with torch.cuda.device(s_emb.device):
+        _lib.check(_lib.lib().kge_score_emb(
+            ctypes.byref(tc), code, s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(),
+            p_emb.stride(0), o_emb.data_ptr(), o_emb.stride(0), n, m, out.data_ptr(), max(m, 1),
+            _stream(s_emb.device)), "kge_score_emb")
+    return out.view(n, -1)
+
+
+def rank_counts(scores, true_scores, lbl_rowptr=None, lbl_col=None, col_offset=0, true_col=None,
+                atol=1e-5, rtol=1e-4, rank=None, ties=None):
+    """Accumulate (rank, ties) int64 counts of each row's true score within `scores`
+    [n, c]; filtered columns given as CSR (lbl_rowptr int64 [n+1], lbl_col int64 [nnz],
+    global ids minus col_offset; the entry equal to true_col[i] is kept)."""
+    _require_gpu(scores, "scores")
+    if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
+        raise ValueError("kge_amd: scores must be float32 [n, c] with unit inner stride")
+    dev = scores.device
+    n, c = scores.shape
+    true_scores = true_scores.to(device=dev, dtype=torch.float32).contiguous()
+    if rank is None:
+        rank = torch.zeros(n, dtype=torch.int64, device=dev)
+    if ties is None:
+        ties = torch.zeros(n, dtype=torch.int64, device=dev)
+
+    def p64(x):
+        if x is None:
+            return None
+        x = x.to(device=dev, dtype=torch.int64).contiguous()
+        keep.append(x)
+        return x.data_ptr()
+
+    keep = []
+    rp, cl, tc = p64(lbl_rowptr), p64(lbl_col), p64(true_col)
+    if rp is not None and not cl:  # empty filter set: the ABI still wants a non-NULL array
+        cl = p64(torch.zeros(1, dtype=torch.int64, device=dev))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().kge_rank_counts(
+            scores.data_ptr(), scores.stride(0) if n > 1 else max(c, 1), n, c,
+            true_scores.data_ptr(), rp, cl, int(col_offset), tc, float(atol), float(rtol),
+            rank.data_ptr(), ties.data_ptr(), _stream(dev)), "kge_rank_counts")
+    return rank, ties

@@ -1,0 +1,102 @@
+"""Literal torch restatement of the reference's CPU scoring path (TEST INFRASTRUCTURE).
+
+Used only by bench.py's `cpu_baseline` leg (kind "port") and by tests: it issues the SAME
+torch op sequence as the reference -- embedding gather, cat/chunk, elementwise mul, `mm`,
+`cdist`, `pairwise_distance`, cos/sin -- so on a given host it costs what the reference
+costs and returns what the reference returns (tests/test_oracle_vs_reference.py checks
+bit-equality against the live reference in the build container).  The reference tree
+itself cannot travel to the GPU box.
+
+  score_emb  <- ComplExScorer.score_emb   kge/model/complex.py:18-43
+                DistMultScorer.score_emb  kge/model/distmult.py:13-25
+                TransEScorer.score_emb    kge/model/transe.py:15-37
+                RotatEScorer.score_emb    kge/model/rotate.py:20-69 (+ helpers :146-213)
+  score_sp/po/spo <- KgeModel.score_*     kge/model/kge_model.py:663-725
+                     (LookupEmbedder.embed / embed_all, lookup_embedder.py:96-112)
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _abs_complex(re, im):
+    return torch.norm(torch.stack((re, im), dim=0), dim=0)
+
+
+def _norm_nonneg(x, dim, p):
+    return torch.sum(x, dim=dim) if p == 1.0 else torch.norm(x, dim=dim, p=p)
+
+
+def score_emb(model, s, p, o, combine, l_norm=1.0):
+    n = p.size(0)
+    if model == "distmult":
+        if combine == "spo":
+            out = (s * p * o).sum(dim=1)
+        elif combine == "sp_":
+            out = (s * p).mm(o.transpose(0, 1))
+        else:
+            out = (o * p).mm(s.transpose(0, 1))
+    elif model == "complex":
+        p_re, p_im = (t.contiguous() for t in p.chunk(2, dim=1))
+        o_re, o_im = (t.contiguous() for t in o.chunk(2, dim=1))
+        s_all = torch.cat((s, s), dim=1)
+        r_all = torch.cat((p_re, p, -p_im), dim=1)
+        o_all = torch.cat((o, o_im, o_re), dim=1)
+        if combine == "spo":
+            out = (s_all * o_all * r_all).sum(dim=1)
+        elif combine == "sp_":
+            out = (s_all * r_all).mm(o_all.transpose(0, 1))
+        else:
+            out = (r_all * o_all).mm(s_all.transpose(0, 1))
+    elif model == "transe":
+        if combine == "spo":
+            out = -F.pairwise_distance(s + p, o, p=l_norm)
+        elif combine == "sp_":
+            out = -torch.cdist(s + p, o, p=l_norm, compute_mode="donot_use_mm_for_euclid_dist")
+        else:
+            out = -torch.cdist(o - p, s, p=l_norm, compute_mode="donot_use_mm_for_euclid_dist")
+    elif model == "rotate":
+        s_re, s_im = torch.chunk(s, 2, dim=1)
+        o_re, o_im = torch.chunk(o, 2, dim=1)
+        p_re, p_im = torch.cos(p), torch.sin(p)
+        if combine == "spo":
+            sp_re = s_re * p_re - s_im * p_im
+            sp_im = s_re * p_im + s_im * p_re
+            out = -_norm_nonneg(_abs_complex(sp_re - o_re, sp_im - o_im), 1, l_norm)
+        elif combine == "sp_":
+            sp_re = s_re * p_re - s_im * p_im
+            sp_im = s_re * p_im + s_im * p_re
+            d_re = sp_re.unsqueeze(1) - o_re
+            d_im = sp_im.unsqueeze(1) - o_im
+            out = -_norm_nonneg(_abs_complex(d_re, d_im), 2, l_norm)
+        else:
+            p_im = -p_im
+            po_re = p_re * o_re - p_im * o_im
+            po_im = p_re * o_im + p_im * o_re
+            d_re = po_re.unsqueeze(1) - s_re
+            d_im = po_im.unsqueeze(1) - s_im
+            out = -_norm_nonneg(_abs_complex(d_re, d_im), 2, l_norm)
+    else:
+        raise ValueError(model)
+    return out.view(n, -1)
+
+
+def _embed(table, idx):
+    return torch.nn.functional.embedding(idx.long(), table)
+
+
+def _embed_all(table):
+    return _embed(table, torch.arange(table.size(0), dtype=torch.long))
+
+
+def score_spo(model, ent, rel, s, p, o, l_norm=1.0):
+    return score_emb(model, _embed(ent, s), _embed(rel, p), _embed(ent, o), "spo", l_norm).view(-1)
+
+
+def score_sp(model, ent, rel, s, p, o=None, l_norm=1.0):
+    tg = _embed_all(ent) if o is None else _embed(ent, o)
+    return score_emb(model, _embed(ent, s), _embed(rel, p), tg, "sp_", l_norm)
+
+
+def score_po(model, ent, rel, p, o, s=None, l_norm=1.0):
+    tg = _embed_all(ent) if s is None else _embed(ent, s)
+    return score_emb(model, tg, _embed(rel, p), _embed(ent, o), "_po", l_norm)

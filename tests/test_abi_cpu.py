@@ -1,0 +1,72 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports every symbol include/kge_amd.h declares (no compute calls without a GPU); argument
+validation that does not touch the device; the product path refuses CPU tensors."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from kge_amd import _lib
+    _lib.build()
+    return _lib.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "kge_amd.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(kge_\w+)\s*\(", header, flags=re.M))
+    from kge_amd import _lib
+    assert declared == set(_lib.PROTOTYPES), (declared ^ set(_lib.PROTOTYPES))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.kge_abi_version() == 1
+    assert lib.kge_status_string(0) == b"ok"
+    assert lib.kge_status_string(-1) == b"invalid argument"
+
+
+def test_struct_layout_matches_header():
+    import ctypes
+    from kge_amd._lib import KgeIndex, KgeTables
+    assert ctypes.sizeof(KgeTables) == 80   # 2 ptr + 2 i32 + 6 i64 + f32 + i32
+    assert ctypes.sizeof(KgeIndex) == 24
+
+
+def test_invalid_arguments_are_rejected_without_a_device(lib):
+    import ctypes
+    from kge_amd._lib import KgeIndex, KgeTables
+    ix = KgeIndex(None, 1, 0, 1)
+    assert lib.kge_score_spo(None, ix, ix, ix, 4, None, None) == -1
+    t = KgeTables(None, None, 0, 7, 10, 3, 32, 32, 32, 32, 1.0, 0)   # bad scorer
+    assert lib.kge_score_spo(ctypes.byref(t), ix, ix, ix, 4, None, None) == -1
+    t = KgeTables(None, None, 0, 0, 10, 3, 33, 33, 33, 33, 1.0, 0)   # ComplEx with odd dim
+    assert lib.kge_score_sp(ctypes.byref(t), ix, ix, 4, ix, 10, None, 10, None) == -1
+    t = KgeTables(None, None, 0, 3, 10, 3, 32, 32, 32, 32, 1.0, 0)   # RotatE rel_dim != dim/2
+    assert lib.kge_score_sp(ctypes.byref(t), ix, ix, 4, ix, 10, None, 10, None) == -1
+    assert lib.kge_rank_counts(None, 3, 2, 5, None, None, None, 0, None, 1e-5, 1e-4, None, None, None) == -1
+
+
+def test_product_path_has_no_cpu_fallback(lib):
+    from kge_amd import engine
+    ent = torch.randn(10, 8)
+    rel = torch.randn(3, 8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        engine.Tables("distmult", ent, rel)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        engine.rank_counts(torch.zeros(2, 3), torch.zeros(2))
+
+
+def test_no_oracle_import_in_product_code():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "kge_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                for pat in (r"#include\s*[<\"].*oracle", r"^\s*(import|from)\s+oracle", r"libkge_oracle",
+                            r"ref_harness", r"sys\.path.*oracle"):
+                    assert not re.search(pat, src, flags=re.M), (f, pat)

@@ -1,0 +1,303 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via kge_amd.engine) against the
+CPU oracle on the golden inputs and on seeded random inputs.
+
+Bars:
+  * f32 arithmetic paths -- every scorer, spo / sp_ / _po / sp_po / negatives, f32 and bf16
+    tables (bf16 widened exactly), and the FLAG_EXACT twin of the bf16 MFMA kernel:
+    BIT-EXACT against the oracle (values compared with ==; +0 and -0 compare equal).
+  * bf16 MFMA kernel (ComplEx/DistMult, d % 64 == 0): the MFMA's internal summation order
+    is unspecified -> reference tolerance atol=1e-5*scale, rtol=1e-4 against the oracle.
+  * everything against the reference's golden outputs: reference tolerance.
+  * rank counts: integer, exact.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as ko
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SCORE_FILES = sorted(glob.glob(os.path.join(GOLDEN, "scores_*.npz")))
+IDS = [os.path.basename(p)[7:-4] for p in SCORE_FILES]
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from kge_amd import engine
+    return engine
+
+
+def _np(x):
+    return x.detach().cpu().numpy()
+
+
+def _eq(name, got, want):
+    """exact comparison with a useful failure report"""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    same = (got == want) | (np.isnan(got) & np.isnan(want))
+    if not same.all():
+        bad = np.argwhere(~same)
+        diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+        raise AssertionError(
+            f"{name}: {len(bad)}/{got.size} elements differ; max|diff|={np.nanmax(diff):.3e}; "
+            f"first bad idx={bad[:5].tolist()} got={got[tuple(bad[0])]!r} want={want[tuple(bad[0])]!r}")
+
+
+def _close(name, got, want, atol=1e-5, rtol=1e-4):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    fin = np.isfinite(want)
+    scale = max(1.0, float(np.sqrt(np.mean(np.square(want[fin]))))) if fin.any() else 1.0
+    err = np.abs(got - want)
+    tol = atol * scale + rtol * np.abs(want)
+    if not (err <= tol).all():
+        i = np.unravel_index(np.argmax(err - tol), err.shape)
+        raise AssertionError(f"{name}: max excess at {i}: got={got[i]} want={want[i]} "
+                             f"err={err[i]:.3e} tol={tol[i]:.3e} (scale={scale:.3g}); "
+                             f"{int((err > tol).sum())}/{err.size} out of tolerance")
+
+
+def _gpu_tables(eng, model, ent, rel, l_norm, bf16=False, flags=0):
+    e, r = torch.from_numpy(np.ascontiguousarray(ent)), torch.from_numpy(np.ascontiguousarray(rel))
+    if bf16:
+        e, r = e.to(torch.bfloat16), r.to(torch.bfloat16)
+    return eng.Tables(model, e.to(DEV), r.to(DEV), l_norm, flags)
+
+
+def _oracle_tables(model, ent, rel, l_norm, bf16=False):
+    if bf16:
+        return ko.Tables(model, ko.f32_to_bf16(ent), ko.f32_to_bf16(rel), l_norm)
+    return ko.Tables(model, ent, rel, l_norm)
+
+
+def _t(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def test_single_hip_runtime_and_library_loaded(eng):
+    from kge_amd import _lib
+    assert _lib.lib().kge_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    hips = {l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l}
+    assert len(hips) == 1, hips
+    assert "libkge_amd.so" in maps
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+@pytest.mark.parametrize("path", SCORE_FILES, ids=IDS)
+def test_golden_inputs_exact_vs_oracle(eng, path, bf16):
+    g = np.load(path)
+    model, l_norm = str(g["model"]), float(g["l_norm"])
+    T = _gpu_tables(eng, model, g["ent"], g["rel"], l_norm, bf16, flags=eng.FLAG_EXACT)
+    O = _oracle_tables(model, g["ent"], g["rel"], l_norm, bf16)
+    s, p, o, sub, neg = g["s"], g["p"], g["o"], g["sub"], g["neg"]
+    ts, tp, to, tsub, tneg = _t(s), _t(p), _t(o), _t(sub), _t(neg)
+    _eq("spo", _np(eng.score_spo(T, ts, tp, to)), ko.score_spo(O, s, p, o))
+    _eq("sp", _np(eng.score_sp(T, ts, tp)), ko.score_sp(O, s, p))
+    _eq("po", _np(eng.score_po(T, tp, to)), ko.score_po(O, p, o))
+    _eq("sp_sub", _np(eng.score_sp(T, ts, tp, tsub)), ko.score_sp(O, s, p, sub))
+    _eq("po_sub", _np(eng.score_po(T, tp, to, tsub)), ko.score_po(O, p, o, sub))
+    _eq("sp_po_sub", _np(eng.score_sp_po(T, ts, tp, to, tsub)), ko.score_sp_po(O, s, p, o, sub))
+    _eq("sp_po_all", _np(eng.score_sp_po(T, ts, tp, to)), ko.score_sp_po(O, s, p, o))
+    _eq("neg_s", _np(eng.score_neg(T, ts, tp, to, 0, tneg)), ko.score_neg(O, s, p, o, 0, neg))
+    _eq("neg_o", _np(eng.score_neg(T, ts, tp, to, 2, tneg)), ko.score_neg(O, s, p, o, 2, neg))
+
+
+@pytest.mark.parametrize("path", SCORE_FILES, ids=IDS)
+def test_golden_outputs_of_the_reference(eng, path):
+    """HIP (f32 tables) against the outputs of the live reference, reference tolerance."""
+    g = np.load(path)
+    T = _gpu_tables(eng, str(g["model"]), g["ent"], g["rel"], float(g["l_norm"]))
+    ts, tp, to, tsub, tneg = (_t(g[k]) for k in ("s", "p", "o", "sub", "neg"))
+    _close("spo", _np(eng.score_spo(T, ts, tp, to)), g["spo"])
+    _close("sp", _np(eng.score_sp(T, ts, tp)), g["sp"])
+    _close("po", _np(eng.score_po(T, tp, to)), g["po"])
+    _close("sp_sub", _np(eng.score_sp(T, ts, tp, tsub)), g["sp_sub"])
+    _close("po_sub", _np(eng.score_po(T, tp, to, tsub)), g["po_sub"])
+    _close("sp_po_sub", _np(eng.score_sp_po(T, ts, tp, to, tsub)), g["sp_po_sub"])
+    _close("sp_po_all", _np(eng.score_sp_po(T, ts, tp, to)), g["sp_po_all"])
+    _close("neg_s", _np(eng.score_neg(T, ts, tp, to, 0, tneg)), g["neg_s"])
+    _close("neg_o", _np(eng.score_neg(T, ts, tp, to, 2, tneg)), g["neg_o"])
+
+
+@pytest.mark.parametrize("model", ["complex", "distmult"])
+def test_f32_mfma_equals_valu_chain(eng, model):
+    """v_mfma_f32_32x32x2_f32 is an exact k-ordered fmaf chain: same bits as the VALU twin."""
+    rng = np.random.default_rng(3)
+    E, R, d, n = 333, 7, 96, 70
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    s, p = rng.integers(0, E, n), rng.integers(0, R, n)
+    T = _gpu_tables(eng, model, ent, rel, 1.0)
+    a = _np(eng.score_sp(T, _t(s), _t(p)))
+    b = _np(eng.score_sp(T, _t(s), _t(p), flags=eng.FLAG_NO_MFMA))
+    _eq("mfma vs valu", a, b)
+    _eq("mfma vs oracle", a, ko.score_sp(ko.Tables(model, ent, rel, 1.0), s, p))
+
+
+RANDOM_CASES = [
+    # model, l_norm, E, R, d, n, m_subset
+    ("complex", 1.0, 1000, 11, 64, 37, 130),
+    ("complex", 1.0, 700, 5, 100, 129, 65),      # d % 8 != 0 -> scalar staging
+    ("complex", 1.0, 900, 9, 256, 200, 257),
+    ("distmult", 1.0, 1000, 11, 100, 64, 64),
+    ("distmult", 1.0, 515, 3, 37, 5, 1),         # odd d, single target
+    ("distmult", 1.0, 800, 6, 512, 70, 129),
+    ("transe", 1.0, 777, 4, 128, 65, 63),
+    ("transe", 2.0, 600, 4, 50, 33, 200),
+    ("transe", 1.0, 300, 4, 1030, 3, 17),        # d > 512: lanes own several chunks
+    ("rotate", 1.0, 640, 5, 128, 66, 64),
+    ("rotate", 2.0, 500, 5, 60, 20, 31),
+    ("rotate", 1.0, 1100, 11, 512, 40, 100),
+]
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", RANDOM_CASES, ids=[f"{c[0]}-p{c[1]:g}-E{c[2]}-d{c[4]}-n{c[5]}" for c in RANDOM_CASES])
+def test_random_shapes_exact_vs_oracle(eng, case, bf16):
+    model, l_norm, E, R, d, n, msub = case
+    rng = np.random.default_rng(E * 7 + d * 3 + n)
+    dr = d // 2 if model == "rotate" else d
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = (rng.uniform(-np.pi, np.pi, (R, dr)) if model == "rotate"
+           else rng.standard_normal((R, dr))).astype(np.float32)
+    tri = np.stack([rng.integers(0, E, n), rng.integers(0, R, n), rng.integers(0, E, n)], 1)
+    sub = rng.permutation(E)[:msub]
+    neg = rng.integers(0, E, (n, 9))
+    T = _gpu_tables(eng, model, ent, rel, l_norm, bf16, flags=eng.FLAG_EXACT)
+    O = _oracle_tables(model, ent, rel, l_norm, bf16)
+    ttri = _t(tri)                       # int64 [n,3]; columns are stride-3 views
+    ts, tp, to = ttri[:, 0], ttri[:, 1], ttri[:, 2]
+    s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
+    _eq("spo", _np(eng.score_spo(T, ts, tp, to)), ko.score_spo(O, s, p, o))
+    _eq("sp_all", _np(eng.score_sp(T, ts, tp)), ko.score_sp(O, s, p))
+    _eq("po_sub", _np(eng.score_po(T, tp, to, _t(sub))), ko.score_po(O, p, o, sub))
+    tri32 = ttri.int()
+    _eq("sp_po_sub_i32", _np(eng.score_sp_po(T, tri32[:, 0], tri32[:, 1], tri32[:, 2], _t(sub).int())),
+        ko.score_sp_po(O, s, p, o, sub))
+    _eq("neg_o", _np(eng.score_neg(T, ts, tp, to, 2, _t(neg))), ko.score_neg(O, s, p, o, 2, neg))
+    _eq("neg_s_i32", _np(eng.score_neg(T, ts, tp, to, 0, _t(neg).int())), ko.score_neg(O, s, p, o, 0, neg))
+
+
+@pytest.mark.parametrize("model,d", [("complex", 128), ("complex", 512), ("distmult", 256), ("distmult", 64)])
+def test_bf16_mfma_kernel_vs_oracle(eng, model, d):
+    """The headline kernel (bf16 tables, bf16 matrix cores) against the oracle's bf16
+    semantics (q rounded to bf16, exact products, f32 accumulation), reference tolerance;
+    ragged n and m exercise the tile tails."""
+    rng = np.random.default_rng(d)
+    E, R, n = 1000 + 37, 13, 200 + 3
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    s, p, o = rng.integers(0, E, n), rng.integers(0, R, n), rng.integers(0, E, n)
+    sub = rng.permutation(E)[:300]
+    T = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+    O = _oracle_tables(model, ent, rel, 1.0, bf16=True)
+    ts, tp, to = _t(s), _t(p), _t(o)
+    _close("sp_all", _np(eng.score_sp(T, ts, tp)), ko.score_sp(O, s, p))
+    _close("po_all", _np(eng.score_po(T, tp, to)), ko.score_po(O, p, o))
+    _close("sp_po_sub", _np(eng.score_sp_po(T, ts, tp, to, _t(sub))), ko.score_sp_po(O, s, p, o, sub))
+    # and its bit-exact twin computes the same semantics
+    _eq("exact twin", _np(eng.score_sp(T, ts, tp, flags=eng.FLAG_EXACT)), ko.score_sp(O, s, p))
+
+
+@pytest.mark.parametrize("model", ["complex", "distmult", "transe", "rotate"])
+def test_score_emb_equals_index_level(eng, model):
+    """RelationalScorer.score_emb on dense embeddings == the fused-gather entry points."""
+    rng = np.random.default_rng(11)
+    E, R, d, n = 300, 5, 64, 33
+    dr = d // 2 if model == "rotate" else d
+    ent = torch.from_numpy(rng.standard_normal((E, d)).astype(np.float32)).to(DEV)
+    rel = torch.from_numpy(rng.standard_normal((R, dr)).astype(np.float32)).to(DEV)
+    s, p, o = (torch.from_numpy(rng.integers(0, hi, n)).to(DEV) for hi in (E, R, E))
+    T = eng.Tables(model, ent, rel, 1.0)
+    se, pe, oe = ent[s], rel[p], ent[o]
+    _eq("spo", _np(eng.score_emb(model, se, pe, oe, "spo")).reshape(-1), _np(eng.score_spo(T, s, p, o)))
+    _eq("sp_", _np(eng.score_emb(model, se, pe, ent, "sp_")), _np(eng.score_sp(T, s, p)))
+    _eq("_po", _np(eng.score_emb(model, ent, pe, oe, "_po")), _np(eng.score_po(T, p, o)))
+    with pytest.raises(ValueError):
+        eng.score_emb(model, se, pe, oe, "s_x")
+
+
+def test_empty_inputs(eng):
+    ent = torch.randn(10, 16, device=DEV)
+    rel = torch.randn(3, 16, device=DEV)
+    T = eng.Tables("distmult", ent, rel)
+    z = torch.zeros(0, dtype=torch.long, device=DEV)
+    assert eng.score_spo(T, z, z, z).shape == (0,)
+    assert eng.score_sp(T, z, z).shape == (0, 10)
+    assert eng.score_sp(T, torch.tensor([1], device=DEV), torch.tensor([0], device=DEV), z).shape == (1, 0)
+
+
+# ---- rank counts ---------------------------------------------------------------------------
+def test_rank_core_golden(eng):
+    g = np.load(os.path.join(GOLDEN, "rankcore.npz"))
+    atol, rtol = float(g["atol"]), float(g["rtol"])
+    rank, ties = eng.rank_counts(_t(g["scores"]), _t(g["true"]), atol=atol, rtol=rtol)
+    _eq("rank", _np(rank), g["rank"])
+    _eq("ties", _np(ties), g["ties"])
+    lab = g["labels"]
+    n, c = g["scores"].shape
+
+    def csr(block):
+        rp, col = [0], []
+        for i in range(n):
+            col.extend(np.nonzero(np.isinf(block[i]))[0].tolist())
+            rp.append(len(col))
+        return np.array(rp, dtype=np.int64), np.array(col, dtype=np.int64)
+
+    rp, col = csr(lab[:, :c])
+    r, t = eng.rank_counts(_t(g["scores"]), _t(g["true"]), _t(rp), _t(col), atol=atol, rtol=rtol)
+    _eq("filt_o_rank", _np(r), g["filt_o_rank"])
+    _eq("filt_o_ties", _np(t), g["filt_o_ties"])
+    rp, col = csr(lab[:, c:])
+    r, t = eng.rank_counts(_t(g["scores_po"]), _t(g["true_po"]), _t(rp), _t(col), atol=atol, rtol=rtol)
+    _eq("filt_s_rank", _np(r), g["filt_s_rank"])
+    _eq("filt_s_ties", _np(t), g["filt_s_ties"])
+
+
+@pytest.mark.parametrize("n,c,lds_pad", [(1, 1, 0), (7, 1000, 3), (33, 14541, 0), (5, 70001, 1)])
+def test_rank_counts_random_vs_oracle_and_torch(eng, n, c, lds_pad):
+    rng = np.random.default_rng(n * 1000 + c)
+    buf = (rng.standard_normal((n, c + lds_pad)) * 3).astype(np.float32)
+    sc = buf[:, :c]
+    tcol = rng.integers(0, c, n)
+    true = sc[np.arange(n), tcol].copy()
+    # ties, near-ties, NaN and infinities
+    for i in range(n):
+        k = rng.integers(0, c, 5)
+        sc[i, k] = true[i] + np.float32(rng.choice([0, 1e-6, -1e-6, 2e-4, 1e-5]))
+    sc[0, 0] = np.nan
+    if c > 3:
+        sc[n - 1, 1] = np.inf
+        sc[n - 1, 2] = -np.inf
+    # CSR filter labels (global ids with an offset), unique per row, may contain the positive
+    off = 17
+    rp, col = [0], []
+    for i in range(n):
+        k = np.unique(np.concatenate([rng.integers(0, c, min(c, 40)), [tcol[i]]])) + off
+        col.extend(k.tolist())
+        rp.append(len(col))
+    rp, col = np.array(rp, np.int64), np.array(col, np.int64)
+    tsc = _t(buf)[:, :c]
+    for use_filter in (False, True):
+        kw = dict(lbl_rowptr=rp, lbl_col=col, col_offset=off, true_col=tcol + off) if use_filter else {}
+        want_r, want_t = ko.rank_counts(sc, true, **kw)
+        gkw = {k: (_t(v) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        r, t = eng.rank_counts(tsc, _t(true), **gkw)
+        _eq(f"rank filt={use_filter}", _np(r), want_r)
+        _eq(f"ties filt={use_filter}", _np(t), want_t)
+    # the reference's own op sequence on the GPU (eval_entity_ranking.py:583-595)
+    x = tsc.clone()
+    x[torch.isnan(x)] = float("-inf")
+    tt = _t(true).view(-1, 1)
+    close = torch.isclose(x, tt, rtol=1e-4, atol=1e-5)
+    r, t = eng.rank_counts(tsc, _t(true))
+    _eq("torch rank", _np(r), _np(((x > tt) & ~close).sum(1)))
+    _eq("torch ties", _np(t), _np(close.sum(1)))

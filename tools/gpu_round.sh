@@ -1,0 +1,25 @@
+#!/bin/bash
+# One gpurun call: parity tests, smoke, bench, per-kernel probe, rocprofv3 kernel trace.
+# Usage (from the repo root on the GPU box):  bash tools/gpu_round.sh [tag]
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -c "import torch;print(torch.cuda.get_device_name(0), torch.version.hip)" > $OUT/env.log 2>&1
+timeout 900 python -m pytest tests -m gpu -q -x --timeout=600 > $OUT/pytest_x.log 2>&1
+echo "pytest -x exit: $?" >> $OUT/env.log
+timeout 1200 python -m pytest tests -m gpu -q --timeout=600 > $OUT/pytest_all.log 2>&1
+echo "pytest all exit: $?" >> $OUT/env.log
+timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
+echo "smoke exit: $?" >> $OUT/env.log
+timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
+echo "bench exit: $?" >> $OUT/env.log
+timeout 900 python tools/perf_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err
+echo "probe exit: $?" >> $OUT/env.log
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err )
+echo "rocprof exit: $?" >> $OUT/env.log
+find $OUT/prof -name "*stats*" | head >> $OUT/env.log
+tail -5 $OUT/pytest_all.log
+cat $OUT/env.log
+cat $OUT/bench.json
