@@ -176,21 +176,35 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
                     int64_t* rank, int64_t* ties, void* stream);
 
 /* ---- backward (autograd twins) ------------------------------------------ */
-/* Gradients of sum_ij gout[i,j]*score(i,j) w.r.t. the gathered query rows and
- * the target rows, for kge_score_sp / kge_score_po (dir = KGE_SP_ / KGE_PO_).
- *   g_a   [n, dim]      grad of the entity query row  (s for SP_, o for PO_)
- *   g_p   [n, rel_dim]  grad of the relation row
- *   g_tgt [m, dim]      grad of the target rows (dense; caller scatters/adds)
- * All f32, overwritten.  Tables must be f32. */
+/* All gradients are f32 and OVERWRITTEN; tables/embeddings must be f32.
+ * `scores` is the forward output (needed by TransE/RotatE with l_norm != 1 to
+ * recover the distance; may be NULL otherwise).
+ *
+ * kge_score_pairs_bwd: gradients of sum_ij gout[i,j]*score(i,j) for
+ * kge_score_sp / kge_score_po (dir = KGE_SP_ / KGE_PO_):
+ *   g_a   [n, dim]      grad of the gathered entity query rows (s for SP_, o for PO_)
+ *   g_p   [n, rel_dim]  grad of the gathered relation rows
+ *   g_tgt [m, dim]      grad of the target rows (dense; caller scatter-adds)   */
 int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p,
                         int64_t n, kge_index targets, int64_t m,
-                        const float* gout, int64_t ldg, float* g_a, float* g_p,
-                        float* g_tgt, void* stream);
+                        const float* gout, int64_t ldg, const float* scores,
+                        int64_t lds, float* g_a, float* g_p, float* g_tgt,
+                        void* stream);
 
 /* Gradients of sum_i gout[i]*score(s_i,p_i,o_i): g_s,g_o [n,dim], g_p [n,rel_dim]. */
 int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p,
-                      kge_index o, int64_t n, const float* gout, float* g_s,
-                      float* g_p, float* g_o, void* stream);
+                      kge_index o, int64_t n, const float* gout,
+                      const float* scores, float* g_s, float* g_p, float* g_o,
+                      void* stream);
+
+/* Backward of kge_score_emb (dense embeddings).  SPO: g_s,g_o [n,dim], g_p [n,rel_dim].
+ * SP_: g_s [n,dim], g_p [n,rel_dim], g_o [m,dim].  PO_: g_o [n,dim], g_p, g_s [m,dim]. */
+int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb,
+                      int64_t s_ld, const void* p_emb, int64_t p_ld,
+                      const void* o_emb, int64_t o_ld, int64_t n, int64_t m,
+                      const float* gout, int64_t ldg, const float* scores,
+                      int64_t lds, float* g_s, float* g_p, float* g_o,
+                      void* stream);
 
 #ifdef __cplusplus
 }

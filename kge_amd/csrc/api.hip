@@ -19,12 +19,13 @@ int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
              long long col_offset, const long long* true_col, float atol, float rtol,
              long long* rank, long long* ties, hipStream_t st);
-int run_pairs_bwd(const kge_tables* t, int dir, const Operand& A, const Operand& R,
-                  const Operand& TG, long long n, long long m, const float* gout, long long ldg,
-                  float* g_a, float* g_p, float* g_tgt, hipStream_t st);
-int run_spo_bwd(const kge_tables* t, const Operand& S, const Operand& R, const Operand& O,
-                long long n, const float* gout, float* g_s, float* g_p, float* g_o,
-                hipStream_t st);
+int run_pairs_bwd(int scorer, float lp, int dir, const Operand& A, const Operand& R,
+                  const Operand& TG, int d, int dr, long long n, long long m, const float* gout,
+                  long long ldg, const float* scores, long long lds, float* g_a, float* g_p,
+                  float* g_tgt, hipStream_t st);
+int run_spo_bwd(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
+                int dr, long long n, const float* gout, const float* scores, float* g_s, float* g_p,
+                float* g_o, hipStream_t st);
 }  // namespace kge
 
 using namespace kge;
@@ -203,23 +204,27 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
 
 int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
                         kge_index targets, int64_t m, const float* gout, int64_t ldg,
-                        float* g_a, float* g_p, float* g_tgt, void* stream) {
+                        const float* scores, int64_t lds, float* g_a, float* g_p, float* g_tgt,
+                        void* stream) {
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
   if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
-  if (n < 0 || m < 0 || ldg < m) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || m < 0 || ldg < m || (scores && lds < m)) return KGE_ERR_INVALID_ARG;
   if (n * m > 0 && (!gout || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
   if ((rc = check_index(a, false)) || (rc = check_index(p, false)) ||
       (rc = check_index(targets, true)))
     return rc;
   if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
-  return run_pairs_bwd(t, dir, ent_op(t, a), rel_op(t, p), ent_op(t, targets), n, m, gout, ldg,
-                       g_a, g_p, g_tgt, (hipStream_t)stream);
+  if (n > 65535LL * 64 || m > 65535LL * 64) return KGE_ERR_UNSUPPORTED;
+  return run_pairs_bwd(t->scorer, t->l_norm, dir, ent_op(t, a), rel_op(t, p), ent_op(t, targets),
+                       (int)t->dim, (int)t->rel_dim, n, m, gout, ldg, scores, lds, g_a, g_p, g_tgt,
+                       (hipStream_t)stream);
 }
 
 int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
-                      const float* gout, float* g_s, float* g_p, float* g_o, void* stream) {
+                      const float* gout, const float* scores, float* g_s, float* g_p, float* g_o,
+                      void* stream) {
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
@@ -227,8 +232,34 @@ int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o
   if ((rc = check_index(s, false)) || (rc = check_index(p, false)) ||
       (rc = check_index(o, false)))
     return rc;
-  return run_spo_bwd(t, ent_op(t, s), rel_op(t, p), ent_op(t, o), n, gout, g_s, g_p, g_o,
-                     (hipStream_t)stream);
+  return run_spo_bwd(t->scorer, t->l_norm, ent_op(t, s), rel_op(t, p), ent_op(t, o), (int)t->dim,
+                     (int)t->rel_dim, n, gout, scores, g_s, g_p, g_o, (hipStream_t)stream);
+}
+
+int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64_t s_ld,
+                      const void* p_emb, int64_t p_ld, const void* o_emb, int64_t o_ld, int64_t n,
+                      int64_t m, const float* gout, int64_t ldg, const float* scores, int64_t lds,
+                      float* g_s, float* g_p, float* g_o, void* stream) {
+  int rc = check_tables(t, false);
+  if (rc) return rc;
+  if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
+  if (!s_emb || !p_emb || !o_emb || !gout || !g_s || !g_p || !g_o || n < 0 || m < 0)
+    return KGE_ERR_INVALID_ARG;
+  if (s_ld < t->dim || o_ld < t->dim || p_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
+  const Index ident{nullptr, 1, KGE_I64};
+  Operand S{s_emb, s_ld, ident}, P{p_emb, p_ld, ident}, O{o_emb, o_ld, ident};
+  hipStream_t st = (hipStream_t)stream;
+  const int d = (int)t->dim, dr = (int)t->rel_dim;
+  if (combine == KGE_SPO)
+    return run_spo_bwd(t->scorer, t->l_norm, S, P, O, d, dr, n, gout, scores, g_s, g_p, g_o, st);
+  if (ldg < m || (scores && lds < m)) return KGE_ERR_INVALID_ARG;
+  if (combine == KGE_SP_)
+    return run_pairs_bwd(t->scorer, t->l_norm, KGE_SP_, S, P, O, d, dr, n, m, gout, ldg, scores,
+                         lds, g_s, g_p, g_o, st);
+  if (combine == KGE_PO_)
+    return run_pairs_bwd(t->scorer, t->l_norm, KGE_PO_, O, P, S, d, dr, n, m, gout, ldg, scores,
+                         lds, g_o, g_p, g_s, st);
+  return KGE_ERR_INVALID_ARG;
 }
 
 }  // extern "C"

@@ -1,23 +1,386 @@
-// bwd.hip -- autograd twins of the scoring kernels (reference: implicit torch autograd
-// through complex.py/distmult.py/transe.py/rotate.py, triggered at train_1vsAll.py:70,81).
+// bwd.hip -- backward twins of the scoring kernels, gfx950.
+//
+// The reference gets these from torch autograd through its scorer ops (complex.py:30-39,
+// distmult.py:15-21, transe.py:18-34, rotate.py:30-64), triggered at
+// kge/job/train_1vsAll.py:70,81, train_KvsAll.py:293-294, train_negative_sampling.py:161.
+// Tolerance-level parity (autograd's summation order is unspecified); f32 only.
+//
+//   bwd_pairs_kernel<.., WHICH=0>  dQ[i,:] = sum_j g_ij * dscore_ij/dq_i, chained in the
+//                                  epilogue to the gathered entity row (g_a) and relation
+//                                  row (g_p) of query i
+//   bwd_pairs_kernel<.., WHICH=1>  dT[j,:] = sum_i g_ij * dscore_ij/dt_j  (g_tgt)
+//   bwd_spo_kernel                 row-wise gradients of score_spo
+//
+// Tile: 64 output rows x 32 coordinate pairs (both halves) per 256-thread workgroup, the
+// reduction index streamed through LDS in chunks of 16; each thread owns 4 rows x 2
+// coordinate pairs.
 #include "common.hpp"
 
 namespace kge {
 
-int run_pairs_bwd(const kge_tables* t, int dir, const Operand& A, const Operand& R,
-                  const Operand& TG, long long n, long long m, const float* gout, long long ldg,
-                  float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
-  (void)t; (void)dir; (void)A; (void)R; (void)TG; (void)n; (void)m; (void)gout; (void)ldg;
-  (void)g_a; (void)g_p; (void)g_tgt; (void)st;
-  return KGE_ERR_UNSUPPORTED;
+constexpr int BW_TR = 64, BW_TC = 32, BW_KY = 16;
+
+__device__ __forceinline__ float ldf(const float* row, int k, int limit) {
+  return k < limit ? row[k] : 0.0f;
 }
 
-int run_spo_bwd(const kge_tables* t, const Operand& S, const Operand& R, const Operand& O,
-                long long n, const float* gout, float* g_s, float* g_p, float* g_o,
-                hipStream_t st) {
-  (void)t; (void)S; (void)R; (void)O; (void)n; (void)gout; (void)g_s; (void)g_p; (void)g_o;
-  (void)st;
-  return KGE_ERR_UNSUPPORTED;
+// weight of one distance component e (TransE) given the pair's distance
+template <int NORM>
+__device__ __forceinline__ float transe_w(float e, float dist, float p) {
+  if (NORM == NORM_L1) return (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
+  if (NORM == NORM_L2) return dist > 0.f ? e / dist : 0.f;
+  if (dist <= 0.f || e == 0.f) return 0.f;
+  float ae = __builtin_fabsf(e);
+  return (e > 0.f ? 1.f : -1.f) * powf(ae, p - 1.f) / powf(dist, p - 1.f);
+}
+
+// weights (wre, wim) of one complex distance component (RotatE)
+template <int NORM>
+__device__ __forceinline__ void rotate_w(float dre, float dim_, float dist, float p, float& wre,
+                                         float& wim) {
+  float ab = __builtin_sqrtf(__builtin_fmaf(dim_, dim_, dre * dre));
+  float f;
+  if (NORM == NORM_L1) f = ab > 0.f ? 1.f / ab : 0.f;
+  else if (NORM == NORM_L2) f = dist > 0.f ? 1.f / dist : 0.f;
+  else f = (dist > 0.f && ab > 0.f) ? powf(ab, p - 2.f) / powf(dist, p - 1.f) : 0.f;
+  wre = dre * f;
+  wim = dim_ * f;
+}
+
+template <int SCORER, int NORM, int WHICH>
+__global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Operand TG, int dir,
+                                                        int d, int dr, long long n, long long m,
+                                                        float lp, const float* __restrict__ gout,
+                                                        long long ldg,
+                                                        const float* __restrict__ scores,
+                                                        long long lds, float* __restrict__ g_a,
+                                                        float* __restrict__ g_p,
+                                                        float* __restrict__ g_tgt) {
+  constexpr bool DOT = (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT);
+  constexpr bool NEED_DIST = !DOT && NORM != NORM_L1;
+  __shared__ float Gs[BW_KY][BW_TR + 4];
+  __shared__ float Ds[BW_KY][BW_TR + 4];
+  __shared__ float V0[BW_KY][BW_TC + 1];
+  __shared__ float V1[BW_KY][BW_TC + 1];
+
+  const int tid = threadIdx.x;
+  const int hh = (d + 1) / 2, lim1 = d - hh;
+  const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;
+  const int rl1 = (SCORER == KGE_ROTATE) ? 0 : lim1;
+  const int c0 = blockIdx.x * BW_TC;
+  const long long row0 = (long long)blockIdx.y * BW_TR;
+  const long long X = WHICH == 0 ? n : m, Y = WHICH == 0 ? m : n;
+  const int tx = tid & 15, ty = tid >> 4;
+
+  // own-side values for this thread's 4 rows x 2 coordinates
+  float own0[4][2], own1[4][2];
+  float oa0[4][2], oa1[4][2], or0[4][2], or1[4][2];  // WHICH==0: gathered a / r values
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    long long x = row0 + ty * 4 + i;
+    if (x >= X) x = X - 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + tx * 2 + j;
+      if (WHICH == 0) {
+        const float* arow = (const float*)A.base + index_at(A.idx, x) * A.ld;
+        const float* rrow = (const float*)R.base + index_at(R.idx, x) * R.ld;
+        f32x4 a0v{ldf(arow, c, hh), 0, 0, 0}, a1v{ldf(arow + hh, c, lim1), 0, 0, 0};
+        f32x4 r0v{ldf(rrow, c, rl0), 0, 0, 0}, r1v{0, 0, 0, 0};
+        if (SCORER != KGE_ROTATE) r1v[0] = ldf(rrow + hh, c, rl1);
+        f32x4 q0v, q1v;
+        build_q4<SCORER>(dir, a0v, a1v, r0v, r1v, q0v, q1v);
+        own0[i][j] = q0v[0];
+        own1[i][j] = q1v[0];
+        oa0[i][j] = a0v[0]; oa1[i][j] = a1v[0]; or0[i][j] = r0v[0]; or1[i][j] = r1v[0];
+      } else {
+        const float* trow = (const float*)TG.base + index_at(TG.idx, x) * TG.ld;
+        own0[i][j] = ldf(trow, c, hh);
+        own1[i][j] = ldf(trow + hh, c, lim1);
+      }
+    }
+  }
+
+  float acc0[4][2], acc1[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc0[i][j] = acc1[i][j] = 0.f;
+
+  for (long long y0 = 0; y0 < Y; y0 += BW_KY) {
+    // ---- stage weights g (and distances) of this chunk
+    if (WHICH == 0) {
+      const int x = tid >> 2, yq = (tid & 3) * 4;
+      const long long gx = row0 + x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long long gy = y0 + yq + k;
+        const bool ok = gx < X && gy < Y;
+        Gs[yq + k][x] = ok ? gout[gx * ldg + gy] : 0.f;
+        if (NEED_DIST) Ds[yq + k][x] = ok ? -scores[gx * lds + gy] : 0.f;
+      }
+    } else {
+      const int y = tid >> 4, xq = (tid & 15) * 4;
+      const long long gy = y0 + y;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long long gx = row0 + xq + k;
+        const bool ok = gx < X && gy < Y;
+        Gs[y][xq + k] = ok ? gout[gy * ldg + gx] : 0.f;
+        if (NEED_DIST) Ds[y][xq + k] = ok ? -scores[gy * lds + gx] : 0.f;
+      }
+    }
+    // ---- stage the other side's vectors: 16 rows x 32 coordinates x 2 halves
+    {
+      const int y = tid >> 4, cq = (tid & 15) * 2;
+      long long gy = y0 + y;
+      const bool ok = gy < Y;
+      if (!ok) gy = Y - 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = c0 + cq + j;
+        float v0, v1;
+        if (WHICH == 0) {
+          const float* trow = (const float*)TG.base + index_at(TG.idx, gy) * TG.ld;
+          v0 = ldf(trow, c, hh);
+          v1 = ldf(trow + hh, c, lim1);
+        } else {
+          const float* arow = (const float*)A.base + index_at(A.idx, gy) * A.ld;
+          const float* rrow = (const float*)R.base + index_at(R.idx, gy) * R.ld;
+          f32x4 a0v{ldf(arow, c, hh), 0, 0, 0}, a1v{ldf(arow + hh, c, lim1), 0, 0, 0};
+          f32x4 r0v{ldf(rrow, c, rl0), 0, 0, 0}, r1v{0, 0, 0, 0};
+          if (SCORER != KGE_ROTATE) r1v[0] = ldf(rrow + hh, c, rl1);
+          f32x4 q0v, q1v;
+          build_q4<SCORER>(dir, a0v, a1v, r0v, r1v, q0v, q1v);
+          v0 = q0v[0];
+          v1 = q1v[0];
+        }
+        V0[y][cq + j] = ok ? v0 : 0.f;
+        V1[y][cq + j] = ok ? v1 : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int y = 0; y < BW_KY; ++y) {
+      float v0[2], v1[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        v0[j] = V0[y][tx * 2 + j];
+        v1[j] = V1[y][tx * 2 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float g = Gs[y][ty * 4 + i];
+        const float dist = NEED_DIST ? Ds[y][ty * 4 + i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (DOT) {
+            acc0[i][j] = __builtin_fmaf(g, v0[j], acc0[i][j]);
+            acc1[i][j] = __builtin_fmaf(g, v1[j], acc1[i][j]);
+          } else {
+            // e = q - t ; dscore/dq = -w(e), dscore/dt = +w(e)
+            const float e0 = WHICH == 0 ? own0[i][j] - v0[j] : v0[j] - own0[i][j];
+            const float e1 = WHICH == 0 ? own1[i][j] - v1[j] : v1[j] - own1[i][j];
+            const float sg = WHICH == 0 ? -g : g;
+            if (SCORER == KGE_TRANSE) {
+              acc0[i][j] = __builtin_fmaf(sg, transe_w<NORM>(e0, dist, lp), acc0[i][j]);
+              acc1[i][j] = __builtin_fmaf(sg, transe_w<NORM>(e1, dist, lp), acc1[i][j]);
+            } else {
+              float wre, wim;
+              rotate_w<NORM>(e0, e1, dist, lp, wre, wim);
+              acc0[i][j] = __builtin_fmaf(sg, wre, acc0[i][j]);
+              acc1[i][j] = __builtin_fmaf(sg, wim, acc1[i][j]);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long x = row0 + ty * 4 + i;
+    if (x >= X) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + tx * 2 + j;
+      if (c >= hh) continue;
+      const bool has1 = c < lim1;
+      const float dq0 = acc0[i][j], dq1 = acc1[i][j];
+      if (WHICH == 1) {
+        g_tgt[x * d + c] = dq0;
+        if (has1) g_tgt[x * d + hh + c] = dq1;
+        continue;
+      }
+      const float a0 = oa0[i][j], a1 = oa1[i][j], r0 = or0[i][j], r1 = or1[i][j];
+      float da0, da1, dr0, dr1 = 0.f;
+      if (SCORER == KGE_DISTMULT) {
+        da0 = dq0 * r0; da1 = dq1 * r1; dr0 = dq0 * a0; dr1 = dq1 * a1;
+      } else if (SCORER == KGE_COMPLEX) {
+        if (dir == KGE_SP_) {
+          da0 = dq0 * r0 + dq1 * r1; da1 = dq1 * r0 - dq0 * r1;
+          dr0 = dq0 * a0 + dq1 * a1; dr1 = dq1 * a0 - dq0 * a1;
+        } else {
+          da0 = dq0 * r0 - dq1 * r1; da1 = dq0 * r1 + dq1 * r0;
+          dr0 = dq0 * a0 + dq1 * a1; dr1 = dq0 * a1 - dq1 * a0;
+        }
+      } else if (SCORER == KGE_TRANSE) {
+        da0 = dq0; da1 = dq1;
+        dr0 = dir == KGE_SP_ ? dq0 : -dq0;
+        dr1 = dir == KGE_SP_ ? dq1 : -dq1;
+      } else {  // ROTATE: r0 = phase
+        float sn, cs;
+        sincos_canon(r0, sn, cs);
+        const float q0 = own0[i][j], q1 = own1[i][j];
+        if (dir == KGE_SP_) {
+          da0 = dq0 * cs + dq1 * sn; da1 = dq1 * cs - dq0 * sn;
+          dr0 = dq1 * q0 - dq0 * q1;
+        } else {
+          da0 = dq0 * cs - dq1 * sn; da1 = dq0 * sn + dq1 * cs;
+          dr0 = dq0 * q1 - dq1 * q0;
+        }
+      }
+      g_a[x * d + c] = da0;
+      if (has1) g_a[x * d + hh + c] = da1;
+      g_p[x * dr + c] = dr0;
+      if (SCORER != KGE_ROTATE && has1) g_p[x * dr + hh + c] = dr1;
+    }
+  }
+}
+
+// ---- score_spo backward: one wave per triple, lanes strided over the coordinate pairs
+template <int SCORER, int NORM>
+__global__ __launch_bounds__(256) void bwd_spo_kernel(Operand S, Operand R, Operand O, int d, int dr,
+                                                      long long n, float lp,
+                                                      const float* __restrict__ gout,
+                                                      const float* __restrict__ scores,
+                                                      float* __restrict__ g_s,
+                                                      float* __restrict__ g_p,
+                                                      float* __restrict__ g_o) {
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int hh = (d + 1) / 2, lim1 = d - hh;
+  const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;
+  const int rl1 = (SCORER == KGE_ROTATE) ? 0 : lim1;
+  const float* srow = (const float*)S.base + index_at(S.idx, i) * S.ld;
+  const float* rrow = (const float*)R.base + index_at(R.idx, i) * R.ld;
+  const float* orow = (const float*)O.base + index_at(O.idx, i) * O.ld;
+  const float g = gout[i];
+  const float dist = (SCORER == KGE_TRANSE || SCORER == KGE_ROTATE) && NORM != NORM_L1 ? -scores[i] : 0.f;
+  for (int c = lane; c < hh; c += 64) {
+    const bool has1 = c < lim1;
+    const float s0 = srow[c], s1 = has1 ? srow[hh + c] : 0.f;
+    const float o0 = orow[c], o1 = has1 ? orow[hh + c] : 0.f;
+    const float r0 = c < rl0 ? rrow[c] : 0.f, r1 = c < rl1 ? rrow[hh + c] : 0.f;
+    float ds0, ds1, dp0, dp1 = 0.f, do0, do1;
+    if (SCORER == KGE_DISTMULT) {
+      ds0 = g * (r0 * o0); ds1 = g * (r1 * o1);
+      dp0 = g * (s0 * o0); dp1 = g * (s1 * o1);
+      do0 = g * (s0 * r0); do1 = g * (s1 * r1);
+    } else if (SCORER == KGE_COMPLEX) {
+      ds0 = g * (o0 * r0 + o1 * r1); ds1 = g * (o1 * r0 - o0 * r1);
+      dp0 = g * (o0 * s0 + o1 * s1); dp1 = g * (o1 * s0 - o0 * s1);
+      do0 = g * (s0 * r0 - s1 * r1); do1 = g * (s1 * r0 + s0 * r1);
+    } else if (SCORER == KGE_TRANSE) {
+      const float e0 = ((s0 + r0) - o0) + 1e-6f, e1 = ((s1 + r1) - o1) + 1e-6f;
+      const float w0 = -g * transe_w<NORM>(e0, dist, lp);
+      const float w1 = has1 ? -g * transe_w<NORM>(e1, dist, lp) : 0.f;
+      ds0 = w0; ds1 = w1; dp0 = w0; dp1 = w1; do0 = -w0; do1 = -w1;
+    } else {
+      float sn, cs;
+      sincos_canon(r0, sn, cs);
+      const float q0 = s0 * cs - s1 * sn, q1 = s0 * sn + s1 * cs;
+      float wre, wim;
+      rotate_w<NORM>(q0 - o0, q1 - o1, dist, lp, wre, wim);
+      const float dq0 = -g * wre, dq1 = -g * wim;
+      ds0 = dq0 * cs + dq1 * sn; ds1 = dq1 * cs - dq0 * sn;
+      dp0 = dq1 * q0 - dq0 * q1;
+      do0 = -dq0; do1 = -dq1;
+    }
+    g_s[i * d + c] = ds0;
+    g_o[i * d + c] = do0;
+    g_p[i * dr + c] = dp0;
+    if (has1) {
+      g_s[i * d + hh + c] = ds1;
+      g_o[i * d + hh + c] = do1;
+      if (SCORER != KGE_ROTATE) g_p[i * dr + hh + c] = dp1;
+    }
+  }
+}
+
+template <int SCORER, int NORM>
+static int launch_bwd_pairs(int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
+                            int dr, long long n, long long m, float lp, const float* gout,
+                            long long ldg, const float* scores, long long lds, float* g_a,
+                            float* g_p, float* g_tgt, hipStream_t st) {
+  const int hh = (d + 1) / 2;
+  const unsigned gc = (unsigned)((hh + BW_TC - 1) / BW_TC);
+  hipLaunchKernelGGL((bwd_pairs_kernel<SCORER, NORM, 0>), dim3(gc, (unsigned)((n + BW_TR - 1) / BW_TR)),
+                     dim3(256), 0, st, A, R, TG, dir, d, dr, n, m, lp, gout, ldg, scores, lds, g_a,
+                     g_p, g_tgt);
+  hipLaunchKernelGGL((bwd_pairs_kernel<SCORER, NORM, 1>), dim3(gc, (unsigned)((m + BW_TR - 1) / BW_TR)),
+                     dim3(256), 0, st, A, R, TG, dir, d, dr, n, m, lp, gout, ldg, scores, lds, g_a,
+                     g_p, g_tgt);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_pairs_bwd(int scorer, float lp, int dir, const Operand& A, const Operand& R,
+                  const Operand& TG, int d, int dr, long long n, long long m, const float* gout,
+                  long long ldg, const float* scores, long long lds, float* g_a, float* g_p,
+                  float* g_tgt, hipStream_t st) {
+  if (n == 0 || m == 0) return KGE_OK;
+  const int norm = norm_mode(lp);
+  const bool dot = scorer == KGE_COMPLEX || scorer == KGE_DISTMULT;
+  if (!dot && norm != NORM_L1 && !scores) return KGE_ERR_INVALID_ARG;
+#define KGE_B(SC, NM) \
+  return launch_bwd_pairs<SC, NM>(dir, A, R, TG, d, dr, n, m, lp, gout, ldg, scores, lds, g_a, g_p, g_tgt, st)
+  switch (scorer) {
+    case KGE_COMPLEX: KGE_B(KGE_COMPLEX, NORM_L1);
+    case KGE_DISTMULT: KGE_B(KGE_DISTMULT, NORM_L1);
+    case KGE_TRANSE:
+      if (norm == NORM_L1) KGE_B(KGE_TRANSE, NORM_L1);
+      if (norm == NORM_L2) KGE_B(KGE_TRANSE, NORM_L2);
+      KGE_B(KGE_TRANSE, NORM_LP);
+    case KGE_ROTATE:
+      if (norm == NORM_L1) KGE_B(KGE_ROTATE, NORM_L1);
+      if (norm == NORM_L2) KGE_B(KGE_ROTATE, NORM_L2);
+      KGE_B(KGE_ROTATE, NORM_LP);
+  }
+#undef KGE_B
+  return KGE_ERR_INVALID_ARG;
+}
+
+int run_spo_bwd(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
+                int dr, long long n, const float* gout, const float* scores, float* g_s, float* g_p,
+                float* g_o, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  const int norm = norm_mode(lp);
+  const bool dot = scorer == KGE_COMPLEX || scorer == KGE_DISTMULT;
+  if (!dot && norm != NORM_L1 && !scores) return KGE_ERR_INVALID_ARG;
+  const dim3 grid((unsigned)((n + 3) / 4));
+#define KGE_S(SC, NM)                                                                            \
+  {                                                                                              \
+    hipLaunchKernelGGL((bwd_spo_kernel<SC, NM>), grid, dim3(256), 0, st, S, R, O, d, dr, n, lp,   \
+                       gout, scores, g_s, g_p, g_o);                                             \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;                            \
+  }
+  switch (scorer) {
+    case KGE_COMPLEX: KGE_S(KGE_COMPLEX, NORM_L1);
+    case KGE_DISTMULT: KGE_S(KGE_DISTMULT, NORM_L1);
+    case KGE_TRANSE:
+      if (norm == NORM_L1) KGE_S(KGE_TRANSE, NORM_L1);
+      if (norm == NORM_L2) KGE_S(KGE_TRANSE, NORM_L2);
+      KGE_S(KGE_TRANSE, NORM_LP);
+    case KGE_ROTATE:
+      if (norm == NORM_L1) KGE_S(KGE_ROTATE, NORM_L1);
+      if (norm == NORM_L2) KGE_S(KGE_ROTATE, NORM_L2);
+      KGE_S(KGE_ROTATE, NORM_LP);
+  }
+#undef KGE_S
+  return KGE_ERR_INVALID_ARG;
 }
 
 }  // namespace kge

@@ -183,4 +183,41 @@ __device__ __forceinline__ float norm_acc(float acc, float a, float p) {
   return acc + powf(a, p);  // general p: libm pow, tolerance-level only
 }
 
+// q halves for 4 coordinates.  a0/a1: entity row halves, r0/r1: relation row halves
+// (RotatE: r0 = phases).  dir: KGE_SP_ or KGE_PO_.
+template <int SCORER>
+__device__ __forceinline__ void build_q4(int dir, const f32x4& a0, const f32x4& a1,
+                                         const f32x4& r0, const f32x4& r1, f32x4& q0,
+                                         f32x4& q1) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (SCORER == KGE_DISTMULT) {
+      q0[i] = a0[i] * r0[i];
+      q1[i] = a1[i] * r1[i];
+    } else if (SCORER == KGE_TRANSE) {
+      q0[i] = (dir == KGE_SP_) ? (a0[i] + r0[i]) : (a0[i] - r0[i]);
+      q1[i] = (dir == KGE_SP_) ? (a1[i] + r1[i]) : (a1[i] - r1[i]);
+    } else if (SCORER == KGE_COMPLEX) {
+      if (dir == KGE_SP_) {
+        q0[i] = a0[i] * r0[i] - a1[i] * r1[i];
+        q1[i] = a1[i] * r0[i] + a0[i] * r1[i];
+      } else {
+        q0[i] = r0[i] * a0[i] + r1[i] * a1[i];
+        q1[i] = r0[i] * a1[i] - r1[i] * a0[i];
+      }
+    } else {  // ROTATE
+      float sn, cs;
+      sincos_canon(r0[i], sn, cs);
+      if (dir == KGE_SP_) {
+        q0[i] = a0[i] * cs - a1[i] * sn;
+        q1[i] = a0[i] * sn + a1[i] * cs;
+      } else {
+        q0[i] = cs * a0[i] + sn * a1[i];
+        q1[i] = cs * a1[i] - sn * a0[i];
+      }
+    }
+  }
+}
+
+
 }  // namespace kge

@@ -238,3 +238,73 @@ def rank_counts(scores, true_scores, lbl_rowptr=None, lbl_col=None, col_offset=0
             true_scores.data_ptr(), rp, cl, int(col_offset), tc, float(atol), float(rtol),
             rank.data_ptr(), ties.data_ptr(), _stream(dev)), "kge_rank_counts")
     return rank, ties
+
+
+# ---- backward twins (csrc/bwd.hip) ---------------------------------------------------------
+def _f32c(x, dev):
+    return x.to(device=dev, dtype=torch.float32).contiguous()
+
+
+def score_spo_bwd(t: Tables, s, p, o, gout, scores=None):
+    """Gradients of sum_i gout[i]*score_spo_i w.r.t. the gathered rows:
+    (g_s [n,d], g_p [n,d_r], g_o [n,d])."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = keep[0].numel()
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    gout = _f32c(gout, t.device)
+    sc = None if scores is None else _f32c(scores, t.device)
+    g_s, g_p, g_o = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((n, d), t.device)
+    with torch.cuda.device(t.device):
+        tc = t.c()
+        _lib.check(_lib.lib().kge_score_spo_bwd(
+            ctypes.byref(tc), si, pi, oi, n, gout.data_ptr(), None if sc is None else sc.data_ptr(),
+            g_s.data_ptr(), g_p.data_ptr(), g_o.data_ptr(), _stream(t.device)), "kge_score_spo_bwd")
+    return g_s, g_p, g_o
+
+
+def score_pairs_bwd(t: Tables, direction: str, a, p, targets, gout, scores=None):
+    """Backward of score_sp (direction 'sp', a = s) / score_po ('po', a = o):
+    (g_a [n,d], g_p [n,d_r], g_targets [m,d])."""
+    keep = []
+    ai, pi = _index(a, t.device, keep), _index(p, t.device, keep)
+    n = keep[0].numel()
+    ti = _index(targets, t.device, keep)
+    m = t.num_ent if targets is None else keep[-1].numel()
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    gout = gout.to(device=t.device, dtype=torch.float32)
+    if gout.dim() != 2 or gout.stride(1) != 1:
+        gout = gout.contiguous().view(n, m)
+    sc = None
+    if scores is not None:
+        sc = scores if scores.stride(-1) == 1 else scores.contiguous()
+    g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((m, d), t.device)
+    with torch.cuda.device(t.device):
+        tc = t.c()
+        _lib.check(_lib.lib().kge_score_pairs_bwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, n, ti, m, gout.data_ptr(),
+            gout.stride(0) if n > 1 else max(m, 1), None if sc is None else sc.data_ptr(),
+            0 if sc is None else (sc.stride(0) if n > 1 else max(m, 1)), g_a.data_ptr(),
+            g_p.data_ptr(), g_t.data_ptr(), _stream(t.device)), "kge_score_pairs_bwd")
+    return g_a, g_p, g_t
+
+
+def score_emb_bwd(scorer, s_emb, p_emb, o_emb, combine: str, l_norm, gout, scores=None):
+    """Backward of score_emb: gradients w.r.t. (s_emb, p_emb, o_emb)."""
+    code = {"spo": SPO, "sp_": SP_, "_po": PO_}[combine]
+    dev = s_emb.device
+    s_emb, p_emb, o_emb = (_f32c(x.detach(), dev) for x in (s_emb, p_emb, o_emb))
+    sc_code = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
+    n, d, dr = p_emb.shape[0], s_emb.shape[1], p_emb.shape[1]
+    m = 0 if code == SPO else (o_emb.shape[0] if code == SP_ else s_emb.shape[0])
+    gout = _f32c(gout, dev).view(n, -1) if code != SPO else _f32c(gout, dev).view(-1)
+    sc = None if scores is None else _f32c(scores, dev)
+    g_s, g_p, g_o = _empty(tuple(s_emb.shape), dev), _empty(tuple(p_emb.shape), dev), _empty(tuple(o_emb.shape), dev)
+    tc = KgeTables(None, None, F32, sc_code, 0, 0, d, dr, d, dr, float(l_norm), 0)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().kge_score_emb_bwd(
+            ctypes.byref(tc), code, s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(),
+            p_emb.stride(0), o_emb.data_ptr(), o_emb.stride(0), n, m, gout.data_ptr(), max(m, 1),
+            None if sc is None else sc.data_ptr(), max(m, 1), g_s.data_ptr(), g_p.data_ptr(),
+            g_o.data_ptr(), _stream(dev)), "kge_score_emb_bwd")
+    return g_s, g_p, g_o

@@ -1,0 +1,184 @@
+"""Entity-ranking evaluation on the fused kernels: host-side mirror of the reference's
+EntityRankingJob (kge/job/eval_entity_ranking.py) for the part of it that is on the hot path.
+
+What is kept from the reference and what is replaced:
+  * batching, the true-score-through-subset rule (:192-203), the entity chunk loop
+    (:216-229), tie policy (:598-618), float32 rank histogram and MRR / Hits@k
+    (:620-649, 665-687) -- same semantics, same names;
+  * `_collate` + sparse label tensors + `_densify_chunk_of_labels` (:77-101, 179-181,
+    489-531) become ONE CSR of filtered entity ids per batch row (FilterIndex), built from
+    sorted (key, value) arrays instead of the numba KvsAllIndex dict (kge/indexing.py:10-194);
+  * `_filter_and_rank` / `_get_ranks_and_num_ties` (:533-596) become kge_rank_counts: one
+    streaming pass over the scores per ranking instead of ~10.
+
+Rankings follow the reference: "_raw", "_filt" (filter_splits + the eval split) and, if
+filter_with_test, "_filt_test" (additionally the test split).  Because the reference
+applies the filters cumulatively (:305-307), "_filt_test" filters with the union.
+"""
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import engine
+
+
+class FilterIndex:
+    """(s,p)->{o} and (p,o)->{s} over a union of splits, as sorted arrays (CSR by key).
+
+    Replaces KvsAllIndex (kge/indexing.py:10-194) + get_sp_po_coords_from_spo_batch
+    (kge/job/util.py:6-29).  Values are unique and sorted per key, so the union over
+    splits needs no de-duplication at lookup time."""
+
+    def __init__(self, triples_list: List[np.ndarray], num_entities: int, num_relations: int):
+        tri = np.concatenate([np.asarray(t).reshape(-1, 3) for t in triples_list]).astype(np.int64)
+        self.E, self.R = int(num_entities), int(num_relations)
+        self._sp = self._build(tri[:, 0] * self.R + tri[:, 1], tri[:, 2])
+        self._po = self._build(tri[:, 1] * self.E + tri[:, 2], tri[:, 0])
+
+    def _build(self, keys, vals):
+        kv = np.unique(keys * self.E + vals)  # sorted unique (key, value) pairs
+        k, v = kv // self.E, kv % self.E
+        uk, start = np.unique(k, return_index=True)
+        return uk, np.append(start, len(k)).astype(np.int64), v
+
+    @staticmethod
+    def _lookup(index, keys):
+        uk, start, v = index
+        pos = np.searchsorted(uk, keys)
+        pos_c = np.minimum(pos, len(uk) - 1) if len(uk) else pos
+        hit = (pos < len(uk)) & (uk[pos_c] == keys) if len(uk) else np.zeros(len(keys), bool)
+        lo = np.where(hit, start[pos_c], 0)
+        hi = np.where(hit, start[pos_c + 1], 0) if len(uk) else lo
+        cnt = hi - lo
+        rowptr = np.zeros(len(keys) + 1, dtype=np.int64)
+        np.cumsum(cnt, out=rowptr[1:])
+        # gather the segments
+        idx = np.repeat(lo - rowptr[:-1], cnt) + np.arange(rowptr[-1])
+        return rowptr, v[idx] if rowptr[-1] else np.zeros(0, dtype=np.int64)
+
+    def labels(self, batch: np.ndarray):
+        """-> (sp_rowptr, sp_col, po_rowptr, po_col) for a batch of (s,p,o) triples."""
+        b = np.asarray(batch).astype(np.int64)
+        sp = self._lookup(self._sp, b[:, 0] * self.R + b[:, 1])
+        po = self._lookup(self._po, b[:, 1] * self.E + b[:, 2])
+        return sp + po
+
+
+def get_ranks(rank, ties, tie_handling="rounded_mean_rank"):
+    """EntityRankingJob._get_ranks (eval_entity_ranking.py:598-618)."""
+    if tie_handling == "rounded_mean_rank":
+        return rank + ties // 2
+    if tie_handling == "best_rank":
+        return rank
+    if tie_handling == "worst_rank":
+        return rank + ties - 1
+    raise NotImplementedError
+
+
+def compute_metrics(rank_hist: torch.Tensor, hits_at_k_s, suffix="") -> Dict[str, float]:
+    """EntityRankingJob._compute_metrics (eval_entity_ranking.py:620-649), same arithmetic:
+    float32 histogram, float32 reciprocal ranks, python-float division."""
+    metrics = {}
+    n = torch.sum(rank_hist).item()
+    E = rank_hist.numel()
+    ranks = torch.arange(1, E + 1, device=rank_hist.device).float()
+    metrics["mean_rank" + suffix] = (torch.sum(rank_hist * ranks).item() / n) if n > 0.0 else 0.0
+    metrics["mean_reciprocal_rank" + suffix] = (
+        (torch.sum(rank_hist * (1.0 / ranks)).item() / n) if n > 0.0 else 0.0)
+    hits = [k for k in hits_at_k_s if k <= E]
+    if hits:
+        cum = (torch.cumsum(rank_hist[: max(hits)], dim=0, dtype=torch.float64) / n).tolist() \
+            if n > 0.0 else [0.0] * max(hits)
+        for k in hits:
+            metrics["hits_at_{}{}".format(k, suffix)] = cum[k - 1]
+    return metrics
+
+
+class EntityRankingEvaluator:
+    """Mirror of EntityRankingJob._evaluate (eval_entity_ranking.py:103-481)."""
+
+    def __init__(self, model, splits: Dict[str, np.ndarray], num_entities: int, num_relations: int,
+                 eval_split: str = "valid", filter_splits=("train", "valid"),
+                 filter_with_test: bool = True, batch_size: int = 100, chunk_size: int = -1,
+                 tie_handling: str = "rounded_mean_rank", tie_atol: float = 1e-5,
+                 tie_rtol: float = 1e-4,
+                 hits_at_k_s=(1, 3, 10, 50, 100, 200, 300, 400, 500, 1000)):
+        self.model = model
+        self.E, self.R = num_entities, num_relations
+        self.triples = np.asarray(splits[eval_split]).reshape(-1, 3)
+        fs = list(filter_splits)
+        if eval_split not in fs:
+            fs.append(eval_split)  # eval_entity_ranking.py:28-29
+        self.filter_with_test = filter_with_test and "test" not in fs
+        self.index_filt = FilterIndex([splits[s] for s in fs], num_entities, num_relations)
+        self.index_filt_test = (FilterIndex([splits[s] for s in fs + ["test"]], num_entities,
+                                            num_relations) if self.filter_with_test else None)
+        self.batch_size, self.chunk_size = batch_size, chunk_size
+        self.tie_handling, self.tie_atol, self.tie_rtol = tie_handling, tie_atol, tie_rtol
+        self.hits_at_k_s = [k for k in hits_at_k_s if k <= min(num_entities, max(hits_at_k_s))]
+
+    @torch.no_grad()
+    def run(self, return_ranks: bool = False):
+        model = self.model
+        tables = model.tables() if hasattr(model, "tables") else model
+        dev = tables.device
+        E = self.E
+        rankings = ["_raw", "_filt"] + (["_filt_test"] if self.filter_with_test else [])
+        hists = {r: torch.zeros(E, dtype=torch.float, device=dev) for r in rankings}
+        all_ranks = {f"{d}{r}": [] for r in rankings for d in "so"}
+        chunk = E if self.chunk_size < 0 else self.chunk_size
+
+        for b0 in range(0, len(self.triples), self.batch_size):
+            batch_np = self.triples[b0:b0 + self.batch_size]
+            batch = torch.from_numpy(np.ascontiguousarray(batch_np)).to(dev)
+            s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
+            n = len(batch_np)
+            labels = {"_raw": None, "_filt": self.index_filt.labels(batch_np)}
+            if self.filter_with_test:
+                labels["_filt_test"] = self.index_filt_test.labels(batch_np)
+            labels = {k: (None if v is None else tuple(torch.from_numpy(x).to(dev) for x in v))
+                      for k, v in labels.items()}
+
+            # true scores through the subset path (:192-203)
+            unique_o, inv_o = torch.unique(o, return_inverse=True)
+            o_true = torch.gather(engine.score_sp(tables, s, p, unique_o), 1, inv_o.view(-1, 1)).view(-1)
+            unique_s, inv_s = torch.unique(s, return_inverse=True)
+            s_true = torch.gather(engine.score_po(tables, p, o, unique_s), 1, inv_s.view(-1, 1)).view(-1)
+
+            counts = {f"{d}{r}": [torch.zeros(n, dtype=torch.int64, device=dev),
+                                  torch.zeros(n, dtype=torch.int64, device=dev)]
+                      for r in rankings for d in "so"}
+            s64, o64 = s.long(), o.long()
+            for start in range(0, E, chunk):
+                end = min(start + chunk, E)
+                sub = None if (start == 0 and end == E) else torch.arange(start, end, device=dev)
+                scores = engine.score_sp_po(tables, s, p, o, sub)
+                c = end - start
+                sc_sp, sc_po = scores[:, :c], scores[:, c:]
+                for r in rankings:
+                    lab = labels[r]
+                    sp_rp, sp_col, po_rp, po_col = lab if lab is not None else (None,) * 4
+                    engine.rank_counts(sc_sp, o_true, sp_rp, sp_col, start, o64, self.tie_atol,
+                                       self.tie_rtol, *counts["o" + r])
+                    engine.rank_counts(sc_po, s_true, po_rp, po_col, start, s64, self.tie_atol,
+                                       self.tie_rtol, *counts["s" + r])
+            for r in rankings:
+                s_ranks = get_ranks(*counts["s" + r], self.tie_handling)
+                o_ranks = get_ranks(*counts["o" + r], self.tie_handling)
+                # hist_all (:665-687)
+                for ranks in (o_ranks, s_ranks):
+                    u, cnt = torch.unique(ranks, return_counts=True)
+                    hists[r].index_add_(0, u, cnt.float())
+                if return_ranks:
+                    all_ranks["s" + r].append(s_ranks)
+                    all_ranks["o" + r].append(o_ranks)
+
+        suffix = {"_raw": "", "_filt": "_filtered", "_filt_test": "_filtered_with_test"}
+        metrics = {}
+        for r in rankings:
+            metrics.update(compute_metrics(hists[r], self.hits_at_k_s, suffix[r]))
+        if return_ranks:
+            return metrics, {k: torch.cat(v).cpu().numpy() if v else np.zeros(0, np.int64)
+                             for k, v in all_ranks.items()}
+        return metrics

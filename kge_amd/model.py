@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's model API for the scoring hot path.
+
+Same class names, method names, argument meaning and error behaviour as the reference
+(kge/model/kge_model.py, kge/model/embedder/lookup_embedder.py, complex.py, distmult.py,
+transe.py, rotate.py), with every score_* routed to the fused HIP kernels.  The reference
+package itself cannot travel to the GPU box, so these classes are self-contained
+torch.nn.Modules; `kge_amd.libkge_plugin` wraps the same kernels in subclasses of the
+*reference's* KgeModel for use inside LibKGE (modules: [..., kge_amd.libkge_plugin]).
+
+Parameter names/shapes equal the reference's (`_entity_embedder._embeddings.weight` [E,d],
+`_relation_embedder._embeddings.weight` [R,d_r]) so state_dicts / checkpoints interoperate.
+"""
+import math
+
+import torch
+from torch import Tensor
+
+from . import engine
+from ._lib import SCORERS
+
+
+class LookupEmbedder(torch.nn.Module):
+    """kge/model/embedder/lookup_embedder.py:13-112 (table owner; dropout; normalize)."""
+
+    def __init__(self, vocab_size: int, dim: int, dropout: float = 0.0, normalize_p: float = -1.0,
+                 initialize: str = "normal_", initialize_args=None, sparse: bool = False,
+                 dtype=torch.float32, device=None):
+        super().__init__()
+        self.vocab_size, self.dim = vocab_size, dim
+        self.normalize_p = normalize_p
+        self._embeddings = torch.nn.Embedding(vocab_size, dim, sparse=sparse, device=device, dtype=dtype)
+        getattr(torch.nn.init, initialize)(self._embeddings.weight.data, **(initialize_args or {}))
+        self._normalize_embeddings()
+        self.dropout = torch.nn.Dropout(max(0.0, dropout))
+
+    def _normalize_embeddings(self):
+        if self.normalize_p > 0:
+            with torch.no_grad():
+                self._embeddings.weight.data = torch.nn.functional.normalize(
+                    self._embeddings.weight.data, p=self.normalize_p, dim=-1)
+
+    def embed(self, indexes: Tensor) -> Tensor:
+        return self._postprocess(self._embeddings(indexes.long()))
+
+    def embed_all(self) -> Tensor:
+        # the reference gathers arange(E): a full-table copy (lookup_embedder.py:107-112);
+        # the weight itself is returned here, the fused kernels read it in place.
+        return self._postprocess(self._embeddings.weight)
+
+    def _postprocess(self, embeddings: Tensor) -> Tensor:
+        if self.dropout.p > 0:
+            embeddings = self.dropout(embeddings)
+        return embeddings
+
+    @property
+    def weight(self) -> Tensor:
+        return self._embeddings.weight
+
+    def fused_ok(self) -> bool:
+        """Fused gather is valid when the embedder is a pure lookup (no active dropout)."""
+        return not (self.training and self.dropout.p > 0)
+
+
+class RelationalScorer(torch.nn.Module):
+    """kge/model/kge_model.py:111-213: embedding-level scoring, combine in spo/sp_/_po/s_o."""
+
+    name = None
+
+    def __init__(self, l_norm: float = 1.0):
+        super().__init__()
+        self._norm = float(l_norm)
+
+    def score_emb_spo(self, s_emb: Tensor, p_emb: Tensor, o_emb: Tensor) -> Tensor:
+        return self.score_emb(s_emb, p_emb, o_emb, "spo")
+
+    def score_emb(self, s_emb: Tensor, p_emb: Tensor, o_emb: Tensor, combine: str) -> Tensor:
+        n = p_emb.size(0)
+        if combine in ("spo", "sp_", "_po"):
+            if combine == "spo":
+                assert s_emb.size(0) == n and o_emb.size(0) == n
+            return _ScoreEmb.apply(self.name, combine, self._norm, s_emb, p_emb, o_emb).view(n, -1)
+        if combine == "s_o":  # generic fallback of the reference (kge_model.py:202-209)
+            n = s_emb.size(0)
+            assert o_emb.size(0) == n
+            n_p = p_emb.size(0)
+            s_embs = s_emb.repeat_interleave(n_p, 0)
+            p_embs = p_emb.repeat((n, 1))
+            o_embs = o_emb.repeat_interleave(n_p, 0)
+            return _ScoreEmb.apply(self.name, "spo", self._norm, s_embs, p_embs, o_embs).view(n, -1)
+        raise ValueError('cannot handle combine="{}".format(combine)')
+
+
+class ComplExScorer(RelationalScorer):
+    name = "complex"
+
+
+class DistMultScorer(RelationalScorer):
+    name = "distmult"
+
+
+class TransEScorer(RelationalScorer):
+    name = "transe"
+
+
+class RotatEScorer(RelationalScorer):
+    name = "rotate"
+
+
+class KgeModel(torch.nn.Module):
+    """Index-level API of kge/model/kge_model.py:587-789 on the fused kernels."""
+
+    scorer_cls = None
+
+    def __init__(self, num_entities: int, num_relations: int, dim: int, l_norm: float = 1.0,
+                 dtype=torch.float32, device=None, entity_args=None, relation_args=None):
+        super().__init__()
+        rel_dim = dim // 2 if self.scorer_cls is RotatEScorer else dim
+        if self.scorer_cls in (RotatEScorer, ComplExScorer) and dim % 2:
+            raise ValueError("{} requires embeddings of even dimensionality (got {})".format(
+                type(self).__name__, dim))
+        relation_args = dict(relation_args or {})
+        if self.scorer_cls is RotatEScorer:  # rotate.yaml:22-26
+            relation_args.setdefault("initialize", "uniform_")
+            relation_args.setdefault("initialize_args", {"a": -math.pi, "b": math.pi})
+        self._entity_embedder = LookupEmbedder(num_entities, dim, dtype=dtype, device=device,
+                                               **(entity_args or {}))
+        self._relation_embedder = LookupEmbedder(num_relations, rel_dim, dtype=dtype, device=device,
+                                                 **relation_args)
+        self._scorer = self.scorer_cls(l_norm)
+
+    # -- accessors (kge_model.py:649-661)
+    def get_s_embedder(self):
+        return self._entity_embedder
+
+    def get_o_embedder(self):
+        return self._entity_embedder
+
+    def get_p_embedder(self):
+        return self._relation_embedder
+
+    def get_scorer(self):
+        return self._scorer
+
+    def tables(self, flags: int = 0) -> engine.Tables:
+        return engine.Tables(self._scorer.name, self._entity_embedder.weight.detach(),
+                             self._relation_embedder.weight.detach(), self._scorer._norm, flags)
+
+    def _fused(self) -> bool:
+        return self._entity_embedder.fused_ok() and self._relation_embedder.fused_ok()
+
+    # -- scoring
+    def score_spo(self, s: Tensor, p: Tensor, o: Tensor, direction=None) -> Tensor:
+        if self._fused():
+            return _ScoreSPO.apply(self, self._entity_embedder.weight, self._relation_embedder.weight, s, p, o)
+        se, pe, oe = self._entity_embedder.embed(s), self._relation_embedder.embed(p), self._entity_embedder.embed(o)
+        return self._scorer.score_emb(se, pe, oe, combine="spo").view(-1)
+
+    def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
+        if self._fused():
+            return _ScorePairs.apply(self, "sp", self._entity_embedder.weight,
+                                     self._relation_embedder.weight, s, p, o)
+        se, pe = self._entity_embedder.embed(s), self._relation_embedder.embed(p)
+        oe = self._entity_embedder.embed_all() if o is None else self._entity_embedder.embed(o)
+        return self._scorer.score_emb(se, pe, oe, combine="sp_")
+
+    def score_po(self, p: Tensor, o: Tensor, s: Tensor = None) -> Tensor:
+        if self._fused():
+            return _ScorePairs.apply(self, "po", self._entity_embedder.weight,
+                                     self._relation_embedder.weight, o, p, s)
+        se = self._entity_embedder.embed_all() if s is None else self._entity_embedder.embed(s)
+        oe, pe = self._entity_embedder.embed(o), self._relation_embedder.embed(p)
+        return self._scorer.score_emb(se, pe, oe, combine="_po")
+
+    def score_so(self, s: Tensor, o: Tensor, p: Tensor = None) -> Tensor:
+        se, oe = self._entity_embedder.embed(s), self._entity_embedder.embed(o)
+        pe = self._relation_embedder.embed_all() if p is None else self._relation_embedder.embed(p)
+        return self._scorer.score_emb(se, pe, oe, combine="s_o")
+
+    def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
+        if self._fused() and not torch.is_grad_enabled():
+            return engine.score_sp_po(self.tables(), s, p, o, entity_subset)
+        return torch.cat((self.score_sp(s, p, entity_subset), self.score_po(p, o, entity_subset)), dim=1)
+
+
+class ComplEx(KgeModel):
+    scorer_cls = ComplExScorer
+
+
+class DistMult(KgeModel):
+    scorer_cls = DistMultScorer
+
+
+class TransE(KgeModel):
+    scorer_cls = TransEScorer
+
+
+class RotatE(KgeModel):
+    scorer_cls = RotatEScorer
+
+    @torch.no_grad()
+    def normalize_phases(self):
+        """rotate.py:103-118: wrap phases to [-pi, pi)."""
+        w = self._relation_embedder.weight.data
+        w[:] = torch.remainder(w + math.pi, 2.0 * math.pi) - math.pi
+
+
+MODELS = {"complex": ComplEx, "distmult": DistMult, "transe": TransE, "rotate": RotatE}
+
+
+def create(model: str, num_entities: int, num_relations: int, dim: int, **kw) -> KgeModel:
+    return MODELS[model](num_entities, num_relations, dim, **kw)
+
+
+# ---- autograd glue (the reference gets backward from torch autograd; here the twins in
+# ---- csrc/bwd.hip are called explicitly) --------------------------------------------------
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+
+
+def _scatter_rows(grad_table, idx, rows):
+    grad_table.index_add_(0, idx.reshape(-1).long(), rows)
+
+
+class _ScoreSPO(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, ent, rel, s, p, o):
+        t = engine.Tables(model._scorer.name, ent.detach(), rel.detach(), model._scorer._norm)
+        ctx.t, ctx.idx = t, (s, p, o)
+        out = engine.score_spo(t, s, p, o)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        s, p, o = ctx.idx
+        (scores,) = ctx.saved_tensors
+        g_s, g_p, g_o = engine.score_spo_bwd(ctx.t, s, p, o, gout.contiguous(), scores)
+        ge, gr = torch.zeros_like(ctx.t.ent), torch.zeros_like(ctx.t.rel)
+        _scatter_rows(ge, s, g_s)
+        _scatter_rows(ge, o, g_o)
+        _scatter_rows(gr, p, g_p)
+        return None, ge, gr, None, None, None
+
+
+class _ScorePairs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, direction, ent, rel, a, p, targets):
+        t = engine.Tables(model._scorer.name, ent.detach(), rel.detach(), model._scorer._norm)
+        out = (engine.score_sp if direction == "sp" else engine.score_po)(t, *((a, p) if direction == "sp" else (p, a)), targets)
+        ctx.t, ctx.direction, ctx.idx = t, direction, (a, p, targets)
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, p, targets = ctx.idx
+        (scores,) = ctx.saved_tensors
+        g_a, g_p, g_t = engine.score_pairs_bwd(ctx.t, ctx.direction, a, p, targets, gout, scores)
+        ge, gr = torch.zeros_like(ctx.t.ent), torch.zeros_like(ctx.t.rel)
+        _scatter_rows(ge, a, g_a)
+        _scatter_rows(gr, p, g_p)
+        if targets is None:
+            ge += g_t
+        else:
+            _scatter_rows(ge, targets, g_t)
+        return None, None, ge, gr, None, None, None
+
+
+class _ScoreEmb(torch.autograd.Function):
+    """Dense-embedding scoring (RelationalScorer.score_emb)."""
+
+    @staticmethod
+    def forward(ctx, name, combine, l_norm, s_emb, p_emb, o_emb):
+        out = engine.score_emb(name, s_emb.detach(), p_emb.detach(), o_emb.detach(), combine, l_norm)
+        ctx.meta = (name, combine, l_norm)
+        ctx.save_for_backward(s_emb, p_emb, o_emb, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        name, combine, l_norm = ctx.meta
+        s_emb, p_emb, o_emb, out = ctx.saved_tensors
+        g_s, g_p, g_o = engine.score_emb_bwd(name, s_emb, p_emb, o_emb, combine, l_norm, gout, out)
+        return None, None, None, g_s, g_p, g_o

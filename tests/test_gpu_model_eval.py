@@ -1,0 +1,148 @@
+"""GPU tests of the host-side mirror of the reference API (kge_amd.model, kge_amd.eval):
+they read like the reference's own tests (tests/test_model.py) and add the golden
+EntityRankingJob comparison and autograd checks."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as ko
+import torch_port as tp
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(name, E, R, d, **kw):
+    from kge_amd import model
+    torch.manual_seed(0)
+    return model.create(name, E, R, d, device=DEV, **kw)
+
+
+@pytest.mark.parametrize("name,opts", [("complex", {}), ("distmult", {}), ("transe", {}),
+                                       ("transe", {"l_norm": 2.0}), ("rotate", {}),
+                                       ("rotate", {"l_norm": 2.0})])
+def test_score_equality(name, opts):
+    """The reference's BaseTestModel.test_score_equality (tests/test_model.py:29-71):
+    score_spo(direction=o) ~ score_sp and score_spo(direction=s) ~ score_po.t()."""
+    E, R = 4, 3
+    m = _model(name, E, R, 32, **opts).eval()
+    s = torch.arange(E).repeat_interleave(R * E).to(DEV)
+    p = torch.arange(R).repeat_interleave(E).repeat(E).to(DEV)
+    o = torch.arange(E).repeat(R * E).to(DEV)
+    with torch.no_grad():
+        spo_s = m.score_spo(s, p, o, direction="s")
+        spo_o = m.score_spo(s, p, o, direction="o")
+        s2 = torch.arange(E).repeat_interleave(R).to(DEV)
+        p2 = torch.arange(R).repeat(E).to(DEV)
+        sp = m.score_sp(s2, p2).contiguous()
+        assert torch.allclose(spo_o.view(-1), sp.view(-1), atol=1e-5, rtol=1e-4)
+        p3 = torch.arange(R).repeat_interleave(E).to(DEV)
+        o3 = torch.arange(E).repeat(R).to(DEV)
+        po = m.score_po(p3, o3).t().contiguous()
+        assert torch.allclose(spo_s.view(-1), po.view(-1), atol=1e-5, rtol=1e-4)
+
+
+def test_rotate_normalize_phases_keeps_scores():
+    """tests/test_model.py:132-167."""
+    m = _model("rotate", 20, 4, 32).eval()
+    with torch.no_grad():
+        m.get_p_embedder().weight.mul_(3.0)  # phases outside [-pi, pi)
+        s, p, o = (torch.randint(hi, (50,), device=DEV) for hi in (20, 4, 20))
+        before = m.score_spo(s, p, o)
+        m.normalize_phases()
+        w = m.get_p_embedder().weight
+        assert (w >= -np.pi).all() and (w < np.pi + 1e-6).all()
+        assert torch.allclose(before, m.score_spo(s, p, o), atol=1e-4, rtol=1e-4)
+
+
+def test_state_dict_names_and_cpu_refusal():
+    from kge_amd import model
+    m = model.create("complex", 10, 3, 16)  # on CPU
+    assert list(m.state_dict().keys()) == ["_entity_embedder._embeddings.weight",
+                                           "_relation_embedder._embeddings.weight"]
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.score_sp(torch.tensor([1]), torch.tensor([0]))
+    with pytest.raises(ValueError):
+        model.create("rotate", 10, 3, 15)
+
+
+def test_score_so_and_unknown_combine():
+    m = _model("distmult", 12, 5, 16).eval()
+    s, o = torch.tensor([1, 2], device=DEV), torch.tensor([3, 4], device=DEV)
+    with torch.no_grad():
+        so = m.score_so(s, o)
+        assert so.shape == (2, 5)
+        for j in range(5):
+            pj = torch.full((2,), j, device=DEV)
+            assert torch.allclose(so[:, j], m.score_spo(s, pj, o), atol=1e-5, rtol=1e-4)
+        with pytest.raises(ValueError):
+            m.get_scorer().score_emb(m.get_s_embedder().embed(s), m.get_p_embedder().embed(s),
+                                     m.get_o_embedder().embed(o), "xx")
+
+
+@pytest.mark.parametrize("name", ["complex", "distmult", "transe", "rotate"])
+@pytest.mark.parametrize("tag,chunk", [("full", -1), ("chunk17", 17)])
+def test_entity_ranking_matches_reference_golden(name, tag, chunk):
+    """EntityRankingJob on the golden synthetic dataset: identical per-example ranks for the
+    raw / filtered / filtered_with_test rankings, MRR and Hits within 1e-5."""
+    from kge_amd import model
+    from kge_amd.eval import EntityRankingEvaluator
+    g = np.load(os.path.join(GOLDEN, f"eval_{name}.npz"))
+    E, R = int(g["num_entities"]), int(g["num_relations"])
+    m = model.create(name, E, R, g["ent"].shape[1], device=DEV).eval()
+    with torch.no_grad():
+        m.get_s_embedder().weight.copy_(torch.from_numpy(g["ent"]))
+        m.get_p_embedder().weight.copy_(torch.from_numpy(g["rel"]))
+    splits = {k: g[k] for k in ("train", "valid", "test")}
+    ev = EntityRankingEvaluator(m, splits, E, R, eval_split="valid", batch_size=16, chunk_size=chunk)
+    metrics, ranks = ev.run(return_ranks=True)
+    for key in ("_raw", "_filt", "_filt_test"):
+        gk = "" if key == "_raw" else key
+        assert np.array_equal(ranks["o" + key], g[f"o_rank{gk}_{tag}"]), (name, key, "o")
+        assert np.array_equal(ranks["s" + key], g[f"s_rank{gk}_{tag}"]), (name, key, "s")
+    ref = json.loads(str(g[f"metrics_{tag}"]))
+    for k, v in metrics.items():
+        assert abs(v - ref[k]) <= 1e-5, (k, v, ref[k])
+
+
+# ---- autograd --------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,l_norm", [("complex", 1.0), ("distmult", 1.0), ("transe", 1.0),
+                                         ("transe", 2.0), ("rotate", 1.0), ("rotate", 2.0)])
+def test_backward_matches_torch_autograd(name, l_norm):
+    """Gradients of a random linear functional of score_sp / score_po / score_spo w.r.t. both
+    tables against torch autograd through the reference's op sequence (oracle/torch_port.py,
+    CPU, float64-free): tolerance level (autograd's reduction order is unspecified)."""
+    E, R, d, n = 150, 5, 40, 37
+    m = _model(name, E, R, d, l_norm=l_norm).train()
+    ent0 = m.get_s_embedder().weight.detach().cpu().clone()
+    rel0 = m.get_p_embedder().weight.detach().cpu().clone()
+    g = torch.Generator().manual_seed(3)
+    s, p, o = (torch.randint(hi, (n,), generator=g) for hi in (E, R, E))
+    sub = torch.randperm(E, generator=g)[:45]
+    w_sp = torch.randn(n, E, generator=g)
+    w_po = torch.randn(n, 45, generator=g)
+    w_spo = torch.randn(n, generator=g)
+
+    # reference gradients on CPU
+    ent, rel = ent0.clone().requires_grad_(), rel0.clone().requires_grad_()
+    loss = ((tp.score_sp(name, ent, rel, s, p, None, l_norm) * w_sp).sum()
+            + (tp.score_po(name, ent, rel, p, o, sub, l_norm) * w_po).sum()
+            + (tp.score_spo(name, ent, rel, s, p, o, l_norm) * w_spo).sum())
+    loss.backward()
+
+    sd, pd, od, subd = (x.to(DEV) for x in (s, p, o, sub))
+    loss2 = ((m.score_sp(sd, pd) * w_sp.to(DEV)).sum()
+             + (m.score_po(pd, od, subd) * w_po.to(DEV)).sum()
+             + (m.score_spo(sd, pd, od) * w_spo.to(DEV)).sum())
+    loss2.backward()
+    ge = m.get_s_embedder().weight.grad.cpu()
+    gr = m.get_p_embedder().weight.grad.cpu()
+    assert abs(loss.item() - loss2.item()) <= 1e-3 * max(1.0, abs(loss.item()))
+    for got, want, nm in ((ge, ent.grad, "entity"), (gr, rel.grad, "relation")):
+        scale = max(1.0, float(want.abs().max()))
+        err = float((got - want).abs().max())
+        assert err <= 2e-4 * scale, (name, l_norm, nm, err, scale)
