@@ -1,0 +1,26 @@
+"""LibKGE plugin: the fused gfx950 kernels behind the reference's own plugin API.
+
+Usage inside an unmodified LibKGE installation (config-default.yaml:137, README.md:556-563):
+
+    modules: [kge.job, kge.model, kge.model.embedder, kge_amd.libkge_plugin]
+    model: hip_complex            # or hip_distmult / hip_transe / hip_rotate
+    # optional: eval.type: hip_entity_ranking
+
+`Config._import("hip_complex")` finds hip_complex.yaml in this package (config.py:280-325)
+and `init_from(class_name, modules)` (misc.py:13-42) resolves the classes below.  They
+subclass the reference's KgeModel / RelationalScorer / EntityRankingJob, keep its parameter
+names (`_entity_embedder._embeddings.weight`, ...) so optimizers, checkpoints and
+ReciprocalRelationsModel work unchanged, and override only the score_* hot path.
+
+This module needs the reference package `kge` to be importable; it is not used on the GPU
+box of this repo's CI (no reference tree there) -- kge_amd.model mirrors the same API
+stand-alone.
+"""
+try:
+    import kge  # noqa: F401
+except ImportError as e:  # pragma: no cover
+    raise ImportError("kge_amd.libkge_plugin needs LibKGE (`kge`) to be importable") from e
+
+from .models import (HipComplEx, HipComplExScorer, HipDistMult, HipDistMultScorer,  # noqa: F401
+                     HipRotatE, HipRotatEScorer, HipTransE, HipTransEScorer)
+from .eval_job import HipEntityRankingJob  # noqa: F401

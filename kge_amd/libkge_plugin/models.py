@@ -1,0 +1,124 @@
+"""KgeModel / RelationalScorer subclasses routing the hot path to libkge_amd.so."""
+import torch
+from torch import Tensor
+
+from kge import Config, Dataset
+from kge.model.kge_model import KgeModel, RelationalScorer
+from kge.model.rotate import RotatE as _RefRotatE
+from kge.model.transe import TransE as _RefTransE
+
+from .. import engine
+from ..model import _ScoreEmb, _ScorePairs, _ScoreSPO
+
+
+class _HipScorer(RelationalScorer):
+    """score_emb of the reference scorers (complex.py:18-43, distmult.py:13-25,
+    transe.py:15-37, rotate.py:20-69) on dense embeddings; `s_o` keeps the reference's
+    generic fallback (kge_model.py:202-209), which lands in score_emb(..., "spo") here."""
+
+    name = None
+
+    def __init__(self, config: Config, dataset: Dataset, configuration_key=None):
+        super().__init__(config, dataset, configuration_key)
+        self._norm = float(self.get_option("l_norm")) if self.name in ("transe", "rotate") else 1.0
+
+    def score_emb(self, s_emb, p_emb, o_emb, combine: str):
+        if combine in ("spo", "sp_", "_po"):
+            n = p_emb.size(0)
+            return _ScoreEmb.apply(self.name, combine, self._norm, s_emb, p_emb, o_emb).view(n, -1)
+        return super().score_emb(s_emb, p_emb, o_emb, combine)
+
+
+class HipComplExScorer(_HipScorer):
+    name = "complex"
+
+
+class HipDistMultScorer(_HipScorer):
+    name = "distmult"
+
+
+class HipTransEScorer(_HipScorer):
+    name = "transe"
+
+
+class HipRotatEScorer(_HipScorer):
+    name = "rotate"
+
+
+class _FusedScoring:
+    """Overrides of KgeModel.score_* (kge_model.py:663-789): fused gather + score when both
+    embedders are plain lookup tables (no active dropout, shared entity embedder)."""
+
+    def _fused(self) -> bool:
+        from kge.model import LookupEmbedder
+        se, oe, pe = self.get_s_embedder(), self.get_o_embedder(), self.get_p_embedder()
+        if se is not oe or type(se) is not LookupEmbedder or type(pe) is not LookupEmbedder:
+            return False
+        return not (self.training and (se.dropout.p > 0 or pe.dropout.p > 0))
+
+    def _w(self):
+        return (self.get_s_embedder()._embeddings.weight, self.get_p_embedder()._embeddings.weight)
+
+    def score_spo(self, s: Tensor, p: Tensor, o: Tensor, direction=None) -> Tensor:
+        if not self._fused():
+            return super().score_spo(s, p, o, direction)
+        ent, rel = self._w()
+        return _ScoreSPO.apply(self._scorer.name, self._scorer._norm, ent, rel, s, p, o)
+
+    def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
+        if not self._fused():
+            return super().score_sp(s, p, o)
+        ent, rel = self._w()
+        return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp", ent, rel, s, p, o)
+
+    def score_po(self, p: Tensor, o: Tensor, s: Tensor = None) -> Tensor:
+        if not self._fused():
+            return super().score_po(p, o, s)
+        ent, rel = self._w()
+        return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, s)
+
+    def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
+        if not self._fused():
+            return super().score_sp_po(s, p, o, entity_subset)
+        if not torch.is_grad_enabled():
+            ent, rel = self._w()
+            t = engine.Tables(self._scorer.name, ent.detach(), rel.detach(), self._scorer._norm)
+            return engine.score_sp_po(t, s, p, o, entity_subset)
+        return torch.cat((self.score_sp(s, p, entity_subset), self.score_po(p, o, entity_subset)), dim=1)
+
+
+def _init(self, scorer, config, dataset, configuration_key, init_for_load_only):
+    KgeModel.__init__(self, config=config, dataset=dataset, scorer=scorer,
+                      configuration_key=configuration_key, init_for_load_only=init_for_load_only)
+
+
+class HipComplEx(_FusedScoring, KgeModel):
+    def __init__(self, config: Config, dataset: Dataset, configuration_key=None, init_for_load_only=False):
+        _init(self, HipComplExScorer, config, dataset, configuration_key, init_for_load_only)
+
+
+class HipDistMult(_FusedScoring, KgeModel):
+    def __init__(self, config: Config, dataset: Dataset, configuration_key=None, init_for_load_only=False):
+        _init(self, HipDistMultScorer, config, dataset, configuration_key, init_for_load_only)
+
+
+class HipTransE(_FusedScoring, _RefTransE):
+    """Inherits prepare_job (forces negative_sampling.implementation=triple, transe.py:58-68)."""
+
+    def __init__(self, config: Config, dataset: Dataset, configuration_key=None, init_for_load_only=False):
+        _init(self, HipTransEScorer, config, dataset, configuration_key, init_for_load_only)
+
+
+class HipRotatE(_FusedScoring, _RefRotatE):
+    """Inherits normalize_phases / prepare_job (rotate.py:103-143); the constructor repeats
+    rotate.py:72-101 with the HIP scorer."""
+
+    def __init__(self, config: Config, dataset: Dataset, configuration_key=None, init_for_load_only=False):
+        self._init_configuration(config, configuration_key)
+        if self.get_option("entity_embedder.dim") % 2 != 0:
+            raise ValueError("RotatE requires embeddings of even dimensionality"
+                             " (got {})".format(self.get_option("entity_embedder.dim")))
+        if self.get_option("relation_embedder.dim") < 0:
+            self.set_option("relation_embedder.dim", self.get_option("entity_embedder.dim") // 2, log=True)
+        _init(self, HipRotatEScorer, config, dataset, self.configuration_key, init_for_load_only)
+        self._normalize_phases = self.get_option("normalize_phases")

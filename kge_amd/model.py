@@ -151,13 +151,15 @@ class KgeModel(torch.nn.Module):
     # -- scoring
     def score_spo(self, s: Tensor, p: Tensor, o: Tensor, direction=None) -> Tensor:
         if self._fused():
-            return _ScoreSPO.apply(self, self._entity_embedder.weight, self._relation_embedder.weight, s, p, o)
+            return _ScoreSPO.apply(self._scorer.name, self._scorer._norm, self._entity_embedder.weight,
+                                   self._relation_embedder.weight, s, p, o)
         se, pe, oe = self._entity_embedder.embed(s), self._relation_embedder.embed(p), self._entity_embedder.embed(o)
         return self._scorer.score_emb(se, pe, oe, combine="spo").view(-1)
 
     def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
         if self._fused():
-            return _ScorePairs.apply(self, "sp", self._entity_embedder.weight,
+            return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp",
+                                     self._entity_embedder.weight,
                                      self._relation_embedder.weight, s, p, o)
         se, pe = self._entity_embedder.embed(s), self._relation_embedder.embed(p)
         oe = self._entity_embedder.embed_all() if o is None else self._entity_embedder.embed(o)
@@ -165,7 +167,8 @@ class KgeModel(torch.nn.Module):
 
     def score_po(self, p: Tensor, o: Tensor, s: Tensor = None) -> Tensor:
         if self._fused():
-            return _ScorePairs.apply(self, "po", self._entity_embedder.weight,
+            return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po",
+                                     self._entity_embedder.weight,
                                      self._relation_embedder.weight, o, p, s)
         se = self._entity_embedder.embed_all() if s is None else self._entity_embedder.embed(s)
         oe, pe = self._entity_embedder.embed(o), self._relation_embedder.embed(p)
@@ -223,8 +226,8 @@ def _scatter_rows(grad_table, idx, rows):
 
 class _ScoreSPO(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, ent, rel, s, p, o):
-        t = engine.Tables(model._scorer.name, ent.detach(), rel.detach(), model._scorer._norm)
+    def forward(ctx, name, l_norm, ent, rel, s, p, o):
+        t = engine.Tables(name, ent.detach(), rel.detach(), l_norm)
         ctx.t, ctx.idx = t, (s, p, o)
         out = engine.score_spo(t, s, p, o)
         ctx.save_for_backward(out)
@@ -239,13 +242,13 @@ class _ScoreSPO(torch.autograd.Function):
         _scatter_rows(ge, s, g_s)
         _scatter_rows(ge, o, g_o)
         _scatter_rows(gr, p, g_p)
-        return None, ge, gr, None, None, None
+        return None, None, ge, gr, None, None, None
 
 
 class _ScorePairs(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, direction, ent, rel, a, p, targets):
-        t = engine.Tables(model._scorer.name, ent.detach(), rel.detach(), model._scorer._norm)
+    def forward(ctx, name, l_norm, direction, ent, rel, a, p, targets):
+        t = engine.Tables(name, ent.detach(), rel.detach(), l_norm)
         out = (engine.score_sp if direction == "sp" else engine.score_po)(t, *((a, p) if direction == "sp" else (p, a)), targets)
         ctx.t, ctx.direction, ctx.idx = t, direction, (a, p, targets)
         ctx.save_for_backward(out)
@@ -263,7 +266,7 @@ class _ScorePairs(torch.autograd.Function):
             ge += g_t
         else:
             _scatter_rows(ge, targets, g_t)
-        return None, None, ge, gr, None, None, None
+        return None, None, None, ge, gr, None, None, None
 
 
 class _ScoreEmb(torch.autograd.Function):

@@ -1,0 +1,71 @@
+"""LibKGE plugin plumbing (build container only: needs the reference tree).  The plugin is
+discovered through the reference's own mechanism (modules: + <name>.yaml + class_name),
+keeps its parameter names, and refuses to compute on job.device=cpu (no CPU fallback)."""
+import pytest
+import torch
+
+import ref_harness as rh
+
+pytestmark = pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+
+MODELS = ["hip_complex", "hip_distmult", "hip_transe", "hip_rotate"]
+
+
+def _config(model, dim=16):
+    rh.import_reference()
+    from kge import Config
+    config = Config()
+    config.folder = None
+    config.set("console.quiet", True)
+    config.set("modules", ["kge.job", "kge.model", "kge.model.embedder", "kge_amd.libkge_plugin"])
+    config.set("model", model)
+    config._import(model)
+    config.set("job.device", "cpu")
+    config.set_all({"lookup_embedder.dim": dim})
+    config.set("dataset.num_entities", 30)
+    config.set("dataset.num_relations", 4)
+    return config
+
+
+@pytest.mark.parametrize("model", MODELS)
+def test_plugin_is_discovered_and_keeps_parameter_names(model):
+    config = _config(model)
+    from kge import Dataset
+    from kge.model import KgeModel
+    import kge_amd.libkge_plugin as plugin
+    m = KgeModel.create(config, Dataset(config, folder=None))
+    assert type(m).__name__ == config.get(f"{model}.class_name")
+    assert isinstance(m, KgeModel) and isinstance(m, plugin.models._FusedScoring)
+    assert list(m.state_dict().keys()) == ["_entity_embedder._embeddings.weight",
+                                           "_relation_embedder._embeddings.weight"]
+    e, r = m.state_dict().values()
+    assert e.shape == (30, 16) and r.shape == (4, 8 if model == "hip_rotate" else 16)
+    assert m._fused()
+    s, p, o = torch.tensor([1, 2]), torch.tensor([0, 3]), torch.tensor([5, 6])
+    for call in (lambda: m.score_sp(s, p), lambda: m.score_po(p, o), lambda: m.score_spo(s, p, o),
+                 lambda: m.score_sp_po(s, p, o)):
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            call()
+
+
+def test_reference_checkpoint_state_loads_into_plugin_model():
+    """Same shapes/names: a reference model's state_dict loads into the plugin class."""
+    rh.import_reference()
+    ref = rh.make_model("complex", 30, 4, 16)
+    config = _config("hip_complex")
+    from kge import Dataset
+    from kge.model import KgeModel
+    m = KgeModel.create(config, Dataset(config, folder=None))
+    m.load_state_dict(ref.state_dict())
+    assert torch.equal(m.get_s_embedder()._embeddings.weight, ref.get_s_embedder()._embeddings.weight)
+
+
+def test_eval_job_plugin_resolves():
+    config = _config("hip_distmult")
+    config.set("eval.type", "hip_entity_ranking", create=True)
+    config._import("hip_entity_ranking")
+    assert config.get_default("hip_entity_ranking.class_name") == "HipEntityRankingJob"
+    from kge.misc import init_from  # noqa: F401
+    import kge_amd.libkge_plugin as plugin
+    from kge.job import EntityRankingJob
+    assert issubclass(plugin.HipEntityRankingJob, EntityRankingJob)
