@@ -122,7 +122,9 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
     with torch.cuda.device(t.device):
         tc = t.c(flags)
         fn = getattr(_lib.lib(), fn_name)
-        _lib.check(fn(ctypes.byref(tc), ai, pi, n, ti, m, out.data_ptr(), ldo,
+        # C signatures: kge_score_sp(t, s, p, ...) but kge_score_po(t, p, o, ...)
+        first, second = (ai, pi) if fn_name == "kge_score_sp" else (pi, ai)
+        _lib.check(fn(ctypes.byref(tc), first, second, n, ti, m, out.data_ptr(), ldo,
                       _stream(t.device)), fn_name)
     return out
 
