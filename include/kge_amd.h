@@ -97,8 +97,10 @@ typedef struct kge_tables {
 typedef enum kge_flags {
   KGE_FLAG_EXACT = 1,         /* ComplEx/DistMult on bf16 tables: use the bit-reproducible
                                  f32-chain kernel instead of the bf16 MFMA kernel            */
-  KGE_FLAG_NO_MFMA = 2        /* f32 ComplEx/DistMult: VALU fmaf chain instead of the f32
+  KGE_FLAG_NO_MFMA = 2,       /* f32 ComplEx/DistMult: VALU fmaf chain instead of the f32
                                  MFMA (same bits; used to cross-check the MFMA mapping)      */
+  KGE_FLAG_BF16_V1 = 4        /* bf16 ComplEx/DistMult: the tile-per-workgroup kernel (v1)
+                                 instead of the row-persistent kernel (A/B measurements)     */
 } kge_flags;
 
 /* An index vector: element i is ptr[i*stride] of type itype.

@@ -15,6 +15,11 @@ bool pairs_bf16_supported(int scorer, int dtype, int d, const Operand& A, const 
                           const Operand& TG);
 int run_pairs_bf16(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                    int d, long long n, long long m, float* out, long long ldo, hipStream_t st);
+bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
+                             const Operand& TG);
+int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
+                      int d, long long n, long long m, float* out, long long ldo,
+                      hipStream_t st);
 int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
              long long col_offset, const long long* true_col, float atol, float rtol,
@@ -72,8 +77,12 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
                    const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo,
                    hipStream_t st) {
   const int d = (int)t->dim, dr = (int)t->rel_dim;
-  if (!(t->flags & KGE_FLAG_EXACT) && pairs_bf16_supported(t->scorer, t->dtype, d, A, R, TG))
-    return run_pairs_bf16(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
+  if (!(t->flags & KGE_FLAG_EXACT)) {
+    if (!(t->flags & KGE_FLAG_BF16_V1) && pairs_bf16_v2_supported(t->scorer, t->dtype, d, A, R, TG))
+      return run_pairs_bf16_v2(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
+    if (pairs_bf16_supported(t->scorer, t->dtype, d, A, R, TG))
+      return run_pairs_bf16(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
+  }
   const bool mfma = !(t->flags & KGE_FLAG_NO_MFMA);
   return run_pairs_exact(t->scorer, t->dtype, mfma, A, R, TG, dir, d, dr, n, m, t->l_norm, out,
                          ldo, st);

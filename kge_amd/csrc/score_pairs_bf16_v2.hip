@@ -1,0 +1,293 @@
+// score_pairs_bf16_v2.hip -- "row-persistent" ComplEx / DistMult sp_/_po kernel for bf16
+// tables, d in {128, 256, 512}: the BASELINE.json headline path on gfx950.
+//
+// v1 (score_pairs_bf16.hip) walks K in 8 dependent load->barrier->MFMA stages per tile and
+// rebuilds the query tile for every target tile: latency bound (29.5 us at C2).  Here:
+//
+//   * a workgroup = 4 waves owns 128 query rows (32 per wave) and a contiguous RANGE of
+//     target tiles; it builds the bf16 query fragments q = s (x) r ONCE, for the whole
+//     reduction dimension, directly in MFMA A-operand registers (d=512: 32 K-blocks x 4
+//     VGPRs = 128 VGPRs per lane), and keeps them for every target tile;
+//   * the gather of the s / r rows is staged through LDS in 128-byte segments (full cache
+//     lines: two rows x four row-halves per wave-instruction) and re-read in fragment
+//     shape with an XOR swizzle (conflict-free ds_read_b128);
+//   * target tiles (32 rows x d bf16) stream HBM -> LDS by LDS-DMA (global_load_lds, 16 B per
+//     lane, no VGPRs) through a 3-deep LDS ring, two tiles ahead, ONE raw s_barrier per tile
+//     and a COUNTED s_waitcnt vmcnt(40): the in-order VMEM counter also counts the 16 score
+//     stores of each tile, so every wave issues exactly 8 DMA ops + 16 stores per tile
+//     (row / column tails are clamped, never predicated: a clamped lane recomputes and
+//     rewrites the bits of the last valid row / column) and stores are never waited for;
+//     the MFMA loop per tile is 32 v_mfma_f32_32x32x16_bf16 with the B operand from LDS
+//     (XOR swizzle applied on the DMA source address, the LDS image is lane-linear);
+//   * 1-D XCD-aware grid: all row groups of a target range run on the same XCD (block id
+//     mod 8), so each XCD pulls its 1/8 of the table through its own L2 once.
+//
+// K-block <-> data: block kb < HH/16 holds first-half coordinates [16kb, 16kb+16) (lane half
+// h = lane>>5 holds 8 of them), block HH/16+kb the same coordinates of the second half;
+// A and B fragments use the same map, so the contraction is over all d coordinates.
+#include "common.hpp"
+
+namespace kge {
+
+constexpr int V2_ROWS = 128, V2_TN = 32;
+
+__device__ __forceinline__ unsigned int v2_pack(float lo, float hi) {
+  unsigned int r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// two coordinates per dword: (a0,a1) entity halves, (r0,r1) relation halves -> (q0,q1)
+template <int SCORER>
+__device__ __forceinline__ void v2_qpair(int dir, unsigned int a0, unsigned int a1,
+                                         unsigned int r0, unsigned int r1, unsigned int& q0,
+                                         unsigned int& q1) {
+  const float a0l = __uint_as_float(a0 << 16), a0h = __uint_as_float(a0 & 0xffff0000u);
+  const float a1l = __uint_as_float(a1 << 16), a1h = __uint_as_float(a1 & 0xffff0000u);
+  const float r0l = __uint_as_float(r0 << 16), r0h = __uint_as_float(r0 & 0xffff0000u);
+  const float r1l = __uint_as_float(r1 << 16), r1h = __uint_as_float(r1 & 0xffff0000u);
+  float q0l, q0h, q1l, q1h;
+  if (SCORER == KGE_DISTMULT) {
+    q0l = a0l * r0l; q0h = a0h * r0h; q1l = a1l * r1l; q1h = a1h * r1h;
+  } else if (dir == KGE_SP_) {
+    q0l = a0l * r0l - a1l * r1l; q0h = a0h * r0h - a1h * r1h;
+    q1l = a1l * r0l + a0l * r1l; q1h = a1h * r0h + a0h * r1h;
+  } else {
+    q0l = r0l * a0l + r1l * a1l; q0h = r0h * a0h + r1h * a1h;
+    q1l = r0l * a1l - r1l * a0l; q1h = r0h * a1h - r1h * a0h;
+  }
+  q0 = v2_pack(q0l, q0h);
+  q1 = v2_pack(q1l, q1h);
+}
+
+__device__ __forceinline__ long long shfl64(long long v, int src) {
+  int lo = __shfl((int)(v & 0xffffffffLL), src, 64);
+  int hi = __shfl((int)(v >> 32), src, 64);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+// row index through an index vector; MODE 0 = identity, 1 = int32, 2 = int64 (no branches)
+template <int MODE>
+__device__ __forceinline__ long long v2_index(const Index& ix, long long i) {
+  if (MODE == 0) return i;
+  if (MODE == 1) return (long long)((const int*)ix.ptr)[i * ix.stride];
+  return ((const long long*)ix.ptr)[i * ix.stride];
+}
+
+template <int SCORER, int HH, int TGMODE>
+__global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
+    Operand A, Operand R, Operand TG, int dir, long long n, long long m, int rgn, int ncg,
+    int tiles_per_cg, int ntiles, float* __restrict__ out, long long ldo) {
+  constexpr int NKB = 2 * HH / 16;        // K-blocks of 16
+  constexpr int NKH = HH / 16;            // K-blocks per half
+  constexpr int ROWB = 4 * HH;            // bytes per table row (2*HH bf16)
+  constexpr int SPR = HH / 4;             // 16-byte slots per row
+  constexpr int TILEB = V2_TN * ROWB;     // bytes per target tile
+  constexpr int NL = TILEB / 16 / 256;    // 16-byte loads per thread per tile
+  constexpr int PASSES = HH / 64;         // prologue passes of 64 coordinates
+  constexpr int STAGE = 4 * 16384;        // prologue staging: 16 KiB per wave
+  constexpr int SMEM = 2 * TILEB + ((TILEB > STAGE) ? TILEB : STAGE);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+  // ---- which rows / target tiles
+  const int b = blockIdx.x;
+  const int q8 = b >> 3;
+  const int rg = q8 % rgn;
+  const int cg = (q8 / rgn) * 8 + (b & 7);
+  if (cg >= ncg) return;
+  const int tile_lo = cg * tiles_per_cg;
+  int ntl = ntiles - tile_lo;
+  if (ntl > tiles_per_cg) ntl = tiles_per_cg;
+  if (ntl <= 0) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fi = lane & 31, fh = lane >> 5;
+  const long long row0 = (long long)rg * V2_ROWS + 32 * wave;
+  const unsigned short* tgb = (const unsigned short*)TG.base;
+
+  // ---- target tile DMA (HBM -> LDS, no registers), issued two tiles ahead
+  auto tile_dma = [&](int tt, int buf) {
+    if (tt >= ntl) tt = ntl - 1;  // keep the VMEM op count per step constant (see header)
+    long long ridx[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int L = (wave * NL + k) * 64 + lane;  // linear 16-B slot of the tile image
+      long long tr = (long long)(tile_lo + tt) * V2_TN + L / SPR;
+      if (tr >= m) tr = m - 1;
+      ridx[k] = v2_index<TGMODE>(TG.idx, tr);
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int L = (wave * NL + k) * 64 + lane;
+      const int row = L / SPR, slot = L % SPR;
+      const unsigned short* src = tgb + ridx[k] * TG.ld + ((slot ^ (row & 15)) << 3);
+      unsigned char* dst = smem + buf * TILEB + (wave * NL + k) * 1024;  // wave-uniform
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  tile_dma(0, 0);
+  tile_dma(1, 1);
+
+  // ---- prologue: build the query fragments of this wave's 32 rows in registers
+  bf16x8 afr[NKB];
+  {
+    long long qrow = row0 + fi;
+    if (qrow >= n) qrow = n - 1;
+    const long long aoff = index_at(A.idx, qrow) * A.ld;  // element offsets of row `fi`
+    const long long roff = index_at(R.idx, qrow) * R.ld;
+    unsigned char* stage = smem + 2 * TILEB + wave * 16384;  // free until tile 2 is issued
+    const int arr = (lane >> 3) & 3, sslot = lane & 7;
+    const unsigned short* ab = (const unsigned short*)A.base;
+    const unsigned short* rb = (const unsigned short*)R.base;
+    u32x4 g[16];
+    auto gather = [&](int p) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int rr = 2 * k + fh;  // row of this wave served by this lane in load k
+        const long long ao = shfl64(aoff, rr), ro = shfl64(roff, rr);
+        const unsigned short* base = (arr < 2) ? ab + ao : rb + ro;
+        g[k] = *reinterpret_cast<const u32x4*>(base + (arr & 1) * HH + (8 * p + sslot) * 8);
+      }
+    };
+    gather(0);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int rr = 2 * k + fh;
+        *reinterpret_cast<u32x4*>(stage + rr * 512 + (((lane & 31) ^ (rr & 15)) << 4)) = g[k];
+      }
+      __syncthreads();
+      if (p + 1 < PASSES) gather(p + 1);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        u32x4 v[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int p5 = a * 8 + 2 * jj + fh;
+          v[a] = *reinterpret_cast<const u32x4*>(stage + fi * 512 + ((p5 ^ (fi & 15)) << 4));
+        }
+        u32x4 q0, q1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned int x0, x1;
+          v2_qpair<SCORER>(dir, v[0][e], v[1][e], v[2][e], v[3][e], x0, x1);
+          q0[e] = x0;
+          q1[e] = x1;
+        }
+        afr[4 * p + jj] = __builtin_bit_cast(bf16x8, q0);
+        afr[NKH + 4 * p + jj] = __builtin_bit_cast(bf16x8, q1);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- main loop over this workgroup's target tiles
+  unsigned int boff[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) boff[t] = (unsigned int)(((2 * t + fh) ^ (fi & 15)) << 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tiles 0 and 1 have landed
+  for (int tt = 0; tt < ntl; ++tt) {
+    // newer than tile tt's DMA: stores(tt-2) 16 + DMA(tt+1) 8 + stores(tt-1) 16
+    asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // tile tt visible to all; everyone finished tile tt-1
+    __builtin_amdgcn_sched_barrier(0);
+    tile_dma(tt + 2, (tt + 2) % 3);
+    // B fragment of K-block kb sits at 16-B slot s = s0(kb) + fh of target row fi, stored at
+    // slot s ^ (fi & 15): with s = 16*a + b the swizzle only touches b, so the address is
+    // (per-lane base for b) + immediate a*256 -- 8 address registers instead of 32.
+    const unsigned int bt = (unsigned int)((tt % 3) * TILEB + fi * ROWB);
+    unsigned int bp[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bp[t] = bt + boff[t];
+    auto bfrag = [&](int kb) {
+      const int s0 = (kb < NKH) ? (2 * kb) : (HH / 8 + 2 * (kb - NKH));
+      return *reinterpret_cast<const bf16x8*>(smem + bp[(s0 & 15) >> 1] + (s0 >> 4) * 256);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // software pipeline: PF ds_read_b128 in flight ahead of the MFMA chain
+    constexpr int PF = (NKB < 8) ? NKB : 8;
+    bf16x8 bq[PF];
+#pragma unroll
+    for (int kb = 0; kb < PF; ++kb) bq[kb] = bfrag(kb);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kb], bq[kb % PF], acc, 0, 0, 0);
+      if (kb + PF < NKB) bq[kb % PF] = bfrag(kb + PF);
+    }
+    // pin the interleave: PF reads up front, then one read behind every MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (kb + PF < NKB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    // tails are clamped, not predicated: a clamped lane holds the bits of the last valid
+    // row / column (its query / target row was clamped the same way) and rewrites them.
+    long long ocol = (long long)(tile_lo + tt) * V2_TN + fi;
+    if (ocol >= m) ocol = m - 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      long long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      if (orow >= n) orow = n - 1;
+      out[orow * ldo + ocol] = acc[r];
+    }
+  }
+}
+
+static inline bool v2_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
+                             const Operand& TG) {
+  if (dtype != KGE_BF16) return false;
+  if (scorer != KGE_COMPLEX && scorer != KGE_DISTMULT) return false;
+  if (d != 128 && d != 256 && d != 512) return false;
+  if (!v2_al16(A.base) || !v2_al16(R.base) || !v2_al16(TG.base)) return false;
+  if ((A.ld % 8) || (R.ld % 8) || (TG.ld % 8)) return false;
+  return true;
+}
+
+template <int SCORER, int HH>
+static int launch_v2(const Operand& A, const Operand& R, const Operand& TG, int dir, long long n,
+                     long long m, float* out, long long ldo, hipStream_t st) {
+  const int rgn = (int)((n + V2_ROWS - 1) / V2_ROWS);
+  const int ntiles = (int)((m + V2_TN - 1) / V2_TN);
+  // one workgroup per CU (256 CUs): split the target tiles into column groups
+  int ncg = 256 / rgn;
+  if (ncg < 1) ncg = 1;
+  int tpc = (ntiles + ncg - 1) / ncg;
+  if (tpc < 1) tpc = 1;
+  ncg = (ntiles + tpc - 1) / tpc;
+  const int grid = 8 * rgn * ((ncg + 7) / 8);
+  const int tgmode = TG.idx.ptr == nullptr ? 0 : (TG.idx.itype ? 2 : 1);
+#define KGE_V2L(MODE)                                                                          \
+  hipLaunchKernelGGL((pairs_bf16_v2_kernel<SCORER, HH, MODE>), dim3(grid), dim3(256), 0, st, A, \
+                     R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo)
+  if (tgmode == 0) KGE_V2L(0);
+  else if (tgmode == 1) KGE_V2L(1);
+  else KGE_V2L(2);
+#undef KGE_V2L
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
+                      int d, long long n, long long m, float* out, long long ldo,
+                      hipStream_t st) {
+  if (n == 0 || m == 0) return KGE_OK;
+#define KGE_V2(SC)                                                                   \
+  switch (d) {                                                                       \
+    case 128: return launch_v2<SC, 64>(A, R, TG, dir, n, m, out, ldo, st);           \
+    case 256: return launch_v2<SC, 128>(A, R, TG, dir, n, m, out, ldo, st);          \
+    case 512: return launch_v2<SC, 256>(A, R, TG, dir, n, m, out, ldo, st);          \
+  }
+  if (scorer == KGE_COMPLEX) { KGE_V2(KGE_COMPLEX) } else { KGE_V2(KGE_DISTMULT) }
+#undef KGE_V2
+  return KGE_ERR_UNSUPPORTED;
+}
+
+}  // namespace kge

@@ -203,8 +203,27 @@ def test_bf16_mfma_kernel_vs_oracle(eng, model, d):
     _close("sp_all", _np(eng.score_sp(T, ts, tp)), ko.score_sp(O, s, p))
     _close("po_all", _np(eng.score_po(T, tp, to)), ko.score_po(O, p, o))
     _close("sp_po_sub", _np(eng.score_sp_po(T, ts, tp, to, _t(sub))), ko.score_sp_po(O, s, p, o, sub))
+    _close("sp_sub_i32", _np(eng.score_sp(T, ts.int(), tp.int(), _t(sub).int())), ko.score_sp(O, s, p, sub))
+    # the tile-per-workgroup kernel (v1) computes the same thing
+    _close("v1 sp_all", _np(eng.score_sp(T, ts, tp, flags=eng.FLAG_BF16_V1)), ko.score_sp(O, s, p))
+    _close("v1 po_sub", _np(eng.score_po(T, tp, to, _t(sub), flags=eng.FLAG_BF16_V1)), ko.score_po(O, p, o, sub))
     # and its bit-exact twin computes the same semantics
     _eq("exact twin", _np(eng.score_sp(T, ts, tp, flags=eng.FLAG_EXACT)), ko.score_sp(O, s, p))
+
+
+def test_bf16_mfma_kernel_small_and_single_row(eng):
+    """n = 1 and n < 32, m < 32: every tail path of the row-persistent kernel."""
+    rng = np.random.default_rng(5)
+    E, R, d = 70, 3, 512
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    T = _gpu_tables(eng, "complex", ent, rel, 1.0, bf16=True)
+    O = _oracle_tables("complex", ent, rel, 1.0, bf16=True)
+    for n, msub in ((1, None), (5, 7), (33, 1)):
+        s, p = rng.integers(0, E, n), rng.integers(0, R, n)
+        sub = None if msub is None else rng.permutation(E)[:msub]
+        got = _np(eng.score_sp(T, _t(s), _t(p), None if sub is None else _t(sub)))
+        _close(f"n={n}", got, ko.score_sp(O, s, p, sub))
 
 
 @pytest.mark.parametrize("model", ["complex", "distmult", "transe", "rotate"])

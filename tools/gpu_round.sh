@@ -7,8 +7,6 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import torch;print(torch.cuda.get_device_name(0), torch.version.hip)" > $OUT/env.log 2>&1
-timeout 900 python -m pytest tests -m gpu -q -x --timeout=600 > $OUT/pytest_x.log 2>&1
-echo "pytest -x exit: $?" >> $OUT/env.log
 timeout 1200 python -m pytest tests -m gpu -q --timeout=600 > $OUT/pytest_all.log 2>&1
 echo "pytest all exit: $?" >> $OUT/env.log
 timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
@@ -19,6 +17,10 @@ timeout 900 python tools/perf_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err
 echo "probe exit: $?" >> $OUT/env.log
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err )
 echo "rocprof exit: $?" >> $OUT/env.log
+for C in FETCH_SIZE WRITE_SIZE; do
+( cd /tmp && timeout 300 rocprofv3 --pmc $C -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err )
+echo "pmc $C exit: $?" >> $OUT/env.log
+done
 find $OUT/prof -name "*stats*" | head >> $OUT/env.log
 tail -5 $OUT/pytest_all.log
 cat $OUT/env.log

@@ -41,12 +41,24 @@ def emit(**kw):
 
 def main():
     q = torch.Generator().manual_seed(1)
+    # ---- reference points: plain HBM write / copy of the score-matrix size (torch kernels)
+    x = torch.empty(512, 14541, device=dev)
+    y = torch.empty_like(x)
+    med, mn, avg = timeit(lambda: x.fill_(1.0))
+    emit(kernel="torch.fill_ 29.8MB", us_med=med, us_min=mn, gbs=x.numel() * 4 / med / 1e3)
+    med, mn, avg = timeit(lambda: y.copy_(x))
+    emit(kernel="torch.copy_ 29.8MB", us_med=med, us_min=mn, gbs=2 * x.numel() * 4 / med / 1e3)
+    big = torch.empty(64 * 1024 * 1024, device=dev)
+    med, mn, avg = timeit(lambda: big.fill_(1.0))
+    emit(kernel="torch.fill_ 256MB", us_med=med, us_min=mn, gbs=big.numel() * 4 / med / 1e3)
+    del x, y, big
     # ---- pair kernels (sp_) at FB15k-237 shape
     E, R, d = 14541, 237, 512
     for n in (128, 512, 1024):
         s = torch.randint(E, (n,), generator=q).to(dev); p = torch.randint(R, (n,), generator=q).to(dev)
         for model, dtype, flags, tag in [
             ("complex", torch.bfloat16, 0, "bf16-mfma"),
+            ("complex", torch.bfloat16, engine.FLAG_BF16_V1, "bf16-mfma-v1"),
             ("distmult", torch.bfloat16, 0, "bf16-mfma"),
             ("complex", torch.bfloat16, engine.FLAG_EXACT, "bf16-exact-f32mfma"),
             ("complex", torch.float32, 0, "f32-mfma"),
@@ -54,7 +66,7 @@ def main():
             ("transe", torch.float32, 0, "f32-valu"),
             ("rotate", torch.float32, 0, "f32-valu"),
         ]:
-            if n != 512 and tag not in ("bf16-mfma",):
+            if n != 512 and tag not in ("bf16-mfma", "bf16-mfma-v1"):
                 continue
             T = tables(model, E, R, d, dtype)
             med, mn, avg = timeit(lambda: engine.score_sp(T, s, p, flags=flags))
