@@ -59,8 +59,8 @@ int check_tables(const kge_tables* t, bool need_ptrs) {
   return KGE_OK;
 }
 
-int check_index(const kge_index& ix, bool allow_null) {
-  if (!ix.ptr) return allow_null ? KGE_OK : KGE_ERR_INVALID_ARG;
+int check_index(const kge_index& ix, bool allow_null, int64_t len = 1) {
+  if (!ix.ptr) return (allow_null || len == 0) ? KGE_OK : KGE_ERR_INVALID_ARG;
   if (ix.itype != KGE_I32 && ix.itype != KGE_I64) return KGE_ERR_INVALID_ARG;
   if (ix.stride < 1) return KGE_ERR_INVALID_ARG;
   return KGE_OK;
@@ -93,6 +93,7 @@ int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (n < 0 || m < 0 || (!out && n * m > 0) || ldo < m) return KGE_ERR_INVALID_ARG;
+  if (n == 0 || m == 0) return KGE_OK;  // empty batch / empty subset: nothing to score
   if ((rc = check_index(a, false)) || (rc = check_index(p, false)) ||
       (rc = check_index(targets, true)))
     return rc;
@@ -133,6 +134,7 @@ int kge_score_spo(const kge_tables* t, kge_index s, kge_index p, kge_index o, in
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (n < 0 || (!out && n > 0)) return KGE_ERR_INVALID_ARG;
+  if (n == 0) return KGE_OK;
   if ((rc = check_index(s, false)) || (rc = check_index(p, false)) ||
       (rc = check_index(o, false)))
     return rc;
@@ -168,6 +170,7 @@ int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o, in
   if (n * num_neg > 0 && (!out || !neg)) return KGE_ERR_INVALID_ARG;
   if (neg_ld < num_neg || ldo < num_neg) return KGE_ERR_INVALID_ARG;
   if (neg_itype != KGE_I32 && neg_itype != KGE_I64) return KGE_ERR_INVALID_ARG;
+  if (n == 0 || num_neg == 0) return KGE_OK;
   if (n > 65535) return KGE_ERR_UNSUPPORTED;  // grid.y; callers sub-batch far below this
   if ((rc = check_index(s, false)) || (rc = check_index(p, false)) ||
       (rc = check_index(o, false)))

@@ -13,12 +13,14 @@
 //     shape with an XOR swizzle (conflict-free ds_read_b128);
 //   * target tiles (32 rows x d bf16) stream HBM -> LDS by LDS-DMA (global_load_lds, 16 B per
 //     lane, no VGPRs) through a 3-deep LDS ring, two tiles ahead, ONE raw s_barrier per tile
-//     and a COUNTED s_waitcnt vmcnt(40): the in-order VMEM counter also counts the 16 score
-//     stores of each tile, so every wave issues exactly 8 DMA ops + 16 stores per tile
-//     (row / column tails are clamped, never predicated: a clamped lane recomputes and
-//     rewrites the bits of the last valid row / column) and stores are never waited for;
-//     the MFMA loop per tile is 32 v_mfma_f32_32x32x16_bf16 with the B operand from LDS
-//     (XOR swizzle applied on the DMA source address, the LDS image is lane-linear);
+//     and a COUNTED s_waitcnt vmcnt(16): the in-order VMEM counter also counts the score
+//     stores of each tile, so every wave issues exactly 8 DMA ops + 4 stores per full tile
+//     (row tails are clamped, never predicated: a clamped lane recomputes and rewrites the
+//     bits of the last valid row) and stores are never waited for;
+//   * per tile 32 v_mfma_f32_32x32x16_bf16 with the TARGET fragment (from LDS, XOR swizzle
+//     applied on the DMA source address, lane-linear LDS image) as the "A" operand and the
+//     query fragment as "B": each lane then owns 4 x 4 consecutive targets of one query row
+//     and writes them with 16-byte stores (dword stores are issue-bound: 1.3 us per tile);
 //   * 1-D XCD-aware grid: all row groups of a target range run on the same XCD (block id
 //     mod 8), so each XCD pulls its 1/8 of the table through its own L2 once.
 //
@@ -30,6 +32,7 @@
 namespace kge {
 
 constexpr int V2_ROWS = 128, V2_TN = 32;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 __device__ __forceinline__ unsigned int v2_pack(float lo, float hi) {
   unsigned int r;
@@ -85,8 +88,9 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   constexpr int TILEB = V2_TN * ROWB;     // bytes per target tile
   constexpr int NL = TILEB / 16 / 256;    // 16-byte loads per thread per tile
   constexpr int PASSES = HH / 64;         // prologue passes of 64 coordinates
-  constexpr int STAGE = 4 * 16384;        // prologue staging: 16 KiB per wave
-  constexpr int SMEM = 2 * TILEB + ((TILEB > STAGE) ? TILEB : STAGE);
+  constexpr int STAGE = 4 * 16384;        // one prologue staging slot: 16 KiB per wave
+  constexpr int STG0 = TILEB;             // two slots behind ring buffer 0
+  constexpr int SMEM = (3 * TILEB > STG0 + 2 * STAGE) ? 3 * TILEB : STG0 + 2 * STAGE;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
   // ---- which rows / target tiles
@@ -128,47 +132,45 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
     }
   };
 
-  tile_dma(0, 0);
-  tile_dma(1, 1);
-
-  // ---- prologue: build the query fragments of this wave's 32 rows in registers
+  // ---- prologue: build the query fragments of this wave's 32 rows in registers.
+  // The s / r rows are gathered by LDS-DMA (no registers) into a wave-private staging area,
+  // two passes (of 64 coordinates) in flight; the in-order VMEM counter is waited with
+  // counted vmcnt: issue order G0, G1, T0, then G(p+2) after pass p is consumed.
   bf16x8 afr[NKB];
   {
     long long qrow = row0 + fi;
     if (qrow >= n) qrow = n - 1;
     const long long aoff = index_at(A.idx, qrow) * A.ld;  // element offsets of row `fi`
     const long long roff = index_at(R.idx, qrow) * R.ld;
-    unsigned char* stage = smem + 2 * TILEB + wave * 16384;  // free until tile 2 is issued
-    const int arr = (lane >> 3) & 3, sslot = lane & 7;
     const unsigned short* ab = (const unsigned short*)A.base;
     const unsigned short* rb = (const unsigned short*)R.base;
-    u32x4 g[16];
+    // source pointer of DMA instruction k: row rr = 2k + fh, LDS slot (lane & 31) holds the
+    // logical slot p5 = (lane & 31) ^ (rr & 15) = array (p5 >> 3), 16-B chunk (p5 & 7)
+    const unsigned short* gsrc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int rr = 2 * k + fh;
+      const int p5 = (lane & 31) ^ (rr & 15);
+      const long long ao = shfl64(aoff, rr), ro = shfl64(roff, rr);
+      gsrc[k] = ((p5 < 16) ? ab + ao : rb + ro) + ((p5 >> 3) & 1) * HH + (p5 & 7) * 8;
+    }
     auto gather = [&](int p) {
+      unsigned char* dst = smem + STG0 + (p & 1) * STAGE + wave * 16384;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int rr = 2 * k + fh;  // row of this wave served by this lane in load k
-        const long long ao = shfl64(aoff, rr), ro = shfl64(roff, rr);
-        const unsigned short* base = (arr < 2) ? ab + ao : rb + ro;
-        g[k] = *reinterpret_cast<const u32x4*>(base + (arr & 1) * HH + (8 * p + sslot) * 8);
-      }
+      for (int k = 0; k < 16; ++k)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(gsrc[k] + 64 * p),
+            (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, 0, 0);
     };
-    gather(0);
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int rr = 2 * k + fh;
-        *reinterpret_cast<u32x4*>(stage + rr * 512 + (((lane & 31) ^ (rr & 15)) << 4)) = g[k];
-      }
-      __syncthreads();
-      if (p + 1 < PASSES) gather(p + 1);
+    auto build = [&](int p) {
+      const unsigned char* stage = smem + STG0 + (p & 1) * STAGE + wave * 16384 + fi * 512;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         u32x4 v[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int p5 = a * 8 + 2 * jj + fh;
-          v[a] = *reinterpret_cast<const u32x4*>(stage + fi * 512 + ((p5 ^ (fi & 15)) << 4));
+          v[a] = *reinterpret_cast<const u32x4*>(stage + ((p5 ^ (fi & 15)) << 4));
         }
         u32x4 q0, q1;
 #pragma unroll
@@ -181,18 +183,51 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
         afr[4 * p + jj] = __builtin_bit_cast(bf16x8, q0);
         afr[NKH + 4 * p + jj] = __builtin_bit_cast(bf16x8, q1);
       }
-      __syncthreads();
+    };
+    gather(0);
+    if (PASSES > 1) gather(1);
+    tile_dma(0, 0);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      // ops newer than G_p: G_{p+1} (16) if it exists, T0 (8) for p < 2
+      constexpr int T0N = 8;
+      if (p + 1 < PASSES) {
+        if (p < 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else {
+        if (p < 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      (void)T0N;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      build(p);
+      // the staging slot of pass p is free again once this wave's reads have returned
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 2 < PASSES) gather(p + 2);
     }
   }
+  // staging overlaps ring buffers 1 and 2: everyone must be done before tile 1 streams in
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  tile_dma(1, 1);
 
   // ---- main loop over this workgroup's target tiles
   unsigned int boff[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) boff[t] = (unsigned int)(((2 * t + fh) ^ (fi & 15)) << 4);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tiles 0 and 1 have landed
+  // this lane's output row (query row0 + fi; clamped rows rewrite the bits of row n-1)
+  long long orow = row0 + fi;
+  if (orow >= n) orow = n - 1;
+  float* const orow_ptr = out + orow * ldo;
   for (int tt = 0; tt < ntl; ++tt) {
-    // newer than tile tt's DMA: stores(tt-2) 16 + DMA(tt+1) 8 + stores(tt-1) 16
-    asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    // newer than tile tt's DMA: stores(tt-2) 4 + DMA(tt+1) 8 + stores(tt-1) 4 = 16 in steady
+    // state; tile 0 landed before the barrier above; at tt == 1: DMA(2) 8 + stores(0) 4.
+    if (tt == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // tile tt visible to all; everyone finished tile tt-1
     __builtin_amdgcn_sched_barrier(0);
     tile_dma(tt + 2, (tt + 2) % 3);
@@ -210,14 +245,16 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    // software pipeline: PF ds_read_b128 in flight ahead of the MFMA chain
+    // software pipeline: PF ds_read_b128 in flight ahead of the MFMA chain.  The TARGET
+    // fragment is the MFMA "A" operand and the query fragment the "B" operand, so the
+    // accumulator holds, for query row fi, 4 x 4 CONSECUTIVE targets: 16-byte stores.
     constexpr int PF = (NKB < 8) ? NKB : 8;
     bf16x8 bq[PF];
 #pragma unroll
     for (int kb = 0; kb < PF; ++kb) bq[kb] = bfrag(kb);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kb], bq[kb % PF], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[kb % PF], afr[kb], acc, 0, 0, 0);
       if (kb + PF < NKB) bq[kb % PF] = bfrag(kb + PF);
     }
     // pin the interleave: PF reads up front, then one read behind every MFMA
@@ -227,15 +264,22 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       if (kb + PF < NKB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    // tails are clamped, not predicated: a clamped lane holds the bits of the last valid
-    // row / column (its query / target row was clamped the same way) and rewrites them.
-    long long ocol = (long long)(tile_lo + tt) * V2_TN + fi;
-    if (ocol >= m) ocol = m - 1;
+    // acc[4g + e] = score(query fi, target col0 + 8g + 4fh + e)
+    const long long col0 = (long long)(tile_lo + tt) * V2_TN;
+    if (col0 + V2_TN <= m) {  // wave-uniform: full tile -> 4 x 16-byte stores per lane
+      float* p = orow_ptr + col0 + 4 * fh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      long long orow = row0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-      if (orow >= n) orow = n - 1;
-      out[orow * ldo + ocol] = acc[r];
+      for (int g = 0; g < 4; ++g) {
+        f32x4u v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        *reinterpret_cast<f32x4u*>(p + 8 * g) = v;
+      }
+    } else {  // ragged last tile of the table: scalar stores, clamped to column m-1
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        long long oc = col0 + 8 * (r >> 2) + 4 * fh + (r & 3);
+        if (oc >= m) oc = m - 1;
+        orow_ptr[oc] = acc[r];
+      }
     }
   }
 }
