@@ -19,7 +19,7 @@ bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, con
                              const Operand& TG);
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
-                      hipStream_t st);
+                      hipStream_t st, unsigned long long* dbg = nullptr);
 int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
              long long col_offset, const long long* true_col, float atol, float rtol,
@@ -272,6 +272,20 @@ int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64
     return run_pairs_bwd(t->scorer, t->l_norm, KGE_PO_, O, P, S, d, dr, n, m, gout, ldg, scores,
                          lds, g_o, g_p, g_s, st);
   return KGE_ERR_INVALID_ARG;
+}
+
+// Not part of the public ABI (include/kge_amd.h): the row-persistent bf16 kernel with a
+// per-workgroup timestamp buffer (64 x u64 per workgroup) for tools/v2_phases.py.
+int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, int64_t n,
+                               int64_t m, float* out, int64_t ldo, unsigned long long* stamps,
+                               void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  kge_index all{nullptr, KGE_I64, 0, 1};
+  Operand A = ent_op(t, s), R = rel_op(t, p), TG = ent_op(t, all);
+  if (!pairs_bf16_v2_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) return KGE_ERR_UNSUPPORTED;
+  return run_pairs_bf16_v2(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
+                           (hipStream_t)stream, stamps);
 }
 
 }  // extern "C"

@@ -80,13 +80,14 @@ __device__ __forceinline__ long long v2_index(const Index& ix, long long i) {
 template <int SCORER, int HH, int TGMODE>
 __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
     Operand A, Operand R, Operand TG, int dir, long long n, long long m, int rgn, int ncg,
-    int tiles_per_cg, int ntiles, float* __restrict__ out, long long ldo) {
+    int tiles_per_cg, int ntiles, float* __restrict__ out, long long ldo,
+    unsigned long long* __restrict__ dbg) {
   constexpr int NKB = 2 * HH / 16;        // K-blocks of 16
   constexpr int NKH = HH / 16;            // K-blocks per half
   constexpr int ROWB = 4 * HH;            // bytes per table row (2*HH bf16)
   constexpr int SPR = HH / 4;             // 16-byte slots per row
   constexpr int TILEB = V2_TN * ROWB;     // bytes per target tile
-  constexpr int NL = TILEB / 16 / 256;    // 16-byte loads per thread per tile
+  constexpr int NL = TILEB / 16 / 256;    // 16-byte DMA ops per wave-lane per tile
   constexpr int PASSES = HH / 64;         // prologue passes of 64 coordinates
   constexpr int STAGE = 4 * 16384;        // one prologue staging slot: 16 KiB per wave
   constexpr int STG0 = TILEB;             // two slots behind ring buffer 0
@@ -104,38 +105,57 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   if (ntl > tiles_per_cg) ntl = tiles_per_cg;
   if (ntl <= 0) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR)
   const int fi = lane & 31, fh = lane >> 5;
   const long long row0 = (long long)rg * V2_ROWS + 32 * wave;
   const unsigned short* tgb = (const unsigned short*)TG.base;
 
-  // ---- target tile DMA (HBM -> LDS, no registers), issued two tiles ahead
-  auto tile_dma = [&](int tt, int buf) {
+  int dbg_i = 0;
+  auto stamp = [&]() {  // optional per-phase timestamps (tools/v2_phases.py); dbg == NULL in production
+    if (dbg != nullptr && tid == 0 && dbg_i < 64)
+      dbg[(long long)blockIdx.x * 64 + dbg_i] = __builtin_readcyclecounter();
+    ++dbg_i;
+  };
+  stamp();  // 0: kernel start
+
+  // ---- target tile DMA (HBM -> LDS, no registers), one 1-KiB piece per call
+  // element offset of this lane's 16-B chunk inside a full tile of consecutive table rows
+  unsigned int toff[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const int L = (wave * NL + k) * 64 + lane;  // linear 16-B slot of the tile image
+    const int row = L / SPR, slot = L % SPR;
+    toff[k] = (unsigned int)(row * (int)TG.ld + ((slot ^ (row & 15)) << 3));
+  }
+  auto dma_piece = [&](int tt, int buf, int k) {
     if (tt >= ntl) tt = ntl - 1;  // keep the VMEM op count per step constant (see header)
-    long long ridx[NL];
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const int L = (wave * NL + k) * 64 + lane;  // linear 16-B slot of the tile image
-      long long tr = (long long)(tile_lo + tt) * V2_TN + L / SPR;
-      if (tr >= m) tr = m - 1;
-      ridx[k] = v2_index<TGMODE>(TG.idx, tr);
-    }
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
+    const long long trow0 = (long long)(tile_lo + tt) * V2_TN;
+    unsigned char* dst = smem + buf * TILEB + (wave * NL + k) * 1024;  // wave-uniform
+    const unsigned short* src;
+    if (TGMODE == 0 && trow0 + V2_TN <= m) {  // all entities, full tile: uniform base + lane offset
+      src = tgb + trow0 * TG.ld + toff[k];
+    } else {
       const int L = (wave * NL + k) * 64 + lane;
       const int row = L / SPR, slot = L % SPR;
-      const unsigned short* src = tgb + ridx[k] * TG.ld + ((slot ^ (row & 15)) << 3);
-      unsigned char* dst = smem + buf * TILEB + (wave * NL + k) * 1024;  // wave-uniform
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)src,
-          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      long long tr = trow0 + row;
+      if (tr >= m) tr = m - 1;
+      src = tgb + v2_index<TGMODE>(TG.idx, tr) * TG.ld + ((slot ^ (row & 15)) << 3);
     }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  };
+  auto tile_dma = [&](int tt, int buf) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) dma_piece(tt, buf, k);
   };
 
   // ---- prologue: build the query fragments of this wave's 32 rows in registers.
-  // The s / r rows are gathered by LDS-DMA (no registers) into a wave-private staging area,
-  // two passes (of 64 coordinates) in flight; the in-order VMEM counter is waited with
-  // counted vmcnt: issue order G0, G1, T0, then G(p+2) after pass p is consumed.
+  // Tile 0 streams first (it needs no index), then the s / r rows are gathered by LDS-DMA
+  // into a wave-private staging area, two passes (of 64 coordinates) in flight.  The VMEM
+  // counter retires in order, so the gathers are waited with counted vmcnt: issue order
+  // T0, G0, G1, then G(p+2) once pass p has been consumed.
+  tile_dma(0, 0);
   bf16x8 afr[NKB];
   {
     long long qrow = row0 + fi;
@@ -154,6 +174,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
       const long long ao = shfl64(aoff, rr), ro = shfl64(roff, rr);
       gsrc[k] = ((p5 < 16) ? ab + ao : rb + ro) + ((p5 >> 3) & 1) * HH + (p5 & 7) * 8;
     }
+    stamp();  // 1: tile 0 issued, indices loaded, source pointers built
     auto gather = [&](int p) {
       unsigned char* dst = smem + STG0 + (p & 1) * STAGE + wave * 16384;
 #pragma unroll
@@ -186,26 +207,21 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
     };
     gather(0);
     if (PASSES > 1) gather(1);
-    tile_dma(0, 0);
+    stamp();  // 2: gathers issued
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      // ops newer than G_p: G_{p+1} (16) if it exists, T0 (8) for p < 2
-      constexpr int T0N = 8;
-      if (p + 1 < PASSES) {
-        if (p < 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      } else {
-        if (p < 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      (void)T0N;
+      // ops newer than G_p: G_{p+1} (16) if it exists
+      if (p + 1 < PASSES) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      stamp();  // 3+2p: pass p landed
       build(p);
       // the staging slot of pass p is free again once this wave's reads have returned
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      stamp();  // 4+2p: pass p built
       if (p + 2 < PASSES) gather(p + 2);
     }
   }
@@ -214,6 +230,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   tile_dma(1, 1);
+  stamp();  // 3+2*PASSES: prologue done, all waves synchronised
 
   // ---- main loop over this workgroup's target tiles
   unsigned int boff[8];
@@ -223,48 +240,9 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   long long orow = row0 + fi;
   if (orow >= n) orow = n - 1;
   float* const orow_ptr = out + orow * ldo;
-  for (int tt = 0; tt < ntl; ++tt) {
-    // newer than tile tt's DMA: stores(tt-2) 4 + DMA(tt+1) 8 + stores(tt-1) 4 = 16 in steady
-    // state; tile 0 landed before the barrier above; at tt == 1: DMA(2) 8 + stores(0) 4.
-    if (tt == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile tt visible to all; everyone finished tile tt-1
-    __builtin_amdgcn_sched_barrier(0);
-    tile_dma(tt + 2, (tt + 2) % 3);
-    // B fragment of K-block kb sits at 16-B slot s = s0(kb) + fh of target row fi, stored at
-    // slot s ^ (fi & 15): with s = 16*a + b the swizzle only touches b, so the address is
-    // (per-lane base for b) + immediate a*256 -- 8 address registers instead of 32.
-    const unsigned int bt = (unsigned int)((tt % 3) * TILEB + fi * ROWB);
-    unsigned int bp[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) bp[t] = bt + boff[t];
-    auto bfrag = [&](int kb) {
-      const int s0 = (kb < NKH) ? (2 * kb) : (HH / 8 + 2 * (kb - NKH));
-      return *reinterpret_cast<const bf16x8*>(smem + bp[(s0 & 15) >> 1] + (s0 >> 4) * 256);
-    };
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    // software pipeline: PF ds_read_b128 in flight ahead of the MFMA chain.  The TARGET
-    // fragment is the MFMA "A" operand and the query fragment the "B" operand, so the
-    // accumulator holds, for query row fi, 4 x 4 CONSECUTIVE targets: 16-byte stores.
-    constexpr int PF = (NKB < 8) ? NKB : 8;
-    bf16x8 bq[PF];
-#pragma unroll
-    for (int kb = 0; kb < PF; ++kb) bq[kb] = bfrag(kb);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[kb % PF], afr[kb], acc, 0, 0, 0);
-      if (kb + PF < NKB) bq[kb % PF] = bfrag(kb + PF);
-    }
-    // pin the interleave: PF reads up front, then one read behind every MFMA
-    __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (kb + PF < NKB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    // acc[4g + e] = score(query fi, target col0 + 8g + 4fh + e)
+
+  // acc[4g + e] = score(query fi, target col0 + 8g + 4fh + e)
+  auto store_tile = [&](int tt, const f32x16& acc) {
     const long long col0 = (long long)(tile_lo + tt) * V2_TN;
     if (col0 + V2_TN <= m) {  // wave-uniform: full tile -> 4 x 16-byte stores per lane
       float* p = orow_ptr + col0 + 4 * fh;
@@ -281,7 +259,69 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
         orow_ptr[oc] = acc[r];
       }
     }
-  }
+  };
+
+  // One tile: wait + barrier, first batch of B reads, the PREVIOUS tile's stores (their
+  // VALU / VMEM issue hides under the LDS latency), then the MFMA chain with the DMA of
+  // tile tt+2 interleaved piece by piece (an LDS-DMA piece costs ~100 issue cycles: behind
+  // 4 MFMAs it is free, in front of the chain it was 800 cycles per tile).
+  // VMEM order per wave: T1 | T2 | S0 T3 | S1 T4 | ...  -> newer than T(tt) at the wait of
+  // tile tt: NL at tt == 1, NL + 4 from tt == 2 on (tile 0 landed before the barrier above).
+  f32x16 accp;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
+  auto tile_body = [&](int tt, bool store_prev) {
+    if (tt == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL + 4) : "memory");
+    __builtin_amdgcn_s_barrier();  // tile tt visible to all; everyone finished reading tile tt-1
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();  // tile tt released
+    // B fragment of K-block kb sits at 16-B slot s = s0(kb) + fh of target row fi, stored at
+    // slot s ^ (fi & 15): with s = 16*a + b the swizzle only touches b, so the address is
+    // (per-lane base for b) + immediate a*256 -- 8 address registers instead of 32.
+    const unsigned int bt = (unsigned int)((tt % 3) * TILEB + fi * ROWB);
+    unsigned int bp[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bp[t] = bt + boff[t];
+    auto bfrag = [&](int kb) {
+      const int s0 = (kb < NKH) ? (2 * kb) : (HH / 8 + 2 * (kb - NKH));
+      return *reinterpret_cast<const bf16x8*>(smem + bp[(s0 & 15) >> 1] + (s0 >> 4) * 256);
+    };
+    // The TARGET fragment is the MFMA "A" operand and the query fragment the "B" operand,
+    // so the accumulator holds, for query row fi, 4 x 4 CONSECUTIVE targets: 16-byte stores.
+    // B fragments are double-buffered in batches of BB reads (hipcc retires LDS reads with
+    // lgkmcnt(0) here, so a wait also covers the newest read: batch b+1 is issued ahead of
+    // the MFMAs of batch b).
+    constexpr int BB = (NKB >= 16) ? 8 : 4;
+    constexpr int NB = NKB / BB;
+    constexpr int DSTEP = NKB / NL;  // one DMA piece every DSTEP MFMAs
+    bf16x8 bq[2][BB];
+#pragma unroll
+    for (int j = 0; j < BB; ++j) bq[0][j] = bfrag(j);
+    if (store_prev) store_tile(tt - 1, accp);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (b + 1 < NB) {
+#pragma unroll
+        for (int j = 0; j < BB; ++j) bq[(b + 1) & 1][j] = bfrag((b + 1) * BB + j);
+      }
+#pragma unroll
+      for (int j = 0; j < BB; ++j) {
+        const int kb = b * BB + j;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[b & 1][j], afr[kb], acc, 0, 0, 0);
+        if ((kb % DSTEP) == DSTEP - 1) dma_piece(tt + 2, (tt + 2) % 3, kb / DSTEP);
+      }
+    }
+    stamp();  // tile tt: MFMA chain issued
+    accp = acc;
+  };
+
+  tile_body(0, false);
+  for (int tt = 1; tt < ntl; ++tt) tile_body(tt, true);
+  store_tile(ntl - 1, accp);
 }
 
 static inline bool v2_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -298,7 +338,8 @@ bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, con
 
 template <int SCORER, int HH>
 static int launch_v2(const Operand& A, const Operand& R, const Operand& TG, int dir, long long n,
-                     long long m, float* out, long long ldo, hipStream_t st) {
+                     long long m, float* out, long long ldo, hipStream_t st,
+                     unsigned long long* dbg) {
   const int rgn = (int)((n + V2_ROWS - 1) / V2_ROWS);
   const int ntiles = (int)((m + V2_TN - 1) / V2_TN);
   // one workgroup per CU (256 CUs): split the target tiles into column groups
@@ -311,7 +352,7 @@ static int launch_v2(const Operand& A, const Operand& R, const Operand& TG, int 
   const int tgmode = TG.idx.ptr == nullptr ? 0 : (TG.idx.itype ? 2 : 1);
 #define KGE_V2L(MODE)                                                                          \
   hipLaunchKernelGGL((pairs_bf16_v2_kernel<SCORER, HH, MODE>), dim3(grid), dim3(256), 0, st, A, \
-                     R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo)
+                     R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg)
   if (tgmode == 0) KGE_V2L(0);
   else if (tgmode == 1) KGE_V2L(1);
   else KGE_V2L(2);
@@ -321,13 +362,13 @@ static int launch_v2(const Operand& A, const Operand& R, const Operand& TG, int 
 
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
-                      hipStream_t st) {
+                      hipStream_t st, unsigned long long* dbg) {
   if (n == 0 || m == 0) return KGE_OK;
 #define KGE_V2(SC)                                                                   \
   switch (d) {                                                                       \
-    case 128: return launch_v2<SC, 64>(A, R, TG, dir, n, m, out, ldo, st);           \
-    case 256: return launch_v2<SC, 128>(A, R, TG, dir, n, m, out, ldo, st);          \
-    case 512: return launch_v2<SC, 256>(A, R, TG, dir, n, m, out, ldo, st);          \
+    case 128: return launch_v2<SC, 64>(A, R, TG, dir, n, m, out, ldo, st, dbg);      \
+    case 256: return launch_v2<SC, 128>(A, R, TG, dir, n, m, out, ldo, st, dbg);     \
+    case 512: return launch_v2<SC, 256>(A, R, TG, dir, n, m, out, ldo, st, dbg);     \
   }
   if (scorer == KGE_COMPLEX) { KGE_V2(KGE_COMPLEX) } else { KGE_V2(KGE_DISTMULT) }
 #undef KGE_V2

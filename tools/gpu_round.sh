@@ -13,6 +13,7 @@ timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 echo "smoke exit: $?" >> $OUT/env.log
 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit: $?" >> $OUT/env.log
+timeout 300 python tools/v2_phases.py > $OUT/v2_phases.txt 2>&1
 timeout 900 python tools/perf_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err
 echo "probe exit: $?" >> $OUT/env.log
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err )
