@@ -15,6 +15,9 @@ bool pairs_bf16_supported(int scorer, int dtype, int d, const Operand& A, const 
                           const Operand& TG);
 int run_pairs_bf16(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                    int d, long long n, long long m, float* out, long long ldo, hipStream_t st);
+int run_pairs_bf16_v2_ablate(int abl, const Operand& A, const Operand& R, const Operand& TG, long long n,
+                             long long m, float* out, long long ldo, hipStream_t st,
+                             unsigned long long* dbg);
 bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
                              const Operand& TG);
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
@@ -278,12 +281,16 @@ int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64
 // per-workgroup timestamp buffer (64 x u64 per workgroup) for tools/v2_phases.py.
 int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, int64_t n,
                                int64_t m, float* out, int64_t ldo, unsigned long long* stamps,
-                               void* stream) {
+                               int ablate, void* stream) {
   int rc = check_tables(t, true);
   if (rc) return rc;
   kge_index all{nullptr, KGE_I64, 0, 1};
   Operand A = ent_op(t, s), R = rel_op(t, p), TG = ent_op(t, all);
   if (!pairs_bf16_v2_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) return KGE_ERR_UNSUPPORTED;
+  if (ablate) {
+    if (t->scorer != KGE_COMPLEX || t->dim != 512) return KGE_ERR_UNSUPPORTED;
+    return run_pairs_bf16_v2_ablate(ablate, A, R, TG, n, m, out, ldo, (hipStream_t)stream, stamps);
+  }
   return run_pairs_bf16_v2(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
                            (hipStream_t)stream, stamps);
 }

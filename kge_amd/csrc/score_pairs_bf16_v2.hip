@@ -77,7 +77,9 @@ __device__ __forceinline__ long long v2_index(const Index& ix, long long i) {
   return ((const long long*)ix.ptr)[i * ix.stride];
 }
 
-template <int SCORER, int HH, int TGMODE>
+// ABL (ablation, debug entry only): bit 0 = drop the global score stores, bit 1 = drop the
+// in-loop tile DMA (results are wrong; used to attribute time, tools/v2_phases.py)
+template <int SCORER, int HH, int TGMODE, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
     Operand A, Operand R, Operand TG, int dir, long long n, long long m, int rgn, int ncg,
     int tiles_per_cg, int ntiles, float* __restrict__ out, long long ldo,
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   constexpr int PASSES = HH / 64;         // prologue passes of 64 coordinates
   constexpr int STAGE = 4 * 16384;        // one prologue staging slot: 16 KiB per wave
   constexpr int STG0 = TILEB;             // two slots behind ring buffer 0
-  constexpr int SMEM = (3 * TILEB > STG0 + 2 * STAGE) ? 3 * TILEB : STG0 + 2 * STAGE;
+  constexpr int CST = 4 * 32 * 144;       // per-wave C-tile transpose buffers (after the ring)
+  constexpr int SMEM = (3 * TILEB + CST > STG0 + 2 * STAGE) ? 3 * TILEB + CST : STG0 + 2 * STAGE;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
   // ---- which rows / target tiles
@@ -151,20 +154,18 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   };
 
   // ---- prologue: build the query fragments of this wave's 32 rows in registers.
-  // Tile 0 streams first (it needs no index), then the s / r rows are gathered by LDS-DMA
-  // into a wave-private staging area, two passes (of 64 coordinates) in flight.  The VMEM
-  // counter retires in order, so the gathers are waited with counted vmcnt: issue order
-  // T0, G0, G1, then G(p+2) once pass p has been consumed.
-  tile_dma(0, 0);
+  // Tile 0 streams first (it needs no index), then the s / r rows are gathered in passes of
+  // 64 coordinates: 128-byte segments (full cache lines) -> registers -> wave-private LDS
+  // staging -> re-read in fragment shape.  The loads of pass p+1 fly while pass p is built.
   bf16x8 afr[NKB];
   {
+    const unsigned short* ab = (const unsigned short*)A.base;
+    const unsigned short* rb = (const unsigned short*)R.base;
     long long qrow = row0 + fi;
     if (qrow >= n) qrow = n - 1;
     const long long aoff = index_at(A.idx, qrow) * A.ld;  // element offsets of row `fi`
     const long long roff = index_at(R.idx, qrow) * R.ld;
-    const unsigned short* ab = (const unsigned short*)A.base;
-    const unsigned short* rb = (const unsigned short*)R.base;
-    // source pointer of DMA instruction k: row rr = 2k + fh, LDS slot (lane & 31) holds the
+    // source pointer of gather load k: row rr = 2k + fh, LDS slot (lane & 31) holds the
     // logical slot p5 = (lane & 31) ^ (rr & 15) = array (p5 >> 3), 16-B chunk (p5 & 7)
     const unsigned short* gsrc[16];
 #pragma unroll
@@ -174,14 +175,18 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
       const long long ao = shfl64(aoff, rr), ro = shfl64(roff, rr);
       gsrc[k] = ((p5 < 16) ? ab + ao : rb + ro) + ((p5 >> 3) & 1) * HH + (p5 & 7) * 8;
     }
-    stamp();  // 1: tile 0 issued, indices loaded, source pointers built
+    stamp();  // 1: indices loaded, source pointers built
+    // gather of pass p: 16 plain 16-B loads per lane (an LDS-DMA piece costs ~100 issue
+    // cycles, a global_load ~8), written to the wave-private staging slot p & 1 lane-linearly
+    u32x4 g[16];
     auto gather = [&](int p) {
-      unsigned char* dst = smem + STG0 + (p & 1) * STAGE + wave * 16384;
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(gsrc[k] + 64 * p),
-            (__attribute__((address_space(3))) void*)(dst + k * 1024), 16, 0, 0);
+      for (int k = 0; k < 16; ++k) g[k] = *reinterpret_cast<const u32x4*>(gsrc[k] + 64 * p);
+    };
+    auto stage_write = [&](int p) {
+      unsigned char* dst = smem + STG0 + (p & 1) * STAGE + wave * 16384 + lane * 16;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) *reinterpret_cast<u32x4*>(dst + k * 1024) = g[k];
     };
     auto build = [&](int p) {
       const unsigned char* stage = smem + STG0 + (p & 1) * STAGE + wave * 16384 + fi * 512;
@@ -206,23 +211,18 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
       }
     };
     gather(0);
-    if (PASSES > 1) gather(1);
-    stamp();  // 2: gathers issued
+    tile_dma(0, 0);  // behind the gather in the in-order VMEM queue
+    stamp();  // 2: gather 0 and tile 0 issued
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
-      // ops newer than G_p: G_{p+1} (16) if it exists
-      if (p + 1 < PASSES) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stage_write(p);  // waits for the loads of pass p (compiler-tracked)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      stamp();  // 3+2p: pass p landed
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      stamp();  // 3+2p: pass p landed and staged
+      if (p + 1 < PASSES) gather(p + 1);  // flies while pass p is built
       build(p);
-      // the staging slot of pass p is free again once this wave's reads have returned
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_sched_barrier(0);
       stamp();  // 4+2p: pass p built
-      if (p + 2 < PASSES) gather(p + 2);
     }
   }
   // staging overlaps ring buffers 1 and 2: everyone must be done before tile 1 streams in
@@ -241,36 +241,49 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   if (orow >= n) orow = n - 1;
   float* const orow_ptr = out + orow * ldo;
 
-  // acc[4g + e] = score(query fi, target col0 + 8g + 4fh + e)
-  auto store_tile = [&](int tt, const f32x16& acc) {
+  // acc[4g + e] = score(query fi, target col0 + 8g + 4fh + e).  The finished tile goes through
+  // a wave-private LDS transpose so that every store instruction writes 8 rows x 128
+  // contiguous bytes, and its ~60 instructions are spread between the MFMAs of the NEXT tile
+  // (two accumulator sets, ping-pong), where they are free.
+  unsigned char* const cst = smem + 3 * TILEB + wave * (32 * 144);  // free after the prologue
+  auto ep_write = [&](const f32x16& acc, int g) {
+    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    *reinterpret_cast<f32x4*>(cst + fi * 144 + (8 * g + 4 * fh) * 4) = v;
+  };
+  auto ep_fence = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto ep_read = [&](int i) {
+    return *reinterpret_cast<const f32x4*>(cst + (8 * i + (lane >> 3)) * 144 + (lane & 7) * 16);
+  };
+  auto ep_store = [&](int tt, int i, const f32x4& v) {
+    if (ABL & 1) {
+      asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+      return;
+    }
+    long long orow_i = row0 + 8 * i + (lane >> 3);
+    if (orow_i >= n) orow_i = n - 1;  // clamped rows rewrite the bits of row n-1
+    *reinterpret_cast<f32x4u*>(out + orow_i * ldo + (long long)(tile_lo + tt) * V2_TN + 4 * (lane & 7)) = v;
+  };
+  auto store_ragged = [&](int tt, const f32x16& acc) {  // last tile of the table, m % 32 != 0
     const long long col0 = (long long)(tile_lo + tt) * V2_TN;
-    if (col0 + V2_TN <= m) {  // wave-uniform: full tile -> 4 x 16-byte stores per lane
-      float* p = orow_ptr + col0 + 4 * fh;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4u v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        *reinterpret_cast<f32x4u*>(p + 8 * g) = v;
-      }
-    } else {  // ragged last tile of the table: scalar stores, clamped to column m-1
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        long long oc = col0 + 8 * (r >> 2) + 4 * fh + (r & 3);
-        if (oc >= m) oc = m - 1;
-        orow_ptr[oc] = acc[r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      long long oc = col0 + 8 * (r >> 2) + 4 * fh + (r & 3);
+      if (oc >= m) oc = m - 1;
+      orow_ptr[oc] = acc[r];
     }
   };
+  auto tile_full = [&](int tt) { return (long long)(tile_lo + tt + 1) * V2_TN <= m; };
 
-  // One tile: wait + barrier, first batch of B reads, the PREVIOUS tile's stores (their
-  // VALU / VMEM issue hides under the LDS latency), then the MFMA chain with the DMA of
-  // tile tt+2 interleaved piece by piece (an LDS-DMA piece costs ~100 issue cycles: behind
-  // 4 MFMAs it is free, in front of the chain it was 800 cycles per tile).
+  // One tile: wait + barrier, then the MFMA chain; between its MFMAs: the B-fragment reads
+  // (double-buffered batches), the DMA pieces of tile tt+2, and the epilogue of tile tt-1.
   // VMEM order per wave: T1 | T2 | S0 T3 | S1 T4 | ...  -> newer than T(tt) at the wait of
-  // tile tt: NL at tt == 1, NL + 4 from tt == 2 on (tile 0 landed before the barrier above).
-  f32x16 accp;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) accp[r] = 0.0f;
-  auto tile_body = [&](int tt, bool store_prev) {
+  // tile tt: NL at tt == 1, NL + 4 from tt == 2 on (tile 0 landed before the barrier above);
+  // only the last tile of the table can be ragged, and it is stored after the loop.
+  auto tile_body = [&](int tt, f32x16& acc, const f32x16& accp, bool store_prev) {
     if (tt == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL + 4) : "memory");
     __builtin_amdgcn_s_barrier();  // tile tt visible to all; everyone finished reading tile tt-1
@@ -288,40 +301,75 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
       return *reinterpret_cast<const bf16x8*>(smem + bp[(s0 & 15) >> 1] + (s0 >> 4) * 256);
     };
     // The TARGET fragment is the MFMA "A" operand and the query fragment the "B" operand,
-    // so the accumulator holds, for query row fi, 4 x 4 CONSECUTIVE targets: 16-byte stores.
-    // B fragments are double-buffered in batches of BB reads (hipcc retires LDS reads with
-    // lgkmcnt(0) here, so a wait also covers the newest read: batch b+1 is issued ahead of
-    // the MFMAs of batch b).
-    constexpr int BB = (NKB >= 16) ? 8 : 4;
-    constexpr int NB = NKB / BB;
+    // so the accumulator holds, for query row fi, 4 x 4 CONSECUTIVE targets.
+    // B fragments: PF ds_read_b128 in flight, issued by inline asm and retired with COUNTED
+    // lgkmcnt waits (LDS ops return in order).  hipcc only ever emits lgkmcnt(0) for the LDS
+    // reads of this kernel, which stalls every few MFMAs on the newest read (measured: 2000
+    // cycles per tile for a 1056-cycle MFMA chain).  Extra compiler-issued LDS ops between
+    // the reads (C-tile transpose) only make a counted wait stricter, never weaker.
+    constexpr int PF = (NKB < 8) ? NKB : 8;
     constexpr int DSTEP = NKB / NL;  // one DMA piece every DSTEP MFMAs
-    bf16x8 bq[2][BB];
+    bf16x8 bq[PF];
+    f32x4 cv[4];
+    auto bread = [&](bf16x8& dst, int kb) {
+      const int s0 = (kb < NKH) ? (2 * kb) : (HH / 8 + 2 * (kb - NKH));
+      asm volatile("ds_read_b128 %0, %1 offset:%2"
+                   : "=v"(dst)
+                   : "v"(bp[(s0 & 15) >> 1]), "i"((s0 >> 4) * 256)
+                   : "memory");
+    };
 #pragma unroll
-    for (int j = 0; j < BB; ++j) bq[0][j] = bfrag(j);
-    if (store_prev) store_tile(tt - 1, accp);
-    f32x16 acc;
+    for (int j = 0; j < PF; ++j) bread(bq[j], j);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      if (b + 1 < NB) {
+    for (int kb = 0; kb < NKB; ++kb) {
+      // reads newer than read kb: min(PF - 1, NKB - 1 - kb)
+      if (NKB - 1 - kb >= PF - 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(PF - 1) : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(NKB - 1 - kb) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[kb % PF], afr[kb], acc, 0, 0, 0);
+      if (kb + PF < NKB) bread(bq[kb % PF], kb + PF);
+      if (!(ABL & 2) && (kb % DSTEP) == DSTEP - 1) dma_piece(tt + 2, (tt + 2) % 3, kb / DSTEP);
+      if (store_prev) {  // epilogue of tile tt-1, spread over the chain (positions scale with NKB)
 #pragma unroll
-        for (int j = 0; j < BB; ++j) bq[(b + 1) & 1][j] = bfrag((b + 1) * BB + j);
-      }
+        for (int g = 0; g < 4; ++g)
+          if (kb == g * NKB / 32) ep_write(accp, g);
+        if (kb == 4 * NKB / 32) ep_fence();
 #pragma unroll
-      for (int j = 0; j < BB; ++j) {
-        const int kb = b * BB + j;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[b & 1][j], afr[kb], acc, 0, 0, 0);
-        if ((kb % DSTEP) == DSTEP - 1) dma_piece(tt + 2, (tt + 2) % 3, kb / DSTEP);
+        for (int i = 0; i < 4; ++i)
+          if (kb == (6 + i) * NKB / 32) cv[i] = ep_read(i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (kb == (14 + 2 * i) * NKB / 32) ep_store(tt - 1, i, cv[i]);
       }
     }
     stamp();  // tile tt: MFMA chain issued
-    accp = acc;
   };
 
-  tile_body(0, false);
-  for (int tt = 1; tt < ntl; ++tt) tile_body(tt, true);
-  store_tile(ntl - 1, accp);
+  f32x16 acc_a, acc_b;
+  tile_body(0, acc_a, acc_b, false);
+  int tt = 1;
+  for (; tt + 1 < ntl; tt += 2) {
+    tile_body(tt, acc_b, acc_a, true);
+    tile_body(tt + 1, acc_a, acc_b, true);
+  }
+  if (tt < ntl) {  // odd tail: last tile accumulates in acc_b
+    tile_body(tt, acc_b, acc_a, true);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_a[r] = acc_b[r];
+    ++tt;
+  }
+  // the workgroup's last tile (tt - 1 == ntl - 1) is in acc_a
+  if (tile_full(ntl - 1)) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ep_write(acc_a, g);
+    ep_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ep_store(ntl - 1, i, ep_read(i));
+  } else {
+    store_ragged(ntl - 1, acc_a);
+  }
 }
 
 static inline bool v2_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -357,6 +405,28 @@ static int launch_v2(const Operand& A, const Operand& R, const Operand& TG, int 
   else if (tgmode == 1) KGE_V2L(1);
   else KGE_V2L(2);
 #undef KGE_V2L
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// debug: ComplEx d=512, all entities, with ablation mode
+int run_pairs_bf16_v2_ablate(int abl, const Operand& A, const Operand& R, const Operand& TG, long long n,
+                             long long m, float* out, long long ldo, hipStream_t st,
+                             unsigned long long* dbg) {
+  const int rgn = (int)((n + V2_ROWS - 1) / V2_ROWS);
+  const int ntiles = (int)((m + V2_TN - 1) / V2_TN);
+  int ncg = 256 / rgn;
+  if (ncg < 1) ncg = 1;
+  int tpc = (ntiles + ncg - 1) / ncg;
+  ncg = (ntiles + tpc - 1) / tpc;
+  const int grid = 8 * rgn * ((ncg + 7) / 8);
+#define KGE_ABL(X)                                                                              \
+  hipLaunchKernelGGL((pairs_bf16_v2_kernel<KGE_COMPLEX, 256, 0, X>), dim3(grid), dim3(256), 0, st, \
+                     A, R, TG, (int)KGE_SP_, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg)
+  if (abl == 1) KGE_ABL(1);
+  else if (abl == 2) KGE_ABL(2);
+  else if (abl == 3) KGE_ABL(3);
+  else KGE_ABL(0);
+#undef KGE_ABL
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 

@@ -28,7 +28,7 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0):
     fn = L.kge_debug_score_sp_bf16_v2
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.POINTER(_lib.KgeTables), _lib.KgeIndex, _lib.KgeIndex, ctypes.c_int64,
-                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     keep = []
     si, pi = engine._index(s, dev, keep), engine._index(p, dev, keep)
     nwg = 4096
@@ -38,7 +38,7 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0):
         stamps.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        rc = fn(ctypes.byref(tc), si, pi, n, E, out.data_ptr(), E, stamps.data_ptr(),
+        rc = fn(ctypes.byref(tc), si, pi, n, E, out.data_ptr(), E, stamps.data_ptr(), mode,
                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         b.record()
         torch.cuda.synchronize()
@@ -73,5 +73,5 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0):
 
 
 if __name__ == "__main__":
-    for n in (128, 512, 1024):
-        run(n)
+    for n, mode in ((128, 0), (512, 0), (1024, 0), (512, 1), (512, 2), (512, 3)):
+        run(n, mode=mode)
