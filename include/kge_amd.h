@@ -120,6 +120,14 @@ int kge_device_count(void);
 
 /* ---- index-level scoring (fused gather + score) ------------------------ */
 
+/* Optional device workspace for the scoring calls below.  The library never allocates:
+ * a caller that passes `workspace_bytes >= kge_score_workspace_bytes(t, n)` lets the
+ * bf16 ComplEx/DistMult path build the n query vectors ONCE (a small builder kernel) instead
+ * of once per workgroup inside the scoring kernel; workspace == NULL (or too small) selects
+ * the fully fused single-kernel path.  Results are identical.  The workspace is only used
+ * during the call (stream order); 16-byte aligned. */
+int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n);
+
 /* out[i] = score(s[i], p[i], o[i]), i < n.        KgeModel.score_spo */
 int kge_score_spo(const kge_tables* t, kge_index s, kge_index p, kge_index o,
                   int64_t n, float* out, void* stream);
@@ -128,18 +136,19 @@ int kge_score_spo(const kge_tables* t, kge_index s, kge_index p, kge_index o,
  * targets.ptr == NULL: all entities, m must equal t->num_ent. */
 int kge_score_sp(const kge_tables* t, kge_index s, kge_index p, int64_t n,
                  kge_index targets, int64_t m, float* out, int64_t ldo,
-                 void* stream);
+                 void* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[i*ldo + j] = score(targets[j], p[i], o[i]).  KgeModel.score_po */
 int kge_score_po(const kge_tables* t, kge_index p, kge_index o, int64_t n,
                  kge_index targets, int64_t m, float* out, int64_t ldo,
-                 void* stream);
+                 void* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[i*ldo + j] = sp score, out[i*ldo + m + j] = po score (j < m); ldo >= 2m.
  * KgeModel.score_sp_po (cat of score_sp and score_po over one entity subset). */
 int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o,
                     int64_t n, kge_index targets, int64_t m, float* out,
-                    int64_t ldo, void* stream);
+                    int64_t ldo, void* workspace, int64_t workspace_bytes,
+                    void* stream);
 
 /* Negative-sampling scores, the "triple" implementation without building the
  * [n*K,3] index tensor: slot 0/2 = corrupt s / o.
@@ -157,7 +166,8 @@ int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o,
 int kge_score_emb(const kge_tables* t, int combine, const void* s_emb,
                   int64_t s_ld, const void* p_emb, int64_t p_ld,
                   const void* o_emb, int64_t o_ld, int64_t n, int64_t m,
-                  float* out, int64_t ldo, void* stream);
+                  float* out, int64_t ldo, void* workspace,
+                  int64_t workspace_bytes, void* stream);
 
 /* ---- ranking ------------------------------------------------------------ */
 /* For each row i of scores[n, c] (leading dim lds) and its true score:

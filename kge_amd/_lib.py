@@ -48,13 +48,14 @@ PROTOTYPES = {
     "kge_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "kge_device_count": (ctypes.c_int, []),
     "kge_score_spo": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp]),
-    "kge_score_sp": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
-    "kge_score_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
-    "kge_score_sp_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_workspace_bytes": (c_i64, [_PT, c_i64]),
+    "kge_score_sp": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_sp_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_neg": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int, c_vp,
                                      ctypes.c_int32, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_emb": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
-                                     c_i64, c_i64, c_vp, c_i64, c_vp]),
+                                     c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_rank_counts": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                        ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
     "kge_score_pairs_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, KgeIndex,

@@ -22,7 +22,8 @@ bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, con
                              const Operand& TG);
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
-                      hipStream_t st, unsigned long long* dbg = nullptr);
+                      hipStream_t st, unsigned long long* dbg = nullptr, void* ws = nullptr,
+                      long long ws_bytes = 0);
 int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
              long long col_offset, const long long* true_col, float atol, float rtol,
@@ -78,11 +79,11 @@ Operand rel_op(const kge_tables* t, const kge_index& ix) {
 
 int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand& R,
                    const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo,
-                   hipStream_t st) {
+                   void* ws, int64_t ws_bytes, hipStream_t st) {
   const int d = (int)t->dim, dr = (int)t->rel_dim;
   if (!(t->flags & KGE_FLAG_EXACT)) {
     if (!(t->flags & KGE_FLAG_BF16_V1) && pairs_bf16_v2_supported(t->scorer, t->dtype, d, A, R, TG))
-      return run_pairs_bf16_v2(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
+      return run_pairs_bf16_v2(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
     if (pairs_bf16_supported(t->scorer, t->dtype, d, A, R, TG))
       return run_pairs_bf16(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
   }
@@ -92,7 +93,8 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
 }
 
 int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
-                kge_index targets, int64_t m, float* out, int64_t ldo, void* stream) {
+                kge_index targets, int64_t m, float* out, int64_t ldo, void* ws, int64_t ws_bytes,
+                void* stream) {
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (n < 0 || m < 0 || (!out && n * m > 0) || ldo < m) return KGE_ERR_INVALID_ARG;
@@ -102,7 +104,7 @@ int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
     return rc;
   if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
   return pairs_dispatch(t, dir, ent_op(t, a), rel_op(t, p), ent_op(t, targets), n, m, out, ldo,
-                        (hipStream_t)stream);
+                        ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -146,22 +148,33 @@ int kge_score_spo(const kge_tables* t, kge_index s, kge_index p, kge_index o, in
                  (hipStream_t)stream);
 }
 
+int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n) {
+  if (!t || n <= 0 || t->dtype != KGE_BF16) return 0;
+  if (t->scorer != KGE_COMPLEX && t->scorer != KGE_DISTMULT) return 0;
+  if (t->dim != 128 && t->dim != 256 && t->dim != 512) return 0;
+  return ((n + 127) / 128) * 128 * t->dim * 2;  // bf16 query fragments, whole 128-row groups
+}
+
 int kge_score_sp(const kge_tables* t, kge_index s, kge_index p, int64_t n, kge_index targets,
-                 int64_t m, float* out, int64_t ldo, void* stream) {
-  return pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, stream);
+                 int64_t m, float* out, int64_t ldo, void* workspace, int64_t workspace_bytes,
+                 void* stream) {
+  return pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, workspace, workspace_bytes, stream);
 }
 
 int kge_score_po(const kge_tables* t, kge_index p, kge_index o, int64_t n, kge_index targets,
-                 int64_t m, float* out, int64_t ldo, void* stream) {
-  return pairs_entry(t, KGE_PO_, o, p, n, targets, m, out, ldo, stream);
+                 int64_t m, float* out, int64_t ldo, void* workspace, int64_t workspace_bytes,
+                 void* stream) {
+  return pairs_entry(t, KGE_PO_, o, p, n, targets, m, out, ldo, workspace, workspace_bytes, stream);
 }
 
 int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
-                    kge_index targets, int64_t m, float* out, int64_t ldo, void* stream) {
+                    kge_index targets, int64_t m, float* out, int64_t ldo, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
   if (ldo < 2 * m) return KGE_ERR_INVALID_ARG;
-  int rc = pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, stream);
+  int rc = pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, workspace, workspace_bytes, stream);
   if (rc) return rc;
-  return pairs_entry(t, KGE_PO_, o, p, n, targets, m, out ? out + m : out, ldo, stream);
+  return pairs_entry(t, KGE_PO_, o, p, n, targets, m, out ? out + m : out, ldo, workspace,
+                     workspace_bytes, stream);
 }
 
 int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
@@ -185,7 +198,8 @@ int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o, in
 
 int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s_ld,
                   const void* p_emb, int64_t p_ld, const void* o_emb, int64_t o_ld, int64_t n,
-                  int64_t m, float* out, int64_t ldo, void* stream) {
+                  int64_t m, float* out, int64_t ldo, void* workspace, int64_t workspace_bytes,
+                  void* stream) {
   int rc = check_tables(t, false);
   if (rc) return rc;
   if (!s_emb || !p_emb || !o_emb || n < 0 || m < 0) return KGE_ERR_INVALID_ARG;
@@ -199,8 +213,10 @@ int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s
                    nullptr, 0, 0, 0, t->l_norm, out, 0, st);
   }
   if ((!out && n * m > 0) || ldo < m) return KGE_ERR_INVALID_ARG;
-  if (combine == KGE_SP_) return pairs_dispatch(t, KGE_SP_, S, P, O, n, m, out, ldo, st);
-  if (combine == KGE_PO_) return pairs_dispatch(t, KGE_PO_, O, P, S, n, m, out, ldo, st);
+  if (combine == KGE_SP_)
+    return pairs_dispatch(t, KGE_SP_, S, P, O, n, m, out, ldo, workspace, workspace_bytes, st);
+  if (combine == KGE_PO_)
+    return pairs_dispatch(t, KGE_PO_, O, P, S, n, m, out, ldo, workspace, workspace_bytes, st);
   return KGE_ERR_INVALID_ARG;
 }
 
@@ -281,7 +297,8 @@ int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64
 // per-workgroup timestamp buffer (64 x u64 per workgroup) for tools/v2_phases.py.
 int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, int64_t n,
                                int64_t m, float* out, int64_t ldo, unsigned long long* stamps,
-                               int ablate, void* stream) {
+                               int ablate, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
   int rc = check_tables(t, true);
   if (rc) return rc;
   kge_index all{nullptr, KGE_I64, 0, 1};
@@ -292,7 +309,7 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
     return run_pairs_bf16_v2_ablate(ablate, A, R, TG, n, m, out, ldo, (hipStream_t)stream, stamps);
   }
   return run_pairs_bf16_v2(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
-                           (hipStream_t)stream, stamps);
+                           (hipStream_t)stream, stamps, workspace, workspace_bytes);
 }
 
 }  // extern "C"

@@ -79,11 +79,13 @@ __device__ __forceinline__ long long v2_index(const Index& ix, long long i) {
 
 // ABL (ablation, debug entry only): bit 0 = drop the global score stores, bit 1 = drop the
 // in-loop tile DMA (results are wrong; used to attribute time, tools/v2_phases.py)
-template <int SCORER, int HH, int TGMODE, int ABL = 0>
+// PREQ: the query fragments were built by build_queries_kernel into `qf` (workspace);
+// otherwise the prologue gathers and builds them itself (fused, no workspace).
+template <int SCORER, int HH, int TGMODE, int ABL = 0, bool PREQ = false>
 __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
     Operand A, Operand R, Operand TG, int dir, long long n, long long m, int rgn, int ncg,
     int tiles_per_cg, int ntiles, float* __restrict__ out, long long ldo,
-    unsigned long long* __restrict__ dbg) {
+    unsigned long long* __restrict__ dbg, const u32x4* __restrict__ qf) {
   constexpr int NKB = 2 * HH / 16;        // K-blocks of 16
   constexpr int NKH = HH / 16;            // K-blocks per half
   constexpr int ROWB = 4 * HH;            // bytes per table row (2*HH bf16)
@@ -158,6 +160,15 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   // 64 coordinates: 128-byte segments (full cache lines) -> registers -> wave-private LDS
   // staging -> re-read in fragment shape.  The loads of pass p+1 fly while pass p is built.
   bf16x8 afr[NKB];
+  if constexpr (PREQ) {
+    // fragment-major workspace: K-block kb of 32-row block rb is 64 lanes x 16 B, contiguous
+    const u32x4* src = qf + ((long long)(rg * (V2_ROWS / 32) + wave) * NKB) * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) afr[kb] = __builtin_bit_cast(bf16x8, src[kb * 64]);
+    tile_dma(0, 0);
+    tile_dma(1, 1);
+    stamp();  // 1: fragment loads and tiles 0, 1 issued
+  } else
   {
     const unsigned short* ab = (const unsigned short*)A.base;
     const unsigned short* rb = (const unsigned short*)R.base;
@@ -224,13 +235,13 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
       build(p);
       stamp();  // 4+2p: pass p built
     }
+    // staging overlaps ring buffers 1 and 2: everyone must be done before tile 1 streams in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    tile_dma(1, 1);
+    stamp();  // 3+2*PASSES: prologue done, all waves synchronised
   }
-  // staging overlaps ring buffers 1 and 2: everyone must be done before tile 1 streams in
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  tile_dma(1, 1);
-  stamp();  // 3+2*PASSES: prologue done, all waves synchronised
 
   // ---- main loop over this workgroup's target tiles
   unsigned int boff[8];
@@ -281,10 +292,10 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   // One tile: wait + barrier, then the MFMA chain; between its MFMAs: the B-fragment reads
   // (double-buffered batches), the DMA pieces of tile tt+2, and the epilogue of tile tt-1.
   // VMEM order per wave: T1 | T2 | S0 T3 | S1 T4 | ...  -> newer than T(tt) at the wait of
-  // tile tt: NL at tt == 1, NL + 4 from tt == 2 on (tile 0 landed before the barrier above);
+  // tile tt: NL for tt < 2 (T(tt+1) only), NL + 4 from tt == 2 on;
   // only the last tile of the table can be ragged, and it is stored after the loop.
   auto tile_body = [&](int tt, f32x16& acc, const f32x16& accp, bool store_prev) {
-    if (tt == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL) : "memory");
+    if (tt < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL + 4) : "memory");
     __builtin_amdgcn_s_barrier();  // tile tt visible to all; everyone finished reading tile tt-1
     __builtin_amdgcn_sched_barrier(0);
@@ -372,6 +383,41 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
   }
 }
 
+
+// ---- query-fragment builder (workspace path) ----------------------------------------------
+// One thread per (query row, group of 8 coordinates): gather 4 x 16 B (both halves of the s and
+// r rows), build q = s (x) r in f32, round to bf16 and write the two 16-B fragments where the
+// scoring kernel loads them: qf[((row/32 * NKB + kb) * 64 + lane)], lane = row%32 + 32*(cg&1),
+// kb = cg/2 (first half) and NKH + cg/2 (second half).  n * d/16 threads: fully parallel, two
+// dependent memory latencies.  Removes the 64-fold redundant query build (8,400 VALU cycles
+// per wave) from the scoring kernel's prologue.
+template <int SCORER, int HH>
+__global__ __launch_bounds__(256) void build_queries_kernel(Operand A, Operand R, int dir,
+                                                            long long n, long long nrows,
+                                                            u32x4* __restrict__ qf) {
+  constexpr int NKB = 2 * HH / 16, NKH = HH / 16, CG = HH / 8;  // coordinate groups per row
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long row = t / CG;
+  const int cg = (int)(t % CG);
+  if (row >= nrows) return;
+  long long qrow = row < n ? row : n - 1;  // padded rows repeat row n-1
+  const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + cg * 8;
+  const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + cg * 8;
+  const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
+  const u32x4 r0 = *reinterpret_cast<const u32x4*>(r), r1 = *reinterpret_cast<const u32x4*>(r + HH);
+  u32x4 q0, q1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    unsigned int x0, x1;
+    v2_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+    q0[e] = x0;
+    q1[e] = x1;
+  }
+  u32x4* dst = qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (cg & 1);
+  dst[(cg >> 1) * 64] = q0;
+  dst[(NKH + (cg >> 1)) * 64] = q1;
+}
+
 static inline bool v2_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
@@ -387,7 +433,7 @@ bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, con
 template <int SCORER, int HH>
 static int launch_v2(const Operand& A, const Operand& R, const Operand& TG, int dir, long long n,
                      long long m, float* out, long long ldo, hipStream_t st,
-                     unsigned long long* dbg) {
+                     unsigned long long* dbg, void* ws, long long ws_bytes) {
   const int rgn = (int)((n + V2_ROWS - 1) / V2_ROWS);
   const int ntiles = (int)((m + V2_TN - 1) / V2_TN);
   // one workgroup per CU (256 CUs): split the target tiles into column groups
@@ -398,12 +444,24 @@ static int launch_v2(const Operand& A, const Operand& R, const Operand& TG, int 
   ncg = (ntiles + tpc - 1) / tpc;
   const int grid = 8 * rgn * ((ncg + 7) / 8);
   const int tgmode = TG.idx.ptr == nullptr ? 0 : (TG.idx.itype ? 2 : 1);
-#define KGE_V2L(MODE)                                                                          \
-  hipLaunchKernelGGL((pairs_bf16_v2_kernel<SCORER, HH, MODE>), dim3(grid), dim3(256), 0, st, A, \
-                     R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg)
-  if (tgmode == 0) KGE_V2L(0);
-  else if (tgmode == 1) KGE_V2L(1);
-  else KGE_V2L(2);
+  const long long rb32 = (long long)rgn * (V2_ROWS / 32);  // every wave of every row group loads a block
+  const bool preq = ws != nullptr && v2_al16(ws) && ws_bytes >= rb32 * 32 * (long long)HH * 4;
+  u32x4* qf = (u32x4*)ws;
+  if (preq) {
+    const long long nrows = rb32 * 32, nthreads = nrows * (HH / 8);
+    hipLaunchKernelGGL((build_queries_kernel<SCORER, HH>), dim3((unsigned)((nthreads + 255) / 256)),
+                       dim3(256), 0, st, A, R, dir, n, nrows, qf);
+  }
+#define KGE_V2L(MODE)                                                                             \
+  if (preq)                                                                                       \
+    hipLaunchKernelGGL((pairs_bf16_v2_kernel<SCORER, HH, MODE, 0, true>), dim3(grid), dim3(256), 0, \
+                       st, A, R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, qf);        \
+  else                                                                                            \
+    hipLaunchKernelGGL((pairs_bf16_v2_kernel<SCORER, HH, MODE, 0, false>), dim3(grid), dim3(256),   \
+                       0, st, A, R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, qf)
+  if (tgmode == 0) { KGE_V2L(0); }
+  else if (tgmode == 1) { KGE_V2L(1); }
+  else { KGE_V2L(2); }
 #undef KGE_V2L
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
@@ -421,7 +479,7 @@ int run_pairs_bf16_v2_ablate(int abl, const Operand& A, const Operand& R, const 
   const int grid = 8 * rgn * ((ncg + 7) / 8);
 #define KGE_ABL(X)                                                                              \
   hipLaunchKernelGGL((pairs_bf16_v2_kernel<KGE_COMPLEX, 256, 0, X>), dim3(grid), dim3(256), 0, st, \
-                     A, R, TG, (int)KGE_SP_, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg)
+                     A, R, TG, (int)KGE_SP_, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, nullptr)
   if (abl == 1) KGE_ABL(1);
   else if (abl == 2) KGE_ABL(2);
   else if (abl == 3) KGE_ABL(3);
@@ -432,13 +490,13 @@ int run_pairs_bf16_v2_ablate(int abl, const Operand& A, const Operand& R, const 
 
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
-                      hipStream_t st, unsigned long long* dbg) {
+                      hipStream_t st, unsigned long long* dbg, void* ws, long long ws_bytes) {
   if (n == 0 || m == 0) return KGE_OK;
 #define KGE_V2(SC)                                                                   \
   switch (d) {                                                                       \
-    case 128: return launch_v2<SC, 64>(A, R, TG, dir, n, m, out, ldo, st, dbg);      \
-    case 256: return launch_v2<SC, 128>(A, R, TG, dir, n, m, out, ldo, st, dbg);     \
-    case 512: return launch_v2<SC, 256>(A, R, TG, dir, n, m, out, ldo, st, dbg);     \
+    case 128: return launch_v2<SC, 64>(A, R, TG, dir, n, m, out, ldo, st, dbg, ws, ws_bytes); \
+    case 256: return launch_v2<SC, 128>(A, R, TG, dir, n, m, out, ldo, st, dbg, ws, ws_bytes); \
+    case 512: return launch_v2<SC, 256>(A, R, TG, dir, n, m, out, ldo, st, dbg, ws, ws_bytes); \
   }
   if (scorer == KGE_COMPLEX) { KGE_V2(KGE_COMPLEX) } else { KGE_V2(KGE_DISTMULT) }
 #undef KGE_V2

@@ -42,6 +42,26 @@ def _stream(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_WORKSPACES = {}
+
+
+def _workspace(tc, n, device, enable=True):
+    """(ptr, bytes) of the per-(device, stream) scratch buffer the bf16 path uses to build the
+    query vectors once (kge_score_workspace_bytes); (None, 0) when the call needs none.
+    Stream-ordered reuse: one buffer per stream, grown on demand through torch's allocator."""
+    if not enable:
+        return None, 0
+    need = _lib.lib().kge_score_workspace_bytes(ctypes.byref(tc), n)
+    if need <= 0:
+        return None, 0
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _empty((max(need, 1 << 20),), device, torch.uint8)
+        _WORKSPACES[key] = buf
+    return buf.data_ptr(), buf.numel()
+
+
 def _dtype_code(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return F32
@@ -75,7 +95,7 @@ class Tables:
     kge/model/embedder/lookup_embedder.py:44-46) as the kernels see them."""
 
     def __init__(self, scorer, ent: torch.Tensor, rel: torch.Tensor, l_norm: float = 1.0,
-                 flags: int = 0):
+                 flags: int = 0, use_workspace: bool = True):
         self.scorer = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
         _require_gpu(ent, "entity table")
         _require_gpu(rel, "relation table")
@@ -85,6 +105,7 @@ class Tables:
             raise TypeError("kge_amd: entity and relation tables must share a dtype")
         self.ent, self.rel = ent, rel
         self.l_norm, self.flags = float(l_norm), int(flags)
+        self.use_workspace = bool(use_workspace)  # False: fully fused single-kernel bf16 path
         self.device = ent.device
 
     def c(self, flags=None) -> KgeTables:
@@ -124,7 +145,8 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
         fn = getattr(_lib.lib(), fn_name)
         # C signatures: kge_score_sp(t, s, p, ...) but kge_score_po(t, p, o, ...)
         first, second = (ai, pi) if fn_name == "kge_score_sp" else (pi, ai)
-        _lib.check(fn(ctypes.byref(tc), first, second, n, ti, m, out.data_ptr(), ldo,
+        ws, wsb = _workspace(tc, n, t.device, t.use_workspace)
+        _lib.check(fn(ctypes.byref(tc), first, second, n, ti, m, out.data_ptr(), ldo, ws, wsb,
                       _stream(t.device)), fn_name)
     return out
 
@@ -150,8 +172,9 @@ def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Ten
     out = _empty((n, 2 * m), t.device)
     with torch.cuda.device(t.device):
         tc = t.c(flags)
+        ws, wsb = _workspace(tc, n, t.device, t.use_workspace)
         _lib.check(_lib.lib().kge_score_sp_po(ctypes.byref(tc), si, pi, oi, n, ti, m,
-                                              out.data_ptr(), 2 * m, _stream(t.device)),
+                                              out.data_ptr(), 2 * m, ws, wsb, _stream(t.device)),
                    "kge_score_sp_po")
     return out
 
@@ -200,10 +223,11 @@ def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, fl
         out = _empty((n, m), s_emb.device)
     tc = KgeTables(None, None, _dtype_code(s_emb), sc, 0, 0, d, dr, d, dr, float(l_norm), int(flags))
     with torch.cuda.device(s_emb.device):
+        ws, wsb = _workspace(tc, n, s_emb.device)
         _lib.check(_lib.lib().kge_score_emb(
             ctypes.byref(tc), code, s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(),
             p_emb.stride(0), o_emb.data_ptr(), o_emb.stride(0), n, m, out.data_ptr(), max(m, 1),
-            _stream(s_emb.device)), "kge_score_emb")
+            ws, wsb, _stream(s_emb.device)), "kge_score_emb")
     return out.view(n, -1)
 
 

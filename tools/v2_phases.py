@@ -16,7 +16,7 @@ from kge_amd import _lib, engine  # noqa: E402
 dev = torch.device("cuda", 0)
 
 
-def run(n, E=14541, R=237, d=512, reps=5, mode=0):
+def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False):
     g = torch.Generator().manual_seed(0)
     ent = torch.empty(E, d).normal_(0, 0.1, generator=g).bfloat16().to(dev)
     rel = torch.empty(R, d).normal_(0, 0.1, generator=g).bfloat16().to(dev)
@@ -28,17 +28,19 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0):
     fn = L.kge_debug_score_sp_bf16_v2
     fn.restype = ctypes.c_int
     fn.argtypes = [ctypes.POINTER(_lib.KgeTables), _lib.KgeIndex, _lib.KgeIndex, ctypes.c_int64,
-                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     keep = []
     si, pi = engine._index(s, dev, keep), engine._index(p, dev, keep)
     nwg = 4096
     stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
+    wsb = ((n + 127) // 128) * 128 * d * 2
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     tc = T.c()
     for _ in range(reps):
         stamps.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        rc = fn(ctypes.byref(tc), si, pi, n, E, out.data_ptr(), E, stamps.data_ptr(), mode,
+        rc = fn(ctypes.byref(tc), si, pi, n, E, out.data_ptr(), E, stamps.data_ptr(), mode, ws.data_ptr() if use_ws else None, wsb if use_ws else 0,
                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         b.record()
         torch.cuda.synchronize()
@@ -54,7 +56,7 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0):
     # per-workgroup relative times (counters are per XCD): median over workgroups of (stamp_i - stamp_0)
     own = (st[:, :nst] - st[:, :1]).double()
     med = own.median(dim=0).values
-    print(json.dumps({"mode": mode, "n": n, "own_median": [float(x) for x in med]}))
+    print(json.dumps({"mode": mode, "ws": use_ws, "n": n, "own_median": [float(x) for x in med]}))
     print(json.dumps({"n": n, "workgroups": int(used.sum()), "stamps": nst, "event_us": us,
                       "span_ticks": total, "ticks_per_us_if_span_eq_event": total / us}))
     names = ["start", "T0+idx+ptrs", "gathers issued"]
@@ -73,5 +75,5 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0):
 
 
 if __name__ == "__main__":
-    for n, mode in ((128, 0), (512, 0), (1024, 0), (512, 1), (512, 2), (512, 3)):
-        run(n, mode=mode)
+    for n, ws in ((128, False), (512, False), (1024, False), (128, True), (512, True), (1024, True)):
+        run(n, use_ws=ws)
