@@ -55,6 +55,17 @@ def make_inputs(rank, device, n):
             s.to(device), p.to(device), o.to(device))
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of
+    this same command (profiles/pmc_latest.json: FETCH_SIZE x2 per the gfx950 correction in
+    MI355X_MICROARCH.md + WRITE_SIZE).  bench.py itself cannot collect PMC counters."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def algorithmic_bytes(n, m, d, elt=2):
     """target rows once + query rows (s and r) + f32 scores out + indices."""
     return m * d * elt + n * (d + d) * elt + n * m * 4 + 2 * n * 8
@@ -95,7 +106,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    # KGE_BENCH_FORCE_DIST=1: exercise the sharded step (RCCL init + all-gather) with one rank
+    dist = world > 1 or os.environ.get("KGE_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if dist:
@@ -150,19 +162,29 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         el = float(tt.item())
 
-    # per-launch duration of the dominant kernel, HIP events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(2 * a.steps)]
-    for k in range(a.steps):
-        ev[2 * k][0].record()
-        engine.score_sp(T, s, p)
-        ev[2 * k][1].record()
-        ev[2 * k + 1][0].record()
-        engine.score_po(T, p, o)
-        ev[2 * k + 1][1].record()
+    # Duration of one scoring call (= one launch of the dominant kernel pairs_bf16_v2_kernel):
+    # HIP events on the launch stream bracketing a
+    # second timed region of the same K steps, divided by the 2K calls.  Back-to-back calls
+    # pipeline their launch overhead exactly as in the timed region above.
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    kern_ms = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
-    avg_ms = sum(kern_ms) / len(kern_ms)
+    e0.record()
+    for _ in range(a.steps):
+        engine.score_sp(T, s, p)
+        engine.score_po(T, p, o)
+    e1.record()
+    torch.cuda.synchronize()
+    avg_ms = e0.elapsed_time(e1) / (2 * a.steps)
+    # isolated calls (event pair around every call; includes un-hidden launch latency)
+    ev = []
+    for k in range(min(a.steps, 50)):
+        x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x0.record()
+        engine.score_sp(T, s, p)
+        x1.record()
+        ev.append((x0, x1))
+    torch.cuda.synchronize()
+    iso = sorted(x0.elapsed_time(x1) for x0, x1 in ev)
 
     if rank == 0:
         total = 2.0 * n * E_FB * world * a.steps
@@ -189,15 +211,16 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "pairs_bf16_kernel<ComplEx> (one score_sp / score_po launch)",
+                "kernel": "pairs_bf16_v2_kernel<ComplEx,d=512> (one score_sp / score_po call = one launch, "
+                          "fully fused gather + query build + contraction + score store)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": ab,
                 "avg_launch_us": avg_ms * 1e3,
-                "median_launch_us": kern_ms[len(kern_ms) // 2] * 1e3,
-                "traffic": None,
+                "isolated_call_median_us": iso[len(iso) // 2] * 1e3,
+                "traffic": pmc_traffic(),
             },
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -95,7 +95,7 @@ class Tables:
     kge/model/embedder/lookup_embedder.py:44-46) as the kernels see them."""
 
     def __init__(self, scorer, ent: torch.Tensor, rel: torch.Tensor, l_norm: float = 1.0,
-                 flags: int = 0, use_workspace: bool = True):
+                 flags: int = 0, use_workspace: bool = False):
         self.scorer = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
         _require_gpu(ent, "entity table")
         _require_gpu(rel, "relation table")
@@ -105,7 +105,10 @@ class Tables:
             raise TypeError("kge_amd: entity and relation tables must share a dtype")
         self.ent, self.rel = ent, rel
         self.l_norm, self.flags = float(l_norm), int(flags)
-        self.use_workspace = bool(use_workspace)  # False: fully fused single-kernel bf16 path
+        # False (default): fully fused single-kernel bf16 path.  True: query vectors are built
+        # once by a small builder kernel into a scratch buffer (two launches; same results,
+        # 16 + 3.5 us of kernels instead of 23 us, but the launch gap makes it a wash at n = 512)
+        self.use_workspace = bool(use_workspace)
         self.device = ent.device
 
     def c(self, flags=None) -> KgeTables:
@@ -223,7 +226,7 @@ def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, fl
         out = _empty((n, m), s_emb.device)
     tc = KgeTables(None, None, _dtype_code(s_emb), sc, 0, 0, d, dr, d, dr, float(l_norm), int(flags))
     with torch.cuda.device(s_emb.device):
-        ws, wsb = _workspace(tc, n, s_emb.device)
+        ws, wsb = _workspace(tc, n, s_emb.device, False)
         _lib.check(_lib.lib().kge_score_emb(
             ctypes.byref(tc), code, s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(),
             p_emb.stride(0), o_emb.data_ptr(), o_emb.stride(0), n, m, out.data_ptr(), max(m, 1),
