@@ -99,8 +99,10 @@ typedef enum kge_flags {
                                  f32-chain kernel instead of the bf16 MFMA kernel            */
   KGE_FLAG_NO_MFMA = 2,       /* f32 ComplEx/DistMult: VALU fmaf chain instead of the f32
                                  MFMA (same bits; used to cross-check the MFMA mapping)      */
-  KGE_FLAG_BF16_V1 = 4        /* bf16 ComplEx/DistMult: the tile-per-workgroup kernel (v1)
+  KGE_FLAG_BF16_V1 = 4,       /* bf16 ComplEx/DistMult: the tile-per-workgroup kernel (v1)
                                  instead of the row-persistent kernel (A/B measurements)     */
+  KGE_FLAG_BF16_V2 = 8        /* bf16 ComplEx/DistMult: the row-persistent kernel with
+                                 32-target tiles (v2) instead of 64-target tiles (v3)        */
 } kge_flags;
 
 /* An index vector: element i is ptr[i*stride] of type itype.
@@ -122,10 +124,13 @@ int kge_device_count(void);
 
 /* Optional device workspace for the scoring calls below.  The library never allocates:
  * a caller that passes `workspace_bytes >= kge_score_workspace_bytes(t, n)` lets the
- * bf16 ComplEx/DistMult path build the n query vectors ONCE (a small builder kernel) instead
- * of once per workgroup inside the scoring kernel; workspace == NULL (or too small) selects
- * the fully fused single-kernel path.  Results are identical.  The workspace is only used
- * during the call (stream order); 16-byte aligned. */
+ * bf16 ComplEx/DistMult path build the n query vectors ONCE -- cooperatively inside the one
+ * scoring kernel: a few workgroups build, publish through the workspace, all workgroups
+ * consume -- instead of once per workgroup.  workspace == NULL (or too small, or a call made
+ * under hipGraph stream capture) selects the path where every workgroup builds its own
+ * copy.  Results are identical bit for bit.  The workspace needs no initialisation, is only
+ * used during the call (stream order) and must not be shared by calls that may run
+ * concurrently on different streams; 16-byte aligned. */
 int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n);
 
 /* out[i] = score(s[i], p[i], o[i]), i < n.        KgeModel.score_spo */

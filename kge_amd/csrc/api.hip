@@ -20,6 +20,12 @@ int run_pairs_bf16_v2_ablate(int abl, const Operand& A, const Operand& R, const 
                              unsigned long long* dbg);
 bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
                              const Operand& TG);
+bool pairs_bf16_v3_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
+                             const Operand& TG);
+int run_pairs_bf16_v3(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
+                      int d, long long n, long long m, float* out, long long ldo, hipStream_t st,
+                      unsigned long long* dbg, void* ws, long long ws_bytes);
+long long pairs_bf16_v3_workspace_bytes(int d, long long n);
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
                       hipStream_t st, unsigned long long* dbg = nullptr, void* ws = nullptr,
@@ -82,7 +88,10 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
                    void* ws, int64_t ws_bytes, hipStream_t st) {
   const int d = (int)t->dim, dr = (int)t->rel_dim;
   if (!(t->flags & KGE_FLAG_EXACT)) {
-    if (!(t->flags & KGE_FLAG_BF16_V1) && pairs_bf16_v2_supported(t->scorer, t->dtype, d, A, R, TG))
+    const bool v1 = t->flags & KGE_FLAG_BF16_V1, v2 = t->flags & KGE_FLAG_BF16_V2;
+    if (!v1 && !v2 && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))
+      return run_pairs_bf16_v3(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
+    if (!v1 && pairs_bf16_v2_supported(t->scorer, t->dtype, d, A, R, TG))
       return run_pairs_bf16_v2(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
     if (pairs_bf16_supported(t->scorer, t->dtype, d, A, R, TG))
       return run_pairs_bf16(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
@@ -152,7 +161,8 @@ int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n) {
   if (!t || n <= 0 || t->dtype != KGE_BF16) return 0;
   if (t->scorer != KGE_COMPLEX && t->scorer != KGE_DISTMULT) return 0;
   if (t->dim != 128 && t->dim != 256 && t->dim != 512) return 0;
-  return ((n + 127) / 128) * 128 * t->dim * 2;  // bf16 query fragments, whole 128-row groups
+  // bf16 query fragments of whole 128-row groups + the publication flags of the builders
+  return pairs_bf16_v3_workspace_bytes((int)t->dim, n);
 }
 
 int kge_score_sp(const kge_tables* t, kge_index s, kge_index p, int64_t n, kge_index targets,
@@ -308,6 +318,9 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
     if (t->scorer != KGE_COMPLEX || t->dim != 512) return KGE_ERR_UNSUPPORTED;
     return run_pairs_bf16_v2_ablate(ablate, A, R, TG, n, m, out, ldo, (hipStream_t)stream, stamps);
   }
+  if (!(t->flags & KGE_FLAG_BF16_V2))
+    return run_pairs_bf16_v3(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
+                             (hipStream_t)stream, stamps, workspace, workspace_bytes);
   return run_pairs_bf16_v2(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
                            (hipStream_t)stream, stamps, workspace, workspace_bytes);
 }

@@ -15,11 +15,11 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_EXACT, FLAG_NO_MFMA, I32, I64, PO_, SCORERS, SP_, SPO, KgeIndex,
+from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_EXACT, FLAG_NO_MFMA, I32, I64, PO_, SCORERS, SP_, SPO, KgeIndex,
                    KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1"]
+           "score_emb", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2"]
 
 
 def _require_gpu(t: torch.Tensor, what: str):
@@ -95,7 +95,7 @@ class Tables:
     kge/model/embedder/lookup_embedder.py:44-46) as the kernels see them."""
 
     def __init__(self, scorer, ent: torch.Tensor, rel: torch.Tensor, l_norm: float = 1.0,
-                 flags: int = 0, use_workspace: bool = False):
+                 flags: int = 0, use_workspace: bool = True):
         self.scorer = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
         _require_gpu(ent, "entity table")
         _require_gpu(rel, "relation table")
@@ -105,9 +105,9 @@ class Tables:
             raise TypeError("kge_amd: entity and relation tables must share a dtype")
         self.ent, self.rel = ent, rel
         self.l_norm, self.flags = float(l_norm), int(flags)
-        # False (default): fully fused single-kernel bf16 path.  True: query vectors are built
-        # once by a small builder kernel into a scratch buffer (two launches; same results,
-        # 16 + 3.5 us of kernels instead of 23 us, but the launch gap makes it a wash at n = 512)
+        # True (default): the bf16 ComplEx/DistMult kernel gets a per-(device, stream) scratch
+        # buffer and builds the query vectors once, cooperatively, instead of once per
+        # workgroup (same bits, one launch either way).  False: no scratch buffer.
         self.use_workspace = bool(use_workspace)
         self.device = ent.device
 

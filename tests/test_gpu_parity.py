@@ -204,12 +204,18 @@ def test_bf16_mfma_kernel_vs_oracle(eng, model, d):
     _close("po_all", _np(eng.score_po(T, tp, to)), ko.score_po(O, p, o))
     _close("sp_po_sub", _np(eng.score_sp_po(T, ts, tp, to, _t(sub))), ko.score_sp_po(O, s, p, o, sub))
     _close("sp_sub_i32", _np(eng.score_sp(T, ts.int(), tp.int(), _t(sub).int())), ko.score_sp(O, s, p, sub))
-    # workspace path (query vectors built once by the builder kernel): identical semantics and
-    # K order -> the same bits as the fully fused default
-    Tw = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
-    Tw.use_workspace = True
-    _eq("workspace == fused", _np(eng.score_sp(Tw, ts, tp)), _np(eng.score_sp(T, ts, tp)))
-    _eq("workspace == fused (po, subset)", _np(eng.score_po(Tw, tp, to, _t(sub))), _np(eng.score_po(T, tp, to, _t(sub))))
+    # default = cooperative query build through the scratch buffer; without a buffer every
+    # workgroup builds its own copy; v2 = 32-target tiles (with buffer: separate builder
+    # kernel).  Identical semantics and K order -> the same bits everywhere.
+    Tn = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+    Tn.use_workspace = False
+    ref_sp, ref_po = _np(eng.score_sp(Tn, ts, tp)), _np(eng.score_po(Tn, tp, to, _t(sub).int()))
+    _close("sp_all (no workspace)", ref_sp, ko.score_sp(O, s, p))
+    _eq("coop == fused", _np(eng.score_sp(T, ts, tp)), ref_sp)
+    _eq("coop == fused (po, subset i32)", _np(eng.score_po(T, tp, to, _t(sub).int())), ref_po)
+    for TT, nm in ((T, "v2+builder"), (Tn, "v2 fused")):
+        _eq(f"{nm} == v3", _np(eng.score_sp(TT, ts, tp, flags=eng.FLAG_BF16_V2)), ref_sp)
+        _eq(f"{nm} == v3 (po, subset i32)", _np(eng.score_po(TT, tp, to, _t(sub).int(), flags=eng.FLAG_BF16_V2)), ref_po)
     # the tile-per-workgroup kernel (v1) computes the same thing
     _close("v1 sp_all", _np(eng.score_sp(T, ts, tp, flags=eng.FLAG_BF16_V1)), ko.score_sp(O, s, p))
     _close("v1 po_sub", _np(eng.score_po(T, tp, to, _t(sub), flags=eng.FLAG_BF16_V1)), ko.score_po(O, p, o, sub))
@@ -230,6 +236,58 @@ def test_bf16_mfma_kernel_small_and_single_row(eng):
         sub = None if msub is None else rng.permutation(E)[:msub]
         got = _np(eng.score_sp(T, _t(s), _t(p), None if sub is None else _t(sub)))
         _close(f"n={n}", got, ko.score_sp(O, s, p, sub))
+
+
+@pytest.mark.parametrize("d,n,E", [(128, 520, 3000), (512, 300, 9000), (256, 1100, 2500)])
+def test_bf16_cooperative_build_repeated_calls(eng, d, n, E):
+    """Cooperative query build: several row groups, builder shares of different sizes, the
+    same scratch buffer reused by consecutive calls with different queries (a stale fragment
+    or flag from the previous call would show), against the no-workspace path (same bits)."""
+    rng = np.random.default_rng(d + n)
+    R = 11
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    T = _gpu_tables(eng, "complex", ent, rel, 1.0, bf16=True)
+    Tn = _gpu_tables(eng, "complex", ent, rel, 1.0, bf16=True)
+    Tn.use_workspace = False
+    outs, refs = [], []
+    for it in range(6):  # back to back, no host sync in between
+        s, p = _t(rng.integers(0, E, n)), _t(rng.integers(0, R, n))
+        if it % 2:
+            outs.append(eng.score_po(T, p, s))
+            refs.append(eng.score_po(Tn, p, s))
+        else:
+            outs.append(eng.score_sp(T, s, p))
+            refs.append(eng.score_sp(Tn, s, p))
+    for it, (a, b) in enumerate(zip(outs, refs)):
+        _eq(f"call {it}", _np(a), _np(b))
+    O = _oracle_tables("complex", ent, rel, 1.0, bf16=True)
+    s, p = rng.integers(0, E, 64), rng.integers(0, R, 64)
+    _close("vs oracle", _np(eng.score_sp(T, _t(s), _t(p))), ko.score_sp(O, s, p))
+
+
+def test_bf16_under_graph_capture(eng):
+    """Under hipGraph capture the kernel arguments are frozen, so the library must not use the
+    per-launch epoch protocol: replays with new queries still give the right scores."""
+    rng = np.random.default_rng(3)
+    E, R, d, n = 2000, 7, 256, 256
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    T = _gpu_tables(eng, "distmult", ent, rel, 1.0, bf16=True)
+    Tn = _gpu_tables(eng, "distmult", ent, rel, 1.0, bf16=True)
+    Tn.use_workspace = False
+    s, p = _t(rng.integers(0, E, n)), _t(rng.integers(0, R, n))
+    eng.score_sp(T, s, p)  # warm-up outside capture (scratch buffer, module load)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = eng.score_sp(T, s, p)
+    for it in range(3):
+        s.copy_(_t(rng.integers(0, E, n)))
+        p.copy_(_t(rng.integers(0, R, n)))
+        g.replay()
+        torch.cuda.synchronize()
+        _eq(f"replay {it}", _np(out), _np(eng.score_sp(Tn, s, p)))
 
 
 @pytest.mark.parametrize("model", ["complex", "distmult", "transe", "rotate"])

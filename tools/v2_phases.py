@@ -16,13 +16,13 @@ from kge_amd import _lib, engine  # noqa: E402
 dev = torch.device("cuda", 0)
 
 
-def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False):
+def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False, flags=0):
     g = torch.Generator().manual_seed(0)
     ent = torch.empty(E, d).normal_(0, 0.1, generator=g).bfloat16().to(dev)
     rel = torch.empty(R, d).normal_(0, 0.1, generator=g).bfloat16().to(dev)
     s = torch.randint(E, (n,), generator=g).to(dev)
     p = torch.randint(R, (n,), generator=g).to(dev)
-    T = engine.Tables("complex", ent, rel)
+    T = engine.Tables("complex", ent, rel, flags=flags)
     out = torch.empty(n, E, device=dev)
     L = _lib.lib()
     fn = L.kge_debug_score_sp_bf16_v2
@@ -33,7 +33,7 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False):
     si, pi = engine._index(s, dev, keep), engine._index(p, dev, keep)
     nwg = 4096
     stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
-    wsb = ((n + 127) // 128) * 128 * d * 2
+    wsb = ((n + 127) // 128) * 128 * d * 2 + 256 * 16 * 8
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     tc = T.c()
     for _ in range(reps):
@@ -59,11 +59,14 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False):
     print(json.dumps({"mode": mode, "ws": use_ws, "n": n, "own_median": [float(x) for x in med]}))
     print(json.dumps({"n": n, "workgroups": int(used.sum()), "stamps": nst, "event_us": us,
                       "span_ticks": total, "ticks_per_us_if_span_eq_event": total / us}))
-    names = ["start", "T0+idx+ptrs", "gathers issued"]
-    passes = 4
-    for p_ in range(passes):
-        names += [f"pass{p_} landed", f"pass{p_} built"]
-    names += ["prologue done"]
+    if use_ws and not (flags & 8):
+        names = ["start", "share built+published", "tiles 0,1 issued", "flags seen", "fragments loaded"]
+    else:
+        names = ["start", "T0+idx+ptrs", "gathers issued"]
+        passes = 4
+        for p_ in range(passes):
+            names += [f"pass{p_} landed", f"pass{p_} built"]
+        names += ["prologue done"]
     k = len(names)
     tt = 0
     while len(names) < nst:
@@ -76,4 +79,7 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False):
 
 if __name__ == "__main__":
     for n, ws in ((128, False), (512, False), (1024, False), (128, True), (512, True), (1024, True)):
+        print(f"==== v3 (64-target tiles) n={n} workspace={ws}")
         run(n, use_ws=ws)
+    print("==== v2 (32-target tiles) n=512, fused")
+    run(512, flags=8)
