@@ -101,8 +101,10 @@ typedef enum kge_flags {
                                  MFMA (same bits; used to cross-check the MFMA mapping)      */
   KGE_FLAG_BF16_V1 = 4,       /* bf16 ComplEx/DistMult: the tile-per-workgroup kernel (v1)
                                  instead of the row-persistent kernel (A/B measurements)     */
-  KGE_FLAG_BF16_V2 = 8        /* bf16 ComplEx/DistMult: the row-persistent kernel with
+  KGE_FLAG_BF16_V2 = 8,       /* bf16 ComplEx/DistMult: the row-persistent kernel with
                                  32-target tiles (v2) instead of 64-target tiles (v3)        */
+  KGE_FLAG_BF16_V3 = 16       /* bf16 ComplEx/DistMult with a workspace: the single-role
+                                 kernel (v3) instead of the loader/consumer kernel (v4)      */
 } kge_flags;
 
 /* An index vector: element i is ptr[i*stride] of type itype.

@@ -26,6 +26,11 @@ int run_pairs_bf16_v3(int scorer, const Operand& A, const Operand& R, const Oper
                       int d, long long n, long long m, float* out, long long ldo, hipStream_t st,
                       unsigned long long* dbg, void* ws, long long ws_bytes);
 long long pairs_bf16_v3_workspace_bytes(int d, long long n);
+bool pairs_bf16_v4_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
+                             const Operand& TG);
+int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
+                      int d, long long n, long long m, float* out, long long ldo, hipStream_t st,
+                      unsigned long long* dbg, void* ws, long long ws_bytes);
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
                       hipStream_t st, unsigned long long* dbg = nullptr, void* ws = nullptr,
@@ -89,6 +94,11 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
   const int d = (int)t->dim, dr = (int)t->rel_dim;
   if (!(t->flags & KGE_FLAG_EXACT)) {
     const bool v1 = t->flags & KGE_FLAG_BF16_V1, v2 = t->flags & KGE_FLAG_BF16_V2;
+    if (!v1 && !v2 && !(t->flags & KGE_FLAG_BF16_V3) && ws != nullptr &&
+        pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
+      const int rc = run_pairs_bf16_v4(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
+      if (rc != KGE_ERR_UNSUPPORTED) return rc;  // else: launch conditions not met, single-role kernel
+    }
     if (!v1 && !v2 && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))
       return run_pairs_bf16_v3(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
     if (!v1 && pairs_bf16_v2_supported(t->scorer, t->dtype, d, A, R, TG))
@@ -317,6 +327,12 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
   if (ablate) {
     if (t->scorer != KGE_COMPLEX || t->dim != 512) return KGE_ERR_UNSUPPORTED;
     return run_pairs_bf16_v2_ablate(ablate, A, R, TG, n, m, out, ldo, (hipStream_t)stream, stamps);
+  }
+  if (!(t->flags & (KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) && workspace != nullptr &&
+      pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {
+    const int rc4 = run_pairs_bf16_v4(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
+                                      (hipStream_t)stream, stamps, workspace, workspace_bytes);
+    if (rc4 != KGE_ERR_UNSUPPORTED) return rc4;
   }
   if (!(t->flags & KGE_FLAG_BF16_V2))
     return run_pairs_bf16_v3(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,

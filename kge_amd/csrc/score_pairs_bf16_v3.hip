@@ -473,7 +473,7 @@ static int v3_cu_count() {
 
 long long pairs_bf16_v3_workspace_bytes(int d, long long n) {
   const long long rgn = (n + V3_ROWS - 1) / V3_ROWS;
-  return rgn * V3_ROWS * (long long)d * 2 + 256 * 16 * 8;  // fragments + flags (16 per row group)
+  return rgn * V3_ROWS * (long long)d * 2 + 256 * 64 * 8;  // fragments + flags (64 per row group)
 }
 
 template <int SCORER, int HH>

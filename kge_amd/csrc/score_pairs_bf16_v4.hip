@@ -1,0 +1,468 @@
+// score_pairs_bf16_v4.hip -- row-persistent ComplEx / DistMult sp_/_po kernel for bf16 tables,
+// d in {256, 512}, workspace given: the BASELINE.json headline path on gfx950.
+//
+// One workgroup per CU = 128 query rows x a contiguous range of 64-target tiles, 8 waves in two
+// roles (one of each per SIMD):
+//
+//   * consumer waves 0-3 (32 query rows each): hold their query fragments in MFMA operand
+//     registers for the whole kernel and do nothing but ds_read_b128 + v_mfma_f32_32x32x16_bf16
+//     (64 per tile, two accumulators); the finished accumulators go to an LDS staging buffer
+//     during the first MFMAs of the next tile;
+//   * loader waves 4-7: stream the target tiles HBM -> LDS with LDS-DMA (ring of two 64 KiB
+//     buffers, a whole tile time ahead) and move the staged scores LDS -> HBM with 16-byte
+//     stores (4 rows x 256 contiguous bytes per instruction).
+//
+// Why two roles: a vector-memory instruction blocks its wave until the texture addresser takes
+// it (64 B/clk per CU: a tile is 1,024 cycles of loads + 512 of stores against 2,100 cycles of
+// MFMA), and with one wave per SIMD that wave's MFMA pipe drains meanwhile (v3: 3,950 cycles
+// per tile).  Here the waves that block have nothing else to do.
+//
+// Query vectors: built ONCE per row group, cooperatively (first `nbuild` workgroups of the row
+// group build a share each, publish through the workspace with agent-scope write-through
+// stores + a per-workgroup flag = this launch's epoch; everybody polls the flags and loads its
+// fragments).  All workgroups are co-resident (grid <= number of CUs; the launcher checks), so
+// the spin-wait cannot deadlock.
+//
+// Synchronisation per tile: two workgroup barriers.  B1(t): tile t has landed (loaders waited
+// for their DMA) / everybody is done with tile t-1's buffer and the staging buffer has been
+// drained.  B2(t), three quarters into the MFMA chain (the loaders need about that long to
+// issue the next tile's DMA; the rest of the chain covers their stores): the scores of tile
+// t-1 are in staging.
+#include "common.hpp"
+#include <atomic>
+#include <chrono>
+#include <type_traits>
+
+namespace kge {
+
+constexpr int V4_ROWS = 128, V4_TN = 64;
+typedef float f32x4v4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void v4_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    v4_static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ unsigned int v4_pack(float lo, float hi) {
+  unsigned int r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// two coordinates per dword: (a0,a1) entity halves, (r0,r1) relation halves -> (q0,q1); every
+// product and sum rounded on its own: the bits of the oracle's build_q(), then RNE to bf16.
+template <int SCORER>
+__device__ __forceinline__ void v4_qpair(int dir, unsigned int a0, unsigned int a1,
+                                         unsigned int r0, unsigned int r1, unsigned int& q0,
+                                         unsigned int& q1) {
+  const float a0l = __uint_as_float(a0 << 16), a0h = __uint_as_float(a0 & 0xffff0000u);
+  const float a1l = __uint_as_float(a1 << 16), a1h = __uint_as_float(a1 & 0xffff0000u);
+  const float r0l = __uint_as_float(r0 << 16), r0h = __uint_as_float(r0 & 0xffff0000u);
+  const float r1l = __uint_as_float(r1 << 16), r1h = __uint_as_float(r1 & 0xffff0000u);
+  float q0l, q0h, q1l, q1h;
+  if (SCORER == KGE_DISTMULT) {
+    q0l = a0l * r0l; q0h = a0h * r0h; q1l = a1l * r1l; q1h = a1h * r1h;
+  } else if (dir == KGE_SP_) {
+    q0l = a0l * r0l - a1l * r1l; q0h = a0h * r0h - a1h * r1h;
+    q1l = a1l * r0l + a0l * r1l; q1h = a1h * r0h + a0h * r1h;
+  } else {
+    q0l = r0l * a0l + r1l * a1l; q0h = r0h * a0h + r1h * a1h;
+    q1l = r0l * a1l - r1l * a0l; q1h = r0h * a1h - r1h * a0h;
+  }
+  q0 = v4_pack(q0l, q0h);
+  q1 = v4_pack(q1l, q1h);
+}
+
+template <int MODE>
+__device__ __forceinline__ long long v4_index(const Index& ix, long long i) {
+  if (MODE == 0) return i;
+  if (MODE == 1) return (long long)((const int*)ix.ptr)[i * ix.stride];
+  return ((const long long*)ix.ptr)[i * ix.stride];
+}
+
+template <int SCORER, int HH, int TGMODE>
+__global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
+    Operand A, Operand R, Operand TG, int dir, long long n, long long m, int rgn, int ncg,
+    int tiles_per_cg, int ntiles, float* __restrict__ out, long long ldo,
+    unsigned long long* __restrict__ dbg, u32x4* __restrict__ qf,
+    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild) {
+  constexpr int NKB = 2 * HH / 16;       // K-blocks of 16
+  constexpr int NKH = HH / 16;           // K-blocks per half
+  constexpr int ROWB = 4 * HH;           // bytes per table row (2*HH bf16)
+  constexpr int SPR = HH / 4;            // 16-byte slots per row
+  constexpr int TILEB = V4_TN * ROWB;    // bytes per target tile
+  constexpr int NL = TILEB / 1024 / 4;   // 1-KiB DMA pieces per loader wave per tile
+  constexpr int RPP = 64 / SPR;          // target rows per piece
+  constexpr int CST0 = 2 * TILEB;        // score staging: 4 x [32 rows][64 cols] f32
+  constexpr int CSTW = 32 * V4_TN * 4;
+  constexpr int SMEM = CST0 + 4 * CSTW;
+  constexpr int NQ = 2 * NKB;            // MFMAs per tile (two 32-target halves)
+  constexpr int QB2 = 3 * NQ / 4;         // MFMA slot of barrier B2
+  static_assert(NL * RPP == 16 && SPR >= 32, "d in {256, 512}");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+  // ---- which rows / target tiles
+  const int b = blockIdx.x;
+  const int q8 = b >> 3;
+  const int rg = q8 % rgn;
+  const int cg = (q8 / rgn) * 8 + (b & 7);
+  if (cg >= ncg) return;
+  const int tile_lo = cg * tiles_per_cg;
+  int ntl = ntiles - tile_lo;
+  if (ntl > tiles_per_cg) ntl = tiles_per_cg;
+  if (ntl <= 0) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR)
+  const int w4 = wave & 3;  // consumer w4 and loader 4 + w4 work on query rows 32*w4 .. 32*w4+31
+  const long long row0 = (long long)rg * V4_ROWS + 32 * w4;
+
+  int dbg_i = 0;
+  auto stamp = [&]() {  // optional per-phase timestamps (tools/v2_phases.py); dbg == NULL in production
+    if (dbg != nullptr && tid == 0 && dbg_i < 64)
+      dbg[(long long)blockIdx.x * 64 + dbg_i] = __builtin_readcyclecounter();
+    ++dbg_i;
+  };
+  stamp();  // 0: kernel start
+
+  // ---- cooperative query build: this workgroup's share of the row group's rows
+  if (cg < nbuild) {
+    constexpr int CGR = HH / 8;  // groups of 8 coordinates per row
+    for (int it = cg * 512 + tid; it < V4_ROWS * CGR; it += nbuild * 512) {
+      const long long row = (long long)rg * V4_ROWS + it / CGR;
+      const int c8 = it % CGR;
+      const long long qrow = row < n ? row : n - 1;  // padded rows repeat row n-1
+      const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + c8 * 8;
+      const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + c8 * 8;
+      const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
+      const u32x4 r0 = *reinterpret_cast<const u32x4*>(r), r1 = *reinterpret_cast<const u32x4*>(r + HH);
+      u32x4 q0, q1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned int x0, x1;
+        v4_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+        q0[e] = x0;
+        q1[e] = x1;
+      }
+      // fragment-major: K-block kb of 32-row block rb is 64 lanes x 16 B, contiguous.  Agent-scope
+      // (sc1) write-through stores: visible to the other XCDs' L2s once acknowledged, without
+      // the whole-L2 write-back of a release fence.  A 128-byte line (8 rows x 16 B) is
+      // written by one workgroup only.
+      u32x4* dst = qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (c8 >> 1) * 64), "v"(q0) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (NKH + (c8 >> 1)) * 64), "v"(q1)
+                   : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread: its stores are acknowledged ...
+    __syncthreads();                                  // ... before thread 0 publishes
+    if (tid == 0)
+      __hip_atomic_store(flags + rg * 16 + cg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  stamp();  // 1: share built and published
+
+  if (wave >= 4) {
+    // =================================== loader waves ===================================
+    const unsigned short* tgb = (const unsigned short*)TG.base;
+    const long long tld2 = TG.ld * 2;  // row stride in bytes
+    const int nfull = (int)(m / V4_TN);  // tiles below this index are fully inside the table
+    // LDS image of a tile: [row][16-B slot], lane-linear for the DMA; the XOR swizzle
+    // (slot ^ (row & 15)) is applied on the SOURCE address.  Piece k of this wave: rows
+    // 16*w4 + RPP*k + lr, so row & 15 = RPP*k | lr.
+    const int lr = lane / SPR, slot = lane % SPR;
+    unsigned int dvoff[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k)
+      dvoff[k] = (unsigned int)(lr * (int)tld2) + (unsigned int)(((slot ^ lr) << 4) ^ ((RPP * k) << 4));
+    auto tile_dma = [&](int tt) {  // this wave's NL pieces of tile tt into ring buffer tt & 1
+      const int tc = tt < ntl ? tt : ntl - 1;
+      const long long trow0 = (long long)(tile_lo + tc) * V4_TN;
+      unsigned int d = (unsigned int)((tt & 1) * TILEB + w4 * NL * 1024);
+      if (TGMODE == 0 && tile_lo + tc < nfull && tld2 < (1LL << 28)) {
+        // all targets, tile fully inside the table: uniform base (SGPRs) + per-lane 32-bit offset
+        const unsigned char* p = (const unsigned char*)tgb + (trow0 + w4 * 16) * tld2;
+        v4_static_for<0, NL>([&](auto kc) __attribute__((always_inline)) {
+          const unsigned int vo = dvoff[decltype(kc)::value];
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                       :
+                       : "s"(d), "v"(vo), "s"(p)
+                       : "memory", "m0");
+          p += RPP * tld2;
+          d += 1024;
+        });
+      } else {  // index vector and / or ragged end of the table (rows clamped to m-1)
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          const int row = w4 * 16 + RPP * k + lr;
+          long long tr = trow0 + row;
+          if (tr >= m) tr = m - 1;
+          const unsigned short* src = tgb + v4_index<TGMODE>(TG.idx, tr) * TG.ld + ((slot ^ (row & 15)) << 3);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(smem + d + k * 1024),
+                                           16, 0, 0);
+        }
+      }
+    };
+    tile_dma(0);
+    if (ntl > 1) tile_dma(1);
+    __builtin_amdgcn_s_barrier();  // B0: consumer wave 0 has seen the builders' flags
+
+    // staged scores of consumer w4: [32 rows][16 chunks of 16 B], chunk c of row r at c ^ (r & 15).
+    // Store i (0..7): rows 4i + (lane >> 4), chunk lane & 15: 4 rows x 256 contiguous bytes.
+    const int cl = lane & 15, rq = lane >> 4;
+    const unsigned int crd = (unsigned int)(CST0 + w4 * CSTW + rq * 256);
+    const int z = cl ^ rq;  // (cl ^ (row & 15)) = z ^ ((4i) & 15)
+    const long long rb = row0 < n ? row0 : n - 1;
+    unsigned int svoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      long long r = row0 + 4 * i + rq;
+      if (r >= n) r = n - 1;  // clamped rows rewrite the bits of row n-1 (same store count for every tile)
+      svoff[i] = (unsigned int)((r - rb) * ldo * 4) + (unsigned int)(cl * 16);
+    }
+    unsigned char* const out_rb = (unsigned char*)(out + rb * ldo);
+    auto store_tile = [&](int tt) {
+      const long long col0 = (long long)(tile_lo + tt) * V4_TN;
+      f32x4 cv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        cv[i] = *reinterpret_cast<const f32x4*>(smem + crd + i * 1024 + ((z ^ ((4 * i) & 15)) << 4));
+      if (col0 + V4_TN <= m) {
+        unsigned char* sbase = out_rb + col0 * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4v4u*>(sbase + svoff[i]) = cv[i];
+      } else {  // ragged end of the table (always this workgroup's last tile)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col0 + 4 * cl + e < m)
+              *reinterpret_cast<float*>(out_rb + (col0 + e) * 4 + svoff[i]) = cv[i][e];
+      }
+    };
+
+    auto lstamp = [&](int slot) {  // loader-side timestamps (wave 4), slots 32..63
+      if (dbg != nullptr && tid == 256 && slot < 64) dbg[(long long)blockIdx.x * 64 + slot] = __builtin_readcyclecounter();
+    };
+    for (int tt = 0; tt <= ntl; ++tt) {
+      // in-order VMEM queue of this wave: step 0: [tile 0][tile 1]; step 1: [tile 1]; later:
+      // [tile tt (NL pieces)][8 stores of tile tt-2] -- the stores may stay in flight
+      if (tt == 0) {
+        if (ntl > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (tt == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (tt < ntl) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads of the previous step are done
+      lstamp(32 + 4 * tt);  // tile tt landed (this wave's pieces)
+      __builtin_amdgcn_s_barrier();  // B1(tt)
+      lstamp(33 + 4 * tt);
+      if (tt >= 1 && tt + 1 < ntl) tile_dma(tt + 1);  // into the buffer tile tt-1 was read from
+      lstamp(34 + 4 * tt);  // DMA of tile tt+1 issued
+      __builtin_amdgcn_s_barrier();  // B2(tt): scores of tile tt-1 are staged
+      if (tt >= 1) store_tile(tt - 1);
+      lstamp(35 + 4 * tt);  // stores of tile tt-1 issued
+    }
+    return;
+  }
+
+  // =================================== consumer waves ===================================
+  const int fi = lane & 31, fh = lane >> 5;
+  bf16x8 afr[NKB];
+  if (wave == 0) {
+    // ONE wave per workgroup polls (255 pollers already cost chip bandwidth): one flag per builder
+    const unsigned long long* f = flags + rg * 16;
+    for (int spin = 0; spin < (1 << 24); ++spin) {  // bounded: a lost builder must not hang the GPU
+      const unsigned long long v =
+          lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+      if (__all(v == epoch)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published
+  stamp();  // 2: all shares of this row group published
+  {
+    // The builders stored with sc1 (write-through); sc1 loads (served by L2, never by this CU's
+    // L1) complete the hand-off without an acquire fence.  The 32 loads are NOT waited for here:
+    // the MFMA chain of the first tile waits for fragment kb right before it needs it.
+    const unsigned char* sb =
+        (const unsigned char*)(qf + ((long long)(rg * (V4_ROWS / 32) + w4) * NKB) * 64);  // uniform
+    auto fload = [](bf16x8& dst, unsigned int vo, const unsigned char* base) __attribute__((always_inline)) {
+      asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
+    };
+    v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      fload(afr[kb], (unsigned int)(lane * 16 + kb * 1024), sb);
+    });
+  }
+  // B fragment (K-block kb, half hf) of target row 32*hf + fi: 16-B slot s = s0(kb) + fh, stored
+  // at slot s ^ (fi & 15): with s = 16*a + b the swizzle only touches b -> 8 address registers
+  // plus immediates a*256 + hf*32*ROWB.
+  unsigned int boff[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) boff[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
+  // staging: acc[4g + e] = score(query fi, target 32*hf + 8g + 4fh + e) -> chunk (8hf + 2g) | fh of
+  // row fi, stored at chunk ^ (fi & 15) = (8hf + 2g) ^ y
+  const unsigned int cwr = (unsigned int)(CST0 + w4 * CSTW + fi * 256);
+  const int y = fh ^ (fi & 15);
+  auto c_write = [&](const f32x16& acc, int hf, int g) {
+    f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    *reinterpret_cast<f32x4*>(smem + cwr + (((8 * hf + 2 * g) ^ y) << 4)) = v;
+  };
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+  stamp();  // 3: fragment loads issued
+
+  constexpr int PF = 8;
+  for (int tt = 0; tt < ntl; ++tt) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; staging drained
+    __builtin_amdgcn_sched_barrier(0);
+    stamp();  // tile tt released
+    const unsigned int bt = (unsigned int)((tt & 1) * TILEB);
+    unsigned int bp[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bp[t] = bt + boff[t];
+    bf16x8 bq[PF];
+    auto bread = [&](bf16x8& dst, auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int kb = q >> 1, hf = q & 1;
+      constexpr int s0 = (kb < NKH) ? (2 * kb) : (HH / 8 + 2 * (kb - NKH));
+      const unsigned int addr = bp[(s0 & 15) >> 1];
+      asm volatile("ds_read_b128 %0, %1 offset:%2"
+                   : "=v"(dst)
+                   : "v"(addr), "i"((s0 >> 4) * 256 + hf * 32 * ROWB)
+                   : "memory");
+    };
+    v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
+    // the PREVIOUS tile's scores -> staging, behind the first reads of this tile in the LDS queue
+    // (tile 0 stages zeros that nobody reads: one schedule for every tile)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) c_write(acc1, 1, g);
+    // LDS ops younger than read q when slot q waits: q < 8: the rest of the prefetch, the 8
+    // writes and the reads of slots 0..q-1 = 15; q >= 8: min(7, NQ-1-q) reads
+    v4_static_for<0, NQ>([&](auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;
+      constexpr int younger = q < 8 ? 15 : ((NQ - 1 - q >= PF - 1) ? PF - 1 : NQ - 1 - q);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(younger) : "memory");
+      // first tile: fragment kb has arrived (in-order returns: at most NKB-1-kb younger loads
+      // outstanding); a no-op afterwards
+      if constexpr ((q & 1) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NKB - 1 - (q >> 1)) : "memory");
+      if constexpr (q == QB2) __builtin_amdgcn_s_barrier();  // B2(tt): the scores of tile tt-1 are staged
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (q == 0) {
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[0], afr[0], zero, 0, 0, 0);
+      } else if constexpr (q == 1) {
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[1], afr[0], zero, 0, 0, 0);
+      } else if constexpr (q & 1) {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[q % PF], afr[q >> 1], acc1, 0, 0, 0);
+      } else {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[q % PF], afr[q >> 1], acc0, 0, 0, 0);
+      }
+      if constexpr (q + PF < NQ) bread(bq[q % PF], std::integral_constant<int, q + PF>{});
+    });
+    stamp();  // tile tt: MFMA chain issued
+  }
+  // the last tile's scores: stage them for the loaders' final pass
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // B1(ntl)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) c_write(acc1, 1, g);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // B2(ntl)
+}
+
+static inline bool v4_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+static std::atomic<unsigned long long> g_v4_epoch{0};
+
+static int v4_cu_count() {
+  static int cus = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return v;
+  }();
+  return cus;
+}
+
+template <int SCORER, int HH>
+static int launch_v4(const Operand& A, const Operand& R, const Operand& TG, int dir, long long n,
+                     long long m, float* out, long long ldo, hipStream_t st,
+                     unsigned long long* dbg, void* ws, long long ws_bytes) {
+  const int rgn = (int)((n + V4_ROWS - 1) / V4_ROWS);
+  const int ntiles = (int)((m + V4_TN - 1) / V4_TN);
+  // one workgroup per CU (256 CUs): split the target tiles into column groups
+  int ncg = 256 / rgn;
+  if (ncg < 1) ncg = 1;
+  int tpc = (ntiles + ncg - 1) / ncg;
+  if (tpc < 1) tpc = 1;
+  ncg = (ntiles + tpc - 1) / tpc;
+  const int grid = 8 * rgn * ((ncg + 7) / 8);
+  const int tgmode = TG.idx.ptr == nullptr ? 0 : (TG.idx.itype ? 2 : 1);
+  // needs: the workspace, every workgroup resident at once (spin-wait on the builders' flags),
+  // a fresh epoch per launch (so not under graph capture, where kernel arguments are frozen)
+  const long long qf_bytes = (long long)rgn * V4_ROWS * HH * 4;
+  if (ws == nullptr || !v4_al16(ws) || rgn > 256 || ws_bytes < qf_bytes + 256 * 16 * 8 ||
+      grid > v4_cu_count() || ldo >= (1LL << 24))
+    return KGE_ERR_UNSUPPORTED;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+    return KGE_ERR_UNSUPPORTED;
+  u32x4* qf = (u32x4*)ws;
+  unsigned long long* flags = (unsigned long long*)((char*)ws + qf_bytes);
+  static const unsigned long long seed =
+      (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20;
+  const unsigned long long epoch = seed + ++g_v4_epoch;
+  int nbuild = ncg < 8 ? ncg : 8;
+  const int items = V4_ROWS * (HH / 8);  // at least one item per builder thread
+  while (nbuild > 1 && nbuild * 512 > items) --nbuild;
+#define KGE_V4L(MODE)                                                                          \
+  hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE>), dim3(grid), dim3(512), 0, st, A, \
+                     R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, qf, flags, epoch,  \
+                     nbuild)
+  if (tgmode == 0) KGE_V4L(0);
+  else if (tgmode == 1) KGE_V4L(1);
+  else KGE_V4L(2);
+#undef KGE_V4L
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+bool pairs_bf16_v4_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
+                             const Operand& TG) {
+  if (dtype != KGE_BF16) return false;
+  if (scorer != KGE_COMPLEX && scorer != KGE_DISTMULT) return false;
+  if (d != 256 && d != 512) return false;
+  if (!v4_al16(A.base) || !v4_al16(R.base) || !v4_al16(TG.base)) return false;
+  if ((A.ld % 8) || (R.ld % 8) || (TG.ld % 8)) return false;
+  return true;
+}
+
+// KGE_ERR_UNSUPPORTED: the caller falls back to the single-role kernel (v3)
+int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
+                      int d, long long n, long long m, float* out, long long ldo, hipStream_t st,
+                      unsigned long long* dbg, void* ws, long long ws_bytes) {
+  if (n == 0 || m == 0) return KGE_OK;
+#define KGE_V4(SC)                                                                             \
+  switch (d) {                                                                                 \
+    case 256: return launch_v4<SC, 128>(A, R, TG, dir, n, m, out, ldo, st, dbg, ws, ws_bytes);  \
+    case 512: return launch_v4<SC, 256>(A, R, TG, dir, n, m, out, ldo, st, dbg, ws, ws_bytes);  \
+  }
+  if (scorer == KGE_COMPLEX) { KGE_V4(KGE_COMPLEX) } else { KGE_V4(KGE_DISTMULT) }
+#undef KGE_V4
+  return KGE_ERR_UNSUPPORTED;
+}
+
+}  // namespace kge

@@ -15,11 +15,11 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_EXACT, FLAG_NO_MFMA, I32, I64, PO_, SCORERS, SP_, SPO, KgeIndex,
+from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_BF16_V3, FLAG_EXACT, FLAG_NO_MFMA, I32, I64, PO_, SCORERS, SP_, SPO, KgeIndex,
                    KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2"]
+           "score_emb", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3"]
 
 
 def _require_gpu(t: torch.Tensor, what: str):

@@ -213,6 +213,8 @@ def test_bf16_mfma_kernel_vs_oracle(eng, model, d):
     _close("sp_all (no workspace)", ref_sp, ko.score_sp(O, s, p))
     _eq("coop == fused", _np(eng.score_sp(T, ts, tp)), ref_sp)
     _eq("coop == fused (po, subset i32)", _np(eng.score_po(T, tp, to, _t(sub).int())), ref_po)
+    _eq("v3 coop == fused", _np(eng.score_sp(T, ts, tp, flags=eng.FLAG_BF16_V3)), ref_sp)
+    _eq("v3 coop == fused (po, subset i32)", _np(eng.score_po(T, tp, to, _t(sub).int(), flags=eng.FLAG_BF16_V3)), ref_po)
     for TT, nm in ((T, "v2+builder"), (Tn, "v2 fused")):
         _eq(f"{nm} == v3", _np(eng.score_sp(TT, ts, tp, flags=eng.FLAG_BF16_V2)), ref_sp)
         _eq(f"{nm} == v3 (po, subset i32)", _np(eng.score_po(TT, tp, to, _t(sub).int(), flags=eng.FLAG_BF16_V2)), ref_po)

@@ -33,7 +33,7 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False, flags=0):
     si, pi = engine._index(s, dev, keep), engine._index(p, dev, keep)
     nwg = 4096
     stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
-    wsb = ((n + 127) // 128) * 128 * d * 2 + 256 * 16 * 8
+    wsb = ((n + 127) // 128) * 128 * d * 2 + 256 * 64 * 8
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     tc = T.c()
     for _ in range(reps):
@@ -46,6 +46,23 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False, flags=0):
         torch.cuda.synchronize()
         assert rc == 0, rc
     st = stamps.view(nwg, 64).cpu()
+    ld = st[:, 32] != 0
+    if bool(ld.any()):
+        bb = st[ld]
+        nm4 = ["landed", "B1 passed", "dma issued", "stores issued"]
+        for c in range(32, 64):
+            if not bool((bb[:, c] != 0).all()):
+                break
+            d = (bb[:, c] - bb[:, 0]).double()
+            print(f"  loader step {(c - 32) // 4} {nm4[(c - 32) % 4]:<14s} median {float(d.median()):8.0f}")
+    st[:, 32:60] = 0
+    bld = st[:, 60] != 0
+    if bool(bld.any()):
+        bb = st[bld]
+        for nm, col in (("idx loaded", 60), ("rows gathered", 61), ("stores acked", 62)):
+            d = (bb[:, col] - bb[:, 0]).double()
+            print(f"  builder ({int(bld.sum())} wgs) {nm:<14s} median {float(d.median()):8.0f}  min {float(d.min()):8.0f}  max {float(d.max()):8.0f}")
+    st[:, 60:] = 0
     used = st[:, 0] != 0
     st = st[used]
     t0 = st[:, 0].min()
@@ -59,7 +76,9 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False, flags=0):
     print(json.dumps({"mode": mode, "ws": use_ws, "n": n, "own_median": [float(x) for x in med]}))
     print(json.dumps({"n": n, "workgroups": int(used.sum()), "stamps": nst, "event_us": us,
                       "span_ticks": total, "ticks_per_us_if_span_eq_event": total / us}))
-    if use_ws and not (flags & 8):
+    if use_ws and not (flags & 24):
+        names = ["start", "share built+published", "flags seen", "fragment loads issued"]
+    elif use_ws and not (flags & 8):
         names = ["start", "share built+published", "tiles 0,1 issued", "flags seen", "fragments loaded"]
     else:
         names = ["start", "T0+idx+ptrs", "gathers issued"]
@@ -79,7 +98,9 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False, flags=0):
 
 if __name__ == "__main__":
     for n, ws in ((128, False), (512, False), (1024, False), (128, True), (512, True), (1024, True)):
-        print(f"==== v3 (64-target tiles) n={n} workspace={ws}")
+        print(f"==== {'v4 (loader/consumer waves)' if ws else 'v3 (64-target tiles)'} n={n} workspace={ws}")
         run(n, use_ws=ws)
+    print("==== v3 (single role, cooperative build) n=512 workspace=True")
+    run(512, use_ws=True, flags=16)
     print("==== v2 (32-target tiles) n=512, fused")
     run(512, flags=8)
