@@ -162,7 +162,7 @@ def main():
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         el = float(tt.item())
 
-    # Duration of one scoring call (= one launch of the dominant kernel pairs_bf16_v2_kernel):
+    # Duration of one scoring call (= one launch of the dominant kernel pairs_bf16_v4_kernel):
     # HIP events on the launch stream bracketing a
     # second timed region of the same K steps, divided by the 2K calls.  Back-to-back calls
     # pipeline their launch overhead exactly as in the timed region above.
@@ -211,8 +211,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "pairs_bf16_v2_kernel<ComplEx,d=512> (one score_sp / score_po call = one launch, "
-                          "fully fused gather + query build + contraction + score store)",
+                "kernel": "pairs_bf16_v4_kernel<ComplEx,d=512> (one score_sp / score_po call = one launch: "
+                          "gather + cooperative query build + MFMA contraction + score store)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

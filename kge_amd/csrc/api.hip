@@ -28,9 +28,10 @@ int run_pairs_bf16_v3(int scorer, const Operand& A, const Operand& R, const Oper
 long long pairs_bf16_v3_workspace_bytes(int d, long long n);
 bool pairs_bf16_v4_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
                              const Operand& TG);
-int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
-                      int d, long long n, long long m, float* out, long long ldo, hipStream_t st,
-                      unsigned long long* dbg, void* ws, long long ws_bytes);
+int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Operand& R,
+                      const Operand& TG, int dir, int d, long long n, long long m, float* out,
+                      long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
+                      void* ws, long long ws_bytes);
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
                       hipStream_t st, unsigned long long* dbg = nullptr, void* ws = nullptr,
@@ -96,7 +97,8 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
     const bool v1 = t->flags & KGE_FLAG_BF16_V1, v2 = t->flags & KGE_FLAG_BF16_V2;
     if (!v1 && !v2 && !(t->flags & KGE_FLAG_BF16_V3) && ws != nullptr &&
         pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
-      const int rc = run_pairs_bf16_v4(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
+      const int rc = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr,
+                                       ws, ws_bytes);
       if (rc != KGE_ERR_UNSUPPORTED) return rc;  // else: launch conditions not met, single-role kernel
     }
     if (!v1 && !v2 && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))
@@ -191,6 +193,21 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
                     kge_index targets, int64_t m, float* out, int64_t ldo, void* workspace,
                     int64_t workspace_bytes, void* stream) {
   if (ldo < 2 * m) return KGE_ERR_INVALID_ARG;
+  // one two-sided launch of the loader/consumer kernel when it applies: the query build, the
+  // kernel start-up and the launch overhead are paid once for both score blocks
+  if (t && workspace && n > 0 && m > 0 && out && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 |
+                                                                KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) &&
+      check_tables(t, true) == KGE_OK && check_index(s, false) == KGE_OK &&
+      check_index(p, false) == KGE_OK && check_index(o, false) == KGE_OK &&
+      check_index(targets, true) == KGE_OK && (targets.ptr || m == t->num_ent)) {
+    Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, targets);
+    if (pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
+        pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
+      const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
+                                        (hipStream_t)stream, nullptr, workspace, workspace_bytes);
+      if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;
+    }
+  }
   int rc = pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, workspace, workspace_bytes, stream);
   if (rc) return rc;
   return pairs_entry(t, KGE_PO_, o, p, n, targets, m, out ? out + m : out, ldo, workspace,
@@ -330,8 +347,8 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
   }
   if (!(t->flags & (KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) && workspace != nullptr &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {
-    const int rc4 = run_pairs_bf16_v4(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
-                                      (hipStream_t)stream, stamps, workspace, workspace_bytes);
+    const int rc4 = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
+                                      0, (hipStream_t)stream, stamps, workspace, workspace_bytes);
     if (rc4 != KGE_ERR_UNSUPPORTED) return rc4;
   }
   if (!(t->flags & KGE_FLAG_BF16_V2))

@@ -472,8 +472,9 @@ static int v3_cu_count() {
 }
 
 long long pairs_bf16_v3_workspace_bytes(int d, long long n) {
-  const long long rgn = (n + V3_ROWS - 1) / V3_ROWS;
-  return rgn * V3_ROWS * (long long)d * 2 + 256 * 64 * 8;  // fragments + flags (64 per row group)
+  // fragments of whole 128-row groups, both sides of a score_sp_po call, + the builders' flags
+  const long long rgn = 2 * ((n + V3_ROWS - 1) / V3_ROWS);
+  return rgn * V3_ROWS * (long long)d * 2 + 512 * 8 * 8;
 }
 
 template <int SCORER, int HH>

@@ -85,9 +85,9 @@ __device__ __forceinline__ long long v4_index(const Index& ix, long long i) {
 
 template <int SCORER, int HH, int TGMODE>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
-    Operand A, Operand R, Operand TG, int dir, long long n, long long m, int rgn, int ncg,
-    int tiles_per_cg, int ntiles, float* __restrict__ out, long long ldo,
-    unsigned long long* __restrict__ dbg, u32x4* __restrict__ qf,
+    Operand A, Operand A2, Operand R, Operand TG, int dir, long long n, long long m, int rgn,
+    int rgn1, long long out2_off, int ncg, int tiles_per_cg, int ntiles, float* __restrict__ out,
+    long long ldo, unsigned long long* __restrict__ dbg, u32x4* __restrict__ qf,
     unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild) {
   constexpr int NKB = 2 * HH / 16;       // K-blocks of 16
   constexpr int NKH = HH / 16;           // K-blocks per half
@@ -118,7 +118,17 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR)
   const int w4 = wave & 3;  // consumer w4 and loader 4 + w4 work on query rows 32*w4 .. 32*w4+31
-  const long long row0 = (long long)rg * V4_ROWS + 32 * w4;
+  // Two-sided launch (score_sp_po, EntityRankingJob's call): row groups [0, rgn1) are the n
+  // (s, p, ?) queries, row groups [rgn1, rgn) the n (?, p, o) queries, scored into the column
+  // block behind the first one.  One-sided: rgn1 == rgn.
+  const bool second = rg >= rgn1;
+  const int rgl = second ? rg - rgn1 : rg;
+  if (second) {
+    A = A2;
+    dir = KGE_PO_;
+    out += out2_off;
+  }
+  const long long row0 = (long long)rgl * V4_ROWS + 32 * w4;  // first query row (within its side)
 
   int dbg_i = 0;
   auto stamp = [&]() {  // optional per-phase timestamps (tools/v2_phases.py); dbg == NULL in production
@@ -132,9 +142,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   if (cg < nbuild) {
     constexpr int CGR = HH / 8;  // groups of 8 coordinates per row
     for (int it = cg * 512 + tid; it < V4_ROWS * CGR; it += nbuild * 512) {
-      const long long row = (long long)rg * V4_ROWS + it / CGR;
+      const long long row = (long long)rg * V4_ROWS + it / CGR;  // row of the fragment workspace
+      const long long lrow = (long long)rgl * V4_ROWS + it / CGR;  // query row within its side
       const int c8 = it % CGR;
-      const long long qrow = row < n ? row : n - 1;  // padded rows repeat row n-1
+      const long long qrow = lrow < n ? lrow : n - 1;  // padded rows repeat row n-1
       const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + c8 * 8;
       const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + c8 * 8;
       const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
@@ -157,9 +168,13 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
                    : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread: its stores are acknowledged ...
-    __syncthreads();                                  // ... before thread 0 publishes
-    if (tid == 0)
-      __hip_atomic_store(flags + rg * 16 + cg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                  // ... before wave 0 publishes
+    // one flag per (consumer workgroup, builder): every consumer polls a 64-byte line of its own
+    // (64 pollers on one line serialise at its memory channel)
+    if (wave == 0)
+      for (int c = lane; c < ncg; c += 64)
+        __hip_atomic_store(flags + ((long long)rg * ncg + c) * 8 + cg, epoch, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
   }
   stamp();  // 1: share built and published
 
@@ -275,12 +290,12 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   bf16x8 afr[NKB];
   if (wave == 0) {
     // ONE wave per workgroup polls (255 pollers already cost chip bandwidth): one flag per builder
-    const unsigned long long* f = flags + rg * 16;
+    const unsigned long long* f = flags + ((long long)rg * ncg + cg) * 8;
     for (int spin = 0; spin < (1 << 24); ++spin) {  // bounded: a lost builder must not hang the GPU
       const unsigned long long v =
           lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
       if (__all(v == epoch)) break;
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
     }
   }
   __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published
@@ -398,11 +413,14 @@ static int v4_cu_count() {
   return cus;
 }
 
+// A2 != nullptr: two-sided launch (A = subjects scored sp_, A2 = objects scored _po into the
+// column block `out2_off` floats behind).
 template <int SCORER, int HH>
-static int launch_v4(const Operand& A, const Operand& R, const Operand& TG, int dir, long long n,
-                     long long m, float* out, long long ldo, hipStream_t st,
-                     unsigned long long* dbg, void* ws, long long ws_bytes) {
-  const int rgn = (int)((n + V4_ROWS - 1) / V4_ROWS);
+static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
+                     long long n, long long m, float* out, long long ldo, long long out2_off,
+                     hipStream_t st, unsigned long long* dbg, void* ws, long long ws_bytes) {
+  const int rgn1 = (int)((n + V4_ROWS - 1) / V4_ROWS);
+  const int rgn = A2 ? 2 * rgn1 : rgn1;
   const int ntiles = (int)((m + V4_TN - 1) / V4_TN);
   // one workgroup per CU (256 CUs): split the target tiles into column groups
   int ncg = 256 / rgn;
@@ -415,7 +433,7 @@ static int launch_v4(const Operand& A, const Operand& R, const Operand& TG, int 
   // needs: the workspace, every workgroup resident at once (spin-wait on the builders' flags),
   // a fresh epoch per launch (so not under graph capture, where kernel arguments are frozen)
   const long long qf_bytes = (long long)rgn * V4_ROWS * HH * 4;
-  if (ws == nullptr || !v4_al16(ws) || rgn > 256 || ws_bytes < qf_bytes + 256 * 16 * 8 ||
+  if (ws == nullptr || !v4_al16(ws) || (long long)rgn * ncg > 512 || ws_bytes < qf_bytes + 512 * 8 * 8 ||
       grid > v4_cu_count() || ldo >= (1LL << 24))
     return KGE_ERR_UNSUPPORTED;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -429,10 +447,11 @@ static int launch_v4(const Operand& A, const Operand& R, const Operand& TG, int 
   int nbuild = ncg < 8 ? ncg : 8;
   const int items = V4_ROWS * (HH / 8);  // at least one item per builder thread
   while (nbuild > 1 && nbuild * 512 > items) --nbuild;
+  const Operand& AA2 = A2 ? *A2 : A;
 #define KGE_V4L(MODE)                                                                          \
   hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE>), dim3(grid), dim3(512), 0, st, A, \
-                     R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, qf, flags, epoch,  \
-                     nbuild)
+                     AA2, R, TG, dir, n, m, rgn, rgn1, out2_off, ncg, tpc, ntiles, out, ldo,    \
+                     dbg, qf, flags, epoch, nbuild)
   if (tgmode == 0) KGE_V4L(0);
   else if (tgmode == 1) KGE_V4L(1);
   else KGE_V4L(2);
@@ -450,15 +469,18 @@ bool pairs_bf16_v4_supported(int scorer, int dtype, int d, const Operand& A, con
   return true;
 }
 
-// KGE_ERR_UNSUPPORTED: the caller falls back to the single-role kernel (v3)
-int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
-                      int d, long long n, long long m, float* out, long long ldo, hipStream_t st,
-                      unsigned long long* dbg, void* ws, long long ws_bytes) {
+// KGE_ERR_UNSUPPORTED: the caller falls back to the single-role kernel (v3).  A2: see launch_v4.
+int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Operand& R,
+                      const Operand& TG, int dir, int d, long long n, long long m, float* out,
+                      long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
+                      void* ws, long long ws_bytes) {
   if (n == 0 || m == 0) return KGE_OK;
-#define KGE_V4(SC)                                                                             \
-  switch (d) {                                                                                 \
-    case 256: return launch_v4<SC, 128>(A, R, TG, dir, n, m, out, ldo, st, dbg, ws, ws_bytes);  \
-    case 512: return launch_v4<SC, 256>(A, R, TG, dir, n, m, out, ldo, st, dbg, ws, ws_bytes);  \
+#define KGE_V4(SC)                                                                                 \
+  switch (d) {                                                                                     \
+    case 256:                                                                                      \
+      return launch_v4<SC, 128>(A, A2, R, TG, dir, n, m, out, ldo, out2_off, st, dbg, ws, ws_bytes); \
+    case 512:                                                                                      \
+      return launch_v4<SC, 256>(A, A2, R, TG, dir, n, m, out, ldo, out2_off, st, dbg, ws, ws_bytes); \
   }
   if (scorer == KGE_COMPLEX) { KGE_V4(KGE_COMPLEX) } else { KGE_V4(KGE_DISTMULT) }
 #undef KGE_V4

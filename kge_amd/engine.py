@@ -38,23 +38,54 @@ def _empty(shape, device, dtype=torch.float32):
         raise RuntimeError("CUDA out of memory (kge_amd: " + str(e) + ")") from e
 
 
+_raw_stream_fn = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_handle(device) -> int:
+    """Raw hipStream_t of torch's current stream on `device` (the fast C entry when torch has it:
+    torch.cuda.current_stream() builds a Python Stream object, ~4 us per call)."""
+    if _raw_stream_fn is not None:
+        return _raw_stream_fn(device.index)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(_stream_handle(device))
+
+
+class _on_device:
+    """`with torch.cuda.device(d)` only when d is not already current (the context manager
+    costs ~3 us, the scoring calls are ~15 us of GPU time)."""
+
+    def __init__(self, device):
+        self.ctx = None if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 _WORKSPACES = {}
+_WS_NEED = {}
 
 
-def _workspace(tc, n, device, enable=True):
+def _workspace(tc, n, device, enable=True, stream=None):
     """(ptr, bytes) of the per-(device, stream) scratch buffer the bf16 path uses to build the
     query vectors once (kge_score_workspace_bytes); (None, 0) when the call needs none.
     Stream-ordered reuse: one buffer per stream, grown on demand through torch's allocator."""
     if not enable:
         return None, 0
-    need = _lib.lib().kge_score_workspace_bytes(ctypes.byref(tc), n)
+    nk = (tc.dtype, tc.scorer, tc.dim, n)
+    need = _WS_NEED.get(nk)
+    if need is None:
+        need = _WS_NEED[nk] = _lib.lib().kge_score_workspace_bytes(ctypes.byref(tc), n)
     if need <= 0:
         return None, 0
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_handle(device) if stream is None else stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < need:
         buf = _empty((max(need, 1 << 20),), device, torch.uint8)
@@ -110,12 +141,20 @@ class Tables:
         # workgroup (same bits, one launch either way).  False: no scratch buffer.
         self.use_workspace = bool(use_workspace)
         self.device = ent.device
+        self._c_cache = {}
 
     def c(self, flags=None) -> KgeTables:
+        """The C view of the tables; cached per flags value (rebuilt if a table was re-allocated)."""
         e, r = self.ent, self.rel
-        return KgeTables(e.data_ptr(), r.data_ptr(), _dtype_code(e), self.scorer, e.shape[0],
-                         r.shape[0], e.shape[1], r.shape[1], e.stride(0), r.stride(0),
-                         self.l_norm, self.flags if flags is None else flags)
+        flags = self.flags if flags is None else flags
+        hit = self._c_cache.get(flags)
+        if hit is not None and hit[1] == e.data_ptr() and hit[2] == r.data_ptr():
+            return hit[0]
+        tc = KgeTables(e.data_ptr(), r.data_ptr(), _dtype_code(e), self.scorer, e.shape[0],
+                       r.shape[0], e.shape[1], r.shape[1], e.stride(0), r.stride(0),
+                       self.l_norm, flags)
+        self._c_cache[flags] = (tc, e.data_ptr(), r.data_ptr())
+        return tc
 
     @property
     def num_ent(self):
@@ -143,14 +182,16 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
     if out is None:
         out = _empty((n, m), t.device)
         ldo = m
-    with torch.cuda.device(t.device):
+    with _on_device(t.device):
         tc = t.c(flags)
         fn = getattr(_lib.lib(), fn_name)
         # C signatures: kge_score_sp(t, s, p, ...) but kge_score_po(t, p, o, ...)
         first, second = (ai, pi) if fn_name == "kge_score_sp" else (pi, ai)
-        ws, wsb = _workspace(tc, n, t.device, t.use_workspace)
-        _lib.check(fn(ctypes.byref(tc), first, second, n, ti, m, out.data_ptr(), ldo, ws, wsb,
-                      _stream(t.device)), fn_name)
+        st = _stream_handle(t.device)
+        ws, wsb = _workspace(tc, n, t.device, t.use_workspace, st)
+        rc = fn(ctypes.byref(tc), first, second, n, ti, m, out.data_ptr(), ldo, ws, wsb, st)
+        if rc:
+            _lib.check(rc, fn_name)
     return out
 
 
@@ -173,12 +214,14 @@ def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Ten
     ti = _index(entity_subset, t.device, keep)
     m = t.num_ent if entity_subset is None else keep[-1].numel()
     out = _empty((n, 2 * m), t.device)
-    with torch.cuda.device(t.device):
+    with _on_device(t.device):
         tc = t.c(flags)
-        ws, wsb = _workspace(tc, n, t.device, t.use_workspace)
-        _lib.check(_lib.lib().kge_score_sp_po(ctypes.byref(tc), si, pi, oi, n, ti, m,
-                                              out.data_ptr(), 2 * m, ws, wsb, _stream(t.device)),
-                   "kge_score_sp_po")
+        st = _stream_handle(t.device)
+        ws, wsb = _workspace(tc, n, t.device, t.use_workspace, st)
+        rc = _lib.lib().kge_score_sp_po(ctypes.byref(tc), si, pi, oi, n, ti, m, out.data_ptr(), 2 * m,
+                                        ws, wsb, st)
+        if rc:
+            _lib.check(rc, "kge_score_sp_po")
     return out
 
 
@@ -226,7 +269,7 @@ def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, fl
         out = _empty((n, m), s_emb.device)
     tc = KgeTables(None, None, _dtype_code(s_emb), sc, 0, 0, d, dr, d, dr, float(l_norm), int(flags))
     with torch.cuda.device(s_emb.device):
-        ws, wsb = _workspace(tc, n, s_emb.device, False)
+        ws, wsb = _workspace(tc, n, s_emb.device, True)
         _lib.check(_lib.lib().kge_score_emb(
             ctypes.byref(tc), code, s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(),
             p_emb.stride(0), o_emb.data_ptr(), o_emb.stride(0), n, m, out.data_ptr(), max(m, 1),

@@ -263,6 +263,14 @@ def test_bf16_cooperative_build_repeated_calls(eng, d, n, E):
             refs.append(eng.score_sp(Tn, s, p))
     for it, (a, b) in enumerate(zip(outs, refs)):
         _eq(f"call {it}", _np(a), _np(b))
+    # score_sp_po = one two-sided launch (sp_ row groups, then _po row groups into the second
+    # column block); all entities and a ragged subset
+    s, p, o = (_t(rng.integers(0, hi, n)) for hi in (E, R, E))
+    sub = _t(rng.permutation(E)[: 64 * 7 + 5])
+    for ss in (None, sub):
+        both = _np(eng.score_sp_po(T, s, p, o, ss))
+        _eq(f"two-sided sp block (subset={ss is not None})", both[:, : both.shape[1] // 2], _np(eng.score_sp(Tn, s, p, ss)))
+        _eq(f"two-sided po block (subset={ss is not None})", both[:, both.shape[1] // 2:], _np(eng.score_po(Tn, p, o, ss)))
     O = _oracle_tables("complex", ent, rel, 1.0, bf16=True)
     s, p = rng.integers(0, E, 64), rng.integers(0, R, 64)
     _close("vs oracle", _np(eng.score_sp(T, _t(s), _t(p))), ko.score_sp(O, s, p))

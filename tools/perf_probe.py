@@ -24,7 +24,14 @@ def timeit(fn, iters=30, warm=5):
         evs.append((a, b))
     torch.cuda.synchronize()
     t = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
-    return t[len(t) // 2], t[0], sum(t) / len(t)
+    # back-to-back (launch overhead pipelined, as in bench.py): one event pair around `iters` calls
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return t[len(t) // 2], t[0], a.elapsed_time(b) * 1e3 / iters
 
 
 def tables(model, E, R, d, dtype, seed=0):
@@ -58,6 +65,9 @@ def main():
         s = torch.randint(E, (n,), generator=q).to(dev); p = torch.randint(R, (n,), generator=q).to(dev)
         for model, dtype, flags, tag in [
             ("complex", torch.bfloat16, 0, "bf16-mfma"),
+            ("complex", torch.bfloat16, engine.FLAG_BF16_V3, "bf16-mfma-v3-coop"),
+            ("complex", torch.bfloat16, -1, "bf16-mfma-v3-noworkspace"),
+            ("complex", torch.bfloat16, engine.FLAG_BF16_V2, "bf16-mfma-v2"),
             ("complex", torch.bfloat16, engine.FLAG_BF16_V1, "bf16-mfma-v1"),
             ("distmult", torch.bfloat16, 0, "bf16-mfma"),
             ("complex", torch.bfloat16, engine.FLAG_EXACT, "bf16-exact-f32mfma"),
@@ -66,14 +76,31 @@ def main():
             ("transe", torch.float32, 0, "f32-valu"),
             ("rotate", torch.float32, 0, "f32-valu"),
         ]:
-            if n != 512 and tag not in ("bf16-mfma", "bf16-mfma-v1"):
+            if n != 512 and tag not in ("bf16-mfma", "bf16-mfma-v3-coop"):
                 continue
             T = tables(model, E, R, d, dtype)
+            if flags == -1:
+                T.use_workspace, flags = False, 0
             med, mn, avg = timeit(lambda: engine.score_sp(T, s, p, flags=flags))
             elt = 2 if dtype == torch.bfloat16 else 4
             byts = E * d * elt + n * 2 * d * elt + n * E * 4
-            emit(kernel="score_sp", model=model, tag=tag, n=n, E=E, d=d, us_med=med, us_min=mn,
+            emit(kernel="score_sp", model=model, tag=tag, n=n, E=E, d=d, us_pipelined=avg, us_med=med, us_min=mn,
                  gbs=byts / med / 1e3, gflops=2.0 * n * E * d / med / 1e3, triples_per_s=n * E / med * 1e6)
+    # ---- score_sp_po (EntityRankingJob's call): one two-sided launch vs two one-sided calls
+    for n in (128, 512):
+        s = torch.randint(E, (n,), generator=q).to(dev); p = torch.randint(R, (n,), generator=q).to(dev)
+        o = torch.randint(E, (n,), generator=q).to(dev)
+        T = tables("complex", E, R, d, torch.bfloat16)
+        byts = 2 * (E * d * 2 + n * 2 * d * 2 + n * E * 4)
+        med, mn, avg = timeit(lambda: engine.score_sp_po(T, s, p, o))
+        emit(kernel="score_sp_po", tag="two-sided launch", n=n, us_pipelined=avg, us_med=med, us_min=mn, gbs=byts / med / 1e3,
+             triples_per_s=2 * n * E / med * 1e6)
+        med, mn, avg = timeit(lambda: engine.score_sp_po(T, s, p, o, flags=engine.FLAG_BF16_V3))
+        emit(kernel="score_sp_po", tag="two v3 launches", n=n, us_pipelined=avg, us_med=med, us_min=mn, gbs=byts / med / 1e3,
+             triples_per_s=2 * n * E / med * 1e6)
+        med, mn, avg = timeit(lambda: (engine.score_sp(T, s, p), engine.score_po(T, p, o)))
+        emit(kernel="score_sp+score_po", tag="two v4 launches", n=n, us_pipelined=avg, us_med=med, us_min=mn, gbs=byts / med / 1e3,
+             triples_per_s=2 * n * E / med * 1e6)
     # ---- spo / negatives at WN18RR shape (gather bound)
     E, R, d = 40943, 11, 512
     for model in ("rotate", "transe", "complex", "distmult"):

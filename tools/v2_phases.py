@@ -33,7 +33,7 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False, flags=0):
     si, pi = engine._index(s, dev, keep), engine._index(p, dev, keep)
     nwg = 4096
     stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
-    wsb = ((n + 127) // 128) * 128 * d * 2 + 256 * 64 * 8
+    wsb = 2 * ((n + 127) // 128) * 128 * d * 2 + 512 * 8 * 8
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     tc = T.c()
     for _ in range(reps):
