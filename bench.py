@@ -15,7 +15,8 @@ tables (examples/toy-complex-train.yaml:18-22), uniform random queries.
 
 N > 1 (weak scaling): the entity table is row-sharded, every rank owns an FB15k-237-sized
 shard (global E = N * 14,541) and scores the same n queries against its shard; the query
-rows live on their owner shards and are exchanged with ONE all-gather per step (RCCL).
+rows live on their owner shards and are exchanged with ONE all-gather per step (RCCL; the
+exchange's three small kernels are replayed as one hipGraph).
 """
 import argparse
 import json
@@ -122,25 +123,71 @@ def main():
 
     if dist:
         import torch.distributed as td
-        # query rows live on their owner shard: rank r owns rows [r*n/world, (r+1)*n/world)
+        # Query rows live on their owner shard: rank r owns rows [r*n/world, (r+1)*n/world).
+        # Exchange of a step: one gather kernel for the s/o rows this rank owns, ONE all-gather
+        # over RCCL, one gather of the relation rows; then the two scoring calls.
         per = (n + world - 1) // world
         lo, hi = min(rank * per, n), min((rank + 1) * per, n)
-        loc = torch.zeros(2, per, DIM, dtype=torch.bfloat16, device=device)
-        gath = torch.empty(world, 2, per, DIM, dtype=torch.bfloat16, device=device)
+        own = torch.zeros(per, dtype=torch.int64, device=device)
+        own_o = torch.zeros(per, dtype=torch.int64, device=device)
+        own[: hi - lo], own_o[: hi - lo] = s[lo:hi], o[lo:hi]
+        so_idx = torch.stack([own, own_o], 1).reshape(-1)  # rows interleaved: s_0, o_0, s_1, o_1, ...
+        buf = {
+            "loc": torch.empty(per * 2, DIM, dtype=torch.bfloat16, device=device),
+            "gath": torch.empty(world * per, 2 * DIM, dtype=torch.bfloat16, device=device),
+            "pe": torch.empty(n, DIM, dtype=torch.bfloat16, device=device),
+        }
+        s_rows, o_rows = buf["gath"][:n, :DIM], buf["gath"][:n, DIM:]  # row i = [s row | o row] of query i
 
-        def step():
-            loc[0, : hi - lo] = ent[s[lo:hi]]
-            loc[1, : hi - lo] = ent[o[lo:hi]]
-            td.all_gather_into_tensor(gath.view(-1), loc.view(-1))
-            gs = gath[:, 0].reshape(world * per, DIM)[:n]
-            go = gath[:, 1].reshape(world * per, DIM)[:n]
-            pe = rel[p]
-            engine.score_emb("complex", gs, pe, ent, "sp_")
-            engine.score_emb("complex", ent, pe, go, "_po")
+        def exchange():
+            torch.index_select(ent, 0, so_idx, out=buf["loc"])
+            td.all_gather_into_tensor(buf["gath"].view(-1), buf["loc"].view(-1))
+            torch.index_select(rel, 0, p, out=buf["pe"])
+
+        def score():
+            engine.score_emb("complex", s_rows, buf["pe"], ent, "sp_")
+            engine.score_emb("complex", ent, buf["pe"], o_rows, "_po")
+
+        # The exchange (3 small kernels incl. the RCCL all-gather) costs 28 us of host work when
+        # issued op by op; captured once in a hipGraph it is one 12 us replay per step.  Measured
+        # alternatives on one rank (tools/dist_probe.py, profiles/): replaying it on a side stream
+        # one step ahead of the scoring is SLOWER (53 vs 47 us per step): the persistent scoring
+        # kernel needs whole CUs (160 KB LDS, all VGPRs), so the side stream's kernels and its
+        # workgroups only take turns, and the event traffic adds host work.
+        xg = None
+        if os.environ.get("KGE_BENCH_NO_GRAPH") != "1":
+            try:
+                exchange()  # warm up the kernels / the RCCL channel outside the capture
+                torch.cuda.synchronize()
+                td.barrier()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    exchange()
+                g.replay()
+                torch.cuda.synchronize()
+                xg = g
+            except Exception as e:  # RCCL / torch without capture support
+                print(f"[bench] graph capture of the exchange unavailable ({type(e).__name__}: {e}); "
+                      "eager exchange", file=sys.stderr)
+                xg = None
+                torch.cuda.synchronize()
+        exchange_mode = "one all-gather per step, exchange replayed as a hipGraph" if xg else \
+            "one all-gather per step, eager"
+
+        def run_steps(k_steps):
+            for _ in range(k_steps):
+                if xg is not None:
+                    xg.replay()
+                else:
+                    exchange()
+                score()
     else:
-        def step():
-            engine.score_sp(T, s, p)
-            engine.score_po(T, p, o)
+        exchange_mode = None
+
+        def run_steps(k):
+            for _ in range(k):
+                engine.score_sp(T, s, p)
+                engine.score_po(T, p, o)
 
     def sync():
         if dist:
@@ -148,12 +195,11 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
+    run_steps(a.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    run_steps(a.steps)
+    host_el = time.perf_counter() - t0  # host time to ISSUE the steps (no device wait)
     sync()
     el = time.perf_counter() - t0
     if dist:
@@ -198,6 +244,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": el / a.steps * 1e3,
+            "host_issue_ms_per_step": host_el / a.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -208,6 +255,7 @@ def main():
                             "score_sp + score_po per step",
                 "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n,
                 "parallelism": f"entity-shard x{world}" if world > 1 else "single GPU",
+                **({"exchange": exchange_mode} if exchange_mode else {}),
             },
             "roofline": {
                 "bound": "hbm",

@@ -106,6 +106,11 @@ typedef enum kge_flags {
   KGE_FLAG_BF16_V3 = 16       /* bf16 ComplEx/DistMult with a workspace: the single-role
                                  kernel (v3) instead of the loader/consumer kernel (v4)      */
 } kge_flags;
+/* Bits 8..15 of `flags`: number of compute units the persistent bf16 scoring kernel leaves
+ * free (it launches one workgroup per remaining CU), so that kernels on other streams -- the
+ * RCCL kernels of an overlapped exchange -- run beside it.  0 = all.  */
+#define KGE_FLAG_RESERVE_CUS_SHIFT 8
+#define KGE_FLAG_RESERVE_CUS(n) (((n) & 255) << KGE_FLAG_RESERVE_CUS_SHIFT)
 
 /* An index vector: element i is ptr[i*stride] of type itype.
  * ptr == NULL means the identity 0,1,2,... (used for "all entities"). */
@@ -128,10 +133,10 @@ int kge_device_count(void);
  * a caller that passes `workspace_bytes >= kge_score_workspace_bytes(t, n)` lets the
  * bf16 ComplEx/DistMult path build the n query vectors ONCE -- cooperatively inside the one
  * scoring kernel: a few workgroups build, publish through the workspace, all workgroups
- * consume -- instead of once per workgroup.  workspace == NULL (or too small, or a call made
- * under hipGraph stream capture) selects the path where every workgroup builds its own
- * copy.  Results are identical bit for bit.  The workspace needs no initialisation, is only
- * used during the call (stream order) and must not be shared by calls that may run
+ * consume -- instead of once per workgroup.  workspace == NULL (or too small) selects the
+ * path where every workgroup builds its own copy.  Results are identical bit for bit.  The
+ * workspace needs no initialisation, is only used during the call (stream order; calls may
+ * be captured into a hipGraph and replayed) and must not be shared by calls that may run
  * concurrently on different streams; 16-byte aligned. */
 int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n);
 

@@ -31,7 +31,7 @@ bool pairs_bf16_v4_supported(int scorer, int dtype, int d, const Operand& A, con
 int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Operand& R,
                       const Operand& TG, int dir, int d, long long n, long long m, float* out,
                       long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
-                      void* ws, long long ws_bytes);
+                      void* ws, long long ws_bytes, int reserve_cus);
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
                       hipStream_t st, unsigned long long* dbg = nullptr, void* ws = nullptr,
@@ -98,7 +98,7 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
     if (!v1 && !v2 && !(t->flags & KGE_FLAG_BF16_V3) && ws != nullptr &&
         pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
       const int rc = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr,
-                                       ws, ws_bytes);
+                                       ws, ws_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
       if (rc != KGE_ERR_UNSUPPORTED) return rc;  // else: launch conditions not met, single-role kernel
     }
     if (!v1 && !v2 && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))
@@ -204,7 +204,8 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
     if (pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
         pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
       const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
-                                        (hipStream_t)stream, nullptr, workspace, workspace_bytes);
+                                        (hipStream_t)stream, nullptr, workspace, workspace_bytes,
+                                        (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
       if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;
     }
   }
@@ -348,7 +349,8 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
   if (!(t->flags & (KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) && workspace != nullptr &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {
     const int rc4 = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
-                                      0, (hipStream_t)stream, stamps, workspace, workspace_bytes);
+                                      0, (hipStream_t)stream, stamps, workspace, workspace_bytes,
+                                      (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
     if (rc4 != KGE_ERR_UNSUPPORTED) return rc4;
   }
   if (!(t->flags & KGE_FLAG_BF16_V2))

@@ -290,13 +290,17 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   bf16x8 afr[NKB];
   if (wave == 0) {
     // ONE wave per workgroup polls (255 pollers already cost chip bandwidth): one flag per builder
-    const unsigned long long* f = flags + ((long long)rg * ncg + cg) * 8;
+    unsigned long long* f = flags + ((long long)rg * ncg + cg) * 8;
     for (int spin = 0; spin < (1 << 24); ++spin) {  // bounded: a lost builder must not hang the GPU
       const unsigned long long v =
           lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
       if (__all(v == epoch)) break;
       __builtin_amdgcn_s_sleep(1);
     }
+    // This line belongs to this workgroup alone (the builders write it, nobody else reads it):
+    // clear it, so that a replay of this very launch (hipGraph: the kernel arguments, epoch
+    // included, are frozen at capture) starts from "not published" again.
+    if (lane < nbuild) __hip_atomic_store(f + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published
   stamp();  // 2: all shares of this row group published
@@ -418,32 +422,35 @@ static int v4_cu_count() {
 template <int SCORER, int HH>
 static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                      long long n, long long m, float* out, long long ldo, long long out2_off,
-                     hipStream_t st, unsigned long long* dbg, void* ws, long long ws_bytes) {
+                     hipStream_t st, unsigned long long* dbg, void* ws, long long ws_bytes,
+                     int reserve_cus) {
   const int rgn1 = (int)((n + V4_ROWS - 1) / V4_ROWS);
   const int rgn = A2 ? 2 * rgn1 : rgn1;
   const int ntiles = (int)((m + V4_TN - 1) / V4_TN);
-  // one workgroup per CU (256 CUs): split the target tiles into column groups
-  int ncg = 256 / rgn;
+  // one workgroup per CU (minus the CUs the caller keeps free for concurrent work, e.g. the
+  // RCCL kernels of an overlapped exchange): split the target tiles into column groups
+  int cus = v4_cu_count() - reserve_cus;
+  if (cus > 256) cus = 256;
+  if (cus < 8) cus = 8;
+  int ncg = cus / rgn;
   if (ncg < 1) ncg = 1;
   int tpc = (ntiles + ncg - 1) / ncg;
   if (tpc < 1) tpc = 1;
   ncg = (ntiles + tpc - 1) / tpc;
   const int grid = 8 * rgn * ((ncg + 7) / 8);
   const int tgmode = TG.idx.ptr == nullptr ? 0 : (TG.idx.itype ? 2 : 1);
-  // needs: the workspace, every workgroup resident at once (spin-wait on the builders' flags),
-  // a fresh epoch per launch (so not under graph capture, where kernel arguments are frozen)
+  // needs: the workspace and every workgroup resident at once (spin-wait on the builders' flags).
+  // Fine under hipGraph capture: the epoch is frozen then, but every consumer clears its own
+  // flag line after reading it, so a replay never sees the previous run's flags.
   const long long qf_bytes = (long long)rgn * V4_ROWS * HH * 4;
   if (ws == nullptr || !v4_al16(ws) || (long long)rgn * ncg > 512 || ws_bytes < qf_bytes + 512 * 8 * 8 ||
       grid > v4_cu_count() || ldo >= (1LL << 24))
     return KGE_ERR_UNSUPPORTED;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
-    return KGE_ERR_UNSUPPORTED;
   u32x4* qf = (u32x4*)ws;
   unsigned long long* flags = (unsigned long long*)((char*)ws + qf_bytes);
   static const unsigned long long seed =
-      (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20;
-  const unsigned long long epoch = seed + ++g_v4_epoch;
+      ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20) | (1ull << 63);
+  const unsigned long long epoch = seed + ++g_v4_epoch;  // never 0 (= "cleared")
   int nbuild = ncg < 8 ? ncg : 8;
   const int items = V4_ROWS * (HH / 8);  // at least one item per builder thread
   while (nbuild > 1 && nbuild * 512 > items) --nbuild;
@@ -473,14 +480,16 @@ bool pairs_bf16_v4_supported(int scorer, int dtype, int d, const Operand& A, con
 int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Operand& R,
                       const Operand& TG, int dir, int d, long long n, long long m, float* out,
                       long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
-                      void* ws, long long ws_bytes) {
+                      void* ws, long long ws_bytes, int reserve_cus) {
   if (n == 0 || m == 0) return KGE_OK;
 #define KGE_V4(SC)                                                                                 \
   switch (d) {                                                                                     \
     case 256:                                                                                      \
-      return launch_v4<SC, 128>(A, A2, R, TG, dir, n, m, out, ldo, out2_off, st, dbg, ws, ws_bytes); \
+      return launch_v4<SC, 128>(A, A2, R, TG, dir, n, m, out, ldo, out2_off, st, dbg, ws, ws_bytes, \
+                                reserve_cus);                                                      \
     case 512:                                                                                      \
-      return launch_v4<SC, 256>(A, A2, R, TG, dir, n, m, out, ldo, out2_off, st, dbg, ws, ws_bytes); \
+      return launch_v4<SC, 256>(A, A2, R, TG, dir, n, m, out, ldo, out2_off, st, dbg, ws, ws_bytes, \
+                                reserve_cus);                                                      \
   }
   if (scorer == KGE_COMPLEX) { KGE_V4(KGE_COMPLEX) } else { KGE_V4(KGE_DISTMULT) }
 #undef KGE_V4

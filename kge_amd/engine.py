@@ -19,7 +19,12 @@ from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_BF16_V3, FLAG_EXA
                    KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3"]
+           "score_emb", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3", "reserve_cus"]
+
+
+def reserve_cus(n: int) -> int:
+    """flags value: leave `n` compute units free for kernels on other streams (KGE_FLAG_RESERVE_CUS)."""
+    return (int(n) & 255) << 8
 
 
 def _require_gpu(t: torch.Tensor, what: str):

@@ -277,8 +277,10 @@ def test_bf16_cooperative_build_repeated_calls(eng, d, n, E):
 
 
 def test_bf16_under_graph_capture(eng):
-    """Under hipGraph capture the kernel arguments are frozen, so the library must not use the
-    per-launch epoch protocol: replays with new queries still give the right scores."""
+    """Under hipGraph capture the kernel arguments (the hand-off epoch included) are frozen:
+    replays with new queries must still give the right scores (every consumer clears its flag
+    line after reading it), back to back and with eager calls on the same scratch buffer in
+    between."""
     rng = np.random.default_rng(3)
     E, R, d, n = 2000, 7, 256, 256
     ent = rng.standard_normal((E, d)).astype(np.float32)
@@ -298,6 +300,17 @@ def test_bf16_under_graph_capture(eng):
         g.replay()
         torch.cuda.synchronize()
         _eq(f"replay {it}", _np(out), _np(eng.score_sp(Tn, s, p)))
+    # replays back to back (no host sync), inputs changed by stream-ordered copies in between
+    news = [(_t(rng.integers(0, E, n)), _t(rng.integers(0, R, n))) for _ in range(4)]
+    outs = []
+    for s2, p2 in news:
+        s.copy_(s2)
+        p.copy_(p2)
+        g.replay()
+        outs.append(out.clone())
+    torch.cuda.synchronize()
+    for it, ((s2, p2), got) in enumerate(zip(news, outs)):
+        _eq(f"back-to-back replay {it}", _np(got), _np(eng.score_sp(Tn, s2, p2)))
 
 
 @pytest.mark.parametrize("model", ["complex", "distmult", "transe", "rotate"])
