@@ -43,7 +43,7 @@ int run_rank(const float* scores, long long lds, long long n, long long c,
 int run_pairs_bwd(int scorer, float lp, int dir, const Operand& A, const Operand& R,
                   const Operand& TG, int d, int dr, long long n, long long m, const float* gout,
                   long long ldg, const float* scores, long long lds, float* g_a, float* g_p,
-                  float* g_tgt, hipStream_t st);
+                  float* g_tgt, hipStream_t st, bool self_contained);
 int run_spo_bwd(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
                 int dr, long long n, const float* gout, const float* scores, float* g_s, float* g_p,
                 float* g_o, hipStream_t st);
@@ -288,7 +288,7 @@ int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
   if (n > 65535LL * 64 || m > 65535LL * 64) return KGE_ERR_UNSUPPORTED;
   return run_pairs_bwd(t->scorer, t->l_norm, dir, ent_op(t, a), rel_op(t, p), ent_op(t, targets),
                        (int)t->dim, (int)t->rel_dim, n, m, gout, ldg, scores, lds, g_a, g_p, g_tgt,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, (t->flags & KGE_FLAG_EXACT) != 0);
 }
 
 int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
@@ -324,10 +324,10 @@ int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64
   if (ldg < m || (scores && lds < m)) return KGE_ERR_INVALID_ARG;
   if (combine == KGE_SP_)
     return run_pairs_bwd(t->scorer, t->l_norm, KGE_SP_, S, P, O, d, dr, n, m, gout, ldg, scores,
-                         lds, g_s, g_p, g_o, st);
+                         lds, g_s, g_p, g_o, st, (t->flags & KGE_FLAG_EXACT) != 0);
   if (combine == KGE_PO_)
     return run_pairs_bwd(t->scorer, t->l_norm, KGE_PO_, O, P, S, d, dr, n, m, gout, ldg, scores,
-                         lds, g_o, g_p, g_s, st);
+                         lds, g_o, g_p, g_s, st, (t->flags & KGE_FLAG_EXACT) != 0);
   return KGE_ERR_INVALID_ARG;
 }
 

@@ -327,11 +327,19 @@ static int launch_bwd_pairs(int dir, const Operand& A, const Operand& R, const O
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
+int run_pairs_bwd_gemm(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG,
+                       int d, int dr, long long n, long long m, const float* gout, long long ldg,
+                       float* g_a, float* g_p, float* g_tgt, hipStream_t st);
+
 int run_pairs_bwd(int scorer, float lp, int dir, const Operand& A, const Operand& R,
                   const Operand& TG, int d, int dr, long long n, long long m, const float* gout,
                   long long ldg, const float* scores, long long lds, float* g_a, float* g_p,
-                  float* g_tgt, hipStream_t st) {
+                  float* g_tgt, hipStream_t st, bool self_contained) {
   if (n == 0 || m == 0) return KGE_OK;
+  if (!self_contained) {  // ComplEx / DistMult: two library GEMMs + elementwise kernels (bwd_gemm.hip)
+    const int rc = run_pairs_bwd_gemm(scorer, dir, A, R, TG, d, dr, n, m, gout, ldg, g_a, g_p, g_tgt, st);
+    if (rc != KGE_ERR_UNSUPPORTED) return rc;
+  }
   const int norm = norm_mode(lp);
   const bool dot = scorer == KGE_COMPLEX || scorer == KGE_DISTMULT;
   if (!dot && norm != NORM_L1 && !scores) return KGE_ERR_INVALID_ARG;

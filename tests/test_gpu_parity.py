@@ -86,6 +86,8 @@ def test_single_hip_runtime_and_library_loaded(eng):
     maps = open("/proc/self/maps").read()
     hips = {l.split()[-1] for l in maps.splitlines() if "libamdhip64" in l}
     assert len(hips) == 1, hips
+    blas = {l.split()[-1] for l in maps.splitlines() if "librocblas" in l}
+    assert len(blas) <= 1, blas  # the backward GEMMs run on the rocBLAS torch already loaded
     assert "libkge_amd.so" in maps
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
 
