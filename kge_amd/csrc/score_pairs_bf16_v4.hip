@@ -191,7 +191,23 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
 #pragma unroll
     for (int k = 0; k < NL; ++k)
       dvoff[k] = (unsigned int)(lr * (int)tld2) + (unsigned int)(((slot ^ lr) << 4) ^ ((RPP * k) << 4));
-    auto tile_dma = [&](int tt) {  // this wave's NL pieces of tile tt into ring buffer tt & 1
+    // table rows of this wave's 16 target rows of tile tt (lane l & 15: local row 16*w4 + (l & 15));
+    // for an index vector this is a memory load, issued one step ahead of the DMA that needs it
+    auto load_rows = [&](int tt) -> long long {
+      const int tc = tt < ntl ? tt : ntl - 1;
+      long long tr = (long long)(tile_lo + tc) * V4_TN + w4 * 16 + (lane & 15);
+      if (tr >= m) tr = m - 1;  // ragged end of the table: rows clamped to m-1
+      return v4_index<TGMODE>(TG.idx, tr);
+    };
+    auto bcast_row = [&](long long rows, int l) -> long long {  // rows of lane l, wave-uniform
+      const int lo = __builtin_amdgcn_readlane((int)(rows & 0xffffffffLL), l);
+      const int hi = __builtin_amdgcn_readlane((int)(rows >> 32), l);
+      return ((long long)hi << 32) | (unsigned int)lo;
+    };
+    unsigned int dsw[NL];  // swizzled 16-byte slot of this lane within its row, per piece
+#pragma unroll
+    for (int k = 0; k < NL; ++k) dsw[k] = (unsigned int)(((slot ^ lr) << 4) ^ ((RPP * k) << 4));
+    auto tile_dma = [&](int tt, long long rows) {  // this wave's NL pieces of tile tt into ring buffer tt & 1
       const int tc = tt < ntl ? tt : ntl - 1;
       const long long trow0 = (long long)(tile_lo + tc) * V4_TN;
       unsigned int d = (unsigned int)((tt & 1) * TILEB + w4 * NL * 1024);
@@ -207,21 +223,27 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
           p += RPP * tld2;
           d += 1024;
         });
-      } else {  // index vector and / or ragged end of the table (rows clamped to m-1)
+      } else {  // index vector and / or ragged end of the table: row ids from `rows`
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
-          const int row = w4 * 16 + RPP * k + lr;
-          long long tr = trow0 + row;
-          if (tr >= m) tr = m - 1;
-          const unsigned short* src = tgb + v4_index<TGMODE>(TG.idx, tr) * TG.ld + ((slot ^ (row & 15)) << 3);
+          long long r = bcast_row(rows, RPP * k);
+          if (RPP == 2) {
+            const long long r1 = bcast_row(rows, RPP * k + 1);
+            r = lr ? r1 : r;
+          }
+          const unsigned char* src = (const unsigned char*)tgb + r * tld2 + dsw[k];
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                            (__attribute__((address_space(3))) void*)(smem + d + k * 1024),
                                            16, 0, 0);
         }
       }
     };
-    tile_dma(0);
-    if (ntl > 1) tile_dma(1);
+    {
+      const long long rows0 = load_rows(0), rows1 = load_rows(1);
+      tile_dma(0, rows0);
+      if (ntl > 1) tile_dma(1, rows1);
+    }
+    long long rows_next = load_rows(2);
     __builtin_amdgcn_s_barrier();  // B0: consumer wave 0 has seen the builders' flags
 
     // staged scores of consumer w4: [32 rows][16 chunks of 16 B], chunk c of row r at c ^ (r & 15).
@@ -276,7 +298,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       lstamp(32 + 4 * tt);  // tile tt landed (this wave's pieces)
       __builtin_amdgcn_s_barrier();  // B1(tt)
       lstamp(33 + 4 * tt);
-      if (tt >= 1 && tt + 1 < ntl) tile_dma(tt + 1);  // into the buffer tile tt-1 was read from
+      if (tt >= 1 && tt + 1 < ntl) {
+        tile_dma(tt + 1, rows_next);  // into the buffer tile tt-1 was read from
+        rows_next = load_rows(tt + 2);
+      }
       lstamp(34 + 4 * tt);  // DMA of tile tt+1 issued
       __builtin_amdgcn_s_barrier();  // B2(tt): scores of tile tt-1 are staged
       if (tt >= 1) store_tile(tt - 1);
