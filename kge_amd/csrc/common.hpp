@@ -220,4 +220,47 @@ __device__ __forceinline__ void build_q4(int dir, const f32x4& a0, const f32x4& 
 }
 
 
+
+// ---- helpers shared by the bf16 matrix-core pair kernels (score_pairs_bf16_v2/v3/v4.hip) ----
+
+// RNE pack of two f32 into one dword of two bf16 (lo in bits 0-15)
+__device__ __forceinline__ unsigned int bf16_pack(float lo, float hi) {
+  unsigned int r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// Query vector of ComplEx / DistMult on bf16 tables, two coordinates per dword: (a0,a1) entity
+// halves, (r0,r1) relation halves -> (q0,q1).  Every product and sum is rounded on its own
+// (no contraction: -ffp-contract=off), then RNE to bf16: the bits of build_q() of the oracle.
+template <int SCORER>
+__device__ __forceinline__ void bf16_qpair(int dir, unsigned int a0, unsigned int a1,
+                                           unsigned int r0, unsigned int r1, unsigned int& q0,
+                                           unsigned int& q1) {
+  const float a0l = __uint_as_float(a0 << 16), a0h = __uint_as_float(a0 & 0xffff0000u);
+  const float a1l = __uint_as_float(a1 << 16), a1h = __uint_as_float(a1 & 0xffff0000u);
+  const float r0l = __uint_as_float(r0 << 16), r0h = __uint_as_float(r0 & 0xffff0000u);
+  const float r1l = __uint_as_float(r1 << 16), r1h = __uint_as_float(r1 & 0xffff0000u);
+  float q0l, q0h, q1l, q1h;
+  if (SCORER == KGE_DISTMULT) {
+    q0l = a0l * r0l; q0h = a0h * r0h; q1l = a1l * r1l; q1h = a1h * r1h;
+  } else if (dir == KGE_SP_) {
+    q0l = a0l * r0l - a1l * r1l; q0h = a0h * r0h - a1h * r1h;
+    q1l = a1l * r0l + a0l * r1l; q1h = a1h * r0h + a0h * r1h;
+  } else {
+    q0l = r0l * a0l + r1l * a1l; q0h = r0h * a0h + r1h * a1h;
+    q1l = r0l * a1l - r1l * a0l; q1h = r0h * a1h - r1h * a0h;
+  }
+  q0 = bf16_pack(q0l, q0h);
+  q1 = bf16_pack(q1l, q1h);
+}
+
+// row index through an index vector; MODE 0 = identity, 1 = int32, 2 = int64 (no branches)
+template <int MODE>
+__device__ __forceinline__ long long index_mode(const Index& ix, long long i) {
+  if (MODE == 0) return i;
+  if (MODE == 1) return (long long)((const int*)ix.ptr)[i * ix.stride];
+  return ((const long long*)ix.ptr)[i * ix.stride];
+}
+
 }  // namespace kge

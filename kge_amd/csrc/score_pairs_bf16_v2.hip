@@ -34,47 +34,10 @@ namespace kge {
 constexpr int V2_ROWS = 128, V2_TN = 32;
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-__device__ __forceinline__ unsigned int v2_pack(float lo, float hi) {
-  unsigned int r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-// two coordinates per dword: (a0,a1) entity halves, (r0,r1) relation halves -> (q0,q1)
-template <int SCORER>
-__device__ __forceinline__ void v2_qpair(int dir, unsigned int a0, unsigned int a1,
-                                         unsigned int r0, unsigned int r1, unsigned int& q0,
-                                         unsigned int& q1) {
-  const float a0l = __uint_as_float(a0 << 16), a0h = __uint_as_float(a0 & 0xffff0000u);
-  const float a1l = __uint_as_float(a1 << 16), a1h = __uint_as_float(a1 & 0xffff0000u);
-  const float r0l = __uint_as_float(r0 << 16), r0h = __uint_as_float(r0 & 0xffff0000u);
-  const float r1l = __uint_as_float(r1 << 16), r1h = __uint_as_float(r1 & 0xffff0000u);
-  float q0l, q0h, q1l, q1h;
-  if (SCORER == KGE_DISTMULT) {
-    q0l = a0l * r0l; q0h = a0h * r0h; q1l = a1l * r1l; q1h = a1h * r1h;
-  } else if (dir == KGE_SP_) {
-    q0l = a0l * r0l - a1l * r1l; q0h = a0h * r0h - a1h * r1h;
-    q1l = a1l * r0l + a0l * r1l; q1h = a1h * r0h + a0h * r1h;
-  } else {
-    q0l = r0l * a0l + r1l * a1l; q0h = r0h * a0h + r1h * a1h;
-    q1l = r0l * a1l - r1l * a0l; q1h = r0h * a1h - r1h * a0h;
-  }
-  q0 = v2_pack(q0l, q0h);
-  q1 = v2_pack(q1l, q1h);
-}
-
 __device__ __forceinline__ long long shfl64(long long v, int src) {
   int lo = __shfl((int)(v & 0xffffffffLL), src, 64);
   int hi = __shfl((int)(v >> 32), src, 64);
   return ((long long)hi << 32) | (unsigned int)lo;
-}
-
-// row index through an index vector; MODE 0 = identity, 1 = int32, 2 = int64 (no branches)
-template <int MODE>
-__device__ __forceinline__ long long v2_index(const Index& ix, long long i) {
-  if (MODE == 0) return i;
-  if (MODE == 1) return (long long)((const int*)ix.ptr)[i * ix.stride];
-  return ((const long long*)ix.ptr)[i * ix.stride];
 }
 
 // ABL (ablation, debug entry only): bit 0 = drop the global score stores, bit 1 = drop the
@@ -145,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
       const int row = L / SPR, slot = L % SPR;
       long long tr = trow0 + row;
       if (tr >= m) tr = m - 1;
-      src = tgb + v2_index<TGMODE>(TG.idx, tr) * TG.ld + ((slot ^ (row & 15)) << 3);
+      src = tgb + index_mode<TGMODE>(TG.idx, tr) * TG.ld + ((slot ^ (row & 15)) << 3);
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -213,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned int x0, x1;
-          v2_qpair<SCORER>(dir, v[0][e], v[1][e], v[2][e], v[3][e], x0, x1);
+          bf16_qpair<SCORER>(dir, v[0][e], v[1][e], v[2][e], v[3][e], x0, x1);
           q0[e] = x0;
           q1[e] = x1;
         }
@@ -409,7 +372,7 @@ __global__ __launch_bounds__(256) void build_queries_kernel(Operand A, Operand R
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     unsigned int x0, x1;
-    v2_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+    bf16_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
     q0[e] = x0;
     q1[e] = x1;
   }

@@ -25,37 +25,6 @@ namespace kge {
 constexpr int V3_ROWS = 128, V3_TN = 64;
 typedef float f32x4v3u __attribute__((ext_vector_type(4), aligned(4)));
 
-__device__ __forceinline__ unsigned int v3_pack(float lo, float hi) {
-  unsigned int r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-// two coordinates per dword: (a0,a1) entity halves, (r0,r1) relation halves -> (q0,q1).
-// Every product is rounded on its own (v_pk_mul_f32 / v_pk_add_f32 are IEEE per element):
-// the same bits as build_q() of the oracle, then RNE to bf16.
-template <int SCORER>
-__device__ __forceinline__ void v3_qpair(int dir, unsigned int a0, unsigned int a1,
-                                         unsigned int r0, unsigned int r1, unsigned int& q0,
-                                         unsigned int& q1) {
-  const float a0l = __uint_as_float(a0 << 16), a0h = __uint_as_float(a0 & 0xffff0000u);
-  const float a1l = __uint_as_float(a1 << 16), a1h = __uint_as_float(a1 & 0xffff0000u);
-  const float r0l = __uint_as_float(r0 << 16), r0h = __uint_as_float(r0 & 0xffff0000u);
-  const float r1l = __uint_as_float(r1 << 16), r1h = __uint_as_float(r1 & 0xffff0000u);
-  float q0l, q0h, q1l, q1h;
-  if (SCORER == KGE_DISTMULT) {
-    q0l = a0l * r0l; q0h = a0h * r0h; q1l = a1l * r1l; q1h = a1h * r1h;
-  } else if (dir == KGE_SP_) {
-    q0l = a0l * r0l - a1l * r1l; q0h = a0h * r0h - a1h * r1h;
-    q1l = a1l * r0l + a0l * r1l; q1h = a1h * r0h + a0h * r1h;
-  } else {
-    q0l = r0l * a0l + r1l * a1l; q0h = r0h * a0h + r1h * a1h;
-    q1l = r0l * a1l - r1l * a0l; q1h = r0h * a1h - r1h * a0h;
-  }
-  q0 = v3_pack(q0l, q0h);
-  q1 = v3_pack(q1l, q1h);
-}
-
 __device__ __forceinline__ long long v3_shfl64(long long v, int src) {
   int lo = __shfl((int)(v & 0xffffffffLL), src, 64);
   int hi = __shfl((int)(v >> 32), src, 64);
@@ -69,13 +38,6 @@ __device__ __forceinline__ void v3_static_for(F&& f) {
     f(std::integral_constant<int, I>{});
     v3_static_for<I + 1, N>(f);
   }
-}
-
-template <int MODE>
-__device__ __forceinline__ long long v3_index(const Index& ix, long long i) {
-  if (MODE == 0) return i;
-  if (MODE == 1) return (long long)((const int*)ix.ptr)[i * ix.stride];
-  return ((const long long*)ix.ptr)[i * ix.stride];
 }
 
 // COOP (cooperative query build, needs a workspace): the query rows of a row group are needed
@@ -143,7 +105,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     long long tr = trow0 + row;
     if (tr >= m) tr = m - 1;
     const unsigned short* src =
-        tgb + v3_index<TGMODE>(TG.idx, tr) * TG.ld + ((slot ^ (row & 15)) << 3);
+        tgb + index_mode<TGMODE>(TG.idx, tr) * TG.ld + ((slot ^ (row & 15)) << 3);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   };
@@ -172,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned int x0, x1;
-          v3_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+          bf16_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
           q0[e] = x0;
           q1[e] = x1;
         }
@@ -259,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned int x0, x1;
-          v3_qpair<SCORER>(dir, v[0][e], v[1][e], v[2][e], v[3][e], x0, x1);
+          bf16_qpair<SCORER>(dir, v[0][e], v[1][e], v[2][e], v[3][e], x0, x1);
           q0[e] = x0;
           q1[e] = x1;
         }

@@ -46,43 +46,6 @@ __device__ __forceinline__ void v4_static_for(F&& f) {
   }
 }
 
-__device__ __forceinline__ unsigned int v4_pack(float lo, float hi) {
-  unsigned int r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-// two coordinates per dword: (a0,a1) entity halves, (r0,r1) relation halves -> (q0,q1); every
-// product and sum rounded on its own: the bits of the oracle's build_q(), then RNE to bf16.
-template <int SCORER>
-__device__ __forceinline__ void v4_qpair(int dir, unsigned int a0, unsigned int a1,
-                                         unsigned int r0, unsigned int r1, unsigned int& q0,
-                                         unsigned int& q1) {
-  const float a0l = __uint_as_float(a0 << 16), a0h = __uint_as_float(a0 & 0xffff0000u);
-  const float a1l = __uint_as_float(a1 << 16), a1h = __uint_as_float(a1 & 0xffff0000u);
-  const float r0l = __uint_as_float(r0 << 16), r0h = __uint_as_float(r0 & 0xffff0000u);
-  const float r1l = __uint_as_float(r1 << 16), r1h = __uint_as_float(r1 & 0xffff0000u);
-  float q0l, q0h, q1l, q1h;
-  if (SCORER == KGE_DISTMULT) {
-    q0l = a0l * r0l; q0h = a0h * r0h; q1l = a1l * r1l; q1h = a1h * r1h;
-  } else if (dir == KGE_SP_) {
-    q0l = a0l * r0l - a1l * r1l; q0h = a0h * r0h - a1h * r1h;
-    q1l = a1l * r0l + a0l * r1l; q1h = a1h * r0h + a0h * r1h;
-  } else {
-    q0l = r0l * a0l + r1l * a1l; q0h = r0h * a0h + r1h * a1h;
-    q1l = r0l * a1l - r1l * a0l; q1h = r0h * a1h - r1h * a0h;
-  }
-  q0 = v4_pack(q0l, q0h);
-  q1 = v4_pack(q1l, q1h);
-}
-
-template <int MODE>
-__device__ __forceinline__ long long v4_index(const Index& ix, long long i) {
-  if (MODE == 0) return i;
-  if (MODE == 1) return (long long)((const int*)ix.ptr)[i * ix.stride];
-  return ((const long long*)ix.ptr)[i * ix.stride];
-}
-
 template <int SCORER, int HH, int TGMODE>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     Operand A, Operand A2, Operand R, Operand TG, int dir, long long n, long long m, int rgn,
@@ -154,7 +117,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned int x0, x1;
-        v4_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+        bf16_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
         q0[e] = x0;
         q1[e] = x1;
       }
@@ -197,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       const int tc = tt < ntl ? tt : ntl - 1;
       long long tr = (long long)(tile_lo + tc) * V4_TN + w4 * 16 + (lane & 15);
       if (tr >= m) tr = m - 1;  // ragged end of the table: rows clamped to m-1
-      return v4_index<TGMODE>(TG.idx, tr);
+      return index_mode<TGMODE>(TG.idx, tr);
     };
     auto bcast_row = [&](long long rows, int l) -> long long {  // rows of lane l, wave-uniform
       const int lo = __builtin_amdgcn_readlane((int)(rows & 0xffffffffLL), l);

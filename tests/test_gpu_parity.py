@@ -217,6 +217,7 @@ def test_bf16_mfma_kernel_vs_oracle(eng, model, d):
     _eq("coop == fused (po, subset i32)", _np(eng.score_po(T, tp, to, _t(sub).int())), ref_po)
     _eq("v3 coop == fused", _np(eng.score_sp(T, ts, tp, flags=eng.FLAG_BF16_V3)), ref_sp)
     _eq("v3 coop == fused (po, subset i32)", _np(eng.score_po(T, tp, to, _t(sub).int(), flags=eng.FLAG_BF16_V3)), ref_po)
+    _eq("16 CUs left free == default", _np(eng.score_sp(T, ts, tp, flags=eng.reserve_cus(16))), ref_sp)
     for TT, nm in ((T, "v2+builder"), (Tn, "v2 fused")):
         _eq(f"{nm} == v3", _np(eng.score_sp(TT, ts, tp, flags=eng.FLAG_BF16_V2)), ref_sp)
         _eq(f"{nm} == v3 (po, subset i32)", _np(eng.score_po(TT, tp, to, _t(sub).int(), flags=eng.FLAG_BF16_V2)), ref_po)
