@@ -8,7 +8,7 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import _ScoreEmb, _ScorePairs, _ScoreSPO
+from ..model import BF16Shadow, _ScoreEmb, _ScorePairs, _ScoreSPO
 
 
 class _HipScorer(RelationalScorer):
@@ -59,6 +59,23 @@ class _FusedScoring:
     def _w(self):
         return (self.get_s_embedder()._embeddings.weight, self.get_p_embedder()._embeddings.weight)
 
+    def _fwd_tables(self):
+        """`score_dtype: bfloat16` (hip_complex.yaml / hip_distmult.yaml) with float32 parameters:
+        sp_/_po scores come from the bf16 matrix-core kernel on bf16 copies of the tables (re-cast
+        after every optimizer step), gradients are taken w.r.t. the float32 masters."""
+        ent, rel = self._w()
+        if self._scorer.name not in ("complex", "distmult") or ent.dtype != torch.float32:
+            return None
+        try:
+            want = self.get_option("score_dtype")
+        except KeyError:
+            return None
+        if want not in ("bfloat16", "bf16"):
+            return None
+        if getattr(self, "_bf16_shadow", None) is None:
+            self._bf16_shadow = BF16Shadow()
+        return self._bf16_shadow.tables(self._scorer.name, ent, rel, self._scorer._norm)
+
     def score_spo(self, s: Tensor, p: Tensor, o: Tensor, direction=None) -> Tensor:
         if not self._fused():
             return super().score_spo(s, p, o, direction)
@@ -69,20 +86,23 @@ class _FusedScoring:
         if not self._fused():
             return super().score_sp(s, p, o)
         ent, rel = self._w()
-        return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp", ent, rel, s, p, o)
+        return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp", ent, rel, s, p, o,
+                                 self._fwd_tables())
 
     def score_po(self, p: Tensor, o: Tensor, s: Tensor = None) -> Tensor:
         if not self._fused():
             return super().score_po(p, o, s)
         ent, rel = self._w()
-        return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, s)
+        return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, s,
+                                 self._fwd_tables())
 
     def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
         if not self._fused():
             return super().score_sp_po(s, p, o, entity_subset)
         if not torch.is_grad_enabled():
             ent, rel = self._w()
-            t = engine.Tables(self._scorer.name, ent.detach(), rel.detach(), self._scorer._norm)
+            t = self._fwd_tables() or engine.Tables(self._scorer.name, ent.detach(), rel.detach(),
+                                                    self._scorer._norm)
             return engine.score_sp_po(t, s, p, o, entity_subset)
         return torch.cat((self.score_sp(s, p, entity_subset), self.score_po(p, o, entity_subset)), dim=1)
 

@@ -112,8 +112,13 @@ class KgeModel(torch.nn.Module):
     scorer_cls = None
 
     def __init__(self, num_entities: int, num_relations: int, dim: int, l_norm: float = 1.0,
-                 dtype=torch.float32, device=None, entity_args=None, relation_args=None):
+                 dtype=torch.float32, device=None, entity_args=None, relation_args=None,
+                 score_dtype=None):
         super().__init__()
+        # score_dtype=torch.bfloat16 with f32 parameters (ComplEx / DistMult): sp_/_po scores from
+        # the bf16 matrix-core kernel on bf16 copies of the tables, gradients w.r.t. the f32 masters
+        self._shadow = BF16Shadow() if (score_dtype == torch.bfloat16 and dtype == torch.float32 and
+                                        self.scorer_cls in (ComplExScorer, DistMultScorer)) else None
         rel_dim = dim // 2 if self.scorer_cls is RotatEScorer else dim
         if self.scorer_cls in (RotatEScorer, ComplExScorer) and dim % 2:
             raise ValueError("{} requires embeddings of even dimensionality (got {})".format(
@@ -142,8 +147,17 @@ class KgeModel(torch.nn.Module):
         return self._scorer
 
     def tables(self, flags: int = 0) -> engine.Tables:
+        """The tables the pair scores are computed from (the bf16 copies in mixed precision)."""
+        if self._shadow is not None and flags == 0:
+            return self._fwd_tables()
         return engine.Tables(self._scorer.name, self._entity_embedder.weight.detach(),
                              self._relation_embedder.weight.detach(), self._scorer._norm, flags)
+
+    def _fwd_tables(self):
+        if self._shadow is None:
+            return None
+        return self._shadow.tables(self._scorer.name, self._entity_embedder.weight,
+                                   self._relation_embedder.weight, self._scorer._norm)
 
     def _fused(self) -> bool:
         return self._entity_embedder.fused_ok() and self._relation_embedder.fused_ok()
@@ -160,7 +174,7 @@ class KgeModel(torch.nn.Module):
         if self._fused():
             return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp",
                                      self._entity_embedder.weight,
-                                     self._relation_embedder.weight, s, p, o)
+                                     self._relation_embedder.weight, s, p, o, self._fwd_tables())
         se, pe = self._entity_embedder.embed(s), self._relation_embedder.embed(p)
         oe = self._entity_embedder.embed_all() if o is None else self._entity_embedder.embed(o)
         return self._scorer.score_emb(se, pe, oe, combine="sp_")
@@ -169,7 +183,7 @@ class KgeModel(torch.nn.Module):
         if self._fused():
             return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po",
                                      self._entity_embedder.weight,
-                                     self._relation_embedder.weight, o, p, s)
+                                     self._relation_embedder.weight, o, p, s, self._fwd_tables())
         se = self._entity_embedder.embed_all() if s is None else self._entity_embedder.embed(s)
         oe, pe = self._entity_embedder.embed(o), self._relation_embedder.embed(p)
         return self._scorer.score_emb(se, pe, oe, combine="_po")
@@ -245,11 +259,32 @@ class _ScoreSPO(torch.autograd.Function):
         return None, None, ge, gr, None, None, None
 
 
+class BF16Shadow:
+    """bf16 copies of f32 master tables for mixed-precision scoring (`score_dtype: bfloat16`):
+    the forward runs the bf16 matrix-core kernel on the copies, the backward differentiates the
+    f32 masters.  With autograd enabled (training) the copies are re-cast on every call (two
+    15 MB writes at the FB15k-237 shape, ~10 us); without (evaluation) only when a master's
+    storage or version counter changed -- in-place edits through `.data` do not bump the
+    counter, hence no caching while training."""
+
+    def __init__(self):
+        self._key, self._tables = None, None
+
+    def tables(self, name, ent, rel, l_norm) -> "engine.Tables":
+        key = (ent.data_ptr(), ent._version, rel.data_ptr(), rel._version)
+        if key != self._key or torch.is_grad_enabled():
+            self._tables = engine.Tables(name, ent.detach().to(torch.bfloat16), rel.detach().to(torch.bfloat16),
+                                         l_norm)
+            self._key = key
+        return self._tables
+
+
 class _ScorePairs(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, name, l_norm, direction, ent, rel, a, p, targets):
+    def forward(ctx, name, l_norm, direction, ent, rel, a, p, targets, fwd_tables=None):
         t = engine.Tables(name, ent.detach(), rel.detach(), l_norm)
-        out = (engine.score_sp if direction == "sp" else engine.score_po)(t, *((a, p) if direction == "sp" else (p, a)), targets)
+        tf = t if fwd_tables is None else fwd_tables  # mixed precision: bf16 copies, forward only
+        out = (engine.score_sp if direction == "sp" else engine.score_po)(tf, *((a, p) if direction == "sp" else (p, a)), targets)
         ctx.t, ctx.direction, ctx.idx = t, direction, (a, p, targets)
         ctx.save_for_backward(out)
         return out
@@ -266,7 +301,7 @@ class _ScorePairs(torch.autograd.Function):
             ge += g_t
         else:
             _scatter_rows(ge, targets, g_t)
-        return None, None, None, ge, gr, None, None, None
+        return None, None, None, ge, gr, None, None, None, None
 
 
 class _ScoreEmb(torch.autograd.Function):

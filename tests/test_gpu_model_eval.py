@@ -146,3 +146,42 @@ def test_backward_matches_torch_autograd(name, l_norm):
         scale = max(1.0, float(want.abs().max()))
         err = float((got - want).abs().max())
         assert err <= 2e-4 * scale, (name, l_norm, nm, err, scale)
+
+
+def test_mixed_precision_scoring():
+    """score_dtype=bfloat16 on f32 parameters (ComplEx / DistMult): the forward is the bf16
+    matrix-core kernel on bf16 copies of the tables (bit for bit), the backward is the f32 one
+    (same gradients as the f32 model for the same upstream gradient), and the copies follow the
+    parameters."""
+    from kge_amd import engine as eng
+    from kge_amd import model as km
+    E, R, d, n = 1500, 9, 256, 130
+    for name in ("complex", "distmult"):
+        torch.manual_seed(0)
+        m32 = km.create(name, E, R, d, device=DEV)
+        mmp = km.create(name, E, R, d, device=DEV, score_dtype=torch.bfloat16)
+        mmp.load_state_dict(m32.state_dict())
+        g = torch.Generator().manual_seed(1)
+        s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+        w = torch.randn(n, E, generator=g).to(DEV)
+        ent16 = mmp._entity_embedder.weight.detach().bfloat16()
+        rel16 = mmp._relation_embedder.weight.detach().bfloat16()
+        T16 = eng.Tables(name, ent16, rel16)
+        for fn, args, ref in ((mmp.score_sp, (s, p), eng.score_sp(T16, s, p)),
+                              (mmp.score_po, (p, o), eng.score_po(T16, p, o))):
+            out = fn(*args)
+            assert torch.equal(out, ref), name
+            out32 = getattr(m32, fn.__name__)(*args)
+            for mod in (m32, mmp):
+                mod.zero_grad()
+            (out * w).sum().backward()
+            (out32 * w).sum().backward()
+            for a, b in ((mmp._entity_embedder.weight.grad, m32._entity_embedder.weight.grad),
+                         (mmp._relation_embedder.weight.grad, m32._relation_embedder.weight.grad)):
+                torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+        # evaluation path (no autograd): two-sided launch on the copies, refreshed after an update
+        with torch.no_grad():
+            assert torch.equal(mmp.score_sp_po(s, p, o), eng.score_sp_po(T16, s, p, o))
+            mmp._entity_embedder.weight.mul_(0.5)
+            T16b = eng.Tables(name, mmp._entity_embedder.weight.detach().bfloat16(), rel16)
+            assert torch.equal(mmp.score_sp_po(s, p, o), eng.score_sp_po(T16b, s, p, o))

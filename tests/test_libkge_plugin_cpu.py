@@ -48,6 +48,22 @@ def test_plugin_is_discovered_and_keeps_parameter_names(model):
             call()
 
 
+@pytest.mark.parametrize("model", ["hip_complex", "hip_distmult"])
+def test_mixed_precision_option(model):
+    """`score_dtype` defaults to float32 (no bf16 copies); bfloat16 selects the bf16 copies, which
+    only exist on a GPU -- on job.device=cpu the request fails loudly like every scoring call."""
+    config = _config(model)
+    assert config.get(f"{model}.score_dtype") == "float32"
+    from kge import Dataset
+    from kge.model import KgeModel
+    m = KgeModel.create(config, Dataset(config, folder=None))
+    assert m._fwd_tables() is None
+    config.set(f"{model}.score_dtype", "bfloat16")
+    m = KgeModel.create(config, Dataset(config, folder=None))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m._fwd_tables()
+
+
 def test_reference_checkpoint_state_loads_into_plugin_model():
     """Same shapes/names: a reference model's state_dict loads into the plugin class."""
     rh.import_reference()
