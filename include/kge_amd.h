@@ -200,7 +200,11 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
                     int64_t* rank, int64_t* ties, void* stream);
 
 /* ---- backward (autograd twins) ------------------------------------------ */
-/* All gradients are f32 and OVERWRITTEN; tables/embeddings must be f32.
+/* All gradients are f32 and OVERWRITTEN; tables/embeddings must be f32, except
+ * kge_score_pairs_bwd for ComplEx/DistMult, which also takes bf16 tables (mixed-precision
+ * training: gout rounded to bf16, both products on the bf16 matrix cores, f32 accumulation)
+ * and then needs `workspace_bytes >= kge_score_bwd_workspace_bytes(t, n, m)` of 256-byte
+ * aligned device scratch (0 / NULL for f32 tables).
  * `scores` is the forward output (needed by TransE/RotatE with l_norm != 1 to
  * recover the distance; may be NULL otherwise).
  *
@@ -209,11 +213,12 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
  *   g_a   [n, dim]      grad of the gathered entity query rows (s for SP_, o for PO_)
  *   g_p   [n, rel_dim]  grad of the gathered relation rows
  *   g_tgt [m, dim]      grad of the target rows (dense; caller scatter-adds)   */
+int64_t kge_score_bwd_workspace_bytes(const kge_tables* t, int64_t n, int64_t m);
 int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p,
                         int64_t n, kge_index targets, int64_t m,
                         const float* gout, int64_t ldg, const float* scores,
                         int64_t lds, float* g_a, float* g_p, float* g_tgt,
-                        void* stream);
+                        void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Gradients of sum_i gout[i]*score(s_i,p_i,o_i): g_s,g_o [n,dim], g_p [n,rel_dim]. */
 int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p,

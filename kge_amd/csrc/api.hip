@@ -40,6 +40,10 @@ int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
              long long col_offset, const long long* true_col, float atol, float rtol,
              long long* rank, long long* ties, hipStream_t st);
+int run_pairs_bwd_gemm16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
+                         int dr, long long n, long long m, const float* gout, long long ldg, float* g_a,
+                         float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
+long long pairs_bwd_workspace_bytes(int dtype, int scorer, int d, long long n, long long m);
 int run_pairs_bwd(int scorer, float lp, int dir, const Operand& A, const Operand& R,
                   const Operand& TG, int d, int dr, long long n, long long m, const float* gout,
                   long long ldg, const float* scores, long long lds, float* g_a, float* g_p,
@@ -271,12 +275,28 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
                   (long long*)rank, (long long*)ties, (hipStream_t)stream);
 }
 
+int64_t kge_score_bwd_workspace_bytes(const kge_tables* t, int64_t n, int64_t m) {
+  if (!t || n <= 0 || m <= 0) return 0;
+  return pairs_bwd_workspace_bytes(t->dtype, t->scorer, (int)t->dim, n, m);
+}
+
 int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
                         kge_index targets, int64_t m, const float* gout, int64_t ldg,
                         const float* scores, int64_t lds, float* g_a, float* g_p, float* g_tgt,
-                        void* stream) {
+                        void* workspace, int64_t workspace_bytes, void* stream) {
   int rc = check_tables(t, true);
   if (rc) return rc;
+  if (t->dtype == KGE_BF16) {  // mixed precision: ComplEx / DistMult on the bf16 matrix cores
+    if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
+    if (n < 0 || m < 0 || ldg < m) return KGE_ERR_INVALID_ARG;
+    if (n * m > 0 && (!gout || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
+    if ((rc = check_index(a, false)) || (rc = check_index(p, false)) || (rc = check_index(targets, true)))
+      return rc;
+    if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
+    return run_pairs_bwd_gemm16(t->scorer, dir, ent_op(t, a), rel_op(t, p), ent_op(t, targets), (int)t->dim,
+                                (int)t->rel_dim, n, m, gout, ldg, g_a, g_p, g_tgt, workspace, workspace_bytes,
+                                (hipStream_t)stream);
+  }
   if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
   if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
   if (n < 0 || m < 0 || ldg < m || (scores && lds < m)) return KGE_ERR_INVALID_ARG;

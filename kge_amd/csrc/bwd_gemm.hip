@@ -110,18 +110,23 @@ static rocblas_handle bwdg_handle() {
 
 // ---- column-major f32 GEMM C[m,n] = op(A) * op(B) through hipBLASLt, plans cached per shape
 struct LtPlan {
-  int ta, tb;
-  long long m, n, k, lda, ldb, ldc;
+  int ta, tb, in16, batch;
+  long long m, n, k, lda, ldb, ldc, sa, sb, sc;
   size_t ws_avail;
   bool ok;
   hipblasLtMatmulDesc_t desc;
   hipblasLtMatrixLayout_t la, lb, lc;
-  hipblasLtMatmulHeuristicResult_t res;
+  hipblasLtMatmulHeuristicResult_t res;  // the chosen algorithm
+  int ncand;
+  bool tuned;
+  hipblasLtMatmulHeuristicResult_t cand[8];
 };
 
-static bool lt_gemm(int ta, int tb, long long m, long long n, long long k, const float* A, long long lda,
-                    const float* B, long long ldb, float* C, long long ldc, void* ws, size_t ws_bytes,
-                    hipStream_t st) {
+// in16: A and B are bf16 (f32 accumulation and f32 C either way).  batch > 1: strided batch
+// (strides sa, sb, sc in elements).
+static bool lt_gemm(int in16, int ta, int tb, long long m, long long n, long long k, const void* A, long long lda,
+                    const void* B, long long ldb, float* C, long long ldc, void* ws, size_t ws_bytes,
+                    hipStream_t st, int batch = 1, long long sa = 0, long long sb = 0, long long sc = 0) {
   static std::mutex mu;
   static hipblasLtHandle_t handles[64] = {};
   static std::vector<LtPlan> plans[64];
@@ -136,13 +141,16 @@ static bool lt_gemm(int ta, int tb, long long m, long long n, long long k, const
   ws_bytes &= ~(size_t)255;
   LtPlan* pl = nullptr;
   for (auto& q : plans[dev])
-    if (q.ta == ta && q.tb == tb && q.m == m && q.n == n && q.k == k && q.lda == lda && q.ldb == ldb &&
+    if (q.in16 == in16 && q.batch == batch && q.sa == sa && q.sb == sb && q.sc == sc && q.ta == ta && q.tb == tb &&
+        q.m == m && q.n == n && q.k == k && q.lda == lda && q.ldb == ldb &&
         q.ldc == ldc && q.ws_avail == ws_bytes) {
       pl = &q;
       break;
     }
   if (!pl) {
-    LtPlan q{ta, tb, m, n, k, lda, ldb, ldc, ws_bytes, false, nullptr, nullptr, nullptr, nullptr, {}};
+    LtPlan q{ta, tb, in16, batch, m, n, k, lda, ldb, ldc, sa, sb, sc, ws_bytes, false, nullptr, nullptr, nullptr, nullptr,
+             {}, 0, false, {}};
+    const hipDataType tin = in16 ? HIP_R_16BF : HIP_R_32F;
     const hipblasOperation_t opa = ta ? HIPBLAS_OP_T : HIPBLAS_OP_N, opb = tb ? HIPBLAS_OP_T : HIPBLAS_OP_N;
     hipblasLtMatmulPreference_t pref = nullptr;
     int found = 0;
@@ -151,23 +159,148 @@ static bool lt_gemm(int ta, int tb, long long m, long long n, long long k, const
                        HIPBLAS_STATUS_SUCCESS;
     good = good && hipblasLtMatmulDescSetAttribute(q.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb)) ==
                        HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatrixLayoutCreate(&q.la, HIP_R_32F, ta ? k : m, ta ? m : k, lda) == HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatrixLayoutCreate(&q.lb, HIP_R_32F, tb ? n : k, tb ? k : n, ldb) == HIPBLAS_STATUS_SUCCESS;
+    good = good && hipblasLtMatrixLayoutCreate(&q.la, tin, ta ? k : m, ta ? m : k, lda) == HIPBLAS_STATUS_SUCCESS;
+    good = good && hipblasLtMatrixLayoutCreate(&q.lb, tin, tb ? n : k, tb ? k : n, ldb) == HIPBLAS_STATUS_SUCCESS;
     good = good && hipblasLtMatrixLayoutCreate(&q.lc, HIP_R_32F, m, n, ldc) == HIPBLAS_STATUS_SUCCESS;
+    if (good && batch > 1) {
+      const int32_t bc = batch;
+      const int64_t st3[3] = {sa, sb, sc};
+      hipblasLtMatrixLayout_t ls[3] = {q.la, q.lb, q.lc};
+      for (int i = 0; i < 3 && good; ++i) {
+        good = hipblasLtMatrixLayoutSetAttribute(ls[i], HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)) ==
+                   HIPBLAS_STATUS_SUCCESS &&
+               hipblasLtMatrixLayoutSetAttribute(ls[i], HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &st3[i],
+                                                 sizeof(int64_t)) == HIPBLAS_STATUS_SUCCESS;
+      }
+    }
     good = good && hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
     good = good && hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes,
                                                          sizeof(ws_bytes)) == HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatmulAlgoGetHeuristic(handles[dev], q.desc, q.la, q.lb, q.lc, q.lc, pref, 1, &q.res,
+    good = good && hipblasLtMatmulAlgoGetHeuristic(handles[dev], q.desc, q.la, q.lb, q.lc, q.lc, pref, 8, q.cand,
                                                    &found) == HIPBLAS_STATUS_SUCCESS;
     if (pref) hipblasLtMatmulPreferenceDestroy(pref);
-    q.ok = good && found > 0 && q.res.workspaceSize <= ws_bytes;
+    q.ncand = 0;
+    for (int i = 0; good && i < found; ++i)
+      if (q.cand[i].state == HIPBLAS_STATUS_SUCCESS && q.cand[i].workspaceSize <= ws_bytes)
+        q.cand[q.ncand++] = q.cand[i];
+    q.ok = good && q.ncand > 0;
+    if (q.ok) q.res = q.cand[0];
     plans[dev].push_back(q);
     pl = &plans[dev].back();
   }
   if (!pl->ok) return false;
   const float one = 1.0f, zero = 0.0f;
+  if (!pl->tuned) {
+    // First use of this shape: time the library's candidates once on the caller's data (the
+    // heuristic's first choice for the 512 x 512 x 14,541 dQ product is 5x slower than its
+    // best) and keep the fastest.  Host-synchronous, once per shape and process.
+    pl->tuned = true;
+    if (pl->ncand > 1) {
+      hipEvent_t e0, e1;
+      if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        float best = 1e30f;
+        int besti = 0;
+        for (int i = 0; i < pl->ncand; ++i) {
+          bool okrun = true;
+          float ms = 1e30f;
+          for (int rep = 0; rep < 3 && okrun; ++rep) {  // rep 0 = warm-up
+            if (rep == 1) hipEventRecord(e0, st);
+            okrun = hipblasLtMatmul(handles[dev], pl->desc, &one, A, pl->la, B, pl->lb, &zero, C, pl->lc, C,
+                                    pl->lc, &pl->cand[i].algo, ws, pl->cand[i].workspaceSize, st) ==
+                    HIPBLAS_STATUS_SUCCESS;
+          }
+          if (okrun && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+              hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) {
+            best = ms;
+            besti = i;
+          }
+        }
+        pl->res = pl->cand[besti];
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+      }
+    }
+  }
   return hipblasLtMatmul(handles[dev], pl->desc, &one, A, pl->la, B, pl->lb, &zero, C, pl->lc, C, pl->lc,
                          &pl->res.algo, ws, pl->res.workspaceSize, st) == HIPBLAS_STATUS_SUCCESS;
+}
+
+// sum of P partial [cnt] f32 arrays
+__global__ __launch_bounds__(256) void bwdg_reduce_kernel(const float* __restrict__ part, long long cnt, int P,
+                                                          float* __restrict__ out) {
+  const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= cnt) return;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(part + i);
+  for (int p = 1; p < P; ++p) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(part + (long long)p * cnt + i);
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+  }
+  *reinterpret_cast<f32x4*>(out + i) = acc;
+}
+
+// dQ^T[d, n] = T^T[d, m] * G^T[m, n] (column-major views): a small output with a very long
+// reduction (m = all entities).  The library has no split-K kernel for it (bf16 -> f32: 53 us for
+// 512 x 512 x 14,541 whatever the algorithm), so the reduction is split by hand: P strided-batch
+// products over K-chunks into P partial outputs (scratch), a tail product for m % P, one
+// reduction kernel.  P (or the plain product) is chosen by timing each once per shape.
+static bool gemm_long_k(int in16, int d, long long n, long long m, const void* T, long long ldt, const void* G,
+                        long long ldg, float* C, float* scratch, size_t scratch_bytes, hipStream_t st) {
+  struct Choice {
+    int in16, d;
+    long long n, m, ldt, ldg;
+    size_t sb;
+    int P;
+  };
+  static std::mutex mu;
+  static std::vector<Choice> choices;
+  const size_t es = in16 ? 2 : 4;
+  const long long cnt = n * d;
+  auto run = [&](int P) -> bool {
+    if (P <= 1) return lt_gemm(in16, 0, 0, d, n, m, T, ldt, G, ldg, C, d, scratch, scratch_bytes, st);
+    const long long kc = m / P, rem = m - kc * P;
+    const int slots = P + (rem ? 1 : 0);
+    if ((size_t)slots * cnt * 4 > scratch_bytes || kc == 0 || (cnt & 3)) return false;
+    if (!lt_gemm(in16, 0, 0, d, n, kc, T, ldt, G, ldg, scratch, d, nullptr, 0, st, P, kc * ldt, kc, cnt)) return false;
+    if (rem && !lt_gemm(in16, 0, 0, d, n, rem, (const char*)T + (size_t)(kc * P) * ldt * es, ldt,
+                        (const char*)G + (size_t)(kc * P) * es, ldg, scratch + (long long)P * cnt, d, nullptr, 0, st))
+      return false;
+    hipLaunchKernelGGL(bwdg_reduce_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, st, scratch, cnt,
+                       slots, C);
+    return true;
+  };
+  int P = -1;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& c : choices)
+      if (c.in16 == in16 && c.d == d && c.n == n && c.m == m && c.ldt == ldt && c.ldg == ldg && c.sb == scratch_bytes)
+        P = c.P;
+  }
+  if (P < 0) {  // first use of this shape: time the strategies once (host-synchronous)
+    const int cands[4] = {1, 4, 8, 16};
+    float best = 1e30f;
+    P = 1;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+      for (int ci = 0; ci < 4; ++ci) {
+        bool okrun = run(cands[ci]);  // warm-up (also tunes the library plan)
+        float ms = 1e30f;
+        if (okrun) {
+          hipEventRecord(e0, st);
+          okrun = run(cands[ci]) && run(cands[ci]);
+          if (okrun && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+              hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) {
+            best = ms;
+            P = cands[ci];
+          }
+        }
+      }
+      hipEventDestroy(e0);
+      hipEventDestroy(e1);
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    choices.push_back(Choice{in16, d, n, m, ldt, ldg, scratch_bytes, P});
+  }
+  return run(P);
 }
 
 template <int SCORER>
@@ -196,7 +329,7 @@ static int bwdg_run(int dir, const Operand& A, const Operand& R, const Operand& 
   // entities: g_tgt (written by the second product only) is the library's workspace here
   void* ws = TG.idx.ptr == nullptr ? (void*)g_tgt : nullptr;
   const size_t ws_bytes = TG.idx.ptr == nullptr ? (size_t)m * d * sizeof(float) : 0;
-  if (!lt_gemm(0, 0, d, n, m, T, ldt, gout, ldg, g_a, d, ws, ws_bytes, st)) {
+  if (!gemm_long_k(0, d, n, m, T, ldt, gout, ldg, g_a, (float*)ws, ws_bytes, st)) {
     if (!fallback()) return KGE_ERR_UNSUPPORTED;
     if (rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, d, (int)n, (int)m, &one, T, (int)ldt,
                       gout, (int)ldg, &zero, g_a, d) != rocblas_status_success)
@@ -204,7 +337,7 @@ static int bwdg_run(int dir, const Operand& A, const Operand& R, const Operand& 
   }
   // Q -> g_p, then dT = G^T * Q (row-major [m, d]) == column-major dT^T[d, m] = Q^T[d, n] * G[n, m]
   hipLaunchKernelGGL((bwdg_build_q_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_p);
-  if (!lt_gemm(0, 1, d, m, n, g_p, d, gout, ldg, g_tgt, d, nullptr, 0, st)) {
+  if (!lt_gemm(0, 0, 1, d, m, n, g_p, d, gout, ldg, g_tgt, d, nullptr, 0, st)) {
     if (!fallback()) return KGE_ERR_UNSUPPORTED;
     if (rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, d, (int)m, (int)n, &one, g_p, d,
                       gout, (int)ldg, &zero, g_tgt, d) != rocblas_status_success)
@@ -212,6 +345,148 @@ static int bwdg_run(int dir, const Operand& A, const Operand& R, const Operand& 
   }
   hipLaunchKernelGGL((bwdg_chain_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// ---- bf16 tables (mixed-precision training): the same two products on the bf16 matrix cores.
+// G is rounded to bf16 (what autocast does to the incoming gradient of a bf16 matmul), Q is the
+// bf16 query matrix of the forward; f32 accumulation, f32 gradients.  Scratch (caller-provided):
+// G16 [n, m] + Q16 [n, d] bf16.
+
+__global__ __launch_bounds__(256) void bwdg_cast_kernel(const float* __restrict__ g, long long ldg, long long n,
+                                                        long long m, unsigned short* __restrict__ out) {
+  // two columns per thread; row pitch of `out` = m rounded up to 8 elements (16-byte rows)
+  const long long mp2 = ((m + 7) & ~7LL) >> 1;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i = t / mp2;
+  const long long j = (t % mp2) * 2;
+  if (i >= n) return;
+  const float a = j < m ? g[i * ldg + j] : 0.0f, b = (j + 1 < m) ? g[i * ldg + j + 1] : 0.0f;
+  reinterpret_cast<unsigned int*>(out)[i * mp2 + (j >> 1)] = bf16_pack(a, b);
+}
+
+__device__ __forceinline__ float bwdg_w(const unsigned short* p, long long k) {
+  return __uint_as_float((unsigned int)p[k] << 16);
+}
+
+template <int SCORER>
+__global__ __launch_bounds__(256) void bwdg_build_q16_kernel(Operand A, Operand R, int dir, int d, long long n,
+                                                             unsigned short* __restrict__ Q) {
+  const int h = SCORER == KGE_COMPLEX ? d / 2 : d;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i = t / h;
+  const int c = (int)(t % h);
+  if (i >= n) return;
+  const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, i) * A.ld;
+  const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, i) * R.ld;
+  unsigned short* q = Q + i * d;
+  float q0, q1 = 0.0f;
+  if (SCORER == KGE_DISTMULT) {
+    q0 = bwdg_w(a, c) * bwdg_w(r, c);
+  } else if (dir == KGE_SP_) {
+    q0 = bwdg_w(a, c) * bwdg_w(r, c) - bwdg_w(a, h + c) * bwdg_w(r, h + c);
+    q1 = bwdg_w(a, h + c) * bwdg_w(r, c) + bwdg_w(a, c) * bwdg_w(r, h + c);
+  } else {
+    q0 = bwdg_w(r, c) * bwdg_w(a, c) + bwdg_w(r, h + c) * bwdg_w(a, h + c);
+    q1 = bwdg_w(r, c) * bwdg_w(a, h + c) - bwdg_w(r, h + c) * bwdg_w(a, c);
+  }
+  const unsigned int pk = bf16_pack(q0, q1);  // RNE, the forward's rounding of q
+  q[c] = (unsigned short)(pk & 0xffffu);
+  if (SCORER == KGE_COMPLEX) q[h + c] = (unsigned short)(pk >> 16);
+}
+
+template <int SCORER>
+__global__ __launch_bounds__(256) void bwdg_chain16_kernel(Operand A, Operand R, int dir, int d, long long n,
+                                                           float* __restrict__ g_a, float* __restrict__ g_p) {
+  const int h = SCORER == KGE_COMPLEX ? d / 2 : d;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i = t / h;
+  const int c = (int)(t % h);
+  if (i >= n) return;
+  const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, i) * A.ld;
+  const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, i) * R.ld;
+  float* ga = g_a + i * d;
+  float* gp = g_p + i * d;
+  if (SCORER == KGE_DISTMULT) {
+    const float dq = ga[c];
+    ga[c] = dq * bwdg_w(r, c);
+    gp[c] = dq * bwdg_w(a, c);
+    return;
+  }
+  const float dre = ga[c], dim_ = ga[h + c];
+  const float are = bwdg_w(a, c), aim = bwdg_w(a, h + c), rre = bwdg_w(r, c), rim = bwdg_w(r, h + c);
+  if (dir == KGE_SP_) {
+    ga[c] = dre * rre + dim_ * rim;
+    ga[h + c] = dim_ * rre - dre * rim;
+    gp[c] = dre * are + dim_ * aim;
+    gp[h + c] = dim_ * are - dre * aim;
+  } else {
+    ga[c] = dre * rre - dim_ * rim;
+    ga[h + c] = dre * rim + dim_ * rre;
+    gp[c] = dre * are + dim_ * aim;
+    gp[h + c] = dre * aim - dim_ * are;
+  }
+}
+
+__global__ __launch_bounds__(256) void bwdg_gather16_kernel(Operand TG, int d, long long m,
+                                                            unsigned short* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long j = t / d;
+  const int c = (int)(t % d);
+  if (j >= m) return;
+  out[j * d + c] = ((const unsigned short*)TG.base + index_at(TG.idx, j) * TG.ld)[c];
+}
+
+long long pairs_bwd_workspace_bytes(int dtype, int scorer, int d, long long n, long long m) {
+  if (dtype != KGE_BF16 || (scorer != KGE_COMPLEX && scorer != KGE_DISTMULT)) return 0;
+  const long long mp = (m + 7) & ~7LL;
+  return ((n * mp * 2 + 255) & ~255LL) + ((n * (long long)d * 2 + 255) & ~255LL);
+}
+
+template <int SCORER>
+static int bwdg_run16(int dir, const Operand& A, const Operand& R, const Operand& TG, int d, long long n,
+                      long long m, const float* gout, long long ldg, float* g_a, float* g_p, float* g_tgt,
+                      void* wsp, long long ws_bytes, hipStream_t st) {
+  const long long mp = (m + 7) & ~7LL;  // row pitch of G16 (elements)
+  const long long g16_bytes = (n * mp * 2 + 255) & ~255LL;
+  if (wsp == nullptr || ((uintptr_t)wsp & 255) || ws_bytes < g16_bytes + n * (long long)d * 2) return KGE_ERR_WORKSPACE;
+  unsigned short* G16 = (unsigned short*)wsp;
+  unsigned short* Q16 = (unsigned short*)((char*)wsp + g16_bytes);
+  const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
+  const unsigned qblocks = (unsigned)((n * half + 255) / 256);
+  hipLaunchKernelGGL(bwdg_cast_kernel, dim3((unsigned)((n * (mp / 2) + 255) / 256)), dim3(256), 0, st, gout, ldg, n,
+                     m, G16);
+  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, Q16);
+  const unsigned short* T = (const unsigned short*)TG.base;
+  long long ldt = TG.ld;
+  if (TG.idx.ptr != nullptr) {  // gathered target rows live in g_tgt until dT overwrites it
+    hipLaunchKernelGGL(bwdg_gather16_kernel, dim3((unsigned)((m * d + 255) / 256)), dim3(256), 0, st, TG, d, m,
+                       (unsigned short*)g_tgt);
+    T = (const unsigned short*)g_tgt;
+    ldt = d;
+  }
+  // dQ^T[d, n] = T^T[d, m] * G^T[m, n];  dT^T[d, m] = Q^T[d, n] * G[n, m]  (column-major views)
+  // all entities: g_tgt (written by the second product only) is the library's split-K workspace
+  void* lws = TG.idx.ptr == nullptr ? (void*)g_tgt : nullptr;
+  const size_t lws_bytes = TG.idx.ptr == nullptr ? (size_t)m * d * sizeof(float) : 0;
+  if (!gemm_long_k(1, d, n, m, T, ldt, G16, mp, g_a, (float*)lws, lws_bytes, st)) return KGE_ERR_UNSUPPORTED;
+  if (!lt_gemm(1, 0, 1, d, m, n, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st)) return KGE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_pairs_bwd_gemm16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
+                         int dr, long long n, long long m, const float* gout, long long ldg, float* g_a,
+                         float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st) {
+  if (n == 0 || m == 0) return KGE_OK;
+  if (scorer != KGE_COMPLEX && scorer != KGE_DISTMULT) return KGE_ERR_UNSUPPORTED;
+  if (dr != d || !g_a || !g_p || !g_tgt || (d % 2)) return KGE_ERR_UNSUPPORTED;
+  if (n >= (1LL << 31) || m >= (1LL << 31) || TG.ld >= (1LL << 31)) return KGE_ERR_UNSUPPORTED;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+    return KGE_ERR_UNSUPPORTED;
+  if (scorer == KGE_COMPLEX)
+    return bwdg_run16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, ws, ws_bytes, st);
+  return bwdg_run16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, ws, ws_bytes, st);
 }
 
 // KGE_ERR_UNSUPPORTED: the caller uses the self-contained kernels of bwd.hip

@@ -356,13 +356,22 @@ def score_pairs_bwd(t: Tables, direction: str, a, p, targets, gout, scores=None)
     if scores is not None:
         sc = scores if scores.stride(-1) == 1 else scores.contiguous()
     g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((m, d), t.device)
-    with torch.cuda.device(t.device):
+    with _on_device(t.device):
         tc = t.c()
+        st = _stream_handle(t.device)
+        need = _lib.lib().kge_score_bwd_workspace_bytes(ctypes.byref(tc), n, m)
+        ws, wsb = (None, 0)
+        if need > 0:  # bf16 tables: scratch for the bf16 copies of gout and of the query matrix
+            key = (t.device.index, st, "bwd")
+            buf = _WORKSPACES.get(key)
+            if buf is None or buf.numel() < need:
+                buf = _WORKSPACES[key] = _empty((need,), t.device, torch.uint8)
+            ws, wsb = buf.data_ptr(), buf.numel()
         _lib.check(_lib.lib().kge_score_pairs_bwd(
             ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, n, ti, m, gout.data_ptr(),
             gout.stride(0) if n > 1 else max(m, 1), None if sc is None else sc.data_ptr(),
             0 if sc is None else (sc.stride(0) if n > 1 else max(m, 1)), g_a.data_ptr(),
-            g_p.data_ptr(), g_t.data_ptr(), _stream(t.device)), "kge_score_pairs_bwd")
+            g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_score_pairs_bwd")
     return g_a, g_p, g_t
 
 

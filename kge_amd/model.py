@@ -286,6 +286,7 @@ class _ScorePairs(torch.autograd.Function):
         tf = t if fwd_tables is None else fwd_tables  # mixed precision: bf16 copies, forward only
         out = (engine.score_sp if direction == "sp" else engine.score_po)(tf, *((a, p) if direction == "sp" else (p, a)), targets)
         ctx.t, ctx.direction, ctx.idx = t, direction, (a, p, targets)
+        ctx.tf = fwd_tables
         ctx.save_for_backward(out)
         return out
 
@@ -293,7 +294,10 @@ class _ScorePairs(torch.autograd.Function):
     def backward(ctx, gout):
         a, p, targets = ctx.idx
         (scores,) = ctx.saved_tensors
-        g_a, g_p, g_t = engine.score_pairs_bwd(ctx.t, ctx.direction, a, p, targets, gout, scores)
+        # mixed precision: both gradient products on the bf16 matrix cores too (bf16 copies of the
+        # tables, gout rounded to bf16, f32 accumulation) -- autocast semantics
+        g_a, g_p, g_t = engine.score_pairs_bwd(ctx.tf if ctx.tf is not None else ctx.t, ctx.direction, a, p,
+                                               targets, gout, scores)
         ge, gr = torch.zeros_like(ctx.t.ent), torch.zeros_like(ctx.t.rel)
         _scatter_rows(ge, a, g_a)
         _scatter_rows(gr, p, g_p)

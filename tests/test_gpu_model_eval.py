@@ -150,8 +150,8 @@ def test_backward_matches_torch_autograd(name, l_norm):
 
 def test_mixed_precision_scoring():
     """score_dtype=bfloat16 on f32 parameters (ComplEx / DistMult): the forward is the bf16
-    matrix-core kernel on bf16 copies of the tables (bit for bit), the backward is the f32 one
-    (same gradients as the f32 model for the same upstream gradient), and the copies follow the
+    matrix-core kernel on bf16 copies of the tables (bit for bit), the backward runs on the bf16
+    copies too (gradients of the f32 model within bf16 rounding), and the copies follow the
     parameters."""
     from kge_amd import engine as eng
     from kge_amd import model as km
@@ -178,10 +178,52 @@ def test_mixed_precision_scoring():
             (out32 * w).sum().backward()
             for a, b in ((mmp._entity_embedder.weight.grad, m32._entity_embedder.weight.grad),
                          (mmp._relation_embedder.weight.grad, m32._relation_embedder.weight.grad)):
-                torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+                # backward of the mixed-precision model runs on the bf16 matrix cores (operands
+                # rounded to bf16): agreement with the f32 backward within that rounding
+                torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+                assert float((a - b).abs().mean()) <= 2e-3 * float(b.abs().max())
         # evaluation path (no autograd): two-sided launch on the copies, refreshed after an update
         with torch.no_grad():
             assert torch.equal(mmp.score_sp_po(s, p, o), eng.score_sp_po(T16, s, p, o))
             mmp._entity_embedder.weight.mul_(0.5)
             T16b = eng.Tables(name, mmp._entity_embedder.weight.detach().bfloat16(), rel16)
             assert torch.equal(mmp.score_sp_po(s, p, o), eng.score_sp_po(T16b, s, p, o))
+
+
+@pytest.mark.parametrize("name", ["complex", "distmult"])
+def test_bf16_backward_vs_f32_autograd(name):
+    """kge_score_pairs_bwd on bf16 tables (both products on the bf16 matrix cores, gout rounded to
+    bf16) against torch autograd of the reference op sequence in f32 on the same table values:
+    within bf16 rounding of the operands (relative to the size of the gradient rows)."""
+    from kge_amd import engine as eng
+    E, R, d, n = 1100 + 3, 7, 256, 130
+    g = torch.Generator().manual_seed(5)
+    ent = torch.empty(E, d).normal_(0, 0.3, generator=g).bfloat16().to(DEV)
+    rel = torch.empty(R, d).normal_(0, 0.3, generator=g).bfloat16().to(DEV)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    sub = torch.randperm(E, generator=g)[:257].to(DEV)
+    T = eng.Tables(name, ent, rel)
+    for direction, a, targets in (("sp", s, None), ("po", o, None), ("sp", s, sub)):
+        m = E if targets is None else sub.numel()
+        gout = torch.randn(n, m, generator=g).to(DEV)
+        g_a, g_p, g_t = eng.score_pairs_bwd(T, direction, a, p, targets, gout)
+        ef, rf = ent.float().requires_grad_(True), rel.float().requires_grad_(True)
+        tgt = ef if targets is None else ef[targets]
+        args = (ef[a], rf[p], tgt, "sp_") if direction == "sp" else (tgt, rf[p], ef[a], "_po")
+        (tp.score_emb(name, *args, 1.0) * gout).sum().backward()
+        want_t = ef.grad.clone()
+        # reference grads of the gathered rows: subtract the query rows' own contribution is not
+        # possible, so compare scatter-added tables
+        ge = torch.zeros_like(want_t)
+        ge.index_add_(0, a, g_a)
+        if targets is None:
+            ge += g_t
+        else:
+            ge.index_add_(0, targets, g_t)
+        gr = torch.zeros_like(rf.grad)
+        gr.index_add_(0, p, g_p)
+        for got, want in ((ge, want_t), (gr, rf.grad)):
+            scale = float(want.abs().max())
+            torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2 * scale)
+            # and much tighter on average
+            assert float((got - want).abs().mean()) <= 2e-3 * scale

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""One 1vsAll training step (train_1vsAll.py:48-82: score_sp -> KL/CE loss -> backward, score_po ->
+loss -> backward, Adagrad step) at the C2 shape with float32 parameters: the stand-alone mirror
+model (f32 scoring, mixed-precision scoring) vs the reference's op sequence in PyTorch-ROCm."""
+import os, sys, time
+import torch
+import torch.nn.functional as F
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from kge_amd import model as km
+
+dev = torch.device("cuda", 0)
+E, R, d, n = 14541, 237, 512, 512
+g = torch.Generator().manual_seed(0)
+s = torch.randint(E, (n,), generator=g).to(dev); p = torch.randint(R, (n,), generator=g).to(dev)
+o = torch.randint(E, (n,), generator=g).to(dev)
+
+
+class RefModel(torch.nn.Module):  # complex.py:24-39 / distmult.py:15-21 on LookupEmbedder tables
+    def __init__(self, name):
+        super().__init__()
+        self.name = name
+        self.ent = torch.nn.Parameter(torch.empty(E, d, device=dev).normal_(0, 0.1))
+        self.rel = torch.nn.Parameter(torch.empty(R, d, device=dev).normal_(0, 0.1))
+        self.all = torch.arange(E, device=dev)
+
+    def _emb(self, s_emb, p_emb, o_emb, combine):
+        if self.name == "distmult":
+            return (s_emb * p_emb).mm(o_emb.t()) if combine == "sp_" else (o_emb * p_emb).mm(s_emb.t())
+        p_re, p_im = (t.contiguous() for t in p_emb.chunk(2, dim=1))
+        o_re, o_im = (t.contiguous() for t in o_emb.chunk(2, dim=1))
+        s_all = torch.cat((s_emb, s_emb), dim=1)
+        r_all = torch.cat((p_re, p_emb, -p_im), dim=1)
+        o_all = torch.cat((o_emb, o_im, o_re), dim=1)
+        return (s_all * r_all).mm(o_all.t()) if combine == "sp_" else (r_all * o_all).mm(s_all.t())
+
+    def score_sp(self, s, p):
+        return self._emb(self.ent[s], self.rel[p], self.ent[self.all], "sp_")
+
+    def score_po(self, p, o):
+        return self._emb(self.ent[self.all], self.rel[p], self.ent[o], "_po")
+
+
+def step(m, opt):
+    opt.zero_grad(set_to_none=True)
+    F.cross_entropy(m.score_sp(s, p), o, reduction="sum").backward()
+    F.cross_entropy(m.score_po(p, o), s, reduction="sum").backward()
+    opt.step()
+
+
+def timeit(fn, k=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(k): fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / k
+
+
+for name in ("complex", "distmult"):
+    res = {}
+    for tag, mk in (("reference ops (PyTorch-ROCm)", lambda: RefModel(name)),
+                    ("kge_amd f32 scoring", lambda: km.create(name, E, R, d, device=dev)),
+                    ("kge_amd score_dtype=bfloat16", lambda: km.create(name, E, R, d, device=dev, score_dtype=torch.bfloat16))):
+        m = mk()
+        opt = torch.optim.Adagrad(m.parameters(), lr=0.1)
+        res[tag] = timeit(lambda: step(m, opt))
+    print(name, " | ".join(f"{k}: {v:.2f} ms" for k, v in res.items()))
+
+# ---- where the mixed-precision step spends its GPU time
+from torch.profiler import profile, ProfilerActivity
+m = km.create("complex", E, R, d, device=dev, score_dtype=torch.bfloat16)
+opt = torch.optim.Adagrad(m.parameters(), lr=0.1)
+for _ in range(3): step(m, opt)
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for _ in range(5): step(m, opt)
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=70))
