@@ -158,21 +158,29 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     stamp();  // 2: tiles 0, 1 issued
     {
       const unsigned long long* f = flags + rg * 16;
-      for (int spin = 0; spin < (1 << 24); ++spin) {  // bounded: a lost builder must not hang the GPU
+      for (int spin = 0;; ++spin) {
         const unsigned long long v =
             lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
         if (__all(v == epoch)) break;
+        // bounded (seconds): a lost builder must neither hang the GPU nor let this workgroup
+        // score with garbage -- abort the launch, the host sees a launch failure
+        if (spin == (1 << 21)) __builtin_trap();
         __builtin_amdgcn_s_sleep(4);
       }
-      // No acquire fence (it would invalidate the whole L2, target tiles included): the
-      // fragment lines cannot be stale in this CU's L1 or this XCD's L2 -- both are
-      // invalidated at kernel start and nothing reads the fragments before the flags are seen.
+      // No acquire fence (it would invalidate this CU's L1 and cost ~1.7 us): the builders
+      // stored with sc1, the fragments are read with sc1 loads below (served by L2, never by L1).
       asm volatile("" ::: "memory");
     }
     stamp();  // 3: all shares of this row group published
-    const u32x4* src = qf + ((long long)(rg * (V3_ROWS / 32) + wave) * NKB) * 64 + lane;
-#pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) afr[kb] = __builtin_bit_cast(bf16x8, src[kb * 64]);
+    const unsigned char* sb =
+        (const unsigned char*)(qf + ((long long)(rg * (V3_ROWS / 32) + wave) * NKB) * 64);  // uniform
+    auto fload = [](bf16x8& dst, unsigned int vo, const unsigned char* base) __attribute__((always_inline)) {
+      asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
+    };
+    v3_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      fload(afr[kb], (unsigned int)(lane * 16 + kb * 1024), sb);
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp();  // 4: fragments loaded
   } else {

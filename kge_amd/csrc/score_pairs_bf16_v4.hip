@@ -279,10 +279,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   if (wave == 0) {
     // ONE wave per workgroup polls (255 pollers already cost chip bandwidth): one flag per builder
     unsigned long long* f = flags + ((long long)rg * ncg + cg) * 8;
-    for (int spin = 0; spin < (1 << 24); ++spin) {  // bounded: a lost builder must not hang the GPU
+    int spin = 0;
+    for (;; ++spin) {
       const unsigned long long v =
           lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
       if (__all(v == epoch)) break;
+      // bounded (seconds): a lost builder must neither hang the GPU nor let this workgroup score
+      // with garbage -- abort the launch, the host sees a launch failure
+      if (spin == (1 << 21)) __builtin_trap();
       __builtin_amdgcn_s_sleep(1);
     }
     // This line belongs to this workgroup alone (the builders write it, nobody else reads it):
