@@ -410,3 +410,43 @@ def test_rank_counts_random_vs_oracle_and_torch(eng, n, c, lds_pad):
     r, t = eng.rank_counts(tsc, _t(true))
     _eq("torch rank", _np(r), _np(((x > tt) & ~close).sum(1)))
     _eq("torch ties", _np(t), _np(close.sum(1)))
+
+
+def test_duplicates_zero_rows_and_non_finite_values(eng):
+    """Collisions and degenerate values: repeated query indices, repeated ids in the listed
+    subset, an all-zero entity row, infinities and NaNs in the tables.  f32-arithmetic paths
+    bit for bit against the oracle (NaN == NaN); the bf16 matrix-core kernel: duplicates give
+    identical columns / rows, finite entries within tolerance, non-finite entries where the
+    oracle has them."""
+    rng = np.random.default_rng(21)
+    E, R, d, n = 300, 5, 256, 70
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    ent[7] = 0.0
+    ent[11, 3] = np.inf
+    ent[13, 200] = np.nan
+    rel[2, 5] = -np.inf
+    s = rng.integers(0, E, n); s[:6] = [7, 11, 13, 7, 11, 13]; s[10:20] = s[20:30]  # repeated queries
+    p = rng.integers(0, R, n); p[:6] = [0, 1, 2, 2, 0, 1]; p[10:20] = p[20:30]
+    sub = np.concatenate([rng.integers(0, E, 150), [7, 11, 13, 7, 7], rng.integers(0, E, 40)])  # repeated targets
+    for model in ("complex", "distmult", "transe", "rotate"):
+        rl = rel[:, : d // 2] if model == "rotate" else rel
+        T = _gpu_tables(eng, model, ent, rl, 1.0, flags=eng.FLAG_EXACT)
+        O = _oracle_tables(model, ent, rl, 1.0)
+        _eq(f"{model} sp_sub", _np(eng.score_sp(T, _t(s), _t(p), _t(sub))), ko.score_sp(O, s, p, sub))
+        _eq(f"{model} spo", _np(eng.score_spo(T, _t(s), _t(p), _t(s[::-1].copy()))), ko.score_spo(O, s, p, s[::-1].copy()))
+    for model in ("complex", "distmult"):
+        T = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+        O = _oracle_tables(model, ent, rel, 1.0, bf16=True)
+        got, want = _np(eng.score_sp(T, _t(s), _t(p), _t(sub))), ko.score_sp(O, s, p, sub)
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), model
+        assert np.array_equal(got[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)]), model  # same infinities
+        g2, w2 = got.copy(), want.copy()
+        g2[~fin] = 0.0
+        w2[~fin] = 0.0
+        _close(f"{model} bf16 finite entries", g2, w2)
+        _eq(f"{model} repeated queries -> identical rows", got[10:20], got[20:30])
+        first7 = int(np.nonzero(sub == 7)[0][0])
+        for j in np.nonzero(sub == 7)[0][1:]:
+            _eq(f"{model} repeated target -> identical columns", got[:, j], got[:, first7])
