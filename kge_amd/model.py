@@ -298,13 +298,14 @@ class _ScorePairs(torch.autograd.Function):
         # tables, gout rounded to bf16, f32 accumulation) -- autocast semantics
         g_a, g_p, g_t = engine.score_pairs_bwd(ctx.tf if ctx.tf is not None else ctx.t, ctx.direction, a, p,
                                                targets, gout, scores)
-        ge, gr = torch.zeros_like(ctx.t.ent), torch.zeros_like(ctx.t.rel)
-        _scatter_rows(ge, a, g_a)
+        gr = torch.zeros_like(ctx.t.rel)
         _scatter_rows(gr, p, g_p)
         if targets is None:
-            ge += g_t
+            ge = g_t  # [E, d], fresh: the dense target gradient IS the table gradient, plus the query rows
         else:
+            ge = torch.zeros_like(ctx.t.ent)
             _scatter_rows(ge, targets, g_t)
+        _scatter_rows(ge, a, g_a)
         return None, None, None, ge, gr, None, None, None, None
 
 
