@@ -140,16 +140,17 @@ def main():
         s_rows, o_rows = buf["gath"][:n, :DIM], buf["gath"][:n, DIM:]  # row i = [s row | o row] of query i
 
         def exchange():
-            torch.index_select(ent, 0, so_idx, out=buf["loc"])
+            # the query rows this rank owns (s and o interleaved) and the relation rows: ONE
+            # gather launch (kge_embed), then ONE all-gather
+            engine.embed(T, so_idx, p, buf["loc"], buf["pe"])
             td.all_gather_into_tensor(buf["gath"].view(-1), buf["loc"].view(-1))
-            torch.index_select(rel, 0, p, out=buf["pe"])
 
         def score():
             engine.score_emb("complex", s_rows, buf["pe"], ent, "sp_")
             engine.score_emb("complex", ent, buf["pe"], o_rows, "_po")
 
-        # The exchange (3 small kernels incl. the RCCL all-gather) costs 28 us of host work when
-        # issued op by op; captured once in a hipGraph it is one 12 us replay per step.  Measured
+        # The exchange (a gather kernel and the RCCL all-gather) is captured once in a hipGraph
+        # (issued op by op it costs more host work than the scoring it feeds).  Measured
         # alternatives on one rank (tools/dist_probe.py, profiles/): replaying it on a side stream
         # one step ahead of the scoring is SLOWER (53 vs 47 us per step): the persistent scoring
         # kernel needs whole CUs (160 KB LDS, all VGPRs), so the side stream's kernels and its

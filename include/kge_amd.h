@@ -199,6 +199,16 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
                     const int64_t* true_col, float atol, float rtol,
                     int64_t* rank, int64_t* ties, void* stream);
 
+/* ---- LookupEmbedder.embed ------------------------------------------------ */
+/* ent_out[i, :] = ent[ent_idx[i], :] (n_ent rows, leading dimension ent_ldo elements) and
+ * rel_out[i, :] = rel[rel_idx[i], :] in ONE launch (table dtype; rows of 16-byte multiples).
+ * kge/model/embedder/lookup_embedder.py:96-105.  The scoring entry points gather on the fly
+ * and never need this; the entity-sharded path does: a rank gathers the query rows it owns
+ * before the single all-gather of a batch.  Either count may be 0. */
+int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_out,
+              int64_t ent_ldo, kge_index rel_idx, int64_t n_rel, void* rel_out,
+              int64_t rel_ldo, void* stream);
+
 /* ---- backward (autograd twins) ------------------------------------------ */
 /* All gradients are f32 and OVERWRITTEN; tables/embeddings must be f32, except
  * kge_score_pairs_bwd for ComplEx/DistMult, which also takes bf16 tables (mixed-precision

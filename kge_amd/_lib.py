@@ -56,6 +56,7 @@ PROTOTYPES = {
                                      ctypes.c_int32, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_emb": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                      c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kge_embed": (ctypes.c_int, [_PT, KgeIndex, c_i64, c_vp, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
     "kge_rank_counts": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                        ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
     "kge_score_bwd_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),

@@ -36,6 +36,7 @@ int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Oper
                       int d, long long n, long long m, float* out, long long ldo,
                       hipStream_t st, unsigned long long* dbg = nullptr, void* ws = nullptr,
                       long long ws_bytes = 0);
+int run_embed2(const EmbedJob& a, const EmbedJob& b, int rowbytes, int esize, hipStream_t st);
 int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
              long long col_offset, const long long* true_col, float atol, float rtol,
@@ -236,6 +237,31 @@ int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o, in
   return run_spo(t->scorer, t->dtype, true, ent_op(t, s), rel_op(t, p), ent_op(t, o),
                  (int)t->dim, (int)t->rel_dim, n, slot, neg, neg_itype, neg_ld, num_neg,
                  t->l_norm, out, ldo, (hipStream_t)stream);
+}
+
+// ---- LookupEmbedder.embed: gathered entity rows and relation rows of a batch, one launch
+int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_out, int64_t ent_ldo,
+              kge_index rel_idx, int64_t n_rel, void* rel_out, int64_t rel_ldo, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (n_ent < 0 || n_rel < 0 || (n_ent > 0 && !ent_out) || (n_rel > 0 && !rel_out)) return KGE_ERR_INVALID_ARG;
+  if ((n_ent > 0 && (rc = check_index(ent_idx, false))) || (n_rel > 0 && (rc = check_index(rel_idx, false))))
+    return rc;
+  const int es = t->dtype == KGE_BF16 ? 2 : 4;
+  const long long eb = t->dim * es, rb = t->rel_dim * es;  // bytes per row
+  auto ok = [&](const void* p, long long ld, long long rowb) {
+    return ((uintptr_t)p & 15) == 0 && (ld * es) % 16 == 0 && rowb % 16 == 0 && rowb < (1LL << 31);
+  };
+  if ((n_ent && (!ok(t->ent, t->ent_ld, eb) || !ok(ent_out, ent_ldo, eb))) ||
+      (n_rel && (!ok(t->rel, t->rel_ld, rb) || !ok(rel_out, rel_ldo, rb))))
+    return KGE_ERR_UNSUPPORTED;
+  EmbedJob a{t->ent, t->ent_ld, make_index(ent_idx), n_ent, ent_out, ent_ldo};
+  EmbedJob b{t->rel, t->rel_ld, make_index(rel_idx), n_rel, rel_out, rel_ldo};
+  const EmbedJob none{nullptr, 0, Index{}, 0, nullptr, 0};
+  if (eb == rb || n_ent == 0 || n_rel == 0)
+    return run_embed2(n_ent ? a : none, n_rel ? b : none, (int)(n_ent ? eb : rb), es, (hipStream_t)stream);
+  rc = run_embed2(a, none, (int)eb, es, (hipStream_t)stream);  // RotatE: rows of different length
+  return rc ? rc : run_embed2(none, b, (int)rb, es, (hipStream_t)stream);
 }
 
 int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s_ld,

@@ -48,6 +48,16 @@ struct Operand {
   Index idx;
 };
 
+// One gather job of embed.hip: out[i, :] = table[idx[i], :]
+struct EmbedJob {
+  const void* table;
+  long long ld;  // elements
+  Index idx;
+  long long n;
+  void* out;
+  long long ldo;  // elements
+};
+
 // Flattened table descriptor for kernels.
 struct Tables {
   const void* ent;

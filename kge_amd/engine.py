@@ -19,7 +19,7 @@ from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_BF16_V3, FLAG_EXA
                    KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3", "reserve_cus"]
+           "score_emb", "embed", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3", "reserve_cus"]
 
 
 def reserve_cus(n: int) -> int:
@@ -280,6 +280,32 @@ def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, fl
             p_emb.stride(0), o_emb.data_ptr(), o_emb.stride(0), n, m, out.data_ptr(), max(m, 1),
             ws, wsb, _stream(s_emb.device)), "kge_score_emb")
     return out.view(n, -1)
+
+
+def embed(t: Tables, ent_idx=None, rel_idx=None, ent_out=None, rel_out=None):
+    """LookupEmbedder.embed for both tables in ONE launch: (ent[ent_idx], rel[rel_idx]); outputs
+    may be preallocated (row stride free, e.g. a slice of an exchange buffer)."""
+    keep = []
+    tc = t.c()
+    ne = nr = 0
+    ei = ri = KgeIndex(None, I64, 0, 1)
+    if ent_idx is not None:
+        ei = _index(ent_idx, t.device, keep)
+        ne = keep[-1].numel()
+        if ent_out is None:
+            ent_out = _empty((ne, t.ent.shape[1]), t.device, t.ent.dtype)
+    if rel_idx is not None:
+        ri = _index(rel_idx, t.device, keep)
+        nr = keep[-1].numel()
+        if rel_out is None:
+            rel_out = _empty((nr, t.rel.shape[1]), t.device, t.rel.dtype)
+    with _on_device(t.device):
+        rc = _lib.lib().kge_embed(ctypes.byref(tc), ei, ne, ent_out.data_ptr() if ne else None,
+                                  ent_out.stride(0) if ne else 0, ri, nr, rel_out.data_ptr() if nr else None,
+                                  rel_out.stride(0) if nr else 0, _stream_handle(t.device))
+        if rc:
+            _lib.check(rc, "kge_embed")
+    return ent_out, rel_out
 
 
 def rank_counts(scores, true_scores, lbl_rowptr=None, lbl_col=None, col_offset=0, true_col=None,

@@ -450,3 +450,24 @@ def test_duplicates_zero_rows_and_non_finite_values(eng):
         first7 = int(np.nonzero(sub == 7)[0][0])
         for j in np.nonzero(sub == 7)[0][1:]:
             _eq(f"{model} repeated target -> identical columns", got[:, j], got[:, first7])
+
+
+@pytest.mark.parametrize("model,dt", [("complex", torch.bfloat16), ("rotate", torch.float32)])
+def test_embed_rows(eng, model, dt):
+    """kge_embed (LookupEmbedder.embed, both tables in one launch) == tensor indexing; strided
+    outputs, int32 / int64 / strided index views, empty sides."""
+    g = torch.Generator().manual_seed(9)
+    E, R, d = 500, 7, 128
+    dr = d // 2 if model == "rotate" else d
+    ent = torch.randn(E, d, generator=g).to(dt).to(DEV)
+    rel = torch.randn(R, dr, generator=g).to(dt).to(DEV)
+    T = eng.Tables(model, ent, rel)
+    tri = torch.stack([torch.randint(E, (77,), generator=g), torch.randint(R, (77,), generator=g),
+                       torch.randint(E, (77,), generator=g)], 1).to(DEV)
+    e, r = eng.embed(T, tri[:, 0], tri[:, 1].int())
+    assert torch.equal(e, ent[tri[:, 0]]) and torch.equal(r, rel[tri[:, 1]])
+    wide = torch.zeros(77, 2 * d, dtype=dt, device=DEV)
+    eng.embed(T, tri[:, 2], None, wide[:, d:], None)
+    assert torch.equal(wide[:, d:], ent[tri[:, 2]]) and not wide[:, :d].any()
+    e2, r2 = eng.embed(T, None, tri[:5, 1])
+    assert e2 is None and torch.equal(r2, rel[tri[:5, 1]])
