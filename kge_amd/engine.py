@@ -253,6 +253,9 @@ def score_neg(t: Tables, s, p, o, slot: int, neg: torch.Tensor, flags=None) -> t
     return out
 
 
+_EMB_TC = {}
+
+
 def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, flags: int = 0):
     """RelationalScorer.score_emb on dense embeddings (no gather)."""
     code = {"spo": SPO, "sp_": SP_, "_po": PO_}.get(combine)
@@ -272,13 +275,20 @@ def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, fl
     else:
         m = o_emb.shape[0] if code == SP_ else s_emb.shape[0]
         out = _empty((n, m), s_emb.device)
-    tc = KgeTables(None, None, _dtype_code(s_emb), sc, 0, 0, d, dr, d, dr, float(l_norm), int(flags))
-    with torch.cuda.device(s_emb.device):
-        ws, wsb = _workspace(tc, n, s_emb.device, True)
-        _lib.check(_lib.lib().kge_score_emb(
+    key = (s_emb.dtype, sc, d, dr, float(l_norm), int(flags))
+    tc = _EMB_TC.get(key)
+    if tc is None:
+        tc = _EMB_TC[key] = KgeTables(None, None, _dtype_code(s_emb), sc, 0, 0, d, dr, d, dr, float(l_norm),
+                                      int(flags))
+    with _on_device(s_emb.device):
+        st = _stream_handle(s_emb.device)
+        ws, wsb = _workspace(tc, n, s_emb.device, True, st)
+        rc = _lib.lib().kge_score_emb(
             ctypes.byref(tc), code, s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(),
             p_emb.stride(0), o_emb.data_ptr(), o_emb.stride(0), n, m, out.data_ptr(), max(m, 1),
-            ws, wsb, _stream(s_emb.device)), "kge_score_emb")
+            ws, wsb, st)
+        if rc:
+            _lib.check(rc, "kge_score_emb")
     return out.view(n, -1)
 
 
