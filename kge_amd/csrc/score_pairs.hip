@@ -233,6 +233,9 @@ static int pairs_norm(int norm, bool vec, bool mfma, const Operand& A, const Ope
   }
 }
 
+int run_pairs_f32(int scorer, int dtype, const Operand& A, const Operand& R, const Operand& TG, int dir, int d,
+                  long long n, long long m, int round_q, float* out, long long ldo, hipStream_t st);
+
 // exact (canonical f32) pair scoring for every scorer / dtype / dimension
 int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, const Operand& R,
                     const Operand& TG, int dir, int d, int dr, long long n, long long m,
@@ -244,6 +247,12 @@ int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, cons
   const int norm = norm_mode(lp);
   const int round_q =
       (dtype == KGE_BF16 && (scorer == KGE_COMPLEX || scorer == KGE_DISTMULT)) ? 1 : 0;
+  // ComplEx / DistMult on the f32 matrix cores: 128 x 128 tiles (score_pairs_f32.hip) unless the
+  // batch is too small to fill them; same chain order, same bits
+  if ((scorer == KGE_COMPLEX || scorer == KGE_DISTMULT) && use_mfma && vec && n > 64 && m > 64) {
+    const int rc = run_pairs_f32(scorer, dtype, A, R, TG, dir, d, n, m, round_q, out, ldo, st);
+    if (rc != KGE_ERR_UNSUPPORTED) return rc;
+  }
 #define KGE_DT(SC)                                                                            \
   return dtype == KGE_BF16                                                                    \
              ? pairs_norm<SC, unsigned short>(norm, vec, use_mfma, A, R, TG, dir, d, dr, n, m, \
