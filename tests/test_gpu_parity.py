@@ -471,3 +471,35 @@ def test_embed_rows(eng, model, dt):
     assert torch.equal(wide[:, d:], ent[tri[:, 2]]) and not wide[:, :d].any()
     e2, r2 = eng.embed(T, None, tri[:5, 1])
     assert e2 is None and torch.equal(r2, rel[tri[:5, 1]])
+
+
+def test_bf16_handoff_stress_under_load(eng):
+    """The cooperative query build's hand-off (sc1 stores -> flag -> sc1 loads) checked on every
+    word, 400 launches with fresh queries, while a side stream keeps the memory system busy with
+    copies (uneven load: the published fragments compete with 256 MB transfers), alternating
+    one- and two-sided launches on the same scratch buffer."""
+    g = torch.Generator().manual_seed(77)
+    E, R, d, n = 9000, 11, 512, 384
+    ent = torch.randn(E, d, generator=g).bfloat16().to(DEV)
+    rel = torch.randn(R, d, generator=g).bfloat16().to(DEV)
+    T = eng.Tables("complex", ent, rel)
+    Tn = eng.Tables("complex", ent, rel, use_workspace=False)
+    side = torch.cuda.Stream(DEV)
+    big_a = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    big_b = torch.empty_like(big_a)
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    S = torch.randint(E, (400, n), generator=g).to(DEV)
+    P = torch.randint(R, (400, n), generator=g).to(DEV)
+    for it in range(400):
+        if it % 4 == 0:
+            with torch.cuda.stream(side):
+                big_b.copy_(big_a, non_blocking=True)
+        s, p = S[it], P[it]
+        if it % 3 == 2:
+            got = eng.score_sp_po(T, s, p, s)
+            ref = torch.cat((eng.score_sp(Tn, s, p), eng.score_po(Tn, p, s)), 1)
+        else:
+            got, ref = eng.score_sp(T, s, p), eng.score_sp(Tn, s, p)
+        bad += (got != ref).sum()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0
