@@ -1,14 +1,13 @@
 #!/usr/bin/env python3
 """Timing of forward + backward of one 1vsAll score_sp call (ComplEx / DistMult / TransE, f32
 tables, C2 shape) through kge_amd's autograd glue, next to plain torch ops on the same GPU
-(the reference's op sequence, oracle/torch_port.py, run on the device)."""
+(the reference's op sequence written out below, run on the device)."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 from kge_amd import engine
 from kge_amd import model as km
-import torch_port as tp
 
 dev = torch.device("cuda", 0)
 E, R, d, n = 14541, 237, 512, 512

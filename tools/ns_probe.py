@@ -4,9 +4,27 @@ implementation, sampler.py:291-306), W shape, f32: ours vs the reference's torch
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 from kge_amd import model as km
-import torch_port as tp
+
+
+def ref_spo(name, s_emb, p_emb, o_emb):
+    """the reference's spo op sequences (complex.py:24-35, transe.py:18-22, rotate.py:30-41,146-213)"""
+    if name == "transe":
+        return -torch.nn.functional.pairwise_distance(s_emb + p_emb, o_emb, p=1.0)
+    if name == "complex":
+        p_re, p_im = (t.contiguous() for t in p_emb.chunk(2, dim=1))
+        o_re, o_im = (t.contiguous() for t in o_emb.chunk(2, dim=1))
+        s_all = torch.cat((s_emb, s_emb), dim=1)
+        r_all = torch.cat((p_re, p_emb, -p_im), dim=1)
+        o_all = torch.cat((o_emb, o_im, o_re), dim=1)
+        return (s_all * o_all * r_all).sum(dim=1)
+    s_re, s_im = s_emb.chunk(2, dim=1)
+    o_re, o_im = o_emb.chunk(2, dim=1)
+    cs, sn = torch.cos(p_emb), torch.sin(p_emb)
+    d_re, d_im = s_re * cs - s_im * sn - o_re, s_re * sn + s_im * cs - o_im
+    return -torch.stack((d_re, d_im), dim=0).norm(dim=0).sum(dim=1)
+
 
 dev = torch.device("cuda", 0)
 E, R, d = 40943, 11, 512
@@ -39,7 +57,7 @@ for name in ("rotate", "transe", "complex"):
         (ours_fwd() * w).sum().backward()
 
     def ref_fwd():
-        return tp.score_emb(name, ent[s], rel[p], ent[o], "spo", 1.0).view(-1)
+        return ref_spo(name, ent[s], rel[p], ent[o])
 
     def ref():
         ent.grad = rel.grad = None
