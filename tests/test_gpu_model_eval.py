@@ -227,3 +227,41 @@ def test_bf16_backward_vs_f32_autograd(name):
             torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2 * scale)
             # and much tighter on average
             assert float((got - want).abs().mean()) <= 2e-3 * scale
+
+
+def test_sharded_table_on_the_gpu_kernels():
+    """kge_amd.sharded.ShardedEntityTable with the real engine as backend (one rank, no process
+    group: the exchange steps degenerate to identities): ranks / ties equal the unsharded
+    engine path, for f32 (exact kernels) and bf16 (matrix-core kernel) tables, with filter labels."""
+    from kge_amd import engine as eng
+    from kge_amd.sharded import ShardedEntityTable
+    g = torch.Generator().manual_seed(4)
+    E, R, d, n = 700, 6, 256, 90
+    tri = torch.stack([torch.randint(E, (n,), generator=g), torch.randint(R, (n,), generator=g),
+                       torch.randint(E, (n,), generator=g)], 1).to(DEV)
+    # CSR labels: a few filtered entities per row (the true entity among them)
+    cnt = torch.randint(1, 6, (n,), generator=g)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(cnt, 0)
+    col_sp = torch.randint(E, (int(rowptr[-1]),), generator=g)
+    col_po = torch.randint(E, (int(rowptr[-1]),), generator=g)
+    col_sp[rowptr[:-1]] = tri[:, 2].cpu()
+    col_po[rowptr[:-1]] = tri[:, 0].cpu()
+    labels = tuple(x.to(DEV) for x in (rowptr, col_sp, rowptr, col_po))
+    for dt in (torch.float32, torch.bfloat16):
+        ent = torch.randn(E, d, generator=g).to(dt).to(DEV)
+        rel = torch.randn(R, d, generator=g).to(dt).to(DEV)
+        sh = ShardedEntityTable("distmult", ent, rel, E)
+        s_rank, s_ties, o_rank, o_ties = sh.rank_batch(tri, labels)
+        T = eng.Tables("distmult", ent, rel)
+        s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
+        both = eng.score_sp_po(T, s, p, o)
+        ar = torch.arange(n, device=DEV)
+        o_true, s_true = both[ar, o], both[ar, E + s]
+        r_o, t_o = eng.rank_counts(both[:, :E], o_true, labels[0], labels[1], 0, o)
+        r_s, t_s = eng.rank_counts(both[:, E:], s_true, labels[2], labels[3], 0, s)
+        for a, b in ((o_rank, r_o), (o_ties, t_o), (s_rank, r_s), (s_ties, t_s)):
+            assert torch.equal(a, b), dt
+        tv, ti = sh.topk(sh.score_sp(s, p), 5)
+        rv, ri = torch.topk(both[:, :E], 5, dim=1)
+        assert torch.equal(tv, rv) and torch.equal(ti, ri)
