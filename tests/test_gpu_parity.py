@@ -503,3 +503,36 @@ def test_bf16_handoff_stress_under_load(eng):
         bad += (got != ref).sum()
     torch.cuda.synchronize()
     assert int(bad.item()) == 0
+
+
+def test_bf16_random_shapes_against_the_single_role_kernel(eng):
+    """40 random shapes (rows 1..1500, targets 1..6000, d in {256, 512}, all / listed targets,
+    one- and two-sided): the loader/consumer kernel with the cooperative build must give the bits
+    of the no-workspace kernel (same arithmetic, independent partitioning logic), and a sampled
+    row must match the oracle within the bf16 tolerance."""
+    rng = np.random.default_rng(123)
+    for it in range(40):
+        d = int(rng.choice([256, 512]))
+        E = int(rng.integers(1, 6001))
+        n = int(rng.integers(1, 1501)) if it % 5 else int(rng.integers(1, 40))
+        R = 5
+        model = "complex" if it % 2 else "distmult"
+        ent = rng.standard_normal((E, d)).astype(np.float32)
+        rel = rng.standard_normal((R, d)).astype(np.float32)
+        T = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+        Tn = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+        Tn.use_workspace = False
+        s, p, o = rng.integers(0, E, n), rng.integers(0, R, n), rng.integers(0, E, n)
+        sub = None if it % 3 else rng.integers(0, E, int(rng.integers(1, E + 1)))
+        ts, tp, to = _t(s), _t(p), _t(o)
+        tsub = None if sub is None else _t(sub)
+        tag = f"it={it} {model} d={d} n={n} E={E} sub={None if sub is None else len(sub)}"
+        got = _np(eng.score_sp(T, ts, tp, tsub))
+        _eq("sp " + tag, got, _np(eng.score_sp(Tn, ts, tp, tsub)))
+        both = _np(eng.score_sp_po(T, ts, tp, to, tsub))
+        m = got.shape[1]
+        _eq("two-sided sp " + tag, both[:, :m], got)
+        _eq("two-sided po " + tag, both[:, m:], _np(eng.score_po(Tn, tp, to, tsub)))
+        O = _oracle_tables(model, ent, rel, 1.0, bf16=True)
+        i = int(rng.integers(0, n))
+        _close("oracle row " + tag, got[i:i + 1], ko.score_sp(O, s[i:i + 1], p[i:i + 1], sub))
