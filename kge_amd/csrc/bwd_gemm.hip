@@ -204,7 +204,7 @@ static bool lt_gemm(int in16, int ta, int tb, long long m, long long n, long lon
           bool okrun = true;
           float ms = 1e30f;
           for (int rep = 0; rep < 3 && okrun; ++rep) {  // rep 0 = warm-up
-            if (rep == 1) hipEventRecord(e0, st);
+            if (rep == 1) (void)hipEventRecord(e0, st);
             okrun = hipblasLtMatmul(handles[dev], pl->desc, &one, A, pl->la, B, pl->lb, &zero, C, pl->lc, C,
                                     pl->lc, &pl->cand[i].algo, ws, pl->cand[i].workspaceSize, st) ==
                     HIPBLAS_STATUS_SUCCESS;
@@ -216,8 +216,8 @@ static bool lt_gemm(int in16, int ta, int tb, long long m, long long n, long lon
           }
         }
         pl->res = pl->cand[besti];
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
       }
     }
   }
@@ -285,7 +285,7 @@ static bool gemm_long_k(int in16, int d, long long n, long long m, const void* T
         bool okrun = run(cands[ci]);  // warm-up (also tunes the library plan)
         float ms = 1e30f;
         if (okrun) {
-          hipEventRecord(e0, st);
+          (void)hipEventRecord(e0, st);
           okrun = run(cands[ci]) && run(cands[ci]);
           if (okrun && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
               hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) {
@@ -294,8 +294,8 @@ static bool gemm_long_k(int in16, int d, long long n, long long m, const void* T
           }
         }
       }
-      hipEventDestroy(e0);
-      hipEventDestroy(e1);
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
     }
     std::lock_guard<std::mutex> lock(mu);
     choices.push_back(Choice{in16, d, n, m, ldt, ldg, scratch_bytes, P});

@@ -270,10 +270,6 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
     unsigned int bp[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) bp[t] = bt + boff[t];
-    auto bfrag = [&](int kb) {
-      const int s0 = (kb < NKH) ? (2 * kb) : (HH / 8 + 2 * (kb - NKH));
-      return *reinterpret_cast<const bf16x8*>(smem + bp[(s0 & 15) >> 1] + (s0 >> 4) * 256);
-    };
     // The TARGET fragment is the MFMA "A" operand and the query fragment the "B" operand,
     // so the accumulator holds, for query row fi, 4 x 4 CONSECUTIVE targets.
     // B fragments: PF ds_read_b128 in flight, issued by inline asm and retired with COUNTED
@@ -321,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v2_kernel(
     stamp();  // tile tt: MFMA chain issued
   };
 
-  f32x16 acc_a, acc_b;
+  f32x16 acc_a = {}, acc_b = {};
   tile_body(0, acc_a, acc_b, false);
   int tt = 1;
   for (; tt + 1 < ntl; tt += 2) {

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     stamp();  // tile tt: MFMA chain issued
   };
 
-  f32x16 a0, a1, b0, b1;
+  f32x16 a0 = {}, a1 = {}, b0 = {}, b1 = {};
   tile_body(0, a0, a1, b0, b1, false);
   int tt = 1;
   for (; tt + 1 < ntl; tt += 2) {
