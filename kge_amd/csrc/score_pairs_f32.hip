@@ -20,6 +20,7 @@
 namespace kge {
 
 constexpr int F3_BM = 128, F3_BN = 128, F3_KC = 16, F3_LD = 132;  // LD: row pitch of a [pair] line
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int SCORER, typename T>
 __global__ __launch_bounds__(256) void pairs_f32_kernel(Operand A, Operand R, Operand TG, int dir, int d,
@@ -34,62 +35,68 @@ __global__ __launch_bounds__(256) void pairs_f32_kernel(Operand A, Operand R, Op
   const int hh = d / 2;
   const int nchunk = (hh + F3_KC - 1) / F3_KC;
 
-  // staging role: 2 query units and 2 target units per thread; unit u = (row sr[u], coordinates
-  // 4*scq .. +3 of the chunk)
+  // staging role: 2 query units and 2 target units per thread; unit u = (row sru, coordinates
+  // 4*scq .. +3 of the chunk).  (Plain variables, no arrays: arrays indexed in the lambdas below
+  // ended up in scratch memory.)
   const int scq = tid & 3;
-  const T* arow[2];
-  const T* rrow[2];
-  const T* trow[2];
-  int sr[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    sr[u] = (tid >> 2) + 64 * u;
-    long long qr = row0 + sr[u];
-    if (qr >= n) qr = n - 1;  // clamp: rows beyond n are computed but never stored
-    long long tr = col0 + sr[u];
-    if (tr >= m) tr = m - 1;
-    arow[u] = (const T*)A.base + index_at(A.idx, qr) * A.ld;
-    rrow[u] = (const T*)R.base + index_at(R.idx, qr) * R.ld;
-    trow[u] = (const T*)TG.base + index_at(TG.idx, tr) * TG.ld;
-  }
+  const int sr0 = tid >> 2, sr1 = (tid >> 2) + 64;
+  auto qrow_of = [&](int sr) {
+    long long qr = row0 + sr;
+    return qr >= n ? n - 1 : qr;  // clamp: rows beyond n are computed but never stored
+  };
+  auto trow_of = [&](int sr) {
+    long long tr = col0 + sr;
+    return tr >= m ? m - 1 : tr;
+  };
+  const T* const arow0 = (const T*)A.base + index_at(A.idx, qrow_of(sr0)) * A.ld;
+  const T* const arow1 = (const T*)A.base + index_at(A.idx, qrow_of(sr1)) * A.ld;
+  const T* const rrow0 = (const T*)R.base + index_at(R.idx, qrow_of(sr0)) * R.ld;
+  const T* const rrow1 = (const T*)R.base + index_at(R.idx, qrow_of(sr1)) * R.ld;
+  const T* const trow0 = (const T*)TG.base + index_at(TG.idx, trow_of(sr0)) * TG.ld;
+  const T* const trow1 = (const T*)TG.base + index_at(TG.idx, trow_of(sr1)) * TG.ld;
 
-  f32x4 a0[2], a1[2], r0[2], r1[2], t0[2], t1[2];
+  struct Unit {
+    f32x4 a0, a1, r0, r1, t0, t1;
+  };
+  Unit u0, u1;
+  auto gload1 = [&](Unit& u, const T* arow, const T* rrow, const T* trow, int c) {
+    if (c >= hh) {  // chunk tail beyond the row (hh % 4 == 0 on this path): zeros
+      u.a0 = u.a1 = u.r0 = u.r1 = u.t0 = u.t1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      u.a0 = ld4<T>(arow + c);
+      u.a1 = ld4<T>(arow + hh + c);
+      u.r0 = ld4<T>(rrow + c);
+      u.r1 = ld4<T>(rrow + hh + c);
+      u.t0 = ld4<T>(trow + c);
+      u.t1 = ld4<T>(trow + hh + c);
+    }
+  };
   auto gload = [&](int ch) {
     const int c = ch * F3_KC + scq * 4;
+    gload1(u0, arow0, rrow0, trow0, c);
+    gload1(u1, arow1, rrow1, trow1, c);
+  };
+  auto sstore1 = [&](const Unit& u, int sr, int buf) {
+    f32x4 q0, q1;
+    build_q4<SCORER>(dir, u.a0, u.a1, u.r0, u.r1, q0, q1);
+    if (round_q) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (c >= hh) {  // chunk tail beyond the row (hh % 4 == 0 on this path): zeros
-        a0[u] = a1[u] = r0[u] = r1[u] = t0[u] = t1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      } else {
-        a0[u] = ld4<T>(arow[u] + c);
-        a1[u] = ld4<T>(arow[u] + hh + c);
-        r0[u] = ld4<T>(rrow[u] + c);
-        r1[u] = ld4<T>(rrow[u] + hh + c);
-        t0[u] = ld4<T>(trow[u] + c);
-        t1[u] = ld4<T>(trow[u] + hh + c);
+      for (int i = 0; i < 4; ++i) {
+        q0[i] = round_bf16(q0[i]);
+        q1[i] = round_bf16(q1[i]);
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      lds[buf][0][0][scq * 4 + i][sr] = q0[i];
+      lds[buf][0][1][scq * 4 + i][sr] = q1[i];
+      lds[buf][1][0][scq * 4 + i][sr] = u.t0[i];
+      lds[buf][1][1][scq * 4 + i][sr] = u.t1[i];
     }
   };
   auto sstore = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      f32x4 q0, q1;
-      build_q4<SCORER>(dir, a0[u], a1[u], r0[u], r1[u], q0, q1);
-      if (round_q) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          q0[i] = round_bf16(q0[i]);
-          q1[i] = round_bf16(q1[i]);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        lds[buf][0][0][scq * 4 + i][sr[u]] = q0[i];
-        lds[buf][0][1][scq * 4 + i][sr[u]] = q1[i];
-        lds[buf][1][0][scq * 4 + i][sr[u]] = t0[u][i];
-        lds[buf][1][1][scq * 4 + i][sr[u]] = t1[u][i];
-      }
-    }
+    sstore1(u0, sr0, buf);
+    sstore1(u1, sr1, buf);
   };
 
   f32x16 acc[2][2];
@@ -114,14 +121,32 @@ __global__ __launch_bounds__(256) void pairs_f32_kernel(Operand A, Operand R, Op
     // barrier that ended iteration ch-1; then the loads of chunk ch+2 take off
     if (ch + 1 < nchunk) sstore(buf ^ 1);
     if (ch + 2 < nchunk) gload(ch + 2);
+    // Operands of pair cc+1 are read right behind the first MFMA of pair cc (inline asm: hipcc
+    // sinks compiler-visible reads behind the fourth MFMA and then waits for them with an empty
+    // matrix pipe), into the other register pair; `lds` is the only __shared__ object, so LDS
+    // byte addresses are plain offsets into it.
+    const unsigned int qaddr = (unsigned int)((((buf * 2 + 0) * 2 + mh) * F3_KC * F3_LD + qb) * 4);
+    const unsigned int taddr = (unsigned int)((((buf * 2 + 1) * 2 + mh) * F3_KC * F3_LD + tb) * 4);
+    f32x2 qv[2], tv[2];
+    auto oread = [&](f32x2& q2, f32x2& t2, int cc) {
+      const unsigned int qa_ = qaddr + cc * (F3_LD * 4), ta_ = taddr + cc * (F3_LD * 4);
+      asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(q2) : "v"(qa_) : "memory");
+      asm volatile("ds_read2_b32 %0, %1 offset1:32" : "=v"(t2) : "v"(ta_) : "memory");
+    };
+    oread(qv[0], tv[0], 0);
 #pragma unroll
     for (int cc = 0; cc < F3_KC; ++cc) {
-      const float qa = lds[buf][0][mh][cc][qb], qc = lds[buf][0][mh][cc][qb + 32];
-      const float ta = lds[buf][1][mh][cc][tb], tc = lds[buf][1][mh][cc][tb + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, ta, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qa, tc, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc, ta, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc, tc, acc[1][1], 0, 0, 0);
+      const int cur = cc & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[cur][0], tv[cur][0], acc[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (cc + 1 < F3_KC) oread(qv[cur ^ 1], tv[cur ^ 1], cc + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[cur][0], tv[cur][1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[cur][1], tv[cur][0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[cur][1], tv[cur][1], acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);  // the next pair's wait stays behind these three
     }
     __syncthreads();
   }
