@@ -236,6 +236,16 @@ int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p,
                       const float* scores, float* g_s, float* g_p, float* g_o,
                       void* stream);
 
+/* The same gradients ACCUMULATED (float atomics) into dense table gradients grad_ent [num_ent,
+ * dim] and grad_rel [num_rel, rel_dim] (caller zeroes or pre-loads them): what autograd's
+ * scatter-add of the gathered rows produces, without the three [n, dim] row-gradient tensors.
+ * Runs of equal s / p indices (negative sampling: n*K triples, s and p repeated K times in a
+ * row, kge/util/sampler.py:291-306) are summed in registers first.  dim <= 1024. */
+int kge_score_spo_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_index o,
+                            int64_t n, const float* gout, const float* scores,
+                            float* grad_ent, int64_t grad_ent_ld, float* grad_rel,
+                            int64_t grad_rel_ld, void* stream);
+
 /* Backward of kge_score_emb (dense embeddings).  SPO: g_s,g_o [n,dim], g_p [n,rel_dim].
  * SP_: g_s [n,dim], g_p [n,rel_dim], g_o [m,dim].  PO_: g_o [n,dim], g_p, g_s [m,dim]. */
 int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb,

@@ -16,6 +16,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libkge_amd.so")
 
 KGE_OK = 0
+KGE_ERR_UNSUPPORTED = -2
 COMPLEX, DISTMULT, TRANSE, ROTATE = 0, 1, 2, 3
 SCORERS = {"complex": COMPLEX, "distmult": DISTMULT, "transe": TRANSE, "rotate": ROTATE}
 F32, BF16 = 0, 1
@@ -65,6 +66,8 @@ PROTOTYPES = {
                                            c_i64, c_vp]),
     "kge_score_spo_bwd": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_vp]),
+    "kge_score_spo_bwd_accum": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp,
+                                               c_i64, c_vp, c_i64, c_vp]),
     "kge_score_emb_bwd": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                          c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
                                          c_vp]),

@@ -52,6 +52,9 @@ int run_pairs_bwd(int scorer, float lp, int dir, const Operand& A, const Operand
 int run_spo_bwd(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
                 int dr, long long n, const float* gout, const float* scores, float* g_s, float* g_p,
                 float* g_o, hipStream_t st);
+int run_spo_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
+                      int dr, long long n, const float* gout, const float* scores, float* ge, long long ge_ld,
+                      float* gr, long long gr_ld, hipStream_t st);
 }  // namespace kge
 
 using namespace kge;
@@ -349,6 +352,21 @@ int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o
     return rc;
   return run_spo_bwd(t->scorer, t->l_norm, ent_op(t, s), rel_op(t, p), ent_op(t, o), (int)t->dim,
                      (int)t->rel_dim, n, gout, scores, g_s, g_p, g_o, (hipStream_t)stream);
+}
+
+int kge_score_spo_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                            const float* gout, const float* scores, float* grad_ent, int64_t grad_ent_ld,
+                            float* grad_rel, int64_t grad_rel_ld, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
+  if (n < 0 || (n > 0 && (!gout || !grad_ent || !grad_rel))) return KGE_ERR_INVALID_ARG;
+  if (grad_ent_ld < t->dim || grad_rel_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s, false)) || (rc = check_index(p, false)) || (rc = check_index(o, false)))
+    return rc;
+  return run_spo_bwd_accum(t->scorer, t->l_norm, ent_op(t, s), rel_op(t, p), ent_op(t, o), (int)t->dim,
+                           (int)t->rel_dim, n, gout, scores, grad_ent, grad_ent_ld, grad_rel, grad_rel_ld,
+                           (hipStream_t)stream);
 }
 
 int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64_t s_ld,

@@ -250,7 +250,41 @@ __global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Op
   }
 }
 
-// ---- score_spo backward: one wave per triple, lanes strided over the coordinate pairs
+// ---- score_spo backward ---------------------------------------------------------------------
+// gradients of g * score(s, p, o) w.r.t. one coordinate pair (first-half element 0, second-half
+// element 1) of the s, p and o rows
+template <int SCORER, int NORM>
+__device__ __forceinline__ void spo_pair_grads(float s0, float s1, float r0, float r1, float o0, float o1,
+                                               bool has1, float g, float dist, float lp, float& ds0,
+                                               float& ds1, float& dp0, float& dp1, float& do0, float& do1) {
+  dp1 = 0.f;
+  if (SCORER == KGE_DISTMULT) {
+    ds0 = g * (r0 * o0); ds1 = g * (r1 * o1);
+    dp0 = g * (s0 * o0); dp1 = g * (s1 * o1);
+    do0 = g * (s0 * r0); do1 = g * (s1 * r1);
+  } else if (SCORER == KGE_COMPLEX) {
+    ds0 = g * (o0 * r0 + o1 * r1); ds1 = g * (o1 * r0 - o0 * r1);
+    dp0 = g * (o0 * s0 + o1 * s1); dp1 = g * (o1 * s0 - o0 * s1);
+    do0 = g * (s0 * r0 - s1 * r1); do1 = g * (s1 * r0 + s0 * r1);
+  } else if (SCORER == KGE_TRANSE) {
+    const float e0 = ((s0 + r0) - o0) + 1e-6f, e1 = ((s1 + r1) - o1) + 1e-6f;
+    const float w0 = -g * transe_w<NORM>(e0, dist, lp);
+    const float w1 = has1 ? -g * transe_w<NORM>(e1, dist, lp) : 0.f;
+    ds0 = w0; ds1 = w1; dp0 = w0; dp1 = w1; do0 = -w0; do1 = -w1;
+  } else {
+    float sn, cs;
+    sincos_canon(r0, sn, cs);
+    const float q0 = s0 * cs - s1 * sn, q1 = s0 * sn + s1 * cs;
+    float wre, wim;
+    rotate_w<NORM>(q0 - o0, q1 - o1, dist, lp, wre, wim);
+    const float dq0 = -g * wre, dq1 = -g * wim;
+    ds0 = dq0 * cs + dq1 * sn; ds1 = dq1 * cs - dq0 * sn;
+    dp0 = dq1 * q0 - dq0 * q1;
+    do0 = -dq0; do1 = -dq1;
+  }
+}
+
+// row-wise gradients: one wave per triple, lanes strided over the coordinate pairs
 template <int SCORER, int NORM>
 __global__ __launch_bounds__(256) void bwd_spo_kernel(Operand S, Operand R, Operand O, int d, int dr,
                                                       long long n, float lp,
@@ -275,31 +309,8 @@ __global__ __launch_bounds__(256) void bwd_spo_kernel(Operand S, Operand R, Oper
     const float s0 = srow[c], s1 = has1 ? srow[hh + c] : 0.f;
     const float o0 = orow[c], o1 = has1 ? orow[hh + c] : 0.f;
     const float r0 = c < rl0 ? rrow[c] : 0.f, r1 = c < rl1 ? rrow[hh + c] : 0.f;
-    float ds0, ds1, dp0, dp1 = 0.f, do0, do1;
-    if (SCORER == KGE_DISTMULT) {
-      ds0 = g * (r0 * o0); ds1 = g * (r1 * o1);
-      dp0 = g * (s0 * o0); dp1 = g * (s1 * o1);
-      do0 = g * (s0 * r0); do1 = g * (s1 * r1);
-    } else if (SCORER == KGE_COMPLEX) {
-      ds0 = g * (o0 * r0 + o1 * r1); ds1 = g * (o1 * r0 - o0 * r1);
-      dp0 = g * (o0 * s0 + o1 * s1); dp1 = g * (o1 * s0 - o0 * s1);
-      do0 = g * (s0 * r0 - s1 * r1); do1 = g * (s1 * r0 + s0 * r1);
-    } else if (SCORER == KGE_TRANSE) {
-      const float e0 = ((s0 + r0) - o0) + 1e-6f, e1 = ((s1 + r1) - o1) + 1e-6f;
-      const float w0 = -g * transe_w<NORM>(e0, dist, lp);
-      const float w1 = has1 ? -g * transe_w<NORM>(e1, dist, lp) : 0.f;
-      ds0 = w0; ds1 = w1; dp0 = w0; dp1 = w1; do0 = -w0; do1 = -w1;
-    } else {
-      float sn, cs;
-      sincos_canon(r0, sn, cs);
-      const float q0 = s0 * cs - s1 * sn, q1 = s0 * sn + s1 * cs;
-      float wre, wim;
-      rotate_w<NORM>(q0 - o0, q1 - o1, dist, lp, wre, wim);
-      const float dq0 = -g * wre, dq1 = -g * wim;
-      ds0 = dq0 * cs + dq1 * sn; ds1 = dq1 * cs - dq0 * sn;
-      dp0 = dq1 * q0 - dq0 * q1;
-      do0 = -dq0; do1 = -dq1;
-    }
+    float ds0, ds1, dp0, dp1, do0, do1;
+    spo_pair_grads<SCORER, NORM>(s0, s1, r0, r1, o0, o1, has1, g, dist, lp, ds0, ds1, dp0, dp1, do0, do1);
     g_s[i * d + c] = ds0;
     g_o[i * d + c] = do0;
     g_p[i * dr + c] = dp0;
@@ -309,6 +320,83 @@ __global__ __launch_bounds__(256) void bwd_spo_kernel(Operand S, Operand R, Oper
       if (SCORER != KGE_ROTATE) g_p[i * dr + hh + c] = dp1;
     }
   }
+}
+
+// The same gradients ACCUMULATED into the dense table gradients (what autograd's scatter-add of
+// the gathered rows does afterwards: lookup_embedder.py:97 backward with sparse=False), without
+// materialising three [n, d] row-gradient tensors: one wave walks a chunk of SPA_CH consecutive
+// triples; the s-row and p-row gradients are summed in registers while the index stays the same
+// (negative sampling scores n*K triples whose s and p repeat K times in a row, sampler.py:291-306:
+// 1000 same-address atomics become one), the o-row gradient goes out as one float atomic per
+// element.  d <= 1024 (8 coordinate pairs per lane).
+constexpr int SPA_CH = 32, SPA_NC = 8;
+
+template <int SCORER, int NORM>
+__global__ __launch_bounds__(256) void bwd_spo_accum_kernel(Operand S, Operand R, Operand O, int d, int dr,
+                                                            long long n, float lp,
+                                                            const float* __restrict__ gout,
+                                                            const float* __restrict__ scores,
+                                                            float* __restrict__ ge, long long ge_ld,
+                                                            float* __restrict__ gr, long long gr_ld) {
+  const long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long i0 = chunk * SPA_CH;
+  if (i0 >= n) return;
+  const long long i1 = i0 + SPA_CH < n ? i0 + SPA_CH : n;
+  const int lane = threadIdx.x & 63;
+  const int hh = (d + 1) / 2, lim1 = d - hh;
+  const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;
+  const int rl1 = (SCORER == KGE_ROTATE) ? 0 : lim1;
+  float as0[SPA_NC], as1[SPA_NC], ap0[SPA_NC], ap1[SPA_NC];
+#pragma unroll
+  for (int k = 0; k < SPA_NC; ++k) as0[k] = as1[k] = ap0[k] = ap1[k] = 0.f;
+  long long run_s = -1, run_p = -1;
+  auto flush = [&](float* tab, long long ld, long long row, float* a0, float* a1, int l0, int l1) {
+    if (row < 0) return;
+    float* dst = tab + row * ld;
+#pragma unroll
+    for (int k = 0; k < SPA_NC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < l0) unsafeAtomicAdd(dst + c, a0[k]);
+      if (c < l1) unsafeAtomicAdd(dst + hh + c, a1[k]);
+      a0[k] = a1[k] = 0.f;
+    }
+  };
+  for (long long i = i0; i < i1; ++i) {
+    const long long si = index_at(S.idx, i), pi = index_at(R.idx, i), oi = index_at(O.idx, i);
+    if (si != run_s) {
+      flush(ge, ge_ld, run_s, as0, as1, hh, lim1);
+      run_s = si;
+    }
+    if (pi != run_p) {
+      flush(gr, gr_ld, run_p, ap0, ap1, rl0, rl1);
+      run_p = pi;
+    }
+    const float* srow = (const float*)S.base + si * S.ld;
+    const float* rrow = (const float*)R.base + pi * R.ld;
+    const float* orow = (const float*)O.base + oi * O.ld;
+    float* god = ge + oi * ge_ld;
+    const float g = gout[i];
+    const float dist = (SCORER == KGE_TRANSE || SCORER == KGE_ROTATE) && NORM != NORM_L1 ? -scores[i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < SPA_NC; ++k) {
+      const int c = lane + 64 * k;
+      if (c >= hh) break;
+      const bool has1 = c < lim1;
+      const float s0 = srow[c], s1 = has1 ? srow[hh + c] : 0.f;
+      const float o0 = orow[c], o1 = has1 ? orow[hh + c] : 0.f;
+      const float r0 = c < rl0 ? rrow[c] : 0.f, r1 = c < rl1 ? rrow[hh + c] : 0.f;
+      float ds0, ds1, dp0, dp1, do0, do1;
+      spo_pair_grads<SCORER, NORM>(s0, s1, r0, r1, o0, o1, has1, g, dist, lp, ds0, ds1, dp0, dp1, do0, do1);
+      as0[k] += ds0;
+      as1[k] += ds1;
+      ap0[k] += dp0;
+      ap1[k] += dp1;
+      unsafeAtomicAdd(god + c, do0);
+      if (has1) unsafeAtomicAdd(god + hh + c, do1);
+    }
+  }
+  flush(ge, ge_ld, run_s, as0, as1, hh, lim1);
+  flush(gr, gr_ld, run_p, ap0, ap1, rl0, rl1);
 }
 
 template <int SCORER, int NORM>
@@ -388,6 +476,38 @@ int run_spo_bwd(int scorer, float lp, const Operand& S, const Operand& R, const 
       KGE_S(KGE_ROTATE, NORM_LP);
   }
 #undef KGE_S
+  return KGE_ERR_INVALID_ARG;
+}
+
+int run_spo_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
+                      int dr, long long n, const float* gout, const float* scores, float* ge, long long ge_ld,
+                      float* gr, long long gr_ld, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if ((d + 1) / 2 > 64 * SPA_NC) return KGE_ERR_UNSUPPORTED;
+  const int norm = norm_mode(lp);
+  const bool dot = scorer == KGE_COMPLEX || scorer == KGE_DISTMULT;
+  if (!dot && norm != NORM_L1 && !scores) return KGE_ERR_INVALID_ARG;
+  const long long chunks = (n + SPA_CH - 1) / SPA_CH;
+  const dim3 grid((unsigned)((chunks + 3) / 4));
+#define KGE_SA(SC, NM)                                                                                \
+  {                                                                                                   \
+    hipLaunchKernelGGL((bwd_spo_accum_kernel<SC, NM>), grid, dim3(256), 0, st, S, R, O, d, dr, n, lp,  \
+                       gout, scores, ge, ge_ld, gr, gr_ld);                                           \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;                                 \
+  }
+  switch (scorer) {
+    case KGE_COMPLEX: KGE_SA(KGE_COMPLEX, NORM_L1);
+    case KGE_DISTMULT: KGE_SA(KGE_DISTMULT, NORM_L1);
+    case KGE_TRANSE:
+      if (norm == NORM_L1) KGE_SA(KGE_TRANSE, NORM_L1);
+      if (norm == NORM_L2) KGE_SA(KGE_TRANSE, NORM_L2);
+      KGE_SA(KGE_TRANSE, NORM_LP);
+    case KGE_ROTATE:
+      if (norm == NORM_L1) KGE_SA(KGE_ROTATE, NORM_L1);
+      if (norm == NORM_L2) KGE_SA(KGE_ROTATE, NORM_L2);
+      KGE_SA(KGE_ROTATE, NORM_LP);
+  }
+#undef KGE_SA
   return KGE_ERR_INVALID_ARG;
 }
 

@@ -376,6 +376,28 @@ def score_spo_bwd(t: Tables, s, p, o, gout, scores=None):
     return g_s, g_p, g_o
 
 
+def score_spo_bwd_accum(t: Tables, s, p, o, gout, scores, grad_ent, grad_rel):
+    """score_spo backward accumulated straight into the dense table gradients `grad_ent` [E, d] and
+    `grad_rel` [R, d_r] (f32, modified in place); returns False if the kernel does not take this
+    shape (the caller then uses score_spo_bwd + index_add)."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = keep[0].numel()
+    gout = _f32c(gout, t.device)
+    sc = None if scores is None else _f32c(scores, t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        rc = _lib.lib().kge_score_spo_bwd_accum(
+            ctypes.byref(tc), si, pi, oi, n, gout.data_ptr(), None if sc is None else sc.data_ptr(),
+            grad_ent.data_ptr(), grad_ent.stride(0), grad_rel.data_ptr(), grad_rel.stride(0),
+            _stream_handle(t.device))
+    if rc == _lib.KGE_ERR_UNSUPPORTED:
+        return False
+    if rc:
+        _lib.check(rc, "kge_score_spo_bwd_accum")
+    return True
+
+
 def score_pairs_bwd(t: Tables, direction: str, a, p, targets, gout, scores=None):
     """Backward of score_sp (direction 'sp', a = s) / score_po ('po', a = o):
     (g_a [n,d], g_p [n,d_r], g_targets [m,d])."""

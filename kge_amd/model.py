@@ -251,11 +251,14 @@ class _ScoreSPO(torch.autograd.Function):
     def backward(ctx, gout):
         s, p, o = ctx.idx
         (scores,) = ctx.saved_tensors
-        g_s, g_p, g_o = engine.score_spo_bwd(ctx.t, s, p, o, gout.contiguous(), scores)
         ge, gr = torch.zeros_like(ctx.t.ent), torch.zeros_like(ctx.t.rel)
-        _scatter_rows(ge, s, g_s)
-        _scatter_rows(ge, o, g_o)
-        _scatter_rows(gr, p, g_p)
+        # one kernel: row gradients accumulated into the table gradients (runs of equal s / p
+        # summed in registers first); fallback: row gradients + three scatter-adds
+        if not engine.score_spo_bwd_accum(ctx.t, s, p, o, gout.contiguous(), scores, ge, gr):
+            g_s, g_p, g_o = engine.score_spo_bwd(ctx.t, s, p, o, gout.contiguous(), scores)
+            _scatter_rows(ge, s, g_s)
+            _scatter_rows(ge, o, g_o)
+            _scatter_rows(gr, p, g_p)
         return None, None, ge, gr, None, None, None
 
 

@@ -73,3 +73,27 @@ for name in ("rotate", "transe", "complex"):
     except Exception as e:
         rf = tr = float("nan"); print("torch ops failed:", type(e).__name__, str(e)[:200])
     print(f"{name:8s} N={n*K}: ours fwd {tf:8.1f} us, fwd+bwd {to:9.1f} us | torch ops fwd {rf:9.1f} us, fwd+bwd {tr:9.1f} us")
+
+# ---- kernel breakdown of the RotatE forward + backward
+from torch.profiler import profile, ProfilerActivity
+name = "rotate"
+ent = torch.empty(E, d).normal_(0, 0.1, generator=g).to(dev).requires_grad_(True)
+rel = torch.empty(R, d // 2).normal_(0, 0.1, generator=g).to(dev).requires_grad_(True)
+n, K = 128, 1000
+s = torch.randint(E, (n,), generator=g).to(dev).repeat_interleave(K)
+p = torch.randint(R, (n,), generator=g).to(dev).repeat_interleave(K)
+o = torch.randint(E, (n * K,), generator=g).to(dev)
+w = torch.randn(n * K, device=dev)
+
+
+def one():
+    ent.grad = rel.grad = None
+    (km._ScoreSPO.apply(name, 1.0, ent, rel, s, p, o) * w).sum().backward()
+
+
+for _ in range(3): one()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for _ in range(5): one()
+    torch.cuda.synchronize()
+print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=10, max_name_column_width=60))
