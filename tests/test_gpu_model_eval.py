@@ -265,3 +265,26 @@ def test_sharded_table_on_the_gpu_kernels():
         tv, ti = sh.topk(sh.score_sp(s, p), 5)
         rv, ri = torch.topk(both[:, :E], 5, dim=1)
         assert torch.equal(tv, rv) and torch.equal(ti, ri)
+
+
+@pytest.mark.parametrize("name", ["rotate", "transe", "complex", "distmult"])
+def test_spo_backward_accumulated_with_repeated_indices(name):
+    """Negative-sampling layout (s and p repeated K times in a row, random o with collisions, chunk
+    boundaries inside runs): table gradients from the accumulate kernel vs torch autograd of the
+    reference op sequence (oracle/torch_port.py on the GPU)."""
+    from kge_amd import model as km
+    E, R, d, n, K = 400, 5, 128, 37, 45
+    g = torch.Generator().manual_seed(8)
+    dr = d // 2 if name == "rotate" else d
+    ent = (torch.randn(E, d, generator=g) * 0.5).to(DEV).requires_grad_(True)
+    rel = (torch.randn(R, dr, generator=g) * 0.5).to(DEV).requires_grad_(True)
+    s = torch.randint(E, (n,), generator=g).to(DEV).repeat_interleave(K)
+    p = torch.randint(R, (n,), generator=g).to(DEV).repeat_interleave(K)
+    o = torch.randint(E, (n * K,), generator=g).to(DEV)
+    w = torch.randn(n * K, generator=g).to(DEV)
+    (km._ScoreSPO.apply(name, 1.0, ent, rel, s, p, o) * w).sum().backward()
+    ge, gr = ent.grad.clone(), rel.grad.clone()
+    ent.grad = rel.grad = None
+    (tp.score_emb(name, ent[s], rel[p], ent[o], "spo", 1.0).view(-1) * w).sum().backward()
+    for got, want in ((ge, ent.grad), (gr, rel.grad)):
+        torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5 * float(want.abs().max()) + 1e-6)
