@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Op
                                                         const float* __restrict__ scores,
                                                         long long lds, float* __restrict__ g_a,
                                                         float* __restrict__ g_p,
-                                                        float* __restrict__ g_tgt) {
+                                                        float* __restrict__ g_tgt, long long ychunk) {
+  // ychunk < Y (WHICH == 0 only): the reduction over the other side is split over blockIdx.z and
+  // the (linear) chain-ruled partial sums are added atomically into pre-zeroed g_a / g_p -- with
+  // 512 query rows the unsplit grid is 64 workgroups on a 256-CU chip
   constexpr bool DOT = (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT);
   constexpr bool NEED_DIST = !DOT && NORM != NORM_L1;
   __shared__ float Gs[BW_KY][BW_TR + 4];
@@ -107,7 +110,10 @@ __global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Op
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc0[i][j] = acc1[i][j] = 0.f;
 
-  for (long long y0 = 0; y0 < Y; y0 += BW_KY) {
+  const bool split = ychunk < Y;
+  const long long ybeg = split ? (long long)blockIdx.z * ychunk : 0;
+  const long long yend = split ? (ybeg + ychunk < Y ? ybeg + ychunk : Y) : Y;
+  for (long long y0 = ybeg; y0 < yend; y0 += BW_KY) {
     // ---- stage weights g (and distances) of this chunk
     if (WHICH == 0) {
       const int x = tid >> 2, yq = (tid & 3) * 4;
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Op
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const long long gy = y0 + yq + k;
-        const bool ok = gx < X && gy < Y;
+        const bool ok = gx < X && gy < yend;
         Gs[yq + k][x] = ok ? gout[gx * ldg + gy] : 0.f;
         if (NEED_DIST) Ds[yq + k][x] = ok ? -scores[gx * lds + gy] : 0.f;
       }
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Op
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const long long gx = row0 + xq + k;
-        const bool ok = gx < X && gy < Y;
+        const bool ok = gx < X && gy < yend;
         Gs[y][xq + k] = ok ? gout[gy * ldg + gx] : 0.f;
         if (NEED_DIST) Ds[y][xq + k] = ok ? -scores[gy * lds + gx] : 0.f;
       }
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Op
     {
       const int y = tid >> 4, cq = (tid & 15) * 2;
       long long gy = y0 + y;
-      const bool ok = gy < Y;
+      const bool ok = gy < yend;
       if (!ok) gy = Y - 1;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -242,10 +248,17 @@ __global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Op
           dr0 = dq0 * q1 - dq1 * q0;
         }
       }
-      g_a[x * d + c] = da0;
-      if (has1) g_a[x * d + hh + c] = da1;
-      g_p[x * dr + c] = dr0;
-      if (SCORER != KGE_ROTATE && has1) g_p[x * dr + hh + c] = dr1;
+      if (split) {
+        unsafeAtomicAdd(g_a + x * d + c, da0);
+        if (has1) unsafeAtomicAdd(g_a + x * d + hh + c, da1);
+        unsafeAtomicAdd(g_p + x * dr + c, dr0);
+        if (SCORER != KGE_ROTATE && has1) unsafeAtomicAdd(g_p + x * dr + hh + c, dr1);
+      } else {
+        g_a[x * d + c] = da0;
+        if (has1) g_a[x * d + hh + c] = da1;
+        g_p[x * dr + c] = dr0;
+        if (SCORER != KGE_ROTATE && has1) g_p[x * dr + hh + c] = dr1;
+      }
     }
   }
 }
@@ -406,12 +419,28 @@ static int launch_bwd_pairs(int dir, const Operand& A, const Operand& R, const O
                             float* g_p, float* g_tgt, hipStream_t st) {
   const int hh = (d + 1) / 2;
   const unsigned gc = (unsigned)((hh + BW_TC - 1) / BW_TC);
-  hipLaunchKernelGGL((bwd_pairs_kernel<SCORER, NORM, 0>), dim3(gc, (unsigned)((n + BW_TR - 1) / BW_TR)),
-                     dim3(256), 0, st, A, R, TG, dir, d, dr, n, m, lp, gout, ldg, scores, lds, g_a,
-                     g_p, g_tgt);
+  const unsigned gr = (unsigned)((n + BW_TR - 1) / BW_TR);
+  // query-side pass: split the reduction over the targets until ~1024 workgroups exist
+  long long ys = 1024 / ((long long)gc * gr);
+  if (ys > 32) ys = 32;
+  long long ychunk = m;
+  if (ys > 1) {
+    ychunk = ((m + ys - 1) / ys + BW_KY - 1) / BW_KY * BW_KY;
+    ys = (m + ychunk - 1) / ychunk;
+  }
+  if (ys > 1) {
+    if (hipMemsetAsync(g_a, 0, (size_t)n * d * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(g_p, 0, (size_t)n * dr * sizeof(float), st) != hipSuccess)
+      return KGE_ERR_LAUNCH;
+  } else {
+    ys = 1;
+    ychunk = m;
+  }
+  hipLaunchKernelGGL((bwd_pairs_kernel<SCORER, NORM, 0>), dim3(gc, gr, (unsigned)ys), dim3(256), 0, st, A, R, TG,
+                     dir, d, dr, n, m, lp, gout, ldg, scores, lds, g_a, g_p, g_tgt, ychunk);
   hipLaunchKernelGGL((bwd_pairs_kernel<SCORER, NORM, 1>), dim3(gc, (unsigned)((m + BW_TR - 1) / BW_TR)),
                      dim3(256), 0, st, A, R, TG, dir, d, dr, n, m, lp, gout, ldg, scores, lds, g_a,
-                     g_p, g_tgt);
+                     g_p, g_tgt, (long long)n);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
