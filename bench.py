@@ -149,14 +149,16 @@ def main():
             engine.score_emb("complex", s_rows, buf["pe"], ent, "sp_")
             engine.score_emb("complex", ent, buf["pe"], o_rows, "_po")
 
-        # The exchange (a gather kernel and the RCCL all-gather) is captured once in a hipGraph
-        # (issued op by op it costs more host work than the scoring it feeds).  Measured
+        # The exchange (a gather kernel and the RCCL all-gather) can be captured once in a hipGraph.  Measured
         # alternatives on one rank (tools/dist_probe.py, profiles/): replaying it on a side stream
         # one step ahead of the scoring is SLOWER (53 vs 47 us per step): the persistent scoring
         # kernel needs whole CUs (160 KB LDS, all VGPRs), so the side stream's kernels and its
         # workgroups only take turns, and the event traffic adds host work.
+        # Off by default: measured on one rank the graph saves 5 % (46.0 vs 48.5 us per step) and
+        # capturing RCCL collectives is the one thing here that cannot be tried on more than one
+        # rank in the build environment.  KGE_BENCH_EXCHANGE_GRAPH=1 turns it on.
         xg = None
-        if os.environ.get("KGE_BENCH_NO_GRAPH") != "1":
+        if os.environ.get("KGE_BENCH_EXCHANGE_GRAPH") == "1":
             try:
                 exchange()  # warm up the kernels / the RCCL channel outside the capture
                 torch.cuda.synchronize()

@@ -13,7 +13,7 @@ timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1
 echo "smoke exit: $?" >> $OUT/env.log
 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit: $?" >> $OUT/env.log
-KGE_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err
+KGE_BENCH_FORCE_DIST=1 KGE_BENCH_EXCHANGE_GRAPH=0 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err
 echo "dist(1 rank, RCCL) bench exit: $?" >> $OUT/env.log
 timeout 300 python tools/v2_phases.py > $OUT/v2_phases.txt 2>&1
 timeout 900 python tools/perf_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err
