@@ -8,6 +8,8 @@
 // vector loads, so a group reads whole contiguous row segments.  The row reduction is
 // the canonical "64 strided partials + xor butterfly" of oracle/kge_oracle.c
 // (spo_score): levels with offset >= G add an exact +0 and are skipped.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace kge {
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void spo_kernel(Operand S, Operand R, Operand 
       f32x8 x0 = load_chunk<T, VEC>(orow, c0, D);
       f32x8 x1 = x0;
       if (CPLX) x1 = load_chunk<T, VEC>(orow + h, c0, D);
-      P = apply_chunk<SCORER, NORM>(2, P, F, x0, x1, cnt, lp);
+      P = apply_chunk<SCORER, NORM>(2, P, F, x0, x1, VEC ? 8 : cnt, lp);
     }
   }
   P = group_butterfly<G>(P);
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void spo_kernel(Operand S, Operand R, Operand 
 // non-corrupted entity row and the relation row are loaded ONCE per group into registers
 // (one chunk per lane; D <= 512) so only the corrupted-slot row streams from HBM.
 template <int SCORER, typename T, int NORM, bool VEC, int G>
-__global__ __launch_bounds__(256) void neg_kernel(Operand S, Operand R, Operand O, int d,
+__global__ __launch_bounds__(256, 4) void neg_kernel(Operand S, Operand R, Operand O, int d,
                                                   int dr, int slot, const void* neg,
                                                   int neg_itype, long long neg_ld,
                                                   long long K, float lp,
@@ -206,28 +208,45 @@ __global__ __launch_bounds__(256) void neg_kernel(Operand S, Operand R, Operand 
   const int cnt0 = (D - c00 < 8) ? (D - c00) : 8;
   if (lg < nchunks) F0 = load_fixed<SCORER, T, VEC>(slot, fixrow, rrow, c00, D, h);
 
-  for (long long k = (long long)blockIdx.x * GPB + gid; k < K;
-       k += (long long)gridDim.x * GPB) {
-    const T* xrow = ent + index_at(nix, i * neg_ld + k) * S.ld;
-    float P = 0.0f;
-    if (lg < nchunks) {
-      f32x8 x0 = load_chunk<T, VEC>(xrow, c00, D);
-      f32x8 x1 = x0;
-      if (CPLX) x1 = load_chunk<T, VEC>(xrow + h, c00, D);
-      P = apply_chunk<SCORER, NORM>(slot, P, F0, x0, x1, cnt0, lp);
+  // The slot is uniform over the launch: one specialised copy of the loop per side keeps the
+  // side selection out of the per-coordinate arithmetic; on the vector path every chunk is full
+  // (D % 8 == 0), so the per-coordinate tail test folds away as well.
+  auto sweep = [&](auto slot_c) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    const long long step = (long long)gridDim.x * GPB;
+    const bool act = lg < nchunks;
+    auto row_of = [&](long long kk) { return ent + index_at(nix, i * neg_ld + kk) * S.ld; };
+    auto load_x = [&](const T* xr, f32x8& a, f32x8& b) {
+      a = load_chunk<T, VEC>(xr, c00, D);
+      b = a;
+      if (CPLX) b = load_chunk<T, VEC>(xr + h, c00, D);
+    };
+    // No software pipeline: prefetching the next negative's index (RotatE 159 -> 167 us) or its
+    // index and row (159 -> 270 us, TransE 138 -> 145 us) was slower on MI355X than leaving the
+    // latency to the 4..8 resident waves per SIMD -- the extra live registers cost occupancy.
+    for (long long k = (long long)blockIdx.x * GPB + gid; k < K; k += step) {
+      const T* rc = row_of(k);
+      float P = 0.0f;
+      if (act) {
+        f32x8 x0, x1;
+        load_x(rc, x0, x1);
+        P = apply_chunk<SCORER, NORM>(SLOT, P, F0, x0, x1, VEC ? 8 : cnt0, lp);
+      }
+      for (int ci = lg + 64; ci < nchunks; ci += 64) {  // only when D > 512
+        const int c0 = ci * 8;
+        const int cnt = (D - c0 < 8) ? (D - c0) : 8;
+        Fixed F = load_fixed<SCORER, T, VEC>(SLOT, fixrow, rrow, c0, D, h);
+        f32x8 y0 = load_chunk<T, VEC>(rc, c0, D);
+        f32x8 y1 = y0;
+        if (CPLX) y1 = load_chunk<T, VEC>(rc + h, c0, D);
+        P = apply_chunk<SCORER, NORM>(SLOT, P, F, y0, y1, VEC ? 8 : cnt, lp);
+      }
+      P = group_butterfly<G>(P);
+      if (lg == 0) out[i * ldo + k] = finalize<SCORER, NORM>(P, lp);
     }
-    for (int ci = lg + 64; ci < nchunks; ci += 64) {  // only when D > 512
-      const int c0 = ci * 8;
-      const int cnt = (D - c0 < 8) ? (D - c0) : 8;
-      Fixed F = load_fixed<SCORER, T, VEC>(slot, fixrow, rrow, c0, D, h);
-      f32x8 x0 = load_chunk<T, VEC>(xrow, c0, D);
-      f32x8 x1 = x0;
-      if (CPLX) x1 = load_chunk<T, VEC>(xrow + h, c0, D);
-      P = apply_chunk<SCORER, NORM>(slot, P, F, x0, x1, cnt, lp);
-    }
-    P = group_butterfly<G>(P);
-    if (lg == 0) out[i * ldo + k] = finalize<SCORER, NORM>(P, lp);
-  }
+  };
+  if (slot == 0) sweep(std::integral_constant<int, 0>{});
+  else sweep(std::integral_constant<int, 2>{});
 }
 
 // ---- host-side dispatch -------------------------------------------------------------------
@@ -269,7 +288,11 @@ static int launch_neg_g(int G, const Operand& S, const Operand& R, const Operand
 #define KGE_NEG_CASE(GG)                                                                   \
   case GG: {                                                                               \
     long long gpb = 4LL * (64 / GG);                                                       \
-    long long bx = (K + gpb * 4 - 1) / (gpb * 4); /* ~4 negatives per group */             \
+    /* negatives per group: 16 amortises the group's fixed side (two row loads, RotatE: */  \
+    /* sin/cos), 4 when that would leave fewer than ~2048 workgroups */                    \
+    long long per = 16;                                                                    \
+    while (per > 4 && n * ((K + gpb * per - 1) / (gpb * per)) < 2048) per >>= 1;           \
+    long long bx = (K + gpb * per - 1) / (gpb * per);                                      \
     if (bx < 1) bx = 1;                                                                    \
     if (bx > 64) bx = 64;                                                                  \
     hipLaunchKernelGGL((neg_kernel<SCORER, T, NORM, VEC, GG>), dim3((unsigned)bx, (unsigned)n), \
