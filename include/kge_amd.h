@@ -209,6 +209,37 @@ int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_o
               int64_t ent_ldo, kge_index rel_idx, int64_t n_rel, void* rel_out,
               int64_t rel_ldo, void* stream);
 
+/* ---- 1vsAll loss fused with the scoring ---------------- */
+/* loss_rows[i] = logsumexp_j score(i, j) - score(i, label[i]),  lse[i] = logsumexp_j score(i, j),
+ * j over ALL entities; score(i, .) = the kge_score_sp row (dir = KGE_SP_, a = s, label = o) or
+ * the kge_score_po row (dir = KGE_PO_, a = o, label = s).  sum_i loss_rows[i] is what
+ * TrainingJob1vsAll computes with the default `train.loss: kl`: score_sp / score_po
+ * (kge/job/train_1vsAll.py:64, 75) followed by KLDivWithSoftmaxKgeLoss with index labels =
+ * CrossEntropyLoss(reduction="sum") (kge/util/loss.py:192-207, train_1vsAll.py:65, 76).
+ * The [n, num_ent] score matrix is never written: the scoring kernel folds every tile into a
+ * per-row running (max, sum exp).  The scores inside are bit-identical to kge_score_sp /
+ * kge_score_po on the same tables.
+ *
+ * kge_ce_bwd: gradients of sum_i g_i * loss_rows[i] (g_i = g_rows[i], or g_scalar if g_rows is
+ * NULL -- the reference's 1 / batch_size), laid out as for kge_score_pairs_bwd:
+ *   g_a [n, dim], g_p [n, rel_dim], g_tgt [num_ent, dim]   (f32, OVERWRITTEN)
+ * The kernel recomputes the score tiles, writes d loss / d score in bf16 to the workspace and
+ * runs the two gradient products of the mixed-precision backward on it.
+ *
+ * ComplEx / DistMult, bf16 tables, dim in {128, 256, 512}; anything else:
+ * KGE_ERR_UNSUPPORTED (compose kge_score_sp + the loss instead).  Both calls need
+ * `workspace_bytes >= kge_ce_workspace_bytes(t, n)` of 256-byte aligned device scratch (no
+ * initialisation; stream-ordered use; not shared by concurrent calls).  Not capturable into a
+ * hipGraph (the gradient products go through hipBLASLt). */
+int64_t kge_ce_workspace_bytes(const kge_tables* t, int64_t n);
+int kge_ce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index label,
+               int64_t n, float* loss_rows, float* lse, void* workspace,
+               int64_t workspace_bytes, void* stream);
+int kge_ce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index label,
+               int64_t n, const float* lse, const float* g_rows, float g_scalar, float* g_a,
+               float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes,
+               void* stream);
+
 /* ---- backward (autograd twins) ------------------------------------------ */
 /* All gradients are f32 and OVERWRITTEN; tables/embeddings must be f32, except
  * kge_score_pairs_bwd for ComplEx/DistMult, which also takes bf16 tables (mixed-precision

@@ -55,6 +55,15 @@ int run_spo_bwd(int scorer, float lp, const Operand& S, const Operand& R, const 
 int run_spo_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
                       int dr, long long n, const float* gout, const float* scores, float* ge, long long ge_ld,
                       float* gr, long long gr_ld, hipStream_t st);
+long long ce_workspace_bytes(int d, long long n, long long m);
+void ce_set_stamps(unsigned long long* p);
+bool ce_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
+int run_ce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+               long long m, const Index& label, float* loss_rows, float* lse, void* ws, long long ws_bytes,
+               hipStream_t st);
+int run_ce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+               long long m, const Index& label, const float* lse, const float* g_rows, float g_scalar, float* g_a,
+               float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
 }  // namespace kge
 
 using namespace kge;
@@ -340,6 +349,52 @@ int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
                        (hipStream_t)stream, (t->flags & KGE_FLAG_EXACT) != 0);
 }
 
+// ---- fused 1vsAll loss (ce_loss.hip) ------------------------------------------------------
+namespace {
+int ce_check(const kge_tables* t, int dir, const kge_index& a, const kge_index& p, const kge_index& label,
+             int64_t n) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
+  if (n < 0) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(a, false, n)) || (rc = check_index(p, false, n)) || (rc = check_index(label, false, n)))
+    return rc;
+  const kge_index all = {nullptr, 0, 0, 1};
+  if (!ce_supported(t->scorer, t->dtype, (int)t->dim, ent_op(t, a), rel_op(t, p), ent_op(t, all)))
+    return KGE_ERR_UNSUPPORTED;
+  return KGE_OK;
+}
+}  // namespace
+
+int64_t kge_ce_workspace_bytes(const kge_tables* t, int64_t n) {
+  if (check_tables(t, false) != KGE_OK || n <= 0 || t->num_ent <= 0) return 0;
+  if (t->dtype != KGE_BF16 || (t->scorer != KGE_COMPLEX && t->scorer != KGE_DISTMULT)) return 0;
+  if (t->dim != 128 && t->dim != 256 && t->dim != 512) return 0;
+  return ce_workspace_bytes((int)t->dim, n, t->num_ent);
+}
+
+int kge_ce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index label, int64_t n,
+               float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
+  const int rc = ce_check(t, dir, a, p, label, n);
+  if (rc) return rc;
+  if (n > 0 && (!loss_rows || !lse)) return KGE_ERR_INVALID_ARG;
+  const kge_index all = {nullptr, 0, 0, 1};
+  return run_ce_fwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, all), dir, (int)t->dim, n, t->num_ent,
+                    make_index(label), loss_rows, lse, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int kge_ce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index label, int64_t n,
+               const float* lse, const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt,
+               void* workspace, int64_t workspace_bytes, void* stream) {
+  const int rc = ce_check(t, dir, a, p, label, n);
+  if (rc) return rc;
+  if (n > 0 && (!lse || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
+  const kge_index all = {nullptr, 0, 0, 1};
+  return run_ce_bwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, all), dir, (int)t->dim, n, t->num_ent,
+                    make_index(label), lse, g_rows, g_scalar, g_a, g_p, g_tgt, workspace, workspace_bytes,
+                    (hipStream_t)stream);
+}
+
 int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
                       const float* gout, const float* scores, float* g_s, float* g_p, float* g_o,
                       void* stream) {
@@ -394,6 +449,10 @@ int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64
                          lds, g_o, g_p, g_s, st, (t->flags & KGE_FLAG_EXACT) != 0);
   return KGE_ERR_INVALID_ARG;
 }
+
+// Not part of the public ABI: timestamp buffer (64 x u64 per workgroup) for the next
+// kge_ce_fwd / kge_ce_bwd scoring launches (tools/ce_phases.py); NULL switches it off.
+void kge_debug_ce_stamps(unsigned long long* stamps) { kge::ce_set_stamps(stamps); }
 
 // Not part of the public ABI (include/kge_amd.h): the row-persistent bf16 kernel with a
 // per-workgroup timestamp buffer (64 x u64 per workgroup) for tools/v2_phases.py.

@@ -442,19 +442,15 @@ long long pairs_bwd_workspace_bytes(int dtype, int scorer, int d, long long n, l
   return ((n * mp * 2 + 255) & ~255LL) + ((n * (long long)d * 2 + 255) & ~255LL);
 }
 
+// Both gradient products from G16 = d loss / d score in bf16 ([n, mp], row pitch mp elements):
+// the tail of the mixed-precision backward, shared with the fused 1vsAll loss (ce_loss.hip), whose
+// scoring kernel writes G16 itself.
 template <int SCORER>
-static int bwdg_run16(int dir, const Operand& A, const Operand& R, const Operand& TG, int d, long long n,
-                      long long m, const float* gout, long long ldg, float* g_a, float* g_p, float* g_tgt,
-                      void* wsp, long long ws_bytes, hipStream_t st) {
-  const long long mp = (m + 7) & ~7LL;  // row pitch of G16 (elements)
-  const long long g16_bytes = (n * mp * 2 + 255) & ~255LL;
-  if (wsp == nullptr || ((uintptr_t)wsp & 255) || ws_bytes < g16_bytes + n * (long long)d * 2) return KGE_ERR_WORKSPACE;
-  unsigned short* G16 = (unsigned short*)wsp;
-  unsigned short* Q16 = (unsigned short*)((char*)wsp + g16_bytes);
+static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Operand& TG, int d, long long n,
+                           long long m, const unsigned short* G16, long long mp, unsigned short* Q16,
+                           float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
   const unsigned qblocks = (unsigned)((n * half + 255) / 256);
-  hipLaunchKernelGGL(bwdg_cast_kernel, dim3((unsigned)((n * (mp / 2) + 255) / 256)), dim3(256), 0, st, gout, ldg, n,
-                     m, G16);
   hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, Q16);
   const unsigned short* T = (const unsigned short*)TG.base;
   long long ldt = TG.ld;
@@ -472,6 +468,35 @@ static int bwdg_run16(int dir, const Operand& A, const Operand& R, const Operand
   if (!lt_gemm(1, 0, 1, d, m, n, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st)) return KGE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+template <int SCORER>
+static int bwdg_run16(int dir, const Operand& A, const Operand& R, const Operand& TG, int d, long long n,
+                      long long m, const float* gout, long long ldg, float* g_a, float* g_p, float* g_tgt,
+                      void* wsp, long long ws_bytes, hipStream_t st) {
+  const long long mp = (m + 7) & ~7LL;  // row pitch of G16 (elements)
+  const long long g16_bytes = (n * mp * 2 + 255) & ~255LL;
+  if (wsp == nullptr || ((uintptr_t)wsp & 255) || ws_bytes < g16_bytes + n * (long long)d * 2) return KGE_ERR_WORKSPACE;
+  unsigned short* G16 = (unsigned short*)wsp;
+  unsigned short* Q16 = (unsigned short*)((char*)wsp + g16_bytes);
+  hipLaunchKernelGGL(bwdg_cast_kernel, dim3((unsigned)((n * (mp / 2) + 255) / 256)), dim3(256), 0, st, gout, ldg, n,
+                     m, G16);
+  return bwdg_products16<SCORER>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+}
+
+// ce_loss.hip: G16 (pitch mp) was written by the scoring kernel; Q16 = n * d * 2 bytes of scratch
+int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
+                             long long n, long long m, const unsigned short* G16, long long mp,
+                             unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
+  if (n == 0 || m == 0) return KGE_OK;
+  if (n >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31)) return KGE_ERR_UNSUPPORTED;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return KGE_ERR_UNSUPPORTED;
+  if (scorer == KGE_COMPLEX)
+    return bwdg_products16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+  if (scorer == KGE_DISTMULT)
+    return bwdg_products16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+  return KGE_ERR_UNSUPPORTED;
 }
 
 int run_pairs_bwd_gemm16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,

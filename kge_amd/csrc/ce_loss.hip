@@ -1,0 +1,120 @@
+// ce_loss.hip -- 1vsAll training loss fused with the sp_/_po scoring.
+//
+// Reference: TrainingJob1vsAll scores a batch against all entities and feeds the [n, E] matrix to
+// KLDivWithSoftmaxKgeLoss, which for index labels is CrossEntropyLoss(reduction="sum")
+// (kge/job/train_1vsAll.py:64-65, 75-76; kge/util/loss.py:192-207).  Unfused, the score matrix is
+// written once (29.8 MB at the FB15k-237 shape, the dominant HBM term of the scoring kernel), read
+// twice by softmax + nll forward, and a same-size gradient matrix is written and read again by the
+// backward.  Here the scoring kernel keeps the tiles in registers:
+//
+//   kge_ce_fwd  pairs_bf16_v3_kernel<.., V3_LSE>: per row and column group (max, sum exp) by
+//               online softmax over the tiles + the label's score; ce_combine_kernel merges the
+//               column groups:  lse_i = logsumexp_j score(i, j),  loss_i = lse_i - score(i, label_i).
+//               HBM traffic: the tables once + n * ncg * 8 bytes.
+//   kge_ce_bwd  pairs_bf16_v3_kernel<.., V3_DS> recomputes the tiles and writes
+//               G16 = g_i * (softmax(i, j) - [j == label_i]) in bf16 (half the bytes of the f32
+//               gradient matrix, no cast pass), then the two gradient GEMMs of the mixed-precision
+//               backward (bwd_gemm.hip) consume it.
+//
+// Scores inside both kernels are bit-identical to kge_score_sp / kge_score_po on the same bf16 tables
+// (same MFMA chain); exp/log are the hardware v_exp_f32 / libm logf: results match
+// CrossEntropyLoss on those scores to float rounding (tests/test_gpu_ce.py states the tolerance).
+#include "common.hpp"
+
+namespace kge {
+
+bool pairs_bf16_v3_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
+int pairs_bf16_v3_column_groups(long long n, long long m);
+long long pairs_bf16_v3_workspace_bytes(int d, long long n);
+int run_pairs_bf16_v3_ce(int scorer, int epi, const Operand& A, const Operand& R, const Operand& TG, int dir,
+                         int d, long long n, long long m, hipStream_t st, void* ws, long long ws_bytes,
+                         const CeArgs& ce, unsigned long long* dbg);
+int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
+                             long long n, long long m, const unsigned short* G16, long long mp,
+                             unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st);
+
+// merge the column groups of a row: M = max_c m_c, L = sum_c l_c exp(m_c - M).  One wave per row,
+// lanes over the column groups, xor-butterfly reductions (fixed order: deterministic).
+__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ part, int ncg, long long n,
+                                                         const float* __restrict__ true_score,
+                                                         float* __restrict__ loss_rows, float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* p = part + i * ncg * 2;
+  float M = -__builtin_inff();
+  for (int c = lane; c < ncg; c += 64) M = fmaxf(M, p[2 * c]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+  float L = 0.0f;
+  for (int c = lane; c < ncg; c += 64) L += p[2 * c + 1] * expf(p[2 * c] - M);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) L += __shfl_xor(L, off, 64);
+  if (lane == 0) {
+    const float z = M + logf(L);
+    lse[i] = z;
+    loss_rows[i] = z - true_score[i];
+  }
+}
+
+// tools/ce_phases.py: per-workgroup s_memtime stamps of the next fused-loss launches (not part of the ABI)
+static unsigned long long* g_ce_stamps = nullptr;
+
+static inline long long al256(long long x) { return (x + 255) & ~255LL; }
+
+// scratch layout: [fragments + flags of the cooperative build][part n*ncg*2 f32][true n f32]   (forward)
+//                 [fragments + flags][G16 n * ld16 bf16][Q16 n * d bf16]                          (backward)
+static inline long long ce_ld16(long long m) { return (m + 63) & ~63LL; }
+
+long long ce_workspace_bytes(int d, long long n, long long m) {
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const long long fwd = al256(n * pairs_bf16_v3_column_groups(n, m) * 8) + al256(n * 4);
+  const long long bwd = al256(n * ce_ld16(m) * 2) + al256(n * (long long)d * 2);
+  return coop + (fwd > bwd ? fwd : bwd);
+}
+
+bool ce_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG) {
+  return TG.idx.ptr == nullptr && pairs_bf16_v3_supported(scorer, dtype, d, A, R, TG);
+}
+
+int run_ce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+               long long m, const Index& label, float* loss_rows, float* lse, void* ws, long long ws_bytes,
+               hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const int ncg = pairs_bf16_v3_column_groups(n, m);
+  CeArgs ce{};
+  ce.label = label;
+  ce.part = (float*)((char*)ws + coop);
+  ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));
+  const int rc = run_pairs_bf16_v3_ce(scorer, V3_LSE, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  if (rc != KGE_OK) return rc;
+  hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, n,
+                     ce.true_score, loss_rows, lse);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_ce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+               long long m, const Index& label, const float* lse, const float* g_rows, float g_scalar, float* g_a,
+               float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const long long ld16 = ce_ld16(m);
+  CeArgs ce{};
+  ce.label = label;
+  ce.lse = lse;
+  ce.g_rows = g_rows;
+  ce.g_scalar = g_scalar;
+  ce.g16 = (unsigned short*)((char*)ws + coop);
+  ce.ld16 = ld16;
+  unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(n * ld16 * 2));
+  const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  if (rc != KGE_OK) return rc;
+  return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
+}
+
+void ce_set_stamps(unsigned long long* p) { g_ce_stamps = p; }
+
+}  // namespace kge

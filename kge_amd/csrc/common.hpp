@@ -273,4 +273,27 @@ __device__ __forceinline__ long long index_mode(const Index& ix, long long i) {
   return ((const long long*)ix.ptr)[i * ix.stride];
 }
 
+// ---- fused 1vsAll loss epilogues of pairs_bf16_v3_kernel (score_pairs_bf16_v3.hip, ce_loss.hip) ----
+// What happens to a finished 128 x 64 score tile (template parameter EPI):
+//   V3_STORE  written to out[n, m] (f32)                                    -- kge_score_sp/_po
+//   V3_LSE    folded into per-row running (max, sum exp) and the label's score picked out; the
+//             score matrix is never written                                 -- kge_ce_fwd
+//   V3_DS     d loss / d score = g_i * (exp(score - lse_i) - [j == label_i]) rounded to bf16 and
+//             written to G16[n, ld16] (the left operand of both gradient GEMMs) -- kge_ce_bwd
+// The MFMA chain, its operands and their order are the same in all three: the scores inside
+// V3_LSE / V3_DS are bit-identical to what V3_STORE writes.
+constexpr int V3_STORE = 0, V3_LSE = 1, V3_DS = 2;
+constexpr float V3_LOG2E = 1.44269504088896340736f;
+
+struct CeArgs {
+  Index label;              // [n] entity ids (the true target of row i)
+  float* part;              // V3_LSE: [n][ncg][2] per-column-group (max, sum exp)
+  float* true_score;        // V3_LSE: [n] score(i, label_i)
+  const float* lse;         // V3_DS: [n] logsumexp of row i
+  const float* g_rows;      // V3_DS: [n] upstream gradient of row i's loss, or NULL: g_scalar
+  float g_scalar;
+  unsigned short* g16;      // V3_DS: [n][ld16] bf16, ld16 % 64 == 0 and ld16 >= 64 * ntiles
+  long long ld16;
+};
+
 }  // namespace kge

@@ -23,6 +23,7 @@
 namespace kge {
 
 constexpr int V3_ROWS = 128, V3_TN = 64;
+
 typedef float f32x4v3u __attribute__((ext_vector_type(4), aligned(4)));
 
 __device__ __forceinline__ long long v3_shfl64(long long v, int src) {
@@ -40,6 +41,18 @@ __device__ __forceinline__ void v3_static_for(F&& f) {
   }
 }
 
+// element of the tile's two accumulators at tile-relative column `rel` (minus 4 fh; -1: none):
+// accumulator element r of half hf is column 32 hf + 8 (r >> 2) + 4 fh + (r & 3)
+__device__ __forceinline__ float v3_pick(f32x16 h0, f32x16 h1, int rel, float cur) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int off = 8 * (r >> 2) + (r & 3);
+    cur = rel == off ? h0[r] : cur;
+    cur = rel == 32 + off ? h1[r] : cur;
+  }
+  return cur;
+}
+
 // COOP (cooperative query build, needs a workspace): the query rows of a row group are needed
 // by all `ncg` workgroups of that row group.  Instead of every workgroup rebuilding all 128
 // rows (ncg-fold redundant: gather 256 KiB + ~8,000 VALU cycles per wave), the first `nbuild`
@@ -48,12 +61,12 @@ __device__ __forceinline__ void v3_static_for(F&& f) {
 // (= this launch's epoch); every workgroup then polls the flags (agent-scope loads) and loads
 // its fragments with 32 plain 16-byte loads per lane.  All workgroups are co-resident (grid <= number of CUs, one
 // workgroup per CU -- checked by the launcher), so the spin-wait cannot deadlock.
-template <int SCORER, int HH, int TGMODE, bool COOP>
+template <int SCORER, int HH, int TGMODE, bool COOP, int EPI = V3_STORE>
 __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     Operand A, Operand R, Operand TG, int dir, long long n, long long m, int rgn, int ncg,
     int tiles_per_cg, int ntiles, float* __restrict__ out, long long ldo,
     unsigned long long* __restrict__ dbg, u32x4* __restrict__ qf,
-    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild) {
+    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild, CeArgs ce) {
   constexpr int NKB = 2 * HH / 16;        // K-blocks of 16
   constexpr int NKH = HH / 16;            // K-blocks per half
   constexpr int ROWB = 4 * HH;            // bytes per table row (2*HH bf16)
@@ -66,6 +79,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   constexpr int CST0 = (2 * TILEB > STG0 + STAGE) ? 2 * TILEB : STG0 + STAGE;
   constexpr int SMEM = CST0 + 4 * 32 * 144;
   constexpr int NQ = 2 * NKB;             // MFMAs per tile (two 32-target halves)
+  constexpr int NST = EPI == V3_STORE ? 8 : (EPI == V3_DS ? 4 : 0);  // vector stores per tile per lane
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
   // ---- which rows / target tiles
@@ -266,6 +280,52 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   if (orow >= n) orow = n - 1;
   float* const orow_ptr = out + orow * ldo;
 
+  // ---- fused loss epilogues: per-lane state of query row `fi` (both lanes fh = 0 / 1 of a row
+  // hold it; padded rows repeat row n-1 like their query fragments do)
+  long long lab = -1;             // label column of this lane's row
+  float rmax = -__builtin_inff(); // V3_LSE: running max over this lane's columns so far
+  float rsum = 0.0f;              //         running sum of exp(score - rmax)
+  float tsc = 0.0f;               //         score(row, label) if one of this lane's columns
+  bool tfound = false;
+  float lse_i = 0.0f, g_i = 0.0f; // V3_DS
+  if constexpr (EPI != V3_STORE) {
+    lab = index_at(ce.label, orow);
+    if constexpr (EPI == V3_DS) {
+      lse_i = ce.lse[orow];
+      g_i = ce.g_rows != nullptr ? ce.g_rows[orow] : ce.g_scalar;
+    }
+  }
+  // accumulator element r of half hf is column  col0(tile) + 32 hf + 8 (r >> 2) + 4 fh + (r & 3)
+  auto lse_pick = [&](int tt, const f32x16& h0, const f32x16& h1) __attribute__((always_inline)) {
+    const long long rel = lab - ((long long)(tile_lo + tt) * V3_TN + 4 * fh);
+    const bool hit = rel >= 0 && rel < V3_TN && (rel & 7) < 4;
+    if (__any(hit)) {  // rare: a row's label lies in exactly one tile of the table
+      tsc = v3_pick(h0, h1, hit ? (int)rel : -1, tsc);
+      tfound = tfound || hit;
+    }
+  };
+  auto ds_value = [&](float sc, long long rel, int off) {
+    float pv = __builtin_amdgcn_exp2f((sc - lse_i) * V3_LOG2E) * g_i;
+    if (rel == off) pv -= g_i;
+    return pv;
+  };
+  // four d-loss/d-score values (group g of half hf) -> bf16 -> transpose buffer; a row of the
+  // buffer is the tile's 64 columns x 2 B = 128 B
+  unsigned char* const cst16 = smem + CST0 + wave * (32 * 144);
+  auto ds_write = [&](int tt, const f32x16& acc, int hf, int g) {
+    const long long rel = lab - ((long long)(tile_lo + tt) * V3_TN + 4 * fh);
+    const int off = 32 * hf + 8 * g;
+    const float p0 = ds_value(acc[4 * g], rel, off), p1 = ds_value(acc[4 * g + 1], rel, off + 1);
+    const float p2 = ds_value(acc[4 * g + 2], rel, off + 2), p3 = ds_value(acc[4 * g + 3], rel, off + 3);
+    u32x2 v = {bf16_pack(p0, p1), bf16_pack(p2, p3)};
+    *reinterpret_cast<u32x2*>(cst16 + fi * 144 + (off + 4 * fh) * 2) = v;
+  };
+  auto ds_store = [&](int tt, int i, const f32x4& v) {
+    long long orow_i = row0 + 8 * i + (lane >> 3);
+    if (orow_i >= n) orow_i = n - 1;
+    *reinterpret_cast<f32x4*>(ce.g16 + orow_i * ce.ld16 + (long long)(tile_lo + tt) * V3_TN + 8 * (lane & 7)) = v;
+  };
+
   // acc[4g + e] = score(query fi, target col0 + 8g + 4fh + e) for one 32-target half.  The
   // finished half goes through a wave-private LDS transpose so that every store instruction
   // writes 8 rows x 128 contiguous bytes; its instructions are spread between the MFMAs of the
@@ -323,10 +383,10 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   auto tile_body = [&](int tt, f32x16& acc0, f32x16& acc1, const f32x16& accp0, const f32x16& accp1,
                        bool store_prev) {
     // in-order VMEM queue at this point: step 0: [tile 0][tile 1]; step 1: [tile 1]; later:
-    // [DMA of tile tt (NL pieces)][8 stores of tile tt-2] -- the stores may stay in flight
+    // [DMA of tile tt (NL pieces)][NST stores of tile tt-2] -- the stores may stay in flight
     if (tt == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NL) : "memory");
     else if (tt == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NST) : "memory");
     __builtin_amdgcn_s_barrier();  // tile tt visible to all; everyone finished reading tile tt-1
     __builtin_amdgcn_sched_barrier(0);
     stamp();  // tile tt released
@@ -341,6 +401,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     constexpr int U = NQ / 16;  // epilogue schedule unit
     bf16x8 bq[PF];
     f32x4 cv0[4], cv1[4];
+    float tmax = 0.0f, tsum = 0.0f;  // V3_LSE: max / partial sum of the tile being folded in
     auto bread = [&](bf16x8& dst, auto qc) __attribute__((always_inline)) {
       constexpr int q = decltype(qc)::value;
       constexpr int kb = q >> 1, hf = q & 1;
@@ -367,7 +428,48 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
       // was issued by the prologue); second half: the stores of tile tt-1 (behind the DMA in
       // the VMEM queue, so the next step's counted wait leaves them in flight)
       if (tt >= 1 && (q & 1) == 0 && (q >> 1) < NL) dma_piece(tt + 1, (tt + 1) & 1, q >> 1);
-      if (store_prev) {  // epilogue of tile tt-1: half 0 then half 1 through the same buffer
+      if constexpr (EPI == V3_LSE) {
+        if (store_prev) {  // online softmax over tile tt-1: 32 columns of this lane's row
+          if (q == 0) {
+            float mx = rmax;
+            v3_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+              constexpr int r = decltype(rc)::value;
+              mx = __builtin_fmaxf(mx, __builtin_fmaxf(accp0[r], accp1[r]));
+            });
+            tmax = mx;
+            tsum = 0.0f;
+          }
+          if constexpr (q % U == 0 && q / U >= 1 && q / U <= 8) {
+            constexpr int k = q / U - 1;
+            tsum += (__builtin_amdgcn_exp2f((accp0[2 * k] - tmax) * V3_LOG2E) +
+                     __builtin_amdgcn_exp2f((accp0[2 * k + 1] - tmax) * V3_LOG2E)) +
+                    (__builtin_amdgcn_exp2f((accp1[2 * k] - tmax) * V3_LOG2E) +
+                     __builtin_amdgcn_exp2f((accp1[2 * k + 1] - tmax) * V3_LOG2E));
+          }
+          if (q == 9 * U) {
+            rsum = rsum * __builtin_amdgcn_exp2f((rmax - tmax) * V3_LOG2E) + tsum;
+            rmax = tmax;
+          }
+          if (q == 10 * U) lse_pick(tt - 1, accp0, accp1);
+        }
+      } else if constexpr (EPI == V3_DS) {
+        if (store_prev) {  // d loss / d score of tile tt-1 -> bf16 -> transpose -> 4 x 16-byte stores
+          if constexpr (q % U == 0 && q / U < 8) {
+            constexpr int k = q / U;
+            if constexpr (k < 4) ds_write(tt - 1, accp0, 0, k);
+            else ds_write(tt - 1, accp1, 1, k - 4);
+          }
+          if (q == 8 * U) ep_fence();
+          if (q == 9 * U) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cv0[i] = ep_read(i);
+          }
+          if (q == 10 * U) ep_fence();
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (q == (11 + i) * U) ds_store(tt - 1, i, cv0[i]);
+        }
+      } else if (store_prev) {  // epilogue of tile tt-1: half 0 then half 1 through the same buffer
         if (q == 0) { ep_write(accp0, 0); ep_write(accp0, 1); }
         if (q == U) { ep_write(accp0, 2); ep_write(accp0, 3); }
         if (q == 2 * U) ep_fence();
@@ -410,9 +512,56 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   }
   // the workgroup's last tile (ntl - 1) is in a0 / a1
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  store_half_now(ntl - 1, 0, a0);
-  ep_fence();
-  store_half_now(ntl - 1, 1, a1);
+  if constexpr (EPI == V3_LSE) {
+    // only this tile can reach beyond column m (its rows then repeat row m-1): mask
+    const long long c0 = (long long)(tile_lo + ntl - 1) * V3_TN + 4 * fh;
+    f32x16 m0, m1;  // masked copies
+    float mx = rmax;
+    v3_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      const long long c = c0 + 8 * (r >> 2) + (r & 3);
+      m0[r] = c < m ? a0[r] : -__builtin_inff();
+      m1[r] = c + 32 < m ? a1[r] : -__builtin_inff();
+      mx = __builtin_fmaxf(mx, __builtin_fmaxf(m0[r], m1[r]));
+    });
+    float sm = 0.0f;
+    v3_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      sm += __builtin_amdgcn_exp2f((m0[r] - mx) * V3_LOG2E) + __builtin_amdgcn_exp2f((m1[r] - mx) * V3_LOG2E);
+    });
+    rsum = rsum * __builtin_amdgcn_exp2f((rmax - mx) * V3_LOG2E) + sm;
+    rmax = mx;
+    lse_pick(ntl - 1, a0, a1);
+    // the two lanes of a row -> one (max, sum exp) per row and column group
+    const float omax = __shfl_xor(rmax, 32, 64), osum = __shfl_xor(rsum, 32, 64);
+    const float M = __builtin_fmaxf(rmax, omax);
+    const float L = rsum * __builtin_amdgcn_exp2f((rmax - M) * V3_LOG2E) +
+                    osum * __builtin_amdgcn_exp2f((omax - M) * V3_LOG2E);
+    const long long row = row0 + fi;
+    if (row < n) {
+      if (fh == 0) {
+        float* pp = ce.part + (row * ncg + cg) * 2;
+        pp[0] = M;
+        pp[1] = L;
+      }
+      if (tfound) ce.true_score[row] = tsc;
+    }
+  } else if constexpr (EPI == V3_DS) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ds_write(ntl - 1, a0, 0, g);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ds_write(ntl - 1, a1, 1, g);
+    ep_fence();
+    f32x4 cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cv[i] = ep_read(i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ds_store(ntl - 1, i, cv[i]);
+  } else {
+    store_half_now(ntl - 1, 0, a0);
+    ep_fence();
+    store_half_now(ntl - 1, 1, a1);
+  }
 }
 
 static inline bool v3_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -447,18 +596,29 @@ long long pairs_bf16_v3_workspace_bytes(int d, long long n) {
   return rgn * V3_ROWS * (long long)d * 2 + 512 * 8 * 8;
 }
 
-template <int SCORER, int HH>
-static int launch_v3(const Operand& A, const Operand& R, const Operand& TG, int dir, long long n,
-                     long long m, float* out, long long ldo, hipStream_t st,
-                     unsigned long long* dbg, void* ws, long long ws_bytes) {
-  const int rgn = (int)((n + V3_ROWS - 1) / V3_ROWS);
-  const int ntiles = (int)((m + V3_TN - 1) / V3_TN);
-  // one workgroup per CU (256 CUs): split the target tiles into column groups
-  int ncg = 256 / rgn;
+// one workgroup per CU (256 CUs): the target tiles are split into `ncg` column groups of `tpc` tiles
+static void v3_geometry(long long n, long long m, int& rgn, int& ntiles, int& ncg, int& tpc) {
+  rgn = (int)((n + V3_ROWS - 1) / V3_ROWS);
+  ntiles = (int)((m + V3_TN - 1) / V3_TN);
+  ncg = 256 / rgn;
   if (ncg < 1) ncg = 1;
-  int tpc = (ntiles + ncg - 1) / ncg;
+  tpc = (ntiles + ncg - 1) / ncg;
   if (tpc < 1) tpc = 1;
   ncg = (ntiles + tpc - 1) / tpc;
+}
+
+int pairs_bf16_v3_column_groups(long long n, long long m) {
+  int rgn, ntiles, ncg, tpc;
+  v3_geometry(n, m, rgn, ntiles, ncg, tpc);
+  return ncg;
+}
+
+template <int SCORER, int HH, int EPI = V3_STORE>
+static int launch_v3(const Operand& A, const Operand& R, const Operand& TG, int dir, long long n,
+                     long long m, float* out, long long ldo, hipStream_t st,
+                     unsigned long long* dbg, void* ws, long long ws_bytes, const CeArgs& ce = CeArgs{}) {
+  int rgn, ntiles, ncg, tpc;
+  v3_geometry(n, m, rgn, ntiles, ncg, tpc);
   const int grid = 8 * rgn * ((ncg + 7) / 8);
   const int tgmode = TG.idx.ptr == nullptr ? 0 : (TG.idx.itype ? 2 : 1);
   // cooperative query build: needs the workspace, more than one column group, every workgroup
@@ -483,20 +643,45 @@ static int launch_v3(const Operand& A, const Operand& R, const Operand& TG, int 
     const int items = V3_ROWS * (HH / 8);  // at least one item per builder thread
     while (nbuild > 1 && nbuild * 256 > items) --nbuild;
   }
-#define KGE_V3L(MODE)                                                                            \
-  if (coop)                                                                                      \
-    hipLaunchKernelGGL((pairs_bf16_v3_kernel<SCORER, HH, MODE, true>), dim3(grid), dim3(256), 0,  \
-                       st, A, R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, qf, flags, \
-                       epoch, nbuild);                                                           \
-  else                                                                                           \
-    hipLaunchKernelGGL((pairs_bf16_v3_kernel<SCORER, HH, MODE, false>), dim3(grid), dim3(256), 0, \
-                       st, A, R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, qf, flags, \
-                       epoch, nbuild)
-  if (tgmode == 0) { KGE_V3L(0); }
-  else if (tgmode == 1) { KGE_V3L(1); }
-  else { KGE_V3L(2); }
+#define KGE_V3L(MODE)                                                                                 \
+  if (coop)                                                                                           \
+    hipLaunchKernelGGL((pairs_bf16_v3_kernel<SCORER, HH, MODE, true, EPI>), dim3(grid), dim3(256), 0,  \
+                       st, A, R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, qf, flags,      \
+                       epoch, nbuild, ce);                                                            \
+  else                                                                                                \
+    hipLaunchKernelGGL((pairs_bf16_v3_kernel<SCORER, HH, MODE, false, EPI>), dim3(grid), dim3(256), 0, \
+                       st, A, R, TG, dir, n, m, rgn, ncg, tpc, ntiles, out, ldo, dbg, qf, flags,      \
+                       epoch, nbuild, ce)
+  if constexpr (EPI != V3_STORE) {  // the fused-loss launches score against all entities only
+    if (tgmode != 0) return KGE_ERR_UNSUPPORTED;
+    KGE_V3L(0);
+  } else {
+    if (tgmode == 0) { KGE_V3L(0); }
+    else if (tgmode == 1) { KGE_V3L(1); }
+    else { KGE_V3L(2); }
+  }
 #undef KGE_V3L
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// Fused 1vsAll loss launches (ce_loss.hip): the same kernel with the V3_LSE / V3_DS epilogue.
+// `ws` = fragment + flag scratch of pairs_bf16_v3_workspace_bytes (cooperative query build), or NULL.
+int run_pairs_bf16_v3_ce(int scorer, int epi, const Operand& A, const Operand& R, const Operand& TG, int dir,
+                         int d, long long n, long long m, hipStream_t st, void* ws, long long ws_bytes,
+                         const CeArgs& ce, unsigned long long* dbg) {
+  if (n == 0 || m == 0) return KGE_OK;
+#define KGE_V3C(SC, EP)                                                                                       \
+  switch (d) {                                                                                                \
+    case 128: return launch_v3<SC, 64, EP>(A, R, TG, dir, n, m, nullptr, 0, st, dbg, ws, ws_bytes, ce);        \
+    case 256: return launch_v3<SC, 128, EP>(A, R, TG, dir, n, m, nullptr, 0, st, dbg, ws, ws_bytes, ce);       \
+    case 512: return launch_v3<SC, 256, EP>(A, R, TG, dir, n, m, nullptr, 0, st, dbg, ws, ws_bytes, ce);       \
+  }
+  if (scorer == KGE_COMPLEX && epi == V3_LSE) { KGE_V3C(KGE_COMPLEX, V3_LSE) }
+  else if (scorer == KGE_COMPLEX && epi == V3_DS) { KGE_V3C(KGE_COMPLEX, V3_DS) }
+  else if (scorer == KGE_DISTMULT && epi == V3_LSE) { KGE_V3C(KGE_DISTMULT, V3_LSE) }
+  else if (scorer == KGE_DISTMULT && epi == V3_DS) { KGE_V3C(KGE_DISTMULT, V3_DS) }
+#undef KGE_V3C
+  return KGE_ERR_UNSUPPORTED;
 }
 
 int run_pairs_bf16_v3(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,

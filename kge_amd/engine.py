@@ -433,6 +433,62 @@ def score_pairs_bwd(t: Tables, direction: str, a, p, targets, gout, scores=None)
     return g_a, g_p, g_t
 
 
+def _ce_workspace(tc, n, device, st):
+    need = _lib.lib().kge_ce_workspace_bytes(ctypes.byref(tc), n)
+    if need <= 0:
+        raise RuntimeError("kge_ce_fwd/kge_ce_bwd: bf16 ComplEx/DistMult tables with dim in {128, 256, 512} only")
+    key = (device.index, st, "ce")
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _WORKSPACES[key] = _empty((need,), device, torch.uint8)
+    return buf.data_ptr(), buf.numel()
+
+
+def ce_supported(t: Tables) -> bool:
+    """Can the fused 1vsAll loss run on these tables (kge_ce_workspace_bytes > 0)?"""
+    if not t.ent.is_cuda:
+        return False
+    return _lib.lib().kge_ce_workspace_bytes(ctypes.byref(t.c()), 1) > 0
+
+
+def ce_fwd(t: Tables, direction: str, a, p, label):
+    """Fused score_sp ('sp': a = s, label = o) / score_po ('po': a = o, label = s) + cross entropy
+    against all entities: (loss_rows [n], lse [n]); sum(loss_rows) = the reference's
+    KLDivWithSoftmaxKgeLoss (kge/util/loss.py:192-207) on the [n, E] scores, never written here."""
+    keep = []
+    ai, pi, li = (_index(x, t.device, keep) for x in (a, p, label))
+    n = keep[0].numel()
+    loss_rows, lse = _empty((n,), t.device), _empty((n,), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_fwd(ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, li, n,
+                                         loss_rows.data_ptr(), lse.data_ptr(), ws, wsb, st), "kge_ce_fwd")
+    return loss_rows, lse
+
+
+def ce_bwd(t: Tables, direction: str, a, p, label, lse, g_rows=None, g_scalar: float = 1.0):
+    """Backward of ce_fwd: gradients of sum_i g_i * loss_rows[i] w.r.t. the gathered query rows and
+    all entity rows: (g_a [n, d], g_p [n, d], g_entities [E, d])."""
+    keep = []
+    ai, pi, li = (_index(x, t.device, keep) for x in (a, p, label))
+    n = keep[0].numel()
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    lse = _f32c(lse, t.device)
+    gr = None if g_rows is None else _f32c(g_rows, t.device)
+    g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((t.num_ent, d), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_bwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, li, n, lse.data_ptr(),
+            None if gr is None else gr.data_ptr(), float(g_scalar), g_a.data_ptr(), g_p.data_ptr(),
+            g_t.data_ptr(), ws, wsb, st), "kge_ce_bwd")
+    return g_a, g_p, g_t
+
+
 def score_emb_bwd(scorer, s_emb, p_emb, o_emb, combine: str, l_norm, gout, scores=None):
     """Backward of score_emb: gradients w.r.t. (s_emb, p_emb, o_emb)."""
     code = {"spo": SPO, "sp_": SP_, "_po": PO_}[combine]

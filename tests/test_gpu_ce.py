@@ -1,0 +1,171 @@
+"""Fused 1vsAll loss (kge_ce_fwd / kge_ce_bwd) on the GPU, through the C ABI.
+
+What is compared (tolerances stated at each assert):
+  * forward against float64 cross entropy of the scores kge_score_sp / kge_score_po write for the
+    same inputs (the kernel's scores are bit-identical inside both; what differs is f32 exp / log /
+    summation): |diff| <= 1e-5 + 1e-5 |ref|;
+  * forward against float64 cross entropy of the ORACLE's bf16-semantics scores: the bf16 score
+    tolerance of test_gpu_parity.py (1e-5 * max(1, rms) + 1e-4 |score|), which a log-sum-exp
+    propagates at most 1:1, twice (lse and the label's score);
+  * backward against float64 gradients of the same loss on the same (bf16-valued) tables:
+    d loss / d score and the query matrix are rounded to bf16 before the two products (the
+    mixed-precision backward), so relative error in the Frobenius norm <= 1e-2; and
+    against the unfused mixed-precision backward (kge_score_pairs_bwd on the softmax gradient
+    computed by torch from the written scores), which rounds the same way: <= 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle as ko
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from kge_amd import engine
+    return engine
+
+
+def _t(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def _tables(eng, model, ent, rel):
+    return eng.Tables(model, torch.from_numpy(ent).to(torch.bfloat16).to(DEV),
+                      torch.from_numpy(rel).to(torch.bfloat16).to(DEV), 1.0)
+
+
+def _ce64(scores, label):
+    """float64 (loss_rows, lse) of scores [n, E] with index labels"""
+    x = np.asarray(scores, dtype=np.float64)
+    mx = x.max(axis=1)
+    lse = mx + np.log(np.exp(x - mx[:, None]).sum(axis=1))
+    return lse - x[np.arange(len(label)), label], lse
+
+
+def _case(seed, model, d, E, R, n, scale=1.0):
+    rng = np.random.default_rng(seed)
+    ent = (rng.standard_normal((E, d)) * scale).astype(np.float32)
+    rel = (rng.standard_normal((R, d)) * scale).astype(np.float32)
+    s, p, o = rng.integers(0, E, n), rng.integers(0, R, n), rng.integers(0, E, n)
+    return ent, rel, s, p, o
+
+
+CASES = [
+    ("complex", 512, 1037, 13, 203, 0.3),     # ragged rows and columns
+    ("distmult", 256, 1037, 13, 203, 0.5),
+    ("complex", 128, 70, 3, 1, 1.0),          # one row, one column group, one ragged tile
+    ("distmult", 128, 64, 3, 33, 1.0),        # exactly one full tile
+    ("complex", 512, 14541, 237, 512, 0.1),   # BASELINE configs[1] shape (C2)
+    ("complex", 256, 20000, 50, 700, 0.2),    # six row groups
+]
+
+
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES)
+def test_ce_fwd(eng, model, d, E, R, n, scale):
+    ent, rel, s, p, o = _case(d + n, model, d, E, R, n, scale)
+    T = _tables(eng, model, ent, rel)
+    O = ko.Tables(model, ko.f32_to_bf16(ent), ko.f32_to_bf16(rel), 1.0)
+    for direction, a, lab in (("sp", s, o), ("po", o, s)):
+        loss, lse = eng.ce_fwd(T, direction, _t(a), _t(p), _t(lab))
+        loss, lse = loss.cpu().numpy().astype(np.float64), lse.cpu().numpy().astype(np.float64)
+        assert np.isfinite(loss).all() and (loss >= 0).all(), direction
+        # (1) the kernel's own scores
+        sc = (eng.score_sp(T, _t(a), _t(p)) if direction == "sp" else eng.score_po(T, _t(p), _t(a))).cpu().numpy()
+        want_loss, want_lse = _ce64(sc, lab)
+        for nm, got, want in (("lse", lse, want_lse), ("loss", loss, want_loss)):
+            err = np.abs(got - want)
+            tol = 1e-5 + 1e-5 * np.abs(want)
+            assert (err <= tol).all(), (direction, nm, float(err.max()), int((err > tol).sum()))
+        # (2) the oracle's scores (bf16 semantics of the matrix-core path)
+        osc = ko.score_sp(O, a, p) if direction == "sp" else ko.score_po(O, p, a)
+        o_loss, o_lse = _ce64(osc, lab)
+        rms = max(1.0, float(np.sqrt(np.mean(np.square(osc.astype(np.float64))))))
+        stol = 1e-5 * rms + 1e-4 * np.abs(osc).max(axis=1)   # per-row bound on a score's tolerance
+        assert (np.abs(lse - o_lse) <= stol + 1e-5).all(), (direction, float(np.abs(lse - o_lse).max()))
+        assert (np.abs(loss - o_loss) <= 2 * stol + 1e-5).all(), (direction, float(np.abs(loss - o_loss).max()))
+
+
+def test_ce_fwd_strided_int32_indices_and_repeats(eng):
+    """indices as the reference passes them: columns of an int32 [n, 3] triple tensor
+    (train_1vsAll.py:64: triples[:, 0], triples[:, 1]); repeated calls give identical bits."""
+    ent, rel, s, p, o = _case(7, "complex", 256, 3000, 11, 300, 0.3)
+    T = _tables(eng, "complex", ent, rel)
+    tri = torch.from_numpy(np.stack([s, p, o], axis=1)).to(torch.int32).to(DEV)
+    a = eng.ce_fwd(T, "sp", tri[:, 0], tri[:, 1], tri[:, 2])
+    b = eng.ce_fwd(T, "sp", _t(s), _t(p), _t(o))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for _ in range(5):
+        c = eng.ce_fwd(T, "sp", tri[:, 0], tri[:, 1], tri[:, 2])
+        assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
+
+
+def _grads64(model, ent16, rel16, a, p, lab, direction, g):
+    """float64 autograd of sum_i g_i * CE_i on the bf16-valued tables (torch CPU)."""
+    e = ent16.double().requires_grad_(True)
+    r = rel16.double().requires_grad_(True)
+    ea, rp = e[a], r[p]
+    h = e.shape[1] // 2
+    if model == "distmult":
+        q = ea * rp
+    else:
+        are, aim, rre, rim = ea[:, :h], ea[:, h:], rp[:, :h], rp[:, h:]
+        if direction == "sp":   # Re<s, r, conj(o)>: q = s * r
+            q = torch.cat([are * rre - aim * rim, are * rim + aim * rre], dim=1)
+        else:                   # as a function of s: q = conj(r) * o
+            q = torch.cat([are * rre + aim * rim, aim * rre - are * rim], dim=1)
+    sc = q @ e.t()
+    loss = (torch.nn.functional.cross_entropy(sc, lab, reduction="none") * g).sum()
+    loss.backward()
+    return e.grad, r.grad
+
+
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5])
+def test_ce_bwd(eng, model, d, E, R, n, scale):
+    ent, rel, s, p, o = _case(3 * d + n, model, d, E, R, n, scale)
+    T = _tables(eng, model, ent, rel)
+    rng = np.random.default_rng(1)
+    g_rows = (rng.random(n).astype(np.float32) + 0.5) / n
+    for direction, a, lab in (("sp", s, o), ("po", o, s)):
+        ta, tp, tl = _t(a), _t(p), _t(lab)
+        loss, lse = eng.ce_fwd(T, direction, ta, tp, tl)
+        g_a, g_p, g_t = eng.ce_bwd(T, direction, ta, tp, tl, lse, g_rows=_t(g_rows))
+        ge = g_t.clone()
+        ge.index_add_(0, ta, g_a)
+        gr = torch.zeros(R, d, device=DEV).index_add_(0, tp, g_p)
+        # float64 reference
+        we, wr = _grads64(model, T.ent.cpu(), T.rel.cpu(), torch.from_numpy(a), torch.from_numpy(p),
+                          torch.from_numpy(lab), direction, torch.from_numpy(g_rows).double())
+        for nm, got, want in (("ent", ge, we), ("rel", gr, wr)):
+            got = got.cpu().double()
+            rel_err = float((got - want).norm() / want.norm())
+            assert rel_err <= 1e-2, (direction, nm, rel_err)
+        # the unfused mixed-precision backward on torch's softmax gradient of the written scores
+        sc = eng.score_sp(T, ta, tp) if direction == "sp" else eng.score_po(T, tp, ta)
+        ds = torch.softmax(sc, dim=1)
+        ds[torch.arange(n, device=DEV), tl] -= 1.0
+        ds *= _t(g_rows)[:, None]
+        u_a, u_p, u_t = eng.score_pairs_bwd(T, direction, ta, tp, None, ds)
+        for nm, got, want in (("g_a", g_a, u_a), ("g_p", g_p, u_p), ("g_t", g_t, u_t)):
+            rel_err = float((got - want).norm() / want.norm())
+            assert rel_err <= 2e-3, (direction, nm, rel_err)
+        # scalar upstream gradient == a constant row vector
+        c_a, c_p, c_t = eng.ce_bwd(T, direction, ta, tp, tl, lse, g_scalar=1.0 / n)
+        v_a, v_p, v_t = eng.ce_bwd(T, direction, ta, tp, tl, lse, g_rows=torch.full((n,), 1.0 / n, device=DEV))
+        assert torch.equal(c_a, v_a) and torch.equal(c_p, v_p) and torch.equal(c_t, v_t)
+
+
+def test_ce_unsupported_tables_fail_loudly(eng):
+    ent, rel, s, p, o = _case(11, "complex", 128, 100, 3, 10)
+    Tf = eng.Tables("complex", torch.from_numpy(ent).to(DEV), torch.from_numpy(rel).to(DEV), 1.0)
+    assert not eng.ce_supported(Tf)
+    with pytest.raises(RuntimeError):
+        eng.ce_fwd(Tf, "sp", _t(s), _t(p), _t(o))
+    Tt = eng.Tables("transe", torch.from_numpy(ent).to(torch.bfloat16).to(DEV),
+                    torch.from_numpy(rel).to(torch.bfloat16).to(DEV), 1.0)
+    assert not eng.ce_supported(Tt)
+    with pytest.raises(RuntimeError):
+        eng.ce_fwd(Tt, "sp", _t(s), _t(p), _t(o))
