@@ -8,7 +8,7 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import BF16Shadow, _ScoreEmb, _ScorePairs, _ScoreSPO
+from ..model import BF16Shadow, _FusedCE, _ScoreEmb, _ScorePairs, _ScoreSPO
 
 
 class _HipScorer(RelationalScorer):
@@ -95,6 +95,31 @@ class _FusedScoring:
         ent, rel = self._w()
         return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, s,
                                  self._fwd_tables())
+
+    # 1vsAll loss fused with the scoring (HipTrainingJob1vsAll; kge_ce_fwd / kge_ce_bwd)
+    def _ce_tables(self):
+        if not self._fused() or self._scorer.name not in ("complex", "distmult"):
+            return None
+        ent, rel = self._w()
+        t = self._fwd_tables()
+        if t is None and ent.dtype == torch.bfloat16:
+            t = engine.Tables(self._scorer.name, ent.detach(), rel.detach(), self._scorer._norm)
+        return t if (t is not None and ent.is_cuda and engine.ce_supported(t)) else None
+
+    def loss_sp(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
+        """[n] cross entropy of score_sp(s, p) against o; None if the fused path does not apply."""
+        t = self._ce_tables()
+        if t is None:
+            return None
+        ent, rel = self._w()
+        return _FusedCE.apply("sp", ent, rel, s, p, o, t)
+
+    def loss_po(self, p: Tensor, o: Tensor, s: Tensor) -> Tensor:
+        t = self._ce_tables()
+        if t is None:
+            return None
+        ent, rel = self._w()
+        return _FusedCE.apply("po", ent, rel, o, p, s, t)
 
     def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
         if not self._fused():

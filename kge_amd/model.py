@@ -188,6 +188,32 @@ class KgeModel(torch.nn.Module):
         oe, pe = self._entity_embedder.embed(o), self._relation_embedder.embed(p)
         return self._scorer.score_emb(se, pe, oe, combine="_po")
 
+    # -- 1vsAll loss: train_1vsAll.py:64-65 / 75-76 in one call
+    def _ce_tables(self):
+        """bf16 tables for the fused loss, or None (then the loss is composed from score_sp/_po)."""
+        if not self._fused() or self._scorer.name not in ("complex", "distmult"):
+            return None
+        w = self._entity_embedder.weight
+        t = self._fwd_tables()
+        if t is None and w.dtype == torch.bfloat16:
+            t = engine.Tables(self._scorer.name, w.detach(), self._relation_embedder.weight.detach())
+        return t if (t is not None and w.is_cuda and engine.ce_supported(t)) else None
+
+    def loss_sp(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
+        """Per-row cross entropy of score_sp(s, p) against the true objects o ([n]); its sum is the
+        reference's `self.loss(scores_sp, triples[:, 2])` with train.loss=kl (loss.py:192-207)."""
+        t = self._ce_tables()
+        if t is not None:
+            return _FusedCE.apply("sp", self._entity_embedder.weight, self._relation_embedder.weight, s, p, o, t)
+        return torch.nn.functional.cross_entropy(self.score_sp(s, p), o.long(), reduction="none")
+
+    def loss_po(self, p: Tensor, o: Tensor, s: Tensor) -> Tensor:
+        """Per-row cross entropy of score_po(p, o) against the true subjects s."""
+        t = self._ce_tables()
+        if t is not None:
+            return _FusedCE.apply("po", self._entity_embedder.weight, self._relation_embedder.weight, o, p, s, t)
+        return torch.nn.functional.cross_entropy(self.score_po(p, o), s.long(), reduction="none")
+
     def score_so(self, s: Tensor, o: Tensor, p: Tensor = None) -> Tensor:
         se, oe = self._entity_embedder.embed(s), self._entity_embedder.embed(o)
         pe = self._relation_embedder.embed_all() if p is None else self._relation_embedder.embed(p)
@@ -310,6 +336,30 @@ class _ScorePairs(torch.autograd.Function):
             _scatter_rows(ge, targets, g_t)
         _scatter_rows(ge, a, g_a)
         return None, None, None, ge, gr, None, None, None, None
+
+
+class _FusedCE(torch.autograd.Function):
+    """Per-row 1vsAll cross entropy fused with the sp_/_po scoring (kge_ce_fwd / kge_ce_bwd):
+    `tables16` are the bf16 tables the scores come from (the parameters themselves, or their
+    bf16 copies in mixed precision); gradients go to `ent` / `rel`."""
+
+    @staticmethod
+    def forward(ctx, direction, ent, rel, a, p, label, tables16):
+        loss_rows, lse = engine.ce_fwd(tables16, direction, a, p, label)
+        ctx.t16, ctx.direction, ctx.idx = tables16, direction, (a, p, label)
+        ctx.rel_shape = rel.shape
+        ctx.save_for_backward(lse)
+        return loss_rows
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        a, p, label = ctx.idx
+        (lse,) = ctx.saved_tensors
+        g_a, g_p, ge = engine.ce_bwd(ctx.t16, ctx.direction, a, p, label, lse, g_rows=g_rows.contiguous())
+        gr = torch.zeros(ctx.rel_shape, dtype=torch.float32, device=ge.device)
+        _scatter_rows(gr, p, g_p)
+        _scatter_rows(ge, a, g_a)  # ge [E, d] is fresh: the dense target gradient + the query rows
+        return None, ge, gr, None, None, None, None
 
 
 class _ScoreEmb(torch.autograd.Function):

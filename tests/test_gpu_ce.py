@@ -169,3 +169,39 @@ def test_ce_unsupported_tables_fail_loudly(eng):
     assert not eng.ce_supported(Tt)
     with pytest.raises(RuntimeError):
         eng.ce_fwd(Tt, "sp", _t(s), _t(p), _t(o))
+
+
+@pytest.mark.parametrize("name", ["complex", "distmult"])
+def test_model_level_fused_loss_against_composed_loss(name):
+    """KgeModel.loss_sp / loss_po (mixed precision: f32 parameters, bf16 scoring) against the same
+    model's score_sp / score_po + CrossEntropyLoss(reduction="sum") / batch_size, the reference's
+    1vsAll step (train_1vsAll.py:64-81): loss values to f32 rounding (the scores inside are the same
+    bits), parameter gradients within the bf16 rounding both backward paths apply."""
+    from kge_amd import model as km
+    E, R, d, n = 3000 + 5, 11, 256, 300
+    torch.manual_seed(0)
+    m = km.create(name, E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    assert m._ce_tables() is not None
+    g = torch.Generator().manual_seed(2)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    for fused, composed in ((lambda: m.loss_sp(s, p, o), lambda: torch.nn.functional.cross_entropy(m.score_sp(s, p), o, reduction="sum")),
+                            (lambda: m.loss_po(p, o, s), lambda: torch.nn.functional.cross_entropy(m.score_po(p, o), s, reduction="sum"))):
+        m.zero_grad()
+        lf = fused().sum() / n
+        lf.backward()
+        gf = [x.grad.clone() for x in m.parameters()]
+        m.zero_grad()
+        lc = composed() / n
+        lc.backward()
+        gc = [x.grad.clone() for x in m.parameters()]
+        assert abs(float(lf) - float(lc)) <= 1e-5 * max(1.0, abs(float(lc))), (float(lf), float(lc))
+        for a, b in zip(gf, gc):
+            assert a.dtype == b.dtype and a.shape == b.shape
+            rel_err = float((a - b).norm() / b.norm())
+            assert rel_err <= 2e-3, rel_err
+    # f32 scoring (no bf16 copies): the fused path does not apply, the loss is composed
+    m32 = km.create(name, E, R, d, device=DEV)
+    assert m32._ce_tables() is None
+    rows = m32.loss_sp(s, p, o)
+    want = torch.nn.functional.cross_entropy(m32.score_sp(s, p), o, reduction="none")
+    assert torch.equal(rows, want)

@@ -85,3 +85,21 @@ def test_eval_job_plugin_resolves():
     import kge_amd.libkge_plugin as plugin
     from kge.job import EntityRankingJob
     assert issubclass(plugin.HipEntityRankingJob, EntityRankingJob)
+
+
+def test_training_job_plugin_resolves_and_declines_without_gpu():
+    """train.type: hip_1vsAll resolves through the reference's factory lookup
+    (train.py:127-137); without a GPU the models decline the fused loss (loss_sp -> None), so
+    the job runs the reference's _process_subbatch -- whose scoring call then fails loudly."""
+    config = _config("hip_complex")
+    config.set("train.type", "hip_1vsAll")
+    config._import("hip_1vsAll")
+    assert config.get_default("hip_1vsAll.class_name") == "HipTrainingJob1vsAll"
+    import kge_amd.libkge_plugin as plugin
+    from kge.job.train_1vsAll import TrainingJob1vsAll
+    assert issubclass(plugin.HipTrainingJob1vsAll, TrainingJob1vsAll)
+    from kge import Dataset
+    from kge.model import KgeModel
+    m = KgeModel.create(config, Dataset(config, folder=None))
+    s, p, o = torch.tensor([1, 2]), torch.tensor([0, 3]), torch.tensor([5, 6])
+    assert m.loss_sp(s, p, o) is None and m.loss_po(p, o, s) is None

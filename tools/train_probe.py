@@ -48,6 +48,13 @@ def step(m, opt):
     opt.step()
 
 
+def step_fused(m, opt):  # loss fused into the scoring kernel (kge_ce_fwd / kge_ce_bwd)
+    opt.zero_grad(set_to_none=True)
+    m.loss_sp(s, p, o).sum().backward()
+    m.loss_po(p, o, s).sum().backward()
+    opt.step()
+
+
 def timeit(fn, k=20):
     for _ in range(3): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -64,15 +71,20 @@ for name in ("complex", "distmult"):
         m = mk()
         opt = torch.optim.Adagrad(m.parameters(), lr=0.1)
         res[tag] = timeit(lambda: step(m, opt))
+    m = km.create(name, E, R, d, device=dev, score_dtype=torch.bfloat16)
+    opt = torch.optim.Adagrad(m.parameters(), lr=0.1)
+    res["kge_amd score_dtype=bfloat16, fused loss"] = timeit(lambda: step_fused(m, opt))
     print(name, " | ".join(f"{k}: {v:.2f} ms" for k, v in res.items()))
 
 # ---- where the mixed-precision step spends its GPU time
 from torch.profiler import profile, ProfilerActivity
 m = km.create("complex", E, R, d, device=dev, score_dtype=torch.bfloat16)
 opt = torch.optim.Adagrad(m.parameters(), lr=0.1)
-for _ in range(3): step(m, opt)
-torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA]) as prof:
-    for _ in range(5): step(m, opt)
+for tag, fn in (("composed loss", step), ("fused loss", step_fused)):
+    for _ in range(3): fn(m, opt)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=70))
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(5): fn(m, opt)
+        torch.cuda.synchronize()
+    print(f"---- mixed precision, {tag}: 5 steps")
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=22, max_name_column_width=70))
