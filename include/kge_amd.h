@@ -199,6 +199,42 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
                     const int64_t* true_col, float atol, float rtol,
                     int64_t* rank, int64_t* ties, void* stream);
 
+/* ---- evaluation without host round trips --------------- */
+/* The filter index of a set of splits lives on the device as sorted arrays:
+ *   sorted_keys[num_keys]   unique keys (s*num_rel + p for the sp index, p*num_ent + o for po)
+ *   starts[num_keys + 1]    range of key k in the index's value array
+ *   values[...]             the known answers of each key, unique per key
+ * (replaces the numba dict KvsAllIndex, kge/indexing.py:10-194).
+ *
+ * kge_filter_lookup: begin[i], end[i] = range of key a[i]*mult + b[i] (0, 0 if absent): what
+ * get_sp_po_coords_from_spo_batch (kge/job/util.py:6-29) + _collate
+ * (eval_entity_ranking.py:77-101) look up per batch on the host. */
+int kge_filter_lookup(const int64_t* sorted_keys, int64_t num_keys, const int64_t* starts,
+                      kge_index a, kge_index b, int64_t mult, int64_t n, int64_t* begin,
+                      int64_t* end, void* stream);
+
+/* kge_rank_counts for the raw ranking and `num_filters` (<= KGE_MAX_FILTERS) filtered
+ * rankings from ONE scan of the scores: rank/ties are [num_filters + 1][n] int64, row 0 raw,
+ * row k + 1 filtered by the columns lbl_col[k][lbl_begin[k][i] .. lbl_end[k][i]) of row i
+ * (global ids, minus col_offset; the one equal to true_col[i] stays).  ACCUMULATED over
+ * entity chunks.  lbl_begin / lbl_end / lbl_col are HOST arrays of device pointers.
+ * eval_entity_ranking.py:233-313 runs _filter_and_rank once per ranking. */
+#define KGE_MAX_FILTERS 4
+int kge_rank_counts_multi(const float* scores, int64_t lds, int64_t n, int64_t c,
+                          const float* true_scores, int num_filters,
+                          const int64_t* const* lbl_begin, const int64_t* const* lbl_end,
+                          const int64_t* const* lbl_col, int64_t col_offset,
+                          const int64_t* true_col, float atol, float rtol, int64_t* rank,
+                          int64_t* ties, void* stream);
+
+/* hist[m*ldh + r] += 1.0f with r = rank of the tie policy, for all [num_rankings][n] counts;
+ * ranks_out (may be NULL) receives r.  EntityRankingJob._get_ranks (:598-618) + hist_all
+ * (:665-687); the float32 histogram is the reference's. */
+enum { KGE_TIES_ROUNDED_MEAN = 0, KGE_TIES_BEST = 1, KGE_TIES_WORST = 2 };
+int kge_rank_hist(const int64_t* rank, const int64_t* ties, int num_rankings, int64_t n,
+                  int tie_policy, float* hist, int64_t ldh, int64_t num_ent,
+                  int64_t* ranks_out, void* stream);
+
 /* ---- LookupEmbedder.embed ------------------------------------------------ */
 /* ent_out[i, :] = ent[ent_idx[i], :] (n_ent rows, leading dimension ent_ldo elements) and
  * rel_out[i, :] = rel[rel_idx[i], :] in ONE launch (table dtype; rows of 16-byte multiples).

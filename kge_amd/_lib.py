@@ -60,6 +60,11 @@ PROTOTYPES = {
     "kge_embed": (ctypes.c_int, [_PT, KgeIndex, c_i64, c_vp, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
     "kge_rank_counts": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                        ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
+    "kge_filter_lookup": (ctypes.c_int, [c_vp, c_i64, c_vp, KgeIndex, KgeIndex, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "kge_rank_counts_multi": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, ctypes.c_int, c_vp, c_vp, c_vp,
+                                             c_i64, c_vp, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
+    "kge_rank_hist": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_i64, c_i64, c_vp,
+                                     c_vp]),
     "kge_score_bwd_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),
     "kge_score_pairs_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, KgeIndex,
                                            c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp,

@@ -41,6 +41,15 @@ int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
              long long col_offset, const long long* true_col, float atol, float rtol,
              long long* rank, long long* ties, hipStream_t st);
+int run_filter_lookup(const long long* keys, long long num_keys, const long long* starts, const Index& a,
+                      const Index& b, long long mult, long long n, long long* begin, long long* end,
+                      hipStream_t st);
+int run_rank_multi(const float* scores, long long lds, long long n, long long c, const float* true_scores,
+                   int K, const long long* const* begin, const long long* const* end,
+                   const long long* const* col, long long col_offset, const long long* true_col, float atol,
+                   float rtol, long long* rank, long long* ties, hipStream_t st);
+int run_rank_hist(const long long* rank, const long long* ties, int M, long long n, int policy, float* hist,
+                  long long ldh, long long num_ent, long long* ranks_out, hipStream_t st);
 int run_pairs_bwd_gemm16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
                          int dr, long long n, long long m, const float* gout, long long ldg, float* g_a,
                          float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
@@ -311,6 +320,44 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
   return run_rank(scores, lds, n, c, true_scores, (const long long*)lbl_rowptr,
                   (const long long*)lbl_col, col_offset, (const long long*)true_col, atol, rtol,
                   (long long*)rank, (long long*)ties, (hipStream_t)stream);
+}
+
+int kge_filter_lookup(const int64_t* sorted_keys, int64_t num_keys, const int64_t* starts, kge_index a,
+                      kge_index b, int64_t mult, int64_t n, int64_t* begin, int64_t* end, void* stream) {
+  if (n < 0 || num_keys < 0) return KGE_ERR_INVALID_ARG;
+  if (n > 0 && (!begin || !end || (num_keys > 0 && (!sorted_keys || !starts)))) return KGE_ERR_INVALID_ARG;
+  int rc;
+  if ((rc = check_index(a, false, n)) || (rc = check_index(b, false, n))) return rc;
+  return run_filter_lookup((const long long*)sorted_keys, num_keys, (const long long*)starts, make_index(a),
+                           make_index(b), mult, n, (long long*)begin, (long long*)end, (hipStream_t)stream);
+}
+
+int kge_rank_counts_multi(const float* scores, int64_t lds, int64_t n, int64_t c, const float* true_scores,
+                          int num_filters, const int64_t* const* lbl_begin, const int64_t* const* lbl_end,
+                          const int64_t* const* lbl_col, int64_t col_offset, const int64_t* true_col,
+                          float atol, float rtol, int64_t* rank, int64_t* ties, void* stream) {
+  if (n < 0 || c < 0 || lds < c || num_filters < 0) return KGE_ERR_INVALID_ARG;
+  if (num_filters > KGE_MAX_FILTERS) return KGE_ERR_UNSUPPORTED;
+  if (n * c > 0 && (!scores || !true_scores || !rank || !ties)) return KGE_ERR_INVALID_ARG;
+  if (num_filters > 0 && n > 0) {
+    if (!lbl_begin || !lbl_end || !lbl_col) return KGE_ERR_INVALID_ARG;
+    for (int k = 0; k < num_filters; ++k)
+      if (!lbl_begin[k] || !lbl_end[k] || !lbl_col[k]) return KGE_ERR_INVALID_ARG;
+  }
+  if (n > 65535) return KGE_ERR_UNSUPPORTED;
+  return run_rank_multi(scores, lds, n, c, true_scores, num_filters, (const long long* const*)lbl_begin,
+                        (const long long* const*)lbl_end, (const long long* const*)lbl_col, col_offset,
+                        (const long long*)true_col, atol, rtol, (long long*)rank, (long long*)ties,
+                        (hipStream_t)stream);
+}
+
+int kge_rank_hist(const int64_t* rank, const int64_t* ties, int num_rankings, int64_t n, int tie_policy,
+                  float* hist, int64_t ldh, int64_t num_ent, int64_t* ranks_out, void* stream) {
+  if (num_rankings < 0 || n < 0 || num_ent < 0 || ldh < num_ent) return KGE_ERR_INVALID_ARG;
+  if (tie_policy < KGE_TIES_ROUNDED_MEAN || tie_policy > KGE_TIES_WORST) return KGE_ERR_INVALID_ARG;
+  if ((int64_t)num_rankings * n > 0 && (!rank || !ties || !hist)) return KGE_ERR_INVALID_ARG;
+  return run_rank_hist((const long long*)rank, (const long long*)ties, num_rankings, n, tie_policy, hist, ldh,
+                       num_ent, (long long*)ranks_out, (hipStream_t)stream);
 }
 
 int64_t kge_score_bwd_workspace_bytes(const kge_tables* t, int64_t n, int64_t m) {

@@ -123,4 +123,180 @@ int run_rank(const float* scores, long long lds, long long n, long long c,
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
+// ---- evaluation without host round trips -------------------------------------
+// The reference builds, per batch, sparse label tensors from numba dict lookups on the host
+// (KvsAllIndex: kge/indexing.py:10-194; job/util.py:6-29; _collate: eval_entity_ranking.py:77-101),
+// densifies them per chunk (:489-531) and ranks raw / filtered / filtered-with-test in three
+// passes.  Here the index lives in HBM as sorted arrays; a batch needs
+//   filter_lookup_kernel   per-row binary search: key -> [begin, end) into the index's value array
+//   rank_multi_kernel      ONE scan of the scores for the raw counts + a sparse correction per
+//                          filter set: all rankings of a direction from one pass
+//   rank_hist_kernel       tie policy + rank histogram (:598-618, 665-687)
+// and no device -> host synchronisation.
+
+__global__ __launch_bounds__(256) void filter_lookup_kernel(const long long* __restrict__ keys, long long num_keys,
+                                                            const long long* __restrict__ starts, Index a,
+                                                            Index b, long long mult, long long n,
+                                                            long long* __restrict__ begin,
+                                                            long long* __restrict__ end) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long key = index_at(a, i) * mult + index_at(b, i);
+  long long lo = 0, hi = num_keys;  // first position with keys[pos] >= key
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (keys[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  const bool hit = lo < num_keys && keys[lo] == key;
+  begin[i] = hit ? starts[lo] : 0;
+  end[i] = hit ? starts[lo + 1] : 0;
+}
+
+constexpr int RK_MAXF = 4;
+struct RankFilters {
+  int K;
+  const long long* begin[RK_MAXF];  // [n] ranges into col[k]
+  const long long* end[RK_MAXF];
+  const long long* col[RK_MAXF];    // global entity ids, unique within a range
+};
+
+__device__ __forceinline__ void rk_block_sum(int& a, int& b, int* sa, int* sb) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  __syncthreads();  // previous use of sa / sb is over
+  if ((threadIdx.x & 63) == 0) {
+    sa[threadIdx.x >> 6] = a;
+    sb[threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  a = b = 0;
+#pragma unroll
+  for (int w = 0; w < RK_THREADS / 64; ++w) {
+    a += sa[w];
+    b += sb[w];
+  }
+}
+
+// rank / ties: [K + 1][n], row 0 = raw, row k + 1 = filter set k; ACCUMULATED
+__global__ __launch_bounds__(RK_THREADS) void rank_multi_kernel(
+    const float* __restrict__ scores, long long lds, long long n, long long c,
+    const float* __restrict__ true_scores, RankFilters F, long long col_offset,
+    const long long* __restrict__ true_col, float atol, float rtol, unsigned long long* __restrict__ rank,
+    unsigned long long* __restrict__ ties, long long cols_per_block) {
+  __shared__ int sg[RK_THREADS / 64], sc[RK_THREADS / 64];
+  const long long i = blockIdx.y;
+  const long long jb = (long long)blockIdx.x * cols_per_block;
+  long long je = jb + cols_per_block;
+  if (je > c) je = c;
+  float t = true_scores[i];
+  if (t != t) t = -__builtin_inff();
+  const float* row = scores + i * lds;
+  int gt = 0, cl = 0;
+  const uintptr_t addr = (uintptr_t)(row + jb);
+  long long head = ((16 - (addr & 15)) & 15) >> 2;
+  if (head > je - jb) head = je - jb;
+  if ((long long)threadIdx.x < head) count_one(row[jb + threadIdx.x], t, atol, rtol, gt, cl);
+  const long long j0 = jb + head;
+  const long long nvec = (je - j0) >> 2;
+  const f32x4* vrow = reinterpret_cast<const f32x4*>(row + j0);
+  for (long long v = threadIdx.x; v < nvec; v += RK_THREADS) {
+    f32x4 x = vrow[v];
+    count_one(x[0], t, atol, rtol, gt, cl);
+    count_one(x[1], t, atol, rtol, gt, cl);
+    count_one(x[2], t, atol, rtol, gt, cl);
+    count_one(x[3], t, atol, rtol, gt, cl);
+  }
+  const long long jt = j0 + (nvec << 2);
+  if (jt + (long long)threadIdx.x < je) count_one(row[jt + threadIdx.x], t, atol, rtol, gt, cl);
+  rk_block_sum(gt, cl, sg, sc);
+  const int G = gt, C = cl;  // raw counts of this block's columns (every thread)
+  if (threadIdx.x == 0) {
+    if (G != 0) atomicAdd(&rank[i], (unsigned long long)G);
+    if (C != 0) atomicAdd(&ties[i], (unsigned long long)C);
+  }
+  const long long tc = true_col ? true_col[i] : -1;
+  const int fc = is_close(-__builtin_inff(), t, atol, rtol) ? 1 : 0;
+  for (int k = 0; k < F.K; ++k) {
+    int dg = 0, dc = 0;  // a filtered column becomes -inf: take its raw contribution out, put -inf's in
+    const long long* lcol = F.col[k];
+    for (long long e = F.begin[k][i] + threadIdx.x; e < F.end[k][i]; e += RK_THREADS) {
+      const long long g = lcol[e];
+      if (true_col && g == tc) continue;  // the positive itself stays (:288-290)
+      const long long j = g - col_offset;
+      if (j < jb || j >= je) continue;
+      int rg = 0, rc = 0;
+      count_one(row[j], t, atol, rtol, rg, rc);
+      dg -= rg;
+      dc += fc - rc;
+    }
+    rk_block_sum(dg, dc, sg, sc);
+    if (threadIdx.x == 0) {
+      const long long Gk = (long long)G + dg, Ck = (long long)C + dc;
+      if (Gk != 0) atomicAdd(&rank[(k + 1) * n + i], (unsigned long long)Gk);
+      if (Ck != 0) atomicAdd(&ties[(k + 1) * n + i], (unsigned long long)Ck);
+    }
+  }
+}
+
+// hist[m][rank_of(rank[m][i], ties[m][i])] += 1 (float32 histogram, like the reference's)
+__global__ __launch_bounds__(256) void rank_hist_kernel(const long long* __restrict__ rank,
+                                                        const long long* __restrict__ ties, long long total,
+                                                        long long n, int policy, float* __restrict__ hist,
+                                                        long long ldh, long long num_ent,
+                                                        long long* __restrict__ ranks_out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const long long r0 = rank[t], ti = ties[t];
+  // EntityRankingJob._get_ranks (:598-618): 0 rounded_mean_rank, 1 best_rank, 2 worst_rank
+  const long long r = policy == 0 ? r0 + ti / 2 : (policy == 1 ? r0 : r0 + ti - 1);
+  if (ranks_out) ranks_out[t] = r;
+  if (r >= 0 && r < num_ent) unsafeAtomicAdd(hist + (t / n) * ldh + r, 1.0f);
+}
+
+int run_filter_lookup(const long long* keys, long long num_keys, const long long* starts, const Index& a,
+                      const Index& b, long long mult, long long n, long long* begin, long long* end,
+                      hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  hipLaunchKernelGGL(filter_lookup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, keys, num_keys,
+                     starts, a, b, mult, n, begin, end);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_rank_multi(const float* scores, long long lds, long long n, long long c, const float* true_scores,
+                   int K, const long long* const* begin, const long long* const* end,
+                   const long long* const* col, long long col_offset, const long long* true_col, float atol,
+                   float rtol, long long* rank, long long* ties, hipStream_t st) {
+  if (n == 0 || c == 0) return KGE_OK;
+  if (K < 0 || K > RK_MAXF) return KGE_ERR_UNSUPPORTED;
+  RankFilters F{};
+  F.K = K;
+  for (int k = 0; k < K; ++k) {
+    F.begin[k] = begin[k];
+    F.end[k] = end[k];
+    F.col[k] = col[k];
+  }
+  long long splits = (2048 + n - 1) / n;
+  long long cpb = (c + splits - 1) / splits;
+  if (cpb < 4096) cpb = 4096;
+  cpb = (cpb + 3) & ~3LL;
+  splits = (c + cpb - 1) / cpb;
+  hipLaunchKernelGGL(rank_multi_kernel, dim3((unsigned)splits, (unsigned)n), dim3(RK_THREADS), 0, st, scores, lds,
+                     n, c, true_scores, F, col_offset, true_col, atol, rtol, (unsigned long long*)rank,
+                     (unsigned long long*)ties, cpb);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_rank_hist(const long long* rank, const long long* ties, int M, long long n, int policy, float* hist,
+                  long long ldh, long long num_ent, long long* ranks_out, hipStream_t st) {
+  const long long total = (long long)M * n;
+  if (total == 0) return KGE_OK;
+  hipLaunchKernelGGL(rank_hist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rank, ties, total,
+                     n, policy, hist, ldh, num_ent, ranks_out);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
 }  // namespace kge

@@ -353,6 +353,57 @@ def rank_counts(scores, true_scores, lbl_rowptr=None, lbl_col=None, col_offset=0
     return rank, ties
 
 
+def filter_lookup(sorted_keys, starts, a, b, mult: int, begin, end):
+    """begin[i], end[i] = range of key a[i] * mult + b[i] in a device-resident filter index
+    (sorted unique int64 keys + starts[len(keys) + 1]); (0, 0) for unknown keys."""
+    dev = begin.device
+    keep = []
+    ai, bi = _index(a, dev, keep), _index(b, dev, keep)
+    n = keep[0].numel()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().kge_filter_lookup(
+            sorted_keys.data_ptr(), sorted_keys.numel(), starts.data_ptr(), ai, bi, int(mult), n,
+            begin.data_ptr(), end.data_ptr(), _stream(dev)), "kge_filter_lookup")
+    return begin, end
+
+
+def rank_counts_multi(scores, true_scores, filters, col_offset, true_col, atol, rtol, rank, ties):
+    """Raw + len(filters) filtered (rank, ties) counts from one scan of `scores` [n, c]:
+    filters = [(begin [n], end [n], col [nnz]), ...] int64 device tensors; rank / ties are
+    int64 [len(filters) + 1, n], accumulated."""
+    _require_gpu(scores, "scores")
+    if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
+        raise ValueError("kge_amd: scores must be float32 [n, c] with unit inner stride")
+    dev = scores.device
+    n, c = scores.shape
+    K = len(filters)
+    assert rank.shape == (K + 1, n) and ties.shape == (K + 1, n) and rank.is_contiguous() and ties.is_contiguous()
+    arr = ctypes.c_void_p * max(K, 1)
+    pb, pe, pc = (arr(*[f[j].data_ptr() for f in filters]) if K else None for j in range(3))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().kge_rank_counts_multi(
+            scores.data_ptr(), scores.stride(0) if n > 1 else max(c, 1), n, c, true_scores.data_ptr(), K,
+            pb, pe, pc, int(col_offset), None if true_col is None else true_col.data_ptr(), float(atol),
+            float(rtol), rank.data_ptr(), ties.data_ptr(), _stream(dev)), "kge_rank_counts_multi")
+    return rank, ties
+
+
+TIE_POLICIES = {"rounded_mean_rank": 0, "best_rank": 1, "worst_rank": 2}
+
+
+def rank_hist(rank, ties, tie_handling: str, hist, ranks_out=None):
+    """hist[m, rank_of(rank[m, i], ties[m, i])] += 1 (float32 [M, E]) for int64 [M, n] counts."""
+    if tie_handling not in TIE_POLICIES:
+        raise NotImplementedError(tie_handling)
+    M, n = rank.shape
+    with torch.cuda.device(rank.device):
+        _lib.check(_lib.lib().kge_rank_hist(
+            rank.data_ptr(), ties.data_ptr(), M, n, TIE_POLICIES[tie_handling], hist.data_ptr(), hist.stride(0),
+            hist.shape[1], None if ranks_out is None else ranks_out.data_ptr(), _stream(rank.device)),
+            "kge_rank_hist")
+    return hist
+
+
 # ---- backward twins (csrc/bwd.hip) ---------------------------------------------------------
 def _f32c(x, dev):
     return x.to(device=dev, dtype=torch.float32).contiguous()

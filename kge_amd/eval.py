@@ -6,10 +6,13 @@ What is kept from the reference and what is replaced:
     (:216-229), tie policy (:598-618), float32 rank histogram and MRR / Hits@k
     (:620-649, 665-687) -- same semantics, same names;
   * `_collate` + sparse label tensors + `_densify_chunk_of_labels` (:77-101, 179-181,
-    489-531) become ONE CSR of filtered entity ids per batch row (FilterIndex), built from
-    sorted (key, value) arrays instead of the numba KvsAllIndex dict (kge/indexing.py:10-194);
-  * `_filter_and_rank` / `_get_ranks_and_num_ties` (:533-596) become kge_rank_counts: one
-    streaming pass over the scores per ranking instead of ~10.
+    489-531) become ranges into a device-resident filter index (FilterIndex: sorted
+    (key, value) arrays instead of the numba KvsAllIndex dict, kge/indexing.py:10-194),
+    looked up per batch by kge_filter_lookup -- no host work, no host -> device copies;
+  * `_filter_and_rank` / `_get_ranks_and_num_ties` (:533-596), run once per ranking by the
+    reference, become ONE kge_rank_counts_multi scan per direction for raw + filtered +
+    filtered-with-test; `_get_ranks` + `hist_all` become kge_rank_hist.  The loop never waits
+    for the device (the reference's torch.unique / .item() calls do).
 
 Rankings follow the reference: "_raw", "_filt" (filter_splits + the eval split) and, if
 filter_with_test, "_filt_test" (additionally the test split).  Because the reference
@@ -118,66 +121,100 @@ class EntityRankingEvaluator:
         self.tie_handling, self.tie_atol, self.tie_rtol = tie_handling, tie_atol, tie_rtol
         self.hits_at_k_s = [k for k in hits_at_k_s if k <= min(num_entities, max(hits_at_k_s))]
 
+    def _device_state(self, dev):
+        """Everything the loop needs, resident on `dev` (built once): the eval triples, the filter
+        indexes as sorted arrays, per-batch scratch."""
+        st = getattr(self, "_dev_state", None)
+        if st is not None and st["dev"] == dev:
+            return st
+        idx = [self.index_filt] + ([self.index_filt_test] if self.filter_with_test else [])
+        K, bs = len(idx), self.batch_size
+        st = {
+            "dev": dev,
+            "triples": torch.from_numpy(np.ascontiguousarray(self.triples.astype(np.int64))).to(dev),
+            "sp": [tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in i._sp) for i in idx],
+            "po": [tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in i._po) for i in idx],
+            # [direction (o: sp-filters, s: po-filters)][filter][begin | end][row]
+            "ranges": torch.zeros(2, K, 2, bs, dtype=torch.int64, device=dev),
+            # [direction][rank | ties][ranking][row]
+            "counts": torch.zeros(2, 2, K + 1, bs, dtype=torch.int64, device=dev),
+        }
+        for k in range(K):  # an empty value array still needs an address
+            for side in ("sp", "po"):
+                uk, start, v = st[side][k]
+                if v.numel() == 0:
+                    st[side][k] = (uk, start, torch.zeros(1, dtype=torch.int64, device=dev))
+        self._dev_state = st
+        return st
+
     @torch.no_grad()
     def run(self, return_ranks: bool = False):
+        """No device -> host synchronisation inside the loop: the batch's filter ranges come from
+        kge_filter_lookup on the device-resident index, all rankings of a direction from one
+        kge_rank_counts_multi scan, tie policy + histogram from kge_rank_hist."""
         model = self.model
         tables = model.tables() if hasattr(model, "tables") else model
         dev = tables.device
-        E = self.E
+        E, R = self.E, self.R
         rankings = ["_raw", "_filt"] + (["_filt_test"] if self.filter_with_test else [])
-        hists = {r: torch.zeros(E, dtype=torch.float, device=dev) for r in rankings}
+        M = len(rankings)
+        st = self._device_state(dev)
+        hist = torch.zeros(M, E, dtype=torch.float, device=dev)
         all_ranks = {f"{d}{r}": [] for r in rankings for d in "so"}
         chunk = E if self.chunk_size < 0 else self.chunk_size
+        triples = st["triples"]
 
         for b0 in range(0, len(self.triples), self.batch_size):
-            batch_np = self.triples[b0:b0 + self.batch_size]
-            batch = torch.from_numpy(np.ascontiguousarray(batch_np)).to(dev)
+            batch = triples[b0:b0 + self.batch_size]
             s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
-            n = len(batch_np)
-            labels = {"_raw": None, "_filt": self.index_filt.labels(batch_np)}
-            if self.filter_with_test:
-                labels["_filt_test"] = self.index_filt_test.labels(batch_np)
-            labels = {k: (None if v is None else tuple(torch.from_numpy(x).to(dev) for x in v))
-                      for k, v in labels.items()}
+            sc_, oc_ = s.contiguous(), o.contiguous()  # true_col of the po / sp rankings
+            n = batch.shape[0]
+            rng = st["ranges"][:, :, :, :n].contiguous() if n != self.batch_size else st["ranges"]
+            cnt = st["counts"][:, :, :, :n].contiguous() if n != self.batch_size else st["counts"]
+            cnt.zero_()
+            filt_o, filt_s = [], []
+            for k in range(M - 1):
+                uk, start, v = st["sp"][k]
+                engine.filter_lookup(uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1])
+                filt_o.append((rng[0, k, 0], rng[0, k, 1], v))
+                uk, start, v = st["po"][k]
+                engine.filter_lookup(uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1])
+                filt_s.append((rng[1, k, 0], rng[1, k, 1], v))
 
-            # true scores through the subset path (:192-203)
-            unique_o, inv_o = torch.unique(o, return_inverse=True)
-            o_true = torch.gather(engine.score_sp(tables, s, p, unique_o), 1, inv_o.view(-1, 1)).view(-1)
-            unique_s, inv_s = torch.unique(s, return_inverse=True)
-            s_true = torch.gather(engine.score_po(tables, p, o, unique_s), 1, inv_s.view(-1, 1)).view(-1)
-
-            counts = {f"{d}{r}": [torch.zeros(n, dtype=torch.int64, device=dev),
-                                  torch.zeros(n, dtype=torch.int64, device=dev)]
-                      for r in rankings for d in "so"}
-            s64, o64 = s.long(), o.long()
+            o_true = s_true = None
+            if chunk < E:
+                # true scores through the subset path (:192-203), without torch.unique (a host
+                # sync): score every row against the batch's own targets, keep the diagonal --
+                # each score is its own chain, so the bits do not depend on the subset
+                o_true = engine.score_sp(tables, s, p, o).diagonal().contiguous()
+                s_true = engine.score_po(tables, p, o, s).diagonal().contiguous()
             for start in range(0, E, chunk):
                 end = min(start + chunk, E)
                 sub = None if (start == 0 and end == E) else torch.arange(start, end, device=dev)
                 scores = engine.score_sp_po(tables, s, p, o, sub)
                 c = end - start
                 sc_sp, sc_po = scores[:, :c], scores[:, c:]
-                for r in rankings:
-                    lab = labels[r]
-                    sp_rp, sp_col, po_rp, po_col = lab if lab is not None else (None,) * 4
-                    engine.rank_counts(sc_sp, o_true, sp_rp, sp_col, start, o64, self.tie_atol,
-                                       self.tie_rtol, *counts["o" + r])
-                    engine.rank_counts(sc_po, s_true, po_rp, po_col, start, s64, self.tie_atol,
-                                       self.tie_rtol, *counts["s" + r])
-            for r in rankings:
-                s_ranks = get_ranks(*counts["s" + r], self.tie_handling)
-                o_ranks = get_ranks(*counts["o" + r], self.tie_handling)
-                # hist_all (:665-687)
-                for ranks in (o_ranks, s_ranks):
-                    u, cnt = torch.unique(ranks, return_counts=True)
-                    hists[r].index_add_(0, u, cnt.float())
-                if return_ranks:
-                    all_ranks["s" + r].append(s_ranks)
-                    all_ranks["o" + r].append(o_ranks)
+                if o_true is None:  # unchunked: the true scores are elements of the matrix
+                    o_true = sc_sp.gather(1, oc_.view(-1, 1)).view(-1)
+                    s_true = sc_po.gather(1, sc_.view(-1, 1)).view(-1)
+                engine.rank_counts_multi(sc_sp, o_true, filt_o, start, oc_, self.tie_atol, self.tie_rtol,
+                                         cnt[0, 0], cnt[0, 1])
+                engine.rank_counts_multi(sc_po, s_true, filt_s, start, sc_, self.tie_atol, self.tie_rtol,
+                                         cnt[1, 0], cnt[1, 1])
+            # hist_all (:665-687): object ranks and subject ranks into the same histograms
+            ro = torch.empty(M, n, dtype=torch.int64, device=dev) if return_ranks else None
+            rs = torch.empty(M, n, dtype=torch.int64, device=dev) if return_ranks else None
+            engine.rank_hist(cnt[0, 0], cnt[0, 1], self.tie_handling, hist, ro)
+            engine.rank_hist(cnt[1, 0], cnt[1, 1], self.tie_handling, hist, rs)
+            if return_ranks:
+                for m_, r in enumerate(rankings):
+                    all_ranks["o" + r].append(ro[m_])
+                    all_ranks["s" + r].append(rs[m_])
 
         suffix = {"_raw": "", "_filt": "_filtered", "_filt_test": "_filtered_with_test"}
         metrics = {}
-        for r in rankings:
-            metrics.update(compute_metrics(hists[r], self.hits_at_k_s, suffix[r]))
+        for m_, r in enumerate(rankings):
+            metrics.update(compute_metrics(hist[m_], self.hits_at_k_s, suffix[r]))
         if return_ranks:
             return metrics, {k: torch.cat(v).cpu().numpy() if v else np.zeros(0, np.int64)
                              for k, v in all_ranks.items()}
