@@ -412,6 +412,75 @@ def test_rank_counts_random_vs_oracle_and_torch(eng, n, c, lds_pad):
     _eq("torch ties", _np(t), _np(close.sum(1)))
 
 
+@pytest.mark.parametrize("n,c", [(1, 1), (7, 1000), (33, 14541), (5, 70001)])
+def test_filter_lookup_multi_ranking_and_histogram_vs_oracle(eng, n, c):
+    """The sync-free evaluation entries against the oracle: kge_filter_lookup on a device-resident
+    sorted index (known and unknown keys), kge_rank_counts_multi (raw + two filter sets from one
+    scan, accumulated over two column chunks) against one oracle rank_counts per ranking, and
+    kge_rank_hist for the three tie policies against numpy.  Integer work: exact."""
+    rng = np.random.default_rng(n * 7 + c)
+    sc = (rng.standard_normal((n, c)) * 3).astype(np.float32)
+    tcol = rng.integers(0, c, n)
+    true = sc[np.arange(n), tcol].copy()
+    for i in range(n):
+        sc[i, rng.integers(0, c, 5)] = true[i] + np.float32(rng.choice([0, 1e-6, -1e-6, 2e-4, 1e-5]))
+    sc[0, 0] = np.nan
+    # an index over keys a * mult + b with a few values each; queries: known keys + one unknown
+    mult = 50
+    a, b = rng.integers(0, 40, n), rng.integers(0, mult, n)
+    a[-1], b[-1] = 45, 3                     # never inserted
+    qkeys = a * mult + b
+    filters_np = []
+    for f in range(2):
+        keys = np.unique(np.concatenate([qkeys[:-1], rng.integers(0, 40 * mult, 30)]))
+        starts, vals = [0], []
+        for k in keys:
+            v = np.unique(rng.integers(0, c, min(c, 10 + 20 * f)))
+            hit = np.nonzero(qkeys == k)[0]
+            if len(hit) and f == 0:          # the positive is among the known answers
+                v = np.unique(np.append(v, tcol[hit[0]]))
+            vals.extend(v.tolist())
+            starts.append(len(vals))
+        filters_np.append((keys.astype(np.int64), np.array(starts, np.int64), np.array(vals, np.int64)))
+    filters, csrs = [], []
+    for keys, starts, vals in filters_np:
+        beg, end = torch.zeros(n, dtype=torch.int64, device=DEV), torch.zeros(n, dtype=torch.int64, device=DEV)
+        eng.filter_lookup(_t(keys), _t(starts), _t(a), _t(b), mult, beg, end)
+        pos = np.searchsorted(keys, qkeys)
+        hit = (pos < len(keys)) & (keys[np.minimum(pos, len(keys) - 1)] == qkeys)
+        wb = np.where(hit, starts[np.minimum(pos, len(keys) - 1)], 0)
+        we = np.where(hit, starts[np.minimum(pos, len(keys) - 1) + 1], 0)
+        _eq("begin", _np(beg), wb)
+        _eq("end", _np(end), we)
+        assert wb[-1] == 0 and we[-1] == 0
+        filters.append((beg, end, _t(vals)))
+        rp = np.concatenate([[0], np.cumsum(we - wb)])
+        col = np.concatenate([vals[x:y] for x, y in zip(wb, we)] + [np.zeros(0, np.int64)])
+        csrs.append((rp.astype(np.int64), col.astype(np.int64)))
+    rank = torch.zeros(3, n, dtype=torch.int64, device=DEV)
+    ties = torch.zeros(3, n, dtype=torch.int64, device=DEV)
+    tsc, half = _t(sc), max(1, c // 2)
+    for lo, hi in ((0, half), (half, c)):
+        if hi > lo:
+            eng.rank_counts_multi(tsc[:, lo:hi], _t(true), filters, lo, _t(tcol), 1e-5, 1e-4, rank, ties)
+    want = [ko.rank_counts(sc, true)] + [ko.rank_counts(sc, true, lbl_rowptr=rp, lbl_col=col, col_offset=0,
+                                                        true_col=tcol) for rp, col in csrs]
+    for k in range(3):
+        _eq(f"rank[{k}]", _np(rank[k]), want[k][0])
+        _eq(f"ties[{k}]", _np(ties[k]), want[k][1])
+    for policy in ("rounded_mean_rank", "best_rank", "worst_rank"):
+        hist = torch.zeros(3, c, device=DEV)
+        out = torch.empty(3, n, dtype=torch.int64, device=DEV)
+        eng.rank_hist(rank, ties, policy, hist, out)
+        r, t = _np(rank), _np(ties)
+        wr = {"rounded_mean_rank": r + t // 2, "best_rank": r, "worst_rank": r + t - 1}[policy]
+        _eq(policy, _np(out), wr)
+        wh = np.zeros((3, c), np.float32)
+        for k in range(3):
+            np.add.at(wh[k], wr[k][(wr[k] >= 0) & (wr[k] < c)], 1.0)
+        _eq(policy + " hist", _np(hist), wh)
+
+
 def test_duplicates_zero_rows_and_non_finite_values(eng):
     """Collisions and degenerate values: repeated query indices, repeated ids in the listed
     subset, an all-zero entity row, infinities and NaNs in the tables.  f32-arithmetic paths
