@@ -276,6 +276,24 @@ int kge_ce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index
                float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes,
                void* stream);
 
+/* KvsAll variant: KL divergence of softmax(score(i, .)) from the row's normalised multi-hot
+ * labels, lbl_col[lbl_rowptr[i] .. lbl_rowptr[i+1]) (int64 CSR on the device, entity ids unique
+ * per row), y_ij = 1/k_i:
+ *   loss_rows[i] = lse[i] - (1/k_i) sum_{j in labels_i} score(i, j) - log k_i     (0 if k_i = 0)
+ * = KLDivWithSoftmaxKgeLoss with a label matrix, no label smoothing (kge/util/loss.py:208-213),
+ * as TrainingJobKvsAll computes it for sp_ / _po queries (kge/job/train_KvsAll.py:244-294).
+ * The label scores use the same operands as the matrix-core kernel (query vector rounded to
+ * bf16, exact products, f32 accumulation) in a different f32 summation order.  kge_kl_bwd:
+ * gradients of sum_i g_i * loss_rows[i], outputs as kge_ce_bwd.  Same support matrix and
+ * workspace as kge_ce_fwd / kge_ce_bwd. */
+int kge_kl_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+               const int64_t* lbl_rowptr, const int64_t* lbl_col, float* loss_rows, float* lse,
+               void* workspace, int64_t workspace_bytes, void* stream);
+int kge_kl_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+               const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* lse,
+               const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt,
+               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- backward (autograd twins) ------------------------------------------ */
 /* All gradients are f32 and OVERWRITTEN; tables/embeddings must be f32, except
  * kge_score_pairs_bwd for ComplEx/DistMult, which also takes bf16 tables (mixed-precision

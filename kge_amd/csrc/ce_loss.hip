@@ -57,6 +57,97 @@ __global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict
   }
 }
 
+// ---- KvsAll: KL divergence against the normalised multi-hot labels of a row -------------------
+// KLDivWithSoftmaxKgeLoss with a label matrix (kge/util/loss.py:208-213; train_KvsAll.py:274-294,
+// no label smoothing): y_ij = 1/k_i on the k_i labels P_i of row i, so
+//   loss_i = sum_j y_ij (log y_ij - log softmax_ij) = lse_i - (1/k_i) sum_{j in P_i} score(i,j) - log k_i
+//   d loss_i / d score(i,j) = softmax_ij - y_ij
+// (a row without labels has y = 0: loss 0, gradient 0).  lse_i comes from the V3_LSE kernel; the
+// few label scores are evaluated here (one wave per row: q_i in registers, bf16-rounded like the
+// matrix-core kernel's fragments, exact bf16 products, f32 accumulation in lane-partial +
+// butterfly order -- equal to the kernel's scores up to f32 summation order); the backward
+// subtracts g_i y_ij from the softmax gradient the V3_DS kernel wrote.
+template <int SCORER>
+__global__ __launch_bounds__(256) void kl_label_kernel(Operand A, Operand R, Operand TG, int dir, int d,
+                                                       long long n, const long long* __restrict__ rowptr,
+                                                       const long long* __restrict__ col,
+                                                       float* __restrict__ label_sum) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int hp = d / 4;  // packed pairs (two bf16 per dword) per half
+  const unsigned int* a = (const unsigned int*)((const unsigned short*)A.base + index_at(A.idx, i) * A.ld);
+  const unsigned int* r = (const unsigned int*)((const unsigned short*)R.base + index_at(R.idx, i) * R.ld);
+  unsigned int q0[2] = {0u, 0u}, q1[2] = {0u, 0u};  // d <= 512: at most 2 pairs per lane and half
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = lane + 64 * u;
+    if (c < hp) bf16_qpair<SCORER>(dir, a[c], a[hp + c], r[c], r[hp + c], q0[u], q1[u]);
+  }
+  float tsum = 0.0f;
+  for (long long e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    const unsigned int* t = (const unsigned int*)((const unsigned short*)TG.base + col[e] * TG.ld);
+    float acc = 0.0f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = lane + 64 * u;
+      if (c < hp) {
+        const unsigned int t0 = t[c], t1 = t[hp + c];
+        acc = __builtin_fmaf(__uint_as_float(q0[u] << 16), __uint_as_float(t0 << 16), acc);
+        acc = __builtin_fmaf(__uint_as_float(q0[u] & 0xffff0000u), __uint_as_float(t0 & 0xffff0000u), acc);
+        acc = __builtin_fmaf(__uint_as_float(q1[u] << 16), __uint_as_float(t1 << 16), acc);
+        acc = __builtin_fmaf(__uint_as_float(q1[u] & 0xffff0000u), __uint_as_float(t1 & 0xffff0000u), acc);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    tsum += acc;
+  }
+  if (lane == 0) label_sum[i] = tsum;
+}
+
+__global__ __launch_bounds__(256) void kl_combine_kernel(const float* __restrict__ part, int ncg, long long n,
+                                                         const float* __restrict__ label_sum,
+                                                         const long long* __restrict__ rowptr,
+                                                         float* __restrict__ loss_rows, float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* p = part + i * ncg * 2;
+  float M = -__builtin_inff();
+  for (int c = lane; c < ncg; c += 64) M = fmaxf(M, p[2 * c]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+  float L = 0.0f;
+  for (int c = lane; c < ncg; c += 64) L += p[2 * c + 1] * expf(p[2 * c] - M);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) L += __shfl_xor(L, off, 64);
+  if (lane == 0) {
+    const float z = M + logf(L);
+    const long long k = rowptr[i + 1] - rowptr[i];
+    lse[i] = z;
+    loss_rows[i] = k > 0 ? z - label_sum[i] / (float)k - logf((float)k) : 0.0f;
+  }
+}
+
+// G16[i, j] -= g_i / k_i for the labels j of row i (bf16 read-modify-write; labels unique per row)
+__global__ __launch_bounds__(256) void kl_sub_kernel(unsigned short* __restrict__ g16, long long ld16, long long n,
+                                                     const long long* __restrict__ rowptr,
+                                                     const long long* __restrict__ col,
+                                                     const float* __restrict__ g_rows, float g_scalar) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const long long b = rowptr[i], e = rowptr[i + 1];
+  if (e <= b) return;
+  const float y = (g_rows != nullptr ? g_rows[i] : g_scalar) / (float)(e - b);
+  for (long long x = b + lane; x < e; x += 64) {
+    unsigned short* p = g16 + i * ld16 + col[x];
+    const float v = __uint_as_float((unsigned int)*p << 16) - y;
+    *p = (unsigned short)(bf16_pack(v, 0.0f) & 0xffffu);
+  }
+}
+
 // tools/ce_phases.py: per-workgroup s_memtime stamps of the next fused-loss launches (not part of the ABI)
 static unsigned long long* g_ce_stamps = nullptr;
 
@@ -112,6 +203,53 @@ int run_ce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(n * ld16 * 2));
   const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
+  return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
+}
+
+int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+               long long m, const long long* rowptr, const long long* col, float* loss_rows, float* lse, void* ws,
+               long long ws_bytes, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const int ncg = pairs_bf16_v3_column_groups(n, m);
+  CeArgs ce{};
+  ce.part = (float*)((char*)ws + coop);
+  ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));  // here: the rows' label-score sums
+  const int rc = run_pairs_bf16_v3_ce(scorer, V3_LSE, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  if (rc != KGE_OK) return rc;
+  const dim3 grid((unsigned)((n + 3) / 4));
+  if (scorer == KGE_COMPLEX)
+    hipLaunchKernelGGL(kl_label_kernel<KGE_COMPLEX>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
+                       ce.true_score);
+  else
+    hipLaunchKernelGGL(kl_label_kernel<KGE_DISTMULT>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
+                       ce.true_score);
+  hipLaunchKernelGGL(kl_combine_kernel, grid, dim3(256), 0, st, ce.part, ncg, n, ce.true_score, rowptr, loss_rows,
+                     lse);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+               long long m, const long long* rowptr, const long long* col, const float* lse, const float* g_rows,
+               float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const long long ld16 = ce_ld16(m);
+  CeArgs ce{};
+  ce.rowptr = rowptr;
+  ce.lse = lse;
+  ce.g_rows = g_rows;
+  ce.g_scalar = g_scalar;
+  ce.g16 = (unsigned short*)((char*)ws + coop);
+  ce.ld16 = ld16;
+  unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(n * ld16 * 2));
+  const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  if (rc != KGE_OK) return rc;
+  hipLaunchKernelGGL(kl_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.g16, ld16, n, rowptr, col,
+                     g_rows, g_scalar);
+  if (hipGetLastError() != hipSuccess) return KGE_ERR_LAUNCH;
   return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
 }
 

@@ -286,7 +286,9 @@ constexpr int V3_STORE = 0, V3_LSE = 1, V3_DS = 2;
 constexpr float V3_LOG2E = 1.44269504088896340736f;
 
 struct CeArgs {
-  Index label;              // [n] entity ids (the true target of row i)
+  Index label;              // [n] entity ids (the true target of row i); ptr == NULL: no single label
+  const long long* rowptr;  // multi-label loss (kge_kl_*): [n + 1] label CSR; rows without labels get
+                            // a zero gradient (V3_DS); NULL otherwise
   float* part;              // V3_LSE: [n][ncg][2] per-column-group (max, sum exp)
   float* true_score;        // V3_LSE: [n] score(i, label_i)
   const float* lse;         // V3_DS: [n] logsumexp of row i

@@ -289,10 +289,11 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   bool tfound = false;
   float lse_i = 0.0f, g_i = 0.0f; // V3_DS
   if constexpr (EPI != V3_STORE) {
-    lab = index_at(ce.label, orow);
+    if (ce.label.ptr != nullptr) lab = index_at(ce.label, orow);
     if constexpr (EPI == V3_DS) {
       lse_i = ce.lse[orow];
       g_i = ce.g_rows != nullptr ? ce.g_rows[orow] : ce.g_scalar;
+      if (ce.rowptr != nullptr && ce.rowptr[orow + 1] == ce.rowptr[orow]) g_i = 0.0f;
     }
   }
   // accumulator element r of half hf is column  col0(tile) + 32 hf + 8 (r >> 2) + 4 fh + (r & 3)
@@ -544,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
         pp[0] = M;
         pp[1] = L;
       }
-      if (tfound) ce.true_score[row] = tsc;
+      if (tfound) ce.true_score[row] = tsc;  // (never with ce.label.ptr == NULL: lab stays -1)
     }
   } else if constexpr (EPI == V3_DS) {
 #pragma unroll

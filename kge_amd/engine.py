@@ -540,6 +540,53 @@ def ce_bwd(t: Tables, direction: str, a, p, label, lse, g_rows=None, g_scalar: f
     return g_a, g_p, g_t
 
 
+def _csr64(rowptr, col, dev):
+    rp = rowptr.to(device=dev, dtype=torch.int64).contiguous()
+    cl = col.to(device=dev, dtype=torch.int64).contiguous()
+    if cl.numel() == 0:
+        cl = torch.zeros(1, dtype=torch.int64, device=dev)
+    return rp, cl
+
+
+def kl_fwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col):
+    """KvsAll: fused score_sp / score_po + KL divergence from the rows' normalised multi-hot
+    labels (int64 CSR): (loss_rows [n], lse [n]); kge/util/loss.py:208-213 without smoothing."""
+    keep = []
+    ai, pi = (_index(x, t.device, keep) for x in (a, p))
+    n = keep[0].numel()
+    rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
+    loss_rows, lse = _empty((n,), t.device), _empty((n,), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_kl_fwd(ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, n,
+                                         rp.data_ptr(), cl.data_ptr(), loss_rows.data_ptr(), lse.data_ptr(),
+                                         ws, wsb, st), "kge_kl_fwd")
+    return loss_rows, lse
+
+
+def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=None, g_scalar: float = 1.0):
+    """Backward of kl_fwd: (g_a [n, d], g_p [n, d], g_entities [E, d])."""
+    keep = []
+    ai, pi = (_index(x, t.device, keep) for x in (a, p))
+    n = keep[0].numel()
+    rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    lse = _f32c(lse, t.device)
+    gr = None if g_rows is None else _f32c(g_rows, t.device)
+    g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((t.num_ent, d), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_kl_bwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, n, rp.data_ptr(), cl.data_ptr(),
+            lse.data_ptr(), None if gr is None else gr.data_ptr(), float(g_scalar), g_a.data_ptr(),
+            g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_kl_bwd")
+    return g_a, g_p, g_t
+
+
 def score_emb_bwd(scorer, s_emb, p_emb, o_emb, combine: str, l_norm, gout, scores=None):
     """Backward of score_emb: gradients w.r.t. (s_emb, p_emb, o_emb)."""
     code = {"spo": SPO, "sp_": SP_, "_po": PO_}[combine]

@@ -214,6 +214,34 @@ class KgeModel(torch.nn.Module):
             return _FusedCE.apply("po", self._entity_embedder.weight, self._relation_embedder.weight, o, p, s, t)
         return torch.nn.functional.cross_entropy(self.score_po(p, o), s.long(), reduction="none")
 
+    # -- KvsAll loss: train_KvsAll.py:274-294 with train.loss=kl, no label smoothing
+    @staticmethod
+    def _kl_composed(scores: Tensor, rowptr: Tensor, col: Tensor) -> Tensor:
+        """loss.py:208-213 row by row: KLDivLoss(log_softmax(scores), normalize(labels, p=1))."""
+        n = scores.shape[0]
+        cnt = (rowptr[1:] - rowptr[:-1]).to(scores.device)
+        rows = torch.repeat_interleave(torch.arange(n, device=scores.device), cnt)
+        labels = torch.zeros_like(scores)
+        labels[rows, col.to(scores.device).long()] = 1.0
+        y = torch.nn.functional.normalize(labels, p=1, dim=1)
+        return torch.nn.functional.kl_div(torch.log_softmax(scores, dim=1), y, reduction="none").sum(dim=1)
+
+    def kl_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
+        """Per-row KL divergence of softmax(score_sp(s, p)) from the normalised multi-hot labels
+        given as an int64 CSR over the rows (the known objects of each (s, p) query)."""
+        t = self._ce_tables()
+        if t is not None:
+            return _FusedKL.apply("sp", self._entity_embedder.weight, self._relation_embedder.weight, s, p,
+                                  lbl_rowptr, lbl_col, t)
+        return self._kl_composed(self.score_sp(s, p), lbl_rowptr, lbl_col)
+
+    def kl_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
+        t = self._ce_tables()
+        if t is not None:
+            return _FusedKL.apply("po", self._entity_embedder.weight, self._relation_embedder.weight, o, p,
+                                  lbl_rowptr, lbl_col, t)
+        return self._kl_composed(self.score_po(p, o), lbl_rowptr, lbl_col)
+
     def score_so(self, s: Tensor, o: Tensor, p: Tensor = None) -> Tensor:
         se, oe = self._entity_embedder.embed(s), self._entity_embedder.embed(o)
         pe = self._relation_embedder.embed_all() if p is None else self._relation_embedder.embed(p)
@@ -360,6 +388,29 @@ class _FusedCE(torch.autograd.Function):
         _scatter_rows(gr, p, g_p)
         _scatter_rows(ge, a, g_a)  # ge [E, d] is fresh: the dense target gradient + the query rows
         return None, ge, gr, None, None, None, None
+
+
+class _FusedKL(torch.autograd.Function):
+    """Per-row KvsAll KL loss fused with the sp_/_po scoring (kge_kl_fwd / kge_kl_bwd); labels as an
+    int64 CSR (rowptr [n + 1], col [nnz]) of the rows' known answers."""
+
+    @staticmethod
+    def forward(ctx, direction, ent, rel, a, p, rowptr, col, tables16):
+        loss_rows, lse = engine.kl_fwd(tables16, direction, a, p, rowptr, col)
+        ctx.t16, ctx.direction, ctx.idx = tables16, direction, (a, p, rowptr, col)
+        ctx.rel_shape = rel.shape
+        ctx.save_for_backward(lse)
+        return loss_rows
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        a, p, rowptr, col = ctx.idx
+        (lse,) = ctx.saved_tensors
+        g_a, g_p, ge = engine.kl_bwd(ctx.t16, ctx.direction, a, p, rowptr, col, lse, g_rows=g_rows.contiguous())
+        gr = torch.zeros(ctx.rel_shape, dtype=torch.float32, device=ge.device)
+        _scatter_rows(gr, p, g_p)
+        _scatter_rows(ge, a, g_a)
+        return None, ge, gr, None, None, None, None, None
 
 
 class _ScoreEmb(torch.autograd.Function):

@@ -194,7 +194,7 @@ def test_model_level_fused_loss_against_composed_loss(name):
         lc = composed() / n
         lc.backward()
         gc = [x.grad.clone() for x in m.parameters()]
-        assert abs(float(lf) - float(lc)) <= 1e-5 * max(1.0, abs(float(lc))), (float(lf), float(lc))
+        assert abs(float(lf.detach()) - float(lc.detach())) <= 1e-5 * max(1.0, abs(float(lc.detach())))
         for a, b in zip(gf, gc):
             assert a.dtype == b.dtype and a.shape == b.shape
             rel_err = float((a - b).norm() / b.norm())
@@ -205,3 +205,106 @@ def test_model_level_fused_loss_against_composed_loss(name):
     rows = m32.loss_sp(s, p, o)
     want = torch.nn.functional.cross_entropy(m32.score_sp(s, p), o, reduction="none")
     assert torch.equal(rows, want)
+
+
+# ---- KvsAll: KL divergence from normalised multi-hot labels (kge_kl_fwd / kge_kl_bwd) --------------
+def _kl_case(seed, model, d, E, R, n, scale):
+    ent, rel, s, p, o = _case(seed, model, d, E, R, n, scale)
+    rng = np.random.default_rng(seed + 1)
+    cnt = rng.integers(1, 8, n)
+    cnt[rng.integers(0, n)] = min(E, 70)          # one row with many labels
+    if n > 2:
+        cnt[1] = 0                                # one row without labels: loss 0, gradient 0
+    col = np.concatenate([np.sort(rng.choice(E, c, replace=False)) for c in cnt] + [np.zeros(0, np.int64)])
+    rowptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    return ent, rel, s, p, o, rowptr, col.astype(np.int64)
+
+
+def _kl64(scores, rowptr, col):
+    x = np.asarray(scores, dtype=np.float64)
+    mx = x.max(axis=1)
+    lse = mx + np.log(np.exp(x - mx[:, None]).sum(axis=1))
+    loss = np.zeros(len(x))
+    for i in range(len(x)):
+        js = col[rowptr[i]:rowptr[i + 1]]
+        if len(js):
+            loss[i] = lse[i] - x[i, js].mean() - np.log(len(js))
+    return loss, lse
+
+
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5])
+def test_kl_fwd_bwd(eng, model, d, E, R, n, scale):
+    """Forward against float64 KL of the written scores (the label scores are re-evaluated in a
+    different f32 summation order: + 2e-6 * max|score| per row on top of the CE tolerance) and
+    against torch's KLDivLoss(log_softmax, normalize(labels)); backward against float64 autograd of
+    that composition (<= 1e-2, bf16 operands) -- the checks of test_ce_bwd, multi-label."""
+    ent, rel, s, p, o, rowptr, col = _kl_case(5 * d + n, model, d, E, R, n, scale)
+    T = _tables(eng, model, ent, rel)
+    trp, tcl = _t(rowptr), _t(col)
+    rng = np.random.default_rng(2)
+    g_rows = (rng.random(n).astype(np.float32) + 0.5) / n
+    for direction, a in (("sp", s), ("po", o)):
+        ta, tp = _t(a), _t(p)
+        loss, lse = eng.kl_fwd(T, direction, ta, tp, trp, tcl)
+        sc = (eng.score_sp(T, ta, tp) if direction == "sp" else eng.score_po(T, tp, ta)).cpu().numpy()
+        want, want_lse = _kl64(sc, rowptr, col)
+        got = loss.cpu().numpy().astype(np.float64)
+        tol = 1e-5 + 1e-5 * np.abs(want_lse) + 2e-6 * np.abs(sc).max(axis=1)
+        assert (np.abs(got - want) <= tol).all(), (direction, float(np.abs(got - want).max()))
+        assert (np.abs(lse.cpu().numpy() - want_lse) <= 1e-5 + 1e-5 * np.abs(want_lse)).all()
+        if n > 2:
+            assert got[1] == 0.0
+        # torch's own composition on the written scores (loss.py:208-213)
+        tsc = torch.from_numpy(sc).double()
+        lab = torch.zeros_like(tsc)
+        rows = np.repeat(np.arange(n), np.diff(rowptr))
+        lab[torch.from_numpy(rows), torch.from_numpy(col)] = 1.0
+        ref = torch.nn.functional.kl_div(torch.log_softmax(tsc, 1), torch.nn.functional.normalize(lab, p=1, dim=1),
+                                         reduction="none").sum(1).numpy()
+        assert (np.abs(got - ref) <= tol).all(), (direction, float(np.abs(got - ref).max()))
+        # backward
+        g_a, g_p, g_t = eng.kl_bwd(T, direction, ta, tp, trp, tcl, lse, g_rows=_t(g_rows))
+        ge = g_t.clone()
+        ge.index_add_(0, ta, g_a)
+        gr = torch.zeros(R, d, device=DEV).index_add_(0, tp, g_p)
+        e = T.ent.cpu().double().requires_grad_(True)
+        r = T.rel.cpu().double().requires_grad_(True)
+        ea, rp_ = e[torch.from_numpy(a)], r[torch.from_numpy(p)]
+        h = d // 2
+        if model == "distmult":
+            q = ea * rp_
+        elif direction == "sp":
+            q = torch.cat([ea[:, :h] * rp_[:, :h] - ea[:, h:] * rp_[:, h:], ea[:, :h] * rp_[:, h:] + ea[:, h:] * rp_[:, :h]], 1)
+        else:
+            q = torch.cat([ea[:, :h] * rp_[:, :h] + ea[:, h:] * rp_[:, h:], ea[:, h:] * rp_[:, :h] - ea[:, :h] * rp_[:, h:]], 1)
+        s64 = q @ e.t()
+        l64 = torch.nn.functional.kl_div(torch.log_softmax(s64, 1), torch.nn.functional.normalize(lab, p=1, dim=1),
+                                         reduction="none").sum(1)
+        (l64 * torch.from_numpy(g_rows).double()).sum().backward()
+        for nm, gotg, wantg in (("ent", ge, e.grad), ("rel", gr, r.grad)):
+            rel_err = float((gotg.cpu().double() - wantg).norm() / wantg.norm())
+            assert rel_err <= 1e-2, (direction, nm, rel_err)
+        if n > 2:  # the row without labels contributes nothing
+            assert float(g_p[1].abs().max()) == 0.0 and float(g_a[1].abs().max()) == 0.0
+
+
+def test_model_level_kl_loss_against_composed():
+    from kge_amd import model as km
+    E, R, d, n = 2000 + 3, 7, 256, 150
+    torch.manual_seed(0)
+    m = km.create("distmult", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    ent, rel, s, p, o, rowptr, col = _kl_case(9, "distmult", d, E, R, n, 0.3)
+    ts, tp, to, trp, tcl = _t(s), _t(p), _t(o), _t(rowptr), _t(col)
+    for fused, composed in ((lambda: m.kl_loss_sp(ts, tp, trp, tcl), lambda: m._kl_composed(m.score_sp(ts, tp), trp, tcl)),
+                            (lambda: m.kl_loss_po(tp, to, trp, tcl), lambda: m._kl_composed(m.score_po(tp, to), trp, tcl))):
+        m.zero_grad()
+        lf = fused().sum() / n
+        lf.backward()
+        gf = [x.grad.clone() for x in m.parameters()]
+        m.zero_grad()
+        lc = composed().sum() / n
+        lc.backward()
+        gc = [x.grad.clone() for x in m.parameters()]
+        assert abs(float(lf.detach()) - float(lc.detach())) <= 2e-5 * max(1.0, abs(float(lc.detach())))
+        for a_, b_ in zip(gf, gc):
+            assert float((a_ - b_).norm() / b_.norm()) <= 2e-3
