@@ -5,7 +5,7 @@ Usage inside an unmodified LibKGE installation (config-default.yaml:137, README.
     modules: [kge.job, kge.model, kge.model.embedder, kge_amd.libkge_plugin]
     model: hip_complex            # or hip_distmult / hip_transe / hip_rotate
     # optional: eval.type: hip_entity_ranking
-    # optional: train.type: hip_1vsAll  (kl loss fused into the scoring kernel)
+    # optional: train.type: hip_1vsAll / hip_KvsAll  (kl loss fused into the scoring kernel)
 
 `Config._import("hip_complex")` finds hip_complex.yaml in this package (config.py:280-325)
 and `init_from(class_name, modules)` (misc.py:13-42) resolves the classes below.  They
@@ -25,4 +25,4 @@ except ImportError as e:  # pragma: no cover
 from .models import (HipComplEx, HipComplExScorer, HipDistMult, HipDistMultScorer,  # noqa: F401
                      HipRotatE, HipRotatEScorer, HipTransE, HipTransEScorer)
 from .eval_job import HipEntityRankingJob  # noqa: F401
-from .train_job import HipTrainingJob1vsAll  # noqa: F401
+from .train_job import HipTrainingJob1vsAll, HipTrainingJobKvsAll  # noqa: F401

@@ -8,7 +8,7 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import BF16Shadow, _FusedCE, _ScoreEmb, _ScorePairs, _ScoreSPO
+from ..model import BF16Shadow, _FusedCE, _FusedKL, _ScoreEmb, _ScorePairs, _ScoreSPO
 
 
 class _HipScorer(RelationalScorer):
@@ -120,6 +120,22 @@ class _FusedScoring:
             return None
         ent, rel = self._w()
         return _FusedCE.apply("po", ent, rel, o, p, s, t)
+
+    def kl_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
+        """[n] KL divergence of softmax(score_sp(s, p)) from the rows' normalised multi-hot labels
+        (int64 CSR); None if the fused path does not apply (HipTrainingJobKvsAll; kge_kl_fwd)."""
+        t = self._ce_tables()
+        if t is None:
+            return None
+        ent, rel = self._w()
+        return _FusedKL.apply("sp", ent, rel, s, p, lbl_rowptr, lbl_col, t)
+
+    def kl_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
+        t = self._ce_tables()
+        if t is None:
+            return None
+        ent, rel = self._w()
+        return _FusedKL.apply("po", ent, rel, o, p, lbl_rowptr, lbl_col, t)
 
     def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
         if not self._fused():

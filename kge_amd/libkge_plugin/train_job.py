@@ -1,8 +1,12 @@
-"""TrainingJob1vsAll with the loss fused into the scoring kernel (train.type: hip_1vsAll)."""
+"""TrainingJob1vsAll / TrainingJobKvsAll with the kl loss fused into the scoring kernel
+(train.type: hip_1vsAll / hip_KvsAll)."""
 import time
+
+import torch
 
 from kge.job import Job
 from kge.job.train_1vsAll import TrainingJob1vsAll
+from kge.job.train_KvsAll import TrainingJobKvsAll
 from kge.util.loss import KLDivWithSoftmaxKgeLoss
 
 
@@ -34,6 +38,65 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
             if rows is None:  # the model declined (tables / options changed): reference path for all
                 return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
             loss_value = rows.sum() / batch_size
+            result.avg_loss += loss_value.item()
+            result.forward_time += time.time()
+            result.backward_time -= time.time()
+            if not self.is_forward_only:
+                loss_value.backward()
+            result.backward_time += time.time()
+
+
+class HipTrainingJobKvsAll(TrainingJobKvsAll):
+    """Overrides only `_process_subbatch` (train_KvsAll.py:216-294).  With `train.loss: kl`, no label
+    smoothing and a model that offers `kl_loss_sp` / `kl_loss_po`, the sp_ and _po queries of a
+    subbatch get their loss from one fused kernel each (kge_kl_fwd: scores never written; labels as
+    a CSR cut out of the batch's `label_coords`); s_o queries and every other configuration run
+    the reference's code."""
+
+    def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
+        super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
+        if self.__class__ == HipTrainingJobKvsAll:
+            for f in Job.job_created_hooks:
+                f(self)
+
+    def _fused_ok(self) -> bool:
+        return (isinstance(self.loss, KLDivWithSoftmaxKgeLoss) and self.label_smoothing == 0.0
+                and hasattr(self.model, "kl_loss_sp") and "s_o" not in self.query_types)
+
+    def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
+        if not self._fused_ok():
+            return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
+        batch_size = result.size
+        result.prepare_time -= time.time()
+        queries = batch["queries"][subbatch_slice].to(self.device)
+        coords = batch["label_coords"]  # [nnz, 2] (batch row, label), rows ascending; on the device
+        qtype = batch["query_type_indexes"][subbatch_slice].to(self.device)
+        row0 = subbatch_slice.start or 0
+        # label ranges of all batch rows: counts -> offsets (no host sync)
+        counts = torch.bincount(coords[:, 0].long(), minlength=batch_size)
+        offsets = torch.zeros(batch_size + 1, dtype=torch.long, device=coords.device)
+        torch.cumsum(counts, 0, out=offsets[1:])
+        result.prepare_time += time.time()
+        for query_type_index, query_type in enumerate(self.query_types):
+            examples = (qtype == query_type_index).nonzero(as_tuple=False).view(-1)
+            if len(examples) == 0:
+                continue
+            result.forward_time -= time.time()
+            rows = examples + row0
+            cnt = counts[rows]
+            rowptr = torch.zeros(len(rows) + 1, dtype=torch.long, device=cnt.device)
+            torch.cumsum(cnt, 0, out=rowptr[1:])
+            total = int(rowptr[-1])
+            idx = torch.repeat_interleave(offsets[rows] - rowptr[:-1], cnt, output_size=total) \
+                + torch.arange(total, device=cnt.device)
+            col = coords[idx, 1].long()
+            q0, q1 = queries[examples, 0], queries[examples, 1]
+            loss_rows = (self.model.kl_loss_sp(q0, q1, rowptr, col) if query_type == "sp_"
+                         else self.model.kl_loss_po(q0, q1, rowptr, col))
+            if loss_rows is None:  # the model declined: reference path for the whole subbatch
+                result.forward_time += time.time()
+                return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
+            loss_value = loss_rows.sum() / batch_size  # averaged over the batch, not the subbatch
             result.avg_loss += loss_value.item()
             result.forward_time += time.time()
             result.backward_time -= time.time()

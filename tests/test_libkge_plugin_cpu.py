@@ -103,3 +103,68 @@ def test_training_job_plugin_resolves_and_declines_without_gpu():
     m = KgeModel.create(config, Dataset(config, folder=None))
     s, p, o = torch.tensor([1, 2]), torch.tensor([0, 3]), torch.tensor([5, 6])
     assert m.loss_sp(s, p, o) is None and m.loss_po(p, o, s) is None
+
+
+def _job_config(tmp, model, train_type, seed=7):
+    rh.import_reference()
+    import os
+    from kge import Config
+    config = Config()
+    config.folder = os.path.join(tmp, f"run_{train_type}_{model}")
+    os.makedirs(config.folder, exist_ok=True)
+    config.set("console.quiet", True)
+    config.set("modules", ["kge.job", "kge.model", "kge.model.embedder", "kge_amd.libkge_plugin"])
+    config.set("model", model)
+    config._import(model)
+    config.set("dataset.name", "dataset_test")
+    config.set("job.device", "cpu")
+    config.set("train.max_epochs", 1)
+    config.set("train.batch_size", 32)
+    config.set("train.num_workers", 0)
+    config.set("lookup_embedder.dim", 16)
+    config.set("random_seed.default", seed)
+    if train_type.startswith("hip_"):
+        config._import(train_type)
+    config.set("train.type", train_type)
+    return config
+
+
+@pytest.mark.parametrize("ref_type,hip_type", [("1vsAll", "hip_1vsAll"), ("KvsAll", "hip_KvsAll")])
+def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type):
+    """Control flow of the plugin training jobs on CPU: with a model whose loss_sp / loss_po
+    (kl_loss_sp / kl_loss_po) are the reference's own ops, one epoch of HipTrainingJob* must give
+    the reference job's avg_loss and parameters -- batching, label CSR cut-out (KvsAll),
+    loss scaling by the batch size, backward and optimizer steps are then the same."""
+    import os
+    import shutil
+    import types
+    import torch.nn.functional as F
+    rh.import_reference()
+    from kge import Dataset
+    from kge.job import TrainingJob
+    from kge_amd.model import KgeModel as Mirror
+    data = os.path.join(str(tmp_path), "dataset_test")  # the jobs write index caches next to the data
+    shutil.copytree(os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test"), data)
+    results = {}
+    for train_type in (ref_type, hip_type):
+        config = _job_config(str(tmp_path), "complex", train_type)
+        torch.manual_seed(11)  # same initialisation and batch order for both jobs
+        job = TrainingJob.create(config, Dataset.create(config, folder=data))
+        assert type(job).__name__ == ("TrainingJob" if not train_type.startswith("hip_") else "HipTrainingJob") + ref_type
+        m = job.model
+        if train_type.startswith("hip_"):
+            m.loss_sp = types.MethodType(
+                lambda self, s, p, o: F.cross_entropy(self.score_sp(s, p), o.long(), reduction="none"), m)
+            m.loss_po = types.MethodType(
+                lambda self, p, o, s: F.cross_entropy(self.score_po(p, o), s.long(), reduction="none"), m)
+            m.kl_loss_sp = types.MethodType(
+                lambda self, s, p, rp, col: Mirror._kl_composed(self.score_sp(s, p), rp, col), m)
+            m.kl_loss_po = types.MethodType(
+                lambda self, p, o, rp, col: Mirror._kl_composed(self.score_po(p, o), rp, col), m)
+        job._prepare()
+        trace = job.run_epoch()
+        results[train_type] = (trace["avg_loss"], [x.detach().clone() for x in m.parameters()])
+    (l_ref, p_ref), (l_hip, p_hip) = results[ref_type], results[hip_type]
+    assert abs(l_ref - l_hip) <= 1e-5 * max(1.0, abs(l_ref)), (l_ref, l_hip)
+    for a, b in zip(p_ref, p_hip):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
