@@ -19,7 +19,7 @@ timeout 300 python tools/v2_phases.py > $OUT/v2_phases.txt 2>&1
 timeout 900 python tools/perf_probe.py > $OUT/probe.jsonl 2> $OUT/probe.err
 echo "probe exit: $?" >> $OUT/env.log
 # job-level probes: backward, negative sampling, one training step, evaluation, listed subsets
-for P in bwd_probe ns_probe train_probe eval_probe subset_probe; do
+for P in bwd_probe ns_probe train_probe eval_probe subset_probe ce_probe ce_phases ce_host; do
   timeout 300 python tools/$P.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|_warn_once\|ROCTracer" > $OUT/$P.txt
 done
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err )
@@ -29,6 +29,8 @@ for C in FETCH_SIZE WRITE_SIZE; do
 echo "pmc $C exit: $?" >> $OUT/env.log
 done
 find $OUT/prof -name "*stats*" | head >> $OUT/env.log
+# MFMA-utilisation counters of the headline kernel + HBM counters of the gather kernels
+bash tools/gpu_pmc.sh ${TAG}pmc > $OUT/gpu_pmc.log 2>&1
 tail -5 $OUT/pytest_all.log
 cat $OUT/env.log
 cat $OUT/bench.json
