@@ -256,6 +256,8 @@ int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_o
  * per-row running (max, sum exp).  The scores inside are bit-identical to kge_score_sp /
  * kge_score_po on the same tables.
  *
+ * A label outside [0, num_ent) gives loss_rows[i] = NaN (the reference raises an index error).
+ *
  * kge_ce_bwd: gradients of sum_i g_i * loss_rows[i] (g_i = g_rows[i], or g_scalar if g_rows is
  * NULL -- the reference's 1 / batch_size), laid out as for kge_score_pairs_bwd:
  *   g_a [n, dim], g_p [n, rel_dim], g_tgt [num_ent, dim]   (f32, OVERWRITTEN)

@@ -179,6 +179,8 @@ int run_ce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   ce.label = label;
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));
+  // a label outside [0, num_ent) is found by no lane: its row's loss then reads NaN, not stale scratch
+  if (hipMemsetAsync(ce.true_score, 0xff, (size_t)n * sizeof(float), st) != hipSuccess) return KGE_ERR_LAUNCH;
   const int rc = run_pairs_bf16_v3_ce(scorer, V3_LSE, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, n,

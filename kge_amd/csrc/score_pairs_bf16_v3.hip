@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   // accumulator element r of half hf is column  col0(tile) + 32 hf + 8 (r >> 2) + 4 fh + (r & 3)
   auto lse_pick = [&](int tt, const f32x16& h0, const f32x16& h1) __attribute__((always_inline)) {
     const long long rel = lab - ((long long)(tile_lo + tt) * V3_TN + 4 * fh);
-    const bool hit = rel >= 0 && rel < V3_TN && (rel & 7) < 4;
+    const bool hit = rel >= 0 && rel < V3_TN && (rel & 7) < 4 && lab < m;  // not a padded column
     if (__any(hit)) {  // rare: a row's label lies in exactly one tile of the table
       tsc = v3_pick(h0, h1, hit ? (int)rel : -1, tsc);
       tfound = tfound || hit;

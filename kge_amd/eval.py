@@ -60,6 +60,30 @@ class FilterIndex:
         idx = np.repeat(lo - rowptr[:-1], cnt) + np.arange(rowptr[-1])
         return rowptr, v[idx] if rowptr[-1] else np.zeros(0, dtype=np.int64)
 
+    @staticmethod
+    def _ranges(index, keys):
+        uk, start, _ = index
+        if not len(uk):
+            z = np.zeros(len(keys), dtype=np.int64)
+            return z, z.copy()
+        pos = np.minimum(np.searchsorted(uk, keys), len(uk) - 1)
+        hit = uk[pos] == keys
+        return np.where(hit, start[pos], 0).astype(np.int64), np.where(hit, start[pos + 1], 0).astype(np.int64)
+
+    def ranges(self, batch: np.ndarray):
+        """-> (sp_begin, sp_end, po_begin, po_end): per row the range of its known answers in
+        `sp_values` / `po_values` -- what kge_filter_lookup computes on the device."""
+        b = np.asarray(batch).astype(np.int64)
+        return self._ranges(self._sp, b[:, 0] * self.R + b[:, 1]) + self._ranges(self._po, b[:, 1] * self.E + b[:, 2])
+
+    @property
+    def sp_values(self):
+        return self._sp[2]
+
+    @property
+    def po_values(self):
+        return self._po[2]
+
     def labels(self, batch: np.ndarray):
         """-> (sp_rowptr, sp_col, po_rowptr, po_col) for a batch of (s,p,o) triples."""
         b = np.asarray(batch).astype(np.int64)

@@ -105,6 +105,25 @@ class ShardedEntityTable:
         s_rank, s_ties = self.rank_counts(po, s_true, po_rp, po_col, s.long(), atol, rtol)
         return s_rank, s_ties, o_rank, o_ties
 
+    def rank_batch_multi(self, triples: torch.Tensor, filters_o, filters_s, atol=1e-5, rtol=1e-4):
+        """Raw + len(filters) filtered rankings of a batch from ONE scan per direction and ONE
+        counter all-reduce: filters_o / filters_s = [(begin [n], end [n], values), ...] ranges
+        into a filter index's value arrays (GLOBAL entity ids; kge_filter_lookup /
+        FilterIndex.ranges) for the sp_ / _po direction.  Returns int64 counts
+        [2 (o, s), 2 (rank, ties), len(filters) + 1, n]."""
+        s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
+        n, K = triples.shape[0], len(filters_o)
+        sp = self.score_sp(s, p)
+        po = self.score_po(p, o)
+        o_true = self.true_scores(sp, o)
+        s_true = self.true_scores(po, s)
+        counts = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=sp.device)
+        self.backend.rank_counts_multi(sp, o_true, filters_o, self.lo, o.long().contiguous(), atol, rtol,
+                                       counts[0, 0], counts[0, 1])
+        self.backend.rank_counts_multi(po, s_true, filters_s, self.lo, s.long().contiguous(), atol, rtol,
+                                       counts[1, 0], counts[1, 1])
+        return self._allreduce(counts)
+
     def topk(self, slab: torch.Tensor, k: int):
         """Global top-k (scores, entity ids) per row: local top-k, all-gather, merge
         (north_star's "RCCL all-gather of per-shard top-k")."""

@@ -308,3 +308,16 @@ def test_model_level_kl_loss_against_composed():
         assert abs(float(lf.detach()) - float(lc.detach())) <= 2e-5 * max(1.0, abs(float(lc.detach())))
         for a_, b_ in zip(gf, gc):
             assert float((a_ - b_).norm() / b_.norm()) <= 2e-3
+
+
+def test_ce_label_out_of_range_gives_nan_and_empty_batch(eng):
+    ent, rel, s, p, o = _case(13, "distmult", 128, 300, 5, 40, 0.5)
+    T = _tables(eng, "distmult", ent, rel)
+    bad = o.copy()
+    bad[3] = 300          # == num_ent: no lane owns this column
+    loss, lse = eng.ce_fwd(T, "sp", _t(s), _t(p), _t(bad))
+    loss = loss.cpu().numpy()
+    assert np.isnan(loss[3]) and np.isfinite(np.delete(loss, 3)).all() and np.isfinite(lse.cpu().numpy()).all()
+    e = torch.zeros(0, dtype=torch.int64, device=DEV)
+    l0, z0 = eng.ce_fwd(T, "sp", e, e, e)
+    assert l0.numel() == 0 and z0.numel() == 0

@@ -262,6 +262,13 @@ def test_sharded_table_on_the_gpu_kernels():
         r_s, t_s = eng.rank_counts(both[:, E:], s_true, labels[2], labels[3], 0, s)
         for a, b in ((o_rank, r_o), (o_ties, t_o), (s_rank, r_s), (s_ties, t_s)):
             assert torch.equal(a, b), dt
+        # raw + filtered from one scan per direction (ranges into a value array instead of a CSR)
+        beg, end = labels[0][:-1].contiguous(), labels[0][1:].contiguous()
+        cm = sh.rank_batch_multi(tri, [(beg, end, labels[1])], [(beg, end, labels[3])])
+        raw = sh.rank_batch(tri, None)
+        for k, (sr, st_, or_, ot) in enumerate((raw, (s_rank, s_ties, o_rank, o_ties))):
+            assert torch.equal(cm[0, 0, k], or_) and torch.equal(cm[0, 1, k], ot), (dt, k)
+            assert torch.equal(cm[1, 0, k], sr) and torch.equal(cm[1, 1, k], st_), (dt, k)
         tv, ti = sh.topk(sh.score_sp(s, p), 5)
         rv, ri = torch.topk(both[:, :E], 5, dim=1)
         assert torch.equal(tv, rv) and torch.equal(ti, ri)

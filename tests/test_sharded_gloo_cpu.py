@@ -39,6 +39,22 @@ class OracleBackend:
         return torch.from_numpy(r), torch.from_numpy(t)
 
 
+    @staticmethod
+    def rank_counts_multi(scores, true, filters, col_offset, true_col, atol, rtol, rank, ties):
+        """kge_rank_counts_multi on the oracle: one rank_counts per ranking (rank / ties [K + 1, n])."""
+        sc, tr, tc = scores.numpy(), true.numpy(), true_col.numpy()
+        r, t = ko.rank_counts(sc, tr, atol=atol, rtol=rtol)
+        rank[0] += torch.from_numpy(r)
+        ties[0] += torch.from_numpy(t)
+        for k, (beg, end, vals) in enumerate(filters):
+            beg, end, vals = beg.numpy(), end.numpy(), vals.numpy()
+            rp = np.concatenate([[0], np.cumsum(end - beg)]).astype(np.int64)
+            col = np.concatenate([vals[b:e] for b, e in zip(beg, end)] + [np.zeros(0, np.int64)]).astype(np.int64)
+            r, t = ko.rank_counts(sc, tr, rp, col, col_offset, tc, atol, rtol)
+            rank[k + 1] += torch.from_numpy(r)
+            ties[k + 1] += torch.from_numpy(t)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -69,6 +85,14 @@ def _worker(rank, world, port, model, q):
         for key, lab in (("raw", None), ("filt", labels)):
             s_rank, s_ties, o_rank, o_ties = sh.rank_batch(tb, lab)
             out[key] = (s_rank.numpy(), s_ties.numpy(), o_rank.numpy(), o_ties.numpy())
+        # raw + filtered from one call (device-resident index ranges instead of a per-batch CSR)
+        sb, se, pb, pe = (torch.from_numpy(x) for x in fi.ranges(batch))
+        cm = sh.rank_batch_multi(tb, [(sb, se, torch.from_numpy(fi.sp_values))],
+                                 [(pb, pe, torch.from_numpy(fi.po_values))])
+        for k, key in enumerate(("raw", "filt")):
+            s_rank, s_ties, o_rank, o_ties = out[key]
+            assert np.array_equal(cm[0, 0, k].numpy(), o_rank) and np.array_equal(cm[0, 1, k].numpy(), o_ties), key
+            assert np.array_equal(cm[1, 0, k].numpy(), s_rank) and np.array_equal(cm[1, 1, k].numpy(), s_ties), key
         rows = sh.gather_entity_rows(tb[:, 0])
         assert np.array_equal(rows.numpy(), ent[batch[:, 0]])
         slab = sh.score_sp(tb[:, 0], tb[:, 1])
