@@ -296,6 +296,18 @@ int kge_kl_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n
                const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt,
                void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- optimizer step over a table ---------------------- */
+/* One dense Adagrad step on `count` contiguous f32 elements (16-byte aligned arrays), in place:
+ *   g = grad + weight_decay * param (if weight_decay != 0);  state_sum += g*g;
+ *   param += (minus_clr * g) / (sqrt(state_sum) + eps)
+ * with minus_clr = -lr / (1 + (step - 1) * lr_decay): torch.optim.Adagrad's update
+ * (the optimizer LibKGE creates by default, kge/util/optimizer.py:15-20; config-default.yaml
+ * train.optimizer), one pass instead of five element-wise kernels.  bf16_copy != NULL: also
+ * writes RNE(param) there (8-byte aligned) -- the table copies the bf16 scoring kernels read. */
+int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t count,
+                     float minus_clr, float weight_decay, float eps, void* bf16_copy,
+                     void* stream);
+
 /* ---- backward (autograd twins) ------------------------------------------ */
 /* All gradients are f32 and OVERWRITTEN; tables/embeddings must be f32, except
  * kge_score_pairs_bwd for ComplEx/DistMult, which also takes bf16 tables (mixed-precision

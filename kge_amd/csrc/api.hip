@@ -66,6 +66,8 @@ int run_spo_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, 
                       float* gr, long long gr_ld, hipStream_t st);
 long long ce_workspace_bytes(int d, long long n, long long m);
 void ce_set_stamps(unsigned long long* p);
+int run_adagrad(float* param, const float* grad, float* sum, long long count, float minus_clr, float weight_decay,
+                float eps, unsigned short* copy16, hipStream_t st);
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, float* loss_rows, float* lse, void* ws,
                long long ws_bytes, hipStream_t st);
@@ -478,6 +480,15 @@ int kge_kl_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n
   return run_kl_bwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, none), dir, (int)t->dim, n, t->num_ent,
                     (const long long*)lbl_rowptr, (const long long*)lbl_col, lse, g_rows, g_scalar, g_a, g_p, g_tgt,
                     workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t count, float minus_clr,
+                     float weight_decay, float eps, void* bf16_copy, void* stream) {
+  if (count < 0 || (count > 0 && (!param || !grad || !state_sum))) return KGE_ERR_INVALID_ARG;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)state_sum) & 15) return KGE_ERR_INVALID_ARG;
+  if (bf16_copy && ((uintptr_t)bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
+  return run_adagrad(param, grad, state_sum, count, minus_clr, weight_decay, eps, (unsigned short*)bf16_copy,
+                     (hipStream_t)stream);
 }
 
 int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,

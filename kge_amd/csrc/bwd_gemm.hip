@@ -108,6 +108,19 @@ static rocblas_handle bwdg_handle() {
   return handles[dev];
 }
 
+// Set while a bf16 backward is issued into a stream that is being captured into a hipGraph: the
+// products may then only use plans / split-K choices that were tuned by an earlier eager call of
+// the same shape (tuning times kernels and waits for them: not capturable); otherwise the call
+// fails with KGE_ERR_UNSUPPORTED and the capture has to be preceded by a warm-up step.
+static thread_local bool tl_capturing = false;
+
+static bool stream_is_capturing(hipStream_t st, bool& capturing) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) return false;
+  capturing = cs != hipStreamCaptureStatusNone;
+  return true;
+}
+
 // ---- column-major f32 GEMM C[m,n] = op(A) * op(B) through hipBLASLt, plans cached per shape
 struct LtPlan {
   int ta, tb, in16, batch;
@@ -190,6 +203,7 @@ static bool lt_gemm(int in16, int ta, int tb, long long m, long long n, long lon
   }
   if (!pl->ok) return false;
   const float one = 1.0f, zero = 0.0f;
+  if (!pl->tuned && tl_capturing) return false;
   if (!pl->tuned) {
     // First use of this shape: time the library's candidates once on the caller's data (the
     // heuristic's first choice for the 512 x 512 x 14,541 dQ product is 5x slower than its
@@ -275,6 +289,7 @@ static bool gemm_long_k(int in16, int d, long long n, long long m, const void* T
       if (c.in16 == in16 && c.d == d && c.n == n && c.m == m && c.ldt == ldt && c.ldg == ldg && c.sb == scratch_bytes)
         P = c.P;
   }
+  if (P < 0 && tl_capturing) return false;
   if (P < 0) {  // first use of this shape: time the strategies once (host-synchronous)
     const int cands[4] = {1, 4, 8, 16};
     float best = 1e30f;
@@ -490,13 +505,16 @@ int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operan
                              unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
   if (n == 0 || m == 0) return KGE_OK;
   if (n >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31)) return KGE_ERR_UNSUPPORTED;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return KGE_ERR_UNSUPPORTED;
+  bool capturing = false;
+  if (!stream_is_capturing(st, capturing)) return KGE_ERR_UNSUPPORTED;
+  tl_capturing = capturing;
+  int rc = KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
-    return bwdg_products16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
-  if (scorer == KGE_DISTMULT)
-    return bwdg_products16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
-  return KGE_ERR_UNSUPPORTED;
+    rc = bwdg_products16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+  else if (scorer == KGE_DISTMULT)
+    rc = bwdg_products16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+  tl_capturing = false;
+  return rc;
 }
 
 int run_pairs_bwd_gemm16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
@@ -506,12 +524,14 @@ int run_pairs_bwd_gemm16(int scorer, int dir, const Operand& A, const Operand& R
   if (scorer != KGE_COMPLEX && scorer != KGE_DISTMULT) return KGE_ERR_UNSUPPORTED;
   if (dr != d || !g_a || !g_p || !g_tgt || (d % 2)) return KGE_ERR_UNSUPPORTED;
   if (n >= (1LL << 31) || m >= (1LL << 31) || TG.ld >= (1LL << 31)) return KGE_ERR_UNSUPPORTED;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
-    return KGE_ERR_UNSUPPORTED;
-  if (scorer == KGE_COMPLEX)
-    return bwdg_run16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, ws, ws_bytes, st);
-  return bwdg_run16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, ws, ws_bytes, st);
+  bool capturing = false;
+  if (!stream_is_capturing(st, capturing)) return KGE_ERR_UNSUPPORTED;
+  tl_capturing = capturing;
+  const int rc = scorer == KGE_COMPLEX
+                     ? bwdg_run16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, ws, ws_bytes, st)
+                     : bwdg_run16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, ws, ws_bytes, st);
+  tl_capturing = false;
+  return rc;
 }
 
 // KGE_ERR_UNSUPPORTED: the caller uses the self-contained kernels of bwd.hip

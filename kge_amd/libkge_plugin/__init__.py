@@ -6,6 +6,8 @@ Usage inside an unmodified LibKGE installation (config-default.yaml:137, README.
     model: hip_complex            # or hip_distmult / hip_transe / hip_rotate
     # optional: eval.type: hip_entity_ranking
     # optional: train.type: hip_1vsAll / hip_KvsAll  (kl loss fused into the scoring kernel)
+    # optional: train.optimizer.default.type: HipAdagrad  (one-pass Adagrad; args as for Adagrad,
+    #           plus bf16_copies: true to keep the bf16 scoring tables fresh without a cast)
 
 `Config._import("hip_complex")` finds hip_complex.yaml in this package (config.py:280-325)
 and `init_from(class_name, modules)` (misc.py:13-42) resolves the classes below.  They
@@ -26,3 +28,9 @@ from .models import (HipComplEx, HipComplExScorer, HipDistMult, HipDistMultScore
                      HipRotatE, HipRotatEScorer, HipTransE, HipTransEScorer)
 from .eval_job import HipEntityRankingJob  # noqa: F401
 from .train_job import HipTrainingJob1vsAll, HipTrainingJobKvsAll  # noqa: F401
+
+# kge/util/optimizer.py:15-20 resolves train.optimizer.default.type with getattr(torch.optim, ...)
+import torch.optim as _torch_optim
+from ..optim import Adagrad as HipAdagrad  # noqa: E402
+
+_torch_optim.HipAdagrad = HipAdagrad

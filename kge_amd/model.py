@@ -316,6 +316,13 @@ class _ScoreSPO(torch.autograd.Function):
         return None, None, ge, gr, None, None, None
 
 
+def _bf16_copy_of(param):
+    rec = getattr(param, "_kge_bf16_copy", None)  # kge_amd.optim.BF16_ATTR
+    if rec is None or rec[1] != param._version:
+        return None
+    return rec[0]
+
+
 class BF16Shadow:
     """bf16 copies of f32 master tables for mixed-precision scoring (`score_dtype: bfloat16`):
     the forward runs the bf16 matrix-core kernel on the copies, the backward differentiates the
@@ -328,6 +335,14 @@ class BF16Shadow:
         self._key, self._tables = None, None
 
     def tables(self, name, ent, rel, l_norm) -> "engine.Tables":
+        # copies written by the optimizer's own pass over the tables (kge_amd.optim.Adagrad with
+        # bf16_copies=True) are fresh by construction: no cast at all
+        e16, r16 = _bf16_copy_of(ent), _bf16_copy_of(rel)
+        if e16 is not None and r16 is not None:
+            key = (e16.data_ptr(), ent._version, r16.data_ptr(), rel._version, "opt")
+            if key != self._key:
+                self._tables, self._key = engine.Tables(name, e16, r16, l_norm), key
+            return self._tables
         key = (ent.data_ptr(), ent._version, rel.data_ptr(), rel._version)
         if key != self._key or torch.is_grad_enabled():
             self._tables = engine.Tables(name, ent.detach().to(torch.bfloat16), rel.detach().to(torch.bfloat16),

@@ -1,0 +1,89 @@
+"""torch.optim.Adagrad with the dense update done by one HIP kernel per parameter
+(kge_adagrad_step), optionally maintaining the bf16 copies of the tables that mixed-precision
+scoring reads.
+
+Drop-in for `torch.optim.Adagrad` (same constructor arguments, same `state_dict`: per-parameter
+"step" and "sum"), so LibKGE's optimizer checkpoints load either way.  Parameters the kernel does
+not cover (CPU tensors, non-float32, sparse gradients) are stepped by torch's own functional
+Adagrad.  kge/util/optimizer.py:15-20 resolves `train.optimizer.default.type` with
+`getattr(torch.optim, ...)`; the LibKGE plugin registers this class there as `HipAdagrad`.
+"""
+import ctypes
+
+import torch
+from torch.optim.adagrad import Adagrad as _TorchAdagrad
+from torch.optim.adagrad import adagrad as _functional_adagrad
+
+from . import _lib, engine
+
+BF16_ATTR = "_kge_bf16_copy"  # (tensor, version of the parameter it was made from), set on the parameter
+
+
+def bf16_copy_of(param: torch.Tensor):
+    """The optimizer-maintained bf16 copy of `param`, or None if there is none / it is stale."""
+    rec = getattr(param, BF16_ATTR, None)
+    if rec is None or rec[1] != param._version or rec[0].data_ptr() == 0:
+        return None
+    return rec[0]
+
+
+class Adagrad(_TorchAdagrad):
+    def __init__(self, params, lr=1e-2, lr_decay=0, weight_decay=0, initial_accumulator_value=0, eps=1e-10,
+                 bf16_copies: bool = False, **kw):
+        """bf16_copies=True: after every step each 2-D float32 parameter carries a fresh bf16 copy
+        (written by the same kernel pass) that `kge_amd.model.BF16Shadow` picks up instead of
+        re-casting the table before the next scoring call."""
+        kw.pop("foreach", None)
+        kw.pop("fused", None)
+        super().__init__(params, lr=lr, lr_decay=lr_decay, weight_decay=weight_decay,
+                         initial_accumulator_value=initial_accumulator_value, eps=eps, foreach=False, **kw)
+        self.bf16_copies = bool(bf16_copies)
+
+    @staticmethod
+    def _kernel_ok(p: torch.Tensor) -> bool:
+        g = p.grad
+        return (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g is not None
+                and not g.is_sparse and g.dtype == torch.float32 and g.is_contiguous())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            if group.get("maximize") or group.get("differentiable"):
+                raise NotImplementedError("kge_amd.optim.Adagrad: maximize / differentiable are not supported")
+            rest = []
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not self._kernel_ok(p):
+                    rest.append(p)
+                    continue
+                state = self.state[p]
+                state["step"] += 1
+                step = float(state["step"])
+                minus_clr = -float(group["lr"]) / (1.0 + (step - 1.0) * group["lr_decay"])
+                s = state["sum"]
+                copy = None
+                if self.bf16_copies and p.dim() == 2:
+                    rec = getattr(p, BF16_ATTR, None)
+                    copy = rec[0] if rec is not None and rec[0].shape == p.shape else \
+                        torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
+                with torch.cuda.device(p.device):
+                    _lib.check(_lib.lib().kge_adagrad_step(
+                        p.data_ptr(), p.grad.data_ptr(), s.data_ptr(), p.numel(), minus_clr,
+                        float(group["weight_decay"]), float(group["eps"]),
+                        None if copy is None else copy.data_ptr(), engine._stream(p.device)), "kge_adagrad_step")
+                torch.autograd.graph.increment_version(p)  # the kernel wrote through the raw pointer
+                if copy is not None:
+                    setattr(p, BF16_ATTR, (copy, p._version))
+            if rest:  # torch's own update for everything else
+                grads = [p.grad for p in rest]
+                sums = [self.state[p]["sum"] for p in rest]
+                steps = [self.state[p]["step"] for p in rest]
+                _functional_adagrad(rest, grads, sums, steps, has_sparse_grad=any(g.is_sparse for g in grads),
+                                    foreach=False, lr=group["lr"], weight_decay=group["weight_decay"],
+                                    lr_decay=group["lr_decay"], eps=group["eps"], maximize=False)
+        return loss

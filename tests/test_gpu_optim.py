@@ -1,0 +1,122 @@
+"""kge_amd.optim.Adagrad (kge_adagrad_step: one pass per table) against torch.optim.Adagrad:
+same trajectory within float rounding (torch's element-wise kernels may contract `sum + g*g` and
+`g + wd*p` into fma, this kernel rounds every operation: a few ulp per step), interchangeable
+state_dicts, and the bf16 copies of the tables written in the same pass."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("lr_decay,weight_decay,init_acc", [(0.0, 0.0, 0.0), (0.01, 1e-3, 0.1)])
+def test_adagrad_matches_torch(lr_decay, weight_decay, init_acc):
+    from kge_amd.optim import Adagrad
+    torch.manual_seed(0)
+    shapes = [(1001, 96), (7, 33), (5,)]     # a table, an odd-sized one (scalar tail), a vector
+    ref = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    got = [r.detach().clone().requires_grad_(True) for r in ref]
+    o_ref = torch.optim.Adagrad(ref, lr=0.1, lr_decay=lr_decay, weight_decay=weight_decay,
+                                initial_accumulator_value=init_acc, eps=1e-10)
+    o_got = Adagrad(got, lr=0.1, lr_decay=lr_decay, weight_decay=weight_decay,
+                    initial_accumulator_value=init_acc, eps=1e-10, bf16_copies=True)
+    for step in range(4):
+        for r, g in zip(ref, got):
+            grad = torch.randn_like(r)
+            r.grad, g.grad = grad.clone(), grad.clone()
+        v0 = [g._version for g in got]
+        o_ref.step()
+        o_got.step()
+        for r, g, v in zip(ref, got, v0):
+            torch.testing.assert_close(g.detach(), r.detach(), rtol=2e-6, atol=1e-7)
+            assert g._version > v                       # the raw-pointer update is visible to autograd
+        for (kr, sr), (kg, sg) in zip(o_ref.state.items(), o_got.state.items()):
+            torch.testing.assert_close(sg["sum"], sr["sum"], rtol=2e-6, atol=1e-30)
+            assert float(sg["step"]) == float(sr["step"]) == step + 1
+    # bf16 copies: only for 2-D parameters, equal to the RNE cast of the new parameter, fresh
+    from kge_amd.optim import bf16_copy_of
+    for g in got:
+        c = bf16_copy_of(g)
+        if g.dim() == 2:
+            assert c is not None and torch.equal(c, g.detach().to(torch.bfloat16))
+        else:
+            assert c is None
+    got[0].data.mul_(1.0)            # .data edits do not bump the version ...
+    with torch.no_grad():
+        got[0].mul_(1.0)             # ... in-place ops do: the copy is stale now
+    assert bf16_copy_of(got[0]) is None
+    # state_dicts are interchangeable
+    o_ref.load_state_dict(o_got.state_dict())
+    o_got.load_state_dict(o_ref.state_dict())
+
+
+def test_mixed_precision_model_uses_the_optimizer_copies():
+    """score_dtype=bfloat16 + Adagrad(bf16_copies=True): after a step the scoring tables ARE the
+    optimizer's copies (no cast kernels), and the scores equal those of freshly cast tables."""
+    from kge_amd import engine as eng
+    from kge_amd import model as km
+    from kge_amd.optim import Adagrad, bf16_copy_of
+    E, R, d, n = 1500, 9, 256, 130
+    torch.manual_seed(0)
+    m = km.create("complex", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    opt = Adagrad(m.parameters(), lr=0.1, bf16_copies=True)
+    g = torch.Generator().manual_seed(1)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    for _ in range(2):
+        opt.zero_grad()
+        (m.loss_sp(s, p, o).sum() / n).backward()
+        opt.step()
+    ent, rel = m._entity_embedder.weight, m._relation_embedder.weight
+    t = m._fwd_tables()
+    assert t.ent.data_ptr() == bf16_copy_of(ent).data_ptr() and t.rel.data_ptr() == bf16_copy_of(rel).data_ptr()
+    fresh = eng.Tables("complex", ent.detach().bfloat16(), rel.detach().bfloat16())
+    with torch.no_grad():
+        assert torch.equal(m.score_sp(s, p), eng.score_sp(fresh, s, p))
+
+
+def test_whole_training_step_replayed_as_a_hip_graph():
+    """Fused loss (both directions) + backward + one-pass Adagrad captured ONCE into a hipGraph
+    (after an eager warm-up, which tunes the GEMM plans) and replayed: parameters after k replays
+    equal those of k eager steps from the same state (same kernels, same plans; the captured
+    scoring launches build their query fragments per workgroup instead of cooperatively --
+    identical bits)."""
+    from kge_amd import model as km
+    from kge_amd.optim import Adagrad
+    E, R, d, n = 2000 + 7, 11, 256, 256
+    g = torch.Generator().manual_seed(3)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+
+    def make():
+        torch.manual_seed(0)
+        m = km.create("distmult", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+        return m, Adagrad(m.parameters(), lr=0.05, bf16_copies=True)
+
+    def step(m, opt):
+        opt.zero_grad(set_to_none=True)
+        (m.loss_sp(s, p, o).sum() / n).backward()
+        (m.loss_po(p, o, s).sum() / n).backward()
+        opt.step()
+
+    m_e, o_e = make()
+    m_g, o_g = make()
+    warm, k = 2, 3
+    for _ in range(warm + k):
+        step(m_e, o_e)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warm):
+            step(m_g, o_g)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    o_g.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        (m_g.loss_sp(s, p, o).sum() / n).backward()
+        (m_g.loss_po(p, o, s).sum() / n).backward()
+        o_g.step()
+    # the capture itself executes nothing: k replays = k steps
+    for _ in range(k):
+        graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(m_e.parameters(), m_g.parameters()):
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-6, atol=1e-7)

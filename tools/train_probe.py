@@ -55,12 +55,16 @@ def step_fused(m, opt):  # loss fused into the scoring kernel (kge
     opt.step()
 
 
-def timeit(fn, k=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(k): fn()
-    torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0) / k
+def timeit(fn, k=20, reps=5):
+    """best of `reps` runs of k steps (the step is close to host-bound: the host's state matters)"""
+    for _ in range(5): fn()
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(k): fn()
+        torch.cuda.synchronize()
+        best = min(best, 1e3 * (time.perf_counter() - t0) / k)
+    return best
 
 
 for name in ("complex", "distmult"):
@@ -74,13 +78,36 @@ for name in ("complex", "distmult"):
     m = km.create(name, E, R, d, device=dev, score_dtype=torch.bfloat16)
     opt = torch.optim.Adagrad(m.parameters(), lr=0.1)
     res["kge_amd score_dtype=bfloat16, fused loss"] = timeit(lambda: step_fused(m, opt))
+    from kge_amd.optim import Adagrad as HipAdagrad
+    m = km.create(name, E, R, d, device=dev, score_dtype=torch.bfloat16)
+    opt = HipAdagrad(m.parameters(), lr=0.1, bf16_copies=True)
+    res["... + one-pass Adagrad with bf16 copies"] = timeit(lambda: step_fused(m, opt))
+    # the same step captured once into a hipGraph and replayed: no per-launch host work at all
+    m = km.create(name, E, R, d, device=dev, score_dtype=torch.bfloat16)
+    opt = HipAdagrad(m.parameters(), lr=0.1, bf16_copies=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3): step_fused(m, opt)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        m.loss_sp(s, p, o).sum().backward()
+        m.loss_po(p, o, s).sum().backward()
+        opt.step()
+    res["... replayed as one hipGraph"] = timeit(graph.replay)
     print(name, " | ".join(f"{k}: {v:.2f} ms" for k, v in res.items()))
 
 # ---- where the mixed-precision step spends its GPU time
 from torch.profiler import profile, ProfilerActivity
 m = km.create("complex", E, R, d, device=dev, score_dtype=torch.bfloat16)
 opt = torch.optim.Adagrad(m.parameters(), lr=0.1)
-for tag, fn in (("composed loss", step), ("fused loss", step_fused)):
+from kge_amd.optim import Adagrad as HipAdagrad
+m2 = km.create("complex", E, R, d, device=dev, score_dtype=torch.bfloat16)
+opt2 = HipAdagrad(m2.parameters(), lr=0.1, bf16_copies=True)
+for tag, fn, m, opt in (("composed loss", step, m, opt), ("fused loss", step_fused, m, opt),
+                        ("fused loss + one-pass Adagrad with bf16 copies", step_fused, m2, opt2)):
     for _ in range(3): fn(m, opt)
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
