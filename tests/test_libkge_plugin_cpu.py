@@ -168,3 +168,27 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type)
     assert abs(l_ref - l_hip) <= 1e-5 * max(1.0, abs(l_ref)), (l_ref, l_hip)
     for a, b in zip(p_ref, p_hip):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_optimizer_plugin_resolves_through_the_reference_factory():
+    """train.optimizer.default.type: HipAdagrad -> KgeOptimizer.create (optimizer.py:15-20) finds the
+    class the plugin registered on torch.optim; on CPU parameters it steps like torch's Adagrad."""
+    config = _config("hip_distmult")
+    import kge_amd.libkge_plugin  # noqa: F401  (registers torch.optim.HipAdagrad)
+    from kge import Dataset
+    from kge.model import KgeModel
+    from kge.util import KgeOptimizer
+    config.set("train.optimizer.default.type", "HipAdagrad")
+    config.set("train.optimizer.default.args.lr", 0.1, create=True)
+    m = KgeModel.create(config, Dataset(config, folder=None))
+    opt = KgeOptimizer.create(config, m)
+    assert type(opt).__name__ == "Adagrad" and type(opt).__module__ == "kge_amd.optim"
+    ref = [p.detach().clone().requires_grad_(True) for p in m.parameters()]
+    o_ref = torch.optim.Adagrad(ref, lr=0.1)
+    for p, r in zip(m.parameters(), ref):
+        g = torch.randn_like(p)
+        p.grad, r.grad = g.clone(), g.clone()
+    opt.step()
+    o_ref.step()
+    for p, r in zip(m.parameters(), ref):
+        torch.testing.assert_close(p.detach(), r.detach())
