@@ -278,6 +278,23 @@ int kge_ce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index
                float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes,
                void* stream);
 
+/* Both directions of a 1vsAll batch at once (train_1vsAll.py:64-81 in one pass): rows [0, n) of
+ * loss_rows / lse / g_rows are the (s, p, ?) queries with labels o, rows [n, 2n) the (?, p, o)
+ * queries with labels s.  One scoring launch for both sides; the gradient products run once
+ * over the 2n rows.  kge_ce_sp_po_bwd: g_a [2n, dim] (rows [0, n): gradient of the s rows,
+ * [n, 2n): of the o rows), g_p [2n, rel_dim], g_tgt [num_ent, dim], OVERWRITTEN.  Values equal
+ * the two one-sided calls up to f32 summation order (the same scores; the log-sum-exp merges a
+ * different split of the columns, the products sum over 2n rows).
+ * Workspace: kge_ce_sp_po_workspace_bytes(t, n). */
+int64_t kge_ce_sp_po_workspace_bytes(const kge_tables* t, int64_t n);
+int kge_ce_sp_po_fwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                     float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+int kge_ce_sp_po_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                     const float* lse, const float* g_rows, float g_scalar, float* g_a,
+                     float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+
 /* KvsAll variant: KL divergence of softmax(score(i, .)) from the row's normalised multi-hot
  * labels, lbl_col[lbl_rowptr[i] .. lbl_rowptr[i+1]) (int64 CSR on the device, entity ids unique
  * per row), y_ij = 1/k_i:

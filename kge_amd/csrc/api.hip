@@ -66,6 +66,13 @@ int run_spo_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, 
                       float* gr, long long gr_ld, hipStream_t st);
 long long ce_workspace_bytes(int d, long long n, long long m);
 void ce_set_stamps(unsigned long long* p);
+long long ce2_workspace_bytes(int d, long long n, long long m);
+int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
+                long long n, long long m, float* loss_rows, float* lse, void* ws, long long ws_bytes,
+                hipStream_t st);
+int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
+                long long n, long long m, const float* lse, const float* g_rows, float g_scalar, float* g_a,
+                float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
 int run_adagrad(float* param, const float* grad, float* sum, long long count, float minus_clr, float weight_decay,
                 float eps, unsigned short* copy16, hipStream_t st);
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
@@ -448,6 +455,33 @@ int kge_ce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index
   return run_ce_bwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, all), dir, (int)t->dim, n, t->num_ent,
                     make_index(label), lse, g_rows, g_scalar, g_a, g_p, g_tgt, workspace, workspace_bytes,
                     (hipStream_t)stream);
+}
+
+int64_t kge_ce_sp_po_workspace_bytes(const kge_tables* t, int64_t n) {
+  if (kge_ce_workspace_bytes(t, n) <= 0) return 0;
+  return ce2_workspace_bytes((int)t->dim, n, t->num_ent);
+}
+
+int kge_ce_sp_po_fwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, float* loss_rows,
+                     float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = ce_check(t, KGE_SP_, s, p, o, n);
+  if (rc) return rc;
+  if (n > 0 && (!loss_rows || !lse)) return KGE_ERR_INVALID_ARG;
+  const kge_index all = {nullptr, 0, 0, 1};
+  return run_ce2_fwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
+                     t->num_ent, loss_rows, lse, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int kge_ce_sp_po_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, const float* lse,
+                     const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
+                     int64_t workspace_bytes, void* stream) {
+  int rc = ce_check(t, KGE_SP_, s, p, o, n);
+  if (rc) return rc;
+  if (n > 0 && (!lse || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
+  const kge_index all = {nullptr, 0, 0, 1};
+  return run_ce2_bwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
+                     t->num_ent, lse, g_rows, g_scalar, g_a, g_p, g_tgt, workspace, workspace_bytes,
+                     (hipStream_t)stream);
 }
 
 int kge_kl_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,

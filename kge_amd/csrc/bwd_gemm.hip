@@ -485,6 +485,48 @@ static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Op
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
+// Two-sided variant (kge_ce_sp_po_bwd): rows [0, n) of G16 / Q16 / g_a / g_p belong to the sp_ queries
+// (entity operand A1), rows [n, 2n) to the _po queries (A2); both products run ONCE over the 2n
+// rows (dT sums the two sides inside the product instead of in a separate accumulation pass).
+template <int SCORER>
+static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Operand& R, const Operand& TG, int d,
+                               long long n, long long m, const unsigned short* G16, long long mp,
+                               unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
+  const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
+  const unsigned qblocks = (unsigned)((n * half + 255) / 256);
+  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A1, R, KGE_SP_, d, n, Q16);
+  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A2, R, KGE_PO_, d, n,
+                     Q16 + n * d);
+  if (TG.idx.ptr != nullptr) return KGE_ERR_UNSUPPORTED;  // all entities only
+  const unsigned short* T = (const unsigned short*)TG.base;
+  if (!gemm_long_k(1, d, 2 * n, m, T, TG.ld, G16, mp, g_a, g_tgt, (size_t)m * d * sizeof(float), st))
+    return KGE_ERR_UNSUPPORTED;
+  if (!lt_gemm(1, 0, 1, d, m, 2 * n, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st)) return KGE_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A1, R, KGE_SP_, d, n, g_a, g_p);
+  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A2, R, KGE_PO_, d, n,
+                     g_a + n * d, g_p + n * d);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A2, const Operand& R,
+                                 const Operand& TG, int d, long long n, long long m, const unsigned short* G16,
+                                 long long mp, unsigned short* Q16, float* g_a, float* g_p, float* g_tgt,
+                                 hipStream_t st) {
+  if (n == 0 || m == 0) return KGE_OK;
+  if (2 * n >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31))
+    return KGE_ERR_UNSUPPORTED;
+  bool capturing = false;
+  if (!stream_is_capturing(st, capturing)) return KGE_ERR_UNSUPPORTED;
+  tl_capturing = capturing;
+  int rc = KGE_ERR_UNSUPPORTED;
+  if (scorer == KGE_COMPLEX)
+    rc = bwdg_products16_two<KGE_COMPLEX>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+  else if (scorer == KGE_DISTMULT)
+    rc = bwdg_products16_two<KGE_DISTMULT>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+  tl_capturing = false;
+  return rc;
+}
+
 template <int SCORER>
 static int bwdg_run16(int dir, const Operand& A, const Operand& R, const Operand& TG, int d, long long n,
                       long long m, const float* gout, long long ldg, float* g_a, float* g_p, float* g_tgt,

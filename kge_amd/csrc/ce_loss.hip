@@ -33,6 +33,11 @@ int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operan
                              long long n, long long m, const unsigned short* G16, long long mp,
                              unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st);
 
+int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A2, const Operand& R,
+                                 const Operand& TG, int d, long long n, long long m, const unsigned short* G16,
+                                 long long mp, unsigned short* Q16, float* g_a, float* g_p, float* g_tgt,
+                                 hipStream_t st);
+
 // merge the column groups of a row: M = max_c m_c, L = sum_c l_c exp(m_c - M).  One wave per row,
 // lanes over the column groups, xor-butterfly reductions (fixed order: deterministic).
 __global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ part, int ncg, long long n,
@@ -253,6 +258,67 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
                      g_rows, g_scalar);
   if (hipGetLastError() != hipSuccess) return KGE_ERR_LAUNCH;
   return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
+}
+
+// ---- both directions of a 1vsAll batch in one set of launches (kge_ce_sp_po_fwd / _bwd) ---------
+// Rows [0, n) of every per-row array are the (s, p, ?) queries with labels o, rows [n, 2n) the
+// (?, p, o) queries with labels s: what train_1vsAll.py:64-81 does in two passes.  One scoring
+// launch covers both sides (one start-up, like kge_score_sp_po), the gradient products run once
+// over 2n rows, and dT needs no second accumulation pass.
+static inline long long ce2_rows(long long n) { return 2 * ((n + 127) / 128) * 128; }  // padded, for geometry
+
+long long ce2_workspace_bytes(int d, long long n, long long m) {
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));  // sized for two sides
+  const long long fwd = al256(2 * n * pairs_bf16_v3_column_groups(ce2_rows(n), m) * 8) + al256(2 * n * 4);
+  const long long bwd = al256(2 * n * ce_ld16(m) * 2) + al256(2 * n * (long long)d * 2);
+  return coop + (fwd > bwd ? fwd : bwd);
+}
+
+int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
+                long long n, long long m, float* loss_rows, float* lse, void* ws, long long ws_bytes,
+                hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce2_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const int ncg = pairs_bf16_v3_column_groups(ce2_rows(n), m);
+  CeArgs ce{};
+  ce.label = O.idx;   // side 1: true objects
+  ce.label2 = S.idx;  // side 2: true subjects
+  ce.rgn1 = -1;       // two-sided: the launcher fills in the row-group split
+  ce.a2 = O;
+  ce.side2_off = n;
+  ce.part = (float*)((char*)ws + coop);
+  ce.true_score = (float*)((char*)ws + coop + al256(2 * n * ncg * 8));
+  if (hipMemsetAsync(ce.true_score, 0xff, (size_t)(2 * n) * sizeof(float), st) != hipSuccess) return KGE_ERR_LAUNCH;
+  const int rc = run_pairs_bf16_v3_ce(scorer, V3_LSE, S, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  if (rc != KGE_OK) return rc;
+  hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, 2 * n,
+                     ce.true_score, loss_rows, lse);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
+                long long n, long long m, const float* lse, const float* g_rows, float g_scalar, float* g_a,
+                float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce2_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const long long ld16 = ce_ld16(m);
+  CeArgs ce{};
+  ce.label = O.idx;
+  ce.label2 = S.idx;
+  ce.rgn1 = -1;
+  ce.a2 = O;
+  ce.side2_off = n;
+  ce.lse = lse;
+  ce.g_rows = g_rows;
+  ce.g_scalar = g_scalar;
+  ce.g16 = (unsigned short*)((char*)ws + coop);
+  ce.ld16 = ld16;
+  unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(2 * n * ld16 * 2));
+  const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, S, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  if (rc != KGE_OK) return rc;
+  return run_pairs_bwd_products16_two(scorer, S, O, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
 }
 
 void ce_set_stamps(unsigned long long* p) { g_ce_stamps = p; }

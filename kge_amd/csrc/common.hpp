@@ -296,6 +296,12 @@ struct CeArgs {
   float g_scalar;
   unsigned short* g16;      // V3_DS: [n][ld16] bf16, ld16 % 64 == 0 and ld16 >= 64 * ntiles
   long long ld16;
+  // two-sided launch (sp_ queries in row groups [0, rgn1), _po queries behind them): the entity
+  // operand, labels and row offset (into lse / g_rows / part / true_score / g16) of the second side
+  int rgn1;                 // 0: one-sided
+  Operand a2;
+  Index label2;
+  long long side2_off;
 };
 
 }  // namespace kge

@@ -96,7 +96,22 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR)
   const int fi = lane & 31, fh = lane >> 5;
-  const long long row0 = (long long)rg * V3_ROWS + 32 * wave;
+  // Two-sided fused-loss launch (kge_ce_sp_po_*): row groups [0, rgn1) are the n (s, p, ?) queries,
+  // row groups [rgn1, rgn) the n (?, p, o) queries; per-row arrays of the second side start at
+  // row ce.side2_off.  One-sided: ce.rgn1 == 0.
+  int rgl = rg;              // row group within its side
+  long long roff = 0;        // offset of this side's rows in lse / g_rows / part / true_score / G16
+  Index lab_ix = ce.label;
+  if constexpr (EPI != V3_STORE) {
+    if (ce.rgn1 > 0 && rg >= ce.rgn1) {
+      rgl = rg - ce.rgn1;
+      roff = ce.side2_off;
+      A = ce.a2;
+      dir = KGE_PO_;
+      lab_ix = ce.label2;
+    }
+  }
+  const long long row0 = (long long)rgl * V3_ROWS + 32 * wave;  // first query row (within its side)
   const unsigned short* tgb = (const unsigned short*)TG.base;
 
   int dbg_i = 0;
@@ -137,9 +152,10 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     if (cg < nbuild) {  // this workgroup's share of the row group's query rows
       constexpr int CGR = HH / 8;  // groups of 8 coordinates per row
       for (int it = cg * 256 + tid; it < V3_ROWS * CGR; it += nbuild * 256) {
-        const long long row = (long long)rg * V3_ROWS + it / CGR;
+        const long long row = (long long)rg * V3_ROWS + it / CGR;    // row of the fragment workspace
+        const long long lrow = (long long)rgl * V3_ROWS + it / CGR;  // query row within its side
         const int c8 = it % CGR;
-        const long long qrow = row < n ? row : n - 1;  // padded rows repeat row n-1
+        const long long qrow = lrow < n ? lrow : n - 1;  // padded rows repeat row n-1
         const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + c8 * 8;
         const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + c8 * 8;
         const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
@@ -289,10 +305,10 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   bool tfound = false;
   float lse_i = 0.0f, g_i = 0.0f; // V3_DS
   if constexpr (EPI != V3_STORE) {
-    if (ce.label.ptr != nullptr) lab = index_at(ce.label, orow);
+    if (lab_ix.ptr != nullptr) lab = index_at(lab_ix, orow);
     if constexpr (EPI == V3_DS) {
-      lse_i = ce.lse[orow];
-      g_i = ce.g_rows != nullptr ? ce.g_rows[orow] : ce.g_scalar;
+      lse_i = ce.lse[orow + roff];
+      g_i = ce.g_rows != nullptr ? ce.g_rows[orow + roff] : ce.g_scalar;
       if (ce.rowptr != nullptr && ce.rowptr[orow + 1] == ce.rowptr[orow]) g_i = 0.0f;
     }
   }
@@ -324,7 +340,8 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   auto ds_store = [&](int tt, int i, const f32x4& v) {
     long long orow_i = row0 + 8 * i + (lane >> 3);
     if (orow_i >= n) orow_i = n - 1;
-    *reinterpret_cast<f32x4*>(ce.g16 + orow_i * ce.ld16 + (long long)(tile_lo + tt) * V3_TN + 8 * (lane & 7)) = v;
+    *reinterpret_cast<f32x4*>(ce.g16 + (orow_i + roff) * ce.ld16 + (long long)(tile_lo + tt) * V3_TN +
+                              8 * (lane & 7)) = v;
   };
 
   // acc[4g + e] = score(query fi, target col0 + 8g + 4fh + e) for one 32-target half.  The
@@ -541,11 +558,11 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     const long long row = row0 + fi;
     if (row < n) {
       if (fh == 0) {
-        float* pp = ce.part + (row * ncg + cg) * 2;
+        float* pp = ce.part + ((row + roff) * ncg + cg) * 2;
         pp[0] = M;
         pp[1] = L;
       }
-      if (tfound) ce.true_score[row] = tsc;  // (never with ce.label.ptr == NULL: lab stays -1)
+      if (tfound) ce.true_score[row + roff] = tsc;  // (never with ce.label.ptr == NULL: lab stays -1)
     }
   } else if constexpr (EPI == V3_DS) {
 #pragma unroll
@@ -617,9 +634,13 @@ int pairs_bf16_v3_column_groups(long long n, long long m) {
 template <int SCORER, int HH, int EPI = V3_STORE>
 static int launch_v3(const Operand& A, const Operand& R, const Operand& TG, int dir, long long n,
                      long long m, float* out, long long ldo, hipStream_t st,
-                     unsigned long long* dbg, void* ws, long long ws_bytes, const CeArgs& ce = CeArgs{}) {
+                     unsigned long long* dbg, void* ws, long long ws_bytes, const CeArgs& ce_in = CeArgs{}) {
   int rgn, ntiles, ncg, tpc;
-  v3_geometry(n, m, rgn, ntiles, ncg, tpc);
+  // two-sided fused-loss launch (ce_in.rgn1 != 0): both sides padded to whole row groups
+  const bool two = EPI != V3_STORE && ce_in.rgn1 != 0;
+  v3_geometry(two ? 2 * ((n + V3_ROWS - 1) / V3_ROWS) * V3_ROWS : n, m, rgn, ntiles, ncg, tpc);
+  CeArgs ce = ce_in;
+  ce.rgn1 = two ? rgn / 2 : 0;
   const int grid = 8 * rgn * ((ncg + 7) / 8);
   const int tgmode = TG.idx.ptr == nullptr ? 0 : (TG.idx.itype ? 2 : 1);
   // cooperative query build: needs the workspace, more than one column group, every workgroup

@@ -540,6 +540,53 @@ def ce_bwd(t: Tables, direction: str, a, p, label, lse, g_rows=None, g_scalar: f
     return g_a, g_p, g_t
 
 
+def _ce2_workspace(tc, n, device, st):
+    need = _lib.lib().kge_ce_sp_po_workspace_bytes(ctypes.byref(tc), n)
+    if need <= 0:
+        raise RuntimeError("kge_ce_sp_po_*: bf16 ComplEx/DistMult tables with dim in {128, 256, 512} only")
+    key = (device.index, st, "ce2")
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _WORKSPACES[key] = _empty((need,), device, torch.uint8)
+    return buf.data_ptr(), buf.numel()
+
+
+def ce_sp_po_fwd(t: Tables, s, p, o):
+    """Both directions of a 1vsAll batch in one pass: (loss_rows [2n], lse [2n]); rows [0, n) =
+    cross entropy of score_sp(s, p) against o, rows [n, 2n) = of score_po(p, o) against s."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = keep[0].numel()
+    loss_rows, lse = _empty((2 * n,), t.device), _empty((2 * n,), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce2_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_sp_po_fwd(ctypes.byref(tc), si, pi, oi, n, loss_rows.data_ptr(),
+                                               lse.data_ptr(), ws, wsb, st), "kge_ce_sp_po_fwd")
+    return loss_rows, lse
+
+
+def ce_sp_po_bwd(t: Tables, s, p, o, lse, g_rows=None, g_scalar: float = 1.0):
+    """Backward of ce_sp_po_fwd: (g_a [2n, d]: rows [0, n) for the s rows, [n, 2n) for the o rows;
+    g_p [2n, d]; g_entities [E, d])."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = keep[0].numel()
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    lse = _f32c(lse, t.device)
+    gr = None if g_rows is None else _f32c(g_rows, t.device)
+    g_a, g_p, g_t = _empty((2 * n, d), t.device), _empty((2 * n, dr), t.device), _empty((t.num_ent, d), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce2_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_sp_po_bwd(
+            ctypes.byref(tc), si, pi, oi, n, lse.data_ptr(), None if gr is None else gr.data_ptr(),
+            float(g_scalar), g_a.data_ptr(), g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_ce_sp_po_bwd")
+    return g_a, g_p, g_t
+
+
 def _csr64(rowptr, col, dev):
     rp = rowptr.to(device=dev, dtype=torch.int64).contiguous()
     cl = col.to(device=dev, dtype=torch.int64).contiguous()

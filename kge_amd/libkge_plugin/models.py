@@ -8,7 +8,7 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import BF16Shadow, _FusedCE, _FusedKL, _ScoreEmb, _ScorePairs, _ScoreSPO
+from ..model import BF16Shadow, _FusedCE, _FusedCE2, _FusedKL, _ScoreEmb, _ScorePairs, _ScoreSPO
 
 
 class _HipScorer(RelationalScorer):
@@ -120,6 +120,14 @@ class _FusedScoring:
             return None
         ent, rel = self._w()
         return _FusedCE.apply("po", ent, rel, o, p, s, t)
+
+    def loss_sp_po(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
+        """[2n] loss_sp rows then loss_po rows from one pass over the batch; None if not applicable."""
+        t = self._ce_tables()
+        if t is None:
+            return None
+        ent, rel = self._w()
+        return _FusedCE2.apply(ent, rel, s, p, o, t)
 
     def kl_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
         """[n] KL divergence of softmax(score_sp(s, p)) from the rows' normalised multi-hot labels

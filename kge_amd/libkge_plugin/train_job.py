@@ -31,6 +31,22 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
         result.prepare_time -= time.time()
         triples = batch["triples"][subbatch_slice].to(self.device)
         result.prepare_time += time.time()
+        if hasattr(self.model, "loss_sp_po"):
+            # both directions from one scoring launch and one pair of gradient products; the sum of
+            # the two losses is back-propagated once (the reference does it in two passes:
+            # the same gradients, accumulated)
+            result.forward_time -= time.time()
+            rows = self.model.loss_sp_po(triples[:, 0], triples[:, 1], triples[:, 2])
+            if rows is not None:
+                loss_value = rows.sum() / batch_size
+                result.avg_loss += loss_value.item()
+                result.forward_time += time.time()
+                result.backward_time -= time.time()
+                if not self.is_forward_only:
+                    loss_value.backward()
+                result.backward_time += time.time()
+                return
+            result.forward_time += time.time()
         for loss_rows_fn in (lambda: self.model.loss_sp(triples[:, 0], triples[:, 1], triples[:, 2]),
                              lambda: self.model.loss_po(triples[:, 1], triples[:, 2], triples[:, 0])):
             result.forward_time -= time.time()

@@ -207,6 +207,15 @@ class KgeModel(torch.nn.Module):
             return _FusedCE.apply("sp", self._entity_embedder.weight, self._relation_embedder.weight, s, p, o, t)
         return torch.nn.functional.cross_entropy(self.score_sp(s, p), o.long(), reduction="none")
 
+    def loss_sp_po(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
+        """[2n]: loss_sp(s, p, o) followed by loss_po(p, o, s) -- both directions of a 1vsAll batch
+        from one scoring launch and one pair of gradient products (train_1vsAll.py:64-81 sums and
+        back-propagates the two separately)."""
+        t = self._ce_tables()
+        if t is not None:
+            return _FusedCE2.apply(self._entity_embedder.weight, self._relation_embedder.weight, s, p, o, t)
+        return torch.cat([self.loss_sp(s, p, o), self.loss_po(p, o, s)])
+
     def loss_po(self, p: Tensor, o: Tensor, s: Tensor) -> Tensor:
         """Per-row cross entropy of score_po(p, o) against the true subjects s."""
         t = self._ce_tables()
@@ -403,6 +412,30 @@ class _FusedCE(torch.autograd.Function):
         _scatter_rows(gr, p, g_p)
         _scatter_rows(ge, a, g_a)  # ge [E, d] is fresh: the dense target gradient + the query rows
         return None, ge, gr, None, None, None, None
+
+
+class _FusedCE2(torch.autograd.Function):
+    """Both directions of a 1vsAll batch (kge_ce_sp_po_fwd / _bwd): [2n] loss rows, sp_ queries
+    first; one scoring launch and one pair of gradient products for the whole batch."""
+
+    @staticmethod
+    def forward(ctx, ent, rel, s, p, o, tables16):
+        loss_rows, lse = engine.ce_sp_po_fwd(tables16, s, p, o)
+        ctx.t16, ctx.idx, ctx.rel_shape = tables16, (s, p, o), rel.shape
+        ctx.save_for_backward(lse)
+        return loss_rows
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        s, p, o = ctx.idx
+        (lse,) = ctx.saved_tensors
+        g_a, g_p, ge = engine.ce_sp_po_bwd(ctx.t16, s, p, o, lse, g_rows=g_rows.contiguous())
+        n = g_a.shape[0] // 2
+        gr = torch.zeros(ctx.rel_shape, dtype=torch.float32, device=ge.device)
+        pl = p.reshape(-1).long()
+        gr.index_add_(0, torch.cat([pl, pl]), g_p)
+        ge.index_add_(0, torch.cat([s.reshape(-1).long(), o.reshape(-1).long()]), g_a)
+        return ge, gr, None, None, None, None
 
 
 class _FusedKL(torch.autograd.Function):

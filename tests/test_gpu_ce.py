@@ -321,3 +321,55 @@ def test_ce_label_out_of_range_gives_nan_and_empty_batch(eng):
     e = torch.zeros(0, dtype=torch.int64, device=DEV)
     l0, z0 = eng.ce_fwd(T, "sp", e, e, e)
     assert l0.numel() == 0 and z0.numel() == 0
+
+
+# ---- both directions at once (kge_ce_sp_po_fwd / _bwd) ---------------------------------------------
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:])
+def test_ce_sp_po_equals_the_two_one_sided_calls(eng, model, d, E, R, n, scale):
+    """Forward: the [2n] rows are the one-sided results up to the f32 rounding of the log-sum-exp
+    merge (same kernel and scores, the side is a per-row-group choice of operand -- but twice the
+    row groups means a different split of the columns into groups): |diff| <= 2e-6 * max(1, |lse|),
+    bit for bit when the split is the same.  Backward: the products sum over 2n rows at once, so
+    gradients agree to f32 summation order / bf16 rounding of d loss / d score at the changed
+    lse bits (relative Frobenius error <= 1e-4)."""
+    ent, rel, s, p, o = _case(7 * d + n, model, d, E, R, n, scale)
+    T = _tables(eng, model, ent, rel)
+    ts, tp, to = _t(s), _t(p), _t(o)
+    loss2, lse2 = eng.ce_sp_po_fwd(T, ts, tp, to)
+    l_sp, z_sp = eng.ce_fwd(T, "sp", ts, tp, to)
+    l_po, z_po = eng.ce_fwd(T, "po", to, tp, ts)
+    for got, want in ((loss2, torch.cat([l_sp, l_po])), (lse2, torch.cat([z_sp, z_po]))):
+        tol = 2e-6 * torch.clamp(torch.cat([z_sp, z_po]).abs(), min=1.0)
+        assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
+    rng = np.random.default_rng(3)
+    g_rows = _t((rng.random(2 * n).astype(np.float32) + 0.5) / n)
+    g_a, g_p, g_t = eng.ce_sp_po_bwd(T, ts, tp, to, lse2, g_rows=g_rows)
+    a1, p1, t1 = eng.ce_bwd(T, "sp", ts, tp, to, z_sp, g_rows=g_rows[:n].contiguous())
+    a2, p2, t2 = eng.ce_bwd(T, "po", to, tp, ts, z_po, g_rows=g_rows[n:].contiguous())
+    for nm, got, want in (("g_a", g_a, torch.cat([a1, a2])), ("g_p", g_p, torch.cat([p1, p2])), ("g_t", g_t, t1 + t2)):
+        rel_err = float((got - want).norm() / want.norm())
+        assert rel_err <= 1e-4, (nm, rel_err)
+    # strided int32 triple columns, as the training job passes them
+    tri = torch.stack([ts, tp, to], 1).to(torch.int32)
+    l3, z3 = eng.ce_sp_po_fwd(T, tri[:, 0], tri[:, 1], tri[:, 2])
+    assert torch.equal(l3, loss2) and torch.equal(z3, lse2)
+
+
+def test_model_level_two_sided_loss():
+    from kge_amd import model as km
+    E, R, d, n = 3000 + 5, 11, 256, 300
+    torch.manual_seed(0)
+    m = km.create("complex", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(2)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    m.zero_grad()
+    rows = m.loss_sp_po(s, p, o)
+    (rows.sum() / n).backward()
+    g2 = [x.grad.clone() for x in m.parameters()]
+    m.zero_grad()
+    r_sp, r_po = m.loss_sp(s, p, o), m.loss_po(p, o, s)
+    torch.testing.assert_close(rows.detach(), torch.cat([r_sp, r_po]).detach(), rtol=2e-6, atol=2e-6)
+    (r_sp.sum() / n).backward()
+    (r_po.sum() / n).backward()
+    for a, b in zip(g2, [x.grad for x in m.parameters()]):
+        assert float((a - b).norm() / b.norm()) <= 1e-4

@@ -157,6 +157,9 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type)
                 lambda self, s, p, o: F.cross_entropy(self.score_sp(s, p), o.long(), reduction="none"), m)
             m.loss_po = types.MethodType(
                 lambda self, p, o, s: F.cross_entropy(self.score_po(p, o), s.long(), reduction="none"), m)
+            if train_type == "hip_1vsAll" and os.environ.get("KGE_TEST_TWO_SIDED", "1") == "1":
+                m.loss_sp_po = types.MethodType(
+                    lambda self, s, p, o: torch.cat([self.loss_sp(s, p, o), self.loss_po(p, o, s)]), m)
             m.kl_loss_sp = types.MethodType(
                 lambda self, s, p, rp, col: Mirror._kl_composed(self.score_sp(s, p), rp, col), m)
             m.kl_loss_po = types.MethodType(

@@ -48,6 +48,12 @@ def step(m, opt):
     opt.step()
 
 
+def step_fused2(m, opt):  # both directions from one scoring launch / one pair of gradient products
+    opt.zero_grad(set_to_none=True)
+    m.loss_sp_po(s, p, o).sum().backward()
+    opt.step()
+
+
 def step_fused(m, opt):  # loss fused into the scoring kernel (kge_ce_fwd / kge_ce_bwd)
     opt.zero_grad(set_to_none=True)
     m.loss_sp(s, p, o).sum().backward()
@@ -82,19 +88,21 @@ for name in ("complex", "distmult"):
     m = km.create(name, E, R, d, device=dev, score_dtype=torch.bfloat16)
     opt = HipAdagrad(m.parameters(), lr=0.1, bf16_copies=True)
     res["... + one-pass Adagrad with bf16 copies"] = timeit(lambda: step_fused(m, opt))
+    m = km.create(name, E, R, d, device=dev, score_dtype=torch.bfloat16)
+    opt = HipAdagrad(m.parameters(), lr=0.1, bf16_copies=True)
+    res["... + both directions in one pass"] = timeit(lambda: step_fused2(m, opt))
     # the same step captured once into a hipGraph and replayed: no per-launch host work at all
     m = km.create(name, E, R, d, device=dev, score_dtype=torch.bfloat16)
     opt = HipAdagrad(m.parameters(), lr=0.1, bf16_copies=True)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(3): step_fused(m, opt)
+        for _ in range(3): step_fused2(m, opt)
     torch.cuda.current_stream().wait_stream(side)
     graph = torch.cuda.CUDAGraph()
     opt.zero_grad(set_to_none=True)
     with torch.cuda.graph(graph):
-        m.loss_sp(s, p, o).sum().backward()
-        m.loss_po(p, o, s).sum().backward()
+        m.loss_sp_po(s, p, o).sum().backward()
         opt.step()
     res["... replayed as one hipGraph"] = timeit(graph.replay)
     print(name, " | ".join(f"{k}: {v:.2f} ms" for k, v in res.items()))
@@ -107,7 +115,7 @@ from kge_amd.optim import Adagrad as HipAdagrad
 m2 = km.create("complex", E, R, d, device=dev, score_dtype=torch.bfloat16)
 opt2 = HipAdagrad(m2.parameters(), lr=0.1, bf16_copies=True)
 for tag, fn, m, opt in (("composed loss", step, m, opt), ("fused loss", step_fused, m, opt),
-                        ("fused loss + one-pass Adagrad with bf16 copies", step_fused, m2, opt2)):
+                        ("fused loss, both directions in one pass + one-pass Adagrad with bf16 copies", step_fused2, m2, opt2)):
     for _ in range(3): fn(m, opt)
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
