@@ -295,6 +295,15 @@ int kge_ce_sp_po_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o,
                      float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes,
                      void* stream);
 
+/* kge_ce_sp_po_bwd with the scatter-add of the row gradients done by the library:
+ * grad_ent [num_ent, dim] and grad_rel [num_rel, rel_dim] (contiguous f32, OVERWRITTEN) receive the
+ * complete gradients of both tables -- what autograd accumulates into `.grad` for the reference
+ * (the dense target gradient, plus the gathered s / o rows, plus the gathered relation rows). */
+int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                           const float* lse, const float* g_rows, float g_scalar,
+                           float* grad_ent, float* grad_rel, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
 /* KvsAll variant: KL divergence of softmax(score(i, .)) from the row's normalised multi-hot
  * labels, lbl_col[lbl_rowptr[i] .. lbl_rowptr[i+1]) (int64 CSR on the device, entity ids unique
  * per row), y_ij = 1/k_i:

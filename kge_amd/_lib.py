@@ -78,6 +78,8 @@ PROTOTYPES = {
     "kge_ce_sp_po_fwd": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_ce_sp_po_bwd": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, ctypes.c_float, c_vp,
                                         c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kge_ce_sp_po_bwd_accum": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, ctypes.c_float,
+                                              c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_kl_fwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
     "kge_kl_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp,

@@ -72,7 +72,8 @@ int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R
                 hipStream_t st);
 int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, const float* lse, const float* g_rows, float g_scalar, float* g_a,
-                float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
+                float* g_p, float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, void* ws,
+                long long ws_bytes, hipStream_t st);
 int run_adagrad(float* param, const float* grad, float* sum, long long count, float minus_clr, float weight_decay,
                 float eps, unsigned short* copy16, hipStream_t st);
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
@@ -480,8 +481,20 @@ int kge_ce_sp_po_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o,
   if (n > 0 && (!lse || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
   const kge_index all = {nullptr, 0, 0, 1};
   return run_ce2_bwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
-                     t->num_ent, lse, g_rows, g_scalar, g_a, g_p, g_tgt, workspace, workspace_bytes,
+                     t->num_ent, lse, g_rows, g_scalar, g_a, g_p, g_tgt, nullptr, 0, 0, workspace, workspace_bytes,
                      (hipStream_t)stream);
+}
+
+int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, const float* lse,
+                           const float* g_rows, float g_scalar, float* grad_ent, float* grad_rel, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+  int rc = ce_check(t, KGE_SP_, s, p, o, n);
+  if (rc) return rc;
+  if (!grad_ent || !grad_rel || (n > 0 && !lse)) return KGE_ERR_INVALID_ARG;
+  const kge_index all = {nullptr, 0, 0, 1};
+  return run_ce2_bwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
+                     t->num_ent, lse, g_rows, g_scalar, nullptr, nullptr, grad_ent, grad_rel, t->num_rel,
+                     t->rel_dim, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int kge_kl_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,

@@ -385,7 +385,12 @@ __device__ __forceinline__ float bwdg_w(const unsigned short* p, long long k) {
 
 template <int SCORER>
 __global__ __launch_bounds__(256) void bwdg_build_q16_kernel(Operand A, Operand R, int dir, int d, long long n,
-                                                             unsigned short* __restrict__ Q) {
+                                                             unsigned short* __restrict__ Q, Operand A2) {
+  if (blockIdx.y == 1) {  // two-sided launch: the _po queries, rows [n, 2n)
+    A = A2;
+    dir = KGE_PO_;
+    Q += n * d;
+  }
   const int h = SCORER == KGE_COMPLEX ? d / 2 : d;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long i = t / h;
@@ -409,36 +414,65 @@ __global__ __launch_bounds__(256) void bwdg_build_q16_kernel(Operand A, Operand 
   if (SCORER == KGE_COMPLEX) q[h + c] = (unsigned short)(pk >> 16);
 }
 
+// acc_ent == NULL: row gradients written to g_a (in place over dQ) / g_p.  Otherwise they are added
+// straight into table gradients (float atomics; the scatter-add of the gathered rows, which the
+// reference gets from autograd's index backward): acc_ent[A.idx[i], :] += ..., acc_rel[R.idx[i], :] += ...
 template <int SCORER>
 __global__ __launch_bounds__(256) void bwdg_chain16_kernel(Operand A, Operand R, int dir, int d, long long n,
-                                                           float* __restrict__ g_a, float* __restrict__ g_p) {
+                                                           float* __restrict__ g_a, float* __restrict__ g_p,
+                                                           Operand A2, float* __restrict__ acc_ent,
+                                                           long long acc_ent_ld, float* __restrict__ acc_rel,
+                                                           long long acc_rel_ld) {
+  if (blockIdx.y == 1) {  // two-sided launch: the _po queries, rows [n, 2n)
+    A = A2;
+    dir = KGE_PO_;
+    g_a += n * d;
+    if (g_p != nullptr) g_p += n * d;
+  }
   const int h = SCORER == KGE_COMPLEX ? d / 2 : d;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long i = t / h;
   const int c = (int)(t % h);
   if (i >= n) return;
-  const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, i) * A.ld;
-  const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, i) * R.ld;
+  const long long ia = index_at(A.idx, i), ir = index_at(R.idx, i);
+  const unsigned short* a = (const unsigned short*)A.base + ia * A.ld;
+  const unsigned short* r = (const unsigned short*)R.base + ir * R.ld;
   float* ga = g_a + i * d;
-  float* gp = g_p + i * d;
+  float va0, va1 = 0.0f, vp0, vp1 = 0.0f;
   if (SCORER == KGE_DISTMULT) {
     const float dq = ga[c];
-    ga[c] = dq * bwdg_w(r, c);
-    gp[c] = dq * bwdg_w(a, c);
+    va0 = dq * bwdg_w(r, c);
+    vp0 = dq * bwdg_w(a, c);
+  } else {
+    const float dre = ga[c], dim_ = ga[h + c];
+    const float are = bwdg_w(a, c), aim = bwdg_w(a, h + c), rre = bwdg_w(r, c), rim = bwdg_w(r, h + c);
+    if (dir == KGE_SP_) {
+      va0 = dre * rre + dim_ * rim;
+      va1 = dim_ * rre - dre * rim;
+      vp0 = dre * are + dim_ * aim;
+      vp1 = dim_ * are - dre * aim;
+    } else {
+      va0 = dre * rre - dim_ * rim;
+      va1 = dre * rim + dim_ * rre;
+      vp0 = dre * are + dim_ * aim;
+      vp1 = dre * aim - dim_ * are;
+    }
+  }
+  if (acc_ent != nullptr) {
+    unsafeAtomicAdd(acc_ent + ia * acc_ent_ld + c, va0);
+    unsafeAtomicAdd(acc_rel + ir * acc_rel_ld + c, vp0);
+    if (SCORER == KGE_COMPLEX) {
+      unsafeAtomicAdd(acc_ent + ia * acc_ent_ld + h + c, va1);
+      unsafeAtomicAdd(acc_rel + ir * acc_rel_ld + h + c, vp1);
+    }
     return;
   }
-  const float dre = ga[c], dim_ = ga[h + c];
-  const float are = bwdg_w(a, c), aim = bwdg_w(a, h + c), rre = bwdg_w(r, c), rim = bwdg_w(r, h + c);
-  if (dir == KGE_SP_) {
-    ga[c] = dre * rre + dim_ * rim;
-    ga[h + c] = dim_ * rre - dre * rim;
-    gp[c] = dre * are + dim_ * aim;
-    gp[h + c] = dim_ * are - dre * aim;
-  } else {
-    ga[c] = dre * rre - dim_ * rim;
-    ga[h + c] = dre * rim + dim_ * rre;
-    gp[c] = dre * are + dim_ * aim;
-    gp[h + c] = dre * aim - dim_ * are;
+  float* gp = g_p + i * d;
+  ga[c] = va0;
+  gp[c] = vp0;
+  if (SCORER == KGE_COMPLEX) {
+    ga[h + c] = va1;
+    gp[h + c] = vp1;
   }
 }
 
@@ -466,7 +500,7 @@ static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Op
                            float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
   const unsigned qblocks = (unsigned)((n * half + 255) / 256);
-  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, Q16);
+  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, Q16, A);
   const unsigned short* T = (const unsigned short*)TG.base;
   long long ldt = TG.ld;
   if (TG.idx.ptr != nullptr) {  // gathered target rows live in g_tgt until dT overwrites it
@@ -481,7 +515,8 @@ static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Op
   const size_t lws_bytes = TG.idx.ptr == nullptr ? (size_t)m * d * sizeof(float) : 0;
   if (!gemm_long_k(1, d, n, m, T, ldt, G16, mp, g_a, (float*)lws, lws_bytes, st)) return KGE_ERR_UNSUPPORTED;
   if (!lt_gemm(1, 0, 1, d, m, n, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st)) return KGE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p);
+  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p, A,
+                     (float*)nullptr, 0LL, (float*)nullptr, 0LL);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
@@ -491,27 +526,27 @@ static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Op
 template <int SCORER>
 static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Operand& R, const Operand& TG, int d,
                                long long n, long long m, const unsigned short* G16, long long mp,
-                               unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
+                               unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, float* acc_rel,
+                               long long acc_rel_ld, hipStream_t st) {
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
-  const unsigned qblocks = (unsigned)((n * half + 255) / 256);
-  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A1, R, KGE_SP_, d, n, Q16);
-  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A2, R, KGE_PO_, d, n,
-                     Q16 + n * d);
+  const dim3 qgrid((unsigned)((n * half + 255) / 256), 2);  // y = side
+  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, Q16, A2);
   if (TG.idx.ptr != nullptr) return KGE_ERR_UNSUPPORTED;  // all entities only
   const unsigned short* T = (const unsigned short*)TG.base;
   if (!gemm_long_k(1, d, 2 * n, m, T, TG.ld, G16, mp, g_a, g_tgt, (size_t)m * d * sizeof(float), st))
     return KGE_ERR_UNSUPPORTED;
   if (!lt_gemm(1, 0, 1, d, m, 2 * n, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st)) return KGE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A1, R, KGE_SP_, d, n, g_a, g_p);
-  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A2, R, KGE_PO_, d, n,
-                     g_a + n * d, g_p + n * d);
+  // acc_rel != NULL: the row gradients go straight into the table gradients -- the entity rows
+  // on top of dT in g_tgt [m, d] (all entities: row ids are table rows), the relation rows into acc_rel
+  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, g_a, g_p, A2,
+                     acc_rel != nullptr ? g_tgt : (float*)nullptr, (long long)d, acc_rel, acc_rel_ld);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
 int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A2, const Operand& R,
                                  const Operand& TG, int d, long long n, long long m, const unsigned short* G16,
                                  long long mp, unsigned short* Q16, float* g_a, float* g_p, float* g_tgt,
-                                 hipStream_t st) {
+                                 float* acc_rel, long long acc_rel_ld, hipStream_t st) {
   if (n == 0 || m == 0) return KGE_OK;
   if (2 * n >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31))
     return KGE_ERR_UNSUPPORTED;
@@ -520,9 +555,11 @@ int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A
   tl_capturing = capturing;
   int rc = KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
-    rc = bwdg_products16_two<KGE_COMPLEX>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+    rc = bwdg_products16_two<KGE_COMPLEX>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
+                                          acc_rel_ld, st);
   else if (scorer == KGE_DISTMULT)
-    rc = bwdg_products16_two<KGE_DISTMULT>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+    rc = bwdg_products16_two<KGE_DISTMULT>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
+                                           acc_rel_ld, st);
   tl_capturing = false;
   return rc;
 }

@@ -36,7 +36,7 @@ int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operan
 int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A2, const Operand& R,
                                  const Operand& TG, int d, long long n, long long m, const unsigned short* G16,
                                  long long mp, unsigned short* Q16, float* g_a, float* g_p, float* g_tgt,
-                                 hipStream_t st);
+                                 float* acc_rel, long long acc_rel_ld, hipStream_t st);
 
 // merge the column groups of a row: M = max_c m_c, L = sum_c l_c exp(m_c - M).  One wave per row,
 // lanes over the column groups, xor-butterfly reductions (fixed order: deterministic).
@@ -270,7 +270,8 @@ static inline long long ce2_rows(long long n) { return 2 * ((n + 127) / 128) * 1
 long long ce2_workspace_bytes(int d, long long n, long long m) {
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));  // sized for two sides
   const long long fwd = al256(2 * n * pairs_bf16_v3_column_groups(ce2_rows(n), m) * 8) + al256(2 * n * 4);
-  const long long bwd = al256(2 * n * ce_ld16(m) * 2) + al256(2 * n * (long long)d * 2);
+  // backward: G16, Q16 and (kge_ce_sp_po_bwd_accum) the f32 dQ rows
+  const long long bwd = al256(2 * n * ce_ld16(m) * 2) + al256(2 * n * (long long)d * 2) + al256(2 * n * (long long)d * 4);
   return coop + (fwd > bwd ? fwd : bwd);
 }
 
@@ -299,11 +300,23 @@ int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R
 
 int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, const float* lse, const float* g_rows, float g_scalar, float* g_a,
-                float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st) {
-  if (n == 0) return KGE_OK;
+                float* g_p, float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, void* ws,
+                long long ws_bytes, hipStream_t st) {
+  // acc_rel != NULL (kge_ce_sp_po_bwd_accum): g_a / g_p are not returned; the row gradients are added
+  // into g_tgt (on top of dT) and into the zeroed acc_rel [acc_rel_rows, acc_rel_ld]
+  if (acc_rel != nullptr &&
+      hipMemsetAsync(acc_rel, 0, (size_t)acc_rel_rows * acc_rel_ld * sizeof(float), st) != hipSuccess)
+    return KGE_ERR_LAUNCH;
+  if (n == 0) {
+    if (acc_rel != nullptr && hipMemsetAsync(g_tgt, 0, (size_t)m * d * sizeof(float), st) != hipSuccess)
+      return KGE_ERR_LAUNCH;
+    return KGE_OK;
+  }
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce2_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
   const long long ld16 = ce_ld16(m);
+  if (acc_rel != nullptr)
+    g_a = (float*)((char*)ws + coop + al256(2 * n * ld16 * 2) + al256(2 * n * (long long)d * 2));
   CeArgs ce{};
   ce.label = O.idx;
   ce.label2 = S.idx;
@@ -318,7 +331,8 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(2 * n * ld16 * 2));
   const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, S, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
-  return run_pairs_bwd_products16_two(scorer, S, O, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
+  return run_pairs_bwd_products16_two(scorer, S, O, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, acc_rel,
+                                      acc_rel_ld, st);
 }
 
 void ce_set_stamps(unsigned long long* p) { g_ce_stamps = p; }

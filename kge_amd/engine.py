@@ -587,6 +587,25 @@ def ce_sp_po_bwd(t: Tables, s, p, o, lse, g_rows=None, g_scalar: float = 1.0):
     return g_a, g_p, g_t
 
 
+def ce_sp_po_bwd_accum(t: Tables, s, p, o, lse, g_rows=None, g_scalar: float = 1.0):
+    """Backward of ce_sp_po_fwd with the row scatter-adds done by the library: the complete
+    (grad_entities [E, d], grad_relations [R, d]) of the two tables."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = keep[0].numel()
+    lse = _f32c(lse, t.device)
+    gr = None if g_rows is None else _f32c(g_rows, t.device)
+    ge, grel = _empty(tuple(t.ent.shape), t.device), _empty(tuple(t.rel.shape), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce2_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_sp_po_bwd_accum(
+            ctypes.byref(tc), si, pi, oi, n, lse.data_ptr(), None if gr is None else gr.data_ptr(),
+            float(g_scalar), ge.data_ptr(), grel.data_ptr(), ws, wsb, st), "kge_ce_sp_po_bwd_accum")
+    return ge, grel
+
+
 def _csr64(rowptr, col, dev):
     rp = rowptr.to(device=dev, dtype=torch.int64).contiguous()
     cl = col.to(device=dev, dtype=torch.int64).contiguous()

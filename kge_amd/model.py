@@ -429,12 +429,8 @@ class _FusedCE2(torch.autograd.Function):
     def backward(ctx, g_rows):
         s, p, o = ctx.idx
         (lse,) = ctx.saved_tensors
-        g_a, g_p, ge = engine.ce_sp_po_bwd(ctx.t16, s, p, o, lse, g_rows=g_rows.contiguous())
-        n = g_a.shape[0] // 2
-        gr = torch.zeros(ctx.rel_shape, dtype=torch.float32, device=ge.device)
-        pl = p.reshape(-1).long()
-        gr.index_add_(0, torch.cat([pl, pl]), g_p)
-        ge.index_add_(0, torch.cat([s.reshape(-1).long(), o.reshape(-1).long()]), g_a)
+        # complete table gradients from the library (the scatter-add of the gathered rows included)
+        ge, gr = engine.ce_sp_po_bwd_accum(ctx.t16, s, p, o, lse, g_rows=g_rows.contiguous())
         return ge, gr, None, None, None, None
 
 

@@ -373,3 +373,22 @@ def test_model_level_two_sided_loss():
     (r_po.sum() / n).backward()
     for a, b in zip(g2, [x.grad for x in m.parameters()]):
         assert float((a - b).norm() / b.norm()) <= 1e-4
+
+
+def test_ce_sp_po_bwd_accum_equals_scatter_of_row_gradients(eng):
+    """kge_ce_sp_po_bwd_accum (row gradients added into the table gradients by float atomics) against
+    kge_ce_sp_po_bwd + index_add: same values up to the order of the atomic adds (repeated s / o / p
+    indices in the batch exercise it)."""
+    ent, rel, s, p, o = _case(21, "complex", 256, 500, 3, 300, 0.3)   # few relations, repeated entities
+    T = _tables(eng, "complex", ent, rel)
+    ts, tp, to = _t(s), _t(p), _t(o)
+    n = len(s)
+    loss, lse = eng.ce_sp_po_fwd(T, ts, tp, to)
+    g_rows = torch.full((2 * n,), 1.0 / n, device=DEV)
+    g_a, g_p, g_t = eng.ce_sp_po_bwd(T, ts, tp, to, lse, g_rows=g_rows)
+    want_e = g_t.clone().index_add_(0, torch.cat([ts, to]), g_a)
+    want_r = torch.zeros(3, 256, device=DEV).index_add_(0, torch.cat([tp, tp]), g_p)
+    ge, gr = eng.ce_sp_po_bwd_accum(T, ts, tp, to, lse, g_rows=g_rows)
+    for nm, got, want in (("ent", ge, want_e), ("rel", gr, want_r)):
+        rel_err = float((got - want).norm() / want.norm())
+        assert rel_err <= 1e-5, (nm, rel_err)
