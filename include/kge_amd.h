@@ -181,6 +181,16 @@ int kge_score_emb(const kge_tables* t, int combine, const void* s_emb,
                   float* out, int64_t ldo, void* workspace,
                   int64_t workspace_bytes, void* stream);
 
+/* score_sp_po on dense rows (KgeModel.score_sp_po, kge/model/kge_model.py:749-789, after its
+ * embed() calls): s_emb / p_emb / o_emb are the n query rows, tgt_emb the m target rows;
+ * out[i, :m] = sp_ scores, out[i, m:2m] = _po scores (ldo >= 2m), one two-sided launch when the
+ * bf16 matrix-core kernel applies (workspace as for kge_score_sp_po).  Used by the entity-sharded
+ * path, whose query rows arrive by all-gather. */
+int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb,
+                        int64_t p_ld, const void* o_emb, int64_t o_ld, int64_t n,
+                        const void* tgt_emb, int64_t tgt_ld, int64_t m, float* out, int64_t ldo,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- ranking ------------------------------------------------------------ */
 /* For each row i of scores[n, c] (leading dim lds) and its true score:
  *   x = NaN -> -inf; filtered columns -> -inf; t = NaN -> -inf

@@ -325,6 +325,30 @@ int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s
   return KGE_ERR_INVALID_ARG;
 }
 
+int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb, int64_t p_ld,
+                        const void* o_emb, int64_t o_ld, int64_t n, const void* tgt_emb, int64_t tgt_ld, int64_t m,
+                        float* out, int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_tables(t, false);
+  if (rc) return rc;
+  if (!s_emb || !p_emb || !o_emb || !tgt_emb || n < 0 || m < 0) return KGE_ERR_INVALID_ARG;
+  if (s_ld < t->dim || o_ld < t->dim || tgt_ld < t->dim || p_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
+  if ((!out && n * m > 0) || ldo < 2 * m) return KGE_ERR_INVALID_ARG;
+  const Index ident{nullptr, 1, KGE_I64};
+  Operand S{s_emb, s_ld, ident}, P{p_emb, p_ld, ident}, O{o_emb, o_ld, ident}, TG{tgt_emb, tgt_ld, ident};
+  hipStream_t st = (hipStream_t)stream;
+  if (workspace && n > 0 && m > 0 &&
+      !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) &&
+      pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
+      pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
+    const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr,
+                                      workspace, workspace_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
+    if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;
+  }
+  rc = pairs_dispatch(t, KGE_SP_, S, P, TG, n, m, out, ldo, workspace, workspace_bytes, st);
+  if (rc) return rc;
+  return pairs_dispatch(t, KGE_PO_, O, P, TG, n, m, out ? out + m : out, ldo, workspace, workspace_bytes, st);
+}
+
 int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
                     const float* true_scores, const int64_t* lbl_rowptr,
                     const int64_t* lbl_col, int64_t col_offset, const int64_t* true_col,

@@ -292,6 +292,36 @@ def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, fl
     return out.view(n, -1)
 
 
+def score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm: float = 1.0, flags: int = 0, out=None):
+    """[n, 2m]: score_emb(.., "sp_") against `targets` followed by score_emb(.., "_po") against
+    `targets`, for dense query rows (one two-sided launch on the bf16 matrix-core path)."""
+    for x in (s_emb, p_emb, o_emb, targets):
+        _require_gpu(x, "embedding")
+    if len({s_emb.dtype, p_emb.dtype, o_emb.dtype, targets.dtype}) != 1:
+        raise TypeError("kge_amd: embeddings must share a dtype")
+    s_emb, p_emb, o_emb, targets = (x if x.stride(-1) == 1 else x.contiguous() for x in (s_emb, p_emb, o_emb, targets))
+    sc = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
+    n, m = p_emb.shape[0], targets.shape[0]
+    d, dr = s_emb.shape[1], p_emb.shape[1]
+    if out is None:
+        out = _empty((n, 2 * m), s_emb.device)
+    key = (s_emb.dtype, sc, d, dr, float(l_norm), int(flags))
+    tc = _EMB_TC.get(key)
+    if tc is None:
+        tc = _EMB_TC[key] = KgeTables(None, None, _dtype_code(s_emb), sc, 0, 0, d, dr, d, dr, float(l_norm),
+                                      int(flags))
+    with _on_device(s_emb.device):
+        st = _stream_handle(s_emb.device)
+        ws, wsb = _workspace(tc, n, s_emb.device, True, st)
+        rc = _lib.lib().kge_score_emb_sp_po(
+            ctypes.byref(tc), s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(), p_emb.stride(0),
+            o_emb.data_ptr(), o_emb.stride(0), n, targets.data_ptr(), targets.stride(0), m, out.data_ptr(),
+            out.stride(0) if n > 1 else max(2 * m, 1), ws, wsb, st)
+        if rc:
+            _lib.check(rc, "kge_score_emb_sp_po")
+    return out
+
+
 def embed(t: Tables, ent_idx=None, rel_idx=None, ent_out=None, rel_out=None):
     """LookupEmbedder.embed for both tables in ONE launch: (ent[ent_idx], rel[rel_idx]); outputs
     may be preallocated (row stride free, e.g. a slice of an exchange buffer)."""

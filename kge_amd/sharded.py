@@ -72,6 +72,15 @@ class ShardedEntityTable:
         return self.backend.score_emb(self.scorer, self.ent_local, self.rel[p.long()], o_rows, "_po",
                                       self.l_norm)
 
+    def score_sp_po(self, s: torch.Tensor, p: torch.Tensor, o: torch.Tensor):
+        """[n, 2 E_g]: score_sp and score_po slabs side by side from one launch (backends with
+        score_emb_sp_po), else the two calls."""
+        s_rows, o_rows = self.gather_entity_rows(s), self.gather_entity_rows(o)
+        if hasattr(self.backend, "score_emb_sp_po"):
+            return self.backend.score_emb_sp_po(self.scorer, s_rows, self.rel[p.long()], o_rows, self.ent_local,
+                                                self.l_norm)
+        return torch.cat([self.score_sp(s, p, s_rows), self.score_po(p, o, o_rows)], dim=1)
+
     def true_scores(self, slab: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """Score of each row's true entity, taken from the owner's slab (exchange step 2)."""
         target = target.long()
@@ -113,8 +122,9 @@ class ShardedEntityTable:
         [2 (o, s), 2 (rank, ties), len(filters) + 1, n]."""
         s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
         n, K = triples.shape[0], len(filters_o)
-        sp = self.score_sp(s, p)
-        po = self.score_po(p, o)
+        both = self.score_sp_po(s, p, o)
+        c = both.shape[1] // 2
+        sp, po = both[:, :c], both[:, c:]
         o_true = self.true_scores(sp, o)
         s_true = self.true_scores(po, s)
         counts = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=sp.device)

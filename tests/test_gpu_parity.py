@@ -330,8 +330,17 @@ def test_score_emb_equals_index_level(eng, model):
     _eq("spo", _np(eng.score_emb(model, se, pe, oe, "spo")).reshape(-1), _np(eng.score_spo(T, s, p, o)))
     _eq("sp_", _np(eng.score_emb(model, se, pe, ent, "sp_")), _np(eng.score_sp(T, s, p)))
     _eq("_po", _np(eng.score_emb(model, ent, pe, oe, "_po")), _np(eng.score_po(T, p, o)))
+    _eq("sp_po (dense rows)", _np(eng.score_emb_sp_po(model, se, pe, oe, ent)), _np(eng.score_sp_po(T, s, p, o)))
     with pytest.raises(ValueError):
         eng.score_emb(model, se, pe, oe, "s_x")
+    if model in ("complex", "distmult"):  # the two-sided launch of the bf16 matrix-core kernel
+        d5 = 512
+        ent5 = torch.from_numpy(rng.standard_normal((E, d5)).astype(np.float32)).bfloat16().to(DEV)
+        rel5 = torch.from_numpy(rng.standard_normal((R, d5)).astype(np.float32)).bfloat16().to(DEV)
+        T5 = eng.Tables(model, ent5, rel5, 1.0)
+        _eq("bf16 sp_po (dense rows, strided)", _np(eng.score_emb_sp_po(
+            model, torch.cat([ent5[s], ent5[o]], 1)[:, :d5], rel5[p], torch.cat([ent5[s], ent5[o]], 1)[:, d5:], ent5)),
+            _np(eng.score_sp_po(T5, s, p, o)))
 
 
 def test_empty_inputs(eng):

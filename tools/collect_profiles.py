@@ -27,7 +27,7 @@ dbs = glob.glob(f"{src}/prof/**/*_results.db", recursive=True)
 v4_us = None
 if dbs:
     c = sqlite3.connect(dbs[0])
-    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline  (MI355X, round 1 run {tag})",
+    lines = [f"rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-one-sided  (MI355X, round 1 run {tag})",
              "name | total_calls | total_duration | average | percentage"]
     for r in c.execute("select * from top_kernels"):
         lines.append(" | ".join(str(x) for x in r))

@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*\|SQ_BUSY[A-Z_]*\|GRBM_GUI_ACTIVE\|SQ_WAVE_CYCLES\|SQ_CYCLES" | sort -u > $OUT/avail.txt
-B="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-one-sided"
 N="python $GRAFT_REPO_ROOT/tools/neg_pmc.py"
 run() { # name, counters, cmd
   timeout 300 rocprofv3 --pmc $2 -d $OUT/$1 -o r -- $3 > $OUT/$1.out 2> $OUT/$1.err

@@ -22,10 +22,10 @@ echo "probe exit: $?" >> $OUT/env.log
 for P in bwd_probe ns_probe train_probe eval_probe subset_probe ce_probe ce_phases ce_host; do
   timeout 300 python tools/$P.py 2>&1 | grep -v "amdgpu.ids\|UserWarning\|_warn_once\|ROCTracer" > $OUT/$P.txt
 done
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-one-sided > $GRAFT_REPO_ROOT/$OUT/prof_bench.json 2> $GRAFT_REPO_ROOT/$OUT/prof.err )
 echo "rocprof exit: $?" >> $OUT/env.log
 for C in FETCH_SIZE WRITE_SIZE; do
-( cd /tmp && timeout 300 rocprofv3 --pmc $C -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err )
+( cd /tmp && timeout 300 rocprofv3 --pmc $C -d $GRAFT_REPO_ROOT/$OUT/pmc_$C -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-one-sided > /dev/null 2> $GRAFT_REPO_ROOT/$OUT/pmc_$C.err )
 echo "pmc $C exit: $?" >> $OUT/env.log
 done
 find $OUT/prof -name "*stats*" | head >> $OUT/env.log

@@ -30,15 +30,18 @@ for sub in ("mfma_a", "mfma_b", "mfma_c"):
             L.append(f"  {sub}  {c:30s} dispatches={n:4d} mean/dispatch={v:14.1f}")
 busy = m["SQ_VALU_MFMA_BUSY_CYCLES"]
 n_mfma = busy / 32.0
+sides = int(round(n_mfma / 233472.0))          # 1: score_sp launches, 2: two-sided score_sp_po launches
+wgs = 228 if sides == 1 else 232               # workgroups of the launch (one per CU)
+flops = n_mfma * 32768.0
 L += ["",
-      f"  MFMAs per launch = BUSY/32 = {n_mfma:.0f}  (= 512 x 14592 x 512 / 16384 = 233472 v_mfma_f32_32x32x16_bf16;",
-      f"    SQ_INSTS_VALU_MFMA_MOPS_BF16 = {m.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0):.0f} = 64 x that: 512-flop units)",
+      f"  MFMAs per launch = BUSY/32 = {n_mfma:.0f}  (= {sides} x 512 x 14592 x 512 / 16384 = {sides * 233472} v_mfma_f32_32x32x16_bf16:",
+      f"    no redundant MFMA work; SQ_INSTS_VALU_MFMA_MOPS_BF16 = {m.get('SQ_INSTS_VALU_MFMA_MOPS_BF16', 0):.0f} = 64 x that: 512-flop units)",
       f"  kernel duration {v4_us} us (rocprofv3 --kernel-trace, same command) = {v4_us*1e-6*CLK:.0f} cycles at 2.4 GHz",
       f"  MFMA utilisation, whole chip  = {busy:.0f} / ({v4_us*1e-6*CLK:.0f} x {CUS*SIMDS} SIMDs) = {busy/(v4_us*1e-6*CLK*CUS*SIMDS):.3f}",
-      f"  per consumer SIMD (228 workgroups x 4 consumer waves): {n_mfma/912:.0f} MFMAs x 32 = {n_mfma/912*32:.0f} busy cycles"
-      f" of {v4_us*1e-6*CLK:.0f} = {n_mfma/912*32/(v4_us*1e-6*CLK):.3f}; of the ~13.3k-cycle tile phase = {n_mfma/912*32/13300:.2f}",
-      f"  flops {2*512*14592*512/1e9:.2f} G / {v4_us} us = {2*512*14592*512/v4_us/1e6:.0f} TFLOP/s = "
-      f"{2*512*14592*512/v4_us/1e6/2500:.3f} of the 2.5 PFLOP/s dense bf16 peak (the kernel is HBM-write bound: roofline.bound = hbm)",
+      f"  per consumer SIMD ({wgs} workgroups x 4 consumer waves): {n_mfma/(wgs*4):.0f} MFMAs x 32 = {n_mfma/(wgs*4)*32:.0f} busy cycles"
+      f" of {v4_us*1e-6*CLK:.0f} = {n_mfma/(wgs*4)*32/(v4_us*1e-6*CLK):.3f}",
+      f"  flops {flops/1e9:.2f} G / {v4_us} us = {flops/v4_us/1e6:.0f} TFLOP/s = "
+      f"{flops/v4_us/1e6/2500:.3f} of the 2.5 PFLOP/s dense bf16 peak (the kernel is HBM bound: roofline.bound = hbm)",
       ""]
 L.append("== gather-bound kernels (tools/neg_pmc.py: kge_score_neg, E=40943 d=512 f32, 512 positives x 1000 negatives)")
 tr = sqlite3.connect(f"{out_dir}/neg_trace/r_results.db")
