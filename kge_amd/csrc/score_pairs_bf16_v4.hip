@@ -8,9 +8,13 @@
 //     registers for the whole kernel and do nothing but ds_read_b128 + v_mfma_f32_32x32x16_bf16
 //     (64 per tile, two accumulators); the finished accumulators go to an LDS staging buffer
 //     during the first MFMAs of the next tile;
-//   * loader waves 4-7: stream the target tiles HBM -> LDS with LDS-DMA (ring of two 64 KiB
-//     buffers, a whole tile time ahead) and move the staged scores LDS -> HBM with 16-byte
-//     stores (4 rows x 256 contiguous bytes per instruction).
+//   * loader waves: 4 and 5 stream the target tiles HBM -> LDS with LDS-DMA (ring of two 64 KiB
+//     buffers, a whole tile time ahead; each the pieces of two quarters of a tile), 6 and 7 move
+//     the staged scores LDS -> registers -> HBM with 16-byte stores (4 rows x 256 contiguous bytes
+//     per instruction; each the blocks of two consumers).  One kind of traffic per wave: the
+//     score stores of tile t-2 are issued while the other two waves issue the DMA of tile t+1
+//     (with all four waves doing both in turn the tile period was 3.8 k cycles, the consumers
+//     waiting ~1 k of it at B1; now the 2.7 k-cycle MFMA chain sets it).
 //
 // Why two roles: a vector-memory instruction blocks its wave until the texture addresser takes
 // it (64 B/clk per CU: a tile is 1,024 cycles of loads + 512 of stores against 2,100 cycles of
@@ -23,11 +27,11 @@
 // fragments).  All workgroups are co-resident (grid <= number of CUs; the launcher checks), so
 // the spin-wait cannot deadlock.
 //
-// Synchronisation per tile: two workgroup barriers.  B1(t): tile t has landed (loaders waited
-// for their DMA) / everybody is done with tile t-1's buffer and the staging buffer has been
-// drained.  B2(t), three quarters into the MFMA chain (the loaders need about that long to
-// issue the next tile's DMA; the rest of the chain covers their stores): the scores of tile
-// t-1 are in staging.
+// Synchronisation per tile: two workgroup barriers.  B1(t): tile t has landed (the DMA waves
+// waited for their pieces) / everybody is done with tile t-1's buffer and the staging buffer has
+// been drained into the store waves' registers.  B2(t), three quarters into the MFMA chain: the
+// scores of tile t-1 are in staging; the store waves read them and issue the global stores after
+// B1(t+1).
 #include "common.hpp"
 #include <atomic>
 #include <chrono>
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (SGPR)
-  const int w4 = wave & 3;  // consumer w4 and loader 4 + w4 work on query rows 32*w4 .. 32*w4+31
+  const int w4 = wave & 3;  // consumer w4 works on query rows 32*w4 .. 32*w4+31 of the row group
   // Two-sided launch (score_sp_po, EntityRankingJob's call): row groups [0, rgn1) are the n
   // (s, p, ?) queries, row groups [rgn1, rgn) the n (?, p, o) queries, scored into the column
   // block behind the first one.  One-sided: rgn1 == rgn.
@@ -91,7 +95,6 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     dir = KGE_PO_;
     out += out2_off;
   }
-  const long long row0 = (long long)rgl * V4_ROWS + 32 * w4;  // first query row (within its side)
 
   int dbg_i = 0;
   auto stamp = [&]() {  // optional per-phase timestamps (tools/v2_phases.py); dbg == NULL in production
@@ -142,134 +145,147 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   stamp();  // 1: share built and published
 
   if (wave >= 4) {
-    // =================================== loader waves ===================================
+    // ============ loader waves, split duties: waves 4, 5 stream the target tiles in (each the
+    // pieces of two quarters), waves 6, 7 move the staged scores out (each two consumers' blocks).
+    // A VMEM instruction blocks its wave until the memory pipeline takes it, and the stores are
+    // taken at HBM write speed: with one kind of traffic per wave the score stores of tile t-2 are
+    // issued WHILE the other waves issue the DMA of tile t+1, instead of one after the other.
     const unsigned short* tgb = (const unsigned short*)TG.base;
-    const long long tld2 = TG.ld * 2;  // row stride in bytes
-    const int nfull = (int)(m / V4_TN);  // tiles below this index are fully inside the table
-    // LDS image of a tile: [row][16-B slot], lane-linear for the DMA; the XOR swizzle
-    // (slot ^ (row & 15)) is applied on the SOURCE address.  Piece k of this wave: rows
-    // 16*w4 + RPP*k + lr, so row & 15 = RPP*k | lr.
+    const long long tld2 = TG.ld * 2;
+    const int nfull = (int)(m / V4_TN);
     const int lr = lane / SPR, slot = lane % SPR;
-    unsigned int dvoff[NL];
+    const int j2 = (wave & 1) * 2;  // this wave's quarters: j2, j2 + 1
+    if (wave < 6) {
+      // ------------------------------- DMA waves -------------------------------
+      unsigned int dvoff[NL], dsw[NL];
 #pragma unroll
-    for (int k = 0; k < NL; ++k)
-      dvoff[k] = (unsigned int)(lr * (int)tld2) + (unsigned int)(((slot ^ lr) << 4) ^ ((RPP * k) << 4));
-    // table rows of this wave's 16 target rows of tile tt (lane l & 15: local row 16*w4 + (l & 15));
-    // for an index vector this is a memory load, issued one step ahead of the DMA that needs it
-    auto load_rows = [&](int tt) -> long long {
-      const int tc = tt < ntl ? tt : ntl - 1;
-      long long tr = (long long)(tile_lo + tc) * V4_TN + w4 * 16 + (lane & 15);
-      if (tr >= m) tr = m - 1;  // ragged end of the table: rows clamped to m-1
-      return index_mode<TGMODE>(TG.idx, tr);
-    };
-    auto bcast_row = [&](long long rows, int l) -> long long {  // rows of lane l, wave-uniform
-      const int lo = __builtin_amdgcn_readlane((int)(rows & 0xffffffffLL), l);
-      const int hi = __builtin_amdgcn_readlane((int)(rows >> 32), l);
-      return ((long long)hi << 32) | (unsigned int)lo;
-    };
-    unsigned int dsw[NL];  // swizzled 16-byte slot of this lane within its row, per piece
+      for (int k = 0; k < NL; ++k) {
+        dsw[k] = (unsigned int)(((slot ^ lr) << 4) ^ ((RPP * k) << 4));
+        dvoff[k] = (unsigned int)(lr * (int)tld2) + dsw[k];
+      }
+      auto load_rows = [&](int tt, int w) -> long long {
+        const int tc = tt < ntl ? tt : ntl - 1;
+        long long tr = (long long)(tile_lo + tc) * V4_TN + w * 16 + (lane & 15);
+        if (tr >= m) tr = m - 1;
+        return index_mode<TGMODE>(TG.idx, tr);
+      };
+      auto bcast_row = [&](long long rows, int l) -> long long {
+        const int lo = __builtin_amdgcn_readlane((int)(rows & 0xffffffffLL), l);
+        const int hi = __builtin_amdgcn_readlane((int)(rows >> 32), l);
+        return ((long long)hi << 32) | (unsigned int)lo;
+      };
+      auto tile_dma = [&](int tt, long long rows, int w) {
+        const int tc = tt < ntl ? tt : ntl - 1;
+        const long long trow0 = (long long)(tile_lo + tc) * V4_TN;
+        unsigned int d = (unsigned int)((tt & 1) * TILEB + w * NL * 1024);
+        if (TGMODE == 0 && tile_lo + tc < nfull && tld2 < (1LL << 28)) {
+          const unsigned char* p = (const unsigned char*)tgb + (trow0 + w * 16) * tld2;
+          v4_static_for<0, NL>([&](auto kc) __attribute__((always_inline)) {
+            const unsigned int vo = dvoff[decltype(kc)::value];
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :
+                         : "s"(d), "v"(vo), "s"(p)
+                         : "memory", "m0");
+            p += RPP * tld2;
+            d += 1024;
+          });
+        } else {
 #pragma unroll
-    for (int k = 0; k < NL; ++k) dsw[k] = (unsigned int)(((slot ^ lr) << 4) ^ ((RPP * k) << 4));
-    auto tile_dma = [&](int tt, long long rows) {  // this wave's NL pieces of tile tt into ring buffer tt & 1
-      const int tc = tt < ntl ? tt : ntl - 1;
-      const long long trow0 = (long long)(tile_lo + tc) * V4_TN;
-      unsigned int d = (unsigned int)((tt & 1) * TILEB + w4 * NL * 1024);
-      if (TGMODE == 0 && tile_lo + tc < nfull && tld2 < (1LL << 28)) {
-        // all targets, tile fully inside the table: uniform base (SGPRs) + per-lane 32-bit offset
-        const unsigned char* p = (const unsigned char*)tgb + (trow0 + w4 * 16) * tld2;
-        v4_static_for<0, NL>([&](auto kc) __attribute__((always_inline)) {
-          const unsigned int vo = dvoff[decltype(kc)::value];
-          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                       :
-                       : "s"(d), "v"(vo), "s"(p)
-                       : "memory", "m0");
-          p += RPP * tld2;
-          d += 1024;
-        });
-      } else {  // index vector and / or ragged end of the table: row ids from `rows`
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-          long long r = bcast_row(rows, RPP * k);
-          if (RPP == 2) {
-            const long long r1 = bcast_row(rows, RPP * k + 1);
-            r = lr ? r1 : r;
+          for (int k = 0; k < NL; ++k) {
+            long long r = bcast_row(rows, RPP * k);
+            if (RPP == 2) {
+              const long long r1 = bcast_row(rows, RPP * k + 1);
+              r = lr ? r1 : r;
+            }
+            const unsigned char* src = (const unsigned char*)tgb + r * tld2 + dsw[k];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + d + k * 1024),
+                                             16, 0, 0);
           }
-          const unsigned char* src = (const unsigned char*)tgb + r * tld2 + dsw[k];
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(smem + d + k * 1024),
-                                           16, 0, 0);
+        }
+      };
+      {
+        const long long ra0 = load_rows(0, j2), rb0 = load_rows(0, j2 + 1);
+        const long long ra1 = load_rows(1, j2), rb1 = load_rows(1, j2 + 1);
+        tile_dma(0, ra0, j2);
+        tile_dma(0, rb0, j2 + 1);
+        if (ntl > 1) {
+          tile_dma(1, ra1, j2);
+          tile_dma(1, rb1, j2 + 1);
+        }
+      }
+      long long rna = load_rows(2, j2), rnb = load_rows(2, j2 + 1);
+      __builtin_amdgcn_s_barrier();  // B0
+      for (int tt = 0; tt <= ntl; ++tt) {
+        // VMEM queue of this wave: only tile pieces (2 NL per tile), in order
+        if (tt == 0 && ntl > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // B1(tt)
+        if (tt >= 1 && tt + 1 < ntl) {
+          tile_dma(tt + 1, rna, j2);
+          tile_dma(tt + 1, rnb, j2 + 1);
+          rna = load_rows(tt + 2, j2);
+          rnb = load_rows(tt + 2, j2 + 1);
+        }
+        __builtin_amdgcn_s_barrier();  // B2(tt)
+      }
+      return;
+    }
+    // ------------------------------- store waves -------------------------------
+    const int cl = lane & 15, rq = lane >> 4;
+    const int z = cl ^ rq;
+    unsigned int crd[2], svoff[2][8];
+    unsigned char* out_rb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int w = j2 + u;
+      const long long r0 = (long long)rgl * V4_ROWS + 32 * w;
+      const long long rb = r0 < n ? r0 : n - 1;
+      crd[u] = (unsigned int)(CST0 + w * CSTW + rq * 256);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        long long r = r0 + 4 * i + rq;
+        if (r >= n) r = n - 1;
+        svoff[u][i] = (unsigned int)((r - rb) * ldo * 4) + (unsigned int)(cl * 16);
+      }
+      out_rb[u] = (unsigned char*)(out + rb * ldo);
+    }
+    f32x4 cv[2][8];
+    auto read_staging = [&]() {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          cv[u][i] = *reinterpret_cast<const f32x4*>(smem + crd[u] + i * 1024 + ((z ^ ((4 * i) & 15)) << 4));
+    };
+    auto store_tile = [&](int tt) {
+      const long long col0 = (long long)(tile_lo + tt) * V4_TN;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (col0 + V4_TN <= m) {
+          unsigned char* sbase = out_rb[u] + col0 * 4;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4v4u*>(sbase + svoff[u][i]) = cv[u][i];
+        } else {  // ragged end of the table (always this workgroup's last tile)
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col0 + 4 * cl + e < m)
+                *reinterpret_cast<float*>(out_rb[u] + (col0 + e) * 4 + svoff[u][i]) = cv[u][i][e];
         }
       }
     };
-    {
-      const long long rows0 = load_rows(0), rows1 = load_rows(1);
-      tile_dma(0, rows0);
-      if (ntl > 1) tile_dma(1, rows1);
-    }
-    long long rows_next = load_rows(2);
-    __builtin_amdgcn_s_barrier();  // B0: consumer wave 0 has seen the builders' flags
-
-    // staged scores of consumer w4: [32 rows][16 chunks of 16 B], chunk c of row r at c ^ (r & 15).
-    // Store i (0..7): rows 4i + (lane >> 4), chunk lane & 15: 4 rows x 256 contiguous bytes.
-    const int cl = lane & 15, rq = lane >> 4;
-    const unsigned int crd = (unsigned int)(CST0 + w4 * CSTW + rq * 256);
-    const int z = cl ^ rq;  // (cl ^ (row & 15)) = z ^ ((4i) & 15)
-    const long long rb = row0 < n ? row0 : n - 1;
-    unsigned int svoff[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      long long r = row0 + 4 * i + rq;
-      if (r >= n) r = n - 1;  // clamped rows rewrite the bits of row n-1 (same store count for every tile)
-      svoff[i] = (unsigned int)((r - rb) * ldo * 4) + (unsigned int)(cl * 16);
-    }
-    unsigned char* const out_rb = (unsigned char*)(out + rb * ldo);
-    auto store_tile = [&](int tt) {
-      const long long col0 = (long long)(tile_lo + tt) * V4_TN;
-      f32x4 cv[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        cv[i] = *reinterpret_cast<const f32x4*>(smem + crd + i * 1024 + ((z ^ ((4 * i) & 15)) << 4));
-      if (col0 + V4_TN <= m) {
-        unsigned char* sbase = out_rb + col0 * 4;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4v4u*>(sbase + svoff[i]) = cv[i];
-      } else {  // ragged end of the table (always this workgroup's last tile)
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col0 + 4 * cl + e < m)
-              *reinterpret_cast<float*>(out_rb + (col0 + e) * 4 + svoff[i]) = cv[i][e];
-      }
-    };
-
-    auto lstamp = [&](int slot) {  // loader-side timestamps (wave 4), slots 32..63
-      if (dbg != nullptr && tid == 256 && slot < 64) dbg[(long long)blockIdx.x * 64 + slot] = __builtin_readcyclecounter();
-    };
+    __builtin_amdgcn_s_barrier();  // B0
     for (int tt = 0; tt <= ntl; ++tt) {
-      // in-order VMEM queue of this wave: step 0: [tile 0][tile 1]; step 1: [tile 1]; later:
-      // [tile tt (NL pieces)][8 stores of tile tt-2] -- the stores may stay in flight
-      if (tt == 0) {
-        if (ntl > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else if (tt == 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else if (tt < ntl) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads of the previous step are done
-      lstamp(32 + 4 * tt);  // tile tt landed (this wave's pieces)
-      __builtin_amdgcn_s_barrier();  // B1(tt)
-      lstamp(33 + 4 * tt);
-      if (tt >= 1 && tt + 1 < ntl) {
-        tile_dma(tt + 1, rows_next);  // into the buffer tile tt-1 was read from
-        rows_next = load_rows(tt + 2);
-      }
-      lstamp(34 + 4 * tt);  // DMA of tile tt+1 issued
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging reads of the previous step are in registers
+      __builtin_amdgcn_s_barrier();  // B1(tt): the consumers may overwrite the staging buffer
+      if (tt >= 2) store_tile(tt - 2);  // from registers, while the DMA waves issue tile tt+1
       __builtin_amdgcn_s_barrier();  // B2(tt): scores of tile tt-1 are staged
-      if (tt >= 1) store_tile(tt - 1);
-      lstamp(35 + 4 * tt);  // stores of tile tt-1 issued
+      if (tt >= 1) read_staging();
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    store_tile(ntl - 1);
     return;
   }
 
