@@ -73,6 +73,16 @@ for name in ("rotate", "transe", "complex"):
     except Exception as e:
         rf = tr = float("nan"); print("torch ops failed:", type(e).__name__, str(e)[:200])
     print(f"{name:8s} N={n*K}: ours fwd {tf:8.1f} us, fwd+bwd {to:9.1f} us | torch ops fwd {rf:9.1f} us, fwd+bwd {tr:9.1f} us")
+    # whole step: + Adagrad over both tables (dense gradients, as LibKGE's default sparse=False gives)
+    from kge_amd.optim import Adagrad as HipAdagrad
+    for tag, mk in (("torch.optim.Adagrad", lambda: torch.optim.Adagrad([ent, rel], lr=0.1)),
+                    ("one-pass Adagrad", lambda: HipAdagrad([ent, rel], lr=0.1))):
+        opt = mk()
+
+        def step():
+            ours()
+            opt.step()
+        print(f"           whole step with {tag:20s}: {timeit(step):9.1f} us")
 
 # ---- kernel breakdown of the RotatE forward + backward
 from torch.profiler import profile, ProfilerActivity
