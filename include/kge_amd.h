@@ -332,6 +332,20 @@ int kge_kl_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n
                const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt,
                void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Binary cross entropy with logits against the rows' multi-hot labels (CSR as for kge_kl_fwd), summed
+ * over ALL entities:  loss_rows[i] = sum_j BCEWithLogits(score(i, j) + offset, y_ij), y_ij = 1 on
+ * the labels = BCEWithLogitsKgeLoss with bce_type None (kge/util/loss.py:137-159; `offset` =
+ * train.loss_arg), as TrainingJobKvsAll / TrainingJob1vsAll use it with train.loss: bce.
+ * kge_bce_bwd: gradients of sum_i g_i * loss_rows[i] (d/d score = sigmoid(score + offset) - y),
+ * outputs as kge_ce_bwd.  Same support matrix and workspace as kge_ce_fwd / kge_ce_bwd. */
+int kge_bce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+                const int64_t* lbl_rowptr, const int64_t* lbl_col, float offset,
+                float* loss_rows, void* workspace, int64_t workspace_bytes, void* stream);
+int kge_bce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+                const int64_t* lbl_rowptr, const int64_t* lbl_col, float offset,
+                const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt,
+                void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- optimizer step over a table ---------------------- */
 /* One dense Adagrad step on `count` contiguous f32 elements (16-byte aligned arrays), in place:
  *   g = grad + weight_decay * param (if weight_decay != 0);  state_sum += g*g;

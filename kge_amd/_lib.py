@@ -86,6 +86,10 @@ PROTOTYPES = {
                                   c_i64, c_vp]),
     "kge_kl_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp,
                                   ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kge_bce_fwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, ctypes.c_float, c_vp,
+                                   c_vp, c_i64, c_vp]),
+    "kge_bce_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, ctypes.c_float, c_vp,
+                                   ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_adagrad_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                         c_vp, c_vp]),
     "kge_score_spo_bwd": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp,

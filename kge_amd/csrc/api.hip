@@ -66,6 +66,12 @@ int run_spo_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, 
                       float* gr, long long gr_ld, hipStream_t st);
 long long ce_workspace_bytes(int d, long long n, long long m);
 void ce_set_stamps(unsigned long long* p);
+int run_bce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+                long long m, const long long* rowptr, const long long* col, float offset, float* loss_rows, void* ws,
+                long long ws_bytes, hipStream_t st);
+int run_bce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+                long long m, const long long* rowptr, const long long* col, float offset, const float* g_rows,
+                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
 long long ce2_workspace_bytes(int d, long long n, long long m);
 int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, float* loss_rows, float* lse, void* ws, long long ws_bytes,
@@ -560,6 +566,38 @@ int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t 
   if (bf16_copy && ((uintptr_t)bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
   return run_adagrad(param, grad, state_sum, count, minus_clr, weight_decay, eps, (unsigned short*)bf16_copy,
                      (hipStream_t)stream);
+}
+
+int kge_bce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,
+                const int64_t* lbl_col, float offset, float* loss_rows, void* workspace, int64_t workspace_bytes,
+                void* stream) {
+  const kge_index none = {nullptr, 0, 0, 1};
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!lbl_rowptr || !lbl_col || !loss_rows))) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(a, false, n)) || (rc = check_index(p, false, n))) return rc;
+  if (!ce_supported(t->scorer, t->dtype, (int)t->dim, ent_op(t, a), rel_op(t, p), ent_op(t, none)))
+    return KGE_ERR_UNSUPPORTED;
+  return run_bce_fwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, none), dir, (int)t->dim, n, t->num_ent,
+                     (const long long*)lbl_rowptr, (const long long*)lbl_col, offset, loss_rows, workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+int kge_bce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,
+                const int64_t* lbl_col, float offset, const float* g_rows, float g_scalar, float* g_a, float* g_p,
+                float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream) {
+  const kge_index none = {nullptr, 0, 0, 1};
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!lbl_rowptr || !lbl_col || !g_a || !g_p || !g_tgt))) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(a, false, n)) || (rc = check_index(p, false, n))) return rc;
+  if (!ce_supported(t->scorer, t->dtype, (int)t->dim, ent_op(t, a), rel_op(t, p), ent_op(t, none)))
+    return KGE_ERR_UNSUPPORTED;
+  return run_bce_bwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, none), dir, (int)t->dim, n, t->num_ent,
+                     (const long long*)lbl_rowptr, (const long long*)lbl_col, offset, g_rows, g_scalar, g_a, g_p,
+                     g_tgt, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,

@@ -153,6 +153,47 @@ __global__ __launch_bounds__(256) void kl_sub_kernel(unsigned short* __restrict_
   }
 }
 
+// ---- binary cross entropy with logits against multi-hot labels ---------------------------------
+// BCEWithLogitsKgeLoss, bce_type None (kge/util/loss.py:137-159): sum over ALL entities j of
+// BCEWithLogits(score(i,j) + offset, y_ij), y_ij = 1 on the row's labels.  With
+// softplus(x) = log(1 + e^x):   loss_i = sum_j softplus(x_ij) - sum_{j in P_i} x_ij,  x = score + offset,
+//   d loss_i / d score(i,j) = sigmoid(x_ij) - y_ij.
+// The V3_SPLUS kernel accumulates the softplus sums (per row and column group), kl_label_kernel the
+// label scores; the backward is the V3_DSIG kernel + the label subtraction + the two products.
+__global__ __launch_bounds__(256) void bce_combine_kernel(const float* __restrict__ part, int ncg, long long n,
+                                                          const float* __restrict__ label_sum,
+                                                          const long long* __restrict__ rowptr, float offset,
+                                                          float* __restrict__ loss_rows) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float* p = part + i * ncg * 2;
+  float S = 0.0f;
+  for (int c = lane; c < ncg; c += 64) S += p[2 * c];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) S += __shfl_xor(S, off, 64);
+  if (lane == 0) {
+    const long long k = rowptr[i + 1] - rowptr[i];
+    loss_rows[i] = S - (label_sum[i] + (float)k * offset);
+  }
+}
+
+// G16[i, j] -= g_i for the labels j of row i (y_ij = 1)
+__global__ __launch_bounds__(256) void bce_sub_kernel(unsigned short* __restrict__ g16, long long ld16, long long n,
+                                                      const long long* __restrict__ rowptr,
+                                                      const long long* __restrict__ col,
+                                                      const float* __restrict__ g_rows, float g_scalar) {
+  const int lane = threadIdx.x & 63;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const float y = g_rows != nullptr ? g_rows[i] : g_scalar;
+  for (long long x = rowptr[i] + lane; x < rowptr[i + 1]; x += 64) {
+    unsigned short* p = g16 + i * ld16 + col[x];
+    const float v = __uint_as_float((unsigned int)*p << 16) - y;
+    *p = (unsigned short)(bf16_pack(v, 0.0f) & 0xffffu);
+  }
+}
+
 // tools/ce_phases.py: per-workgroup s_memtime stamps of the next fused-loss launches (not part of the ABI)
 static unsigned long long* g_ce_stamps = nullptr;
 
@@ -255,6 +296,53 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(kl_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.g16, ld16, n, rowptr, col,
+                     g_rows, g_scalar);
+  if (hipGetLastError() != hipSuccess) return KGE_ERR_LAUNCH;
+  return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
+}
+
+int run_bce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+                long long m, const long long* rowptr, const long long* col, float offset, float* loss_rows, void* ws,
+                long long ws_bytes, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const int ncg = pairs_bf16_v3_column_groups(n, m);
+  CeArgs ce{};
+  ce.offset = offset;
+  ce.part = (float*)((char*)ws + coop);
+  ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));  // the rows' label-score sums
+  const int rc = run_pairs_bf16_v3_ce(scorer, V3_SPLUS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  if (rc != KGE_OK) return rc;
+  const dim3 grid((unsigned)((n + 3) / 4));
+  if (scorer == KGE_COMPLEX)
+    hipLaunchKernelGGL(kl_label_kernel<KGE_COMPLEX>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
+                       ce.true_score);
+  else
+    hipLaunchKernelGGL(kl_label_kernel<KGE_DISTMULT>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
+                       ce.true_score);
+  hipLaunchKernelGGL(bce_combine_kernel, grid, dim3(256), 0, st, ce.part, ncg, n, ce.true_score, rowptr, offset,
+                     loss_rows);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_bce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
+                long long m, const long long* rowptr, const long long* col, float offset, const float* g_rows,
+                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
+  const long long ld16 = ce_ld16(m);
+  CeArgs ce{};
+  ce.offset = offset;
+  ce.g_rows = g_rows;
+  ce.g_scalar = g_scalar;
+  ce.g16 = (unsigned short*)((char*)ws + coop);
+  ce.ld16 = ld16;
+  unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(n * ld16 * 2));
+  const int rc = run_pairs_bf16_v3_ce(scorer, V3_DSIG, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  if (rc != KGE_OK) return rc;
+  hipLaunchKernelGGL(bce_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.g16, ld16, n, rowptr, col,
                      g_rows, g_scalar);
   if (hipGetLastError() != hipSuccess) return KGE_ERR_LAUNCH;
   return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);

@@ -282,8 +282,21 @@ __device__ __forceinline__ long long index_mode(const Index& ix, long long i) {
 //             written to G16[n, ld16] (the left operand of both gradient GEMMs) -- kge_ce_bwd
 // The MFMA chain, its operands and their order are the same in all three: the scores inside
 // V3_LSE / V3_DS are bit-identical to what V3_STORE writes.
-constexpr int V3_STORE = 0, V3_LSE = 1, V3_DS = 2;
+//   V3_SPLUS  folded into a per-row running sum of softplus(score + offset) (binary cross entropy
+//             with logits against all-zero labels; the label terms are added outside)  -- kge_bce_fwd
+//   V3_DSIG   d loss / d score = g_i * (sigmoid(score + offset) - [j == label_i]) as bf16 -> G16
+//                                                                                    -- kge_bce_bwd
+constexpr int V3_STORE = 0, V3_LSE = 1, V3_DS = 2, V3_SPLUS = 3, V3_DSIG = 4;
 constexpr float V3_LOG2E = 1.44269504088896340736f;
+constexpr float V3_LN2 = 0.69314718055994530942f;
+
+// log(1 + exp(x)) without overflow: max(x, 0) + log1p(exp(-|x|)); the series below 2^-7 keeps the
+// relative error of the small terms at ~1e-5 where 1 + e would round e away
+__device__ __forceinline__ float v3_softplus(float x) {
+  const float e = __builtin_amdgcn_exp2f(-__builtin_fabsf(x) * V3_LOG2E);  // (0, 1]
+  const float l = e < 0.0078125f ? e * (1.0f - 0.5f * e) : __builtin_amdgcn_logf(1.0f + e) * V3_LN2;
+  return __builtin_fmaxf(x, 0.0f) + l;
+}
 
 struct CeArgs {
   Index label;              // [n] entity ids (the true target of row i); ptr == NULL: no single label
@@ -292,8 +305,9 @@ struct CeArgs {
   float* part;              // V3_LSE: [n][ncg][2] per-column-group (max, sum exp)
   float* true_score;        // V3_LSE: [n] score(i, label_i)
   const float* lse;         // V3_DS: [n] logsumexp of row i
-  const float* g_rows;      // V3_DS: [n] upstream gradient of row i's loss, or NULL: g_scalar
+  const float* g_rows;      // V3_DS / V3_DSIG: [n] upstream gradient of row i's loss, or NULL: g_scalar
   float g_scalar;
+  float offset;             // V3_SPLUS / V3_DSIG: added to every score (train.loss_arg of the bce loss)
   unsigned short* g16;      // V3_DS: [n][ld16] bf16, ld16 % 64 == 0 and ld16 >= 64 * ntiles
   long long ld16;
   // two-sided launch (sp_ queries in row groups [0, rgn1), _po queries behind them): the entity

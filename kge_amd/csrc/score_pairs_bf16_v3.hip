@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   constexpr int CST0 = (2 * TILEB > STG0 + STAGE) ? 2 * TILEB : STG0 + STAGE;
   constexpr int SMEM = CST0 + 4 * 32 * 144;
   constexpr int NQ = 2 * NKB;             // MFMAs per tile (two 32-target halves)
-  constexpr int NST = EPI == V3_STORE ? 8 : (EPI == V3_DS ? 4 : 0);  // vector stores per tile per lane
+  constexpr bool IS_DS = EPI == V3_DS || EPI == V3_DSIG;      // writes bf16 gradients of the scores
+  constexpr int NST = EPI == V3_STORE ? 8 : (IS_DS ? 4 : 0);  // vector stores per tile per lane
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
   // ---- which rows / target tiles
@@ -204,14 +205,18 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     stamp();  // 3: all shares of this row group published
     const unsigned char* sb =
         (const unsigned char*)(qf + ((long long)(rg * (V3_ROWS / 32) + wave) * NKB) * 64);  // uniform
-    auto fload = [](bf16x8& dst, unsigned int vo, const unsigned char* base) __attribute__((always_inline)) {
-      asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
-    };
+    // sc1 buffer loads through the compiler's builtin (not inline asm): the register allocator then
+    // knows the values arrive asynchronously.  With asm loads + a later asm s_waitcnt it is free to
+    // move a fragment register (say into an AGPR, under register pressure) between the two -- copying
+    // garbage and letting the late data land in a register it has reused (seen as memory faults in
+    // the 450-VGPR softplus variant at d = 512).
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)sb, 0, NKB * 1024, 0x00020000);
     v3_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
-      fload(afr[kb], (unsigned int)(lane * 16 + kb * 1024), sb);
+      afr[kb] = __builtin_bit_cast(
+          bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16 + kb * 1024), 0, 16 /* sc1 */));
     });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // not waited for here: the compiler waits for fragment kb in front of its first MFMA (tile 0)
     stamp();  // 4: fragments loaded
   } else {
     const unsigned short* ab = (const unsigned short*)A.base;
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   float lse_i = 0.0f, g_i = 0.0f; // V3_DS
   if constexpr (EPI != V3_STORE) {
     if (lab_ix.ptr != nullptr) lab = index_at(lab_ix, orow);
-    if constexpr (EPI == V3_DS) {
-      lse_i = ce.lse[orow + roff];
+    if constexpr (IS_DS) {
+      if constexpr (EPI == V3_DS) lse_i = ce.lse[orow + roff];
       g_i = ce.g_rows != nullptr ? ce.g_rows[orow + roff] : ce.g_scalar;
       if (ce.rowptr != nullptr && ce.rowptr[orow + 1] == ce.rowptr[orow]) g_i = 0.0f;
     }
@@ -322,7 +327,11 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     }
   };
   auto ds_value = [&](float sc, long long rel, int off) {
-    float pv = __builtin_amdgcn_exp2f((sc - lse_i) * V3_LOG2E) * g_i;
+    float pv;
+    if constexpr (EPI == V3_DSIG)  // sigmoid(score + offset)
+      pv = g_i / (1.0f + __builtin_amdgcn_exp2f(-(sc + ce.offset) * V3_LOG2E));
+    else  // softmax
+      pv = __builtin_amdgcn_exp2f((sc - lse_i) * V3_LOG2E) * g_i;
     if (rel == off) pv -= g_i;
     return pv;
   };
@@ -470,7 +479,16 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
           }
           if (q == 10 * U) lse_pick(tt - 1, accp0, accp1);
         }
-      } else if constexpr (EPI == V3_DS) {
+      } else if constexpr (EPI == V3_SPLUS) {
+        if (store_prev) {  // running sum of softplus over tile tt-1: 32 columns of this lane's row
+          if constexpr (q % U == 0 && q / U >= 1 && q / U <= 8) {
+            constexpr int k = q / U - 1;
+            rsum += (v3_softplus(accp0[2 * k] + ce.offset) + v3_softplus(accp0[2 * k + 1] + ce.offset)) +
+                    (v3_softplus(accp1[2 * k] + ce.offset) + v3_softplus(accp1[2 * k + 1] + ce.offset));
+          }
+          if (q == 10 * U) lse_pick(tt - 1, accp0, accp1);
+        }
+      } else if constexpr (IS_DS) {
         if (store_prev) {  // d loss / d score of tile tt-1 -> bf16 -> transpose -> 4 x 16-byte stores
           if constexpr (q % U == 0 && q / U < 8) {
             constexpr int k = q / U;
@@ -564,7 +582,27 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
       }
       if (tfound) ce.true_score[row + roff] = tsc;  // (never with ce.label.ptr == NULL: lab stays -1)
     }
-  } else if constexpr (EPI == V3_DS) {
+  } else if constexpr (EPI == V3_SPLUS) {
+    const long long c0 = (long long)(tile_lo + ntl - 1) * V3_TN + 4 * fh;
+    float sm = 0.0f;  // columns beyond m contribute nothing
+    v3_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
+      constexpr int r = decltype(rc)::value;
+      const long long c = c0 + 8 * (r >> 2) + (r & 3);
+      sm += (c < m ? v3_softplus(a0[r] + ce.offset) : 0.0f) + (c + 32 < m ? v3_softplus(a1[r] + ce.offset) : 0.0f);
+    });
+    rsum += sm;
+    lse_pick(ntl - 1, a0, a1);
+    const float S = rsum + __shfl_xor(rsum, 32, 64);  // the two lanes of a row
+    const long long row = row0 + fi;
+    if (row < n) {
+      if (fh == 0) {
+        float* pp = ce.part + ((row + roff) * ncg + cg) * 2;
+        pp[0] = S;
+        pp[1] = 0.0f;
+      }
+      if (tfound) ce.true_score[row + roff] = tsc;
+    }
+  } else if constexpr (IS_DS) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) ds_write(ntl - 1, a0, 0, g);
 #pragma unroll
@@ -700,8 +738,12 @@ int run_pairs_bf16_v3_ce(int scorer, int epi, const Operand& A, const Operand& R
   }
   if (scorer == KGE_COMPLEX && epi == V3_LSE) { KGE_V3C(KGE_COMPLEX, V3_LSE) }
   else if (scorer == KGE_COMPLEX && epi == V3_DS) { KGE_V3C(KGE_COMPLEX, V3_DS) }
+  else if (scorer == KGE_COMPLEX && epi == V3_SPLUS) { KGE_V3C(KGE_COMPLEX, V3_SPLUS) }
+  else if (scorer == KGE_COMPLEX && epi == V3_DSIG) { KGE_V3C(KGE_COMPLEX, V3_DSIG) }
   else if (scorer == KGE_DISTMULT && epi == V3_LSE) { KGE_V3C(KGE_DISTMULT, V3_LSE) }
   else if (scorer == KGE_DISTMULT && epi == V3_DS) { KGE_V3C(KGE_DISTMULT, V3_DS) }
+  else if (scorer == KGE_DISTMULT && epi == V3_SPLUS) { KGE_V3C(KGE_DISTMULT, V3_SPLUS) }
+  else if (scorer == KGE_DISTMULT && epi == V3_DSIG) { KGE_V3C(KGE_DISTMULT, V3_DSIG) }
 #undef KGE_V3C
   return KGE_ERR_UNSUPPORTED;
 }

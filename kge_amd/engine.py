@@ -683,6 +683,45 @@ def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=Non
     return g_a, g_p, g_t
 
 
+def bce_fwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, offset: float = 0.0):
+    """Fused score_sp / score_po + BCEWithLogits (summed over all entities) against the rows'
+    multi-hot labels (int64 CSR): loss_rows [n]; kge/util/loss.py:137-159, bce_type None."""
+    keep = []
+    ai, pi = (_index(x, t.device, keep) for x in (a, p))
+    n = keep[0].numel()
+    rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
+    loss_rows = _empty((n,), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_bce_fwd(ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, n,
+                                          rp.data_ptr(), cl.data_ptr(), float(offset), loss_rows.data_ptr(),
+                                          ws, wsb, st), "kge_bce_fwd")
+    return loss_rows
+
+
+def bce_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, offset: float = 0.0, g_rows=None,
+            g_scalar: float = 1.0):
+    """Backward of bce_fwd: (g_a [n, d], g_p [n, d], g_entities [E, d])."""
+    keep = []
+    ai, pi = (_index(x, t.device, keep) for x in (a, p))
+    n = keep[0].numel()
+    rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    gr = None if g_rows is None else _f32c(g_rows, t.device)
+    g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((t.num_ent, d), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_bce_bwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, n, rp.data_ptr(), cl.data_ptr(),
+            float(offset), None if gr is None else gr.data_ptr(), float(g_scalar), g_a.data_ptr(),
+            g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_bce_bwd")
+    return g_a, g_p, g_t
+
+
 def score_emb_bwd(scorer, s_emb, p_emb, o_emb, combine: str, l_norm, gout, scores=None):
     """Backward of score_emb: gradients w.r.t. (s_emb, p_emb, o_emb)."""
     code = {"spo": SPO, "sp_": SP_, "_po": PO_}[combine]

@@ -251,6 +251,32 @@ class KgeModel(torch.nn.Module):
                                   lbl_rowptr, lbl_col, t)
         return self._kl_composed(self.score_po(p, o), lbl_rowptr, lbl_col)
 
+    # -- bce loss (train.loss: bce, loss.py:137-159 with bce_type None) on multi-hot labels
+    @staticmethod
+    def _bce_composed(scores: Tensor, rowptr: Tensor, col: Tensor, offset: float = 0.0) -> Tensor:
+        n = scores.shape[0]
+        cnt = (rowptr[1:] - rowptr[:-1]).to(scores.device)
+        rows = torch.repeat_interleave(torch.arange(n, device=scores.device), cnt)
+        labels = torch.zeros_like(scores)
+        labels[rows, col.to(scores.device).long()] = 1.0
+        return torch.nn.functional.binary_cross_entropy_with_logits(scores + offset, labels,
+                                                                     reduction="none").sum(dim=1)
+
+    def bce_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0) -> Tensor:
+        """Per-row sum over all entities of BCEWithLogits(score_sp(s, p) + offset, multi-hot labels)."""
+        t = self._ce_tables()
+        if t is not None:
+            return _FusedBCE.apply("sp", self._entity_embedder.weight, self._relation_embedder.weight, s, p,
+                                   lbl_rowptr, lbl_col, float(offset), t)
+        return self._bce_composed(self.score_sp(s, p), lbl_rowptr, lbl_col, offset)
+
+    def bce_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0) -> Tensor:
+        t = self._ce_tables()
+        if t is not None:
+            return _FusedBCE.apply("po", self._entity_embedder.weight, self._relation_embedder.weight, o, p,
+                                   lbl_rowptr, lbl_col, float(offset), t)
+        return self._bce_composed(self.score_po(p, o), lbl_rowptr, lbl_col, offset)
+
     def score_so(self, s: Tensor, o: Tensor, p: Tensor = None) -> Tensor:
         se, oe = self._entity_embedder.embed(s), self._entity_embedder.embed(o)
         pe = self._relation_embedder.embed_all() if p is None else self._relation_embedder.embed(p)
@@ -455,6 +481,28 @@ class _FusedKL(torch.autograd.Function):
         _scatter_rows(gr, p, g_p)
         _scatter_rows(ge, a, g_a)
         return None, ge, gr, None, None, None, None, None
+
+
+class _FusedBCE(torch.autograd.Function):
+    """Per-row BCE-with-logits (summed over all entities) fused with the sp_/_po scoring
+    (kge_bce_fwd / kge_bce_bwd); labels as an int64 CSR of the rows' positives."""
+
+    @staticmethod
+    def forward(ctx, direction, ent, rel, a, p, rowptr, col, offset, tables16):
+        loss_rows = engine.bce_fwd(tables16, direction, a, p, rowptr, col, offset)
+        ctx.t16, ctx.direction, ctx.idx, ctx.offset = tables16, direction, (a, p, rowptr, col), offset
+        ctx.rel_shape = rel.shape
+        return loss_rows
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        a, p, rowptr, col = ctx.idx
+        g_a, g_p, ge = engine.bce_bwd(ctx.t16, ctx.direction, a, p, rowptr, col, ctx.offset,
+                                      g_rows=g_rows.contiguous())
+        gr = torch.zeros(ctx.rel_shape, dtype=torch.float32, device=ge.device)
+        _scatter_rows(gr, p, g_p)
+        _scatter_rows(ge, a, g_a)
+        return None, ge, gr, None, None, None, None, None, None
 
 
 class _ScoreEmb(torch.autograd.Function):

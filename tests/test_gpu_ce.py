@@ -392,3 +392,68 @@ def test_ce_sp_po_bwd_accum_equals_scatter_of_row_gradients(eng):
     for nm, got, want in (("ent", ge, want_e), ("rel", gr, want_r)):
         rel_err = float((got - want).norm() / want.norm())
         assert rel_err <= 1e-5, (nm, rel_err)
+
+
+# ---- bce loss (kge_bce_fwd / kge_bce_bwd) ------------------------------------------------------------
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5])
+@pytest.mark.parametrize("offset", [0.0, -1.5])
+def test_bce_fwd_bwd(eng, model, d, E, R, n, scale, offset):
+    """Forward against float64 sum_j BCEWithLogits(score + offset, y) of the written scores
+    (1e-5 relative + the label-score tolerance of the KL test); backward against float64 autograd of
+    that loss on the bf16-valued tables (<= 1e-2, bf16 operands)."""
+    ent, rel, s, p, o, rowptr, col = _kl_case(11 * d + n, model, d, E, R, n, scale)
+    T = _tables(eng, model, ent, rel)
+    trp, tcl = _t(rowptr), _t(col)
+    rng = np.random.default_rng(4)
+    g_rows = (rng.random(n).astype(np.float32) + 0.5) / n
+    lab = torch.zeros(n, E, dtype=torch.float64)
+    lab[torch.from_numpy(np.repeat(np.arange(n), np.diff(rowptr))), torch.from_numpy(col)] = 1.0
+    for direction, a in (("sp", s), ("po", o)):
+        ta, tp = _t(a), _t(p)
+        loss = eng.bce_fwd(T, direction, ta, tp, trp, tcl, offset).cpu().numpy().astype(np.float64)
+        sc = (eng.score_sp(T, ta, tp) if direction == "sp" else eng.score_po(T, tp, ta)).cpu().double()
+        want = torch.nn.functional.binary_cross_entropy_with_logits(sc + offset, lab, reduction="none").sum(1).numpy()
+        tol = 1e-5 * np.abs(want) + 1e-4 + 2e-6 * np.abs(sc.numpy()).max(axis=1) * np.maximum(1, np.diff(rowptr))
+        assert (np.abs(loss - want) <= tol).all(), (direction, float(np.abs(loss - want).max()), float(want.max()))
+        g_a, g_p, g_t = eng.bce_bwd(T, direction, ta, tp, trp, tcl, offset, g_rows=_t(g_rows))
+        ge = g_t.clone()
+        ge.index_add_(0, ta, g_a)
+        gr = torch.zeros(R, d, device=DEV).index_add_(0, tp, g_p)
+        e = T.ent.cpu().double().requires_grad_(True)
+        r = T.rel.cpu().double().requires_grad_(True)
+        ea, rp_ = e[torch.from_numpy(a)], r[torch.from_numpy(p)]
+        h = d // 2
+        if model == "distmult":
+            q = ea * rp_
+        elif direction == "sp":
+            q = torch.cat([ea[:, :h] * rp_[:, :h] - ea[:, h:] * rp_[:, h:], ea[:, :h] * rp_[:, h:] + ea[:, h:] * rp_[:, :h]], 1)
+        else:
+            q = torch.cat([ea[:, :h] * rp_[:, :h] + ea[:, h:] * rp_[:, h:], ea[:, h:] * rp_[:, :h] - ea[:, :h] * rp_[:, h:]], 1)
+        l64 = torch.nn.functional.binary_cross_entropy_with_logits(q @ e.t() + offset, lab, reduction="none").sum(1)
+        (l64 * torch.from_numpy(g_rows).double()).sum().backward()
+        for nm, gotg, wantg in (("ent", ge, e.grad), ("rel", gr, r.grad)):
+            rel_err = float((gotg.cpu().double() - wantg).norm() / wantg.norm())
+            assert rel_err <= 1e-2, (direction, nm, rel_err)
+
+
+def test_model_level_bce_loss_against_composed():
+    from kge_amd import model as km
+    E, R, d, n = 2000 + 3, 7, 256, 150
+    torch.manual_seed(0)
+    m = km.create("complex", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    ent, rel, s, p, o, rowptr, col = _kl_case(19, "complex", d, E, R, n, 0.3)
+    ts, tp, to, trp, tcl = _t(s), _t(p), _t(o), _t(rowptr), _t(col)
+    for fused, composed in ((lambda: m.bce_loss_sp(ts, tp, trp, tcl, -0.5),
+                             lambda: m._bce_composed(m.score_sp(ts, tp), trp, tcl, -0.5)),
+                            (lambda: m.bce_loss_po(tp, to, trp, tcl), lambda: m._bce_composed(m.score_po(tp, to), trp, tcl))):
+        m.zero_grad()
+        lf = fused().sum() / n
+        lf.backward()
+        gf = [x.grad.clone() for x in m.parameters()]
+        m.zero_grad()
+        lc = composed().sum() / n
+        lc.backward()
+        gc = [x.grad.clone() for x in m.parameters()]
+        assert abs(float(lf.detach()) - float(lc.detach())) <= 2e-5 * max(1.0, abs(float(lc.detach())))
+        for a_, b_ in zip(gf, gc):
+            assert float((a_ - b_).norm() / b_.norm()) <= 2e-3
