@@ -8,7 +8,7 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import BF16Shadow, _FusedCE, _FusedCE2, _FusedKL, _ScoreEmb, _ScorePairs, _ScoreSPO
+from ..model import BF16Shadow, _FusedBCE, _FusedCE, _FusedCE2, _FusedKL, _ScoreEmb, _ScorePairs, _ScoreSPO
 
 
 class _HipScorer(RelationalScorer):
@@ -144,6 +144,22 @@ class _FusedScoring:
             return None
         ent, rel = self._w()
         return _FusedKL.apply("po", ent, rel, o, p, lbl_rowptr, lbl_col, t)
+
+    def bce_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0):
+        """[n] sum over all entities of BCEWithLogits(score_sp(s, p) + offset, multi-hot labels);
+        None if the fused path does not apply (kge_bce_fwd)."""
+        t = self._ce_tables()
+        if t is None:
+            return None
+        ent, rel = self._w()
+        return _FusedBCE.apply("sp", ent, rel, s, p, lbl_rowptr, lbl_col, float(offset), t)
+
+    def bce_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0):
+        t = self._ce_tables()
+        if t is None:
+            return None
+        ent, rel = self._w()
+        return _FusedBCE.apply("po", ent, rel, o, p, lbl_rowptr, lbl_col, float(offset), t)
 
     def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
         if not self._fused():

@@ -1,13 +1,25 @@
-"""TrainingJob1vsAll / TrainingJobKvsAll with the kl loss fused into the scoring kernel
+"""TrainingJob1vsAll / TrainingJobKvsAll with the kl or bce loss fused into the scoring kernel
 (train.type: hip_1vsAll / hip_KvsAll)."""
 import time
 
 import torch
 
+
+def _plain_bce(loss):
+    """BCEWithLogitsKgeLoss as the fused kernel computes it: bce_type None (sum over all entities),
+    default BCEWithLogitsLoss arguments; returns the score offset (train.loss_arg) or None."""
+    from kge.util.loss import BCEWithLogitsKgeLoss
+    if not isinstance(loss, BCEWithLogitsKgeLoss) or loss._bce_type is not None:
+        return None
+    inner = loss._loss
+    if getattr(inner, "weight", None) is not None or getattr(inner, "pos_weight", None) is not None:
+        return None
+    return float(loss._offset)
+
 from kge.job import Job
 from kge.job.train_1vsAll import TrainingJob1vsAll
 from kge.job.train_KvsAll import TrainingJobKvsAll
-from kge.util.loss import KLDivWithSoftmaxKgeLoss
+from kge.util.loss import BCEWithLogitsKgeLoss, KLDivWithSoftmaxKgeLoss
 
 
 class HipTrainingJob1vsAll(TrainingJob1vsAll):
@@ -23,7 +35,32 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
             for f in Job.job_created_hooks:
                 f(self)
 
+    def _process_subbatch_bce(self, batch_index, batch, subbatch_slice, result, offset):
+        """train.loss: bce -- every triple's (s, p) row has the single label o (and (p, o) the label s):
+        kge_bce_fwd with a one-entry-per-row CSR."""
+        batch_size = result.size
+        result.prepare_time -= time.time()
+        triples = batch["triples"][subbatch_slice].to(self.device)
+        rowptr = torch.arange(len(triples) + 1, dtype=torch.long, device=triples.device)
+        result.prepare_time += time.time()
+        for rows_fn in (lambda: self.model.bce_loss_sp(triples[:, 0], triples[:, 1], rowptr, triples[:, 2], offset),
+                        lambda: self.model.bce_loss_po(triples[:, 1], triples[:, 2], rowptr, triples[:, 0], offset)):
+            result.forward_time -= time.time()
+            rows = rows_fn()
+            if rows is None:
+                return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
+            loss_value = rows.sum() / batch_size
+            result.avg_loss += loss_value.item()
+            result.forward_time += time.time()
+            result.backward_time -= time.time()
+            if not self.is_forward_only:
+                loss_value.backward()
+            result.backward_time += time.time()
+
     def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
+        offset = _plain_bce(self.loss)
+        if offset is not None and hasattr(self.model, "bce_loss_sp"):
+            return self._process_subbatch_bce(batch_index, batch, subbatch_slice, result, offset)
         fused = isinstance(self.loss, KLDivWithSoftmaxKgeLoss) and hasattr(self.model, "loss_sp")
         if not fused:
             return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
@@ -63,11 +100,11 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
 
 
 class HipTrainingJobKvsAll(TrainingJobKvsAll):
-    """Overrides only `_process_subbatch` (train_KvsAll.py:216-294).  With `train.loss: kl`, no label
-    smoothing and a model that offers `kl_loss_sp` / `kl_loss_po`, the sp_ and _po queries of a
-    subbatch get their loss from one fused kernel each (kge_kl_fwd: scores never written; labels as
-    a CSR cut out of the batch's `label_coords`); s_o queries and every other configuration run
-    the reference's code."""
+    """Overrides only `_process_subbatch` (train_KvsAll.py:216-294).  With `train.loss: kl` or `bce`
+    (plain: bce_type None), no label smoothing and a model that offers `kl_loss_sp` / `kl_loss_po`
+    (`bce_loss_sp` / `bce_loss_po`), the sp_ and _po queries of a subbatch get their loss from one
+    fused kernel each (kge_kl_fwd / kge_bce_fwd: scores never written; labels as a CSR cut out of the
+    batch's `label_coords`); s_o queries and every other configuration run the reference's code."""
 
     def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
         super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
@@ -76,8 +113,11 @@ class HipTrainingJobKvsAll(TrainingJobKvsAll):
                 f(self)
 
     def _fused_ok(self) -> bool:
-        return (isinstance(self.loss, KLDivWithSoftmaxKgeLoss) and self.label_smoothing == 0.0
-                and hasattr(self.model, "kl_loss_sp") and "s_o" not in self.query_types)
+        if self.label_smoothing != 0.0 or "s_o" in self.query_types:
+            return False
+        if isinstance(self.loss, KLDivWithSoftmaxKgeLoss):
+            return hasattr(self.model, "kl_loss_sp")
+        return _plain_bce(self.loss) is not None and hasattr(self.model, "bce_loss_sp")
 
     def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
         if not self._fused_ok():
@@ -107,8 +147,13 @@ class HipTrainingJobKvsAll(TrainingJobKvsAll):
                 + torch.arange(total, device=cnt.device)
             col = coords[idx, 1].long()
             q0, q1 = queries[examples, 0], queries[examples, 1]
-            loss_rows = (self.model.kl_loss_sp(q0, q1, rowptr, col) if query_type == "sp_"
-                         else self.model.kl_loss_po(q0, q1, rowptr, col))
+            offset = _plain_bce(self.loss)
+            if offset is None:
+                loss_rows = (self.model.kl_loss_sp(q0, q1, rowptr, col) if query_type == "sp_"
+                             else self.model.kl_loss_po(q0, q1, rowptr, col))
+            else:
+                loss_rows = (self.model.bce_loss_sp(q0, q1, rowptr, col, offset) if query_type == "sp_"
+                             else self.model.bce_loss_po(q0, q1, rowptr, col, offset))
             if loss_rows is None:  # the model declined: reference path for the whole subbatch
                 result.forward_time += time.time()
                 return super()._process_subbatch(batch_index, batch, subbatch_slice, result)

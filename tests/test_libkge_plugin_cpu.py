@@ -129,8 +129,9 @@ def _job_config(tmp, model, train_type, seed=7):
     return config
 
 
+@pytest.mark.parametrize("loss", ["kl", "bce"])
 @pytest.mark.parametrize("ref_type,hip_type", [("1vsAll", "hip_1vsAll"), ("KvsAll", "hip_KvsAll")])
-def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type):
+def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type, loss):
     """Control flow of the plugin training jobs on CPU: with a model whose loss_sp / loss_po
     (kl_loss_sp / kl_loss_po) are the reference's own ops, one epoch of HipTrainingJob* must give
     the reference job's avg_loss and parameters -- batching, label CSR cut-out (KvsAll),
@@ -148,6 +149,9 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type)
     results = {}
     for train_type in (ref_type, hip_type):
         config = _job_config(str(tmp_path), "complex", train_type)
+        config.set("train.loss", loss)
+        if loss == "bce":
+            config.set("train.loss_arg", -0.5)  # score offset
         torch.manual_seed(11)  # same initialisation and batch order for both jobs
         job = TrainingJob.create(config, Dataset.create(config, folder=data))
         assert type(job).__name__ == ("TrainingJob" if not train_type.startswith("hip_") else "HipTrainingJob") + ref_type
@@ -164,6 +168,10 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type)
                 lambda self, s, p, rp, col: Mirror._kl_composed(self.score_sp(s, p), rp, col), m)
             m.kl_loss_po = types.MethodType(
                 lambda self, p, o, rp, col: Mirror._kl_composed(self.score_po(p, o), rp, col), m)
+            m.bce_loss_sp = types.MethodType(
+                lambda self, s, p, rp, col, off: Mirror._bce_composed(self.score_sp(s, p), rp, col, off), m)
+            m.bce_loss_po = types.MethodType(
+                lambda self, p, o, rp, col, off: Mirror._bce_composed(self.score_po(p, o), rp, col, off), m)
         job._prepare()
         trace = job.run_epoch()
         results[train_type] = (trace["avg_loss"], [x.detach().clone() for x in m.parameters()])
