@@ -75,3 +75,47 @@ def test_no_oracle_import_in_product_code():
                 for pat in (r"#include\s*[<\"].*oracle", r"^\s*(import|from)\s+oracle", r"libkge_oracle",
                             r"ref_harness", r"sys\.path.*oracle"):
                     assert not re.search(pat, src, flags=re.M), (f, pat)
+
+
+def test_new_entries_validate_arguments_without_a_device(lib):
+    """Fused-loss, evaluation and optimizer entry points: argument checks that return before any
+    launch (no GPU here)."""
+    import ctypes
+    from kge_amd._lib import KgeIndex, KgeTables
+    ix = KgeIndex(None, 1, 0, 1)
+    good = KgeIndex(ctypes.c_void_p(16), 1, 0, 1)  # never dereferenced on these paths
+    f32 = KgeTables(ctypes.c_void_p(16), ctypes.c_void_p(16), 0, 0, 10, 3, 512, 512, 512, 512, 1.0, 0)
+    bf16 = KgeTables(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 0, 10, 3, 512, 512, 512, 512, 1.0, 0)
+    transe = KgeTables(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 2, 10, 3, 512, 512, 512, 512, 1.0, 0)
+    odd = KgeTables(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 0, 10, 3, 320, 320, 320, 320, 1.0, 0)
+    # workspace queries: only bf16 ComplEx / DistMult with dim in {128, 256, 512}
+    assert lib.kge_ce_workspace_bytes(ctypes.byref(bf16), 512) > 0
+    assert lib.kge_ce_sp_po_workspace_bytes(ctypes.byref(bf16), 512) >= lib.kge_ce_workspace_bytes(ctypes.byref(bf16), 512)
+    for t in (f32, transe, odd):
+        assert lib.kge_ce_workspace_bytes(ctypes.byref(t), 512) == 0
+        assert lib.kge_ce_sp_po_workspace_bytes(ctypes.byref(t), 512) == 0
+    # unsupported tables / bad direction / missing index vectors
+    assert lib.kge_ce_fwd(ctypes.byref(f32), 1, good, good, good, 4, None, None, None, 0, None) == -2
+    assert lib.kge_ce_fwd(ctypes.byref(bf16), 0, good, good, good, 4, None, None, None, 0, None) == -1
+    assert lib.kge_ce_fwd(ctypes.byref(bf16), 1, ix, good, good, 4, None, None, None, 0, None) == -1
+    assert lib.kge_ce_fwd(ctypes.byref(bf16), 1, good, good, good, 4, None, None, None, 0, None) == -1  # no outputs
+    assert lib.kge_ce_sp_po_fwd(ctypes.byref(transe), good, good, good, 4, None, None, None, 0, None) == -2
+    assert lib.kge_kl_fwd(ctypes.byref(bf16), 1, good, good, 4, None, None, None, None, None, 0, None) == -1  # no labels
+    assert lib.kge_bce_fwd(ctypes.byref(f32), 1, good, good, 4, ctypes.c_void_p(16), ctypes.c_void_p(16), 0.0,
+                           ctypes.c_void_p(16), None, 0, None) == -2
+    # empty batches are fine without a workspace
+    assert lib.kge_ce_fwd(ctypes.byref(bf16), 1, ix, ix, ix, 0, None, None, None, 0, None) == 0
+    assert lib.kge_ce_sp_po_fwd(ctypes.byref(bf16), ix, ix, ix, 0, None, None, None, 0, None) == 0
+    # evaluation entries
+    assert lib.kge_filter_lookup(None, 5, None, good, good, 7, 3, ctypes.c_void_p(16), ctypes.c_void_p(16), None) == -1
+    assert lib.kge_filter_lookup(None, 0, None, ix, ix, 7, 0, None, None, None) == 0
+    assert lib.kge_rank_counts_multi(None, 3, 2, 5, None, 0, None, None, None, 0, None, 1e-5, 1e-4, None, None, None) == -1
+    assert lib.kge_rank_counts_multi(ctypes.c_void_p(16), 5, 2, 5, ctypes.c_void_p(16), 9, None, None, None, 0, None,
+                                     1e-5, 1e-4, ctypes.c_void_p(16), ctypes.c_void_p(16), None) == -2  # > KGE_MAX_FILTERS
+    assert lib.kge_rank_hist(None, None, 3, 4, 7, None, 10, 10, None, None) == -1   # unknown tie policy
+    assert lib.kge_rank_hist(None, None, 0, 0, 0, None, 10, 10, None, None) == 0
+    # optimizer step: null / misaligned arrays
+    assert lib.kge_adagrad_step(None, None, None, 8, -0.1, 0.0, 1e-10, None, None) == -1
+    assert lib.kge_adagrad_step(ctypes.c_void_p(20), ctypes.c_void_p(16), ctypes.c_void_p(16), 8, -0.1, 0.0, 1e-10,
+                                None, None) == -1
+    assert lib.kge_adagrad_step(None, None, None, 0, -0.1, 0.0, 1e-10, None, None) == 0
