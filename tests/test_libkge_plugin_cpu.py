@@ -203,3 +203,36 @@ def test_optimizer_plugin_resolves_through_the_reference_factory():
     o_ref.step()
     for p, r in zip(m.parameters(), ref):
         torch.testing.assert_close(p.detach(), r.detach())
+
+
+def test_full_plugin_configuration_runs_an_epoch_and_a_validation_on_cpu(tmp_path):
+    """Everything the plugin registers, switched on at once in one LibKGE config:
+    train.type hip_1vsAll, optimizer HipAdagrad with bf16_copies, eval.type hip_entity_ranking.
+    With the reference's own `complex` model on job.device=cpu every fused path declines or falls
+    back, so this checks the plumbing: the factories resolve, an epoch trains, a validation
+    produces the reference's metric keys."""
+    import os
+    import shutil
+    rh.import_reference()
+    from kge import Dataset
+    from kge.job import TrainingJob
+    data = os.path.join(str(tmp_path), "dataset_test")
+    shutil.copytree(os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test"), data)
+    config = _job_config(str(tmp_path), "complex", "hip_1vsAll")
+    config._import("hip_entity_ranking")
+    config.set("eval.type", "hip_entity_ranking")
+    config.set("train.optimizer.default.type", "HipAdagrad")
+    config.set("train.optimizer.default.args.lr", 0.1, create=True)
+    config.set("train.optimizer.default.args.bf16_copies", True, create=True)
+    config.set("valid.every", 1)
+    config.set("valid.metric", "mean_reciprocal_rank_filtered")
+    torch.manual_seed(3)
+    job = TrainingJob.create(config, Dataset.create(config, folder=data))
+    assert type(job).__name__ == "HipTrainingJob1vsAll"
+    assert type(job.optimizer).__module__ == "kge_amd.optim"
+    assert type(job.valid_job).__name__ == "HipEntityRankingJob"
+    job.run()
+    assert job.epoch == 1 and len(job.valid_trace) == 1
+    metrics = job.valid_trace[0]
+    for key in ("mean_reciprocal_rank", "mean_reciprocal_rank_filtered", "hits_at_1_filtered"):
+        assert key in metrics and 0.0 <= metrics[key] <= 1.0
