@@ -318,12 +318,15 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     // the MFMA chain of the first tile waits for fragment kb right before it needs it.
     const unsigned char* sb =
         (const unsigned char*)(qf + ((long long)(rg * (V4_ROWS / 32) + w4) * NKB) * 64);  // uniform
-    auto fload = [](bf16x8& dst, unsigned int vo, const unsigned char* base) __attribute__((always_inline)) {
-      asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(dst) : "v"(vo), "s"(base) : "memory");
-    };
+    // compiler-visible buffer loads (not inline asm): the register allocator then knows the values
+    // arrive asynchronously and places the vmcnt waits itself, in front of the first MFMA of tile 0
+    // that needs each fragment (asm loads + asm waits are safe only while nothing
+    // is moved between them)
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)sb, 0, NKB * 1024, 0x00020000);
     v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
-      fload(afr[kb], (unsigned int)(lane * 16 + kb * 1024), sb);
+      afr[kb] = __builtin_bit_cast(
+          bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16 + kb * 1024), 0, 16 /* sc1 */));
     });
   }
   // B fragment (K-block kb, half hf) of target row 32*hf + fi: 16-B slot s = s0(kb) + fh, stored
@@ -347,7 +350,9 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   stamp();  // 3: fragment loads issued
 
   constexpr int PF = 8;
-  for (int tt = 0; tt < ntl; ++tt) {
+  // tile 0 is peeled off the loop: in straight-line code the compiler waits for fragment kb right in
+  // front of its first MFMA (inside a loop it waits for all of them at the loop entry)
+  auto tile = [&](int tt) __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; staging drained
     __builtin_amdgcn_sched_barrier(0);
@@ -382,7 +387,6 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(younger) : "memory");
       // first tile: fragment kb has arrived (in-order returns: at most NKB-1-kb younger loads
       // outstanding); a no-op afterwards
-      if constexpr ((q & 1) == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NKB - 1 - (q >> 1)) : "memory");
       if constexpr (q == QB2) __builtin_amdgcn_s_barrier();  // B2(tt): the scores of tile tt-1 are staged
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (q == 0) {
@@ -399,7 +403,9 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       if constexpr (q + PF < NQ) bread(bq[q % PF], std::integral_constant<int, q + PF>{});
     });
     stamp();  // tile tt: MFMA chain issued
-  }
+  };
+  tile(0);
+  for (int tt = 1; tt < ntl; ++tt) tile(tt);
   // the last tile's scores: stage them for the loaders' final pass
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // B1(ntl)
