@@ -395,6 +395,21 @@ int kge_score_spo_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_i
                             float* grad_ent, int64_t grad_ent_ld, float* grad_rel,
                             int64_t grad_rel_ld, void* stream);
 
+/* Backward of kge_score_neg (replaces autograd through BatchNegativeSample.score,
+ * kge/util/sampler.py:263-306, called at kge/job/train_negative_sampling.py:142-163): gradients
+ * of sum_{i,k} gout[i*ldg + k] * score(triple i with `slot` replaced by neg[i*neg_ld + k])
+ * ACCUMULATED into the dense table gradients like kge_score_spo_bwd_accum.  The relation row and
+ * the uncorrupted entity row of a positive are read once and their gradients summed in registers
+ * over 64 negatives; only the corrupted rows stream.  `scores` = the forward output [n, num_neg]
+ * (row pitch lds; needed for TransE / RotatE with l_norm != 1, may be NULL otherwise).
+ * f32 tables, dim <= 1024. */
+int kge_score_neg_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_index o,
+                            int64_t n, int slot, const void* neg, int32_t neg_itype,
+                            int64_t neg_ld, int64_t num_neg, const float* gout, int64_t ldg,
+                            const float* scores, int64_t lds, float* grad_ent,
+                            int64_t grad_ent_ld, float* grad_rel, int64_t grad_rel_ld,
+                            void* stream);
+
 /* Backward of kge_score_emb (dense embeddings).  SPO: g_s,g_o [n,dim], g_p [n,rel_dim].
  * SP_: g_s [n,dim], g_p [n,rel_dim], g_o [m,dim].  PO_: g_o [n,dim], g_p, g_s [m,dim]. */
 int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb,

@@ -412,6 +412,127 @@ __global__ __launch_bounds__(256) void bwd_spo_accum_kernel(Operand S, Operand R
   flush(gr, gr_ld, run_p, ap0, ap1, rl0, rl1);
 }
 
+// Backward of kge_score_neg (BatchNegativeSample.score, sampler.py:263-306, followed by autograd's
+// scatter-add of the gathered rows): gradients of sum_{i,k} gout[i,k] * score(triple i with `slot`
+// replaced by neg[i,k]) accumulated into the dense table gradients.  One wave per (positive, chunk
+// of NGA_CH negatives): the two FIXED rows of the positive (relation + the uncorrupted entity) are
+// loaded once and their gradients summed in registers over the chunk (one atomic per element and
+// chunk instead of one per negative); only the corrupted rows stream, and only their gradients go
+// out per negative.  No [n*K, 3] index tensor, no [n*K, d] row-gradient tensors.  d <= 1024.
+constexpr int NGA_CH = 64;
+
+template <int SCORER, int NORM, int SLOT>
+__global__ __launch_bounds__(256) void bwd_neg_accum_kernel(
+    Operand S, Operand R, Operand O, int d, int dr, long long n, const void* __restrict__ neg,
+    int neg_itype, long long neg_ld, long long K, int chunks_per_row, float lp,
+    const float* __restrict__ gout, long long ldg, const float* __restrict__ scores, long long lds,
+    float* __restrict__ ge, long long ge_ld, float* __restrict__ gr, long long gr_ld) {
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long row = w / chunks_per_row;
+  if (row >= n) return;
+  const long long k0 = (w % chunks_per_row) * NGA_CH;
+  const long long k1 = k0 + NGA_CH < K ? k0 + NGA_CH : K;
+  const int lane = threadIdx.x & 63;
+  const int hh = (d + 1) / 2, lim1 = d - hh;
+  const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;
+  const int rl1 = (SCORER == KGE_ROTATE) ? 0 : lim1;
+  const long long fi = SLOT == 0 ? index_at(O.idx, row) : index_at(S.idx, row);
+  const long long pi = index_at(R.idx, row);
+  const float* frow = (const float*)S.base + fi * S.ld;  // S.base == O.base: the entity table
+  const float* rrow = (const float*)R.base + pi * R.ld;
+  float f0[SPA_NC], f1[SPA_NC], r0[SPA_NC], r1[SPA_NC];
+  float af0[SPA_NC], af1[SPA_NC], ap0[SPA_NC], ap1[SPA_NC];
+#pragma unroll
+  for (int k = 0; k < SPA_NC; ++k) {
+    const int c = lane + 64 * k;
+    f0[k] = c < hh ? frow[c] : 0.f;
+    f1[k] = c < lim1 ? frow[hh + c] : 0.f;
+    r0[k] = c < rl0 ? rrow[c] : 0.f;
+    r1[k] = c < rl1 ? rrow[hh + c] : 0.f;
+    af0[k] = af1[k] = ap0[k] = ap1[k] = 0.f;
+  }
+  for (long long kk = k0; kk < k1; ++kk) {
+    const long long vi = neg_itype ? ((const long long*)neg)[row * neg_ld + kk]
+                                   : (long long)((const int*)neg)[row * neg_ld + kk];
+    const float* vrow = (const float*)S.base + vi * S.ld;
+    float* gv = ge + vi * ge_ld;
+    const float g = gout[row * ldg + kk];
+    const float dist =
+        (SCORER == KGE_TRANSE || SCORER == KGE_ROTATE) && NORM != NORM_L1 ? -scores[row * lds + kk] : 0.f;
+#pragma unroll
+    for (int k = 0; k < SPA_NC; ++k) {
+      const int c = lane + 64 * k;
+      if (c >= hh) break;
+      const bool has1 = c < lim1;
+      const float v0 = vrow[c], v1 = has1 ? vrow[hh + c] : 0.f;
+      float ds0, ds1, dp0, dp1, do0, do1;
+      if (SLOT == 0)
+        spo_pair_grads<SCORER, NORM>(v0, v1, r0[k], r1[k], f0[k], f1[k], has1, g, dist, lp, ds0, ds1, dp0, dp1,
+                                     do0, do1);
+      else
+        spo_pair_grads<SCORER, NORM>(f0[k], f1[k], r0[k], r1[k], v0, v1, has1, g, dist, lp, ds0, ds1, dp0, dp1,
+                                     do0, do1);
+      const float dv0 = SLOT == 0 ? ds0 : do0, dv1 = SLOT == 0 ? ds1 : do1;
+      af0[k] += SLOT == 0 ? do0 : ds0;
+      af1[k] += SLOT == 0 ? do1 : ds1;
+      ap0[k] += dp0;
+      ap1[k] += dp1;
+      unsafeAtomicAdd(gv + c, dv0);
+      if (has1) unsafeAtomicAdd(gv + hh + c, dv1);
+    }
+  }
+  float* gf = ge + fi * ge_ld;
+  float* gp = gr + pi * gr_ld;
+#pragma unroll
+  for (int k = 0; k < SPA_NC; ++k) {
+    const int c = lane + 64 * k;
+    if (c < hh) unsafeAtomicAdd(gf + c, af0[k]);
+    if (c < lim1) unsafeAtomicAdd(gf + hh + c, af1[k]);
+    if (c < rl0) unsafeAtomicAdd(gp + c, ap0[k]);
+    if (c < rl1) unsafeAtomicAdd(gp + hh + c, ap1[k]);
+  }
+}
+
+int run_neg_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
+                      int dr, long long n, int slot, const void* neg, int neg_itype, long long neg_ld,
+                      long long K, const float* gout, long long ldg, const float* scores, long long lds,
+                      float* ge, long long ge_ld, float* gr, long long gr_ld, hipStream_t st) {
+  if (n == 0 || K == 0) return KGE_OK;
+  if ((d + 1) / 2 > 64 * SPA_NC) return KGE_ERR_UNSUPPORTED;
+  const int norm = norm_mode(lp);
+  const bool dot = scorer == KGE_COMPLEX || scorer == KGE_DISTMULT;
+  if (!dot && norm != NORM_L1 && !scores) return KGE_ERR_INVALID_ARG;
+  const long long cpr = (K + NGA_CH - 1) / NGA_CH;
+  const long long waves = n * cpr;
+  if (cpr > (1LL << 30) || (waves + 3) / 4 > 0x7fffffffLL) return KGE_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+#define KGE_NA2(SC, NM, SL)                                                                         \
+  hipLaunchKernelGGL((bwd_neg_accum_kernel<SC, NM, SL>), grid, dim3(256), 0, st, S, R, O, d, dr, n,  \
+                     neg, neg_itype, neg_ld, K, (int)cpr, lp, gout, ldg, scores, lds, ge, ge_ld, gr, \
+                     gr_ld)
+#define KGE_NA(SC, NM)                                                \
+  {                                                                   \
+    if (slot == 0) KGE_NA2(SC, NM, 0);                                \
+    else KGE_NA2(SC, NM, 2);                                          \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH; \
+  }
+  switch (scorer) {
+    case KGE_COMPLEX: KGE_NA(KGE_COMPLEX, NORM_L1);
+    case KGE_DISTMULT: KGE_NA(KGE_DISTMULT, NORM_L1);
+    case KGE_TRANSE:
+      if (norm == NORM_L1) KGE_NA(KGE_TRANSE, NORM_L1);
+      if (norm == NORM_L2) KGE_NA(KGE_TRANSE, NORM_L2);
+      KGE_NA(KGE_TRANSE, NORM_LP);
+    case KGE_ROTATE:
+      if (norm == NORM_L1) KGE_NA(KGE_ROTATE, NORM_L1);
+      if (norm == NORM_L2) KGE_NA(KGE_ROTATE, NORM_L2);
+      KGE_NA(KGE_ROTATE, NORM_LP);
+  }
+#undef KGE_NA
+#undef KGE_NA2
+  return KGE_ERR_INVALID_ARG;
+}
+
 template <int SCORER, int NORM>
 static int launch_bwd_pairs(int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
                             int dr, long long n, long long m, float lp, const float* gout,

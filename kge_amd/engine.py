@@ -126,6 +126,17 @@ def _index(ix, device, keep):
     return KgeIndex(ix.data_ptr(), I32 if ix.dtype == torch.int32 else I64, 0, stride)
 
 
+def _same_len(ixs, what):
+    """All index operands of one call must have the same length (the reference would raise a shape
+    error; a shorter vector here would be an out-of-bounds read on the device)."""
+    n = ixs[0].numel()
+    for x in ixs[1:]:
+        if x.numel() != n:
+            raise ValueError(f"kge_amd: {what}: index vectors of different lengths "
+                             f"({[int(y.numel()) for y in ixs]})")
+    return n
+
+
 class Tables:
     """Entity and relation lookup tables of one model (LookupEmbedder weights,
     kge/model/embedder/lookup_embedder.py:44-46) as the kernels see them."""
@@ -169,7 +180,7 @@ class Tables:
 def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "score_spo")
     out = _empty((n,), t.device)
     with torch.cuda.device(t.device):
         tc = t.c(flags)
@@ -181,7 +192,7 @@ def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
 def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
     keep = []
     ai, pi = _index(a, t.device, keep), _index(p, t.device, keep)
-    n = keep[0].numel()
+    n = _same_len(keep[:2], "_pairs")
     ti = _index(targets, t.device, keep)
     m = t.num_ent if targets is None else keep[-1].numel()
     if out is None:
@@ -215,7 +226,7 @@ def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Ten
     into the two halves of the output (no torch.cat copy, kge_model.py:789)."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "score_sp_po")
     ti = _index(entity_subset, t.device, keep)
     m = t.num_ent if entity_subset is None else keep[-1].numel()
     out = _empty((n, 2 * m), t.device)
@@ -234,7 +245,7 @@ def score_neg(t: Tables, s, p, o, slot: int, neg: torch.Tensor, flags=None) -> t
     """[n, K] scores of triple i with `slot` (0 = s, 2 = o) replaced by neg[i, k]."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "score_neg")
     _require_gpu(neg, "negative samples")
     if neg.dtype not in (torch.int32, torch.int64):
         neg = neg.long()
@@ -251,6 +262,40 @@ def score_neg(t: Tables, s, p, o, slot: int, neg: torch.Tensor, flags=None) -> t
             I32 if neg.dtype == torch.int32 else I64, neg.stride(0) if n > 1 else K, K,
             out.data_ptr(), K, _stream(t.device)), "kge_score_neg")
     return out
+
+
+def score_neg_bwd_accum(t: Tables, s, p, o, slot: int, neg: torch.Tensor, gout, scores, grad_ent, grad_rel):
+    """Backward of score_neg accumulated straight into the dense table gradients `grad_ent` [E, d] and
+    `grad_rel` [R, d_r] (f32, modified in place); False if the kernel does not take this shape."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = _same_len(keep[:3], "score_neg_bwd_accum")
+    if neg.dtype not in (torch.int32, torch.int64):
+        neg = neg.long()
+    if neg.dim() != 2 or neg.shape[0] != n:
+        raise ValueError("kge_amd: neg must be [n, K]")
+    if neg.stride(1) != 1:
+        neg = neg.contiguous()
+    K = neg.shape[1]
+    gout = gout.to(device=t.device, dtype=torch.float32)
+    if gout.dim() != 2 or gout.stride(1) != 1:
+        gout = gout.contiguous().view(n, K)
+    sc = None
+    if scores is not None:
+        sc = scores if (scores.dim() == 2 and scores.stride(1) == 1) else scores.contiguous().view(n, K)
+    with _on_device(t.device):
+        tc = t.c()
+        rc = _lib.lib().kge_score_neg_bwd_accum(
+            ctypes.byref(tc), si, pi, oi, n, int(slot), neg.data_ptr(),
+            I32 if neg.dtype == torch.int32 else I64, neg.stride(0) if n > 1 else max(K, 1), K,
+            gout.data_ptr(), gout.stride(0) if n > 1 else max(K, 1), None if sc is None else sc.data_ptr(),
+            0 if sc is None else (sc.stride(0) if n > 1 else max(K, 1)), grad_ent.data_ptr(), grad_ent.stride(0),
+            grad_rel.data_ptr(), grad_rel.stride(0), _stream_handle(t.device))
+    if rc == _lib.KGE_ERR_UNSUPPORTED:
+        return False
+    if rc:
+        _lib.check(rc, "kge_score_neg_bwd_accum")
+    return True
 
 
 _EMB_TC = {}
@@ -389,7 +434,7 @@ def filter_lookup(sorted_keys, starts, a, b, mult: int, begin, end):
     dev = begin.device
     keep = []
     ai, bi = _index(a, dev, keep), _index(b, dev, keep)
-    n = keep[0].numel()
+    n = _same_len(keep[:2], "filter_lookup")
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().kge_filter_lookup(
             sorted_keys.data_ptr(), sorted_keys.numel(), starts.data_ptr(), ai, bi, int(mult), n,
@@ -444,7 +489,7 @@ def score_spo_bwd(t: Tables, s, p, o, gout, scores=None):
     (g_s [n,d], g_p [n,d_r], g_o [n,d])."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "score_spo_bwd")
     d, dr = t.ent.shape[1], t.rel.shape[1]
     gout = _f32c(gout, t.device)
     sc = None if scores is None else _f32c(scores, t.device)
@@ -463,7 +508,7 @@ def score_spo_bwd_accum(t: Tables, s, p, o, gout, scores, grad_ent, grad_rel):
     shape (the caller then uses score_spo_bwd + index_add)."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "score_spo_bwd_accum")
     gout = _f32c(gout, t.device)
     sc = None if scores is None else _f32c(scores, t.device)
     with _on_device(t.device):
@@ -484,7 +529,7 @@ def score_pairs_bwd(t: Tables, direction: str, a, p, targets, gout, scores=None)
     (g_a [n,d], g_p [n,d_r], g_targets [m,d])."""
     keep = []
     ai, pi = _index(a, t.device, keep), _index(p, t.device, keep)
-    n = keep[0].numel()
+    n = _same_len(keep[:2], "score_pairs_bwd")
     ti = _index(targets, t.device, keep)
     m = t.num_ent if targets is None else keep[-1].numel()
     d, dr = t.ent.shape[1], t.rel.shape[1]
@@ -538,7 +583,7 @@ def ce_fwd(t: Tables, direction: str, a, p, label):
     KLDivWithSoftmaxKgeLoss (kge/util/loss.py:192-207) on the [n, E] scores, never written here."""
     keep = []
     ai, pi, li = (_index(x, t.device, keep) for x in (a, p, label))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "ce_fwd")
     loss_rows, lse = _empty((n,), t.device), _empty((n,), t.device)
     with _on_device(t.device):
         tc = t.c()
@@ -554,7 +599,7 @@ def ce_bwd(t: Tables, direction: str, a, p, label, lse, g_rows=None, g_scalar: f
     all entity rows: (g_a [n, d], g_p [n, d], g_entities [E, d])."""
     keep = []
     ai, pi, li = (_index(x, t.device, keep) for x in (a, p, label))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "ce_bwd")
     d, dr = t.ent.shape[1], t.rel.shape[1]
     lse = _f32c(lse, t.device)
     gr = None if g_rows is None else _f32c(g_rows, t.device)
@@ -586,7 +631,7 @@ def ce_sp_po_fwd(t: Tables, s, p, o):
     cross entropy of score_sp(s, p) against o, rows [n, 2n) = of score_po(p, o) against s."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "ce_sp_po_fwd")
     loss_rows, lse = _empty((2 * n,), t.device), _empty((2 * n,), t.device)
     with _on_device(t.device):
         tc = t.c()
@@ -602,7 +647,7 @@ def ce_sp_po_bwd(t: Tables, s, p, o, lse, g_rows=None, g_scalar: float = 1.0):
     g_p [2n, d]; g_entities [E, d])."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "ce_sp_po_bwd")
     d, dr = t.ent.shape[1], t.rel.shape[1]
     lse = _f32c(lse, t.device)
     gr = None if g_rows is None else _f32c(g_rows, t.device)
@@ -622,7 +667,7 @@ def ce_sp_po_bwd_accum(t: Tables, s, p, o, lse, g_rows=None, g_scalar: float = 1
     (grad_entities [E, d], grad_relations [R, d]) of the two tables."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = keep[0].numel()
+    n = _same_len(keep[:3], "ce_sp_po_bwd_accum")
     lse = _f32c(lse, t.device)
     gr = None if g_rows is None else _f32c(g_rows, t.device)
     ge, grel = _empty(tuple(t.ent.shape), t.device), _empty(tuple(t.rel.shape), t.device)
@@ -649,7 +694,7 @@ def kl_fwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col):
     labels (int64 CSR): (loss_rows [n], lse [n]); kge/util/loss.py:208-213 without smoothing."""
     keep = []
     ai, pi = (_index(x, t.device, keep) for x in (a, p))
-    n = keep[0].numel()
+    n = _same_len(keep[:2], "kl_fwd")
     rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
     loss_rows, lse = _empty((n,), t.device), _empty((n,), t.device)
     with _on_device(t.device):
@@ -666,7 +711,7 @@ def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=Non
     """Backward of kl_fwd: (g_a [n, d], g_p [n, d], g_entities [E, d])."""
     keep = []
     ai, pi = (_index(x, t.device, keep) for x in (a, p))
-    n = keep[0].numel()
+    n = _same_len(keep[:2], "kl_bwd")
     rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
     d, dr = t.ent.shape[1], t.rel.shape[1]
     lse = _f32c(lse, t.device)
@@ -688,7 +733,7 @@ def bce_fwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, offset: float 
     multi-hot labels (int64 CSR): loss_rows [n]; kge/util/loss.py:137-159, bce_type None."""
     keep = []
     ai, pi = (_index(x, t.device, keep) for x in (a, p))
-    n = keep[0].numel()
+    n = _same_len(keep[:2], "bce_fwd")
     rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
     loss_rows = _empty((n,), t.device)
     with _on_device(t.device):
@@ -706,7 +751,7 @@ def bce_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, offset: float 
     """Backward of bce_fwd: (g_a [n, d], g_p [n, d], g_entities [E, d])."""
     keep = []
     ai, pi = (_index(x, t.device, keep) for x in (a, p))
-    n = keep[0].numel()
+    n = _same_len(keep[:2], "bce_bwd")
     rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
     d, dr = t.ent.shape[1], t.rel.shape[1]
     gr = None if g_rows is None else _f32c(g_rows, t.device)

@@ -5,7 +5,8 @@ Usage inside an unmodified LibKGE installation (config-default.yaml:137, README.
     modules: [kge.job, kge.model, kge.model.embedder, kge_amd.libkge_plugin]
     model: hip_complex            # or hip_distmult / hip_transe / hip_rotate
     # optional: eval.type: hip_entity_ranking
-    # optional: train.type: hip_1vsAll / hip_KvsAll  (kl loss fused into the scoring kernel)
+    # optional: train.type: hip_1vsAll / hip_KvsAll  (kl / bce loss fused into the scoring kernel)
+    #           train.type: hip_negative_sampling  (negatives through the fused gather + score kernel)
     # optional: train.optimizer.default.type: HipAdagrad  (one-pass Adagrad; args as for Adagrad,
     #           plus bf16_copies: true to keep the bf16 scoring tables fresh without a cast)
 
@@ -27,7 +28,8 @@ except ImportError as e:  # pragma: no cover
 from .models import (HipComplEx, HipComplExScorer, HipDistMult, HipDistMultScorer,  # noqa: F401
                      HipRotatE, HipRotatEScorer, HipTransE, HipTransEScorer)
 from .eval_job import HipEntityRankingJob  # noqa: F401
-from .train_job import HipTrainingJob1vsAll, HipTrainingJobKvsAll  # noqa: F401
+from .train_job import (HipTrainingJob1vsAll, HipTrainingJobKvsAll,  # noqa: F401
+                        HipTrainingJobNegativeSampling)
 
 # kge/util/optimizer.py:15-20 resolves train.optimizer.default.type with getattr(torch.optim, ...)
 import torch.optim as _torch_optim

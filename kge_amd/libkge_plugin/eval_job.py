@@ -1,16 +1,38 @@
-"""EntityRankingJob with the fused rank-count kernel (eval.type: hip_entity_ranking)."""
+"""EntityRankingJob on the fused kernels (eval.type: hip_entity_ranking)."""
+import math
+import time
+
+import numpy as np
 import torch
 
-from kge.job.eval_entity_ranking import EntityRankingJob
+from kge.job import EvaluationJob
+from kge.job.eval_entity_ranking import EntityRankingJob, hist_all
 
 from .. import engine
+from ..eval import FilterIndex
 
 
 class HipEntityRankingJob(EntityRankingJob):
-    """Overrides only `_get_ranks_and_num_ties` (eval_entity_ranking.py:571-596): one
-    streaming kernel pass instead of clone/isnan/isclose/gt/and/2x sum.  The loop,
-    label handling, histograms and metrics stay the reference's code, so identical counts
-    give identical MRR / Hits@k."""
+    """`EntityRankingJob._evaluate` (eval_entity_ranking.py:103-481) without its per-batch host work.
+
+    With a hip_* model on a GPU (`_fast_path()`), a batch never leaves the device:
+
+      * `_collate`'s numba dictionary lookups + `coord_to_sparse_tensor` + `_densify_chunk_of_labels`
+        (:77-101, 179-181, 489-531; kge/job/util.py:6-60) become ranges into a device-resident
+        sorted filter index (kge_amd.eval.FilterIndex, built once in `_prepare` from the same
+        splits) looked up by kge_filter_lookup -- no `[n, 2E]` dense 0/inf label matrix;
+      * one `_filter_and_rank` per ranking (:533-596, ~10 passes over `[n, 2E]` each) becomes ONE
+        kge_rank_counts_multi scan per direction for raw + filtered + filtered-with-test;
+      * the true scores are elements of the score matrix (unchunked) or come from scoring every row
+        against the batch's own targets (chunked) -- the same kernel chain as the matrix entries, so
+        the reference's tie-consistency check (:254-274) holds by construction and the
+        `torch.unique` waits (:192-203) disappear;
+      * `hist_all` (:665-687) becomes kge_rank_hist when it is the only histogram hook.
+
+    Everything observable stays the reference's: hooks, trace entries and their keys, per-batch and
+    final metrics (`_compute_metrics`, `_get_ranks` are inherited), console output.  Any other model
+    or device runs the reference's `_evaluate`, with `_get_ranks_and_num_ties` (:571-596) replaced
+    by the streaming rank-count kernel when the scores are on a GPU."""
 
     def _get_ranks_and_num_ties(self, scores: torch.Tensor, true_scores: torch.Tensor):
         if not scores.is_cuda:
@@ -18,3 +40,181 @@ class HipEntityRankingJob(EntityRankingJob):
         if scores.stride(-1) != 1:
             scores = scores.contiguous()
         return engine.rank_counts(scores, true_scores.view(-1), atol=self.tie_atol, rtol=self.tie_rtol)
+
+    # ------------------------------------------------------------------------------------------
+    def _fast_path(self) -> bool:
+        m = self.model
+        if not (hasattr(m, "_fused") and hasattr(m, "_w")):
+            return False
+        if not str(self.device).startswith("cuda"):
+            return False
+        was_training = m.training
+        m.eval()  # _evaluate runs in eval mode (eval.py:58-95): dropout is inactive then
+        ok = bool(m._fused()) and m._w()[0].is_cuda
+        m.train(was_training)
+        return ok
+
+    def _prepare(self):
+        self._hip_fast = self._fast_path()
+        if not self._hip_fast:
+            return super()._prepare()
+        EvaluationJob._prepare(self)  # the base class's part; EntityRankingJob's builds the numba indexes
+        self.triples = self.dataset.split(self.config.get("eval.split"))
+        E, R = self.dataset.num_entities(), self.dataset.num_relations()
+        dev = torch.device(self.device)
+        splits = [self.dataset.split(s).numpy() for s in self.filter_splits]
+        idx = [FilterIndex(splits, E, R)]
+        self._hip_filter_with_test = "test" not in self.filter_splits and self.filter_with_test
+        if self._hip_filter_with_test:
+            idx.append(FilterIndex(splits + [self.dataset.split("test").numpy()], E, R))
+
+        def dev_arrays(t):
+            uk, start, v = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in t)
+            if v.numel() == 0:  # an empty value array still needs an address
+                v = torch.zeros(1, dtype=torch.int64, device=dev)
+            return uk, start, v
+
+        self._hip_sp = [dev_arrays(i._sp) for i in idx]
+        self._hip_po = [dev_arrays(i._po) for i in idx]
+        self.loader = torch.utils.data.DataLoader(
+            self.triples,
+            collate_fn=lambda batch: (torch.cat(batch).reshape((-1, 3)),),
+            shuffle=False,
+            batch_size=self.batch_size,
+            num_workers=self.config.get("eval.num_workers"),
+            pin_memory=self.config.get("eval.pin_memory"),
+        )
+
+    @torch.no_grad()
+    def _evaluate(self):
+        if not getattr(self, "_hip_fast", False):
+            return super()._evaluate()
+        E, R = self.dataset.num_entities(), self.dataset.num_relations()
+        dev = torch.device(self.device)
+        filter_with_test = self._hip_filter_with_test
+        rankings = ["_raw", "_filt", "_filt_test"] if filter_with_test else ["_raw", "_filt"]
+        M = len(rankings)
+        suffixes = ["", "_filtered", "_filtered_with_test"][:M]
+        kernel_hist = self.hist_hooks == [hist_all] and not self.head_and_tail
+        hists = [dict() for _ in range(M)]  # raw, filt, filt_test: key -> histogram
+        chunk_size = self.config.get("entity_ranking.chunk_size")
+        if chunk_size <= -1:
+            chunk_size = E
+
+        self.current_trace["epoch"] = dict(
+            type="entity_ranking", scope="epoch", split=self.eval_split, filter_splits=self.filter_splits,
+            epoch=self.epoch, batches=len(self.loader), size=len(self.triples))
+        for f in self.pre_epoch_hooks:
+            f(self)
+
+        metrics = {}
+        epoch_time = -time.time()
+        for batch_number, batch_coords in enumerate(self.loader):
+            self.current_trace["batch"] = dict(
+                type="entity_ranking", scope="batch", split=self.eval_split, filter_splits=self.filter_splits,
+                epoch=self.epoch, batch=batch_number, size=len(batch_coords[0]), batches=len(self.loader))
+            for f in self.pre_batch_hooks:
+                f(self)
+
+            batch = batch_coords[0].to(dev)
+            s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
+            n = batch.shape[0]
+            s64, o64 = s.long().contiguous(), o.long().contiguous()  # true_col of the po / sp rankings
+            rng = torch.empty(2, M - 1, 2, n, dtype=torch.int64, device=dev)
+            cnt = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)  # [o|s][rank|ties][ranking][row]
+            filt_o, filt_s = [], []
+            for k in range(M - 1):
+                uk, start, v = self._hip_sp[k]
+                engine.filter_lookup(uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1])
+                filt_o.append((rng[0, k, 0], rng[0, k, 1], v))
+                uk, start, v = self._hip_po[k]
+                engine.filter_lookup(uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1])
+                filt_s.append((rng[1, k, 0], rng[1, k, 1], v))
+
+            o_true = s_true = None
+            if chunk_size < E:
+                # the subset path of :192-203 without torch.unique: every row against the batch's
+                # own targets, diagonal kept (each score is its own kernel chain)
+                o_true = self.model.score_sp(s, p, o64).diagonal().contiguous()
+                s_true = self.model.score_po(p, o, s64).diagonal().contiguous()
+            for chunk_number in range(math.ceil(E / chunk_size)):
+                chunk_start = chunk_size * chunk_number
+                chunk_end = min(chunk_size * (chunk_number + 1), E)
+                c = chunk_end - chunk_start
+                sub = None if c == E else torch.arange(chunk_start, chunk_end, device=dev)
+                scores = self.model.score_sp_po(s, p, o, sub)
+                scores_sp, scores_po = scores[:, :c], scores[:, c:]
+                if o_true is None:
+                    o_true = scores_sp.gather(1, o64.view(-1, 1)).view(-1)
+                    s_true = scores_po.gather(1, s64.view(-1, 1)).view(-1)
+                engine.rank_counts_multi(scores_sp, o_true, filt_o, chunk_start, o64, self.tie_atol,
+                                         self.tie_rtol, cnt[0, 0], cnt[0, 1])
+                engine.rank_counts_multi(scores_po, s_true, filt_s, chunk_start, s64, self.tie_atol,
+                                         self.tie_rtol, cnt[1, 0], cnt[1, 1])
+
+            # final ranks from the counts (inherited tie policy) + histograms
+            o_ranks = [self._get_ranks(cnt[0, 0, m], cnt[0, 1, m]) for m in range(M)]
+            s_ranks = [self._get_ranks(cnt[1, 0, m], cnt[1, 1, m]) for m in range(M)]
+            batch_hists = [dict() for _ in range(M)]
+            if kernel_hist:
+                h = torch.zeros(M, E, dtype=torch.float, device=dev)
+                engine.rank_hist(cnt[0, 0], cnt[0, 1], self.tie_handling, h)
+                engine.rank_hist(cnt[1, 0], cnt[1, 1], self.tie_handling, h)
+                for m in range(M):
+                    batch_hists[m]["all"] = h[m]
+            else:
+                for f in self.hist_hooks:
+                    for m in range(M):
+                        f(batch_hists[m], s, p, o, s_ranks[m], o_ranks[m], job=self)
+
+            if self.trace_examples:
+                entry = {"type": "entity_ranking", "scope": "example", "split": self.eval_split,
+                         "filter_splits": self.filter_splits, "size": len(batch), "batches": len(self.loader),
+                         "epoch": self.epoch}
+                sl, pl, ol = s.tolist(), p.tolist(), o.tolist()
+                o_r = [r.tolist() for r in o_ranks]
+                s_r = [r.tolist() for r in s_ranks]
+                for i in range(len(batch)):
+                    entry["batch"] = i
+                    entry["s"], entry["p"], entry["o"] = sl[i], pl[i], ol[i]
+                    if filter_with_test:
+                        entry["rank_filtered_with_test"] = o_r[2][i] + 1
+                    self.trace(event="example_rank", task="sp", rank=o_r[0][i] + 1,
+                               rank_filtered=o_r[1][i] + 1, **entry)
+                    if filter_with_test:
+                        entry["rank_filtered_with_test"] = s_r[2][i] + 1
+                    self.trace(event="example_rank", task="po", rank=s_r[0][i] + 1,
+                               rank_filtered=s_r[1][i] + 1, **entry)
+
+            metrics = {}
+            for m in range(M):
+                metrics.update(self._compute_metrics(batch_hists[m]["all"], suffix=suffixes[m]))
+            self.current_trace["batch"].update(metrics)
+            for f in self.post_batch_hooks:
+                f(self)
+            if self.trace_batch:
+                self.trace(**self.current_trace["batch"])
+            self.current_trace["batch"] = None
+
+            self.config.print(
+                ("\r" + "{}  batch:{: " + str(1 + int(math.ceil(math.log10(len(self.loader))))) + "d}/{}, "
+                 + "mrr (filt.): {:4.3f} ({:4.3f}), hits@1: {:4.3f} ({:4.3f}), hits@{}: {:4.3f} ({:4.3f})"
+                 + "\033[K").format(
+                    self.config.log_prefix, batch_number, len(self.loader) - 1,
+                    metrics["mean_reciprocal_rank"], metrics["mean_reciprocal_rank_filtered"],
+                    metrics["hits_at_1"], metrics["hits_at_1_filtered"], self.hits_at_k_s[-1],
+                    metrics["hits_at_{}".format(self.hits_at_k_s[-1])],
+                    metrics["hits_at_{}_filtered".format(self.hits_at_k_s[-1])]),
+                end="", flush=True)
+
+            for m in range(M):
+                for key, hist in batch_hists[m].items():
+                    hists[m][key] = hists[m][key] + hist if key in hists[m] else hist
+
+        self.config.print("\033[2K\r", end="", flush=True)
+        for key in hists[0]:
+            name = "_" + key if key != "all" else ""
+            for m in range(M):
+                metrics.update(self._compute_metrics(hists[m][key], suffix=suffixes[m] + name))
+        epoch_time += time.time()
+        self.current_trace["epoch"].update(dict(epoch_time=epoch_time, event="eval_completed", **metrics))

@@ -8,7 +8,8 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import BF16Shadow, _FusedBCE, _FusedCE, _FusedCE2, _FusedKL, _ScoreEmb, _ScorePairs, _ScoreSPO
+from ..model import (BF16Shadow, _FusedBCE, _FusedCE, _FusedCE2, _FusedKL, _ScoreEmb, _ScoreNeg, _ScorePairs,
+                     _ScoreSPO)
 
 
 class _HipScorer(RelationalScorer):
@@ -81,6 +82,18 @@ class _FusedScoring:
             return super().score_spo(s, p, o, direction)
         ent, rel = self._w()
         return _ScoreSPO.apply(self._scorer.name, self._scorer._norm, ent, rel, s, p, o)
+
+    def score_neg(self, s: Tensor, p: Tensor, o: Tensor, slot: int, neg: Tensor) -> Tensor:
+        """[n, K] scores of the positives with slot (0 = s, 2 = o) replaced by neg[i, k]: what
+        BatchNegativeSample.score returns (kge/util/sampler.py:263-306), from kge_score_neg -- the
+        positives' fixed rows are read once, only the corrupted rows stream; None if the fused
+        path does not apply (HipTrainingJobNegativeSampling then calls the sampler's own score)."""
+        if not self._fused() or slot not in (0, 2):
+            return None
+        ent, rel = self._w()
+        if not ent.is_cuda:
+            return None
+        return _ScoreNeg.apply(self._scorer.name, self._scorer._norm, ent, rel, s, p, o, int(slot), neg)
 
     def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
         if not self._fused():

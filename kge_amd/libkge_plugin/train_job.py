@@ -1,5 +1,6 @@
 """TrainingJob1vsAll / TrainingJobKvsAll with the kl or bce loss fused into the scoring kernel
-(train.type: hip_1vsAll / hip_KvsAll)."""
+(train.type: hip_1vsAll / hip_KvsAll) and TrainingJobNegativeSampling with the negatives scored by
+the fused gather + score kernel (train.type: hip_negative_sampling)."""
 import time
 
 import torch
@@ -16,9 +17,24 @@ def _plain_bce(loss):
         return None
     return float(loss._offset)
 
+
+
+def _model_takes_fused_loss(model) -> bool:
+    """Decided ONCE per subbatch, before any backward: a decline after the first direction's
+    loss.backward() would make the reference path back-propagate that direction a second time."""
+    f = getattr(model, "_ce_tables", None)
+    return f is not None and f() is not None
+
+
+def _declined_late(what):
+    raise RuntimeError(f"kge_amd: {what} declined after part of the subbatch was already back-propagated "
+                       "(tables or options changed inside a subbatch)")
+
+
 from kge.job import Job
 from kge.job.train_1vsAll import TrainingJob1vsAll
 from kge.job.train_KvsAll import TrainingJobKvsAll
+from kge.job.train_negative_sampling import SLOT_STR, TrainingJobNegativeSampling, S, P, O
 from kge.util.loss import BCEWithLogitsKgeLoss, KLDivWithSoftmaxKgeLoss
 
 
@@ -48,7 +64,7 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
             result.forward_time -= time.time()
             rows = rows_fn()
             if rows is None:
-                return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
+                _declined_late("bce_loss_sp / bce_loss_po")
             loss_value = rows.sum() / batch_size
             result.avg_loss += loss_value.item()
             result.forward_time += time.time()
@@ -58,6 +74,8 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
             result.backward_time += time.time()
 
     def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
+        if not _model_takes_fused_loss(self.model):
+            return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
         offset = _plain_bce(self.loss)
         if offset is not None and hasattr(self.model, "bce_loss_sp"):
             return self._process_subbatch_bce(batch_index, batch, subbatch_slice, result, offset)
@@ -74,22 +92,22 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
             # the same gradients, accumulated)
             result.forward_time -= time.time()
             rows = self.model.loss_sp_po(triples[:, 0], triples[:, 1], triples[:, 2])
-            if rows is not None:
-                loss_value = rows.sum() / batch_size
-                result.avg_loss += loss_value.item()
-                result.forward_time += time.time()
-                result.backward_time -= time.time()
-                if not self.is_forward_only:
-                    loss_value.backward()
-                result.backward_time += time.time()
-                return
+            if rows is None:
+                _declined_late("loss_sp_po")
+            loss_value = rows.sum() / batch_size
+            result.avg_loss += loss_value.item()
             result.forward_time += time.time()
+            result.backward_time -= time.time()
+            if not self.is_forward_only:
+                loss_value.backward()
+            result.backward_time += time.time()
+            return
         for loss_rows_fn in (lambda: self.model.loss_sp(triples[:, 0], triples[:, 1], triples[:, 2]),
                              lambda: self.model.loss_po(triples[:, 1], triples[:, 2], triples[:, 0])):
             result.forward_time -= time.time()
             rows = loss_rows_fn()
-            if rows is None:  # the model declined (tables / options changed): reference path for all
-                return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
+            if rows is None:
+                _declined_late("loss_sp / loss_po")
             loss_value = rows.sum() / batch_size
             result.avg_loss += loss_value.item()
             result.forward_time += time.time()
@@ -120,7 +138,7 @@ class HipTrainingJobKvsAll(TrainingJobKvsAll):
         return _plain_bce(self.loss) is not None and hasattr(self.model, "bce_loss_sp")
 
     def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
-        if not self._fused_ok():
+        if not self._fused_ok() or not _model_takes_fused_loss(self.model):
             return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
         batch_size = result.size
         result.prepare_time -= time.time()
@@ -154,13 +172,73 @@ class HipTrainingJobKvsAll(TrainingJobKvsAll):
             else:
                 loss_rows = (self.model.bce_loss_sp(q0, q1, rowptr, col, offset) if query_type == "sp_"
                              else self.model.bce_loss_po(q0, q1, rowptr, col, offset))
-            if loss_rows is None:  # the model declined: reference path for the whole subbatch
-                result.forward_time += time.time()
-                return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
+            if loss_rows is None:
+                _declined_late("kl_loss_* / bce_loss_*")
             loss_value = loss_rows.sum() / batch_size  # averaged over the batch, not the subbatch
             result.avg_loss += loss_value.item()
             result.forward_time += time.time()
             result.backward_time -= time.time()
             if not self.is_forward_only:
                 loss_value.backward()
+            result.backward_time += time.time()
+
+
+class HipTrainingJobNegativeSampling(TrainingJobNegativeSampling):
+    """Overrides only `_process_subbatch` (train_negative_sampling.py:103-164).  The reference scores
+    a slot's negatives through `BatchNegativeSample.score` (sampler.py:263-344): implementation
+    "triple" builds an [n*K, 3] index tensor and gathers three [n*K, d] row sets for score_spo,
+    "batch" / "all" score against the unique samples and pick entries out of an [n, U] matrix.
+    Here the subject- and object-slot negatives of a model that offers `score_neg` (the hip_* models)
+    go to kge_score_neg as (positives, neg [n, K]) directly: the relation row and the uncorrupted
+    entity row of each positive are read once, only the corrupted rows stream, and
+    the backward accumulates straight into the table gradients (kge_score_neg_bwd_accum).  Labels,
+    loss, averaging, timing keys and the relation slot (score_so) stay the reference's code."""
+
+    def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
+        super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
+        self.type_str = "negative_sampling"
+        if self.__class__ == HipTrainingJobNegativeSampling:
+            for f in Job.job_created_hooks:
+                f(self)
+
+    def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
+        if not hasattr(self.model, "score_neg"):
+            return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
+        batch_size = result.size
+        result.prepare_time -= time.time()
+        triples = batch["triples"][subbatch_slice]
+        batch_negative_samples = batch["negative_samples"]
+        subbatch_size = len(triples)
+        result.prepare_time += time.time()
+        labels = batch["labels"]  # reuse b/w subbatches
+        for slot in [S, P, O]:
+            num_samples = self._sampler.num_samples[slot]
+            if num_samples <= 0:
+                continue
+            if labels[slot] is None or labels[slot].shape != (subbatch_size, 1 + num_samples):
+                result.prepare_time -= time.time()
+                labels[slot] = torch.zeros((subbatch_size, 1 + num_samples), device=self.device)
+                labels[slot][:, 0] = 1
+                result.prepare_time += time.time()
+            result.forward_time -= time.time()
+            scores = torch.empty((subbatch_size, num_samples + 1), device=self.device)
+            scores[:, 0] = self.model.score_spo(triples[:, S], triples[:, P], triples[:, O],
+                                                direction=SLOT_STR[slot])
+            neg_scores = None
+            if slot != P:
+                neg_scores = self.model.score_neg(triples[:, S], triples[:, P], triples[:, O], slot,
+                                                  batch_negative_samples[slot].samples(subbatch_slice))
+            result.forward_time += time.time()
+            if neg_scores is None:  # relation slot, or the model declined: the sampler's own scoring
+                neg_scores = batch_negative_samples[slot].score(self.model, indexes=subbatch_slice)
+                result.forward_time += batch_negative_samples[slot].forward_time
+                result.prepare_time += batch_negative_samples[slot].prepare_time
+            scores[:, 1:] = neg_scores
+            result.forward_time -= time.time()
+            loss_value_torch = self.loss(scores, labels[slot], num_negatives=num_samples) / batch_size
+            result.avg_loss += loss_value_torch.item()
+            result.forward_time += time.time()
+            result.backward_time -= time.time()
+            if not self.is_forward_only:
+                loss_value_torch.backward()
             result.backward_time += time.time()

@@ -87,7 +87,7 @@ class RelationalScorer(torch.nn.Module):
             p_embs = p_emb.repeat((n, 1))
             o_embs = o_emb.repeat_interleave(n_p, 0)
             return _ScoreEmb.apply(self.name, "spo", self._norm, s_embs, p_embs, o_embs).view(n, -1)
-        raise ValueError('cannot handle combine="{}".format(combine)')
+        raise ValueError('cannot handle combine="{}"'.format(combine))
 
 
 class ComplExScorer(RelationalScorer):
@@ -169,6 +169,17 @@ class KgeModel(torch.nn.Module):
                                    self._relation_embedder.weight, s, p, o)
         se, pe, oe = self._entity_embedder.embed(s), self._relation_embedder.embed(p), self._entity_embedder.embed(o)
         return self._scorer.score_emb(se, pe, oe, combine="spo").view(-1)
+
+    def score_neg(self, s: Tensor, p: Tensor, o: Tensor, slot: int, neg: Tensor) -> Tensor:
+        """[n, K]: score of triple i with slot (0 = s, 2 = o) replaced by neg[i, k]; equals
+        BatchNegativeSample.score with implementation "triple" (kge/util/sampler.py:291-306)."""
+        if self._fused() and slot in (0, 2):
+            return _ScoreNeg.apply(self._scorer.name, self._scorer._norm, self._entity_embedder.weight,
+                                   self._relation_embedder.weight, s, p, o, int(slot), neg)
+        K = neg.shape[1]
+        tr = [x.reshape(-1).long().repeat_interleave(K) for x in (s, p, o)]
+        tr[slot] = neg.reshape(-1).long()
+        return self.score_spo(tr[0], tr[1], tr[2]).view(-1, K)
 
     def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
         if self._fused():
@@ -351,11 +362,43 @@ class _ScoreSPO(torch.autograd.Function):
         return None, None, ge, gr, None, None, None
 
 
+class _ScoreNeg(torch.autograd.Function):
+    """[n, K] scores of the positives with `slot` (0 = s, 2 = o) replaced by neg[i, k] -- what
+    BatchNegativeSample.score computes with implementation "triple" (sampler.py:291-306) -- from
+    kge_score_neg; backward = kge_score_neg_bwd_accum (complete table gradients, no [n*K, 3] index
+    tensor and no [n*K, d] gathered rows in either pass)."""
+
+    @staticmethod
+    def forward(ctx, name, l_norm, ent, rel, s, p, o, slot, neg):
+        t = engine.Tables(name, ent.detach(), rel.detach(), l_norm)
+        out = engine.score_neg(t, s, p, o, slot, neg)
+        ctx.t, ctx.idx, ctx.slot = t, (s, p, o, neg), slot
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        s, p, o, neg = ctx.idx
+        (scores,) = ctx.saved_tensors
+        ge, gr = torch.zeros_like(ctx.t.ent), torch.zeros_like(ctx.t.rel)
+        if not engine.score_neg_bwd_accum(ctx.t, s, p, o, ctx.slot, neg, gout, scores, ge, gr):
+            # shapes the accumulate kernel does not take (bf16 parameters, d > 1024): expanded triples
+            K = neg.shape[1]
+            tr = [x.reshape(-1).long().repeat_interleave(K) for x in (s, p, o)]
+            tr[ctx.slot] = neg.reshape(-1).long()
+            g_s, g_p, g_o = engine.score_spo_bwd(ctx.t, tr[0], tr[1], tr[2], gout.reshape(-1).contiguous(),
+                                                 scores.reshape(-1))
+            ge, gr = ge.float(), gr.float()
+            _scatter_rows(ge, tr[0], g_s)
+            _scatter_rows(ge, tr[2], g_o)
+            _scatter_rows(gr, tr[1], g_p)
+            ge, gr = ge.to(ctx.t.ent.dtype), gr.to(ctx.t.rel.dtype)
+        return None, None, ge, gr, None, None, None, None, None
+
+
 def _bf16_copy_of(param):
-    rec = getattr(param, "_kge_bf16_copy", None)  # kge_amd.optim.BF16_ATTR
-    if rec is None or rec[1] != param._version:
-        return None
-    return rec[0]
+    from .optim import bf16_copy_of  # (copy, version, data_ptr of the master) must all still match
+    return bf16_copy_of(param)
 
 
 class BF16Shadow:
@@ -374,7 +417,7 @@ class BF16Shadow:
         # bf16_copies=True) are fresh by construction: no cast at all
         e16, r16 = _bf16_copy_of(ent), _bf16_copy_of(rel)
         if e16 is not None and r16 is not None:
-            key = (e16.data_ptr(), ent._version, r16.data_ptr(), rel._version, "opt")
+            key = (e16.data_ptr(), ent._version, ent.data_ptr(), r16.data_ptr(), rel._version, rel.data_ptr(), "opt")
             if key != self._key:
                 self._tables, self._key = engine.Tables(name, e16, r16, l_norm), key
             return self._tables

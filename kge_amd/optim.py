@@ -16,13 +16,18 @@ from torch.optim.adagrad import adagrad as _functional_adagrad
 
 from . import _lib, engine
 
-BF16_ATTR = "_kge_bf16_copy"  # (tensor, version of the parameter it was made from), set on the parameter
+# (bf16 tensor, version of the parameter it was made from, data_ptr of the parameter's storage then),
+# set on the parameter
+BF16_ATTR = "_kge_bf16_copy"
 
 
 def bf16_copy_of(param: torch.Tensor):
-    """The optimizer-maintained bf16 copy of `param`, or None if there is none / it is stale."""
+    """The optimizer-maintained bf16 copy of `param`, or None if there is none / it is stale.
+    Stale = the version counter moved OR the storage was replaced: `weight.data = ...`
+    (LookupEmbedder._normalize_embeddings, lookup_embedder.py:64-69, run as a post-batch hook when
+    normalize.p > 0) swaps the storage without bumping the counter."""
     rec = getattr(param, BF16_ATTR, None)
-    if rec is None or rec[1] != param._version or rec[0].data_ptr() == 0:
+    if rec is None or rec[1] != param._version or rec[2] != param.data_ptr() or rec[0].data_ptr() == 0:
         return None
     return rec[0]
 
@@ -78,7 +83,7 @@ class Adagrad(_TorchAdagrad):
                         None if copy is None else copy.data_ptr(), engine._stream(p.device)), "kge_adagrad_step")
                 torch.autograd.graph.increment_version(p)  # the kernel wrote through the raw pointer
                 if copy is not None:
-                    setattr(p, BF16_ATTR, (copy, p._version))
+                    setattr(p, BF16_ATTR, (copy, p._version, p.data_ptr()))
             if rest:  # torch's own update for everything else
                 grads = [p.grad for p in rest]
                 sums = [self.state[p]["sum"] for p in rest]

@@ -157,6 +157,7 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type,
         assert type(job).__name__ == ("TrainingJob" if not train_type.startswith("hip_") else "HipTrainingJob") + ref_type
         m = job.model
         if train_type.startswith("hip_"):
+            m._ce_tables = lambda: object()  # "the fused loss applies", asked once per subbatch
             m.loss_sp = types.MethodType(
                 lambda self, s, p, o: F.cross_entropy(self.score_sp(s, p), o.long(), reduction="none"), m)
             m.loss_po = types.MethodType(
