@@ -142,7 +142,7 @@ class Tables:
     kge/model/embedder/lookup_embedder.py:44-46) as the kernels see them."""
 
     def __init__(self, scorer, ent: torch.Tensor, rel: torch.Tensor, l_norm: float = 1.0,
-                 flags: int = 0, use_workspace: bool = True):
+                 flags: int = 0, use_workspace: bool = True, pad_pitch: bool = False):
         self.scorer = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
         _require_gpu(ent, "entity table")
         _require_gpu(rel, "relation table")
@@ -156,6 +156,11 @@ class Tables:
         # buffer and builds the query vectors once, cooperatively, instead of once per
         # workgroup (same bits, one launch either way).  False: no scratch buffer.
         self.use_workspace = bool(use_workspace)
+        # True (opt-in): score_sp / score_po return a [:, :m] VIEW of a matrix whose row pitch is
+        # rounded up to 32 floats, so every row starts on a 128-byte line and the kernel's 16-byte
+        # stores never straddle a 32-byte sector (E = 14,541: rows of a contiguous matrix start at
+        # 4-byte granularity).  The reference returns a contiguous tensor, hence not the default.
+        self.pad_pitch = bool(pad_pitch)
         self.device = ent.device
         self._c_cache = {}
 
@@ -195,9 +200,15 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
     n = _same_len(keep[:2], "_pairs")
     ti = _index(targets, t.device, keep)
     m = t.num_ent if targets is None else keep[-1].numel()
+    ret = None
     if out is None:
-        out = _empty((n, m), t.device)
-        ldo = m
+        if t.pad_pitch and m % 32:
+            ldo = (m + 31) // 32 * 32
+            out = _empty((n, ldo), t.device)
+            ret = out[:, :m]
+        else:
+            out = _empty((n, m), t.device)
+            ldo = m
     with _on_device(t.device):
         tc = t.c(flags)
         fn = getattr(_lib.lib(), fn_name)
@@ -208,7 +219,7 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
         rc = fn(ctypes.byref(tc), first, second, n, ti, m, out.data_ptr(), ldo, ws, wsb, st)
         if rc:
             _lib.check(rc, fn_name)
-    return out
+    return out if ret is None else ret
 
 
 def score_sp(t: Tables, s, p, o=None, flags=None) -> torch.Tensor:

@@ -15,8 +15,23 @@ loader (kge/util/io.py:41).
 import os
 import sys
 
-REFERENCE_ROOT = os.environ.get("KGE_REFERENCE_ROOT", "/root/reference")
-_STUBS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_stubs")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_STUBS = os.path.join(_HERE, "ref_stubs")
+
+
+def _find_root():
+    """KGE_REFERENCE_ROOT, else /root/reference (build container), else oracle/_ref/libkge: an
+    UNTRACKED, git-ignored copy of the reference's `kge` package that tools/gpu_plugin.sh places
+    there for the duration of one gpurun call, so that tests/test_gpu_libkge_plugin.py can drive
+    the plugin through an unmodified LibKGE on the MI355X (reference sources are never committed)."""
+    cands = [os.environ.get("KGE_REFERENCE_ROOT"), "/root/reference", os.path.join(_HERE, "_ref", "libkge")]
+    for c in cands:
+        if c and os.path.isdir(os.path.join(c, "kge")):
+            return c
+    return "/root/reference"
+
+
+REFERENCE_ROOT = _find_root()
 
 
 def available() -> bool:

@@ -70,18 +70,43 @@ def test_state_dict_names_and_cpu_refusal():
         model.create("rotate", 10, 3, 15)
 
 
-def test_score_so_and_unknown_combine():
+@pytest.mark.parametrize("name", ["complex", "distmult", "transe", "rotate"])
+def test_score_so_against_the_oracle(name):
+    """KgeModel.score_so (kge_model.py:727-747 -> the generic s_o fallback :202-209): column j is
+    score_spo with relation j -- compared with the C oracle's score_spo bit for bit (the fallback
+    runs the spo kernel on repeated rows, the same chain) and with the reference's op sequence
+    (oracle/torch_port.py) at the reference's own tolerance."""
+    E, R, d, n = 23, 5, 16, 7
+    m = _model(name, E, R, d).eval()
+    ent = m.get_s_embedder().weight.detach().cpu()
+    rel = m.get_p_embedder().weight.detach().cpu()
+    g = torch.Generator().manual_seed(8)
+    s, o = torch.randint(E, (n,), generator=g), torch.randint(E, (n,), generator=g)
+    O = ko.Tables(name, ent.numpy(), rel.numpy(), 1.0)
+    with torch.no_grad():
+        so = m.score_so(s.to(DEV), o.to(DEV)).cpu()
+        some = m.score_so(s.to(DEV), o.to(DEV), torch.tensor([3, 1], device=DEV)).cpu()
+    assert so.shape == (n, R) and some.shape == (n, 2)
+    for j in range(R):
+        pj = np.full(n, j, dtype=np.int64)
+        want = ko.score_spo(O, s.numpy(), pj, o.numpy())
+        assert np.array_equal(so[:, j].numpy(), want), (name, j)
+        ref = tp.score_spo(name, ent, rel, s, torch.from_numpy(pj), o)
+        assert torch.allclose(so[:, j], ref, atol=1e-5, rtol=1e-4)
+    assert torch.equal(some[:, 0], so[:, 3]) and torch.equal(some[:, 1], so[:, 1])
+
+
+def test_unknown_combine_and_mismatched_index_lengths():
     m = _model("distmult", 12, 5, 16).eval()
     s, o = torch.tensor([1, 2], device=DEV), torch.tensor([3, 4], device=DEV)
     with torch.no_grad():
-        so = m.score_so(s, o)
-        assert so.shape == (2, 5)
-        for j in range(5):
-            pj = torch.full((2,), j, device=DEV)
-            assert torch.allclose(so[:, j], m.score_spo(s, pj, o), atol=1e-5, rtol=1e-4)
-        with pytest.raises(ValueError):
+        with pytest.raises(ValueError, match='cannot handle combine="xx"'):
             m.get_scorer().score_emb(m.get_s_embedder().embed(s), m.get_p_embedder().embed(s),
                                      m.get_o_embedder().embed(o), "xx")
+        with pytest.raises(ValueError, match="different lengths"):
+            m.score_spo(s, torch.tensor([0], device=DEV), o)
+        with pytest.raises(ValueError, match="different lengths"):
+            m.score_sp(s, torch.tensor([0, 1, 2], device=DEV))
 
 
 @pytest.mark.parametrize("name", ["complex", "distmult", "transe", "rotate"])
@@ -110,6 +135,43 @@ def test_entity_ranking_matches_reference_golden(name, tag, chunk):
 
 
 # ---- autograd --------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,l_norm", [("complex", 1.0), ("distmult", 1.0), ("transe", 1.0),
+                                         ("transe", 2.0), ("rotate", 1.0), ("rotate", 2.0)])
+@pytest.mark.parametrize("d", [40, 33])
+def test_score_neg_forward_and_backward(name, l_norm, d):
+    """KgeModel.score_neg = BatchNegativeSample.score, implementation "triple" (sampler.py:291-306):
+    forward bit-identical to the C oracle; gradients of a random linear functional w.r.t. both
+    tables (kge_score_neg_bwd_accum) against torch autograd through the reference's op sequence on
+    the expanded triples, for both corruptible slots, int32 and int64 samples, duplicates included."""
+    if name in ("complex", "rotate") and d % 2:
+        pytest.skip("even dimensionality only")
+    E, R, n, K = 60, 4, 19, 70  # K > 64: more than one chunk of negatives per positive
+    m = _model(name, E, R, d, l_norm=l_norm).train()
+    ent0 = m.get_s_embedder().weight.detach().cpu().clone()
+    rel0 = m.get_p_embedder().weight.detach().cpu().clone()
+    g = torch.Generator().manual_seed(4)
+    s, p, o = (torch.randint(hi, (n,), generator=g) for hi in (E, R, E))
+    O = ko.Tables(name, ent0.numpy(), rel0.numpy(), l_norm)
+    for slot, idt in ((0, torch.int64), (2, torch.int32)):
+        neg = torch.randint(E, (n, K), generator=g)
+        w = torch.randn(n, K, generator=g)
+        ent, rel = ent0.clone().requires_grad_(), rel0.clone().requires_grad_()
+        tr = [x.repeat_interleave(K) for x in (s, p, o)]
+        tr[slot] = neg.reshape(-1)
+        ref = tp.score_spo(name, ent, rel, tr[0], tr[1], tr[2], l_norm).view(n, K)
+        (ref * w).sum().backward()
+        m.zero_grad()
+        got = m.score_neg(s.to(DEV), p.to(DEV), o.to(DEV), slot, neg.to(DEV).to(idt))
+        assert np.array_equal(got.detach().cpu().numpy(),
+                              ko.score_neg(O, s.numpy(), p.numpy(), o.numpy(), slot, neg.numpy()))
+        (got * w.to(DEV)).sum().backward()
+        for gv, want, nm in ((m.get_s_embedder().weight.grad.cpu(), ent.grad, "entity"),
+                             (m.get_p_embedder().weight.grad.cpu(), rel.grad, "relation")):
+            scale = max(1.0, float(want.abs().max()))
+            err = float((gv - want).abs().max())
+            assert err <= 2e-4 * scale, (name, l_norm, slot, nm, err, scale)
+
+
 @pytest.mark.parametrize("name,l_norm", [("complex", 1.0), ("distmult", 1.0), ("transe", 1.0),
                                          ("transe", 2.0), ("rotate", 1.0), ("rotate", 2.0)])
 def test_backward_matches_torch_autograd(name, l_norm):

@@ -237,3 +237,50 @@ def test_full_plugin_configuration_runs_an_epoch_and_a_validation_on_cpu(tmp_pat
     metrics = job.valid_trace[0]
     for key in ("mean_reciprocal_rank", "mean_reciprocal_rank_filtered", "hits_at_1_filtered"):
         assert key in metrics and 0.0 <= metrics[key] <= 1.0
+
+
+@pytest.mark.parametrize("model", ["transe", "distmult"])
+def test_negative_sampling_job_follows_the_reference_job(tmp_path, model):
+    """Control flow of HipTrainingJobNegativeSampling on CPU: with a model whose `score_neg` is the
+    reference's own composition (expanded triples -> score_spo, sampler.py:291-306), one epoch must
+    give the reference job's avg_loss and parameters -- labels, slot loop, loss scaling, the
+    positives' column and the relation slot (which stays with the sampler) are then the same."""
+    import os
+    import shutil
+    import types
+    rh.import_reference()
+    from kge import Dataset
+    from kge.job import TrainingJob
+    data = os.path.join(str(tmp_path), "dataset_test")
+    shutil.copytree(os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test"), data)
+    calls = []
+
+    def score_neg(self, s, p, o, slot, neg):
+        calls.append(slot)
+        K = neg.shape[1]
+        tr = [x.reshape(-1).long().repeat_interleave(K) for x in (s, p, o)]
+        tr[slot] = neg.reshape(-1).long()
+        return self.score_spo(tr[0], tr[1], tr[2]).view(-1, K)
+
+    results = {}
+    for train_type in ("negative_sampling", "hip_negative_sampling"):
+        config = _job_config(str(tmp_path), model, train_type)
+        config.set("negative_sampling.num_samples.s", 4)
+        config.set("negative_sampling.num_samples.p", 2)
+        config.set("negative_sampling.num_samples.o", 3)
+        config.set("negative_sampling.implementation", "triple")
+        torch.manual_seed(11)
+        job = TrainingJob.create(config, Dataset.create(config, folder=data))
+        assert type(job).__name__ == ("TrainingJobNegativeSampling" if train_type == "negative_sampling"
+                                      else "HipTrainingJobNegativeSampling")
+        if train_type.startswith("hip_"):
+            job.model.score_neg = types.MethodType(score_neg, job.model)
+        torch.manual_seed(12)
+        job._prepare()
+        trace = job.run_epoch()
+        results[train_type] = (trace["avg_loss"], [x.detach().clone() for x in job.model.parameters()])
+    assert set(calls) == {0, 2}  # subject and object slots through score_neg, the relation slot not
+    (l_ref, p_ref), (l_hip, p_hip) = results["negative_sampling"], results["hip_negative_sampling"]
+    assert abs(l_ref - l_hip) <= 1e-6 * max(1.0, abs(l_ref)), (l_ref, l_hip)
+    for a, b in zip(p_ref, p_hip):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)

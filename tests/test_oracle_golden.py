@@ -126,3 +126,32 @@ def test_entity_ranking_matches_reference(model, tag, chunk):
         m = ko.compute_metrics(s_ranks, o_ranks, E)
         for name in ("mean_reciprocal_rank", "mean_rank", "hits_at_1", "hits_at_10"):
             assert abs(m[name] - metrics_ref[name + suffix[key]]) <= 1e-5 * max(1.0, abs(m[name]))
+
+
+@pytest.mark.parametrize("model", ["distmult", "complex"])
+def test_oracle_ranks_at_the_fb15k237_shape(model):
+    """The C oracle against the reference's EntityRankingJob at E=14,541, d=512 (fixture of
+    tests/golden/make_golden_bshape.py) on the first 32 validation triples: raw, filtered and
+    filtered-with-test ranks of both directions.  The oracle's summation order is not MKL's, so a
+    score a few ulp from the tie band's edge may land on the other side: at most one of the 192
+    ranks may differ, by one position."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import make_golden_bshape as gb
+    g = np.load(os.path.join(GOLDEN, f"bshape_{model}.npz"))
+    splits = gb.bshape_splits(g)
+    ent, rel = gb.bshape_tables(model)
+    t = ko.Tables(model, ent.numpy(), rel.numpy(), 1.0)
+    batch = splits["valid"][:32].astype(np.int64)
+    fs = [splits["train"], splits["valid"]]
+    idx_sp = [ko.build_index(x, (0, 1), 2) for x in fs]
+    idx_po = [ko.build_index(x, (1, 2), 0) for x in fs]
+    tsp, tpo = ko.build_index(splits["test"], (0, 1), 2), ko.build_index(splits["test"], (1, 2), 0)
+    bad = 0
+    for key, isp, ipo in (("", None, None), ("_filt", idx_sp, idx_po), ("_filt_test", idx_sp + [tsp], idx_po + [tpo])):
+        s_r, o_r = ko.evaluate_ranks(t, batch, isp, ipo)
+        for got, name in ((o_r, "o_rank"), (s_r, "s_rank")):
+            d = got - g[f"{name}{key}_f32"][:32]
+            assert np.abs(d).max() <= 1, (model, name, key, d)
+            bad += int((d != 0).sum())
+    assert bad <= 1, bad
