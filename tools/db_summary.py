@@ -29,6 +29,6 @@ for db in sorted(glob.glob(f"{root}/**/*_results.db", recursive=True)):
     try:
         for r in c.execute("select * from top_kernels"):
             if r[4] >= 1.0:
-                print(f"{rel}: {r[0][:80]} calls={r[1]} avg_us={r[3] / 1e3 if r[3] > 1e4 else r[3]:.2f} pct={r[4]:.1f}")
+                print(f"{rel}: {r[0][:80]} calls={r[1]} avg_us={r[3]:.2f} pct={r[4]:.1f}")
     except sqlite3.Error as e:
         print(rel, "no top_kernels:", e)
