@@ -170,7 +170,11 @@ def test_b_negative_sampling_jobs(data, model):
          loss_hip=l_hip, loss_fused=l_fus, rel=_rel(l_hip, l_ref), rel_fused=_rel(l_fus, l_ref),
          param_rel_diff=d1, param_rel_diff_fused=d2)
     assert _rel(l_hip, l_ref) <= 1e-4 and _rel(l_fus, l_ref) <= 1e-4
-    assert d1 <= 1e-3 and d2 <= 1e-3
+    # TransE's default L1 norm has a sign() gradient and Adagrad's first step is +-lr whatever the
+    # gradient's size: a coordinate whose |s + p - o| is within rounding of 0 steps the other way --
+    # the parameter bound for it is wider than for the smooth models, the loss bound is not
+    bound = 5e-3 if model == "transe" else 1e-3
+    assert d1 <= bound and d2 <= bound
 
 
 def _eval(root, folder, tag, model, eval_type, state, chunk=-1, dim=512, opts=None):
