@@ -129,8 +129,11 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       // the whole-L2 write-back of a release fence.  A 128-byte line (8 rows x 16 B) is
       // written by one workgroup only.
       u32x4* dst = qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (c8 >> 1) * 64), "v"(q0) : "memory");
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + (NKH + (c8 >> 1)) * 64), "v"(q1)
+      // s_nop 1: the two wait states a >64-bit VMEM store needs before its data registers may be
+      // overwritten -- the hazard recogniser cannot see into inline asm (found the hard way: an
+      // unrolled variant of this loop reused q0's registers for the next address and stored garbage)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (c8 >> 1) * 64), "v"(q0) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (NKH + (c8 >> 1)) * 64), "v"(q1)
                    : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread: its stores are acknowledged ...

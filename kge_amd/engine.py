@@ -93,7 +93,12 @@ def _workspace(tc, n, device, enable=True, stream=None):
     key = (device.index, _stream_handle(device) if stream is None else stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < need:
-        buf = _empty((max(need, 1 << 20),), device, torch.uint8)
+        # zero-initialised once: the builders' flag lines of the cooperative query build live in it
+        # (a tag that happens to equal a launch's epoch in fresh memory is 2^-64 unlikely, not impossible)
+        try:
+            buf = torch.zeros((max(need, 1 << 20),), device=device, dtype=torch.uint8)
+        except torch.OutOfMemoryError as e:  # pragma: no cover
+            raise RuntimeError("CUDA out of memory (kge_amd: " + str(e) + ")") from e
         _WORKSPACES[key] = buf
     return buf.data_ptr(), buf.numel()
 

@@ -33,9 +33,9 @@ def run(n, E=14541, R=237, d=512, reps=5, mode=0, use_ws=False, flags=0):
     si, pi = engine._index(s, dev, keep), engine._index(p, dev, keep)
     nwg = 4096
     stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
-    wsb = 2 * ((n + 127) // 128) * 128 * d * 2 + 512 * 8 * 8
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     tc = T.c()
+    wsb = max(int(L.kge_score_workspace_bytes(ctypes.byref(tc), n)), 1 << 20)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=dev)
     for _ in range(reps):
         stamps.zero_()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
