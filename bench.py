@@ -16,10 +16,15 @@ roofline.one_sided_launch).  Inputs (tables, index vectors) are resident in HBM 
 timed region.  Data is synthetic (no datasets/network here): N(0, 0.1)
 tables (examples/toy-complex-train.yaml:18-22), uniform random queries.
 
-N > 1 (weak scaling): the entity table is row-sharded, every rank owns an FB15k-237-sized
-shard (global E = N * 14,541) and scores the same n queries against its shard; the query
-rows live on their owner shards and are exchanged with ONE all-gather per step (RCCL), then
-scored by the same two-sided launch on the gathered dense rows (kge_score_emb_sp_po).
+N > 1: the entity table is row-sharded over the ranks (kge_amd/sharded.py, the class the gloo
+tests cover): every rank sees the same batch, gathers the query rows it owns, ONE all-gather over
+RCCL brings every rank the s and o rows of the batch, and each rank scores the batch against its own
+shard with the same two-sided launch (kge_score_emb_sp_po) -- no collective on the score data.
+Default shape for N > 1 (--shape wikidata5m) = BASELINE configs[4], the one north_star names for
+scaling: E = 4,594,485 entities split over the N ranks (574,311 rows per rank at N = 8), R = 822,
+d = 256, bf16, n = 512: STRONG scaling (total work fixed).  The FB15k-237-shape weak-scaling step of
+earlier rounds (every rank an E = 14,541, d = 512 shard) is measured in the same run and reported
+beside it (`fb15k_weak`).
 """
 import argparse
 import json
@@ -33,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 E_FB, R_FB, DIM, BATCH = 14541, 237, 512, 512
+E_WD, R_WD, DIM_WD = 4594485, 822, 256  # Wikidata5M shape (K5)
+F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 
 
@@ -47,6 +54,10 @@ def parse():
                     help="skip the reference region of one-sided launches (profiling runs: the kernel "
                          "trace then holds two-sided launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region of K steps is run this many times; the median region is reported")
+    ap.add_argument("--shape", choices=["wikidata5m", "fb15k"], default="wikidata5m",
+                    help="N > 1 only: which sharded workload is the headline value (the other is reported beside it)")
     return ap.parse_args()
 
 
@@ -84,9 +95,17 @@ def algorithmic_bytes(n, m, d, elt=2, sides=1):
 
 def cpu_baseline(n, seconds):
     """Reference CPU path restated op-for-op in torch (oracle/torch_port.py, bit-identical to
-    the live reference in the build container), fp32, all host cores, on a bounded sample."""
+    the live reference in the build container), fp32, torch.no_grad, on a bounded sample: for 8,
+    32 and all physical cores (an oversubscribed MKL makes the reference look worse
+    than it is) one warm-up step, then best of 5 steps (score_sp + score_po); the best thread
+    count is the reported baseline, the others are listed."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch_port as tp
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        phys = os.cpu_count()
 
     g = torch.Generator().manual_seed(0)
     ent = torch.empty(E_FB, DIM).normal_(0, 0.1, generator=g)
@@ -94,22 +113,161 @@ def cpu_baseline(n, seconds):
     s = torch.randint(E_FB, (n,), generator=g)
     p = torch.randint(R_FB, (n,), generator=g)
     o = torch.randint(E_FB, (n,), generator=g)
-    cores = torch.get_num_threads()
+    before = torch.get_num_threads()
+    runs, t_all = {}, time.perf_counter()
     with torch.no_grad():
-        tp.score_sp("complex", ent, rel, s, p)  # warm-up
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
+        for threads in sorted({min(8, phys), min(32, phys), phys}):
+            torch.set_num_threads(threads)
             tp.score_sp("complex", ent, rel, s, p)
             tp.score_po("complex", ent, rel, p, o)
-            reps += 1
-            el = time.perf_counter() - t0
-            if el > seconds or reps >= 200:
-                break
-    return {"value": 2.0 * n * E_FB * reps / el, "unit": "scored triples/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{reps} 1vsAll steps (score_sp+score_po, n={n}, E={E_FB}, d={DIM}, fp32) "
-                      f"of oracle/torch_port.py (reference torch op sequence) in {el:.1f}s"}
+            best = float("inf")
+            for _ in range(5):
+                t0 = time.perf_counter()
+                tp.score_sp("complex", ent, rel, s, p)
+                tp.score_po("complex", ent, rel, p, o)
+                best = min(best, time.perf_counter() - t0)
+                if time.perf_counter() - t_all > seconds:
+                    break
+            runs[threads] = 2.0 * n * E_FB / best
+    torch.set_num_threads(before)
+    cores = max(runs, key=runs.get)
+    return {"value": runs[cores], "unit": "scored triples/s", "cores": cores, "kind": "port",
+            "by_threads": {str(k): v for k, v in runs.items()},
+            "sample": f"best of 5 1vsAll steps (score_sp + score_po, n={n}, E={E_FB}, d={DIM}, fp32, no_grad) "
+                      f"of oracle/torch_port.py (the reference's torch op sequence) per thread count "
+                      f"{sorted(runs)} ({phys} physical cores), {time.perf_counter() - t_all:.1f}s in all"}
+
+
+def timed_regions(run_steps, sync, steps, repeats, reduce_max=None):
+    """`repeats` timed regions of exactly `steps` steps, each bracketed by barrier + synchronize on
+    both sides (max over ranks); returns (median seconds, all seconds, host-issue seconds of the
+    median region)."""
+    regions = []
+    for _ in range(max(1, repeats)):
+        sync()
+        t0 = time.perf_counter()
+        run_steps(steps)
+        host = time.perf_counter() - t0
+        sync()
+        el = time.perf_counter() - t0
+        if reduce_max is not None:
+            el = reduce_max(el)
+        regions.append((el, host))
+    order = sorted(regions)
+    med = order[len(order) // 2]
+    return med[0], [r[0] for r in regions], med[1]
+
+
+def event_avg_ms(fn, steps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+
+def sharded_workload(shape, world, rank, device, n, engine):
+    """The rank's shard of the named shape + the replicated batch: (ShardedEntityTable, s, p, o, E, d)."""
+    from kge_amd.sharded import ShardedEntityTable
+    if shape == "wikidata5m":
+        E, R, d = E_WD, R_WD, DIM_WD
+    else:  # every rank an FB15k-237-sized shard: weak scaling
+        E, R, d = E_FB * world, R_FB, DIM
+    lo, hi = ShardedEntityTable.partition(E, world, rank)
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    ent = torch.empty(hi - lo, d, device=device, dtype=torch.bfloat16).normal_(0, 0.1, generator=g)
+    rel = torch.empty(R, d, dtype=torch.float32).normal_(0, 0.1, generator=torch.Generator().manual_seed(1234))
+    q = torch.Generator().manual_seed(1)  # the same batch on every rank
+    s = torch.randint(E, (n,), generator=q).to(device)
+    p = torch.randint(R, (n,), generator=q).to(device)
+    o = torch.randint(E, (n,), generator=q).to(device)
+    sh = ShardedEntityTable("complex", ent, rel.to(torch.bfloat16).to(device), E, backend=engine)
+    return sh, s, p, o, E, d
+
+
+def main_sharded(a, world, rank, device):
+    import torch.distributed as td
+    from kge_amd import engine
+    td.init_process_group("nccl", device_id=device)
+    n = a.batch
+
+    def sync():
+        td.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(x):
+        t = torch.tensor([x], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        return float(t.item())
+
+    results = {}
+    for shape in ("wikidata5m", "fb15k"):
+        sh, s, p, o, E, d = sharded_workload(shape, world, rank, device, n, engine)
+
+        def run_steps(k, sh=sh, s=s, p=p, o=o):
+            for _ in range(k):
+                sh.score_sp_po_blocks(s, p, o)  # exchange (gather, all-gather, gather) + the scoring launch(es)
+
+        run_steps(a.warmup)
+        el, regions, host = timed_regions(run_steps, sync, a.steps, a.repeats, reduce_max)
+        # the scoring launch alone, on rows already exchanged (HIP events on the launch stream)
+        rows, rel_rows = sh.exchange_rows([s, o], p)
+        s_rows, o_rows = rows[:n].clone(), rows[n:].clone()
+        rel_rows = rel_rows.clone()
+        big = n * (sh.hi - sh.lo) * 4 > sh.BIG_SLAB_BYTES
+
+        def score_only():  # what ShardedEntityTable.score_sp_po_blocks launches after the exchange
+            if big:
+                engine.score_emb("complex", s_rows, rel_rows, sh.ent_local, "sp_", pad_pitch=True)
+                engine.score_emb("complex", sh.ent_local, rel_rows, o_rows, "_po", pad_pitch=True)
+            else:
+                engine.score_emb_sp_po("complex", s_rows, rel_rows, o_rows, sh.ent_local)
+        k_ms = event_avg_ms(score_only, max(5, a.steps // 4))
+        x_ms = event_avg_ms(lambda: sh.exchange_rows([s, o], p), max(5, a.steps // 4))
+        m = sh.hi - sh.lo
+        results[shape] = {
+            "value": 2.0 * n * E * a.steps / el, "ms_per_step": el / a.steps * 1e3,
+            "host_issue_ms_per_step": host / a.steps * 1e3, "regions_ms_per_step": [r / a.steps * 1e3 for r in regions],
+            "num_entities": E, "rows_per_rank": m, "dim": d, "batch": n,
+            "scaling": "strong" if shape == "wikidata5m" else "weak",
+            "scoring_launch_ms": k_ms, "exchange_ms": x_ms, "launches_per_step": 2 if big else 1,
+            "algorithmic_bytes_per_launch": algorithmic_bytes(n, m, d, sides=2) if not big else
+            2 * algorithmic_bytes(n, m, d, sides=1),
+        }
+        del sh, s_rows, o_rows, rows
+        torch.cuda.empty_cache()
+    if rank == 0:
+        main_shape = a.shape
+        r = results[main_shape]
+        ach = r["algorithmic_bytes_per_launch"] / (r["scoring_launch_ms"] * 1e-3) / 1e9
+        out = {
+            "metric": "scored triples/sec (1vsAll, ComplEx d=512)",
+            "value": r["value"], "unit": "scored triples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "repeats": a.repeats, "ms_per_step": r["ms_per_step"], "host_issue_ms_per_step": r["host_issue_ms_per_step"],
+            "higher_is_better": True, "scaling": r["scaling"], "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": ("Wikidata5M shape (E=4,594,485, R=822) ComplEx d=256 1vsAll scoring, entity table "
+                             "row-sharded over the ranks, bf16 tables, f32 scores: score_sp and score_po blocks of "
+                             "the batch against every shard per step" if main_shape == "wikidata5m" else
+                             "FB15k-237 shape ComplEx d=512 1vsAll scoring, one E=14,541 shard per rank"),
+                "num_entities": r["num_entities"], "rows_per_rank": r["rows_per_rank"], "dim": r["dim"], "batch": n,
+                "parallelism": f"entity-shard x{world} (kge_amd.sharded.ShardedEntityTable)",
+                "exchange": "kge_embed gather -> ONE all_gather_into_tensor (RCCL) -> kge_embed pick, per step",
+            },
+            "roofline": {"bound": "hbm", "kernel": "pairs_bf16_v4_kernel on this rank's shard (score_sp + score_po "
+                                                   "launches of one step together)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
+                         "avg_launch_us": r["scoring_launch_ms"] * 1e3, "traffic": None},
+            "exchange_ms": r["exchange_ms"],
+            ("fb15k_weak" if main_shape == "wikidata5m" else "wikidata5m_strong"):
+                results["fb15k" if main_shape == "wikidata5m" else "wikidata5m"],
+        }
+        print(json.dumps(out))
+    td.destroy_process_group()
 
 
 def main():
@@ -117,13 +275,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # KGE_BENCH_FORCE_DIST=1: exercise the sharded step (RCCL init + all-gather) with one rank
-    dist = world > 1 or os.environ.get("KGE_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if dist:
-        import torch.distributed as td
-        td.init_process_group("nccl", device_id=device)
+    # KGE_BENCH_FORCE_DIST=1: exercise the sharded step (RCCL init + all-gather) with one rank
+    if world > 1 or os.environ.get("KGE_BENCH_FORCE_DIST") == "1":
+        return main_sharded(a, world, rank, device)
 
     from kge_amd import engine
 
@@ -131,106 +287,17 @@ def main():
     ent, rel, s, p, o = make_inputs(rank, device, n)
     T = engine.Tables("complex", ent, rel)
 
-    if dist:
-        import torch.distributed as td
-        # Query rows live on their owner shard: rank r owns rows [r*n/world, (r+1)*n/world).
-        # Exchange of a step: one gather kernel for the s/o rows this rank owns, ONE all-gather
-        # over RCCL, one gather of the relation rows; then the two scoring calls.
-        per = (n + world - 1) // world
-        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
-        own = torch.zeros(per, dtype=torch.int64, device=device)
-        own_o = torch.zeros(per, dtype=torch.int64, device=device)
-        own[: hi - lo], own_o[: hi - lo] = s[lo:hi], o[lo:hi]
-        so_idx = torch.stack([own, own_o], 1).reshape(-1)  # rows interleaved: s_0, o_0, s_1, o_1, ...
-        buf = {
-            "loc": torch.empty(per * 2, DIM, dtype=torch.bfloat16, device=device),
-            "gath": torch.empty(world * per, 2 * DIM, dtype=torch.bfloat16, device=device),
-            "pe": torch.empty(n, DIM, dtype=torch.bfloat16, device=device),
-        }
-        s_rows, o_rows = buf["gath"][:n, :DIM], buf["gath"][:n, DIM:]  # row i = [s row | o row] of query i
-
-        def exchange():
-            # the query rows this rank owns (s and o interleaved) and the relation rows: ONE
-            # gather launch (kge_embed), then ONE all-gather
-            engine.embed(T, so_idx, p, buf["loc"], buf["pe"])
-            td.all_gather_into_tensor(buf["gath"].view(-1), buf["loc"].view(-1))
-
-        def score():  # both score blocks from one two-sided launch on the gathered dense rows
-            engine.score_emb_sp_po("complex", s_rows, buf["pe"], o_rows, ent)
-
-        # The exchange (a gather kernel and the RCCL all-gather) can be captured once in a hipGraph.  Measured
-        # alternatives on one rank (tools/dist_probe.py, profiles/): replaying it on a side stream
-        # one step ahead of the scoring is SLOWER (53 vs 47 us per step): the persistent scoring
-        # kernel needs whole CUs (160 KB LDS, all VGPRs), so the side stream's kernels and its
-        # workgroups only take turns, and the event traffic adds host work.
-        # Off by default: measured on one rank the graph saves 5 % (46.0 vs 48.5 us per step) and
-        # capturing RCCL collectives is the one thing here that cannot be tried on more than one
-        # rank in the build environment.  KGE_BENCH_EXCHANGE_GRAPH=1 turns it on.
-        xg = None
-        if os.environ.get("KGE_BENCH_EXCHANGE_GRAPH") == "1":
-            try:
-                exchange()  # warm up the kernels / the RCCL channel outside the capture
-                torch.cuda.synchronize()
-                td.barrier()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    exchange()
-                g.replay()
-                torch.cuda.synchronize()
-                xg = g
-            except Exception as e:  # RCCL / torch without capture support
-                print(f"[bench] graph capture of the exchange unavailable ({type(e).__name__}: {e}); "
-                      "eager exchange", file=sys.stderr)
-                xg = None
-                torch.cuda.synchronize()
-        exchange_mode = "one all-gather per step, exchange replayed as a hipGraph" if xg else \
-            "one all-gather per step, eager"
-
-        def run_steps(k_steps):
-            for _ in range(k_steps):
-                if xg is not None:
-                    xg.replay()
-                else:
-                    exchange()
-                score()
-    else:
-        exchange_mode = None
-
-        def run_steps(k):  # KgeModel.score_sp_po: the score_sp and score_po blocks of the batch, one launch
-            for _ in range(k):
-                engine.score_sp_po(T, s, p, o)
-
-    def sync():
-        if dist:
-            import torch.distributed as td
-            td.barrier()
-        torch.cuda.synchronize()
+    def run_steps(k):  # KgeModel.score_sp_po: the score_sp and score_po blocks of the batch, one launch
+        for _ in range(k):
+            engine.score_sp_po(T, s, p, o)
 
     run_steps(a.warmup)
-    sync()
-    t0 = time.perf_counter()
-    run_steps(a.steps)
-    host_el = time.perf_counter() - t0  # host time to ISSUE the steps (no device wait)
-    sync()
-    el = time.perf_counter() - t0
-    if dist:
-        import torch.distributed as td
-        tt = torch.tensor([el], device=device, dtype=torch.float64)
-        td.all_reduce(tt, op=td.ReduceOp.MAX)
-        el = float(tt.item())
+    el, regions, host_el = timed_regions(run_steps, torch.cuda.synchronize, a.steps, a.repeats)
 
-    # Duration of one scoring call (= one launch of the dominant kernel pairs_bf16_v4_kernel):
-    # HIP events on the launch stream bracketing a
-    # second timed region of the same K steps, divided by the 2K calls.  Back-to-back calls
+    # Duration of one scoring call (= one launch of the dominant kernel pairs_bf16_v4_kernel): HIP
+    # events on the launch stream bracketing a region of the same K steps.  Back-to-back calls
     # pipeline their launch overhead exactly as in the timed region above.
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(a.steps):
-        engine.score_sp_po(T, s, p, o)
-    e1.record()
-    torch.cuda.synchronize()
-    avg_ms = e0.elapsed_time(e1) / a.steps
+    avg_ms = event_avg_ms(lambda: engine.score_sp_po(T, s, p, o), a.steps)
     # isolated calls (event pair around every call; includes un-hidden launch latency)
     ev = []
     for k in range(min(a.steps, 50)):
@@ -241,70 +308,97 @@ def main():
         ev.append((x0, x1))
     torch.cuda.synchronize()
     iso = sorted(x0.elapsed_time(x1) for x0, x1 in ev)
-    # for reference: the same step as two one-sided launches (score_sp, then score_po), as
-    # TrainingJob1vsAll issues them (north_star quotes its roofline target on score_sp)
-    one_ms = None
+
+    extra = {}
     if not a.no_one_sided:
-        e0.record()
-        for _ in range(a.steps):
+        # the same step as two one-sided launches (score_sp, then score_po), as TrainingJob1vsAll issues
+        # them (north_star quotes its roofline target on score_sp) ...
+        def one():
             engine.score_sp(T, s, p)
             engine.score_po(T, p, o)
-        e1.record()
-        torch.cuda.synchronize()
-        one_ms = e0.elapsed_time(e1) / (2 * a.steps)
-
-    if rank == 0:
-        total = 2.0 * n * E_FB * world * a.steps
-        ab = algorithmic_bytes(n, E_FB, DIM, sides=2)
+        one_ms = event_avg_ms(one, a.steps) / 2
         ab1 = algorithmic_bytes(n, E_FB, DIM)
-        achieved = ab / (avg_ms * 1e-3) / 1e9
-        out = {
-            "metric": "scored triples/sec (1vsAll, ComplEx d=512)",
-            "value": total / el,
-            "unit": "scored triples/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3,
-            "host_issue_ms_per_step": host_el / a.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic",
-            "config": {
-                "workload": "FB15k-237 shape ComplEx d=512 1vsAll scoring, bf16 tables, f32 scores: the "
-                            "score_sp and score_po blocks of the batch per step (KgeModel.score_sp_po, one "
-                            "two-sided launch)",
-                "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n,
-                "parallelism": f"entity-shard x{world}" if world > 1 else "single GPU",
-                **({"exchange": exchange_mode} if exchange_mode else {}),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "pairs_bf16_v4_kernel<ComplEx,d=512>, two-sided (one score_sp_po call = one launch: "
-                          "gather + cooperative query build + MFMA contraction + store of both score blocks)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": ab,
-                "avg_launch_us": avg_ms * 1e3,
-                "isolated_call_median_us": iso[len(iso) // 2] * 1e3,
-                "traffic": pmc_traffic(),
-                # the same kernel launched once per direction (score_sp, score_po), same run
-                **({"one_sided_launch": {"avg_launch_us": one_ms * 1e3, "algorithmic_bytes_per_launch": ab1,
-                                         "achieved": ab1 / (one_ms * 1e-3) / 1e9,
-                                         "frac": ab1 / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
-                   if one_ms is not None else {}),
-            },
-        }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
-        print(json.dumps(out))
-    if dist:
-        import torch.distributed as td
-        td.destroy_process_group()
+        extra["one_sided_launch"] = {"avg_launch_us": one_ms * 1e3, "algorithmic_bytes_per_launch": ab1,
+                                     "achieved": ab1 / (one_ms * 1e-3) / 1e9,
+                                     "frac": ab1 / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # ... and at the other batch sizes SURVEY.md 8(d) lists (and beyond): the start-up of a launch
+        # (index load -> row gather -> query build -> hand-off, ~8 us) is paid once per call, so the
+        # per-launch fraction of the roofline grows with n
+        by_n = {}
+        for nn in (128, 1024, 2048, 4096):
+            q = torch.Generator().manual_seed(nn)
+            s2 = torch.randint(E_FB, (nn,), generator=q).to(device)
+            p2 = torch.randint(R_FB, (nn,), generator=q).to(device)
+            for _ in range(3):
+                engine.score_sp(T, s2, p2)
+            ms = event_avg_ms(lambda: engine.score_sp(T, s2, p2), max(10, a.steps // 4))
+            abn = algorithmic_bytes(nn, E_FB, DIM)
+            by_n[str(nn)] = {"avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": abn,
+                             "frac": abn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "scored_triples_per_s": nn * E_FB / (ms * 1e-3)}
+            del s2, p2
+        extra["one_sided_by_batch"] = by_n
+        # float32 tables (the dtype of an unmodified LibKGE config; the reference's own precision):
+        # the exact f32 chain on v_mfma_f32_32x32x2_f32 -- MFMA-bound, flops = 2 n d m
+        T32 = engine.Tables("complex", ent.float(), rel.float())
+        for _ in range(3):
+            engine.score_sp(T32, s, p)
+        f_ms = event_avg_ms(lambda: engine.score_sp(T32, s, p), max(10, a.steps // 4))
+        tf = 2.0 * n * DIM * E_FB / (f_ms * 1e-3) / 1e12
+        extra_f32 = {"bound": "mfma", "kernel": "pairs_f32_kernel<ComplEx> (score_sp, float32 tables, exact f32 chain)",
+                     "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
+                     "avg_launch_us": f_ms * 1e3, "flops_per_launch": 2.0 * n * DIM * E_FB,
+                     "scored_triples_per_s": n * E_FB / (f_ms * 1e-3)}
+        del T32
+    else:
+        extra_f32 = None
+
+    total = 2.0 * n * E_FB * a.steps
+    ab = algorithmic_bytes(n, E_FB, DIM, sides=2)
+    achieved = ab / (avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "scored triples/sec (1vsAll, ComplEx d=512)",
+        "value": total / el,
+        "unit": "scored triples/s",
+        "n_gpus": 1,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "repeats": a.repeats,
+        "ms_per_step": el / a.steps * 1e3,
+        "regions_ms_per_step": [r / a.steps * 1e3 for r in regions],
+        "host_issue_ms_per_step": host_el / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": "FB15k-237 shape ComplEx d=512 1vsAll scoring, bf16 tables, f32 scores: the "
+                        "score_sp and score_po blocks of the batch per step (KgeModel.score_sp_po, one "
+                        "two-sided launch)",
+            "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n,
+            "parallelism": "single GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "pairs_bf16_v4_kernel<ComplEx,d=512>, two-sided (one score_sp_po call = one launch: "
+                      "gather + cooperative query build + MFMA contraction + store of both score blocks)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": ab,
+            "avg_launch_us": avg_ms * 1e3,
+            "isolated_call_median_us": iso[len(iso) // 2] * 1e3,
+            "traffic": pmc_traffic(),
+            **extra,
+        },
+    }
+    if extra_f32 is not None:
+        out["roofline_f32"] = extra_f32
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

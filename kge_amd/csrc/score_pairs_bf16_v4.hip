@@ -35,6 +35,7 @@
 #include "common.hpp"
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <type_traits>
 
 namespace kge {
@@ -77,9 +78,15 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   const int rg = q8 % rgn;
   const int cg = (q8 / rgn) * 8 + (b & 7);
   if (cg >= ncg) return;
-  const int tile_lo = cg * tiles_per_cg;
-  int ntl = ntiles - tile_lo;
-  if (ntl > tiles_per_cg) ntl = tiles_per_cg;
+  // Which 64-target tiles: tiles_per_cg > 0: the contiguous range [cg * tiles_per_cg, ...);
+  // tiles_per_cg == 0: every ncg-th tile (cg, cg + ncg, ...) -- the workgroups then write
+  // NEIGHBOURING 256-byte segments of the same score rows at about the same time, which is what the
+  // memory controllers need once the score matrix no longer fits the Infinity Cache (a 574,311-column
+  // shard: 2.35 GB per call; with contiguous ranges 32 k write streams 0.5 MB apart thrash the DRAM pages)
+  const int tile_lo = tiles_per_cg > 0 ? cg * tiles_per_cg : cg;
+  const int tile_st = tiles_per_cg > 0 ? 1 : ncg;
+  int ntl = tiles_per_cg > 0 ? ntiles - tile_lo : (ntiles - cg + ncg - 1) / ncg;
+  if (tiles_per_cg > 0 && ntl > tiles_per_cg) ntl = tiles_per_cg;
   if (ntl <= 0) return;
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       }
       auto load_rows = [&](int tt, int w) -> long long {
         const int tc = tt < ntl ? tt : ntl - 1;
-        long long tr = (long long)(tile_lo + tc) * V4_TN + w * 16 + (lane & 15);
+        long long tr = (long long)(tile_lo + tc * tile_st) * V4_TN + w * 16 + (lane & 15);
         if (tr >= m) tr = m - 1;
         return index_mode<TGMODE>(TG.idx, tr);
       };
@@ -179,9 +186,9 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       };
       auto tile_dma = [&](int tt, long long rows, int w) {
         const int tc = tt < ntl ? tt : ntl - 1;
-        const long long trow0 = (long long)(tile_lo + tc) * V4_TN;
+        const long long trow0 = (long long)(tile_lo + tc * tile_st) * V4_TN;
         unsigned int d = (unsigned int)((tt & 1) * TILEB + w * NL * 1024);
-        if (TGMODE == 0 && tile_lo + tc < nfull && tld2 < (1LL << 28)) {
+        if (TGMODE == 0 && tile_lo + tc * tile_st < nfull && tld2 < (1LL << 28)) {
           const unsigned char* p = (const unsigned char*)tgb + (trow0 + w * 16) * tld2;
           v4_static_for<0, NL>([&](auto kc) __attribute__((always_inline)) {
             const unsigned int vo = dvoff[decltype(kc)::value];
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
           cv[u][i] = *reinterpret_cast<const f32x4*>(smem + crd[u] + i * 1024 + ((z ^ ((4 * i) & 15)) << 4));
     };
     auto store_tile = [&](int tt) {
-      const long long col0 = (long long)(tile_lo + tt) * V4_TN;
+      const long long col0 = (long long)(tile_lo + tt * tile_st) * V4_TN;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (col0 + V4_TN <= m) {
@@ -472,9 +479,13 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   const int items = V4_ROWS * (HH / 8);  // at least one item per builder thread
   while (nbuild > 1 && nbuild * 512 > items) --nbuild;
   const Operand& AA2 = A2 ? *A2 : A;
+  // interleaved tiles (tiles_per_cg = 0) once a launch's score block outgrows the Infinity Cache
+  const char* il = getenv("KGE_V4_INTERLEAVE");
+  const bool interleave = il ? il[0] == '1' : (double)n * (double)m * 4.0 * (A2 ? 2 : 1) > 192e6;
+  const int tpc_arg = interleave ? 0 : tpc;
 #define KGE_V4L(MODE)                                                                          \
   hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE>), dim3(grid), dim3(512), 0, st, A, \
-                     AA2, R, TG, dir, n, m, rgn, rgn1, out2_off, ncg, tpc, ntiles, out, ldo,    \
+                     AA2, R, TG, dir, n, m, rgn, rgn1, out2_off, ncg, tpc_arg, ntiles, out, ldo, \
                      dbg, qf, flags, epoch, nbuild)
   if (tgmode == 0) KGE_V4L(0);
   else if (tgmode == 1) KGE_V4L(1);

@@ -8,11 +8,17 @@ the reference itself: score columns are independent and EntityRankingJob sums pe
 unsharded ranks exactly.
 
 Layout: rank g owns entity rows [g*S, min((g+1)*S, E)), S = ceil(E / G); the relation table
-(<= ~1 MB) is replicated.  Exchange steps, all small (latency-bound, <= ~1 MB):
-  1. query rows: every rank fills the rows it owns, zeros elsewhere, ONE all-reduce(sum)
-     (x + 0 is exact, so the gathered rows are bit-identical to the owner's);
-  2. true scores: computed by the owner of the true entity, zeros elsewhere, all-reduce(sum);
-  3. rank/tie counters: int64 all-reduce(sum).
+(<= ~1 MB) is replicated; every rank sees the same batch of queries.  Exchange steps, all small
+(latency-bound, <= ~2 MB) and all free of host synchronisation (no boolean-mask indexing, no
+nonzero: every shape is fixed by n, so a step can be captured in a hipGraph):
+  1. query rows: ONE gather launch (kge_embed) fills a fixed [k*n, d] send block
+     -- row i from this shard if it owns id i, any local row otherwise -- ONE
+     all_gather_into_tensor, and one more gather launch picks row i out of its owner's block
+     (index owner(i)*k*n + i, computed on the device).  The s and the o rows of a batch travel in
+     the same collective; the relation rows come from the replicated table in the first launch;
+  2. true scores: taken from the owner's slab (torch.where on the ownership mask), zeros
+     elsewhere, all-reduce(sum) of n floats (x + 0 is exact);
+  3. rank/tie counters: one int64 all-reduce(sum) for all rankings of both directions.
 Scoring itself needs no collective: each rank writes its own [n, E_g] slab.
 """
 from typing import Optional
@@ -38,6 +44,7 @@ class ShardedEntityTable:
         if backend is None:
             from . import engine as backend  # the HIP kernels; no CPU fallback
         self.backend = backend
+        self._bufs, self._tcache = {}, {}
 
     @staticmethod
     def partition(num_entities: int, world: int, rank: int):
@@ -51,44 +58,91 @@ class ShardedEntityTable:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def _tables(self, ent, key):
+        """backend.Tables over `ent` + the replicated relation table, cached per buffer."""
+        hit = self._tcache.get(key)
+        if hit is None or hit[0] != ent.data_ptr():
+            hit = (ent.data_ptr(), self.backend.Tables(self.scorer, ent, self.rel, self.l_norm))
+            self._tcache[key] = hit
+        return hit[1]
+
+    def _buffer(self, key, shape, like):
+        b = self._bufs.get(key)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != like.dtype:
+            b = self._bufs[key] = torch.empty(shape, dtype=like.dtype, device=like.device)
+        return b
+
+    def exchange_rows(self, ids, rel_ids: Optional[torch.Tensor] = None):
+        """Exchange step 1.  `ids` = list of k index vectors [n] of GLOBAL entity ids (the s and
+        the o column of a batch): returns ([k*n, d] entity rows, vector after vector, and the
+        [n, d_r] relation rows of `rel_ids` or None).  Two gather launches + one all-gather;
+        nothing here waits for the device."""
+        k, n = len(ids), ids[0].numel()
+        gid = torch.cat([x.reshape(-1).long() for x in ids])
+        d = self.ent_local.shape[1]
+        local = (gid - self.lo).clamp_(0, max(self.hi - self.lo - 1, 0))  # not owned: any local row
+        send = self._buffer(("send", k), (k * n, d), self.ent_local)
+        rel_rows = None if rel_ids is None else self._buffer("rel", (n, self.rel.shape[1]), self.rel)
+        self.backend.embed(self._tables(self.ent_local, "local"), local, rel_ids, send, rel_rows)
+        if self.world == 1:
+            return send, rel_rows
+        gath = self._buffer(("gath", k), (self.world * k * n, d), self.ent_local)
+        dist.all_gather_into_tensor(gath.view(-1), send.view(-1), group=self.group)
+        owner = torch.div(gid, self.shard, rounding_mode="floor")
+        pick = owner * (k * n) + torch.arange(k * n, device=gid.device)
+        rows = self._buffer(("rows", k), (k * n, d), self.ent_local)
+        self.backend.embed(self._tables(gath, ("gath", k)), pick, None, rows, None)
+        return rows, rel_rows
+
     def gather_entity_rows(self, idx: torch.Tensor) -> torch.Tensor:
-        """[n, d] rows of the GLOBAL entity table for global ids `idx` (exchange step 1)."""
-        idx = idx.long()
-        own = (idx >= self.lo) & (idx < self.hi)
-        rows = torch.zeros(idx.numel(), self.ent_local.shape[1], dtype=self.ent_local.dtype,
-                           device=self.ent_local.device)
-        rows[own] = self.ent_local[idx[own] - self.lo]
-        return self._allreduce(rows)
+        """[n, d] rows of the GLOBAL entity table for global ids `idx`."""
+        return self.exchange_rows([idx])[0].clone()
 
     # ---- scoring: local slabs, no collective ---------------------------------------------
-    def score_sp(self, s: torch.Tensor, p: torch.Tensor, s_rows: Optional[torch.Tensor] = None):
+    def score_sp(self, s: torch.Tensor, p: torch.Tensor):
         """[n, E_g]: scores of (s_i, p_i, ·) against this rank's entities."""
-        s_rows = self.gather_entity_rows(s) if s_rows is None else s_rows
-        return self.backend.score_emb(self.scorer, s_rows, self.rel[p.long()], self.ent_local, "sp_",
-                                      self.l_norm)
+        rows, rel_rows = self.exchange_rows([s], p)
+        return self.backend.score_emb(self.scorer, rows, rel_rows, self.ent_local, "sp_", self.l_norm)
 
-    def score_po(self, p: torch.Tensor, o: torch.Tensor, o_rows: Optional[torch.Tensor] = None):
-        o_rows = self.gather_entity_rows(o) if o_rows is None else o_rows
-        return self.backend.score_emb(self.scorer, self.ent_local, self.rel[p.long()], o_rows, "_po",
-                                      self.l_norm)
+    def score_po(self, p: torch.Tensor, o: torch.Tensor):
+        rows, rel_rows = self.exchange_rows([o], p)
+        return self.backend.score_emb(self.scorer, self.ent_local, rel_rows, rows, "_po", self.l_norm)
+
+    # a score block beyond this many bytes no longer sits in the 256 MB Infinity Cache while it is
+    # written: rows are then 128-byte aligned (padded pitch) and each direction gets its own launch
+    BIG_SLAB_BYTES = 96 << 20
+
+    def score_sp_po_blocks(self, s: torch.Tensor, p: torch.Tensor, o: torch.Tensor):
+        """(score_sp slab, score_po slab), each [n, E_g] (row pitch >= E_g): ONE exchange for the s
+        and the o rows, then one two-sided launch on the shard (backends with score_emb_sp_po; the
+        blocks are the halves of its [n, 2 E_g] output) or, for slabs that outgrow the Infinity Cache,
+        one launch per direction into matrices with a 128-byte-aligned row pitch."""
+        n, m = s.numel(), self.hi - self.lo
+        rows, rel_rows = self.exchange_rows([s, o], p)
+        s_rows, o_rows = rows[:n], rows[n:]
+        big = n * m * 4 > self.BIG_SLAB_BYTES
+        if hasattr(self.backend, "score_emb_sp_po") and not big:
+            both = self.backend.score_emb_sp_po(self.scorer, s_rows, rel_rows, o_rows, self.ent_local, self.l_norm)
+            return both[:, :m], both[:, m:]
+        kw = {"pad_pitch": True} if big else {}
+        return (self.backend.score_emb(self.scorer, s_rows, rel_rows, self.ent_local, "sp_", self.l_norm, **kw),
+                self.backend.score_emb(self.scorer, self.ent_local, rel_rows, o_rows, "_po", self.l_norm, **kw))
 
     def score_sp_po(self, s: torch.Tensor, p: torch.Tensor, o: torch.Tensor):
-        """[n, 2 E_g]: score_sp and score_po slabs side by side from one launch (backends with
-        score_emb_sp_po), else the two calls."""
-        s_rows, o_rows = self.gather_entity_rows(s), self.gather_entity_rows(o)
-        if hasattr(self.backend, "score_emb_sp_po"):
-            return self.backend.score_emb_sp_po(self.scorer, s_rows, self.rel[p.long()], o_rows, self.ent_local,
-                                                self.l_norm)
-        return torch.cat([self.score_sp(s, p, s_rows), self.score_po(p, o, o_rows)], dim=1)
+        """[n, 2 E_g]: the two slabs of score_sp_po_blocks side by side (KgeModel.score_sp_po's layout)."""
+        sp, po = self.score_sp_po_blocks(s, p, o)
+        if sp.data_ptr() + sp.shape[1] * 4 == po.data_ptr() and sp.stride(0) == 2 * sp.shape[1]:
+            return torch.as_strided(sp, (sp.shape[0], 2 * sp.shape[1]), (sp.stride(0), 1))
+        return torch.cat([sp, po], dim=1)
 
     def true_scores(self, slab: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """Score of each row's true entity, taken from the owner's slab (exchange step 2)."""
         target = target.long()
         own = (target >= self.lo) & (target < self.hi)
-        t = torch.zeros(target.numel(), dtype=torch.float32, device=slab.device)
-        r = torch.nonzero(own).view(-1)
-        t[r] = slab[r, target[r] - self.lo]
-        return self._allreduce(t)
+        col = (target - self.lo).clamp_(0, max(slab.shape[1] - 1, 0))
+        t = torch.where(own, slab.gather(1, col.view(-1, 1)).view(-1), torch.zeros((), dtype=slab.dtype,
+                                                                                  device=slab.device))
+        return self._allreduce(t.float())
 
     def rank_counts(self, slab, true, lbl_rowptr=None, lbl_col=None, true_col=None, atol=1e-5,
                     rtol=1e-4):
@@ -105,8 +159,7 @@ class ShardedEntityTable:
         """(s_rank, s_ties, o_rank, o_ties) for a batch of (s,p,o) triples; `labels` =
         (sp_rowptr, sp_col, po_rowptr, po_col) CSR of filtered GLOBAL entity ids or None."""
         s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
-        sp = self.score_sp(s, p)
-        po = self.score_po(p, o)
+        sp, po = self.score_sp_po_blocks(s, p, o)
         o_true = self.true_scores(sp, o)
         s_true = self.true_scores(po, s)
         sp_rp, sp_col, po_rp, po_col = labels if labels is not None else (None,) * 4
@@ -122,9 +175,7 @@ class ShardedEntityTable:
         [2 (o, s), 2 (rank, ties), len(filters) + 1, n]."""
         s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
         n, K = triples.shape[0], len(filters_o)
-        both = self.score_sp_po(s, p, o)
-        c = both.shape[1] // 2
-        sp, po = both[:, :c], both[:, c:]
+        sp, po = self.score_sp_po_blocks(s, p, o)
         o_true = self.true_scores(sp, o)
         s_true = self.true_scores(po, s)
         counts = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=sp.device)

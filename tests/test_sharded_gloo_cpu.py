@@ -14,8 +14,30 @@ import torch.multiprocessing as mp
 import oracle as ko
 
 
+class _FakeTables:
+    def __init__(self, scorer, ent, rel, l_norm=1.0):
+        self.scorer, self.ent, self.rel, self.l_norm = scorer, ent, rel, l_norm
+
+
 class OracleBackend:
-    """Drop-in for kge_amd.engine in kge_amd.sharded (score_emb + rank_counts on CPU)."""
+    """Drop-in for kge_amd.engine in kge_amd.sharded (Tables, embed, score_emb, score_emb_sp_po,
+    rank_counts, rank_counts_multi on CPU)."""
+
+    Tables = _FakeTables
+
+    @staticmethod
+    def embed(t, ent_idx=None, rel_idx=None, ent_out=None, rel_out=None):
+        """engine.embed: (ent[ent_idx], rel[rel_idx]) into the preallocated outputs."""
+        if ent_idx is not None:
+            ent_out.copy_(t.ent[ent_idx.long()])
+        if rel_idx is not None:
+            rel_out.copy_(t.rel[rel_idx.long()])
+        return ent_out, rel_out
+
+    @staticmethod
+    def score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm=1.0):
+        return torch.cat([OracleBackend.score_emb(scorer, s_emb, p_emb, targets, "sp_", l_norm),
+                          OracleBackend.score_emb(scorer, targets, p_emb, o_emb, "_po", l_norm)], 1)
 
     @staticmethod
     def score_emb(scorer, s_emb, p_emb, o_emb, combine, l_norm=1.0):
@@ -95,6 +117,18 @@ def _worker(rank, world, port, model, q):
             assert np.array_equal(cm[1, 0, k].numpy(), s_rank) and np.array_equal(cm[1, 1, k].numpy(), s_ties), key
         rows = sh.gather_entity_rows(tb[:, 0])
         assert np.array_equal(rows.numpy(), ent[batch[:, 0]])
+        # the call sequence of bench.py --gpus N: one exchange for the s and o rows (strided int32
+        # views of the batch, as the trainers pass them), relation rows from the replicated table,
+        # one two-sided scoring call on the shard -> this rank's [n, 2 E_g] slab
+        b32 = torch.from_numpy(batch.astype(np.int32))
+        rows2, rel_rows = sh.exchange_rows([b32[:, 0], b32[:, 2]], b32[:, 1])
+        assert np.array_equal(rows2.numpy(), np.concatenate([ent[batch[:, 0]], ent[batch[:, 2]]]))
+        assert np.array_equal(rel_rows.numpy(), rel[batch[:, 1]])
+        both = sh.score_sp_po(b32[:, 0], b32[:, 1], b32[:, 2])
+        full = ko.Tables(model, ent, rel, 1.0)
+        want = np.concatenate([ko.score_sp(full, batch[:, 0], batch[:, 1], np.arange(lo, hi)),
+                               ko.score_po(full, batch[:, 1], batch[:, 2], np.arange(lo, hi))], 1)
+        assert np.array_equal(both.numpy(), want)
         slab = sh.score_sp(tb[:, 0], tb[:, 1])
         tv, ti = sh.topk(slab, 5)
         if rank == 0:
