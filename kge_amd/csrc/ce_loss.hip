@@ -20,12 +20,16 @@
 // (same MFMA chain); exp/log are the hardware v_exp_f32 / libm logf: results match
 // CrossEntropyLoss on those scores to float rounding (tests/test_gpu_ce.py states the tolerance).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace kge {
 
 bool pairs_bf16_v3_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
 int pairs_bf16_v3_column_groups(long long n, long long m);
 long long pairs_bf16_v3_workspace_bytes(int d, long long n);
+int run_pairs_bf16_v4_lse(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG,
+                          int dir, int d, long long n, long long m, hipStream_t st, void* ws, long long ws_bytes,
+                          const CeArgs& ce, unsigned long long* dbg);
 int run_pairs_bf16_v3_ce(int scorer, int epi, const Operand& A, const Operand& R, const Operand& TG, int dir,
                          int d, long long n, long long m, hipStream_t st, void* ws, long long ws_bytes,
                          const CeArgs& ce, unsigned long long* dbg);
@@ -199,6 +203,22 @@ static unsigned long long* g_ce_stamps = nullptr;
 
 static inline long long al256(long long x) { return (x + 255) & ~255LL; }
 
+// The V3_LSE pass (row statistics of softmax over all entities + the label's score): on the
+// loader/consumer kernel (score_pairs_bf16_v4.hip) where it applies -- d in {256, 512}, one workgroup
+// per CU -- else on the single-role kernel.  KGE_CE_V3=1 (tests, profiling) forces the latter.
+static int run_lse_pass(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
+                        int d, long long n, long long m, hipStream_t st, void* ws, long long coop, const CeArgs& ce,
+                        unsigned long long* dbg) {
+  const char* f = getenv("KGE_CE_V3");
+  if (!(f && f[0] == '1')) {
+    CeArgs c4 = ce;
+    if (A2 != nullptr) c4.rgn1 = 0;  // the v4 launcher takes the second side as an operand, not a marker
+    const int rc = run_pairs_bf16_v4_lse(scorer, A, A2, R, TG, dir, d, n, m, st, ws, coop, c4, dbg);
+    if (rc != KGE_ERR_UNSUPPORTED) return rc;
+  }
+  return run_pairs_bf16_v3_ce(scorer, V3_LSE, A, R, TG, dir, d, n, m, st, ws, coop, ce, dbg);
+}
+
 // scratch layout: [fragments + flags of the cooperative build][part n*ncg*2 f32][true n f32]   (forward)
 //                 [fragments + flags][G16 n * ld16 bf16][Q16 n * d bf16]                          (backward)
 static inline long long ce_ld16(long long m) { return (m + 63) & ~63LL; }
@@ -227,7 +247,7 @@ int run_ce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));
   // a label outside [0, num_ent) is found by no lane: its row's loss then reads NaN, not stale scratch
   if (hipMemsetAsync(ce.true_score, 0xff, (size_t)n * sizeof(float), st) != hipSuccess) return KGE_ERR_LAUNCH;
-  const int rc = run_pairs_bf16_v3_ce(scorer, V3_LSE, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  const int rc = run_lse_pass(scorer, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, n,
                      ce.true_score, loss_rows, lse);
@@ -264,7 +284,7 @@ int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   CeArgs ce{};
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));  // here: the rows' label-score sums
-  const int rc = run_pairs_bf16_v3_ce(scorer, V3_LSE, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  const int rc = run_lse_pass(scorer, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   const dim3 grid((unsigned)((n + 3) / 4));
   if (scorer == KGE_COMPLEX)
@@ -379,7 +399,7 @@ int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(2 * n * ncg * 8));
   if (hipMemsetAsync(ce.true_score, 0xff, (size_t)(2 * n) * sizeof(float), st) != hipSuccess) return KGE_ERR_LAUNCH;
-  const int rc = run_pairs_bf16_v3_ce(scorer, V3_LSE, S, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  const int rc = run_lse_pass(scorer, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, 2 * n,
                      ce.true_score, loss_rows, lse);

@@ -51,12 +51,17 @@ __device__ __forceinline__ void v4_static_for(F&& f) {
   }
 }
 
-template <int SCORER, int HH, int TGMODE>
+// EPI (common.hpp): V3_STORE writes the score tiles; V3_LSE folds them into the per-row running
+// (max, sum exp) of the 1vsAll cross entropy and picks out the label's score instead -- the consumer
+// waves do that on the accumulators right after a tile's MFMA chain, the DMA waves keep streaming,
+// the store waves have nothing to do (kge_ce_fwd / kge_ce_sp_po_fwd: the [n, E] matrix is never
+// written; per row and column group 8 bytes leave the kernel, merged by ce_combine_kernel).
+template <int SCORER, int HH, int TGMODE, int EPI>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     Operand A, Operand A2, Operand R, Operand TG, int dir, long long n, long long m, int rgn,
     int rgn1, long long out2_off, int ncg, int tiles_per_cg, int ntiles, float* __restrict__ out,
     long long ldo, unsigned long long* __restrict__ dbg, u32x4* __restrict__ qf,
-    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild) {
+    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild, CeArgs ce) {
   constexpr int NKB = 2 * HH / 16;       // K-blocks of 16
   constexpr int NKH = HH / 16;           // K-blocks per half
   constexpr int ROWB = 4 * HH;           // bytes per table row (2*HH bf16)
@@ -290,12 +295,16 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     for (int tt = 0; tt <= ntl; ++tt) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging reads of the previous step are in registers
       __builtin_amdgcn_s_barrier();  // B1(tt): the consumers may overwrite the staging buffer
-      if (tt >= 2) store_tile(tt - 2);  // from registers, while the DMA waves issue tile tt+1
+      if constexpr (EPI == V3_STORE)
+        if (tt >= 2) store_tile(tt - 2);  // from registers, while the DMA waves issue tile tt+1
       __builtin_amdgcn_s_barrier();  // B2(tt): scores of tile tt-1 are staged
-      if (tt >= 1) read_staging();
+      if constexpr (EPI == V3_STORE)
+        if (tt >= 1) read_staging();
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    store_tile(ntl - 1);
+    if constexpr (EPI == V3_STORE) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      store_tile(ntl - 1);
+    }
     return;
   }
 
@@ -359,6 +368,53 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
   stamp();  // 3: fragment loads issued
 
+  // ---- fused 1vsAll loss (EPI == V3_LSE): per-lane state of query row fi (both lanes fh = 0 / 1 of
+  // a row hold it; padded rows repeat row n-1 like their query fragments do).  Accumulator element r
+  // of half hf is column  col0(tile) + 32 hf + 8 (r >> 2) + 4 fh + (r & 3).
+  long long lab = -1;              // label column of this lane's row
+  float rmax = -__builtin_inff();  // running max over this lane's columns so far
+  float rsum = 0.0f;               // running sum of exp(score - rmax)
+  float tsc = 0.0f;                // score(row, label) if one of this lane's columns
+  bool tfound = false;
+  const long long roff = (EPI != V3_STORE && second) ? ce.side2_off : 0;
+  if constexpr (EPI == V3_LSE) {
+    const Index& lix = second ? ce.label2 : ce.label;
+    long long orow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
+    if (orow >= n) orow = n - 1;
+    if (lix.ptr != nullptr) lab = index_at(lix, orow);
+  }
+  auto lse_tile = [&](int tt) __attribute__((always_inline)) {
+    const long long c0 = (long long)(tile_lo + tt * tile_st) * V4_TN + 4 * fh;
+    if (c0 - 4 * fh + V4_TN > m) {  // the ragged last tile of the table: columns beyond m do not exist
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long c = c0 + 8 * (r >> 2) + (r & 3);
+        acc0[r] = c < m ? acc0[r] : -__builtin_inff();
+        acc1[r] = c + 32 < m ? acc1[r] : -__builtin_inff();
+      }
+    }
+    float mx = rmax;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, __builtin_fmaxf(acc0[r], acc1[r]));
+    float sm = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      sm += __builtin_amdgcn_exp2f((acc0[r] - mx) * V3_LOG2E) + __builtin_amdgcn_exp2f((acc1[r] - mx) * V3_LOG2E);
+    rsum = rsum * __builtin_amdgcn_exp2f((rmax - mx) * V3_LOG2E) + sm;
+    rmax = mx;
+    const long long rel = lab - c0;
+    const bool hit = rel >= 0 && rel < V4_TN && (rel & 7) < 4 && lab < m;  // not a padded column
+    if (__any(hit)) {  // rare: a row's label lies in exactly one tile of the table
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int off = 8 * (r >> 2) + (r & 3);
+        tsc = (hit && rel == off) ? acc0[r] : tsc;
+        tsc = (hit && rel == 32 + off) ? acc1[r] : tsc;
+      }
+      tfound = tfound || hit;
+    }
+  };
+
   constexpr int PF = 8;
   // tile 0 is peeled off the loop: in straight-line code the compiler waits for fragment kb right in
   // front of its first MFMA (inside a loop it waits for all of them at the loop entry)
@@ -385,15 +441,17 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
     // the PREVIOUS tile's scores -> staging, behind the first reads of this tile in the LDS queue
     // (tile 0 stages zeros that nobody reads: one schedule for every tile)
+    if constexpr (EPI == V3_STORE) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
+      for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) c_write(acc1, 1, g);
+      for (int g = 0; g < 4; ++g) c_write(acc1, 1, g);
+    }
     // LDS ops younger than read q when slot q waits: q < 8: the rest of the prefetch, the 8
-    // writes and the reads of slots 0..q-1 = 15; q >= 8: min(7, NQ-1-q) reads
+    // writes (V3_STORE) and the reads of slots 0..q-1 = 15 (7 without the writes); q >= 8: min(7, NQ-1-q) reads
     v4_static_for<0, NQ>([&](auto qc) __attribute__((always_inline)) {
       constexpr int q = decltype(qc)::value;
-      constexpr int younger = q < 8 ? 15 : ((NQ - 1 - q >= PF - 1) ? PF - 1 : NQ - 1 - q);
+      constexpr int younger = q < 8 ? (EPI == V3_STORE ? 15 : 7) : ((NQ - 1 - q >= PF - 1) ? PF - 1 : NQ - 1 - q);
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(younger) : "memory");
       // first tile: fragment kb has arrived (in-order returns: at most NKB-1-kb younger loads
       // outstanding); a no-op afterwards
@@ -415,16 +473,38 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     stamp();  // tile tt: MFMA chain issued
   };
   tile(0);
-  for (int tt = 1; tt < ntl; ++tt) tile(tt);
+  if constexpr (EPI == V3_LSE) lse_tile(0);
+  for (int tt = 1; tt < ntl; ++tt) {
+    tile(tt);
+    if constexpr (EPI == V3_LSE) lse_tile(tt);
+  }
   // the last tile's scores: stage them for the loaders' final pass
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // B1(ntl)
+  if constexpr (EPI == V3_STORE) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
+    for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
 #pragma unroll
-  for (int g = 0; g < 4; ++g) c_write(acc1, 1, g);
+    for (int g = 0; g < 4; ++g) c_write(acc1, 1, g);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // B2(ntl)
+  if constexpr (EPI == V3_LSE) {
+    // the two lanes of a row -> one (max, sum exp) per row and column group
+    const float omax = __shfl_xor(rmax, 32, 64), osum = __shfl_xor(rsum, 32, 64);
+    const float M = __builtin_fmaxf(rmax, omax);
+    const float L = rsum * __builtin_amdgcn_exp2f((rmax - M) * V3_LOG2E) +
+                    osum * __builtin_amdgcn_exp2f((omax - M) * V3_LOG2E);
+    const long long row = (long long)rgl * V4_ROWS + 32 * w4 + fi;
+    if (row < n) {
+      if (fh == 0) {
+        float* pp = ce.part + ((row + roff) * ncg + cg) * 2;
+        pp[0] = M;
+        pp[1] = L;
+      }
+      if (tfound) ce.true_score[row + roff] = tsc;  // (never with a NULL label vector: lab stays -1)
+    }
+  }
 }
 
 static inline bool v4_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -443,11 +523,11 @@ static int v4_cu_count() {
 
 // A2 != nullptr: two-sided launch (A = subjects scored sp_, A2 = objects scored _po into the
 // column block `out2_off` floats behind).
-template <int SCORER, int HH>
+template <int SCORER, int HH, int EPI = V3_STORE>
 static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                      long long n, long long m, float* out, long long ldo, long long out2_off,
                      hipStream_t st, unsigned long long* dbg, void* ws, long long ws_bytes,
-                     int reserve_cus) {
+                     int reserve_cus, const CeArgs& ce = CeArgs{}) {
   const int rgn1 = (int)((n + V4_ROWS - 1) / V4_ROWS);
   const int rgn = A2 ? 2 * rgn1 : rgn1;
   const int ntiles = (int)((m + V4_TN - 1) / V4_TN);
@@ -456,6 +536,9 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   int cus = v4_cu_count() - reserve_cus;
   if (cus > 256) cus = 256;
   if (cus < 8) cus = 8;
+  // fused loss: the caller sized its partial-result scratch for the geometry of
+  // pairs_bf16_v3_column_groups (256 workgroup slots); fewer CUs: the launch check below declines
+  if (EPI != V3_STORE) cus = 256;
   int ncg = cus / rgn;
   if (ncg < 1) ncg = 1;
   int tpc = (ntiles + ncg - 1) / ncg;
@@ -484,9 +567,9 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   const bool interleave = il ? il[0] == '1' : (double)n * (double)m * 4.0 * (A2 ? 2 : 1) > 192e6;
   const int tpc_arg = interleave ? 0 : tpc;
 #define KGE_V4L(MODE)                                                                          \
-  hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE>), dim3(grid), dim3(512), 0, st, A, \
+  hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE, EPI>), dim3(grid), dim3(512), 0, st, A, \
                      AA2, R, TG, dir, n, m, rgn, rgn1, out2_off, ncg, tpc_arg, ntiles, out, ldo, \
-                     dbg, qf, flags, epoch, nbuild)
+                     dbg, qf, flags, epoch, nbuild, ce)
   if (tgmode == 0) KGE_V4L(0);
   else if (tgmode == 1) KGE_V4L(1);
   else KGE_V4L(2);
@@ -521,6 +604,27 @@ int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Ope
   }
   if (scorer == KGE_COMPLEX) { KGE_V4(KGE_COMPLEX) } else { KGE_V4(KGE_DISTMULT) }
 #undef KGE_V4
+  return KGE_ERR_UNSUPPORTED;
+}
+
+// Fused 1vsAll loss forward (ce_loss.hip) on the loader/consumer kernel: V3_LSE epilogue.  A2 != NULL:
+// both directions of a batch in one launch (ce.label / ce.label2, ce.side2_off).  `ws` = the fragment
+// + flag block of the cooperative build (layout of pairs_bf16_v3_workspace_bytes).  KGE_ERR_UNSUPPORTED:
+// the caller uses the single-role kernel.
+int run_pairs_bf16_v4_lse(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG,
+                          int dir, int d, long long n, long long m, hipStream_t st, void* ws, long long ws_bytes,
+                          const CeArgs& ce, unsigned long long* dbg) {
+  if (n == 0 || m == 0) return KGE_OK;
+  if (TG.idx.ptr != nullptr) return KGE_ERR_UNSUPPORTED;
+#define KGE_V4E(SC)                                                                                       \
+  switch (d) {                                                                                            \
+    case 256:                                                                                             \
+      return launch_v4<SC, 128, V3_LSE>(A, A2, R, TG, dir, n, m, nullptr, 1, 0, st, dbg, ws, ws_bytes, 0, ce); \
+    case 512:                                                                                             \
+      return launch_v4<SC, 256, V3_LSE>(A, A2, R, TG, dir, n, m, nullptr, 1, 0, st, dbg, ws, ws_bytes, 0, ce); \
+  }
+  if (scorer == KGE_COMPLEX) { KGE_V4E(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_V4E(KGE_DISTMULT) }
+#undef KGE_V4E
   return KGE_ERR_UNSUPPORTED;
 }
 

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python -c "import torch;print(torch.cuda.get_device_name(0), torch.version.hip)" > $OUT/env.log 2>&1
 if [ "$MODE" = "full" ]; then
-KGE_PLUGIN_LOG=$R/$OUT/plugin_gpu.jsonl timeout 1500 python -m pytest tests -m gpu -q --timeout=900 > $OUT/pytest_all.log 2>&1
+KGE_BSHAPE_LOG=$R/$OUT/bshape_ranks.jsonl KGE_PLUGIN_LOG=$R/$OUT/plugin_gpu.jsonl timeout 1500 python -m pytest tests -m gpu -q --timeout=900 > $OUT/pytest_all.log 2>&1
 echo "pytest all exit: $?" >> $OUT/env.log
 grep -h "PLUGIN_GPU\|BSHAPE_RANKS" $OUT/pytest_all.log > $OUT/plugin_lines.txt
 else
