@@ -135,9 +135,15 @@ int kge_device_count(void);
  * scoring kernel: a few workgroups build, publish through the workspace, all workgroups
  * consume -- instead of once per workgroup.  workspace == NULL (or too small) selects the
  * path where every workgroup builds its own copy.  Results are identical bit for bit.  The
- * workspace needs no initialisation, is only used during the call (stream order; calls may
- * be captured into a hipGraph and replayed) and must not be shared by calls that may run
- * concurrently on different streams; 16-byte aligned. */
+ * workspace must be ZEROED ONCE (hipMemset) before its first use and left to the library from
+ * then on: besides scratch it holds the builders' flag lines and a "degraded" word.  A consumer
+ * workgroup waits for its builders only for a bounded time (they may not be running: other
+ * streams' kernels, a second process, CU masking); after a time-out it builds its own query
+ * vectors, sets that word, and every later call on the workspace skips the hand-off -- slower,
+ * never wrong, never a hang (non-zero garbage in a fresh workspace has the same effect).  The
+ * workspace is only accessed during a call (stream order; calls may be captured into a hipGraph
+ * and replayed) and must not be shared by calls that may run concurrently on different streams;
+ * 16-byte aligned.  The same holds for the workspaces of the fused-loss entry points below. */
 int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n);
 
 /* out[i] = score(s[i], p[i], o[i]), i < n.        KgeModel.score_spo */

@@ -651,7 +651,7 @@ static int v3_cu_count() {
 long long pairs_bf16_v3_workspace_bytes(int d, long long n) {
   // fragments of whole 128-row groups, both sides of a score_sp_po call, + the builders' flags
   const long long rgn = 2 * ((n + V3_ROWS - 1) / V3_ROWS);
-  return rgn * V3_ROWS * (long long)d * 2 + 512 * 8 * 8;
+  return rgn * V3_ROWS * (long long)d * 2 + 512 * 8 * 8 + 64;  // + the "degraded" word of the v4 hand-off
 }
 
 // one workgroup per CU (256 CUs): the target tiles are split into `ncg` column groups of `tpc` tiles

@@ -24,8 +24,10 @@
 // Query vectors: built ONCE per row group, cooperatively (first `nbuild` workgroups of the row
 // group build a share each, publish through the workspace with agent-scope write-through
 // stores + a per-workgroup flag = this launch's epoch; everybody polls the flags and loads its
-// fragments).  All workgroups are co-resident (grid <= number of CUs; the launcher checks), so
-// the spin-wait cannot deadlock.
+// fragments).  The launcher asks for one workgroup per CU (grid <= number of CUs), so builders and
+// consumers normally run side by side; a plain launch does not GUARANTEE that (other streams'
+// kernels, a second process, CU masking), so the wait is bounded and a consumer whose builders
+// do not show up builds its own fragments instead (same bits) -- never a hang, never a trap.
 //
 // Synchronisation per tile: two workgroup barriers.  B1(t): tile t has landed (the DMA waves
 // waited for their pieces) / everybody is done with tile t-1's buffer and the staging buffer has
@@ -311,27 +313,39 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   // =================================== consumer waves ===================================
   const int fi = lane & 31, fh = lane >> 5;
   bf16x8 afr[NKB];
+  // A consumer never trusts a builder blindly.  The wait is bounded (a builder workgroup that is not
+  // running -- its CU busy with another stream's kernel, CU masking, a second process -- must neither
+  // hang this workgroup nor kill the process): on a time-out this workgroup builds its own fragments in
+  // registers (same bits) and marks the workspace DEGRADED; every later launch on that workspace then
+  // skips the hand-off at once (a flag published late cannot be told from a fresh one by a replay of a
+  // captured launch, whose epoch is frozen).  KGE_V4_OWN_BUILD=1 (tests) takes that path on purpose.
+  unsigned long long* const degraded = flags + 512 * 8;
+  int* const sb_flag = reinterpret_cast<int*>(smem + CST0);  // the staging buffer is idle until tile 0 is done
   if (wave == 0) {
     // ONE wave per workgroup polls (255 pollers already cost chip bandwidth): one flag per builder
     unsigned long long* f = flags + ((long long)rg * ncg + cg) * 8;
-    int spin = 0;
-    for (;; ++spin) {
+    bool ok = nbuild > 0 && __hip_atomic_load(degraded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
+    for (int spin = 0; ok; ++spin) {
       const unsigned long long v =
           lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
       if (__all(v == epoch)) break;
-      // bounded (seconds): a lost builder must neither hang the GPU nor let this workgroup score
-      // with garbage -- abort the launch, the host sees a launch failure
-      if (spin == (1 << 21)) __builtin_trap();
+      if (spin == (1 << 16)) {  // ~0.1 s: far beyond any launch skew
+        ok = false;
+        if (lane == 0 && nbuild > 0) __hip_atomic_store(degraded, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       __builtin_amdgcn_s_sleep(1);
     }
     // This line belongs to this workgroup alone (the builders write it, nobody else reads it):
     // clear it, so that a replay of this very launch (hipGraph: the kernel arguments, epoch
     // included, are frozen at capture) starts from "not published" again.
-    if (lane < nbuild) __hip_atomic_store(f + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ok && lane < nbuild) __hip_atomic_store(f + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) *sb_flag = ok ? 1 : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS write has landed before the barrier
   }
-  __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published
+  __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published (or given up on)
   stamp();  // 2: all shares of this row group published
-  {
+  const bool coop = *reinterpret_cast<volatile int*>(sb_flag) != 0;
+  if (coop) {
     // The builders stored with sc1 (write-through); sc1 loads (served by L2, never by this CU's
     // L1) complete the hand-off without an acquire fence.  The 32 loads are NOT waited for here:
     // the MFMA chain of the first tile waits for fragment kb right before it needs it.
@@ -346,6 +360,28 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       constexpr int kb = decltype(kc)::value;
       afr[kb] = __builtin_bit_cast(
           bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16 + kb * 1024), 0, 16 /* sc1 */));
+    });
+  } else {
+    // own build, straight into the MFMA operand registers: lane (fi, fh) holds coordinates
+    // 16 kb + 8 fh .. + 7 of query row fi for every K-block kb -- the same values, bit for bit
+    const long long lrow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
+    const long long qrow = lrow < n ? lrow : n - 1;
+    const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + fh * 8;
+    const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + fh * 8;
+    v4_static_for<0, NKH>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      const u32x4 a0 = *reinterpret_cast<const u32x4*>(a + kb * 16), a1 = *reinterpret_cast<const u32x4*>(a + HH + kb * 16);
+      const u32x4 r0 = *reinterpret_cast<const u32x4*>(r + kb * 16), r1 = *reinterpret_cast<const u32x4*>(r + HH + kb * 16);
+      u32x4 q0, q1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned int x0, x1;
+        bf16_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+        q0[e] = x0;
+        q1[e] = x1;
+      }
+      afr[kb] = __builtin_bit_cast(bf16x8, q0);
+      afr[NKH + kb] = __builtin_bit_cast(bf16x8, q1);
     });
   }
   // B fragment (K-block kb, half hf) of target row 32*hf + fi: 16-B slot s = s0(kb) + fh, stored
@@ -550,7 +586,7 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   // Fine under hipGraph capture: the epoch is frozen then, but every consumer clears its own
   // flag line after reading it, so a replay never sees the previous run's flags.
   const long long qf_bytes = (long long)rgn * V4_ROWS * HH * 4;
-  if (ws == nullptr || !v4_al16(ws) || (long long)rgn * ncg > 512 || ws_bytes < qf_bytes + 512 * 8 * 8 ||
+  if (ws == nullptr || !v4_al16(ws) || (long long)rgn * ncg > 512 || ws_bytes < qf_bytes + 512 * 8 * 8 + 64 ||
       grid > v4_cu_count() || ldo >= (1LL << 24))
     return KGE_ERR_UNSUPPORTED;
   u32x4* qf = (u32x4*)ws;
@@ -561,6 +597,10 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   int nbuild = ncg < 8 ? ncg : 8;
   const int items = V4_ROWS * (HH / 8);  // at least one item per builder thread
   while (nbuild > 1 && nbuild * 512 > items) --nbuild;
+  // KGE_V4_OWN_BUILD=1 (tests): no cooperative build, every consumer wave builds its own fragments --
+  // the path a consumer otherwise only takes after a time-out or on a degraded workspace
+  const char* own = getenv("KGE_V4_OWN_BUILD");
+  if (own && own[0] == '1') nbuild = 0;
   const Operand& AA2 = A2 ? *A2 : A;
   // interleaved tiles (tiles_per_cg = 0) once a launch's score block outgrows the Infinity Cache
   const char* il = getenv("KGE_V4_INTERLEAVE");

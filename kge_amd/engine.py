@@ -93,8 +93,8 @@ def _workspace(tc, n, device, enable=True, stream=None):
     key = (device.index, _stream_handle(device) if stream is None else stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < need:
-        # zero-initialised once: the builders' flag lines of the cooperative query build live in it
-        # (a tag that happens to equal a launch's epoch in fresh memory is 2^-64 unlikely, not impossible)
+        # zero-initialised ONCE (include/kge_amd.h): besides scratch it holds the builders' flag lines
+        # and the "degraded" word of the cooperative query build, maintained by the kernels from then on
         try:
             buf = torch.zeros((max(need, 1 << 20),), device=device, dtype=torch.uint8)
         except torch.OutOfMemoryError as e:  # pragma: no cover
@@ -588,7 +588,7 @@ def _ce_workspace(tc, n, device, st):
     key = (device.index, st, "ce")
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < need:
-        buf = _WORKSPACES[key] = _empty((need,), device, torch.uint8)
+        buf = _WORKSPACES[key] = torch.zeros((need,), device=device, dtype=torch.uint8)  # zeroed once, see _workspace
     return buf.data_ptr(), buf.numel()
 
 
@@ -644,7 +644,7 @@ def _ce2_workspace(tc, n, device, st):
     key = (device.index, st, "ce2")
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < need:
-        buf = _WORKSPACES[key] = _empty((need,), device, torch.uint8)
+        buf = _WORKSPACES[key] = torch.zeros((need,), device=device, dtype=torch.uint8)
     return buf.data_ptr(), buf.numel()
 
 

@@ -614,3 +614,42 @@ def test_bf16_random_shapes_against_the_single_role_kernel(eng):
         O = _oracle_tables(model, ent, rel, 1.0, bf16=True)
         i = int(rng.integers(0, n))
         _close("oracle row " + tag, got[i:i + 1], ko.score_sp(O, s[i:i + 1], p[i:i + 1], sub))
+
+
+@pytest.mark.parametrize("d,n,E", [(512, 512, 14541), (256, 130, 700)])
+def test_bf16_own_build_fallback_is_bit_identical(eng, monkeypatch, d, n, E):
+    """A consumer workgroup of the loader/consumer kernel whose builders do not show up within a
+    bounded wait (their CUs busy with another kernel) builds its own query fragments in registers and
+    marks the workspace degraded; KGE_V4_OWN_BUILD=1 forces that path for every workgroup.  The scores
+    must be the bits of the cooperative build, one- and two-sided, the two modes must alternate on one
+    scratch buffer, and a workspace whose "degraded" word is set must keep giving the same bits."""
+    from kge_amd import engine as engmod
+    rng = np.random.default_rng(d + n)
+    R = 9
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    for model in ("complex", "distmult"):
+        T = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+        s, p, o = (_t(rng.integers(0, hi, n)) for hi in (E, R, E))
+
+        def calls():
+            return [_np(eng.score_sp(T, s, p)), _np(eng.score_po(T, p, o)), _np(eng.score_sp_po(T, s, p, o))]
+        coop = calls()
+        for rep in range(2):
+            monkeypatch.setenv("KGE_V4_OWN_BUILD", "1")
+            own = calls()
+            monkeypatch.setenv("KGE_V4_OWN_BUILD", "0")
+            again = calls()
+            for k, (a, b, c) in enumerate(zip(coop, own, again)):
+                _eq(f"{model} own build, call {k}, rep {rep}", b, a)
+                _eq(f"{model} cooperative build after own build, call {k}, rep {rep}", c, a)
+    # a degraded workspace: poison every scratch buffer of this process (flag lines and the degraded
+    # word become non-zero garbage), score again, then restore zeros
+    bufs = [b for k, b in engmod._WORKSPACES.items() if len(k) == 2]
+    for b in bufs:
+        b.fill_(0xA5)
+    degraded = calls()
+    for b in bufs:
+        b.zero_()
+    for k, (a, b) in enumerate(zip(coop, degraded)):
+        _eq(f"degraded workspace, call {k}", b, a)
