@@ -364,6 +364,26 @@ int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t 
                      float minus_clr, float weight_decay, float eps, void* bf16_copy,
                      void* stream);
 
+/* One dense Adam step (torch.optim.Adam, amsgrad / maximize off) on `count` contiguous f32 elements,
+ * in place, one pass:  g = grad + weight_decay * param (if != 0);  exp_avg += (g - exp_avg)(1 - beta1);
+ * exp_avg_sq = exp_avg_sq * beta2 + (1 - beta2) g g;
+ * param -= step_size * exp_avg / (sqrt(exp_avg_sq) / bias_correction2_sqrt + eps),
+ * step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t) computed by the caller
+ * (kge/util/optimizer.py:15-20 with train.optimizer.default.type: Adam).  bf16_copy as above. */
+int kge_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                  float step_size, float bias_correction2_sqrt, double beta1, double beta2,
+                  float weight_decay, float eps, void* bf16_copy, void* stream);
+
+/* Row-sparse Adagrad step: only the `num_rows` listed rows (unique ids, int64) of a [*, dim] table
+ * have a gradient, grad_rows[r, :] belonging to row rows[r] -- torch.optim.Adagrad's update for the
+ * sparse gradients of lookup_embedder.sparse: True (kge/model/embedder/lookup_embedder.yaml:78-81):
+ *   state_sum[row] += g*g;  param[row] += minus_clr * g / (sqrt(state_sum[row]) + eps).
+ * Untouched rows are neither read nor written.  bf16_copy: the same rows of the bf16 table copy. */
+int kge_adagrad_step_rows(float* param, int64_t param_ld, const float* grad_rows, int64_t grad_ld,
+                          float* state_sum, int64_t sum_ld, const int64_t* rows, int64_t num_rows,
+                          int64_t dim, float minus_clr, float eps, void* bf16_copy, int64_t copy_ld,
+                          void* stream);
+
 /* ---- backward (autograd twins) ------------------------------------------ */
 /* All gradients are f32 and OVERWRITTEN; tables/embeddings must be f32, except
  * kge_score_pairs_bwd for ComplEx/DistMult, which also takes bf16 tables (mixed-precision

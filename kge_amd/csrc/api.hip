@@ -86,6 +86,11 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
                 long long ws_bytes, hipStream_t st);
 int run_adagrad(float* param, const float* grad, float* sum, long long count, float minus_clr, float weight_decay,
                 float eps, unsigned short* copy16, hipStream_t st);
+int run_adam(float* param, const float* grad, float* m1, float* m2, long long count, float step_size, float bc2_sqrt,
+             float omb1, float beta2, float omb2, float weight_decay, float eps, unsigned short* copy16, hipStream_t st);
+int run_adagrad_rows(float* param, long long param_ld, const float* grows, long long g_ld, float* sum, long long sum_ld,
+                     const long long* rows, long long nrows, int dim, float minus_clr, float eps,
+                     unsigned short* copy16, long long c_ld, hipStream_t st);
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, float* loss_rows, float* lse, void* ws,
                long long ws_bytes, hipStream_t st);
@@ -570,6 +575,29 @@ int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t 
   if (bf16_copy && ((uintptr_t)bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
   return run_adagrad(param, grad, state_sum, count, minus_clr, weight_decay, eps, (unsigned short*)bf16_copy,
                      (hipStream_t)stream);
+}
+
+int kge_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float step_size,
+                  float bias_correction2_sqrt, double beta1, double beta2, float weight_decay, float eps,
+                  void* bf16_copy, void* stream) {
+  if (count < 0 || (count > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return KGE_ERR_INVALID_ARG;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return KGE_ERR_INVALID_ARG;
+  if (bf16_copy && ((uintptr_t)bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
+  if (!(bias_correction2_sqrt > 0.0f)) return KGE_ERR_INVALID_ARG;
+  // 1 - beta in double, then rounded: the weights torch derives from the Python floats
+  return run_adam(param, grad, exp_avg, exp_avg_sq, count, step_size, bias_correction2_sqrt, (float)(1.0 - beta1),
+                  (float)beta2, (float)(1.0 - beta2),
+                  weight_decay, eps, (unsigned short*)bf16_copy, (hipStream_t)stream);
+}
+
+int kge_adagrad_step_rows(float* param, int64_t param_ld, const float* grad_rows, int64_t grad_ld, float* state_sum,
+                          int64_t sum_ld, const int64_t* rows, int64_t num_rows, int64_t dim, float minus_clr,
+                          float eps, void* bf16_copy, int64_t copy_ld, void* stream) {
+  if (num_rows < 0 || dim < 0 || dim > 0x7fffffff) return KGE_ERR_INVALID_ARG;
+  if (num_rows > 0 && dim > 0 && (!param || !grad_rows || !state_sum || !rows)) return KGE_ERR_INVALID_ARG;
+  if (param_ld < dim || grad_ld < dim || sum_ld < dim || (bf16_copy && copy_ld < dim)) return KGE_ERR_INVALID_ARG;
+  return run_adagrad_rows(param, param_ld, grad_rows, grad_ld, state_sum, sum_ld, (const long long*)rows, num_rows,
+                          (int)dim, minus_clr, eps, (unsigned short*)bf16_copy, copy_ld, (hipStream_t)stream);
 }
 
 int kge_bce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,

@@ -7,7 +7,7 @@ Usage inside an unmodified LibKGE installation (config-default.yaml:137, README.
     # optional: eval.type: hip_entity_ranking
     # optional: train.type: hip_1vsAll / hip_KvsAll  (kl / bce loss fused into the scoring kernel)
     #           train.type: hip_negative_sampling  (negatives through the fused gather + score kernel)
-    # optional: train.optimizer.default.type: HipAdagrad  (one-pass Adagrad; args as for Adagrad,
+    # optional: train.optimizer.default.type: HipAdagrad / HipAdam  (one-pass update; args as for Adagrad / Adam,
     #           plus bf16_copies: true to keep the bf16 scoring tables fresh without a cast)
 
 `Config._import("hip_complex")` finds hip_complex.yaml in this package (config.py:280-325)
@@ -34,5 +34,7 @@ from .train_job import (HipTrainingJob1vsAll, HipTrainingJobKvsAll,  # noqa: F40
 # kge/util/optimizer.py:15-20 resolves train.optimizer.default.type with getattr(torch.optim, ...)
 import torch.optim as _torch_optim
 from ..optim import Adagrad as HipAdagrad  # noqa: E402
+from ..optim import Adam as HipAdam  # noqa: E402
 
 _torch_optim.HipAdagrad = HipAdagrad
+_torch_optim.HipAdam = HipAdam

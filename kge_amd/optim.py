@@ -1,6 +1,6 @@
-"""torch.optim.Adagrad with the dense update done by one HIP kernel per parameter
-(kge_adagrad_step), optionally maintaining the bf16 copies of the tables that mixed-precision
-scoring reads.
+"""torch.optim.Adagrad / torch.optim.Adam with the update done by one HIP kernel per parameter
+(kge_adagrad_step, kge_adagrad_step_rows for row-sparse gradients, kge_adam_step), optionally
+maintaining the bf16 copies of the tables that mixed-precision scoring reads.
 
 Drop-in for `torch.optim.Adagrad` (same constructor arguments, same `state_dict`: per-parameter
 "step" and "sum"), so LibKGE's optimizer checkpoints load either way.  Parameters the kernel does
@@ -50,6 +50,38 @@ class Adagrad(_TorchAdagrad):
         return (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and g is not None
                 and not g.is_sparse and g.dtype == torch.float32 and g.is_contiguous())
 
+    @staticmethod
+    def _rows_ok(p: torch.Tensor, group) -> bool:
+        """Row-sparse gradient of a 2-D table (lookup_embedder.sparse: True -> nn.Embedding(sparse=True),
+        lookup_embedder.py:44-46): kge_adagrad_step_rows touches only the rows that have a gradient."""
+        g = p.grad
+        return (g is not None and g.is_sparse and p.is_cuda and p.dim() == 2 and p.dtype == torch.float32
+                and p.is_contiguous() and g.dtype == torch.float32 and group["weight_decay"] == 0)
+
+    def _step_rows(self, p, group):
+        state = self.state[p]
+        state["step"] += 1
+        step = float(state["step"])
+        minus_clr = -float(group["lr"]) / (1.0 + (step - 1.0) * group["lr_decay"])
+        g = p.grad.coalesce()  # unique row ids, summed value rows (what torch's sparse Adagrad does first)
+        rows = g.indices()[0].contiguous()
+        vals = g.values().contiguous()
+        if rows.numel() == 0:
+            return
+        s = state["sum"]
+        copy = None
+        if self.bf16_copies:
+            rec = getattr(p, BF16_ATTR, None)
+            copy = rec[0] if rec is not None and rec[0].shape == p.shape else p.detach().to(torch.bfloat16)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().kge_adagrad_step_rows(
+                p.data_ptr(), p.stride(0), vals.data_ptr(), vals.stride(0), s.data_ptr(), s.stride(0), rows.data_ptr(),
+                rows.numel(), p.shape[1], minus_clr, float(group["eps"]), None if copy is None else copy.data_ptr(),
+                0 if copy is None else copy.stride(0), engine._stream(p.device)), "kge_adagrad_step_rows")
+        torch.autograd.graph.increment_version(p)
+        if copy is not None:
+            setattr(p, BF16_ATTR, (copy, p._version, p.data_ptr()))
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -62,6 +94,9 @@ class Adagrad(_TorchAdagrad):
             rest = []
             for p in group["params"]:
                 if p.grad is None:
+                    continue
+                if self._rows_ok(p, group):
+                    self._step_rows(p, group)
                     continue
                 if not self._kernel_ok(p):
                     rest.append(p)
@@ -91,4 +126,74 @@ class Adagrad(_TorchAdagrad):
                 _functional_adagrad(rest, grads, sums, steps, has_sparse_grad=any(g.is_sparse for g in grads),
                                     foreach=False, lr=group["lr"], weight_decay=group["weight_decay"],
                                     lr_decay=group["lr_decay"], eps=group["eps"], maximize=False)
+        return loss
+
+
+class Adam(torch.optim.Adam):
+    """torch.optim.Adam (same constructor arguments and `state_dict`: "step", "exp_avg", "exp_avg_sq")
+    with the dense update of float32 GPU parameters done by kge_adam_step: one pass instead of the
+    multi-tensor sequence, optionally writing the bf16 scoring copies in the same pass.  amsgrad,
+    maximize, capturable and differentiable are not supported; parameters the kernel does not cover
+    are stepped by torch's own Adam."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False,
+                 bf16_copies: bool = False, **kw):
+        kw.pop("foreach", None)
+        kw.pop("fused", None)
+        if amsgrad:
+            raise NotImplementedError("kge_amd.optim.Adam: amsgrad is not supported")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, foreach=False,
+                         **kw)
+        self.bf16_copies = bool(bf16_copies)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        done, held = [], False
+        for group in self.param_groups:
+            if group.get("maximize") or group.get("differentiable") or group.get("capturable"):
+                raise NotImplementedError("kge_amd.optim.Adam: maximize / differentiable / capturable are not supported")
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not Adagrad._kernel_ok(p):
+                    held = True
+                    continue
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                t = float(state["step"])
+                step_size = float(group["lr"]) / (1.0 - beta1 ** t)
+                bc2_sqrt = (1.0 - beta2 ** t) ** 0.5
+                copy = None
+                if self.bf16_copies and p.dim() == 2:
+                    rec = getattr(p, BF16_ATTR, None)
+                    copy = rec[0] if rec is not None and rec[0].shape == p.shape else \
+                        torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
+                with torch.cuda.device(p.device):
+                    _lib.check(_lib.lib().kge_adam_step(
+                        p.data_ptr(), p.grad.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                        p.numel(), step_size, bc2_sqrt, float(beta1), float(beta2), float(group["weight_decay"]),
+                        float(group["eps"]), None if copy is None else copy.data_ptr(), engine._stream(p.device)),
+                        "kge_adam_step")
+                torch.autograd.graph.increment_version(p)
+                if copy is not None:
+                    setattr(p, BF16_ATTR, (copy, p._version, p.data_ptr()))
+                done.append(p)
+        if held:  # torch's own update for everything else: hide the stepped parameters' gradients for the call
+            stash = [(q, q.grad) for q in done]
+            for q, _ in stash:
+                q.grad = None
+            try:
+                torch.optim.Adam.step(self)
+            finally:
+                for q, g in stash:
+                    q.grad = g
         return loss

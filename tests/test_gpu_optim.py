@@ -120,3 +120,64 @@ def test_whole_training_step_replayed_as_a_hip_graph():
     torch.cuda.synchronize()
     for a, b in zip(m_e.parameters(), m_g.parameters()):
         torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("weight_decay", [0.0, 1e-3])
+def test_adam_matches_torch(weight_decay):
+    """kge_amd.optim.Adam (kge_adam_step: one pass per table) against torch.optim.Adam over 5 steps:
+    parameters and both moment estimates within float rounding, interchangeable state_dicts, bf16
+    copies written in the same pass; a CPU parameter in the same optimizer is stepped by torch."""
+    from kge_amd.optim import Adam, bf16_copy_of
+    torch.manual_seed(1)
+    shapes = [(777, 64), (9, 31), (6,)]
+    ref = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes] + [torch.randn(4, 3, requires_grad=True)]
+    got = [r.detach().clone().requires_grad_(True) for r in ref]
+    o_ref = torch.optim.Adam(ref, lr=0.05, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay)
+    o_got = Adam(got, lr=0.05, betas=(0.9, 0.99), eps=1e-8, weight_decay=weight_decay, bf16_copies=True)
+    for step in range(5):
+        for r, g in zip(ref, got):
+            grad = torch.randn_like(r)
+            r.grad, g.grad = grad.clone(), grad.clone()
+        o_ref.step()
+        o_got.step()
+        for r, g in zip(ref, got):
+            torch.testing.assert_close(g.detach(), r.detach(), rtol=5e-6, atol=2e-6)
+        for sr, sg in zip(o_ref.state.values(), o_got.state.values()):
+            torch.testing.assert_close(sg["exp_avg"], sr["exp_avg"], rtol=5e-6, atol=2e-7)
+            torch.testing.assert_close(sg["exp_avg_sq"], sr["exp_avg_sq"], rtol=5e-6, atol=1e-9)
+            assert float(sg["step"]) == float(sr["step"]) == step + 1
+    c = bf16_copy_of(got[0])
+    assert c is not None and torch.equal(c, got[0].detach().to(torch.bfloat16))
+    o_ref.load_state_dict(o_got.state_dict())
+    o_got.load_state_dict(o_ref.state_dict())
+
+
+def test_adagrad_row_sparse_gradients_match_torch():
+    """lookup_embedder.sparse: True gives nn.Embedding(sparse=True) and with it row-sparse gradients:
+    kge_adagrad_step_rows (only the touched rows are read and written) against torch.optim.Adagrad's
+    sparse path, duplicate ids in the batch included; the bf16 copy follows the touched rows."""
+    from kge_amd.optim import Adagrad, bf16_copy_of
+    torch.manual_seed(2)
+    E, d = 5000, 96
+    w0 = torch.randn(E, d, device=DEV)
+    emb_ref = torch.nn.Embedding(E, d, sparse=True, device=DEV)
+    emb_got = torch.nn.Embedding(E, d, sparse=True, device=DEV)
+    with torch.no_grad():
+        emb_ref.weight.copy_(w0)
+        emb_got.weight.copy_(w0)
+    o_ref = torch.optim.Adagrad(emb_ref.parameters(), lr=0.1, lr_decay=0.01, eps=1e-10)
+    o_got = Adagrad(emb_got.parameters(), lr=0.1, lr_decay=0.01, eps=1e-10, bf16_copies=True)
+    for step in range(4):
+        idx = torch.randint(E, (300,), device=DEV)
+        idx[:20] = idx[20:40]  # duplicates: coalesced before the update
+        wgt = torch.randn(300, d, device=DEV)
+        for emb, opt in ((emb_ref, o_ref), (emb_got, o_got)):
+            opt.zero_grad()
+            (emb(idx) * wgt).sum().backward()
+            assert emb.weight.grad.is_sparse
+            opt.step()
+        torch.testing.assert_close(emb_got.weight.detach(), emb_ref.weight.detach(), rtol=2e-6, atol=1e-7)
+        torch.testing.assert_close(o_got.state[emb_got.weight]["sum"], o_ref.state[emb_ref.weight]["sum"],
+                                   rtol=2e-6, atol=1e-30)
+    c = bf16_copy_of(emb_got.weight)
+    assert c is not None and torch.equal(c, emb_got.weight.detach().to(torch.bfloat16))
