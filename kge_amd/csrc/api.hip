@@ -2,6 +2,7 @@
 // kernel selection.  No torch, no allocation, no global state; every call enqueues on the
 // caller's hipStream_t and returns a kge_status.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace kge {
 int run_spo(int scorer, int dtype, bool neg_mode, const Operand& S, const Operand& R,
@@ -32,6 +33,10 @@ int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Ope
                       const Operand& TG, int dir, int d, long long n, long long m, float* out,
                       long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
                       void* ws, long long ws_bytes, int reserve_cus);
+bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
+int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
+                      int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
+                      unsigned long long* dbg);
 int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo,
                       hipStream_t st, unsigned long long* dbg = nullptr, void* ws = nullptr,
@@ -132,6 +137,15 @@ int check_tables(const kge_tables* t, bool need_ptrs) {
   return KGE_OK;
 }
 
+// The workgroup-local-build kernel (score_pairs_bf16_v5.hip) IN FRONT of the cooperative one (v4) instead
+// of behind it (where it takes what v4 declines): KGE_V5=1, for tests and measurements.
+constexpr bool V5_DEFAULT = false;
+bool v5_on(const kge_tables* t) {
+  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) return false;
+  const char* e = getenv("KGE_V5");
+  return e ? e[0] == '1' : V5_DEFAULT;
+}
+
 int check_index(const kge_index& ix, bool allow_null, int64_t len = 1) {
   if (!ix.ptr) return (allow_null || len == 0) ? KGE_OK : KGE_ERR_INVALID_ARG;
   if (ix.itype != KGE_I32 && ix.itype != KGE_I64) return KGE_ERR_INVALID_ARG;
@@ -150,6 +164,10 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
                    const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo,
                    void* ws, int64_t ws_bytes, hipStream_t st) {
   const int d = (int)t->dim, dr = (int)t->rel_dim;
+  if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, d, A, R, TG)) {
+    const int rc = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr);
+    if (rc != KGE_ERR_UNSUPPORTED) return rc;
+  }
   if (!(t->flags & KGE_FLAG_EXACT)) {
     const bool v1 = t->flags & KGE_FLAG_BF16_V1, v2 = t->flags & KGE_FLAG_BF16_V2;
     if (!v1 && !v2 && !(t->flags & KGE_FLAG_BF16_V3) && ws != nullptr &&
@@ -157,6 +175,12 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
       const int rc = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr,
                                        ws, ws_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
       if (rc != KGE_ERR_UNSUPPORTED) return rc;  // else: launch conditions not met, single-role kernel
+    }
+    // v4 declined (no workspace, more than 32 row groups, fewer CUs than workgroups): the kernel with
+    // the workgroup-local query build, same bits
+    if (!v1 && !v2 && !(t->flags & KGE_FLAG_BF16_V3) && pairs_bf16_v5_supported(t->scorer, t->dtype, d, A, R, TG)) {
+      const int rc = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr);
+      if (rc != KGE_ERR_UNSUPPORTED) return rc;
     }
     if (!v1 && !v2 && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))
       return run_pairs_bf16_v3(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
@@ -258,6 +282,12 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
       check_index(p, false) == KGE_OK && check_index(o, false) == KGE_OK &&
       check_index(targets, true) == KGE_OK && (targets.ptr || m == t->num_ent)) {
     Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, targets);
+    if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
+        pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
+      const int rc5 = run_pairs_bf16_v5(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
+                                        (hipStream_t)stream, nullptr);
+      if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
+    }
     if (pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
         pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
       const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
@@ -351,6 +381,11 @@ int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, co
   const Index ident{nullptr, 1, KGE_I64};
   Operand S{s_emb, s_ld, ident}, P{p_emb, p_ld, ident}, O{o_emb, o_ld, ident}, TG{tgt_emb, tgt_ld, ident};
   hipStream_t st = (hipStream_t)stream;
+  if (n > 0 && m > 0 && v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
+      pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
+    const int rc5 = run_pairs_bf16_v5(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr);
+    if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
+  }
   if (workspace && n > 0 && m > 0 &&
       !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
@@ -725,6 +760,11 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
   if (ablate) {
     if (t->scorer != KGE_COMPLEX || t->dim != 512) return KGE_ERR_UNSUPPORTED;
     return run_pairs_bf16_v2_ablate(ablate, A, R, TG, n, m, out, ldo, (hipStream_t)stream, stamps);
+  }
+  if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {
+    const int rc5 = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, 0,
+                                      (hipStream_t)stream, stamps);
+    if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
   }
   if (!(t->flags & (KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) && workspace != nullptr &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned int x0, x1;
-        bf16_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+        bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
         q0[e] = x0;
         q1[e] = x1;
       }
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned int x0, x1;
-        bf16_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+        bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
         q0[e] = x0;
         q1[e] = x1;
       }

@@ -653,3 +653,47 @@ def test_bf16_own_build_fallback_is_bit_identical(eng, monkeypatch, d, n, E):
         b.zero_()
     for k, (a, b) in enumerate(zip(coop, degraded)):
         _eq(f"degraded workspace, call {k}", b, a)
+
+
+def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch):
+    """score_pairs_bf16_v5.hip (every workgroup builds the query vectors of its own 64 rows: no workspace,
+    no hand-off, any n) takes the calls the cooperative kernel declines.  Forced in front of it
+    (KGE_V5=1) it must give the same bits -- all / listed targets, one- and two-sided, dense rows, d = 256
+    and 512, ragged shapes; and so must the calls it takes on its own: no scratch buffer, n > 4096."""
+    rng = np.random.default_rng(55)
+    for it in range(14):
+        d = int(rng.choice([256, 512]))
+        E = int(rng.integers(1, 5000))
+        n = int(rng.integers(1, 1300)) if it % 4 else int(rng.integers(1, 70))
+        R = 5
+        model = "complex" if it % 2 else "distmult"
+        ent = rng.standard_normal((E, d)).astype(np.float32)
+        rel = rng.standard_normal((R, d)).astype(np.float32)
+        T = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+        s, p, o = (_t(rng.integers(0, hi, n)) for hi in (E, R, E))
+        sub = None if it % 3 else _t(rng.integers(0, E, int(rng.integers(1, E + 1))))
+        want = (_np(eng.score_sp(T, s, p, sub)), _np(eng.score_po(T, p, o, sub)), _np(eng.score_sp_po(T, s, p, o, sub)))
+        monkeypatch.setenv("KGE_V5", "1")
+        got = (_np(eng.score_sp(T, s, p, sub)), _np(eng.score_po(T, p, o, sub)), _np(eng.score_sp_po(T, s, p, o, sub)))
+        dense = _np(eng.score_emb(model, T.ent[s.long()], T.rel[p.long()], T.ent if sub is None else T.ent[sub.long()], "sp_"))
+        monkeypatch.setenv("KGE_V5", "0")
+        tag = f"it={it} {model} d={d} n={n} E={E} sub={None if sub is None else int(sub.numel())}"
+        for k, (a, b) in enumerate(zip(got, want)):
+            _eq(f"local build, call {k}, {tag}", a, b)
+        _eq(f"local build, dense rows, {tag}", dense, want[0])
+    monkeypatch.delenv("KGE_V5")
+    # the calls it takes on its own
+    E, d, n = 3000, 512, 4500
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    T = _gpu_tables(eng, "complex", ent, rel, 1.0, bf16=True)
+    Tn = _gpu_tables(eng, "complex", ent, rel, 1.0, bf16=True)
+    Tn.use_workspace = False
+    s, p = _t(rng.integers(0, E, n)), _t(rng.integers(0, R, n))
+    big = _np(eng.score_sp(T, s, p))            # 36 row groups of 128: beyond the cooperative kernel
+    _eq("n = 4500 vs two halves", big, np.concatenate([_np(eng.score_sp(T, s[:2250], p[:2250])),
+                                                       _np(eng.score_sp(T, s[2250:], p[2250:]))]))
+    _eq("no scratch buffer", _np(eng.score_sp(Tn, s[:700], p[:700])), big[:700])
+    O = _oracle_tables("complex", ent, rel, 1.0, bf16=True)
+    rows = rng.integers(0, n, 8)
+    _close("vs oracle", big[rows], ko.score_sp(O, _np(s)[rows], _np(p)[rows]))
