@@ -259,12 +259,18 @@ __global__ __launch_bounds__(256) void bwdg_reduce_kernel(const float* __restric
 // reduction kernel.  P (or the plain product) is chosen by timing each once per shape.
 static bool gemm_long_k(int in16, int d, long long n, long long m, const void* T, long long ldt, const void* G,
                         long long ldg, float* C, float* scratch, size_t scratch_bytes, hipStream_t st) {
+  // The strategy is tuned once per BUCKET of shapes: n rounded up to a multiple of 128 (KvsAll batches
+  // change their number of sp_ / _po queries with every batch: a key on the exact n meant a timing pass
+  // with a host synchronisation in nearly every backward call), leading dimensions and scratch size not
+  // part of the key (a choice that does not fit this call's scratch falls back to the plain product).
+  // The cache is bounded: the oldest entry goes when it is full.
   struct Choice {
     int in16, d;
-    long long n, m, ldt, ldg;
-    size_t sb;
+    long long nb, m;
     int P;
   };
+  constexpr size_t MAX_CHOICES = 64;
+  const long long nb = (n + 127) / 128;
   static std::mutex mu;
   static std::vector<Choice> choices;
   const size_t es = in16 ? 2 : 4;
@@ -286,8 +292,7 @@ static bool gemm_long_k(int in16, int d, long long n, long long m, const void* T
   {
     std::lock_guard<std::mutex> lock(mu);
     for (auto& c : choices)
-      if (c.in16 == in16 && c.d == d && c.n == n && c.m == m && c.ldt == ldt && c.ldg == ldg && c.sb == scratch_bytes)
-        P = c.P;
+      if (c.in16 == in16 && c.d == d && c.nb == nb && c.m == m) P = c.P;
   }
   if (P < 0 && tl_capturing) return false;
   if (P < 0) {  // first use of this shape: time the strategies once (host-synchronous)
@@ -313,9 +318,10 @@ static bool gemm_long_k(int in16, int d, long long n, long long m, const void* T
       (void)hipEventDestroy(e1);
     }
     std::lock_guard<std::mutex> lock(mu);
-    choices.push_back(Choice{in16, d, n, m, ldt, ldg, scratch_bytes, P});
+    if (choices.size() >= MAX_CHOICES) choices.erase(choices.begin());
+    choices.push_back(Choice{in16, d, nb, m, P});
   }
-  return run(P);
+  return run(P) || (P > 1 && run(1));
 }
 
 template <int SCORER>
