@@ -294,6 +294,22 @@ int kge_ce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index
                float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes,
                void* stream);
 
+/* The same pair with DENSE query rows (a_rows [n, dim], p_rows [n, rel_dim], row-major, bf16) scored
+ * against ALL rows of t->ent: the per-shard step of entity-sharded 1vsAll training:
+ * the query rows of a batch come out of the exchange between the shards, t->ent is this rank's shard,
+ * `label[i]` is the LOCAL row id of row i's true entity or any value outside [0, t->num_ent) (also a
+ * NULL vector) if another shard owns it -- loss_rows[i] is then NaN and lse[i] the shard's log-sum-exp;
+ * the caller merges the shards' lse and the owner's score and passes the GLOBAL lse to the backward,
+ * which returns this shard's part of the query-row gradients (g_a, g_p: summed over the shards by the
+ * caller) and the gradient of its own rows (g_tgt).  Workspace as for kge_ce_fwd. */
+int kge_ce_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows,
+                   int64_t p_ld, kge_index label, int64_t n, float* loss_rows, float* lse,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+int kge_ce_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows,
+                   int64_t p_ld, kge_index label, int64_t n, const float* lse, const float* g_rows,
+                   float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
 /* Both directions of a 1vsAll batch at once (train_1vsAll.py:64-81 in one pass): rows [0, n) of
  * loss_rows / lse / g_rows are the (s, p, ?) queries with labels o, rows [n, 2n) the (?, p, o)
  * queries with labels s.  One scoring launch for both sides; the gradient products run once

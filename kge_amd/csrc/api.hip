@@ -532,6 +532,48 @@ int kge_ce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index
                     (hipStream_t)stream);
 }
 
+// ---- the same with DENSE query rows (entity-sharded training: the query rows of a batch come out of
+// an exchange between the shards, the targets are this rank's rows, the label is a local row id or
+// none) -------------------------------------------------------------------------------------------
+namespace {
+int ce_emb_check(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
+                 const kge_index& label, int64_t n, Operand& A, Operand& R, Operand& TG) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!a_rows || !p_rows)) || a_ld < t->dim || p_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(label, true, n))) return rc;
+  const Index ident{nullptr, 1, KGE_I64};
+  A = Operand{a_rows, a_ld, ident};
+  R = Operand{p_rows, p_ld, ident};
+  TG = Operand{t->ent, t->ent_ld, ident};
+  if (!ce_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) return KGE_ERR_UNSUPPORTED;
+  return KGE_OK;
+}
+}  // namespace
+
+int kge_ce_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
+                   kge_index label, int64_t n, float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes,
+                   void* stream) {
+  Operand A, R, TG;
+  const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, label, n, A, R, TG);
+  if (rc) return rc;
+  if (n > 0 && (!loss_rows || !lse)) return KGE_ERR_INVALID_ARG;
+  return run_ce_fwd(t->scorer, A, R, TG, dir, (int)t->dim, n, t->num_ent, make_index(label), loss_rows, lse, workspace,
+                    workspace_bytes, (hipStream_t)stream);
+}
+
+int kge_ce_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
+                   kge_index label, int64_t n, const float* lse, const float* g_rows, float g_scalar, float* g_a,
+                   float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream) {
+  Operand A, R, TG;
+  const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, label, n, A, R, TG);
+  if (rc) return rc;
+  if (n > 0 && (!lse || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
+  return run_ce_bwd(t->scorer, A, R, TG, dir, (int)t->dim, n, t->num_ent, make_index(label), lse, g_rows, g_scalar, g_a,
+                    g_p, g_tgt, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int64_t kge_ce_sp_po_workspace_bytes(const kge_tables* t, int64_t n) {
   if (kge_ce_workspace_bytes(t, n) <= 0) return 0;
   return ce2_workspace_bytes((int)t->dim, n, t->num_ent);

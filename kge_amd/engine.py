@@ -637,6 +637,45 @@ def ce_bwd(t: Tables, direction: str, a, p, label, lse, g_rows=None, g_scalar: f
     return g_a, g_p, g_t
 
 
+def ce_emb_fwd(t: Tables, direction: str, a_rows, p_rows, label):
+    """ce_fwd with dense bf16 query rows against ALL rows of t.ent (the per-shard step of entity-sharded
+    1vsAll training): (loss_rows [n] -- NaN where `label` (local row ids) is outside [0, num_ent) --, lse [n])."""
+    keep = []
+    n = a_rows.shape[0]
+    li = _index(label, t.device, keep)
+    loss_rows, lse = _empty((n,), t.device), _empty((n,), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_emb_fwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, a_rows.data_ptr(), a_rows.stride(0),
+            p_rows.data_ptr(), p_rows.stride(0), li, n, loss_rows.data_ptr(), lse.data_ptr(), ws, wsb, st),
+            "kge_ce_emb_fwd")
+    return loss_rows, lse
+
+
+def ce_emb_bwd(t: Tables, direction: str, a_rows, p_rows, label, lse, g_rows=None, g_scalar: float = 1.0):
+    """Backward of ce_emb_fwd given the (global) lse: (g_a [n, d], g_p [n, d_r] -- this shard's part of the
+    query-row gradients --, g_targets [num_ent, d])."""
+    keep = []
+    n = a_rows.shape[0]
+    li = _index(label, t.device, keep)
+    lse = _f32c(lse, t.device)
+    gr = None if g_rows is None else _f32c(g_rows, t.device)
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((t.num_ent, d), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_emb_bwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, a_rows.data_ptr(), a_rows.stride(0),
+            p_rows.data_ptr(), p_rows.stride(0), li, n, lse.data_ptr(), None if gr is None else gr.data_ptr(),
+            float(g_scalar), g_a.data_ptr(), g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_ce_emb_bwd")
+    return g_a, g_p, g_t
+
+
 def _ce2_workspace(tc, n, device, st):
     need = _lib.lib().kge_ce_sp_po_workspace_bytes(ctypes.byref(tc), n)
     if need <= 0:

@@ -20,11 +20,68 @@ nonzero: every shape is fixed by n, so a step can be captured in a hipGraph):
      elsewhere, all-reduce(sum) of n floats (x + 0 is exact);
   3. rank/tie counters: one int64 all-reduce(sum) for all rankings of both directions.
 Scoring itself needs no collective: each rank writes its own [n, E_g] slab.
+
+Training (1vsAll with the kl loss = cross entropy over ALL entities, train_1vsAll.py:64-81), SURVEY 8e
+(3)-(4): `ce_loss` runs the fused score + loss kernels per shard on the exchanged query rows
+(kge_ce_emb_fwd: the shard's log-sum-exp and, on the owner, the label's score), merges the shards'
+log-sum-exps (all-gather of n floats, logsumexp) and the owner's score (all-reduce of n floats), and in
+the backward hands the GLOBAL log-sum-exp to kge_ce_emb_bwd: softmax - onehot over the shard's columns,
+both gradient products per shard; the query-row gradients are summed over the shards (ONE all-reduce of
+[n, d + d_r] floats) and scatter-added by the owners; the gradient of a shard's own rows never leaves
+it and the relation gradients come out identical on every rank (no E x d all-reduce, no relation
+all-reduce).  Optimizer state follows the rows: every rank steps its own shard.
 """
 from typing import Optional
 
 import torch
 import torch.distributed as dist
+
+
+class _ShardedCE(torch.autograd.Function):
+    """Per-row cross entropy of the batch's sp_ (or _po) scores over the entities of ALL shards."""
+
+    @staticmethod
+    def forward(ctx, sh, direction, ent_master, rel_master, ids, p, labels):
+        rows, rel_rows = sh.exchange_rows([ids], p)
+        rows, rel_rows = rows.clone(), rel_rows.clone()  # the exchange buffers are reused by the next call
+        lab = labels.reshape(-1).long()
+        own = (lab >= sh.lo) & (lab < sh.hi)
+        lab_local = torch.where(own, lab - sh.lo, torch.full_like(lab, -1))  # -1: another shard owns it
+        t16 = sh._tables(sh.ent_local, "local")
+        loss_loc, lse_loc = sh.backend.ce_emb_fwd(t16, direction, rows, rel_rows, lab_local)
+        true = torch.where(own, lse_loc - loss_loc, torch.zeros_like(lse_loc))  # the owner's label score
+        if sh.world > 1:
+            allse = torch.empty(sh.world * lse_loc.numel(), dtype=lse_loc.dtype, device=lse_loc.device)
+            dist.all_gather_into_tensor(allse, lse_loc.contiguous(), group=sh.group)
+            lse = torch.logsumexp(allse.view(sh.world, -1), dim=0)
+            dist.all_reduce(true, op=dist.ReduceOp.SUM, group=sh.group)
+        else:
+            lse = lse_loc
+        ctx.sh, ctx.direction = sh, direction
+        ctx.meta = (ids, p, lab_local, ent_master.shape, rel_master.shape)
+        ctx.save_for_backward(rows, rel_rows, lse)
+        return lse - true
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        sh = ctx.sh
+        ids, p, lab_local, ent_shape, rel_shape = ctx.meta
+        rows, rel_rows, lse = ctx.saved_tensors
+        t16 = sh._tables(sh.ent_local, "local")
+        g_a, g_p, g_t = sh.backend.ce_emb_bwd(t16, ctx.direction, rows, rel_rows, lab_local, lse,
+                                              g_rows=g_rows.contiguous())
+        d = g_a.shape[1]
+        both = torch.cat([g_a, g_p], dim=1)  # this shard's part of the query-row gradients
+        sh._allreduce(both)
+        g_a, g_p = both[:, :d], both[:, d:]
+        gid = ids.reshape(-1).long()
+        own = ((gid >= sh.lo) & (gid < sh.hi)).to(g_a.dtype).unsqueeze(1)
+        local = (gid - sh.lo).clamp_(0, max(sh.hi - sh.lo - 1, 0))
+        ge = g_t  # [E_g, d], fresh: the gradient of this shard's rows as targets ...
+        ge.index_add_(0, local, g_a * own)  # ... plus the query rows it owns (others add zeros)
+        gr = torch.zeros(rel_shape, dtype=torch.float32, device=g_p.device)
+        gr.index_add_(0, p.reshape(-1).long(), g_p.contiguous())  # the same on every rank
+        return None, None, ge.to(torch.float32).view(ent_shape), gr, None, None, None
 
 
 class ShardedEntityTable:
@@ -134,6 +191,27 @@ class ShardedEntityTable:
         if sp.data_ptr() + sp.shape[1] * 4 == po.data_ptr() and sp.stride(0) == 2 * sp.shape[1]:
             return torch.as_strided(sp, (sp.shape[0], 2 * sp.shape[1]), (sp.stride(0), 1))
         return torch.cat([sp, po], dim=1)
+
+    # ---- training: 1vsAll cross entropy over the entities of all shards -----------------------------
+    def ce_loss(self, direction: str, ids: torch.Tensor, p: torch.Tensor, labels: torch.Tensor,
+                ent_master: Optional[torch.Tensor] = None, rel_master: Optional[torch.Tensor] = None):
+        """[n] cross entropy of score_sp(ids, p) ("sp": ids = subjects, labels = true objects) or
+        score_po(p, ids) ("po": ids = objects, labels = true subjects) over ALL entities; sum / batch
+        size = the reference's 1vsAll loss (train_1vsAll.py:64-81, loss.py:192-207).  Differentiable
+        w.r.t. `ent_master` (this rank's shard of the entity parameters, [E_g, d]) and `rel_master` (the
+        replicated relation parameters): float32 masters whose bf16 scoring copies are this object's
+        tables (refresh them with `refresh_tables` after an optimizer step), or omitted when the tables
+        themselves are the parameters."""
+        ent_master = self.ent_local if ent_master is None else ent_master
+        rel_master = self.rel if rel_master is None else rel_master
+        return _ShardedCE.apply(self, direction, ent_master, rel_master, ids, p, labels)
+
+    @torch.no_grad()
+    def refresh_tables(self, ent_master: torch.Tensor, rel_master: torch.Tensor):
+        """Re-cast the float32 masters into this object's scoring tables IN PLACE (same storage: cached
+        kernel descriptors and exchange buffers stay valid)."""
+        self.ent_local.copy_(ent_master)
+        self.rel.copy_(rel_master)
 
     def true_scores(self, slab: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """Score of each row's true entity, taken from the owner's slab (exchange step 2)."""

@@ -357,3 +357,55 @@ def test_spo_backward_accumulated_with_repeated_indices(name):
     (tp.score_emb(name, ent[s], rel[p], ent[o], "spo", 1.0).view(-1) * w).sum().backward()
     for got, want in ((ge, ent.grad), (gr, rel.grad)):
         torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-5 * float(want.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("name", ["complex", "distmult"])
+def test_sharded_ce_loss_on_the_gpu_kernels(name):
+    """ShardedEntityTable.ce_loss on the real engine (one rank: the collectives degenerate, the dense-row
+    entry points kge_ce_emb_fwd / kge_ce_emb_bwd and the scatter of the owned query rows do not): per-row
+    losses and both table gradients against the index-level fused loss (kge_ce_fwd / kge_ce_bwd) on the
+    same bf16 tables, and a few optimizer steps with float32 masters + refreshed bf16 scoring tables."""
+    from kge_amd import engine as eng
+    from kge_amd import model as km
+    from kge_amd.optim import Adagrad
+    from kge_amd.sharded import ShardedEntityTable
+    E, R, d, n = 1500 + 7, 9, 256, 200
+    g = torch.Generator().manual_seed(6)
+    ent32 = (torch.randn(E, d, generator=g) * 0.3).to(DEV)
+    rel32 = (torch.randn(R, d, generator=g) * 0.3).to(DEV)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    w = (torch.rand(2 * n, generator=g) + 0.5).to(DEV)
+    ent_m, rel_m = ent32.clone().requires_grad_(True), rel32.clone().requires_grad_(True)
+    sh = ShardedEntityTable(name, ent32.bfloat16(), rel32.bfloat16(), E)
+    loss = torch.cat([sh.ce_loss("sp", s, p, o, ent_m, rel_m), sh.ce_loss("po", o, p, s, ent_m, rel_m)])
+    (loss * w).sum().backward()
+    # the unsharded fused loss on the same bf16 tables
+    m = km.create(name, E, R, d, device=DEV, dtype=torch.bfloat16).train()
+    with torch.no_grad():
+        m.get_s_embedder().weight.copy_(ent32.bfloat16())
+        m.get_p_embedder().weight.copy_(rel32.bfloat16())
+    T = eng.Tables(name, m.get_s_embedder().weight.detach(), m.get_p_embedder().weight.detach())
+    l_sp, lse_sp = eng.ce_fwd(T, "sp", s, p, o)
+    l_po, lse_po = eng.ce_fwd(T, "po", o, p, s)
+    torch.testing.assert_close(loss, torch.cat([l_sp, l_po]), rtol=1e-5, atol=1e-5)
+    ge, gr = torch.zeros(E, d, device=DEV), torch.zeros(R, d, device=DEV)
+    for direction, a, lab, lse, ww in (("sp", s, o, lse_sp, w[:n]), ("po", o, s, lse_po, w[n:])):
+        g_a, g_p, g_t = eng.ce_bwd(T, direction, a, p, lab, lse, g_rows=ww)
+        ge += g_t
+        ge.index_add_(0, a, g_a)
+        gr.index_add_(0, p, g_p)
+    for got, want in ((ent_m.grad, ge), (rel_m.grad, gr)):
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+    # three training steps: float32 masters, bf16 scoring tables refreshed after every step; the loss falls
+    opt = Adagrad([ent_m, rel_m], lr=0.1)
+    first = last = None
+    for step in range(3):
+        opt.zero_grad()
+        rows = torch.cat([sh.ce_loss("sp", s, p, o, ent_m, rel_m), sh.ce_loss("po", o, p, s, ent_m, rel_m)])
+        val = rows.sum() / n
+        val.backward()
+        opt.step()
+        sh.refresh_tables(ent_m, rel_m)
+        first = float(val.detach()) if first is None else first
+        last = float(val.detach())
+    assert last < first

@@ -35,6 +35,37 @@ class OracleBackend:
         return ent_out, rel_out
 
     @staticmethod
+    def _scores(t, direction, a_rows, p_rows, targets):
+        import torch_port as tp
+        if direction == "sp":
+            return tp.score_emb(t.scorer, a_rows, p_rows, targets, "sp_", t.l_norm)
+        return tp.score_emb(t.scorer, targets, p_rows, a_rows, "_po", t.l_norm)
+
+    @staticmethod
+    def ce_emb_fwd(t, direction, a_rows, p_rows, label):
+        """engine.ce_emb_fwd: (loss_rows -- NaN without a local label --, lse) over the shard's rows."""
+        sc = OracleBackend._scores(t, direction, a_rows, p_rows, t.ent)
+        lse = torch.logsumexp(sc, dim=1)
+        ok = (label >= 0) & (label < t.ent.shape[0])
+        true = sc.gather(1, label.clamp(0, t.ent.shape[0] - 1).view(-1, 1)).view(-1)
+        return torch.where(ok, lse - true, torch.full_like(lse, float("nan"))), lse
+
+    @staticmethod
+    def ce_emb_bwd(t, direction, a_rows, p_rows, label, lse, g_rows=None, g_scalar=1.0):
+        """engine.ce_emb_bwd: gradients of sum_i g_i * (lse_i - score(i, label_i)) restricted to the shard's
+        columns, `lse` being the GLOBAL log-sum-exp."""
+        with torch.enable_grad():  # (called from inside an autograd backward)
+            a, pr, T = (x.detach().clone().requires_grad_(True) for x in (a_rows, p_rows, t.ent))
+            sc = OracleBackend._scores(t, direction, a, pr, T)
+            g = g_rows if g_rows is not None else torch.full_like(lse, g_scalar)
+            G = torch.exp(sc.detach() - lse.view(-1, 1)) * g.view(-1, 1)
+            ok = (label >= 0) & (label < T.shape[0])
+            rows = torch.nonzero(ok).view(-1)
+            G[rows, label[rows]] -= g[rows]
+            (sc * G).sum().backward()
+        return a.grad, pr.grad, T.grad
+
+    @staticmethod
     def score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm=1.0):
         return torch.cat([OracleBackend.score_emb(scorer, s_emb, p_emb, targets, "sp_", l_norm),
                           OracleBackend.score_emb(scorer, targets, p_emb, o_emb, "_po", l_norm)], 1)
@@ -171,3 +202,75 @@ def test_two_shards_equal_unsharded(model):
     order = np.argsort(-sp, axis=1, kind="stable")[:, :5]
     assert np.array_equal(np.take_along_axis(sp, order, 1), tv)
     assert np.array_equal(np.sort(ti, 1), np.sort(order, 1)) or np.allclose(np.take_along_axis(sp, ti, 1), tv)
+
+
+def _train_worker(rank, world, port, model, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kge_amd.sharded import ShardedEntityTable
+        E, R, d, n = 47, 5, 16, 21   # odd E: ragged shards
+        g = torch.Generator().manual_seed(3)
+        ent = torch.randn(E, d, generator=g)
+        rel = torch.randn(R, d, generator=g)
+        s, p, o = (torch.randint(hi, (n,), generator=g) for hi in (E, R, E))
+        w = torch.rand(2 * n, generator=g) + 0.5  # per-row weights: a non-trivial upstream gradient
+        lo, hi = ShardedEntityTable.partition(E, world, rank)
+        ent_master = ent[lo:hi].clone().requires_grad_(True)   # this rank's shard of the parameters
+        rel_master = rel.clone().requires_grad_(True)          # replicated
+        sh = ShardedEntityTable(model, ent_master.detach().clone(), rel_master.detach().clone(), E,
+                                backend=OracleBackend)
+        # one 1vsAll step (train_1vsAll.py:64-81): sp_ rows labelled with o, _po rows labelled with s
+        loss_sp = sh.ce_loss("sp", s, p, o, ent_master, rel_master)
+        loss_po = sh.ce_loss("po", o, p, s, ent_master, rel_master)
+        (torch.cat([loss_sp, loss_po]) * w).sum().backward()
+        q.put((rank, lo, hi, loss_sp.detach().numpy(), loss_po.detach().numpy(), ent_master.grad.numpy(),
+               rel_master.grad.numpy(), ent.numpy(), rel.numpy(), s.numpy(), p.numpy(), o.numpy(), w.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["complex", "distmult"])
+def test_sharded_1vsAll_loss_and_gradients_equal_unsharded(model):
+    """Entity-sharded 1vsAll training step on two ranks (ShardedEntityTable.ce_loss: per-shard fused
+    score + loss, log-sum-exps merged across the shards, query-row gradients summed with one
+    all-reduce, target-row gradients local) against the unsharded computation: torch cross entropy of
+    the reference's op sequence over all entities and autograd of it -- per-row losses, the entity
+    gradient (the two shards' rows side by side) and the relation gradient, which every rank must hold
+    identically."""
+    import torch.nn.functional as F
+    import torch_port as tp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, model, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = []
+    import time
+    t0 = time.time()
+    while len(outs) < world and time.time() - t0 < 120:  # a crashed worker must fail the test, not hang it
+        if not q.empty():
+            outs.append(q.get())
+        elif any(pr.exitcode not in (None, 0) for pr in procs):
+            break
+        else:
+            time.sleep(0.05)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert len(outs) == world
+    outs.sort(key=lambda x: x[0])
+    _, _, _, lsp, lpo, _, _, ent, rel, s, p, o, w = outs[0]
+    ent_t, rel_t = torch.from_numpy(ent).requires_grad_(True), torch.from_numpy(rel).requires_grad_(True)
+    s, p, o, w = (torch.from_numpy(x) for x in (s, p, o, w))
+    ref_sp = F.cross_entropy(tp.score_sp(model, ent_t, rel_t, s, p), o, reduction="none")
+    ref_po = F.cross_entropy(tp.score_po(model, ent_t, rel_t, p, o), s, reduction="none")
+    (torch.cat([ref_sp, ref_po]) * w).sum().backward()
+    for out in outs:  # losses are global on every rank
+        np.testing.assert_allclose(out[3], ref_sp.detach().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out[4], ref_po.detach().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out[6], rel_t.grad.numpy(), rtol=1e-4, atol=1e-5)  # relation grads: same everywhere
+    ge = np.concatenate([out[5] for out in outs])
+    assert [out[1] for out in outs] == [0, outs[0][2]] and outs[-1][2] == ent.shape[0]
+    np.testing.assert_allclose(ge, ent_t.grad.numpy(), rtol=1e-4, atol=1e-5)
