@@ -354,6 +354,24 @@ int kge_kl_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n
                const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt,
                void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The pair with a per-row LABEL WEIGHT w_i instead of 1/k_i -- what KvsAll label smoothing
+ * (kge/job/train_KvsAll.py:34-49, 262-270: labels = (1 - eps) * labels + 1/E, then normalised) needs
+ * from the fused kernels:
+ *   loss_rows[i] = lse[i] - w_i * sum_{j in labels_i} score(i, j)              (rows without labels: lse[i])
+ *   d / d score(i, j) of sum_i g_i loss_rows[i] = g_i * (softmax_ij - w_i [j in labels_i])
+ * With Z_i = (1 - eps) k_i + 1, a_i = ((1 - eps) + 1/E) / Z_i, b_i = (1/E) / Z_i the smoothed loss of row i is
+ *   loss_rows[i] (w_i = a_i - b_i)  -  b_i * sum_j score(i, j)  +  k_i a_i log a_i + (E - k_i) b_i log b_i;
+ * the middle term is linear in the entity table (sum_j score(i, j) = score of row i against the table's
+ * column sum): kge_amd.model adds it and the constant on the host side of the ABI. */
+int kge_kl_weighted_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+                        const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
+                        float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+int kge_kl_weighted_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+                        const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
+                        const float* lse, const float* g_rows, float g_scalar, float* g_a, float* g_p,
+                        float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* Binary cross entropy with logits against the rows' multi-hot labels (CSR as for kge_kl_fwd), summed
  * over ALL entities:  loss_rows[i] = sum_j BCEWithLogits(score(i, j) + offset, y_ij), y_ij = 1 on
  * the labels = BCEWithLogitsKgeLoss with bce_type None (kge/util/loss.py:137-159; `offset` =

@@ -98,10 +98,11 @@ int run_adagrad_rows(float* param, long long param_ld, const float* grows, long 
                      unsigned short* copy16, long long c_ld, hipStream_t st);
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, float* loss_rows, float* lse, void* ws,
-               long long ws_bytes, hipStream_t st);
+               long long ws_bytes, hipStream_t st, const float* label_weight = nullptr);
 int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, const float* lse, const float* g_rows,
-               float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
+               float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
+               const float* label_weight = nullptr);
 bool ce_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
 int run_ce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const Index& label, float* loss_rows, float* lse, void* ws, long long ws_bytes,
@@ -611,6 +612,40 @@ int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_in
   return run_ce2_bwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
                      t->num_ent, lse, g_rows, g_scalar, nullptr, nullptr, grad_ent, grad_rel, t->num_rel,
                      t->rel_dim, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int kge_kl_weighted_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+                        const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
+                        float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
+  const kge_index none = {nullptr, 0, 0, 1};
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!lbl_rowptr || !lbl_col || !label_weight || !loss_rows || !lse))) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(a, false, n)) || (rc = check_index(p, false, n))) return rc;
+  if (!ce_supported(t->scorer, t->dtype, (int)t->dim, ent_op(t, a), rel_op(t, p), ent_op(t, none)))
+    return KGE_ERR_UNSUPPORTED;
+  return run_kl_fwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, none), dir, (int)t->dim, n, t->num_ent,
+                    (const long long*)lbl_rowptr, (const long long*)lbl_col, loss_rows, lse, workspace,
+                    workspace_bytes, (hipStream_t)stream, label_weight);
+}
+
+int kge_kl_weighted_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
+                        const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
+                        const float* lse, const float* g_rows, float g_scalar, float* g_a, float* g_p,
+                        float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream) {
+  const kge_index none = {nullptr, 0, 0, 1};
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (dir != KGE_SP_ && dir != KGE_PO_) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!lbl_rowptr || !lbl_col || !label_weight || !lse || !g_a || !g_p || !g_tgt)))
+    return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(a, false, n)) || (rc = check_index(p, false, n))) return rc;
+  if (!ce_supported(t->scorer, t->dtype, (int)t->dim, ent_op(t, a), rel_op(t, p), ent_op(t, none)))
+    return KGE_ERR_UNSUPPORTED;
+  return run_kl_bwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, none), dir, (int)t->dim, n, t->num_ent,
+                    (const long long*)lbl_rowptr, (const long long*)lbl_col, lse, g_rows, g_scalar, g_a, g_p, g_tgt,
+                    workspace, workspace_bytes, (hipStream_t)stream, label_weight);
 }
 
 int kge_kl_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,

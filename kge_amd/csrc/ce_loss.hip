@@ -118,7 +118,8 @@ __global__ __launch_bounds__(256) void kl_label_kernel(Operand A, Operand R, Ope
 __global__ __launch_bounds__(256) void kl_combine_kernel(const float* __restrict__ part, int ncg, long long n,
                                                          const float* __restrict__ label_sum,
                                                          const long long* __restrict__ rowptr,
-                                                         float* __restrict__ loss_rows, float* __restrict__ lse) {
+                                                         float* __restrict__ loss_rows, float* __restrict__ lse,
+                                                         const float* __restrict__ label_weight) {
   const int lane = threadIdx.x & 63;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -135,7 +136,10 @@ __global__ __launch_bounds__(256) void kl_combine_kernel(const float* __restrict
     const float z = M + logf(L);
     const long long k = rowptr[i + 1] - rowptr[i];
     lse[i] = z;
-    loss_rows[i] = k > 0 ? z - label_sum[i] / (float)k - logf((float)k) : 0.0f;
+    // label_weight (label smoothing, kge_kl_weighted_fwd): lse_i - w_i * (sum of the label scores), for
+    // every row; the caller adds the terms that do not depend on the label scores
+    if (label_weight != nullptr) loss_rows[i] = z - label_weight[i] * (k > 0 ? label_sum[i] : 0.0f);
+    else loss_rows[i] = k > 0 ? z - label_sum[i] / (float)k - logf((float)k) : 0.0f;
   }
 }
 
@@ -143,13 +147,15 @@ __global__ __launch_bounds__(256) void kl_combine_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void kl_sub_kernel(unsigned short* __restrict__ g16, long long ld16, long long n,
                                                      const long long* __restrict__ rowptr,
                                                      const long long* __restrict__ col,
-                                                     const float* __restrict__ g_rows, float g_scalar) {
+                                                     const float* __restrict__ g_rows, float g_scalar,
+                                                     const float* __restrict__ label_weight) {
   const int lane = threadIdx.x & 63;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const long long b = rowptr[i], e = rowptr[i + 1];
   if (e <= b) return;
-  const float y = (g_rows != nullptr ? g_rows[i] : g_scalar) / (float)(e - b);
+  const float gi = g_rows != nullptr ? g_rows[i] : g_scalar;
+  const float y = label_weight != nullptr ? gi * label_weight[i] : gi / (float)(e - b);
   for (long long x = b + lane; x < e; x += 64) {
     unsigned short* p = g16 + i * ld16 + col[x];
     const float v = __uint_as_float((unsigned int)*p << 16) - y;
@@ -276,7 +282,7 @@ int run_ce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
 
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, float* loss_rows, float* lse, void* ws,
-               long long ws_bytes, hipStream_t st) {
+               long long ws_bytes, hipStream_t st, const float* label_weight) {
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
@@ -294,19 +300,22 @@ int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
     hipLaunchKernelGGL(kl_label_kernel<KGE_DISTMULT>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
                        ce.true_score);
   hipLaunchKernelGGL(kl_combine_kernel, grid, dim3(256), 0, st, ce.part, ncg, n, ce.true_score, rowptr, loss_rows,
-                     lse);
+                     lse, label_weight);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
 int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, const float* lse, const float* g_rows,
-               float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st) {
+               float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
+               const float* label_weight) {
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
   const long long ld16 = ce_ld16(m);
   CeArgs ce{};
-  ce.rowptr = rowptr;
+  // rows without labels: zero gradient (all-zero label rows normalise to zero) -- but not under label
+  // smoothing (label_weight given), where every row's label distribution has mass on every entity
+  ce.rowptr = label_weight != nullptr ? nullptr : rowptr;
   ce.lse = lse;
   ce.g_rows = g_rows;
   ce.g_scalar = g_scalar;
@@ -316,7 +325,7 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(kl_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.g16, ld16, n, rowptr, col,
-                     g_rows, g_scalar);
+                     g_rows, g_scalar, label_weight);
   if (hipGetLastError() != hipSuccess) return KGE_ERR_LAUNCH;
   return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
 }

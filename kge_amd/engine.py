@@ -750,25 +750,36 @@ def _csr64(rowptr, col, dev):
     return rp, cl
 
 
-def kl_fwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col):
+def kl_fwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, label_weight=None):
     """KvsAll: fused score_sp / score_po + KL divergence from the rows' normalised multi-hot
-    labels (int64 CSR): (loss_rows [n], lse [n]); kge/util/loss.py:208-213 without smoothing."""
+    labels (int64 CSR): (loss_rows [n], lse [n]); kge/util/loss.py:208-213 without smoothing.
+    With `label_weight` [n] (label smoothing; include/kge_amd.h kge_kl_weighted_fwd):
+    loss_rows[i] = lse[i] - label_weight[i] * (sum of row i's label scores)."""
     keep = []
     ai, pi = (_index(x, t.device, keep) for x in (a, p))
     n = _same_len(keep[:2], "kl_fwd")
     rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
     loss_rows, lse = _empty((n,), t.device), _empty((n,), t.device)
+    lw = None if label_weight is None else _f32c(label_weight, t.device)
+    if lw is not None and lw.numel() != n:
+        raise ValueError(f"kl_fwd: label_weight has {lw.numel()} entries for {n} rows")
     with _on_device(t.device):
         tc = t.c()
         st = _stream_handle(t.device)
         ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
-        _lib.check(_lib.lib().kge_kl_fwd(ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, n,
-                                         rp.data_ptr(), cl.data_ptr(), loss_rows.data_ptr(), lse.data_ptr(),
-                                         ws, wsb, st), "kge_kl_fwd")
+        dirc = SP_ if direction == "sp" else PO_
+        if lw is None:
+            _lib.check(_lib.lib().kge_kl_fwd(ctypes.byref(tc), dirc, ai, pi, n, rp.data_ptr(), cl.data_ptr(),
+                                             loss_rows.data_ptr(), lse.data_ptr(), ws, wsb, st), "kge_kl_fwd")
+        else:
+            _lib.check(_lib.lib().kge_kl_weighted_fwd(
+                ctypes.byref(tc), dirc, ai, pi, n, rp.data_ptr(), cl.data_ptr(), lw.data_ptr(),
+                loss_rows.data_ptr(), lse.data_ptr(), ws, wsb, st), "kge_kl_weighted_fwd")
     return loss_rows, lse
 
 
-def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=None, g_scalar: float = 1.0):
+def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=None, g_scalar: float = 1.0,
+           label_weight=None):
     """Backward of kl_fwd: (g_a [n, d], g_p [n, d], g_entities [E, d])."""
     keep = []
     ai, pi = (_index(x, t.device, keep) for x in (a, p))
@@ -778,14 +789,24 @@ def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=Non
     lse = _f32c(lse, t.device)
     gr = None if g_rows is None else _f32c(g_rows, t.device)
     g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((t.num_ent, d), t.device)
+    lw = None if label_weight is None else _f32c(label_weight, t.device)
+    if lw is not None and lw.numel() != n:
+        raise ValueError(f"kl_bwd: label_weight has {lw.numel()} entries for {n} rows")
     with _on_device(t.device):
         tc = t.c()
         st = _stream_handle(t.device)
         ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
-        _lib.check(_lib.lib().kge_kl_bwd(
-            ctypes.byref(tc), SP_ if direction == "sp" else PO_, ai, pi, n, rp.data_ptr(), cl.data_ptr(),
-            lse.data_ptr(), None if gr is None else gr.data_ptr(), float(g_scalar), g_a.data_ptr(),
-            g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_kl_bwd")
+        dirc = SP_ if direction == "sp" else PO_
+        grp = None if gr is None else gr.data_ptr()
+        if lw is None:
+            _lib.check(_lib.lib().kge_kl_bwd(
+                ctypes.byref(tc), dirc, ai, pi, n, rp.data_ptr(), cl.data_ptr(), lse.data_ptr(), grp,
+                float(g_scalar), g_a.data_ptr(), g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_kl_bwd")
+        else:
+            _lib.check(_lib.lib().kge_kl_weighted_bwd(
+                ctypes.byref(tc), dirc, ai, pi, n, rp.data_ptr(), cl.data_ptr(), lw.data_ptr(), lse.data_ptr(),
+                grp, float(g_scalar), g_a.data_ptr(), g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st),
+                "kge_kl_weighted_bwd")
     return g_a, g_p, g_t
 
 

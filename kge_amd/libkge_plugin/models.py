@@ -9,7 +9,7 @@ from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
 from ..model import (BF16Shadow, _FusedBCE, _FusedCE, _FusedCE2, _FusedKL, _ScoreEmb, _ScoreNeg, _ScorePairs,
-                     _ScoreSPO)
+                     _ScoreSPO, bce_fused, kl_fused)
 
 
 class _HipScorer(RelationalScorer):
@@ -142,37 +142,46 @@ class _FusedScoring:
         ent, rel = self._w()
         return _FusedCE2.apply(ent, rel, s, p, o, t)
 
-    def kl_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
-        """[n] KL divergence of softmax(score_sp(s, p)) from the rows' normalised multi-hot labels
-        (int64 CSR); None if the fused path does not apply (HipTrainingJobKvsAll; kge_kl_fwd)."""
+    def kl_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor,
+                   label_smoothing: float = 0.0) -> Tensor:
+        """[n] KL divergence of softmax(score_sp(s, p)) from the rows' normalised (and, with
+        `label_smoothing`, smoothed: train_KvsAll.py:260-266) multi-hot labels (int64 CSR); None if the
+        fused path does not apply (HipTrainingJobKvsAll; kge_kl_fwd / kge_kl_weighted_fwd)."""
         t = self._ce_tables()
         if t is None:
             return None
         ent, rel = self._w()
-        return _FusedKL.apply("sp", ent, rel, s, p, lbl_rowptr, lbl_col, t)
+        return kl_fused(self._scorer.name, self._scorer._norm, "sp", ent, rel, s, p, lbl_rowptr, lbl_col,
+                        float(label_smoothing), t)
 
-    def kl_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
+    def kl_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor,
+                   label_smoothing: float = 0.0) -> Tensor:
         t = self._ce_tables()
         if t is None:
             return None
         ent, rel = self._w()
-        return _FusedKL.apply("po", ent, rel, o, p, lbl_rowptr, lbl_col, t)
+        return kl_fused(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, lbl_rowptr, lbl_col,
+                        float(label_smoothing), t)
 
-    def bce_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0):
-        """[n] sum over all entities of BCEWithLogits(score_sp(s, p) + offset, multi-hot labels);
+    def bce_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0,
+                    label_smoothing: float = 0.0):
+        """[n] sum over all entities of BCEWithLogits(score_sp(s, p) + offset, (smoothed) multi-hot labels);
         None if the fused path does not apply (kge_bce_fwd)."""
         t = self._ce_tables()
         if t is None:
             return None
         ent, rel = self._w()
-        return _FusedBCE.apply("sp", ent, rel, s, p, lbl_rowptr, lbl_col, float(offset), t)
+        return bce_fused(self._scorer.name, self._scorer._norm, "sp", ent, rel, s, p, lbl_rowptr, lbl_col,
+                         float(offset), float(label_smoothing), t)
 
-    def bce_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0):
+    def bce_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0,
+                    label_smoothing: float = 0.0):
         t = self._ce_tables()
         if t is None:
             return None
         ent, rel = self._w()
-        return _FusedBCE.apply("po", ent, rel, o, p, lbl_rowptr, lbl_col, float(offset), t)
+        return bce_fused(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, lbl_rowptr, lbl_col,
+                         float(offset), float(label_smoothing), t)
 
     def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
         if not self._fused():

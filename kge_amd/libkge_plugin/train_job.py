@@ -119,10 +119,11 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
 
 class HipTrainingJobKvsAll(TrainingJobKvsAll):
     """Overrides only `_process_subbatch` (train_KvsAll.py:216-294).  With `train.loss: kl` or `bce`
-    (plain: bce_type None), no label smoothing and a model that offers `kl_loss_sp` / `kl_loss_po`
-    (`bce_loss_sp` / `bce_loss_po`), the sp_ and _po queries of a subbatch get their loss from one
-    fused kernel each (kge_kl_fwd / kge_bce_fwd: scores never written; labels as a CSR cut out of the
-    batch's `label_coords`); s_o queries and every other configuration run the reference's code."""
+    (plain: bce_type None), with or without `KvsAll.label_smoothing`, and a model
+    that offers `kl_loss_sp` / `kl_loss_po` (`bce_loss_sp` / `bce_loss_po`), the sp_ and _po queries of a
+    subbatch get their loss from one fused kernel each (kge_kl_fwd / kge_kl_weighted_fwd /
+    kge_bce_fwd: scores never written; labels as a CSR cut out of the batch's `label_coords`); s_o
+    queries and every other configuration run the reference's code."""
 
     def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
         super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
@@ -131,7 +132,7 @@ class HipTrainingJobKvsAll(TrainingJobKvsAll):
                 f(self)
 
     def _fused_ok(self) -> bool:
-        if self.label_smoothing != 0.0 or "s_o" in self.query_types:
+        if "s_o" in self.query_types:
             return False
         if isinstance(self.loss, KLDivWithSoftmaxKgeLoss):
             return hasattr(self.model, "kl_loss_sp")
@@ -165,13 +166,13 @@ class HipTrainingJobKvsAll(TrainingJobKvsAll):
                 + torch.arange(total, device=cnt.device)
             col = coords[idx, 1].long()
             q0, q1 = queries[examples, 0], queries[examples, 1]
-            offset = _plain_bce(self.loss)
+            offset, ls = _plain_bce(self.loss), float(self.label_smoothing)
             if offset is None:
-                loss_rows = (self.model.kl_loss_sp(q0, q1, rowptr, col) if query_type == "sp_"
-                             else self.model.kl_loss_po(q0, q1, rowptr, col))
+                loss_rows = (self.model.kl_loss_sp(q0, q1, rowptr, col, ls) if query_type == "sp_"
+                             else self.model.kl_loss_po(q0, q1, rowptr, col, ls))
             else:
-                loss_rows = (self.model.bce_loss_sp(q0, q1, rowptr, col, offset) if query_type == "sp_"
-                             else self.model.bce_loss_po(q0, q1, rowptr, col, offset))
+                loss_rows = (self.model.bce_loss_sp(q0, q1, rowptr, col, offset, ls) if query_type == "sp_"
+                             else self.model.bce_loss_po(q0, q1, rowptr, col, offset, ls))
             if loss_rows is None:
                 _declined_late("kl_loss_* / bce_loss_*")
             loss_value = loss_rows.sum() / batch_size  # averaged over the batch, not the subbatch

@@ -234,59 +234,73 @@ class KgeModel(torch.nn.Module):
             return _FusedCE.apply("po", self._entity_embedder.weight, self._relation_embedder.weight, o, p, s, t)
         return torch.nn.functional.cross_entropy(self.score_po(p, o), s.long(), reduction="none")
 
-    # -- KvsAll loss: train_KvsAll.py:274-294 with train.loss=kl, no label smoothing
+    # -- KvsAll loss: train_KvsAll.py:274-294 with train.loss=kl
     @staticmethod
-    def _kl_composed(scores: Tensor, rowptr: Tensor, col: Tensor) -> Tensor:
-        """loss.py:208-213 row by row: KLDivLoss(log_softmax(scores), normalize(labels, p=1))."""
+    def _kl_composed(scores: Tensor, rowptr: Tensor, col: Tensor, label_smoothing: float = 0.0) -> Tensor:
+        """loss.py:208-213 row by row: KLDivLoss(log_softmax(scores), normalize(labels, p=1)); labels
+        smoothed as train_KvsAll.py:260-266 does."""
         n = scores.shape[0]
         cnt = (rowptr[1:] - rowptr[:-1]).to(scores.device)
         rows = torch.repeat_interleave(torch.arange(n, device=scores.device), cnt)
         labels = torch.zeros_like(scores)
         labels[rows, col.to(scores.device).long()] = 1.0
+        if label_smoothing > 0.0:
+            labels = (1.0 - label_smoothing) * labels + 1.0 / labels.size(1)
         y = torch.nn.functional.normalize(labels, p=1, dim=1)
         return torch.nn.functional.kl_div(torch.log_softmax(scores, dim=1), y, reduction="none").sum(dim=1)
 
-    def kl_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
+    def _kl_fused(self, direction: str, a: Tensor, p: Tensor, rowptr: Tensor, col: Tensor, eps: float, t) -> Tensor:
+        return kl_fused(self._scorer.name, self._scorer._norm, direction, self._entity_embedder.weight,
+                        self._relation_embedder.weight, a, p, rowptr, col, eps, t)
+
+    def kl_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor,
+                   label_smoothing: float = 0.0) -> Tensor:
         """Per-row KL divergence of softmax(score_sp(s, p)) from the normalised multi-hot labels
         given as an int64 CSR over the rows (the known objects of each (s, p) query)."""
         t = self._ce_tables()
         if t is not None:
-            return _FusedKL.apply("sp", self._entity_embedder.weight, self._relation_embedder.weight, s, p,
-                                  lbl_rowptr, lbl_col, t)
-        return self._kl_composed(self.score_sp(s, p), lbl_rowptr, lbl_col)
+            return self._kl_fused("sp", s, p, lbl_rowptr, lbl_col, float(label_smoothing), t)
+        return self._kl_composed(self.score_sp(s, p), lbl_rowptr, lbl_col, label_smoothing)
 
-    def kl_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor) -> Tensor:
+    def kl_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor,
+                   label_smoothing: float = 0.0) -> Tensor:
         t = self._ce_tables()
         if t is not None:
-            return _FusedKL.apply("po", self._entity_embedder.weight, self._relation_embedder.weight, o, p,
-                                  lbl_rowptr, lbl_col, t)
-        return self._kl_composed(self.score_po(p, o), lbl_rowptr, lbl_col)
+            return self._kl_fused("po", o, p, lbl_rowptr, lbl_col, float(label_smoothing), t)
+        return self._kl_composed(self.score_po(p, o), lbl_rowptr, lbl_col, label_smoothing)
 
     # -- bce loss (train.loss: bce, loss.py:137-159 with bce_type None) on multi-hot labels
     @staticmethod
-    def _bce_composed(scores: Tensor, rowptr: Tensor, col: Tensor, offset: float = 0.0) -> Tensor:
+    def _bce_composed(scores: Tensor, rowptr: Tensor, col: Tensor, offset: float = 0.0,
+                      label_smoothing: float = 0.0) -> Tensor:
         n = scores.shape[0]
         cnt = (rowptr[1:] - rowptr[:-1]).to(scores.device)
         rows = torch.repeat_interleave(torch.arange(n, device=scores.device), cnt)
         labels = torch.zeros_like(scores)
         labels[rows, col.to(scores.device).long()] = 1.0
+        if label_smoothing > 0.0:
+            labels = (1.0 - label_smoothing) * labels + 1.0 / labels.size(1)
         return torch.nn.functional.binary_cross_entropy_with_logits(scores + offset, labels,
                                                                      reduction="none").sum(dim=1)
 
-    def bce_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0) -> Tensor:
+    def bce_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0,
+                    label_smoothing: float = 0.0) -> Tensor:
         """Per-row sum over all entities of BCEWithLogits(score_sp(s, p) + offset, multi-hot labels)."""
         t = self._ce_tables()
         if t is not None:
-            return _FusedBCE.apply("sp", self._entity_embedder.weight, self._relation_embedder.weight, s, p,
-                                   lbl_rowptr, lbl_col, float(offset), t)
-        return self._bce_composed(self.score_sp(s, p), lbl_rowptr, lbl_col, offset)
+            return bce_fused(self._scorer.name, self._scorer._norm, "sp", self._entity_embedder.weight,
+                             self._relation_embedder.weight, s, p, lbl_rowptr, lbl_col, float(offset),
+                             float(label_smoothing), t)
+        return self._bce_composed(self.score_sp(s, p), lbl_rowptr, lbl_col, offset, label_smoothing)
 
-    def bce_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0) -> Tensor:
+    def bce_loss_po(self, p: Tensor, o: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor, offset: float = 0.0,
+                    label_smoothing: float = 0.0) -> Tensor:
         t = self._ce_tables()
         if t is not None:
-            return _FusedBCE.apply("po", self._entity_embedder.weight, self._relation_embedder.weight, o, p,
-                                   lbl_rowptr, lbl_col, float(offset), t)
-        return self._bce_composed(self.score_po(p, o), lbl_rowptr, lbl_col, offset)
+            return bce_fused(self._scorer.name, self._scorer._norm, "po", self._entity_embedder.weight,
+                             self._relation_embedder.weight, o, p, lbl_rowptr, lbl_col, float(offset),
+                             float(label_smoothing), t)
+        return self._bce_composed(self.score_po(p, o), lbl_rowptr, lbl_col, offset, label_smoothing)
 
     def score_so(self, s: Tensor, o: Tensor, p: Tensor = None) -> Tensor:
         se, oe = self._entity_embedder.embed(s), self._entity_embedder.embed(o)
@@ -508,22 +522,46 @@ class _FusedKL(torch.autograd.Function):
     int64 CSR (rowptr [n + 1], col [nnz]) of the rows' known answers."""
 
     @staticmethod
-    def forward(ctx, direction, ent, rel, a, p, rowptr, col, tables16):
-        loss_rows, lse = engine.kl_fwd(tables16, direction, a, p, rowptr, col)
-        ctx.t16, ctx.direction, ctx.idx = tables16, direction, (a, p, rowptr, col)
+    def forward(ctx, direction, ent, rel, a, p, rowptr, col, label_weight, tables16):
+        loss_rows, lse = engine.kl_fwd(tables16, direction, a, p, rowptr, col, label_weight)
+        ctx.t16, ctx.direction, ctx.idx = tables16, direction, (a, p, rowptr, col, label_weight)
         ctx.rel_shape = rel.shape
         ctx.save_for_backward(lse)
         return loss_rows
 
     @staticmethod
     def backward(ctx, g_rows):
-        a, p, rowptr, col = ctx.idx
+        a, p, rowptr, col, label_weight = ctx.idx
         (lse,) = ctx.saved_tensors
-        g_a, g_p, ge = engine.kl_bwd(ctx.t16, ctx.direction, a, p, rowptr, col, lse, g_rows=g_rows.contiguous())
+        g_a, g_p, ge = engine.kl_bwd(ctx.t16, ctx.direction, a, p, rowptr, col, lse, g_rows=g_rows.contiguous(),
+                                     label_weight=label_weight)
         gr = torch.zeros(ctx.rel_shape, dtype=torch.float32, device=ge.device)
         _scatter_rows(gr, p, g_p)
         _scatter_rows(ge, a, g_a)
-        return None, ge, gr, None, None, None, None, None
+        return None, ge, gr, None, None, None, None, None, None
+
+
+def kl_fused(name: str, l_norm, direction: str, ent: Tensor, rel: Tensor, a: Tensor, p: Tensor, rowptr: Tensor,
+             col: Tensor, eps: float, t) -> Tensor:
+    """The fused KvsAll KL loss with label smoothing `eps` (train_KvsAll.py:260-266: labels =
+    (1 - eps) * multi_hot + 1/E before loss.py:208-213 normalises them).  The smoothed label row is a_i on
+    row i's k_i labels and b_i elsewhere (Z_i = (1 - eps) k_i + 1, a_i = (1 - eps + 1/E) / Z_i,
+    b_i = (1/E) / Z_i), so
+        KL_i = lse_i - (a_i - b_i) * sum_{labels} score_ij       <- kge_kl_weighted_fwd, fused
+               - b_i * sum_j score_ij                            <- linear in the entity table (ComplEx and
+                                                                    DistMult, the fused path's scorers): ONE
+                                                                    [n, 1] score against the table's column sum
+               + k_i a_i log a_i + (E - k_i) b_i log b_i         <- constant."""
+    if eps == 0.0:
+        return _FusedKL.apply(direction, ent, rel, a, p, rowptr, col, None, t)
+    E = ent.shape[0]
+    k = (rowptr[1:] - rowptr[:-1]).to(device=ent.device, dtype=torch.float32)
+    Z = (1.0 - eps) * k + 1.0
+    a_w, b_w = (1.0 - eps + 1.0 / E) / Z, (1.0 / E) / Z
+    fused = _FusedKL.apply(direction, ent, rel, a, p, rowptr, col, (a_w - b_w).contiguous(), t)
+    s_all = _score_against_column_sum(name, l_norm, direction, ent, rel, a, p)
+    const = k * a_w * torch.log(a_w) + (E - k) * b_w * torch.log(b_w)
+    return fused - b_w * s_all + const
 
 
 class _FusedBCE(torch.autograd.Function):
@@ -546,6 +584,41 @@ class _FusedBCE(torch.autograd.Function):
         _scatter_rows(gr, p, g_p)
         _scatter_rows(ge, a, g_a)
         return None, ge, gr, None, None, None, None, None, None
+
+
+def _score_against_column_sum(name: str, l_norm, direction: str, ent: Tensor, rel: Tensor, a: Tensor,
+                              p: Tensor) -> Tensor:
+    """[n]: sum_j score(i, j) over ALL entities j.  ComplEx and DistMult are linear in the target row, so
+    this is one score of each query against the entity table's column sum."""
+    colsum = ent.float().sum(dim=0, keepdim=True)
+    rows, prow = ent[a.long()].float(), rel[p.long()].float()
+    if direction == "sp":
+        return _ScoreEmb.apply(name, "sp_", l_norm, rows, prow, colsum).view(-1)
+    return _ScoreEmb.apply(name, "_po", l_norm, colsum, prow, rows).view(-1)
+
+
+def bce_fused(name: str, l_norm, direction: str, ent: Tensor, rel: Tensor, a: Tensor, p: Tensor, rowptr: Tensor,
+              col: Tensor, offset: float, eps: float, t) -> Tensor:
+    """The fused KvsAll BCE loss with label smoothing `eps` (train_KvsAll.py:260-266; loss.py:137-159 with
+    bce_type None).  With x_ij = score_ij + offset and y_ij = (1 - eps) [j in labels_i] + 1/E,
+        sum_j softplus(x_ij) - y_ij x_ij
+          = [sum_j softplus(x_ij) - sum_{labels} x_ij]      <- kge_bce_fwd, fused, scores never written
+            + eps * sum_{labels} x_ij                       <- nnz(labels) spo scores (kge_score_spo)
+            - (1/E) * sum_j x_ij                            <- one [n, 1] score against the column sum."""
+    fused = _FusedBCE.apply(direction, ent, rel, a, p, rowptr, col, offset, t)
+    if eps == 0.0:
+        return fused
+    n, E = a.shape[0], ent.shape[0]
+    cnt = (rowptr[1:] - rowptr[:-1]).to(ent.device)
+    col = col.to(ent.device).long()
+    rows = torch.repeat_interleave(torch.arange(n, device=ent.device), cnt, output_size=col.numel())
+    ar, pr = a.long()[rows], p.long()[rows]
+    ent32, rel32 = ent.float(), rel.float()
+    lab = (_ScoreSPO.apply(name, l_norm, ent32, rel32, ar, pr, col) if direction == "sp"
+           else _ScoreSPO.apply(name, l_norm, ent32, rel32, col, pr, ar))
+    s_lab = torch.zeros(n, dtype=torch.float32, device=ent.device).index_add(0, rows, lab.view(-1) + offset)
+    s_all = _score_against_column_sum(name, l_norm, direction, ent, rel, a, p) + E * offset
+    return fused + eps * s_lab - s_all / E
 
 
 class _ScoreEmb(torch.autograd.Function):

@@ -288,15 +288,21 @@ def test_kl_fwd_bwd(eng, model, d, E, R, n, scale):
             assert float(g_p[1].abs().max()) == 0.0 and float(g_a[1].abs().max()) == 0.0
 
 
-def test_model_level_kl_loss_against_composed():
+@pytest.mark.parametrize("name,ls", [("distmult", 0.0), ("distmult", 0.1), ("complex", 0.3)])
+def test_model_level_kl_loss_against_composed(name, ls):
+    """Fused KvsAll KL loss (and, ls > 0, its label-smoothed form: train_KvsAll.py:260-266 -- the fused
+    kernel's per-row label weight + one linear [n, 1] score + a constant) against the composed
+    score -> smooth -> normalise -> KLDivLoss path on the same model; rows without labels included."""
     from kge_amd import model as km
     E, R, d, n = 2000 + 3, 7, 256, 150
     torch.manual_seed(0)
-    m = km.create("distmult", E, R, d, device=DEV, score_dtype=torch.bfloat16)
-    ent, rel, s, p, o, rowptr, col = _kl_case(9, "distmult", d, E, R, n, 0.3)
+    m = km.create(name, E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    ent, rel, s, p, o, rowptr, col = _kl_case(9, name, d, E, R, n, 0.3)
     ts, tp, to, trp, tcl = _t(s), _t(p), _t(o), _t(rowptr), _t(col)
-    for fused, composed in ((lambda: m.kl_loss_sp(ts, tp, trp, tcl), lambda: m._kl_composed(m.score_sp(ts, tp), trp, tcl)),
-                            (lambda: m.kl_loss_po(tp, to, trp, tcl), lambda: m._kl_composed(m.score_po(tp, to), trp, tcl))):
+    for fused, composed in ((lambda: m.kl_loss_sp(ts, tp, trp, tcl, ls),
+                             lambda: m._kl_composed(m.score_sp(ts, tp), trp, tcl, ls)),
+                            (lambda: m.kl_loss_po(tp, to, trp, tcl, ls),
+                             lambda: m._kl_composed(m.score_po(tp, to), trp, tcl, ls))):
         m.zero_grad()
         lf = fused().sum() / n
         lf.backward()
@@ -436,16 +442,19 @@ def test_bce_fwd_bwd(eng, model, d, E, R, n, scale, offset):
             assert rel_err <= 1e-2, (direction, nm, rel_err)
 
 
-def test_model_level_bce_loss_against_composed():
+@pytest.mark.parametrize("ls", [0.0, 0.2])
+def test_model_level_bce_loss_against_composed(ls):
+    """Fused KvsAll BCE loss (ls > 0: label-smoothed, model.bce_fused) against the composed path."""
     from kge_amd import model as km
     E, R, d, n = 2000 + 3, 7, 256, 150
     torch.manual_seed(0)
     m = km.create("complex", E, R, d, device=DEV, score_dtype=torch.bfloat16)
     ent, rel, s, p, o, rowptr, col = _kl_case(19, "complex", d, E, R, n, 0.3)
     ts, tp, to, trp, tcl = _t(s), _t(p), _t(o), _t(rowptr), _t(col)
-    for fused, composed in ((lambda: m.bce_loss_sp(ts, tp, trp, tcl, -0.5),
-                             lambda: m._bce_composed(m.score_sp(ts, tp), trp, tcl, -0.5)),
-                            (lambda: m.bce_loss_po(tp, to, trp, tcl), lambda: m._bce_composed(m.score_po(tp, to), trp, tcl))):
+    for fused, composed in ((lambda: m.bce_loss_sp(ts, tp, trp, tcl, -0.5, ls),
+                             lambda: m._bce_composed(m.score_sp(ts, tp), trp, tcl, -0.5, ls)),
+                            (lambda: m.bce_loss_po(tp, to, trp, tcl, 0.0, ls),
+                             lambda: m._bce_composed(m.score_po(tp, to), trp, tcl, 0.0, ls))):
         m.zero_grad()
         lf = fused().sum() / n
         lf.backward()

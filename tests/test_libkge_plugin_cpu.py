@@ -129,7 +129,7 @@ def _job_config(tmp, model, train_type, seed=7):
     return config
 
 
-@pytest.mark.parametrize("loss", ["kl", "bce"])
+@pytest.mark.parametrize("loss", ["kl", "bce", "kl_smoothed", "bce_smoothed"])
 @pytest.mark.parametrize("ref_type,hip_type", [("1vsAll", "hip_1vsAll"), ("KvsAll", "hip_KvsAll")])
 def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type, loss):
     """Control flow of the plugin training jobs on CPU: with a model whose loss_sp / loss_po
@@ -146,10 +146,16 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type,
     from kge_amd.model import KgeModel as Mirror
     data = os.path.join(str(tmp_path), "dataset_test")  # the jobs write index caches next to the data
     shutil.copytree(os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test"), data)
+    smoothing = 0.0
+    if loss.endswith("_smoothed"):  # KvsAll.label_smoothing (train_KvsAll.py:260-266): kl_/bce_loss_*'s last argument
+        if ref_type != "KvsAll":
+            pytest.skip("label smoothing is a KvsAll option")
+        loss, smoothing = loss[:-9], 0.4  # dataset_test has 4 entities; the job wants > 1/E
     results = {}
     for train_type in (ref_type, hip_type):
         config = _job_config(str(tmp_path), "complex", train_type)
         config.set("train.loss", loss)
+        config.set("KvsAll.label_smoothing", smoothing)
         if loss == "bce":
             config.set("train.loss_arg", -0.5)  # score offset
         torch.manual_seed(11)  # same initialisation and batch order for both jobs
@@ -166,13 +172,13 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type,
                 m.loss_sp_po = types.MethodType(
                     lambda self, s, p, o: torch.cat([self.loss_sp(s, p, o), self.loss_po(p, o, s)]), m)
             m.kl_loss_sp = types.MethodType(
-                lambda self, s, p, rp, col: Mirror._kl_composed(self.score_sp(s, p), rp, col), m)
+                lambda self, s, p, rp, col, ls=0.0: Mirror._kl_composed(self.score_sp(s, p), rp, col, ls), m)
             m.kl_loss_po = types.MethodType(
-                lambda self, p, o, rp, col: Mirror._kl_composed(self.score_po(p, o), rp, col), m)
+                lambda self, p, o, rp, col, ls=0.0: Mirror._kl_composed(self.score_po(p, o), rp, col, ls), m)
             m.bce_loss_sp = types.MethodType(
-                lambda self, s, p, rp, col, off: Mirror._bce_composed(self.score_sp(s, p), rp, col, off), m)
+                lambda self, s, p, rp, col, off, ls=0.0: Mirror._bce_composed(self.score_sp(s, p), rp, col, off, ls), m)
             m.bce_loss_po = types.MethodType(
-                lambda self, p, o, rp, col, off: Mirror._bce_composed(self.score_po(p, o), rp, col, off), m)
+                lambda self, p, o, rp, col, off, ls=0.0: Mirror._bce_composed(self.score_po(p, o), rp, col, off, ls), m)
         job._prepare()
         trace = job.run_epoch()
         results[train_type] = (trace["avg_loss"], [x.detach().clone() for x in m.parameters()])
