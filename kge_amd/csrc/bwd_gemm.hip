@@ -24,6 +24,13 @@
 
 namespace kge {
 
+// bwd_gemm16.hip: the hand-written bf16 contractions
+int run_gemm16_dq(int d, long long rows, long long m, const unsigned short* T, long long ldt,
+                  const unsigned short* G16, long long mp, float* C, float* scratch, size_t scratch_bytes,
+                  hipStream_t st);
+bool run_gemm16_dt(int d, long long rows, long long m, const unsigned short* Q16, const unsigned short* G16,
+                   long long mp, float* dT, hipStream_t st);
+
 // Q[i, :] = q(a_i, r_i), f32, ld = d.  One thread per (row, coordinate of the first half).
 template <int SCORER>
 __global__ __launch_bounds__(256) void bwdg_build_q_kernel(Operand A, Operand R, int dir, int d,
@@ -497,6 +504,48 @@ long long pairs_bwd_workspace_bytes(int dtype, int scorer, int d, long long n, l
   return ((n * mp * 2 + 255) & ~255LL) + ((n * (long long)d * 2 + 255) & ~255LL);
 }
 
+// dQ = G16 * T and dT = G16^T * Q16 on the bf16 matrix cores: the hand-written kernel of bwd_gemm16.hip,
+// the library where that declines (d not a multiple of 256, KGE_BWD_GEMM_LIB=1).  `lws`: scratch for the
+// split-K partials of dQ (g_tgt before dT overwrites it) or NULL.
+static bool bwdg_dq16(int d, long long rows, long long m, const unsigned short* T, long long ldt,
+                      const unsigned short* G16, long long mp, float* g_a, float* lws, size_t lws_bytes,
+                      hipStream_t st) {
+  const int sp = run_gemm16_dq(d, rows, m, T, ldt, G16, mp, g_a, lws, lws_bytes, st);
+  if (sp > 1) {
+    const long long cnt = rows * d;  // d % 256 == 0: cnt % 4 == 0
+    hipLaunchKernelGGL(bwdg_reduce_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, st, lws, cnt, sp,
+                       g_a);
+  }
+  if (sp >= 1) return true;
+  return gemm_long_k(1, d, rows, m, T, ldt, G16, mp, g_a, lws, lws_bytes, st);
+}
+
+static bool bwdg_dt16(int d, long long rows, long long m, const unsigned short* Q16, const unsigned short* G16,
+                      long long mp, float* g_tgt, hipStream_t st) {
+  if (run_gemm16_dt(d, rows, m, Q16, G16, mp, g_tgt, st)) return true;
+  return lt_gemm(1, 0, 1, d, m, rows, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st);
+}
+
+// tests / tools: one of the two products on its own (which = 0: dQ [rows, d] from T [m, d]; 1: dT [m, d] from
+// Q16 [rows, d]); lib != 0 forces the library path
+int run_debug_gemm16(int which, int lib, int d, long long rows, long long m, const unsigned short* X, long long ldx,
+                     const unsigned short* G16, long long mp, float* out, float* scratch, long long scratch_bytes,
+                     hipStream_t st) {
+  bool capturing = false;
+  if (!stream_is_capturing(st, capturing)) return KGE_ERR_UNSUPPORTED;
+  tl_capturing = capturing;
+  bool ok;
+  if (which == 0)
+    ok = lib ? gemm_long_k(1, d, rows, m, X, ldx, G16, mp, out, scratch, (size_t)scratch_bytes, st)
+             : bwdg_dq16(d, rows, m, X, ldx, G16, mp, out, scratch, (size_t)scratch_bytes, st);
+  else
+    ok = lib ? lt_gemm(1, 0, 1, d, m, rows, X, d, G16, mp, out, d, nullptr, 0, st)
+             : bwdg_dt16(d, rows, m, X, G16, mp, out, st);
+  tl_capturing = false;
+  if (!ok) return KGE_ERR_UNSUPPORTED;
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
 // Both gradient products from G16 = d loss / d score in bf16 ([n, mp], row pitch mp elements):
 // the tail of the mixed-precision backward, shared with the fused 1vsAll loss (ce_loss.hip), whose
 // scoring kernel writes G16 itself.
@@ -519,8 +568,8 @@ static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Op
   // all entities: g_tgt (written by the second product only) is the library's split-K workspace
   void* lws = TG.idx.ptr == nullptr ? (void*)g_tgt : nullptr;
   const size_t lws_bytes = TG.idx.ptr == nullptr ? (size_t)m * d * sizeof(float) : 0;
-  if (!gemm_long_k(1, d, n, m, T, ldt, G16, mp, g_a, (float*)lws, lws_bytes, st)) return KGE_ERR_UNSUPPORTED;
-  if (!lt_gemm(1, 0, 1, d, m, n, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st)) return KGE_ERR_UNSUPPORTED;
+  if (!bwdg_dq16(d, n, m, T, ldt, G16, mp, g_a, (float*)lws, lws_bytes, st)) return KGE_ERR_UNSUPPORTED;
+  if (!bwdg_dt16(d, n, m, Q16, G16, mp, g_tgt, st)) return KGE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p, A,
                      (float*)nullptr, 0LL, (float*)nullptr, 0LL);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
@@ -539,9 +588,9 @@ static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Opera
   hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, Q16, A2);
   if (TG.idx.ptr != nullptr) return KGE_ERR_UNSUPPORTED;  // all entities only
   const unsigned short* T = (const unsigned short*)TG.base;
-  if (!gemm_long_k(1, d, 2 * n, m, T, TG.ld, G16, mp, g_a, g_tgt, (size_t)m * d * sizeof(float), st))
+  if (!bwdg_dq16(d, 2 * n, m, T, TG.ld, G16, mp, g_a, g_tgt, (size_t)m * d * sizeof(float), st))
     return KGE_ERR_UNSUPPORTED;
-  if (!lt_gemm(1, 0, 1, d, m, 2 * n, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st)) return KGE_ERR_UNSUPPORTED;
+  if (!bwdg_dt16(d, 2 * n, m, Q16, G16, mp, g_tgt, st)) return KGE_ERR_UNSUPPORTED;
   // acc_rel != NULL: the row gradients go straight into the table gradients -- the entity rows
   // on top of dT in g_tgt [m, d] (all entities: row ids are table rows), the relation rows into acc_rel
   hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, g_a, g_p, A2,

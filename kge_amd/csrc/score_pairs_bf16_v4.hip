@@ -604,7 +604,10 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   const Operand& AA2 = A2 ? *A2 : A;
   // interleaved tiles (tiles_per_cg = 0) once a launch's score block outgrows the Infinity Cache
   const char* il = getenv("KGE_V4_INTERLEAVE");
-  const bool interleave = il ? il[0] == '1' : (double)n * (double)m * 4.0 * (A2 ? 2 : 1) > 192e6;
+  // AND the output pitch is sector-aligned (padded pitch: 433 -> 417 us on a 574,311-column shard; with an
+  // unpadded pitch the partial sectors at tile edges then come from two XCDs' L2s: 9.9 -> 10.5 ms, so no)
+  const bool interleave =
+      il ? il[0] == '1' : ((double)n * (double)m * 4.0 * (A2 ? 2 : 1) > 192e6 && (ldo & 7) == 0);
   const int tpc_arg = interleave ? 0 : tpc;
 #define KGE_V4L(MODE)                                                                          \
   hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE, EPI>), dim3(grid), dim3(512), 0, st, A, \

@@ -21,7 +21,7 @@ for db in sorted(glob.glob(f"{root}/**/*_results.db", recursive=True)):
         for k, cn, v in rows:
             agg.setdefault((cn, k.split("(")[0][:70]), []).append(v)
         for (cn, k), v in sorted(agg.items()):
-            if "pairs" in k or "rank" in k or "neg" in k or "ce_" in k:
+            if any(x in k for x in ("pairs", "rank", "neg", "ce_", "gemm16", "adagrad")):
                 m = statistics.mean(v)
                 extra = f" -> {m * 1024 * (2 if cn == 'FETCH_SIZE' else 1) / 1e6:.2f} MB" if cn in ("FETCH_SIZE", "WRITE_SIZE") else ""
                 print(f"{rel}: {cn} {k} n={len(v)} mean={m:.1f}{extra}")
