@@ -103,6 +103,7 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
                long long m, const long long* rowptr, const long long* col, const float* lse, const float* g_rows,
                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
                const float* label_weight = nullptr);
+void set_g16_dbg(unsigned long long* p);
 int run_debug_gemm16(int which, int lib, int d, long long rows, long long m, const unsigned short* X, long long ldx,
                      const unsigned short* G16, long long mp, float* out, float* scratch, long long scratch_bytes,
                      hipStream_t st);
@@ -828,6 +829,8 @@ void kge_debug_ce_stamps(unsigned long long* stamps) { kge::ce_set_stamps(stamps
 
 // Not part of the public ABI: one gradient contraction of the bf16 backward on its own
 // (tests/test_gpu_bwd_gemm16.py, tools/gemm16_probe.py); see run_debug_gemm16 in bwd_gemm.hip.
+void kge_debug_gemm16_stamps(unsigned long long* stamps) { kge::set_g16_dbg(stamps); }
+
 int kge_debug_gemm16(int which, int lib, int d, int64_t rows, int64_t m, const void* x, int64_t ldx, const void* g16,
                      int64_t mp, float* out, float* scratch, int64_t scratch_bytes, void* stream) {
   return kge::run_debug_gemm16(which, lib, d, rows, m, (const unsigned short*)x, ldx, (const unsigned short*)g16, mp,

@@ -59,6 +59,7 @@ struct G16Args {
   long long ldc, c_split;
   int M, N, K;
   int mtiles, ntiles, splits, ksteps;
+  unsigned long long* dbg;  // optional per-workgroup phase stamps (8 x u64 each; tools/gemm16_phases.py), else NULL
 };
 
 template <int I, int N, class F>
@@ -80,6 +81,12 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x, xcd = b & 7, idx = b >> 3;
+  int dbg_i = 0;
+  auto stamp = [&]() {
+    if (g.dbg != nullptr && tid == 0) g.dbg[(long long)blockIdx.x * 8 + dbg_i] = __builtin_readcyclecounter();
+    ++dbg_i;
+  };
+  stamp();  // 0: start
   int mt, nt, split;
   if (A_TR) {  // the column halves of a row tile next to each other on one XCD
     nt = idx % g.ntiles;
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
   using U0 = std::integral_constant<int, 0>;
   using U3 = std::integral_constant<int, 3>;
   open_stage(0);
+  stamp();  // 1: first stage landed
   if (pend_step >= 0) issue_range(pend_step, pend_buf, I0{}, I3{});  // nothing to hide these three behind
   load(S0{}, 0u, f0);
   for (int t = 0; t < nsteps; ++t) {
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
 
   // ---- the two K groups exchange halves through LDS (the ring is dead: 128 of its 144 KiB): wave w of
   // group 0 ends up with columns 0-63 of its 64 x 128 block (j = 0, 1), its partner w + 4 with columns 64-127
+  stamp();  // 2: K loop done (MFMAs issued)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS
   __builtin_amdgcn_s_barrier();                      // every wave has read its last fragments
   auto exchange = [&](auto kg) __attribute__((always_inline)) {  // kg = this wave's K group, compile-time:
@@ -306,32 +315,63 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    float* C = g.C + (long long)split * g.c_split;
+    stamp();  // 3: halves exchanged
+    // the sums of this wave's 64 x 64 block, in place of the half it keeps
+    constexpr int KOFF = KG ? 2 : 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        constexpr int KOFF = KG ? 2 : 0;  // the half this wave keeps
-        const int col = n0 + wn * 128 + (jj + KOFF) * 32 + l32;
+      for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(take + ((i * 2 + jj) * 4 + q) * 1024);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // accumulator register r of a 32 x 32 block is row 8 (r / 4) + 4 h + r % 4, column lane % 32
-            const int row = m0 + wm * 64 + i * 32 + q * 8 + h * 4 + e;
-            if (row < g.M) C[(long long)row * g.ldc + col] = acc[i][jj + KOFF][4 * q + e] + v[e];
-          }
+          for (int e = 0; e < 4; ++e) acc[i][jj + KOFF][4 * q + e] += v[e];
         }
-      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave has taken its partner's half: the exchange area is free
+    // Store through a wave-private row-major image of the block (64 rows x 272 B): the accumulator layout
+    // puts one column per lane (64 dword stores of 2 x 128 B each, 5.7 k cycles to issue); from the image every
+    // store instruction writes 4 rows x 256 contiguous bytes, 16 bytes per lane.
+    // Accumulator register r of a 32 x 32 block is row 8 (r / 4) + 4 h + r % 4, column lane % 32.
+    constexpr int WP = 272;
+    unsigned char* img = smem + (KG * 4 + wq) * (64 * WP);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
+          *reinterpret_cast<float*>(img + row * WP + (jj * 32 + l32) * 4) = acc[i][jj + KOFF][r];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (wave-private: no barrier)
+    float* C = g.C + (long long)split * g.c_split;
+    const int rsub = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + rsub;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(img + row * WP + c4 * 4);
+      const int grow = m0 + wm * 64 + row;
+      if (grow < g.M)
+        *reinterpret_cast<f32x4*>(C + (long long)grow * g.ldc + n0 + wn * 128 + KOFF * 32 + c4) = v;
+    }
   };
   if (kgrp) exchange(std::integral_constant<int, 1>{});
   else exchange(std::integral_constant<int, 0>{});
+  stamp();  // 4: stores issued
+  if (g.dbg != nullptr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();  // 5: stores acknowledged
+  }
 }
 
 bool g16_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+static unsigned long long* g16_dbg = nullptr;  // set by kge_debug_gemm16_stamps
+void set_g16_dbg(unsigned long long* p) { g16_dbg = p; }
 
 bool bwd_gemm16_enabled() {
   static const bool lib = [] {
@@ -363,6 +403,7 @@ int run_gemm16_dq(int d, long long rows, long long m, const unsigned short* T, l
   if (splits > fit) splits = fit;
   if (splits > g.ksteps) splits = g.ksteps;
   if (splits < 2) splits = 1;
+  g.dbg = g16_dbg;
   g.splits = (int)splits;
   g.C = splits > 1 ? scratch : C;
   const long long grid = 8 * per * ((splits + 7) / 8);
@@ -385,6 +426,7 @@ bool run_gemm16_dt(int d, long long rows, long long m, const unsigned short* Q16
   g.ntiles = d / G16_BN;
   g.ksteps = (int)((rows + G16_BK - 1) / G16_BK);
   g.splits = 1;
+  g.dbg = g16_dbg;
   const long long grid = 8LL * g.ntiles * ((g.mtiles + 7) / 8);
   if (grid > 0x7fffffffLL) return false;
   hipLaunchKernelGGL((gemm16_kernel<true>), dim3((unsigned)grid), dim3(512), 0, st, g);

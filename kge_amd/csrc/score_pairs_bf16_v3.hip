@@ -343,8 +343,18 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   auto ds_write = [&](int tt, const f32x16& acc, int hf, int g) {
     const long long rel = lab - ((long long)(tile_lo + tt) * V3_TN + 4 * fh);
     const int off = 32 * hf + 8 * g;
-    const float p0 = ds_value(acc[4 * g], rel, off), p1 = ds_value(acc[4 * g + 1], rel, off + 1);
-    const float p2 = ds_value(acc[4 * g + 2], rel, off + 2), p3 = ds_value(acc[4 * g + 3], rel, off + 3);
+    float p0 = ds_value(acc[4 * g], rel, off), p1 = ds_value(acc[4 * g + 1], rel, off + 1);
+    float p2 = ds_value(acc[4 * g + 2], rel, off + 2), p3 = ds_value(acc[4 * g + 3], rel, off + 3);
+    // The pad columns [m, pitch) of the last tile are ZERO: the gradient products (bwd_gemm16.hip) read
+    // whole 16-byte chunks of a row and rely on it.  (Wave-uniform branch: only the ragged last tile.)
+    const long long colb = (long long)(tile_lo + tt) * V3_TN;
+    if (colb + V3_TN > m) {
+      const long long lim = m - (colb + 4 * fh + off);  // columns of this group that exist
+      p0 = lim > 0 ? p0 : 0.0f;
+      p1 = lim > 1 ? p1 : 0.0f;
+      p2 = lim > 2 ? p2 : 0.0f;
+      p3 = lim > 3 ? p3 : 0.0f;
+    }
     u32x2 v = {bf16_pack(p0, p1), bf16_pack(p2, p3)};
     *reinterpret_cast<u32x2*>(cst16 + fi * 144 + (off + 4 * fh) * 2) = v;
   };
