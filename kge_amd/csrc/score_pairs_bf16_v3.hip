@@ -196,7 +196,11 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
             lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
         if (__all(v == epoch)) break;
         // bounded (seconds): a lost builder must neither hang the GPU nor let this workgroup
-        // score with garbage -- abort the launch, the host sees a launch failure
+        // score with garbage -- abort the launch, the host sees a launch failure.  Not reachable by a
+        // co-residency shortfall: the builders are the workgroups cg < nbuild <= 8 of every row group,
+        // i.e. the first 8 * rgn block ids, and workgroups are dispatched in id order -- whenever a
+        // consumer runs, its builders were dispatched before it and wait for nobody.  (v4, the default
+        // path, additionally falls back to an in-register build after its time-out.)
         if (spin == (1 << 21)) __builtin_trap();
         __builtin_amdgcn_s_sleep(4);
       }
