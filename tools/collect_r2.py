@@ -15,7 +15,10 @@ import sys
 tag = sys.argv[1]
 src, dst = f"gpurun_out/{tag}", "profiles"
 for a, b in (("plugin_gpu.jsonl", "libkge_plugin_gpu.jsonl"), ("bshape_ranks.jsonl", "bshape_ranks.jsonl"),
-             ("v2_phases.txt", "phase_timestamps.txt"), ("env.log", "env.log")):
+             ("v2_phases.txt", "phase_timestamps.txt"), ("env.log", "env.log"),
+             ("gemm16_probe.txt", "gemm16_probe.txt"), ("gemm16_phases.txt", "gemm16_phase_stamps.txt"),
+             ("bench_dist1_wikidata5m.json", "bench_dist1rank_wikidata5m.json"),
+             ("bench_dist1_fb15k.json", "bench_dist1rank_fb15k.json")):
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"{dst}/{tag}_{b}")
 if os.path.exists(f"{src}/bench.json"):
@@ -27,7 +30,8 @@ if os.path.exists(f"{src}/pytest_all.log"):
 lines = [f"rocprofv3 --kernel-trace --stats, MI355X, run {tag}: name | calls | total (us) | average (us) | % of run"]
 for sub, what in (("prof", "python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-one-sided  (two-sided score_sp_po launches)"),
                   ("prof1", "python tools/one_sided.py  (one-sided score_sp launches, C2 shape)"),
-                  ("prof1p", "python tools/one_sided.py --pad  (one-sided, row pitch padded to 32 floats)")):
+                  ("prof1p", "python tools/one_sided.py --pad  (one-sided, row pitch padded to 32 floats)"),
+                  ("prof_step", "python tools/step_kernels.py  (30 fused 1vsAll training steps: loss_sp_po + backward + one-pass Adagrad)")):
     dbs = glob.glob(f"{src}/{sub}/**/*_results.db", recursive=True)
     if not dbs:
         continue

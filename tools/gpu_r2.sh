@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 python -c "import torch;print(torch.cuda.get_device_name(0), torch.version.hip)" > $OUT/env.log 2>&1
 if [ "$MODE" = "full" ]; then
-KGE_BSHAPE_LOG=$R/$OUT/bshape_ranks.jsonl KGE_PLUGIN_LOG=$R/$OUT/plugin_gpu.jsonl timeout 1500 python -m pytest tests -m gpu -q --timeout=900 > $OUT/pytest_all.log 2>&1
+KGE_BSHAPE_LOG=$R/$OUT/bshape_ranks.jsonl KGE_PLUGIN_LOG=$R/$OUT/plugin_gpu.jsonl timeout 1800 python -m pytest tests -m gpu -q --timeout=900 > $OUT/pytest_all.log 2>&1
 echo "pytest all exit: $?" >> $OUT/env.log
 grep -h "PLUGIN_GPU\|BSHAPE_RANKS" $OUT/pytest_all.log > $OUT/plugin_lines.txt
 else
@@ -24,6 +24,13 @@ echo "smoke exit: $?" >> $OUT/env.log
 timeout 600 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit: $?" >> $OUT/env.log
 timeout 300 python tools/v2_phases.py > $OUT/v2_phases.txt 2>&1
+timeout 200 python tools/gemm16_probe.py > $OUT/gemm16_probe.txt 2>&1
+timeout 200 python tools/gemm16_phases.py > $OUT/gemm16_phases.txt 2>&1
+# the sharded step with ONE rank (RCCL init, exchange, padded slabs): the code path of bench.py --gpus N
+for SH in wikidata5m fb15k; do
+KGE_BENCH_FORCE_DIST=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 20 --warmup 3 --shape $SH --no-cpu-baseline > $OUT/bench_dist1_$SH.json 2> $OUT/bench_dist1_$SH.err
+echo "bench dist1 $SH exit: $?" >> $OUT/env.log
+done
 cd /tmp
 B="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-one-sided"
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- $B > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err
@@ -37,6 +44,7 @@ echo "pmc $C exit: $?" >> $R/$OUT/env.log
 timeout 300 rocprofv3 --pmc $C -d $R/$OUT/pmc1_$C -o one -- python $R/tools/one_sided.py --steps 20 > /dev/null 2> $R/$OUT/pmc1_$C.err
 timeout 300 rocprofv3 --pmc $C -d $R/$OUT/pmc1p_$C -o one -- python $R/tools/one_sided.py --steps 20 --pad > /dev/null 2> $R/$OUT/pmc1p_$C.err
 done
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_step -o step -- python $R/tools/step_kernels.py > $R/$OUT/step_kernels.log 2>&1
 cd $R
 python tools/db_summary.py $OUT > $OUT/summary.txt 2>&1
 tail -5 $OUT/pytest_*.log
