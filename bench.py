@@ -184,7 +184,9 @@ def sharded_workload(shape, world, rank, device, n, engine):
     s = torch.randint(E, (n,), generator=q).to(device)
     p = torch.randint(R, (n,), generator=q).to(device)
     o = torch.randint(E, (n,), generator=q).to(device)
-    sh = ShardedEntityTable("complex", ent, rel.to(torch.bfloat16).to(device), E, backend=engine)
+    # one forced rank (KGE_BENCH_FORCE_DIST=1): still run every collective, so a 1-GPU box exercises RCCL
+    sh = ShardedEntityTable("complex", ent, rel.to(torch.bfloat16).to(device), E, backend=engine,
+                            force_collectives=os.environ.get("KGE_BENCH_FORCE_DIST") == "1")
     return sh, s, p, o, E, d
 
 

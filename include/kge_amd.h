@@ -143,7 +143,9 @@ int kge_device_count(void);
  * never wrong, never a hang (non-zero garbage in a fresh workspace has the same effect).  The
  * workspace is only accessed during a call (stream order; calls may be captured into a hipGraph
  * and replayed) and must not be shared by calls that may run concurrently on different streams;
- * 16-byte aligned.  The same holds for the workspaces of the fused-loss entry points below. */
+ * 16-byte aligned.  ONE workspace may serve calls with different n (size it for the largest): the
+ * control block -- flag lines and the degraded word -- lies at its start, at an offset that does not
+ * depend on n; the query vectors follow.  The same holds for the workspaces of the fused-loss entry points below. */
 int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n);
 
 /* out[i] = score(s[i], p[i], o[i]), i < n.        KgeModel.score_spo */

@@ -12,6 +12,9 @@
 
 namespace kge {
 
+// control block at the start of the cooperative-build workspace: 512 flag lines of 64 B + the degraded word
+constexpr long long PAIRS_WS_CTRL_BYTES = 512 * 8 * 8 + 256;
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));

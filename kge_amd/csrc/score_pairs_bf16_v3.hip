@@ -576,12 +576,16 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
       m1[r] = c + 32 < m ? a1[r] : -__builtin_inff();
       mx = __builtin_fmaxf(mx, __builtin_fmaxf(m0[r], m1[r]));
     });
+    // A lane whose columns of this tile are ALL padding, in a column group that holds nothing but this tile
+    // (m % 64 <= 4 and one tile per group), still has mx = -inf: (-inf) - (-inf) would make its (0, 0) a NaN
+    // and the row's loss with it.  Exponents are taken against a finite reference then (same bits otherwise).
+    const float rf = mx == -__builtin_inff() ? 0.0f : mx;
     float sm = 0.0f;
     v3_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
-      sm += __builtin_amdgcn_exp2f((m0[r] - mx) * V3_LOG2E) + __builtin_amdgcn_exp2f((m1[r] - mx) * V3_LOG2E);
+      sm += __builtin_amdgcn_exp2f((m0[r] - rf) * V3_LOG2E) + __builtin_amdgcn_exp2f((m1[r] - rf) * V3_LOG2E);
     });
-    rsum = rsum * __builtin_amdgcn_exp2f((rmax - mx) * V3_LOG2E) + sm;
+    rsum = rsum * __builtin_amdgcn_exp2f((rmax - rf) * V3_LOG2E) + sm;
     rmax = mx;
     lse_pick(ntl - 1, a0, a1);
     // the two lanes of a row -> one (max, sum exp) per row and column group
@@ -663,9 +667,15 @@ static int v3_cu_count() {
 }
 
 long long pairs_bf16_v3_workspace_bytes(int d, long long n) {
-  // fragments of whole 128-row groups, both sides of a score_sp_po call, + the builders' flags
+  // [control block: the builders' flag lines (512 x 64 B) + the "degraded" word of the v4 hand-off]
+  // [query fragments of whole 128-row groups, both sides of a score_sp_po call].
+  // The control block comes FIRST, at an offset that does not depend on n: calls with different row counts
+  // share one workspace (per stream), and behind the fragments the flag lines and the degraded word of a
+  // small call lay inside the fragment area of a larger one -- whose fragment data then read as "degraded"
+  // to every later small call (own query build in every workgroup: 17 -> 24 us at C2, found in the bench
+  // line's one-sided figure).
   const long long rgn = 2 * ((n + V3_ROWS - 1) / V3_ROWS);
-  return rgn * V3_ROWS * (long long)d * 2 + 512 * 8 * 8 + 64;  // + the "degraded" word of the v4 hand-off
+  return PAIRS_WS_CTRL_BYTES + rgn * V3_ROWS * (long long)d * 2;
 }
 
 // one workgroup per CU (256 CUs): the target tiles are split into `ncg` column groups of `tpc` tiles
@@ -702,13 +712,14 @@ static int launch_v3(const Operand& A, const Operand& R, const Operand& TG, int 
   // where the kernel arguments are frozen)
   const long long qf_bytes = (long long)rgn * V3_ROWS * HH * 4;
   bool coop = ws != nullptr && v3_al16(ws) && ncg > 1 && rgn <= 256 &&
-              ws_bytes >= qf_bytes + 256 * 16 * 8 && grid <= v3_cu_count();
+              ws_bytes >= qf_bytes + PAIRS_WS_CTRL_BYTES && grid <= v3_cu_count();
   if (coop) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) coop = false;
   }
-  u32x4* qf = (u32x4*)ws;
-  unsigned long long* flags = (unsigned long long*)((char*)ws + qf_bytes);
+  // control block FIRST (see pairs_bf16_v3_workspace_bytes), fragments behind it
+  unsigned long long* flags = (unsigned long long*)ws;
+  u32x4* qf = (u32x4*)((char*)ws + PAIRS_WS_CTRL_BYTES);
   unsigned long long epoch = 0;
   int nbuild = 0;
   if (coop) {

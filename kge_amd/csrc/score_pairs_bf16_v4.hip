@@ -432,11 +432,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     float mx = rmax;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = __builtin_fmaxf(mx, __builtin_fmaxf(acc0[r], acc1[r]));
+    // all of this lane's columns padded and nothing before them (a column group of just the ragged last tile,
+    // m % 64 <= 4): mx is still -inf; a finite reference keeps (-inf) - (-inf) out of the exponents
+    const float rf = mx == -__builtin_inff() ? 0.0f : mx;
     float sm = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      sm += __builtin_amdgcn_exp2f((acc0[r] - mx) * V3_LOG2E) + __builtin_amdgcn_exp2f((acc1[r] - mx) * V3_LOG2E);
-    rsum = rsum * __builtin_amdgcn_exp2f((rmax - mx) * V3_LOG2E) + sm;
+      sm += __builtin_amdgcn_exp2f((acc0[r] - rf) * V3_LOG2E) + __builtin_amdgcn_exp2f((acc1[r] - rf) * V3_LOG2E);
+    rsum = rsum * __builtin_amdgcn_exp2f((rmax - rf) * V3_LOG2E) + sm;
     rmax = mx;
     const long long rel = lab - c0;
     const bool hit = rel >= 0 && rel < V4_TN && (rel & 7) < 4 && lab < m;  // not a padded column
@@ -586,11 +589,12 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   // Fine under hipGraph capture: the epoch is frozen then, but every consumer clears its own
   // flag line after reading it, so a replay never sees the previous run's flags.
   const long long qf_bytes = (long long)rgn * V4_ROWS * HH * 4;
-  if (ws == nullptr || !v4_al16(ws) || (long long)rgn * ncg > 512 || ws_bytes < qf_bytes + 512 * 8 * 8 + 64 ||
+  if (ws == nullptr || !v4_al16(ws) || (long long)rgn * ncg > 512 || ws_bytes < qf_bytes + PAIRS_WS_CTRL_BYTES ||
       grid > v4_cu_count() || ldo >= (1LL << 24))
     return KGE_ERR_UNSUPPORTED;
-  u32x4* qf = (u32x4*)ws;
-  unsigned long long* flags = (unsigned long long*)((char*)ws + qf_bytes);
+  // control block first, at an offset independent of n (pairs_bf16_v3_workspace_bytes)
+  unsigned long long* flags = (unsigned long long*)ws;
+  u32x4* qf = (u32x4*)((char*)ws + PAIRS_WS_CTRL_BYTES);
   static const unsigned long long seed =
       ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20) | (1ull << 63);
   const unsigned long long epoch = seed + ++g_v4_epoch;  // never 0 (= "cleared")

@@ -33,6 +33,8 @@ all-reduce).  Optimizer state follows the rows: every rank steps its own shard.
 """
 from typing import Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -50,7 +52,7 @@ class _ShardedCE(torch.autograd.Function):
         t16 = sh._tables(sh.ent_local, "local")
         loss_loc, lse_loc = sh.backend.ce_emb_fwd(t16, direction, rows, rel_rows, lab_local)
         true = torch.where(own, lse_loc - loss_loc, torch.zeros_like(lse_loc))  # the owner's label score
-        if sh.world > 1:
+        if sh.collectives:
             allse = torch.empty(sh.world * lse_loc.numel(), dtype=lse_loc.dtype, device=lse_loc.device)
             dist.all_gather_into_tensor(allse, lse_loc.contiguous(), group=sh.group)
             lse = torch.logsumexp(allse.view(sh.world, -1), dim=0)
@@ -86,11 +88,16 @@ class _ShardedCE(torch.autograd.Function):
 
 class ShardedEntityTable:
     def __init__(self, scorer: str, ent_local: torch.Tensor, rel: torch.Tensor, num_entities: int,
-                 l_norm: float = 1.0, group=None, backend=None):
+                 l_norm: float = 1.0, group=None, backend=None, force_collectives: bool = False):
         self.scorer, self.l_norm = scorer, float(l_norm)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # With one rank every exchange step is an identity and is skipped -- unless `force_collectives` (or
+        # KGE_SHARDED_FORCE_COLLECTIVES=1): then a one-rank process group still runs every all-gather /
+        # all-reduce, so that a single-GPU box exercises the RCCL calls of the N > 1 path (tests, bench).
+        force = force_collectives or os.environ.get("KGE_SHARDED_FORCE_COLLECTIVES") == "1"
+        self.collectives = self.world > 1 or (force and dist.is_initialized())
         self.E = int(num_entities)
         self.shard = (self.E + self.world - 1) // self.world
         self.lo = min(self.rank * self.shard, self.E)
@@ -111,7 +118,7 @@ class ShardedEntityTable:
 
     # ---- exchange steps -------------------------------------------------------------------
     def _allreduce(self, t: torch.Tensor) -> torch.Tensor:
-        if self.world > 1:
+        if self.collectives:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
@@ -141,7 +148,7 @@ class ShardedEntityTable:
         send = self._buffer(("send", k), (k * n, d), self.ent_local)
         rel_rows = None if rel_ids is None else self._buffer("rel", (n, self.rel.shape[1]), self.rel)
         self.backend.embed(self._tables(self.ent_local, "local"), local, rel_ids, send, rel_rows)
-        if self.world == 1:
+        if not self.collectives:
             return send, rel_rows
         gath = self._buffer(("gath", k), (self.world * k * n, d), self.ent_local)
         dist.all_gather_into_tensor(gath.view(-1), send.view(-1), group=self.group)
@@ -273,7 +280,7 @@ class ShardedEntityTable:
             pad = k - kk
             v = torch.cat([v, torch.full((v.shape[0], pad), float("-inf"), device=v.device)], 1)
             i = torch.cat([i, torch.full((i.shape[0], pad), -1, dtype=i.dtype, device=i.device)], 1)
-        if self.world > 1:
+        if self.collectives:
             vs = [torch.empty_like(v) for _ in range(self.world)]
             is_ = [torch.empty_like(i) for _ in range(self.world)]
             dist.all_gather(vs, v, group=self.group)

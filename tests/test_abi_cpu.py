@@ -48,8 +48,8 @@ def test_invalid_arguments_are_rejected_without_a_device(lib):
     t = KgeTables(None, None, 0, 3, 10, 3, 32, 32, 32, 32, 1.0, 0)   # RotatE rel_dim != dim/2
     assert lib.kge_score_sp(ctypes.byref(t), ix, ix, 4, ix, 10, None, 10, None, 0, None) == -1
     t = KgeTables(None, None, 1, 0, 10, 3, 512, 512, 512, 512, 1.0, 0)  # bf16 ComplEx d=512
-    assert lib.kge_score_workspace_bytes(ctypes.byref(t), 512) == 2 * 512 * 512 * 2 + 512 * 8 * 8 + 64
-    assert lib.kge_score_workspace_bytes(ctypes.byref(t), 33) == 2 * 128 * 512 * 2 + 512 * 8 * 8 + 64
+    assert lib.kge_score_workspace_bytes(ctypes.byref(t), 512) == 2 * 512 * 512 * 2 + 512 * 8 * 8 + 256
+    assert lib.kge_score_workspace_bytes(ctypes.byref(t), 33) == 2 * 128 * 512 * 2 + 512 * 8 * 8 + 256
     t = KgeTables(None, None, 0, 0, 10, 3, 512, 512, 512, 512, 1.0, 0)  # f32: no workspace
     assert lib.kge_score_workspace_bytes(ctypes.byref(t), 512) == 0
     assert lib.kge_rank_counts(None, 3, 2, 5, None, None, None, 0, None, 1e-5, 1e-4, None, None, None) == -1

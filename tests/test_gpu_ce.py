@@ -61,6 +61,10 @@ CASES = [
     ("distmult", 128, 64, 3, 33, 1.0),        # exactly one full tile
     ("complex", 512, 14541, 237, 512, 0.1),   # BASELINE configs[1] shape (C2)
     ("complex", 256, 20000, 50, 700, 0.2),    # six row groups
+    # m % 64 <= 4 with one tile per column group: half the lanes of the last workgroup see nothing but padding
+    # (their running max stays -inf; this was a NaN loss for every row until round 2)
+    ("complex", 256, 900, 5, 64, 0.3),
+    ("distmult", 512, 14 * 64 + 1, 5, 130, 0.3),
 ]
 
 
@@ -123,7 +127,7 @@ def _grads64(model, ent16, rel16, a, p, lab, direction, g):
     return e.grad, r.grad
 
 
-@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5])
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5] + CASES[6:8])
 def test_ce_bwd(eng, model, d, E, R, n, scale):
     ent, rel, s, p, o = _case(3 * d + n, model, d, E, R, n, scale)
     T = _tables(eng, model, ent, rel)
@@ -232,7 +236,7 @@ def _kl64(scores, rowptr, col):
     return loss, lse
 
 
-@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5])
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5] + CASES[6:8])
 def test_kl_fwd_bwd(eng, model, d, E, R, n, scale):
     """Forward against float64 KL of the written scores (the label scores are re-evaluated in a
     different f32 summation order: + 2e-6 * max|score| per row on top of the CE tolerance) and
@@ -401,7 +405,7 @@ def test_ce_sp_po_bwd_accum_equals_scatter_of_row_gradients(eng):
 
 
 # ---- bce loss (kge_bce_fwd / kge_bce_bwd) ------------------------------------------------------------
-@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5])
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5] + CASES[6:8])
 @pytest.mark.parametrize("offset", [0.0, -1.5])
 def test_bce_fwd_bwd(eng, model, d, E, R, n, scale, offset):
     """Forward against float64 sum_j BCEWithLogits(score + offset, y) of the written scores

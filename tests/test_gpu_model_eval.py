@@ -409,3 +409,47 @@ def test_sharded_ce_loss_on_the_gpu_kernels(name):
         first = float(val.detach()) if first is None else first
         last = float(val.detach())
     assert last < first
+
+
+def test_sharded_path_through_a_real_rccl_process_group():
+    """The sharded exchange with REAL collectives on the GPU: a one-rank process group on the nccl (= RCCL)
+    backend and `force_collectives=True`, so that all_gather_into_tensor / all_reduce / all_gather run through
+    RCCL on device buffers instead of being skipped as identities ("the real engine has never met
+    a real collective in a test"; a 1-GPU box cannot host two ranks).  Results must equal the same table
+    without a process group: ranks, top-k, and the sharded 1vsAll loss with both table gradients."""
+    import torch.distributed as dist
+    from kge_amd.sharded import ShardedEntityTable
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    g = torch.Generator().manual_seed(8)
+    E, R, d, n = 900, 5, 256, 64
+    ent32 = (torch.randn(E, d, generator=g) * 0.3).to(DEV)
+    rel32 = (torch.randn(R, d, generator=g) * 0.3).to(DEV)
+    tri = torch.stack([torch.randint(E, (n,), generator=g), torch.randint(R, (n,), generator=g),
+                       torch.randint(E, (n,), generator=g)], 1).to(DEV)
+    s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
+
+    def run(sh):
+        ranks = sh.rank_batch(tri, None)
+        slab = sh.score_sp(s, p)
+        top = sh.topk(slab, 5)
+        ent_m, rel_m = ent32.clone().requires_grad_(True), rel32.clone().requires_grad_(True)
+        loss = sh.ce_loss("sp", s, p, o, ent_m, rel_m)
+        loss.sum().backward()
+        return ranks, top, loss.detach(), ent_m.grad, rel_m.grad
+
+    plain = run(ShardedEntityTable("complex", ent32.bfloat16(), rel32.bfloat16(), E))
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        sh = ShardedEntityTable("complex", ent32.bfloat16(), rel32.bfloat16(), E, force_collectives=True)
+        assert sh.collectives and sh.world == 1
+        forced = run(sh)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(plain[0], forced[0]):
+        assert torch.equal(a, b)
+    assert torch.equal(plain[1][0], forced[1][0]) and torch.equal(plain[1][1], forced[1][1])
+    for a, b in zip(plain[2:], forced[2:]):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)

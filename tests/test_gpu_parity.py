@@ -655,6 +655,36 @@ def test_bf16_own_build_fallback_is_bit_identical(eng, monkeypatch, d, n, E):
         _eq(f"degraded workspace, call {k}", b, a)
 
 
+def test_workspace_control_block_survives_calls_of_other_sizes(eng):
+    """One scratch buffer per stream serves calls with different row counts.  The control block (flag lines +
+    the "degraded" word) sits at the START of the workspace, at an offset that does not depend on n: when it
+    lay behind the query fragments, the fragments of a larger call overwrote the degraded word of a smaller
+    one, and every later small call took the own-build path (same bits, 17 -> 24 us at C2).  After calls of
+    several sizes, one- and two-sided, the degraded word is still zero and no flag line is left set."""
+    from kge_amd import engine as engmod
+    rng = np.random.default_rng(77)
+    E, R, d = 3000, 7, 512
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    T = _gpu_tables(eng, "complex", ent, rel, 1.0, bf16=True)
+    ref = {}
+    for rep in range(2):
+        for n in (2048, 130, 512, 1024, 64):
+            s, p, o = (_t(np.random.default_rng(n).integers(0, hi, n)) for hi in (E, R, E))
+            got = (_np(eng.score_sp(T, s, p)), _np(eng.score_sp_po(T, s, p, o)))
+            if n in ref:
+                _eq(f"n={n}, repeat", got[0], ref[n][0])
+                _eq(f"n={n}, repeat (two-sided)", got[1], ref[n][1])
+            ref[n] = got
+    torch.cuda.synchronize()
+    bufs = [b for k, b in engmod._WORKSPACES.items() if len(k) == 2]
+    assert bufs
+    for b in bufs:
+        ctrl = b[:512 * 64 + 8].cpu().numpy()
+        assert not ctrl[512 * 64:].any(), "the degraded word was set (or overwritten)"
+        assert not ctrl[:512 * 64].any(), "a flag line was left behind"
+
+
 def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch):
     """score_pairs_bf16_v5.hip (every workgroup builds the query vectors of its own 64 rows: no workspace,
     no hand-off, any n) takes the calls the cooperative kernel declines.  Forced in front of it
