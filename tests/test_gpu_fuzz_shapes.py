@@ -124,3 +124,90 @@ def test_random_shape_training_step(seed):
         assert torch.isfinite(a).all(), tag
         denom = float(b.norm())
         assert float((a - b).norm()) <= 3e-3 * denom + 1e-6, (tag, float((a - b).norm()), denom)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shape_f32_paths_bit_exact(seed):
+    """All four scorers on float32 tables (the parity path), random d -- odd, tiny, not a multiple of any tile
+    -- and random sizes, index dtypes and strides: spo / sp_ / _po / sp_po / listed subsets / negatives
+    BIT-EXACT against the C oracle (the canonical arithmetic)."""
+    from kge_amd import engine as eng
+    rng = np.random.default_rng(5000 + seed)
+    model = ("complex", "distmult", "transe", "rotate")[seed % 4]
+    d = int(rng.choice([2, 4, 6, 10, 18, 34, 50, 66, 96, 130, 258, 514]))
+    if model in ("distmult", "transe") and seed % 3 == 0:
+        d += 1  # odd dimensions where the scorer allows them
+    E, R = int(rng.integers(1, 400)), int(rng.integers(1, 9))
+    n, m_sub, K = int(rng.integers(1, 150)), int(rng.integers(1, 40)), int(rng.integers(1, 9))
+    l_norm = float(rng.choice([1.0, 2.0])) if model in ("transe", "rotate") else 1.0
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d // 2 if model == "rotate" else d)).astype(np.float32)
+    if model == "rotate":
+        rel = (rel * 1.5).astype(np.float32)
+    s, p, o = rng.integers(0, E, n), rng.integers(0, R, n), rng.integers(0, E, n)
+    sub, neg = rng.integers(0, E, m_sub), rng.integers(0, E, (n, K))
+    T = eng.Tables(model, _t(ent), _t(rel), l_norm, eng.FLAG_EXACT)
+    O = ko.Tables(model, ent, rel, l_norm)
+    # index tensors as a training job hands them over: columns of an [n, 3] int triple tensor (stride 3)
+    tri = torch.from_numpy(np.stack([s, p, o], 1)).to(DEV)
+    if seed % 2:
+        tri = tri.int()
+    ts, tp, to = tri[:, 0], tri[:, 1], tri[:, 2]
+    tsub, tneg = _t(sub), _t(neg)
+    tag = f"{model} d={d} E={E} n={n} l_norm={l_norm}"
+
+    def eq(name, got, want):
+        got, want = got.cpu().numpy(), np.asarray(want)
+        assert got.shape == want.shape and ((got == want) | (np.isnan(got) & np.isnan(want))).all(), (tag, name)
+
+    eq("spo", eng.score_spo(T, ts, tp, to), ko.score_spo(O, s, p, o))
+    eq("sp", eng.score_sp(T, ts, tp), ko.score_sp(O, s, p))
+    eq("po", eng.score_po(T, tp, to), ko.score_po(O, p, o))
+    eq("sp_sub", eng.score_sp(T, ts, tp, tsub), ko.score_sp(O, s, p, sub))
+    eq("po_sub", eng.score_po(T, tp, to, tsub), ko.score_po(O, p, o, sub))
+    eq("sp_po", eng.score_sp_po(T, ts, tp, to), ko.score_sp_po(O, s, p, o))
+    eq("sp_po_sub", eng.score_sp_po(T, ts, tp, to, tsub), ko.score_sp_po(O, s, p, o, sub))
+    eq("neg_s", eng.score_neg(T, ts, tp, to, 0, tneg), ko.score_neg(O, s, p, o, 0, neg))
+    eq("neg_o", eng.score_neg(T, ts, tp, to, 2, tneg), ko.score_neg(O, s, p, o, 2, neg))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shape_kvsall_losses(seed):
+    """KvsAll: the fused KL / BCE losses with and without label smoothing (kge_kl_fwd / kge_kl_weighted_fwd /
+    kge_bce_fwd + the linear column-sum term) against the composed path (scores -> dense smoothed labels ->
+    torch loss) of the same model, rows without labels and rows with many labels included; loss and both
+    parameter gradients.  The uniform part of the smoothed labels (weight (1/E)/Z per entity) is evaluated in
+    float32 on the master weights, the composed path scores it with bf16 operands like everything else: for a
+    tiny table (E < 512, where that weight is not tiny) the two differ at the bf16 level, hence the wider bar."""
+    from kge_amd import model as km
+    model, d, E, n, rng = _shape(200 + seed)
+    d = max(d, 256)
+    E = max(E, 8)
+    n = min(n, 300)
+    ls = (0.0, 0.1, 0.3)[seed % 3]
+    torch.manual_seed(seed)
+    m = km.create(model, E, 5, d, device=DEV, score_dtype=torch.bfloat16)
+    if m._ce_tables() is None:
+        pytest.skip("fused loss not available for this shape")
+    cnt = rng.integers(0, min(E, 6) + 1, n)
+    cnt[int(rng.integers(0, n))] = min(E, 40)
+    col = np.concatenate([np.sort(rng.choice(E, c, replace=False)) for c in cnt] + [np.zeros(0, np.int64)]).astype(np.int64)
+    rowptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    s, p = (torch.from_numpy(rng.integers(0, hi, n)).to(DEV) for hi in (E, 5))
+    trp, tcl = torch.from_numpy(rowptr).to(DEV), torch.from_numpy(col).to(DEV)
+    tag = f"{model} d={d} E={E} n={n} ls={ls}"
+    cases = [(lambda: m.kl_loss_sp(s, p, trp, tcl, ls), lambda: m._kl_composed(m.score_sp(s, p), trp, tcl, ls)),
+             (lambda: m.bce_loss_po(p, s, trp, tcl, -0.3, ls), lambda: m._bce_composed(m.score_po(p, s), trp, tcl, -0.3, ls))]
+    for fused, composed in cases:
+        m.zero_grad()
+        lf = fused().sum() / n
+        lf.backward()
+        gf = [x.grad.clone() for x in m.parameters()]
+        m.zero_grad()
+        lc = composed().sum() / n
+        lc.backward()
+        gc = [x.grad.clone() for x in m.parameters()]
+        tol = 2e-3 if (ls > 0 and E < 512) else 3e-5
+        assert torch.isfinite(lf) and abs(float(lf) - float(lc)) <= tol * max(1.0, abs(float(lc))), (tag, float(lf), float(lc))
+        for a, b in zip(gf, gc):
+            assert float((a - b).norm()) <= (100 * tol + 3e-3) * float(b.norm()) + 1e-6, (tag, float((a - b).norm()), float(b.norm()))
