@@ -212,6 +212,24 @@ static inline long long al256(long long x) { return (x + 255) & ~255LL; }
 // The V3_LSE pass (row statistics of softmax over all entities + the label's score): on the
 // loader/consumer kernel (score_pairs_bf16_v4.hip) where it applies -- d in {256, 512}, one workgroup
 // per CU -- else on the single-role kernel.  KGE_CE_V3=1 (tests, profiling) forces the latter.
+int run_pairs_bf16_v4_epi(int scorer, int epi, const Operand& A, const Operand* A2, const Operand& R,
+                          const Operand& TG, int dir, int d, long long n, long long m, hipStream_t st, void* ws,
+                          long long ws_bytes, const CeArgs& ce, unsigned long long* dbg);
+
+// the G16 pass of a backward (V3_DS / V3_DSIG): the loader/consumer kernel, else the single-role one
+static int run_ds_pass(int scorer, int epi, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG,
+                       int dir, int d, long long n, long long m, hipStream_t st, void* ws, long long coop,
+                       const CeArgs& ce, unsigned long long* dbg) {
+  const char* f = getenv("KGE_CE_V3");
+  if (!(f && f[0] == '1')) {
+    CeArgs c4 = ce;
+    if (A2 != nullptr) c4.rgn1 = 0;  // the v4 launcher takes the second side as an operand, not a marker
+    const int rc = run_pairs_bf16_v4_epi(scorer, epi, A, A2, R, TG, dir, d, n, m, st, ws, coop, c4, dbg);
+    if (rc != KGE_ERR_UNSUPPORTED) return rc;
+  }
+  return run_pairs_bf16_v3_ce(scorer, epi, A, R, TG, dir, d, n, m, st, ws, coop, ce, dbg);
+}
+
 static int run_lse_pass(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                         int d, long long n, long long m, hipStream_t st, void* ws, long long coop, const CeArgs& ce,
                         unsigned long long* dbg) {
@@ -275,7 +293,7 @@ int run_ce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   ce.g16 = (unsigned short*)((char*)ws + coop);
   ce.ld16 = ld16;
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(n * ld16 * 2));
-  const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  const int rc = run_ds_pass(scorer, V3_DS, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
 }
@@ -322,7 +340,7 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   ce.g16 = (unsigned short*)((char*)ws + coop);
   ce.ld16 = ld16;
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(n * ld16 * 2));
-  const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  const int rc = run_ds_pass(scorer, V3_DS, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(kl_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.g16, ld16, n, rowptr, col,
                      g_rows, g_scalar, label_weight);
@@ -369,7 +387,7 @@ int run_bce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& T
   ce.g16 = (unsigned short*)((char*)ws + coop);
   ce.ld16 = ld16;
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(n * ld16 * 2));
-  const int rc = run_pairs_bf16_v3_ce(scorer, V3_DSIG, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  const int rc = run_ds_pass(scorer, V3_DSIG, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(bce_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.g16, ld16, n, rowptr, col,
                      g_rows, g_scalar);
@@ -446,7 +464,7 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   ce.g16 = (unsigned short*)((char*)ws + coop);
   ce.ld16 = ld16;
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(2 * n * ld16 * 2));
-  const int rc = run_pairs_bf16_v3_ce(scorer, V3_DS, S, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  const int rc = run_ds_pass(scorer, V3_DS, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   return run_pairs_bwd_products16_two(scorer, S, O, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, acc_rel,
                                       acc_rel_ld, st);

@@ -71,6 +71,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   constexpr int TILEB = V4_TN * ROWB;    // bytes per target tile
   constexpr int NL = TILEB / 1024 / 4;   // 1-KiB DMA pieces per loader wave per tile
   constexpr int RPP = 64 / SPR;          // target rows per piece
+  constexpr bool IS_DS = EPI == V3_DS || EPI == V3_DSIG;  // writes bf16 gradients of the scores (G16)
+  constexpr bool STAGED = EPI == V3_STORE || IS_DS;       // tiles go through the staging buffer to the store waves
   constexpr int CST0 = 2 * TILEB;        // score staging: 4 x [32 rows][64 cols] f32
   constexpr int CSTW = 32 * V4_TN * 4;
   constexpr int SMEM = CST0 + 4 * CSTW;
@@ -265,7 +267,19 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
         if (r >= n) r = n - 1;
         svoff[u][i] = (unsigned int)((r - rb) * ldo * 4) + (unsigned int)(cl * 16);
       }
-      out_rb[u] = (unsigned char*)(out + rb * ldo);
+      if constexpr (IS_DS) {
+        // G16: [rows][ld16] bf16, the second side's rows behind ce.side2_off; 8 bytes (4 columns) per lane
+        const long long roff_s = second ? ce.side2_off : 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          long long r = r0 + 4 * i + rq;
+          if (r >= n) r = n - 1;
+          svoff[u][i] = (unsigned int)((r - rb) * ce.ld16 * 2) + (unsigned int)(cl * 8);
+        }
+        out_rb[u] = (unsigned char*)(ce.g16 + (rb + roff_s) * ce.ld16);
+      } else {
+        out_rb[u] = (unsigned char*)(out + rb * ldo);
+      }
     }
     f32x4 cv[2][8];
     auto read_staging = [&]() {
@@ -277,6 +291,16 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     };
     auto store_tile = [&](int tt) {
       const long long col0 = (long long)(tile_lo + tt * tile_st) * V4_TN;
+      if constexpr (IS_DS) {  // the pitch of G16 covers whole tiles (pad columns are zeros): no ragged path
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            u32x2 pk = {bf16_pack(cv[u][i][0], cv[u][i][1]), bf16_pack(cv[u][i][2], cv[u][i][3])};
+            *reinterpret_cast<u32x2*>(out_rb[u] + col0 * 2 + svoff[u][i]) = pk;
+          }
+        return;
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (col0 + V4_TN <= m) {
@@ -297,13 +321,13 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     for (int tt = 0; tt <= ntl; ++tt) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging reads of the previous step are in registers
       __builtin_amdgcn_s_barrier();  // B1(tt): the consumers may overwrite the staging buffer
-      if constexpr (EPI == V3_STORE)
+      if constexpr (STAGED)
         if (tt >= 2) store_tile(tt - 2);  // from registers, while the DMA waves issue tile tt+1
       __builtin_amdgcn_s_barrier();  // B2(tt): scores of tile tt-1 are staged
-      if constexpr (EPI == V3_STORE)
+      if constexpr (STAGED)
         if (tt >= 1) read_staging();
     }
-    if constexpr (EPI == V3_STORE) {
+    if constexpr (STAGED) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       store_tile(ntl - 1);
     }
@@ -419,6 +443,44 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     if (orow >= n) orow = n - 1;
     if (lix.ptr != nullptr) lab = index_at(lix, orow);
   }
+  float lse_i = 0.0f, g_i = 0.0f;  // V3_DS / V3_DSIG: the row's logsumexp and upstream gradient
+  if constexpr (IS_DS) {
+    const Index& lix = second ? ce.label2 : ce.label;
+    long long orow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
+    if (orow >= n) orow = n - 1;
+    if (lix.ptr != nullptr) lab = index_at(lix, orow);
+    if constexpr (EPI == V3_DS) lse_i = ce.lse[orow + roff];
+    g_i = ce.g_rows != nullptr ? ce.g_rows[orow + roff] : ce.g_scalar;
+    if (ce.rowptr != nullptr && ce.rowptr[orow + 1] == ce.rowptr[orow]) g_i = 0.0f;  // (one-sided multi-label loss)
+  }
+  // d loss / d score of a finished tile, in place of the scores (same chain, same bits as the forward):
+  // g_i * (softmax - [label]) or g_i * sigmoid(score + offset); the pad columns of the ragged last tile are
+  // zeros (the gradient products read whole 16-byte chunks of a G16 row and rely on it).
+  auto ds_tile = [&](int tt) __attribute__((always_inline)) {
+    const long long c0 = (long long)(tile_lo + tt * tile_st) * V4_TN + 4 * fh;
+    const long long rel = lab - c0;
+    const bool ragged = c0 - 4 * fh + V4_TN > m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int off = 8 * (r >> 2) + (r & 3);
+      float p0, p1;
+      if constexpr (EPI == V3_DSIG) {
+        p0 = g_i / (1.0f + __builtin_amdgcn_exp2f(-(acc0[r] + ce.offset) * V3_LOG2E));
+        p1 = g_i / (1.0f + __builtin_amdgcn_exp2f(-(acc1[r] + ce.offset) * V3_LOG2E));
+      } else {
+        p0 = __builtin_amdgcn_exp2f((acc0[r] - lse_i) * V3_LOG2E) * g_i;
+        p1 = __builtin_amdgcn_exp2f((acc1[r] - lse_i) * V3_LOG2E) * g_i;
+      }
+      if (rel == off) p0 -= g_i;
+      if (rel == 32 + off) p1 -= g_i;
+      if (ragged) {
+        p0 = c0 + off < m ? p0 : 0.0f;
+        p1 = c0 + 32 + off < m ? p1 : 0.0f;
+      }
+      acc0[r] = p0;
+      acc1[r] = p1;
+    }
+  };
   auto lse_tile = [&](int tt) __attribute__((always_inline)) {
     const long long c0 = (long long)(tile_lo + tt * tile_st) * V4_TN + 4 * fh;
     if (c0 - 4 * fh + V4_TN > m) {  // the ragged last tile of the table: columns beyond m do not exist
@@ -480,7 +542,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
     // the PREVIOUS tile's scores -> staging, behind the first reads of this tile in the LDS queue
     // (tile 0 stages zeros that nobody reads: one schedule for every tile)
-    if constexpr (EPI == V3_STORE) {
+    if constexpr (STAGED) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
 #pragma unroll
@@ -490,7 +552,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     // writes (V3_STORE) and the reads of slots 0..q-1 = 15 (7 without the writes); q >= 8: min(7, NQ-1-q) reads
     v4_static_for<0, NQ>([&](auto qc) __attribute__((always_inline)) {
       constexpr int q = decltype(qc)::value;
-      constexpr int younger = q < 8 ? (EPI == V3_STORE ? 15 : 7) : ((NQ - 1 - q >= PF - 1) ? PF - 1 : NQ - 1 - q);
+      constexpr int younger = q < 8 ? (STAGED ? 15 : 7) : ((NQ - 1 - q >= PF - 1) ? PF - 1 : NQ - 1 - q);
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(younger) : "memory");
       // first tile: fragment kb has arrived (in-order returns: at most NKB-1-kb younger loads
       // outstanding); a no-op afterwards
@@ -513,14 +575,16 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   };
   tile(0);
   if constexpr (EPI == V3_LSE) lse_tile(0);
+  if constexpr (IS_DS) ds_tile(0);
   for (int tt = 1; tt < ntl; ++tt) {
     tile(tt);
     if constexpr (EPI == V3_LSE) lse_tile(tt);
+    if constexpr (IS_DS) ds_tile(tt);
   }
   // the last tile's scores: stage them for the loaders' final pass
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // B1(ntl)
-  if constexpr (EPI == V3_STORE) {
+  if constexpr (STAGED) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
 #pragma unroll
@@ -658,19 +722,35 @@ int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Ope
 // both directions of a batch in one launch (ce.label / ce.label2, ce.side2_off).  `ws` = the fragment
 // + flag block of the cooperative build (layout of pairs_bf16_v3_workspace_bytes).  KGE_ERR_UNSUPPORTED:
 // the caller uses the single-role kernel.
+int run_pairs_bf16_v4_epi(int scorer, int epi, const Operand& A, const Operand* A2, const Operand& R,
+                          const Operand& TG, int dir, int d, long long n, long long m, hipStream_t st, void* ws,
+                          long long ws_bytes, const CeArgs& ce, unsigned long long* dbg);
+
 int run_pairs_bf16_v4_lse(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG,
                           int dir, int d, long long n, long long m, hipStream_t st, void* ws, long long ws_bytes,
                           const CeArgs& ce, unsigned long long* dbg) {
+  return run_pairs_bf16_v4_epi(scorer, V3_LSE, A, A2, R, TG, dir, d, n, m, st, ws, ws_bytes, ce, dbg);
+}
+
+// Any fused-loss epilogue on the loader/consumer kernel: V3_LSE (forward), V3_DS / V3_DSIG (the G16 pass of
+// the backward: the consumers turn a finished tile into d loss / d score in place, the store waves round to
+// bf16 and write 8 bytes per lane).  V3_SPLUS stays on the single-role kernel.
+int run_pairs_bf16_v4_epi(int scorer, int epi, const Operand& A, const Operand* A2, const Operand& R,
+                          const Operand& TG, int dir, int d, long long n, long long m, hipStream_t st, void* ws,
+                          long long ws_bytes, const CeArgs& ce, unsigned long long* dbg) {
   if (n == 0 || m == 0) return KGE_OK;
   if (TG.idx.ptr != nullptr) return KGE_ERR_UNSUPPORTED;
-#define KGE_V4E(SC)                                                                                       \
+#define KGE_V4E(SC, EP)                                                                                    \
   switch (d) {                                                                                            \
     case 256:                                                                                             \
-      return launch_v4<SC, 128, V3_LSE>(A, A2, R, TG, dir, n, m, nullptr, 1, 0, st, dbg, ws, ws_bytes, 0, ce); \
+      return launch_v4<SC, 128, EP>(A, A2, R, TG, dir, n, m, nullptr, 1, 0, st, dbg, ws, ws_bytes, 0, ce); \
     case 512:                                                                                             \
-      return launch_v4<SC, 256, V3_LSE>(A, A2, R, TG, dir, n, m, nullptr, 1, 0, st, dbg, ws, ws_bytes, 0, ce); \
+      return launch_v4<SC, 256, EP>(A, A2, R, TG, dir, n, m, nullptr, 1, 0, st, dbg, ws, ws_bytes, 0, ce); \
   }
-  if (scorer == KGE_COMPLEX) { KGE_V4E(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_V4E(KGE_DISTMULT) }
+#define KGE_V4S(EP)                                                                                              \
+  if (scorer == KGE_COMPLEX) { KGE_V4E(KGE_COMPLEX, EP) } else if (scorer == KGE_DISTMULT) { KGE_V4E(KGE_DISTMULT, EP) }
+  if (epi == V3_LSE) { KGE_V4S(V3_LSE) } else if (epi == V3_DS) { KGE_V4S(V3_DS) } else if (epi == V3_DSIG) { KGE_V4S(V3_DSIG) }
+#undef KGE_V4S
 #undef KGE_V4E
   return KGE_ERR_UNSUPPORTED;
 }

@@ -162,6 +162,36 @@ def test_ce_bwd(eng, model, d, E, R, n, scale):
         assert torch.equal(c_a, v_a) and torch.equal(c_p, v_p) and torch.equal(c_t, v_t)
 
 
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5] + CASES[6:8])
+def test_fused_loss_on_both_kernel_generations(eng, monkeypatch, model, d, E, R, n, scale):
+    """The forward (V3_LSE) and the gradient pass (V3_DS / V3_DSIG) run on the loader/consumer kernel for
+    d in {256, 512} and on the single-role kernel otherwise; KGE_CE_V3=1 forces the latter.  Same tiles, same
+    chains, same per-lane order: the two must agree to float32 rounding of the merged row statistics, one-
+    and two-sided, cross entropy and BCE."""
+    ent, rel, s, p, o = _case(7 * d + n, model, d, E, R, n, scale)
+    T = _tables(eng, model, ent, rel)
+    ts, tp, to = _t(s), _t(p), _t(o)
+    rowptr = torch.arange(n + 1, device=DEV, dtype=torch.int64)
+
+    def run():
+        loss, lse = eng.ce_fwd(T, "sp", ts, tp, to)
+        grads = eng.ce_bwd(T, "sp", ts, tp, to, lse, g_scalar=1.0 / n)
+        l2, z2 = eng.ce_sp_po_fwd(T, ts, tp, to)
+        g2 = eng.ce_sp_po_bwd(T, ts, tp, to, z2, g_scalar=1.0 / n)
+        bl = eng.bce_fwd(T, "po", to, tp, rowptr, ts, -0.25)
+        bg = eng.bce_bwd(T, "po", to, tp, rowptr, ts, -0.25, g_scalar=1.0 / n)
+        return [loss, lse, *grads, l2, z2, *g2, bl, *bg]
+
+    monkeypatch.setenv("KGE_CE_V3", "0")
+    new = run()
+    monkeypatch.setenv("KGE_CE_V3", "1")
+    old = run()
+    for k, (a_, b_) in enumerate(zip(new, old)):
+        assert a_.shape == b_.shape and not torch.isnan(a_).any(), k
+        den = float(b_.abs().max()) + 1e-30
+        assert float((a_ - b_).abs().max()) <= 2e-6 * den + 1e-7, (k, float((a_ - b_).abs().max()), den)
+
+
 def test_ce_unsupported_tables_fail_loudly(eng):
     ent, rel, s, p, o = _case(11, "complex", 128, 100, 3, 10)
     Tf = eng.Tables("complex", torch.from_numpy(ent).to(DEV), torch.from_numpy(rel).to(DEV), 1.0)
