@@ -21,6 +21,11 @@ for a, b in (("plugin_gpu.jsonl", "libkge_plugin_gpu.jsonl"), ("bshape_ranks.jso
              ("bench_dist1_fb15k.json", "bench_dist1rank_fb15k.json")):
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"{dst}/{tag}_{b}")
+# the rank-parity log holds the FB15k-237-shape lines and (tagged "shape": "wn18rr") the WN18RR-shape ones
+if os.path.exists(f"{src}/bshape_ranks.jsonl"):
+    lines = open(f"{src}/bshape_ranks.jsonl").read().splitlines()
+    open(f"{dst}/{tag}_bshape_ranks.jsonl", "w").write("".join(l + "\n" for l in lines if '"wn18rr"' not in l))
+    open(f"{dst}/{tag}_wshape_ranks.jsonl", "w").write("".join(l + "\n" for l in lines if '"wn18rr"' in l))
 if os.path.exists(f"{src}/bench.json"):
     rows = [ln for ln in open(f"{src}/bench.json") if ln.startswith("{")]
     open(f"{dst}/{tag}_bench.json", "w").write("".join(rows))
