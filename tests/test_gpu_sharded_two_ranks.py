@@ -1,0 +1,137 @@
+"""ShardedEntityTable with the REAL engine in TWO processes (both on cuda:0; a 1-GPU box cannot host two RCCL
+ranks, so the process group is gloo and, in these workers only, the three collectives the class uses are
+staged through host memory).  What this adds over the other sharded tests: the gloo CPU tests run the
+choreography on a fake backend, the one-rank GPU tests run the kernels with identity collectives -- here the
+shard arithmetic (ragged shards, owner / pick indices of the exchange, cross-shard log-sum-exp, the all-reduce of
+the query-row gradients, rank-count sums, top-k merge) meets the HIP kernels across two real ranks.
+Checked against the unsharded engine on the same tables: rank / tie counts and top-k exactly, the sharded 1vsAll
+loss to float32 rounding of the merged statistics, both table gradients."""
+import os
+import socket
+import time
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _host_staged_collectives():
+    """gloo moves host tensors: stage the device tensors of the three collectives through the host."""
+    agt, ar, ag = dist.all_gather_into_tensor, dist.all_reduce, dist.all_gather
+
+    def all_gather_into_tensor(out, inp, group=None):
+        o = torch.empty(out.shape, dtype=out.dtype if out.dtype != torch.bfloat16 else torch.float32)
+        agt(o, inp.detach().to("cpu", dtype=o.dtype).contiguous(), group=group)
+        out.copy_(o.to(out.dtype))
+
+    def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+        h = t.detach().cpu()
+        ar(h, op=op, group=group)
+        t.copy_(h)
+
+    def all_gather(outs, t, group=None):
+        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        ag(hs, t.detach().cpu(), group=group)
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+
+    dist.all_gather_into_tensor, dist.all_reduce, dist.all_gather = all_gather_into_tensor, all_reduce, all_gather
+
+
+def _worker(rank, world, port, model, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _host_staged_collectives()
+        from kge_amd.sharded import ShardedEntityTable
+        E, R, d, n = 1000 + 37, 5, 256, 96   # odd E: ragged shards (519 + 518 rows)
+        g = torch.Generator().manual_seed(3)
+        ent = (torch.randn(E, d, generator=g) * 0.3)
+        rel = (torch.randn(R, d, generator=g) * 0.3)
+        tri = torch.stack([torch.randint(E, (n,), generator=g), torch.randint(R, (n,), generator=g),
+                           torch.randint(E, (n,), generator=g)], 1).to(DEV)
+        w = (torch.rand(2 * n, generator=g) + 0.5).to(DEV)
+        lo, hi = ShardedEntityTable.partition(E, world, rank)
+        ent_m = ent[lo:hi].clone().to(DEV).requires_grad_(True)
+        rel_m = rel.clone().to(DEV).requires_grad_(True)
+        sh = ShardedEntityTable(model, ent_m.detach().bfloat16(), rel_m.detach().bfloat16(), E)
+        assert sh.world == 2 and sh.collectives
+        s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
+        ranks = [x.cpu().numpy() for x in sh.rank_batch(tri, None)]
+        tv, ti = sh.topk(sh.score_sp(s, p), 7)
+        loss = torch.cat([sh.ce_loss("sp", s, p, o, ent_m, rel_m), sh.ce_loss("po", o, p, s, ent_m, rel_m)])
+        (loss * w).sum().backward()
+        torch.cuda.synchronize()
+        q.put((rank, lo, hi, ranks, tv.cpu().numpy(), ti.cpu().numpy(), loss.detach().cpu().numpy(),
+               ent_m.grad.cpu().numpy(), rel_m.grad.cpu().numpy(), ent.numpy(), rel.numpy(), tri.cpu().numpy(),
+               w.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["complex", "distmult"])
+def test_two_ranks_on_the_real_kernels(model):
+    from kge_amd import engine as eng
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, model, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs, t0 = [], time.time()
+    while len(outs) < world and time.time() - t0 < 240:  # a crashed worker must fail the test, not hang it
+        if not q.empty():
+            outs.append(q.get())
+        elif any(pr.exitcode not in (None, 0) for pr in procs):
+            break
+        else:
+            time.sleep(0.05)
+    for pr in procs:
+        pr.join(60)
+        if pr.is_alive():
+            pr.kill()
+    assert len(outs) == world, [pr.exitcode for pr in procs]
+    outs.sort(key=lambda x: x[0])
+    ent, rel, tri, w = (torch.from_numpy(outs[0][k]) for k in (9, 10, 11, 12))
+    E, n = ent.shape[0], tri.shape[0]
+    e16, r16 = ent.bfloat16().to(DEV), rel.bfloat16().to(DEV)
+    T = eng.Tables(model, e16, r16)
+    s, p, o = (tri[:, k].to(DEV) for k in range(3))
+    both = eng.score_sp_po(T, s, p, o)
+    ar = torch.arange(n, device=DEV)
+    r_o, t_o = eng.rank_counts(both[:, :E].contiguous(), both[ar, o], None, None, 0, o)
+    r_s, t_s = eng.rank_counts(both[:, E:].contiguous(), both[ar, E + s], None, None, 0, s)
+    want_ranks = [x.cpu().numpy() for x in (r_s, t_s, r_o, t_o)]
+    tv, ti = torch.topk(both[:, :E], 7, dim=1)
+    # the unsharded fused loss and its gradients on the same bf16 tables
+    l_sp, z_sp = eng.ce_fwd(T, "sp", s, p, o)
+    l_po, z_po = eng.ce_fwd(T, "po", o, p, s)
+    ge, gr = torch.zeros(E, ent.shape[1], device=DEV), torch.zeros(rel.shape[0], rel.shape[1], device=DEV)
+    wd = w.to(DEV)
+    for direction, a, lab, lse, ww in (("sp", s, o, z_sp, wd[:n]), ("po", o, s, z_po, wd[n:])):
+        g_a, g_p, g_t = eng.ce_bwd(T, direction, a, p, lab, lse, g_rows=ww.contiguous())
+        ge += g_t
+        ge.index_add_(0, a, g_a)
+        gr.index_add_(0, p, g_p)
+    want_loss = torch.cat([l_sp, l_po]).cpu().numpy()
+    for rank, lo, hi, ranks, rtv, rti, loss, g_ent, g_rel, *_ in outs:
+        for a_, b_ in zip(ranks, want_ranks):
+            assert np.array_equal(a_, b_), (model, rank)
+        assert np.array_equal(rtv, tv.cpu().numpy()), (model, rank)
+        assert np.array_equal(np.take_along_axis(both[:, :E].cpu().numpy(), rti, 1), rtv), (model, rank)
+        assert np.allclose(loss, want_loss, rtol=2e-5, atol=2e-5), (model, rank)
+        we = ge[lo:hi].cpu().numpy()
+        assert np.linalg.norm(g_ent - we) <= 2e-3 * np.linalg.norm(we), (model, rank)
+        wr = gr.cpu().numpy()
+        assert np.linalg.norm(g_rel - wr) <= 2e-3 * np.linalg.norm(wr), (model, rank)
