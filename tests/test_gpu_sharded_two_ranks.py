@@ -70,12 +70,17 @@ def _worker(rank, world, port, model, q):
         s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
         ranks = [x.cpu().numpy() for x in sh.rank_batch(tri, None)]
         tv, ti = sh.topk(sh.score_sp(s, p), 7)
+        blk_sp, blk_po = (x.clone() for x in sh.score_sp_po_blocks(s, p, o))  # the step bench.py --gpus N times
+        small, sh.BIG_SLAB_BYTES = sh.BIG_SLAB_BYTES, 0                      # ... and its big-slab form (padded pitch,
+        big_sp, big_po = (x.clone() for x in sh.score_sp_po_blocks(s, p, o))  #     one launch per direction)
+        sh.BIG_SLAB_BYTES = small
+        assert torch.equal(big_sp, blk_sp) and torch.equal(big_po, blk_po)
         loss = torch.cat([sh.ce_loss("sp", s, p, o, ent_m, rel_m), sh.ce_loss("po", o, p, s, ent_m, rel_m)])
         (loss * w).sum().backward()
         torch.cuda.synchronize()
         q.put((rank, lo, hi, ranks, tv.cpu().numpy(), ti.cpu().numpy(), loss.detach().cpu().numpy(),
                ent_m.grad.cpu().numpy(), rel_m.grad.cpu().numpy(), ent.numpy(), rel.numpy(), tri.cpu().numpy(),
-               w.cpu().numpy()))
+               w.cpu().numpy(), blk_sp.cpu().numpy(), blk_po.cpu().numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -125,7 +130,10 @@ def test_two_ranks_on_the_real_kernels(model):
         ge.index_add_(0, a, g_a)
         gr.index_add_(0, p, g_p)
     want_loss = torch.cat([l_sp, l_po]).cpu().numpy()
-    for rank, lo, hi, ranks, rtv, rti, loss, g_ent, g_rel, *_ in outs:
+    for rank, lo, hi, ranks, rtv, rti, loss, g_ent, g_rel, *rest in outs:
+        # the shard's score blocks are the unsharded matrix's columns, bit for bit
+        assert np.array_equal(rest[4], both[:, lo:hi].cpu().numpy()), (model, rank, "sp block")
+        assert np.array_equal(rest[5], both[:, E + lo:E + hi].cpu().numpy()), (model, rank, "po block")
         for a_, b_ in zip(ranks, want_ranks):
             assert np.array_equal(a_, b_), (model, rank)
         assert np.array_equal(rtv, tv.cpu().numpy()), (model, rank)
