@@ -60,6 +60,18 @@ class _FusedScoring:
     def _w(self):
         return (self.get_s_embedder()._embeddings.weight, self.get_p_embedder()._embeddings.weight)
 
+    def penalty(self, **kwargs):
+        """KgeModel.penalty (kge_model.py:603-640) first copies the batch's triples to the device -- a blocking
+        host-to-device copy in every batch -- and then asks the embedders, which answer with nothing when their
+        `regularize_weight` is 0 (the default; lookup_embedder.py:122-126).  In exactly that case (plain
+        LookupEmbedders, no penalty configured) the result is the empty list either way; the copy is skipped
+        (0.1 ms of the 0.5 ms a fused 1vsAll batch takes through the trainer).  Anything else: the reference's code."""
+        from kge.model import LookupEmbedder
+        for e in {id(x): x for x in (self.get_s_embedder(), self.get_o_embedder(), self.get_p_embedder())}.values():
+            if type(e) is not LookupEmbedder or not (e.regularize == "" or e.get_option("regularize_weight") == 0.0):
+                return super().penalty(**kwargs)
+        return []
+
     def _fwd_tables(self):
         """`score_dtype: bfloat16` (hip_complex.yaml / hip_distmult.yaml) with float32 parameters:
         sp_/_po scores come from the bf16 matrix-core kernel on bf16 copies of the tables (re-cast

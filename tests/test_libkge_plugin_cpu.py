@@ -48,6 +48,37 @@ def test_plugin_is_discovered_and_keeps_parameter_names(model):
             call()
 
 
+@pytest.mark.parametrize("model", MODELS)
+def test_penalty_shortcut_equals_the_reference_penalty(model):
+    """The plugin models skip KgeModel.penalty's per-batch host-to-device copy when no penalty is configured
+    (the default: regularize_weight 0) -- the reference then returns the empty list too -- and hand everything
+    else to the reference's code: same names, same values as the reference model with the same weights."""
+    config = _config(model)  # (imports the reference)
+    from kge import Dataset
+    from kge.model import KgeModel
+    batch = {"triples": torch.tensor([[1, 0, 5], [2, 3, 6], [1, 1, 7]])}
+    kw = dict(epoch=1, batch_index=0, num_batches=1, batch=batch)
+    m = KgeModel.create(config, Dataset(config, folder=None))
+    ref_config = _config(model[4:])
+    ref = KgeModel.create(ref_config, Dataset(ref_config, folder=None))
+    assert m.penalty(**kw) == [] and ref.penalty(**kw) == []
+    for weighted in (False, True):
+        cfgs = []
+        for name in (model, model[4:]):
+            c = _config(name)
+            c.set("lookup_embedder.regularize_weight", 0.3)
+            c.set("lookup_embedder.regularize_args.weighted", weighted)
+            cfgs.append(c)
+        m = KgeModel.create(cfgs[0], Dataset(cfgs[0], folder=None))
+        ref = KgeModel.create(cfgs[1], Dataset(cfgs[1], folder=None))
+        ref.load_state_dict(m.state_dict())
+        got, want = m.penalty(**kw), ref.penalty(**kw)
+        assert len(got) == len(want) > 0
+        for (gk, gv), (wk, wv) in zip(got, want):
+            assert gk.replace("hip_", "") == wk
+            torch.testing.assert_close(gv, wv)
+
+
 @pytest.mark.parametrize("model", ["hip_complex", "hip_distmult"])
 def test_mixed_precision_option(model):
     """`score_dtype` defaults to float32 (no bf16 copies); bfloat16 selects the bf16 copies, which
