@@ -12,6 +12,21 @@ from .. import engine
 from ..eval import FilterIndex
 
 
+class _SliceLoader:
+    """len() and iteration of DataLoader(triples, batch_size=b, shuffle=False) with the fast path's collate:
+    one-element tuples of consecutive [<= b, 3] slices."""
+
+    def __init__(self, triples, batch_size):
+        self.triples, self.batch_size = triples, int(batch_size)
+
+    def __len__(self):
+        return (len(self.triples) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for b0 in range(0, len(self.triples), self.batch_size):
+            yield (self.triples[b0:b0 + self.batch_size],)
+
+
 class HipEntityRankingJob(EntityRankingJob):
     """`EntityRankingJob._evaluate` (eval_entity_ranking.py:103-481) without its per-batch host work.
 
@@ -76,14 +91,19 @@ class HipEntityRankingJob(EntityRankingJob):
 
         self._hip_sp = [dev_arrays(i._sp) for i in idx]
         self._hip_po = [dev_arrays(i._po) for i in idx]
-        self.loader = torch.utils.data.DataLoader(
-            self.triples,
-            collate_fn=lambda batch: (torch.cat(batch).reshape((-1, 3)),),
-            shuffle=False,
-            batch_size=self.batch_size,
-            num_workers=self.config.get("eval.num_workers"),
-            pin_memory=self.config.get("eval.pin_memory"),
-        )
+        if self.config.get("eval.num_workers") == 0 and not self.config.get("eval.pin_memory"):
+            # same batches in the same order as the DataLoader below (shuffle=False), without indexing the
+            # triple tensor row by row and concatenating 512 one-row tensors per batch (0.45 ms per batch)
+            self.loader = _SliceLoader(self.triples, self.batch_size)
+        else:
+            self.loader = torch.utils.data.DataLoader(
+                self.triples,
+                collate_fn=lambda batch: (torch.cat(batch).reshape((-1, 3)),),
+                shuffle=False,
+                batch_size=self.batch_size,
+                num_workers=self.config.get("eval.num_workers"),
+                pin_memory=self.config.get("eval.pin_memory"),
+            )
 
     @torch.no_grad()
     def _evaluate(self):
