@@ -13,6 +13,8 @@ Per shape:
   * the fused 1vsAll loss (kge_ce_fwd) against float64 cross entropy of those very scores, no NaN;
   * rank counts of the scores against the oracle's rank core on the same matrix (integers, exact).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -21,6 +23,7 @@ import oracle as ko
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+MULT = int(os.environ.get("KGE_FUZZ_MULT", "1"))  # KGE_FUZZ_MULT=8: eight times the seeds (one-off soak runs)
 RES = [0, 1, 2, 3, 4, 5, 31, 32, 33, 59, 60, 61, 62, 63]
 NS = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 200, 257, 511, 513, 700]
 
@@ -39,7 +42,7 @@ def _t(x):
     return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
 
 
-@pytest.mark.parametrize("seed", range(36))
+@pytest.mark.parametrize("seed", range(36 * MULT))
 def test_random_shape(seed):
     from kge_amd import engine as eng
     model, d, E, n, rng = _shape(seed)
@@ -93,7 +96,7 @@ def test_random_shape(seed):
     assert np.array_equal(rank.cpu().numpy(), w_rank) and np.array_equal(ties.cpu().numpy(), w_ties), tag
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", range(14 * MULT))
 def test_random_shape_training_step(seed):
     """The fused two-sided 1vsAll loss (kge_ce_sp_po_fwd / _bwd: scoring kernel epilogues + the hand-written
     gradient products of bwd_gemm16.hip, rows = 2 n and m = E as the fuzz draws them) against the composed
@@ -126,7 +129,7 @@ def test_random_shape_training_step(seed):
         assert float((a - b).norm()) <= 3e-3 * denom + 1e-6, (tag, float((a - b).norm()), denom)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * MULT))
 def test_random_shape_f32_paths_bit_exact(seed):
     """All four scorers on float32 tables (the parity path), random d -- odd, tiny, not a multiple of any tile
     -- and random sizes, index dtypes and strides: spo / sp_ / _po / sp_po / listed subsets / negatives
@@ -171,7 +174,7 @@ def test_random_shape_f32_paths_bit_exact(seed):
     eq("neg_o", eng.score_neg(T, ts, tp, to, 2, tneg), ko.score_neg(O, s, p, o, 2, neg))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * MULT))
 def test_random_shape_kvsall_losses(seed):
     """KvsAll: the fused KL / BCE losses with and without label smoothing (kge_kl_fwd / kge_kl_weighted_fwd /
     kge_bce_fwd + the linear column-sum term) against the composed path (scores -> dense smoothed labels ->
@@ -213,7 +216,7 @@ def test_random_shape_kvsall_losses(seed):
             assert float((a - b).norm()) <= (100 * tol + 3e-3) * float(b.norm()) + 1e-6, (tag, float((a - b).norm()), float(b.norm()))
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * MULT))
 def test_random_dataset_entity_ranking(seed):
     """The sync-free evaluation loop (device-resident filter index, kge_filter_lookup, kge_rank_counts_multi,
     column chunks) on random small datasets with duplicate triples, heavy (s, p) collisions and unknown keys:
@@ -247,3 +250,39 @@ def test_random_dataset_entity_ranking(seed):
         s_r, o_r = ko.evaluate_ranks(O, valid, a, b, chunk_size=chunk)
         assert np.array_equal(ranks["o" + key], o_r), (tag, "o" + key)
         assert np.array_equal(ranks["s" + key], s_r), (tag, "s" + key)
+
+
+@pytest.mark.parametrize("seed", range(16 * MULT))
+def test_random_shape_gradient_products(seed):
+    """bwd_gemm16.hip on its own at random ragged shapes (rows, m, d; G16 pitch = m rounded up to 8 .. 64, pad
+    columns zero as the producers leave them), with and without room for split-K partials: dQ = G16 * T and
+    dT = G16^T * Q16 against float64 products of the same bf16 operands."""
+    import ctypes
+    from kge_amd import _lib
+    rng = np.random.default_rng(7000 + seed)
+    rows = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 300, 511, 513, 1024, 1500, 2049]))
+    m = int(rng.choice([1, 7, 63, 64, 65, 200, 1000, 4097, 14541, 20011]))
+    d = int(rng.choice([256, 512, 768]))
+    mp = (m + 7) // 8 * 8 if seed % 2 else (m + 63) // 64 * 64
+    g16 = torch.zeros(rows, mp, dtype=torch.bfloat16, device=DEV)
+    g16[:, :m] = torch.from_numpy(rng.standard_normal((rows, m)).astype(np.float32)).to(DEV).bfloat16()
+    T = torch.from_numpy((rng.standard_normal((m, d)) * 0.5).astype(np.float32)).to(DEV).bfloat16()
+    Q = torch.from_numpy((rng.standard_normal((rows, d)) * 0.5).astype(np.float32)).to(DEV).bfloat16()
+    fn = _lib.lib().kge_debug_gemm16
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_int64, ctypes.c_void_p]
+    G = g16[:, :m].double()
+    st = torch.cuda.current_stream().cuda_stream
+    tag = f"rows={rows} m={m} d={d} mp={mp}"
+    for which, x, want in ((0, T, G @ T.double()), (1, Q, G.t() @ Q.double())):
+        for scratch_mb in ((24, 0) if which == 0 else (0,)):
+            out = torch.full(tuple(want.shape), float("nan"), dtype=torch.float32, device=DEV)
+            scratch = torch.empty(max(1, scratch_mb << 20), dtype=torch.uint8, device=DEV)
+            rc = fn(which, 0, d, rows, m, x.data_ptr(), x.stride(0), g16.data_ptr(), mp, out.data_ptr(),
+                    scratch.data_ptr() if scratch_mb else None, scratch_mb << 20, st)
+            torch.cuda.synchronize()
+            assert rc == 0, (tag, which, rc)
+            err = float((out.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+            assert err <= 3e-6, (tag, which, scratch_mb, err)
