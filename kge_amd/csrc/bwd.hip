@@ -350,11 +350,14 @@ __global__ __launch_bounds__(256) void bwd_spo_accum_kernel(Operand S, Operand R
                                                             const float* __restrict__ gout,
                                                             const float* __restrict__ scores,
                                                             float* __restrict__ ge, long long ge_ld,
-                                                            float* __restrict__ gr, long long gr_ld) {
+                                                            float* __restrict__ gr, long long gr_ld, int ch) {
+  // `ch` triples per wave: SPA_CH for the n*K triples of a negative-sampling batch (runs of equal s / p are
+  // summed in registers), fewer when there are few triples -- a wave walks its chunk sequentially (index ->
+  // rows -> atomics per triple), and the 512 positives of a batch in 16 chunks of 32 took 77 us of latency
   const long long chunk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long i0 = chunk * SPA_CH;
+  const long long i0 = chunk * ch;
   if (i0 >= n) return;
-  const long long i1 = i0 + SPA_CH < n ? i0 + SPA_CH : n;
+  const long long i1 = i0 + ch < n ? i0 + ch : n;
   const int lane = threadIdx.x & 63;
   const int hh = (d + 1) / 2, lim1 = d - hh;
   const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;
@@ -637,12 +640,16 @@ int run_spo_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, 
   const int norm = norm_mode(lp);
   const bool dot = scorer == KGE_COMPLEX || scorer == KGE_DISTMULT;
   if (!dot && norm != NORM_L1 && !scores) return KGE_ERR_INVALID_ARG;
-  const long long chunks = (n + SPA_CH - 1) / SPA_CH;
+  long long chl = n / 4096;  // ~4 k waves before the chunks grow
+  if (chl < 1) chl = 1;
+  if (chl > SPA_CH) chl = SPA_CH;
+  const int ch = (int)chl;
+  const long long chunks = (n + ch - 1) / ch;
   const dim3 grid((unsigned)((chunks + 3) / 4));
 #define KGE_SA(SC, NM)                                                                                \
   {                                                                                                   \
     hipLaunchKernelGGL((bwd_spo_accum_kernel<SC, NM>), grid, dim3(256), 0, st, S, R, O, d, dr, n, lp,  \
-                       gout, scores, ge, ge_ld, gr, gr_ld);                                           \
+                       gout, scores, ge, ge_ld, gr, gr_ld, ch);                                       \
     return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;                                 \
   }
   switch (scorer) {
