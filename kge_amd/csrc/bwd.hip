@@ -427,14 +427,14 @@ constexpr int NGA_CH = 64;
 template <int SCORER, int NORM, int SLOT>
 __global__ __launch_bounds__(256) void bwd_neg_accum_kernel(
     Operand S, Operand R, Operand O, int d, int dr, long long n, const void* __restrict__ neg,
-    int neg_itype, long long neg_ld, long long K, int chunks_per_row, float lp,
+    int neg_itype, long long neg_ld, long long K, int chunks_per_row, int ch, float lp,
     const float* __restrict__ gout, long long ldg, const float* __restrict__ scores, long long lds,
     float* __restrict__ ge, long long ge_ld, float* __restrict__ gr, long long gr_ld) {
   const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const long long row = w / chunks_per_row;
   if (row >= n) return;
-  const long long k0 = (w % chunks_per_row) * NGA_CH;
-  const long long k1 = k0 + NGA_CH < K ? k0 + NGA_CH : K;
+  const long long k0 = (w % chunks_per_row) * ch;
+  const long long k1 = k0 + ch < K ? k0 + ch : K;
   const int lane = threadIdx.x & 63;
   const int hh = (d + 1) / 2, lim1 = d - hh;
   const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;
@@ -505,13 +505,20 @@ int run_neg_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, 
   const int norm = norm_mode(lp);
   const bool dot = scorer == KGE_COMPLEX || scorer == KGE_DISTMULT;
   if (!dot && norm != NORM_L1 && !scores) return KGE_ERR_INVALID_ARG;
-  const long long cpr = (K + NGA_CH - 1) / NGA_CH;
+  // negatives per wave: NGA_CH for large batches; fewer when n * K is small -- a wave walks its negatives one
+  // after the other (index -> row -> atomics), and 1,024 waves of 64 left the chip latency-bound (90 us for
+  // 512 x 100 negatives); ~8 k waves hide it
+  long long chl = n * K / 8192;
+  if (chl < 4) chl = 4;
+  if (chl > NGA_CH) chl = NGA_CH;
+  const int ch = (int)chl;
+  const long long cpr = (K + ch - 1) / ch;
   const long long waves = n * cpr;
   if (cpr > (1LL << 30) || (waves + 3) / 4 > 0x7fffffffLL) return KGE_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)((waves + 3) / 4));
 #define KGE_NA2(SC, NM, SL)                                                                         \
   hipLaunchKernelGGL((bwd_neg_accum_kernel<SC, NM, SL>), grid, dim3(256), 0, st, S, R, O, d, dr, n,  \
-                     neg, neg_itype, neg_ld, K, (int)cpr, lp, gout, ldg, scores, lds, ge, ge_ld, gr, \
+                     neg, neg_itype, neg_ld, K, (int)cpr, ch, lp, gout, ldg, scores, lds, ge, ge_ld, gr, \
                      gr_ld)
 #define KGE_NA(SC, NM)                                                \
   {                                                                   \
