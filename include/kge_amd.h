@@ -361,6 +361,8 @@ int kge_kl_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n
  * from the fused kernels:
  *   loss_rows[i] = lse[i] - w_i * sum_{j in labels_i} score(i, j)              (rows without labels: lse[i])
  *   d / d score(i, j) of sum_i g_i loss_rows[i] = g_i * (softmax_ij - w_i [j in labels_i])
+ *   (kge_kl_weighted_bwd with label_bias b != NULL: g_i * (softmax_ij - b_i - w_i [j in labels_i]), i.e. the
+ *   gradient of loss_rows[i] - b_i * sum_j score(i, j): the uniform term below, taken inside the kernel)
  * With Z_i = (1 - eps) k_i + 1, a_i = ((1 - eps) + 1/E) / Z_i, b_i = (1/E) / Z_i the smoothed loss of row i is
  *   loss_rows[i] (w_i = a_i - b_i)  -  b_i * sum_j score(i, j)  +  k_i a_i log a_i + (E - k_i) b_i log b_i;
  * the middle term is linear in the entity table (sum_j score(i, j) = score of row i against the table's
@@ -371,7 +373,8 @@ int kge_kl_weighted_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
                         void* stream);
 int kge_kl_weighted_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
                         const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
-                        const float* lse, const float* g_rows, float g_scalar, float* g_a, float* g_p,
+                        const float* label_bias /* [n] or NULL */, const float* lse, const float* g_rows,
+                        float g_scalar, float* g_a, float* g_p,
                         float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Binary cross entropy with logits against the rows' multi-hot labels (CSR as for kge_kl_fwd), summed

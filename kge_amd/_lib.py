@@ -70,7 +70,7 @@ PROTOTYPES = {
     "kge_score_bwd_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),
     "kge_kl_weighted_fwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_i64, c_vp]),
-    "kge_kl_weighted_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+    "kge_kl_weighted_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_ce_emb_fwd": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, KgeIndex, c_i64, c_vp, c_vp,
                                       c_vp, c_i64, c_vp]),

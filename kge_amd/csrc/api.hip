@@ -102,7 +102,7 @@ int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
 int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, const float* lse, const float* g_rows,
                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
-               const float* label_weight = nullptr);
+               const float* label_weight = nullptr, const float* label_bias = nullptr);
 void set_g16_dbg(unsigned long long* p);
 int run_debug_gemm16(int which, int lib, int d, long long rows, long long m, const unsigned short* X, long long ldx,
                      const unsigned short* G16, long long mp, float* out, float* scratch, long long scratch_bytes,
@@ -636,7 +636,7 @@ int kge_kl_weighted_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
 
 int kge_kl_weighted_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
                         const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
-                        const float* lse, const float* g_rows, float g_scalar, float* g_a, float* g_p,
+                        const float* label_bias, const float* lse, const float* g_rows, float g_scalar, float* g_a, float* g_p,
                         float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream) {
   const kge_index none = {nullptr, 0, 0, 1};
   int rc = check_tables(t, true);
@@ -649,7 +649,7 @@ int kge_kl_weighted_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
     return KGE_ERR_UNSUPPORTED;
   return run_kl_bwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, none), dir, (int)t->dim, n, t->num_ent,
                     (const long long*)lbl_rowptr, (const long long*)lbl_col, lse, g_rows, g_scalar, g_a, g_p, g_tgt,
-                    workspace, workspace_bytes, (hipStream_t)stream, label_weight);
+                    workspace, workspace_bytes, (hipStream_t)stream, label_weight, label_bias);
 }
 
 int kge_kl_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,

@@ -325,7 +325,7 @@ int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
 int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, const float* lse, const float* g_rows,
                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
-               const float* label_weight) {
+               const float* label_weight, const float* label_bias) {
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
@@ -334,6 +334,7 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   // rows without labels: zero gradient (all-zero label rows normalise to zero) -- but not under label
   // smoothing (label_weight given), where every row's label distribution has mass on every entity
   ce.rowptr = label_weight != nullptr ? nullptr : rowptr;
+  ce.row_bias = label_bias;  // the uniform mass of smoothed labels, subtracted at every column inside the kernel
   ce.lse = lse;
   ce.g_rows = g_rows;
   ce.g_scalar = g_scalar;

@@ -340,6 +340,8 @@ struct CeArgs {
   float* part;              // V3_LSE: [n][ncg][2] per-column-group (max, sum exp)
   float* true_score;        // V3_LSE: [n] score(i, label_i)
   const float* lse;         // V3_DS: [n] logsumexp of row i
+  const float* row_bias;    // V3_DS: [n] or NULL: d loss_i / d score_ij = g_i * (softmax_ij - row_bias[i]) - (labels);
+                            // the uniform part of smoothed labels (kge_kl_weighted_bwd)
   const float* g_rows;      // V3_DS / V3_DSIG: [n] upstream gradient of row i's loss, or NULL: g_scalar
   float g_scalar;
   float offset;             // V3_SPLUS / V3_DSIG: added to every score (train.loss_arg of the bce loss)

@@ -314,13 +314,14 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   float rsum = 0.0f;              //         running sum of exp(score - rmax)
   float tsc = 0.0f;               //         score(row, label) if one of this lane's columns
   bool tfound = false;
-  float lse_i = 0.0f, g_i = 0.0f; // V3_DS
+  float lse_i = 0.0f, g_i = 0.0f, gb_i = 0.0f; // V3_DS (gb_i = g_i * row_bias[i])
   if constexpr (EPI != V3_STORE) {
     if (lab_ix.ptr != nullptr) lab = index_at(lab_ix, orow);
     if constexpr (IS_DS) {
       if constexpr (EPI == V3_DS) lse_i = ce.lse[orow + roff];
       g_i = ce.g_rows != nullptr ? ce.g_rows[orow + roff] : ce.g_scalar;
       if (ce.rowptr != nullptr && ce.rowptr[orow + 1] == ce.rowptr[orow]) g_i = 0.0f;
+      if (EPI == V3_DS && ce.row_bias != nullptr) gb_i = g_i * ce.row_bias[orow + roff];
     }
   }
   // accumulator element r of half hf is column  col0(tile) + 32 hf + 8 (r >> 2) + 4 fh + (r & 3)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     if constexpr (EPI == V3_DSIG)  // sigmoid(score + offset)
       pv = g_i / (1.0f + __builtin_amdgcn_exp2f(-(sc + ce.offset) * V3_LOG2E));
     else  // softmax
-      pv = __builtin_amdgcn_exp2f((sc - lse_i) * V3_LOG2E) * g_i;
+      pv = __builtin_amdgcn_exp2f((sc - lse_i) * V3_LOG2E) * g_i - gb_i;
     if (rel == off) pv -= g_i;
     return pv;
   };

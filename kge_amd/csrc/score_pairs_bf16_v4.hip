@@ -443,7 +443,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     if (orow >= n) orow = n - 1;
     if (lix.ptr != nullptr) lab = index_at(lix, orow);
   }
-  float lse_i = 0.0f, g_i = 0.0f;  // V3_DS / V3_DSIG: the row's logsumexp and upstream gradient
+  float lse_i = 0.0f, g_i = 0.0f, gb_i = 0.0f;  // V3_DS / V3_DSIG: the row's logsumexp, upstream gradient, g_i * row_bias[i]
   if constexpr (IS_DS) {
     const Index& lix = second ? ce.label2 : ce.label;
     long long orow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
@@ -452,6 +452,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     if constexpr (EPI == V3_DS) lse_i = ce.lse[orow + roff];
     g_i = ce.g_rows != nullptr ? ce.g_rows[orow + roff] : ce.g_scalar;
     if (ce.rowptr != nullptr && ce.rowptr[orow + 1] == ce.rowptr[orow]) g_i = 0.0f;  // (one-sided multi-label loss)
+    if (EPI == V3_DS && ce.row_bias != nullptr) gb_i = g_i * ce.row_bias[orow + roff];
   }
   // d loss / d score of a finished tile, in place of the scores (same chain, same bits as the forward):
   // g_i * (softmax - [label]) or g_i * sigmoid(score + offset); the pad columns of the ragged last tile are
@@ -468,8 +469,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
         p0 = g_i / (1.0f + __builtin_amdgcn_exp2f(-(acc0[r] + ce.offset) * V3_LOG2E));
         p1 = g_i / (1.0f + __builtin_amdgcn_exp2f(-(acc1[r] + ce.offset) * V3_LOG2E));
       } else {
-        p0 = __builtin_amdgcn_exp2f((acc0[r] - lse_i) * V3_LOG2E) * g_i;
-        p1 = __builtin_amdgcn_exp2f((acc1[r] - lse_i) * V3_LOG2E) * g_i;
+        p0 = __builtin_amdgcn_exp2f((acc0[r] - lse_i) * V3_LOG2E) * g_i - gb_i;
+        p1 = __builtin_amdgcn_exp2f((acc1[r] - lse_i) * V3_LOG2E) * g_i - gb_i;
       }
       if (rel == off) p0 -= g_i;
       if (rel == 32 + off) p1 -= g_i;

@@ -779,7 +779,7 @@ def kl_fwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, label_weight=No
 
 
 def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=None, g_scalar: float = 1.0,
-           label_weight=None):
+           label_weight=None, label_bias=None):
     """Backward of kl_fwd: (g_a [n, d], g_p [n, d], g_entities [E, d])."""
     keep = []
     ai, pi = (_index(x, t.device, keep) for x in (a, p))
@@ -803,8 +803,12 @@ def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=Non
                 ctypes.byref(tc), dirc, ai, pi, n, rp.data_ptr(), cl.data_ptr(), lse.data_ptr(), grp,
                 float(g_scalar), g_a.data_ptr(), g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_kl_bwd")
         else:
+            lb = None if label_bias is None else _f32c(label_bias, t.device)
+            if lb is not None and lb.numel() != n:
+                raise ValueError(f"kl_bwd: label_bias has {lb.numel()} entries for {n} rows")
             _lib.check(_lib.lib().kge_kl_weighted_bwd(
-                ctypes.byref(tc), dirc, ai, pi, n, rp.data_ptr(), cl.data_ptr(), lw.data_ptr(), lse.data_ptr(),
+                ctypes.byref(tc), dirc, ai, pi, n, rp.data_ptr(), cl.data_ptr(), lw.data_ptr(),
+                None if lb is None else lb.data_ptr(), lse.data_ptr(),
                 grp, float(g_scalar), g_a.data_ptr(), g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st),
                 "kge_kl_weighted_bwd")
     return g_a, g_p, g_t

@@ -522,23 +522,23 @@ class _FusedKL(torch.autograd.Function):
     int64 CSR (rowptr [n + 1], col [nnz]) of the rows' known answers."""
 
     @staticmethod
-    def forward(ctx, direction, ent, rel, a, p, rowptr, col, label_weight, tables16):
+    def forward(ctx, direction, ent, rel, a, p, rowptr, col, label_weight, label_bias, tables16):
         loss_rows, lse = engine.kl_fwd(tables16, direction, a, p, rowptr, col, label_weight)
-        ctx.t16, ctx.direction, ctx.idx = tables16, direction, (a, p, rowptr, col, label_weight)
+        ctx.t16, ctx.direction, ctx.idx = tables16, direction, (a, p, rowptr, col, label_weight, label_bias)
         ctx.rel_shape = rel.shape
         ctx.save_for_backward(lse)
         return loss_rows
 
     @staticmethod
     def backward(ctx, g_rows):
-        a, p, rowptr, col, label_weight = ctx.idx
+        a, p, rowptr, col, label_weight, label_bias = ctx.idx
         (lse,) = ctx.saved_tensors
         g_a, g_p, ge = engine.kl_bwd(ctx.t16, ctx.direction, a, p, rowptr, col, lse, g_rows=g_rows.contiguous(),
-                                     label_weight=label_weight)
+                                     label_weight=label_weight, label_bias=label_bias)
         gr = torch.zeros(ctx.rel_shape, dtype=torch.float32, device=ge.device)
         _scatter_rows(gr, p, g_p)
         _scatter_rows(ge, a, g_a)
-        return None, ge, gr, None, None, None, None, None, None
+        return None, ge, gr, None, None, None, None, None, None, None
 
 
 def kl_fused(name: str, l_norm, direction: str, ent: Tensor, rel: Tensor, a: Tensor, p: Tensor, rowptr: Tensor,
@@ -553,13 +553,16 @@ def kl_fused(name: str, l_norm, direction: str, ent: Tensor, rel: Tensor, a: Ten
                                                                     [n, 1] score against the table's column sum
                + k_i a_i log a_i + (E - k_i) b_i log b_i         <- constant."""
     if eps == 0.0:
-        return _FusedKL.apply(direction, ent, rel, a, p, rowptr, col, None, t)
+        return _FusedKL.apply(direction, ent, rel, a, p, rowptr, col, None, None, t)
     E = ent.shape[0]
     k = (rowptr[1:] - rowptr[:-1]).to(device=ent.device, dtype=torch.float32)
     Z = (1.0 - eps) * k + 1.0
     a_w, b_w = (1.0 - eps + 1.0 / E) / Z, (1.0 / E) / Z
-    fused = _FusedKL.apply(direction, ent, rel, a, p, rowptr, col, (a_w - b_w).contiguous(), t)
-    s_all = _score_against_column_sum(name, l_norm, direction, ent, rel, a, p)
+    # the GRADIENT of the uniform term is taken inside the gradient kernel (label_bias = b_i: b_i is subtracted at
+    # every column next to the softmax), so only its VALUE is computed here
+    fused = _FusedKL.apply(direction, ent, rel, a, p, rowptr, col, (a_w - b_w).contiguous(), b_w.contiguous(), t)
+    with torch.no_grad():
+        s_all = _sum_of_scores_value(name, direction, ent, rel, a, p)
     const = k * a_w * torch.log(a_w) + (E - k) * b_w * torch.log(b_w)
     return fused - b_w * s_all + const
 
@@ -595,6 +598,21 @@ def _score_against_column_sum(name: str, l_norm, direction: str, ent: Tensor, re
     if direction == "sp":
         return _ScoreEmb.apply(name, "sp_", l_norm, rows, prow, colsum).view(-1)
     return _ScoreEmb.apply(name, "_po", l_norm, colsum, prow, rows).view(-1)
+
+
+def _sum_of_scores_value(name: str, direction: str, ent: Tensor, rel: Tensor, a: Tensor, p: Tensor) -> Tensor:
+    """[n] values of sum_j score(i, j) (no autograd) from a handful of elementwise ops on [n, d]: the query
+    against the table's column sum c.  ComplEx (complex.py:30-39): Re<s, r, conj(o)> =
+    (s_re r_re - s_im r_im) o_re + (s_re r_im + s_im r_re) o_im, linear in o ("sp": o = c) and in s ("po": s = c)."""
+    c = ent.float().sum(dim=0)
+    x, r = ent[a.long()].float(), rel[p.long()].float()
+    if name == "distmult":
+        return (x * r * c).sum(dim=1)
+    h = x.shape[1] // 2
+    x_re, x_im, r_re, r_im, c_re, c_im = x[:, :h], x[:, h:], r[:, :h], r[:, h:], c[:h], c[h:]
+    if direction == "sp":
+        return ((x_re * r_re - x_im * r_im) * c_re + (x_re * r_im + x_im * r_re) * c_im).sum(dim=1)
+    return ((c_re * r_re - c_im * r_im) * x_re + (c_re * r_im + c_im * r_re) * x_im).sum(dim=1)
 
 
 def bce_fused(name: str, l_norm, direction: str, ent: Tensor, rel: Tensor, a: Tensor, p: Tensor, rowptr: Tensor,

@@ -15,9 +15,24 @@ o = torch.randint(E, (n,), generator=g).to(dev)
 torch.manual_seed(0)
 m = km.create(os.environ.get("MODEL", "complex"), E, R, d, device=dev, score_dtype=torch.bfloat16)
 opt = ko.Adagrad(m.parameters(), lr=0.1, bf16_copies=True)
+MODE = os.environ.get("MODE", "1vsAll")  # KvsAll: kl (label smoothing LS) and bce losses on random multi-label rows
+if MODE != "1vsAll":
+    import numpy as np
+    rng = np.random.default_rng(0)
+    cnt = rng.integers(1, 8, n)
+    col = torch.from_numpy(np.concatenate([np.sort(rng.choice(E, c, replace=False)) for c in cnt]).astype(np.int64)).to(dev)
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)).to(dev)
+    LS = float(os.environ.get("LS", "0"))
 for it in range(int(os.environ.get("STEPS", "30"))):
     opt.zero_grad(set_to_none=True)
-    m.loss_sp_po(s, p, o).sum().backward()
+    if MODE == "1vsAll":
+        m.loss_sp_po(s, p, o).sum().backward()
+    elif MODE == "KvsAll":
+        m.kl_loss_sp(s, p, rowptr, col, LS).sum().backward()
+        m.kl_loss_po(p, o, rowptr, col, LS).sum().backward()
+    else:
+        m.bce_loss_sp(s, p, rowptr, col, 0.0, LS).sum().backward()
+        m.bce_loss_po(p, o, rowptr, col, 0.0, LS).sum().backward()
     opt.step()
 torch.cuda.synchronize()
 print("done")
