@@ -451,5 +451,6 @@ def test_sharded_path_through_a_real_rccl_process_group():
     for a, b in zip(plain[0], forced[0]):
         assert torch.equal(a, b)
     assert torch.equal(plain[1][0], forced[1][0]) and torch.equal(plain[1][1], forced[1][1])
-    for a, b in zip(plain[2:], forced[2:]):
-        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(plain[2], forced[2], rtol=1e-6, atol=1e-7)   # the per-row losses
+    for a, b in zip(plain[3:], forced[3:]):  # gradients: float atomics / index_add accumulate in any order
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-6)
