@@ -139,8 +139,9 @@ int kge_device_count(void);
  * then on: besides scratch it holds the builders' flag lines and a "degraded" word.  A consumer
  * workgroup waits for its builders only for a bounded time (they may not be running: other
  * streams' kernels, a second process, CU masking); after a time-out it builds its own query
- * vectors, sets that word, and every later call on the workspace skips the hand-off -- slower,
- * never wrong, never a hang (non-zero garbage in a fresh workspace has the same effect).  The
+ * vectors and sets that word to a count of launches; the next few thousand calls on the workspace
+ * skip the hand-off (slower, never wrong, never a hang), then it is tried again (non-zero garbage
+ * in a fresh workspace has the same effect, for as long as it takes to count it down).  The
  * workspace is only accessed during a call (stream order; calls may be captured into a hipGraph
  * and replayed) and must not be shared by calls that may run concurrently on different streams;
  * 16-byte aligned.  ONE workspace may serve calls with different n (size it for the largest): the

@@ -58,6 +58,8 @@ __device__ __forceinline__ void v4_static_for(F&& f) {
 // waves do that on the accumulators right after a tile's MFMA chain, the DMA waves keep streaming,
 // the store waves have nothing to do (kge_ce_fwd / kge_ce_sp_po_fwd: the [n, E] matrix is never
 // written; per row and column group 8 bytes leave the kernel, merged by ce_combine_kernel).
+constexpr int V4_DEGRADED_LAUNCHES = 4096;  // launches a timed-out hand-off is skipped for before it is tried again
+
 template <int SCORER, int HH, int TGMODE, int EPI>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     Operand A, Operand A2, Operand R, Operand TG, int dir, long long n, long long m, int rgn,
@@ -160,6 +162,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       for (int c = lane; c < ncg; c += 64)
         __hip_atomic_store(flags + ((long long)rg * ncg + c) * 8 + cg, epoch, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // The degraded word is a COUNTDOWN of launches, not a latch: one thread per launch takes one off, so that a
+  // workspace degraded by a single hiccup (a builder held up for > ~60 ms once) goes back to the cooperative
+  // build after V4_DEGRADED_LAUNCHES launches instead of paying the own-build path for the life of the process.
+  if (blockIdx.x == 0 && tid == 0) {
+    unsigned long long* const dgw = flags + 512 * 8;
+    const unsigned long long v = __hip_atomic_load(dgw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v != 0ull) __hip_atomic_store(dgw, v - 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   stamp();  // 1: share built and published
 
@@ -340,8 +350,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   // A consumer never trusts a builder blindly.  The wait is bounded (a builder workgroup that is not
   // running -- its CU busy with another stream's kernel, CU masking, a second process -- must neither
   // hang this workgroup nor kill the process): on a time-out this workgroup builds its own fragments in
-  // registers (same bits) and marks the workspace DEGRADED; every later launch on that workspace then
-  // skips the hand-off at once (a flag published late cannot be told from a fresh one by a replay of a
+  // registers (same bits) and marks the workspace DEGRADED; the next V4_DEGRADED_LAUNCHES launches on that workspace
+  // skip the hand-off at once (a flag published late cannot be told from a fresh one by a replay of a
   // captured launch, whose epoch is frozen).  KGE_V4_OWN_BUILD=1 (tests) takes that path on purpose.
   unsigned long long* const degraded = flags + 512 * 8;
   int* const sb_flag = reinterpret_cast<int*>(smem + CST0);  // the staging buffer is idle until tile 0 is done
@@ -355,7 +365,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       if (__all(v == epoch)) break;
       if (spin == (1 << 16)) {  // ~0.1 s: far beyond any launch skew
         ok = false;
-        if (lane == 0 && nbuild > 0) __hip_atomic_store(degraded, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && nbuild > 0)
+          __hip_atomic_store(degraded, (unsigned long long)V4_DEGRADED_LAUNCHES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __builtin_amdgcn_s_sleep(1);
     }

@@ -685,6 +685,32 @@ def test_workspace_control_block_survives_calls_of_other_sizes(eng):
         assert not ctrl[:512 * 64].any(), "a flag line was left behind"
 
 
+def test_degraded_workspace_recovers(eng):
+    """The "degraded" word of the cooperative build is a countdown of launches: a workspace marked degraded (a
+    hand-off timed out once) takes the own-build path for that many launches -- same bits -- and then goes back
+    to the cooperative build on its own."""
+    from kge_amd import engine as engmod
+    rng = np.random.default_rng(78)
+    E, R, d, n = 2000, 7, 512, 300
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    rel = rng.standard_normal((R, d)).astype(np.float32)
+    T = _gpu_tables(eng, "complex", ent, rel, 1.0, bf16=True)
+    s, p = _t(rng.integers(0, E, n)), _t(rng.integers(0, R, n))
+    ref = _np(eng.score_sp(T, s, p))
+    torch.cuda.synchronize()
+    bufs = [b for k, b in engmod._WORKSPACES.items() if len(k) == 2]
+    assert bufs
+    word = slice(512 * 64, 512 * 64 + 8)
+    for b in bufs:
+        b[word] = torch.tensor([3, 0, 0, 0, 0, 0, 0, 0], dtype=torch.uint8, device=b.device)  # little-endian 3
+    seen = []
+    for k in range(5):
+        _eq(f"launch {k} on a degraded workspace", _np(eng.score_sp(T, s, p)), ref)
+        torch.cuda.synchronize()
+        seen.append(int(bufs[0][word].cpu().numpy().view(np.uint64)[0]))
+    assert seen == [2, 1, 0, 0, 0], seen
+
+
 def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch):
     """score_pairs_bf16_v5.hip (every workgroup builds the query vectors of its own 64 rows: no workspace,
     no hand-off, any n) takes the calls the cooperative kernel declines.  Forced in front of it
