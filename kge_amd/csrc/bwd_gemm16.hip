@@ -14,12 +14,16 @@
 // operand is G16 again but as [K][M] (m contiguous): the same transpose read as B.
 //
 // One kernel, `gemm16_kernel<A_TR>`:
-//   * 128 x 256 output tile per workgroup, 8 waves as 2 (M) x 4 (N), 64 x 64 per wave = 2 x 2 accumulators of
-//     v_mfma_f32_32x32x16_bf16; K in steps of 64;
+//   * 128 x 256 output tile per workgroup; the eight waves form two groups that split every 64-wide K stage
+//     between them (waves 0-3: K slices 0, 1; waves 4-7: slices 2, 3), each wave 64 x 128 = 2 x 4 accumulators
+//     of v_mfma_f32_32x32x16_bf16 (12 transpose reads per 8 MFMAs); at the end the groups exchange halves
+//     through the dead ring, add, and store 16 bytes per lane from a wave-private row-major image;
 //   * HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging), a ring of three 48 KiB stages
-//     (A 16 KiB + B 32 KiB), stage t+2 issued right after the barrier that opens stage t: one barrier per
-//     K step, two steps of latency hiding.  The DMA writes LDS lane-linearly (16 B per lane), so every
-//     layout above is produced by choosing WHICH 16 bytes each lane fetches;
+//     (A 16 KiB + B 32 KiB).  The DMA writes LDS lane-linearly (16 B per lane), so every layout above is
+//     produced by choosing WHICH 16 bytes each lane fetches.  One barrier per stage, placed BEHIND the first
+//     slice's 8 queued MFMAs, with the next stage's first fragments requested right after it; the six DMA
+//     pieces a wave owes to stage t + 2 are issued one at a time between the following MFMAs (a DMA
+//     instruction blocks its wave for ~90 cycles; in a burst all eight waves stalled together);
 //   * ragged edges are clamped in the address (never predicated: constant VMEM counts); out-of-range k of the
 //     last step are fetched from a zero page instead of A (G16's pad columns [m, mp) are zero by contract);
 //   * XCD-aware block ids (block b runs on XCD b mod 8): dQ -- all output tiles of a K split on one XCD
