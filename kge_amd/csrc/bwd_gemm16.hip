@@ -177,7 +177,8 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
   if (nsteps > 1) issue_range(st_lo + 1, 1, I0{}, I6{});
 
   // ---- roles: waves 0-3 contract the K slices 0, 1 of every 64-wide stage, waves 4-7 the slices 2, 3 (an
-  // intra-workgroup split of K: halves the split-K partials dQ needs between workgroups); within a group
+  // intra-workgroup split of K: each wave then owns a 64 x 128 block and needs 12 transpose reads per 8 MFMAs
+  // instead of 8 per 4); within a group
   // wave (wm, wn) owns rows 64 wm .., columns 128 wn .. of the tile = 2 x 4 accumulators
   const int kgrp = wave >> 2, wq = wave & 3, wm = wq >> 1, wn = wq & 1;
   const int h = lane >> 5, g1 = (lane >> 4) & 1, l16 = lane & 15, l32 = lane & 31;
