@@ -232,6 +232,21 @@ int kge_filter_lookup(const int64_t* sorted_keys, int64_t num_keys, const int64_
                       kge_index a, kge_index b, int64_t mult, int64_t n, int64_t* begin,
                       int64_t* end, void* stream);
 
+/* Up to KGE_MAX_FILTER_QUERIES lookups in ONE launch: an evaluation batch needs four (the (s, p) and the
+ * (p, o) keys of the filtered and of the filtered-with-test index), each a few dependent round trips of pure
+ * latency on its own. */
+#define KGE_MAX_FILTER_QUERIES 4
+typedef struct kge_filter_query {
+  const int64_t* sorted_keys;
+  int64_t num_keys;
+  const int64_t* starts;
+  kge_index a, b;
+  int64_t mult;
+  int64_t* begin;
+  int64_t* end;
+} kge_filter_query;
+int kge_filter_lookup_multi(const kge_filter_query* queries, int num_queries, int64_t n, void* stream);
+
 /* kge_rank_counts for the raw ranking and `num_filters` (<= KGE_MAX_FILTERS) filtered
  * rankings from ONE scan of the scores: rank/ties are [num_filters + 1][n] int64, row 0 raw,
  * row k + 1 filtered by the columns lbl_col[k][lbl_begin[k][i] .. lbl_end[k][i]) of row i

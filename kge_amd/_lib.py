@@ -42,6 +42,11 @@ class KgeIndex(ctypes.Structure):
                 ("stride", c_i64)]
 
 
+class KgeFilterQuery(ctypes.Structure):
+    _fields_ = [("sorted_keys", c_vp), ("num_keys", c_i64), ("starts", c_vp), ("a", KgeIndex), ("b", KgeIndex),
+                ("mult", c_i64), ("begin", c_vp), ("end", c_vp)]
+
+
 # every symbol include/kge_amd.h declares: name -> (restype, argtypes)
 _PT = ctypes.POINTER(KgeTables)
 PROTOTYPES = {
@@ -63,6 +68,7 @@ PROTOTYPES = {
     "kge_rank_counts": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                        ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
     "kge_filter_lookup": (ctypes.c_int, [c_vp, c_i64, c_vp, KgeIndex, KgeIndex, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "kge_filter_lookup_multi": (ctypes.c_int, [ctypes.POINTER(KgeFilterQuery), ctypes.c_int, c_i64, c_vp]),
     "kge_rank_counts_multi": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, ctypes.c_int, c_vp, c_vp, c_vp,
                                              c_i64, c_vp, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
     "kge_rank_hist": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_i64, c_i64, c_vp,

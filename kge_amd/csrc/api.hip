@@ -49,6 +49,9 @@ int run_rank(const float* scores, long long lds, long long n, long long c,
 int run_filter_lookup(const long long* keys, long long num_keys, const long long* starts, const Index& a,
                       const Index& b, long long mult, long long n, long long* begin, long long* end,
                       hipStream_t st);
+int run_filter_lookup_multi(int nq, const long long* const* keys, const long long* num_keys,
+                            const long long* const* starts, const Index* a, const Index* b, const long long* mult,
+                            long long n, long long* const* begin, long long* const* end, hipStream_t st);
 int run_rank_multi(const float* scores, long long lds, long long n, long long c, const float* true_scores,
                    int K, const long long* const* begin, const long long* const* end,
                    const long long* const* col, long long col_offset, const long long* true_col, float atol,
@@ -425,6 +428,26 @@ int kge_filter_lookup(const int64_t* sorted_keys, int64_t num_keys, const int64_
   if ((rc = check_index(a, false, n)) || (rc = check_index(b, false, n))) return rc;
   return run_filter_lookup((const long long*)sorted_keys, num_keys, (const long long*)starts, make_index(a),
                            make_index(b), mult, n, (long long*)begin, (long long*)end, (hipStream_t)stream);
+}
+
+int kge_filter_lookup_multi(const kge_filter_query* queries, int num_queries, int64_t n, void* stream) {
+  if (n < 0 || num_queries < 0 || (num_queries > 0 && !queries)) return KGE_ERR_INVALID_ARG;
+  if (num_queries > KGE_MAX_FILTER_QUERIES) return KGE_ERR_UNSUPPORTED;
+  const long long *keys[KGE_MAX_FILTER_QUERIES], *starts[KGE_MAX_FILTER_QUERIES];
+  long long nk[KGE_MAX_FILTER_QUERIES], mult[KGE_MAX_FILTER_QUERIES];
+  long long *begin[KGE_MAX_FILTER_QUERIES], *end[KGE_MAX_FILTER_QUERIES];
+  Index a[KGE_MAX_FILTER_QUERIES], b[KGE_MAX_FILTER_QUERIES];
+  for (int q = 0; q < num_queries; ++q) {
+    const kge_filter_query& x = queries[q];
+    if (x.num_keys < 0) return KGE_ERR_INVALID_ARG;
+    if (n > 0 && (!x.begin || !x.end || (x.num_keys > 0 && (!x.sorted_keys || !x.starts)))) return KGE_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = check_index(x.a, false, n)) || (rc = check_index(x.b, false, n))) return rc;
+    keys[q] = (const long long*)x.sorted_keys; starts[q] = (const long long*)x.starts; nk[q] = x.num_keys;
+    mult[q] = x.mult; begin[q] = (long long*)x.begin; end[q] = (long long*)x.end;
+    a[q] = make_index(x.a); b[q] = make_index(x.b);
+  }
+  return run_filter_lookup_multi(num_queries, keys, nk, starts, a, b, mult, n, begin, end, (hipStream_t)stream);
 }
 
 int kge_rank_counts_multi(const float* scores, int64_t lds, int64_t n, int64_t c, const float* true_scores,

@@ -464,6 +464,27 @@ def filter_lookup(sorted_keys, starts, a, b, mult: int, begin, end):
     return begin, end
 
 
+def filter_lookup_multi(queries):
+    """Several filter_lookup calls in ONE launch: queries = [(sorted_keys, starts, a, b, mult, begin, end), ...]
+    (at most 4; all index vectors of the same length)."""
+    if not queries:
+        return
+    dev = queries[0][5].device
+    keep, arr = [], (_lib.KgeFilterQuery * len(queries))()
+    n = None
+    for q, (keys, starts, a, b, mult, begin, end) in enumerate(queries):
+        k0 = len(keep)
+        ai, bi = _index(a, dev, keep), _index(b, dev, keep)
+        nq = _same_len(keep[k0:k0 + 2], "filter_lookup_multi")
+        if n is not None and nq != n:
+            raise ValueError("filter_lookup_multi: the queries differ in length")
+        n = nq
+        arr[q] = _lib.KgeFilterQuery(keys.data_ptr(), keys.numel(), starts.data_ptr(), ai, bi, int(mult),
+                                     begin.data_ptr(), end.data_ptr())
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().kge_filter_lookup_multi(arr, len(queries), n, _stream(dev)), "kge_filter_lookup_multi")
+
+
 def rank_counts_multi(scores, true_scores, filters, col_offset, true_col, atol, rtol, rank, ties):
     """Raw + len(filters) filtered (rank, ties) counts from one scan of `scores` [n, c]:
     filters = [(begin [n], end [n], col [nnz]), ...] int64 device tensors; rank / ties are

@@ -196,14 +196,15 @@ class EntityRankingEvaluator:
             rng = st["ranges"][:, :, :, :n].contiguous() if n != self.batch_size else st["ranges"]
             cnt = st["counts"][:, :, :, :n].contiguous() if n != self.batch_size else st["counts"]
             cnt.zero_()
-            filt_o, filt_s = [], []
+            filt_o, filt_s, lookups = [], [], []
             for k in range(M - 1):
                 uk, start, v = st["sp"][k]
-                engine.filter_lookup(uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1])
+                lookups.append((uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1]))
                 filt_o.append((rng[0, k, 0], rng[0, k, 1], v))
                 uk, start, v = st["po"][k]
-                engine.filter_lookup(uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1])
+                lookups.append((uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1]))
                 filt_s.append((rng[1, k, 0], rng[1, k, 1], v))
+            engine.filter_lookup_multi(lookups)  # all lookups of the batch in one launch
 
             o_true = s_true = None
             if chunk < E:

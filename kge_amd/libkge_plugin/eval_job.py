@@ -142,14 +142,15 @@ class HipEntityRankingJob(EntityRankingJob):
             s64, o64 = s.long().contiguous(), o.long().contiguous()  # true_col of the po / sp rankings
             rng = torch.empty(2, M - 1, 2, n, dtype=torch.int64, device=dev)
             cnt = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)  # [o|s][rank|ties][ranking][row]
-            filt_o, filt_s = [], []
+            filt_o, filt_s, lookups = [], [], []
             for k in range(M - 1):
                 uk, start, v = self._hip_sp[k]
-                engine.filter_lookup(uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1])
+                lookups.append((uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1]))
                 filt_o.append((rng[0, k, 0], rng[0, k, 1], v))
                 uk, start, v = self._hip_po[k]
-                engine.filter_lookup(uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1])
+                lookups.append((uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1]))
                 filt_s.append((rng[1, k, 0], rng[1, k, 1], v))
+            engine.filter_lookup_multi(lookups)  # kge_filter_lookup_multi: the batch's four lookups, one launch
 
             o_true = s_true = None
             if chunk_size < E:

@@ -463,6 +463,14 @@ def test_filter_lookup_multi_ranking_and_histogram_vs_oracle(eng, n, c):
         _eq("end", _np(end), we)
         assert wb[-1] == 0 and we[-1] == 0
         filters.append((beg, end, _t(vals)))
+        # the same lookup through the multi entry (here: twice in one launch, with int32 / strided index views)
+        mb = torch.full((2, 2, n), -7, dtype=torch.int64, device=DEV)
+        a2 = torch.stack([_t(a), _t(b)], 1).int()
+        eng.filter_lookup_multi([(_t(keys), _t(starts), _t(a), _t(b), mult, mb[0, 0], mb[0, 1]),
+                                 (_t(keys), _t(starts), a2[:, 0], a2[:, 1], mult, mb[1, 0], mb[1, 1])])
+        for q in range(2):
+            _eq("begin (multi)", _np(mb[q, 0]), wb)
+            _eq("end (multi)", _np(mb[q, 1]), we)
         rp = np.concatenate([[0], np.cumsum(we - wb)])
         col = np.concatenate([vals[x:y] for x, y in zip(wb, we)] + [np.zeros(0, np.int64)])
         csrs.append((rp.astype(np.int64), col.astype(np.int64)))
