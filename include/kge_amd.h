@@ -261,6 +261,32 @@ int kge_rank_counts_multi(const float* scores, int64_t lds, int64_t n, int64_t c
                           const int64_t* true_col, float atol, float rtol, int64_t* rank,
                           int64_t* ties, void* stream);
 
+/* Scoring and rank counting in ONE kernel: the counts kge_score_sp_po + kge_rank_counts_multi produce for the
+ * entity slice [col_begin, col_begin + m) (bit for bit: the same score chains, the same tie arithmetic),
+ * without the [n, 2m] score matrix ever being written or read -- EntityRankingJob._evaluate's
+ * score_sp_po -> _filter_and_rank -> _get_ranks_and_num_ties (eval_entity_ranking.py:227-313) per entity chunk.
+ *   true_sp[i] / true_po[i]   score of triple i as the sp_ / _po scoring sees it (an element of the score
+ *                             matrix: e.g. the diagonal of kge_score_sp_po against targets = o resp. s);
+ *   sp_* / po_*               num_filters (<= 2) filter sets per direction, as for kge_rank_counts_multi:
+ *                             HOST arrays of device pointers; columns are global entity ids, the row's own
+ *                             o[i] (sp_) / s[i] (_po) is never filtered;
+ *   rank_* / ties_*           [num_filters + 1][ld] int64, row 0 raw, ACCUMULATED (over entity chunks);
+ *   filter_bits               >= kge_score_rank_bits_bytes(n, m, num_filters) bytes, 8-byte aligned, ZEROED ONCE
+ *                             before its first use: the call sets one bit per filtered (row, column), counts,
+ *                             and clears the same words again (all-zero between calls);
+ *   workspace                 as for kge_score_sp_po (kge_score_workspace_bytes(t, n)).
+ * KGE_ERR_UNSUPPORTED (tables other than bf16 ComplEx / DistMult with dim 256 / 512, a launch the
+ * loader/consumer kernel declines): use kge_score_sp_po + kge_rank_counts_multi. */
+int64_t kge_score_rank_bits_bytes(int64_t n, int64_t m, int num_filters);
+int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                         int64_t col_begin, int64_t m, const float* true_sp, const float* true_po,
+                         int num_filters, const int64_t* const* sp_begin, const int64_t* const* sp_end,
+                         const int64_t* const* sp_col, const int64_t* const* po_begin,
+                         const int64_t* const* po_end, const int64_t* const* po_col, float atol, float rtol,
+                         int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po, int64_t* ties_po, int64_t ld,
+                         void* filter_bits, int64_t filter_bits_bytes, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
 /* hist[m*ldh + r] += 1.0f with r = rank of the tie policy, for all [num_rankings][n] counts;
  * ranks_out (may be NULL) receives r.  EntityRankingJob._get_ranks (:598-618) + hist_all
  * (:665-687); the float32 histogram is the reference's. */

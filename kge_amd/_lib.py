@@ -71,6 +71,11 @@ PROTOTYPES = {
     "kge_filter_lookup_multi": (ctypes.c_int, [ctypes.POINTER(KgeFilterQuery), ctypes.c_int, c_i64, c_vp]),
     "kge_rank_counts_multi": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, ctypes.c_int, c_vp, c_vp, c_vp,
                                              c_i64, c_vp, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
+    "kge_score_rank_bits_bytes": (c_i64, [c_i64, c_i64, ctypes.c_int]),
+    "kge_score_rank_sp_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_i64, c_i64, c_vp, c_vp,
+                                            ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float,
+                                            ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                            c_vp]),
     "kge_rank_hist": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_i64, c_i64, c_vp,
                                      c_vp]),
     "kge_score_bwd_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),

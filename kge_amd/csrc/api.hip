@@ -58,6 +58,12 @@ int run_rank_multi(const float* scores, long long lds, long long n, long long c,
                    float rtol, long long* rank, long long* ties, hipStream_t st);
 int run_rank_hist(const long long* rank, const long long* ties, int M, long long n, int policy, float* hist,
                   long long ldh, long long num_ent, long long* ranks_out, hipStream_t st);
+int run_rank_bits(int lists, const long long* const* begin, const long long* const* end, const long long* const* col,
+                  const Index* keep, unsigned long long* const* bits, long long n, long long col_begin, long long m,
+                  long long ld, int set, hipStream_t st);
+int run_pairs_bf16_v4_epi(int scorer, int epi, const Operand& A, const Operand* A2, const Operand& R,
+                          const Operand& TG, int dir, int d, long long n, long long m, hipStream_t st, void* ws,
+                          long long ws_bytes, const CeArgs& ce, unsigned long long* dbg);
 int run_pairs_bwd_gemm16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
                          int dr, long long n, long long m, const float* gout, long long ldg, float* g_a,
                          float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
@@ -467,6 +473,82 @@ int kge_rank_counts_multi(const float* scores, int64_t lds, int64_t n, int64_t c
                         (const long long* const*)lbl_end, (const long long* const*)lbl_col, col_offset,
                         (const long long*)true_col, atol, rtol, (long long*)rank, (long long*)ties,
                         (hipStream_t)stream);
+}
+
+// ---- scoring + rank counting in one kernel (no [n, 2m] score matrix)
+static inline int64_t rank_bits_ld(int64_t m) { return (m + 63) / 64; }
+
+int64_t kge_score_rank_bits_bytes(int64_t n, int64_t m, int num_filters) {
+  if (n <= 0 || m <= 0 || num_filters <= 0) return 0;
+  return 2 * (int64_t)num_filters * n * rank_bits_ld(m) * 8;
+}
+
+int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, int64_t col_begin,
+                         int64_t m, const float* true_sp, const float* true_po, int num_filters,
+                         const int64_t* const* sp_begin, const int64_t* const* sp_end, const int64_t* const* sp_col,
+                         const int64_t* const* po_begin, const int64_t* const* po_end, const int64_t* const* po_col,
+                         float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po,
+                         int64_t* ties_po, int64_t ld, void* filter_bits, int64_t filter_bits_bytes, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (n < 0 || m < 0 || col_begin < 0 || col_begin + m > t->num_ent || num_filters < 0 || ld < n)
+    return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s, false, n)) || (rc = check_index(p, false, n)) || (rc = check_index(o, false, n))) return rc;
+  if (n == 0 || m == 0) return KGE_OK;
+  if (!true_sp || !true_po || !rank_sp || !ties_sp || !rank_po || !ties_po) return KGE_ERR_INVALID_ARG;
+  if (num_filters > 2) return KGE_ERR_UNSUPPORTED;
+  for (int k = 0; k < num_filters; ++k)
+    if (!sp_begin || !sp_end || !sp_col || !po_begin || !po_end || !po_col || !sp_begin[k] || !sp_end[k] ||
+        !sp_col[k] || !po_begin[k] || !po_end[k] || !po_col[k])
+      return KGE_ERR_INVALID_ARG;
+  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
+  const kge_index all = {nullptr, 0, 0, 1};
+  Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, all);
+  const int esize = t->dtype == KGE_BF16 ? 2 : 4;
+  TG.base = (const char*)TG.base + col_begin * TG.ld * esize;
+  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
+      !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
+    return KGE_ERR_UNSUPPORTED;
+  if (!workspace || ((uintptr_t)workspace & 15)) return KGE_ERR_WORKSPACE;
+  const int64_t bld = rank_bits_ld(m);
+  if (num_filters > 0 && (!filter_bits || ((uintptr_t)filter_bits & 7) ||
+                          filter_bits_bytes < kge_score_rank_bits_bytes(n, m, num_filters)))
+    return KGE_ERR_WORKSPACE;
+  CeArgs ce{};
+  ce.rk_true[0] = true_sp;
+  ce.rk_true[1] = true_po;
+  ce.rk_rank[0] = (unsigned long long*)rank_sp;
+  ce.rk_ties[0] = (unsigned long long*)ties_sp;
+  ce.rk_rank[1] = (unsigned long long*)rank_po;
+  ce.rk_ties[1] = (unsigned long long*)ties_po;
+  ce.rk_ld = ld;
+  ce.rk_atol = atol;
+  ce.rk_rtol = rtol;
+  ce.rk_nfilt = num_filters;
+  ce.rk_bits_ld = bld;
+  // lists: [sp side: filter sets][po side: filter sets]; the true column of the sp ranking is o, of the po ranking s
+  const long long *lb[4], *le[4], *lc[4];
+  Index keep[4];
+  unsigned long long* bits[4];
+  for (int k = 0; k < num_filters; ++k) {
+    for (int side = 0; side < 2; ++side) {
+      const int q = side * num_filters + k;
+      lb[q] = (const long long*)(side ? po_begin[k] : sp_begin[k]);
+      le[q] = (const long long*)(side ? po_end[k] : sp_end[k]);
+      lc[q] = (const long long*)(side ? po_col[k] : sp_col[k]);
+      keep[q] = make_index(side ? s : o);
+      bits[q] = (unsigned long long*)filter_bits + (int64_t)q * n * bld;
+      ce.rk_bits[side][k] = bits[q];
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 1, st))) return rc;
+  rc = run_pairs_bf16_v4_epi(t->scorer, V3_RANK, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, st, workspace,
+                             workspace_bytes, ce, nullptr);
+  // (also after a declined launch: the bits must not outlive the call)
+  const int rc2 = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+  return rc ? rc : rc2;
 }
 
 int kge_rank_hist(const int64_t* rank, const int64_t* ties, int num_rankings, int64_t n, int tie_policy,

@@ -321,7 +321,10 @@ __device__ __forceinline__ long long index_mode(const Index& ix, long long i) {
 //             with logits against all-zero labels; the label terms are added outside)  -- kge_bce_fwd
 //   V3_DSIG   d loss / d score = g_i * (sigmoid(score + offset) - [j == label_i]) as bf16 -> G16
 //                                                                                    -- kge_bce_bwd
-constexpr int V3_STORE = 0, V3_LSE = 1, V3_DS = 2, V3_SPLUS = 3, V3_DSIG = 4;
+//   V3_RANK   counted against the row's true score (close / greater-and-not-close, the arithmetic of
+//             rank.hip) right on the accumulators, with up to two filter sets given as per-row column
+//             bit masks: kge_score_rank_sp_po (loader/consumer kernel only; nothing is written per score)
+constexpr int V3_STORE = 0, V3_LSE = 1, V3_DS = 2, V3_SPLUS = 3, V3_DSIG = 4, V3_RANK = 5;
 constexpr float V3_LOG2E = 1.44269504088896340736f;
 constexpr float V3_LN2 = 0.69314718055994530942f;
 
@@ -353,6 +356,34 @@ struct CeArgs {
   Operand a2;
   Index label2;
   long long side2_off;
+  // V3_RANK: per side (index 1 = the _po side of a two-sided launch)
+  const float* rk_true[2];           // [n] true score of row i
+  unsigned long long* rk_rank[2];    // [rk_nfilt + 1][rk_ld] ACCUMULATED: row 0 raw, row k + 1 filter set k
+  unsigned long long* rk_ties[2];
+  long long rk_ld;
+  float rk_atol, rk_rtol;
+  int rk_nfilt;                      // <= 2
+  // bit (j & 63) of word [i * rk_bits_ld + (j >> 6)]: column j of the scored slice is filtered for row i
+  const unsigned long long* rk_bits[2][2];  // [side][filter set]
+  long long rk_bits_ld;
 };
+
+// ---- the tie arithmetic of EntityRankingJob._get_ranks_and_num_ties (eval_entity_ranking.py:571-596), shared by
+// rank.hip and the counting epilogue of the scoring kernel
+__device__ __forceinline__ bool is_close(float x, float t, float atol, float rtol) {
+  // torch.isclose in f32: (x == t) | (isfinite(|x-t|) & (|x-t| <= atol + |rtol*t|))
+  if (x == t) return true;
+  float err = __builtin_fabsf(x - t);
+  float allowed = atol + __builtin_fabsf(rtol * t);
+  return __builtin_isfinite(err) && err <= allowed;
+}
+
+__device__ __forceinline__ void count_one(float x, float t, float atol, float rtol, int& gt,
+                                          int& cl) {
+  if (x != x) x = -__builtin_inff();
+  bool c = is_close(x, t, atol, rtol);
+  cl += c ? 1 : 0;
+  gt += (x > t && !c) ? 1 : 0;
+}
 
 }  // namespace kge

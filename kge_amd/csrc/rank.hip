@@ -12,22 +12,6 @@
 
 namespace kge {
 
-__device__ __forceinline__ bool is_close(float x, float t, float atol, float rtol) {
-  // torch.isclose in f32: (x == t) | (isfinite(|x-t|) & (|x-t| <= atol + |rtol*t|))
-  if (x == t) return true;
-  float err = __builtin_fabsf(x - t);
-  float allowed = atol + __builtin_fabsf(rtol * t);
-  return __builtin_isfinite(err) && err <= allowed;
-}
-
-__device__ __forceinline__ void count_one(float x, float t, float atol, float rtol, int& gt,
-                                          int& cl) {
-  if (x != x) x = -__builtin_inff();
-  bool c = is_close(x, t, atol, rtol);
-  cl += c ? 1 : 0;
-  gt += (x > t && !c) ? 1 : 0;
-}
-
 constexpr int RK_THREADS = 256;
 
 __global__ __launch_bounds__(RK_THREADS) void rank_kernel(
@@ -365,6 +349,51 @@ int run_rank_multi(const float* scores, long long lds, long long n, long long c,
   hipLaunchKernelGGL(rank_multi_kernel, dim3((unsigned)splits, (unsigned)n), dim3(RK_THREADS), 0, st, scores, lds,
                      n, c, true_scores, F, col_offset, true_col, atol, rtol, (unsigned long long*)rank,
                      (unsigned long long*)ties, cpb);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// ---- kge_score_rank_sp_po: the filter sets as per-row column bit masks for the counting epilogue of the scoring
+// kernel (score_pairs_bf16_v4.hip, V3_RANK).  One wave per (row, list); set = 1 sets the bits of the row's filter
+// columns that fall into the scored slice [col_begin, col_begin + m) -- except the row's own true column, which
+// is never filtered (eval_entity_ranking.py:288-290) --, set = 0 clears the words again (the buffer is all-zero
+// between calls, so no pass over it ever touches more than the listed entries).
+struct RankBitLists {
+  const long long* begin[4];
+  const long long* end[4];
+  const long long* col[4];
+  Index keep[4];
+  unsigned long long* bits[4];
+};
+
+__global__ __launch_bounds__(256) void rank_bits_kernel(RankBitLists B, long long n, long long col_begin,
+                                                        long long m, long long ld, int set) {
+  const int q = blockIdx.y;
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const long long keep = index_at(B.keep[q], i);
+  const long long* __restrict__ col = B.col[q];
+  unsigned long long* row = B.bits[q] + i * ld;
+  for (long long e = B.begin[q][i] + (threadIdx.x & 63); e < B.end[q][i]; e += 64) {
+    const long long g = col[e];
+    const long long j = g - col_begin;
+    if (g == keep || j < 0 || j >= m) continue;
+    if (set) atomicOr(row + (j >> 6), 1ull << (j & 63));
+    else row[j >> 6] = 0ull;
+  }
+}
+
+int run_rank_bits(int lists, const long long* const* begin, const long long* const* end, const long long* const* col,
+                  const Index* keep, unsigned long long* const* bits, long long n, long long col_begin, long long m,
+                  long long ld, int set, hipStream_t st) {
+  if (n == 0 || lists == 0) return KGE_OK;
+  if (lists < 0 || lists > 4) return KGE_ERR_UNSUPPORTED;
+  RankBitLists B{};
+  for (int q = 0; q < lists; ++q) {
+    B.begin[q] = begin[q]; B.end[q] = end[q]; B.col[q] = col[q];
+    B.keep[q] = keep[q]; B.bits[q] = bits[q];
+  }
+  hipLaunchKernelGGL(rank_bits_kernel, dim3((unsigned)((n + 3) / 4), (unsigned)lists), dim3(256), 0, st, B, n,
+                     col_begin, m, ld, set);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 

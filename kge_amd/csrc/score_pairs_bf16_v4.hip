@@ -454,6 +454,85 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     if (orow >= n) orow = n - 1;
     if (lix.ptr != nullptr) lab = index_at(lix, orow);
   }
+  // ---- fused rank counts (EPI == V3_RANK): the lane's row against its true score rk_t, and per filter set the
+  // counts over the columns whose bit is set (a filtered column scores -inf: rank.hip's sparse correction)
+  const int rk_side = second ? 1 : 0;
+  float rk_t = 0.0f, rk_al = 0.0f;  // true score (NaN -> -inf), allowed = atol + |rtol * t|
+  bool rk_slow = false;             // some row of the wave has an infinite true score / tolerance: generic arithmetic
+  int rk_g = 0, rk_c = 0;           // raw: greater-and-not-close, close
+  int rk_fg[2] = {0, 0}, rk_fc[2] = {0, 0}, rk_fn[2] = {0, 0};  // per filter set: filtered & greater, & close, filtered
+  unsigned long long rk_w[2] = {0, 0};  // the row's filter bits of the NEXT tile (prefetched one tile ahead)
+  const unsigned long long* rk_bp[2] = {nullptr, nullptr};
+  auto rk_fetch = [&](int tt) __attribute__((always_inline)) {
+    const long long tl = tile_lo + (long long)tt * tile_st;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (k < ce.rk_nfilt) rk_w[k] = tt < ntl ? rk_bp[k][tl] : 0ull;
+  };
+  if constexpr (EPI == V3_RANK) {
+    long long orow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
+    if (orow >= n) orow = n - 1;
+    rk_t = ce.rk_true[rk_side][orow];
+    if (rk_t != rk_t) rk_t = -__builtin_inff();
+    rk_al = ce.rk_atol + __builtin_fabsf(ce.rk_rtol * rk_t);
+    rk_slow = __any(!(__builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al))) != 0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (k < ce.rk_nfilt) rk_bp[k] = ce.rk_bits[rk_side][k] + orow * ce.rk_bits_ld;
+    rk_fetch(0);
+  }
+  // Bit layout of the per-lane masks = the tile's 64 columns: element r of half hf is bit 32 hf + 8 (r >> 2) + 4 fh + (r & 3).
+  auto rank_tile = [&](int tt) __attribute__((always_inline)) {
+    const long long c0t = (long long)(tile_lo + tt * tile_st) * V4_TN;
+    unsigned int g[2] = {0u, 0u}, c[2] = {0u, 0u};
+    if (!rk_slow) {
+      // finite true score, finite tolerance >= 0:  close <=> |x - t| <= allowed,  greater-and-not-close <=>
+      // x - t > allowed  (NaN and -inf scores fail both, +inf is greater: what count_one gives)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned int bit = 1u << (8 * (r >> 2) + (r & 3));
+        const float e0 = acc0[r] - rk_t, e1 = acc1[r] - rk_t;
+        g[0] |= e0 > rk_al ? bit : 0u;
+        c[0] |= __builtin_fabsf(e0) <= rk_al ? bit : 0u;
+        g[1] |= e1 > rk_al ? bit : 0u;
+        c[1] |= __builtin_fabsf(e1) <= rk_al ? bit : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned int bit = 1u << (8 * (r >> 2) + (r & 3));
+        int g0 = 0, c0 = 0, g1 = 0, c1 = 0;
+        count_one(acc0[r], rk_t, ce.rk_atol, ce.rk_rtol, g0, c0);
+        count_one(acc1[r], rk_t, ce.rk_atol, ce.rk_rtol, g1, c1);
+        g[0] |= g0 ? bit : 0u;
+        c[0] |= c0 ? bit : 0u;
+        g[1] |= g1 ? bit : 0u;
+        c[1] |= c1 ? bit : 0u;
+      }
+    }
+    // this lane's columns of the tile that exist (the ragged last tile of the slice ends at m)
+    unsigned long long mine = 0x0f0f0f0f0f0f0f0full << (4 * fh);
+    const long long rem = m - c0t;
+    if (rem < V4_TN) mine &= (1ull << rem) - 1ull;  // (rem >= 1: the tile exists)
+    const unsigned int m0 = (unsigned int)mine, m1 = (unsigned int)(mine >> 32);
+    g[0] = (g[0] << (4 * fh)) & m0;
+    c[0] = (c[0] << (4 * fh)) & m0;
+    g[1] = (g[1] << (4 * fh)) & m1;
+    c[1] = (c[1] << (4 * fh)) & m1;
+    rk_g += __builtin_popcount(g[0]) + __builtin_popcount(g[1]);
+    rk_c += __builtin_popcount(c[0]) + __builtin_popcount(c[1]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k < ce.rk_nfilt) {
+        const unsigned int w0 = (unsigned int)rk_w[k] & m0, w1 = (unsigned int)(rk_w[k] >> 32) & m1;
+        rk_fg[k] += __builtin_popcount(g[0] & w0) + __builtin_popcount(g[1] & w1);
+        rk_fc[k] += __builtin_popcount(c[0] & w0) + __builtin_popcount(c[1] & w1);
+        rk_fn[k] += __builtin_popcount(w0) + __builtin_popcount(w1);
+      }
+    }
+    rk_fetch(tt + 1);
+  };
+
   float lse_i = 0.0f, g_i = 0.0f, gb_i = 0.0f;  // V3_DS / V3_DSIG: the row's logsumexp, upstream gradient, g_i * row_bias[i]
   if constexpr (IS_DS) {
     const Index& lix = second ? ce.label2 : ce.label;
@@ -588,10 +667,12 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   tile(0);
   if constexpr (EPI == V3_LSE) lse_tile(0);
   if constexpr (IS_DS) ds_tile(0);
+  if constexpr (EPI == V3_RANK) rank_tile(0);
   for (int tt = 1; tt < ntl; ++tt) {
     tile(tt);
     if constexpr (EPI == V3_LSE) lse_tile(tt);
     if constexpr (IS_DS) ds_tile(tt);
+    if constexpr (EPI == V3_RANK) rank_tile(tt);
   }
   // the last tile's scores: stage them for the loaders' final pass
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -618,6 +699,27 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
         pp[1] = L;
       }
       if (tfound) ce.true_score[row + roff] = tsc;  // (never with a NULL label vector: lab stays -1)
+    }
+  }
+  if constexpr (EPI == V3_RANK) {
+    // the two lanes of a row -> one contribution per row, column group and ranking
+    const int G = rk_g + __shfl_xor(rk_g, 32, 64), C = rk_c + __shfl_xor(rk_c, 32, 64);
+    const long long row = (long long)rgl * V4_ROWS + 32 * w4 + fi;
+    const bool wr = row < n && fh == 0;
+    unsigned long long* rank = ce.rk_rank[rk_side] + row;
+    unsigned long long* ties = ce.rk_ties[rk_side] + row;
+    if (wr && G != 0) atomicAdd(rank, (unsigned long long)G);
+    if (wr && C != 0) atomicAdd(ties, (unsigned long long)C);
+    const int fc = rk_t == -__builtin_inff() ? 1 : 0;  // is -inf (a filtered column's score) close to the true score
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k < ce.rk_nfilt) {
+        const int FG = rk_fg[k] + __shfl_xor(rk_fg[k], 32, 64), FC = rk_fc[k] + __shfl_xor(rk_fc[k], 32, 64);
+        const int FN = rk_fn[k] + __shfl_xor(rk_fn[k], 32, 64);
+        const int Gk = G - FG, Ck = C - FC + fc * FN;
+        if (wr && Gk != 0) atomicAdd(rank + (k + 1) * ce.rk_ld, (unsigned long long)Gk);
+        if (wr && Ck != 0) atomicAdd(ties + (k + 1) * ce.rk_ld, (unsigned long long)Ck);
+      }
     }
   }
 }
@@ -762,6 +864,7 @@ int run_pairs_bf16_v4_epi(int scorer, int epi, const Operand& A, const Operand* 
 #define KGE_V4S(EP)                                                                                              \
   if (scorer == KGE_COMPLEX) { KGE_V4E(KGE_COMPLEX, EP) } else if (scorer == KGE_DISTMULT) { KGE_V4E(KGE_DISTMULT, EP) }
   if (epi == V3_LSE) { KGE_V4S(V3_LSE) } else if (epi == V3_DS) { KGE_V4S(V3_DS) } else if (epi == V3_DSIG) { KGE_V4S(V3_DSIG) }
+  else if (epi == V3_RANK) { KGE_V4S(V3_RANK) }
 #undef KGE_V4S
 #undef KGE_V4E
   return KGE_ERR_UNSUPPORTED;

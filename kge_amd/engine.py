@@ -506,6 +506,65 @@ def rank_counts_multi(scores, true_scores, filters, col_offset, true_col, atol, 
     return rank, ties
 
 
+_RANK_BITS = {}  # (device index, stream) -> all-zero buffer of kge_score_rank_sp_po's filter bits
+
+
+def _rank_bits(need, device, stream):
+    if need <= 0:
+        return None, 0
+    key = (device.index, stream)
+    buf = _RANK_BITS.get(key)
+    if buf is None or buf.numel() < need:
+        # zeroed ONCE: every call clears the bits it set (include/kge_amd.h)
+        buf = _RANK_BITS[key] = torch.zeros((max(need, 1 << 20),), device=device, dtype=torch.uint8)
+    return buf.data_ptr(), buf.numel()
+
+
+def score_rank_sp_po(t: Tables, s, p, o, true_sp, true_po, filters_sp, filters_po, atol, rtol, rank_sp, ties_sp,
+                     rank_po, ties_po, col_begin: int = 0, col_end=None, flags=None) -> bool:
+    """Raw + filtered (rank, ties) counts of both directions of a batch against the entity rows
+    [col_begin, col_end), counted inside the scoring kernel: what score_sp_po + two rank_counts_multi calls
+    give, without the [n, 2m] score matrix.  true_sp / true_po: float32 [n] scores of the triples
+    themselves; filters_*: [(begin [n], end [n], col [nnz]), ...] (at most two); rank_* / ties_*: int64
+    [len(filters) + 1, n] (a row stride >= n is fine), accumulated.  False: the library declines this
+    configuration (tables other than bf16 ComplEx / DistMult with dim 256 / 512) -- nothing was counted."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = _same_len(keep[:3], "score_rank_sp_po")
+    K = len(filters_sp)
+    if len(filters_po) != K:
+        raise ValueError("kge_amd: one filter list per direction and filter set")
+    col_end = t.num_ent if col_end is None else int(col_end)
+    m = col_end - int(col_begin)
+    for x in (true_sp, true_po):
+        _require_gpu(x, "true scores")
+        if x.dtype != torch.float32 or x.numel() != n or not x.is_contiguous():
+            raise ValueError("kge_amd: true scores must be contiguous float32 [n]")
+    ld = None
+    for x in (rank_sp, ties_sp, rank_po, ties_po):
+        if x.dtype != torch.int64 or x.shape != (K + 1, n) or (n > 1 and x.stride(1) != 1):
+            raise ValueError("kge_amd: rank / ties must be int64 [filters + 1, n] with unit inner stride")
+        l = x.stride(0) if K > 0 and n > 0 else max(n, 1)
+        if ld not in (None, l):
+            raise ValueError("kge_amd: rank / ties must share one row stride")
+        ld = l
+    arr = ctypes.c_void_p * max(K, 1)
+    lists = [(arr(*[f[j].data_ptr() for f in fl]) if K else None) for fl in (filters_sp, filters_po) for j in range(3)]
+    with _on_device(t.device):
+        tc = t.c(flags)
+        st = _stream_handle(t.device)
+        ws, wsb = _workspace(tc, n, t.device, True, st)
+        bits, bits_bytes = _rank_bits(_lib.lib().kge_score_rank_bits_bytes(n, m, K), t.device, st)
+        rc = _lib.lib().kge_score_rank_sp_po(
+            ctypes.byref(tc), si, pi, oi, n, int(col_begin), m, true_sp.data_ptr(), true_po.data_ptr(), K,
+            *lists, float(atol), float(rtol), rank_sp.data_ptr(), ties_sp.data_ptr(), rank_po.data_ptr(),
+            ties_po.data_ptr(), ld, bits, bits_bytes, ws, wsb, st)
+        if rc == _lib.KGE_ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc, "kge_score_rank_sp_po")
+    return True
+
+
 TIE_POLICIES = {"rounded_mean_rank": 0, "best_rank": 1, "worst_rank": 2}
 
 

@@ -1,0 +1,156 @@
+"""kge_score_rank_sp_po (scoring + rank counting in one kernel) against the two-step path it replaces:
+kge_score_sp_po -> kge_rank_counts_multi (EntityRankingJob._evaluate: score_sp_po, _filter_and_rank,
+_get_ranks_and_num_ties; eval_entity_ranking.py:227-313).  Integer work on identical score chains: the bar is
+exact equality of every count -- raw and filtered, both directions, accumulated over entity chunks, with ties,
+NaN / infinite scores, filter sets that contain the true column, columns outside the chunk and hub rows."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _tables(eng, model, E, R, d, seed, scale=0.3):
+    g = torch.Generator().manual_seed(seed)
+    ent = (torch.randn(E, d, generator=g) * scale).to(torch.bfloat16).to(DEV)
+    rel = (torch.randn(R, d, generator=g) * scale).to(torch.bfloat16).to(DEV)
+    return eng.Tables(model, ent, rel, 1.0)
+
+
+def _filters(rng, n, E, K, true_col, hub_rows=()):
+    """K nested filter sets per row as (begin, end, col) over one value array each: a few random columns, the
+    row's true column in most of them, duplicates of other rows' columns, one hub row with thousands."""
+    out, prev = [], [np.zeros(0, np.int64)] * n
+    for k in range(K):
+        begin, end, vals = np.zeros(n, np.int64), np.zeros(n, np.int64), []
+        for i in range(n):
+            cnt = int(rng.integers(0, 12)) if i not in hub_rows else min(E, 3000)
+            v = rng.choice(E, size=min(E, cnt), replace=False)
+            if rng.random() < 0.8:
+                v = np.append(v, true_col[i])
+            v = np.unique(np.concatenate([v, prev[i]])).astype(np.int64)
+            if i % 7 == 3 and k == 0:
+                v = np.zeros(0, np.int64)  # an unknown key: empty range
+            prev[i] = v
+            begin[i] = len(vals)
+            vals.extend(v.tolist())
+            end[i] = len(vals)
+        vals = np.asarray(vals if vals else [0], np.int64)
+        out.append(tuple(torch.from_numpy(x).to(DEV) for x in (begin, end, vals)))
+    return out
+
+
+def _two_step(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol):
+    n, K = s.numel(), len(f_sp)
+    cnt = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=DEV)
+    for lo, hi in chunks:
+        sub = None if (lo == 0 and hi == T.num_ent) else torch.arange(lo, hi, device=DEV)
+        sc = eng.score_sp_po(T, s, p, o, sub)
+        c = hi - lo
+        eng.rank_counts_multi(sc[:, :c], t_sp, f_sp, lo, o.contiguous(), atol, rtol, cnt[0, 0], cnt[0, 1])
+        eng.rank_counts_multi(sc[:, c:], t_po, f_po, lo, s.contiguous(), atol, rtol, cnt[1, 0], cnt[1, 1])
+    return cnt
+
+
+def _fused(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol):
+    n, K = s.numel(), len(f_sp)
+    cnt = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=DEV)
+    for lo, hi in chunks:
+        ok = eng.score_rank_sp_po(T, s, p, o, t_sp, t_po, f_sp, f_po, atol, rtol, cnt[0, 0], cnt[0, 1], cnt[1, 0],
+                                  cnt[1, 1], lo, hi)
+        assert ok, "the fused path declined a configuration it documents as supported"
+    return cnt
+
+
+def _true_scores(eng, T, s, p, o):
+    """Elements of the score matrix: each row scored against its own target (diagonal)."""
+    t_sp = eng.score_sp(T, s, p, o).diagonal().contiguous()
+    t_po = eng.score_po(T, p, o, s).diagonal().contiguous()
+    return t_sp, t_po
+
+
+CASES = [
+    # model, E, R, d, n, K, chunks (None = one chunk)
+    ("complex", 14541, 237, 512, 512, 2, None),
+    ("distmult", 14541, 237, 512, 512, 2, None),
+    ("complex", 5000, 11, 256, 100, 2, None),
+    ("distmult", 4099, 7, 256, 129, 1, None),           # ragged last tile (4099 % 64 = 3), ragged row group
+    ("complex", 777, 5, 512, 3, 0, None),               # no filters, a handful of rows
+    ("distmult", 64, 3, 256, 1, 2, None),               # one row, one tile
+    ("complex", 9000, 13, 256, 300, 2, ((0, 4097), (4097, 9000))),  # entity chunks, accumulated
+    ("distmult", 20000, 13, 512, 1000, 2, ((0, 10000), (10000, 10001), (10001, 20000))),
+]
+
+
+@pytest.mark.parametrize("model,E,R,d,n,K,chunks", CASES)
+def test_fused_counts_equal_the_two_step_counts(model, E, R, d, n, K, chunks):
+    from kge_amd import engine as eng
+    rng = np.random.default_rng(E + 31 * n + K)
+    T = _tables(eng, model, E, R, d, seed=E + n)
+    s = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    p = torch.from_numpy(rng.integers(0, R, n)).to(DEV)
+    o = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    # ties: duplicate entity rows (identical scores for every query) next to the originals
+    dup = rng.integers(0, E, min(E // 2, 40))
+    T.ent[dup] = T.ent[rng.integers(0, E, len(dup))]
+    t_sp, t_po = _true_scores(eng, T, s, p, o)
+    f_sp = _filters(rng, n, E, K, o.cpu().numpy(), hub_rows=(n // 2,))
+    f_po = _filters(rng, n, E, K, s.cpu().numpy(), hub_rows=(0,))
+    chunks = chunks or ((0, E),)
+    for atol, rtol in ((1e-5, 1e-4), (0.05, 0.0)):  # the reference's tolerances; a band wide enough for many ties
+        want = _two_step(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol)
+        got = _fused(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol)
+        assert torch.equal(got, want), (model, E, n, K, atol,
+                                        (got != want).nonzero()[:5].tolist(), got[got != want][:5].tolist(),
+                                        want[got != want][:5].tolist())
+        assert int(want[:, 1].min()) >= 1  # every row is at least close to itself
+    # the filter-bit buffer is all-zero again
+    for buf in eng._RANK_BITS.values():
+        assert int(buf.count_nonzero()) == 0
+
+
+def test_fused_counts_with_nan_and_infinite_scores():
+    """Rows whose true score is NaN (-> -inf), +inf or -inf, and NaN / infinite scores elsewhere: the generic
+    arithmetic of the counting epilogue (taken by a wave as soon as one of its rows needs it)."""
+    from kge_amd import engine as eng
+    E, R, d, n = 3000, 5, 256, 160
+    rng = np.random.default_rng(5)
+    T = _tables(eng, "distmult", E, R, d, seed=9)
+    inf = float("inf")
+    T.ent[10, 0] = inf          # scores against entity 10: +-inf or NaN depending on the query's sign / zero
+    T.ent[11, 3] = -inf
+    T.ent[12, 5] = float("nan")
+    T.ent[13, :] = 0.0
+    s = torch.from_numpy(rng.integers(14, E, n)).to(DEV)
+    p = torch.from_numpy(rng.integers(0, R, n)).to(DEV)
+    o = torch.from_numpy(rng.integers(14, E, n)).to(DEV)
+    o[:8] = torch.tensor([10, 11, 12, 13, 10, 11, 12, 13], device=DEV)  # true scores: inf / -inf / NaN / 0
+    s[40:44] = torch.tensor([10, 11, 12, 13], device=DEV)               # whole rows of NaN / inf queries
+    t_sp, t_po = _true_scores(eng, T, s, p, o)
+    assert not bool(torch.isfinite(t_sp[:3]).any())
+    f_sp = _filters(rng, n, E, 2, o.cpu().numpy())
+    f_po = _filters(rng, n, E, 2, s.cpu().numpy())
+    for rows in (slice(0, n), slice(48, n)):  # with and without the special rows in the first wave
+        a = [x[rows] for x in (s, p, o, t_sp, t_po)]
+        fs = [tuple(y[rows] if j < 2 else y for j, y in enumerate(f)) for f in f_sp]
+        fp = [tuple(y[rows] if j < 2 else y for j, y in enumerate(f)) for f in f_po]
+        a[3], a[4] = a[3].contiguous(), a[4].contiguous()
+        fs = [(b.contiguous(), e.contiguous(), c) for b, e, c in fs]
+        fp = [(b.contiguous(), e.contiguous(), c) for b, e, c in fp]
+        want = _two_step(eng, T, *a, fs, fp, ((0, E),), 1e-5, 1e-4)
+        got = _fused(eng, T, *a, fs, fp, ((0, E),), 1e-5, 1e-4)
+        assert torch.equal(got, want), ((got != want).nonzero()[:8].tolist(), got[got != want][:8].tolist(),
+                                        want[got != want][:8].tolist())
+
+
+def test_fused_path_declines_what_it_does_not_cover():
+    from kge_amd import engine as eng
+    g = torch.Generator().manual_seed(1)
+    ent, rel = torch.randn(500, 128, generator=g).to(DEV), torch.randn(4, 128, generator=g).to(DEV)
+    T = eng.Tables("transe", ent, rel, 1.0)
+    s = p = o = torch.zeros(4, dtype=torch.int64, device=DEV)
+    z = torch.zeros(4, device=DEV)
+    cnt = torch.zeros(4, 1, 4, dtype=torch.int64, device=DEV)
+    assert eng.score_rank_sp_po(T, s, p, o, z, z, [], [], 1e-5, 1e-4, cnt[0], cnt[1], cnt[2], cnt[3]) is False
+    assert int(cnt.abs().sum()) == 0
