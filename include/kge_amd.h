@@ -287,6 +287,21 @@ int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_inde
                          void* filter_bits, int64_t filter_bits_bytes, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
+/* The same for dense query rows (the row-sharded multi-GPU path: s / p / o rows come out of the exchange, the
+ * scored rows tgt_emb[m] are this rank's shard, whose global entity ids start at col_begin; s_ids / o_ids =
+ * the global ids of the rows' true subject / object, which the filters never remove).  Counts of the shard's
+ * columns only: the caller sums them over the ranks (one int64 all-reduce). */
+int kge_score_rank_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb,
+                             int64_t p_ld, const void* o_emb, int64_t o_ld, kge_index s_ids, kge_index o_ids,
+                             int64_t n, const void* tgt_emb, int64_t tgt_ld, int64_t col_begin, int64_t m,
+                             const float* true_sp, const float* true_po, int num_filters,
+                             const int64_t* const* sp_begin, const int64_t* const* sp_end,
+                             const int64_t* const* sp_col, const int64_t* const* po_begin,
+                             const int64_t* const* po_end, const int64_t* const* po_col, float atol, float rtol,
+                             int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po, int64_t* ties_po, int64_t ld,
+                             void* filter_bits, int64_t filter_bits_bytes, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
 /* hist[m*ldh + r] += 1.0f with r = rank of the tie policy, for all [num_rankings][n] counts;
  * ranks_out (may be NULL) receives r.  EntityRankingJob._get_ranks (:598-618) + hist_all
  * (:665-687); the float32 histogram is the reference's. */

@@ -76,6 +76,10 @@ PROTOTYPES = {
                                             ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float,
                                             ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                             c_vp]),
+    "kge_score_rank_emb_sp_po": (ctypes.c_int, [_PT, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, KgeIndex, KgeIndex, c_i64,
+                                                c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp,
+                                                c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp,
+                                                c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_rank_hist": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_i64, c_i64, c_vp,
                                      c_vp]),
     "kge_score_bwd_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),

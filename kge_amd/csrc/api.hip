@@ -483,30 +483,24 @@ int64_t kge_score_rank_bits_bytes(int64_t n, int64_t m, int num_filters) {
   return 2 * (int64_t)num_filters * n * rank_bits_ld(m) * 8;
 }
 
-int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, int64_t col_begin,
-                         int64_t m, const float* true_sp, const float* true_po, int num_filters,
-                         const int64_t* const* sp_begin, const int64_t* const* sp_end, const int64_t* const* sp_col,
-                         const int64_t* const* po_begin, const int64_t* const* po_end, const int64_t* const* po_col,
-                         float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po,
-                         int64_t* ties_po, int64_t ld, void* filter_bits, int64_t filter_bits_bytes, void* workspace,
-                         int64_t workspace_bytes, void* stream) {
-  int rc = check_tables(t, true);
-  if (rc) return rc;
-  if (n < 0 || m < 0 || col_begin < 0 || col_begin + m > t->num_ent || num_filters < 0 || ld < n)
-    return KGE_ERR_INVALID_ARG;
-  if ((rc = check_index(s, false, n)) || (rc = check_index(p, false, n)) || (rc = check_index(o, false, n))) return rc;
-  if (n == 0 || m == 0) return KGE_OK;
-  if (!true_sp || !true_po || !rank_sp || !ties_sp || !rank_po || !ties_po) return KGE_ERR_INVALID_ARG;
+// S / O / P: the query operands (table + index, or dense rows); TG: the scored entity rows, m of them, whose global
+// ids start at col_begin; keep_o / keep_s: the rows' true object / subject ids (never filtered)
+static int score_rank_core(const kge_tables* t, const Operand& S, const Operand& O, const Operand& P,
+                           const Operand& TG, const Index& keep_o, const Index& keep_s, int64_t n, int64_t col_begin,
+                           int64_t m, const float* true_sp, const float* true_po, int num_filters,
+                           const int64_t* const* sp_begin, const int64_t* const* sp_end, const int64_t* const* sp_col,
+                           const int64_t* const* po_begin, const int64_t* const* po_end, const int64_t* const* po_col,
+                           float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po,
+                           int64_t* ties_po, int64_t ld, void* filter_bits, int64_t filter_bits_bytes, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+  if (!true_sp || !true_po || !rank_sp || !ties_sp || !rank_po || !ties_po || ld < n) return KGE_ERR_INVALID_ARG;
+  if (num_filters < 0) return KGE_ERR_INVALID_ARG;
   if (num_filters > 2) return KGE_ERR_UNSUPPORTED;
   for (int k = 0; k < num_filters; ++k)
     if (!sp_begin || !sp_end || !sp_col || !po_begin || !po_end || !po_col || !sp_begin[k] || !sp_end[k] ||
         !sp_col[k] || !po_begin[k] || !po_end[k] || !po_col[k])
       return KGE_ERR_INVALID_ARG;
   if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
-  const kge_index all = {nullptr, 0, 0, 1};
-  Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, all);
-  const int esize = t->dtype == KGE_BF16 ? 2 : 4;
-  TG.base = (const char*)TG.base + col_begin * TG.ld * esize;
   if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
       !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
     return KGE_ERR_UNSUPPORTED;
@@ -537,18 +531,62 @@ int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_inde
       lb[q] = (const long long*)(side ? po_begin[k] : sp_begin[k]);
       le[q] = (const long long*)(side ? po_end[k] : sp_end[k]);
       lc[q] = (const long long*)(side ? po_col[k] : sp_col[k]);
-      keep[q] = make_index(side ? s : o);
+      keep[q] = side ? keep_s : keep_o;
       bits[q] = (unsigned long long*)filter_bits + (int64_t)q * n * bld;
       ce.rk_bits[side][k] = bits[q];
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  if ((rc = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 1, st))) return rc;
+  int rc = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 1, st);
+  if (rc) return rc;
   rc = run_pairs_bf16_v4_epi(t->scorer, V3_RANK, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, st, workspace,
                              workspace_bytes, ce, nullptr);
   // (also after a declined launch: the bits must not outlive the call)
   const int rc2 = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
   return rc ? rc : rc2;
+}
+
+int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, int64_t col_begin,
+                         int64_t m, const float* true_sp, const float* true_po, int num_filters,
+                         const int64_t* const* sp_begin, const int64_t* const* sp_end, const int64_t* const* sp_col,
+                         const int64_t* const* po_begin, const int64_t* const* po_end, const int64_t* const* po_col,
+                         float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po,
+                         int64_t* ties_po, int64_t ld, void* filter_bits, int64_t filter_bits_bytes, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (n < 0 || m < 0 || col_begin < 0 || col_begin + m > t->num_ent) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s, false, n)) || (rc = check_index(p, false, n)) || (rc = check_index(o, false, n))) return rc;
+  if (n == 0 || m == 0) return KGE_OK;
+  const kge_index all = {nullptr, 0, 0, 1};
+  Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, all);
+  TG.base = (const char*)TG.base + col_begin * TG.ld * (t->dtype == KGE_BF16 ? 2 : 4);
+  return score_rank_core(t, S, O, P, TG, make_index(o), make_index(s), n, col_begin, m, true_sp, true_po, num_filters,
+                         sp_begin, sp_end, sp_col, po_begin, po_end, po_col, atol, rtol, rank_sp, ties_sp, rank_po,
+                         ties_po, ld, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream);
+}
+
+int kge_score_rank_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb, int64_t p_ld,
+                             const void* o_emb, int64_t o_ld, kge_index s_ids, kge_index o_ids, int64_t n,
+                             const void* tgt_emb, int64_t tgt_ld, int64_t col_begin, int64_t m, const float* true_sp,
+                             const float* true_po, int num_filters, const int64_t* const* sp_begin,
+                             const int64_t* const* sp_end, const int64_t* const* sp_col,
+                             const int64_t* const* po_begin, const int64_t* const* po_end,
+                             const int64_t* const* po_col, float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp,
+                             int64_t* rank_po, int64_t* ties_po, int64_t ld, void* filter_bits,
+                             int64_t filter_bits_bytes, void* workspace, int64_t workspace_bytes, void* stream) {
+  int rc = check_tables(t, false);
+  if (rc) return rc;
+  if (n < 0 || m < 0 || col_begin < 0) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s_ids, false, n)) || (rc = check_index(o_ids, false, n))) return rc;
+  if (n == 0 || m == 0) return KGE_OK;
+  if (!s_emb || !p_emb || !o_emb || !tgt_emb) return KGE_ERR_INVALID_ARG;
+  if (s_ld < t->dim || o_ld < t->dim || tgt_ld < t->dim || p_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
+  const Index ident{nullptr, 1, KGE_I64};
+  Operand S{s_emb, s_ld, ident}, P{p_emb, p_ld, ident}, O{o_emb, o_ld, ident}, TG{tgt_emb, tgt_ld, ident};
+  return score_rank_core(t, S, O, P, TG, make_index(o_ids), make_index(s_ids), n, col_begin, m, true_sp, true_po,
+                         num_filters, sp_begin, sp_end, sp_col, po_begin, po_end, po_col, atol, rtol, rank_sp, ties_sp,
+                         rank_po, ties_po, ld, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream);
 }
 
 int kge_rank_hist(const int64_t* rank, const int64_t* ties, int num_rankings, int64_t n, int tie_policy,

@@ -520,22 +520,11 @@ def _rank_bits(need, device, stream):
     return buf.data_ptr(), buf.numel()
 
 
-def score_rank_sp_po(t: Tables, s, p, o, true_sp, true_po, filters_sp, filters_po, atol, rtol, rank_sp, ties_sp,
-                     rank_po, ties_po, col_begin: int = 0, col_end=None, flags=None) -> bool:
-    """Raw + filtered (rank, ties) counts of both directions of a batch against the entity rows
-    [col_begin, col_end), counted inside the scoring kernel: what score_sp_po + two rank_counts_multi calls
-    give, without the [n, 2m] score matrix.  true_sp / true_po: float32 [n] scores of the triples
-    themselves; filters_*: [(begin [n], end [n], col [nnz]), ...] (at most two); rank_* / ties_*: int64
-    [len(filters) + 1, n] (a row stride >= n is fine), accumulated.  False: the library declines this
-    configuration (tables other than bf16 ComplEx / DistMult with dim 256 / 512) -- nothing was counted."""
-    keep = []
-    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = _same_len(keep[:3], "score_rank_sp_po")
+def _rank_args(n, true_sp, true_po, filters_sp, filters_po, rank_sp, ties_sp, rank_po, ties_po):
+    """Checked (K, ld, six host arrays of device pointers) of the score_rank_* entries."""
     K = len(filters_sp)
     if len(filters_po) != K:
         raise ValueError("kge_amd: one filter list per direction and filter set")
-    col_end = t.num_ent if col_end is None else int(col_end)
-    m = col_end - int(col_begin)
     for x in (true_sp, true_po):
         _require_gpu(x, "true scores")
         if x.dtype != torch.float32 or x.numel() != n or not x.is_contiguous():
@@ -550,6 +539,23 @@ def score_rank_sp_po(t: Tables, s, p, o, true_sp, true_po, filters_sp, filters_p
         ld = l
     arr = ctypes.c_void_p * max(K, 1)
     lists = [(arr(*[f[j].data_ptr() for f in fl]) if K else None) for fl in (filters_sp, filters_po) for j in range(3)]
+    return K, ld, lists
+
+
+def score_rank_sp_po(t: Tables, s, p, o, true_sp, true_po, filters_sp, filters_po, atol, rtol, rank_sp, ties_sp,
+                     rank_po, ties_po, col_begin: int = 0, col_end=None, flags=None) -> bool:
+    """Raw + filtered (rank, ties) counts of both directions of a batch against the entity rows
+    [col_begin, col_end), counted inside the scoring kernel: what score_sp_po + two rank_counts_multi calls
+    give, without the [n, 2m] score matrix.  true_sp / true_po: float32 [n] scores of the triples
+    themselves; filters_*: [(begin [n], end [n], col [nnz]), ...] (at most two); rank_* / ties_*: int64
+    [len(filters) + 1, n] (a row stride >= n is fine), accumulated.  False: the library declines this
+    configuration (tables other than bf16 ComplEx / DistMult with dim 256 / 512) -- nothing was counted."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = _same_len(keep[:3], "score_rank_sp_po")
+    col_end = t.num_ent if col_end is None else int(col_end)
+    m = col_end - int(col_begin)
+    K, ld, lists = _rank_args(n, true_sp, true_po, filters_sp, filters_po, rank_sp, ties_sp, rank_po, ties_po)
     with _on_device(t.device):
         tc = t.c(flags)
         st = _stream_handle(t.device)
@@ -562,6 +568,46 @@ def score_rank_sp_po(t: Tables, s, p, o, true_sp, true_po, filters_sp, filters_p
         if rc == _lib.KGE_ERR_UNSUPPORTED:
             return False
         _lib.check(rc, "kge_score_rank_sp_po")
+    return True
+
+
+def score_rank_emb_sp_po(scorer, s_emb, p_emb, o_emb, s_ids, o_ids, targets, col_begin, true_sp, true_po, filters_sp,
+                         filters_po, atol, rtol, rank_sp, ties_sp, rank_po, ties_po, l_norm: float = 1.0) -> bool:
+    """score_rank_sp_po for dense query rows against the entity rows `targets` [m, d] whose global ids start at
+    col_begin (a rank's shard): s_ids / o_ids = the global ids of the true subjects / objects.  Counts of these
+    m columns only (the sharded caller all-reduces).  False: declined, nothing counted."""
+    for x in (s_emb, p_emb, o_emb, targets):
+        _require_gpu(x, "embedding")
+    if len({s_emb.dtype, p_emb.dtype, o_emb.dtype, targets.dtype}) != 1:
+        raise TypeError("kge_amd: embeddings must share a dtype")
+    if s_emb.dtype != torch.bfloat16:
+        return False
+    s_emb, p_emb, o_emb, targets = (x if x.stride(-1) == 1 else x.contiguous() for x in (s_emb, p_emb, o_emb, targets))
+    sc = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
+    n, m = p_emb.shape[0], targets.shape[0]
+    d, dr = s_emb.shape[1], p_emb.shape[1]
+    dev = s_emb.device
+    keep = []
+    si, oi = _index(s_ids, dev, keep), _index(o_ids, dev, keep)
+    if _same_len(keep[:2], "score_rank_emb_sp_po") != n:
+        raise ValueError("kge_amd: one true id per query row")
+    K, ld, lists = _rank_args(n, true_sp, true_po, filters_sp, filters_po, rank_sp, ties_sp, rank_po, ties_po)
+    key = (s_emb.dtype, sc, d, dr, float(l_norm), 0)
+    tc = _EMB_TC.get(key)
+    if tc is None:
+        tc = _EMB_TC[key] = KgeTables(None, None, _dtype_code(s_emb), sc, 0, 0, d, dr, d, dr, float(l_norm), 0)
+    with _on_device(dev):
+        st = _stream_handle(dev)
+        ws, wsb = _workspace(tc, n, dev, True, st)
+        bits, bits_bytes = _rank_bits(_lib.lib().kge_score_rank_bits_bytes(n, m, K), dev, st)
+        rc = _lib.lib().kge_score_rank_emb_sp_po(
+            ctypes.byref(tc), s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(), p_emb.stride(0), o_emb.data_ptr(),
+            o_emb.stride(0), si, oi, n, targets.data_ptr(), targets.stride(0), int(col_begin), m, true_sp.data_ptr(),
+            true_po.data_ptr(), K, *lists, float(atol), float(rtol), rank_sp.data_ptr(), ties_sp.data_ptr(),
+            rank_po.data_ptr(), ties_po.data_ptr(), ld, bits, bits_bytes, ws, wsb, st)
+        if rc == _lib.KGE_ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc, "kge_score_rank_emb_sp_po")
     return True
 
 

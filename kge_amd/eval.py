@@ -20,6 +20,8 @@ applies the filters cumulatively (:305-307), "_filt_test" filters with the union
 """
 from typing import Dict, List, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -144,6 +146,8 @@ class EntityRankingEvaluator:
         self.batch_size, self.chunk_size = batch_size, chunk_size
         self.tie_handling, self.tie_atol, self.tie_rtol = tie_handling, tie_atol, tie_rtol
         self.hits_at_k_s = [k for k in hits_at_k_s if k <= min(num_entities, max(hits_at_k_s))]
+        # count inside the scoring kernel where the library offers it (set False to force the two-step path)
+        self._fused = os.environ.get("KGE_EVAL_TWO_STEP", "0") != "1"
 
     def _device_state(self, dev):
         """Everything the loop needs, resident on `dev` (built once): the eval triples, the filter
@@ -187,6 +191,9 @@ class EntityRankingEvaluator:
         all_ranks = {f"{d}{r}": [] for r in rankings for d in "so"}
         chunk = E if self.chunk_size < 0 else self.chunk_size
         triples = st["triples"]
+        fused = (self._fused and isinstance(tables, engine.Tables) and M <= 3 and tables.ent.dtype == torch.bfloat16
+                 and tables.scorer in (engine.SCORERS["complex"], engine.SCORERS["distmult"])
+                 and tables.ent.shape[1] in (256, 512))
 
         for b0 in range(0, len(self.triples), self.batch_size):
             batch = triples[b0:b0 + self.batch_size]
@@ -207,7 +214,14 @@ class EntityRankingEvaluator:
             engine.filter_lookup_multi(lookups)  # all lookups of the batch in one launch
 
             o_true = s_true = None
-            if chunk < E:
+            if fused:
+                # the counting kernel needs the true scores up front: the batch against its own targets in
+                # one two-sided launch ([n, 4n]: sp_ scores of (o | s), then _po scores of (o | s)), the
+                # two diagonals kept -- elements of the score matrix bit for bit, as in the chunked case
+                both = engine.score_sp_po(tables, s, p, o, torch.cat([oc_, sc_]))
+                o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
+                s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
+            elif chunk < E:
                 # true scores through the subset path (:192-203), without torch.unique (a host
                 # sync): score every row against the batch's own targets, keep the diagonal --
                 # each score is its own chain, so the bits do not depend on the subset
@@ -215,6 +229,12 @@ class EntityRankingEvaluator:
                 s_true = engine.score_po(tables, p, o, s).diagonal().contiguous()
             for start in range(0, E, chunk):
                 end = min(start + chunk, E)
+                if fused:
+                    # scoring + counting in one kernel: no [n, 2c] score matrix (kge_score_rank_sp_po)
+                    if engine.score_rank_sp_po(tables, s, p, o, o_true, s_true, filt_o, filt_s, self.tie_atol,
+                                               self.tie_rtol, cnt[0, 0], cnt[0, 1], cnt[1, 0], cnt[1, 1], start, end):
+                        continue
+                    fused = self._fused = False  # declined (not bf16 ComplEx / DistMult, d 256 / 512): two steps
                 sub = None if (start == 0 and end == E) else torch.arange(start, end, device=dev)
                 scores = engine.score_sp_po(tables, s, p, o, sub)
                 c = end - start

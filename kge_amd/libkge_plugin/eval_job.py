@@ -1,5 +1,6 @@
 """EntityRankingJob on the fused kernels (eval.type: hip_entity_ranking)."""
 import math
+import os
 import time
 
 import numpy as np
@@ -127,6 +128,13 @@ class HipEntityRankingJob(EntityRankingJob):
         for f in self.pre_epoch_hooks:
             f(self)
 
+        # bf16 ComplEx / DistMult tables with dim 256 / 512 (score_dtype: bfloat16 or bf16 parameters) behind a
+        # plain hip_* model: scoring and counting in one kernel.  KGE_EVAL_TWO_STEP=1: never.
+        fused_tables = getattr(self.model, "_ce_tables", None)
+        if (os.environ.get("KGE_EVAL_TWO_STEP", "0") == "1" or M > 3 or fused_tables is None or fused_tables() is None
+                or fused_tables().ent.shape[1] not in (256, 512)):
+            fused_tables = None
+
         metrics = {}
         epoch_time = -time.time()
         for batch_number, batch_coords in enumerate(self.loader):
@@ -153,7 +161,14 @@ class HipEntityRankingJob(EntityRankingJob):
             engine.filter_lookup_multi(lookups)  # kge_filter_lookup_multi: the batch's four lookups, one launch
 
             o_true = s_true = None
-            if chunk_size < E:
+            ft = fused_tables() if fused_tables is not None else None
+            if ft is not None:
+                # counts straight from the scoring kernel (kge_score_rank_sp_po): the true scores up front, as
+                # the two diagonals of ONE two-sided call against the batch's own targets (o | s)
+                both = engine.score_sp_po(ft, s, p, o, torch.cat([o64, s64]))
+                o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
+                s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
+            elif chunk_size < E:
                 # the subset path of :192-203 without torch.unique: every row against the batch's
                 # own targets, diagonal kept (each score is its own kernel chain)
                 o_true = self.model.score_sp(s, p, o64).diagonal().contiguous()
@@ -162,6 +177,12 @@ class HipEntityRankingJob(EntityRankingJob):
                 chunk_start = chunk_size * chunk_number
                 chunk_end = min(chunk_size * (chunk_number + 1), E)
                 c = chunk_end - chunk_start
+                if ft is not None:
+                    if engine.score_rank_sp_po(ft, s, p, o, o_true, s_true, filt_o, filt_s, self.tie_atol,
+                                               self.tie_rtol, cnt[0, 0], cnt[0, 1], cnt[1, 0], cnt[1, 1],
+                                               chunk_start, chunk_end):
+                        continue
+                    ft = fused_tables = None  # declined: the two-step path from here on (o_true / s_true stay)
                 sub = None if c == E else torch.arange(chunk_start, chunk_end, device=dev)
                 scores = self.model.score_sp_po(s, p, o, sub)
                 scores_sp, scores_po = scores[:, :c], scores[:, c:]

@@ -109,6 +109,9 @@ class ShardedEntityTable:
             from . import engine as backend  # the HIP kernels; no CPU fallback
         self.backend = backend
         self._bufs, self._tcache = {}, {}
+        # rank_batch_multi counts inside the scoring kernel where the backend offers it (no score slabs);
+        # False / KGE_EVAL_TWO_STEP=1: score slabs + rank_counts_multi
+        self.fused_rank = os.environ.get("KGE_EVAL_TWO_STEP", "0") != "1"
 
     @staticmethod
     def partition(num_entities: int, world: int, rank: int):
@@ -260,6 +263,10 @@ class ShardedEntityTable:
         [2 (o, s), 2 (rank, ties), len(filters) + 1, n]."""
         s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
         n, K = triples.shape[0], len(filters_o)
+        if self.fused_rank and hasattr(self.backend, "score_rank_emb_sp_po") and K <= 2:
+            counts = self._rank_batch_fused(s, p, o, filters_o, filters_s, atol, rtol)
+            if counts is not None:
+                return counts
         sp, po = self.score_sp_po_blocks(s, p, o)
         o_true = self.true_scores(sp, o)
         s_true = self.true_scores(po, s)
@@ -269,6 +276,26 @@ class ShardedEntityTable:
         self.backend.rank_counts_multi(po, s_true, filters_s, self.lo, s.long().contiguous(), atol, rtol,
                                        counts[1, 0], counts[1, 1])
         return self._allreduce(counts)
+
+    def _rank_batch_fused(self, s, p, o, filters_o, filters_s, atol, rtol):
+        """rank_batch_multi without the score slabs: the counts come out of the scoring kernel
+        (kge_score_rank_emb_sp_po over this rank's shard).  The true scores need no exchange of their own: the
+        exchanged rows of s and o are on every rank, so each rank scores every query against its own target row
+        (one two-sided launch on 2n target rows, the diagonals kept) -- the bits the owner's slab would hold.
+        None: the backend declines (tables other than bf16 ComplEx / DistMult, dim 256 / 512)."""
+        n, K = s.numel(), len(filters_o)
+        if self.ent_local.dtype != torch.bfloat16 or not hasattr(self.backend, "score_emb_sp_po"):
+            return None
+        rows, rel_rows = self.exchange_rows([o, s], p)
+        o_rows, s_rows = rows[:n], rows[n:]
+        both = self.backend.score_emb_sp_po(self.scorer, s_rows, rel_rows, o_rows, rows, self.l_norm)  # [n, 4n]
+        o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
+        s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
+        counts = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=rows.device)
+        ok = self.backend.score_rank_emb_sp_po(self.scorer, s_rows, rel_rows, o_rows, s, o, self.ent_local, self.lo,
+                                               o_true, s_true, filters_o, filters_s, atol, rtol, counts[0, 0],
+                                               counts[0, 1], counts[1, 0], counts[1, 1], self.l_norm)
+        return self._allreduce(counts) if ok else None
 
     def topk(self, slab: torch.Tensor, k: int):
         """Global top-k (scores, entity ids) per row: local top-k, all-gather, merge

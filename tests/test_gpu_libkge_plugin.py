@@ -267,6 +267,47 @@ def test_c_hip_entity_ranking_matches_entity_ranking(data, model):
     assert abs(ma["mean_reciprocal_rank_filtered"] - mb["mean_reciprocal_rank_filtered"]) <= 1e-5
 
 
+@pytest.mark.parametrize("model", ["distmult", "complex"])
+def test_c2_fused_counting_equals_the_reference_job_on_the_same_bf16_scores(data, model):
+    """`score_dtype: bfloat16`: HipEntityRankingJob counts inside the scoring kernel (kge_score_rank_sp_po, no
+    score matrix).  The reference's EntityRankingJob over the same hip model ranks the score matrices the
+    kernel writes: per-example ranks and metrics must be identical, unchunked and with entity chunks."""
+    from kge_amd import engine
+    root, folder = data
+    torch.manual_seed(6)
+    d = 512
+    state = {"_entity_embedder._embeddings.weight": torch.randn(E, d, device=DEVICE) * 0.3,
+             "_relation_embedder._embeddings.weight": torch.randn(R, d, device=DEVICE) * 0.3}
+    bf = {f"hip_{model}.score_dtype": "bfloat16"}
+    calls = {"n": 0}
+    orig = engine.score_rank_sp_po
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        ok = orig(*a, **k)
+        assert ok
+        return ok
+
+    engine.score_rank_sp_po = counting
+    try:
+        for chunk in (-1, 5000):
+            j1, ex_1, m_1 = _eval(root, folder, f"c2_mid_{model}", "hip_" + model, "entity_ranking", state, chunk, opts=bf)
+            assert calls["n"] == 0
+            j2, ex_2, m_2 = _eval(root, folder, f"c2_hip_{model}", "hip_" + model, "hip_entity_ranking", state, chunk,
+                                  opts=bf)
+            assert calls["n"] > 0, "the fused entry was not used"
+            calls["n"] = 0
+            assert len(ex_1) == len(ex_2) == 2 * 1500
+            assert ex_1 == ex_2
+            for k in m_1:
+                assert m_1[k] == m_2[k], k
+            _log(case=f"c2: fused counting (score_dtype bfloat16), hip_{model}, chunk {chunk}", examples=len(ex_2),
+                 identical_to_reference_job_on_same_scores=True, eval_seconds_hip_model_reference_job=j1.eval_seconds,
+                 eval_seconds_hip_model_hip_job=j2.eval_seconds)
+    finally:
+        engine.score_rank_sp_po = orig
+
+
 def test_d_reciprocal_relations_model_over_hip_distmult(data):
     root, folder = data
     rr = "reciprocal_relations_model"

@@ -154,3 +154,39 @@ def test_fused_path_declines_what_it_does_not_cover():
     cnt = torch.zeros(4, 1, 4, dtype=torch.int64, device=DEV)
     assert eng.score_rank_sp_po(T, s, p, o, z, z, [], [], 1e-5, 1e-4, cnt[0], cnt[1], cnt[2], cnt[3]) is False
     assert int(cnt.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("model,E,d,bs,chunk", [("complex", 3000, 256, 100, -1), ("distmult", 5003, 512, 77, -1),
+                                                 ("complex", 2500, 512, 64, 999), ("distmult", 700, 256, 300, 64)])
+def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d, bs, chunk):
+    """EntityRankingEvaluator (the mirror of EntityRankingJob._evaluate) takes the fused entry for bf16 ComplEx /
+    DistMult tables: per-example ranks (raw, filtered, filtered-with-test; both directions; ragged last batch;
+    entity chunks) and metrics identical to the same loop over kge_score_sp_po + kge_rank_counts_multi."""
+    from kge_amd import engine as eng
+    from kge_amd.eval import EntityRankingEvaluator
+    from kge_amd.synthetic import make_splits
+    R = 9
+    splits = make_splits(E, R, 6000, 431, 300, seed=E)
+    T = _tables(eng, model, E, R, d, seed=d + E)
+    calls = {"fused": 0}
+    orig = eng.score_rank_sp_po
+
+    def counting(*a, **k):
+        calls["fused"] += 1
+        return orig(*a, **k)
+
+    eng.score_rank_sp_po = counting
+    try:
+        ev = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
+        m1, r1 = ev.run(return_ranks=True)
+        assert calls["fused"] > 0 and ev._fused
+        ev2 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
+        ev2._fused = False
+        before = calls["fused"]
+        m2, r2 = ev2.run(return_ranks=True)
+        assert calls["fused"] == before
+    finally:
+        eng.score_rank_sp_po = orig
+    for k in r2:
+        assert np.array_equal(r1[k], r2[k]), (k, np.nonzero(r1[k] != r2[k])[0][:5])
+    assert m1 == m2

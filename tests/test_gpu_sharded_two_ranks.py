@@ -69,6 +69,23 @@ def _worker(rank, world, port, model, q):
         assert sh.world == 2 and sh.collectives
         s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
         ranks = [x.cpu().numpy() for x in sh.rank_batch(tri, None)]
+        # raw + filtered counts out of the scoring kernel (kge_score_rank_emb_sp_po on each shard, one counter
+        # all-reduce) against score slabs + rank_counts_multi, and against rank_batch's raw counts
+        cnt = torch.randint(0, 6, (n,), generator=g)
+        end = torch.cumsum(cnt, 0)
+        beg = end - cnt
+        def values():  # distinct ids within a row's range (the contract of the filter index)
+            v = [torch.randperm(E, generator=g)[:int(c)] for c in cnt] + [torch.zeros(1, dtype=torch.int64)]
+            return torch.cat(v).to(DEV)
+        fo, fs = [(beg.to(DEV), end.to(DEV), values())], [(beg.to(DEV), end.to(DEV), values())]
+        fused = sh._rank_batch_fused(s, p, o, fo, fs, 1e-5, 1e-4)
+        assert fused is not None, "the sharded path did not count inside the scoring kernel"
+        assert torch.equal(sh.rank_batch_multi(tri, fo, fs), fused)
+        sh.fused_rank = False
+        assert torch.equal(sh.rank_batch_multi(tri, fo, fs), fused)
+        sh.fused_rank = True
+        for a, b in zip((fused[1, 0, 0], fused[1, 1, 0], fused[0, 0, 0], fused[0, 1, 0]), ranks):
+            assert np.array_equal(a.cpu().numpy(), b)
         tv, ti = sh.topk(sh.score_sp(s, p), 7)
         blk_sp, blk_po = (x.clone() for x in sh.score_sp_po_blocks(s, p, o))  # the step bench.py --gpus N times
         small, sh.BIG_SLAB_BYTES = sh.BIG_SLAB_BYTES, 0                      # ... and its big-slab form (padded pitch,
