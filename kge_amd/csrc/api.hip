@@ -539,8 +539,29 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   hipStream_t st = (hipStream_t)stream;
   int rc = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 1, st);
   if (rc) return rc;
-  rc = run_pairs_bf16_v4_epi(t->scorer, V3_RANK, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, st, workspace,
-                             workspace_bytes, ce, nullptr);
+  // one launch holds at most 32 row groups (one workgroup per CU and XCD-aligned column groups): 2,048 rows per
+  // side; larger batches go through in row blocks
+  const int esize = t->dtype == KGE_BF16 ? 2 : 4;
+  auto rows_from = [&](const Operand& x, int64_t r0) {
+    Operand y = x;
+    if (y.idx.ptr == nullptr) y.base = (const char*)y.base + r0 * y.ld * esize;
+    else y.idx.ptr = (const char*)y.idx.ptr + r0 * y.idx.stride * (y.idx.itype ? 8 : 4);
+    return y;
+  };
+  constexpr int64_t BLOCK = 2048;
+  for (int64_t r0 = 0; r0 < n && rc == KGE_OK; r0 += BLOCK) {
+    const int64_t nb = n - r0 < BLOCK ? n - r0 : BLOCK;
+    CeArgs cb = ce;
+    for (int side = 0; side < 2; ++side) {
+      cb.rk_true[side] += r0;
+      cb.rk_rank[side] += r0;
+      cb.rk_ties[side] += r0;
+      for (int k = 0; k < num_filters; ++k) cb.rk_bits[side][k] += r0 * bld;
+    }
+    const Operand Sb = rows_from(S, r0), Ob = rows_from(O, r0), Pb = rows_from(P, r0);
+    rc = run_pairs_bf16_v4_epi(t->scorer, V3_RANK, Sb, &Ob, Pb, TG, KGE_SP_, (int)t->dim, nb, m, st, workspace,
+                               workspace_bytes, cb, nullptr);
+  }
   // (also after a declined launch: the bits must not outlive the call)
   const int rc2 = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
   return rc ? rc : rc2;

@@ -757,6 +757,11 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   // pairs_bf16_v3_column_groups (256 workgroup slots); fewer CUs: the launch check below declines
   if (EPI != V3_STORE) cus = 256;
   int ncg = cus / rgn;
+  // Workgroup b runs on XCD b % 8 and the launch maps its low three bits to the low three bits of the column
+  // group: the grid is 8 * rgn * ceil(ncg / 8) workgroups, one per CU.  Whole groups of eight column groups that
+  // fit the CUs (rgn = 3: 80 instead of 85 -> 240 workgroups, not 264 and a declined launch; a two-sided batch of
+  // 1,151 rows: 8 instead of 14).  The fused-loss epilogues keep the geometry their scratch was sized for.
+  if ((EPI == V3_STORE || EPI == V3_RANK) && ncg > 8) ncg = 8 * (cus / 8 / rgn > 0 ? cus / 8 / rgn : 1);
   if (ncg < 1) ncg = 1;
   int tpc = (ntiles + ncg - 1) / ncg;
   if (tpc < 1) tpc = 1;

@@ -166,6 +166,7 @@ class EntityRankingEvaluator:
             "ranges": torch.zeros(2, K, 2, bs, dtype=torch.int64, device=dev),
             # [direction][rank | ties][ranking][row]
             "counts": torch.zeros(2, 2, K + 1, bs, dtype=torch.int64, device=dev),
+            "diag": {},
         }
         for k in range(K):  # an empty value array still needs an address
             for side in ("sp", "po"):
@@ -219,8 +220,12 @@ class EntityRankingEvaluator:
                 # one two-sided launch ([n, 4n]: sp_ scores of (o | s), then _po scores of (o | s)), the
                 # two diagonals kept -- elements of the score matrix bit for bit, as in the chunked case
                 both = engine.score_sp_po(tables, s, p, o, torch.cat([oc_, sc_]))
-                o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
-                s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
+                diag = st["diag"].get(n)
+                if diag is None:  # flat positions of (i, i) and (i, 3n + i) in the [n, 4n] block
+                    ar = torch.arange(n, device=dev)
+                    diag = st["diag"][n] = torch.cat([ar * (4 * n + 1), ar * (4 * n + 1) + 3 * n])
+                true = both.view(-1).index_select(0, diag)
+                o_true, s_true = true[:n], true[n:]
             elif chunk < E:
                 # true scores through the subset path (:192-203), without torch.unique (a host
                 # sync): score every row against the batch's own targets, keep the diagonal --

@@ -80,6 +80,8 @@ CASES = [
     ("distmult", 64, 3, 256, 1, 2, None),               # one row, one tile
     ("complex", 9000, 13, 256, 300, 2, ((0, 4097), (4097, 9000))),  # entity chunks, accumulated
     ("distmult", 20000, 13, 512, 1000, 2, ((0, 10000), (10000, 10001), (10001, 20000))),
+    ("distmult", 3000, 5, 256, 1151, 1, None),          # 9 + 9 row groups: column groups in whole groups of eight
+    ("complex", 2100, 5, 256, 2500, 2, None),           # more rows than one launch holds: row blocks of 2,048
 ]
 
 
