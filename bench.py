@@ -40,6 +40,7 @@ sys.path.insert(0, ROOT)
 E_FB, R_FB, DIM, BATCH = 14541, 237, 512, 512
 E_WD, R_WD, DIM_WD = 4594485, 822, 256  # Wikidata5M shape (K5)
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (no sparsity)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 
 
@@ -167,6 +168,56 @@ def event_avg_ms(fn, steps):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
+
+
+def rank_legs(engine, device, n, steps):
+    """One entity-ranking evaluation batch (raw + filtered + filtered-with-test counts, both directions) with the
+    counts taken inside the scoring kernel (kge_score_rank_sp_po: no score matrix) and as score_sp_po + two
+    rank_counts_multi scans, at the FB15k-237 shape and at one of eight Wikidata5M shards.  MFMA-bound:
+    flops = 2 directions * 2 n E d."""
+    import numpy as np
+    out = {"bound": "mfma", "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+           "kernel": "pairs_bf16_v4_kernel<ComplEx, V3_RANK> (kge_score_rank_sp_po incl. the two bit set / clear launches)"}
+    rng = np.random.default_rng(0)
+    for tag, E, R, d in (("fb15k-237", E_FB, R_FB, DIM), ("wikidata5m_shard", (E_WD + 7) // 8, R_WD, DIM_WD)):
+        g = torch.Generator(device=device).manual_seed(7)
+        T = engine.Tables("complex", (torch.randn(E, d, generator=g, device=device) * 0.3).bfloat16(),
+                          (torch.randn(R, d, generator=g, device=device) * 0.3).bfloat16())
+        s, p, o = (torch.from_numpy(rng.integers(0, hi, n)).to(device) for hi in (E, R, E))
+        t_sp = engine.score_sp(T, s, p, o).diagonal().contiguous()
+        t_po = engine.score_po(T, p, o, s).diagonal().contiguous()
+
+        lists = []
+        for tc in (o.cpu().numpy(), s.cpu().numpy()):
+            per = [np.unique(np.append(rng.integers(0, E, 4), c)) for c in tc]
+            end = np.cumsum([len(x) for x in per])
+            beg = end - np.array([len(x) for x in per])
+            one = tuple(torch.from_numpy(np.asarray(x, np.int64)).to(device) for x in (beg, end, np.concatenate(per)))
+            lists.append([one, one])
+        cnt = torch.zeros(2, 2, 3, n, dtype=torch.int64, device=device)
+        oc, sc = o.contiguous(), s.contiguous()
+
+        def fused():
+            ok = engine.score_rank_sp_po(T, s, p, o, t_sp, t_po, lists[0], lists[1], 1e-5, 1e-4, cnt[0, 0], cnt[0, 1],
+                                         cnt[1, 0], cnt[1, 1])
+            assert ok
+
+        def two_step():
+            sc2 = engine.score_sp_po(T, s, p, o)
+            engine.rank_counts_multi(sc2[:, :E], t_sp, lists[0], 0, oc, 1e-5, 1e-4, cnt[0, 0], cnt[0, 1])
+            engine.rank_counts_multi(sc2[:, E:], t_po, lists[1], 0, sc, 1e-5, 1e-4, cnt[1, 0], cnt[1, 1])
+
+        for fn in (fused, two_step):
+            for _ in range(3):
+                fn()
+        f_ms, t_ms = event_avg_ms(fused, steps), event_avg_ms(two_step, steps)
+        flops = 2.0 * 2.0 * n * E * d
+        out[tag] = {"num_entities": E, "dim": d, "batch": n, "fused_us": f_ms * 1e3, "two_step_us": t_ms * 1e3,
+                    "flops_per_batch": flops, "achieved": flops / (f_ms * 1e-3) / 1e12,
+                    "frac": flops / (f_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
+        del T
+        torch.cuda.empty_cache()
+    return out
 
 
 def sharded_workload(shape, world, rank, device, n, engine):
@@ -352,8 +403,9 @@ def main():
                      "avg_launch_us": f_ms * 1e3, "flops_per_launch": 2.0 * n * DIM * E_FB,
                      "scored_triples_per_s": n * E_FB / (f_ms * 1e-3)}
         del T32
+        extra_rank = rank_legs(engine, device, n, max(10, a.steps // 4))
     else:
-        extra_f32 = None
+        extra_f32 = extra_rank = None
 
     total = 2.0 * n * E_FB * a.steps
     ab = algorithmic_bytes(n, E_FB, DIM, sides=2)
@@ -398,6 +450,8 @@ def main():
     }
     if extra_f32 is not None:
         out["roofline_f32"] = extra_f32
+    if extra_rank is not None:
+        out["roofline_rank"] = extra_rank
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
     print(json.dumps(out))
