@@ -263,7 +263,8 @@ class ShardedEntityTable:
         [2 (o, s), 2 (rank, ties), len(filters) + 1, n]."""
         s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
         n, K = triples.shape[0], len(filters_o)
-        if self.fused_rank and hasattr(self.backend, "score_rank_emb_sp_po") and K <= 2:
+        if (self.fused_rank and K <= 2 and hasattr(self.backend, "score_rank_emb_sp_po")
+                and hasattr(self.backend, "score_emb_sp_po")):
             counts = self._rank_batch_fused(s, p, o, filters_o, filters_s, atol, rtol)
             if counts is not None:
                 return counts
@@ -284,8 +285,6 @@ class ShardedEntityTable:
         (one two-sided launch on 2n target rows, the diagonals kept) -- the bits the owner's slab would hold.
         None: the backend declines (tables other than bf16 ComplEx / DistMult, dim 256 / 512)."""
         n, K = s.numel(), len(filters_o)
-        if self.ent_local.dtype != torch.bfloat16 or not hasattr(self.backend, "score_emb_sp_po"):
-            return None
         rows, rel_rows = self.exchange_rows([o, s], p)
         o_rows, s_rows = rows[:n], rows[n:]
         both = self.backend.score_emb_sp_po(self.scorer, s_rows, rel_rows, o_rows, rows, self.l_norm)  # [n, 4n]
@@ -295,7 +294,10 @@ class ShardedEntityTable:
         ok = self.backend.score_rank_emb_sp_po(self.scorer, s_rows, rel_rows, o_rows, s, o, self.ent_local, self.lo,
                                                o_true, s_true, filters_o, filters_s, atol, rtol, counts[0, 0],
                                                counts[0, 1], counts[1, 0], counts[1, 1], self.l_norm)
-        return self._allreduce(counts) if ok else None
+        if not ok:  # the same answer on every rank (dtype / scorer / dim): two steps from now on
+            self.fused_rank = False
+            return None
+        return self._allreduce(counts)
 
     def topk(self, slab: torch.Tensor, k: int):
         """Global top-k (scores, entity ids) per row: local top-k, all-gather, merge

@@ -112,6 +112,18 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_rank_counts_multi(None, 3, 2, 5, None, 0, None, None, None, 0, None, 1e-5, 1e-4, None, None, None) == -1
     assert lib.kge_rank_counts_multi(ctypes.c_void_p(16), 5, 2, 5, ctypes.c_void_p(16), 9, None, None, None, 0, None,
                                      1e-5, 1e-4, ctypes.c_void_p(16), ctypes.c_void_p(16), None) == -2  # > KGE_MAX_FILTERS
+    # score + rank in one kernel: size arithmetic, argument checks, what it declines (all before any launch)
+    assert lib.kge_score_rank_bits_bytes(512, 14541, 2) == 2 * 2 * 512 * 228 * 8
+    assert lib.kge_score_rank_bits_bytes(512, 14541, 0) == 0 and lib.kge_score_rank_bits_bytes(0, 64, 2) == 0
+    P = ctypes.c_void_p(16)
+    rank_args = lambda t_, n, cb, m, k, lists=(None,) * 6: (ctypes.byref(t_), good, good, good, n, cb, m, P, P, k,
+                                                            *lists, 1e-5, 1e-4, P, P, P, P, max(n, 1), None, 0, P, 1 << 20, None)
+    assert lib.kge_score_rank_sp_po(*rank_args(bf16, 4, 0, bf16.num_ent + 1, 0)) == -1   # slice beyond the table
+    assert lib.kge_score_rank_sp_po(*rank_args(bf16, 4, 0, bf16.num_ent, 3)) == -2        # > 2 filter sets
+    assert lib.kge_score_rank_sp_po(*rank_args(bf16, 4, 0, bf16.num_ent, 1)) == -1        # filter lists missing
+    assert lib.kge_score_rank_sp_po(*rank_args(f32, 4, 0, f32.num_ent, 0)) == -2           # float32 tables
+    assert lib.kge_score_rank_sp_po(*rank_args(transe, 4, 0, transe.num_ent, 0)) == -2     # TransE
+    assert lib.kge_score_rank_sp_po(*rank_args(bf16, 0, 0, bf16.num_ent, 0)) == 0          # empty batch
     assert lib.kge_rank_hist(None, None, 3, 4, 7, None, 10, 10, None, None) == -1   # unknown tie policy
     assert lib.kge_rank_hist(None, None, 0, 0, 0, None, 10, 10, None, None) == 0
     # optimizer step: null / misaligned arrays

@@ -108,6 +108,24 @@ class OracleBackend:
             ties[k + 1] += torch.from_numpy(t)
 
 
+class FusedOracleBackend(OracleBackend):
+    """+ engine.score_rank_emb_sp_po (counts of this shard's columns without a score slab leaving the call),
+    restated on the oracle: the choreography of ShardedEntityTable._rank_batch_fused runs on CPU."""
+    calls = 0
+
+    @staticmethod
+    def score_rank_emb_sp_po(scorer, s_emb, p_emb, o_emb, s_ids, o_ids, targets, col_begin, true_sp, true_po,
+                             filters_sp, filters_po, atol, rtol, rank_sp, ties_sp, rank_po, ties_po, l_norm=1.0):
+        FusedOracleBackend.calls += 1
+        m = targets.shape[0]
+        both = OracleBackend.score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm)
+        OracleBackend.rank_counts_multi(both[:, :m], true_sp, filters_sp, col_begin, o_ids.long(), atol, rtol,
+                                        rank_sp, ties_sp)
+        OracleBackend.rank_counts_multi(both[:, m:], true_po, filters_po, col_begin, s_ids.long(), atol, rtol,
+                                        rank_po, ties_po)
+        return True
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -146,6 +164,14 @@ def _worker(rank, world, port, model, q):
             s_rank, s_ties, o_rank, o_ties = out[key]
             assert np.array_equal(cm[0, 0, k].numpy(), o_rank) and np.array_equal(cm[0, 1, k].numpy(), o_ties), key
             assert np.array_equal(cm[1, 0, k].numpy(), s_rank) and np.array_equal(cm[1, 1, k].numpy(), s_ties), key
+        # the same counts with the backend's score + rank entry: true scores from the exchanged rows on every rank
+        # (no all-reduce of their own), shard-local counts, ONE counter all-reduce
+        sh2 = ShardedEntityTable(model, torch.from_numpy(ent[lo:hi]), torch.from_numpy(rel), E,
+                                 backend=FusedOracleBackend)
+        cm2 = sh2.rank_batch_multi(tb, [(sb, se, torch.from_numpy(fi.sp_values))],
+                                   [(pb, pe, torch.from_numpy(fi.po_values))])
+        assert FusedOracleBackend.calls == 1 and sh2.fused_rank
+        assert torch.equal(cm2, cm)
         rows = sh.gather_entity_rows(tb[:, 0])
         assert np.array_equal(rows.numpy(), ent[batch[:, 0]])
         # the call sequence of bench.py --gpus N: one exchange for the s and o rows (strided int32
