@@ -75,7 +75,11 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   constexpr int RPP = 64 / SPR;          // target rows per piece
   constexpr bool IS_DS = EPI == V3_DS || EPI == V3_DSIG;  // writes bf16 gradients of the scores (G16)
   constexpr bool STAGED = EPI == V3_STORE || IS_DS;       // tiles go through the staging buffer to the store waves
-  constexpr int CST0 = 2 * TILEB;        // score staging: 4 x [32 rows][64 cols] f32
+  // target tiles in flight: the DMA of a tile is a full L2 round trip (~3 k cycles under load) -- with two buffers
+  // (d = 512: 2 x 64 KiB + staging = the whole LDS) one tile streams in while one is consumed and the loop period
+  // cannot drop below that round trip; d = 256 has room for four 32 KiB buffers: three tiles in flight
+  constexpr int NBUF = HH == 128 ? 4 : 2;
+  constexpr int CST0 = NBUF * TILEB;     // score staging: 4 x [32 rows][64 cols] f32
   constexpr int CSTW = 32 * V4_TN * 4;
   constexpr int SMEM = CST0 + 4 * CSTW;
   constexpr int NQ = 2 * NKB;            // MFMAs per tile (two 32-target halves)
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       auto tile_dma = [&](int tt, long long rows, int w) {
         const int tc = tt < ntl ? tt : ntl - 1;
         const long long trow0 = (long long)(tile_lo + tc * tile_st) * V4_TN;
-        unsigned int d = (unsigned int)((tt & 1) * TILEB + w * NL * 1024);
+        unsigned int d = (unsigned int)((tt % NBUF) * TILEB + w * NL * 1024);
         if (TGMODE == 0 && tile_lo + tc * tile_st < nfull && tld2 < (1LL << 28)) {
           const unsigned char* p = (const unsigned char*)tgb + (trow0 + w * 16) * tld2;
           v4_static_for<0, NL>([&](auto kc) __attribute__((always_inline)) {
@@ -233,28 +237,48 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
           }
         }
       };
-      {
-        const long long ra0 = load_rows(0, j2), rb0 = load_rows(0, j2 + 1);
-        const long long ra1 = load_rows(1, j2), rb1 = load_rows(1, j2 + 1);
-        tile_dma(0, ra0, j2);
-        tile_dma(0, rb0, j2 + 1);
-        if (ntl > 1) {
-          tile_dma(1, ra1, j2);
-          tile_dma(1, rb1, j2 + 1);
+      {  // fill the ring: tiles 0 .. NBUF-1
+        long long ra[NBUF], rb[NBUF];
+#pragma unroll
+        for (int k = 0; k < NBUF; ++k) {
+          ra[k] = load_rows(k, j2);
+          rb[k] = load_rows(k, j2 + 1);
+        }
+#pragma unroll
+        for (int k = 0; k < NBUF; ++k) {
+          if (k < ntl) {
+            tile_dma(k, ra[k], j2);
+            tile_dma(k, rb[k], j2 + 1);
+          }
         }
       }
-      long long rna = load_rows(2, j2), rnb = load_rows(2, j2 + 1);
+      long long rna = load_rows(NBUF, j2), rnb = load_rows(NBUF, j2 + 1);
       __builtin_amdgcn_s_barrier();  // B0
       for (int tt = 0; tt <= ntl; ++tt) {
-        // VMEM queue of this wave: only tile pieces (2 NL per tile), in order
-        if (tt == 0 && ntl > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // B1(tt)
-        if (tt >= 1 && tt + 1 < ntl) {
-          tile_dma(tt + 1, rna, j2);
-          tile_dma(tt + 1, rnb, j2 + 1);
-          rna = load_rows(tt + 2, j2);
-          rnb = load_rows(tt + 2, j2 + 1);
+        // VMEM queue of this wave: tile pieces (2 NL per tile), in order (index loads of the gathered-target modes
+        // only make a wait longer).  Tile tt has landed once at most the pieces of the tiles issued behind it are
+        // outstanding: min(ntl, NBUF) - 1 tiles at the start, then min(ntl - tt - 1, NBUF - 2).
+        int behind = tt == 0 ? (ntl < NBUF ? ntl : NBUF) - 1 : (ntl - tt - 1 < NBUF - 2 ? ntl - tt - 1 : NBUF - 2);
+        bool waited = false;
+        if constexpr (NBUF > 2) {  // (6 NL = 48 <= the counter's 63 at d = 256)
+          if (behind >= 3) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(6 * NL) : "memory");
+            waited = true;
+          } else if (behind == 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * NL) : "memory");
+            waited = true;
+          }
+        }
+        if (!waited) {
+          if (behind >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NL) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; the buffer of tile tt - 1 is free
+        if (tt >= 1 && tt - 1 + NBUF < ntl) {
+          tile_dma(tt - 1 + NBUF, rna, j2);
+          tile_dma(tt - 1 + NBUF, rnb, j2 + 1);
+          rna = load_rows(tt + NBUF, j2);
+          rnb = load_rows(tt + NBUF, j2 + 1);
         }
         __builtin_amdgcn_s_barrier();  // B2(tt)
       }
@@ -482,16 +506,17 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     rk_fetch(0);
   }
   // Bit layout of the per-lane masks = the tile's 64 columns: element r of half hf is bit 32 hf + 8 (r >> 2) + 4 fh + (r & 3).
-  auto rank_tile = [&](int tt) __attribute__((always_inline)) {
-    const long long c0t = (long long)(tile_lo + tt * tile_st) * V4_TN;
-    unsigned int g[2] = {0u, 0u}, c[2] = {0u, 0u};
-    if (!rk_slow) {
+  // rank_masks: the two result masks of one tile from its accumulators (before the 4 fh shift).
+  auto rank_masks = [&](const f32x16& a0, const f32x16& a1, unsigned int (&g)[2], unsigned int (&c)[2], bool fast)
+      __attribute__((always_inline)) {
+    g[0] = g[1] = c[0] = c[1] = 0u;
+    if (fast) {
       // finite true score, finite tolerance >= 0:  close <=> |x - t| <= allowed,  greater-and-not-close <=>
       // x - t > allowed  (NaN and -inf scores fail both, +inf is greater: what count_one gives)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned int bit = 1u << (8 * (r >> 2) + (r & 3));
-        const float e0 = acc0[r] - rk_t, e1 = acc1[r] - rk_t;
+        const float e0 = a0[r] - rk_t, e1 = a1[r] - rk_t;
         g[0] |= e0 > rk_al ? bit : 0u;
         c[0] |= __builtin_fabsf(e0) <= rk_al ? bit : 0u;
         g[1] |= e1 > rk_al ? bit : 0u;
@@ -502,14 +527,18 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       for (int r = 0; r < 16; ++r) {
         const unsigned int bit = 1u << (8 * (r >> 2) + (r & 3));
         int g0 = 0, c0 = 0, g1 = 0, c1 = 0;
-        count_one(acc0[r], rk_t, ce.rk_atol, ce.rk_rtol, g0, c0);
-        count_one(acc1[r], rk_t, ce.rk_atol, ce.rk_rtol, g1, c1);
+        count_one(a0[r], rk_t, ce.rk_atol, ce.rk_rtol, g0, c0);
+        count_one(a1[r], rk_t, ce.rk_atol, ce.rk_rtol, g1, c1);
         g[0] |= g0 ? bit : 0u;
         c[0] |= c0 ? bit : 0u;
         g[1] |= g1 ? bit : 0u;
         c[1] |= c1 ? bit : 0u;
       }
     }
+  };
+  // rank_finish: the masks of tile tt into the counters (its filter words are in rk_w); fetches the next tile's words
+  auto rank_finish = [&](int tt, unsigned int (&g)[2], unsigned int (&c)[2]) __attribute__((always_inline)) {
+    const long long c0t = (long long)(tile_lo + tt * tile_st) * V4_TN;
     // this lane's columns of the tile that exist (the ragged last tile of the slice ends at m)
     unsigned long long mine = 0x0f0f0f0f0f0f0f0full << (4 * fh);
     const long long rem = m - c0t;
@@ -531,6 +560,30 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       }
     }
     rk_fetch(tt + 1);
+  };
+  auto rank_tile = [&](int tt) __attribute__((always_inline)) {
+    unsigned int g[2], c[2];
+    rank_masks(acc0, acc1, g, c, !rk_slow);
+    rank_finish(tt, g, c);
+  };
+  // d = 256 (registers to spare): the comparisons of tile tt - 1 run on a copy of its accumulators in the shadow of
+  // tile tt's MFMA chain -- one element per MFMA slot (a 32x32x16 MFMA occupies the matrix pipe for 32 cycles, a
+  // slot's 7 VALU instructions take 28), instead of 1,100 cycles between two chains with the matrix pipe idle.
+  // A wave with an infinite true score (rk_slow) does the generic arithmetic on the copy after the chain instead.
+  constexpr bool RK_PIPE = EPI == V3_RANK && HH == 128;
+  f32x16 pv0, pv1;               // RK_PIPE: accumulators of the previous tile
+  unsigned int pg[2] = {0u, 0u}, pc[2] = {0u, 0u};
+  if constexpr (RK_PIPE) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pv0[r] = pv1[r] = 0.0f;
+  }
+  auto rank_step = [&](auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int hf = q & 1, r = (q >> 1) & 15;
+    constexpr unsigned int bit = 1u << (8 * (r >> 2) + (r & 3));
+    const float e = (hf ? pv1[r] : pv0[r]) - rk_t;
+    pg[hf] |= e > rk_al ? bit : 0u;
+    pc[hf] |= __builtin_fabsf(e) <= rk_al ? bit : 0u;
   };
 
   float lse_i = 0.0f, g_i = 0.0f, gb_i = 0.0f;  // V3_DS / V3_DSIG: the row's logsumexp, upstream gradient, g_i * row_bias[i]
@@ -615,7 +668,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; staging drained
     __builtin_amdgcn_sched_barrier(0);
     stamp();  // tile tt released
-    const unsigned int bt = (unsigned int)((tt & 1) * TILEB);
+    const unsigned int bt = (unsigned int)((tt % NBUF) * TILEB);
     unsigned int bp[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) bp[t] = bt + boff[t];
@@ -661,19 +714,30 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[q % PF], afr[q >> 1], acc0, 0, 0, 0);
       }
       if constexpr (q + PF < NQ) bread(bq[q % PF], std::integral_constant<int, q + PF>{});
+      if constexpr (RK_PIPE) rank_step(qc);
     });
     stamp();  // tile tt: MFMA chain issued
   };
   tile(0);
   if constexpr (EPI == V3_LSE) lse_tile(0);
   if constexpr (IS_DS) ds_tile(0);
-  if constexpr (EPI == V3_RANK) rank_tile(0);
+  if constexpr (EPI == V3_RANK && !RK_PIPE) rank_tile(0);
   for (int tt = 1; tt < ntl; ++tt) {
+    if constexpr (RK_PIPE) {
+      pv0 = acc0;
+      pv1 = acc1;
+      pg[0] = pg[1] = pc[0] = pc[1] = 0u;
+    }
     tile(tt);
     if constexpr (EPI == V3_LSE) lse_tile(tt);
     if constexpr (IS_DS) ds_tile(tt);
-    if constexpr (EPI == V3_RANK) rank_tile(tt);
+    if constexpr (EPI == V3_RANK && !RK_PIPE) rank_tile(tt);
+    if constexpr (RK_PIPE) {  // tile tt - 1: compared during tile tt's chain
+      if (rk_slow) rank_masks(pv0, pv1, pg, pc, false);
+      rank_finish(tt - 1, pg, pc);
+    }
   }
+  if constexpr (RK_PIPE) rank_tile(ntl - 1);  // the last tile has no chain to hide behind
   // the last tile's scores: stage them for the loaders' final pass
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // B1(ntl)
