@@ -182,6 +182,14 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
         ev = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
         m1, r1 = ev.run(return_ranks=True)
         assert calls["fused"] > 0 and ev._fused
+        # full batches of the unchunked fused loop replay one captured hipGraph; the same loop issued launch by launch
+        assert ev.graph_batches == (max(0, 431 // bs - 1) if chunk < 0 and 431 // bs >= 4 else 0)
+        ev3 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
+        ev3.hip_graph = False
+        m3, r3 = ev3.run(return_ranks=True)
+        assert ev3.graph_batches == 0 and m3 == m1 and all(np.array_equal(r1[k], r3[k]) for k in r1)
+        m1b, _ = ev.run(return_ranks=True)  # a second run captures afresh
+        assert m1b == m1
         ev2 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
         ev2._fused = False
         before = calls["fused"]

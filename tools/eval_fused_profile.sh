@@ -8,12 +8,18 @@ O=$R/gpurun_out/r2_eval_fused.txt
 mkdir -p $R/gpurun_out
 {
 echo "# tools/eval_probe.py (C4 shape: E=14,541, d=512 DistMult bf16, 17,535 valid triples; raw + filtered + filtered-with-test, both directions)"
-echo "## counting inside the scoring kernel (kge_score_rank_sp_po; default)"
+echo "## counting inside the scoring kernel (kge_score_rank_sp_po), full batches replayed as one hipGraph (default; \"second\" = the run that reuses the captured graph)"
 python $R/tools/eval_probe.py 2>&1 | grep "index build"
 BS=2048 python $R/tools/eval_probe.py 2>&1 | grep "index build"
+BS=128 python $R/tools/eval_probe.py 2>&1 | grep "index build"
+echo "## the same loop issued launch by launch (KGE_EVAL_GRAPH=0: no hipGraph replay of the full batches)"
+KGE_EVAL_GRAPH=0 python $R/tools/eval_probe.py 2>&1 | grep "index build"
+KGE_EVAL_GRAPH=0 BS=2048 python $R/tools/eval_probe.py 2>&1 | grep "index build"
+KGE_EVAL_GRAPH=0 BS=128 python $R/tools/eval_probe.py 2>&1 | grep "index build"
 echo "## two-step (KGE_EVAL_TWO_STEP=1: kge_score_sp_po + kge_rank_counts_multi)"
 KGE_EVAL_TWO_STEP=1 python $R/tools/eval_probe.py 2>&1 | grep "index build"
 KGE_EVAL_TWO_STEP=1 BS=2048 python $R/tools/eval_probe.py 2>&1 | grep "index build"
+KGE_EVAL_TWO_STEP=1 BS=128 python $R/tools/eval_probe.py 2>&1 | grep "index build"
 echo "## rocprofv3 --kernel-trace --stats over eval_probe.py, fused, batch 512 (3 evaluations of 35 batches)"
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/evf -o sk -- python $R/tools/eval_probe.py > /dev/null 2>&1
 python $R/tools/db_summary.py $R/gpurun_out/evf 2>/dev/null | head -10 | cut -c1-170
