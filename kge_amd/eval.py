@@ -193,7 +193,9 @@ class EntityRankingEvaluator:
         M = len(rankings)
         st = self._device_state(dev)
         # a captured batch (below) survives from run to run while the tables stay where they are
-        gkey = (tables.ent.data_ptr(), tables.rel.data_ptr(), bool(return_ranks), M) if isinstance(tables, engine.Tables) else None
+        gkey = ((tables.ent.data_ptr(), tables.rel.data_ptr(), tuple(tables.ent.shape), tuple(tables.rel.shape),
+                 tables.ent.stride(0), tables.rel.stride(0), tables.scorer, bool(return_ranks), M)
+                if isinstance(tables, engine.Tables) else None)
         held = self._graph if (self._graph is not None and self._graph["key"] == gkey) else None
         hist = held["hist"].zero_() if held is not None else torch.zeros(M, E, dtype=torch.float, device=dev)
         all_ranks = {f"{d}{r}": [] for r in rankings for d in "so"}
