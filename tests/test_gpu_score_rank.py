@@ -200,3 +200,35 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
     for k in r2:
         assert np.array_equal(r1[k], r2[k]), (k, np.nonzero(r1[k] != r2[k])[0][:5])
     assert m1 == m2
+
+
+def test_fused_counts_against_the_oracle():
+    """Directly against the CPU oracle's restatement of _filter_and_rank / _get_ranks_and_num_ties
+    (oracle.rank_counts: dense 0 / inf label subtraction, isclose, two sums -- eval_entity_ranking.py:533-596) applied
+    to the score matrix the GPU writes: raw and two filtered rankings, both directions, two entity chunks."""
+    import oracle as ko
+    from kge_amd import engine as eng
+    model, E, R, d, n = "complex", 6000, 9, 256, 200
+    rng = np.random.default_rng(77)
+    T = _tables(eng, model, E, R, d, seed=77)
+    s = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    p = torch.from_numpy(rng.integers(0, R, n)).to(DEV)
+    o = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    T.ent[rng.integers(0, E, 30)] = T.ent[rng.integers(0, E, 30)]  # exact ties
+    sc = eng.score_sp_po(T, s, p, o)
+    ar = torch.arange(n, device=DEV)
+    t_sp, t_po = sc[ar, o].contiguous(), sc[ar, E + s].contiguous()
+    f_sp = _filters(rng, n, E, 2, o.cpu().numpy(), hub_rows=(3,))
+    f_po = _filters(rng, n, E, 2, s.cpu().numpy(), hub_rows=(5,))
+    got = _fused(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, ((0, 2500), (2500, E)), 1e-5, 1e-4).cpu().numpy()
+    scn = sc.cpu().numpy()
+    for side, (blk, true, tcol, filt) in enumerate(((scn[:, :E], t_sp, o, f_sp), (scn[:, E:], t_po, s, f_po))):
+        blk, true, tcol = np.ascontiguousarray(blk), true.cpu().numpy(), tcol.cpu().numpy()
+        r0, t0 = ko.rank_counts(blk, true)
+        assert np.array_equal(got[side, 0, 0], r0) and np.array_equal(got[side, 1, 0], t0), ("raw", side)
+        for k, (beg, end, vals) in enumerate(filt):
+            beg, end, vals = beg.cpu().numpy(), end.cpu().numpy(), vals.cpu().numpy()
+            rp = np.concatenate([[0], np.cumsum(end - beg)]).astype(np.int64)
+            col = np.concatenate([vals[b:e] for b, e in zip(beg, end)] + [np.zeros(0, np.int64)]).astype(np.int64)
+            r1, t1 = ko.rank_counts(blk, true, rp, col, 0, tcol, 1e-5, 1e-4)
+            assert np.array_equal(got[side, 0, k + 1], r1) and np.array_equal(got[side, 1, k + 1], t1), (k, side)
