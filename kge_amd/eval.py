@@ -181,12 +181,62 @@ class EntityRankingEvaluator:
         return st
 
     @torch.no_grad()
+    def _run_sharded(self, sh, return_ranks: bool):
+        """The same loop over an entity-sharded table (kge_amd.sharded.ShardedEntityTable; every rank calls this
+        with the same evaluator arguments): the filter index is replicated, each rank counts over its own entity
+        rows -- inside the scoring kernel where the backend offers it --, ONE int64 all-reduce per batch makes the
+        counts global (ShardedEntityTable.rank_batch_multi), and every rank ends with the full histograms and the
+        same metrics.  No score matrix, no device -> host synchronisation inside the loop."""
+        dev = sh.ent_local.device
+        E, R = self.E, self.R
+        rankings = ["_raw", "_filt"] + (["_filt_test"] if self.filter_with_test else [])
+        M = len(rankings)
+        st = self._device_state(dev)
+        hist = torch.zeros(M, E, dtype=torch.float, device=dev)
+        all_ranks = {f"{d}{r}": [] for r in rankings for d in "so"}
+        triples, bs = st["triples"], self.batch_size
+        for b0 in range(0, len(self.triples), bs):
+            batch = triples[b0:b0 + bs]
+            n = batch.shape[0]
+            s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
+            rng = st["ranges"][:, :, :, :n].contiguous() if n != bs else st["ranges"]
+            filt_o, filt_s, lookups = [], [], []
+            for k in range(M - 1):
+                uk, start, v = st["sp"][k]
+                lookups.append((uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1]))
+                filt_o.append((rng[0, k, 0], rng[0, k, 1], v))
+                uk, start, v = st["po"][k]
+                lookups.append((uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1]))
+                filt_s.append((rng[1, k, 0], rng[1, k, 1], v))
+            engine.filter_lookup_multi(lookups)
+            cnt = sh.rank_batch_multi(batch, filt_o, filt_s, self.tie_atol, self.tie_rtol)
+            ro = torch.empty(M, n, dtype=torch.int64, device=dev) if return_ranks else None
+            rs = torch.empty(M, n, dtype=torch.int64, device=dev) if return_ranks else None
+            engine.rank_hist(cnt[0, 0], cnt[0, 1], self.tie_handling, hist, ro)
+            engine.rank_hist(cnt[1, 0], cnt[1, 1], self.tie_handling, hist, rs)
+            if return_ranks:
+                for m_, r in enumerate(rankings):
+                    all_ranks["o" + r].append(ro[m_])
+                    all_ranks["s" + r].append(rs[m_])
+        suffix = {"_raw": "", "_filt": "_filtered", "_filt_test": "_filtered_with_test"}
+        metrics = {}
+        for m_, r in enumerate(rankings):
+            metrics.update(compute_metrics(hist[m_], self.hits_at_k_s, suffix[r]))
+        if return_ranks:
+            return metrics, {k: torch.cat(v).cpu().numpy() if v else np.zeros(0, np.int64)
+                             for k, v in all_ranks.items()}
+        return metrics
+
+    @torch.no_grad()
     def run(self, return_ranks: bool = False):
         """No device -> host synchronisation inside the loop: the batch's filter ranges come from
         kge_filter_lookup on the device-resident index, all rankings of a direction from one
         kge_rank_counts_multi scan, tie policy + histogram from kge_rank_hist."""
         model = self.model
         tables = model.tables() if hasattr(model, "tables") else model
+        from .sharded import ShardedEntityTable
+        if isinstance(tables, ShardedEntityTable):
+            return self._run_sharded(tables, return_ranks)
         dev = tables.device
         E, R = self.E, self.R
         rankings = ["_raw", "_filt"] + (["_filt_test"] if self.filter_with_test else [])

@@ -86,6 +86,13 @@ def _worker(rank, world, port, model, q):
         sh.fused_rank = True
         for a, b in zip((fused[1, 0, 0], fused[1, 1, 0], fused[0, 0, 0], fused[0, 1, 0]), ranks):
             assert np.array_equal(a.cpu().numpy(), b)
+        # the whole evaluation loop over the sharded table (replicated filter index, shard-local counts inside the
+        # scoring kernel, one counter all-reduce per batch): every rank ends with the same ranks and metrics
+        from kge_amd.eval import EntityRankingEvaluator
+        from kge_amd.synthetic import make_splits
+        splits = make_splits(E, R, 3000, 250, 150, seed=11)
+        ev_m, ev_r = EntityRankingEvaluator(sh, splits, E, R, eval_split="valid", batch_size=96).run(return_ranks=True)
+        assert sh.fused_rank
         tv, ti = sh.topk(sh.score_sp(s, p), 7)
         blk_sp, blk_po = (x.clone() for x in sh.score_sp_po_blocks(s, p, o))  # the step bench.py --gpus N times
         small, sh.BIG_SLAB_BYTES = sh.BIG_SLAB_BYTES, 0                      # ... and its big-slab form (padded pitch,
@@ -97,7 +104,7 @@ def _worker(rank, world, port, model, q):
         torch.cuda.synchronize()
         q.put((rank, lo, hi, ranks, tv.cpu().numpy(), ti.cpu().numpy(), loss.detach().cpu().numpy(),
                ent_m.grad.cpu().numpy(), rel_m.grad.cpu().numpy(), ent.numpy(), rel.numpy(), tri.cpu().numpy(),
-               w.cpu().numpy(), blk_sp.cpu().numpy(), blk_po.cpu().numpy()))
+               w.cpu().numpy(), blk_sp.cpu().numpy(), blk_po.cpu().numpy(), ev_m, ev_r))
     finally:
         dist.destroy_process_group()
 
@@ -147,7 +154,15 @@ def test_two_ranks_on_the_real_kernels(model):
         ge.index_add_(0, a, g_a)
         gr.index_add_(0, p, g_p)
     want_loss = torch.cat([l_sp, l_po]).cpu().numpy()
+    # the unsharded evaluator on the same bf16 tables and splits
+    from kge_amd.eval import EntityRankingEvaluator
+    from kge_amd.synthetic import make_splits
+    splits = make_splits(E, rel.shape[0], 3000, 250, 150, seed=11)
+    want_m, want_r = EntityRankingEvaluator(T, splits, E, rel.shape[0], eval_split="valid", batch_size=96).run(return_ranks=True)
     for rank, lo, hi, ranks, rtv, rti, loss, g_ent, g_rel, *rest in outs:
+        assert rest[6] == want_m, (model, rank, "sharded evaluation metrics")
+        for k in want_r:
+            assert np.array_equal(rest[7][k], want_r[k]), (model, rank, k)
         # the shard's score blocks are the unsharded matrix's columns, bit for bit
         assert np.array_equal(rest[4], both[:, lo:hi].cpu().numpy()), (model, rank, "sp block")
         assert np.array_equal(rest[5], both[:, E + lo:E + hi].cpu().numpy()), (model, rank, "po block")
