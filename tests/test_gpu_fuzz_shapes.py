@@ -286,3 +286,35 @@ def test_random_shape_gradient_products(seed):
             assert rc == 0, (tag, which, rc)
             err = float((out.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
             assert err <= 3e-6, (tag, which, scratch_mb, err)
+
+
+@pytest.mark.parametrize("seed", range(24 * MULT))
+def test_random_shape_counts_inside_the_scoring_kernel(seed):
+    """kge_score_rank_sp_po at the fuzzed residues (d = 256 / 512 only): raw + 0..2 filtered rankings, both
+    directions, one or two entity chunks, against kge_score_sp_po + kge_rank_counts_multi -- every count equal --
+    and the filter-bit buffer all-zero afterwards."""
+    from kge_amd import engine as eng
+    import test_gpu_score_rank as sr
+    model, d, E, n, rng = _shape(seed)
+    if d == 128:
+        d = 256
+    if seed % 5 == 0:
+        n = int(rng.integers(1, 2600))  # beyond one launch's 2,048 rows now and then
+    R = 5
+    T = sr._tables(eng, model, E, R, d, seed=5000 + seed)
+    s = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    p = torch.from_numpy(rng.integers(0, R, n)).to(DEV)
+    o = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    if E > 4:
+        T.ent[rng.integers(0, E, 3)] = T.ent[rng.integers(0, E, 3)]  # a few exact ties
+    K = int(rng.integers(0, 3))
+    t_sp, t_po = sr._true_scores(eng, T, s, p, o)
+    f_sp = sr._filters(rng, n, E, K, o.cpu().numpy())
+    f_po = sr._filters(rng, n, E, K, s.cpu().numpy())
+    cut = int(rng.integers(1, E)) if (E > 1 and seed % 2) else None
+    chunks = ((0, cut), (cut, E)) if cut else ((0, E),)
+    want = sr._two_step(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, 1e-5, 1e-4)
+    got = sr._fused(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, 1e-5, 1e-4)
+    assert torch.equal(got, want), (model, d, E, n, K, chunks, (got != want).nonzero()[:5].tolist())
+    for buf in eng._RANK_BITS.values():
+        assert int(buf.count_nonzero()) == 0
