@@ -506,21 +506,33 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     rk_fetch(0);
   }
   // Bit layout of the per-lane masks = the tile's 64 columns: element r of half hf is bit 32 hf + 8 (r >> 2) + 4 fh + (r & 3).
+  // 16 dense bits (element r = 4 q + b at bit r) -> the tile layout before the 4 fh shift (bit 8 q + b)
+  auto rk_spread = [](unsigned int d) __attribute__((always_inline)) -> unsigned int {
+    return (d & 0xfu) | ((d & 0xf0u) << 4) | ((d & 0xf00u) << 8) | ((d & 0xf000u) << 12);
+  };
   // rank_masks: the two result masks of one tile from its accumulators (before the 4 fh shift).
   auto rank_masks = [&](const f32x16& a0, const f32x16& a1, unsigned int (&g)[2], unsigned int (&c)[2], bool fast)
       __attribute__((always_inline)) {
     g[0] = g[1] = c[0] = c[1] = 0u;
     if (fast) {
       // finite true score, finite tolerance >= 0:  close <=> |x - t| <= allowed,  greater-and-not-close <=>
-      // x - t > allowed  (NaN and -inf scores fail both, +inf is greater: what count_one gives)
+      // x - t > allowed  (NaN and -inf scores fail both, +inf is greater: what count_one gives).  As sign bits, so
+      // that no comparison result travels through a scalar register: x' = max(x, -inf) (NaN -> -inf), e = x' - t,
+      // sign(allowed - e) = greater, sign(allowed - |e|) = NOT close; one v_alignbit shifts each into its mask.
+      unsigned int ng[2] = {0u, 0u}, nc[2] = {0u, 0u};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const unsigned int bit = 1u << (8 * (r >> 2) + (r & 3));
-        const float e0 = a0[r] - rk_t, e1 = a1[r] - rk_t;
-        g[0] |= e0 > rk_al ? bit : 0u;
-        c[0] |= __builtin_fabsf(e0) <= rk_al ? bit : 0u;
-        g[1] |= e1 > rk_al ? bit : 0u;
-        c[1] |= __builtin_fabsf(e1) <= rk_al ? bit : 0u;
+      for (int r = 15; r >= 0; --r) {  // element r ends up at bit r
+        const float e0 = __builtin_fmaxf(a0[r], -__builtin_inff()) - rk_t;
+        const float e1 = __builtin_fmaxf(a1[r], -__builtin_inff()) - rk_t;
+        ng[0] = __builtin_amdgcn_alignbit(ng[0], __builtin_bit_cast(unsigned int, rk_al - e0), 31);
+        nc[0] = __builtin_amdgcn_alignbit(nc[0], __builtin_bit_cast(unsigned int, rk_al - __builtin_fabsf(e0)), 31);
+        ng[1] = __builtin_amdgcn_alignbit(ng[1], __builtin_bit_cast(unsigned int, rk_al - e1), 31);
+        nc[1] = __builtin_amdgcn_alignbit(nc[1], __builtin_bit_cast(unsigned int, rk_al - __builtin_fabsf(e1)), 31);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        g[h] = rk_spread(ng[h]);
+        c[h] = rk_spread(~nc[h] & 0xffffu);
       }
     } else {
 #pragma unroll
@@ -579,11 +591,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   }
   auto rank_step = [&](auto qc) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::value;
-    constexpr int hf = q & 1, r = (q >> 1) & 15;
-    constexpr unsigned int bit = 1u << (8 * (r >> 2) + (r & 3));
-    const float e = (hf ? pv1[r] : pv0[r]) - rk_t;
-    pg[hf] |= e > rk_al ? bit : 0u;
-    pc[hf] |= __builtin_fabsf(e) <= rk_al ? bit : 0u;
+    constexpr int hf = q & 1, r = 15 - ((q >> 1) & 15);  // descending: element r ends up at bit r (see rank_masks)
+    const float e = __builtin_fmaxf(hf ? pv1[r] : pv0[r], -__builtin_inff()) - rk_t;
+    pg[hf] = __builtin_amdgcn_alignbit(pg[hf], __builtin_bit_cast(unsigned int, rk_al - e), 31);
+    pc[hf] = __builtin_amdgcn_alignbit(pc[hf], __builtin_bit_cast(unsigned int, rk_al - __builtin_fabsf(e)), 31);
   };
 
   float lse_i = 0.0f, g_i = 0.0f, gb_i = 0.0f;  // V3_DS / V3_DSIG: the row's logsumexp, upstream gradient, g_i * row_bias[i]
@@ -733,7 +744,15 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     if constexpr (IS_DS) ds_tile(tt);
     if constexpr (EPI == V3_RANK && !RK_PIPE) rank_tile(tt);
     if constexpr (RK_PIPE) {  // tile tt - 1: compared during tile tt's chain
-      if (rk_slow) rank_masks(pv0, pv1, pg, pc, false);
+      if (rk_slow) {
+        rank_masks(pv0, pv1, pg, pc, false);
+      } else {  // the slots left dense (greater, NOT close) bits
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          pg[h] = rk_spread(pg[h] & 0xffffu);
+          pc[h] = rk_spread(~pc[h] & 0xffffu);
+        }
+      }
       rank_finish(tt - 1, pg, pc);
     }
   }

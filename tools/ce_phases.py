@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """s_memtime stamps inside the fused-loss scoring kernels (pairs_bf16_v3_kernel<.., V3_LSE / V3_DS>)
-at the BASELINE configs[1] shape: median over workgroups of each stamp relative to the workgroup's
+at the BASELINE configs[1] shape (or E= D= N= from the environment, e.g. E=574311 D=256: a Wikidata5M shard): median over workgroups of each stamp relative to the workgroup's
 own start (kge_debug_ce_stamps, not part of the ABI)."""
 import ctypes
 import os
@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from kge_amd import _lib, engine  # noqa: E402
 
 dev = torch.device("cuda", 0)
-E, R, d, n = 14541, 237, 512, 512
+E, R, d, n = int(os.environ.get("E", "14541")), 237, int(os.environ.get("D", "512")), int(os.environ.get("N", "512"))
 g = torch.Generator().manual_seed(0)
 T = engine.Tables("complex", torch.empty(E, d).normal_(0, 0.1, generator=g).bfloat16().to(dev),
                   torch.empty(R, d).normal_(0, 0.1, generator=g).bfloat16().to(dev))
