@@ -172,6 +172,35 @@ def _worker(rank, world, port, model, q):
                                    [(pb, pe, torch.from_numpy(fi.po_values))])
         assert FusedOracleBackend.calls == 1 and sh2.fused_rank
         assert torch.equal(cm2, cm)
+        # the whole evaluation loop over the sharded table (EntityRankingEvaluator._run_sharded): replicated filter
+        # index, shard-local counts, one counter all-reduce per batch.  Its two device-side helpers (filter lookup,
+        # tie policy + histogram) restated in numpy for this CPU run.
+        import kge_amd.eval as kev
+        TIES = {"rounded_mean_rank": lambda r, t: r + t // 2, "best_rank": lambda r, t: r, "worst_rank": lambda r, t: r + t - 1}
+
+        def lookup_multi(queries):
+            for keys, starts, a, b, mult, beg, end in queries:
+                k, st_ = keys.numpy(), starts.numpy()
+                q = a.long().numpy() * mult + b.long().numpy()
+                pos = np.minimum(np.searchsorted(k, q), max(len(k) - 1, 0))
+                hit = (k[pos] == q) if len(k) else np.zeros(len(q), bool)
+                beg.copy_(torch.from_numpy(np.where(hit, st_[pos], 0)))
+                end.copy_(torch.from_numpy(np.where(hit, st_[pos + 1] if len(k) else 0, 0)))
+
+        def hist_update(rank, ties, policy, hist, ranks_out=None):
+            r = TIES[policy](rank, ties)
+            for m in range(r.shape[0]):
+                hist[m].index_add_(0, r[m], torch.ones(r.shape[1]))
+            if ranks_out is not None:
+                ranks_out.copy_(r)
+
+        orig = kev.engine.filter_lookup_multi, kev.engine.rank_hist
+        kev.engine.filter_lookup_multi, kev.engine.rank_hist = lookup_multi, hist_update
+        try:
+            ev = kev.EntityRankingEvaluator(sh2, splits, E, R, eval_split="valid", batch_size=17)
+            ev_metrics, ev_ranks = ev.run(return_ranks=True)
+        finally:
+            kev.engine.filter_lookup_multi, kev.engine.rank_hist = orig
         rows = sh.gather_entity_rows(tb[:, 0])
         assert np.array_equal(rows.numpy(), ent[batch[:, 0]])
         # the call sequence of bench.py --gpus N: one exchange for the s and o rows (strided int32
@@ -189,7 +218,7 @@ def _worker(rank, world, port, model, q):
         slab = sh.score_sp(tb[:, 0], tb[:, 1])
         tv, ti = sh.topk(slab, 5)
         if rank == 0:
-            q.put((out, tv.numpy(), ti.numpy(), ent, rel, splits, batch))
+            q.put((out, tv.numpy(), ti.numpy(), ent, rel, splits, batch, ev_metrics, ev_ranks))
     finally:
         dist.destroy_process_group()
 
@@ -202,7 +231,7 @@ def test_two_shards_equal_unsharded(model):
     procs = [ctx.Process(target=_worker, args=(r, world, port, model, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, tv, ti, ent, rel, splits, batch = q.get()
+    out, tv, ti, ent, rel, splits, batch, ev_metrics, ev_ranks = q.get()
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -225,6 +254,17 @@ def test_two_shards_equal_unsharded(model):
         g = out[key]
         assert np.array_equal(g[0], s_rank) and np.array_equal(g[1], s_ties), key
         assert np.array_equal(g[2], o_rank) and np.array_equal(g[3], o_ties), key
+    # the sharded evaluation loop: per-example ranks of all three rankings = the oracle's restatement of
+    # EntityRankingJob._evaluate over the whole valid split, metrics from the summed histograms
+    valid = splits["valid"].astype(np.int64)
+    tsp, tpo = ko.build_index(splits["test"], (0, 1), 2), ko.build_index(splits["test"], (1, 2), 0)
+    isp, ipo = [i[0] for i in ix], [i[1] for i in ix]
+    for key, a, b in (("_raw", None, None), ("_filt", isp, ipo), ("_filt_test", isp + [tsp], ipo + [tpo])):
+        s_r, o_r = ko.evaluate_ranks(t, valid, a, b)
+        assert np.array_equal(ev_ranks["o" + key], o_r), ("sharded evaluator", "o" + key)
+        assert np.array_equal(ev_ranks["s" + key], s_r), ("sharded evaluator", "s" + key)
+    both_r = np.concatenate([ev_ranks["s_filt"], ev_ranks["o_filt"]]).astype(np.float64) + 1.0
+    assert abs(ev_metrics["mean_reciprocal_rank_filtered"] - float(np.mean(1.0 / both_r))) <= 1e-6
     order = np.argsort(-sp, axis=1, kind="stable")[:, :5]
     assert np.array_equal(np.take_along_axis(sp, order, 1), tv)
     assert np.array_equal(np.sort(ti, 1), np.sort(order, 1)) or np.allclose(np.take_along_axis(sp, ti, 1), tv)
