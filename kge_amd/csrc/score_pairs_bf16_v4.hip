@@ -578,10 +578,11 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     rank_masks(acc0, acc1, g, c, !rk_slow);
     rank_finish(tt, g, c);
   };
-  // d = 256 (registers to spare): the comparisons of tile tt - 1 run on a copy of its accumulators in the shadow of
-  // tile tt's MFMA chain -- one element per MFMA slot (a 32x32x16 MFMA occupies the matrix pipe for 32 cycles, a
-  // slot's 7 VALU instructions take 28), instead of 1,100 cycles between two chains with the matrix pipe idle.
-  // A wave with an infinite true score (rk_slow) does the generic arithmetic on the copy after the chain instead.
+  // d = 256 (registers to spare): the comparisons of tile tt - 1 are issued between the MFMAs of tile tt, on a copy
+  // of its accumulators -- one element per MFMA slot -- instead of between two chains with the matrix pipe idle.
+  // Measured: 3 % (one wave issues MFMA, fragment read and comparisons in order, so little of it
+  // really overlaps).  A wave with an infinite true score (rk_slow) does the generic arithmetic on the copy after
+  // the chain instead.
   constexpr bool RK_PIPE = EPI == V3_RANK && HH == 128;
   f32x16 pv0, pv1;               // RK_PIPE: accumulators of the previous tile
   unsigned int pg[2] = {0u, 0u}, pc[2] = {0u, 0u};
