@@ -74,7 +74,10 @@ typedef enum kge_dtype { KGE_F32 = 0, KGE_BF16 = 1 } kge_dtype;
 typedef enum kge_itype { KGE_I32 = 0, KGE_I64 = 1 } kge_itype;
 
 /* combine modes of RelationalScorer.score_emb (kge_model.py:151-213) */
-typedef enum kge_combine { KGE_SPO = 0, KGE_SP_ = 1, KGE_PO_ = 2 } kge_combine;
+typedef enum kge_combine {
+  KGE_SPO = 0, KGE_SP_ = 1, KGE_PO_ = 2,
+  KGE_SP_PO = 3               /* both blocks of KgeModel.score_sp_po (prepared-query entry points only) */
+} kge_combine;
 
 /* Entity + relation lookup tables (LookupEmbedder._embeddings.weight,
  * kge/model/embedder/lookup_embedder.py:44-46). */
@@ -103,8 +106,18 @@ typedef enum kge_flags {
                                  instead of the row-persistent kernel (A/B measurements)     */
   KGE_FLAG_BF16_V2 = 8,       /* bf16 ComplEx/DistMult: the row-persistent kernel with
                                  32-target tiles (v2) instead of 64-target tiles (v3)        */
-  KGE_FLAG_BF16_V3 = 16       /* bf16 ComplEx/DistMult with a workspace: the single-role
+  KGE_FLAG_BF16_V3 = 16,      /* bf16 ComplEx/DistMult with a workspace: the single-role
                                  kernel (v3) instead of the loader/consumer kernel (v4)      */
+  KGE_FLAG_SPLIT_QUERY = 32   /* bf16 ComplEx/DistMult scoring: the query vector q = s (x) r is NOT rounded
+                                 to one bf16 but carried as q_hi + q_lo (two bf16 pieces, two MFMA chains,
+                                 one f32 add): products stay exact, only the f32 summation order differs from
+                                 f32 arithmetic on the same bf16 tables (+ a 2^-17 relative residue of q for
+                                 ComplEx, none for DistMult) -- the precision class of KGE_FLAG_EXACT at about
+                                 half the speed of the single-pass kernel instead of a seventh.  Evaluation
+                                 (rank parity with the reference: eval_entity_ranking.py:590-595 ties at
+                                 rtol 1e-4) wants this; training does not.  Applies to kge_score_sp / _po /
+                                 _sp_po / _emb / _emb_sp_po and the prepared-query entry points; shapes the
+                                 matrix-core kernel does not take run the exact f32 chain instead.            */
 } kge_flags;
 /* Bits 8..15 of `flags`: number of compute units the persistent bf16 scoring kernel leaves
  * free (it launches one workgroup per remaining CU), so that kernels on other streams -- the
@@ -170,6 +183,39 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o,
                     int64_t n, kge_index targets, int64_t m, float* out,
                     int64_t ldo, void* workspace, int64_t workspace_bytes,
                     void* stream);
+
+/* ---- prepared queries: the query build taken out of the scoring launch -------------------------------
+ * KgeModel.score_sp / score_po / score_sp_po (kge/model/kge_model.py:682-789) compute, per call,
+ * q_i = embed(s_i) (x) embed(p_i) (complex.py:30-37, distmult.py:17-21: the "sp_" / "_po" halves of score_emb) and
+ * then q . E^T.  Inside ONE launch the first half is a chain of five dependent memory round trips before the
+ * first score can be stored -- 40 % of a launch at the FB15k-237 shape.  A caller that knows its
+ * batches ahead (EntityRankingJob._evaluate iterates a DataLoader: eval_entity_ranking.py:158-170; so does every
+ * training epoch) can take it off the critical path:
+ *
+ *   kge_build_queries(batch 0)                               -- one small launch, once
+ *   kge_score_queries(batch k, next = batch k + 1) ...       -- ONE launch per batch: scores batch k from its
+ *                                                               prepared queries, while workgroups on the compute
+ *                                                               units the launch leaves idle build batch k + 1's
+ *
+ * `queries` is an opaque device buffer of kge_queries_bytes(t, combine, n) bytes (16-byte aligned; bf16 MFMA
+ * operand fragments of the n query vectors; with KGE_FLAG_SPLIT_QUERY the q_hi and q_lo pieces), valid for the
+ * tables, flags, combine and n it was built with; the caller double-buffers (`next->queries` must differ from
+ * `queries`).  combine: KGE_SP_ (s, p given; o ignored), KGE_PO_ (p, o given; s ignored) or KGE_SP_PO (all three;
+ * out[i, :m] = sp scores, out[i, m:2m] = po scores, ldo >= 2m).  Scores are bit-identical to kge_score_sp / _po /
+ * _sp_po on the same tables and flags.  bf16 ComplEx / DistMult, dim 256 / 512; otherwise KGE_ERR_UNSUPPORTED.
+ * No workspace, no flags to zero, no co-residency requirement: capture-safe, any n. */
+typedef struct kge_next_queries {
+  kge_index s, p, o;          /* the next batch (as for kge_build_queries)                       */
+  int64_t n;                  /* 0: nothing to build                                             */
+  void* queries;              /* destination, kge_queries_bytes(t, combine, n) bytes             */
+  int64_t queries_bytes;
+} kge_next_queries;
+int64_t kge_queries_bytes(const kge_tables* t, int combine, int64_t n);
+int kge_build_queries(const kge_tables* t, int combine, kge_index s, kge_index p, kge_index o,
+                      int64_t n, void* queries, int64_t queries_bytes, void* stream);
+int kge_score_queries(const kge_tables* t, int combine, const void* queries, int64_t n,
+                      kge_index targets, int64_t m, float* out, int64_t ldo,
+                      const kge_next_queries* next /* may be NULL */, void* stream);
 
 /* Negative-sampling scores, the "triple" implementation without building the
  * [n*K,3] index tensor: slot 0/2 = corrupt s / o.

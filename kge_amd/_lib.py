@@ -23,6 +23,8 @@ F32, BF16 = 0, 1
 I32, I64 = 0, 1
 SPO, SP_, PO_ = 0, 1, 2
 FLAG_EXACT, FLAG_NO_MFMA, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_BF16_V3 = 1, 2, 4, 8, 16
+FLAG_SPLIT_QUERY = 32
+SP_PO = 3
 
 c_i64 = ctypes.c_int64
 c_vp = ctypes.c_void_p
@@ -42,6 +44,11 @@ class KgeIndex(ctypes.Structure):
                 ("stride", c_i64)]
 
 
+class KgeNextQueries(ctypes.Structure):
+    _fields_ = [("s", KgeIndex), ("p", KgeIndex), ("o", KgeIndex), ("n", c_i64), ("queries", c_vp),
+                ("queries_bytes", c_i64)]
+
+
 class KgeFilterQuery(ctypes.Structure):
     _fields_ = [("sorted_keys", c_vp), ("num_keys", c_i64), ("starts", c_vp), ("a", KgeIndex), ("b", KgeIndex),
                 ("mult", c_i64), ("begin", c_vp), ("end", c_vp)]
@@ -58,6 +65,10 @@ PROTOTYPES = {
     "kge_score_sp": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_sp_po": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kge_queries_bytes": (c_i64, [_PT, ctypes.c_int, c_i64]),
+    "kge_build_queries": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_queries": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, KgeIndex, c_i64, c_vp, c_i64,
+                                         ctypes.POINTER(KgeNextQueries), c_vp]),
     "kge_score_neg": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int, c_vp,
                                      ctypes.c_int32, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_emb": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,

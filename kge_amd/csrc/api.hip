@@ -33,6 +33,14 @@ int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Ope
                       const Operand& TG, int dir, int d, long long n, long long m, float* out,
                       long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
                       void* ws, long long ws_bytes, int reserve_cus);
+long long pairs_bf16_v4_query_bytes(int d, long long n, bool two_sided, bool split);
+int run_query_build(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                    long long n, void* qf, hipStream_t st);
+int run_pairs_bf16_v4_prepared(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R,
+                               const Operand& TG, int dir, int d, long long n, long long m, float* out,
+                               long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
+                               const void* ready, void* ws, long long ws_bytes, int reserve_cus, const Operand* nA,
+                               const Operand* nA2, const Operand* nR, long long nn, void* nqf);
 bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
 int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
@@ -155,7 +163,8 @@ int check_tables(const kge_tables* t, bool need_ptrs) {
 // of behind it (where it takes what v4 declines): KGE_V5=1, for tests and measurements.
 constexpr bool V5_DEFAULT = false;
 bool v5_on(const kge_tables* t) {
-  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) return false;
+  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
+    return false;
   const char* e = getenv("KGE_V5");
   return e ? e[0] == '1' : V5_DEFAULT;
 }
@@ -178,6 +187,19 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
                    const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo,
                    void* ws, int64_t ws_bytes, hipStream_t st) {
   const int d = (int)t->dim, dr = (int)t->rel_dim;
+  if ((t->flags & KGE_FLAG_SPLIT_QUERY) && !(t->flags & KGE_FLAG_EXACT) && t->dtype == KGE_BF16) {
+    // q = q_hi + q_lo on the matrix cores (f32-level parity on the bf16 tables); what the loader/consumer kernel
+    // does not take runs the exact f32 chain below -- the same parity class, never the single-pass bf16 kernel
+    if (ws != nullptr && pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
+      const int rc = run_pairs_bf16_v4_prepared(t->scorer, true, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st,
+                                                nullptr, nullptr, ws, ws_bytes,
+                                                (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr,
+                                                nullptr, 0, nullptr);
+      if (rc != KGE_ERR_UNSUPPORTED) return rc;
+    }
+    return run_pairs_exact(t->scorer, t->dtype, !(t->flags & KGE_FLAG_NO_MFMA), A, R, TG, dir, d, dr, n, m,
+                           t->l_norm, out, ldo, st);
+  }
   if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, d, A, R, TG)) {
     const int rc = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr);
     if (rc != KGE_ERR_UNSUPPORTED) return rc;
@@ -206,6 +228,19 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
   const bool mfma = !(t->flags & KGE_FLAG_NO_MFMA);
   return run_pairs_exact(t->scorer, t->dtype, mfma, A, R, TG, dir, d, dr, n, m, t->l_norm, out,
                          ldo, st);
+}
+
+// KGE_FLAG_SPLIT_QUERY, both score blocks: builder launch + ONE two-sided launch of the loader/consumer kernel on
+// the q_hi / q_lo fragments.  KGE_ERR_UNSUPPORTED: the caller goes side by side through pairs_dispatch (split again,
+// or the exact f32 chain).
+int split_sp_po(const kge_tables* t, const Operand& S, const Operand& O, const Operand& P, const Operand& TG, int64_t n,
+                int64_t m, float* out, int64_t ldo, void* ws, int64_t ws_bytes, hipStream_t st) {
+  if (t->dtype != KGE_BF16 || !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
+      !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
+    return KGE_ERR_UNSUPPORTED;
+  return run_pairs_bf16_v4_prepared(t->scorer, true, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr,
+                                    nullptr, ws, ws_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr,
+                                    nullptr, nullptr, 0, nullptr);
 }
 
 int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
@@ -269,7 +304,93 @@ int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n) {
   if (t->scorer != KGE_COMPLEX && t->scorer != KGE_DISTMULT) return 0;
   if (t->dim != 128 && t->dim != 256 && t->dim != 512) return 0;
   // bf16 query fragments of whole 128-row groups + the publication flags of the builders
+  if ((t->flags & KGE_FLAG_SPLIT_QUERY) && (t->dim == 256 || t->dim == 512))  // q_hi and q_lo rows, both sides
+    return PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, true);
   return pairs_bf16_v3_workspace_bytes((int)t->dim, n);
+}
+
+// ---- prepared queries (include/kge_amd.h) -----------------------------------------------------------------------
+static bool queries_supported(const kge_tables* t) {
+  return t->dtype == KGE_BF16 && (t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT) &&
+         (t->dim == 256 || t->dim == 512) && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 |
+                                                           KGE_FLAG_BF16_V3));
+}
+
+int64_t kge_queries_bytes(const kge_tables* t, int combine, int64_t n) {
+  if (!t || n <= 0 || check_tables(t, false) != KGE_OK || !queries_supported(t)) return 0;
+  if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return 0;
+  return pairs_bf16_v4_query_bytes((int)t->dim, n, combine == KGE_SP_PO, (t->flags & KGE_FLAG_SPLIT_QUERY) != 0);
+}
+
+// the operands of a batch: entity rows of the first side, of the second side (SP_PO), relation rows
+static int query_operands(const kge_tables* t, int combine, const kge_index& s, const kge_index& p,
+                          const kge_index& o, Operand& A, Operand& A2, Operand& R, int& dir) {
+  int rc;
+  if (combine == KGE_SP_ || combine == KGE_SP_PO) {
+    if ((rc = check_index(s, false))) return rc;
+  }
+  if (combine == KGE_PO_ || combine == KGE_SP_PO) {
+    if ((rc = check_index(o, false))) return rc;
+  }
+  if ((rc = check_index(p, false))) return rc;
+  dir = combine == KGE_PO_ ? KGE_PO_ : KGE_SP_;
+  A = ent_op(t, combine == KGE_PO_ ? o : s);
+  A2 = ent_op(t, o);
+  R = rel_op(t, p);
+  return KGE_OK;
+}
+
+int kge_build_queries(const kge_tables* t, int combine, kge_index s, kge_index p, kge_index o, int64_t n,
+                      void* queries, int64_t queries_bytes, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && !queries)) return KGE_ERR_INVALID_ARG;
+  if (n == 0) return KGE_OK;
+  if (!queries_supported(t)) return KGE_ERR_UNSUPPORTED;
+  if (queries_bytes < kge_queries_bytes(t, combine, n)) return KGE_ERR_WORKSPACE;
+  Operand A, A2, R;
+  int dir;
+  if ((rc = query_operands(t, combine, s, p, o, A, A2, R, dir))) return rc;
+  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, A)) return KGE_ERR_UNSUPPORTED;
+  return run_query_build(t->scorer, (t->flags & KGE_FLAG_SPLIT_QUERY) != 0, A, combine == KGE_SP_PO ? &A2 : nullptr, R,
+                         dir, (int)t->dim, n, queries, (hipStream_t)stream);
+}
+
+int kge_score_queries(const kge_tables* t, int combine, const void* queries, int64_t n, kge_index targets, int64_t m,
+                      float* out, int64_t ldo, const kge_next_queries* next, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
+  const int64_t width = combine == KGE_SP_PO ? 2 * m : m;
+  if (n < 0 || m < 0 || (!out && n * m > 0) || ldo < width || (n > 0 && !queries)) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(targets, true))) return rc;
+  if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
+  if (!queries_supported(t)) return KGE_ERR_UNSUPPORTED;
+  const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
+  Operand TG = ent_op(t, targets);
+  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, TG, TG, TG)) return KGE_ERR_UNSUPPORTED;
+  Operand nA{}, nA2{}, nR{};
+  int ndir = KGE_SP_;
+  const bool has_next = next != nullptr && next->n > 0 && next->queries != nullptr;
+  if (has_next) {
+    if (next->queries == queries) return KGE_ERR_INVALID_ARG;  // (this launch still reads `queries`)
+    if (next->queries_bytes < kge_queries_bytes(t, combine, next->n)) return KGE_ERR_WORKSPACE;
+    if ((rc = query_operands(t, combine, next->s, next->p, next->o, nA, nA2, nR, ndir))) return rc;
+    if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, nA, nR, nA)) return KGE_ERR_UNSUPPORTED;
+  }
+  if (n == 0 || m == 0) {  // nothing to score: the next batch still wants its queries
+    if (!has_next) return KGE_OK;
+    return run_query_build(t->scorer, split, nA, combine == KGE_SP_PO ? &nA2 : nullptr, nR, ndir, (int)t->dim,
+                           next->n, next->queries, (hipStream_t)stream);
+  }
+  const Operand none{t->ent, t->ent_ld, Index{nullptr, 1, 1}};  // (never read: the queries are prepared)
+  return run_pairs_bf16_v4_prepared(t->scorer, split, none, combine == KGE_SP_PO ? &none : nullptr, none, TG,
+                                    combine == KGE_PO_ ? KGE_PO_ : KGE_SP_, (int)t->dim, n, m, out, ldo, m,
+                                    (hipStream_t)stream, nullptr, queries, nullptr, 0,
+                                    (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, has_next ? &nA : nullptr,
+                                    has_next && combine == KGE_SP_PO ? &nA2 : nullptr, has_next ? &nR : nullptr,
+                                    has_next ? next->n : 0, has_next ? next->queries : nullptr);
 }
 
 int kge_score_sp(const kge_tables* t, kge_index s, kge_index p, int64_t n, kge_index targets,
@@ -296,13 +417,18 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
       check_index(p, false) == KGE_OK && check_index(o, false) == KGE_OK &&
       check_index(targets, true) == KGE_OK && (targets.ptr || m == t->num_ent)) {
     Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, targets);
+    const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
+    if (split) {  // q_hi + q_lo: one two-sided launch behind a builder launch
+      const int rcs = split_sp_po(t, S, O, P, TG, n, m, out, ldo, workspace, workspace_bytes, (hipStream_t)stream);
+      if (rcs != KGE_ERR_UNSUPPORTED) return rcs;
+    }
     if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
         pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
       const int rc5 = run_pairs_bf16_v5(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
                                         (hipStream_t)stream, nullptr);
       if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
     }
-    if (pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
+    if (!split && pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
         pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
       const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
                                         (hipStream_t)stream, nullptr, workspace, workspace_bytes,
@@ -400,8 +526,12 @@ int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, co
     const int rc5 = run_pairs_bf16_v5(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr);
     if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
   }
+  if (workspace && n > 0 && m > 0 && (t->flags & KGE_FLAG_SPLIT_QUERY) && !(t->flags & KGE_FLAG_EXACT)) {
+    const int rcs = split_sp_po(t, S, O, P, TG, n, m, out, ldo, workspace, workspace_bytes, st);
+    if (rcs != KGE_ERR_UNSUPPORTED) return rcs;
+  }
   if (workspace && n > 0 && m > 0 &&
-      !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) &&
+      !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY)) &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
     const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr,
@@ -500,7 +630,8 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
     if (!sp_begin || !sp_end || !sp_col || !po_begin || !po_end || !po_col || !sp_begin[k] || !sp_end[k] ||
         !sp_col[k] || !po_begin[k] || !po_end[k] || !po_col[k])
       return KGE_ERR_INVALID_ARG;
-  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
+  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
+    return KGE_ERR_UNSUPPORTED;  // (split queries: the counting epilogue sees one consumer wave's partial score)
   if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
       !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
     return KGE_ERR_UNSUPPORTED;
@@ -1012,6 +1143,12 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
   kge_index all{nullptr, KGE_I64, 0, 1};
   Operand A = ent_op(t, s), R = rel_op(t, p), TG = ent_op(t, all);
   if (!pairs_bf16_v2_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) return KGE_ERR_UNSUPPORTED;
+  if (ablate == 100 || ablate == 101) {  // prepared queries (100) / split queries (101): builder launch, then the stamped scoring launch
+    if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) return KGE_ERR_UNSUPPORTED;
+    return run_pairs_bf16_v4_prepared(t->scorer, ablate == 101, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, 0,
+                                      (hipStream_t)stream, stamps, nullptr, workspace, workspace_bytes, 0, nullptr,
+                                      nullptr, nullptr, 0, nullptr);
+  }
   if (ablate) {
     if (t->scorer != KGE_COMPLEX || t->dim != 512) return KGE_ERR_UNSUPPORTED;
     return run_pairs_bf16_v2_ablate(ablate, A, R, TG, n, m, out, ldo, (hipStream_t)stream, stamps);

@@ -58,14 +58,116 @@ __device__ __forceinline__ void v4_static_for(F&& f) {
 // waves do that on the accumulators right after a tile's MFMA chain, the DMA waves keep streaming,
 // the store waves have nothing to do (kge_ce_fwd / kge_ce_sp_po_fwd: the [n, E] matrix is never
 // written; per row and column group 8 bytes leave the kernel, merged by ce_combine_kernel).
-constexpr int V4_DEGRADED_LAUNCHES = 4096;  // launches a timed-out hand-off is skipped for before it is tried again
+constexpr int V4_DEGRADED_LAUNCHES = 4096;
 
-template <int SCORER, int HH, int TGMODE, int EPI>
+// ---- prepared queries (kge_build_queries / kge_score_queries, include/kge_amd.h) -------------------------------
+// The query vectors q_i = s_i (x) r_i of a batch in MFMA-fragment order, built OUTSIDE the scoring launch that
+// consumes them: by query_build_kernel, or by the spare workgroups of the PREVIOUS batch's scoring launch
+// (NextQ).  The scoring kernel then starts with the fragment loads and the tile DMA -- the five dependent round
+// trips of the in-launch cooperative build (index -> rows -> write-through ack -> flag -> fragments, ~12 k cycles
+// during which nothing is scored, profiles/r12_phase_timestamps.txt) are off its critical path.
+//
+// SPLIT (KGE_FLAG_SPLIT_QUERY): q is carried as q_hi + q_lo, q_hi = bf16(q), q_lo = bf16(q - q_hi), as two
+// VIRTUAL query rows; a row group is 64 real rows = 128 virtual rows (32-row blocks 0, 1: q_hi of real rows
+// 0-31 / 32-63, blocks 2, 3: q_lo), the consumer waves are unchanged, the store waves add the two partial
+// scores.  Products of bf16 values are exact in f32, so score = fl(sum q_hi t) + fl(sum q_lo t) differs from
+// f32 arithmetic on the same bf16 tables only by f32 summation order and the 2^-17 relative residue of
+// q - q_hi - q_lo (exactly 0 for DistMult, whose q has 16 significant bits) -- SURVEY.md 8(c) gate 4.
+struct NextQ {
+  Operand A, A2, R;  // entity rows of the first side, of the second side (two-sided), relation rows
+  int dir;           // combine of the first side (KGE_SP_ / KGE_PO_); a second side is always KGE_PO_
+  long long n;       // rows per side
+  int rgn, rgn1;     // row groups in all / of the first side
+  u32x4* qf;         // destination; nullptr: nothing to build
+  int first, nblocks;  // workgroups [first, first + nblocks) of the launch build
+};
+
+template <int SCORER>
+__device__ __forceinline__ void v4_q_f32(int dir, unsigned int a0, unsigned int a1, unsigned int r0, unsigned int r1,
+                                         f32x2q& Q0, f32x2q& Q1) {
+  const f32x2q A0 = {__uint_as_float(a0 << 16), __uint_as_float(a0 & 0xffff0000u)};
+  const f32x2q A1 = {__uint_as_float(a1 << 16), __uint_as_float(a1 & 0xffff0000u)};
+  const f32x2q R0 = {__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u)};
+  const f32x2q R1 = {__uint_as_float(r1 << 16), __uint_as_float(r1 & 0xffff0000u)};
+  if (SCORER == KGE_DISTMULT) {
+    Q0 = A0 * R0;
+    Q1 = A1 * R1;
+  } else if (dir == KGE_SP_) {  // (bf16 x bf16 products are exact in f32: the fma IS the two-rounding form)
+    Q0 = __builtin_elementwise_fma(A0, R0, -(A1 * R1));
+    Q1 = __builtin_elementwise_fma(A1, R0, A0 * R1);
+  } else {
+    Q0 = __builtin_elementwise_fma(R0, A0, R1 * A1);
+    Q1 = __builtin_elementwise_fma(R0, A1, -(R1 * A0));
+  }
+}
+
+// items [item0, item0 + stride, ...) of the batch: one item = 8 coordinates of both halves of one query row
+template <int SCORER, int HH, int SPLIT>
+__device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item0, long long stride) {
+  constexpr int NKB = 2 * HH / 16, NKH = HH / 16, CGR = HH / 8;
+  constexpr int RGR = SPLIT ? 64 : 128;  // real rows per row group
+  const long long items = (long long)nx.rgn * RGR * CGR;
+  for (long long it = item0; it < items; it += stride) {
+    const int rg = (int)(it / (RGR * CGR));
+    const int rr = (int)((it / CGR) % RGR);
+    const int c8 = (int)(it % CGR);
+    const bool second = rg >= nx.rgn1;
+    const long long lrow = (long long)(second ? rg - nx.rgn1 : rg) * RGR + rr;
+    const long long qrow = lrow < nx.n ? lrow : nx.n - 1;  // padded rows repeat row n-1
+    const Operand& E = second ? nx.A2 : nx.A;
+    const int dir = second ? KGE_PO_ : nx.dir;
+    const unsigned short* a = (const unsigned short*)E.base + index_at(E.idx, qrow) * E.ld + c8 * 8;
+    const unsigned short* r = (const unsigned short*)nx.R.base + index_at(nx.R.idx, qrow) * nx.R.ld + c8 * 8;
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
+    const u32x4 r0 = *reinterpret_cast<const u32x4*>(r), r1 = *reinterpret_cast<const u32x4*>(r + HH);
+    u32x4 q0, q1, l0, l1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (SPLIT) {
+        f32x2q Q0, Q1;
+        v4_q_f32<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], Q0, Q1);
+        q0[e] = bf16_pack_hw(Q0);
+        q1[e] = bf16_pack_hw(Q1);
+        const f32x2q H0 = {__uint_as_float(q0[e] << 16), __uint_as_float(q0[e] & 0xffff0000u)};
+        const f32x2q H1 = {__uint_as_float(q1[e] << 16), __uint_as_float(q1[e] & 0xffff0000u)};
+        l0[e] = bf16_pack_hw(Q0 - H0);  // exact differences (Sterbenz-like: |q - q_hi| <= ulp_bf16(q) / 2)
+        l1[e] = bf16_pack_hw(Q1 - H1);
+      } else {
+        unsigned int x0, x1;
+        bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+        q0[e] = x0;
+        q1[e] = x1;
+      }
+    }
+    // fragment-major (as the in-launch build below): K-block kb of 32-row block rb is 64 lanes x 16 B
+    const long long row = (long long)rg * 128 + rr;  // virtual row (SPLIT: the q_hi row; q_lo 64 rows behind)
+    u32x4* dst = nx.qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
+    dst[(c8 >> 1) * 64] = q0;
+    dst[(NKH + (c8 >> 1)) * 64] = q1;
+    if constexpr (SPLIT) {
+      u32x4* dl = dst + 2 * NKB * 64;  // two 32-row blocks further
+      dl[(c8 >> 1) * 64] = l0;
+      dl[(NKH + (c8 >> 1)) * 64] = l1;
+    }
+  }
+}
+
+template <int SCORER, int HH, int SPLIT>
+__global__ __launch_bounds__(256) void query_build_kernel(NextQ nx) {
+  v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+}  // launches a timed-out hand-off is skipped for before it is tried again
+
+// nbuild < 0: PREPARED queries -- qf already holds this launch's fragments (no builders, no flags, no polling, no
+// co-residency requirement).  nx.qf != NULL: workgroups [nx.first, nx.first + nx.nblocks) build the NEXT batch's
+// fragments into nx.qf instead of scoring (they take the compute units the launch geometry leaves idle).
+template <int SCORER, int HH, int TGMODE, int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     Operand A, Operand A2, Operand R, Operand TG, int dir, long long n, long long m, int rgn,
     int rgn1, long long out2_off, int ncg, int tiles_per_cg, int ntiles, float* __restrict__ out,
     long long ldo, unsigned long long* __restrict__ dbg, u32x4* __restrict__ qf,
-    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild, CeArgs ce) {
+    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild, CeArgs ce, NextQ nx) {
+  static_assert(!SPLIT || EPI == V3_STORE, "split queries: score store path only");
+  constexpr int RGR = SPLIT ? 64 : V4_ROWS;  // real query rows per row group
   constexpr int NKB = 2 * HH / 16;       // K-blocks of 16
   constexpr int NKH = HH / 16;           // K-blocks per half
   constexpr int ROWB = 4 * HH;           // bytes per table row (2*HH bf16)
@@ -86,6 +188,13 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   constexpr int QB2 = 3 * NQ / 4;         // MFMA slot of barrier B2
   static_assert(NL * RPP == 16 && SPR >= 32, "d in {256, 512}");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+  if (nx.qf != nullptr && (int)blockIdx.x >= nx.first) {  // a spare workgroup: the next batch's query fragments
+    v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)((int)blockIdx.x - nx.first) * 512 + threadIdx.x,
+                                        (long long)nx.nblocks * 512);
+    return;
+  }
+  const bool prebuilt = nbuild < 0;  // (uniform)
 
   // ---- which rows / target tiles
   const int b = blockIdx.x;
@@ -170,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   // The degraded word is a COUNTDOWN of launches, not a latch: one thread per launch takes one off, so that a
   // workspace degraded by a single hiccup (a builder held up for > ~60 ms once) goes back to the cooperative
   // build after V4_DEGRADED_LAUNCHES launches instead of paying the own-build path for the life of the process.
-  if (blockIdx.x == 0 && tid == 0) {
+  if (!prebuilt && blockIdx.x == 0 && tid == 0) {
     unsigned long long* const dgw = flags + 512 * 8;
     const unsigned long long v = __hip_atomic_load(dgw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v != 0ull) __hip_atomic_store(dgw, v - 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -287,12 +396,16 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     // ------------------------------- store waves -------------------------------
     const int cl = lane & 15, rq = lane >> 4;
     const int z = cl ^ rq;
+    // SPLIT: this wave owns ONE real 32-row block (wave & 1); its q_hi partial scores are consumer (wave & 1)'s
+    // staging block, the q_lo partials consumer (wave & 1) + 2's: read both, store their sum (NU = 1 output block)
+    constexpr int NU = SPLIT ? 1 : 2;
     unsigned int crd[2], svoff[2][8];
     unsigned char* out_rb[2];
+    if constexpr (SPLIT) crd[1] = (unsigned int)(CST0 + ((wave & 1) + 2) * CSTW + rq * 256);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int w = j2 + u;
-      const long long r0 = (long long)rgl * V4_ROWS + 32 * w;
+    for (int u = 0; u < NU; ++u) {
+      const int w = SPLIT ? (wave & 1) : j2 + u;
+      const long long r0 = (long long)rgl * RGR + 32 * w;
       const long long rb = r0 < n ? r0 : n - 1;
       crd[u] = (unsigned int)(CST0 + w * CSTW + rq * 256);
 #pragma unroll
@@ -335,8 +448,12 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
           }
         return;
       }
+      if constexpr (SPLIT) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+        for (int i = 0; i < 8; ++i) cv[0][i] = cv[0][i] + cv[1][i];  // score = (sum q_hi t) + (sum q_lo t)
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
         if (col0 + V4_TN <= m) {
           unsigned char* sbase = out_rb[u] + col0 * 4;
 #pragma unroll
@@ -379,69 +496,79 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   // captured launch, whose epoch is frozen).  KGE_V4_OWN_BUILD=1 (tests) takes that path on purpose.
   unsigned long long* const degraded = flags + 512 * 8;
   int* const sb_flag = reinterpret_cast<int*>(smem + CST0);  // the staging buffer is idle until tile 0 is done
-  if (wave == 0) {
-    // ONE wave per workgroup polls (255 pollers already cost chip bandwidth): one flag per builder
-    unsigned long long* f = flags + ((long long)rg * ncg + cg) * 8;
-    bool ok = nbuild > 0 && __hip_atomic_load(degraded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
-    for (int spin = 0; ok; ++spin) {
-      const unsigned long long v =
-          lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-      if (__all(v == epoch)) break;
-      if (spin == (1 << 16)) {  // ~0.1 s: far beyond any launch skew
-        ok = false;
-        if (lane == 0 && nbuild > 0)
-          __hip_atomic_store(degraded, (unsigned long long)V4_DEGRADED_LAUNCHES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    // This line belongs to this workgroup alone (the builders write it, nobody else reads it):
-    // clear it, so that a replay of this very launch (hipGraph: the kernel arguments, epoch
-    // included, are frozen at capture) starts from "not published" again.
-    if (ok && lane < nbuild) __hip_atomic_store(f + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane == 0) *sb_flag = ok ? 1 : 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS write has landed before the barrier
-  }
-  __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published (or given up on)
-  stamp();  // 2: all shares of this row group published
-  const bool coop = *reinterpret_cast<volatile int*>(sb_flag) != 0;
-  if (coop) {
-    // The builders stored with sc1 (write-through); sc1 loads (served by L2, never by this CU's
-    // L1) complete the hand-off without an acquire fence.  The 32 loads are NOT waited for here:
-    // the MFMA chain of the first tile waits for fragment kb right before it needs it.
+  // The builders stored with sc1 (write-through); sc1 loads (served by L2, never by this CU's
+  // L1) complete the hand-off without an acquire fence.  The 32 loads are NOT waited for here:
+  // the MFMA chain of the first tile waits for fragment kb right before it needs it.
+  // Compiler-visible buffer loads (not inline asm): the register allocator then knows the values
+  // arrive asynchronously and places the vmcnt waits itself, in front of the first MFMA of tile 0
+  // that needs each fragment (asm loads + asm waits are safe only while nothing
+  // is moved between them).  Prepared queries (a previous launch wrote them) take the same loads.
+  auto load_fragments = [&]() __attribute__((always_inline)) {
     const unsigned char* sb =
         (const unsigned char*)(qf + ((long long)(rg * (V4_ROWS / 32) + w4) * NKB) * 64);  // uniform
-    // compiler-visible buffer loads (not inline asm): the register allocator then knows the values
-    // arrive asynchronously and places the vmcnt waits itself, in front of the first MFMA of tile 0
-    // that needs each fragment (asm loads + asm waits are safe only while nothing
-    // is moved between them)
     const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)sb, 0, NKB * 1024, 0x00020000);
     v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
       afr[kb] = __builtin_bit_cast(
           bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16 + kb * 1024), 0, 16 /* sc1 */));
     });
+  };
+  if (prebuilt) {
+    // prepared queries: the fragment loads go out at once, next to the DMA of tiles 0 and 1
+    load_fragments();
+    __builtin_amdgcn_s_barrier();  // B0 (keeps the barrier count of the loader waves)
+    stamp();  // 2
   } else {
-    // own build, straight into the MFMA operand registers: lane (fi, fh) holds coordinates
-    // 16 kb + 8 fh .. + 7 of query row fi for every K-block kb -- the same values, bit for bit
-    const long long lrow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
-    const long long qrow = lrow < n ? lrow : n - 1;
-    const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + fh * 8;
-    const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + fh * 8;
-    v4_static_for<0, NKH>([&](auto kc) __attribute__((always_inline)) {
-      constexpr int kb = decltype(kc)::value;
-      const u32x4 a0 = *reinterpret_cast<const u32x4*>(a + kb * 16), a1 = *reinterpret_cast<const u32x4*>(a + HH + kb * 16);
-      const u32x4 r0 = *reinterpret_cast<const u32x4*>(r + kb * 16), r1 = *reinterpret_cast<const u32x4*>(r + HH + kb * 16);
-      u32x4 q0, q1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unsigned int x0, x1;
-        bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
-        q0[e] = x0;
-        q1[e] = x1;
+    if (wave == 0) {
+      // ONE wave per workgroup polls (255 pollers already cost chip bandwidth): one flag per builder
+      unsigned long long* f = flags + ((long long)rg * ncg + cg) * 8;
+      bool ok = nbuild > 0 && __hip_atomic_load(degraded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
+      for (int spin = 0; ok; ++spin) {
+        const unsigned long long v =
+            lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+        if (__all(v == epoch)) break;
+        if (spin == (1 << 16)) {  // ~0.1 s: far beyond any launch skew
+          ok = false;
+          if (lane == 0 && nbuild > 0)
+            __hip_atomic_store(degraded, (unsigned long long)V4_DEGRADED_LAUNCHES, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      afr[kb] = __builtin_bit_cast(bf16x8, q0);
-      afr[NKH + kb] = __builtin_bit_cast(bf16x8, q1);
-    });
+      // This line belongs to this workgroup alone (the builders write it, nobody else reads it):
+      // clear it, so that a replay of this very launch (hipGraph: the kernel arguments, epoch
+      // included, are frozen at capture) starts from "not published" again.
+      if (ok && lane < nbuild) __hip_atomic_store(f + lane, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) *sb_flag = ok ? 1 : 0;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS write has landed before the barrier
+    }
+    __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published (or given up on)
+    stamp();  // 2: all shares of this row group published
+    const bool coop = *reinterpret_cast<volatile int*>(sb_flag) != 0;
+    if (coop) {
+      load_fragments();
+    } else if constexpr (!SPLIT) {
+      // own build, straight into the MFMA operand registers: lane (fi, fh) holds coordinates
+      // 16 kb + 8 fh .. + 7 of query row fi for every K-block kb -- the same values, bit for bit
+      const long long lrow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
+      const long long qrow = lrow < n ? lrow : n - 1;
+      const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + fh * 8;
+      const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + fh * 8;
+      v4_static_for<0, NKH>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kc)::value;
+        const u32x4 a0 = *reinterpret_cast<const u32x4*>(a + kb * 16), a1 = *reinterpret_cast<const u32x4*>(a + HH + kb * 16);
+        const u32x4 r0 = *reinterpret_cast<const u32x4*>(r + kb * 16), r1 = *reinterpret_cast<const u32x4*>(r + HH + kb * 16);
+        u32x4 q0, q1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned int x0, x1;
+          bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+          q0[e] = x0;
+          q1[e] = x1;
+        }
+        afr[kb] = __builtin_bit_cast(bf16x8, q0);
+        afr[NKH + kb] = __builtin_bit_cast(bf16x8, q1);
+      });
+    }
   }
   // B fragment (K-block kb, half hf) of target row 32*hf + fi: 16-B slot s = s0(kb) + fh, stored
   // at slot s ^ (fi & 15): with s = 16*a + b the swizzle only touches b -> 8 address registers
@@ -812,29 +939,82 @@ static inline bool v4_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 static std::atomic<unsigned long long> g_v4_epoch{0};
 
+// compute units of the CURRENT device (one process may drive several: the count is looked up per device, once)
 static int v4_cu_count() {
-  static int cus = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return v;
-  }();
-  return cus;
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
+// Prepared queries of a launch (kge_build_queries / kge_score_queries; KGE_FLAG_SPLIT_QUERY):
+//   ready        this launch's fragments, already built (by query_build_kernel or by a previous launch's spare
+//                workgroups); NULL: the in-launch cooperative build through the workspace
+//   build_first  ready == NULL: build them into the workspace by a separate launch on the same stream, then score
+//                prepared (what the one-call entry points do for split queries)
+//   next         the NEXT batch, built by this launch's spare workgroups (qf == NULL: none)
+struct V4Prep {
+  const void* ready = nullptr;
+  bool build_first = false;
+  NextQ next = NextQ{};
+};
+
+template <int SCORER, int HH, int SPLIT>
+static NextQ v4_nextq(const Operand& A, const Operand* A2, const Operand& R, int dir, long long n, void* qf) {
+  constexpr int RGR = SPLIT ? 64 : V4_ROWS;
+  NextQ q{};
+  q.A = A;
+  q.A2 = A2 ? *A2 : A;
+  q.R = R;
+  q.dir = dir;
+  q.n = n;
+  q.rgn1 = (int)((n + RGR - 1) / RGR);
+  q.rgn = A2 ? 2 * q.rgn1 : q.rgn1;
+  q.qf = (u32x4*)qf;
+  return q;
+}
+
+// bytes of the fragments of one batch: rgn row groups of 128 (virtual) rows x 2 HH bf16
+long long pairs_bf16_v4_query_bytes(int d, long long n, bool two_sided, bool split) {
+  const long long rgr = split ? 64 : V4_ROWS;
+  const long long rgn = (two_sided ? 2 : 1) * ((n + rgr - 1) / rgr);
+  return rgn * V4_ROWS * (long long)d * 2;
+}
+
+template <int SCORER, int HH, int SPLIT>
+static int launch_query_build(const NextQ& q, hipStream_t st) {
+  constexpr int RGR = SPLIT ? 64 : V4_ROWS;
+  const long long items = (long long)q.rgn * RGR * (HH / 8);
+  long long blocks = (items + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((query_build_kernel<SCORER, HH, SPLIT>), dim3((unsigned)blocks), dim3(256), 0, st, q);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
 // A2 != nullptr: two-sided launch (A = subjects scored sp_, A2 = objects scored _po into the
 // column block `out2_off` floats behind).
-template <int SCORER, int HH, int EPI = V3_STORE>
+template <int SCORER, int HH, int EPI = V3_STORE, int SPLIT = 0>
 static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                      long long n, long long m, float* out, long long ldo, long long out2_off,
                      hipStream_t st, unsigned long long* dbg, void* ws, long long ws_bytes,
-                     int reserve_cus, const CeArgs& ce = CeArgs{}) {
-  const int rgn1 = (int)((n + V4_ROWS - 1) / V4_ROWS);
+                     int reserve_cus, const CeArgs& ce = CeArgs{}, const V4Prep& pp = V4Prep{}) {
+  constexpr int RGR = SPLIT ? 64 : V4_ROWS;
+  const int rgn1 = (int)((n + RGR - 1) / RGR);
   const int rgn = A2 ? 2 * rgn1 : rgn1;
   const int ntiles = (int)((m + V4_TN - 1) / V4_TN);
+  const bool prepared = pp.ready != nullptr || pp.build_first;
   // one workgroup per CU (minus the CUs the caller keeps free for concurrent work, e.g. the
   // RCCL kernels of an overlapped exchange): split the target tiles into column groups
-  int cus = v4_cu_count() - reserve_cus;
+  const int cu_all = v4_cu_count();
+  int cus = cu_all - reserve_cus;
   if (cus > 256) cus = 256;
   if (cus < 8) cus = 8;
   // fused loss: the caller sized its partial-result scratch for the geometry of
@@ -852,26 +1032,52 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   ncg = (ntiles + tpc - 1) / tpc;
   const int grid = 8 * rgn * ((ncg + 7) / 8);
   const int tgmode = TG.idx.ptr == nullptr ? 0 : (TG.idx.itype ? 2 : 1);
-  // needs: the workspace and every workgroup resident at once (spin-wait on the builders' flags).
-  // Fine under hipGraph capture: the epoch is frozen then, but every consumer clears its own
-  // flag line after reading it, so a replay never sees the previous run's flags.
   const long long qf_bytes = (long long)rgn * V4_ROWS * HH * 4;
-  if (ws == nullptr || !v4_al16(ws) || (long long)rgn * ncg > 512 || ws_bytes < qf_bytes + PAIRS_WS_CTRL_BYTES ||
-      grid > v4_cu_count() || ldo >= (1LL << 24))
-    return KGE_ERR_UNSUPPORTED;
-  // control block first, at an offset independent of n (pairs_bf16_v3_workspace_bytes)
-  unsigned long long* flags = (unsigned long long*)ws;
-  u32x4* qf = (u32x4*)((char*)ws + PAIRS_WS_CTRL_BYTES);
-  static const unsigned long long seed =
-      ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20) | (1ull << 63);
-  const unsigned long long epoch = seed + ++g_v4_epoch;  // never 0 (= "cleared")
-  int nbuild = ncg < 8 ? ncg : 8;
-  const int items = V4_ROWS * (HH / 8);  // at least one item per builder thread
-  while (nbuild > 1 && nbuild * 512 > items) --nbuild;
-  // KGE_V4_OWN_BUILD=1 (tests): no cooperative build, every consumer wave builds its own fragments --
-  // the path a consumer otherwise only takes after a time-out or on a degraded workspace
-  const char* own = getenv("KGE_V4_OWN_BUILD");
-  if (own && own[0] == '1') nbuild = 0;
+  if (ldo >= (1LL << 24)) return KGE_ERR_UNSUPPORTED;
+  unsigned long long* flags = nullptr;
+  u32x4* qf = nullptr;
+  unsigned long long epoch = 0;
+  int nbuild = -1;
+  if (pp.ready != nullptr) {
+    if (!v4_al16(pp.ready)) return KGE_ERR_INVALID_ARG;
+    qf = (u32x4*)pp.ready;  // no flags, no polling: workgroups need not be co-resident, any grid goes
+  } else {
+    // the in-launch build needs the workspace and every workgroup resident at once (spin-wait on the builders'
+    // flags).  Fine under hipGraph capture: the epoch is frozen then, but every consumer clears its own
+    // flag line after reading it, so a replay never sees the previous run's flags.
+    if (ws == nullptr || !v4_al16(ws) || ws_bytes < qf_bytes + PAIRS_WS_CTRL_BYTES) return KGE_ERR_UNSUPPORTED;
+    // control block first, at an offset independent of n (pairs_bf16_v3_workspace_bytes)
+    flags = (unsigned long long*)ws;
+    qf = (u32x4*)((char*)ws + PAIRS_WS_CTRL_BYTES);
+    if (pp.build_first) {
+      const int rc = launch_query_build<SCORER, HH, SPLIT>(v4_nextq<SCORER, HH, SPLIT>(A, A2, R, dir, n, qf), st);
+      if (rc != KGE_OK) return rc;
+    } else {
+      if (SPLIT || (long long)rgn * ncg > 512 || grid > cu_all) return KGE_ERR_UNSUPPORTED;
+      static const unsigned long long seed =
+          ((unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() << 20) | (1ull << 63);
+      epoch = seed + ++g_v4_epoch;  // never 0 (= "cleared")
+      nbuild = ncg < 8 ? ncg : 8;
+      const int items = V4_ROWS * (HH / 8);  // at least one item per builder thread
+      while (nbuild > 1 && nbuild * 512 > items) --nbuild;
+      // KGE_V4_OWN_BUILD=1 (tests): no cooperative build, every consumer wave builds its own fragments --
+      // the path a consumer otherwise only takes after a time-out or on a degraded workspace
+      const char* own = getenv("KGE_V4_OWN_BUILD");
+      if (own && own[0] == '1') nbuild = 0;
+    }
+  }
+  // the next batch's queries: built by workgroups appended to the grid -- they start on the compute units the
+  // geometry leaves idle (the column groups rarely fill all of them: 228 of 256 at the FB15k-237 shape) or that
+  // the first finished workgroups free.  Only a launch that does not spin on flags may exceed the CU count.
+  NextQ nx = pp.next;
+  int nb = 0;
+  if (nx.qf != nullptr) {
+    if (!prepared || !v4_al16(nx.qf)) return KGE_ERR_INVALID_ARG;
+    const int spare = cu_all - rgn * ncg;
+    nb = spare < 8 ? 8 : (spare > 32 ? 32 : spare);
+    nx.first = grid;
+    nx.nblocks = nb;
+  }
   const Operand& AA2 = A2 ? *A2 : A;
   // interleaved tiles (tiles_per_cg = 0) once a launch's score block outgrows the Infinity Cache
   const char* il = getenv("KGE_V4_INTERLEAVE");
@@ -880,10 +1086,10 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   const bool interleave =
       il ? il[0] == '1' : ((double)n * (double)m * 4.0 * (A2 ? 2 : 1) > 192e6 && (ldo & 7) == 0);
   const int tpc_arg = interleave ? 0 : tpc;
-#define KGE_V4L(MODE)                                                                          \
-  hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE, EPI>), dim3(grid), dim3(512), 0, st, A, \
-                     AA2, R, TG, dir, n, m, rgn, rgn1, out2_off, ncg, tpc_arg, ntiles, out, ldo, \
-                     dbg, qf, flags, epoch, nbuild, ce)
+#define KGE_V4L(MODE)                                                                                  \
+  hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE, EPI, SPLIT>), dim3(grid + nb), dim3(512), 0, st, A, \
+                     AA2, R, TG, dir, n, m, rgn, rgn1, out2_off, ncg, tpc_arg, ntiles, out, ldo, dbg, qf, flags, \
+                     epoch, nbuild, ce, nx)
   if (tgmode == 0) KGE_V4L(0);
   else if (tgmode == 1) KGE_V4L(1);
   else KGE_V4L(2);
@@ -918,6 +1124,56 @@ int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Ope
   }
   if (scorer == KGE_COMPLEX) { KGE_V4(KGE_COMPLEX) } else { KGE_V4(KGE_DISTMULT) }
 #undef KGE_V4
+  return KGE_ERR_UNSUPPORTED;
+}
+
+// ---- prepared queries ------------------------------------------------------------------------------------------
+// run_query_build: the fragments of one batch into `qf` (pairs_bf16_v4_query_bytes).  A2: two-sided.
+int run_query_build(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                    long long n, void* qf, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (!v4_al16(qf)) return KGE_ERR_INVALID_ARG;
+#define KGE_QB(SC, HHV, SP) return launch_query_build<SC, HHV, SP>(v4_nextq<SC, HHV, SP>(A, A2, R, dir, n, qf), st)
+#define KGE_QB2(SC)                                    \
+  if (d == 256) {                                      \
+    if (split) KGE_QB(SC, 128, 1); else KGE_QB(SC, 128, 0); \
+  } else if (d == 512) {                               \
+    if (split) KGE_QB(SC, 256, 1); else KGE_QB(SC, 256, 0); \
+  }
+  if (scorer == KGE_COMPLEX) { KGE_QB2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_QB2(KGE_DISTMULT) }
+#undef KGE_QB2
+#undef KGE_QB
+  return KGE_ERR_UNSUPPORTED;
+}
+
+// run_pairs_bf16_v4_prepared: score with prepared queries.
+//   ready != NULL            the batch's fragments (A / A2 / R are not read)
+//   ready == NULL            split / build-first: fragments are built into `ws` by a separate launch, then scored
+//   nA / nA2 / nR, nn, nqf   nqf != NULL: the next batch, built by spare workgroups of this launch
+int run_pairs_bf16_v4_prepared(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R,
+                               const Operand& TG, int dir, int d, long long n, long long m, float* out,
+                               long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
+                               const void* ready, void* ws, long long ws_bytes, int reserve_cus, const Operand* nA,
+                               const Operand* nA2, const Operand* nR, long long nn, void* nqf) {
+  if (n == 0 || m == 0) return KGE_OK;
+  V4Prep pp;
+  pp.ready = ready;
+  pp.build_first = ready == nullptr;
+#define KGE_V4P(SC, HHV, SP)                                                                                    \
+  do {                                                                                                          \
+    if (nqf != nullptr && nn > 0) pp.next = v4_nextq<SC, HHV, SP>(*nA, nA2, *nR, dir, nn, nqf);                   \
+    return launch_v4<SC, HHV, V3_STORE, SP>(A, A2, R, TG, dir, n, m, out, ldo, out2_off, st, dbg, ws, ws_bytes, \
+                                            reserve_cus, CeArgs{}, pp);                                         \
+  } while (0)
+#define KGE_V4P2(SC)                                         \
+  if (d == 256) {                                            \
+    if (split) KGE_V4P(SC, 128, 1); else KGE_V4P(SC, 128, 0); \
+  } else if (d == 512) {                                     \
+    if (split) KGE_V4P(SC, 256, 1); else KGE_V4P(SC, 256, 0); \
+  }
+  if (scorer == KGE_COMPLEX) { KGE_V4P2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_V4P2(KGE_DISTMULT) }
+#undef KGE_V4P2
+#undef KGE_V4P
   return KGE_ERR_UNSUPPORTED;
 }
 

@@ -15,11 +15,12 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_BF16_V3, FLAG_EXACT, FLAG_NO_MFMA, I32, I64, PO_, SCORERS, SP_, SPO, KgeIndex,
-                   KgeTables)
+from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_BF16_V3, FLAG_EXACT, FLAG_NO_MFMA, FLAG_SPLIT_QUERY, I32, I64, PO_,
+                   SCORERS, SP_, SP_PO, SPO, KgeIndex, KgeNextQueries, KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "embed", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3", "reserve_cus"]
+           "score_emb", "embed", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3",
+           "FLAG_SPLIT_QUERY", "reserve_cus", "Queries", "build_queries", "score_queries", "ScorePipeline"]
 
 
 def reserve_cus(n: int) -> int:
@@ -255,6 +256,96 @@ def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Ten
         if rc:
             _lib.check(rc, "kge_score_sp_po")
     return out
+
+
+# ---- prepared queries (kge_build_queries / kge_score_queries) ----------------------------------------------------
+_COMBINE = {"sp_": SP_, "_po": PO_, "sp_po": SP_PO}
+
+
+class Queries:
+    """The prepared query vectors of one batch (opaque device buffer, include/kge_amd.h): built by
+    `build_queries` or by the previous batch's `score_queries(..., next=...)`."""
+
+    __slots__ = ("buf", "combine", "n", "flags")
+
+    def __init__(self, t: Tables, combine: str, n: int, flags=None):
+        tc = t.c(flags)
+        need = _lib.lib().kge_queries_bytes(ctypes.byref(tc), _COMBINE[combine], n)
+        if need <= 0:
+            raise RuntimeError("kge_amd: prepared queries need bf16 ComplEx / DistMult tables of dim 256 / 512")
+        self.buf = _empty((need,), t.device, torch.uint8)
+        self.combine, self.n, self.flags = combine, n, flags
+
+
+def build_queries(t: Tables, combine: str, s, p, o, flags=None, out: Queries = None) -> Queries:
+    """Query vectors of the batch (s, p, o) for `score_queries` (combine "sp_": s, p; "_po": p, o; "sp_po": all)."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = _same_len([k for k in keep], "build_queries")
+    q = out if out is not None else Queries(t, combine, n, flags)
+    if q.n != n or q.combine != combine:
+        raise ValueError("kge_amd: build_queries: the Queries buffer was sized for another batch shape")
+    with _on_device(t.device):
+        tc = t.c(q.flags)
+        rc = _lib.lib().kge_build_queries(ctypes.byref(tc), _COMBINE[combine], si, pi, oi, n, q.buf.data_ptr(),
+                                          q.buf.numel(), _stream_handle(t.device))
+        if rc:
+            _lib.check(rc, "kge_build_queries")
+    return q
+
+
+def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None, next_queries: Queries = None):
+    """[n, m] ("sp_", "_po") or [n, 2m] ("sp_po") scores of the prepared batch `q` against all / the listed
+    entities -- the bits of score_sp / score_po / score_sp_po.  next_batch = (s, p, o) + next_queries: the NEXT
+    batch's queries are built by idle workgroups of the same launch (one launch per batch, no start-up chain)."""
+    keep = []
+    ti = _index(targets, t.device, keep)
+    m = t.num_ent if targets is None else keep[-1].numel()
+    width = 2 * m if q.combine == "sp_po" else m
+    if out is None:
+        out = _empty((q.n, width), t.device)
+    nxt = None
+    if next_batch is not None:
+        nkeep = []
+        si, pi, oi = (_index(x, t.device, nkeep) for x in next_batch)
+        nn = _same_len(nkeep, "score_queries(next_batch)")
+        keep += nkeep
+        if next_queries.n != nn or next_queries.combine != q.combine or next_queries.flags != q.flags:
+            raise ValueError("kge_amd: score_queries: next_queries does not match the next batch")
+        nxt = KgeNextQueries(si, pi, oi, nn, next_queries.buf.data_ptr(), next_queries.buf.numel())
+    with _on_device(t.device):
+        tc = t.c(q.flags)
+        rc = _lib.lib().kge_score_queries(ctypes.byref(tc), _COMBINE[q.combine], q.buf.data_ptr(), q.n, ti, m,
+                                          out.data_ptr(), out.stride(0), ctypes.byref(nxt) if nxt is not None else None,
+                                          _stream_handle(t.device))
+        if rc:
+            _lib.check(rc, "kge_score_queries")
+    return out
+
+
+class ScorePipeline:
+    """A stream of equally shaped batches through `score_queries`: batch k is scored while batch k + 1's queries
+    are built inside the same launch (two alternating Queries buffers).
+
+        pipe = ScorePipeline(T, "sp_po", n); pipe.start(s0, p0, o0)
+        for k in ...: scores = pipe.step(next_batch=(s, p, o) of batch k + 1 or None)
+    """
+
+    def __init__(self, t: Tables, combine: str, n: int, flags=None):
+        self.t = t
+        self.q = [Queries(t, combine, n, flags), Queries(t, combine, n, flags)]
+        self.cur = 0
+
+    def start(self, s, p, o):
+        self.cur = 0
+        build_queries(self.t, self.q[0].combine, s, p, o, out=self.q[0])
+
+    def step(self, next_batch=None, targets=None, out=None):
+        q, nq = self.q[self.cur], self.q[1 - self.cur]
+        res = score_queries(self.t, q, targets, out, next_batch, nq if next_batch is not None else None)
+        if next_batch is not None:
+            self.cur = 1 - self.cur
+        return res
 
 
 def score_neg(t: Tables, s, p, o, slot: int, neg: torch.Tensor, flags=None) -> torch.Tensor:

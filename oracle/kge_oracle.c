@@ -31,6 +31,7 @@
 
 enum { KO_COMPLEX = 0, KO_DISTMULT = 1, KO_TRANSE = 2, KO_ROTATE = 3 };
 enum { KO_F32 = 0, KO_BF16 = 1 };
+enum { KO_SPLIT_QUERY = 1 }; /* bit of ko_tables.reserved: the split-query semantics of the bf16 pair path */
 enum { KO_SP = 1, KO_PO = 2 };
 
 typedef struct ko_tables {
@@ -203,6 +204,7 @@ int ko_score_pairs(const ko_tables* t, int dir, const void* a_idx, int a_itype,
   int64_t d = t->dim, dr = t->rel_dim;
   float* a = (float*)malloc(sizeof(float) * (size_t)(2 * d + dr + 8));
   float *r = a + d, *q = r + dr;
+  float* ql = (float*)malloc(sizeof(float) * (size_t)(d + 8));
   float* T = (float*)malloc(sizeof(float) * (size_t)(m > 0 ? m * d : 1));
   int bf16_q = (t->dtype == KO_BF16) &&
                (t->scorer == KO_COMPLEX || t->scorer == KO_DISTMULT);
@@ -212,6 +214,20 @@ int ko_score_pairs(const ko_tables* t, int dir, const void* a_idx, int a_itype,
     load_row(t->ent, t->dtype, t->ent_ld, idx_at(a_idx, a_itype, a_stride, i), d, a);
     load_row(t->rel, t->dtype, t->rel_ld, idx_at(p_idx, p_itype, p_stride, i), dr, r);
     build_q(t->scorer, dir, a, r, d, q);
+    if (bf16_q && (t->reserved & KO_SPLIT_QUERY)) {
+      /* KGE_FLAG_SPLIT_QUERY (include/kge_amd.h): q = q_hi + q_lo, two bf16 pieces, each with its own
+       * canonical f32 chain, one f32 add -- f32 arithmetic on the bf16 table values up to the
+       * 2^-17 relative residue of q and the summation order (SURVEY.md 8(c) gate 4) */
+      for (int64_t k = 0; k < d; ++k) {
+        float hi = bf16_to_f32(f32_to_bf16_rne(q[k]));
+        ql[k] = bf16_to_f32(f32_to_bf16_rne(q[k] - hi));
+        q[k] = hi;
+      }
+      for (int64_t j = 0; j < m; ++j)
+        out[i * ldo + j] = pair_score(t->scorer, t->l_norm, q, T + j * d, d) +
+                           pair_score(t->scorer, t->l_norm, ql, T + j * d, d);
+      continue;
+    }
     if (bf16_q)
       for (int64_t k = 0; k < d; ++k) q[k] = bf16_to_f32(f32_to_bf16_rne(q[k]));
     for (int64_t j = 0; j < m; ++j)
@@ -219,6 +235,7 @@ int ko_score_pairs(const ko_tables* t, int dir, const void* a_idx, int a_itype,
   }
   free(T);
   free(a);
+  free(ql);
   return 0;
 }
 

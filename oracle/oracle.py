@@ -77,7 +77,8 @@ def bf16_to_f32(h: np.ndarray) -> np.ndarray:
 class Tables:
     """Entity/relation lookup tables (LookupEmbedder weights) for the oracle."""
 
-    def __init__(self, scorer, ent, rel, l_norm=1.0):
+    def __init__(self, scorer, ent, rel, l_norm=1.0, split_query=False):
+        """split_query: bf16 ComplEx / DistMult sp_ / _po scores with q = q_hi + q_lo (KGE_FLAG_SPLIT_QUERY)."""
         self.scorer = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
         ent = np.ascontiguousarray(ent)
         rel = np.ascontiguousarray(rel)
@@ -92,7 +93,7 @@ class Tables:
         self.l_norm = float(l_norm)
         self.c = _Tables(ent.ctypes.data, rel.ctypes.data, self.dtype, self.scorer,
                          ent.shape[0], rel.shape[0], ent.shape[1], rel.shape[1],
-                         ent.shape[1], rel.shape[1], self.l_norm, 0)
+                         ent.shape[1], rel.shape[1], self.l_norm, 1 if split_query else 0)
 
     @property
     def num_ent(self):
