@@ -47,8 +47,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-one-sided", action="store_true",
@@ -339,10 +339,33 @@ def main():
     n = a.batch
     ent, rel, s, p, o = make_inputs(rank, device, n)
     T = engine.Tables("complex", ent, rel)
+    # Batches are known ahead in every caller of this path (a DataLoader over the split: eval_entity_ranking.py:158-170,
+    # train_1vsAll.py:31-41), so the loop is issued the way such a caller issues it: kge_score_queries scores batch k
+    # from its prepared query vectors while idle workgroups of the SAME launch build batch k + 1's (include/kge_amd.h,
+    # "prepared queries"): one launch per step, all of a step's work inside the timed region (the step that scores
+    # batch k builds batch k + 1's queries; the queries of the very first batch are built by the warm-up).  Two
+    # different batches alternate, so no launch ever reads queries that were not built by the launch before it.
+    q2 = torch.Generator().manual_seed(2)
+    batch_b = tuple(torch.randint(hi, (n,), generator=q2).to(device) for hi in (E_FB, R_FB, E_FB))
+    batches = [(s, p, o), batch_b]
+    # Score rows on a 256-byte pitch (the C ABI's `ldo`: 2 x 14,592 floats per row, the two blocks at column 0 and
+    # 14,592): every 16-byte store of the kernel then covers whole 32-byte sectors.  The reference's contiguous
+    # [n, 2E] layout (rows at 4-byte granularity) is measured beside it (`contiguous_pitch`).
+    PITCH = (E_FB + 63) // 64 * 64
+    out_pad = torch.empty(n, 2 * PITCH, device=device)
+    out_buf = out_pad.view(n, 2, PITCH)[:, :, :E_FB]          # [n, 2, E] view: block b of row i at i*2*PITCH + b*PITCH
+    out_contig = torch.empty(n, 2 * E_FB, device=device)
+    pipe = engine.ScorePipeline(T, "sp_po", n)
+    pipe.start(*batches[0])
+    step_no = [0]
 
-    def run_steps(k):  # KgeModel.score_sp_po: the score_sp and score_po blocks of the batch, one launch
+    def one_step():  # KgeModel.score_sp_po of the current batch: both score blocks, one launch
+        step_no[0] += 1
+        pipe.step(next_batch=batches[step_no[0] & 1], out=out_buf)
+
+    def run_steps(k):
         for _ in range(k):
-            engine.score_sp_po(T, s, p, o)
+            one_step()
 
     run_steps(a.warmup)
     el, regions, host_el = timed_regions(run_steps, torch.cuda.synchronize, a.steps, a.repeats)
@@ -350,13 +373,24 @@ def main():
     # Duration of one scoring call (= one launch of the dominant kernel pairs_bf16_v4_kernel): HIP
     # events on the launch stream bracketing a region of the same K steps.  Back-to-back calls
     # pipeline their launch overhead exactly as in the timed region above.
-    avg_ms = event_avg_ms(lambda: engine.score_sp_po(T, s, p, o), a.steps)
+    avg_ms = event_avg_ms(one_step, a.steps)
+    # the same step through the one-call entry point (kge_score_sp_po: query build inside the launch, cooperatively)
+    for _ in range(5):
+        engine.score_sp_po(T, s, p, o)
+    coop_ms = event_avg_ms(lambda: engine.score_sp_po(T, s, p, o), a.steps)
+    # the reference's contiguous [n, 2E] score layout
+    def contig_step():
+        step_no[0] += 1
+        pipe.step(next_batch=batches[step_no[0] & 1], out=out_contig)
+    for _ in range(5):
+        contig_step()
+    contig_ms = event_avg_ms(contig_step, a.steps)
     # isolated calls (event pair around every call; includes un-hidden launch latency)
     ev = []
     for k in range(min(a.steps, 50)):
         x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         x0.record()
-        engine.score_sp_po(T, s, p, o)
+        one_step()
         x1.record()
         ev.append((x0, x1))
     torch.cuda.synchronize()
@@ -366,14 +400,46 @@ def main():
     if not a.no_one_sided:
         # the same step as two one-sided launches (score_sp, then score_po), as TrainingJob1vsAll issues
         # them (north_star quotes its roofline target on score_sp) ...
+        out1 = torch.empty(n, PITCH, device=device)[:, :E_FB]
+        pipe1 = engine.ScorePipeline(T, "sp_", n)
+        pipe1.start(*batches[0])
+        k1 = [0]
+
+        def one_sp():  # score_sp of the current batch, the next batch's queries built in the same launch
+            k1[0] += 1
+            pipe1.step(next_batch=batches[k1[0] & 1], out=out1)
+        for _ in range(5):
+            one_sp()
+        one_ms = event_avg_ms(one_sp, a.steps)
+
         def one():
             engine.score_sp(T, s, p)
             engine.score_po(T, p, o)
-        one_ms = event_avg_ms(one, a.steps) / 2
+        one_coop_ms = event_avg_ms(one, a.steps) / 2
         ab1 = algorithmic_bytes(n, E_FB, DIM)
         extra["one_sided_launch"] = {"avg_launch_us": one_ms * 1e3, "algorithmic_bytes_per_launch": ab1,
                                      "achieved": ab1 / (one_ms * 1e-3) / 1e9,
-                                     "frac": ab1 / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                     "frac": ab1 / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "one_call_entry_us": one_coop_ms * 1e3,
+                                     "one_call_entry_frac": ab1 / (one_coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # split queries (KGE_FLAG_SPLIT_QUERY: q = q_hi + q_lo, f32-level parity on the bf16 tables -- the evaluation
+        # setting): the same pipelined step, twice the MFMA work per score
+        TS = engine.Tables("complex", ent, rel, flags=engine.FLAG_SPLIT_QUERY)
+        pipes = engine.ScorePipeline(TS, "sp_po", n, flags=engine.FLAG_SPLIT_QUERY)
+        pipes.start(*batches[0])
+        ks = [0]
+
+        def one_split():
+            ks[0] += 1
+            pipes.step(next_batch=batches[ks[0] & 1], out=out_buf)
+        for _ in range(5):
+            one_split()
+        sp_ms = event_avg_ms(one_split, max(10, a.steps // 2))
+        ab2 = algorithmic_bytes(n, E_FB, DIM, sides=2)
+        extra["split_query_step"] = {"avg_launch_us": sp_ms * 1e3, "algorithmic_bytes_per_launch": ab2,
+                                     "frac": ab2 / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "scored_triples_per_s": 2.0 * n * E_FB / (sp_ms * 1e-3)}
+        del TS, pipes, pipe1, out1
         # ... and at the other batch sizes SURVEY.md 8(d) lists (and beyond): the start-up of a launch
         # (index load -> row gather -> query build -> hand-off, ~8 us) is paid once per call, so the
         # per-launch fraction of the roofline grows with n
@@ -382,9 +448,13 @@ def main():
             q = torch.Generator().manual_seed(nn)
             s2 = torch.randint(E_FB, (nn,), generator=q).to(device)
             p2 = torch.randint(R_FB, (nn,), generator=q).to(device)
+            pn = engine.ScorePipeline(T, "sp_", nn)
+            pn.start(s2, p2, None)
+            outn = torch.empty(nn, PITCH, device=device)[:, :E_FB]
             for _ in range(3):
-                engine.score_sp(T, s2, p2)
-            ms = event_avg_ms(lambda: engine.score_sp(T, s2, p2), max(10, a.steps // 4))
+                pn.step(next_batch=(s2, p2, None), out=outn)
+            ms = event_avg_ms(lambda: pn.step(next_batch=(s2, p2, None), out=outn), max(10, a.steps // 4))
+            del pn, outn
             abn = algorithmic_bytes(nn, E_FB, DIM)
             by_n[str(nn)] = {"avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": abn,
                              "frac": abn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -429,14 +499,16 @@ def main():
         "config": {
             "workload": "FB15k-237 shape ComplEx d=512 1vsAll scoring, bf16 tables, f32 scores: the "
                         "score_sp and score_po blocks of the batch per step (KgeModel.score_sp_po, one "
-                        "two-sided launch)",
+                        "two-sided launch; the next batch's query vectors built inside the same launch; score "
+                        "rows on a 256-byte pitch)",
             "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n,
             "parallelism": "single GPU",
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "pairs_bf16_v4_kernel<ComplEx,d=512>, two-sided (one score_sp_po call = one launch: "
-                      "gather + cooperative query build + MFMA contraction + store of both score blocks)",
+            "kernel": "pairs_bf16_v4_kernel<ComplEx,d=512>, two-sided, prepared queries (kge_score_queries: one "
+                      "launch = MFMA contraction + store of both score blocks of batch k + gather and query build "
+                      "of batch k+1 on idle workgroups)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -444,6 +516,10 @@ def main():
             "algorithmic_bytes_per_launch": ab,
             "avg_launch_us": avg_ms * 1e3,
             "isolated_call_median_us": iso[len(iso) // 2] * 1e3,
+            "score_row_pitch_floats": 2 * PITCH, "block2_offset_floats": PITCH,
+            "contiguous_pitch": {"avg_launch_us": contig_ms * 1e3, "frac": ab / (contig_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "one_call_entry_us": coop_ms * 1e3,  # kge_score_sp_po: the query build inside the launch (cooperative)
+            "one_call_entry_frac": ab / (coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": pmc_traffic(),
             **extra,
         },

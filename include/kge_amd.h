@@ -112,12 +112,15 @@ typedef enum kge_flags {
                                  to one bf16 but carried as q_hi + q_lo (two bf16 pieces, two MFMA chains,
                                  one f32 add): products stay exact, only the f32 summation order differs from
                                  f32 arithmetic on the same bf16 tables (+ a 2^-17 relative residue of q for
-                                 ComplEx, none for DistMult) -- the precision class of KGE_FLAG_EXACT at about
-                                 half the speed of the single-pass kernel instead of a seventh.  Evaluation
+                                 ComplEx, none for DistMult): f32-level parity at about half the speed of the
+                                 single-pass kernel instead of the seventh the f32 kernels run at.  (KGE_FLAG_EXACT
+                                 is something else: the single-pass semantics -- q rounded to bf16 -- as an
+                                 order-specified f32 chain.)  Evaluation
                                  (rank parity with the reference: eval_entity_ranking.py:590-595 ties at
                                  rtol 1e-4) wants this; training does not.  Applies to kge_score_sp / _po /
                                  _sp_po / _emb / _emb_sp_po and the prepared-query entry points; shapes the
-                                 matrix-core kernel does not take run the exact f32 chain instead.            */
+                                 matrix-core kernel does not take run the f32 chain on the widened tables with
+                                 an unrounded query (bit-exact f32 arithmetic on the table values).            */
 } kge_flags;
 /* Bits 8..15 of `flags`: number of compute units the persistent bf16 scoring kernel leaves
  * free (it launches one workgroup per remaining CU), so that kernels on other streams -- the
@@ -201,7 +204,7 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o,
  * operand fragments of the n query vectors; with KGE_FLAG_SPLIT_QUERY the q_hi and q_lo pieces), valid for the
  * tables, flags, combine and n it was built with; the caller double-buffers (`next->queries` must differ from
  * `queries`).  combine: KGE_SP_ (s, p given; o ignored), KGE_PO_ (p, o given; s ignored) or KGE_SP_PO (all three;
- * out[i, :m] = sp scores, out[i, m:2m] = po scores, ldo >= 2m).  Scores are bit-identical to kge_score_sp / _po /
+ * out[i, :m] = sp scores, out[i, b2:b2+m] = po scores, b2 = block2_offset or m).  Scores are bit-identical to kge_score_sp / _po /
  * _sp_po on the same tables and flags.  bf16 ComplEx / DistMult, dim 256 / 512; otherwise KGE_ERR_UNSUPPORTED.
  * No workspace, no flags to zero, no co-residency requirement: capture-safe, any n. */
 typedef struct kge_next_queries {
@@ -213,8 +216,12 @@ typedef struct kge_next_queries {
 int64_t kge_queries_bytes(const kge_tables* t, int combine, int64_t n);
 int kge_build_queries(const kge_tables* t, int combine, kge_index s, kge_index p, kge_index o,
                       int64_t n, void* queries, int64_t queries_bytes, void* stream);
+/* block2_offset (KGE_SP_PO only): column at which the po block of a row starts, >= m and <= ldo - m; 0 = m
+ * (the reference's cat layout).  With ldo and block2_offset multiples of 8 floats on a 32-byte aligned `out`
+ * every store of the kernel covers whole 32-byte memory sectors (8 % per launch at the
+ * FB15k-237 shape, 28 % on a Wikidata5M shard). */
 int kge_score_queries(const kge_tables* t, int combine, const void* queries, int64_t n,
-                      kge_index targets, int64_t m, float* out, int64_t ldo,
+                      kge_index targets, int64_t m, float* out, int64_t ldo, int64_t block2_offset,
                       const kge_next_queries* next /* may be NULL */, void* stream);
 
 /* Negative-sampling scores, the "triple" implementation without building the

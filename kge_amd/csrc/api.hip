@@ -11,7 +11,7 @@ int run_spo(int scorer, int dtype, bool neg_mode, const Operand& S, const Operan
             long long ldo, hipStream_t st);
 int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, const Operand& R,
                     const Operand& TG, int dir, int d, int dr, long long n, long long m,
-                    float lp, float* out, long long ldo, hipStream_t st);
+                    float lp, float* out, long long ldo, hipStream_t st, bool round_query = true);
 bool pairs_bf16_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
                           const Operand& TG);
 int run_pairs_bf16(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
@@ -189,7 +189,8 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
   const int d = (int)t->dim, dr = (int)t->rel_dim;
   if ((t->flags & KGE_FLAG_SPLIT_QUERY) && !(t->flags & KGE_FLAG_EXACT) && t->dtype == KGE_BF16) {
     // q = q_hi + q_lo on the matrix cores (f32-level parity on the bf16 tables); what the loader/consumer kernel
-    // does not take runs the exact f32 chain below -- the same parity class, never the single-pass bf16 kernel
+    // does not take runs the exact f32 chain with the query vector kept in f32 (KGE_FLAG_EXACT rounds it to bf16:
+    // the bits of the single-pass semantics) -- f32 arithmetic on the table values, never a rounded query
     if (ws != nullptr && pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
       const int rc = run_pairs_bf16_v4_prepared(t->scorer, true, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st,
                                                 nullptr, nullptr, ws, ws_bytes,
@@ -198,7 +199,7 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
       if (rc != KGE_ERR_UNSUPPORTED) return rc;
     }
     return run_pairs_exact(t->scorer, t->dtype, !(t->flags & KGE_FLAG_NO_MFMA), A, R, TG, dir, d, dr, n, m,
-                           t->l_norm, out, ldo, st);
+                           t->l_norm, out, ldo, st, /*round_query=*/false);
   }
   if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, d, A, R, TG)) {
     const int rc = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr);
@@ -358,12 +359,15 @@ int kge_build_queries(const kge_tables* t, int combine, kge_index s, kge_index p
 }
 
 int kge_score_queries(const kge_tables* t, int combine, const void* queries, int64_t n, kge_index targets, int64_t m,
-                      float* out, int64_t ldo, const kge_next_queries* next, void* stream) {
+                      float* out, int64_t ldo, int64_t block2_offset, const kge_next_queries* next, void* stream) {
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
-  const int64_t width = combine == KGE_SP_PO ? 2 * m : m;
-  if (n < 0 || m < 0 || (!out && n * m > 0) || ldo < width || (n > 0 && !queries)) return KGE_ERR_INVALID_ARG;
+  const int64_t b2 = combine == KGE_SP_PO ? (block2_offset > 0 ? block2_offset : m) : 0;
+  const int64_t width = combine == KGE_SP_PO ? b2 + m : m;
+  if (n < 0 || m < 0 || (!out && n * m > 0) || ldo < width || b2 < 0 || (combine == KGE_SP_PO && b2 < m) ||
+      (n > 0 && !queries))
+    return KGE_ERR_INVALID_ARG;
   if ((rc = check_index(targets, true))) return rc;
   if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
   if (!queries_supported(t)) return KGE_ERR_UNSUPPORTED;
@@ -386,7 +390,7 @@ int kge_score_queries(const kge_tables* t, int combine, const void* queries, int
   }
   const Operand none{t->ent, t->ent_ld, Index{nullptr, 1, 1}};  // (never read: the queries are prepared)
   return run_pairs_bf16_v4_prepared(t->scorer, split, none, combine == KGE_SP_PO ? &none : nullptr, none, TG,
-                                    combine == KGE_PO_ ? KGE_PO_ : KGE_SP_, (int)t->dim, n, m, out, ldo, m,
+                                    combine == KGE_PO_ ? KGE_PO_ : KGE_SP_, (int)t->dim, n, m, out, ldo, b2,
                                     (hipStream_t)stream, nullptr, queries, nullptr, 0,
                                     (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, has_next ? &nA : nullptr,
                                     has_next && combine == KGE_SP_PO ? &nA2 : nullptr, has_next ? &nR : nullptr,

@@ -237,16 +237,18 @@ int run_pairs_f32(int scorer, int dtype, const Operand& A, const Operand& R, con
                   long long n, long long m, int round_q, float* out, long long ldo, hipStream_t st);
 
 // exact (canonical f32) pair scoring for every scorer / dtype / dimension
+// round_query = false (KGE_FLAG_SPLIT_QUERY's fallback): bf16 tables widened, the query vector kept in f32 --
+// f32 arithmetic on the bf16 table values, the bits of the oracle on the widened tables
 int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, const Operand& R,
                     const Operand& TG, int dir, int d, int dr, long long n, long long m,
-                    float lp, float* out, long long ldo, hipStream_t st) {
+                    float lp, float* out, long long ldo, hipStream_t st, bool round_query) {
   if (n == 0 || m == 0) return KGE_OK;
   const bool cplx = scorer == KGE_COMPLEX || scorer == KGE_ROTATE;
   if (cplx && (d % 2)) return KGE_ERR_INVALID_ARG;
   const bool vec = pairs_vec_ok(dtype, d, dr, scorer, A, R, TG);
   const int norm = norm_mode(lp);
   const int round_q =
-      (dtype == KGE_BF16 && (scorer == KGE_COMPLEX || scorer == KGE_DISTMULT)) ? 1 : 0;
+      (round_query && dtype == KGE_BF16 && (scorer == KGE_COMPLEX || scorer == KGE_DISTMULT)) ? 1 : 0;
   // ComplEx / DistMult on the f32 matrix cores: 128 x 128 tiles (score_pairs_f32.hip) unless the
   // batch is too small to fill them; same chain order, same bits
   if ((scorer == KGE_COMPLEX || scorer == KGE_DISTMULT) && use_mfma && vec && n > 64 && m > 64) {

@@ -58,7 +58,7 @@ __device__ __forceinline__ void v4_static_for(F&& f) {
 // waves do that on the accumulators right after a tile's MFMA chain, the DMA waves keep streaming,
 // the store waves have nothing to do (kge_ce_fwd / kge_ce_sp_po_fwd: the [n, E] matrix is never
 // written; per row and column group 8 bytes leave the kernel, merged by ce_combine_kernel).
-constexpr int V4_DEGRADED_LAUNCHES = 4096;
+constexpr int V4_DEGRADED_LAUNCHES = 4096;  // launches a timed-out hand-off is skipped for before it is tried again
 
 // ---- prepared queries (kge_build_queries / kge_score_queries, include/kge_amd.h) -------------------------------
 // The query vectors q_i = s_i (x) r_i of a batch in MFMA-fragment order, built OUTSIDE the scoring launch that
@@ -79,7 +79,11 @@ struct NextQ {
   long long n;       // rows per side
   int rgn, rgn1;     // row groups in all / of the first side
   u32x4* qf;         // destination; nullptr: nothing to build
-  int first, nblocks;  // workgroups [first, first + nblocks) of the launch build
+  // who builds: mode 1 -- the launch's idle workgroups: column-group slots beyond ncg, which sit on compute units of
+  // their own from the first cycle (nblocks of them, numbered rg * slots-per-row-group + slot); mode 2 (a geometry
+  // without idle slots, e.g. 16 row groups x 16 column groups) -- the consumer waves of EVERY scoring workgroup,
+  // behind their last tile, while the store waves drain (nblocks = scoring workgroups, 256 threads each)
+  int mode, nblocks;
 };
 
 template <int SCORER>
@@ -155,17 +159,18 @@ __device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item
 template <int SCORER, int HH, int SPLIT>
 __global__ __launch_bounds__(256) void query_build_kernel(NextQ nx) {
   v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
-}  // launches a timed-out hand-off is skipped for before it is tried again
+}
 
 // nbuild < 0: PREPARED queries -- qf already holds this launch's fragments (no builders, no flags, no polling, no
-// co-residency requirement).  nx.qf != NULL: workgroups [nx.first, nx.first + nx.nblocks) build the NEXT batch's
+// co-residency requirement).  nx.qf != NULL: idle workgroups of the launch (NextQ::mode) build the NEXT batch's
 // fragments into nx.qf instead of scoring (they take the compute units the launch geometry leaves idle).
 template <int SCORER, int HH, int TGMODE, int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     Operand A, Operand A2, Operand R, Operand TG, int dir, long long n, long long m, int rgn,
     int rgn1, long long out2_off, int ncg, int tiles_per_cg, int ntiles, float* __restrict__ out,
     long long ldo, unsigned long long* __restrict__ dbg, u32x4* __restrict__ qf,
-    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild, CeArgs ce, NextQ nx) {
+    unsigned long long* __restrict__ flags, unsigned long long epoch, int nbuild, CeArgs ce, NextQ nx,
+    int st_sc1) {
   static_assert(!SPLIT || EPI == V3_STORE, "split queries: score store path only");
   constexpr int RGR = SPLIT ? 64 : V4_ROWS;  // real query rows per row group
   constexpr int NKB = 2 * HH / 16;       // K-blocks of 16
@@ -189,11 +194,6 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   static_assert(NL * RPP == 16 && SPR >= 32, "d in {256, 512}");
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
-  if (nx.qf != nullptr && (int)blockIdx.x >= nx.first) {  // a spare workgroup: the next batch's query fragments
-    v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)((int)blockIdx.x - nx.first) * 512 + threadIdx.x,
-                                        (long long)nx.nblocks * 512);
-    return;
-  }
   const bool prebuilt = nbuild < 0;  // (uniform)
 
   // ---- which rows / target tiles
@@ -201,7 +201,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   const int q8 = b >> 3;
   const int rg = q8 % rgn;
   const int cg = (q8 / rgn) * 8 + (b & 7);
-  if (cg >= ncg) return;
+  if (cg >= ncg) {
+    if (nx.qf != nullptr && nx.mode == 1) {  // an idle workgroup: the next batch's query fragments
+      const int spg = ((ncg + 7) & ~7) - ncg;  // idle column-group slots per row group
+      v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)(rg * spg + (cg - ncg)) * 512 + threadIdx.x,
+                                          (long long)nx.nblocks * 512);
+    }
+    return;
+  }
   // Which 64-target tiles: tiles_per_cg > 0: the contiguous range [cg * tiles_per_cg, ...);
   // tiles_per_cg == 0: every ncg-th tile (cg, cg + ncg, ...) -- the workgroups then write
   // NEIGHBOURING 256-byte segments of the same score rows at about the same time, which is what the
@@ -234,39 +241,42 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     ++dbg_i;
   };
   stamp();  // 0: kernel start
+  auto stamp_at = [&](int slot) {  // loader-side stamps (slots 32..): lane 0 of the calling wave
+    if (dbg != nullptr && lane == 0) dbg[(long long)blockIdx.x * 64 + slot] = __builtin_readcyclecounter();
+  };
 
-  // ---- cooperative query build: this workgroup's share of the row group's rows
+  // ---- in-launch query build: one item = 8 coordinates of both halves of one query row, written fragment-major
+  // (K-block kb of 32-row block rb is 64 lanes x 16 B, contiguous) with agent-scope (sc1) write-through stores:
+  // visible to the other XCDs' L2s once acknowledged, without the whole-L2 write-back of a release fence.  A
+  // 128-byte line (8 rows x 16 B) is written by one workgroup only (or by several with the same bytes).
+  auto build_item = [&](int rr, int c8) __attribute__((always_inline)) {
+    const long long row = (long long)rg * V4_ROWS + rr;    // row of the fragment workspace
+    const long long lrow = (long long)rgl * V4_ROWS + rr;  // query row within its side
+    const long long qrow = lrow < n ? lrow : n - 1;        // padded rows repeat row n-1
+    const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + c8 * 8;
+    const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + c8 * 8;
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
+    const u32x4 r0 = *reinterpret_cast<const u32x4*>(r), r1 = *reinterpret_cast<const u32x4*>(r + HH);
+    u32x4 q0, q1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned int x0, x1;
+      bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+      q0[e] = x0;
+      q1[e] = x1;
+    }
+    u32x4* dst = qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
+    // s_nop 1: the two wait states a >64-bit VMEM store needs before its data registers may be
+    // overwritten -- the hazard recogniser cannot see into inline asm (found the hard way: an
+    // unrolled variant of this loop reused q0's registers for the next address and stored garbage)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (c8 >> 1) * 64), "v"(q0) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (NKH + (c8 >> 1)) * 64), "v"(q1)
+                 : "memory");
+  };
+  // cooperative: this workgroup's share of the row group's rows
   if (cg < nbuild) {
     constexpr int CGR = HH / 8;  // groups of 8 coordinates per row
-    for (int it = cg * 512 + tid; it < V4_ROWS * CGR; it += nbuild * 512) {
-      const long long row = (long long)rg * V4_ROWS + it / CGR;  // row of the fragment workspace
-      const long long lrow = (long long)rgl * V4_ROWS + it / CGR;  // query row within its side
-      const int c8 = it % CGR;
-      const long long qrow = lrow < n ? lrow : n - 1;  // padded rows repeat row n-1
-      const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + c8 * 8;
-      const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + c8 * 8;
-      const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
-      const u32x4 r0 = *reinterpret_cast<const u32x4*>(r), r1 = *reinterpret_cast<const u32x4*>(r + HH);
-      u32x4 q0, q1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        unsigned int x0, x1;
-        bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
-        q0[e] = x0;
-        q1[e] = x1;
-      }
-      // fragment-major: K-block kb of 32-row block rb is 64 lanes x 16 B, contiguous.  Agent-scope
-      // (sc1) write-through stores: visible to the other XCDs' L2s once acknowledged, without
-      // the whole-L2 write-back of a release fence.  A 128-byte line (8 rows x 16 B) is
-      // written by one workgroup only.
-      u32x4* dst = qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
-      // s_nop 1: the two wait states a >64-bit VMEM store needs before its data registers may be
-      // overwritten -- the hazard recogniser cannot see into inline asm (found the hard way: an
-      // unrolled variant of this loop reused q0's registers for the next address and stored garbage)
-      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (c8 >> 1) * 64), "v"(q0) : "memory");
-      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (NKH + (c8 >> 1)) * 64), "v"(q1)
-                   : "memory");
-    }
+    for (int it = cg * 512 + tid; it < V4_ROWS * CGR; it += nbuild * 512) build_item(it / CGR, it % CGR);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread: its stores are acknowledged ...
     __syncthreads();                                  // ... before wave 0 publishes
     // one flag per (consumer workgroup, builder): every consumer polls a 64-byte line of its own
@@ -297,9 +307,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     const int nfull = (int)(m / V4_TN);
     const int lr = lane / SPR, slot = lane % SPR;
     const int j2 = (wave & 1) * 2;  // this wave's quarters: j2, j2 + 1
-    if (wave < 6) {
-      // ------------------------------- DMA waves -------------------------------
-      unsigned int dvoff[NL], dsw[NL];
+    // (the tile DMA is shared by both kinds of loader waves during the ring fill, see below)
+    unsigned int dvoff[NL], dsw[NL];
 #pragma unroll
       for (int k = 0; k < NL; ++k) {
         dsw[k] = (unsigned int)(((slot ^ lr) << 4) ^ ((RPP * k) << 4));
@@ -346,54 +355,9 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
           }
         }
       };
-      {  // fill the ring: tiles 0 .. NBUF-1
-        long long ra[NBUF], rb[NBUF];
-#pragma unroll
-        for (int k = 0; k < NBUF; ++k) {
-          ra[k] = load_rows(k, j2);
-          rb[k] = load_rows(k, j2 + 1);
-        }
-#pragma unroll
-        for (int k = 0; k < NBUF; ++k) {
-          if (k < ntl) {
-            tile_dma(k, ra[k], j2);
-            tile_dma(k, rb[k], j2 + 1);
-          }
-        }
-      }
-      long long rna = load_rows(NBUF, j2), rnb = load_rows(NBUF, j2 + 1);
-      __builtin_amdgcn_s_barrier();  // B0
-      for (int tt = 0; tt <= ntl; ++tt) {
-        // VMEM queue of this wave: tile pieces (2 NL per tile), in order (index loads of the gathered-target modes
-        // only make a wait longer).  Tile tt has landed once at most the pieces of the tiles issued behind it are
-        // outstanding: min(ntl, NBUF) - 1 tiles at the start, then min(ntl - tt - 1, NBUF - 2).
-        int behind = tt == 0 ? (ntl < NBUF ? ntl : NBUF) - 1 : (ntl - tt - 1 < NBUF - 2 ? ntl - tt - 1 : NBUF - 2);
-        bool waited = false;
-        if constexpr (NBUF > 2) {  // (6 NL = 48 <= the counter's 63 at d = 256)
-          if (behind >= 3) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(6 * NL) : "memory");
-            waited = true;
-          } else if (behind == 2) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * NL) : "memory");
-            waited = true;
-          }
-        }
-        if (!waited) {
-          if (behind >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NL) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; the buffer of tile tt - 1 is free
-        if (tt >= 1 && tt - 1 + NBUF < ntl) {
-          tile_dma(tt - 1 + NBUF, rna, j2);
-          tile_dma(tt - 1 + NBUF, rnb, j2 + 1);
-          rna = load_rows(tt + NBUF, j2);
-          rnb = load_rows(tt + NBUF, j2 + 1);
-        }
-        __builtin_amdgcn_s_barrier();  // B2(tt)
-      }
-      return;
-    }
-    // ------------------------------- store waves -------------------------------
+    // ---- score path of the loader waves: staging buffer -> registers -> HBM.  Waves 6, 7 carry it tile by tile;
+    // waves 4, 5 (DMA) take over the LAST tile's stores, when they have nothing left to stream (see the end of
+    // their loop): each of 4 / 6 handles the blocks of consumers 0, 1, each of 5 / 7 those of consumers 2, 3.
     const int cl = lane & 15, rq = lane >> 4;
     const int z = cl ^ rq;
     // SPLIT: this wave owns ONE real 32-row block (wave & 1); its q_hi partial scores are consumer (wave & 1)'s
@@ -456,8 +420,22 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       for (int u = 0; u < NU; ++u) {
         if (col0 + V4_TN <= m) {
           unsigned char* sbase = out_rb[u] + col0 * 4;
+          if (st_sc1) {
+            // agent-scope write-through stores: the scores leave the L2 as they are written instead of sitting
+            // there dirty until the end-of-kernel write-back (a 30 MB score block fits the 32 MB of L2)
+            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, 0x7fffffff, 0x00020000);
+#define KGE_V4_ST(AUX)                                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                \
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cv[u][i]), srs, svoff[u][i], 0, AUX)
+            if (st_sc1 == 1) { KGE_V4_ST(16); }        // sc1
+            else if (st_sc1 == 2) { KGE_V4_ST(17); }   // sc0 sc1
+            else if (st_sc1 == 3) { KGE_V4_ST(18); }   // sc1 nt
+            else { KGE_V4_ST(2); }                     // nt
+#undef KGE_V4_ST
+          } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4v4u*>(sbase + svoff[u][i]) = cv[u][i];
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4v4u*>(sbase + svoff[u][i]) = cv[u][i];
+          }
         } else {  // ragged end of the table (always this workgroup's last tile)
 #pragma unroll
           for (int i = 0; i < 8; ++i)
@@ -468,19 +446,118 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
         }
       }
     };
-    __builtin_amdgcn_s_barrier();  // B0
+    // ---- ring fill.  A DMA piece costs its wave 60-180 cycles to issue (more while the consumers'
+    // fragment loads are in the same queue), nothing can be scored before tile 0 has landed, and with prepared
+    // queries the fill IS the start-up of the launch.  So: (i) only the first 64 KiB (FUP tiles) go out before the
+    // loop, the rest of the ring right behind B1(0) -- a whole MFMA chain ahead of its use --; (ii) tiles 0 and 1 are
+    // shared by all four loader waves (a DMA wave takes quarter j2, its store-wave partner, wave + 2, quarter
+    // j2 + 1: 16 instead of 32 pieces per wave in front of tile 0).  Measured (profiles/r3b): two waves issuing two
+    // tiles released tile 0 at 6.2 k cycles.
+    constexpr int FUP = NBUF / 2;
+    if (wave < 6) {
+      // ------------------------------- DMA waves -------------------------------
+      long long ra[NBUF], rb[NBUF];
+#pragma unroll
+      for (int k = 0; k < NBUF; ++k) {
+        ra[k] = load_rows(k, j2);
+        rb[k] = k >= 2 ? load_rows(k, j2 + 1) : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < FUP; ++k)
+        if (k < ntl) tile_dma(k, ra[k], j2);
+      long long rna = load_rows(NBUF, j2), rnb = load_rows(NBUF, j2 + 1);
+      if (wave == 4) stamp_at(32);  // first tiles issued
+      if (!prebuilt) __builtin_amdgcn_s_barrier();  // B0
+      for (int tt = 0; tt <= ntl; ++tt) {
+        // VMEM queue of this wave: tile pieces, in order (index loads of the gathered-target modes only make a wait
+        // longer): NL per tile for tiles 0 and 1 (the partner issued the other quarter), 2 NL from tile 2 on.  Tile
+        // tt has landed once at most the pieces of the tiles issued behind it are outstanding: at tt = 0 the rest of
+        // the first FUP tiles, later min(ntl - tt - 1, NBUF - 2) tiles of 2 NL.
+        const int behind = tt == 0 ? 0 : (ntl - tt - 1 < NBUF - 2 ? ntl - tt - 1 : NBUF - 2);
+        bool waited = false;
+        if (tt == 0 && FUP > 1 && ntl > 1) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL) : "memory");
+          waited = true;
+        }
+        if constexpr (NBUF > 2) {  // (6 NL = 48 <= the counter's 63 at d = 256)
+          if (!waited && behind >= 3) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(6 * NL) : "memory");
+            waited = true;
+          } else if (!waited && behind == 2) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * NL) : "memory");
+            waited = true;
+          }
+        }
+        if (!waited) {
+          if (behind >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * NL) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (tt == 0 && wave == 4) stamp_at(37);  // this wave's pieces of tile 0 have landed
+        __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; the buffer of tile tt - 1 is free
+        if (tt == 0) {  // the rest of the ring
+#pragma unroll
+          for (int k = FUP; k < NBUF; ++k) {
+            if (k < ntl) {
+              tile_dma(k, ra[k], j2);
+              if (k >= 2) tile_dma(k, rb[k], j2 + 1);
+            }
+          }
+        } else if (tt - 1 + NBUF < ntl) {
+          tile_dma(tt - 1 + NBUF, rna, j2);
+          tile_dma(tt - 1 + NBUF, rnb, j2 + 1);
+          rna = load_rows(tt + NBUF, j2);
+          rnb = load_rows(tt + NBUF, j2 + 1);
+        }
+        __builtin_amdgcn_s_barrier();  // B2(tt)
+      }
+      // B2(ntl) is behind: the last tile's scores are staged and this wave has nothing left to stream -- it stores
+      // them, while the store waves are still issuing the stores of the tile before (4.8 k -> 3.4 k cycles of tail)
+      if constexpr (STAGED) {
+        read_staging();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        store_tile(ntl - 1);
+      }
+      if (wave == 4) stamp_at(36);  // last tile's stores issued
+      return;
+    }
+    // ------------------------------- store waves -------------------------------
+    {  // ring fill, this wave's share: quarter j2 + 1 of the tiles < 2 among the first FUP
+      const long long h0 = load_rows(0, j2 + 1);
+      tile_dma(0, h0, j2 + 1);
+      if (FUP > 1 && ntl > 1) tile_dma(1, load_rows(1, j2 + 1), j2 + 1);
+    }
+    const long long h1 = load_rows(1, j2 + 1);
+    if (wave == 6) stamp_at(38);  // its share of the first tiles issued
+    if (!prebuilt) __builtin_amdgcn_s_barrier();  // B0
     for (int tt = 0; tt <= ntl; ++tt) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging reads of the previous step are in registers
+      // this wave's pieces of tiles 0 / 1 have landed (its first score stores are issued behind B1(2))
+      if (tt == 0) {
+        if (FUP > 1 && ntl > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (tt == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (tt == 0 && wave == 6) stamp_at(39);  // landed
       __builtin_amdgcn_s_barrier();  // B1(tt): the consumers may overwrite the staging buffer
+      if (tt == 0 && FUP == 1 && ntl > 1) tile_dma(1, h1, j2 + 1);  // its quarter of tile 1, with the rest of the ring
+      if (tt == ntl) {
+        // last round: nothing is staged behind this barrier pair for THIS wave (the DMA waves store the last tile)
+        __builtin_amdgcn_s_barrier();  // B2(ntl)
+        if constexpr (STAGED)
+          if (tt >= 2) store_tile(tt - 2);
+        break;
+      }
       if constexpr (STAGED)
         if (tt >= 2) store_tile(tt - 2);  // from registers, while the DMA waves issue tile tt+1
       __builtin_amdgcn_s_barrier();  // B2(tt): scores of tile tt-1 are staged
       if constexpr (STAGED)
         if (tt >= 1) read_staging();
     }
-    if constexpr (STAGED) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      store_tile(ntl - 1);
+    if (wave == 6) stamp_at(34);  // last store issued
+    if (wave == 6 && dbg != nullptr) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp_at(35);  // last store acknowledged
     }
     return;
   }
@@ -503,20 +580,26 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   // arrive asynchronously and places the vmcnt waits itself, in front of the first MFMA of tile 0
   // that needs each fragment (asm loads + asm waits are safe only while nothing
   // is moved between them).  Prepared queries (a previous launch wrote them) take the same loads.
-  auto load_fragments = [&]() __attribute__((always_inline)) {
-    const unsigned char* sb =
-        (const unsigned char*)(qf + ((long long)(rg * (V4_ROWS / 32) + w4) * NKB) * 64);  // uniform
-    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)sb, 0, NKB * 1024, 0x00020000);
-    v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+  // In two parts: the first FR0 K-blocks at once, the rest behind B1(0) -- with prepared queries every byte that is
+  // in the vector-memory queue in front of tile 0's last piece delays the first MFMA (128 KiB of fragments + 64 KiB
+  // of tile through a 64 B/clk path: tile 0 released at 5.7 k cycles with all 32 loads up front, profiles/r3c);
+  // FR0 K-blocks cover the first 2 FR0 MFMA slots, behind which the rest arrives.
+  constexpr int FR0 = 8;
+  const unsigned char* const frag_base =
+      (const unsigned char*)(qf + ((long long)(rg * (V4_ROWS / 32) + w4) * NKB) * 64);  // uniform
+  auto load_fragments = [&](auto lo, auto hi) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)frag_base, 0, NKB * 1024, 0x00020000);
+    v4_static_for<decltype(lo)::value, decltype(hi)::value>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
       afr[kb] = __builtin_bit_cast(
           bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16 + kb * 1024), 0, 16 /* sc1 */));
     });
   };
+  using FrLo = std::integral_constant<int, 0>;
+  using FrMid = std::integral_constant<int, FR0>;
   if (prebuilt) {
     // prepared queries: the fragment loads go out at once, next to the DMA of tiles 0 and 1
-    load_fragments();
-    __builtin_amdgcn_s_barrier();  // B0 (keeps the barrier count of the loader waves)
+    load_fragments(FrLo{}, FrMid{});  // (no B0: nobody publishes anything)
     stamp();  // 2
   } else {
     if (wave == 0) {
@@ -544,31 +627,20 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published (or given up on)
     stamp();  // 2: all shares of this row group published
     const bool coop = *reinterpret_cast<volatile int*>(sb_flag) != 0;
-    if (coop) {
-      load_fragments();
-    } else if constexpr (!SPLIT) {
-      // own build, straight into the MFMA operand registers: lane (fi, fh) holds coordinates
-      // 16 kb + 8 fh .. + 7 of query row fi for every K-block kb -- the same values, bit for bit
-      const long long lrow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
-      const long long qrow = lrow < n ? lrow : n - 1;
-      const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + fh * 8;
-      const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + fh * 8;
-      v4_static_for<0, NKH>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int kb = decltype(kc)::value;
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(a + kb * 16), a1 = *reinterpret_cast<const u32x4*>(a + HH + kb * 16);
-        const u32x4 r0 = *reinterpret_cast<const u32x4*>(r + kb * 16), r1 = *reinterpret_cast<const u32x4*>(r + HH + kb * 16);
-        u32x4 q0, q1;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          unsigned int x0, x1;
-          bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
-          q0[e] = x0;
-          q1[e] = x1;
-        }
-        afr[kb] = __builtin_bit_cast(bf16x8, q0);
-        afr[NKH + kb] = __builtin_bit_cast(bf16x8, q1);
-      });
+    if (!coop) {
+      // The builders did not show up (time-out, degraded workspace, KGE_V4_OWN_BUILD): this wave builds the
+      // fragments of its own 32 rows itself -- through the workspace, with the builders' code (same bytes, so it
+      // does not matter who else writes them) --, waits for the acknowledgement of its own stores and loads them
+      // like everybody else.  No cross-wave dependency, hence no barrier (the loader waves are parked at B1(0)).
+      // Slow (32 items per lane) and rare.  [Until round 3 this was a register-resident build: 64 live
+      // registers more than the MFMA loop needs, i.e. spills in the hot path.]
+      if constexpr (!SPLIT) {
+        constexpr int CGR = HH / 8;
+        for (int it = lane; it < 32 * CGR; it += 64) build_item(32 * w4 + it / CGR, it % CGR);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
+    load_fragments(FrLo{}, FrMid{});
   }
   // B fragment (K-block kb, half hf) of target row 32*hf + fi: 16-B slot s = s0(kb) + fh, stored
   // at slot s ^ (fi & 15): with s = 16*a + b the swizzle only touches b -> 8 address registers
@@ -802,7 +874,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   constexpr int PF = 8;
   // tile 0 is peeled off the loop: in straight-line code the compiler waits for fragment kb right in
   // front of its first MFMA (inside a loop it waits for all of them at the loop entry)
-  auto tile = [&](int tt) __attribute__((always_inline)) {
+  auto tile = [&](int tt, auto first) __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; staging drained
     __builtin_amdgcn_sched_barrier(0);
@@ -853,11 +925,17 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[q % PF], afr[q >> 1], acc0, 0, 0, 0);
       }
       if constexpr (q + PF < NQ) bread(bq[q % PF], std::integral_constant<int, q + PF>{});
+      // first tile: the K-blocks FR0.. of the query fragments are requested from inside the chain, one per MFMA
+      // slot (K-block FR0 + q in slot q, 2 (FR0 + q) - q >= 2 FR0 slots = 700 cycles ahead of its MFMA): issued in
+      // front of the chain they cost 1.7 k cycles of blocked issue (a vector-memory instruction holds its wave
+      // ~70 cycles while four waves share the 64 B/clk path), here each hides behind an MFMA (profiles/r3e)
+      if constexpr (decltype(first)::value && q < NKB - FR0)
+        load_fragments(std::integral_constant<int, FR0 + q>{}, std::integral_constant<int, FR0 + q + 1>{});
       if constexpr (RK_PIPE) rank_step(qc);
     });
     stamp();  // tile tt: MFMA chain issued
   };
-  tile(0);
+  tile(0, std::true_type{});
   if constexpr (EPI == V3_LSE) lse_tile(0);
   if constexpr (IS_DS) ds_tile(0);
   if constexpr (EPI == V3_RANK && !RK_PIPE) rank_tile(0);
@@ -867,7 +945,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       pv1 = acc1;
       pg[0] = pg[1] = pc[0] = pc[1] = 0u;
     }
-    tile(tt);
+    tile(tt, std::false_type{});
     if constexpr (EPI == V3_LSE) lse_tile(tt);
     if constexpr (IS_DS) ds_tile(tt);
     if constexpr (EPI == V3_RANK && !RK_PIPE) rank_tile(tt);
@@ -896,6 +974,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();  // B2(ntl)
+  if (nx.qf != nullptr && nx.mode == 2)  // no idle workgroups in this geometry: a slice of the next batch's queries
+    v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)(rg * ncg + cg) * 256 + tid, (long long)nx.nblocks * 256);
   if constexpr (EPI == V3_LSE) {
     // the two lanes of a row -> one (max, sum exp) per row and column group
     const float omax = __shfl_xor(rmax, 32, 64), osum = __shfl_xor(rsum, 32, 64);
@@ -1066,17 +1146,22 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
       if (own && own[0] == '1') nbuild = 0;
     }
   }
-  // the next batch's queries: built by workgroups appended to the grid -- they start on the compute units the
-  // geometry leaves idle (the column groups rarely fill all of them: 228 of 256 at the FB15k-237 shape) or that
-  // the first finished workgroups free.  Only a launch that does not spin on flags may exceed the CU count.
+  // the next batch's queries: built on the compute units the
+  // geometry leaves idle (the column groups rarely fill all of them: 228 of 256 at the FB15k-237 shape).
   NextQ nx = pp.next;
-  int nb = 0;
   if (nx.qf != nullptr) {
     if (!prepared || !v4_al16(nx.qf)) return KGE_ERR_INVALID_ARG;
-    const int spare = cu_all - rgn * ncg;
-    nb = spare < 8 ? 8 : (spare > 32 ? 32 : spare);
-    nx.first = grid;
-    nx.nblocks = nb;
+    // the idle column-group slots of the grid (8 * ceil(ncg / 8) - ncg per row group) are resident on compute
+    // units of their own from the first cycle: they build.  Fewer than four of them: every scoring workgroup's
+    // consumer waves take a slice behind their last tile instead.
+    const int spare = rgn * ((((ncg + 7) / 8) * 8) - ncg);
+    if (spare >= 4) {
+      nx.mode = 1;
+      nx.nblocks = spare;
+    } else {
+      nx.mode = 2;
+      nx.nblocks = rgn * ncg;
+    }
   }
   const Operand& AA2 = A2 ? *A2 : A;
   // interleaved tiles (tiles_per_cg = 0) once a launch's score block outgrows the Infinity Cache
@@ -1086,10 +1171,21 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   const bool interleave =
       il ? il[0] == '1' : ((double)n * (double)m * 4.0 * (A2 ? 2 : 1) > 192e6 && (ldo & 7) == 0);
   const int tpc_arg = interleave ? 0 : tpc;
+  // Score stores: plain (the lines stay dirty in the 32 MB of L2 until they are evicted or the end-of-kernel
+  // write-back flushes them: ~3 us behind a launch whose 30 MB score block fits) or agent-scope write-through (sc1:
+  // the bytes go to memory as they are stored, nothing is left to flush -- but a partial 32-byte sector is then a
+  // read-modify-write at the memory instead of a merge in L2).  Measured (tools/ab_probe.py, tools/big_m_probe.py,
+  // round 3): write-through wins whenever the rows are sector-aligned (FB15k-237 shape one-sided 13.9 -> 12.8 us,
+  // a 574,311-column Wikidata5M shard 394 -> 353 us) and for blocks that fit the L2 even when they are not (14.5 ->
+  // 14.0 us); it loses 7 % on a 1.2 GB slab with an unaligned pitch.  KGE_V4_STORE_SC1=0/1 forces either.
+  const char* sc1e = getenv("KGE_V4_STORE_SC1");
+  const bool st_aligned = (ldo & 7) == 0 && (out2_off & 7) == 0 && ((uintptr_t)out & 31) == 0;
+  const bool st_small = (double)n * (double)m * 4.0 * (A2 ? 2 : 1) <= 48e6;
+  const int st_sc1 = sc1e ? (sc1e[0] - '0') : ((st_aligned || st_small) ? 1 : 0);
 #define KGE_V4L(MODE)                                                                                  \
-  hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE, EPI, SPLIT>), dim3(grid + nb), dim3(512), 0, st, A, \
+  hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE, EPI, SPLIT>), dim3(grid), dim3(512), 0, st, A, \
                      AA2, R, TG, dir, n, m, rgn, rgn1, out2_off, ncg, tpc_arg, ntiles, out, ldo, dbg, qf, flags, \
-                     epoch, nbuild, ce, nx)
+                     epoch, nbuild, ce, nx, st_sc1)
   if (tgmode == 0) KGE_V4L(0);
   else if (tgmode == 1) KGE_V4L(1);
   else KGE_V4L(2);

@@ -304,6 +304,15 @@ def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None
     width = 2 * m if q.combine == "sp_po" else m
     if out is None:
         out = _empty((q.n, width), t.device)
+    # `out` may be any row-pitched view: [n, m] / [n, 2m] with stride (ldo, 1), or -- both blocks on their own
+    # aligned columns -- [n, 2, m] with stride (ldo, block2_offset, 1)
+    ldo, b2 = out.stride(0), 0
+    if out.dim() == 3:
+        if q.combine != "sp_po" or out.shape[1] != 2 or out.stride(2) != 1:
+            raise ValueError("kge_amd: score_queries: a 3-D `out` is [n, 2, m] for combine 'sp_po'")
+        b2 = out.stride(1)
+    if q.n == 1:
+        ldo = max(ldo, width if b2 == 0 else b2 + m)
     nxt = None
     if next_batch is not None:
         nkeep = []
@@ -316,7 +325,7 @@ def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None
     with _on_device(t.device):
         tc = t.c(q.flags)
         rc = _lib.lib().kge_score_queries(ctypes.byref(tc), _COMBINE[q.combine], q.buf.data_ptr(), q.n, ti, m,
-                                          out.data_ptr(), out.stride(0), ctypes.byref(nxt) if nxt is not None else None,
+                                          out.data_ptr(), ldo, b2, ctypes.byref(nxt) if nxt is not None else None,
                                           _stream_handle(t.device))
         if rc:
             _lib.check(rc, "kge_score_queries")

@@ -44,10 +44,12 @@ def main():
     g = torch.Generator().manual_seed(0)
     ent = torch.empty(E, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
     rel = torch.empty(R, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
-    for scorer in ("complex",):
+    for scorer, sc1 in (("complex", "1"), ("complex", "0")):
+        os.environ["KGE_V4_STORE_SC1"] = sc1
+        print(f"---- KGE_V4_STORE_SC1={sc1}")
         T = engine.Tables(scorer, ent, rel)
         TS = engine.Tables(scorer, ent, rel, flags=engine.FLAG_SPLIT_QUERY)
-        for n in (512, 128, 1024, 2048):
+        for n in ((512, 128, 1024, 2048) if sc1 == "0" else (512,)):
             q = torch.Generator().manual_seed(n)
             batches = [tuple(torch.randint(hi, (n,), generator=q).to(dev) for hi in (E, R, E)) for _ in range(2)]
             s, p, o = batches[0]
@@ -79,6 +81,7 @@ def main():
             res["coop_two_sided_frac"] = alg_bytes(n, E, D, 2) / (res["coop_two_sided_us"] * 1e-6) / 8e12
             print(json.dumps(res), flush=True)
             del out1, out2
+    os.environ.pop("KGE_V4_STORE_SC1", None)
     stamps(512)
 
 
@@ -111,8 +114,12 @@ def stamps(n):
             torch.cuda.synchronize()
             assert rc == 0, rc
         v = st.view(4096, 64).cpu()
-        v[:, 32:] = 0
         v = v[v[:, 0] != 0]
+        ld = (v[:, 32:40] - v[:, :1]).double().median(dim=0).values
+        print(f"  tile 0: wave 4 issued {float(ld[0]):.0f} landed {float(ld[5]):.0f}; wave 6 issued {float(ld[6]):.0f} landed {float(ld[7]):.0f}")
+        print(f"  loader side: first tiles issued {float(ld[0]):.0f}, store waves' last store issued {float(ld[2]):.0f}, "
+              f"acknowledged {float(ld[3]):.0f}, DMA waves' last-tile stores issued {float(ld[4]):.0f}")
+        v[:, 32:] = 0
         nst = int((v[0] != 0).sum())
         own = (v[:, :nst] - v[:, :1]).double()
         print(f"==== stamps, {name}, n={n}: {v.shape[0]} workgroups; median cycles since the workgroup's start")
