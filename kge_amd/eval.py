@@ -251,9 +251,11 @@ class EntityRankingEvaluator:
         all_ranks = {f"{d}{r}": [] for r in rankings for d in "so"}
         chunk = E if self.chunk_size < 0 else self.chunk_size
         triples = st["triples"]
+        # (split queries -- engine.FLAG_SPLIT_QUERY, the rank-parity setting of bf16 tables -- score in two steps: the
+        # counting epilogue works on ONE MFMA chain per score)
         fused = (self._fused and isinstance(tables, engine.Tables) and M <= 3 and tables.ent.dtype == torch.bfloat16
                  and tables.scorer in (engine.SCORERS["complex"], engine.SCORERS["distmult"])
-                 and tables.ent.shape[1] in (256, 512))
+                 and tables.ent.shape[1] in (256, 512) and not (tables.flags & engine.FLAG_SPLIT_QUERY))
 
         def do_batch(batch, rng, cnt, ro, rs):
             """One batch: filter ranges, counts (in place in `cnt`), tie policy + histogram; launches only."""

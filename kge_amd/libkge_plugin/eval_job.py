@@ -134,6 +134,16 @@ class HipEntityRankingJob(EntityRankingJob):
         if (os.environ.get("KGE_EVAL_TWO_STEP", "0") == "1" or M > 3 or fused_tables is None or fused_tables() is None
                 or fused_tables().ent.shape[1] not in (256, 512)):
             fused_tables = None
+        # hip_entity_ranking.bf16_queries (hip_entity_ranking.yaml): "split" (default) scores bf16 tables with split
+        # queries -- rank parity with float32 arithmetic on those tables -- through the two-step path; "single" takes
+        # the counting kernel (one rounded query vector per row)
+        try:
+            split = self.config.get("hip_entity_ranking.bf16_queries") != "single"
+        except KeyError:
+            split = True
+        split_tables = fused_tables if (split and fused_tables is not None) else None
+        if split_tables is not None:
+            fused_tables = None
 
         metrics = {}
         epoch_time = -time.time()
@@ -168,6 +178,10 @@ class HipEntityRankingJob(EntityRankingJob):
                 both = engine.score_sp_po(ft, s, p, o, torch.cat([o64, s64]))
                 o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
                 s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
+            elif chunk_size < E and split_tables is not None:
+                both = engine.score_sp_po(split_tables(), s, p, o, torch.cat([o64, s64]), flags=engine.FLAG_SPLIT_QUERY)
+                o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
+                s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
             elif chunk_size < E:
                 # the subset path of :192-203 without torch.unique: every row against the batch's
                 # own targets, diagonal kept (each score is its own kernel chain)
@@ -184,7 +198,10 @@ class HipEntityRankingJob(EntityRankingJob):
                         continue
                     ft = fused_tables = None  # declined: the two-step path from here on (o_true / s_true stay)
                 sub = None if c == E else torch.arange(chunk_start, chunk_end, device=dev)
-                scores = self.model.score_sp_po(s, p, o, sub)
+                if split_tables is not None:
+                    scores = engine.score_sp_po(split_tables(), s, p, o, sub, flags=engine.FLAG_SPLIT_QUERY)
+                else:
+                    scores = self.model.score_sp_po(s, p, o, sub)
                 scores_sp, scores_po = scores[:, :c], scores[:, c:]
                 if o_true is None:
                     o_true = scores_sp.gather(1, o64.view(-1, 1)).view(-1)
