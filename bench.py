@@ -220,6 +220,102 @@ def rank_legs(engine, device, n, steps):
     return out
 
 
+def neg_legs(engine, device, steps):
+    """BASELINE configs[2]: negative-sampling scores, WN18RR shape (E = 40,943, R = 11, d = 512; RotatE relations 256),
+    512 positives x 1,000 uniform negatives per slot (kge/util/sampler.py:291-306, 592-595), float32 tables:
+    kge_score_neg (the "triple" implementation without the [n K, 3] index tensor) -- one gathered entity row per
+    scored triple, HBM-gather bound.  Algorithmic bytes per launch: n K (d 4 + 4 + 8) + the fixed rows.
+    The 84 MB table sits in the 256 MB Infinity Cache, so the same launch is also measured on a table beyond it
+    (E = 2,000,000: 4.1 GB): THAT figure is an HBM figure.  `traffic` = FETCH_SIZE x 2 + WRITE_SIZE of the committed
+    rocprofv3 --pmc passes of tools/neg_pmc.py (profiles/pmc_neg_latest.json)."""
+    n, K, d = 512, 1000, 512
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "kernel": "neg_kernel<scorer> (kge_score_neg: fixed side in registers, corrupted rows stream)",
+           "batch": n, "num_negatives": K, "dim": d, "dtype": "f32"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_neg_latest.json")) as f:
+            pmc = json.load(f)
+    except Exception:
+        pmc = {}
+    for tag, E in (("wn18rr", 40943), ("beyond_infinity_cache", 2000000)):
+        g = torch.Generator(device=device).manual_seed(5)
+        ent = torch.empty(E, d, device=device).normal_(0, 0.1, generator=g)
+        q = torch.Generator().manual_seed(6)
+        s, o = (torch.randint(E, (n,), generator=q).to(device) for _ in range(2))
+        p = torch.randint(11, (n,), generator=q).to(device)
+        neg = torch.randint(E, (n, K), generator=q).to(device)
+        leg = {"num_entities": E, "table_bytes": E * d * 4}
+        for model in ("rotate", "transe"):
+            dr = d // 2 if model == "rotate" else d
+            rel = torch.empty(11, dr, device=device).uniform_(-3.14, 3.14, generator=g)
+            T = engine.Tables(model, ent, rel)
+            for _ in range(3):
+                engine.score_neg(T, s, p, o, 2, neg)
+            ms = event_avg_ms(lambda: engine.score_neg(T, s, p, o, 2, neg), steps)
+            ab = n * K * (d * 4 + 4 + 8) + n * (d + dr + d) * 4 + 3 * n * 8
+            leg[model] = {"avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": ab,
+                          "achieved": ab / (ms * 1e-3) / 1e9, "frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "scored_triples_per_s": n * K / (ms * 1e-3),
+                          "traffic": pmc.get(f"{tag}_{model}")}
+            del T, rel
+        out[tag] = leg
+        del ent, neg
+        torch.cuda.empty_cache()
+    return out
+
+
+def eval_leg(engine, device):
+    """BASELINE configs[3] on one GPU: one EntityRankingJob-equivalent pass (kge_amd.eval.EntityRankingEvaluator, the
+    mirror of eval_entity_ranking.py:103-481) at the FB15k-237 shape -- DistMult d = 512, 17,535 validation triples,
+    filters from a 272,115-triple Zipf train split + valid + test, raw / filtered / filtered-with-test rankings of
+    both directions, batch 512 -- in the three scoring settings: float32 tables (the reference's precision), bf16
+    tables with split queries (rank parity with float32 arithmetic on them) and bf16 tables with the counts taken
+    inside the scoring kernel.  Wall clock of the whole pass (second run: indexes and graphs built), per batch,
+    and the share of it the scoring (+ counting) kernels account for (their back-to-back HIP-event time per batch)."""
+    import numpy as np
+    from kge_amd import eval as kev
+    from kge_amd.synthetic import SHAPES, make_splits
+    E, R, ntr, nva, nte = SHAPES["fb15k-237"]
+    d, bs = 512, 512
+    splits = {k: v.astype(np.int64) for k, v in make_splits(E, R, ntr, nva, nte, seed=0).items()}
+    g = torch.Generator().manual_seed(0)
+    ent = torch.empty(E, d).normal_(0, 0.1, generator=g)
+    rel = torch.empty(R, d).normal_(0, 0.1, generator=g)
+    nb = (nva + bs - 1) // bs
+    q = torch.Generator().manual_seed(1)
+    s, p, o = (torch.randint(hi, (bs,), generator=q).to(device) for hi in (E, R, E))
+    out = {"model": "distmult", "num_entities": E, "dim": d, "triples": nva, "batch": bs, "batches": nb,
+           "rankings": ["raw", "filtered", "filtered_with_test"]}
+    for tag, e_, r_, flags in (("f32_tables", ent, rel, 0),
+                               ("bf16_split_queries", ent.bfloat16(), rel.bfloat16(), engine.FLAG_SPLIT_QUERY),
+                               ("bf16_counting_kernel", ent.bfloat16(), rel.bfloat16(), 0)):
+        T = engine.Tables("distmult", e_.to(device), r_.to(device), flags=flags)
+        ev = kev.EntityRankingEvaluator(T, splits, E, R, batch_size=bs)
+        ev.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m = ev.run()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        if tag == "bf16_counting_kernel":
+            t_sp = engine.score_sp(T, s, p, o).diagonal().contiguous()
+            t_po = engine.score_po(T, p, o, s).diagonal().contiguous()
+            cnt = torch.zeros(2, 2, 1, bs, dtype=torch.int64, device=device)
+            k_ms = event_avg_ms(lambda: engine.score_rank_sp_po(T, s, p, o, t_sp, t_po, [], [], 1e-5, 1e-4, cnt[0, 0],
+                                                                cnt[0, 1], cnt[1, 0], cnt[1, 1]), 50)
+        else:
+            for _ in range(3):
+                engine.score_sp_po(T, s, p, o)
+            k_ms = event_avg_ms(lambda: engine.score_sp_po(T, s, p, o), 50)
+        out[tag] = {"pass_ms": wall * 1e3, "ms_per_batch": wall * 1e3 / nb, "triples_per_s": nva / wall,
+                    "scored_triples_per_s": 2.0 * nva * E / wall, "scoring_kernel_ms_per_batch": k_ms,
+                    "scoring_kernel_share": k_ms * nb / (wall * 1e3), "graph_batches": ev.graph_batches,
+                    "mrr_filtered": m["mean_reciprocal_rank_filtered"]}
+        del T, ev
+        torch.cuda.empty_cache()
+    return out
+
+
 def sharded_workload(shape, world, rank, device, n, engine):
     """The rank's shard of the named shape + the replicated batch: (ShardedEntityTable, s, p, o, E, d)."""
     from kge_amd.sharded import ShardedEntityTable
@@ -473,9 +569,11 @@ def main():
                      "avg_launch_us": f_ms * 1e3, "flops_per_launch": 2.0 * n * DIM * E_FB,
                      "scored_triples_per_s": n * E_FB / (f_ms * 1e-3)}
         del T32
-        extra_rank = rank_legs(engine, device, n, max(10, a.steps // 4))
+        extra_rank = rank_legs(engine, device, n, max(10, min(a.steps, 400) // 4))
+        extra_neg = neg_legs(engine, device, max(10, min(a.steps, 400) // 8))
+        extra_eval = eval_leg(engine, device)
     else:
-        extra_f32 = extra_rank = None
+        extra_f32 = extra_rank = extra_neg = extra_eval = None
 
     total = 2.0 * n * E_FB * a.steps
     ab = algorithmic_bytes(n, E_FB, DIM, sides=2)
@@ -528,6 +626,10 @@ def main():
         out["roofline_f32"] = extra_f32
     if extra_rank is not None:
         out["roofline_rank"] = extra_rank
+    if extra_neg is not None:
+        out["roofline_neg"] = extra_neg
+    if extra_eval is not None:
+        out["roofline_eval"] = extra_eval
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
     print(json.dumps(out))
