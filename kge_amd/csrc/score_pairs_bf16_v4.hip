@@ -35,6 +35,7 @@
 // scores of tile t-1 are in staging; the store waves read them and issue the global stores after
 // B1(t+1).
 #include "common.hpp"
+#include "bf16_queries.hpp"
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -45,121 +46,12 @@ namespace kge {
 constexpr int V4_ROWS = 128, V4_TN = 64;
 typedef float f32x4v4u __attribute__((ext_vector_type(4), aligned(4)));
 
-template <int I, int N, class F>
-__device__ __forceinline__ void v4_static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    v4_static_for<I + 1, N>(f);
-  }
-}
-
 // EPI (common.hpp): V3_STORE writes the score tiles; V3_LSE folds them into the per-row running
 // (max, sum exp) of the 1vsAll cross entropy and picks out the label's score instead -- the consumer
 // waves do that on the accumulators right after a tile's MFMA chain, the DMA waves keep streaming,
 // the store waves have nothing to do (kge_ce_fwd / kge_ce_sp_po_fwd: the [n, E] matrix is never
 // written; per row and column group 8 bytes leave the kernel, merged by ce_combine_kernel).
 constexpr int V4_DEGRADED_LAUNCHES = 4096;  // launches a timed-out hand-off is skipped for before it is tried again
-
-// ---- prepared queries (kge_build_queries / kge_score_queries, include/kge_amd.h) -------------------------------
-// The query vectors q_i = s_i (x) r_i of a batch in MFMA-fragment order, built OUTSIDE the scoring launch that
-// consumes them: by query_build_kernel, or by the spare workgroups of the PREVIOUS batch's scoring launch
-// (NextQ).  The scoring kernel then starts with the fragment loads and the tile DMA -- the five dependent round
-// trips of the in-launch cooperative build (index -> rows -> write-through ack -> flag -> fragments, ~12 k cycles
-// during which nothing is scored, profiles/r12_phase_timestamps.txt) are off its critical path.
-//
-// SPLIT (KGE_FLAG_SPLIT_QUERY): q is carried as q_hi + q_lo, q_hi = bf16(q), q_lo = bf16(q - q_hi), as two
-// VIRTUAL query rows; a row group is 64 real rows = 128 virtual rows (32-row blocks 0, 1: q_hi of real rows
-// 0-31 / 32-63, blocks 2, 3: q_lo), the consumer waves are unchanged, the store waves add the two partial
-// scores.  Products of bf16 values are exact in f32, so score = fl(sum q_hi t) + fl(sum q_lo t) differs from
-// f32 arithmetic on the same bf16 tables only by f32 summation order and the 2^-17 relative residue of
-// q - q_hi - q_lo (exactly 0 for DistMult, whose q has 16 significant bits) -- SURVEY.md 8(c) gate 4.
-struct NextQ {
-  Operand A, A2, R;  // entity rows of the first side, of the second side (two-sided), relation rows
-  int dir;           // combine of the first side (KGE_SP_ / KGE_PO_); a second side is always KGE_PO_
-  long long n;       // rows per side
-  int rgn, rgn1;     // row groups in all / of the first side
-  u32x4* qf;         // destination; nullptr: nothing to build
-  // who builds: mode 1 -- the launch's idle workgroups: column-group slots beyond ncg, which sit on compute units of
-  // their own from the first cycle (nblocks of them, numbered rg * slots-per-row-group + slot); mode 2 (a geometry
-  // without idle slots, e.g. 16 row groups x 16 column groups) -- the consumer waves of EVERY scoring workgroup,
-  // behind their last tile, while the store waves drain (nblocks = scoring workgroups, 256 threads each)
-  int mode, nblocks;
-};
-
-template <int SCORER>
-__device__ __forceinline__ void v4_q_f32(int dir, unsigned int a0, unsigned int a1, unsigned int r0, unsigned int r1,
-                                         f32x2q& Q0, f32x2q& Q1) {
-  const f32x2q A0 = {__uint_as_float(a0 << 16), __uint_as_float(a0 & 0xffff0000u)};
-  const f32x2q A1 = {__uint_as_float(a1 << 16), __uint_as_float(a1 & 0xffff0000u)};
-  const f32x2q R0 = {__uint_as_float(r0 << 16), __uint_as_float(r0 & 0xffff0000u)};
-  const f32x2q R1 = {__uint_as_float(r1 << 16), __uint_as_float(r1 & 0xffff0000u)};
-  if (SCORER == KGE_DISTMULT) {
-    Q0 = A0 * R0;
-    Q1 = A1 * R1;
-  } else if (dir == KGE_SP_) {  // (bf16 x bf16 products are exact in f32: the fma IS the two-rounding form)
-    Q0 = __builtin_elementwise_fma(A0, R0, -(A1 * R1));
-    Q1 = __builtin_elementwise_fma(A1, R0, A0 * R1);
-  } else {
-    Q0 = __builtin_elementwise_fma(R0, A0, R1 * A1);
-    Q1 = __builtin_elementwise_fma(R0, A1, -(R1 * A0));
-  }
-}
-
-// items [item0, item0 + stride, ...) of the batch: one item = 8 coordinates of both halves of one query row
-template <int SCORER, int HH, int SPLIT>
-__device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item0, long long stride) {
-  constexpr int NKB = 2 * HH / 16, NKH = HH / 16, CGR = HH / 8;
-  constexpr int RGR = SPLIT ? 64 : 128;  // real rows per row group
-  const long long items = (long long)nx.rgn * RGR * CGR;
-  for (long long it = item0; it < items; it += stride) {
-    const int rg = (int)(it / (RGR * CGR));
-    const int rr = (int)((it / CGR) % RGR);
-    const int c8 = (int)(it % CGR);
-    const bool second = rg >= nx.rgn1;
-    const long long lrow = (long long)(second ? rg - nx.rgn1 : rg) * RGR + rr;
-    const long long qrow = lrow < nx.n ? lrow : nx.n - 1;  // padded rows repeat row n-1
-    const Operand& E = second ? nx.A2 : nx.A;
-    const int dir = second ? KGE_PO_ : nx.dir;
-    const unsigned short* a = (const unsigned short*)E.base + index_at(E.idx, qrow) * E.ld + c8 * 8;
-    const unsigned short* r = (const unsigned short*)nx.R.base + index_at(nx.R.idx, qrow) * nx.R.ld + c8 * 8;
-    const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
-    const u32x4 r0 = *reinterpret_cast<const u32x4*>(r), r1 = *reinterpret_cast<const u32x4*>(r + HH);
-    u32x4 q0, q1, l0, l1;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if constexpr (SPLIT) {
-        f32x2q Q0, Q1;
-        v4_q_f32<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], Q0, Q1);
-        q0[e] = bf16_pack_hw(Q0);
-        q1[e] = bf16_pack_hw(Q1);
-        const f32x2q H0 = {__uint_as_float(q0[e] << 16), __uint_as_float(q0[e] & 0xffff0000u)};
-        const f32x2q H1 = {__uint_as_float(q1[e] << 16), __uint_as_float(q1[e] & 0xffff0000u)};
-        l0[e] = bf16_pack_hw(Q0 - H0);  // exact differences (Sterbenz-like: |q - q_hi| <= ulp_bf16(q) / 2)
-        l1[e] = bf16_pack_hw(Q1 - H1);
-      } else {
-        unsigned int x0, x1;
-        bf16_qpair_fast<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
-        q0[e] = x0;
-        q1[e] = x1;
-      }
-    }
-    // fragment-major (as the in-launch build below): K-block kb of 32-row block rb is 64 lanes x 16 B
-    const long long row = (long long)rg * 128 + rr;  // virtual row (SPLIT: the q_hi row; q_lo 64 rows behind)
-    u32x4* dst = nx.qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
-    dst[(c8 >> 1) * 64] = q0;
-    dst[(NKH + (c8 >> 1)) * 64] = q1;
-    if constexpr (SPLIT) {
-      u32x4* dl = dst + 2 * NKB * 64;  // two 32-row blocks further
-      dl[(c8 >> 1) * 64] = l0;
-      dl[(NKH + (c8 >> 1)) * 64] = l1;
-    }
-  }
-}
-
-template <int SCORER, int HH, int SPLIT>
-__global__ __launch_bounds__(256) void query_build_kernel(NextQ nx) {
-  v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
-}
 
 // nbuild < 0: PREPARED queries -- qf already holds this launch's fragments (no builders, no flags, no polling, no
 // co-residency requirement).  nx.qf != NULL: idle workgroups of the launch (NextQ::mode) build the NEXT batch's
@@ -1015,6 +907,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   }
 }
 
+int run_pairs_bf16_v6(int scorer, bool split, const Operand& TG, bool two_sided, int d, long long n, long long m,
+                      float* out, long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
+                      const void* qf, const NextQ& nx, int reserve_cus);
+
 static inline bool v4_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 static std::atomic<unsigned long long> g_v4_epoch{0};
@@ -1144,6 +1040,16 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
       // the path a consumer otherwise only takes after a time-out or on a degraded workspace
       const char* own = getenv("KGE_V4_OWN_BUILD");
       if (own && own[0] == '1') nbuild = 0;
+    }
+  }
+  // d = 512, prepared queries, score store, all entities (or a contiguous slice): the unit-pipelined kernel
+  // (score_pairs_bf16_v6.hip) -- same bits, first store ~4 k instead of ~12 k cycles into the launch
+  if constexpr (EPI == V3_STORE && HH == 256) {
+    if (prepared && tgmode == 0) {
+      if (pp.next.qf != nullptr && !v4_al16(pp.next.qf)) return KGE_ERR_INVALID_ARG;
+      const int rc = run_pairs_bf16_v6(SCORER, SPLIT != 0, TG, A2 != nullptr, 2 * HH, n, m, out, ldo, out2_off, st, dbg,
+                                       qf, pp.next, reserve_cus);
+      if (rc != KGE_ERR_UNSUPPORTED) return rc;
     }
   }
   // the next batch's queries: built on the compute units the

@@ -1,0 +1,429 @@
+// score_pairs_bf16_v6.hip -- ComplEx / DistMult sp_/_po scores of bf16 tables at d = 512 from PREPARED query
+// fragments (kge_score_queries, and the one-call entry points behind a query_build_kernel launch): the store
+// path of the BASELINE.json headline configuration.
+//
+// Why a second kernel next to pairs_bf16_v4_kernel.  With prepared queries the v4 launch at the FB15k-237 shape is
+// bounded by its WRITE stream, not by its matrix pipe (profiles/r3_phase_timestamps.txt): the 29.8 MB score block
+// of a one-sided batch leaves the chip at ~4.7 TB/s (16 stores of 1 KiB per store wave and 64-target tile take
+// ~3.4 k cycles to issue, whatever they wait for; torch.fill_ of the same block: 4.5 TB/s), and the launch takes
+//     launch gap + (time until the FIRST store is issued) + bytes written / write rate + acknowledgement.
+// In v4 the first store goes out 12.3 k cycles after the workgroup starts -- a 64-target tile of LDS-DMA
+// (3.8 k), the first MFMA chain with the query-fragment loads in it (4.5 k), then the staging of tile t at the
+// start of chain t + 1, barrier B2 three quarters into that chain and the store after B1(t + 2): a lag of 1 1/4
+// chains -- i.e. nothing is written during half of the kernel.  This kernel is built around that number:
+//
+//   * the unit of work is 32 targets x 128 query rows (32 KiB of table, 16 KiB of scores): the first unit lands
+//     after 32 DMA pieces instead of 64 and is scored by 32 MFMAs per consumer wave instead of 64;
+//   * the LDS holds a ring of FOUR units (128 KiB) and TWO staging buffers (2 x 16 KiB): a consumer wave writes the
+//     unit it has just finished to staging[u & 1] at once, and ONE workgroup barrier R(u + 1) hands it to the store
+//     waves, which read it and issue its stores right behind that barrier -- chain end to first store ~0.4 k
+//     cycles -- while the consumers score unit u + 1 and stage it into the OTHER buffer;
+//   * one barrier per unit (v4: two per tile = the same rate); what R(k) guarantees:
+//       (a) unit k has landed in ring buffer k % 4           (the DMA waves waited for their pieces),
+//       (b) the scores of unit k - 1 are in staging[(k - 1) & 1]   (the consumers wrote them and waited),
+//       (c) the store waves have read staging[k & 1] (unit k - 2)  (they did so right after R(k - 1)),
+//       (d) the consumers are done with ring buffer (k - 1) % 4    (the DMA waves refill it with unit k + 3).
+//
+// Roles as in v4 (one consumer and one loader wave per SIMD): consumer waves 0-3 keep the query fragments of their
+// 32 rows in 128 operand registers and issue ds_read_b128 + v_mfma_f32_32x32x16_bf16, one accumulation chain per
+// score in K order -- the bits of v4 / v3 / v5 and of the oracle's bf16 mode; DMA waves 4, 5 stream the table with
+// LDS-DMA (XOR swizzle on the source address); store waves 6, 7 move staged scores to HBM, 8 rows x 128 bytes per
+// instruction.  The ring fill (units 0, 1) and the last unit's stores are shared by all four loader waves.
+//
+// Not handled here (the launcher falls back to v4): target index lists, d = 256, the fused-loss / counting
+// epilogues, the in-launch cooperative query build.
+#include "common.hpp"
+#include "bf16_queries.hpp"
+#include <atomic>
+#include <cstdlib>
+
+namespace kge {
+
+constexpr int V6_ROWS = 128, V6_UT = 32;
+typedef float f32x4v6u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int SCORER, int SPLIT>
+__global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
+    Operand TG, long long n, long long m, int rgn, int rgn1, long long out2_off, int ncg, int units_per_cg,
+    int nunits, float* __restrict__ out, long long ldo, unsigned long long* __restrict__ dbg,
+    const u32x4* __restrict__ qf, NextQ nx, int st_sc1) {
+  constexpr int HH = 256;
+  constexpr int RGR = SPLIT ? 64 : V6_ROWS;  // real query rows per row group
+  constexpr int NKB = 2 * HH / 16;           // 32 K-blocks of 16
+  constexpr int ROWB = 4 * HH;               // 1 KiB per table row = one DMA piece
+  constexpr int UNITB = V6_UT * ROWB;        // 32 KiB
+  constexpr int NBUF = 4;
+  constexpr int STG0 = NBUF * UNITB;         // staging: 2 x 4 blocks x [32 rows][32 cols] f32
+  constexpr int STGW = 32 * V6_UT * 4;       // one consumer's block: 4 KiB
+  constexpr int STGB = 4 * STGW;
+  constexpr int SMEM = STG0 + 2 * STGB;      // 160 KiB
+  constexpr int FR0 = 16;                    // query K-blocks requested before the first chain
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+  const int b = blockIdx.x;
+  const int q8 = b >> 3;
+  const int rg = q8 % rgn;
+  const int cg = (q8 / rgn) * 8 + (b & 7);  // workgroup b runs on XCD b % 8: a column range stays in one L2
+  if (cg >= ncg) {
+    if (nx.qf != nullptr && nx.mode == 1) {  // an idle workgroup: the next batch's query fragments
+      const int spg = ((ncg + 7) & ~7) - ncg;
+      v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)(rg * spg + (cg - ncg)) * 512 + threadIdx.x,
+                                          (long long)nx.nblocks * 512);
+    }
+    return;
+  }
+  // units_per_cg > 0: the contiguous range [cg * units_per_cg, ...); 0: every ncg-th unit (score blocks beyond the
+  // Infinity Cache with a sector-aligned pitch, see launch_v4)
+  const int unit_lo = units_per_cg > 0 ? cg * units_per_cg : cg;
+  const int unit_st = units_per_cg > 0 ? 1 : ncg;
+  int NU = units_per_cg > 0 ? nunits - unit_lo : (nunits - cg + ncg - 1) / ncg;
+  if (units_per_cg > 0 && NU > units_per_cg) NU = units_per_cg;
+  if (NU <= 0) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool second = rg >= rgn1;  // two-sided launch: row groups [rgn1, rgn) are the (?, p, o) queries
+  const int rgl = second ? rg - rgn1 : rg;
+  if (second) out += out2_off;
+
+  int dbg_i = 0;
+  auto stamp = [&]() {  // optional per-phase timestamps (tools/prep_probe.py); dbg == NULL in production
+    if (dbg != nullptr && tid == 0 && dbg_i < 32) dbg[(long long)blockIdx.x * 64 + dbg_i] = __builtin_readcyclecounter();
+    ++dbg_i;
+  };
+  auto stamp_at = [&](int slot) {
+    if (dbg != nullptr && lane == 0) dbg[(long long)blockIdx.x * 64 + slot] = __builtin_readcyclecounter();
+  };
+  stamp();  // 0: start
+
+  if (wave >= 4) {
+    // =============================== loader waves ===============================
+    const unsigned char* const tgb = (const unsigned char*)TG.base;
+    const long long tld2 = TG.ld * 2;
+    const unsigned int lane16 = (unsigned int)lane << 4;
+    // rows [r0, r0 + CNT) of unit uu -> ring buffer uu % 4: one 1-KiB piece per row, lane l fetching the row's 16-byte
+    // slot l ^ (row & 15) into slot l (the consumers read slot s of row fi at s ^ (fi & 15): conflict-free).  Rows
+    // beyond the table repeat its last row (their scores are never stored).
+    auto dma_rows = [&](int uu, int r0, auto cnt) __attribute__((always_inline)) {
+      const long long row0 = (long long)(unit_lo + uu * unit_st) * V6_UT + r0;
+      const unsigned int d0 = (unsigned int)((uu & (NBUF - 1)) * UNITB + r0 * ROWB);
+      const unsigned int x0 = (unsigned int)(r0 & 15) << 4;
+      v4_static_for<0, decltype(cnt)::value>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        long long r = row0 + k;
+        if (r >= m) r = m - 1;
+        const unsigned char* p = tgb + r * tld2;
+        const unsigned int vo = lane16 ^ (x0 + (k << 4));
+        const unsigned int dk = d0 + k * ROWB;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :
+                     : "s"(dk), "v"(vo), "s"(p)
+                     : "memory", "m0");
+      });
+    };
+    using C8 = std::integral_constant<int, 8>;
+    using C16 = std::integral_constant<int, 16>;
+
+    // ---- score path: staging -> registers -> HBM.  Lane (rq = lane >> 3, cl = lane & 7) moves columns 4 cl .. 4 cl + 3
+    // of rows 8 i + rq of a consumer's [32][32] block: an instruction writes 8 rows x 128 contiguous bytes.
+    const int cl = lane & 7, rq = lane >> 3;
+    f32x4 cv[2][4];
+    unsigned int svoff[2][4];
+    unsigned char* out_rb[2];
+    // which consumers' blocks this wave stores, per unit (store waves: two each; SPLIT: one REAL block = the sum of
+    // the q_hi block (wave & 1) and the q_lo block (wave & 1) + 2) and for the last unit (all four loader waves: one)
+    auto setup_blocks = [&](int w0, int nb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u < nb) {
+          const int w = w0 + u;
+          const long long r0 = (long long)rgl * RGR + 32 * w;
+          const long long rb = r0 < n ? r0 : n - 1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            long long r = r0 + 8 * i + rq;
+            if (r >= n) r = n - 1;  // padded rows repeat row n - 1 (as their query fragments do): same bytes
+            svoff[u][i] = (unsigned int)((r - rb) * ldo * 4) + (unsigned int)(cl * 16);
+          }
+          out_rb[u] = (unsigned char*)(out + rb * ldo);
+        }
+      }
+    };
+    auto read_block = [&](int sb, int w, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+      const unsigned int a = (unsigned int)(STG0 + sb * STGB + w * STGW + rq * 128 + ((cl ^ rq) << 4));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const f32x4*>(smem + a + i * 1024);
+    };
+    auto store_block = [&](int uu, int u) __attribute__((always_inline)) {
+      const long long col0 = (long long)(unit_lo + uu * unit_st) * V6_UT;
+      if (col0 + V6_UT <= m) {
+        unsigned char* sbase = out_rb[u] + col0 * 4;
+        if (st_sc1) {
+          // agent-scope write-through: the scores leave the L2 as they are written (launch_v4's measurements)
+          const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, cv[u][i]), srs, svoff[u][i], 0, 16);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4v6u*>(sbase + svoff[u][i]) = cv[u][i];
+        }
+      } else {  // ragged end of the table (the last unit of the last column group)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col0 + 4 * cl + e < m)
+              *reinterpret_cast<float*>(out_rb[u] + (col0 + e) * 4 + svoff[u][i]) = cv[u][i][e];
+      }
+    };
+    // the last unit: one block per loader wave (SPLIT: the two real blocks go to waves 6, 7)
+    auto last_unit = [&]() __attribute__((always_inline)) {
+      const int sb = (NU - 1) & 1;
+      if constexpr (SPLIT) {
+        if (wave < 6) return;
+        setup_blocks(wave & 1, 1);
+        read_block(sb, wave & 1, cv[0]);
+        read_block(sb, (wave & 1) + 2, cv[1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cv[0][i] = cv[0][i] + cv[1][i];
+        store_block(NU - 1, 0);
+      } else {
+        setup_blocks(wave - 4, 1);
+        read_block(sb, wave - 4, cv[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        store_block(NU - 1, 0);
+      }
+    };
+
+    const int l4 = wave - 4;  // ring fill: this wave's eight rows of units 0 and 1
+    dma_rows(0, 8 * l4, C8{});
+    if (NU > 1) dma_rows(1, 8 * l4, C8{});
+
+    if (wave < 6) {
+      // ------------------------------- DMA waves -------------------------------
+      const int r16 = 16 * (wave & 1);
+      if (wave == 4) stamp_at(32);  // first units issued
+      for (int k = 0; k <= NU; ++k) {
+        // this wave's VMEM queue, in order: u0 (8), u1 (8) | behind R(0): u2 (16), u3 (16) | behind R(k): u(k+3) (16).
+        // Unit k has landed once only the pieces issued behind it are outstanding.
+        if (k < NU) {
+          if (k == 0) {
+            if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          } else {
+            const int behind = NU - 1 - k < 2 ? NU - 1 - k : 2;
+            if (behind == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+        }
+        if (k == 0 && wave == 4) stamp_at(37);  // unit 0: this wave's pieces have landed
+        __builtin_amdgcn_s_barrier();  // R(k)
+        if (k == 0) {
+          if (NU > 2) dma_rows(2, r16, C16{});
+          if (NU > 3) dma_rows(3, r16, C16{});
+        } else if (k + 3 < NU) {
+          dma_rows(k + 3, r16, C16{});  // into the buffer of unit k - 1
+        }
+      }
+      if (NU >= 1) last_unit();
+      if (wave == 4) stamp_at(36);  // last unit's stores issued
+      return;
+    }
+    // ------------------------------- store waves -------------------------------
+    if (wave == 6) stamp_at(38);
+    setup_blocks(SPLIT ? (wave & 1) : 2 * (wave & 1), SPLIT ? 1 : 2);
+    if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 6) stamp_at(39);
+    __builtin_amdgcn_s_barrier();  // R(0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its rows of unit 1 (no store has been issued yet)
+    if (NU >= 1) __builtin_amdgcn_s_barrier();  // R(1)
+    for (int k = 1; k < NU; ++k) {
+      // behind R(k): unit k - 1 is staged in staging[(k - 1) & 1]
+      const int sb = (k - 1) & 1;
+      if constexpr (SPLIT) {
+        read_block(sb, wave & 1, cv[0]);
+        read_block(sb, (wave & 1) + 2, cv[1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cv[0][i] = cv[0][i] + cv[1][i];  // score = (sum q_hi t) + (sum q_lo t)
+        store_block(k - 1, 0);
+      } else {
+        read_block(sb, 2 * (wave & 1), cv[0]);
+        read_block(sb, 2 * (wave & 1) + 1, cv[1]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        store_block(k - 1, 0);
+        store_block(k - 1, 1);
+      }
+      if (k == 1 && wave == 6) stamp_at(33);  // first stores issued
+      __builtin_amdgcn_s_barrier();  // R(k + 1)
+    }
+    last_unit();
+    if (wave == 6) stamp_at(34);  // last store issued
+    if (wave == 6 && dbg != nullptr) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp_at(35);  // acknowledged
+    }
+    return;
+  }
+
+  // =================================== consumer waves ===================================
+  const int w4 = wave;
+  const int fi = lane & 31, fh = lane >> 5;
+  bf16x8 afr[NKB];
+  // the query fragments of this wave's 32 rows: K-block kb = 64 lanes x 16 B, written by a previous launch (or by
+  // query_build_kernel): agent-scope loads (served by L2).  Compiler-visible, so that the vmcnt waits are placed
+  // in front of the first MFMA that needs each fragment (straight-line code: the first unit is peeled).
+  const unsigned char* const frag_base = (const unsigned char*)(qf + ((long long)(rg * (V6_ROWS / 32) + w4) * NKB) * 64);
+  auto load_fragments = [&](auto lo, auto hi) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)frag_base, 0, NKB * 1024, 0x00020000);
+    v4_static_for<decltype(lo)::value, decltype(hi)::value>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      afr[kb] = __builtin_bit_cast(
+          bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16 + kb * 1024), 0, 16 /* sc1 */));
+    });
+  };
+  load_fragments(std::integral_constant<int, 0>{}, std::integral_constant<int, FR0>{});
+  stamp();  // 1: first fragments requested
+  // target fragment kb of row fi: the 16-byte slot 2 kb + fh, stored at slot ^ (fi & 15)
+  unsigned int boff[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) boff[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
+  // staging: acc[4 g + e] = score(query fi, target 8 g + 4 fh + e) -> 16-byte chunk 2 g | fh of row fi, at chunk ^ (fi & 7)
+  const unsigned int cwr = (unsigned int)(STG0 + w4 * STGW + fi * 128);
+  const int y = fh ^ (fi & 7);
+
+  constexpr int PF = 8;
+  f32x16 acc;
+  auto unit = [&](int u, auto first) __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned int bt = (unsigned int)((u & (NBUF - 1)) * UNITB);
+    unsigned int bp[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bp[t] = bt + boff[t];
+    bf16x8 bq[PF];
+    auto bread = [&](bf16x8& dst, auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      const unsigned int addr = bp[kb & 7];
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256) : "memory");
+    };
+    v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
+    v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      constexpr int younger = NKB - 1 - kb >= PF - 1 ? PF - 1 : NKB - 1 - kb;
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(younger) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kb == 0) {
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[0], afr[0], zero, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[kb % PF], afr[kb], acc, 0, 0, 0);
+      }
+      if constexpr (kb + PF < NKB) bread(bq[kb % PF], std::integral_constant<int, kb + PF>{});
+      // first unit: the query K-blocks FR0.. are requested from inside the chain, one per MFMA slot, 16 slots ahead
+      // of their use (issued in front of the chain they would sit in the vector-memory queue before unit 0's pieces)
+      if constexpr (decltype(first)::value && kb < NKB - FR0)
+        load_fragments(std::integral_constant<int, FR0 + kb>{}, std::integral_constant<int, FR0 + kb + 1>{});
+    });
+    stamp();  // unit u: chain issued
+    // the finished unit -> staging[u & 1], at once: R(u + 1) hands it to the store waves
+    const unsigned int sw = cwr + (unsigned int)((u & 1) * STGB);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+      *reinterpret_cast<f32x4*>(smem + sw + (((2 * g) ^ y) << 4)) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  __builtin_amdgcn_s_barrier();  // R(0): unit 0 landed
+  stamp();  // 2
+  unit(0, std::true_type{});
+  for (int u = 1; u < NU; ++u) {
+    __builtin_amdgcn_s_barrier();  // R(u)
+    unit(u, std::false_type{});
+  }
+  __builtin_amdgcn_s_barrier();  // R(NU): the last unit is staged
+  if (nx.qf != nullptr && nx.mode == 2)  // no idle workgroups in this geometry: a slice of the next batch's queries
+    v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)(rg * ncg + cg) * 256 + tid, (long long)nx.nblocks * 256);
+}
+
+static int v6_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
+template <int SCORER, int SPLIT>
+static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m, float* out, long long ldo,
+                     long long out2_off, hipStream_t st, unsigned long long* dbg, const void* qf, NextQ nx,
+                     int reserve_cus) {
+  constexpr int RGR = SPLIT ? 64 : V6_ROWS;
+  const int rgn1 = (int)((n + RGR - 1) / RGR);
+  const int rgn = two_sided ? 2 * rgn1 : rgn1;
+  const int nunits = (int)((m + V6_UT - 1) / V6_UT);
+  int cus = v6_cu_count() - reserve_cus;
+  if (cus > 256) cus = 256;
+  if (cus < 8) cus = 8;
+  // the geometry of launch_v4: workgroup b runs on XCD b % 8 = the low bits of its column group; whole groups of
+  // eight column groups that fit the compute units (prepared queries: no co-residency requirement, any grid goes)
+  int ncg = cus / rgn;
+  if (ncg > 8) ncg = 8 * (cus / 8 / rgn > 0 ? cus / 8 / rgn : 1);
+  if (ncg < 1) ncg = 1;
+  int upc = (nunits + ncg - 1) / ncg;
+  if (upc < 1) upc = 1;
+  ncg = (nunits + upc - 1) / upc;
+  const int grid = 8 * rgn * ((ncg + 7) / 8);
+  if (ldo >= (1LL << 24)) return KGE_ERR_UNSUPPORTED;
+  if (nx.qf != nullptr) {
+    const int spare = rgn * ((((ncg + 7) / 8) * 8) - ncg);
+    if (spare >= 4) {
+      nx.mode = 1;
+      nx.nblocks = spare;
+    } else {
+      nx.mode = 2;
+      nx.nblocks = rgn * ncg;
+    }
+  }
+  const char* il = getenv("KGE_V4_INTERLEAVE");
+  const bool interleave =
+      il ? il[0] == '1' : ((double)n * (double)m * 4.0 * (two_sided ? 2 : 1) > 192e6 && (ldo & 7) == 0);
+  const char* sc1e = getenv("KGE_V4_STORE_SC1");
+  const bool st_aligned = (ldo & 7) == 0 && (out2_off & 7) == 0 && ((uintptr_t)out & 31) == 0;
+  const bool st_small = (double)n * (double)m * 4.0 * (two_sided ? 2 : 1) <= 48e6;
+  const int st_sc1 = sc1e ? (sc1e[0] != '0') : ((st_aligned || st_small) ? 1 : 0);
+  hipLaunchKernelGGL((pairs_bf16_v6_kernel<SCORER, SPLIT>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
+                     out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, st_sc1);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// Scores of prepared queries `qf` (fragment order of v4_build_queries) against the identity-indexed bf16 table TG, d = 512.
+// KGE_ERR_UNSUPPORTED: not this kernel's case (the caller takes pairs_bf16_v4_kernel).  KGE_V6=0 declines everything
+// (A/B measurements).
+int run_pairs_bf16_v6(int scorer, bool split, const Operand& TG, bool two_sided, int d, long long n, long long m,
+                      float* out, long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
+                      const void* qf, const NextQ& nx, int reserve_cus) {
+  if (d != 512 || TG.idx.ptr != nullptr || qf == nullptr) return KGE_ERR_UNSUPPORTED;
+  const char* e = getenv("KGE_V6");
+  if (e && e[0] == '0') return KGE_ERR_UNSUPPORTED;
+  if (TG.ld * 2 >= (1LL << 28)) return KGE_ERR_UNSUPPORTED;
+#define KGE_V6L(SC)                                                                                            \
+  return split ? launch_v6<SC, 1>(TG, two_sided, n, m, out, ldo, out2_off, st, dbg, qf, nx, reserve_cus)       \
+               : launch_v6<SC, 0>(TG, two_sided, n, m, out, ldo, out2_off, st, dbg, qf, nx, reserve_cus)
+  if (scorer == KGE_COMPLEX) { KGE_V6L(KGE_COMPLEX); }
+  if (scorer == KGE_DISTMULT) { KGE_V6L(KGE_DISTMULT); }
+#undef KGE_V6L
+  return KGE_ERR_UNSUPPORTED;
+}
+
+}  // namespace kge

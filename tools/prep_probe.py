@@ -98,7 +98,7 @@ def stamps(n):
     fn.argtypes = [ctypes.POINTER(_lib.KgeTables), _lib.KgeIndex, _lib.KgeIndex, ctypes.c_int64, ctypes.c_int64,
                    ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                    ctypes.c_void_p]
-    for mode, name in ((0, "cooperative in-launch build"), (100, "prepared queries"), (101, "prepared split queries")):
+    for mode, name in ((100, "prepared queries"), (101, "prepared split queries")):
         T = engine.Tables("complex", ent, rel, flags=engine.FLAG_SPLIT_QUERY if mode == 101 else 0)
         tc = T.c()
         keep = []
@@ -117,7 +117,7 @@ def stamps(n):
         v = v[v[:, 0] != 0]
         ld = (v[:, 32:40] - v[:, :1]).double().median(dim=0).values
         print(f"  tile 0: wave 4 issued {float(ld[0]):.0f} landed {float(ld[5]):.0f}; wave 6 issued {float(ld[6]):.0f} landed {float(ld[7]):.0f}")
-        print(f"  loader side: first tiles issued {float(ld[0]):.0f}, store waves' last store issued {float(ld[2]):.0f}, "
+        print(f"  loader side: first tiles issued {float(ld[0]):.0f}, first store issued {float(ld[1]):.0f} (unit kernel only), store waves' last store issued {float(ld[2]):.0f}, "
               f"acknowledged {float(ld[3]):.0f}, DMA waves' last-tile stores issued {float(ld[4]):.0f}")
         v[:, 32:] = 0
         nst = int((v[0] != 0).sum())

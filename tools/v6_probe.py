@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""pairs_bf16_v6_kernel against pairs_bf16_v4_kernel (KGE_V6=0) on prepared queries at the FB15k-237 shape: the
+pipelined step (every launch also builds the next batch's queries), one- and two-sided, contiguous and padded
+pitch, plain and split queries; variants timed in turn (ABAB...), median of R rounds of S back-to-back steps.
+Then the phase stamps of the one-sided launch.      python tools/v6_probe.py [--steps 300] [--rounds 5]"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kge_amd import engine  # noqa: E402
+
+dev = torch.device("cuda", 0)
+E, R, D = 14541, 237, 512
+
+
+def alg_bytes(n, m, d, sides):
+    return m * d * 2 + sides * (n * 2 * d * 2 + n * m * 4 + 2 * n * 8)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--stamps", type=int, default=1)
+    a = ap.parse_args()
+    g = torch.Generator().manual_seed(0)
+    ent = torch.empty(E, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
+    rel = torch.empty(R, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
+    cases = []
+    for n in (512, 128, 2048):
+        batches = [tuple(torch.randint(hi, (n,), generator=g).to(dev) for hi in (E, R, E)) for _ in range(2)]
+        for comb, sides in (("sp_", 1), ("sp_po", 2)):
+            for split in ((0, 1) if n == 512 else (0,)):
+                fl = engine.FLAG_SPLIT_QUERY if split else None
+                T = engine.Tables("complex", ent, rel, flags=fl or 0)
+                pipe = engine.ScorePipeline(T, comb, n, flags=fl)
+                pipe.start(*batches[0])
+                for pad in (0, 1):
+                    P = (E + 63) // 64 * 64 if pad else E
+                    buf = torch.empty(n, sides * P, device=dev)
+                    out = buf.view(n, sides, P)[:, :, :E] if sides == 2 else buf[:, :E]
+                    if sides == 2 and not pad:
+                        out = buf
+                    cases.append(dict(n=n, combine=comb, split=split, pad=pad, pipe=pipe, out=out, batches=batches,
+                                      bytes=alg_bytes(n, E, D, sides), t={"0": [], "1": []}))
+    k = [0]
+    for r in range(a.rounds):
+        for c in cases:
+            for v6 in ("0", "1"):
+                os.environ["KGE_V6"] = v6
+
+                def step():
+                    k[0] += 1
+                    c["pipe"].step(next_batch=c["batches"][k[0] & 1], out=c["out"])
+                for _ in range(20):
+                    step()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(a.steps):
+                    step()
+                e1.record()
+                torch.cuda.synchronize()
+                c["t"][v6].append(e0.elapsed_time(e1) / a.steps * 1e3)
+    for c in cases:
+        m4, m6 = statistics.median(c["t"]["0"]), statistics.median(c["t"]["1"])
+        print(json.dumps({"n": c["n"], "combine": c["combine"], "split": c["split"], "padded_pitch": c["pad"],
+                          "v4_us": round(m4, 2), "v6_us": round(m6, 2),
+                          "v4_frac": round(c["bytes"] / (m4 * 1e-6) / 8e12, 3),
+                          "v6_frac": round(c["bytes"] / (m6 * 1e-6) / 8e12, 3)}), flush=True)
+    os.environ.pop("KGE_V6", None)
+    if a.stamps:
+        import prep_probe
+        for v6 in ("0", "1"):
+            os.environ["KGE_V6"] = v6
+            print(f"######## KGE_V6={v6}")
+            prep_probe.stamps(512)
+
+
+if __name__ == "__main__":
+    main()
