@@ -42,7 +42,18 @@ namespace kge {
 constexpr int V6_ROWS = 128, V6_UT = 32;
 typedef float f32x4v6u __attribute__((ext_vector_type(4), aligned(4)));
 
-template <int SCORER, int SPLIT>
+// one LDS-DMA piece: 64 lanes x 16 B from row pointer P (SGPR pair) + per-lane offset VO to LDS address D (m0)
+#define KGE_V6_DMA(D, VO, P)                                                                          \
+  do {                                                                                                \
+    if constexpr (POL == 0)                                                                           \
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0"); \
+    else if constexpr (POL == 1)                                                                      \
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0"); \
+    else                                                                                              \
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0"); \
+  } while (0)
+
+template <int SCORER, int SPLIT, int FR0_, int AHEAD, int PRO1 = 0, int POL = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
     Operand TG, long long n, long long m, int rgn, int rgn1, long long out2_off, int ncg, int units_per_cg,
     int nunits, float* __restrict__ out, long long ldo, unsigned long long* __restrict__ dbg,
@@ -57,7 +68,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
   constexpr int STGW = 32 * V6_UT * 4;       // one consumer's block: 4 KiB
   constexpr int STGB = 4 * STGW;
   constexpr int SMEM = STG0 + 2 * STGB;      // 160 KiB
-  constexpr int FR0 = 16;                    // query K-blocks requested before the first chain
+  constexpr int FR0 = FR0_;                  // query K-blocks requested before the first chain
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
   const int b = blockIdx.x;
@@ -105,21 +116,32 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
     // slot l ^ (row & 15) into slot l (the consumers read slot s of row fi at s ^ (fi & 15): conflict-free).  Rows
     // beyond the table repeat its last row (their scores are never stored).
     auto dma_rows = [&](int uu, int r0, auto cnt) __attribute__((always_inline)) {
+      constexpr int CNT = decltype(cnt)::value;
       const long long row0 = (long long)(unit_lo + uu * unit_st) * V6_UT + r0;
       const unsigned int d0 = (unsigned int)((uu & (NBUF - 1)) * UNITB + r0 * ROWB);
       const unsigned int x0 = (unsigned int)(r0 & 15) << 4;
-      v4_static_for<0, decltype(cnt)::value>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        long long r = row0 + k;
-        if (r >= m) r = m - 1;
-        const unsigned char* p = tgb + r * tld2;
-        const unsigned int vo = lane16 ^ (x0 + (k << 4));
-        const unsigned int dk = d0 + k * ROWB;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :
-                     : "s"(dk), "v"(vo), "s"(p)
-                     : "memory", "m0");
-      });
+      // (scalar work per piece matters: the issuing wave is the pacemaker of the unit loop -- one pointer add and one
+      // m0 value per piece in the common case; the clamped form only for the unit that reaches the end of the table)
+      if (row0 + CNT <= m) {
+        const unsigned char* p = tgb + row0 * tld2;
+        v4_static_for<0, CNT>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          const unsigned int vo = lane16 ^ (x0 + (k << 4));
+          const unsigned int dk = d0 + k * ROWB;
+          const unsigned char* pk = p + k * tld2;
+          KGE_V6_DMA(dk, vo, pk);
+        });
+      } else {
+        v4_static_for<0, CNT>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          long long r = row0 + k;
+          if (r >= m) r = m - 1;
+          const unsigned char* pk = tgb + r * tld2;
+          const unsigned int vo = lane16 ^ (x0 + (k << 4));
+          const unsigned int dk = d0 + k * ROWB;
+          KGE_V6_DMA(dk, vo, pk);
+        });
+      }
     };
     using C8 = std::integral_constant<int, 8>;
     using C16 = std::integral_constant<int, 16>;
@@ -199,33 +221,41 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
 
     const int l4 = wave - 4;  // ring fill: this wave's eight rows of units 0 and 1
     dma_rows(0, 8 * l4, C8{});
-    if (NU > 1) dma_rows(1, 8 * l4, C8{});
+    if (!PRO1 && NU > 1) dma_rows(1, 8 * l4, C8{});
 
     if (wave < 6) {
       // ------------------------------- DMA waves -------------------------------
       const int r16 = 16 * (wave & 1);
       if (wave == 4) stamp_at(32);  // first units issued
       for (int k = 0; k <= NU; ++k) {
-        // this wave's VMEM queue, in order: u0 (8), u1 (8) | behind R(0): u2 (16), u3 (16) | behind R(k): u(k+3) (16).
-        // Unit k has landed once only the pieces issued behind it are outstanding.
+        // this wave's VMEM queue, in order: u0 (8), u1 (8) | behind R(0): u2 .. u(AHEAD) (16 each) | behind R(k):
+        // u(k + AHEAD) (16).  Unit k has landed once only the pieces issued behind it are outstanding.
         if (k < NU) {
           if (k == 0) {
-            if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (!PRO1 && NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          } else if (PRO1) {
+            // queue: u0 (8) | R(0) | u1 (16), u2 (16) | R(k): u(k + 2) (16): behind unit k only unit k + 1
+            if (k + 1 < NU) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           } else {
-            const int behind = NU - 1 - k < 2 ? NU - 1 - k : 2;
-            if (behind == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            const int behind = NU - 1 - k < AHEAD - 1 ? NU - 1 - k : AHEAD - 1;
+            if (behind >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             else if (behind == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
         }
         if (k == 0 && wave == 4) stamp_at(37);  // unit 0: this wave's pieces have landed
+        if (wave == 4 && k < 8) stamp_at(40 + k);  // arrival at R(k)
         __builtin_amdgcn_s_barrier();  // R(k)
-        if (k == 0) {
+        if (PRO1) {
+          if (k == 0 && NU > 1) dma_rows(1, r16, C16{});
+          if (k + 2 < NU) dma_rows(k + 2, r16, C16{});
+        } else if (k == 0) {
           if (NU > 2) dma_rows(2, r16, C16{});
-          if (NU > 3) dma_rows(3, r16, C16{});
-        } else if (k + 3 < NU) {
-          dma_rows(k + 3, r16, C16{});  // into the buffer of unit k - 1
+          if (AHEAD > 2 && NU > 3) dma_rows(3, r16, C16{});
+        } else if (k + AHEAD < NU) {
+          dma_rows(k + AHEAD, r16, C16{});  // AHEAD = 3: into the buffer of unit k - 1
         }
       }
       if (NU >= 1) last_unit();
@@ -235,12 +265,13 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
     // ------------------------------- store waves -------------------------------
     if (wave == 6) stamp_at(38);
     setup_blocks(SPLIT ? (wave & 1) : 2 * (wave & 1), SPLIT ? 1 : 2);
-    if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (!PRO1 && NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave == 6) stamp_at(39);
     __builtin_amdgcn_s_barrier();  // R(0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its rows of unit 1 (no store has been issued yet)
-    if (NU >= 1) __builtin_amdgcn_s_barrier();  // R(1)
+    if (wave == 6) stamp_at(49);
+    __builtin_amdgcn_s_barrier();  // R(1)
     for (int k = 1; k < NU; ++k) {
       // behind R(k): unit k - 1 is staged in staging[(k - 1) & 1]
       const int sb = (k - 1) & 1;
@@ -259,6 +290,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
         store_block(k - 1, 1);
       }
       if (k == 1 && wave == 6) stamp_at(33);  // first stores issued
+      if (wave == 6 && k + 1 < 8) stamp_at(48 + k + 1);  // arrival at R(k + 1)
       __builtin_amdgcn_s_barrier();  // R(k + 1)
     }
     last_unit();
@@ -337,6 +369,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
       *reinterpret_cast<f32x4*>(smem + sw + (((2 * g) ^ y) << 4)) = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp();  // unit u staged: arrival at R(u + 1)
   };
   __builtin_amdgcn_s_barrier();  // R(0): unit 0 landed
   stamp();  // 2
@@ -402,8 +435,18 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
   const bool st_aligned = (ldo & 7) == 0 && (out2_off & 7) == 0 && ((uintptr_t)out & 31) == 0;
   const bool st_small = (double)n * (double)m * 4.0 * (two_sided ? 2 : 1) <= 48e6;
   const int st_sc1 = sc1e ? (sc1e[0] != '0') : ((st_aligned || st_small) ? 1 : 0);
-  hipLaunchKernelGGL((pairs_bf16_v6_kernel<SCORER, SPLIT>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
-                     out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, st_sc1);
+#define KGE_V6K(F, AH, ...)                                                                                     \
+  hipLaunchKernelGGL((pairs_bf16_v6_kernel<SCORER, SPLIT, F, AH, ##__VA_ARGS__>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1, \
+                     out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, st_sc1)
+  const char* ve = getenv("KGE_V6_VAR");  // A/B of the start-up order (tools/v6_probe.py)
+  const int var = ve ? ve[0] - '0' : 3;
+  if (var == 0) KGE_V6K(16, 3);
+  else if (var == 1) KGE_V6K(8, 2, 1);
+  else if (var == 2) KGE_V6K(16, 2);
+  else if (var == 3) KGE_V6K(16, 2, 1);
+  else if (var == 4) KGE_V6K(16, 2, 0, 1);
+  else KGE_V6K(16, 2, 0, 2);
+#undef KGE_V6K
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
@@ -426,4 +469,5 @@ int run_pairs_bf16_v6(int scorer, bool split, const Operand& TG, bool two_sided,
   return KGE_ERR_UNSUPPORTED;
 }
 
+#undef KGE_V6_DMA
 }  // namespace kge

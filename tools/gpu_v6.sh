@@ -5,8 +5,9 @@ TAG=${1:-v6}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+echo > $OUT/env.log
 timeout 600 python -m pytest tests/test_gpu_queries.py -m gpu -q -x --timeout=300 > $OUT/pytest_queries.log 2>&1
-echo "pytest queries exit: $?" > $OUT/env.log
+echo "pytest queries exit: $?" >> $OUT/env.log
 tail -n 15 $OUT/pytest_queries.log
 timeout 600 python tools/v6_probe.py --steps ${2:-300} --rounds ${3:-5} > $OUT/v6_probe.txt 2>&1
 echo "probe exit: $?" >> $OUT/env.log

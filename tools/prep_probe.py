@@ -119,6 +119,10 @@ def stamps(n):
         print(f"  tile 0: wave 4 issued {float(ld[0]):.0f} landed {float(ld[5]):.0f}; wave 6 issued {float(ld[6]):.0f} landed {float(ld[7]):.0f}")
         print(f"  loader side: first tiles issued {float(ld[0]):.0f}, first store issued {float(ld[1]):.0f} (unit kernel only), store waves' last store issued {float(ld[2]):.0f}, "
               f"acknowledged {float(ld[3]):.0f}, DMA waves' last-tile stores issued {float(ld[4]):.0f}")
+        if bool((v[:, 41] != 0).any()):
+            arr = (v[:, 40:56] - v[:, :1]).double().median(dim=0).values
+            print("  arrival at R(k), DMA wave 4:  " + " ".join(f"{float(x):.0f}" for x in arr[:8]))
+            print("  arrival at R(k), store wave 6: " + " ".join(f"{float(x):.0f}" for x in arr[8:]))
         v[:, 32:] = 0
         nst = int((v[0] != 0).sum())
         own = (v[:, :nst] - v[:, :1]).double()

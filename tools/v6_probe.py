@@ -18,7 +18,13 @@ from kge_amd import engine  # noqa: E402
 
 dev = torch.device("cuda", 0)
 E, R, D = 14541, 237, 512
-
+VARIANTS = {"v4": {"KGE_V6": "0"},
+            "a3": {"KGE_V6": "1", "KGE_V6_VAR": "0"},
+            "a2": {"KGE_V6": "1", "KGE_V6_VAR": "2"},
+            "a2sc1": {"KGE_V6": "1", "KGE_V6_VAR": "4"},
+            "a2nt": {"KGE_V6": "1", "KGE_V6_VAR": "5"},
+            "p1f8": {"KGE_V6": "1", "KGE_V6_VAR": "1"},
+            "p1f16": {"KGE_V6": "1", "KGE_V6_VAR": "3"}}
 
 def alg_bytes(n, m, d, sides):
     return m * d * 2 + sides * (n * 2 * d * 2 + n * m * 4 + 2 * n * 8)
@@ -34,10 +40,10 @@ def main():
     ent = torch.empty(E, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
     rel = torch.empty(R, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
     cases = []
-    for n in (512, 128, 2048):
+    for n in (512, 1024):
         batches = [tuple(torch.randint(hi, (n,), generator=g).to(dev) for hi in (E, R, E)) for _ in range(2)]
         for comb, sides in (("sp_", 1), ("sp_po", 2)):
-            for split in ((0, 1) if n == 512 else (0,)):
+            for split in (0,):
                 fl = engine.FLAG_SPLIT_QUERY if split else None
                 T = engine.Tables("complex", ent, rel, flags=fl or 0)
                 pipe = engine.ScorePipeline(T, comb, n, flags=fl)
@@ -49,12 +55,12 @@ def main():
                     if sides == 2 and not pad:
                         out = buf
                     cases.append(dict(n=n, combine=comb, split=split, pad=pad, pipe=pipe, out=out, batches=batches,
-                                      bytes=alg_bytes(n, E, D, sides), t={"0": [], "1": []}))
+                                      bytes=alg_bytes(n, E, D, sides), t={v: [] for v in VARIANTS}))
     k = [0]
     for r in range(a.rounds):
         for c in cases:
-            for v6 in ("0", "1"):
-                os.environ["KGE_V6"] = v6
+            for v6 in VARIANTS:
+                os.environ.update(VARIANTS[v6])
 
                 def step():
                     k[0] += 1
@@ -70,17 +76,17 @@ def main():
                 torch.cuda.synchronize()
                 c["t"][v6].append(e0.elapsed_time(e1) / a.steps * 1e3)
     for c in cases:
-        m4, m6 = statistics.median(c["t"]["0"]), statistics.median(c["t"]["1"])
-        print(json.dumps({"n": c["n"], "combine": c["combine"], "split": c["split"], "padded_pitch": c["pad"],
-                          "v4_us": round(m4, 2), "v6_us": round(m6, 2),
-                          "v4_frac": round(c["bytes"] / (m4 * 1e-6) / 8e12, 3),
-                          "v6_frac": round(c["bytes"] / (m6 * 1e-6) / 8e12, 3)}), flush=True)
-    os.environ.pop("KGE_V6", None)
+        row = {"n": c["n"], "combine": c["combine"], "split": c["split"], "padded_pitch": c["pad"]}
+        for v in VARIANTS:
+            md = statistics.median(c["t"][v])
+            row[v + "_us"] = round(md, 2)
+            row[v + "_frac"] = round(c["bytes"] / (md * 1e-6) / 8e12, 3)
+        print(json.dumps(row), flush=True)
     if a.stamps:
         import prep_probe
-        for v6 in ("0", "1"):
-            os.environ["KGE_V6"] = v6
-            print(f"######## KGE_V6={v6}")
+        for v6 in VARIANTS:
+            os.environ.update(VARIANTS[v6])
+            print(f"######## {v6}")
             prep_probe.stamps(512)
 
 
