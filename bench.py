@@ -444,10 +444,10 @@ def main():
     q2 = torch.Generator().manual_seed(2)
     batch_b = tuple(torch.randint(hi, (n,), generator=q2).to(device) for hi in (E_FB, R_FB, E_FB))
     batches = [(s, p, o), batch_b]
-    # Score rows on a 256-byte pitch (the C ABI's `ldo`: 2 x 14,592 floats per row, the two blocks at column 0 and
-    # 14,592): every 16-byte store of the kernel then covers whole 32-byte sectors.  The reference's contiguous
+    # Score rows on a 256-byte pitch (the C ABI's `ldo`: 2 x 14,656 floats per row, the two blocks at column 0 and
+    # 14,656; engine.score_pitch): every 16-byte store of the kernel then covers whole 32-byte sectors.  The reference's contiguous
     # [n, 2E] layout (rows at 4-byte granularity) is measured beside it (`contiguous_pitch`).
-    PITCH = (E_FB + 63) // 64 * 64
+    PITCH = engine.score_pitch(E_FB)  # 14,656 floats: whole 256-byte lines, an odd number of them per row
     out_pad = torch.empty(n, 2 * PITCH, device=device)
     out_buf = out_pad.view(n, 2, PITCH)[:, :, :E_FB]          # [n, 2, E] view: block b of row i at i*2*PITCH + b*PITCH
     out_contig = torch.empty(n, 2 * E_FB, device=device)
@@ -604,7 +604,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "pairs_bf16_v4_kernel<ComplEx,d=512>, two-sided, prepared queries (kge_score_queries: one "
+            "kernel": "pairs_bf16_v6_kernel<ComplEx,d=512>, two-sided, prepared queries (kge_score_queries: one "
                       "launch = MFMA contraction + store of both score blocks of batch k + gather and query build "
                       "of batch k+1 on idle workgroups)",
             "achieved": achieved,

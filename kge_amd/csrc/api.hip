@@ -121,6 +121,7 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
                const float* label_weight = nullptr, const float* label_bias = nullptr);
 void set_g16_dbg(unsigned long long* p);
+void v6_set_stamps(unsigned long long* p);
 int run_debug_gemm16(int which, int lib, int d, long long rows, long long m, const unsigned short* X, long long ldx,
                      const unsigned short* G16, long long mp, float* out, float* scratch, long long scratch_bytes,
                      hipStream_t st);
@@ -1125,6 +1126,10 @@ int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64
 // Not part of the public ABI: timestamp buffer (64 x u64 per workgroup) for the next
 // kge_ce_fwd / kge_ce_bwd scoring launches (tools/ce_phases.py); NULL switches it off.
 void kge_debug_ce_stamps(unsigned long long* stamps) { kge::ce_set_stamps(stamps); }
+
+// Not part of the public ABI: timestamp buffer (64 x u64 per workgroup) for the next pairs_bf16_v6_kernel launches
+// that carry none of their own (tools/v6_probe.py: stamps of two-sided / pipelined launches); NULL switches it off.
+void kge_debug_v6_stamps(unsigned long long* stamps) { kge::v6_set_stamps(stamps); }
 
 // Not part of the public ABI: one gradient contraction of the bf16 backward on its own
 // (tests/test_gpu_bwd_gemm16.py, tools/gemm16_probe.py); see run_debug_gemm16 in bwd_gemm.hip.

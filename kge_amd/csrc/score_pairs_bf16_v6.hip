@@ -43,17 +43,24 @@ constexpr int V6_ROWS = 128, V6_UT = 32;
 typedef float f32x4v6u __attribute__((ext_vector_type(4), aligned(4)));
 
 // one LDS-DMA piece: 64 lanes x 16 B from row pointer P (SGPR pair) + per-lane offset VO to LDS address D (m0)
-#define KGE_V6_DMA(D, VO, P)                                                                          \
-  do {                                                                                                \
-    if constexpr (POL == 0)                                                                           \
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0"); \
-    else if constexpr (POL == 1)                                                                      \
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0"); \
-    else                                                                                              \
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0"); \
-  } while (0)
+#define KGE_V6_DMA(D, VO, P) \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0")
 
-template <int SCORER, int SPLIT, int FR0_, int AHEAD, int PRO1 = 0, int POL = 0>
+// LDS operations younger than the fragment read of slot kb when slot kb waits for it: the reads of the next seven
+// slots (the read for slot j is issued in slot j - 8, across unit boundaries; behind the last unit the reads go to
+// the next ring buffer all the same and nobody uses what they return: one schedule for every chain) and the staging
+// writes of the previous unit (one each in slots V6_W0 .. V6_W0 + 3, behind that slot's read).
+constexpr int V6_W0 = 2;   // two MFMA slots behind the previous chain's last MFMA: its result is there, no wait states
+constexpr int V6_PB = 14;  // slot of barrier P(u): every staging write is older than the reads still allowed in flight
+constexpr int v6_younger(int kb, bool writes) {
+  int y = 7;
+  if (writes)
+    for (int j = V6_W0; j < V6_W0 + 4; ++j)
+      if (j >= kb - 8 && j <= kb - 1) ++y;
+  return y;
+}
+
+template <int SCORER, int SPLIT>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
     Operand TG, long long n, long long m, int rgn, int rgn1, long long out2_off, int ncg, int units_per_cg,
     int nunits, float* __restrict__ out, long long ldo, unsigned long long* __restrict__ dbg,
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
   constexpr int STGW = 32 * V6_UT * 4;       // one consumer's block: 4 KiB
   constexpr int STGB = 4 * STGW;
   constexpr int SMEM = STG0 + 2 * STGB;      // 160 KiB
-  constexpr int FR0 = FR0_;                  // query K-blocks requested before the first chain
+  constexpr int FR0 = 16;                    // query K-blocks requested before the first chain
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
   const int b = blockIdx.x;
@@ -107,6 +114,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
   };
   stamp();  // 0: start
 
+  // Barriers (all eight waves): R0; P(u), u = 0 .. NU - 1, which the consumers pass in slot V6_PB of chain u; F.
+  //   R0    unit 0 has landed.
+  //   P(u)  (a) unit u + 1 has landed -- the consumers start reading it in slot 24 of chain u, so that no read latency
+  //             is exposed between two chains;
+  //         (b) the scores of unit u - 1 are in staging[(u - 1) & 1] (written in slots V6_W0.. of chain u);
+  //         (c) the store waves have read staging[u & 1] (unit u - 2; they did so behind P(u - 1));
+  //         (d) the consumers are done with ring buffer (u - 1) % 4: the DMA waves refill it with unit u + 3.
+  //   F     the last unit is staged.
   if (wave >= 4) {
     // =============================== loader waves ===============================
     const unsigned char* const tgb = (const unsigned char*)TG.base;
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
       const long long row0 = (long long)(unit_lo + uu * unit_st) * V6_UT + r0;
       const unsigned int d0 = (unsigned int)((uu & (NBUF - 1)) * UNITB + r0 * ROWB);
       const unsigned int x0 = (unsigned int)(r0 & 15) << 4;
-      // (scalar work per piece matters: the issuing wave is the pacemaker of the unit loop -- one pointer add and one
+      // (scalar work per piece matters: the issuing wave is a pacemaker of the unit loop -- one pointer add and one
       // m0 value per piece in the common case; the clamped form only for the unit that reaches the end of the table)
       if (row0 + CNT <= m) {
         const unsigned char* p = tgb + row0 * tld2;
@@ -221,78 +236,67 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
 
     const int l4 = wave - 4;  // ring fill: this wave's eight rows of units 0 and 1
     dma_rows(0, 8 * l4, C8{});
-    if (!PRO1 && NU > 1) dma_rows(1, 8 * l4, C8{});
+    if (NU > 1) dma_rows(1, 8 * l4, C8{});
 
     if (wave < 6) {
       // ------------------------------- DMA waves -------------------------------
+      // VMEM queue of this wave, in order (LDS-DMA only, in-order returns): u0 (8), u1 (8) | behind P(u): u(u + 3)
+      // (16).  A unit has landed once only the pieces issued behind it are outstanding.
       const int r16 = 16 * (wave & 1);
       if (wave == 4) stamp_at(32);  // first units issued
-      for (int k = 0; k <= NU; ++k) {
-        // this wave's VMEM queue, in order: u0 (8), u1 (8) | behind R(0): u2 .. u(AHEAD) (16 each) | behind R(k):
-        // u(k + AHEAD) (16).  Unit k has landed once only the pieces issued behind it are outstanding.
-        if (k < NU) {
-          if (k == 0) {
-            if (!PRO1 && NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          } else if (PRO1) {
-            // queue: u0 (8) | R(0) | u1 (16), u2 (16) | R(k): u(k + 2) (16): behind unit k only unit k + 1
-            if (k + 1 < NU) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          } else {
-            const int behind = NU - 1 - k < AHEAD - 1 ? NU - 1 - k : AHEAD - 1;
-            if (behind >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else if (behind == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-        }
-        if (k == 0 && wave == 4) stamp_at(37);  // unit 0: this wave's pieces have landed
-        if (wave == 4 && k < 8) stamp_at(40 + k);  // arrival at R(k)
-        __builtin_amdgcn_s_barrier();  // R(k)
-        if (PRO1) {
-          if (k == 0 && NU > 1) dma_rows(1, r16, C16{});
-          if (k + 2 < NU) dma_rows(k + 2, r16, C16{});
-        } else if (k == 0) {
-          if (NU > 2) dma_rows(2, r16, C16{});
-          if (AHEAD > 2 && NU > 3) dma_rows(3, r16, C16{});
-        } else if (k + AHEAD < NU) {
-          dma_rows(k + AHEAD, r16, C16{});  // AHEAD = 3: into the buffer of unit k - 1
-        }
+      if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (wave == 4) stamp_at(37);  // unit 0: this wave's pieces have landed
+      __builtin_amdgcn_s_barrier();  // R0
+      // (unit 2 is the store waves', behind P(0): they have nothing to move before P(1), and whoever issues 16 more
+      // pieces before P(0) holds the consumers there -- the pieces queue behind the query fragments in the
+      // vector-memory path: P(0) passed at 5.1 k cycles instead of 3.7 k)
+      for (int u = 0; u < NU; ++u) {
+        // unit u + 1 (if any) has landed: behind it in this wave's queue only unit u + 2 (from u = 1 on)
+        if (u >= 1 && u + 2 < NU) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wave == 4 && u < 8) stamp_at(40 + u);  // arrival at P(u)
+        __builtin_amdgcn_s_barrier();  // P(u)
+        if (u + 3 < NU) dma_rows(u + 3, r16, C16{});  // into the buffer of unit u - 1
       }
-      if (NU >= 1) last_unit();
+      __builtin_amdgcn_s_barrier();  // F
+      last_unit();
       if (wave == 4) stamp_at(36);  // last unit's stores issued
       return;
     }
     // ------------------------------- store waves -------------------------------
     if (wave == 6) stamp_at(38);
     setup_blocks(SPLIT ? (wave & 1) : 2 * (wave & 1), SPLIT ? 1 : 2);
-    if (!PRO1 && NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave == 6) stamp_at(39);
-    __builtin_amdgcn_s_barrier();  // R(0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its rows of unit 1 (no store has been issued yet)
-    if (wave == 6) stamp_at(49);
-    __builtin_amdgcn_s_barrier();  // R(1)
-    for (int k = 1; k < NU; ++k) {
-      // behind R(k): unit k - 1 is staged in staging[(k - 1) & 1]
-      const int sb = (k - 1) & 1;
+    __builtin_amdgcn_s_barrier();  // R0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its rows of unit 1
+    if (wave == 6) stamp_at(48);
+    __builtin_amdgcn_s_barrier();  // P(0)
+    if (NU > 2) dma_rows(2, 16 * (wave & 1), C16{});  // unit 2: due at P(1), ~30 MFMA slots away
+    for (int u = 1; u < NU; ++u) {
+      if (u == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // unit 2 (no store has been issued yet)
+      if (wave == 6 && u < 8) stamp_at(48 + u);  // arrival at P(u)
+      __builtin_amdgcn_s_barrier();  // P(u): unit u - 1 is staged in staging[(u - 1) & 1]
+      const int sb = (u - 1) & 1;
       if constexpr (SPLIT) {
         read_block(sb, wave & 1, cv[0]);
         read_block(sb, (wave & 1) + 2, cv[1]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; ++i) cv[0][i] = cv[0][i] + cv[1][i];  // score = (sum q_hi t) + (sum q_lo t)
-        store_block(k - 1, 0);
+        store_block(u - 1, 0);
       } else {
         read_block(sb, 2 * (wave & 1), cv[0]);
         read_block(sb, 2 * (wave & 1) + 1, cv[1]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        store_block(k - 1, 0);
-        store_block(k - 1, 1);
+        store_block(u - 1, 0);
+        store_block(u - 1, 1);
       }
-      if (k == 1 && wave == 6) stamp_at(33);  // first stores issued
-      if (wave == 6 && k + 1 < 8) stamp_at(48 + k + 1);  // arrival at R(k + 1)
-      __builtin_amdgcn_s_barrier();  // R(k + 1)
+      if (u == 1 && wave == 6) stamp_at(33);  // first stores issued
     }
+    __builtin_amdgcn_s_barrier();  // F
     last_unit();
     if (wave == 6) stamp_at(34);  // last store issued
     if (wave == 6 && dbg != nullptr) {
@@ -327,26 +331,32 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
   // staging: acc[4 g + e] = score(query fi, target 8 g + 4 fh + e) -> 16-byte chunk 2 g | fh of row fi, at chunk ^ (fi & 7)
   const unsigned int cwr = (unsigned int)(STG0 + w4 * STGW + fi * 128);
   const int y = fh ^ (fi & 7);
+  auto c_write = [&](const f32x16& a, int sb, int g) __attribute__((always_inline)) {
+    const f32x4 v = {a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+    *reinterpret_cast<f32x4*>(smem + cwr + (unsigned int)(sb * STGB) + (((2 * g) ^ y) << 4)) = v;
+  };
 
   constexpr int PF = 8;
-  f32x16 acc;
-  auto unit = [&](int u, auto first) __attribute__((always_inline)) {
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned int bt = (unsigned int)((u & (NBUF - 1)) * UNITB);
-    unsigned int bp[8];
+  bf16x8 bq[PF];  // fragment ring, continuous across units: the read for slot j of unit u lands in bq[j % 8]
+  unsigned int bp[8];  // boff + the base of the ring buffer the next read goes to (moved on in slot 24 of a chain)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) bp[t] = bt + boff[t];
-    bf16x8 bq[PF];
-    auto bread = [&](bf16x8& dst, auto kc) __attribute__((always_inline)) {
-      constexpr int kb = decltype(kc)::value;
-      const unsigned int addr = bp[kb & 7];
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256) : "memory");
-    };
-    v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
+  for (int t = 0; t < 8; ++t) bp[t] = boff[t];
+  auto bread = [&](bf16x8& dst, auto kc) __attribute__((always_inline)) {
+    constexpr int kb = decltype(kc)::value;
+    const unsigned int addr = bp[kb & 7];
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256) : "memory");
+  };
+  f32x16 acc0, acc1;
+  // chain u into `acc`; `prev` = the finished accumulators of unit u - 1 (FIRST: none), staged in slots V6_W0..;
+  // the first eight fragment reads of unit u + 1 are issued in slots 24..31
+  auto chain = [&](int u, f32x16& acc, const f32x16& prev, auto first) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first)::value;
+    const unsigned int bn = (unsigned int)(((u + 1) & (NBUF - 1)) * UNITB);
+    const int sbp = (u - 1) & 1;
     v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
-      constexpr int younger = NKB - 1 - kb >= PF - 1 ? PF - 1 : NKB - 1 - kb;
-      asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(younger) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(v6_younger(kb, !FIRST)) : "memory");
+      if constexpr (kb == V6_PB) __builtin_amdgcn_s_barrier();  // P(u)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kb == 0) {
         const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -354,34 +364,52 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
       } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[kb % PF], afr[kb], acc, 0, 0, 0);
       }
-      if constexpr (kb + PF < NKB) bread(bq[kb % PF], std::integral_constant<int, kb + PF>{});
+      if constexpr (kb + PF == NKB) {  // this unit's reads are all issued: on to the next ring buffer
+#pragma unroll
+        for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %2" : "=v"(bp[t]) : "s"(bn), "v"(boff[t]));
+      }
+      bread(bq[kb % PF], std::integral_constant<int, (kb + PF) % NKB>{});
+      if constexpr (!FIRST && kb >= V6_W0 && kb < V6_W0 + 4) c_write(prev, sbp, kb - V6_W0);
       // first unit: the query K-blocks FR0.. are requested from inside the chain, one per MFMA slot, 16 slots ahead
       // of their use (issued in front of the chain they would sit in the vector-memory queue before unit 0's pieces)
-      if constexpr (decltype(first)::value && kb < NKB - FR0)
+      if constexpr (FIRST && kb < NKB - FR0)
         load_fragments(std::integral_constant<int, FR0 + kb>{}, std::integral_constant<int, FR0 + kb + 1>{});
     });
     stamp();  // unit u: chain issued
-    // the finished unit -> staging[u & 1], at once: R(u + 1) hands it to the store waves
-    const unsigned int sw = cwr + (unsigned int)((u & 1) * STGB);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-      *reinterpret_cast<f32x4*>(smem + sw + (((2 * g) ^ y) << 4)) = v;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    stamp();  // unit u staged: arrival at R(u + 1)
   };
-  __builtin_amdgcn_s_barrier();  // R(0): unit 0 landed
+  using T = std::true_type;
+  using Fz = std::false_type;
+  __builtin_amdgcn_s_barrier();  // R0: unit 0 landed
   stamp();  // 2
-  unit(0, std::true_type{});
-  for (int u = 1; u < NU; ++u) {
-    __builtin_amdgcn_s_barrier();  // R(u)
-    unit(u, std::false_type{});
+  v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
+  chain(0, acc0, acc1, T{});
+  {
+    int u = 1;
+    for (; u + 1 < NU; u += 2) {
+      chain(u, acc1, acc0, Fz{});
+      chain(u + 1, acc0, acc1, Fz{});
+    }
+    if (u < NU) chain(u, acc1, acc0, Fz{});
   }
-  __builtin_amdgcn_s_barrier();  // R(NU): the last unit is staged
+  // the last unit -> staging, for the loaders' final pass
+  {
+    const int sb = (NU - 1) & 1;
+    if ((NU - 1) & 1) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) c_write(acc1, sb, g);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) c_write(acc0, sb, g);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();  // F
   if (nx.qf != nullptr && nx.mode == 2)  // no idle workgroups in this geometry: a slice of the next batch's queries
     v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)(rg * ncg + cg) * 256 + tid, (long long)nx.nblocks * 256);
 }
+
+static std::atomic<unsigned long long*> g_v6_stamps{nullptr};
+void v6_set_stamps(unsigned long long* p) { g_v6_stamps.store(p); }
 
 static int v6_cu_count() {
   static std::atomic<int> cache[64];
@@ -418,6 +446,7 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
   ncg = (nunits + upc - 1) / upc;
   const int grid = 8 * rgn * ((ncg + 7) / 8);
   if (ldo >= (1LL << 24)) return KGE_ERR_UNSUPPORTED;
+  if (dbg == nullptr) dbg = g_v6_stamps.load(std::memory_order_relaxed);
   if (nx.qf != nullptr) {
     const int spare = rgn * ((((ncg + 7) / 8) * 8) - ncg);
     if (spare >= 4) {
@@ -434,19 +463,13 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
   const char* sc1e = getenv("KGE_V4_STORE_SC1");
   const bool st_aligned = (ldo & 7) == 0 && (out2_off & 7) == 0 && ((uintptr_t)out & 31) == 0;
   const bool st_small = (double)n * (double)m * 4.0 * (two_sided ? 2 : 1) <= 48e6;
-  const int st_sc1 = sc1e ? (sc1e[0] != '0') : ((st_aligned || st_small) ? 1 : 0);
-#define KGE_V6K(F, AH, ...)                                                                                     \
-  hipLaunchKernelGGL((pairs_bf16_v6_kernel<SCORER, SPLIT, F, AH, ##__VA_ARGS__>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1, \
-                     out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, st_sc1)
-  const char* ve = getenv("KGE_V6_VAR");  // A/B of the start-up order (tools/v6_probe.py)
-  const int var = ve ? ve[0] - '0' : 3;
-  if (var == 0) KGE_V6K(16, 3);
-  else if (var == 1) KGE_V6K(8, 2, 1);
-  else if (var == 2) KGE_V6K(16, 2);
-  else if (var == 3) KGE_V6K(16, 2, 1);
-  else if (var == 4) KGE_V6K(16, 2, 0, 1);
-  else KGE_V6K(16, 2, 0, 2);
-#undef KGE_V6K
+  // write-through only for sector-aligned rows: this kernel's 128-byte row segments straddle a sector at each end
+  // otherwise, and a partial sector written through is a read-modify-write at the memory (FB15k-237 shape, contiguous
+  // pitch, two-sided: 27.2 us written through, 21.1 us through the L2's write-back; aligned: 20.3 / 20.6)
+  const int st_sc1 = sc1e ? (sc1e[0] != '0') : (st_aligned ? 1 : 0);
+  (void)st_small;
+hipLaunchKernelGGL((pairs_bf16_v6_kernel<SCORER, SPLIT>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
+                     out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, st_sc1);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 

@@ -19,7 +19,7 @@ from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V2, FLAG_BF16_V3, FLAG_EXA
                    SCORERS, SP_, SP_PO, SPO, KgeIndex, KgeNextQueries, KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "embed", "rank_counts", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3",
+           "score_emb", "embed", "rank_counts", "score_pitch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V2", "FLAG_BF16_V3",
            "FLAG_SPLIT_QUERY", "reserve_cus", "Queries", "build_queries", "score_queries", "ScorePipeline"]
 
 
@@ -256,6 +256,15 @@ def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Ten
         if rc:
             _lib.check(rc, "kge_score_sp_po")
     return out
+
+
+def score_pitch(m: int) -> int:
+    """Row pitch (floats) for a score block of m columns that the store path likes: whole 256-byte lines per row
+    segment (sector-aligned 16-byte lane stores, write-through) and an ODD number of lines per row -- at the
+    FB15k-237 shape a two-sided block on a pitch of 228 lines (14,592 floats, 2 x 228 per row pair) takes 21.2 us,
+    on 229 lines 19.0 us (tools/pitch_probe.py: rows 228 lines apart land on few memory channels)."""
+    lines = (m + 63) // 64
+    return (lines | 1) * 64
 
 
 # ---- prepared queries (kge_build_queries / kge_score_queries) ----------------------------------------------------
