@@ -16,11 +16,6 @@ bool pairs_bf16_supported(int scorer, int dtype, int d, const Operand& A, const 
                           const Operand& TG);
 int run_pairs_bf16(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
                    int d, long long n, long long m, float* out, long long ldo, hipStream_t st);
-int run_pairs_bf16_v2_ablate(int abl, const Operand& A, const Operand& R, const Operand& TG, long long n,
-                             long long m, float* out, long long ldo, hipStream_t st,
-                             unsigned long long* dbg);
-bool pairs_bf16_v2_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
-                             const Operand& TG);
 bool pairs_bf16_v3_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
                              const Operand& TG);
 int run_pairs_bf16_v3(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
@@ -45,10 +40,6 @@ bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, con
 int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
                       unsigned long long* dbg);
-int run_pairs_bf16_v2(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
-                      int d, long long n, long long m, float* out, long long ldo,
-                      hipStream_t st, unsigned long long* dbg = nullptr, void* ws = nullptr,
-                      long long ws_bytes = 0);
 int run_embed2(const EmbedJob& a, const EmbedJob& b, int rowbytes, int esize, hipStream_t st);
 int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
@@ -164,7 +155,7 @@ int check_tables(const kge_tables* t, bool need_ptrs) {
 // of behind it (where it takes what v4 declines): KGE_V5=1, for tests and measurements.
 constexpr bool V5_DEFAULT = false;
 bool v5_on(const kge_tables* t) {
-  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
+  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
     return false;
   const char* e = getenv("KGE_V5");
   return e ? e[0] == '1' : V5_DEFAULT;
@@ -207,8 +198,8 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
     if (rc != KGE_ERR_UNSUPPORTED) return rc;
   }
   if (!(t->flags & KGE_FLAG_EXACT)) {
-    const bool v1 = t->flags & KGE_FLAG_BF16_V1, v2 = t->flags & KGE_FLAG_BF16_V2;
-    if (!v1 && !v2 && !(t->flags & KGE_FLAG_BF16_V3) && ws != nullptr &&
+    const bool v1 = t->flags & KGE_FLAG_BF16_V1;
+    if (!v1 && !(t->flags & KGE_FLAG_BF16_V3) && ws != nullptr &&
         pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
       const int rc = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr,
                                        ws, ws_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
@@ -216,14 +207,13 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
     }
     // v4 declined (no workspace, more than 32 row groups, fewer CUs than workgroups): the kernel with
     // the workgroup-local query build, same bits
-    if (!v1 && !v2 && !(t->flags & KGE_FLAG_BF16_V3) && pairs_bf16_v5_supported(t->scorer, t->dtype, d, A, R, TG)) {
+    if (!v1 && !(t->flags & KGE_FLAG_BF16_V3) && pairs_bf16_v5_supported(t->scorer, t->dtype, d, A, R, TG)) {
       const int rc = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr);
       if (rc != KGE_ERR_UNSUPPORTED) return rc;
     }
-    if (!v1 && !v2 && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))
+    if (!v1 && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))
       return run_pairs_bf16_v3(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
-    if (!v1 && pairs_bf16_v2_supported(t->scorer, t->dtype, d, A, R, TG))
-      return run_pairs_bf16_v2(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
+    // every other dim % 64 == 0 (64, 192, 320, ...): the tile-per-workgroup kernel
     if (pairs_bf16_supported(t->scorer, t->dtype, d, A, R, TG))
       return run_pairs_bf16(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
   }
@@ -314,7 +304,7 @@ int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n) {
 // ---- prepared queries (include/kge_amd.h) -----------------------------------------------------------------------
 static bool queries_supported(const kge_tables* t) {
   return t->dtype == KGE_BF16 && (t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT) &&
-         (t->dim == 256 || t->dim == 512) && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 |
+         (t->dim == 256 || t->dim == 512) && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 |
                                                            KGE_FLAG_BF16_V3));
 }
 
@@ -417,7 +407,7 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
   // one two-sided launch of the loader/consumer kernel when it applies: the query build, the
   // kernel start-up and the launch overhead are paid once for both score blocks
   if (t && workspace && n > 0 && m > 0 && out && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 |
-                                                                KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) &&
+                                                                KGE_FLAG_BF16_V3)) &&
       check_tables(t, true) == KGE_OK && check_index(s, false) == KGE_OK &&
       check_index(p, false) == KGE_OK && check_index(o, false) == KGE_OK &&
       check_index(targets, true) == KGE_OK && (targets.ptr || m == t->num_ent)) {
@@ -536,7 +526,7 @@ int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, co
     if (rcs != KGE_ERR_UNSUPPORTED) return rcs;
   }
   if (workspace && n > 0 && m > 0 &&
-      !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY)) &&
+      !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY)) &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
     const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr,
@@ -635,7 +625,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
     if (!sp_begin || !sp_end || !sp_col || !po_begin || !po_end || !po_col || !sp_begin[k] || !sp_end[k] ||
         !sp_col[k] || !po_begin[k] || !po_end[k] || !po_col[k])
       return KGE_ERR_INVALID_ARG;
-  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
+  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
     return KGE_ERR_UNSUPPORTED;  // (split queries: the counting epilogue sees one consumer wave's partial score)
   if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
       !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
@@ -1141,8 +1131,9 @@ int kge_debug_gemm16(int which, int lib, int d, int64_t rows, int64_t m, const v
                                out, scratch, scratch_bytes, (hipStream_t)stream);
 }
 
-// Not part of the public ABI (include/kge_amd.h): the row-persistent bf16 kernel with a
-// per-workgroup timestamp buffer (64 x u64 per workgroup) for tools/v2_phases.py.
+// Not part of the public ABI (include/kge_amd.h): score_sp of the bf16 matrix-core kernels with a per-workgroup
+// timestamp buffer (64 x u64 per workgroup) for tools/v2_phases.py / tools/prep_probe.py.  ablate 100 / 101:
+// prepared / prepared split queries (builder launch, then the stamped scoring launch); 0: the one-call path.
 int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, int64_t n,
                                int64_t m, float* out, int64_t ldo, unsigned long long* stamps,
                                int ablate, void* workspace, int64_t workspace_bytes,
@@ -1151,33 +1142,27 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
   if (rc) return rc;
   kge_index all{nullptr, KGE_I64, 0, 1};
   Operand A = ent_op(t, s), R = rel_op(t, p), TG = ent_op(t, all);
-  if (!pairs_bf16_v2_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) return KGE_ERR_UNSUPPORTED;
-  if (ablate == 100 || ablate == 101) {  // prepared queries (100) / split queries (101): builder launch, then the stamped scoring launch
+  if (!pairs_bf16_v3_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) return KGE_ERR_UNSUPPORTED;
+  if (ablate == 100 || ablate == 101) {
     if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) return KGE_ERR_UNSUPPORTED;
     return run_pairs_bf16_v4_prepared(t->scorer, ablate == 101, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, 0,
                                       (hipStream_t)stream, stamps, nullptr, workspace, workspace_bytes, 0, nullptr,
                                       nullptr, nullptr, 0, nullptr);
   }
-  if (ablate) {
-    if (t->scorer != KGE_COMPLEX || t->dim != 512) return KGE_ERR_UNSUPPORTED;
-    return run_pairs_bf16_v2_ablate(ablate, A, R, TG, n, m, out, ldo, (hipStream_t)stream, stamps);
-  }
+  if (ablate) return KGE_ERR_UNSUPPORTED;
   if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {
     const int rc5 = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, 0,
                                       (hipStream_t)stream, stamps);
     if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
   }
-  if (!(t->flags & (KGE_FLAG_BF16_V2 | KGE_FLAG_BF16_V3)) && workspace != nullptr &&
+  if (!(t->flags & KGE_FLAG_BF16_V3) && workspace != nullptr &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {
     const int rc4 = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
                                       0, (hipStream_t)stream, stamps, workspace, workspace_bytes,
                                       (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
     if (rc4 != KGE_ERR_UNSUPPORTED) return rc4;
   }
-  if (!(t->flags & KGE_FLAG_BF16_V2))
-    return run_pairs_bf16_v3(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
-                             (hipStream_t)stream, stamps, workspace, workspace_bytes);
-  return run_pairs_bf16_v2(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
+  return run_pairs_bf16_v3(t->scorer, A, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,
                            (hipStream_t)stream, stamps, workspace, workspace_bytes);
 }
 

@@ -16,6 +16,7 @@
 //     stores of tile t-1 in the second half, so the next step's counted vmcnt(8) waits for the
 //     tile and leaves the stores in flight.
 #include "common.hpp"
+#include <cstdlib>
 #include <atomic>
 #include <chrono>
 #include <type_traits>
@@ -150,59 +151,74 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
   // fly while pass p is built.
   bf16x8 afr[NKB];
   if constexpr (COOP) {
-    if (cg < nbuild) {  // this workgroup's share of the row group's query rows
-      constexpr int CGR = HH / 8;  // groups of 8 coordinates per row
-      for (int it = cg * 256 + tid; it < V3_ROWS * CGR; it += nbuild * 256) {
-        const long long row = (long long)rg * V3_ROWS + it / CGR;    // row of the fragment workspace
-        const long long lrow = (long long)rgl * V3_ROWS + it / CGR;  // query row within its side
-        const int c8 = it % CGR;
-        const long long qrow = lrow < n ? lrow : n - 1;  // padded rows repeat row n-1
-        const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + c8 * 8;
-        const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + c8 * 8;
-        const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
-        const u32x4 r0 = *reinterpret_cast<const u32x4*>(r), r1 = *reinterpret_cast<const u32x4*>(r + HH);
-        u32x4 q0, q1;
+    // one item = 8 coordinates of both halves of one query row, written fragment-major (K-block kb of 32-row block rb
+    // is 64 lanes x 16 B, contiguous) with agent-scope (sc1) write-through stores: visible to the other XCDs' L2s
+    // once acknowledged, without the whole-L2 write-back of a release fence.  A 128-byte line (8 rows x 16 B) is
+    // written by one workgroup only (or by several with the same bytes).
+    auto build_item = [&](int rr, int c8) __attribute__((always_inline)) {
+      const long long row = (long long)rg * V3_ROWS + rr;    // row of the fragment workspace
+      const long long lrow = (long long)rgl * V3_ROWS + rr;  // query row within its side
+      const long long qrow = lrow < n ? lrow : n - 1;        // padded rows repeat row n-1
+      const unsigned short* a = (const unsigned short*)A.base + index_at(A.idx, qrow) * A.ld + c8 * 8;
+      const unsigned short* r = (const unsigned short*)R.base + index_at(R.idx, qrow) * R.ld + c8 * 8;
+      const u32x4 a0 = *reinterpret_cast<const u32x4*>(a), a1 = *reinterpret_cast<const u32x4*>(a + HH);
+      const u32x4 r0 = *reinterpret_cast<const u32x4*>(r), r1 = *reinterpret_cast<const u32x4*>(r + HH);
+      u32x4 q0, q1;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          unsigned int x0, x1;
-          bf16_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
-          q0[e] = x0;
-          q1[e] = x1;
-        }
-        // fragment-major: K-block kb of 32-row block rb is 64 lanes x 16 B, contiguous
-        // Agent-scope (sc1) write-through stores: visible to the other XCDs' L2s once
-        // acknowledged, without the whole-L2 write-back of a release fence.  A 128-byte line
-        // (8 rows x 16 B) is written by one workgroup only.
-        u32x4* dst = qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
-        // s_nop: the two wait states a >64-bit VMEM store needs before its data registers may be overwritten
-        // (the hazard recogniser cannot see into inline asm)
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (c8 >> 1) * 64), "v"(q0) : "memory");
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (NKH + (c8 >> 1)) * 64), "v"(q1)
-                     : "memory");
+      for (int e = 0; e < 4; ++e) {
+        unsigned int x0, x1;
+        bf16_qpair<SCORER>(dir, a0[e], a1[e], r0[e], r1[e], x0, x1);
+        q0[e] = x0;
+        q1[e] = x1;
       }
+      u32x4* dst = qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
+      // s_nop: the two wait states a >64-bit VMEM store needs before its data registers may be overwritten
+      // (the hazard recogniser cannot see into inline asm)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (c8 >> 1) * 64), "v"(q0) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + (NKH + (c8 >> 1)) * 64), "v"(q1)
+                   : "memory");
+    };
+    constexpr int CGR = HH / 8;  // groups of 8 coordinates per row
+    if (cg < nbuild) {  // this workgroup's share of the row group's query rows
+      for (int it = cg * 256 + tid; it < V3_ROWS * CGR; it += nbuild * 256) build_item(it / CGR, it % CGR);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread: its stores are acknowledged ...
       __syncthreads();                                  // ... before thread 0 publishes
       if (tid == 0)
         __hip_atomic_store(flags + rg * 16 + cg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the workspace's degraded word (shared with the loader/consumer kernel, score_pairs_bf16_v4.hip): a COUNTDOWN of
+    // launches during which the hand-off is not tried; one thread per launch takes one off
+    unsigned long long* const degraded = flags + 512 * 8;
+    if (blockIdx.x == 0 && tid == 0) {
+      const unsigned long long v = __hip_atomic_load(degraded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != 0ull) __hip_atomic_store(degraded, v - 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     stamp();  // 1: share built and published
     tile_dma(0, 0);
     tile_dma(1, 1);
     stamp();  // 2: tiles 0, 1 issued
     {
+      // A consumer never trusts a builder blindly: the wait is bounded (a builder workgroup that is not running --
+      // its CU busy with another stream's kernel, CU masking, a second process -- must neither hang this wave nor
+      // kill the process).  On a time-out the wave builds the fragments of its own 32 rows itself, through the
+      // workspace with the builders' code (same bytes, so it does not matter who else writes them), and marks the
+      // workspace degraded: the next launches skip the hand-off at once.  Never a trap.
       const unsigned long long* f = flags + rg * 16;
-      for (int spin = 0;; ++spin) {
+      bool ok = nbuild > 0 && __hip_atomic_load(degraded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull;
+      for (int spin = 0; ok; ++spin) {
         const unsigned long long v =
             lane < nbuild ? __hip_atomic_load(f + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
         if (__all(v == epoch)) break;
-        // bounded (seconds): a lost builder must neither hang the GPU nor let this workgroup
-        // score with garbage -- abort the launch, the host sees a launch failure.  Not reachable by a
-        // co-residency shortfall: the builders are the workgroups cg < nbuild <= 8 of every row group,
-        // i.e. the first 8 * rgn block ids, and workgroups are dispatched in id order -- whenever a
-        // consumer runs, its builders were dispatched before it and wait for nobody.  (v4, the default
-        // path, additionally falls back to an in-register build after its time-out.)
-        if (spin == (1 << 21)) __builtin_trap();
+        if (spin == (1 << 16)) {  // ~0.1 s: far beyond any launch skew
+          ok = false;
+          if (lane == 0 && nbuild > 0)
+            __hip_atomic_store(degraded, 4096ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __builtin_amdgcn_s_sleep(4);
+      }
+      if (!ok) {  // slow (32 items per lane) and rare
+        for (int it = lane; it < 32 * CGR; it += 64) build_item(32 * wave + it / CGR, it % CGR);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       // No acquire fence (it would invalidate this CU's L1 and cost ~1.7 us): the builders
       // stored with sc1, the fragments are read with sc1 loads below (served by L2, never by L1).
@@ -730,6 +746,10 @@ static int launch_v3(const Operand& A, const Operand& R, const Operand& TG, int 
     nbuild = ncg < 16 ? ncg : 16;
     const int items = V3_ROWS * (HH / 8);  // at least one item per builder thread
     while (nbuild > 1 && nbuild * 256 > items) --nbuild;
+    // KGE_V4_OWN_BUILD=1 (tests): nobody builds for anybody -- every wave takes the path it otherwise only takes
+    // after a time-out or on a degraded workspace
+    const char* own = getenv("KGE_V4_OWN_BUILD");
+    if (own && own[0] == '1') nbuild = 0;
   }
 #define KGE_V3L(MODE)                                                                                 \
   if (coop)                                                                                           \

@@ -24,10 +24,23 @@ class _HipScorer(RelationalScorer):
         self._norm = float(self.get_option("l_norm")) if self.name in ("transe", "rotate") else 1.0
 
     def score_emb(self, s_emb, p_emb, o_emb, combine: str):
+        if not p_emb.is_cuda and combine in ("spo", "sp_", "_po"):
+            # `job.device: cpu` (BASELINE configs[0], examples/toy-complex-train.yaml on CPU): there is no HIP
+            # device to score on, and the class this one stands in for is right there -- the REFERENCE scorer's own
+            # score_emb (complex.py:18-43, ...) on this object (it reads nothing but `_norm`).  Not the oracle.
+            return self._reference_scorer().score_emb(self, s_emb, p_emb, o_emb, combine)
         if combine in ("spo", "sp_", "_po"):
             n = p_emb.size(0)
             return _ScoreEmb.apply(self.name, combine, self._norm, s_emb, p_emb, o_emb).view(n, -1)
         return super().score_emb(s_emb, p_emb, o_emb, combine)
+
+    def _reference_scorer(self):
+        from kge.model.complex import ComplExScorer
+        from kge.model.distmult import DistMultScorer
+        from kge.model.rotate import RotatEScorer
+        from kge.model.transe import TransEScorer
+        return {"complex": ComplExScorer, "distmult": DistMultScorer, "transe": TransEScorer,
+                "rotate": RotatEScorer}[self.name]
 
 
 class HipComplExScorer(_HipScorer):
@@ -54,6 +67,8 @@ class _FusedScoring:
         from kge.model import LookupEmbedder
         se, oe, pe = self.get_s_embedder(), self.get_o_embedder(), self.get_p_embedder()
         if se is not oe or type(se) is not LookupEmbedder or type(pe) is not LookupEmbedder:
+            return False
+        if not se._embeddings.weight.is_cuda:  # job.device: cpu -> KgeModel.score_* with the reference scorer's arithmetic
             return False
         return not (self.training and (se.dropout.p > 0 or pe.dropout.p > 0))
 

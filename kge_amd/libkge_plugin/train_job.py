@@ -1,6 +1,6 @@
 """TrainingJob1vsAll / TrainingJobKvsAll with the kl or bce loss fused into the scoring kernel
-(train.type: hip_1vsAll / hip_KvsAll) and TrainingJobNegativeSampling with the negatives scored by
-the fused gather + score kernel (train.type: hip_negative_sampling)."""
+(train.type: hip_1vsAll / hip_KvsAll) and TrainingJobNegativeSampling with the negatives of the
+per-triple sampler scored by the fused gather + score kernel (train.type: hip_negative_sampling)."""
 import time
 
 import torch
@@ -34,7 +34,7 @@ def _declined_late(what):
 from kge.job import Job
 from kge.job.train_1vsAll import TrainingJob1vsAll
 from kge.job.train_KvsAll import TrainingJobKvsAll
-from kge.job.train_negative_sampling import SLOT_STR, TrainingJobNegativeSampling, S, P, O
+from kge.job.train_negative_sampling import TrainingJobNegativeSampling, S, P, O
 from kge.util.loss import BCEWithLogitsKgeLoss, KLDivWithSoftmaxKgeLoss
 
 
@@ -184,16 +184,38 @@ class HipTrainingJobKvsAll(TrainingJobKvsAll):
             result.backward_time += time.time()
 
 
+class _FusedNegativeScore:
+    """Stands in for `BatchNegativeSample.score` (sampler.py:263-344) of ONE slot's sample object for the
+    duration of a subbatch: the same call, the same `forward_time` / `prepare_time` attributes -- the negatives
+    go to the model's `score_neg` as (positives, neg [n, K]).  Declined by the model: the sampler's own code."""
+
+    def __init__(self, sample, slot):
+        self._sample, self._slot, self._score = sample, slot, sample.score
+
+    def __call__(self, model, indexes=None):
+        smp = self._sample
+        smp.forward_time = smp.prepare_time = 0.0
+        smp.prepare_time -= time.time()
+        neg = smp.samples(indexes)
+        tri = smp.positive_triples[indexes, :] if indexes else smp.positive_triples
+        smp.prepare_time += time.time()
+        smp.forward_time -= time.time()
+        scores = model.score_neg(tri[:, S], tri[:, P], tri[:, O], self._slot, neg)
+        smp.forward_time += time.time()
+        return scores if scores is not None else self._score(model, indexes=indexes)
+
+
 class HipTrainingJobNegativeSampling(TrainingJobNegativeSampling):
-    """Overrides only `_process_subbatch` (train_negative_sampling.py:103-164).  The reference scores
-    a slot's negatives through `BatchNegativeSample.score` (sampler.py:263-344): implementation
-    "triple" builds an [n*K, 3] index tensor and gathers three [n*K, d] row sets for score_spo,
-    "batch" / "all" score against the unique samples and pick entries out of an [n, U] matrix.
-    Here the subject- and object-slot negatives of a model that offers `score_neg` (the hip_* models)
-    go to kge_score_neg as (positives, neg [n, K]) directly: the relation row and the uncorrupted
-    entity row of each positive are read once, only the corrupted rows stream, and
-    the backward accumulates straight into the table gradients (kge_score_neg_bwd_accum).  Labels,
-    loss, averaging, timing keys and the relation slot (score_so) stay the reference's code."""
+    """`_process_subbatch` is the reference's (train_negative_sampling.py:103-164), called unchanged: labels,
+    positive scores, loss, averaging, backward and every timing key are its code.  What changes is what
+    `batch["negative_samples"][slot].score` does for the subject and object slots of a model that offers
+    `score_neg` (the hip_* models) when the samples are the per-triple kind (DefaultBatchNegativeSample,
+    sampler.py:359-380): instead of an [n*K, 3] index tensor and three [n*K, d] gathers for score_spo
+    ("triple"), or an [n, U] matrix against the unique samples ("batch" / "all"), the relation row and the
+    uncorrupted entity row of each positive are read once and only the corrupted rows stream (kge_score_neg,
+    SURVEY 8f N2); the backward accumulates straight into the table gradients (kge_score_neg_bwd_accum).
+    Shared samples (NaiveShared / DefaultShared: their own `score`, which never materialises [n, K] samples)
+    and the relation slot stay the sampler's code."""
 
     def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
         super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
@@ -203,43 +225,16 @@ class HipTrainingJobNegativeSampling(TrainingJobNegativeSampling):
                 f(self)
 
     def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
-        if not hasattr(self.model, "score_neg"):
+        swapped = []
+        if hasattr(self.model, "score_neg"):
+            from kge.util.sampler import DefaultBatchNegativeSample
+            for slot in (S, O):
+                smp = batch["negative_samples"][slot]
+                if self._sampler.num_samples[slot] > 0 and type(smp) is DefaultBatchNegativeSample:
+                    smp.score = _FusedNegativeScore(smp, slot)  # instance attribute: shadows the method
+                    swapped.append(smp)
+        try:
             return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
-        batch_size = result.size
-        result.prepare_time -= time.time()
-        triples = batch["triples"][subbatch_slice]
-        batch_negative_samples = batch["negative_samples"]
-        subbatch_size = len(triples)
-        result.prepare_time += time.time()
-        labels = batch["labels"]  # reuse b/w subbatches
-        for slot in [S, P, O]:
-            num_samples = self._sampler.num_samples[slot]
-            if num_samples <= 0:
-                continue
-            if labels[slot] is None or labels[slot].shape != (subbatch_size, 1 + num_samples):
-                result.prepare_time -= time.time()
-                labels[slot] = torch.zeros((subbatch_size, 1 + num_samples), device=self.device)
-                labels[slot][:, 0] = 1
-                result.prepare_time += time.time()
-            result.forward_time -= time.time()
-            scores = torch.empty((subbatch_size, num_samples + 1), device=self.device)
-            scores[:, 0] = self.model.score_spo(triples[:, S], triples[:, P], triples[:, O],
-                                                direction=SLOT_STR[slot])
-            neg_scores = None
-            if slot != P:
-                neg_scores = self.model.score_neg(triples[:, S], triples[:, P], triples[:, O], slot,
-                                                  batch_negative_samples[slot].samples(subbatch_slice))
-            result.forward_time += time.time()
-            if neg_scores is None:  # relation slot, or the model declined: the sampler's own scoring
-                neg_scores = batch_negative_samples[slot].score(self.model, indexes=subbatch_slice)
-                result.forward_time += batch_negative_samples[slot].forward_time
-                result.prepare_time += batch_negative_samples[slot].prepare_time
-            scores[:, 1:] = neg_scores
-            result.forward_time -= time.time()
-            loss_value_torch = self.loss(scores, labels[slot], num_negatives=num_samples) / batch_size
-            result.avg_loss += loss_value_torch.item()
-            result.forward_time += time.time()
-            result.backward_time -= time.time()
-            if not self.is_forward_only:
-                loss_value_torch.backward()
-            result.backward_time += time.time()
+        finally:
+            for smp in swapped:
+                del smp.score

@@ -71,8 +71,17 @@ class Adagrad(_TorchAdagrad):
         s = state["sum"]
         copy = None
         if self.bf16_copies:
-            rec = getattr(p, BF16_ATTR, None)
-            copy = rec[0] if rec is not None and rec[0].shape == p.shape else p.detach().to(torch.bfloat16)
+            # only the touched rows are rewritten below: the copy must be FRESH before (a parameter changed behind
+            # the optimizer's back -- load_state_dict into the same Parameter, a re-init, a dense torch step --
+            # leaves every other row stale); a stale or missing one is re-cast once, into the old buffer if it fits
+            copy = bf16_copy_of(p)
+            if copy is None:
+                rec = getattr(p, BF16_ATTR, None)
+                if rec is not None and rec[0].shape == p.shape and rec[0].data_ptr() != 0:
+                    copy = rec[0]
+                    copy.copy_(p.detach())
+                else:
+                    copy = p.detach().to(torch.bfloat16)
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().kge_adagrad_step_rows(
                 p.data_ptr(), p.stride(0), vals.data_ptr(), vals.stride(0), s.data_ptr(), s.stride(0), rows.data_ptr(),

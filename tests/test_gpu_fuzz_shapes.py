@@ -70,7 +70,7 @@ def test_random_shape(seed):
     assert (np.abs(got_sp - want_sp) <= 1e-5 * rms + 1e-4 * np.abs(want_sp)).all(), tag
 
     # every kernel generation: the same bits
-    for name, flags, ws in (("v3", eng.FLAG_BF16_V3, True), ("v2", eng.FLAG_BF16_V2, True), ("no workspace", 0, False)):
+    for name, flags, ws in (("v3", eng.FLAG_BF16_V3, True), ("v3 without a workspace", eng.FLAG_BF16_V3, False), ("no workspace", 0, False)):
         Tv = eng.Tables(model, e16, r16, 1.0, flags, use_workspace=ws)
         assert torch.equal(eng.score_sp(Tv, ts, tp), sp), (tag, name)
         assert torch.equal(eng.score_sp_po(Tv, ts, tp, to), both), (tag, name, "two-sided")

@@ -181,3 +181,29 @@ def test_adagrad_row_sparse_gradients_match_torch():
                                    rtol=2e-6, atol=1e-30)
     c = bf16_copy_of(emb_got.weight)
     assert c is not None and torch.equal(c, emb_got.weight.detach().to(torch.bfloat16))
+
+
+def test_adagrad_row_sparse_step_refreshes_a_stale_bf16_copy():
+    """A parameter changed behind the optimizer's back (checkpoint loaded into the same Parameter, re-init, a dense
+    torch step) makes the bf16 copy stale; the row-sparse step rewrites only the touched rows, so it must re-cast
+    the copy first -- otherwise every other row would score with the OLD embeddings."""
+    from kge_amd.optim import Adagrad, bf16_copy_of
+    torch.manual_seed(5)
+    E, d = 800, 64
+    emb = torch.nn.Embedding(E, d, sparse=True, device=DEV)
+    opt = Adagrad(emb.parameters(), lr=0.1, bf16_copies=True)
+
+    def sparse_step():
+        idx = torch.randint(E, (50,), device=DEV)
+        opt.zero_grad()
+        emb(idx).sum().backward()
+        opt.step()
+
+    sparse_step()
+    assert torch.equal(bf16_copy_of(emb.weight), emb.weight.detach().to(torch.bfloat16))
+    with torch.no_grad():  # the whole table changes outside the optimizer
+        emb.weight.copy_(torch.randn(E, d, device=DEV))
+    assert bf16_copy_of(emb.weight) is None
+    sparse_step()
+    c = bf16_copy_of(emb.weight)
+    assert c is not None and torch.equal(c, emb.weight.detach().to(torch.bfloat16))

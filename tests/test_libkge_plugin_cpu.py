@@ -40,12 +40,20 @@ def test_plugin_is_discovered_and_keeps_parameter_names(model):
                                            "_relation_embedder._embeddings.weight"]
     e, r = m.state_dict().values()
     assert e.shape == (30, 16) and r.shape == (4, 8 if model == "hip_rotate" else 16)
-    assert m._fused()
+    # job.device: cpu (BASELINE configs[0]): no HIP device -- the plugin classes subclass the reference's KgeModel,
+    # and on CPU tensors they ARE the reference: KgeModel.score_* with the reference scorer's own score_emb
+    assert not m._fused()
+    ref_config = _config(model[4:])
+    ref = KgeModel.create(ref_config, Dataset(ref_config, folder=None))
+    ref.load_state_dict(m.state_dict())
     s, p, o = torch.tensor([1, 2]), torch.tensor([0, 3]), torch.tensor([5, 6])
-    for call in (lambda: m.score_sp(s, p), lambda: m.score_po(p, o), lambda: m.score_spo(s, p, o),
-                 lambda: m.score_sp_po(s, p, o)):
-        with pytest.raises(RuntimeError, match="no CPU path"):
-            call()
+    for call in (lambda mm: mm.score_sp(s, p), lambda mm: mm.score_po(p, o), lambda mm: mm.score_spo(s, p, o),
+                 lambda mm: mm.score_sp_po(s, p, o), lambda mm: mm.score_so(s, o)):
+        assert torch.equal(call(m), call(ref))
+    # the engine itself has no CPU path (and the oracle is never one)
+    from kge_amd import engine
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        engine.Tables(model[4:], e, r)
 
 
 @pytest.mark.parametrize("model", MODELS)
@@ -321,3 +329,79 @@ def test_negative_sampling_job_follows_the_reference_job(tmp_path, model):
     assert abs(l_ref - l_hip) <= 1e-6 * max(1.0, abs(l_ref)), (l_ref, l_hip)
     for a, b in zip(p_ref, p_hip):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("shared_type", ["naive", "default"])
+def test_negative_sampling_with_shared_samples_keeps_the_samplers_scoring(tmp_path, shared_type):
+    """negative_sampling.shared: true -- the reference resolves implementation "auto" to "batch" and the shared
+    sample objects score without ever materialising per-triple samples (NaiveSharedNegativeSample.samples even
+    fails on a slice: sampler.py:412-426).  hip_negative_sampling must leave those objects alone: same loss and
+    parameters as the reference job, score_neg never called."""
+    import os
+    import random
+    import shutil
+    import types
+    import numpy as np
+    rh.import_reference()
+    from kge import Dataset
+    from kge.job import TrainingJob
+    data = os.path.join(str(tmp_path), "dataset_test")
+    shutil.copytree(os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test"), data)
+    calls = []
+
+    def score_neg(self, s, p, o, slot, neg):
+        calls.append(slot)
+        return None
+
+    results = {}
+    for train_type in ("negative_sampling", "hip_negative_sampling"):
+        config = _job_config(str(tmp_path), "distmult", train_type)
+        config.set("negative_sampling.num_samples.s", 4)
+        config.set("negative_sampling.num_samples.o", 3)
+        config.set("negative_sampling.shared", True)
+        config.set("negative_sampling.shared_type", shared_type)
+        torch.manual_seed(21)
+        job = TrainingJob.create(config, Dataset.create(config, folder=data))
+        if train_type.startswith("hip_"):
+            job.model.score_neg = types.MethodType(score_neg, job.model)
+        torch.manual_seed(22)
+        np.random.seed(23)   # (the shared samplers draw with numpy / random: sampler.py:640-700)
+        random.seed(24)
+        job._prepare()
+        trace = job.run_epoch()
+        results[train_type] = (trace["avg_loss"], [x.detach().clone() for x in job.model.parameters()])
+    assert calls == []
+    (l_ref, p_ref), (l_hip, p_hip) = results["negative_sampling"], results["hip_negative_sampling"]
+    assert abs(l_ref - l_hip) <= 1e-6 * max(1.0, abs(l_ref)), (l_ref, l_hip)
+    for a, b in zip(p_ref, p_hip):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("model,train_type", [("complex", "1vsAll"), ("distmult", "KvsAll"),
+                                              ("rotate", "negative_sampling"), ("transe", "negative_sampling")])
+def test_hip_models_train_on_cpu_like_the_reference_models(tmp_path, model, train_type):
+    """BASELINE.json configs[0] (examples/toy-complex-train.yaml with --job.device cpu; here on tests/data/dataset_test,
+    the toy dataset is not shipped): `model: hip_<m>` trained and evaluated on CPU gives the losses, parameters and
+    metrics of `model: <m>` -- without a HIP device the plugin classes are the reference classes they subclass."""
+    import os
+    import shutil
+    rh.import_reference()
+    from kge import Dataset
+    from kge.job import TrainingJob
+    data = os.path.join(str(tmp_path), "dataset_test")
+    shutil.copytree(os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test"), data)
+    results = {}
+    for name in (model, "hip_" + model):
+        config = _job_config(str(tmp_path), name, train_type)
+        config.set("valid.every", 1)
+        config.set("eval.batch_size", 16)
+        torch.manual_seed(31)
+        job = TrainingJob.create(config, Dataset.create(config, folder=data))
+        torch.manual_seed(32)
+        job.run()
+        results[name] = (job.valid_trace[0], [x.detach().clone() for x in job.model.parameters()])
+    (v_ref, p_ref), (v_hip, p_hip) = results[model], results["hip_" + model]
+    for a, b in zip(p_ref, p_hip):
+        assert torch.equal(a, b)
+    for key in ("mean_reciprocal_rank", "mean_reciprocal_rank_filtered", "hits_at_1_filtered"):
+        assert v_ref[key] == v_hip[key], key

@@ -67,7 +67,6 @@ def main():
             ("complex", torch.bfloat16, 0, "bf16-mfma"),
             ("complex", torch.bfloat16, engine.FLAG_BF16_V3, "bf16-mfma-v3-coop"),
             ("complex", torch.bfloat16, -1, "bf16-mfma-v3-noworkspace"),
-            ("complex", torch.bfloat16, engine.FLAG_BF16_V2, "bf16-mfma-v2"),
             ("complex", torch.bfloat16, engine.FLAG_BF16_V1, "bf16-mfma-v1"),
             ("distmult", torch.bfloat16, 0, "bf16-mfma"),
             ("complex", torch.bfloat16, engine.FLAG_EXACT, "bf16-exact-f32mfma"),

@@ -102,5 +102,4 @@ if __name__ == "__main__":
         run(n, use_ws=ws)
     print("==== v3 (single role, cooperative build) n=512 workspace=True")
     run(512, use_ws=True, flags=16)
-    print("==== v2 (32-target tiles) n=512, fused")
-    run(512, flags=8)
+
