@@ -11,7 +11,8 @@ int run_spo(int scorer, int dtype, bool neg_mode, const Operand& S, const Operan
             long long ldo, hipStream_t st);
 int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, const Operand& R,
                     const Operand& TG, int dir, int d, int dr, long long n, long long m,
-                    float lp, float* out, long long ldo, hipStream_t st, bool round_query = true);
+                    float lp, float* out, long long ldo, hipStream_t st, bool round_query = true,
+                    const RankArgs* rk = nullptr);
 bool pairs_bf16_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
                           const Operand& TG);
 int run_pairs_bf16(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
@@ -113,6 +114,7 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
                const float* label_weight = nullptr, const float* label_bias = nullptr);
 void set_g16_dbg(unsigned long long* p);
 void v6_set_stamps(unsigned long long* p);
+bool pairs_bf16_v4_rank_launchable(int d, long long n, long long m, long long ws_bytes);
 int run_debug_gemm16(int which, int lib, int d, long long rows, long long m, const unsigned short* X, long long ldx,
                      const unsigned short* G16, long long mp, float* out, float* scratch, long long scratch_bytes,
                      hipStream_t st);
@@ -625,12 +627,22 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
     if (!sp_begin || !sp_end || !sp_col || !po_begin || !po_end || !po_col || !sp_begin[k] || !sp_end[k] ||
         !sp_col[k] || !po_begin[k] || !po_end[k] || !po_col[k])
       return KGE_ERR_INVALID_ARG;
-  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
-    return KGE_ERR_UNSUPPORTED;  // (split queries: the counting epilogue sees one consumer wave's partial score)
-  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
-      !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
-    return KGE_ERR_UNSUPPORTED;
-  if (!workspace || ((uintptr_t)workspace & 15)) return KGE_ERR_WORKSPACE;
+  // Which kernel counts -- always the one whose store path kge_score_sp_po would take for these tables, so that the
+  // counts are those of the two-step path bit for bit:
+  //   bf16 ComplEx / DistMult, d in {256, 512}, default flags: the loader/consumer kernel's counting epilogue;
+  //   float32 tables (any scorer), TransE / RotatE (any dtype), bf16 under KGE_FLAG_EXACT: the exact kernels'
+  //   (score_pairs.hip, score_pairs_f32.hip: rank_tile_rows), one launch per side;
+  //   everything else (bf16 at other dims, split queries -- whose partial scores sit in two consumer waves):
+  //   KGE_ERR_UNSUPPORTED, the caller scores and scans.
+  const bool dot = t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT;
+  const bool exact_path = t->dtype == KGE_F32 || !dot || (t->flags & KGE_FLAG_EXACT);
+  if (t->flags & (KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY)) return KGE_ERR_UNSUPPORTED;
+  if (!exact_path) {
+    if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
+        !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
+      return KGE_ERR_UNSUPPORTED;
+    if (!workspace || ((uintptr_t)workspace & 15)) return KGE_ERR_WORKSPACE;
+  }
   const int64_t bld = rank_bits_ld(m);
   if (num_filters > 0 && (!filter_bits || ((uintptr_t)filter_bits & 7) ||
                           filter_bits_bytes < kge_score_rank_bits_bytes(n, m, num_filters)))
@@ -665,6 +677,25 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   hipStream_t st = (hipStream_t)stream;
   int rc = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 1, st);
   if (rc) return rc;
+  if (exact_path) {
+    for (int side = 0; side < 2 && rc == KGE_OK; ++side) {
+      RankArgs rk{};
+      rk.tru = ce.rk_true[side];
+      rk.rank = ce.rk_rank[side];
+      rk.ties = ce.rk_ties[side];
+      rk.ld = ld;
+      rk.atol = atol;
+      rk.rtol = rtol;
+      rk.nfilt = num_filters;
+      rk.bits_ld = bld;
+      for (int k = 0; k < num_filters; ++k) rk.bits[k] = ce.rk_bits[side][k];
+      rc = run_pairs_exact(t->scorer, t->dtype, !(t->flags & KGE_FLAG_NO_MFMA), side ? O : S, P, TG,
+                           side ? KGE_PO_ : KGE_SP_, (int)t->dim, (int)t->rel_dim, n, m, t->l_norm, nullptr, 1, st,
+                           /*round_query=*/true, &rk);
+    }
+    const int rcb = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+    return rc != KGE_OK ? rc : rcb;
+  }
   // one launch holds at most 32 row groups (one workgroup per CU and XCD-aligned column groups): 2,048 rows per
   // side; larger batches go through in row blocks
   const int esize = t->dtype == KGE_BF16 ? 2 : 4;
@@ -675,6 +706,11 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
     return y;
   };
   constexpr int64_t BLOCK = 2048;
+  for (int64_t r0 = 0; r0 < n; r0 += BLOCK)  // every block's launch geometry first: decline before anything counts
+    if (!pairs_bf16_v4_rank_launchable((int)t->dim, n - r0 < BLOCK ? n - r0 : BLOCK, m, workspace_bytes)) {
+      const int rcb = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+      return rcb != KGE_OK ? rcb : KGE_ERR_UNSUPPORTED;
+    }
   for (int64_t r0 = 0; r0 < n && rc == KGE_OK; r0 += BLOCK) {
     const int64_t nb = n - r0 < BLOCK ? n - r0 : BLOCK;
     CeArgs cb = ce;

@@ -386,4 +386,60 @@ __device__ __forceinline__ void count_one(float x, float t, float atol, float rt
   gt += (x > t && !c) ? 1 : 0;
 }
 
+// ---- counting epilogue of the exact pair kernels (score_pairs.hip, score_pairs_f32.hip): kge_score_rank_sp_po for
+// float32 tables and for TransE / RotatE.  One side of the batch per launch.
+struct RankArgs {
+  const float* tru;                   // [n] true score of row i
+  unsigned long long* rank;           // [nfilt + 1][ld] ACCUMULATED: row 0 raw, row k + 1 filter set k
+  unsigned long long* ties;
+  long long ld;
+  float atol, rtol;
+  int nfilt;                          // <= 2
+  const unsigned long long* bits[2];  // bit (j & 63) of word [i * bits_ld + (j >> 6)]: column j is filtered for row i
+  long long bits_ld;
+};
+
+// A finished ROWS x COLS score tile sits in LDS (`tile`, row pitch LDT floats).  256 threads: thread t takes the W =
+// COLS * ROWS / 256 columns [seg * W, ...) of tile row t / SEGS -- W in {16, 64} divides 64 and the tile's first
+// column is a multiple of COLS, so the thread's columns lie inside ONE 64-bit filter word per filter set -- and
+// counts them against the row's true score with the arithmetic of rank.hip (count_one; a filtered column scores
+// -inf): per row, ranking and segment at most two int64 atomics leave the workgroup; no score does.
+template <int ROWS, int COLS, int LDT>
+__device__ __forceinline__ void rank_tile_rows(const float* tile, long long row0, long long col0, long long n,
+                                               long long m, const RankArgs& rk, int tid) {
+  constexpr int SEGS = 256 / ROWS, W = COLS / SEGS;
+  static_assert(W == 16 || W == 64, "segment = 16 or 64 columns");
+  const int row = tid / SEGS, seg = tid % SEGS;
+  const long long orow = row0 + row;
+  if (orow >= n) return;
+  float t = rk.tru[orow];
+  if (t != t) t = -__builtin_inff();
+  const long long c0 = col0 + seg * W;  // first column of the segment (relative to the scored slice)
+  if (c0 >= m) return;
+  unsigned long long gm = 0ull, cm = 0ull, vm = 0ull;
+  const float* src = tile + row * LDT + seg * W;
+#pragma unroll 8
+  for (int c = 0; c < W; ++c) {
+    if (c0 + c < m) {
+      int g = 0, cl = 0;
+      count_one(src[c], t, rk.atol, rk.rtol, g, cl);
+      gm |= (unsigned long long)g << c;
+      cm |= (unsigned long long)cl << c;
+      vm |= 1ull << c;
+    }
+  }
+  const int G = __builtin_popcountll(gm), C = __builtin_popcountll(cm);
+  if (G) atomicAdd(rk.rank + orow, (unsigned long long)G);
+  if (C) atomicAdd(rk.ties + orow, (unsigned long long)C);
+  const int fc = t == -__builtin_inff() ? 1 : 0;  // is -inf (a filtered column's score) close to the true score
+  const int sh = (int)(c0 & 63);
+  for (int k = 0; k < rk.nfilt; ++k) {
+    const unsigned long long w = (rk.bits[k][orow * rk.bits_ld + (c0 >> 6)] >> sh) & vm;
+    const int Gk = G - __builtin_popcountll(gm & w);
+    const int Ck = C - __builtin_popcountll(cm & w) + fc * __builtin_popcountll(w);
+    if (Gk) atomicAdd(rk.rank + (k + 1) * rk.ld + orow, (unsigned long long)Gk);
+    if (Ck) atomicAdd(rk.ties + (k + 1) * rk.ld + orow, (unsigned long long)Ck);
+  }
+}
+
 }  // namespace kge

@@ -32,14 +32,17 @@ __device__ __forceinline__ f32x4 load4(const T* row, int c, int limit) {
   return r;
 }
 
-template <int SCORER, typename T, int NORM, bool VEC, bool MFMA>
+// RANK: counts against the rows' true scores instead of stored scores (rank_tile_rows, common.hpp; the finished
+// tile goes through the operand buffers: 64 x 68 floats, exactly their size).
+template <int SCORER, typename T, int NORM, bool VEC, bool MFMA, bool RANK>
 __global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operand TG, int dir,
                                                     int d, int dr, long long n, long long m,
                                                     float lp, int round_q,
-                                                    float* __restrict__ out, long long ldo) {
+                                                    float* __restrict__ out, long long ldo, RankArgs rk) {
   constexpr bool DOT = (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT);
-  __shared__ __attribute__((aligned(16))) float Qs[2][PT_KC][PT_LD];
-  __shared__ __attribute__((aligned(16))) float Ts[2][PT_KC][PT_LD];
+  __shared__ __attribute__((aligned(16))) float QT[2][2][PT_KC][PT_LD];  // one object: the RANK epilogue reuses it
+  auto& Qs = QT[0];
+  auto& Ts = QT[1];
 
   const int tid = threadIdx.x;
   const long long col0 = (long long)blockIdx.x * PT_BN;
@@ -150,6 +153,31 @@ __global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operan
     __syncthreads();
   }
 
+  if constexpr (RANK) {
+    static_assert(sizeof(QT) >= PT_BM * PT_LD * 4, "the score tile fits the operand buffers");
+    float* const tile = &QT[0][0][0][0];  // [64][PT_LD]; the loop ended with a barrier
+    if (DOT && MFMA) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        tile[(32 * (wave >> 1) + (r & 3) + 8 * (r >> 2) + 4 * mh) * PT_LD + 32 * (wave & 1) + (lane & 31)] = macc[r];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = acc[i][j];
+          if (!DOT) {
+            if (NORM == NORM_L1) v = -v;
+            else if (NORM == NORM_L2) v = -__builtin_sqrtf(v);
+            else v = -powf(v, 1.0f / lp);
+          }
+          tile[(ty * 4 + i) * PT_LD + tx * 4 + j] = v;
+        }
+    }
+    __syncthreads();
+    rank_tile_rows<PT_BM, PT_BN, PT_LD>(tile, row0, col0, n, m, rk, tid);
+    return;
+  }
   if (DOT && MFMA) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -195,12 +223,18 @@ static bool pairs_vec_ok(int dtype, int d, int dr, int scorer, const Operand& A,
 template <int SCORER, typename T, int NORM>
 static int launch_pairs(bool vec, bool mfma, const Operand& A, const Operand& R,
                         const Operand& TG, int dir, int d, int dr, long long n, long long m,
-                        float lp, int round_q, float* out, long long ldo, hipStream_t st) {
+                        float lp, int round_q, float* out, long long ldo, hipStream_t st, const RankArgs* rk) {
   dim3 grid((unsigned)((m + PT_BN - 1) / PT_BN), (unsigned)((n + PT_BM - 1) / PT_BM));
   constexpr bool DOT = (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT);
-#define KGE_PL(VEC, MF)                                                                       \
-  hipLaunchKernelGGL((pairs_kernel<SCORER, T, NORM, VEC, MF>), grid, dim3(256), 0, st, A, R, \
-                     TG, dir, d, dr, n, m, lp, round_q, out, ldo)
+#define KGE_PL(VEC, MF)                                                                               \
+  do {                                                                                                \
+    if (rk != nullptr)                                                                                \
+      hipLaunchKernelGGL((pairs_kernel<SCORER, T, NORM, VEC, MF, true>), grid, dim3(256), 0, st, A, R, \
+                         TG, dir, d, dr, n, m, lp, round_q, out, ldo, *rk);                           \
+    else                                                                                              \
+      hipLaunchKernelGGL((pairs_kernel<SCORER, T, NORM, VEC, MF, false>), grid, dim3(256), 0, st, A, R, \
+                         TG, dir, d, dr, n, m, lp, round_q, out, ldo, RankArgs{});                     \
+  } while (0)
   if constexpr (DOT) {
     if (mfma) {
       if (vec) KGE_PL(true, true); else KGE_PL(false, true);
@@ -217,31 +251,33 @@ static int launch_pairs(bool vec, bool mfma, const Operand& A, const Operand& R,
 template <int SCORER, typename T>
 static int pairs_norm(int norm, bool vec, bool mfma, const Operand& A, const Operand& R,
                       const Operand& TG, int dir, int d, int dr, long long n, long long m,
-                      float lp, int round_q, float* out, long long ldo, hipStream_t st) {
+                      float lp, int round_q, float* out, long long ldo, hipStream_t st, const RankArgs* rk) {
   if constexpr (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT) {
     return launch_pairs<SCORER, T, NORM_L1>(vec, mfma, A, R, TG, dir, d, dr, n, m, lp, round_q,
-                                            out, ldo, st);
+                                            out, ldo, st, rk);
   } else {
     if (norm == NORM_L1)
       return launch_pairs<SCORER, T, NORM_L1>(vec, mfma, A, R, TG, dir, d, dr, n, m, lp, 0, out,
-                                              ldo, st);
+                                              ldo, st, rk);
     if (norm == NORM_L2)
       return launch_pairs<SCORER, T, NORM_L2>(vec, mfma, A, R, TG, dir, d, dr, n, m, lp, 0, out,
-                                              ldo, st);
+                                              ldo, st, rk);
     return launch_pairs<SCORER, T, NORM_LP>(vec, mfma, A, R, TG, dir, d, dr, n, m, lp, 0, out,
-                                            ldo, st);
+                                            ldo, st, rk);
   }
 }
 
 int run_pairs_f32(int scorer, int dtype, const Operand& A, const Operand& R, const Operand& TG, int dir, int d,
-                  long long n, long long m, int round_q, float* out, long long ldo, hipStream_t st);
+                  long long n, long long m, int round_q, float* out, long long ldo, hipStream_t st,
+                  const RankArgs* rk);
 
 // exact (canonical f32) pair scoring for every scorer / dtype / dimension
 // round_query = false (KGE_FLAG_SPLIT_QUERY's fallback): bf16 tables widened, the query vector kept in f32 --
 // f32 arithmetic on the bf16 table values, the bits of the oracle on the widened tables
+// rk != NULL: the counting epilogue instead of the score store (`out` is not touched)
 int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, const Operand& R,
                     const Operand& TG, int dir, int d, int dr, long long n, long long m,
-                    float lp, float* out, long long ldo, hipStream_t st, bool round_query) {
+                    float lp, float* out, long long ldo, hipStream_t st, bool round_query, const RankArgs* rk) {
   if (n == 0 || m == 0) return KGE_OK;
   const bool cplx = scorer == KGE_COMPLEX || scorer == KGE_ROTATE;
   if (cplx && (d % 2)) return KGE_ERR_INVALID_ARG;
@@ -252,15 +288,15 @@ int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, cons
   // ComplEx / DistMult on the f32 matrix cores: 128 x 128 tiles (score_pairs_f32.hip) unless the
   // batch is too small to fill them; same chain order, same bits
   if ((scorer == KGE_COMPLEX || scorer == KGE_DISTMULT) && use_mfma && vec && n > 64 && m > 64) {
-    const int rc = run_pairs_f32(scorer, dtype, A, R, TG, dir, d, n, m, round_q, out, ldo, st);
+    const int rc = run_pairs_f32(scorer, dtype, A, R, TG, dir, d, n, m, round_q, out, ldo, st, rk);
     if (rc != KGE_ERR_UNSUPPORTED) return rc;
   }
 #define KGE_DT(SC)                                                                            \
   return dtype == KGE_BF16                                                                    \
              ? pairs_norm<SC, unsigned short>(norm, vec, use_mfma, A, R, TG, dir, d, dr, n, m, \
-                                              lp, round_q, out, ldo, st)                       \
+                                              lp, round_q, out, ldo, st, rk)                   \
              : pairs_norm<SC, float>(norm, vec, use_mfma, A, R, TG, dir, d, dr, n, m, lp,      \
-                                     round_q, out, ldo, st)
+                                     round_q, out, ldo, st, rk)
   switch (scorer) {
     case KGE_COMPLEX: KGE_DT(KGE_COMPLEX);
     case KGE_DISTMULT: KGE_DT(KGE_DISTMULT);

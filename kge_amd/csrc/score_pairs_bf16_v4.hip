@@ -1193,6 +1193,25 @@ int run_pairs_bf16_v4_lse(int scorer, const Operand& A, const Operand* A2, const
   return run_pairs_bf16_v4_epi(scorer, V3_LSE, A, A2, R, TG, dir, d, n, m, st, ws, ws_bytes, ce, dbg);
 }
 
+// Would a two-sided counting launch (V3_RANK, in-launch cooperative build) of n rows per side against m targets be
+// taken?  The launch conditions of launch_v4 that depend on the shape: kge_score_rank_* checks every row block BEFORE
+// the first one counts anything (a decline halfway through would leave the counters of the earlier blocks behind).
+bool pairs_bf16_v4_rank_launchable(int d, long long n, long long m, long long ws_bytes) {
+  const int HH = d / 2;
+  const int rgn = 2 * (int)((n + V4_ROWS - 1) / V4_ROWS);
+  const int ntiles = (int)((m + V4_TN - 1) / V4_TN);
+  const int cus = 256;
+  int ncg = cus / rgn;
+  if (ncg > 8) ncg = 8 * (cus / 8 / rgn > 0 ? cus / 8 / rgn : 1);
+  if (ncg < 1) ncg = 1;
+  int tpc = (ntiles + ncg - 1) / ncg;
+  if (tpc < 1) tpc = 1;
+  ncg = (ntiles + tpc - 1) / tpc;
+  const int grid = 8 * rgn * ((ncg + 7) / 8);
+  const long long qf_bytes = (long long)rgn * V4_ROWS * HH * 4;
+  return ws_bytes >= qf_bytes + PAIRS_WS_CTRL_BYTES && (long long)rgn * ncg <= 512 && grid <= v4_cu_count();
+}
+
 // Any fused-loss epilogue on the loader/consumer kernel: V3_LSE (forward), V3_DS / V3_DSIG (the G16 pass of
 // the backward: the consumers turn a finished tile into d loss / d score in place, the store waves round to
 // bf16 and write 8 bytes per lane).  V3_SPLUS stays on the single-role kernel.

@@ -22,10 +22,13 @@ namespace kge {
 constexpr int F3_BM = 128, F3_BN = 128, F3_KC = 16, F3_LD = 132;  // LD: row pitch of a [pair] line
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int SCORER, typename T>
+// RANK: the finished tile is not stored but counted against the rows' true scores (rank_tile_rows, common.hpp):
+// the accumulators go through the operand buffers (free behind the last chunk: 128 x 132 floats, exactly their
+// size) so that a thread sees 64 consecutive columns of ONE row = one filter word per filter set.
+template <int SCORER, typename T, bool RANK>
 __global__ __launch_bounds__(256) void pairs_f32_kernel(Operand A, Operand R, Operand TG, int dir, int d,
                                                         long long n, long long m, int round_q,
-                                                        float* __restrict__ out, long long ldo) {
+                                                        float* __restrict__ out, long long ldo, RankArgs rk) {
   // [buffer][q|t][half][pair][row]
   __shared__ __attribute__((aligned(16))) float lds[2][2][2][F3_KC][F3_LD];
 
@@ -152,6 +155,24 @@ __global__ __launch_bounds__(256) void pairs_f32_kernel(Operand A, Operand R, Op
   }
 
   // D[i][j]: lane holds column j = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 mh
+  if constexpr (RANK) {
+    static_assert(sizeof(lds) >= F3_BM * F3_LD * 4, "the score tile fits the operand buffers");
+    float* const tile = &lds[0][0][0][0][0];  // [128][F3_LD]; the loop ended with a barrier
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+      for (int bj = 0; bj < 2; ++bj) {
+        const int lc = 64 * (wave & 1) + 32 * bj + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = 64 * (wave >> 1) + 32 * bi + (r & 3) + 8 * (r >> 2) + 4 * mh;
+          tile[lr * F3_LD + lc] = acc[bi][bj][r];
+        }
+      }
+    __syncthreads();
+    rank_tile_rows<F3_BM, F3_BN, F3_LD>(tile, row0, col0, n, m, rk, tid);
+    return;
+  }
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
@@ -167,25 +188,31 @@ __global__ __launch_bounds__(256) void pairs_f32_kernel(Operand A, Operand R, Op
 
 template <int SCORER, typename T>
 static int launch_pairs_f32(const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
-                            long long m, int round_q, float* out, long long ldo, hipStream_t st) {
+                            long long m, int round_q, float* out, long long ldo, hipStream_t st, const RankArgs* rk) {
   dim3 grid((unsigned)((m + F3_BN - 1) / F3_BN), (unsigned)((n + F3_BM - 1) / F3_BM));
-  hipLaunchKernelGGL((pairs_f32_kernel<SCORER, T>), grid, dim3(256), 0, st, A, R, TG, dir, d, n, m, round_q, out,
-                     ldo);
+  if (rk != nullptr)
+    hipLaunchKernelGGL((pairs_f32_kernel<SCORER, T, true>), grid, dim3(256), 0, st, A, R, TG, dir, d, n, m, round_q,
+                       out, ldo, *rk);
+  else
+    hipLaunchKernelGGL((pairs_f32_kernel<SCORER, T, false>), grid, dim3(256), 0, st, A, R, TG, dir, d, n, m, round_q,
+                       out, ldo, RankArgs{});
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
-// ComplEx / DistMult, vectorisable layout (d % 8 == 0, 16-byte aligned rows): the caller checked
+// ComplEx / DistMult, vectorisable layout (d % 8 == 0, 16-byte aligned rows): the caller checked.  rk != NULL:
+// counts instead of scores (`out` is not touched).
 int run_pairs_f32(int scorer, int dtype, const Operand& A, const Operand& R, const Operand& TG, int dir, int d,
-                  long long n, long long m, int round_q, float* out, long long ldo, hipStream_t st) {
+                  long long n, long long m, int round_q, float* out, long long ldo, hipStream_t st,
+                  const RankArgs* rk) {
   if (n > 65535LL * F3_BM) return KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
     return dtype == KGE_BF16
-               ? launch_pairs_f32<KGE_COMPLEX, unsigned short>(A, R, TG, dir, d, n, m, round_q, out, ldo, st)
-               : launch_pairs_f32<KGE_COMPLEX, float>(A, R, TG, dir, d, n, m, round_q, out, ldo, st);
+               ? launch_pairs_f32<KGE_COMPLEX, unsigned short>(A, R, TG, dir, d, n, m, round_q, out, ldo, st, rk)
+               : launch_pairs_f32<KGE_COMPLEX, float>(A, R, TG, dir, d, n, m, round_q, out, ldo, st, rk);
   if (scorer == KGE_DISTMULT)
     return dtype == KGE_BF16
-               ? launch_pairs_f32<KGE_DISTMULT, unsigned short>(A, R, TG, dir, d, n, m, round_q, out, ldo, st)
-               : launch_pairs_f32<KGE_DISTMULT, float>(A, R, TG, dir, d, n, m, round_q, out, ldo, st);
+               ? launch_pairs_f32<KGE_DISTMULT, unsigned short>(A, R, TG, dir, d, n, m, round_q, out, ldo, st, rk)
+               : launch_pairs_f32<KGE_DISTMULT, float>(A, R, TG, dir, d, n, m, round_q, out, ldo, st, rk);
   return KGE_ERR_UNSUPPORTED;
 }
 

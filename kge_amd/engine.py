@@ -657,8 +657,9 @@ def score_rank_sp_po(t: Tables, s, p, o, true_sp, true_po, filters_sp, filters_p
     [col_begin, col_end), counted inside the scoring kernel: what score_sp_po + two rank_counts_multi calls
     give, without the [n, 2m] score matrix.  true_sp / true_po: float32 [n] scores of the triples
     themselves; filters_*: [(begin [n], end [n], col [nnz]), ...] (at most two); rank_* / ties_*: int64
-    [len(filters) + 1, n] (a row stride >= n is fine), accumulated.  False: the library declines this
-    configuration (tables other than bf16 ComplEx / DistMult with dim 256 / 512) -- nothing was counted."""
+    [len(filters) + 1, n] (a row stride >= n is fine), accumulated.  Counting kernels: float32 tables of every
+    scorer, TransE / RotatE, bf16 ComplEx / DistMult with dim 256 / 512.  False: the library declines this
+    configuration (other bf16 shapes, split queries) -- nothing was counted."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
     n = _same_len(keep[:3], "score_rank_sp_po")
@@ -689,8 +690,6 @@ def score_rank_emb_sp_po(scorer, s_emb, p_emb, o_emb, s_ids, o_ids, targets, col
         _require_gpu(x, "embedding")
     if len({s_emb.dtype, p_emb.dtype, o_emb.dtype, targets.dtype}) != 1:
         raise TypeError("kge_amd: embeddings must share a dtype")
-    if s_emb.dtype != torch.bfloat16:
-        return False
     s_emb, p_emb, o_emb, targets = (x if x.stride(-1) == 1 else x.contiguous() for x in (s_emb, p_emb, o_emb, targets))
     sc = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
     n, m = p_emb.shape[0], targets.shape[0]

@@ -148,6 +148,8 @@ class EntityRankingEvaluator:
         self.hits_at_k_s = [k for k in hits_at_k_s if k <= min(num_entities, max(hits_at_k_s))]
         # count inside the scoring kernel where the library offers it (set False to force the two-step path)
         self._fused = os.environ.get("KGE_EVAL_TWO_STEP", "0") != "1"
+        self._declined = set()  # batch sizes kge_score_rank_sp_po declined for these tables
+        self._declined_for = None
         # replay the fused loop's full batches as one hipGraph (KGE_EVAL_GRAPH=0: issue every launch from Python)
         self.hip_graph = os.environ.get("KGE_EVAL_GRAPH", "1") != "0"
         self.graph_batches = 0  # batches that ran as graph replays (all runs)
@@ -253,13 +255,16 @@ class EntityRankingEvaluator:
         triples = st["triples"]
         # (split queries -- engine.FLAG_SPLIT_QUERY, the rank-parity setting of bf16 tables -- score in two steps: the
         # counting epilogue works on ONE MFMA chain per score)
-        fused = (self._fused and isinstance(tables, engine.Tables) and M <= 3 and tables.ent.dtype == torch.bfloat16
-                 and tables.scorer in (engine.SCORERS["complex"], engine.SCORERS["distmult"])
-                 and tables.ent.shape[1] in (256, 512) and not (tables.flags & engine.FLAG_SPLIT_QUERY))
+        # float32 tables of every scorer and bf16 ComplEx / DistMult at d 256 / 512 have a counting kernel; what the
+        # library declines (other bf16 shapes) is remembered per batch size and scored in two steps
+        fused = (self._fused and isinstance(tables, engine.Tables) and M <= 3
+                 and not (tables.flags & engine.FLAG_SPLIT_QUERY))
+        if self._declined_for != gkey:  # other tables: ask again
+            self._declined_for, self._declined = gkey, set()
+        declined = self._declined
 
         def do_batch(batch, rng, cnt, ro, rs):
             """One batch: filter ranges, counts (in place in `cnt`), tie policy + histogram; launches only."""
-            nonlocal fused
             s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
             sc_, oc_ = s.contiguous(), o.contiguous()  # true_col of the po / sp rankings
             n = batch.shape[0]
@@ -275,7 +280,8 @@ class EntityRankingEvaluator:
             engine.filter_lookup_multi(lookups)  # all lookups of the batch in one launch
 
             o_true = s_true = None
-            if fused:
+            use_fused = fused and n not in declined
+            if use_fused:
                 # the counting kernel needs the true scores up front: the batch against its own targets in
                 # one two-sided launch ([n, 4n]: sp_ scores of (o | s), then _po scores of (o | s)), the
                 # two diagonals kept -- elements of the score matrix bit for bit, as in the chunked case
@@ -294,12 +300,16 @@ class EntityRankingEvaluator:
                 s_true = engine.score_po(tables, p, o, s).diagonal().contiguous()
             for start in range(0, E, chunk):
                 end = min(start + chunk, E)
-                if fused:
+                if use_fused:
                     # scoring + counting in one kernel: no [n, 2c] score matrix (kge_score_rank_sp_po)
                     if engine.score_rank_sp_po(tables, s, p, o, o_true, s_true, filt_o, filt_s, self.tie_atol,
                                                self.tie_rtol, cnt[0, 0], cnt[0, 1], cnt[1, 0], cnt[1, 1], start, end):
                         continue
-                    fused = self._fused = False  # declined (not bf16 ComplEx / DistMult, d 256 / 512): two steps
+                    # declined, before anything was counted: two steps for batches of this size (a shape the
+                    # library has no counting kernel for declines every size; a device with fewer compute units than
+                    # the launch needs only some)
+                    use_fused = False
+                    declined.add(n)
                 sub = None if (start == 0 and end == E) else torch.arange(start, end, device=dev)
                 scores = engine.score_sp_po(tables, s, p, o, sub)
                 c = end - start
@@ -328,7 +338,7 @@ class EntityRankingEvaluator:
         use_graph = self.hip_graph and fused and chunk >= E and dev.type == "cuda" and N // bs >= 4
         for b0 in range(0, N, bs):
             n = min(bs, N - b0)
-            if use_graph and n == bs and fused:
+            if use_graph and n == bs and bs not in declined:
                 if static is None:
                     static = {"batch": torch.empty(bs, 3, dtype=torch.int64, device=dev),
                               "ro": torch.empty(M, bs, dtype=torch.int64, device=dev) if return_ranks else None,
@@ -343,7 +353,7 @@ class EntityRankingEvaluator:
                     static["stream"].wait_stream(cur)
                     with torch.cuda.stream(static["stream"]):
                         do_batch(*args)
-                    if fused:
+                    if bs not in declined:
                         graph = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph, stream=static["stream"]):
                             do_batch(*args)

@@ -128,11 +128,11 @@ class HipEntityRankingJob(EntityRankingJob):
         for f in self.pre_epoch_hooks:
             f(self)
 
-        # bf16 ComplEx / DistMult tables with dim 256 / 512 (score_dtype: bfloat16 or bf16 parameters) behind a
-        # plain hip_* model: scoring and counting in one kernel.  KGE_EVAL_TWO_STEP=1: never.
-        fused_tables = getattr(self.model, "_ce_tables", None)
-        if (os.environ.get("KGE_EVAL_TWO_STEP", "0") == "1" or M > 3 or fused_tables is None or fused_tables() is None
-                or fused_tables().ent.shape[1] not in (256, 512)):
+        # A plain hip_* model (fused gather): scoring and counting in one kernel -- float32 tables of every scorer
+        # (the exact kernels' counting epilogue), bf16 ComplEx / DistMult tables with dim 256 / 512 (the loader /
+        # consumer kernel's); what the library declines falls back below.  KGE_EVAL_TWO_STEP=1: never.
+        fused_tables = getattr(self.model, "_rank_tables", None)
+        if os.environ.get("KGE_EVAL_TWO_STEP", "0") == "1" or M > 3 or fused_tables is None or fused_tables() is None:
             fused_tables = None
         # hip_entity_ranking.bf16_queries (hip_entity_ranking.yaml): "split" (default) scores bf16 tables with split
         # queries -- rank parity with float32 arithmetic on those tables -- through the two-step path; "single" takes
@@ -141,7 +141,9 @@ class HipEntityRankingJob(EntityRankingJob):
             split = self.config.get("hip_entity_ranking.bf16_queries") != "single"
         except KeyError:
             split = True
-        split_tables = fused_tables if (split and fused_tables is not None) else None
+        split_tables = fused_tables if (split and fused_tables is not None
+                                        and fused_tables().ent.dtype == torch.bfloat16
+                                        and self.model._scorer.name in ("complex", "distmult")) else None
         if split_tables is not None:
             fused_tables = None
 

@@ -146,6 +146,16 @@ class _FusedScoring:
             t = engine.Tables(self._scorer.name, ent.detach(), rel.detach(), self._scorer._norm)
         return t if (t is not None and ent.is_cuda and engine.ce_supported(t)) else None
 
+    def _rank_tables(self):
+        """The tables HipEntityRankingJob counts on (kge_score_rank_sp_po: scoring + _filter_and_rank counts in one
+        kernel) -- the ones score_sp_po scores on under no_grad, so that fused and two-step counts agree bit for bit:
+        the bf16 copies under `score_dtype: bfloat16`, else the parameters themselves (float32: every scorer).  None:
+        no fused gather (dropout active, embedders that are not plain lookup tables, job.device cpu)."""
+        if not self._fused():
+            return None
+        ent, rel = self._w()
+        return self._fwd_tables() or engine.Tables(self._scorer.name, ent.detach(), rel.detach(), self._scorer._norm)
+
     def loss_sp(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
         """[n] cross entropy of score_sp(s, p) against o; None if the fused path does not apply."""
         t = self._ce_tables()

@@ -147,29 +147,88 @@ def test_fused_counts_with_nan_and_infinite_scores():
 
 
 def test_fused_path_declines_what_it_does_not_cover():
+    """bf16 ComplEx / DistMult at a dim the loader/consumer kernel does not take (its store path is another bf16
+    matrix-core kernel, without a counting epilogue), and split queries: declined, nothing counted."""
     from kge_amd import engine as eng
     g = torch.Generator().manual_seed(1)
-    ent, rel = torch.randn(500, 128, generator=g).to(DEV), torch.randn(4, 128, generator=g).to(DEV)
-    T = eng.Tables("transe", ent, rel, 1.0)
+    ent, rel = torch.randn(500, 128, generator=g).bfloat16().to(DEV), torch.randn(4, 128, generator=g).bfloat16().to(DEV)
     s = p = o = torch.zeros(4, dtype=torch.int64, device=DEV)
     z = torch.zeros(4, device=DEV)
-    cnt = torch.zeros(4, 1, 4, dtype=torch.int64, device=DEV)
-    assert eng.score_rank_sp_po(T, s, p, o, z, z, [], [], 1e-5, 1e-4, cnt[0], cnt[1], cnt[2], cnt[3]) is False
-    assert int(cnt.abs().sum()) == 0
+    for T in (eng.Tables("complex", ent, rel, 1.0),
+              eng.Tables("distmult", ent.repeat(1, 2).contiguous(), rel.repeat(1, 2).contiguous(), 1.0,
+                         eng.FLAG_SPLIT_QUERY)):
+        cnt = torch.zeros(4, 1, 4, dtype=torch.int64, device=DEV)
+        assert eng.score_rank_sp_po(T, s, p, o, z, z, [], [], 1e-5, 1e-4, cnt[0], cnt[1], cnt[2], cnt[3]) is False
+        assert int(cnt.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("model,E,d,bs,chunk", [("complex", 3000, 256, 100, -1), ("distmult", 5003, 512, 77, -1),
-                                                 ("complex", 2500, 512, 64, 999), ("distmult", 700, 256, 300, 64)])
-def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d, bs, chunk):
+EXACT_CASES = [
+    # model, dtype, flags, E, R, d, n, K, chunks: the counting epilogue of the exact kernels (score_pairs.hip,
+    # score_pairs_f32.hip) -- float32 tables of every scorer (a LibKGE model's default precision), TransE / RotatE on
+    # bf16 tables, bf16 ComplEx under KGE_FLAG_EXACT
+    ("complex", torch.float32, 0, 14541, 237, 512, 512, 2, None),      # 128 x 128 tiles on the f32 matrix cores
+    ("distmult", torch.float32, 0, 4099, 7, 256, 129, 1, None),        # ragged tiles in both directions
+    ("complex", torch.float32, 0, 3000, 5, 128, 40, 2, None),          # n <= 64: the 64 x 64 kernel (MFMA)
+    ("distmult", torch.float32, 2, 2000, 5, 100, 70, 2, None),         # KGE_FLAG_NO_MFMA, d % 8 != 0: scalar loads
+    ("transe", torch.float32, 0, 5000, 11, 128, 200, 2, None),
+    ("rotate", torch.float32, 0, 3001, 11, 64, 65, 2, ((0, 1500), (1500, 3001))),  # entity chunks, accumulated
+    ("transe", torch.bfloat16, 0, 2500, 5, 256, 100, 1, None),
+    ("complex", torch.bfloat16, 1, 3000, 5, 256, 150, 2, None),        # KGE_FLAG_EXACT
+    ("distmult", torch.float32, 0, 64, 3, 64, 1, 0, None),             # one row, one tile, no filters
+]
+
+
+@pytest.mark.parametrize("model,dtype,flags,E,R,d,n,K,chunks", EXACT_CASES)
+def test_exact_kernels_count_what_their_store_path_gives(model, dtype, flags, E, R, d, n, K, chunks):
+    from kge_amd import engine as eng
+    rng = np.random.default_rng(E + 31 * n + K + d)
+    g = torch.Generator().manual_seed(E + n)
+    ent = (torch.randn(E, d, generator=g) * 0.3).to(dtype).to(DEV)
+    rel = (torch.randn(R, d // 2 if model == "rotate" else d, generator=g) * 0.3).to(dtype).to(DEV)
+    T = eng.Tables(model, ent, rel, 1.0, flags)
+    s = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    p = torch.from_numpy(rng.integers(0, R, n)).to(DEV)
+    o = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    dup = rng.integers(0, E, min(E // 2, 40))
+    T.ent[dup] = T.ent[rng.integers(0, E, len(dup))]  # ties
+    T.ent[5, 0] = float("nan")                        # a NaN column (-> -inf) ...
+    if n > 3:
+        o[3] = 5                                      # ... that is also one row's true column
+    t_sp, t_po = _true_scores(eng, T, s, p, o)
+    f_sp = _filters(rng, n, E, K, o.cpu().numpy(), hub_rows=(n // 2,))
+    f_po = _filters(rng, n, E, K, s.cpu().numpy(), hub_rows=(0,))
+    chunks = chunks or ((0, E),)
+    for atol, rtol in ((1e-5, 1e-4), (0.05, 0.0)):
+        want = _two_step(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol)
+        got = _fused(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol)
+        assert torch.equal(got, want), (model, E, n, K, atol,
+                                        (got != want).nonzero()[:5].tolist(), got[got != want][:5].tolist(),
+                                        want[got != want][:5].tolist())
+    for buf in eng._RANK_BITS.values():
+        assert int(buf.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("model,E,d,bs,chunk,dtype", [
+    ("complex", 3000, 256, 100, -1, torch.bfloat16), ("distmult", 5003, 512, 77, -1, torch.bfloat16),
+    ("complex", 2500, 512, 64, 999, torch.bfloat16), ("distmult", 700, 256, 300, 64, torch.bfloat16),
+    ("complex", 3000, 128, 100, -1, torch.float32), ("transe", 2000, 64, 77, -1, torch.float32),
+    ("rotate", 1500, 64, 64, 999, torch.float32)])
+def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d, bs, chunk, dtype):
     """EntityRankingEvaluator (the mirror of EntityRankingJob._evaluate) takes the fused entry for bf16 ComplEx /
-    DistMult tables: per-example ranks (raw, filtered, filtered-with-test; both directions; ragged last batch;
-    entity chunks) and metrics identical to the same loop over kge_score_sp_po + kge_rank_counts_multi."""
+    DistMult tables and for float32 tables of every scorer: per-example ranks (raw, filtered, filtered-with-test;
+    both directions; ragged last batch; entity chunks) and metrics identical to the same loop over kge_score_sp_po +
+    kge_rank_counts_multi."""
     from kge_amd import engine as eng
     from kge_amd.eval import EntityRankingEvaluator
     from kge_amd.synthetic import make_splits
     R = 9
     splits = make_splits(E, R, 6000, 431, 300, seed=E)
-    T = _tables(eng, model, E, R, d, seed=d + E)
+    if dtype == torch.bfloat16:
+        T = _tables(eng, model, E, R, d, seed=d + E)
+    else:
+        g = torch.Generator().manual_seed(d + E)
+        T = eng.Tables(model, (torch.randn(E, d, generator=g) * 0.3).to(DEV),
+                       (torch.randn(R, d // 2 if model == "rotate" else d, generator=g) * 0.3).to(DEV), 1.0)
     calls = {"fused": 0}
     orig = eng.score_rank_sp_po
 
