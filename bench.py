@@ -377,7 +377,33 @@ def main_sharded(a, world, rank, device):
         k_ms = event_avg_ms(score_only, max(5, a.steps // 4))
         x_ms = event_avg_ms(lambda: sh.exchange_rows([s, o], p), max(5, a.steps // 4))
         m = sh.hi - sh.lo
+        # one 1vsAll TRAINING step on the same shard shapes (kge_amd.sharded_train.ShardedTrainingJob1vsAll: fused score
+        # + loss per shard, statistics exchanged, backward, this rank's Adagrad step, tables re-cast): the job-level
+        # number beside the scoring step
+        train_ms = None
+        try:
+            from kge_amd.sharded_train import ShardedTrainingJob1vsAll
+            import gc
+            del rows
+            job = ShardedTrainingJob1vsAll("complex", E, sh.rel.shape[0], d, state_dict=None, seed=3, lr=0.1,
+                                           optimizer="Adagrad", device=device, backend=engine) if E <= 200000 else None
+            if job is not None:
+                tri = torch.stack([s, p, o], 1)
+                for _ in range(3):
+                    job.step(tri)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(max(3, a.steps // 4)):
+                    job.step(tri)
+                sync()
+                train_ms = reduce_max((time.perf_counter() - t0) / max(3, a.steps // 4) * 1e3)
+                del job
+                gc.collect()
+        except Exception as exc:  # a training leg that fails must not take the scoring line with it
+            train_ms = f"failed: {type(exc).__name__}: {exc}"
+        rows = None
         results[shape] = {
+            "train_step_ms": train_ms,
             "value": 2.0 * n * E * a.steps / el, "ms_per_step": el / a.steps * 1e3,
             "host_issue_ms_per_step": host / a.steps * 1e3, "regions_ms_per_step": [r / a.steps * 1e3 for r in regions],
             "num_entities": E, "rows_per_rank": m, "dim": d, "batch": n,
@@ -386,7 +412,7 @@ def main_sharded(a, world, rank, device):
             "algorithmic_bytes_per_launch": algorithmic_bytes(n, m, d, sides=2) if not big else
             2 * algorithmic_bytes(n, m, d, sides=1),
         }
-        del sh, s_rows, o_rows, rows
+        del sh, s_rows, o_rows
         torch.cuda.empty_cache()
     if rank == 0:
         main_shape = a.shape
@@ -412,6 +438,8 @@ def main_sharded(a, world, rank, device):
                          "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
                          "avg_launch_us": r["scoring_launch_ms"] * 1e3, "traffic": None},
             "exchange_ms": r["exchange_ms"],
+            # one whole 1vsAll training step on the same shards (ShardedTrainingJob1vsAll; max over ranks)
+            "train_step_ms": r.get("train_step_ms"),
             ("fb15k_weak" if main_shape == "wikidata5m" else "wikidata5m_strong"):
                 results["fb15k" if main_shape == "wikidata5m" else "wikidata5m"],
         }

@@ -80,7 +80,8 @@ class _ShardedCE(torch.autograd.Function):
         own = ((gid >= sh.lo) & (gid < sh.hi)).to(g_a.dtype).unsqueeze(1)
         local = (gid - sh.lo).clamp_(0, max(sh.hi - sh.lo - 1, 0))
         ge = g_t  # [E_g, d], fresh: the gradient of this shard's rows as targets ...
-        ge.index_add_(0, local, g_a * own)  # ... plus the query rows it owns (others add zeros)
+        if sh.hi > sh.lo:
+            ge.index_add_(0, local, g_a * own)  # ... plus the query rows it owns (others add zeros)
         gr = torch.zeros(rel_shape, dtype=torch.float32, device=g_p.device)
         gr.index_add_(0, p.reshape(-1).long(), g_p.contiguous())  # the same on every rank
         return None, None, ge.to(torch.float32).view(ent_shape), gr, None, None, None
@@ -150,7 +151,14 @@ class ShardedEntityTable:
         local = (gid - self.lo).clamp_(0, max(self.hi - self.lo - 1, 0))  # not owned: any local row
         send = self._buffer(("send", k), (k * n, d), self.ent_local)
         rel_rows = None if rel_ids is None else self._buffer("rel", (n, self.rel.shape[1]), self.rel)
-        self.backend.embed(self._tables(self.ent_local, "local"), local, rel_ids, send, rel_rows)
+        if self.hi > self.lo:
+            self.backend.embed(self._tables(self.ent_local, "local"), local, rel_ids, send, rel_rows)
+        else:
+            # a rank without rows (E = 9 over 4 ranks: rank 3 owns [9, 9)): nothing to gather from -- its block of
+            # the all-gather is never picked (no id has this owner); zeros, and the relation rows on their own
+            send.zero_()
+            if rel_ids is not None:
+                rel_rows.copy_(self.rel[rel_ids.reshape(-1).long()])
         if not self.collectives:
             return send, rel_rows
         gath = self._buffer(("gath", k), (self.world * k * n, d), self.ent_local)

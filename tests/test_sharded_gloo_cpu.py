@@ -340,3 +340,104 @@ def test_sharded_1vsAll_loss_and_gradients_equal_unsharded(model):
     ge = np.concatenate([out[5] for out in outs])
     assert [out[1] for out in outs] == [0, outs[0][2]] and outs[-1][2] == ent.shape[0]
     np.testing.assert_allclose(ge, ent_t.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def _job_worker(rank, world, port, model, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kge_amd.sharded_train import ShardedTrainingJob1vsAll
+        E, R, d, n = 47, 5, 16, 21
+        g = torch.Generator().manual_seed(9)
+        batches = [torch.stack([torch.randint(hi, (n,), generator=g) for hi in (E, R, E)], 1) for _ in range(3)]
+        job = ShardedTrainingJob1vsAll(model, E, R, d, seed=4, lr=0.3, optimizer="Adagrad", score_dtype=torch.float32,
+                                       backend=OracleBackend)
+        losses = [float(job.step(batches[0])), float(job.step(batches[1]))]
+        ck = job.checkpoint()                       # after two steps: ONE [E, d] parameter + gathered optimizer state
+        losses.append(float(job.step(batches[2])))
+        sd = job.state_dict()
+        # a job resumed from the checkpoint on this world size takes the same third step
+        job2 = ShardedTrainingJob1vsAll(model, E, R, d, seed=99, lr=0.3, optimizer="Adagrad",
+                                        score_dtype=torch.float32, backend=OracleBackend)
+        job2.load_checkpoint(ck)
+        l3 = float(job2.step(batches[2]))
+        sd2 = job2.state_dict()
+        q.put((rank, losses, {k: v.numpy() for k, v in sd.items()}, {k: v.numpy() for k, v in ck["model"][1].items()},
+               {k: {kk: (vv.numpy() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                for k, v in ck["optimizer_state"].items()}, l3, {k: v.numpy() for k, v in sd2.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["complex", "distmult"])
+def test_sharded_training_job_equals_the_unsharded_run(model):
+    """ShardedTrainingJob1vsAll on two ranks, three optimizer steps (Adagrad on each rank's own rows, replicated
+    relation table stepping in lock-step without an all-reduce): avg_loss per batch and the gathered parameters equal
+    the unsharded run -- the reference's 1vsAll step (cross entropy `sum` / batch size of score_sp and score_po over
+    all entities, train_1vsAll.py:64-81) with torch.optim.Adagrad on the full tables.  The checkpoint after two steps
+    holds ONE [E, d] entity parameter under the reference's name, and a job resumed from it -- here on the same two
+    ranks, below on ONE rank -- takes the same third step."""
+    import torch.nn.functional as F
+    import torch_port as tp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, model, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = []
+    import time
+    t0 = time.time()
+    while len(outs) < world and time.time() - t0 < 180:
+        if not q.empty():
+            outs.append(q.get())
+        elif any(pr.exitcode not in (None, 0) for pr in procs):
+            break
+        else:
+            time.sleep(0.05)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert len(outs) == world
+    outs.sort(key=lambda x: x[0])
+    # the unsharded run
+    E, R, d, n = 47, 5, 16, 21
+    g = torch.Generator().manual_seed(4)
+    ent = torch.empty(E, d).normal_(0.0, 0.1, generator=g).requires_grad_(True)
+    rel = torch.empty(R, d).normal_(0.0, 0.1, generator=g).requires_grad_(True)
+    g = torch.Generator().manual_seed(9)
+    batches = [torch.stack([torch.randint(hi, (n,), generator=g) for hi in (E, R, E)], 1) for _ in range(3)]
+    opt = torch.optim.Adagrad([ent, rel], lr=0.3)
+    ref_losses, ref_after2 = [], None
+    for k, b in enumerate(batches):
+        s, p, o = b[:, 0], b[:, 1], b[:, 2]
+        opt.zero_grad()
+        l_sp = F.cross_entropy(tp.score_sp(model, ent, rel, s, p), o, reduction="sum") / n
+        l_po = F.cross_entropy(tp.score_po(model, ent, rel, p, o), s, reduction="sum") / n
+        (l_sp + l_po).backward()
+        opt.step()
+        ref_losses.append(float(l_sp + l_po))
+        if k == 1:
+            ref_after2 = (ent.detach().clone().numpy(), rel.detach().clone().numpy(),
+                          opt.state[ent]["sum"].clone().numpy())
+    from kge_amd.sharded_train import ENT_KEY, REL_KEY, ShardedTrainingJob1vsAll
+    for rank, losses, sd, ck_sd, ck_opt, l3, sd2 in outs:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
+        assert sd[ENT_KEY].shape == (E, d) and ck_sd[ENT_KEY].shape == (E, d) and ck_opt[ENT_KEY]["sum"].shape == (E, d)
+        np.testing.assert_allclose(sd[ENT_KEY], ent.detach().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sd[REL_KEY], rel.detach().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ck_sd[ENT_KEY], ref_after2[0], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(ck_opt[ENT_KEY]["sum"], ref_after2[2], rtol=1e-4, atol=1e-7)
+        assert abs(l3 - losses[2]) <= 1e-6 * max(1.0, abs(l3))
+        np.testing.assert_allclose(sd2[ENT_KEY], sd[ENT_KEY], rtol=1e-6, atol=1e-7)
+    assert np.array_equal(outs[0][2][ENT_KEY], outs[1][2][ENT_KEY])  # the gathered parameter is the same everywhere
+    # the two-rank checkpoint resumed on ONE rank (no process group): the same third step
+    rank, losses, sd, ck_sd, ck_opt, l3, sd2 = outs[0]
+    one = ShardedTrainingJob1vsAll(model, E, R, d, seed=1, lr=0.3, optimizer="Adagrad", score_dtype=torch.float32,
+                                   backend=OracleBackend)
+    one.load_checkpoint({"epoch": 0, "model": [None, {k: torch.from_numpy(v) for k, v in ck_sd.items()}],
+                         "optimizer_state": {k: {kk: (torch.from_numpy(vv) if isinstance(vv, np.ndarray) else vv)
+                                                 for kk, vv in v.items()} for k, v in ck_opt.items()}})
+    l3_one = float(one.step(batches[2]))
+    assert abs(l3_one - losses[2]) <= 1e-5 * max(1.0, abs(l3_one))
+    np.testing.assert_allclose(one.state_dict()[ENT_KEY].numpy(), sd[ENT_KEY], rtol=1e-4, atol=1e-6)
