@@ -7,20 +7,14 @@
 //     dT = G^T * Q      [m, d]      (g_tgt)
 //     dQ = G * T        [n, d]      then the chain rule of q = s (x) r to the gathered entity row
 //                                   (g_a) and relation row (g_p) of query i.
-// The two GEMMs are plain library GEMMs (hipBLASLt, f32 MFMA inside; rocBLAS sgemm if hipBLASLt
-// has no plan -- its 128x128 macro-tile without split-K takes 0.8 ms on the 512 x 512 x 14,541
-// dQ product that hipBLASLt does in 0.1 ms); what is hand-written here is the query build, the
-// target-row gather for listed subsets and the chain rule.  No scratch memory of our own: Q
-// lives in g_p and dQ in g_a until the chain rule overwrites both in place, gathered target
-// rows live in g_tgt until dT overwrites them, and when the targets are all entities g_tgt
-// doubles as the library's split-K workspace for the dQ product.  Tolerance-level parity with
-// the reference's autograd (summation order unspecified on both sides).
+// The two contractions are hand-written on the f32 matrix cores (bwd_gemm32.hip: gemm32_kernel, split-K for the
+// long reduction of dQ); here: the query build, the target-row gather for listed subsets and the chain rule.  No
+// scratch memory of our own: Q lives in g_p and dQ in g_a until the chain rule overwrites both in place, gathered
+// target rows live in g_tgt until dT overwrites them, and when the targets are all entities g_tgt holds the split-K
+// partials of the dQ product.  Tolerance-level parity with the reference's autograd (summation order unspecified
+// on both sides).  No BLAS library is linked.
 #include "common.hpp"
 
-#include <mutex>
-#include <vector>
-#include <hipblaslt/hipblaslt.h>
-#include <rocblas/rocblas.h>
 
 namespace kge {
 
@@ -30,6 +24,10 @@ int run_gemm16_dq(int d, long long rows, long long m, const unsigned short* T, l
                   hipStream_t st);
 bool run_gemm16_dt(int d, long long rows, long long m, const unsigned short* Q16, const unsigned short* G16,
                    long long mp, float* dT, hipStream_t st);
+// bwd_gemm32.hip: C[M, N] = A * B on the f32 matrix cores (float32 operands, or bf16 widened)
+bool run_gemm32(bool a_kcont, int in16, long long M, long long N, long long K, const void* A, long long lda,
+                const void* B, long long ldb, float* C, long long ldc, float* scratch, size_t scratch_bytes,
+                hipStream_t st);
 
 // Q[i, :] = q(a_i, r_i), f32, ld = d.  One thread per (row, coordinate of the first half).
 template <int SCORER>
@@ -100,153 +98,6 @@ __global__ __launch_bounds__(256) void bwdg_gather_kernel(Operand TG, int d, lon
   out[j * d + c] = ((const float*)TG.base + index_at(TG.idx, j) * TG.ld)[c];
 }
 
-static rocblas_handle bwdg_handle() {
-  static std::mutex mu;
-  static rocblas_handle handles[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!handles[dev]) {
-    rocblas_handle h = nullptr;
-    if (rocblas_create_handle(&h) != rocblas_status_success) return nullptr;
-    rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
-    handles[dev] = h;
-  }
-  return handles[dev];
-}
-
-// Set while a bf16 backward is issued into a stream that is being captured into a hipGraph: the
-// products may then only use plans / split-K choices that were tuned by an earlier eager call of
-// the same shape (tuning times kernels and waits for them: not capturable); otherwise the call
-// fails with KGE_ERR_UNSUPPORTED and the capture has to be preceded by a warm-up step.
-static thread_local bool tl_capturing = false;
-
-static bool stream_is_capturing(hipStream_t st, bool& capturing) {
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess) return false;
-  capturing = cs != hipStreamCaptureStatusNone;
-  return true;
-}
-
-// ---- column-major f32 GEMM C[m,n] = op(A) * op(B) through hipBLASLt, plans cached per shape
-struct LtPlan {
-  int ta, tb, in16, batch;
-  long long m, n, k, lda, ldb, ldc, sa, sb, sc;
-  size_t ws_avail;
-  bool ok;
-  hipblasLtMatmulDesc_t desc;
-  hipblasLtMatrixLayout_t la, lb, lc;
-  hipblasLtMatmulHeuristicResult_t res;  // the chosen algorithm
-  int ncand;
-  bool tuned;
-  hipblasLtMatmulHeuristicResult_t cand[8];
-};
-
-// in16: A and B are bf16 (f32 accumulation and f32 C either way).  batch > 1: strided batch
-// (strides sa, sb, sc in elements).
-static bool lt_gemm(int in16, int ta, int tb, long long m, long long n, long long k, const void* A, long long lda,
-                    const void* B, long long ldb, float* C, long long ldc, void* ws, size_t ws_bytes,
-                    hipStream_t st, int batch = 1, long long sa = 0, long long sb = 0, long long sc = 0) {
-  static std::mutex mu;
-  static hipblasLtHandle_t handles[64] = {};
-  static std::vector<LtPlan> plans[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  std::lock_guard<std::mutex> lock(mu);
-  if (!handles[dev] && hipblasLtCreate(&handles[dev]) != HIPBLAS_STATUS_SUCCESS) {
-    handles[dev] = nullptr;
-    return false;
-  }
-  if (ws_bytes > (64u << 20)) ws_bytes = 64u << 20;
-  ws_bytes &= ~(size_t)255;
-  LtPlan* pl = nullptr;
-  for (auto& q : plans[dev])
-    if (q.in16 == in16 && q.batch == batch && q.sa == sa && q.sb == sb && q.sc == sc && q.ta == ta && q.tb == tb &&
-        q.m == m && q.n == n && q.k == k && q.lda == lda && q.ldb == ldb &&
-        q.ldc == ldc && q.ws_avail == ws_bytes) {
-      pl = &q;
-      break;
-    }
-  if (!pl) {
-    LtPlan q{ta, tb, in16, batch, m, n, k, lda, ldb, ldc, sa, sb, sc, ws_bytes, false, nullptr, nullptr, nullptr, nullptr,
-             {}, 0, false, {}};
-    const hipDataType tin = in16 ? HIP_R_16BF : HIP_R_32F;
-    const hipblasOperation_t opa = ta ? HIPBLAS_OP_T : HIPBLAS_OP_N, opb = tb ? HIPBLAS_OP_T : HIPBLAS_OP_N;
-    hipblasLtMatmulPreference_t pref = nullptr;
-    int found = 0;
-    bool good = hipblasLtMatmulDescCreate(&q.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatmulDescSetAttribute(q.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opa, sizeof(opa)) ==
-                       HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatmulDescSetAttribute(q.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opb, sizeof(opb)) ==
-                       HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatrixLayoutCreate(&q.la, tin, ta ? k : m, ta ? m : k, lda) == HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatrixLayoutCreate(&q.lb, tin, tb ? n : k, tb ? k : n, ldb) == HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatrixLayoutCreate(&q.lc, HIP_R_32F, m, n, ldc) == HIPBLAS_STATUS_SUCCESS;
-    if (good && batch > 1) {
-      const int32_t bc = batch;
-      const int64_t st3[3] = {sa, sb, sc};
-      hipblasLtMatrixLayout_t ls[3] = {q.la, q.lb, q.lc};
-      for (int i = 0; i < 3 && good; ++i) {
-        good = hipblasLtMatrixLayoutSetAttribute(ls[i], HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &bc, sizeof(bc)) ==
-                   HIPBLAS_STATUS_SUCCESS &&
-               hipblasLtMatrixLayoutSetAttribute(ls[i], HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &st3[i],
-                                                 sizeof(int64_t)) == HIPBLAS_STATUS_SUCCESS;
-      }
-    }
-    good = good && hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws_bytes,
-                                                         sizeof(ws_bytes)) == HIPBLAS_STATUS_SUCCESS;
-    good = good && hipblasLtMatmulAlgoGetHeuristic(handles[dev], q.desc, q.la, q.lb, q.lc, q.lc, pref, 8, q.cand,
-                                                   &found) == HIPBLAS_STATUS_SUCCESS;
-    if (pref) hipblasLtMatmulPreferenceDestroy(pref);
-    q.ncand = 0;
-    for (int i = 0; good && i < found; ++i)
-      if (q.cand[i].state == HIPBLAS_STATUS_SUCCESS && q.cand[i].workspaceSize <= ws_bytes)
-        q.cand[q.ncand++] = q.cand[i];
-    q.ok = good && q.ncand > 0;
-    if (q.ok) q.res = q.cand[0];
-    plans[dev].push_back(q);
-    pl = &plans[dev].back();
-  }
-  if (!pl->ok) return false;
-  const float one = 1.0f, zero = 0.0f;
-  if (!pl->tuned && tl_capturing) return false;
-  if (!pl->tuned) {
-    // First use of this shape: time the library's candidates once on the caller's data (the
-    // heuristic's first choice for the 512 x 512 x 14,541 dQ product is 5x slower than its
-    // best) and keep the fastest.  Host-synchronous, once per shape and process.
-    pl->tuned = true;
-    if (pl->ncand > 1) {
-      hipEvent_t e0, e1;
-      if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-        float best = 1e30f;
-        int besti = 0;
-        for (int i = 0; i < pl->ncand; ++i) {
-          bool okrun = true;
-          float ms = 1e30f;
-          for (int rep = 0; rep < 3 && okrun; ++rep) {  // rep 0 = warm-up
-            if (rep == 1) (void)hipEventRecord(e0, st);
-            okrun = hipblasLtMatmul(handles[dev], pl->desc, &one, A, pl->la, B, pl->lb, &zero, C, pl->lc, C,
-                                    pl->lc, &pl->cand[i].algo, ws, pl->cand[i].workspaceSize, st) ==
-                    HIPBLAS_STATUS_SUCCESS;
-          }
-          if (okrun && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-              hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) {
-            best = ms;
-            besti = i;
-          }
-        }
-        pl->res = pl->cand[besti];
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-      }
-    }
-  }
-  return hipblasLtMatmul(handles[dev], pl->desc, &one, A, pl->la, B, pl->lb, &zero, C, pl->lc, C, pl->lc,
-                         &pl->res.algo, ws, pl->res.workspaceSize, st) == HIPBLAS_STATUS_SUCCESS;
-}
-
-// sum of P partial [cnt] f32 arrays
 __global__ __launch_bounds__(256) void bwdg_reduce_kernel(const float* __restrict__ part, long long cnt, int P,
                                                           float* __restrict__ out) {
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -259,85 +110,12 @@ __global__ __launch_bounds__(256) void bwdg_reduce_kernel(const float* __restric
   *reinterpret_cast<f32x4*>(out + i) = acc;
 }
 
-// dQ^T[d, n] = T^T[d, m] * G^T[m, n] (column-major views): a small output with a very long
-// reduction (m = all entities).  The library has no split-K kernel for it (bf16 -> f32: 53 us for
-// 512 x 512 x 14,541 whatever the algorithm), so the reduction is split by hand: P strided-batch
-// products over K-chunks into P partial outputs (scratch), a tail product for m % P, one
-// reduction kernel.  P (or the plain product) is chosen by timing each once per shape.
-static bool gemm_long_k(int in16, int d, long long n, long long m, const void* T, long long ldt, const void* G,
-                        long long ldg, float* C, float* scratch, size_t scratch_bytes, hipStream_t st) {
-  // The strategy is tuned once per BUCKET of shapes: n rounded up to a multiple of 128 (KvsAll batches
-  // change their number of sp_ / _po queries with every batch: a key on the exact n meant a timing pass
-  // with a host synchronisation in nearly every backward call), leading dimensions and scratch size not
-  // part of the key (a choice that does not fit this call's scratch falls back to the plain product).
-  // The cache is bounded: the oldest entry goes when it is full.
-  struct Choice {
-    int in16, d;
-    long long nb, m;
-    int P;
-  };
-  constexpr size_t MAX_CHOICES = 64;
-  const long long nb = (n + 127) / 128;
-  static std::mutex mu;
-  static std::vector<Choice> choices;
-  const size_t es = in16 ? 2 : 4;
-  const long long cnt = n * d;
-  auto run = [&](int P) -> bool {
-    if (P <= 1) return lt_gemm(in16, 0, 0, d, n, m, T, ldt, G, ldg, C, d, scratch, scratch_bytes, st);
-    const long long kc = m / P, rem = m - kc * P;
-    const int slots = P + (rem ? 1 : 0);
-    if ((size_t)slots * cnt * 4 > scratch_bytes || kc == 0 || (cnt & 3)) return false;
-    if (!lt_gemm(in16, 0, 0, d, n, kc, T, ldt, G, ldg, scratch, d, nullptr, 0, st, P, kc * ldt, kc, cnt)) return false;
-    if (rem && !lt_gemm(in16, 0, 0, d, n, rem, (const char*)T + (size_t)(kc * P) * ldt * es, ldt,
-                        (const char*)G + (size_t)(kc * P) * es, ldg, scratch + (long long)P * cnt, d, nullptr, 0, st))
-      return false;
-    hipLaunchKernelGGL(bwdg_reduce_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, st, scratch, cnt,
-                       slots, C);
-    return true;
-  };
-  int P = -1;
-  {
-    std::lock_guard<std::mutex> lock(mu);
-    for (auto& c : choices)
-      if (c.in16 == in16 && c.d == d && c.nb == nb && c.m == m) P = c.P;
-  }
-  if (P < 0 && tl_capturing) return false;
-  if (P < 0) {  // first use of this shape: time the strategies once (host-synchronous)
-    const int cands[4] = {1, 4, 8, 16};
-    float best = 1e30f;
-    P = 1;
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
-      for (int ci = 0; ci < 4; ++ci) {
-        bool okrun = run(cands[ci]);  // warm-up (also tunes the library plan)
-        float ms = 1e30f;
-        if (okrun) {
-          (void)hipEventRecord(e0, st);
-          okrun = run(cands[ci]) && run(cands[ci]);
-          if (okrun && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
-              hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) {
-            best = ms;
-            P = cands[ci];
-          }
-        }
-      }
-      (void)hipEventDestroy(e0);
-      (void)hipEventDestroy(e1);
-    }
-    std::lock_guard<std::mutex> lock(mu);
-    if (choices.size() >= MAX_CHOICES) choices.erase(choices.begin());
-    choices.push_back(Choice{in16, d, nb, m, P});
-  }
-  return run(P) || (P > 1 && run(1));
-}
-
 template <int SCORER>
 static int bwdg_run(int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
                     long long n, long long m, const float* gout, long long ldg, float* g_a,
                     float* g_p, float* g_tgt, hipStream_t st) {
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
   const unsigned qblocks = (unsigned)((n * half + 255) / 256);
-  const float one = 1.0f, zero = 0.0f;
   // target rows as a dense [m, d] matrix: the table itself, or gathered into g_tgt for now
   const float* T = (const float*)TG.base;
   long long ldt = TG.ld;
@@ -347,30 +125,14 @@ static int bwdg_run(int dir, const Operand& A, const Operand& R, const Operand& 
     T = g_tgt;
     ldt = d;
   }
-  rocblas_handle h = nullptr;  // fallback only
-  auto fallback = [&]() {
-    if (h) return true;
-    h = bwdg_handle();
-    return h != nullptr && rocblas_set_stream(h, st) == rocblas_status_success;
-  };
-  // dQ = G * T  (row-major [n, d]) == column-major dQ^T[d, n] = T^T[d, m] * G^T[m, n]; all
-  // entities: g_tgt (written by the second product only) is the library's workspace here
-  void* ws = TG.idx.ptr == nullptr ? (void*)g_tgt : nullptr;
+  // dQ = G * T  ([n, d]; K = m, split over the K ranges): all entities -> g_tgt (written by the second product
+  // only) holds the partials
+  float* ws = TG.idx.ptr == nullptr ? g_tgt : nullptr;
   const size_t ws_bytes = TG.idx.ptr == nullptr ? (size_t)m * d * sizeof(float) : 0;
-  if (!gemm_long_k(0, d, n, m, T, ldt, gout, ldg, g_a, (float*)ws, ws_bytes, st)) {
-    if (!fallback()) return KGE_ERR_UNSUPPORTED;
-    if (rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_none, d, (int)n, (int)m, &one, T, (int)ldt,
-                      gout, (int)ldg, &zero, g_a, d) != rocblas_status_success)
-      return KGE_ERR_LAUNCH;
-  }
-  // Q -> g_p, then dT = G^T * Q (row-major [m, d]) == column-major dT^T[d, m] = Q^T[d, n] * G[n, m]
+  if (!run_gemm32(true, 0, n, d, m, gout, ldg, T, ldt, g_a, d, ws, ws_bytes, st)) return KGE_ERR_UNSUPPORTED;
+  // Q -> g_p, then dT = G^T * Q  ([m, d]; K = n)
   hipLaunchKernelGGL((bwdg_build_q_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_p);
-  if (!lt_gemm(0, 0, 1, d, m, n, g_p, d, gout, ldg, g_tgt, d, nullptr, 0, st)) {
-    if (!fallback()) return KGE_ERR_UNSUPPORTED;
-    if (rocblas_sgemm(h, rocblas_operation_none, rocblas_operation_transpose, d, (int)m, (int)n, &one, g_p, d,
-                      gout, (int)ldg, &zero, g_tgt, d) != rocblas_status_success)
-      return KGE_ERR_LAUNCH;
-  }
+  if (!run_gemm32(false, 0, m, d, n, gout, ldg, g_p, d, g_tgt, d, nullptr, 0, st)) return KGE_ERR_UNSUPPORTED;
   hipLaunchKernelGGL((bwdg_chain_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
@@ -505,7 +267,8 @@ long long pairs_bwd_workspace_bytes(int dtype, int scorer, int d, long long n, l
 }
 
 // dQ = G16 * T and dT = G16^T * Q16 on the bf16 matrix cores: the hand-written kernel of bwd_gemm16.hip,
-// the library where that declines (d not a multiple of 256, KGE_BWD_GEMM_LIB=1).  `lws`: scratch for the
+// the f32 matrix cores on the widened operands (gemm32_kernel) where that declines (d not a multiple of 256,
+// KGE_BWD_GEMM_LIB=1).  `lws`: scratch for the
 // split-K partials of dQ (g_tgt before dT overwrites it) or NULL.
 static bool bwdg_dq16(int d, long long rows, long long m, const unsigned short* T, long long ldt,
                       const unsigned short* G16, long long mp, float* g_a, float* lws, size_t lws_bytes,
@@ -517,31 +280,27 @@ static bool bwdg_dq16(int d, long long rows, long long m, const unsigned short* 
                        g_a);
   }
   if (sp >= 1) return true;
-  return gemm_long_k(1, d, rows, m, T, ldt, G16, mp, g_a, lws, lws_bytes, st);
+  return run_gemm32(true, 1, rows, d, m, G16, mp, T, ldt, g_a, d, lws, lws_bytes, st);
 }
 
 static bool bwdg_dt16(int d, long long rows, long long m, const unsigned short* Q16, const unsigned short* G16,
                       long long mp, float* g_tgt, hipStream_t st) {
   if (run_gemm16_dt(d, rows, m, Q16, G16, mp, g_tgt, st)) return true;
-  return lt_gemm(1, 0, 1, d, m, rows, Q16, d, G16, mp, g_tgt, d, nullptr, 0, st);
+  return run_gemm32(false, 1, m, d, rows, G16, mp, Q16, d, g_tgt, d, nullptr, 0, st);
 }
 
 // tests / tools: one of the two products on its own (which = 0: dQ [rows, d] from T [m, d]; 1: dT [m, d] from
-// Q16 [rows, d]); lib != 0 forces the library path
+// Q16 [rows, d]); lib != 0 forces gemm32_kernel on the widened operands (the cross-check)
 int run_debug_gemm16(int which, int lib, int d, long long rows, long long m, const unsigned short* X, long long ldx,
                      const unsigned short* G16, long long mp, float* out, float* scratch, long long scratch_bytes,
                      hipStream_t st) {
-  bool capturing = false;
-  if (!stream_is_capturing(st, capturing)) return KGE_ERR_UNSUPPORTED;
-  tl_capturing = capturing;
   bool ok;
   if (which == 0)
-    ok = lib ? gemm_long_k(1, d, rows, m, X, ldx, G16, mp, out, scratch, (size_t)scratch_bytes, st)
+    ok = lib ? run_gemm32(true, 1, rows, d, m, G16, mp, X, ldx, out, d, scratch, (size_t)scratch_bytes, st)
              : bwdg_dq16(d, rows, m, X, ldx, G16, mp, out, scratch, (size_t)scratch_bytes, st);
   else
-    ok = lib ? lt_gemm(1, 0, 1, d, m, rows, X, d, G16, mp, out, d, nullptr, 0, st)
+    ok = lib ? run_gemm32(false, 1, m, d, rows, G16, mp, X, d, out, d, nullptr, 0, st)
              : bwdg_dt16(d, rows, m, X, G16, mp, out, st);
-  tl_capturing = false;
   if (!ok) return KGE_ERR_UNSUPPORTED;
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
@@ -605,9 +364,6 @@ int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A
   if (n == 0 || m == 0) return KGE_OK;
   if (2 * n >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31))
     return KGE_ERR_UNSUPPORTED;
-  bool capturing = false;
-  if (!stream_is_capturing(st, capturing)) return KGE_ERR_UNSUPPORTED;
-  tl_capturing = capturing;
   int rc = KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
     rc = bwdg_products16_two<KGE_COMPLEX>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
@@ -615,7 +371,6 @@ int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A
   else if (scorer == KGE_DISTMULT)
     rc = bwdg_products16_two<KGE_DISTMULT>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
                                            acc_rel_ld, st);
-  tl_capturing = false;
   return rc;
 }
 
@@ -639,15 +394,11 @@ int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operan
                              unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
   if (n == 0 || m == 0) return KGE_OK;
   if (n >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31)) return KGE_ERR_UNSUPPORTED;
-  bool capturing = false;
-  if (!stream_is_capturing(st, capturing)) return KGE_ERR_UNSUPPORTED;
-  tl_capturing = capturing;
   int rc = KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
     rc = bwdg_products16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
   else if (scorer == KGE_DISTMULT)
     rc = bwdg_products16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
-  tl_capturing = false;
   return rc;
 }
 
@@ -658,13 +409,9 @@ int run_pairs_bwd_gemm16(int scorer, int dir, const Operand& A, const Operand& R
   if (scorer != KGE_COMPLEX && scorer != KGE_DISTMULT) return KGE_ERR_UNSUPPORTED;
   if (dr != d || !g_a || !g_p || !g_tgt || (d % 2)) return KGE_ERR_UNSUPPORTED;
   if (n >= (1LL << 31) || m >= (1LL << 31) || TG.ld >= (1LL << 31)) return KGE_ERR_UNSUPPORTED;
-  bool capturing = false;
-  if (!stream_is_capturing(st, capturing)) return KGE_ERR_UNSUPPORTED;
-  tl_capturing = capturing;
   const int rc = scorer == KGE_COMPLEX
                      ? bwdg_run16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, ws, ws_bytes, st)
                      : bwdg_run16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, ws, ws_bytes, st);
-  tl_capturing = false;
   return rc;
 }
 
