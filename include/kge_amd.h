@@ -355,6 +355,30 @@ int kge_score_rank_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_l
                              void* filter_bits, int64_t filter_bits_bytes, void* workspace,
                              int64_t workspace_bytes, void* stream);
 
+/* One evaluation batch of EntityRankingJob._evaluate (eval_entity_ranking.py:103-481: label lookup, score_sp_po,
+ * _filter_and_rank per ranking, _get_ranks, hist_all) against ALL entities in FOUR launches, one call:
+ *   (1) the filter ranges of the batch's (s, p) / (p, o) keys in up to two filter indexes (kge_filter_lookup's
+ *       search) and one bit per filtered (row, column) -- the row's own o / s never --, plus the target list (o | s);
+ *   (2) the true scores: the batch against its own targets (kge_score_sp_po on 2 n target rows), diagonals kept;
+ *   (3) scoring + counting (kge_score_rank_sp_po's kernels: no [n, 2E] score matrix);
+ *   (4) the bits cleared again, tie policy + rank histograms of both directions (kge_rank_hist), counters zeroed.
+ * counts: int64 [2 (o | s)][2 (rank | ties)][num_filters + 1][n], ALL-ZERO on entry and again on return; hist:
+ * float [num_filters + 1][ldh] accumulated (row 0 raw); ranks_o / ranks_s: int64 [num_filters + 1][n] or NULL;
+ * filter_bits: as for kge_score_rank_sp_po (>= kge_score_rank_bits_bytes(n, num_entities, num_filters) bytes, ZEROED
+ * ONCE before its first use, all-zero between calls); scratch: kge_eval_batch_scratch_bytes(t, n, num_filters) bytes,
+ * 16-byte aligned, contents irrelevant; workspace as for kge_score_sp_po.  KGE_ERR_UNSUPPORTED: tables without a
+ * counting kernel (see kge_score_rank_sp_po) -- nothing was counted, nothing left behind.  No host wait. */
+typedef struct kge_eval_filter {
+  const int64_t* sp_keys;   int64_t sp_num_keys; const int64_t* sp_starts; const int64_t* sp_values;  /* key s*R + p -> o's */
+  const int64_t* po_keys;   int64_t po_num_keys; const int64_t* po_starts; const int64_t* po_values;  /* key p*E + o -> s's */
+} kge_eval_filter;
+int64_t kge_eval_batch_scratch_bytes(const kge_tables* t, int64_t n, int num_filters);
+int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, int num_filters,
+                   const kge_eval_filter* filters, float atol, float rtol, int tie_policy, int64_t* counts,
+                   float* hist, int64_t ldh, int64_t* ranks_o, int64_t* ranks_s, void* filter_bits,
+                   int64_t filter_bits_bytes, void* scratch, int64_t scratch_bytes, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
 /* hist[m*ldh + r] += 1.0f with r = rank of the tie policy, for all [num_rankings][n] counts;
  * ranks_out (may be NULL) receives r.  EntityRankingJob._get_ranks (:598-618) + hist_all
  * (:665-687); the float32 histogram is the reference's. */

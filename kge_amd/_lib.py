@@ -49,6 +49,11 @@ class KgeNextQueries(ctypes.Structure):
                 ("queries_bytes", c_i64)]
 
 
+class KgeEvalFilter(ctypes.Structure):
+    _fields_ = [("sp_keys", c_vp), ("sp_num_keys", c_i64), ("sp_starts", c_vp), ("sp_values", c_vp),
+                ("po_keys", c_vp), ("po_num_keys", c_i64), ("po_starts", c_vp), ("po_values", c_vp)]
+
+
 class KgeFilterQuery(ctypes.Structure):
     _fields_ = [("sorted_keys", c_vp), ("num_keys", c_i64), ("starts", c_vp), ("a", KgeIndex), ("b", KgeIndex),
                 ("mult", c_i64), ("begin", c_vp), ("end", c_vp)]
@@ -91,6 +96,10 @@ PROTOTYPES = {
                                                 c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp,
                                                 c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp,
                                                 c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kge_eval_batch_scratch_bytes": (c_i64, [_PT, c_i64, ctypes.c_int]),
+    "kge_eval_batch": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int,
+                                      ctypes.POINTER(KgeEvalFilter), ctypes.c_float, ctypes.c_float, ctypes.c_int, c_vp,
+                                      c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_rank_hist": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_i64, c_i64, c_vp,
                                      c_vp]),
     "kge_score_bwd_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),

@@ -58,6 +58,10 @@ int run_rank_multi(const float* scores, long long lds, long long n, long long c,
                    float rtol, long long* rank, long long* ties, hipStream_t st);
 int run_rank_hist(const long long* rank, const long long* ties, int M, long long n, int policy, float* hist,
                   long long ldh, long long num_ent, long long* ranks_out, hipStream_t st);
+int run_eval_begin(const EvalLists& L, const Index& s, const Index& o, long long n, long long m, long long bld,
+                   long long* tgt, hipStream_t st);
+int run_eval_end(const EvalLists& L, long long n, long long m, long long bld, int M, int policy, long long* counts,
+                 float* hist, long long ldh, long long num_ent, long long* ranks_o, long long* ranks_s, hipStream_t st);
 int run_rank_bits(int lists, const long long* const* begin, const long long* const* end, const long long* const* col,
                   const Index* keep, unsigned long long* const* bits, long long n, long long col_begin, long long m,
                   long long ld, int set, hipStream_t st);
@@ -619,11 +623,13 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
                            const int64_t* const* po_begin, const int64_t* const* po_end, const int64_t* const* po_col,
                            float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po,
                            int64_t* ties_po, int64_t ld, void* filter_bits, int64_t filter_bits_bytes, void* workspace,
-                           int64_t workspace_bytes, void* stream) {
+                           int64_t workspace_bytes, void* stream, int64_t true_stride = 1, bool manage_bits = true) {
+  // manage_bits = false (kge_eval_batch): the filter bits are set already and are cleared by the caller; the lists
+  // are not looked at
   if (!true_sp || !true_po || !rank_sp || !ties_sp || !rank_po || !ties_po || ld < n) return KGE_ERR_INVALID_ARG;
   if (num_filters < 0) return KGE_ERR_INVALID_ARG;
   if (num_filters > 2) return KGE_ERR_UNSUPPORTED;
-  for (int k = 0; k < num_filters; ++k)
+  for (int k = 0; manage_bits && k < num_filters; ++k)
     if (!sp_begin || !sp_end || !sp_col || !po_begin || !po_end || !po_col || !sp_begin[k] || !sp_end[k] ||
         !sp_col[k] || !po_begin[k] || !po_end[k] || !po_col[k])
       return KGE_ERR_INVALID_ARG;
@@ -650,6 +656,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   CeArgs ce{};
   ce.rk_true[0] = true_sp;
   ce.rk_true[1] = true_po;
+  ce.rk_true_stride = true_stride;
   ce.rk_rank[0] = (unsigned long long*)rank_sp;
   ce.rk_ties[0] = (unsigned long long*)ties_sp;
   ce.rk_rank[1] = (unsigned long long*)rank_po;
@@ -666,21 +673,25 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   for (int k = 0; k < num_filters; ++k) {
     for (int side = 0; side < 2; ++side) {
       const int q = side * num_filters + k;
-      lb[q] = (const long long*)(side ? po_begin[k] : sp_begin[k]);
-      le[q] = (const long long*)(side ? po_end[k] : sp_end[k]);
-      lc[q] = (const long long*)(side ? po_col[k] : sp_col[k]);
+      if (manage_bits) {
+        lb[q] = (const long long*)(side ? po_begin[k] : sp_begin[k]);
+        le[q] = (const long long*)(side ? po_end[k] : sp_end[k]);
+        lc[q] = (const long long*)(side ? po_col[k] : sp_col[k]);
+      }
       keep[q] = side ? keep_s : keep_o;
       bits[q] = (unsigned long long*)filter_bits + (int64_t)q * n * bld;
       ce.rk_bits[side][k] = bits[q];
     }
   }
   hipStream_t st = (hipStream_t)stream;
-  int rc = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 1, st);
+  const int nlists = manage_bits ? 2 * num_filters : 0;
+  int rc = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 1, st);
   if (rc) return rc;
   if (exact_path) {
     for (int side = 0; side < 2 && rc == KGE_OK; ++side) {
       RankArgs rk{};
       rk.tru = ce.rk_true[side];
+      rk.tru_stride = true_stride;
       rk.rank = ce.rk_rank[side];
       rk.ties = ce.rk_ties[side];
       rk.ld = ld;
@@ -693,7 +704,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
                            side ? KGE_PO_ : KGE_SP_, (int)t->dim, (int)t->rel_dim, n, m, t->l_norm, nullptr, 1, st,
                            /*round_query=*/true, &rk);
     }
-    const int rcb = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+    const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
     return rc != KGE_OK ? rc : rcb;
   }
   // one launch holds at most 32 row groups (one workgroup per CU and XCD-aligned column groups): 2,048 rows per
@@ -708,14 +719,14 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   constexpr int64_t BLOCK = 2048;
   for (int64_t r0 = 0; r0 < n; r0 += BLOCK)  // every block's launch geometry first: decline before anything counts
     if (!pairs_bf16_v4_rank_launchable((int)t->dim, n - r0 < BLOCK ? n - r0 : BLOCK, m, workspace_bytes)) {
-      const int rcb = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+      const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
       return rcb != KGE_OK ? rcb : KGE_ERR_UNSUPPORTED;
     }
   for (int64_t r0 = 0; r0 < n && rc == KGE_OK; r0 += BLOCK) {
     const int64_t nb = n - r0 < BLOCK ? n - r0 : BLOCK;
     CeArgs cb = ce;
     for (int side = 0; side < 2; ++side) {
-      cb.rk_true[side] += r0;
+      cb.rk_true[side] += r0 * true_stride;
       cb.rk_rank[side] += r0;
       cb.rk_ties[side] += r0;
       for (int k = 0; k < num_filters; ++k) cb.rk_bits[side][k] += r0 * bld;
@@ -725,7 +736,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
                                workspace_bytes, cb, nullptr);
   }
   // (also after a declined launch: the bits must not outlive the call)
-  const int rc2 = run_rank_bits(2 * num_filters, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+  const int rc2 = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
   return rc ? rc : rc2;
 }
 
@@ -770,6 +781,96 @@ int kge_score_rank_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_l
   return score_rank_core(t, S, O, P, TG, make_index(o_ids), make_index(s_ids), n, col_begin, m, true_sp, true_po,
                          num_filters, sp_begin, sp_end, sp_col, po_begin, po_end, po_col, atol, rtol, rank_sp, ties_sp,
                          rank_po, ties_po, ld, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream);
+}
+
+// ---- one evaluation batch in four launches
+static void eval_scratch_layout(int64_t n, int K, int64_t& off_tgt, int64_t& off_true, int64_t& total) {
+  auto up = [](int64_t x) { return (x + 255) & ~(int64_t)255; };
+  off_tgt = up((int64_t)2 * K * 2 * n * 8);  // behind the ranges
+  off_true = off_tgt + up(2 * n * 8);
+  total = off_true + up(n * 4 * n * 4);
+}
+
+int64_t kge_eval_batch_scratch_bytes(const kge_tables* t, int64_t n, int num_filters) {
+  if (!t || n <= 0 || num_filters < 0 || num_filters > 2) return 0;
+  int64_t a, b, total;
+  eval_scratch_layout(n, num_filters, a, b, total);
+  return total;
+}
+
+int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, int num_filters,
+                   const kge_eval_filter* filters, float atol, float rtol, int tie_policy, int64_t* counts,
+                   float* hist, int64_t ldh, int64_t* ranks_o, int64_t* ranks_s, void* filter_bits,
+                   int64_t filter_bits_bytes, void* scratch, int64_t scratch_bytes, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (n < 0 || num_filters < 0 || ldh < t->num_ent) return KGE_ERR_INVALID_ARG;
+  if (num_filters > 2) return KGE_ERR_UNSUPPORTED;
+  if (tie_policy < KGE_TIES_ROUNDED_MEAN || tie_policy > KGE_TIES_WORST) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s, false, n)) || (rc = check_index(p, false, n)) || (rc = check_index(o, false, n))) return rc;
+  if (n == 0) return KGE_OK;
+  if (!counts || !hist || (num_filters > 0 && !filters)) return KGE_ERR_INVALID_ARG;
+  const int64_t E = t->num_ent, R = t->num_rel, m = E, bld = rank_bits_ld(m);
+  int64_t off_tgt, off_true, total;
+  eval_scratch_layout(n, num_filters, off_tgt, off_true, total);
+  if (!scratch || ((uintptr_t)scratch & 15) || scratch_bytes < total) return KGE_ERR_WORKSPACE;
+  const int64_t bits_need = kge_score_rank_bits_bytes(n, m, num_filters);
+  if (num_filters > 0 && (!filter_bits || ((uintptr_t)filter_bits & 7) || filter_bits_bytes < bits_need))
+    return KGE_ERR_WORKSPACE;
+  char* sc = (char*)scratch;
+  long long* tgt = (long long*)(sc + off_tgt);
+  float* trueblk = (float*)(sc + off_true);
+  EvalLists L{};
+  L.nq = 2 * num_filters;
+  const Index si = make_index(s), pi = make_index(p), oi = make_index(o);
+  for (int k = 0; k < num_filters; ++k)
+    for (int side = 0; side < 2; ++side) {
+      const int q = side * num_filters + k;
+      const kge_eval_filter& f = filters[k];
+      const int64_t nk = side ? f.po_num_keys : f.sp_num_keys;
+      const int64_t *keys = side ? f.po_keys : f.sp_keys, *starts = side ? f.po_starts : f.sp_starts,
+                    *values = side ? f.po_values : f.sp_values;
+      if (nk < 0 || (nk > 0 && (!keys || !starts || !values))) return KGE_ERR_INVALID_ARG;
+      L.keys[q] = (const long long*)keys;
+      L.num_keys[q] = nk;
+      L.starts[q] = (const long long*)starts;
+      L.values[q] = (const long long*)values;
+      L.mult[q] = side ? E : R;        // sp: key s * R + p;  po: key p * E + o
+      L.a[q] = side ? pi : si;
+      L.b[q] = side ? oi : pi;
+      L.keep[q] = side ? si : oi;      // the row's own true column is never filtered
+      L.range[q] = (long long*)sc + (int64_t)q * 2 * n;
+      L.bits[q] = (unsigned long long*)filter_bits + (int64_t)q * n * bld;
+    }
+  hipStream_t st = (hipStream_t)stream;
+  // (1) filter lookup + filter bits + the target list (o | s)
+  if ((rc = run_eval_begin(L, si, oi, n, m, bld, tgt, st))) return rc;
+  // (2) the true scores: the batch against its own targets, [n, 4 n] = (sp_ vs o | s, _po vs o | s); the diagonals
+  // (i, i) and (i, 3 n + i) are elements of the score matrix bit for bit (each score is its own chain)
+  kge_index tgi{tgt, KGE_I64, 0, 1};
+  rc = kge_score_sp_po(t, s, p, o, n, tgi, 2 * n, trueblk, 4 * n, workspace, workspace_bytes, stream);
+  // (3) scores + counts against all entities, no score matrix
+  const int M = num_filters + 1;
+  const int64_t per = (int64_t)M * n;
+  if (rc == KGE_OK) {
+    kge_index all{nullptr, KGE_I64, 0, 1};
+    const Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, all);
+    rc = score_rank_core(t, S, O, P, TG, oi, si, n, 0, m, trueblk, trueblk + 3 * n, num_filters, nullptr, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, atol, rtol, counts, counts + per, counts + 2 * per,
+                         counts + 3 * per, n, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream,
+                         4 * n + 1, /*manage_bits=*/false);
+  }
+  // (4) bits cleared, tie policy + histograms, counters back to zero -- also behind a declined step (3), whose
+  // counters are untouched zeros: the histogram part is then skipped by the caller's fallback (nothing was counted)
+  if (rc == KGE_ERR_UNSUPPORTED) {
+    EvalLists Lc = L;  // clear only
+    const int rc2 = run_eval_end(Lc, n, m, bld, 0, tie_policy, (long long*)counts, hist, ldh, E, nullptr, nullptr, st);
+    return rc2 != KGE_OK ? rc2 : KGE_ERR_UNSUPPORTED;
+  }
+  if (rc != KGE_OK) return rc;
+  return run_eval_end(L, n, m, bld, M, tie_policy, (long long*)counts, hist, ldh, E, (long long*)ranks_o,
+                      (long long*)ranks_s, st);
 }
 
 int kge_rank_hist(const int64_t* rank, const int64_t* ties, int num_rankings, int64_t n, int tie_policy,

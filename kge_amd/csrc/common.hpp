@@ -357,7 +357,8 @@ struct CeArgs {
   Index label2;
   long long side2_off;
   // V3_RANK: per side (index 1 = the _po side of a two-sided launch)
-  const float* rk_true[2];           // [n] true score of row i
+  const float* rk_true[2];           // true score of row i at [i * rk_true_stride]
+  long long rk_true_stride;          // 1: a vector; 4 n + 1: the diagonals of the [n, 4 n] block of kge_eval_batch
   unsigned long long* rk_rank[2];    // [rk_nfilt + 1][rk_ld] ACCUMULATED: row 0 raw, row k + 1 filter set k
   unsigned long long* rk_ties[2];
   long long rk_ld;
@@ -389,7 +390,8 @@ __device__ __forceinline__ void count_one(float x, float t, float atol, float rt
 // ---- counting epilogue of the exact pair kernels (score_pairs.hip, score_pairs_f32.hip): kge_score_rank_sp_po for
 // float32 tables and for TransE / RotatE.  One side of the batch per launch.
 struct RankArgs {
-  const float* tru;                   // [n] true score of row i
+  const float* tru;                   // true score of row i at [i * tru_stride]
+  long long tru_stride;
   unsigned long long* rank;           // [nfilt + 1][ld] ACCUMULATED: row 0 raw, row k + 1 filter set k
   unsigned long long* ties;
   long long ld;
@@ -412,7 +414,7 @@ __device__ __forceinline__ void rank_tile_rows(const float* tile, long long row0
   const int row = tid / SEGS, seg = tid % SEGS;
   const long long orow = row0 + row;
   if (orow >= n) return;
-  float t = rk.tru[orow];
+  float t = rk.tru[orow * rk.tru_stride];
   if (t != t) t = -__builtin_inff();
   const long long c0 = col0 + seg * W;  // first column of the segment (relative to the scored slice)
   if (c0 >= m) return;
@@ -441,5 +443,19 @@ __device__ __forceinline__ void rank_tile_rows(const float* tile, long long row0
     if (Ck) atomicAdd(rk.ties + (k + 1) * rk.ld + orow, (unsigned long long)Ck);
   }
 }
+
+// the filter lists of one evaluation batch (kge_eval_batch: rank.hip's eval_begin_kernel / eval_end_kernel)
+constexpr int EV_MAXQ = 4;
+struct EvalLists {
+  int nq;
+  const long long* keys[EV_MAXQ];
+  long long num_keys[EV_MAXQ];
+  const long long* starts[EV_MAXQ];
+  const long long* values[EV_MAXQ];
+  long long mult[EV_MAXQ];
+  Index a[EV_MAXQ], b[EV_MAXQ], keep[EV_MAXQ];
+  long long* range[EV_MAXQ];             // [2][n]: begin, end of row i's values (kept for the clearing pass)
+  unsigned long long* bits[EV_MAXQ];     // [n][bld]
+};
 
 }  // namespace kge

@@ -397,6 +397,119 @@ int run_rank_bits(int lists, const long long* const* begin, const long long* con
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
+// ---- one evaluation batch in four launches (kge_eval_batch): the launch in front of the scoring and the one behind
+// it.  EvalLists: per list q = side * K + k (side 0: the sp_ ranking, key s * R + p, values = objects, the row's own
+// o never filtered; side 1: _po, key p * E + o, values = subjects, keep s): the filter index of set k.
+
+// blockIdx.y < nq: one WAVE per (row, list): the 64-ary search of filter_lookup_kernel, then the wave sets the bits
+// of the row's filtered columns.  blockIdx.y == nq: the target list of the true-score launch, (o | s) as int64.
+__global__ __launch_bounds__(256) void eval_begin_kernel(EvalLists L, Index s, Index o, long long n, long long m,
+                                                         long long bld, long long* __restrict__ tgt) {
+  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.y;
+  if (q == L.nq) {
+    if (lane == 0) {
+      tgt[i] = index_at(o, i);
+      tgt[n + i] = index_at(s, i);
+    }
+    return;
+  }
+  const long long* __restrict__ keys = L.keys[q];
+  const long long num_keys = L.num_keys[q];
+  const long long key = index_at(L.a[q], i) * L.mult[q] + index_at(L.b[q], i);
+  long long lo = 0, hi = num_keys;
+  while (hi - lo > 64) {
+    const long long step = (hi - lo + 63) >> 6;
+    const long long pos = lo + lane * step;
+    const bool below = pos < hi && keys[pos] < key;
+    const int c = __popcll(__ballot(below));
+    if (c == 0) {
+      hi = lo;
+    } else {
+      const long long nhi = lo + c * step;
+      lo = lo + (c - 1) * step + 1;
+      hi = nhi < hi ? nhi : hi;
+    }
+  }
+  const long long pos = lo + lane;
+  const bool below = pos < hi && keys[pos] < key;
+  lo += __popcll(__ballot(below));
+  const bool hit = lo < num_keys && keys[lo] == key;
+  const long long b = hit ? L.starts[q][lo] : 0, e = hit ? L.starts[q][lo + 1] : 0;
+  if (lane == 0) {
+    L.range[q][i] = b;
+    L.range[q][n + i] = e;
+  }
+  const long long keep = index_at(L.keep[q], i);
+  const long long* __restrict__ col = L.values[q];
+  unsigned long long* row = L.bits[q] + i * bld;
+  for (long long x = b + lane; x < e; x += 64) {
+    const long long g = col[x];
+    if (g == keep || g < 0 || g >= m) continue;
+    atomicOr(row + (g >> 6), 1ull << (g & 63));
+  }
+}
+
+// Blocks [0, nq * ceil(n / 4)): the filter bits of (row, list) cleared again (the words that were set: the buffer is
+// all-zero between batches).  The rest: _get_ranks (tie policy) + hist_all of both directions (rank_hist_kernel) on
+// the counters [2 (o | s)][2 (rank | ties)][M][n], which are zeroed for the next batch on the way.
+__global__ __launch_bounds__(256) void eval_end_kernel(EvalLists L, long long n, long long m, long long bld, int M,
+                                                       int policy, long long* __restrict__ counts,
+                                                       float* __restrict__ hist, long long ldh, long long num_ent,
+                                                       long long* __restrict__ ranks_o, long long* __restrict__ ranks_s) {
+  const long long rb = (n + 3) / 4;
+  const long long clear_blocks = (long long)L.nq * rb;
+  if ((long long)blockIdx.x < clear_blocks) {
+    const int q = (int)(blockIdx.x / rb);
+    const long long i = ((long long)blockIdx.x % rb) * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const long long b = L.range[q][i], e = L.range[q][n + i];
+    const long long keep = index_at(L.keep[q], i);
+    const long long* __restrict__ col = L.values[q];
+    unsigned long long* row = L.bits[q] + i * bld;
+    for (long long x = b + lane; x < e; x += 64) {
+      const long long g = col[x];
+      if (g == keep || g < 0 || g >= m) continue;
+      row[g >> 6] = 0ull;
+    }
+    return;
+  }
+  const long long t = ((long long)blockIdx.x - clear_blocks) * 256 + threadIdx.x;
+  const long long per = (long long)M * n;
+  if (t >= 2 * per) return;
+  const int dir = t >= per ? 1 : 0;
+  const long long u = t - dir * per;  // ranking * n + row
+  long long* rank = counts + (long long)(dir * 2) * per + u;
+  long long* ties = counts + (long long)(dir * 2 + 1) * per + u;
+  const long long r0 = *rank, ti = *ties;
+  *rank = 0;
+  *ties = 0;
+  const long long r = policy == 0 ? r0 + ti / 2 : (policy == 1 ? r0 : r0 + ti - 1);
+  long long* ro = dir ? ranks_s : ranks_o;
+  if (ro) ro[u] = r;
+  if (r >= 0 && r < num_ent) unsafeAtomicAdd(hist + (u / n) * ldh + r, 1.0f);
+}
+
+int run_eval_begin(const EvalLists& L, const Index& s, const Index& o, long long n, long long m, long long bld,
+                   long long* tgt, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  hipLaunchKernelGGL(eval_begin_kernel, dim3((unsigned)((n + 3) / 4), (unsigned)(L.nq + 1)), dim3(256), 0, st, L, s, o,
+                     n, m, bld, tgt);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+int run_eval_end(const EvalLists& L, long long n, long long m, long long bld, int M, int policy, long long* counts,
+                 float* hist, long long ldh, long long num_ent, long long* ranks_o, long long* ranks_s, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  const long long blocks = (long long)L.nq * ((n + 3) / 4) + (2LL * M * n + 255) / 256;
+  hipLaunchKernelGGL(eval_end_kernel, dim3((unsigned)blocks), dim3(256), 0, st, L, n, m, bld, M, policy, counts, hist,
+                     ldh, num_ent, ranks_o, ranks_s);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
 int run_rank_hist(const long long* rank, const long long* ties, int M, long long n, int policy, float* hist,
                   long long ldh, long long num_ent, long long* ranks_out, hipStream_t st) {
   const long long total = (long long)M * n;

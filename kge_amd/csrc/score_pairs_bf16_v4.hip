@@ -587,7 +587,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   if constexpr (EPI == V3_RANK) {
     long long orow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
     if (orow >= n) orow = n - 1;
-    rk_t = ce.rk_true[rk_side][orow];
+    rk_t = ce.rk_true[rk_side][orow * ce.rk_true_stride];
     if (rk_t != rk_t) rk_t = -__builtin_inff();
     rk_al = ce.rk_atol + __builtin_fabsf(ce.rk_rtol * rk_t);
     rk_slow = __any(!(__builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al))) != 0;

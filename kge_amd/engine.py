@@ -19,7 +19,7 @@ from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V3, FLAG_EXACT, FLAG_NO_MF
                    SCORERS, SP_, SP_PO, SPO, KgeIndex, KgeNextQueries, KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "embed", "rank_counts", "score_pitch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V3",
+           "score_emb", "embed", "rank_counts", "score_pitch", "eval_batch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V3",
            "FLAG_SPLIT_QUERY", "reserve_cus", "Queries", "build_queries", "score_queries", "ScorePipeline"]
 
 
@@ -720,6 +720,53 @@ def score_rank_emb_sp_po(scorer, s_emb, p_emb, o_emb, s_ids, o_ids, targets, col
 
 
 TIE_POLICIES = {"rounded_mean_rank": 0, "best_rank": 1, "worst_rank": 2}
+
+_EVAL_SCRATCH = {}  # (device index, stream) -> scratch of kge_eval_batch (ranges, target list, true-score block)
+
+
+def eval_batch(t: Tables, s, p, o, filters, atol, rtol, tie_policy, counts, hist, ranks_o=None, ranks_s=None,
+               flags=None) -> bool:
+    """One evaluation batch against all entities in four launches (kge_eval_batch): filter lookup + filter bits,
+    true scores, scoring + counting, bits cleared + tie policy + histograms.  filters = [((sp_keys, sp_starts,
+    sp_values), (po_keys, po_starts, po_values)), ...] (at most two: the device-resident filter indexes of
+    FilterIndex); counts: int64 [2, 2, len(filters) + 1, n], ALL-ZERO on entry and on return; hist: float32
+    [len(filters) + 1, E] accumulated; ranks_o / ranks_s: int64 [len(filters) + 1, n] or None.  False: the library
+    has no counting kernel for these tables -- nothing was counted."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = _same_len(keep[:3], "eval_batch")
+    K = len(filters)
+    M = K + 1
+    if counts.dtype != torch.int64 or tuple(counts.shape) != (2, 2, M, n) or not counts.is_contiguous():
+        raise ValueError("kge_amd: counts must be contiguous int64 [2, 2, filters + 1, n]")
+    if hist.dtype != torch.float32 or hist.shape[0] != M or hist.shape[1] < t.num_ent or hist.stride(1) != 1:
+        raise ValueError("kge_amd: hist must be float32 [filters + 1, >= num_entities]")
+    for r in (ranks_o, ranks_s):
+        if r is not None and (r.dtype != torch.int64 or tuple(r.shape) != (M, n) or not r.is_contiguous()):
+            raise ValueError("kge_amd: ranks must be contiguous int64 [filters + 1, n]")
+    arr = (_lib.KgeEvalFilter * max(K, 1))()
+    for k, (sp, po) in enumerate(filters):
+        arr[k] = _lib.KgeEvalFilter(sp[0].data_ptr(), sp[0].numel(), sp[1].data_ptr(), sp[2].data_ptr(),
+                                    po[0].data_ptr(), po[0].numel(), po[1].data_ptr(), po[2].data_ptr())
+    with _on_device(t.device):
+        tc = t.c(flags)
+        st = _stream_handle(t.device)
+        ws, wsb = _workspace(tc, n, t.device, True, st)
+        bits, bits_bytes = _rank_bits(_lib.lib().kge_score_rank_bits_bytes(n, t.num_ent, K), t.device, st)
+        need = _lib.lib().kge_eval_batch_scratch_bytes(ctypes.byref(tc), n, K)
+        key = (t.device.index, st)
+        buf = _EVAL_SCRATCH.get(key)
+        if buf is None or buf.numel() < need:
+            buf = _EVAL_SCRATCH[key] = torch.empty((max(need, 1 << 20),), device=t.device, dtype=torch.uint8)
+        rc = _lib.lib().kge_eval_batch(
+            ctypes.byref(tc), si, pi, oi, n, K, arr, float(atol), float(rtol), TIE_POLICIES.get(tie_policy, tie_policy)
+            if isinstance(tie_policy, str) else int(tie_policy), counts.data_ptr(), hist.data_ptr(), hist.stride(0),
+            None if ranks_o is None else ranks_o.data_ptr(), None if ranks_s is None else ranks_s.data_ptr(),
+            bits, bits_bytes, buf.data_ptr(), buf.numel(), ws, wsb, st)
+        if rc == _lib.KGE_ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc, "kge_eval_batch")
+    return True
 
 
 def rank_hist(rank, ties, tie_handling: str, hist, ranks_out=None):

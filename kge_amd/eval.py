@@ -150,6 +150,9 @@ class EntityRankingEvaluator:
         self._fused = os.environ.get("KGE_EVAL_TWO_STEP", "0") != "1"
         self._declined = set()  # batch sizes kge_score_rank_sp_po declined for these tables
         self._declined_for = None
+        # KGE_EVAL_LAUNCH_BY_LAUNCH=1: the fused loop as separate engine calls (a dozen launches per batch) instead of
+        # kge_eval_batch's four
+        self.four_launches = os.environ.get("KGE_EVAL_LAUNCH_BY_LAUNCH", "0") != "1"
         # replay the fused loop's full batches as one hipGraph (KGE_EVAL_GRAPH=0: issue every launch from Python)
         self.hip_graph = os.environ.get("KGE_EVAL_GRAPH", "1") != "0"
         self.graph_batches = 0  # batches that ran as graph replays (all runs)
@@ -173,6 +176,7 @@ class EntityRankingEvaluator:
             # [direction][rank | ties][ranking][row]
             "counts": torch.zeros(2, 2, K + 1, bs, dtype=torch.int64, device=dev),
             "diag": {},
+            "counts4": {},  # batch size -> all-zero counters of kge_eval_batch (it returns them zeroed)
         }
         for k in range(K):  # an empty value array still needs an address
             for side in ("sp", "po"):
@@ -266,8 +270,18 @@ class EntityRankingEvaluator:
         def do_batch(batch, rng, cnt, ro, rs):
             """One batch: filter ranges, counts (in place in `cnt`), tie policy + histogram; launches only."""
             s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
-            sc_, oc_ = s.contiguous(), o.contiguous()  # true_col of the po / sp rankings
             n = batch.shape[0]
+            if fused and chunk >= E and M <= 3 and n not in declined and self.four_launches:
+                # the whole batch in four launches (kge_eval_batch): filter lookup + filter bits | true scores |
+                # scoring + counting | bits cleared + tie policy + histograms + counters back to zero
+                c4 = st["counts4"].get(n)
+                if c4 is None:  # zero once; every call leaves it zero
+                    c4 = st["counts4"][n] = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)
+                if engine.eval_batch(tables, s, p, o, [(st["sp"][k], st["po"][k]) for k in range(M - 1)],
+                                     self.tie_atol, self.tie_rtol, self.tie_handling, c4, hist, ro, rs):
+                    return
+                declined.add(n)
+            sc_, oc_ = s.contiguous(), o.contiguous()  # true_col of the po / sp rankings
             cnt.zero_()
             filt_o, filt_s, lookups = [], [], []
             for k in range(M - 1):

@@ -230,13 +230,17 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
         T = eng.Tables(model, (torch.randn(E, d, generator=g) * 0.3).to(DEV),
                        (torch.randn(R, d // 2 if model == "rotate" else d, generator=g) * 0.3).to(DEV), 1.0)
     calls = {"fused": 0}
-    orig = eng.score_rank_sp_po
+    orig, orig_batch = eng.score_rank_sp_po, eng.eval_batch
 
     def counting(*a, **k):
         calls["fused"] += 1
         return orig(*a, **k)
 
-    eng.score_rank_sp_po = counting
+    def counting_batch(*a, **k):
+        calls["fused"] += 1
+        return orig_batch(*a, **k)
+
+    eng.score_rank_sp_po, eng.eval_batch = counting, counting_batch
     try:
         ev = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
         m1, r1 = ev.run(return_ranks=True)
@@ -247,6 +251,11 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
         ev3.hip_graph = False
         m3, r3 = ev3.run(return_ranks=True)
         assert ev3.graph_batches == 0 and m3 == m1 and all(np.array_equal(r1[k], r3[k]) for k in r1)
+        # unchunked batches go through kge_eval_batch (four launches); the same loop as separate engine calls
+        ev4 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
+        ev4.four_launches = False
+        m4, r4 = ev4.run(return_ranks=True)
+        assert m4 == m1 and all(np.array_equal(r1[k], r4[k]) for k in r1)
         m1b, _ = ev.run(return_ranks=True)  # a second run captures afresh
         assert m1b == m1
         ev2 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
@@ -255,7 +264,7 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
         m2, r2 = ev2.run(return_ranks=True)
         assert calls["fused"] == before
     finally:
-        eng.score_rank_sp_po = orig
+        eng.score_rank_sp_po, eng.eval_batch = orig, orig_batch
     for k in r2:
         assert np.array_equal(r1[k], r2[k]), (k, np.nonzero(r1[k] != r2[k])[0][:5])
     assert m1 == m2
