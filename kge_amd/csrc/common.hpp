@@ -399,25 +399,33 @@ struct RankArgs {
   int nfilt;                          // <= 2
   const unsigned long long* bits[2];  // bit (j & 63) of word [i * bits_ld + (j >> 6)]: column j is filtered for row i
   long long bits_ld;
+  int col_tiles;                      // column tiles a workgroup walks (its counts leave it once)
 };
 
 // A finished ROWS x COLS score tile sits in LDS (`tile`, row pitch LDT floats).  256 threads: thread t takes the W =
 // COLS * ROWS / 256 columns [seg * W, ...) of tile row t / SEGS -- W in {16, 64} divides 64 and the tile's first
 // column is a multiple of COLS, so the thread's columns lie inside ONE 64-bit filter word per filter set -- and
 // counts them against the row's true score with the arithmetic of rank.hip (count_one; a filtered column scores
-// -inf): per row, ranking and segment at most two int64 atomics leave the workgroup; no score does.
+// -inf) into its RankAcc.  A workgroup walks several column tiles of its rows (rank_acc_add per tile) and then
+// rank_acc_flush adds the SEGS lanes of a row together and issues the row's int64 atomics once: per row, ranking
+// and workgroup at most two atomics leave the workgroup (one tile per workgroup and one flush per segment was 750 k
+// atomics per evaluation batch at the FB15k-237 shape, more time than the scoring); no score does.
+struct RankAcc {
+  int G, C;          // raw: greater-and-not-close, close
+  int Gf[2], Cf[2];  // per filter set: the same with the filtered columns taken out (+ fc per filtered column)
+};
+
 template <int ROWS, int COLS, int LDT>
-__device__ __forceinline__ void rank_tile_rows(const float* tile, long long row0, long long col0, long long n,
-                                               long long m, const RankArgs& rk, int tid) {
+__device__ __forceinline__ void rank_acc_add(RankAcc& a, const float* tile, long long row0, long long col0,
+                                             long long n, long long m, const RankArgs& rk, int tid) {
   constexpr int SEGS = 256 / ROWS, W = COLS / SEGS;
   static_assert(W == 16 || W == 64, "segment = 16 or 64 columns");
   const int row = tid / SEGS, seg = tid % SEGS;
   const long long orow = row0 + row;
-  if (orow >= n) return;
+  const long long c0 = col0 + seg * W;  // first column of the segment (relative to the scored slice)
+  if (orow >= n || c0 >= m) return;
   float t = rk.tru[orow * rk.tru_stride];
   if (t != t) t = -__builtin_inff();
-  const long long c0 = col0 + seg * W;  // first column of the segment (relative to the scored slice)
-  if (c0 >= m) return;
   unsigned long long gm = 0ull, cm = 0ull, vm = 0ull;
   const float* src = tile + row * LDT + seg * W;
 #pragma unroll 8
@@ -431,16 +439,41 @@ __device__ __forceinline__ void rank_tile_rows(const float* tile, long long row0
     }
   }
   const int G = __builtin_popcountll(gm), C = __builtin_popcountll(cm);
-  if (G) atomicAdd(rk.rank + orow, (unsigned long long)G);
-  if (C) atomicAdd(rk.ties + orow, (unsigned long long)C);
+  a.G += G;
+  a.C += C;
   const int fc = t == -__builtin_inff() ? 1 : 0;  // is -inf (a filtered column's score) close to the true score
   const int sh = (int)(c0 & 63);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (k < rk.nfilt) {
+      const unsigned long long w = (rk.bits[k][orow * rk.bits_ld + (c0 >> 6)] >> sh) & vm;
+      a.Gf[k] += G - __builtin_popcountll(gm & w);
+      a.Cf[k] += C - __builtin_popcountll(cm & w) + fc * __builtin_popcountll(w);
+    }
+  }
+}
+
+// every thread of the workgroup calls this (wave shuffles)
+template <int ROWS>
+__device__ __forceinline__ void rank_acc_flush(RankAcc a, long long row0, long long n, const RankArgs& rk, int tid) {
+  constexpr int SEGS = 256 / ROWS;
+#pragma unroll
+  for (int off = 1; off < SEGS; off <<= 1) {
+    a.G += __shfl_xor(a.G, off, 64);
+    a.C += __shfl_xor(a.C, off, 64);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      a.Gf[k] += __shfl_xor(a.Gf[k], off, 64);
+      a.Cf[k] += __shfl_xor(a.Cf[k], off, 64);
+    }
+  }
+  const long long orow = row0 + tid / SEGS;
+  if (orow >= n || (tid % SEGS) != 0) return;
+  if (a.G) atomicAdd(rk.rank + orow, (unsigned long long)a.G);
+  if (a.C) atomicAdd(rk.ties + orow, (unsigned long long)a.C);
   for (int k = 0; k < rk.nfilt; ++k) {
-    const unsigned long long w = (rk.bits[k][orow * rk.bits_ld + (c0 >> 6)] >> sh) & vm;
-    const int Gk = G - __builtin_popcountll(gm & w);
-    const int Ck = C - __builtin_popcountll(cm & w) + fc * __builtin_popcountll(w);
-    if (Gk) atomicAdd(rk.rank + (k + 1) * rk.ld + orow, (unsigned long long)Gk);
-    if (Ck) atomicAdd(rk.ties + (k + 1) * rk.ld + orow, (unsigned long long)Ck);
+    if (a.Gf[k]) atomicAdd(rk.rank + (k + 1) * rk.ld + orow, (unsigned long long)a.Gf[k]);
+    if (a.Cf[k]) atomicAdd(rk.ties + (k + 1) * rk.ld + orow, (unsigned long long)a.Cf[k]);
   }
 }
 

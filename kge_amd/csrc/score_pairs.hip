@@ -45,8 +45,14 @@ __global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operan
   auto& Ts = QT[1];
 
   const int tid = threadIdx.x;
-  const long long col0 = (long long)blockIdx.x * PT_BN;
+  // RANK: this workgroup walks CT consecutive column tiles of its 64 rows and keeps the counts in registers
+  const int CT = RANK ? rk.col_tiles : 1;
   const long long row0 = (long long)blockIdx.y * PT_BM;
+  RankAcc racc{};
+  for (int ct = 0; ct < CT; ++ct) {
+  const long long col0 = ((long long)blockIdx.x * CT + ct) * PT_BN;
+  if (col0 >= m) break;
+  if (ct > 0) __syncthreads();  // the previous tile's epilogue is done with the operand buffers
   const int hh = (d + 1) / 2;  // coordinate pairs
   const int lim1 = d - hh;     // valid second-half elements
   const int nchunk = (hh + PT_KC - 1) / PT_KC;
@@ -175,8 +181,8 @@ __global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operan
         }
     }
     __syncthreads();
-    rank_tile_rows<PT_BM, PT_BN, PT_LD>(tile, row0, col0, n, m, rk, tid);
-    return;
+    rank_acc_add<PT_BM, PT_BN, PT_LD>(racc, tile, row0, col0, n, m, rk, tid);
+    continue;
   }
   if (DOT && MFMA) {
 #pragma unroll
@@ -204,6 +210,8 @@ __global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operan
       }
     }
   }
+  }  // column tiles
+  if constexpr (RANK) rank_acc_flush<PT_BM>(racc, row0, n, rk, tid);
 }
 
 // ---- host dispatch ------------------------------------------------------------------------
@@ -226,11 +234,16 @@ static int launch_pairs(bool vec, bool mfma, const Operand& A, const Operand& R,
                         float lp, int round_q, float* out, long long ldo, hipStream_t st, const RankArgs* rk) {
   dim3 grid((unsigned)((m + PT_BN - 1) / PT_BN), (unsigned)((n + PT_BM - 1) / PT_BM));
   constexpr bool DOT = (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT);
+  // counting launch: column tiles per workgroup -- as many as still leave four workgroups per compute unit (<= 16)
+  RankArgs r2 = rk != nullptr ? *rk : RankArgs{};
+  long long ctn = (long long)grid.x * grid.y / 1024;
+  r2.col_tiles = (int)(ctn < 1 ? 1 : (ctn > 16 ? 16 : ctn));
+  dim3 rgrid((grid.x + r2.col_tiles - 1) / r2.col_tiles, grid.y);
 #define KGE_PL(VEC, MF)                                                                               \
   do {                                                                                                \
     if (rk != nullptr)                                                                                \
-      hipLaunchKernelGGL((pairs_kernel<SCORER, T, NORM, VEC, MF, true>), grid, dim3(256), 0, st, A, R, \
-                         TG, dir, d, dr, n, m, lp, round_q, out, ldo, *rk);                           \
+      hipLaunchKernelGGL((pairs_kernel<SCORER, T, NORM, VEC, MF, true>), rgrid, dim3(256), 0, st, A, R, \
+                         TG, dir, d, dr, n, m, lp, round_q, out, ldo, r2);                            \
     else                                                                                              \
       hipLaunchKernelGGL((pairs_kernel<SCORER, T, NORM, VEC, MF, false>), grid, dim3(256), 0, st, A, R, \
                          TG, dir, d, dr, n, m, lp, round_q, out, ldo, RankArgs{});                     \

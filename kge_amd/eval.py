@@ -127,6 +127,11 @@ def compute_metrics(rank_hist: torch.Tensor, hits_at_k_s, suffix="") -> Dict[str
 class EntityRankingEvaluator:
     """Mirror of EntityRankingJob._evaluate (eval_entity_ranking.py:103-481)."""
 
+    # score-matrix bytes (both directions of a batch) from which float32 / TransE / RotatE tables are counted inside
+    # the exact kernels instead of scored and scanned (see run())
+    FUSED_EXACT_MIN_BYTES = 1 << 30
+
+
     def __init__(self, model, splits: Dict[str, np.ndarray], num_entities: int, num_relations: int,
                  eval_split: str = "valid", filter_splits=("train", "valid"),
                  filter_with_test: bool = True, batch_size: int = 100, chunk_size: int = -1,
@@ -263,6 +268,14 @@ class EntityRankingEvaluator:
         # library declines (other bf16 shapes) is remembered per batch size and scored in two steps
         fused = (self._fused and isinstance(tables, engine.Tables) and M <= 3
                  and not (tables.flags & engine.FLAG_SPLIT_QUERY))
+        # the exact kernels' counting epilogue (float32 tables, TransE / RotatE) saves the [n, 2E] score matrix, not
+        # time: their scoring is compute-bound and the true scores cost a launch pair of their own (C4 shape,
+        # float32 DistMult: 0.35 ms per batch against 0.24 for score + scan, tools/eval_f32_probe.py) -- taken when
+        # the matrix would be large (FUSED_EXACT_MIN_BYTES) or asked for (KGE_EVAL_FUSED_EXACT=1)
+        if fused and (tables.ent.dtype != torch.bfloat16 or
+                      tables.scorer not in (engine.SCORERS["complex"], engine.SCORERS["distmult"])):
+            want = os.environ.get("KGE_EVAL_FUSED_EXACT")
+            fused = (want == "1") if want is not None else 8 * self.batch_size * min(chunk, E) >= self.FUSED_EXACT_MIN_BYTES
         if self._declined_for != gkey:  # other tables: ask again
             self._declined_for, self._declined = gkey, set()
         declined = self._declined

@@ -134,6 +134,15 @@ class HipEntityRankingJob(EntityRankingJob):
         fused_tables = getattr(self.model, "_rank_tables", None)
         if os.environ.get("KGE_EVAL_TWO_STEP", "0") == "1" or M > 3 or fused_tables is None or fused_tables() is None:
             fused_tables = None
+        # (the exact kernels' counting saves the score matrix, not time -- kge_amd.eval.EntityRankingEvaluator.run:
+        # taken from FUSED_EXACT_MIN_BYTES of score matrix on, or with KGE_EVAL_FUSED_EXACT=1)
+        if fused_tables is not None and (fused_tables().ent.dtype != torch.bfloat16
+                                         or self.model._scorer.name not in ("complex", "distmult")):
+            from ..eval import EntityRankingEvaluator as _Ev
+            want = os.environ.get("KGE_EVAL_FUSED_EXACT")
+            if not ((want == "1") if want is not None
+                    else 8 * self.batch_size * min(chunk_size, E) >= _Ev.FUSED_EXACT_MIN_BYTES):
+                fused_tables = None
         # hip_entity_ranking.bf16_queries (hip_entity_ranking.yaml): "split" (default) scores bf16 tables with split
         # queries -- rank parity with float32 arithmetic on those tables -- through the two-step path; "single" takes
         # the counting kernel (one rounded query vector per row)

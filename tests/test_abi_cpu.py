@@ -121,8 +121,23 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_score_rank_sp_po(*rank_args(bf16, 4, 0, bf16.num_ent + 1, 0)) == -1   # slice beyond the table
     assert lib.kge_score_rank_sp_po(*rank_args(bf16, 4, 0, bf16.num_ent, 3)) == -2        # > 2 filter sets
     assert lib.kge_score_rank_sp_po(*rank_args(bf16, 4, 0, bf16.num_ent, 1)) == -1        # filter lists missing
-    assert lib.kge_score_rank_sp_po(*rank_args(f32, 4, 0, f32.num_ent, 0)) == -2           # float32 tables
-    assert lib.kge_score_rank_sp_po(*rank_args(transe, 4, 0, transe.num_ent, 0)) == -2     # TransE
+    # (float32 tables and TransE / RotatE count in the exact kernels since round 3: no decline to test without a device)
+    assert lib.kge_score_rank_sp_po(*rank_args(odd, 4, 0, odd.num_ent, 0)) == -2           # bf16 at a dim without a counting kernel
+    split = KgeTables(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 0, 10, 3, 512, 512, 512, 512, 1.0, 32)
+    assert lib.kge_score_rank_sp_po(*rank_args(split, 4, 0, split.num_ent, 0)) == -2       # split queries
+    # one evaluation batch in four launches: size arithmetic and argument checks
+    assert lib.kge_eval_batch_scratch_bytes(ctypes.byref(bf16), 512, 2) >= 2 * 2 * 2 * 512 * 8 + 2 * 512 * 8 + 512 * 4 * 512 * 4
+    assert lib.kge_eval_batch_scratch_bytes(ctypes.byref(bf16), 0, 2) == 0
+    assert lib.kge_eval_batch_scratch_bytes(ctypes.byref(bf16), 512, 3) == 0
+    ev_args = lambda t_, n, k, pol=0, counts=P, scratch=P, sb=1 << 30: (
+        ctypes.byref(t_), good, good, good, n, k, None, 1e-5, 1e-4, pol, counts, P, 16, None, None, None, 0, scratch,
+        sb, P, 1 << 20, None)
+    assert lib.kge_eval_batch(*ev_args(bf16, 4, 3)) == -2                  # > 2 filter sets
+    assert lib.kge_eval_batch(*ev_args(bf16, 4, 0, pol=9)) == -1           # unknown tie policy
+    assert lib.kge_eval_batch(*ev_args(bf16, 4, 1)) == -1                  # filters missing
+    assert lib.kge_eval_batch(*ev_args(bf16, 4, 0, counts=None)) == -1     # no counters
+    assert lib.kge_eval_batch(*ev_args(bf16, 4, 0, sb=64)) == -5           # scratch too small
+    assert lib.kge_eval_batch(*ev_args(bf16, 0, 0)) == 0                   # empty batch
     assert lib.kge_score_rank_sp_po(*rank_args(bf16, 0, 0, bf16.num_ent, 0)) == 0          # empty batch
     assert lib.kge_rank_hist(None, None, 3, 4, 7, None, 10, 10, None, None) == -1   # unknown tie policy
     assert lib.kge_rank_hist(None, None, 0, 0, 0, None, 10, 10, None, None) == 0

@@ -213,7 +213,7 @@ def test_exact_kernels_count_what_their_store_path_gives(model, dtype, flags, E,
     ("complex", 2500, 512, 64, 999, torch.bfloat16), ("distmult", 700, 256, 300, 64, torch.bfloat16),
     ("complex", 3000, 128, 100, -1, torch.float32), ("transe", 2000, 64, 77, -1, torch.float32),
     ("rotate", 1500, 64, 64, 999, torch.float32)])
-def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d, bs, chunk, dtype):
+def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d, bs, chunk, dtype, monkeypatch):
     """EntityRankingEvaluator (the mirror of EntityRankingJob._evaluate) takes the fused entry for bf16 ComplEx /
     DistMult tables and for float32 tables of every scorer: per-example ranks (raw, filtered, filtered-with-test;
     both directions; ragged last batch; entity chunks) and metrics identical to the same loop over kge_score_sp_po +
@@ -231,6 +231,7 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
                        (torch.randn(R, d // 2 if model == "rotate" else d, generator=g) * 0.3).to(DEV), 1.0)
     calls = {"fused": 0}
     orig, orig_batch = eng.score_rank_sp_po, eng.eval_batch
+    monkeypatch.setenv("KGE_EVAL_FUSED_EXACT", "1")  # float32 tables: by default only from 1 GiB of score matrix on
 
     def counting(*a, **k):
         calls["fused"] += 1

@@ -47,7 +47,7 @@ def test_sharded_job_on_the_engine_follows_the_reference_step(model, d):
     assert float((sd[ENT_KEY] - ent.detach()).abs().max()) <= 1e-2 * moved + 1e-5
     assert float((sd[REL_KEY] - rel.detach()).abs().max()) <= 1e-2 * float((rel.detach() - sd0[REL_KEY]).abs().max()) + 1e-5
     # the one-pass Adagrad kernel on this rank's rows + the checkpoint round trip: a fresh job resumed from the
-    # checkpoint takes the same next step, bit for bit
+    # checkpoint takes the same next step
     job = ShardedTrainingJob1vsAll(model, E, R, d, seed=11, lr=0.1, optimizer="Adagrad", device=DEV)
     assert type(job.optimizer).__module__ == "kge_amd.optim"
     for b in batches[:2]:
@@ -58,5 +58,6 @@ def test_sharded_job_on_the_engine_follows_the_reference_step(model, d):
     job2 = ShardedTrainingJob1vsAll(model, E, R, d, seed=12, lr=0.1, optimizer="Adagrad", device=DEV)
     job2.load_checkpoint(ck)
     l_b = float(job2.step(batches[2]))
-    assert l_a == l_b
-    assert torch.equal(job.state_dict()[ENT_KEY], job2.state_dict()[ENT_KEY])
+    assert l_a == l_b   # same tables, same optimizer state: the same forward
+    # (the query-row gradients are scatter-added with float atomics -- index_add_ -- whose order is not fixed)
+    torch.testing.assert_close(job.state_dict()[ENT_KEY], job2.state_dict()[ENT_KEY], rtol=0, atol=1e-5)
