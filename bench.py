@@ -55,6 +55,8 @@ def parse():
                     help="skip the reference region of one-sided launches (profiling runs: the kernel "
                          "trace then holds two-sided launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="batches in flight in the timed region: batch k is launched on HIP stream k %% streams")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is run this many times; the median region is reported")
     ap.add_argument("--shape", choices=["wikidata5m", "fb15k"], default="wikidata5m",
@@ -472,6 +474,7 @@ def main():
     q2 = torch.Generator().manual_seed(2)
     batch_b = tuple(torch.randint(hi, (n,), generator=q2).to(device) for hi in (E_FB, R_FB, E_FB))
     batches = [(s, p, o), batch_b]
+    tri = [torch.stack(b, 1).contiguous() for b in batches]  # the reference's batch["triples"]: [n, 3], columns s, p, o
     # Score rows on a 256-byte pitch (the C ABI's `ldo`: 2 x 14,656 floats per row, the two blocks at column 0 and
     # 14,656; engine.score_pitch): every 16-byte store of the kernel then covers whole 32-byte sectors.  The reference's contiguous
     # [n, 2E] layout (rows at 4-byte granularity) is measured beside it (`contiguous_pitch`).
@@ -485,14 +488,39 @@ def main():
 
     def one_step():  # KgeModel.score_sp_po of the current batch: both score blocks, one launch
         step_no[0] += 1
-        pipe.step(next_batch=batches[step_no[0] & 1], out=out_buf)
+        pipe.step(next_batch=tri[step_no[0] & 1], out=out_buf)
+
+    # The timed steps: the same launch per batch, batches alternating between `a.streams` HIP streams (lanes), each
+    # with its own score buffer and its own pair of query buffers (a lane's launch builds the queries of that lane's
+    # next batch).  A scoring launch leaves compute units idle at both ends (launch gap, cold first tiles, the last
+    # stores' acknowledgements) and 28 of 256 for its whole duration (228 workgroups); the next batch's launch on
+    # the other stream runs there.  Every step is a complete pass over one batch; the region ends with a device-wide
+    # synchronize, so all K batches are fully scored inside it.
+    L = max(1, a.streams)
+    pipeL = engine.ScorePipeline(T, "sp_po", n, streams=L) if L > 1 else pipe
+    outs = [out_buf] + [torch.empty(n, 2 * PITCH, device=device).view(n, 2, PITCH)[:, :, :E_FB] for _ in range(L - 1)]
+    if L > 1:
+        pipeL.start([tri[0]] * L)
+    stepL = [0]
 
     def run_steps(k):
+        c = stepL[0]
         for _ in range(k):
-            one_step()
+            # lane c % L scores its current batch and builds its next one (alternating the two synthetic batches)
+            pipeL.step(next_batch=tri[(c // L + 1) & 1], out=outs[c % L])
+            c += 1
+        stepL[0] = c
 
     run_steps(a.warmup)
     el, regions, host_el = timed_regions(run_steps, torch.cuda.synchronize, a.steps, a.repeats)
+    if L > 1:  # every lane's last batch, bit for bit against the same batch scored alone on the current stream
+        pipeL.join()
+        torch.cuda.synchronize()
+        for lane in range(L):
+            c = max(k for k in range(stepL[0] - L, stepL[0]) if k % L == lane)
+            want = engine.score_queries(T, engine.build_queries(T, "sp_po", *batches[(c // L) & 1]))
+            if not torch.equal(outs[lane], want.view(n, 2, E_FB)):
+                raise SystemExit("bench: lane %d of the two-stream pipeline differs from the single launch" % lane)
 
     # Duration of one scoring call (= one launch of the dominant kernel pairs_bf16_v4_kernel): HIP
     # events on the launch stream bracketing a region of the same K steps.  Back-to-back calls
@@ -531,7 +559,7 @@ def main():
 
         def one_sp():  # score_sp of the current batch, the next batch's queries built in the same launch
             k1[0] += 1
-            pipe1.step(next_batch=batches[k1[0] & 1], out=out1)
+            pipe1.step(next_batch=tri[k1[0] & 1], out=out1)
         for _ in range(5):
             one_sp()
         one_ms = event_avg_ms(one_sp, a.steps)
@@ -546,6 +574,24 @@ def main():
                                      "frac": ab1 / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "one_call_entry_us": one_coop_ms * 1e3,
                                      "one_call_entry_frac": ab1 / (one_coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if L > 1:  # the one-sided launch with `streams` batches in flight (host-issue bound below ~10 us per step)
+            pipe1L = engine.ScorePipeline(T, "sp_", n, streams=L)
+            outs1 = [torch.empty(n, PITCH, device=device)[:, :E_FB] for _ in range(L)]
+            pipe1L.start([tri[0]] * L)
+            c1 = [0]
+
+            def run1(k):
+                c = c1[0]
+                for _ in range(k):
+                    pipe1L.step(next_batch=tri[(c // L + 1) & 1], out=outs1[c % L])
+                    c += 1
+                c1[0] = c
+            run1(20)
+            el1, _, host1 = timed_regions(run1, torch.cuda.synchronize, a.steps, 3)
+            extra["one_sided_launch"]["timed_region"] = {
+                "streams": L, "us_per_step": el1 / a.steps * 1e6, "host_issue_us_per_step": host1 / a.steps * 1e6,
+                "frac": ab1 / (el1 / a.steps) / 1e9 / HBM_PEAK_GBS}
+            del pipe1L, outs1
         # split queries (KGE_FLAG_SPLIT_QUERY: q = q_hi + q_lo, f32-level parity on the bf16 tables -- the evaluation
         # setting): the same pipelined step, twice the MFMA work per score
         TS = engine.Tables("complex", ent, rel, flags=engine.FLAG_SPLIT_QUERY)
@@ -629,6 +675,7 @@ def main():
                         "rows on a 256-byte pitch)",
             "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n,
             "parallelism": "single GPU",
+            "streams": L,  # batches in flight in the timed region (batch k on HIP stream k % streams)
         },
         "roofline": {
             "bound": "hbm",
@@ -647,6 +694,9 @@ def main():
             "one_call_entry_us": coop_ms * 1e3,  # kge_score_sp_po: the query build inside the launch (cooperative)
             "one_call_entry_frac": ab / (coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": pmc_traffic(),
+            # the timed region of `value`: `streams` launches in flight; chip-level rate = the same bytes / ms_per_step
+            "timed_region": {"streams": L, "us_per_step": el / a.steps * 1e6,
+                             "achieved": ab / (el / a.steps) / 1e9, "frac": ab / (el / a.steps) / 1e9 / HBM_PEAK_GBS},
             **extra,
         },
     }

@@ -132,6 +132,27 @@ def _index(ix, device, keep):
     return KgeIndex(ix.data_ptr(), I32 if ix.dtype == torch.int32 else I64, 0, stride)
 
 
+def _index3(triples, device, keep):
+    """An [n, 3] int32/int64 triples tensor (the reference's batch["triples"]: s, p, o = its columns,
+    kge/job/eval_entity_ranking.py:196-199, train_1vsAll.py:53) -> three KgeIndex on the one allocation."""
+    if triples.device != device:
+        raise RuntimeError(f"kge_amd: index tensor on {triples.device}, tables on {device}")
+    if triples.dim() != 2 or triples.shape[1] != 3:
+        raise ValueError("kge_amd: a batch is (s, p, o) or an [n, 3] triples tensor")
+    if triples.dtype not in (torch.int32, torch.int64):
+        triples = triples.long()
+    st0, st1 = triples.stride()
+    if st0 < 1 or st1 < 1:
+        triples = triples.contiguous()
+        st0, st1 = 3, 1
+    keep.append(triples)
+    it, w = (I32, 4) if triples.dtype == torch.int32 else (I64, 8)
+    base = triples.data_ptr()
+    n = triples.shape[0]
+    st = st0 if n > 1 else 1
+    return KgeIndex(base, it, 0, st), KgeIndex(base + st1 * w, it, 0, st), KgeIndex(base + 2 * st1 * w, it, 0, st), n
+
+
 def _same_len(ixs, what):
     """All index operands of one call must have the same length (the reference would raise a shape
     error; a shorter vector here would be an out-of-bounds read on the device)."""
@@ -286,27 +307,34 @@ class Queries:
         self.combine, self.n, self.flags = combine, n, flags
 
 
-def build_queries(t: Tables, combine: str, s, p, o, flags=None, out: Queries = None) -> Queries:
-    """Query vectors of the batch (s, p, o) for `score_queries` (combine "sp_": s, p; "_po": p, o; "sp_po": all)."""
+def build_queries(t: Tables, combine: str, s, p=None, o=None, flags=None, out: Queries = None, stream=None) -> Queries:
+    """Query vectors of the batch (s, p, o) for `score_queries` (combine "sp_": s, p; "_po": p, o; "sp_po": all).
+    stream: a raw hipStream_t to launch on (default: torch's current stream)."""
     keep = []
-    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
-    n = _same_len([k for k in keep], "build_queries")
+    if o is None and p is None and torch.is_tensor(s) and s.dim() == 2:  # [n, 3] triples
+        si, pi, oi, n = _index3(s, t.device, keep)
+    else:
+        si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+        n = _same_len([k for k in keep], "build_queries")
     q = out if out is not None else Queries(t, combine, n, flags)
     if q.n != n or q.combine != combine:
         raise ValueError("kge_amd: build_queries: the Queries buffer was sized for another batch shape")
     with _on_device(t.device):
         tc = t.c(q.flags)
         rc = _lib.lib().kge_build_queries(ctypes.byref(tc), _COMBINE[combine], si, pi, oi, n, q.buf.data_ptr(),
-                                          q.buf.numel(), _stream_handle(t.device))
+                                          q.buf.numel(), _stream_handle(t.device) if stream is None else stream)
         if rc:
             _lib.check(rc, "kge_build_queries")
     return q
 
 
-def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None, next_queries: Queries = None):
+def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None, next_queries: Queries = None,
+                  stream=None):
     """[n, m] ("sp_", "_po") or [n, 2m] ("sp_po") scores of the prepared batch `q` against all / the listed
     entities -- the bits of score_sp / score_po / score_sp_po.  next_batch = (s, p, o) + next_queries: the NEXT
-    batch's queries are built by idle workgroups of the same launch (one launch per batch, no start-up chain)."""
+    batch's queries are built by idle workgroups of the same launch (one launch per batch, no start-up chain).
+    stream: a raw hipStream_t to launch on (default: torch's current stream; the caller orders it against the
+    producers of the operands and the consumers of `out`)."""
     keep = []
     ti = _index(targets, t.device, keep)
     m = t.num_ent if targets is None else keep[-1].numel()
@@ -325,8 +353,11 @@ def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None
     nxt = None
     if next_batch is not None:
         nkeep = []
-        si, pi, oi = (_index(x, t.device, nkeep) for x in next_batch)
-        nn = _same_len(nkeep, "score_queries(next_batch)")
+        if torch.is_tensor(next_batch):  # [n, 3] triples: one allocation, three strided index vectors
+            si, pi, oi, nn = _index3(next_batch, t.device, nkeep)
+        else:
+            si, pi, oi = (_index(x, t.device, nkeep) for x in next_batch)
+            nn = _same_len(nkeep, "score_queries(next_batch)")
         keep += nkeep
         if next_queries.n != nn or next_queries.combine != q.combine or next_queries.flags != q.flags:
             raise ValueError("kge_amd: score_queries: next_queries does not match the next batch")
@@ -335,34 +366,96 @@ def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None
         tc = t.c(q.flags)
         rc = _lib.lib().kge_score_queries(ctypes.byref(tc), _COMBINE[q.combine], q.buf.data_ptr(), q.n, ti, m,
                                           out.data_ptr(), ldo, b2, ctypes.byref(nxt) if nxt is not None else None,
-                                          _stream_handle(t.device))
+                                          _stream_handle(t.device) if stream is None else stream)
         if rc:
             _lib.check(rc, "kge_score_queries")
     return out
 
 
 class ScorePipeline:
-    """A stream of equally shaped batches through `score_queries`: batch k is scored while batch k + 1's queries
-    are built inside the same launch (two alternating Queries buffers).
+    """A stream of equally shaped batches through `score_queries`: batch k is scored while a later batch's queries
+    are built inside the same launch (two alternating Queries buffers per lane).
 
         pipe = ScorePipeline(T, "sp_po", n); pipe.start(s0, p0, o0)
         for k in ...: scores = pipe.step(next_batch=(s, p, o) of batch k + 1 or None)
+
+    streams = L > 1: L batches in flight, batch k on HIP stream k % L (lane k % L).  One scoring launch fills the
+    chip for ~10-20 us, of which the first ~2 us (launch gap, cold first tiles) and the last ~1 us (the last stores'
+    acknowledgements) leave compute units idle, as do the 256 - 228 units a [512 x 14,541] grid cannot use; the
+    launch of the next batch on ANOTHER stream runs in those holes (measured: 13.5 -> 10.3 us per one-sided batch,
+    22.0 -> 18.9 us two-sided, tools/dual_stream_probe.py).  A lane's launch builds the queries of that lane's next
+    batch, so `next_batch` is the batch L steps ahead:
+
+        pipe = ScorePipeline(T, "sp_po", n, streams=2); pipe.start([(s0, p0, o0), (s1, p1, o1)])
+        for k in ...: scores_k = pipe.step(next_batch=batch k + 2, out=buffers[k % 2])
+        pipe.join()   # torch's current stream waits for the lanes (consumers on other streams: pipe.event(k % 2))
+
+    fork() (called by start()) orders the lanes behind the current stream: the producers of the tables and of the
+    batches' index tensors, and the READERS of a score buffer that a later step overwrites -- call it again after
+    consuming scores on the current stream and before handing the same buffer to step() once more.
     """
 
-    def __init__(self, t: Tables, combine: str, n: int, flags=None):
+    def __init__(self, t: Tables, combine: str, n: int, flags=None, streams: int = 1):
         self.t = t
-        self.q = [Queries(t, combine, n, flags), Queries(t, combine, n, flags)]
-        self.cur = 0
+        self.lanes = max(1, int(streams))
+        self.q = [[Queries(t, combine, n, flags), Queries(t, combine, n, flags)] for _ in range(self.lanes)]
+        self.cur = [0] * self.lanes
+        self.k = 0
+        self._streams = None
+        if self.lanes > 1:
+            self._streams = [torch.cuda.Stream(device=t.device) for _ in range(self.lanes)]
+            self._handles = [st.cuda_stream for st in self._streams]
 
-    def start(self, s, p, o):
-        self.cur = 0
-        build_queries(self.t, self.q[0].combine, s, p, o, out=self.q[0])
+    def _handle(self, lane):
+        return None if self._streams is None else self._handles[lane]
+
+    def fork(self):
+        """The lanes wait for everything issued to torch's current stream so far."""
+        if self._streams is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            for st in self._streams:
+                st.wait_event(ev)
+
+    def event(self, lane: int):
+        """An event recorded behind the last launch of `lane` (None with a single lane: the current stream)."""
+        if self._streams is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._streams[lane])
+        return ev
+
+    def join(self):
+        """Torch's current stream waits for every lane."""
+        if self._streams is not None:
+            cur = torch.cuda.current_stream(self.t.device)
+            for lane in range(self.lanes):
+                cur.wait_event(self.event(lane))
+
+    def start(self, s, p=None, o=None):
+        """The first batch (one lane) or the list of the first `streams` batches."""
+        first = [s if p is None and o is None and torch.is_tensor(s) and s.dim() == 2 else (s, p, o)] \
+            if self._streams is None else list(s)
+        if len(first) != self.lanes:
+            raise ValueError("kge_amd: ScorePipeline.start takes the first `streams` batches")
+        self.fork()
+        self.k = 0
+        for lane, b in enumerate(first):
+            self.cur[lane] = 0
+            b = (b, None, None) if torch.is_tensor(b) else b
+            build_queries(self.t, self.q[lane][0].combine, *b, out=self.q[lane][0], stream=self._handle(lane))
 
     def step(self, next_batch=None, targets=None, out=None):
-        q, nq = self.q[self.cur], self.q[1 - self.cur]
-        res = score_queries(self.t, q, targets, out, next_batch, nq if next_batch is not None else None)
+        lane = self.k % self.lanes
+        self.k += 1
+        c = self.cur[lane]
+        q, nq = self.q[lane][c], self.q[lane][1 - c]
+        res = score_queries(self.t, q, targets, out, next_batch, nq if next_batch is not None else None,
+                            stream=self._handle(lane))
+        if out is None and self._streams is not None:
+            res.record_stream(self._streams[lane])
         if next_batch is not None:
-            self.cur = 1 - self.cur
+            self.cur[lane] = 1 - c
         return res
 
 

@@ -110,6 +110,35 @@ def test_next_batch_is_built_inside_the_launch(eng, combine):
             _same(got, direct(*batches[k]), f"{combine} n={n} batch {k}")
 
 
+@pytest.mark.parametrize("combine,lanes", [("sp_po", 2), ("sp_", 3)])
+def test_batches_in_flight_on_several_streams(eng, combine, lanes):
+    """ScorePipeline(streams = L): batch k on HIP stream k % L, its launch building the queries of batch k + L (given
+    as the reference's [n, 3] triples tensor); seven different batches = seven direct calls, bit for bit, each lane
+    writing its own score buffer while the other lanes' launches are in flight."""
+    E, R, d, n = 14541, 237, 512, 512
+    T, _, _ = _tables(eng, "complex", E, R, d, 6)
+    direct = {"sp_": lambda s, p, o: eng.score_sp(T, s, p), "sp_po": lambda s, p, o: eng.score_sp_po(T, s, p, o)}[combine]
+    nb = 7
+    trip = [torch.stack(_batch(E, R, n, 20 + k), dim=1).contiguous() for k in range(nb)]
+    want = [direct(t[:, 0], t[:, 1], t[:, 2]) for t in trip]
+    torch.cuda.synchronize()
+    pipe = eng.ScorePipeline(T, combine, n, streams=lanes)
+    outs = [torch.empty_like(want[0]) for _ in range(lanes)]
+    pipe.start(trip[:lanes])
+    got = []
+    for k in range(nb):
+        res = pipe.step(next_batch=trip[k + lanes] if k + lanes < nb else None, out=outs[k % lanes])
+        assert res.data_ptr() == outs[k % lanes].data_ptr()
+        if k % lanes == lanes - 1 or k == nb - 1:   # the consumer side: wait for the lanes, then read their buffers
+            pipe.join()
+            for j in range(k - k % lanes, k + 1):
+                got.append(outs[j % lanes].clone())
+            pipe.fork()                             # ... and the lanes wait for the readers before the buffers are reused
+    torch.cuda.synchronize()
+    for k in range(nb):
+        _same(got[k], want[k], f"{combine} lanes={lanes} batch {k}")
+
+
 def test_empty_and_mismatched_arguments(eng):
     T, _, _ = _tables(eng, "distmult", 500, 7, 256, 7)
     s, p, o = _batch(500, 7, 64, 8)

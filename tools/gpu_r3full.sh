@@ -16,12 +16,12 @@ echo "smoke exit: $?" >> $OUT/env.log
 timeout 900 python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit: $?" >> $OUT/env.log
 cd /tmp
-B="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-one-sided"
+B="python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-one-sided --streams 1"  # one launch at a time: the trace's average duration is roofline.avg_launch_us
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof -o bench -- $B > $R/$OUT/prof_bench.json 2> $R/$OUT/prof.err
 echo "rocprof two-sided exit: $?" >> $R/$OUT/env.log
 if [ "$MODE" != "nopmc" ]; then
 for C in FETCH_SIZE WRITE_SIZE; do
-timeout 300 rocprofv3 --pmc $C -d $R/$OUT/pmc_$C -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-one-sided > /dev/null 2> $R/$OUT/pmc_$C.err
+timeout 300 rocprofv3 --pmc $C -d $R/$OUT/pmc_$C -o bench -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-one-sided --streams 1 > /dev/null 2> $R/$OUT/pmc_$C.err
 echo "pmc $C exit: $?" >> $R/$OUT/env.log
 done
 fi
