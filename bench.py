@@ -55,8 +55,9 @@ def parse():
                     help="skip the reference region of one-sided launches (profiling runs: the kernel "
                          "trace then holds two-sided launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--streams", type=int, default=2,
-                    help="batches in flight in the timed region: batch k is launched on HIP stream k %% streams")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="batches in flight in the timed region: batch k is launched on HIP stream k %% streams "
+                         "(default 2; the sharded step with ONE rank: 1 -- it is bound by the host issuing it)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is run this many times; the median region is reported")
     ap.add_argument("--shape", choices=["wikidata5m", "fb15k"], default="wikidata5m",
@@ -342,6 +343,7 @@ def sharded_workload(shape, world, rank, device, n, engine):
 def main_sharded(a, world, rank, device):
     import torch.distributed as td
     from kge_amd import engine
+    from kge_amd.sharded import ShardedScoreLanes
     td.init_process_group("nccl", device_id=device)
     n = a.batch
 
@@ -358,9 +360,21 @@ def main_sharded(a, world, rank, device):
     for shape in ("wikidata5m", "fb15k"):
         sh, s, p, o, E, d = sharded_workload(shape, world, rank, device, n, engine)
 
-        def run_steps(k, sh=sh, s=s, p=p, o=o):
-            for _ in range(k):
-                sh.score_sp_po_blocks(s, p, o)  # exchange (gather, all-gather, gather) + the scoring launch(es)
+        # `--streams` batches in flight (kge_amd.sharded.ShardedScoreLanes: batch k's exchange and scoring on HIP
+        # stream k % L; the exchange of batch k + 1 runs under the scoring launch of batch k); slabs that outgrow
+        # the Infinity Cache (the Wikidata5M shards) go one batch at a time -- two of them in flight would be
+        # 2 x 2.4 GB of scores written at once for an exchange that is 1 % of the step
+        big_slab = n * (sh.hi - sh.lo) * 4 > sh.BIG_SLAB_BYTES
+        lanes = ShardedScoreLanes(sh, 1 if big_slab else max(1, a.streams if a.streams is not None else
+                                                             (2 if world > 1 else 1)))
+
+        def run_steps(k, lanes=lanes, s=s, p=p, o=o):
+            lanes.fork()
+            for i in range(k):
+                lanes.score_sp_po_blocks(s, p, o)  # exchange (gather, all-gather, gather) + the scoring launch(es)
+                if (i + 1) % lanes.L == 0:
+                    lanes.join()  # the consumer's wait; the slabs of the two batches are released here
+            lanes.join()
 
         run_steps(a.warmup)
         el, regions, host = timed_regions(run_steps, sync, a.steps, a.repeats, reduce_max)
@@ -411,6 +425,7 @@ def main_sharded(a, world, rank, device):
             "num_entities": E, "rows_per_rank": m, "dim": d, "batch": n,
             "scaling": "strong" if shape == "wikidata5m" else "weak",
             "scoring_launch_ms": k_ms, "exchange_ms": x_ms, "launches_per_step": 2 if big else 1,
+            "batches_in_flight": lanes.L,
             "algorithmic_bytes_per_launch": algorithmic_bytes(n, m, d, sides=2) if not big else
             2 * algorithmic_bytes(n, m, d, sides=1),
         }
@@ -496,7 +511,7 @@ def main():
     # stores' acknowledgements) and 28 of 256 for its whole duration (228 workgroups); the next batch's launch on
     # the other stream runs there.  Every step is a complete pass over one batch; the region ends with a device-wide
     # synchronize, so all K batches are fully scored inside it.
-    L = max(1, a.streams)
+    L = max(1, a.streams if a.streams is not None else 2)
     pipeL = engine.ScorePipeline(T, "sp_po", n, streams=L) if L > 1 else pipe
     outs = [out_buf] + [torch.empty(n, 2 * PITCH, device=device).view(n, 2, PITCH)[:, :, :E_FB] for _ in range(L - 1)]
     if L > 1:

@@ -397,6 +397,22 @@ int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_o
               int64_t ent_ldo, kge_index rel_idx, int64_t n_rel, void* rel_out,
               int64_t rel_ldo, void* stream);
 
+/* The two row moves of the entity-sharded exchange (kge_amd/sharded.py: ShardedEntityTable.exchange_rows),
+ * the id arithmetic evaluated inside the kernel, one launch each:
+ *   kge_shard_gather   t->ent = THIS RANK's rows [lo, lo + t->num_ent) of the entity table.  For j < num_ids (1 or 2
+ *                      id vectors of GLOBAL entity ids, e.g. the s and the o column of a batch), i < n:
+ *                        send[(j*n + i) * send_ld ..] = t->ent[clamp(ids[j][i] - lo, 0, t->num_ent - 1)]
+ *                      (an id this rank does not own reads some local row: that entry of the rank's block is never
+ *                      picked) and, if rel_out != NULL, rel_out[i] = t->rel[rel_idx[i]] (replicated relation table).
+ *   kge_shard_pick     after the all-gather of the ranks' blocks (`gathered` = world x [num_ids * n] rows, leading
+ *                      dimension ld):  rows[j*n + i] = gathered[(ids[j][i] / shard_rows) * num_ids * n + j*n + i],
+ *                      the owner's copy of every row (shard_rows = ceil(E / world), the rows per rank).
+ * dtype: kge_dtype of the rows.  Rows must be 16-byte multiples on 16-byte aligned pitches (KGE_ERR_UNSUPPORTED). */
+int kge_shard_gather(const kge_tables* t, int64_t lo, const kge_index* ids, int num_ids, int64_t n, void* send,
+                     int64_t send_ld, kge_index rel_idx, void* rel_out, int64_t rel_ldo, void* stream);
+int kge_shard_pick(const void* gathered, int64_t ld, int dtype, int64_t dim, int64_t shard_rows, int world,
+                   const kge_index* ids, int num_ids, int64_t n, void* rows, int64_t rows_ld, void* stream);
+
 /* ---- 1vsAll loss fused with the scoring ---------------- */
 /* loss_rows[i] = logsumexp_j score(i, j) - score(i, label[i]),  lse[i] = logsumexp_j score(i, j),
  * j over ALL entities; score(i, .) = the kge_score_sp row (dir = KGE_SP_, a = s, label = o) or

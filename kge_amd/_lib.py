@@ -79,6 +79,10 @@ PROTOTYPES = {
     "kge_score_emb": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                      c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_embed": (ctypes.c_int, [_PT, KgeIndex, c_i64, c_vp, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
+    "kge_shard_gather": (ctypes.c_int, [_PT, c_i64, ctypes.POINTER(KgeIndex), ctypes.c_int, c_i64, c_vp, c_i64,
+                                        KgeIndex, c_vp, c_i64, c_vp]),
+    "kge_shard_pick": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_i64, ctypes.c_int,
+                                      ctypes.POINTER(KgeIndex), ctypes.c_int, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_emb_sp_po": (ctypes.c_int, [_PT, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                            c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_rank_counts": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,

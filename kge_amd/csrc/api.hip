@@ -42,6 +42,8 @@ int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Ope
                       int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
                       unsigned long long* dbg);
 int run_embed2(const EmbedJob& a, const EmbedJob& b, int rowbytes, int esize, hipStream_t st);
+int run_shard_rows(const ShardJob& a, const ShardJob& b, const ShardJob& c, int rowbytes01, int rowbytes2, int esize,
+                   hipStream_t st);
 int run_rank(const float* scores, long long lds, long long n, long long c,
              const float* true_scores, const long long* rowptr, const long long* lcol,
              long long col_offset, const long long* true_col, float atol, float rtol,
@@ -485,6 +487,65 @@ int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_o
     return run_embed2(n_ent ? a : none, n_rel ? b : none, (int)(n_ent ? eb : rb), es, (hipStream_t)stream);
   rc = run_embed2(a, none, (int)eb, es, (hipStream_t)stream);  // RotatE: rows of different length
   return rc ? rc : run_embed2(none, b, (int)rb, es, (hipStream_t)stream);
+}
+
+int kge_shard_gather(const kge_tables* t, int64_t lo, const kge_index* ids, int num_ids, int64_t n, void* send,
+                     int64_t send_ld, kge_index rel_idx, void* rel_out, int64_t rel_ldo, void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (num_ids < 1 || num_ids > 2 || !ids || n < 0 || (n > 0 && !send) || lo < 0) return KGE_ERR_INVALID_ARG;
+  for (int j = 0; j < num_ids; ++j)
+    if (n > 0 && (rc = check_index(ids[j], false))) return rc;
+  const bool with_rel = rel_out != nullptr;
+  if (with_rel && n > 0 && (rc = check_index(rel_idx, false))) return rc;
+  const int es = t->dtype == KGE_BF16 ? 2 : 4;
+  const long long eb = t->dim * es, rb = t->rel_dim * es;
+  auto ok = [&](const void* p, long long ld, long long rowb) {
+    return ((uintptr_t)p & 15) == 0 && (ld * es) % 16 == 0 && rowb % 16 == 0 && rowb < (1LL << 31);
+  };
+  if (!ok(t->ent, t->ent_ld, eb) || !ok(send, send_ld, eb) ||
+      (with_rel && (!ok(t->rel, t->rel_ld, rb) || !ok(rel_out, rel_ldo, rb))))
+    return KGE_ERR_UNSUPPORTED;
+  if (n == 0) return KGE_OK;
+  if (t->num_ent < 1) return KGE_ERR_INVALID_ARG;
+  const ShardJob none{nullptr, 0, Index{}, 0, nullptr, 0, 0, 0, 0, 0, 0};
+  ShardJob a{t->ent, t->ent_ld, make_index(ids[0]), n, send, send_ld, lo, t->num_ent - 1, 0, 0, 0};
+  ShardJob b = none;
+  if (num_ids == 2) {
+    b = a;
+    b.idx = make_index(ids[1]);
+    b.out = (char*)send + n * send_ld * es;
+  }
+  ShardJob c = none;
+  if (with_rel) c = ShardJob{t->rel, t->rel_ld, make_index(rel_idx), n, rel_out, rel_ldo, 0, t->num_rel - 1, 0, 0, 0};
+  return run_shard_rows(a, b, c, (int)eb, with_rel ? (int)rb : 0, es, (hipStream_t)stream);
+}
+
+int kge_shard_pick(const void* gathered, int64_t ld, int dtype, int64_t dim, int64_t shard_rows, int world,
+                   const kge_index* ids, int num_ids, int64_t n, void* rows, int64_t rows_ld, void* stream) {
+  if (num_ids < 1 || num_ids > 2 || !ids || n < 0 || world < 1 || shard_rows < 1 || dim < 1 ||
+      (dtype != KGE_BF16 && dtype != KGE_F32) || (n > 0 && (!gathered || !rows)))
+    return KGE_ERR_INVALID_ARG;
+  int rc;
+  for (int j = 0; j < num_ids; ++j)
+    if (n > 0 && (rc = check_index(ids[j], false))) return rc;
+  const int es = dtype == KGE_BF16 ? 2 : 4;
+  const long long eb = dim * es;
+  if (((uintptr_t)gathered & 15) || ((uintptr_t)rows & 15) || (ld * es) % 16 || (rows_ld * es) % 16 || eb % 16 ||
+      eb >= (1LL << 31))
+    return KGE_ERR_UNSUPPORTED;
+  if (n == 0) return KGE_OK;
+  const ShardJob none{nullptr, 0, Index{}, 0, nullptr, 0, 0, 0, 0, 0, 0};
+  const long long kn = (long long)num_ids * n;  // rows per rank's block of the all-gather
+  ShardJob a{gathered, ld, make_index(ids[0]), n, rows, rows_ld, 0, 0, shard_rows, kn, 0};
+  ShardJob b = none;
+  if (num_ids == 2) {
+    b = a;
+    b.idx = make_index(ids[1]);
+    b.out = (char*)rows + n * rows_ld * es;
+    b.add = n;
+  }
+  return run_shard_rows(a, b, none, (int)eb, 0, es, (hipStream_t)stream);
 }
 
 int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s_ld,

@@ -61,6 +61,18 @@ struct EmbedJob {
   long long ldo;  // elements
 };
 
+// One row move of the sharded exchange (embed.hip): out[i] = table[map(idx[i], i)].
+struct ShardJob {
+  const void* table;
+  long long ld;  // elements
+  Index idx;
+  long long n;
+  void* out;
+  long long ldo;             // elements
+  long long sub, hi;         // div == 0: row = clamp(id - sub, 0, hi)
+  long long div, mul, add;   // div > 0:  row = (id / div) * mul + add + i
+};
+
 // Flattened table descriptor for kernels.
 struct Tables {
   const void* ent;

@@ -19,7 +19,7 @@ from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V3, FLAG_EXACT, FLAG_NO_MF
                    SCORERS, SP_, SP_PO, SPO, KgeIndex, KgeNextQueries, KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "embed", "rank_counts", "score_pitch", "eval_batch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V3",
+           "score_emb", "embed", "shard_gather", "shard_pick", "rank_counts", "score_pitch", "eval_batch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V3",
            "FLAG_SPLIT_QUERY", "reserve_cus", "Queries", "build_queries", "score_queries", "ScorePipeline"]
 
 
@@ -615,6 +615,37 @@ def embed(t: Tables, ent_idx=None, rel_idx=None, ent_out=None, rel_out=None):
         if rc:
             _lib.check(rc, "kge_embed")
     return ent_out, rel_out
+
+
+def shard_gather(t: Tables, lo: int, ids, rel_idx, send: torch.Tensor, rel_out=None):
+    """Row move 1 of the sharded exchange (kge_shard_gather): `t.ent` = this rank's rows [lo, lo + rows) of the entity
+    table; send[j*n + i] = the local row of GLOBAL id ids[j][i] (any local row for an id of another rank), and
+    rel_out[i] = rel[rel_idx[i]] -- one launch, the id arithmetic inside the kernel."""
+    keep = []
+    arr = (KgeIndex * len(ids))(*[_index(x, t.device, keep) for x in ids])
+    n = _same_len(keep, "shard_gather")
+    ri = _index(rel_idx, t.device, keep) if rel_out is not None else KgeIndex(None, I64, 0, 1)
+    with _on_device(t.device):
+        tc = t.c()
+        rc = _lib.lib().kge_shard_gather(ctypes.byref(tc), int(lo), arr, len(ids), n, send.data_ptr(), send.stride(0),
+                                         ri, None if rel_out is None else rel_out.data_ptr(),
+                                         0 if rel_out is None else rel_out.stride(0), _stream_handle(t.device))
+        if rc:
+            _lib.check(rc, "kge_shard_gather")
+
+
+def shard_pick(gathered: torch.Tensor, shard_rows: int, world: int, ids, rows: torch.Tensor):
+    """Row move 2 (kge_shard_pick): rows[j*n + i] = the owner's copy of row (j, i) in the all-gathered blocks."""
+    keep = []
+    dev = gathered.device
+    arr = (KgeIndex * len(ids))(*[_index(x, dev, keep) for x in ids])
+    n = _same_len(keep, "shard_pick")
+    with _on_device(dev):
+        rc = _lib.lib().kge_shard_pick(gathered.data_ptr(), gathered.stride(0), _dtype_code(gathered),
+                                       gathered.shape[1], int(shard_rows), int(world), arr, len(ids), n,
+                                       rows.data_ptr(), rows.stride(0), _stream_handle(dev))
+        if rc:
+            _lib.check(rc, "kge_shard_pick")
 
 
 def rank_counts(scores, true_scores, lbl_rowptr=None, lbl_col=None, col_offset=0, true_col=None,

@@ -161,6 +161,7 @@ class EntityRankingEvaluator:
         # replay the fused loop's full batches as one hipGraph (KGE_EVAL_GRAPH=0: issue every launch from Python)
         self.hip_graph = os.environ.get("KGE_EVAL_GRAPH", "1") != "0"
         self.graph_batches = 0  # batches that ran as graph replays (all runs)
+        self.lanes = int(os.environ.get("KGE_EVAL_LANES", "3"))  # captured batches in flight (one HIP stream each)
         self._graph = None
 
     def _device_state(self, dev):
@@ -229,6 +230,8 @@ class EntityRankingEvaluator:
                 for m_, r in enumerate(rankings):
                     all_ranks["o" + r].append(ro[m_])
                     all_ranks["s" + r].append(rs[m_])
+        for li in used:
+            cur.wait_stream(lanes[li]["stream"])
         suffix = {"_raw": "", "_filt": "_filtered", "_filt_test": "_filtered_with_test"}
         metrics = {}
         for m_, r in enumerate(rankings):
@@ -287,9 +290,10 @@ class EntityRankingEvaluator:
             if fused and chunk >= E and M <= 3 and n not in declined and self.four_launches:
                 # the whole batch in four launches (kge_eval_batch): filter lookup + filter bits | true scores |
                 # scoring + counting | bits cleared + tie policy + histograms + counters back to zero
-                c4 = st["counts4"].get(n)
+                ck = (n, engine._stream_handle(dev))  # per stream: two batches may be in flight (lanes, below)
+                c4 = st["counts4"].get(ck)
                 if c4 is None:  # zero once; every call leaves it zero
-                    c4 = st["counts4"][n] = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)
+                    c4 = st["counts4"][ck] = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)
                 if engine.eval_batch(tables, s, p, o, [(st["sp"][k], st["po"][k]) for k in range(M - 1)],
                                      self.tie_atol, self.tie_rtol, self.tie_handling, c4, hist, ro, rs):
                     return
@@ -361,37 +365,60 @@ class EntityRankingEvaluator:
         # Full batches of the fused, unchunked loop have one shape and touch only resident buffers: ONE batch is
         # captured into a hipGraph (its triples in a static buffer) and replayed -- a copy + a graph launch per
         # batch instead of a dozen launches issued from Python (the loop is host-bound at FB15k-237 size).
-        graph, static = (held["graph"], held["static"]) if held is not None else (None, None)
-        use_graph = self.hip_graph and fused and chunk >= E and dev.type == "cuda" and N // bs >= 4
+        # `lanes` such graphs, each with its own static buffers on its own stream, batch k replayed on lane k % lanes:
+        # the launches of a batch depend on each other and each of them leaves compute units idle at its ends (and a
+        # whole batch is four of them, ~60 us at FB15k-237 size) -- the next batch's launches on the other stream run
+        # there.  The histograms are shared: float atomic adds of 1.0, exact in any order.
+        lanes = held["lanes"] if held is not None else []
+        # (the two-step settings too -- float32 tables, split queries: score matrix + scan + histogram of a batch are
+        # launches on resident buffers just the same; their score matrix lives in the graph's memory pool)
+        use_graph = (self.hip_graph and isinstance(tables, engine.Tables) and chunk >= E and dev.type == "cuda"
+                     and N // bs >= 4)
+        L = max(1, self.lanes) if use_graph else 1
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        used = set()
+        kb = 0
         for b0 in range(0, N, bs):
             n = min(bs, N - b0)
             if use_graph and n == bs and bs not in declined:
-                if static is None:
-                    static = {"batch": torch.empty(bs, 3, dtype=torch.int64, device=dev),
-                              "ro": torch.empty(M, bs, dtype=torch.int64, device=dev) if return_ranks else None,
-                              "rs": torch.empty(M, bs, dtype=torch.int64, device=dev) if return_ranks else None,
-                              "stream": torch.cuda.Stream(dev)}
-                args = (static["batch"], st["ranges"], st["counts"], static["ro"], static["rs"])
-                cur = torch.cuda.current_stream(dev)
-                static["batch"].copy_(triples[b0:b0 + bs])
-                if graph is None:
-                    # this batch eagerly on the capture stream (scratch buffers are per stream: they get allocated
-                    # outside the capture), then the capture itself (records, does not run)
-                    static["stream"].wait_stream(cur)
-                    with torch.cuda.stream(static["stream"]):
+                li = kb % L
+                kb += 1
+                if li >= len(lanes):
+                    lanes.append({"batch": torch.empty(bs, 3, dtype=torch.int64, device=dev),
+                                  "ro": torch.empty(M, bs, dtype=torch.int64, device=dev) if return_ranks else None,
+                                  "rs": torch.empty(M, bs, dtype=torch.int64, device=dev) if return_ranks else None,
+                                  "ranges": torch.empty_like(st["ranges"]), "counts": torch.zeros_like(st["counts"]),
+                                  "stream": torch.cuda.Stream(dev), "graph": None})
+                ln = lanes[li]
+                if li not in used:  # the lane waits for whatever produced the tables / zeroed the histograms
+                    ln["stream"].wait_stream(cur)
+                    used.add(li)
+                args = (ln["batch"], ln["ranges"], ln["counts"], ln["ro"], ln["rs"])
+                with torch.cuda.stream(ln["stream"]):
+                    ln["batch"].copy_(triples[b0:b0 + bs])
+                    if ln["graph"] is None:
+                        # this batch eagerly on the lane's stream (scratch buffers are per stream: they get allocated
+                        # outside the capture), then the capture itself (records, does not run)
                         do_batch(*args)
-                    if bs not in declined:
-                        graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph, stream=static["stream"]):
-                            do_batch(*args)
-                        self._graph = {"key": gkey, "graph": graph, "static": static, "hist": hist}
-                    cur.wait_stream(static["stream"])
-                else:
-                    graph.replay()
-                    self.graph_batches += 1
-                if return_ranks:
-                    keep_ranks(static["ro"], static["rs"], True)
+                        if bs not in declined:
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, stream=ln["stream"]):
+                                do_batch(*args)
+                            ln["graph"] = g
+                            self._graph = {"key": gkey, "lanes": lanes, "hist": hist}
+                    else:
+                        ln["graph"].replay()
+                        self.graph_batches += 1
+                    if return_ranks:
+                        keep_ranks(ln["ro"], ln["rs"], True)
+                        for r_ in rankings:
+                            for d_ in "so":
+                                all_ranks[d_ + r_][-1].record_stream(cur)
                 continue
+            if used:  # a ragged last batch on the current stream: behind the lanes (shared scratch of the eager path)
+                for li in used:
+                    cur.wait_stream(lanes[li]["stream"])
+                used = set()
             batch = triples[b0:b0 + bs]
             rng = st["ranges"][:, :, :, :n].contiguous() if n != bs else st["ranges"]
             cnt = st["counts"][:, :, :, :n].contiguous() if n != bs else st["counts"]

@@ -110,6 +110,7 @@ class ShardedEntityTable:
             from . import engine as backend  # the HIP kernels; no CPU fallback
         self.backend = backend
         self._bufs, self._tcache = {}, {}
+        self._lane = 0  # exchange buffers are per lane (ShardedScoreLanes: several batches in flight)
         # rank_batch_multi counts inside the scoring kernel where the backend offers it (no score slabs);
         # False / KGE_EVAL_TWO_STEP=1: score slabs + rank_counts_multi
         self.fused_rank = os.environ.get("KGE_EVAL_TWO_STEP", "0") != "1"
@@ -128,6 +129,7 @@ class ShardedEntityTable:
 
     def _tables(self, ent, key):
         """backend.Tables over `ent` + the replicated relation table, cached per buffer."""
+        key = (self._lane, key)
         hit = self._tcache.get(key)
         if hit is None or hit[0] != ent.data_ptr():
             hit = (ent.data_ptr(), self.backend.Tables(self.scorer, ent, self.rel, self.l_norm))
@@ -135,6 +137,7 @@ class ShardedEntityTable:
         return hit[1]
 
     def _buffer(self, key, shape, like):
+        key = (self._lane, key)
         b = self._bufs.get(key)
         if b is None or tuple(b.shape) != tuple(shape) or b.dtype != like.dtype:
             b = self._bufs[key] = torch.empty(shape, dtype=like.dtype, device=like.device)
@@ -146,8 +149,22 @@ class ShardedEntityTable:
         [n, d_r] relation rows of `rel_ids` or None).  Two gather launches + one all-gather;
         nothing here waits for the device."""
         k, n = len(ids), ids[0].numel()
-        gid = torch.cat([x.reshape(-1).long() for x in ids])
         d = self.ent_local.shape[1]
+        if hasattr(self.backend, "shard_gather") and k <= 2 and self.hi > self.lo:
+            # the id arithmetic inside the two gather kernels (kge_shard_gather / kge_shard_pick): three calls per
+            # exchange instead of ten torch ops -- the step was bound by the HOST issuing them (90 us of Python per
+            # 62 us of device work at the FB15k-237 shard shape)
+            send = self._buffer(("send", k), (k * n, d), self.ent_local)
+            rel_rows = None if rel_ids is None else self._buffer("rel", (n, self.rel.shape[1]), self.rel)
+            self.backend.shard_gather(self._tables(self.ent_local, "local"), self.lo, ids, rel_ids, send, rel_rows)
+            if not self.collectives:
+                return send, rel_rows
+            gath = self._buffer(("gath", k), (self.world * k * n, d), self.ent_local)
+            dist.all_gather_into_tensor(gath.view(-1), send.view(-1), group=self.group)
+            rows = self._buffer(("rows", k), (k * n, d), self.ent_local)
+            self.backend.shard_pick(gath, self.shard, self.world, ids, rows)
+            return rows, rel_rows
+        gid = torch.cat([x.reshape(-1).long() for x in ids])
         local = (gid - self.lo).clamp_(0, max(self.hi - self.lo - 1, 0))  # not owned: any local row
         send = self._buffer(("send", k), (k * n, d), self.ent_local)
         rel_rows = None if rel_ids is None else self._buffer("rel", (n, self.rel.shape[1]), self.rel)
@@ -325,3 +342,81 @@ class ShardedEntityTable:
             v, i = torch.cat(vs, 1), torch.cat(is_, 1)
         tv, ti = torch.topk(v, k, dim=1)
         return tv, torch.gather(i, 1, ti)
+
+
+class ShardedScoreLanes:
+    """Several batches in flight over one ShardedEntityTable: batch k runs on HIP stream k % L -- its row exchange
+    (gather launch, RCCL all-gather, pick launch) and its scoring launch, in that order on that stream -- so the
+    exchange of batch k + 1 (39 of 62 us of a step at the FB15k-237 shard shape, DESIGN.md 6: collective latency, the
+    compute units idle) runs under the scoring launch of batch k, and the scoring launch of batch k + 1 starts in
+    the holes batch k's leaves (ScorePipeline(streams=L) in kge_amd/engine.py has the single-GPU measurements).
+
+    Every rank issues the same batches in the same order, so the collectives of the lanes reach the communicator in
+    one order on all ranks (torch.distributed runs them on the process group's own stream, ordered against the
+    lane's stream by events).  Exchange buffers are per lane; the score slabs are fresh tensors of the lane's
+    stream, handed to torch's current stream by join() -- which the caller invokes before it reads them:
+
+        lanes = ShardedScoreLanes(table, 2)
+        for k, (s, p, o) in enumerate(batches):
+            pending.append(lanes.score_sp_po_blocks(s, p, o))
+            if len(pending) == 2: lanes.join(); consume(pending.pop(0)) ...
+    """
+
+    def __init__(self, table: ShardedEntityTable, lanes: int = 2):
+        self.table = table
+        self.L = max(1, int(lanes))
+        dev = table.ent_local.device
+        self.cuda = dev.type == "cuda"
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.L)] if self.cuda and self.L > 1 else None
+        self.k = 0
+        self._out = []
+
+    def fork(self):
+        """The lanes wait for torch's current stream (producers of the batches; readers of earlier results)."""
+        if self.streams is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            for st in self.streams:
+                st.wait_event(ev)
+
+    def join(self):
+        """Torch's current stream waits for every lane; the slabs returned so far now belong to it."""
+        if self.streams is not None:
+            cur = torch.cuda.current_stream(self.table.ent_local.device)
+            for st in self.streams:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                cur.wait_event(ev)
+            for t in self._out:
+                t.record_stream(cur)
+        self._out = []
+
+    def _run(self, fn, *args):
+        lane = self.k % self.L
+        self.k += 1
+        tb = self.table
+        if self.streams is None:
+            tb._lane = lane
+            try:
+                return fn(*args)
+            finally:
+                tb._lane = 0
+        prev = torch.cuda.current_stream(tb.ent_local.device)
+        torch.cuda.set_stream(self.streams[lane])  # (the context manager costs ~3x this pair; the step is host-bound)
+        tb._lane = lane
+        try:
+            res = fn(*args)
+        finally:
+            tb._lane = 0
+            torch.cuda.set_stream(prev)
+        self._out.extend(r for r in (res if isinstance(res, tuple) else (res,)) if torch.is_tensor(r))
+        return res
+
+    def score_sp_po_blocks(self, s, p, o):
+        return self._run(self.table.score_sp_po_blocks, s, p, o)
+
+    def score_sp(self, s, p):
+        return self._run(self.table.score_sp, s, p)
+
+    def score_po(self, p, o):
+        return self._run(self.table.score_po, p, o)

@@ -246,8 +246,11 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
         ev = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
         m1, r1 = ev.run(return_ranks=True)
         assert calls["fused"] > 0 and ev._fused
-        # full batches of the unchunked fused loop replay one captured hipGraph; the same loop issued launch by launch
-        assert ev.graph_batches == (max(0, 431 // bs - 1) if chunk < 0 and 431 // bs >= 4 else 0)
+        # full batches of the unchunked loop replay captured hipGraphs, `ev.lanes` of them in flight on as many
+        # streams (each lane's first batch is the one it captures); the same loop issued launch by launch
+        full = 431 // bs
+        assert ev.lanes >= 2
+        assert ev.graph_batches == (max(0, full - min(ev.lanes, full)) if chunk < 0 and full >= 4 else 0)
         ev3 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
         ev3.hip_graph = False
         m3, r3 = ev3.run(return_ranks=True)
@@ -259,6 +262,10 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
         assert m4 == m1 and all(np.array_equal(r1[k], r4[k]) for k in r1)
         m1b, _ = ev.run(return_ranks=True)  # a second run captures afresh
         assert m1b == m1
+        ev1 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
+        ev1.lanes = 1  # one captured batch at a time
+        m5, r5 = ev1.run(return_ranks=True)
+        assert m5 == m1 and all(np.array_equal(r1[k], r5[k]) for k in r1)
         ev2 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, chunk_size=chunk)
         ev2._fused = False
         before = calls["fused"]

@@ -99,6 +99,18 @@ def _worker(rank, world, port, model, q):
         big_sp, big_po = (x.clone() for x in sh.score_sp_po_blocks(s, p, o))  #     one launch per direction)
         sh.BIG_SLAB_BYTES = small
         assert torch.equal(big_sp, blk_sp) and torch.equal(big_po, blk_po)
+        # two batches in flight (ShardedScoreLanes: batch k's exchange + scoring on HIP stream k % 2, the
+        # collectives of the lanes in one order on both ranks): five steps, results read after join()
+        from kge_amd.sharded import ShardedScoreLanes
+        lanes = ShardedScoreLanes(sh, 2)
+        tri2 = torch.flip(tri, dims=[0]).contiguous()
+        want2 = tuple(x.clone() for x in sh.score_sp_po_blocks(tri2[:, 0], tri2[:, 1], tri2[:, 2]))
+        lanes.fork()
+        res = [lanes.score_sp_po_blocks(*( (t[:, 0], t[:, 1], t[:, 2]) )) for t in (tri, tri2, tri, tri2, tri)]
+        lanes.join()
+        for k, (a_sp, a_po) in enumerate(res):
+            w_sp, w_po = (blk_sp, blk_po) if k % 2 == 0 else want2
+            assert torch.equal(a_sp, w_sp) and torch.equal(a_po, w_po), ("lanes", k)
         loss = torch.cat([sh.ce_loss("sp", s, p, o, ent_m, rel_m), sh.ce_loss("po", o, p, s, ent_m, rel_m)])
         (loss * w).sum().backward()
         torch.cuda.synchronize()

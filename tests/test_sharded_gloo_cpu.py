@@ -215,6 +215,17 @@ def _worker(rank, world, port, model, q):
         want = np.concatenate([ko.score_sp(full, batch[:, 0], batch[:, 1], np.arange(lo, hi)),
                                ko.score_po(full, batch[:, 1], batch[:, 2], np.arange(lo, hi))], 1)
         assert np.array_equal(both.numpy(), want)
+        # several batches in flight (ShardedScoreLanes; on CPU: the lanes' separate exchange buffers, no streams):
+        # three different batches through two lanes = the three direct calls, read after join()
+        from kge_amd.sharded import ShardedScoreLanes
+        lanes = ShardedScoreLanes(sh, 2)
+        parts = [torch.from_numpy(splits["valid"][k * 12:(k + 1) * 12].astype(np.int64)) for k in range(3)]
+        lanes.fork()
+        res = [lanes.score_sp_po_blocks(x[:, 0], x[:, 1], x[:, 2]) for x in parts]
+        lanes.join()
+        for x, (a_sp, a_po) in zip(parts, res):
+            w_sp, w_po = sh.score_sp_po_blocks(x[:, 0], x[:, 1], x[:, 2])
+            assert torch.equal(a_sp, w_sp) and torch.equal(a_po, w_po)
         slab = sh.score_sp(tb[:, 0], tb[:, 1])
         tv, ti = sh.topk(slab, 5)
         if rank == 0:
