@@ -215,9 +215,41 @@ def rank_legs(engine, device, n, steps):
                 fn()
         f_ms, t_ms = event_avg_ms(fused, steps), event_avg_ms(two_step, steps)
         flops = 2.0 * 2.0 * n * E * d
+        # the way the evaluator issues it (kge_amd/eval.py): the batch captured into a hipGraph per lane, three lanes
+        # in flight on three streams -- wall clock per batch over `steps` replays
+        lanes = []
+        cur = torch.cuda.current_stream(device)
+        for _ in range(3):
+            st, c = torch.cuda.Stream(device), torch.zeros_like(cnt)
+
+            def call(c=c):
+                engine.score_rank_sp_po(T, s, p, o, t_sp, t_po, lists[0], lists[1], 1e-5, 1e-4, c[0, 0], c[0, 1],
+                                        c[1, 0], c[1, 1])
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                call()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=st):
+                    call()
+            lanes.append((st, gr, c))
+
+        def in_flight(k):
+            for i in range(k):
+                st, gr, _ = lanes[i % 3]
+                with torch.cuda.stream(st):
+                    gr.replay()
+        in_flight(6)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        in_flight(steps)
+        torch.cuda.synchronize()
+        l_ms = (time.perf_counter() - t0) / steps * 1e3
+        del lanes
         out[tag] = {"num_entities": E, "dim": d, "batch": n, "fused_us": f_ms * 1e3, "two_step_us": t_ms * 1e3,
                     "flops_per_batch": flops, "achieved": flops / (f_ms * 1e-3) / 1e12,
-                    "frac": flops / (f_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
+                    "frac": flops / (f_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF,
+                    "three_in_flight": {"us_per_batch": l_ms * 1e3, "achieved": flops / (l_ms * 1e-3) / 1e12,
+                                        "frac": flops / (l_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}}
         del T
         torch.cuda.empty_cache()
     return out

@@ -230,8 +230,6 @@ class EntityRankingEvaluator:
                 for m_, r in enumerate(rankings):
                     all_ranks["o" + r].append(ro[m_])
                     all_ranks["s" + r].append(rs[m_])
-        for li in used:
-            cur.wait_stream(lanes[li]["stream"])
         suffix = {"_raw": "", "_filt": "_filtered", "_filt_test": "_filtered_with_test"}
         metrics = {}
         for m_, r in enumerate(rankings):
@@ -428,6 +426,8 @@ class EntityRankingEvaluator:
             if return_ranks:
                 keep_ranks(ro, rs, False)
 
+        for li in used:
+            cur.wait_stream(lanes[li]["stream"])
         suffix = {"_raw": "", "_filt": "_filtered", "_filt_test": "_filtered_with_test"}
         metrics = {}
         for m_, r in enumerate(rankings):

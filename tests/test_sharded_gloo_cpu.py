@@ -242,10 +242,22 @@ def test_two_shards_equal_unsharded(model):
     procs = [ctx.Process(target=_worker, args=(r, world, port, model, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, tv, ti, ent, rel, splits, batch, ev_metrics, ev_ranks = q.get()
+    import time
+    got, t0 = None, time.time()
+    while got is None and time.time() - t0 < 240:  # a crashed worker must fail the test, not hang it
+        if not q.empty():
+            got = q.get()
+        elif any(p.exitcode not in (None, 0) for p in procs):
+            break
+        else:
+            time.sleep(0.05)
     for p in procs:
         p.join(60)
+        if p.is_alive():
+            p.kill()
         assert p.exitcode == 0
+    assert got is not None
+    out, tv, ti, ent, rel, splits, batch, ev_metrics, ev_ranks = got
     E = ent.shape[0]
     t = ko.Tables(model, ent, rel, 1.0)
     s, p_, o = batch[:, 0], batch[:, 1], batch[:, 2]
