@@ -719,7 +719,7 @@ def main():
             "workload": "FB15k-237 shape ComplEx d=512 1vsAll scoring, bf16 tables, f32 scores: the "
                         "score_sp and score_po blocks of the batch per step (KgeModel.score_sp_po, one "
                         "two-sided launch; the next batch's query vectors built inside the same launch; score "
-                        "rows on a 256-byte pitch)",
+                        "rows on a 256-byte pitch); `streams` batches in flight, batch k on HIP stream k % streams",
             "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n,
             "parallelism": "single GPU",
             "streams": L,  # batches in flight in the timed region (batch k on HIP stream k % streams)

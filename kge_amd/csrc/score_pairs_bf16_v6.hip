@@ -64,7 +64,7 @@ template <int SCORER, int SPLIT>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
     Operand TG, long long n, long long m, int rgn, int rgn1, long long out2_off, int ncg, int units_per_cg,
     int nunits, float* __restrict__ out, long long ldo, unsigned long long* __restrict__ dbg,
-    const u32x4* __restrict__ qf, NextQ nx, int st_sc1, int frag_delay) {
+    const u32x4* __restrict__ qf, NextQ nx, int st_sc1) {
   constexpr int HH = 256;
   constexpr int RGR = SPLIT ? 64 : V6_ROWS;  // real query rows per row group
   constexpr int NKB = 2 * HH / 16;           // 32 K-blocks of 16
@@ -322,9 +322,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
           bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16 + kb * 1024), 0, 16 /* sc1 */));
     });
   };
-  // the loader waves' 32 pieces of unit 0 go into the vector-memory queue first: nothing can be scored before unit 0
-  // has landed, and fragment loads issued at cycle 0 sit in front of them (64 KiB: ~1 k cycles of the 64 B/clk path)
-  for (int z = 0; z < frag_delay; ++z) __builtin_amdgcn_s_sleep(2);
+  // (holding these loads back until the loader waves have issued unit 0 -- 0.25 k to 1 k cycles of s_sleep -- moves
+  // nothing: unit 0 lands at ~3.3 k cycles either way; the cold first access, not the queue, sets that time)
   load_fragments(std::integral_constant<int, 0>{}, std::integral_constant<int, FR0>{});
   stamp();  // 1: first fragments requested
   // target fragment kb of row fi: the 16-byte slot 2 kb + fh, stored at slot ^ (fi & 15)
@@ -471,11 +470,8 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
   // pitch, two-sided: 27.2 us written through, 21.1 us through the L2's write-back; aligned: 20.3 / 20.6)
   const int st_sc1 = sc1e ? (sc1e[0] != '0') : (st_aligned ? 1 : 0);
   (void)st_small;
-  const char* fd = getenv("KGE_V6_FRAG_DELAY");  // consumer waves: units of ~128 cycles before their first fragment load
-  const int frag_delay = fd ? atoi(fd) : 0;
   hipLaunchKernelGGL((pairs_bf16_v6_kernel<SCORER, SPLIT>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
-                     out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, st_sc1,
-                     frag_delay);
+                     out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, st_sc1);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 

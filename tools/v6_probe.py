@@ -18,8 +18,7 @@ from kge_amd import engine  # noqa: E402
 
 dev = torch.device("cuda", 0)
 E, R, D = 14541, 237, 512
-VARIANTS = {"d0": {"KGE_V6": "1", "KGE_V6_FRAG_DELAY": "0"}, "d2": {"KGE_V6": "1", "KGE_V6_FRAG_DELAY": "2"},
-            "d4": {"KGE_V6": "1", "KGE_V6_FRAG_DELAY": "4"}, "d8": {"KGE_V6": "1", "KGE_V6_FRAG_DELAY": "8"}}
+VARIANTS = {"v6": {"KGE_V6": "1"}, "v4": {"KGE_V6": "0"}}
 
 def alg_bytes(n, m, d, sides):
     return m * d * 2 + sides * (n * 2 * d * 2 + n * m * 4 + 2 * n * 8)
@@ -36,7 +35,7 @@ def main():
     ent = torch.empty(E, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
     rel = torch.empty(R, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
     cases = []
-    for n in (512,):
+    for n in (512, 1024):
         batches = [tuple(torch.randint(hi, (n,), generator=g).to(dev) for hi in (E, R, E)) for _ in range(2)]
         for comb, sides in (("sp_", 1), ("sp_po", 2)):
             for split in (0,):
