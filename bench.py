@@ -397,13 +397,17 @@ def main_sharded(a, world, rank, device):
         # the Infinity Cache (the Wikidata5M shards) go one batch at a time -- two of them in flight would be
         # 2 x 2.4 GB of scores written at once for an exchange that is 1 % of the step
         big_slab = n * (sh.hi - sh.lo) * 4 > sh.BIG_SLAB_BYTES
-        lanes = ShardedScoreLanes(sh, 1 if big_slab else max(1, a.streams if a.streams is not None else
-                                                             (2 if world > 1 else 1)))
+        # Default: ONE batch at a time, issued call by call -- the configuration every earlier round ran.  Two lanes pay
+        # only with the step captured into a hipGraph (call by call the step is bound by the host: 60 -> 84 us with
+        # two lanes, 60 -> 47 us with two lanes + graph, one rank); the capture of a multi-rank RCCL all-gather has
+        # not run on this code, so N > 1 takes it only when asked (--streams 2 with KGE_SHARDED_GRAPH=1).
+        lanes = ShardedScoreLanes(sh, 1 if big_slab else max(1, a.streams if a.streams is not None else 1))
+        tri3 = torch.stack([s.long(), p.long(), o.long()], 1).contiguous()
 
-        def run_steps(k, lanes=lanes, s=s, p=p, o=o):
+        def run_steps(k, lanes=lanes, tri3=tri3):
             lanes.fork()
             for i in range(k):
-                lanes.score_sp_po_blocks(s, p, o)  # exchange (gather, all-gather, gather) + the scoring launch(es)
+                lanes.score_sp_po_blocks(tri3)  # exchange (gather, all-gather, gather) + the scoring launch(es)
                 if (i + 1) % lanes.L == 0:
                     lanes.join()  # the consumer's wait; the slabs of the two batches are released here
             lanes.join()
@@ -457,7 +461,7 @@ def main_sharded(a, world, rank, device):
             "num_entities": E, "rows_per_rank": m, "dim": d, "batch": n,
             "scaling": "strong" if shape == "wikidata5m" else "weak",
             "scoring_launch_ms": k_ms, "exchange_ms": x_ms, "launches_per_step": 2 if big else 1,
-            "batches_in_flight": lanes.L,
+            "batches_in_flight": lanes.L, "step_as_hipgraph": bool(lanes.use_graph and lanes.graph_replays > 0),
             "algorithmic_bytes_per_launch": algorithmic_bytes(n, m, d, sides=2) if not big else
             2 * algorithmic_bytes(n, m, d, sides=1),
         }

@@ -353,16 +353,27 @@ class ShardedScoreLanes:
 
     Every rank issues the same batches in the same order, so the collectives of the lanes reach the communicator in
     one order on all ranks (torch.distributed runs them on the process group's own stream, ordered against the
-    lane's stream by events).  Exchange buffers are per lane; the score slabs are fresh tensors of the lane's
-    stream, handed to torch's current stream by join() -- which the caller invokes before it reads them:
+    lane's stream by events).  Exchange buffers are per lane.
+
+    graph (default: on without collectives and for a one-rank RCCL group, opt-in -- graph=True / KGE_SHARDED_GRAPH=1 --
+    with more ranks; KGE_SHARDED_GRAPH=0 turns it off): a lane's step -- two gather
+    launches, the all-gather, the scoring launch -- is captured into a hipGraph on first use (per batch shape) and
+    replayed from then on with the batch's ids copied into static index vectors: the step issued from Python is
+    bound by the HOST (55 us of calls for ~45 us of device work at the FB15k-237 shard shape, one rank), a copy and
+    a replay are ~15 us.  A capture that fails (a backend that stages collectives through the host) turns the
+    feature off and the step is issued call by call.
+
+    The score slabs of batch k belong to lane k % L: fresh tensors of the lane's stream (call by call) or the
+    lane's static outputs (graph), valid after join() and until that lane's NEXT batch is issued -- fork() after
+    reading them, as with engine.ScorePipeline:
 
         lanes = ShardedScoreLanes(table, 2)
         for k, (s, p, o) in enumerate(batches):
             pending.append(lanes.score_sp_po_blocks(s, p, o))
-            if len(pending) == 2: lanes.join(); consume(pending.pop(0)) ...
+            if len(pending) == 2: lanes.join(); consume(pending); pending = []; lanes.fork()
     """
 
-    def __init__(self, table: ShardedEntityTable, lanes: int = 2):
+    def __init__(self, table: ShardedEntityTable, lanes: int = 2, graph: Optional[bool] = None):
         self.table = table
         self.L = max(1, int(lanes))
         dev = table.ent_local.device
@@ -370,6 +381,22 @@ class ShardedScoreLanes:
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.L)] if self.cuda and self.L > 1 else None
         self.k = 0
         self._out = []
+        if graph is None:
+            # default: on where it has been run -- no collectives, or RCCL with ONE rank (the capture of the
+            # all-gather works there: tools/gpu runs of bench.py with KGE_BENCH_FORCE_DIST=1); with more ranks the
+            # capture of a multi-GPU RCCL collective has never run on this code (no multi-GPU box in the build
+            # loop), so it is opt-in: graph=True or KGE_SHARDED_GRAPH=1
+            want = os.environ.get("KGE_SHARDED_GRAPH")
+            graph = (want == "1") if want is not None else (not table.collectives or table.world == 1)
+            if graph and table.collectives:
+                try:
+                    graph = dist.get_backend(table.group) == "nccl"
+                except Exception:  # pragma: no cover
+                    graph = False
+        self.use_graph = bool(graph) and self.cuda
+        self._graphs = [dict() for _ in range(self.L)]
+        self._cap_stream = None
+        self.graph_replays = 0
 
     def fork(self):
         """The lanes wait for torch's current stream (producers of the batches; readers of earlier results)."""
@@ -391,32 +418,71 @@ class ShardedScoreLanes:
                 t.record_stream(cur)
         self._out = []
 
-    def _run(self, fn, *args):
+    def _issue(self, lane, name, fn, args):
+        """On the lane's stream (already current): call by call, or copy + replay of the lane's captured step."""
+        if not self.use_graph:
+            return fn(*args), False
+        key = (name,) + tuple((tuple(a.shape), a.dtype) for a in args)
+        ent = self._graphs[lane].get(key)
+        if ent is not None:
+            for d, x in zip(ent["static"], args):
+                d.copy_(x)
+            ent["graph"].replay()
+            self.graph_replays += 1
+            return ent["res"], True
+        static = [torch.empty(a.shape, dtype=a.dtype, device=a.device) for a in args]
+        for d, x in zip(static, args):
+            d.copy_(x)
+        res = fn(*static)  # once call by call: per-stream scratch gets allocated, the communicator warmed up
+        st = torch.cuda.current_stream(self.table.ent_local.device)
+        if self.streams is None:  # a capture needs a stream of its own
+            if self._cap_stream is None:
+                self._cap_stream = torch.cuda.Stream(device=self.table.ent_local.device)
+            st = self._cap_stream
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                cap = fn(*static)
+            self._graphs[lane][key] = {"graph": g, "static": static, "res": cap}
+        except Exception as exc:  # not capturable here: call by call from now on
+            self.use_graph = False
+            self.graph_error = f"{type(exc).__name__}: {exc}"
+            torch.cuda.synchronize()
+        return res, False
+
+    def _run(self, name, fn, *args):
         lane = self.k % self.L
         self.k += 1
         tb = self.table
-        if self.streams is None:
+        if not self.cuda:
             tb._lane = lane
             try:
                 return fn(*args)
             finally:
                 tb._lane = 0
         prev = torch.cuda.current_stream(tb.ent_local.device)
-        torch.cuda.set_stream(self.streams[lane])  # (the context manager costs ~3x this pair; the step is host-bound)
+        if self.streams is not None:
+            torch.cuda.set_stream(self.streams[lane])  # (the context manager costs ~3x this pair)
         tb._lane = lane
         try:
-            res = fn(*args)
+            res, static_out = self._issue(lane, name, fn, args)
         finally:
             tb._lane = 0
-            torch.cuda.set_stream(prev)
-        self._out.extend(r for r in (res if isinstance(res, tuple) else (res,)) if torch.is_tensor(r))
+            if self.streams is not None:
+                torch.cuda.set_stream(prev)
+        if self.streams is not None and not static_out:
+            self._out.extend(r for r in (res if isinstance(res, tuple) else (res,)) if torch.is_tensor(r))
         return res
 
-    def score_sp_po_blocks(self, s, p, o):
-        return self._run(self.table.score_sp_po_blocks, s, p, o)
+    def score_sp_po_blocks(self, s, p=None, o=None):
+        """(s, p, o) index vectors, or the batch as ONE [n, 3] triples tensor (one copy into the lane's static ids)."""
+        if p is None and o is None and s.dim() == 2:
+            tb = self.table
+            return self._run("sp_po3", lambda t: tb.score_sp_po_blocks(t[:, 0], t[:, 1], t[:, 2]), s)
+        return self._run("sp_po", self.table.score_sp_po_blocks, s, p, o)
 
     def score_sp(self, s, p):
-        return self._run(self.table.score_sp, s, p)
+        return self._run("sp", self.table.score_sp, s, p)
 
     def score_po(self, p, o):
-        return self._run(self.table.score_po, p, o)
+        return self._run("po", self.table.score_po, p, o)

@@ -42,3 +42,30 @@ def test_exchange_row_moves(dtype, itype, k):
     eng.shard_gather(T0, 0, ids, None, send, None)
     assert torch.equal(send, ent[:shard][torch.cat([x.long() for x in ids]).clamp(0, shard - 1)])
     eng.shard_gather(T0, 0, [x[:0] for x in ids], None, send[:0], None)
+
+
+def test_lanes_replay_a_captured_step():
+    """ShardedScoreLanes on one rank (no collectives): each lane's step is captured into a hipGraph on first use and
+    replayed with the batch's ids copied into static index vectors; six steps over two alternating batches (strided
+    id columns) = the direct calls, bit for bit; the call-by-call lanes (graph=False) the same."""
+    from kge_amd import engine as eng
+    from kge_amd.sharded import ShardedEntityTable, ShardedScoreLanes
+    E, R, d, n = 14541, 11, 512, 128
+    g = torch.Generator().manual_seed(3)
+    ent = (torch.randn(E, d, generator=g) * 0.3).bfloat16().to(DEV)
+    rel = (torch.randn(R, d, generator=g) * 0.3).bfloat16().to(DEV)
+    sh = ShardedEntityTable("complex", ent, rel, E)
+    trip = [torch.stack([torch.randint(E, (n,), generator=g), torch.randint(R, (n,), generator=g),
+                         torch.randint(E, (n,), generator=g)], 1).to(DEV) for _ in range(2)]
+    want = [tuple(x.clone() for x in sh.score_sp_po_blocks(t[:, 0], t[:, 1], t[:, 2])) for t in trip]
+    for graph in (True, False):
+        lanes = ShardedScoreLanes(sh, 2, graph=graph)
+        lanes.fork()
+        for k in range(6):
+            t = trip[(k // 2) & 1]          # lane k % 2 sees batch 0, 1, 0: its static ids change between replays
+            a_sp, a_po = lanes.score_sp_po_blocks(t[:, 0], t[:, 1], t[:, 2])
+            lanes.join()
+            w_sp, w_po = want[(k // 2) & 1]
+            assert torch.equal(a_sp, w_sp) and torch.equal(a_po, w_po), (graph, k)
+            lanes.fork()
+        assert lanes.graph_replays == (4 if graph else 0), getattr(lanes, "graph_error", None)
