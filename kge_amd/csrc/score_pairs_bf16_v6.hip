@@ -405,9 +405,249 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // (the look-ahead reads issued by the last chain land in bq[] until this wait: the registers stay "in use" up to
+  // here, or the compiler hands them out as temporaries while a read is still on its way -- see pairs_bf16_v7_kernel)
+  asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4]), "v"(bq[5]), "v"(bq[6]), "v"(bq[7]));
   __builtin_amdgcn_s_barrier();  // F
   if (nx.qf != nullptr && nx.mode == 2)  // no idle workgroups in this geometry: a slice of the next batch's queries
     v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)(rg * ncg + cg) * 256 + tid, (long long)nx.nblocks * 256);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pairs_bf16_v7_kernel: the same launch with the scores stored STRAIGHT from the accumulators (one rounded query
+// vector per row; split queries keep the staged path above: their two partial blocks live in different waves).
+//
+// Why.  In the kernel above the two DMA waves are the pacemaker of the unit loop: 16 LDS-DMA pieces per unit and wave
+// at ~90 cycles each = 1.44 k cycles, against 1.26 k for the consumers' own loop (tools/ubench/unit_loop.hip) --
+// the pieces share the vector-memory path with the store waves' 1-KiB stores.  Measured alternatives
+// (profiles/r3_unit_loop_ubench.txt, r3_wide_loop_ubench.txt): a dword store per MFMA slot costs the consumer
+// 3 cycles per MFMA (36.6 against 33.6 bare; the staging writes + their barrier discipline cost 5.8), two 128-byte
+// row segments per instruction.  So: no staging buffers, no store waves -- consumer wave w stores element r of
+// unit u - 1 (row 8 (r >> 2) + 4 fh + (r & 3) of its 32, column = lane & 31) in slot 2 r of chain u, and all FOUR
+// loader waves stream the table, 8 pieces per unit each (their queues hold loads only: counted waits stay valid).
+// Rows beyond n are dropped by the buffer descriptor's range, columns beyond m (ragged last unit) by a per-lane
+// out-of-range offset.  Bits: the same accumulation chains -- identical to v6 / v4.
+//   barriers (all eight waves): R0 (unit 0 landed); P(u) in slot V6_PB of chain u: unit u + 1 has landed and the
+//   consumers are done with ring buffer (u - 1) % 4, which the loaders refill with unit u + 3.
+template <int SCORER, int SC1>
+__global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
+    Operand TG, long long n, long long m, int rgn, int rgn1, long long out2_off, int ncg, int units_per_cg,
+    int nunits, float* __restrict__ out, long long ldo, unsigned long long* __restrict__ dbg,
+    const u32x4* __restrict__ qf, NextQ nx) {
+  constexpr int HH = 256;
+  constexpr int RGR = V6_ROWS;
+  constexpr int NKB = 2 * HH / 16;
+  constexpr int ROWB = 4 * HH;
+  constexpr int UNITB = V6_UT * ROWB;
+  constexpr int NBUF = 4;
+  constexpr int SMEM = NBUF * UNITB;  // 128 KiB
+  constexpr int FR0 = 16;
+  // the ring: LDS bytes [0, 128 KiB), addressed by the DMA pieces (m0) and the fragment reads (ds_read_b128 in asm)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  if (n < 0) smem[threadIdx.x] = 0;  // (never: keeps the allocation -- nothing else names the array)
+
+  const int b = blockIdx.x;
+  const int q8 = b >> 3;
+  const int rg = q8 % rgn;
+  const int cg = (q8 / rgn) * 8 + (b & 7);
+  if (cg >= ncg) {
+    if (nx.qf != nullptr && nx.mode == 1) {
+      const int spg = ((ncg + 7) & ~7) - ncg;
+      v4_build_queries<SCORER, HH, 0>(nx, (long long)(rg * spg + (cg - ncg)) * 512 + threadIdx.x,
+                                      (long long)nx.nblocks * 512);
+    }
+    return;
+  }
+  const int unit_lo = units_per_cg > 0 ? cg * units_per_cg : cg;
+  const int unit_st = units_per_cg > 0 ? 1 : ncg;
+  int NU = units_per_cg > 0 ? nunits - unit_lo : (nunits - cg + ncg - 1) / ncg;
+  if (units_per_cg > 0 && NU > units_per_cg) NU = units_per_cg;
+  if (NU <= 0) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool second = rg >= rgn1;
+  const int rgl = second ? rg - rgn1 : rg;
+  if (second) out += out2_off;
+
+  int dbg_i = 0;
+  auto stamp = [&]() {
+    if (dbg != nullptr && tid == 0 && dbg_i < 32) dbg[(long long)blockIdx.x * 64 + dbg_i] = __builtin_readcyclecounter();
+    ++dbg_i;
+  };
+  auto stamp_at = [&](int slot) {
+    if (dbg != nullptr && lane == 0) dbg[(long long)blockIdx.x * 64 + slot] = __builtin_readcyclecounter();
+  };
+  stamp();  // 0: start
+
+  if (wave >= 4) {
+    // =============================== loader waves ===============================
+    const unsigned char* const tgb = (const unsigned char*)TG.base;
+    const long long tld2 = TG.ld * 2;
+    const unsigned int lane16 = (unsigned int)lane << 4;
+    const int r8 = 8 * (wave - 4);  // this wave's eight rows of every unit
+    auto dma8 = [&](int uu) __attribute__((always_inline)) {
+      const long long row0 = (long long)(unit_lo + uu * unit_st) * V6_UT + r8;
+      const unsigned int d0 = (unsigned int)((uu & (NBUF - 1)) * UNITB + r8 * ROWB);
+      const unsigned int x0 = (unsigned int)(r8 & 15) << 4;
+      if (row0 + 8 <= m) {
+        const unsigned char* p = tgb + row0 * tld2;
+        v4_static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          const unsigned int vo = lane16 ^ (x0 + (k << 4));
+          const unsigned int dk = d0 + k * ROWB;
+          const unsigned char* pk = p + k * tld2;
+          KGE_V6_DMA(dk, vo, pk);
+        });
+      } else {  // rows beyond the table repeat its last row (their scores are never stored)
+        v4_static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int k = decltype(kc)::value;
+          long long r = row0 + k;
+          if (r >= m) r = m - 1;
+          const unsigned char* pk = tgb + r * tld2;
+          const unsigned int vo = lane16 ^ (x0 + (k << 4));
+          const unsigned int dk = d0 + k * ROWB;
+          KGE_V6_DMA(dk, vo, pk);
+        });
+      }
+    };
+    // this wave's queue (loads only, in-order returns): u0 (8), u1 (8) | P(0) | u2, u3 | P(1) | u4 | P(2) | u5 ...
+    dma8(0);
+    if (NU > 1) dma8(1);
+    if (wave == 4) stamp_at(32);  // first units issued
+    if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 4) stamp_at(37);  // unit 0: this wave's pieces have landed
+    __builtin_amdgcn_s_barrier();  // R0
+    for (int u = 0; u < NU; ++u) {
+      // unit u + 1 has landed: behind it in this wave's queue only unit u + 2 (from u = 1 on, while it exists)
+      if (u >= 1 && u + 2 < NU) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (wave == 4 && u < 8) stamp_at(40 + u);  // arrival at P(u)
+      if (wave == 6 && u < 8) stamp_at(48 + u);
+      __builtin_amdgcn_s_barrier();  // P(u)
+      if (u == 0 && NU > 2) dma8(2);
+      if (u + 3 < NU) dma8(u + 3);  // into the buffer of unit u - 1
+    }
+    return;
+  }
+
+  // =================================== consumer waves ===================================
+  const int w4 = wave;
+  const int fi = lane & 31, fh = lane >> 5;
+  bf16x8 afr[NKB];
+  const unsigned char* const frag_base = (const unsigned char*)(qf + ((long long)(rg * (V6_ROWS / 32) + w4) * NKB) * 64);
+  auto load_fragments = [&](auto lo, auto hi) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)frag_base, 0, NKB * 1024, 0x00020000);
+    v4_static_for<decltype(lo)::value, decltype(hi)::value>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      afr[kb] = __builtin_bit_cast(
+          bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16 + kb * 1024), 0, 16 /* sc1 */));
+    });
+  };
+  load_fragments(std::integral_constant<int, 0>{}, std::integral_constant<int, FR0>{});
+  stamp();  // 1: first fragments requested
+  unsigned int boff[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) boff[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
+  // ---- stores.  The MFMA operands are swapped against v6 (queries first, targets second: the same products summed
+  // in the same K order, the tile transposed), so that a lane holds ONE target and sixteen query rows:
+  // acc[r] = score(row 8 (r >> 2) + 4 fh + (r & 3) of this wave's 32, target fi of the unit).  One
+  // instruction = element r of all lanes = two rows x 128 contiguous bytes.  Descriptor over this wave's rows that
+  // exist: a store to a padded row (>= n) falls outside its range and is dropped by the hardware (the range check
+  // sees the per-lane offset = row and target; the unit's column offset travels in the scalar offset).
+  const long long rb = (long long)rgl * RGR + 32 * w4;
+  const long long rows_here = rb < n ? (n - rb < 32 ? n - rb : 32) : 0;
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(out + (rows_here > 0 ? rb : 0) * ldo), 0, (int)(rows_here * ldo * 4), 0x00020000);
+  const unsigned int svo = (unsigned int)(((long long)(4 * fh) * ldo + fi) * 4);
+  const unsigned int ldo4 = (unsigned int)(ldo * 4);
+  auto store_elem = [&](const f32x16& a, auto rc, unsigned int vo, unsigned int colb) __attribute__((always_inline)) {
+    constexpr int r = decltype(rc)::value;
+    // the row in the per-lane offset (one v_add per store): gfx9 bounds-checks the VGPR offset only, the scalar
+    // offset (the unit's column) is added unchecked
+    const unsigned int vr = vo + (unsigned int)(8 * (r >> 2) + (r & 3)) * ldo4;
+    const float v = a[r];  // (a copy first: __builtin_bit_cast straight on the vector element stored element 0 every time)
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), srs, vr, colb, SC1 ? 16 : 0);
+  };
+  // per-lane offset for unit uu: out of range for the columns >= m of the ragged last unit
+  auto unit_vo = [&](int uu, unsigned int& colb) __attribute__((always_inline)) -> unsigned int {
+    const long long col0 = (long long)(unit_lo + uu * unit_st) * V6_UT;
+    colb = (unsigned int)(col0 * 4);
+    return (col0 + V6_UT <= m || col0 + fi < m) ? svo : 0x80000000u;
+  };
+
+  constexpr int PF = 8;
+  bf16x8 bq[PF];
+  unsigned int bp[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) bp[t] = boff[t];
+  auto bread = [&](bf16x8& dst, auto kc) __attribute__((always_inline)) {
+    constexpr int kb = decltype(kc)::value;
+    const unsigned int addr = bp[kb & 7];
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256) : "memory");
+  };
+  f32x16 acc0, acc1;
+  auto chain = [&](int u, f32x16& acc, const f32x16& prev, auto first) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first)::value;
+    const unsigned int bn = (unsigned int)(((u + 1) & (NBUF - 1)) * UNITB);
+    unsigned int colb = 0;
+    const unsigned int vo = FIRST ? 0u : unit_vo(u - 1, colb);
+    v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+      if constexpr (kb == V6_PB) __builtin_amdgcn_s_barrier();  // P(u)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kb == 0) {
+        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bq[0], zero, 0, 0, 0);
+      } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kb], bq[kb % PF], acc, 0, 0, 0);
+      }
+      if constexpr (kb + PF == NKB) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %2" : "=v"(bp[t]) : "s"(bn), "v"(boff[t]));
+      }
+      bread(bq[kb % PF], std::integral_constant<int, (kb + PF) % NKB>{});
+      if constexpr (!FIRST && (kb & 1) == 0) store_elem(prev, std::integral_constant<int, kb / 2>{}, vo, colb);
+      if constexpr (FIRST && kb < NKB - FR0)
+        load_fragments(std::integral_constant<int, FR0 + kb>{}, std::integral_constant<int, FR0 + kb + 1>{});
+    });
+    stamp();  // unit u: chain issued
+  };
+  using T = std::true_type;
+  using Fz = std::false_type;
+  __builtin_amdgcn_s_barrier();  // R0: unit 0 landed
+  stamp();  // 2
+  v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
+  chain(0, acc0, acc1, T{});
+  {
+    int u = 1;
+    for (; u + 1 < NU; u += 2) {
+      chain(u, acc1, acc0, Fz{});
+      chain(u + 1, acc0, acc1, Fz{});
+    }
+    if (u < NU) chain(u, acc1, acc0, Fz{});
+  }
+  {  // the last unit, straight away
+    unsigned int colb = 0;
+    const unsigned int vo = unit_vo(NU - 1, colb);
+    if ((NU - 1) & 1) {
+      v4_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) { store_elem(acc1, rc, vo, colb); });
+    } else {
+      v4_static_for<0, 16>([&](auto rc) __attribute__((always_inline)) { store_elem(acc0, rc, vo, colb); });
+    }
+  }
+  // The look-ahead reads behind the last unit return into bq[] whenever the LDS gets to them.  Nobody uses what they
+  // return -- which is exactly why the registers must be kept: to the compiler an asm output is there at once, a dead
+  // one is free at once, and it put the address of the slot-30 store into such a register (the read then landed on
+  // top of it: a store dropped or misdirected now and then, only with several launches in flight).  The empty asm
+  // below "uses" the eight registers AFTER the wait that drains the reads.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4]), "v"(bq[5]), "v"(bq[6]), "v"(bq[7]));
+  if (w4 == 0) stamp_at(34);  // last store issued
+  if (nx.qf != nullptr && nx.mode == 2)
+    v4_build_queries<SCORER, HH, 0>(nx, (long long)(rg * ncg + cg) * 256 + tid, (long long)nx.nblocks * 256);
 }
 
 static std::atomic<unsigned long long*> g_v6_stamps{nullptr};
@@ -470,6 +710,22 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
   // pitch, two-sided: 27.2 us written through, 21.1 us through the L2's write-back; aligned: 20.3 / 20.6)
   const int st_sc1 = sc1e ? (sc1e[0] != '0') : (st_aligned ? 1 : 0);
   (void)st_small;
+  if constexpr (!SPLIT) {
+    // one rounded query vector per row: scores stored straight from the accumulators (pairs_bf16_v7_kernel);
+    // KGE_V7=0: the staged kernel (A/B measurements)
+    // (one-sided launches into rows that are not sector-aligned stay with the staged kernel: 12.4 against 13.3 us at
+    // the FB15k-237 shape -- dword stores of unaligned 128-byte segments; KGE_V7=1 takes v7 there too)
+    const char* e7 = getenv("KGE_V7");
+    if (!(e7 && e7[0] == '0') && (st_aligned || two_sided || (e7 && e7[0] == '1'))) {
+      if (st_sc1)
+        hipLaunchKernelGGL((pairs_bf16_v7_kernel<SCORER, 1>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
+                           out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx);
+      else
+        hipLaunchKernelGGL((pairs_bf16_v7_kernel<SCORER, 0>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
+                           out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx);
+      return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+    }
+  }
   hipLaunchKernelGGL((pairs_bf16_v6_kernel<SCORER, SPLIT>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
                      out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, st_sc1);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;

@@ -28,7 +28,8 @@ constexpr int STG0 = 3 * UNITB, FLG = STG0 + 32768;
 
 template <int SYNC, int STG, int DMA>
 __global__ __launch_bounds__(512, 1) void k(const bf16x8* __restrict__ g, float* __restrict__ out,
-                                            unsigned long long* __restrict__ t, const unsigned char* __restrict__ gt) {
+                                            unsigned long long* __restrict__ t, const unsigned char* __restrict__ gt,
+                                            float* __restrict__ scores) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[FLG + 256];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(512, 1) void k(const bf16x8* __restrict__ g, float*
       if (SYNC == 1) __builtin_amdgcn_s_barrier();
       if (SYNC == 2 && wave == 4 && lane == 0) flg[8] = u + 2;  // "unit u + 1 landed" (far ahead of need)
       if (SYNC == 2 && wave == 6 && lane == 0) flg[9] = u + 1;
-      if (DMA && wave < 6) {
+      if (DMA == 1 && wave < 6) {
         unsigned int d = (unsigned int)(2 * UNITB + (wave - 4) * 16384);
         const unsigned char* p = gt + (size_t)(wave - 4) * 16384;
 #pragma unroll
@@ -53,6 +54,17 @@ __global__ __launch_bounds__(512, 1) void k(const bf16x8* __restrict__ g, float*
           p += 1024;
         }
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      }
+      if (DMA == 2) {  // all four partner waves load: 8 pieces per unit each (a fresh 32 KiB of the table per unit)
+        unsigned int d = (unsigned int)(2 * UNITB + (wave - 4) * 8192);
+        const unsigned char* p = gt + ((size_t)((blockIdx.x >> 2) * NU + u) & 255) * 32768 + (size_t)(wave - 4) * 8192;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(d), "v"(voff), "s"(p) : "memory", "m0");
+          d += 1024;
+          p += 1024;
+        }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       }
       if (SYNC == 2 && wave >= 6) {
         // a store wave waits until its two consumers have staged unit u
@@ -82,6 +94,8 @@ __global__ __launch_bounds__(512, 1) void k(const bf16x8* __restrict__ g, float*
     const unsigned int addr = bp[kb & 7];
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256) : "memory");
   };
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)scores, 0, 0x7fffffff, 0x00020000);
+  const unsigned int svo = (unsigned int)((((long long)(blockIdx.x & 3) * 128 + 32 * w4 + 4 * fh) * 16640 + fi) * 4);
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
@@ -96,7 +110,7 @@ __global__ __launch_bounds__(512, 1) void k(const bf16x8* __restrict__ g, float*
       constexpr int w_lo = 3;
       constexpr auto younger = [](int k) constexpr {
         int yg = 7;
-        if (STG)
+        if (STG == 1)
           for (int j = w_lo; j < w_lo + 4; ++j)
             if (j >= k - 8 && j <= k - 1) ++yg;
         if (SYNC == 2) {
@@ -117,7 +131,14 @@ __global__ __launch_bounds__(512, 1) void k(const bf16x8* __restrict__ g, float*
         for (int q = 0; q < 8; ++q) asm volatile("v_add_u32 %0, %1, %2" : "=v"(bp[q]) : "s"(bn), "v"(boff[q]));
       }
       bread(bq[kb % 8], std::integral_constant<int, (kb + 8) % NKB>{});
-      if constexpr (STG && kb >= w_lo && kb < w_lo + 4) {
+      if constexpr (STG == 2 && (kb & 1) == 0) {  // direct dword stores of the previous unit: element kb / 2
+        constexpr int r = kb >> 1;
+        const unsigned int so = (unsigned int)((((blockIdx.x >> 2) * NU + u) & 127) * 128) +
+                                (unsigned int)((8 * (r >> 2) + (r & 3)) * 16640 * 4);
+        const float pv = prev[r];  // (bit_cast straight on the vector element stores element 0: clang quirk)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, pv), srs, svo, so, 0);
+      }
+      if constexpr (STG == 1 && kb >= w_lo && kb < w_lo + 4) {
         constexpr int gq = kb - w_lo;
         f32x4 v = {prev[4 * gq], prev[4 * gq + 1], prev[4 * gq + 2], prev[4 * gq + 3]};
         *reinterpret_cast<f32x4*>(smem + cwr + (u & 1) * 16384 + (((2 * gq) ^ y) << 4)) = v;
@@ -146,11 +167,12 @@ static bf16x8* g;
 static float* outp;
 static unsigned long long* tp;
 static unsigned char* gt;
+static float* scores;
 
 template <int SYNC, int STG, int DMA>
 static void run(const char* name) {
   for (int blocks : {1, 256}) {
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<SYNC, STG, DMA>), dim3(blocks), dim3(512), 0, 0, g, outp, tp, gt);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k<SYNC, STG, DMA>), dim3(blocks), dim3(512), 0, 0, g, outp, tp, gt, scores);
     hipDeviceSynchronize();
     unsigned long long h[256];
     hipMemcpy(h, tp, sizeof(unsigned long long) * blocks, hipMemcpyDeviceToHost);
@@ -167,8 +189,9 @@ int main() {
   hipMemset(g, 0x3c, 512 * 16);
   hipMalloc(&outp, 256 * 512 * 4);
   hipMalloc(&tp, 4096 * 8);
-  hipMalloc(&gt, 1 << 20);
-  hipMemset(gt, 0x3c, 1 << 20);
+  hipMalloc(&gt, 8 << 20);
+  hipMemset(gt, 0x3c, 8 << 20);
+  hipMalloc(&scores, (size_t)520 * 16640 * 4);
   run<0, 0, 0>("no sync, no staging");
   run<0, 1, 0>("no sync, staging writes");
   run<1, 1, 0>("s_barrier per unit, staging");
@@ -176,5 +199,9 @@ int main() {
   run<0, 1, 1>("no sync, staging, partners stream 32 KiB per unit");
   run<1, 1, 1>("s_barrier per unit, staging, partners stream");
   run<2, 1, 1>("LDS counters, staging, partners stream");
+  run<1, 2, 0>("s_barrier per unit, DIRECT dword stores (16 / unit / wave)");
+  run<1, 2, 1>("s_barrier, direct stores, two partners stream");
+  run<1, 2, 2>("s_barrier, direct stores, FOUR partners stream fresh units");
+  run<1, 1, 2>("s_barrier, staging (no store waves), four partners stream");
   return 0;
 }

@@ -18,7 +18,7 @@ from kge_amd import engine  # noqa: E402
 
 dev = torch.device("cuda", 0)
 E, R, D = 14541, 237, 512
-VARIANTS = {"v6": {"KGE_V6": "1"}, "v4": {"KGE_V6": "0"}}
+VARIANTS = {"v7": {"KGE_V6": "1", "KGE_V7": "1"}, "v6": {"KGE_V6": "1", "KGE_V7": "0"}}
 
 def alg_bytes(n, m, d, sides):
     return m * d * 2 + sides * (n * 2 * d * 2 + n * m * 4 + 2 * n * 8)
