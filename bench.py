@@ -756,7 +756,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "pairs_bf16_v6_kernel<ComplEx,d=512>, two-sided, prepared queries (kge_score_queries: one "
+            "kernel": "pairs_bf16_v7_kernel<ComplEx,d=512>, two-sided, prepared queries (kge_score_queries: one "
                       "launch = MFMA contraction + store of both score blocks of batch k + gather and query build "
                       "of batch k+1 on idle workgroups)",
             "achieved": achieved,

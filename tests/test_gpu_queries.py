@@ -139,6 +139,39 @@ def test_batches_in_flight_on_several_streams(eng, combine, lanes):
         _same(got[k], want[k], f"{combine} lanes={lanes} batch {k}")
 
 
+@pytest.mark.parametrize("E,n", [(2111, 1), (2111, 63), (4099, 300), (14541, 512), (14541, 640)])
+def test_direct_store_kernel_equals_the_staged_kernel(eng, E, n, monkeypatch):
+    """pairs_bf16_v7_kernel (scores stored straight from the accumulators, KGE_V7=1 forces it for every layout)
+    against pairs_bf16_v6_kernel (staged stores, KGE_V7=0): the same bits, one- and two-sided, contiguous and
+    256-byte-pitched rows -- and nothing written outside the [n, m] blocks: the padded query rows (>= n) are dropped
+    by the buffer descriptor's range, the columns >= m of the ragged last unit by an out-of-range lane offset."""
+    R, d = 7, 512
+    T, _, _ = _tables(eng, "complex", E, R, d, E + n)
+    s, p, o = _batch(E, R, n, 3)
+    P = eng.score_pitch(E)
+    for combine, sides in (("sp_", 1), ("sp_po", 2)):
+        q = eng.build_queries(T, combine, s, p, o if sides == 2 else None)
+        for pitched in (False, True):
+            got = {}
+            for v7 in ("0", "1"):
+                monkeypatch.setenv("KGE_V7", v7)
+                guard = 36
+                ld = sides * P if pitched else sides * E + 13
+                big = torch.full((n + 2 * guard, ld), float("nan"), device=DEV)
+                rows = big[guard:guard + n]
+                if pitched:    # rows on the 256-byte pitch, the po block on a column of its own
+                    out = rows.view(n, 2, P)[:, :, :E] if sides == 2 else rows[:, :E]
+                else:          # contiguous blocks somewhere inside wider rows (4-byte alignment only)
+                    out = rows[:, 5:5 + sides * E]
+                eng.score_queries(T, q, out=out)
+                torch.cuda.synchronize()
+                got[v7] = out.reshape(n, -1).clone()
+                written = ~torch.isnan(big)
+                assert int(written.sum()) == n * sides * E, (combine, pitched, v7, int(written.sum()))
+            _same(got["1"], got["0"], f"{combine} pitched={pitched} E={E} n={n}")
+    monkeypatch.delenv("KGE_V7")
+
+
 def test_empty_and_mismatched_arguments(eng):
     T, _, _ = _tables(eng, "distmult", 500, 7, 256, 7)
     s, p, o = _batch(500, 7, 64, 8)

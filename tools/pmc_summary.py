@@ -20,7 +20,8 @@ tot = 0.0
 for c in res:
     for k, (n, m) in res[c].items():
         lines.append(f"{c:11s} {k[:60]:60s} dispatches={n:4d} mean={m:10.1f} KiB")
-main = [k for k in res["FETCH_SIZE"] if "pairs_bf16_v6_kernel" in k] or \
+main = [k for k in res["FETCH_SIZE"] if "pairs_bf16_v7_kernel" in k] or \
+       [k for k in res["FETCH_SIZE"] if "pairs_bf16_v6_kernel" in k] or \
        [k for k in res["FETCH_SIZE"] if "pairs_bf16_v4_kernel" in k] or \
        [k for k in res["FETCH_SIZE"] if "pairs_bf16_v3_kernel" in k] or \
        [k for k in res["FETCH_SIZE"] if "pairs_bf16_v2_kernel" in k]

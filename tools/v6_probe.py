@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""pairs_bf16_v6_kernel against pairs_bf16_v4_kernel (KGE_V6=0) on prepared queries at the FB15k-237 shape: the
+"""pairs_bf16_v7_kernel (direct stores) against pairs_bf16_v6_kernel (KGE_V7=0; earlier: v6 against v4, KGE_V6=0) on prepared queries at the FB15k-237 shape: the
 pipelined step (every launch also builds the next batch's queries), one- and two-sided, contiguous and padded
 pitch, plain and split queries; variants timed in turn (ABAB...), median of R rounds of S back-to-back steps.
 Then the phase stamps of the one-sided launch.      python tools/v6_probe.py [--steps 300] [--rounds 5]"""
