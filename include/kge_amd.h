@@ -397,6 +397,17 @@ int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_o
               int64_t ent_ldo, kge_index rel_idx, int64_t n_rel, void* rel_out,
               int64_t rel_ldo, void* stream);
 
+/* BCEWithLogitsKgeLoss over the [n, c = 1 + K] score block of one negative-sampling slot (kge/util/loss.py:136-189 on
+ * the block TrainingJobNegativeSampling._process_subbatch assembles, train_negative_sampling.py:120-151: column 0 the
+ * positive, columns 1.. its negatives), forward and gradient in one pass:
+ *   kind 0 "bce": sum_j l(x_j, y_j);  1 "bce_mean": (l(x_0, 1) + sum_{j>=1} l(x_j, 0) / K) / 2;
+ *   2 "bce_self_adversarial": (l(x_0, 1) + sum_{j>=1} w_j l(x_j, 0)) / 2, w = softmax_j(temperature * x_j), not
+ *   differentiated -- x = score + offset (train.loss_arg), l = torch.nn.BCEWithLogitsLoss's element.
+ * loss_rows[i] = row i's term (the job's loss is their sum, divided by the batch size by the job);
+ * grad (may be NULL) [n, c], leading dimension ldg: d (sum_i loss_rows[i]) / d scores[i, j]. */
+int kge_ns_bce_loss(const float* scores, int64_t ld, int64_t n, int64_t c, int kind, float offset, float temperature,
+                    float* loss_rows, float* grad, int64_t ldg, void* stream);
+
 /* The two row moves of the entity-sharded exchange (kge_amd/sharded.py: ShardedEntityTable.exchange_rows),
  * the id arithmetic evaluated inside the kernel, one launch each:
  *   kge_shard_gather   t->ent = THIS RANK's rows [lo, lo + t->num_ent) of the entity table.  For j < num_ids (1 or 2

@@ -79,6 +79,8 @@ PROTOTYPES = {
     "kge_score_emb": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                      c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
     "kge_embed": (ctypes.c_int, [_PT, KgeIndex, c_i64, c_vp, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
+    "kge_ns_bce_loss": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, ctypes.c_int, ctypes.c_float, ctypes.c_float, c_vp, c_vp,
+                                       c_i64, c_vp]),
     "kge_shard_gather": (ctypes.c_int, [_PT, c_i64, ctypes.POINTER(KgeIndex), ctypes.c_int, c_i64, c_vp, c_i64,
                                         KgeIndex, c_vp, c_i64, c_vp]),
     "kge_shard_pick": (ctypes.c_int, [c_vp, c_i64, ctypes.c_int, c_i64, c_i64, ctypes.c_int,

@@ -42,6 +42,8 @@ int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Ope
                       int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
                       unsigned long long* dbg);
 int run_embed2(const EmbedJob& a, const EmbedJob& b, int rowbytes, int esize, hipStream_t st);
+int run_ns_bce(int kind, const float* scores, long long ld, long long n, long long c, float offset, float temp,
+               float* loss_rows, float* grad, long long ldg, hipStream_t st);
 int run_shard_rows(const ShardJob& a, const ShardJob& b, const ShardJob& c, int rowbytes01, int rowbytes2, int esize,
                    hipStream_t st);
 int run_rank(const float* scores, long long lds, long long n, long long c,
@@ -487,6 +489,14 @@ int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_o
     return run_embed2(n_ent ? a : none, n_rel ? b : none, (int)(n_ent ? eb : rb), es, (hipStream_t)stream);
   rc = run_embed2(a, none, (int)eb, es, (hipStream_t)stream);  // RotatE: rows of different length
   return rc ? rc : run_embed2(none, b, (int)rb, es, (hipStream_t)stream);
+}
+
+int kge_ns_bce_loss(const float* scores, int64_t ld, int64_t n, int64_t c, int kind, float offset, float temperature,
+                    float* loss_rows, float* grad, int64_t ldg, void* stream) {
+  if (n < 0 || c < 1 || kind < 0 || kind > 2 || ld < c || (grad && ldg < c)) return KGE_ERR_INVALID_ARG;
+  if (n > 0 && (!scores || !loss_rows)) return KGE_ERR_INVALID_ARG;
+  if (kind != 0 && c < 2) return KGE_ERR_INVALID_ARG;  // the mean / adversarial forms need a negative
+  return run_ns_bce(kind, scores, ld, n, c, offset, temperature, loss_rows, grad, ldg, (hipStream_t)stream);
 }
 
 int kge_shard_gather(const kge_tables* t, int64_t lo, const kge_index* ids, int num_ids, int64_t n, void* send,

@@ -19,7 +19,7 @@ from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V3, FLAG_EXACT, FLAG_NO_MF
                    SCORERS, SP_, SP_PO, SPO, KgeIndex, KgeNextQueries, KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "embed", "shard_gather", "shard_pick", "rank_counts", "score_pitch", "eval_batch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V3",
+           "score_emb", "embed", "shard_gather", "shard_pick", "ns_bce_loss", "rank_counts", "score_pitch", "eval_batch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V3",
            "FLAG_SPLIT_QUERY", "reserve_cus", "Queries", "build_queries", "score_queries", "ScorePipeline"]
 
 
@@ -615,6 +615,28 @@ def embed(t: Tables, ent_idx=None, rel_idx=None, ent_out=None, rel_out=None):
         if rc:
             _lib.check(rc, "kge_embed")
     return ent_out, rel_out
+
+
+NS_BCE_KINDS = {"bce": 0, "bce_mean": 1, "bce_self_adversarial": 2}
+
+
+def ns_bce_loss(scores: torch.Tensor, kind: str, offset: float = 0.0, temperature: float = 1.0, want_grad: bool = True):
+    """(loss_rows [n], grad [n, c] or None) of BCEWithLogitsKgeLoss over a negative-sampling score block [n, 1 + K]
+    with the positives in column 0 (kge_ns_bce_loss): the loss value is loss_rows.sum()."""
+    _require_gpu(scores, "scores")
+    if scores.dim() != 2 or scores.dtype != torch.float32:
+        raise ValueError("kge_amd: ns_bce_loss takes a float32 [n, 1 + K] score block")
+    if scores.stride(1) != 1:
+        scores = scores.contiguous()
+    n, c = scores.shape
+    rows = _empty((n,), scores.device)
+    grad = _empty((n, c), scores.device) if want_grad else None
+    with _on_device(scores.device):
+        _lib.check(_lib.lib().kge_ns_bce_loss(
+            scores.data_ptr(), scores.stride(0) if n > 1 else c, n, c, NS_BCE_KINDS[kind], float(offset),
+            float(temperature), rows.data_ptr(), None if grad is None else grad.data_ptr(), c,
+            _stream_handle(scores.device)), "kge_ns_bce_loss")
+    return rows, grad
 
 
 def shard_gather(t: Tables, lo: int, ids, rel_idx, send: torch.Tensor, rel_out=None):

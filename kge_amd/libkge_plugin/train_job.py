@@ -205,6 +205,62 @@ class _FusedNegativeScore:
         return scores if scores is not None else self._score(model, indexes=indexes)
 
 
+class _FusedNsBce(torch.autograd.Function):
+    """loss = sum of kge_ns_bce_loss's per-row terms; the kernel writes d loss / d scores in the same pass."""
+
+    @staticmethod
+    def forward(ctx, scores, kind, offset, temperature):
+        from .. import engine
+        rows, grad = engine.ns_bce_loss(scores, kind, offset, temperature, want_grad=True)
+        ctx.save_for_backward(grad)
+        return rows.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+class _HipNsBceLoss:
+    """Stands in for the job's BCEWithLogitsKgeLoss (`train.loss: bce | bce_mean | bce_self_adversarial`,
+    kge/util/loss.py:136-189) on the [n, 1 + K] score block of a negative-sampling slot: one kernel for the loss and its
+    gradient instead of ~15 launches -- and, for the self-adversarial form, instead of two torch.nonzero calls (two
+    device -> host waits per slot and step).  Everything it does not recognise -- CPU tensors, index labels, a label
+    matrix that is not "column 0 positive, the rest negative" (checked once per label tensor: the job builds it once
+    per shape and reuses it, train_negative_sampling.py:128-137) -- goes to the reference loss it wraps."""
+
+    def __init__(self, ref_loss):
+        self.ref = ref_loss
+        self.kind = {None: "bce", "mean": "bce_mean", "self_adversarial": "bce_self_adversarial"}[ref_loss._bce_type]
+        self.offset = float(ref_loss._offset)
+        self.temperature = float(getattr(ref_loss, "_temperature", 1.0))
+        self._pattern_ok = {}
+        self.fused_calls = 0
+
+    def __getattr__(self, name):
+        return getattr(self.ref, name)
+
+    def __call__(self, scores, labels, **kwargs):
+        if not (torch.is_tensor(labels) and scores.is_cuda and scores.dim() == 2 and scores.dtype == torch.float32
+                and labels.dim() == 2 and labels.shape == scores.shape and scores.shape[1] >= 2):
+            return self.ref(scores, labels, **kwargs)
+        key = (labels.data_ptr(), tuple(labels.shape))
+        ok = self._pattern_ok.get(key)
+        if ok is None:
+            ok = self._pattern_ok[key] = bool((labels[:, 0] == 1).all()) and bool((labels[:, 1:] == 0).all())
+        if not ok:
+            return self.ref(scores, labels, **kwargs)
+        self.fused_calls += 1
+        return _FusedNsBce.apply(scores, self.kind, self.offset, self.temperature)
+
+
+def _fusable_ns_loss(loss) -> bool:
+    if not isinstance(loss, BCEWithLogitsKgeLoss) or loss._bce_type not in (None, "mean", "self_adversarial"):
+        return False
+    inner = loss._loss
+    return getattr(inner, "weight", None) is None and getattr(inner, "pos_weight", None) is None
+
+
 class HipTrainingJobNegativeSampling(TrainingJobNegativeSampling):
     """`_process_subbatch` is the reference's (train_negative_sampling.py:103-164), called unchanged: labels,
     positive scores, loss, averaging, backward and every timing key are its code.  What changes is what
@@ -220,6 +276,12 @@ class HipTrainingJobNegativeSampling(TrainingJobNegativeSampling):
     def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
         super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
         self.type_str = "negative_sampling"
+        # the bce family of losses on a GPU: loss + gradient of a slot's score block in one kernel (KGE_NS_FUSED_LOSS=0:
+        # the reference's loss object, untouched)
+        import os
+        if (str(self.device).startswith("cuda") and _fusable_ns_loss(self.loss)
+                and os.environ.get("KGE_NS_FUSED_LOSS", "1") != "0"):
+            self.loss = _HipNsBceLoss(self.loss)
         if self.__class__ == HipTrainingJobNegativeSampling:
             for f in Job.job_created_hooks:
                 f(self)

@@ -172,6 +172,25 @@ def test_a_hip_complex_under_1vsAll_matches_the_reference_model(data):
          hip_complex_fused_bf16=_second_epoch_seconds(fus))
 
 
+@pytest.mark.parametrize("loss", ["bce_mean", "bce_self_adversarial"])
+def test_b2_negative_sampling_with_the_fused_bce_losses(data, loss):
+    """`train.loss: bce_mean | bce_self_adversarial` (kge/util/loss.py:160-186) under hip_negative_sampling: the job's
+    loss object is the one-kernel stand-in (loss + gradient of a slot's score block in one launch, no torch.nonzero);
+    one epoch against the reference model + job + loss from the same initial parameters."""
+    root, folder = data
+    opts = {"negative_sampling.num_samples.s": 64, "negative_sampling.num_samples.o": 64,
+            "negative_sampling.implementation": "triple", "train.loss": loss}
+    ref, l_ref, st = _train_epoch(root, folder, f"b2_ref_{loss}", "rotate", "negative_sampling", 128, opts)
+    fus, l_fus, _ = _train_epoch(root, folder, f"b2_fus_{loss}", "hip_rotate", "hip_negative_sampling", 128, opts,
+                                 init_from=st)
+    assert type(fus.loss).__name__ == "_HipNsBceLoss" and fus.loss.fused_calls > 0
+    d = _param_diff(fus, ref)
+    _log(case=f"b2: hip_rotate + hip_negative_sampling, train.loss {loss}, vs rotate + negative_sampling",
+         loss_ref=l_ref, loss_fused=l_fus, rel_fused=_rel(l_fus, l_ref), param_rel_diff_fused=d,
+         seconds_reference=_second_epoch_seconds(ref), seconds_fused=_second_epoch_seconds(fus))
+    assert _rel(l_fus, l_ref) <= 1e-4 and d <= 1e-3
+
+
 @pytest.mark.parametrize("model", ["rotate", "transe"])
 def test_b_negative_sampling_jobs(data, model):
     root, folder = data
