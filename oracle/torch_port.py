@@ -13,6 +13,8 @@ itself cannot travel to the GPU box.
                 RotatEScorer.score_emb    kge/model/rotate.py:20-69 (+ helpers :146-213)
   score_sp/po/spo <- KgeModel.score_*     kge/model/kge_model.py:663-725
                      (LookupEmbedder.embed / embed_all, lookup_embedder.py:96-112)
+  ns_bce_loss     <- BCEWithLogitsKgeLoss.__call__  kge/util/loss.py:153-186 on the label matrix of
+                     TrainingJobNegativeSampling (column 0 = 1, train_negative_sampling.py:128-137)
 """
 import torch
 import torch.nn.functional as F
@@ -100,3 +102,30 @@ def score_sp(model, ent, rel, s, p, o=None, l_norm=1.0):
 def score_po(model, ent, rel, p, o, s=None, l_norm=1.0):
     tg = _embed_all(ent) if s is None else _embed(ent, s)
     return score_emb(model, tg, _embed(rel, p), _embed(ent, o), "_po", l_norm)
+
+
+def ns_bce_loss(scores, kind, offset=0.0, temperature=1.0):
+    """BCEWithLogitsKgeLoss (kge/util/loss.py:153-186) on a negative-sampling score block [n, 1 + K] whose label matrix
+    has ones in column 0: kind "bce" (reduction "sum"), "bce_mean", "bce_self_adversarial".  The reference's op
+    sequence: offset, BCEWithLogitsLoss over the flattened block, the positive column picked by index, the negatives by
+    sum - positive (mean) or by a mask (self-adversarial: softmax of the detached scores * temperature)."""
+    n, c = scores.shape
+    labels = torch.zeros(scores.shape, device=scores.device, dtype=torch.float)
+    labels[:, 0] = 1
+    if offset != 0.0:
+        scores = scores + offset
+    reduction = "sum" if kind == "bce" else "none"
+    losses = torch.nn.BCEWithLogitsLoss(reduction=reduction)(scores.view(-1), labels.view(-1))
+    if kind == "bce":
+        return losses
+    pos_idx = torch.zeros(n, dtype=torch.long, device=scores.device)
+    losses = losses.view(scores.shape)
+    losses_positives = losses[range(n), pos_idx]
+    if kind == "bce_mean":
+        losses_negatives = losses.sum(dim=1) - losses_positives
+        return (losses_positives.sum() + losses_negatives.sum() / (c - 1)) / 2.0
+    negative_indexes = torch.nonzero(labels.view(-1) == 0.0)
+    scores_negatives = scores.detach().view(-1)[negative_indexes].view((n, c - 1))
+    losses_negatives = losses.view(-1)[negative_indexes].view((n, c - 1))
+    losses_negatives = (F.softmax(scores_negatives * temperature, dim=1) * losses_negatives).sum(dim=1)
+    return (losses_positives.sum() + losses_negatives.sum()) / 2.0

@@ -1,7 +1,7 @@
 """kge_ns_bce_loss (BCEWithLogitsKgeLoss over a negative-sampling score block, loss + gradient in one kernel) against
-the reference's formulas restated with torch ops in float32 on the same scores (kge/util/loss.py:153-186: offset,
-BCEWithLogitsLoss elements, `bce_mean`'s positive / negative averaging, the detached softmax weights of
-`bce_self_adversarial`) and torch autograd for the gradient.  Floating point, another summation order: loss within
+the oracle's restatement of the reference's op sequence (oracle/torch_port.ns_bce_loss <- kge/util/loss.py:153-186:
+offset, BCEWithLogitsLoss elements, `bce_mean`'s positive / negative averaging, the detached softmax weights of
+`bce_self_adversarial`) in float32 on the same scores, and torch autograd through it for the gradient.  Floating point, another summation order: loss within
 2e-6 relative, gradient within 1e-6 + 1e-5 relative."""
 import pytest
 import torch
@@ -12,19 +12,10 @@ DEV = "cuda:0"
 
 
 def _reference(scores, kind, offset, temperature):
-    n, c = scores.shape
-    labels = torch.zeros_like(scores)
-    labels[:, 0] = 1.0
-    x = scores + offset if offset != 0.0 else scores
-    if kind == "bce":
-        return F.binary_cross_entropy_with_logits(x.view(-1), labels.view(-1), reduction="sum")
-    losses = F.binary_cross_entropy_with_logits(x.view(-1), labels.view(-1), reduction="none").view(n, c)
-    pos = losses[:, 0]
-    if kind == "bce_mean":
-        neg = losses.sum(dim=1) - pos
-        return (pos.sum() + neg.sum() / (c - 1)) / 2.0
-    w = F.softmax(x.detach()[:, 1:] * temperature, dim=1)
-    return (pos.sum() + (w * losses[:, 1:]).sum()) / 2.0
+    """oracle/torch_port.ns_bce_loss: the reference's op sequence (pinned to the reference's own loss object, bit for bit,
+    by tests/test_oracle_vs_reference.py in the build container)."""
+    import torch_port as tp
+    return tp.ns_bce_loss(scores, kind, offset, temperature)
 
 
 @pytest.mark.parametrize("kind,offset,temperature", [("bce", 0.0, 1.0), ("bce", 0.7, 1.0), ("bce_mean", 0.0, 1.0),

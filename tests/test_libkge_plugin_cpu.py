@@ -405,3 +405,32 @@ def test_hip_models_train_on_cpu_like_the_reference_models(tmp_path, model, trai
         assert torch.equal(a, b)
     for key in ("mean_reciprocal_rank", "mean_reciprocal_rank_filtered", "hits_at_1_filtered"):
         assert v_ref[key] == v_hip[key], key
+
+
+@pytest.mark.parametrize("bce_type", [None, "mean", "self_adversarial"])
+def test_ns_bce_stand_in_hands_everything_it_does_not_recognise_to_the_reference_loss(bce_type):
+    """_HipNsBceLoss (the one-kernel stand-in hip_negative_sampling installs for the bce family on a GPU) wraps the
+    job's BCEWithLogitsKgeLoss: CPU tensors and index labels reach the reference's object unchanged -- same value, same
+    gradient -- and its attributes stay readable through the wrapper."""
+    config = _config("hip_complex")   # (imports the reference and the plugin package)
+    from kge.util.loss import BCEWithLogitsKgeLoss
+    from kge_amd.libkge_plugin.train_job import _HipNsBceLoss, _fusable_ns_loss
+    kw = {"temperature": 2.0} if bce_type == "self_adversarial" else {}
+    ref = BCEWithLogitsKgeLoss(config, offset=0.25, bce_type=bce_type, **kw)
+    assert _fusable_ns_loss(ref)
+    w = _HipNsBceLoss(ref)
+    assert w._offset == 0.25 and w.kind == {None: "bce", "mean": "bce_mean", "self_adversarial": "bce_self_adversarial"}[bce_type]
+    g = torch.Generator().manual_seed(2)
+    scores = torch.randn(9, 13, generator=g)
+    labels = torch.zeros(9, 13)
+    labels[:, 0] = 1
+    a, b = scores.clone().requires_grad_(True), scores.clone().requires_grad_(True)
+    la, lb = ref(a, labels, num_negatives=12), w(b, labels, num_negatives=12)   # CPU: the reference's loss
+    la.backward()
+    lb.backward()
+    assert torch.equal(la, lb) and torch.equal(a.grad, b.grad) and w.fused_calls == 0
+    if bce_type is not None:   # index labels (positions of the ones)
+        idx = torch.zeros(9, dtype=torch.long)
+        assert torch.equal(ref(scores, idx), w(scores, idx))
+    weighted = BCEWithLogitsKgeLoss(config, offset=0.0, bce_type=bce_type, pos_weight=torch.tensor(2.0), **kw)
+    assert not _fusable_ns_loss(weighted)

@@ -50,3 +50,27 @@ def test_c_oracle_vs_live_reference_fb15k237_shape_slice(model):
     r1, t1 = ko.rank_counts(ref, true_ref)
     r2, t2 = ko.rank_counts(got, true_got)
     assert np.abs((r1 + t1 // 2) - (r2 + t2 // 2)).max() <= 1
+
+
+@pytest.mark.parametrize("kind,bce_type,offset,temperature", [("bce", None, 0.0, 1.0), ("bce", None, 0.5, 1.0),
+                                                               ("bce_mean", "mean", 0.0, 1.0), ("bce_mean", "mean", -1.0, 1.0),
+                                                               ("bce_self_adversarial", "self_adversarial", 0.0, 1.0),
+                                                               ("bce_self_adversarial", "self_adversarial", 0.25, 3.0)])
+def test_ns_bce_port_is_bit_identical_to_the_reference_loss(kind, bce_type, offset, temperature):
+    """oracle/torch_port.ns_bce_loss against the reference's own BCEWithLogitsKgeLoss object (kge/util/loss.py:136-189)
+    on the label matrix TrainingJobNegativeSampling builds: loss and gradient, bit for bit (the same torch ops)."""
+    rh.import_reference()
+    from kge.util.loss import BCEWithLogitsKgeLoss
+    config = rh.make_config("complex", 16)
+    kw = {"temperature": temperature} if bce_type == "self_adversarial" else {}
+    ref = BCEWithLogitsKgeLoss(config, offset=offset, bce_type=bce_type, **kw)
+    g = torch.Generator().manual_seed(3)
+    scores = torch.randn(37, 65, generator=g) * 5.0
+    labels = torch.zeros(37, 65)
+    labels[:, 0] = 1
+    a = scores.clone().requires_grad_(True)
+    b = scores.clone().requires_grad_(True)
+    la, lb = ref(a, labels, num_negatives=64), tp.ns_bce_loss(b, kind, offset, temperature)
+    la.backward()
+    lb.backward()
+    assert torch.equal(la, lb) and torch.equal(a.grad, b.grad)
