@@ -681,12 +681,14 @@ def main():
             pipes.step(next_batch=batches[ks[0] & 1], out=out_buf)
         for _ in range(5):
             one_split()
-        sp_ms = event_avg_ms(one_split, max(10, a.steps // 2))
+        sp_ms = event_avg_ms(one_split, max(50, a.steps // 2))
         ab2 = algorithmic_bytes(n, E_FB, DIM, sides=2)
         extra["split_query_step"] = {"avg_launch_us": sp_ms * 1e3, "algorithmic_bytes_per_launch": ab2,
                                      "frac": ab2 / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "scored_triples_per_s": 2.0 * n * E_FB / (sp_ms * 1e-3)}
         del TS, pipes, pipe1, out1
+        # (the legs below are not the timed region: they run at least a few dozen launches each whatever K is -- at the
+        # driver's K = 20 ten launches from a cold start say little)
         # ... and at the other batch sizes SURVEY.md 8(d) lists (and beyond): the start-up of a launch
         # (index load -> row gather -> query build -> hand-off, ~8 us) is paid once per call, so the
         # per-launch fraction of the roofline grows with n
@@ -700,7 +702,7 @@ def main():
             outn = torch.empty(nn, PITCH, device=device)[:, :E_FB]
             for _ in range(3):
                 pn.step(next_batch=(s2, p2, None), out=outn)
-            ms = event_avg_ms(lambda: pn.step(next_batch=(s2, p2, None), out=outn), max(10, a.steps // 4))
+            ms = event_avg_ms(lambda: pn.step(next_batch=(s2, p2, None), out=outn), max(40, a.steps // 4))
             del pn, outn
             abn = algorithmic_bytes(nn, E_FB, DIM)
             by_n[str(nn)] = {"avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": abn,
@@ -713,15 +715,15 @@ def main():
         T32 = engine.Tables("complex", ent.float(), rel.float())
         for _ in range(3):
             engine.score_sp(T32, s, p)
-        f_ms = event_avg_ms(lambda: engine.score_sp(T32, s, p), max(10, a.steps // 4))
+        f_ms = event_avg_ms(lambda: engine.score_sp(T32, s, p), max(30, a.steps // 4))
         tf = 2.0 * n * DIM * E_FB / (f_ms * 1e-3) / 1e12
         extra_f32 = {"bound": "mfma", "kernel": "pairs_f32_kernel<ComplEx> (score_sp, float32 tables, exact f32 chain)",
                      "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TF,
                      "avg_launch_us": f_ms * 1e3, "flops_per_launch": 2.0 * n * DIM * E_FB,
                      "scored_triples_per_s": n * E_FB / (f_ms * 1e-3)}
         del T32
-        extra_rank = rank_legs(engine, device, n, max(10, min(a.steps, 400) // 4))
-        extra_neg = neg_legs(engine, device, max(10, min(a.steps, 400) // 8))
+        extra_rank = rank_legs(engine, device, n, max(25, min(a.steps, 400) // 4))
+        extra_neg = neg_legs(engine, device, max(20, min(a.steps, 400) // 8))
         extra_eval = eval_leg(engine, device)
     else:
         extra_f32 = extra_rank = extra_neg = extra_eval = None
