@@ -422,7 +422,10 @@ class ShardedScoreLanes:
         """On the lane's stream (already current): call by call, or copy + replay of the lane's captured step."""
         if not self.use_graph:
             return fn(*args), False
-        key = (name,) + tuple((tuple(a.shape), a.dtype) for a in args)
+        # (a capture holds the tables' addresses: tables re-allocated behind our back get a capture of their own --
+        # refresh_tables copies in place and keeps them valid)
+        tb = self.table
+        key = (name, tb.ent_local.data_ptr(), tb.rel.data_ptr()) + tuple((tuple(a.shape), a.dtype) for a in args)
         ent = self._graphs[lane].get(key)
         if ent is not None:
             for d, x in zip(ent["static"], args):
