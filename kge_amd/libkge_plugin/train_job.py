@@ -237,7 +237,9 @@ class _HipNsBceLoss:
         self._pattern_ok = {}
         self.fused_calls = 0
 
-    def __getattr__(self, name):
+    def __getattr__(self, name):  # everything else (config, _loss, _offset, ...) is the wrapped loss's
+        if name == "ref":  # not set yet (copy / pickle protocols probe attributes on a blank instance): no recursion
+            raise AttributeError(name)
         return getattr(self.ref, name)
 
     def __call__(self, scores, labels, **kwargs):
