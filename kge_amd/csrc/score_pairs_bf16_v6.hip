@@ -433,7 +433,7 @@ template <int SCORER, int SC1>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
     Operand TG, long long n, long long m, int rgn, int rgn1, long long out2_off, int ncg, int units_per_cg,
     int nunits, float* __restrict__ out, long long ldo, unsigned long long* __restrict__ dbg,
-    const u32x4* __restrict__ qf, NextQ nx) {
+    const u32x4* __restrict__ qf, NextQ nx, int probe) {
   constexpr int HH = 256;
   constexpr int RGR = V6_ROWS;
   constexpr int NKB = 2 * HH / 16;
@@ -557,7 +557,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
   // exist: a store to a padded row (>= n) falls outside its range and is dropped by the hardware (the range check
   // sees the per-lane offset = row and target; the unit's column offset travels in the scalar offset).
   const long long rb = (long long)rgl * RGR + 32 * w4;
-  const long long rows_here = rb < n ? (n - rb < 32 ? n - rb : 32) : 0;
+  long long rows_here = rb < n ? (n - rb < 32 ? n - rb : 32) : 0;
+  if (probe & 1) rows_here = 0;  // tools/r4_diag.py (KGE_V7_NOSTORE=1): every store falls outside the descriptor
   const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(out + (rows_here > 0 ? rb : 0) * ldo), 0, (int)(rows_here * ldo * 4), 0x00020000);
   const unsigned int svo = (unsigned int)(((long long)(4 * fh) * ldo + fi) * 4);
@@ -716,13 +717,15 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
     // (one-sided launches into rows that are not sector-aligned stay with the staged kernel: 12.4 against 13.3 us at
     // the FB15k-237 shape -- dword stores of unaligned 128-byte segments; KGE_V7=1 takes v7 there too)
     const char* e7 = getenv("KGE_V7");
+    const char* ens = getenv("KGE_V7_NOSTORE");
+    const int probe = (ens && ens[0] == '1') ? 1 : 0;
     if (!(e7 && e7[0] == '0') && (st_aligned || two_sided || (e7 && e7[0] == '1'))) {
       if (st_sc1)
         hipLaunchKernelGGL((pairs_bf16_v7_kernel<SCORER, 1>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
-                           out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx);
+                           out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, probe);
       else
         hipLaunchKernelGGL((pairs_bf16_v7_kernel<SCORER, 0>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
-                           out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx);
+                           out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, probe);
       return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
     }
   }
