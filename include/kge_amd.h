@@ -224,6 +224,27 @@ int kge_score_queries(const kge_tables* t, int combine, const void* queries, int
                       kge_index targets, int64_t m, float* out, int64_t ldo, int64_t block2_offset,
                       const kge_next_queries* next /* may be NULL */, void* stream);
 
+/* GROUPS of batches in one launch.  A caller that iterates a split knows more than the next batch: an epoch's
+ * DataLoader (kge/job/train_1vsAll.py:31-41) or EntityRankingJob._evaluate's loop (eval_entity_ranking.py:143-229)
+ * can hand over `num_batches` equally shaped batches at once.  The scoring launch is then ONE persistent kernel that
+ * streams the table through every compute unit once per batch and writes batch l's block at out + l * out_stride
+ * (floats; each block laid out as kge_score_queries lays out its one): the launch gap, the cold start of a launch and
+ * the compute units a single batch's grid cannot fill are paid once per group, not once per batch.
+ *   kge_build_queries_multi   batch l = rows [l n, (l + 1) n) of s / p / o; its fragments at queries + l *
+ *                             queries_stride (bytes; a multiple of 16, >= kge_queries_bytes(t, combine, n));
+ *   kge_score_queries_multi   scores the group; `next` (may be NULL) describes the NEXT group -- num_batches batches of
+ *                             next->n rows each, index vectors of num_batches * next->n entries, fragments next_stride
+ *                             bytes apart in next->queries -- built by the same launch behind its last unit.
+ * Scores are bit-identical to num_batches kge_score_queries calls.  bf16 ComplEx / DistMult at dim 512 against all
+ * entities; anything else KGE_ERR_UNSUPPORTED (loop over kge_score_queries instead). */
+int kge_build_queries_multi(const kge_tables* t, int combine, kge_index s, kge_index p, kge_index o, int64_t n,
+                            int64_t num_batches, void* queries, int64_t queries_stride, int64_t queries_bytes,
+                            void* stream);
+int kge_score_queries_multi(const kge_tables* t, int combine, const void* queries, int64_t queries_stride, int64_t n,
+                            int64_t num_batches, kge_index targets, int64_t m, float* out, int64_t out_stride,
+                            int64_t ldo, int64_t block2_offset, const kge_next_queries* next /* may be NULL */,
+                            int64_t next_stride, void* stream);
+
 /* Negative-sampling scores, the "triple" implementation without building the
  * [n*K,3] index tensor: slot 0/2 = corrupt s / o.
  * out[i*ldo + k] = score of triple i with slot replaced by neg[i*neg_ld + k].

@@ -74,6 +74,10 @@ PROTOTYPES = {
     "kge_build_queries": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_queries": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, KgeIndex, c_i64, c_vp, c_i64, c_i64,
                                          ctypes.POINTER(KgeNextQueries), c_vp]),
+    "kge_build_queries_multi": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, KgeIndex, c_i64, c_i64, c_vp, c_i64,
+                                               c_i64, c_vp]),
+    "kge_score_queries_multi": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_i64, c_i64, KgeIndex, c_i64, c_vp, c_i64,
+                                               c_i64, c_i64, ctypes.POINTER(KgeNextQueries), c_i64, c_vp]),
     "kge_score_neg": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int, c_vp,
                                      ctypes.c_int32, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_emb": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,

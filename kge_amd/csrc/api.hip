@@ -2,6 +2,7 @@
 // kernel selection.  No torch, no allocation, no global state; every call enqueues on the
 // caller's hipStream_t and returns a kge_status.
 #include "common.hpp"
+#include "bf16_queries.hpp"
 #include <cstdlib>
 
 namespace kge {
@@ -37,6 +38,14 @@ int run_pairs_bf16_v4_prepared(int scorer, bool split, const Operand& A, const O
                                long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
                                const void* ready, void* ws, long long ws_bytes, int reserve_cus, const Operand* nA,
                                const Operand* nA2, const Operand* nR, long long nn, void* nqf);
+int run_query_build_multi(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                          long long n, int nbatch, void* qf, long long qstride_bytes, hipStream_t st);
+int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided, int d, long long n, long long m,
+                      int nbatch, const void* qf, long long q_stride_bytes, float* out, long long out_stride,
+                      long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg, const NextQ& nx,
+                      int reserve_cus);
+NextQ pairs_bf16_nextq(bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, long long n,
+                       int nbatch, void* qf, long long qstride_bytes);
 bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
 int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
@@ -396,6 +405,74 @@ int kge_score_queries(const kge_tables* t, int combine, const void* queries, int
                                     (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, has_next ? &nA : nullptr,
                                     has_next && combine == KGE_SP_PO ? &nA2 : nullptr, has_next ? &nR : nullptr,
                                     has_next ? next->n : 0, has_next ? next->queries : nullptr);
+}
+
+// ---- groups of batches: one launch per group (score_pairs_bf16_v8.hip) ---------------------------------------------
+int kge_build_queries_multi(const kge_tables* t, int combine, kge_index s, kge_index p, kge_index o, int64_t n,
+                            int64_t num_batches, void* queries, int64_t queries_stride, int64_t queries_bytes,
+                            void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
+  if (n < 0 || num_batches < 0 || num_batches > (1 << 20) || (n * num_batches > 0 && !queries) || queries_stride < 0)
+    return KGE_ERR_INVALID_ARG;
+  if (n == 0 || num_batches == 0) return KGE_OK;
+  if (!queries_supported(t)) return KGE_ERR_UNSUPPORTED;
+  const int64_t per = kge_queries_bytes(t, combine, n);
+  if ((queries_stride & 15) || queries_stride < per) return KGE_ERR_INVALID_ARG;
+  if (queries_bytes < (num_batches - 1) * queries_stride + per) return KGE_ERR_WORKSPACE;
+  Operand A, A2, R;
+  int dir;
+  if ((rc = query_operands(t, combine, s, p, o, A, A2, R, dir))) return rc;
+  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, A)) return KGE_ERR_UNSUPPORTED;
+  return run_query_build_multi(t->scorer, (t->flags & KGE_FLAG_SPLIT_QUERY) != 0, A, combine == KGE_SP_PO ? &A2 : nullptr,
+                               R, dir, (int)t->dim, n, (int)num_batches, queries, queries_stride, (hipStream_t)stream);
+}
+
+int kge_score_queries_multi(const kge_tables* t, int combine, const void* queries, int64_t queries_stride, int64_t n,
+                            int64_t num_batches, kge_index targets, int64_t m, float* out, int64_t out_stride,
+                            int64_t ldo, int64_t block2_offset, const kge_next_queries* next, int64_t next_stride,
+                            void* stream) {
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
+  const int64_t b2 = combine == KGE_SP_PO ? (block2_offset > 0 ? block2_offset : m) : 0;
+  const int64_t width = combine == KGE_SP_PO ? b2 + m : m;
+  if (n < 0 || m < 0 || num_batches < 0 || num_batches > (1 << 20) || ldo < width || (combine == KGE_SP_PO && b2 < m) ||
+      queries_stride < 0 || out_stride < 0)
+    return KGE_ERR_INVALID_ARG;
+  const bool work = n > 0 && m > 0 && num_batches > 0;
+  if (work && (!out || !queries)) return KGE_ERR_INVALID_ARG;
+  if (work && num_batches > 1 && out_stride < (n - 1) * ldo + width) return KGE_ERR_INVALID_ARG;  // blocks overlap
+  if ((rc = check_index(targets, true))) return rc;
+  if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
+  if (!queries_supported(t) || t->dim != 512 || targets.ptr) return KGE_ERR_UNSUPPORTED;
+  const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
+  const int64_t per = kge_queries_bytes(t, combine, n);
+  if (work && num_batches > 1 && ((queries_stride & 15) || queries_stride < per)) return KGE_ERR_INVALID_ARG;
+  Operand TG = ent_op(t, targets);
+  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, TG, TG, TG)) return KGE_ERR_UNSUPPORTED;
+  NextQ nx{};
+  const bool has_next = next != nullptr && next->n > 0 && next->queries != nullptr;
+  if (has_next) {  // the NEXT group: num_batches batches of next->n rows, fragments next_stride bytes apart
+    Operand nA, nA2, nR;
+    int ndir;
+    const int64_t nper = kge_queries_bytes(t, combine, next->n);
+    if (next->queries == queries || (next_stride & 15) || (num_batches > 1 && next_stride < nper)) return KGE_ERR_INVALID_ARG;
+    if (next->queries_bytes < (num_batches > 0 ? num_batches - 1 : 0) * next_stride + nper) return KGE_ERR_WORKSPACE;
+    if ((rc = query_operands(t, combine, next->s, next->p, next->o, nA, nA2, nR, ndir))) return rc;
+    if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, nA, nR, nA)) return KGE_ERR_UNSUPPORTED;
+    if (!work)
+      return run_query_build_multi(t->scorer, split, nA, combine == KGE_SP_PO ? &nA2 : nullptr, nR, ndir, (int)t->dim,
+                                   next->n, (int)(num_batches > 0 ? num_batches : 1), next->queries, next_stride,
+                                   (hipStream_t)stream);
+    nx = pairs_bf16_nextq(split, nA, combine == KGE_SP_PO ? &nA2 : nullptr, nR, ndir, next->n, (int)num_batches,
+                          next->queries, next_stride);
+  }
+  if (!work) return KGE_OK;
+  return run_pairs_bf16_v8(t->scorer, split, TG, combine == KGE_SP_PO, (int)t->dim, n, m, (int)num_batches, queries,
+                           queries_stride, out, out_stride, ldo, b2, (hipStream_t)stream, nullptr, nx,
+                           (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
 }
 
 int kge_score_sp(const kge_tables* t, kge_index s, kge_index p, int64_t n, kge_index targets,

@@ -39,6 +39,10 @@ struct NextQ {
   // without idle slots, e.g. 16 row groups x 16 column groups) -- the consumer waves of EVERY scoring workgroup,
   // behind their last tile, while the store waves drain (nblocks = scoring workgroups, 256 threads each)
   int mode, nblocks;
+  // a GROUP of equally shaped batches (kge_score_queries_multi / kge_build_queries_multi): batch l = rows
+  // [l n, (l + 1) n) of the index vectors, its fragments `qstride` 16-byte words behind batch l - 1's.  0 = 1 batch.
+  int nbatch;
+  long long qstride;
 };
 
 template <int SCORER>
@@ -65,14 +69,16 @@ template <int SCORER, int HH, int SPLIT>
 __device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item0, long long stride) {
   constexpr int NKB = 2 * HH / 16, NKH = HH / 16, CGR = HH / 8;
   constexpr int RGR = SPLIT ? 64 : 128;  // real rows per row group
-  const long long items = (long long)nx.rgn * RGR * CGR;
+  const int nb = nx.nbatch > 1 ? nx.nbatch : 1;
+  const long long items = (long long)nb * nx.rgn * RGR * CGR;
   for (long long it = item0; it < items; it += stride) {
-    const int rg = (int)(it / (RGR * CGR));
+    const int rgg = (int)(it / (RGR * CGR));
+    const int lb = rgg / nx.rgn, rg = rgg - lb * nx.rgn;  // batch of the group, row group of the batch
     const int rr = (int)((it / CGR) % RGR);
     const int c8 = (int)(it % CGR);
     const bool second = rg >= nx.rgn1;
     const long long lrow = (long long)(second ? rg - nx.rgn1 : rg) * RGR + rr;
-    const long long qrow = lrow < nx.n ? lrow : nx.n - 1;  // padded rows repeat row n-1
+    const long long qrow = (lrow < nx.n ? lrow : nx.n - 1) + (long long)lb * nx.n;  // padded rows repeat row n-1
     const Operand& E = second ? nx.A2 : nx.A;
     const int dir = second ? KGE_PO_ : nx.dir;
     const unsigned short* a = (const unsigned short*)E.base + index_at(E.idx, qrow) * E.ld + c8 * 8;
@@ -100,7 +106,7 @@ __device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item
     }
     // fragment-major (as the in-launch build below): K-block kb of 32-row block rb is 64 lanes x 16 B
     const long long row = (long long)rg * 128 + rr;  // virtual row (SPLIT: the q_hi row; q_lo 64 rows behind)
-    u32x4* dst = nx.qf + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
+    u32x4* dst = nx.qf + (long long)lb * nx.qstride + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
     dst[(c8 >> 1) * 64] = q0;
     dst[(NKH + (c8 >> 1)) * 64] = q1;
     if constexpr (SPLIT) {

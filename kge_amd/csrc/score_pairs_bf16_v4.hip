@@ -910,6 +910,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
 int run_pairs_bf16_v6(int scorer, bool split, const Operand& TG, bool two_sided, int d, long long n, long long m,
                       float* out, long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
                       const void* qf, const NextQ& nx, int reserve_cus);
+int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided, int d, long long n, long long m,
+                      int nbatch, const void* qf, long long q_stride_bytes, float* out, long long out_stride,
+                      long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg, const NextQ& nx,
+                      int reserve_cus);
 
 static inline bool v4_al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -967,7 +971,7 @@ long long pairs_bf16_v4_query_bytes(int d, long long n, bool two_sided, bool spl
 template <int SCORER, int HH, int SPLIT>
 static int launch_query_build(const NextQ& q, hipStream_t st) {
   constexpr int RGR = SPLIT ? 64 : V4_ROWS;
-  const long long items = (long long)q.rgn * RGR * (HH / 8);
+  const long long items = (long long)(q.nbatch > 1 ? q.nbatch : 1) * q.rgn * RGR * (HH / 8);
   long long blocks = (items + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
@@ -1047,6 +1051,10 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   if constexpr (EPI == V3_STORE && HH == 256) {
     if (prepared && tgmode == 0) {
       if (pp.next.qf != nullptr && !v4_al16(pp.next.qf)) return KGE_ERR_INVALID_ARG;
+      // the persistent kernel with two consumer waves per SIMD (score_pairs_bf16_v8.hip); KGE_V8=0: v6 / v7
+      const int rc8 = run_pairs_bf16_v8(SCORER, SPLIT != 0, TG, A2 != nullptr, 2 * HH, n, m, 1, qf, 0, out, 0, ldo,
+                                        out2_off, st, dbg, pp.next, reserve_cus);
+      if (rc8 != KGE_ERR_UNSUPPORTED) return rc8;
       const int rc = run_pairs_bf16_v6(SCORER, SPLIT != 0, TG, A2 != nullptr, 2 * HH, n, m, out, ldo, out2_off, st, dbg,
                                        qf, pp.next, reserve_cus);
       if (rc != KGE_ERR_UNSUPPORTED) return rc;
@@ -1136,6 +1144,34 @@ int run_query_build(int scorer, bool split, const Operand& A, const Operand* A2,
   if (n == 0) return KGE_OK;
   if (!v4_al16(qf)) return KGE_ERR_INVALID_ARG;
 #define KGE_QB(SC, HHV, SP) return launch_query_build<SC, HHV, SP>(v4_nextq<SC, HHV, SP>(A, A2, R, dir, n, qf), st)
+#define KGE_QB2(SC)                                    \
+  if (d == 256) {                                      \
+    if (split) KGE_QB(SC, 128, 1); else KGE_QB(SC, 128, 0); \
+  } else if (d == 512) {                               \
+    if (split) KGE_QB(SC, 256, 1); else KGE_QB(SC, 256, 0); \
+  }
+  if (scorer == KGE_COMPLEX) { KGE_QB2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_QB2(KGE_DISTMULT) }
+#undef KGE_QB2
+#undef KGE_QB
+  return KGE_ERR_UNSUPPORTED;
+}
+
+// A group of `nbatch` equally shaped batches (kge_build_queries_multi / kge_score_queries_multi): batch l = rows
+// [l n, (l + 1) n) of the index vectors, its fragments at qf + l * qstride_bytes.
+NextQ pairs_bf16_nextq(bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, long long n,
+                       int nbatch, void* qf, long long qstride_bytes) {
+  NextQ q = split ? v4_nextq<KGE_COMPLEX, 256, 1>(A, A2, R, dir, n, qf) : v4_nextq<KGE_COMPLEX, 256, 0>(A, A2, R, dir, n, qf);
+  q.nbatch = nbatch;
+  q.qstride = qstride_bytes / 16;
+  return q;
+}
+
+int run_query_build_multi(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                          long long n, int nbatch, void* qf, long long qstride_bytes, hipStream_t st) {
+  if (n == 0 || nbatch == 0) return KGE_OK;
+  if (!v4_al16(qf) || (qstride_bytes & 15)) return KGE_ERR_INVALID_ARG;
+  const NextQ q = pairs_bf16_nextq(split, A, A2, R, dir, n, nbatch, qf, qstride_bytes);
+#define KGE_QB(SC, HHV, SP) return launch_query_build<SC, HHV, SP>(q, st)
 #define KGE_QB2(SC)                                    \
   if (d == 256) {                                      \
     if (split) KGE_QB(SC, 128, 1); else KGE_QB(SC, 128, 0); \

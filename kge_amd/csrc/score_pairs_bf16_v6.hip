@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
 // out-of-range offset.  Bits: the same accumulation chains -- identical to v6 / v4.
 //   barriers (all eight waves): R0 (unit 0 landed); P(u) in slot V6_PB of chain u: unit u + 1 has landed and the
 //   consumers are done with ring buffer (u - 1) % 4, which the loaders refill with unit u + 3.
-template <int SCORER, int SC1>
+template <int SCORER, int SC1, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
     Operand TG, long long n, long long m, int rgn, int rgn1, long long out2_off, int ncg, int units_per_cg,
     int nunits, float* __restrict__ out, long long ldo, unsigned long long* __restrict__ dbg,
@@ -525,9 +525,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (wave == 4 && u < 8) stamp_at(40 + u);  // arrival at P(u)
       if (wave == 6 && u < 8) stamp_at(48 + u);
-      __builtin_amdgcn_s_barrier();  // P(u)
+      if constexpr (!(PROBE & 8)) __builtin_amdgcn_s_barrier();  // P(u)
       if (u == 0 && NU > 2) dma8(2);
-      if (u + 3 < NU) dma8(u + 3);  // into the buffer of unit u - 1
+      if constexpr (!(PROBE & 2))
+        if (u + 3 < NU) dma8(u + 3);  // into the buffer of unit u - 1
     }
     return;
   }
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
     v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
       asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-      if constexpr (kb == V6_PB) __builtin_amdgcn_s_barrier();  // P(u)
+      if constexpr (kb == V6_PB && !(PROBE & 8)) __builtin_amdgcn_s_barrier();  // P(u)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kb == 0) {
         const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -609,8 +610,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
 #pragma unroll
         for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %2" : "=v"(bp[t]) : "s"(bn), "v"(boff[t]));
       }
-      bread(bq[kb % PF], std::integral_constant<int, (kb + PF) % NKB>{});
-      if constexpr (!FIRST && (kb & 1) == 0) store_elem(prev, std::integral_constant<int, kb / 2>{}, vo, colb);
+      if constexpr (!(PROBE & 4)) bread(bq[kb % PF], std::integral_constant<int, (kb + PF) % NKB>{});
+      if constexpr (!FIRST && (kb & 1) == 0 && !(PROBE & 1)) store_elem(prev, std::integral_constant<int, kb / 2>{}, vo, colb);
       if constexpr (FIRST && kb < NKB - FR0)
         load_fragments(std::integral_constant<int, FR0 + kb>{}, std::integral_constant<int, FR0 + kb + 1>{});
     });
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
 
 static std::atomic<unsigned long long*> g_v6_stamps{nullptr};
 void v6_set_stamps(unsigned long long* p) { g_v6_stamps.store(p); }
+unsigned long long* v6_get_stamps() { return g_v6_stamps.load(std::memory_order_relaxed); }
 
 static int v6_cu_count() {
   static std::atomic<int> cache[64];
@@ -720,6 +722,16 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
     const char* ens = getenv("KGE_V7_NOSTORE");
     const int probe = (ens && ens[0] == '1') ? 1 : 0;
     if (!(e7 && e7[0] == '0') && (st_aligned || two_sided || (e7 && e7[0] == '1'))) {
+      const char* epr = getenv("KGE_V7_PROBE");  // compile-time timing variants (tools/r4_diag3.py); wrong scores
+      const int prb = epr ? atoi(epr) : 0;
+#define KGE_V7P(PB)                                                                                               \
+  if (prb == PB) {                                                                                               \
+    hipLaunchKernelGGL((pairs_bf16_v7_kernel<SCORER, 0, PB>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,  \
+                       out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, probe);  \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;                                            \
+  }
+      KGE_V7P(1) KGE_V7P(2) KGE_V7P(3) KGE_V7P(4) KGE_V7P(5) KGE_V7P(7) KGE_V7P(8) KGE_V7P(9) KGE_V7P(15)
+#undef KGE_V7P
       if (st_sc1)
         hipLaunchKernelGGL((pairs_bf16_v7_kernel<SCORER, 1>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
                            out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, probe);

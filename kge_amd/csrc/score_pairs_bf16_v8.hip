@@ -1,0 +1,439 @@
+// score_pairs_bf16_v8.hip -- ComplEx / DistMult sp_/_po scores of bf16 tables at d = 512 from PREPARED query
+// fragments: the store path of the BASELINE.json headline configuration, round 4.  One launch scores a GROUP of
+// equally shaped batches (kge_score_queries_multi; a group of one = kge_score_queries).
+//
+// What round 4 measured on pairs_bf16_v7_kernel (tools/r4_diag.py, r4_diag2.py; profiles/r4_diag*.txt):
+//   * its unit period (32 targets x 128 query rows) is 1.44 k cycles with the stores issued -- also when the hardware
+//     DROPS every one of them, also without the table DMA -- and 1.15 k cycles (36 per MFMA, the matrix pipe's own
+//     rate) once the store INSTRUCTIONS are compiled out: a buffer_store_dword holds its wave ~45 cycles at the
+//     vector-memory port, the consumer wave issues in order, and with one consumer wave per SIMD every cycle it
+//     stands there the matrix pipe of that SIMD idles;
+//   * per launch ~5.4 k cycles pass before the first accumulation chain, 28 of 256 compute units get no workgroup,
+//     and a dependent launch starts ~1.5 us after its predecessor.
+//
+// This kernel therefore
+//   (1) puts TWO consumer waves on every SIMD: eight waves of 32 query rows (a workgroup = 256 rows), each doing ALL
+//       three jobs for its rows -- ds_read_b128 + v_mfma_f32_32x32x16_bf16 (queries in 128 operand registers), the
+//       direct dword stores of the unit before (v7's transposed tile: a lane holds one target and sixteen rows, one
+//       instruction = two rows x 128 contiguous bytes) and four of a unit's 32 LDS-DMA pieces.  While one wave of a
+//       SIMD stands at the memory port the other one feeds the matrix pipe; a table unit is streamed into LDS once
+//       per 256 rows instead of once per 128;
+//   (2) is PERSISTENT: 8 x (CUs / 8) workgroups; XCD x (= blockIdx % 8, a placement the hardware is observed to keep
+//       and nothing depends on) owns the column slice x of the table -- 1/8 of the units, ~1.9 MB at the FB15k-237
+//       shape: it stays in that XCD's L2 --, the (batch, side, 256-row chunk) pairs x the slice's units form one
+//       list per XCD, and workgroup j of the XCD walks a contiguous 1/32 of it, streaming units across pair
+//       boundaries (at a boundary the waves flush their last unit and load the next pair's fragments; the table
+//       stream and the LDS ring never stop).  Cold start, launch gap and idle units are paid once per group.
+//
+// Synchronisation: one workgroup barrier P(k) per unit, in MFMA slot V8_PB of chain k.  Behind it: unit k + 1 has
+// landed in ring buffer (k + 1) % 4 (every wave waited for ITS pieces: s_waitcnt vmcnt(N), N = the vector-memory
+// operations it has issued since -- stores and younger pieces; gfx9 retires a wave's VMEM operations in issue
+// order) and everybody is done reading ring buffer (k - 1) % 4, which the pieces of unit k + 3 then overwrite
+// (slots 17, 21, 25, 29).  The instruction stream of a chain is the same for every unit -- a chain without a unit
+// before it stores through an out-of-range offset, a chain without a unit three ahead re-requests the list's last
+// unit into the free buffer -- so that N is one constant.
+//
+// Bits: one accumulation chain per score in K order = pairs_bf16_v4/v6/v7 and the oracle's bf16 mode.  Split
+// queries (KGE_FLAG_SPLIT_QUERY): the q_hi and q_lo rows of 16 real rows are the 32 operand rows of a wave, arranged
+// so that both partial scores of a (row, target) sit in ONE lane (elements r and r + 4): score = hi + lo, one add,
+// eight stores per unit -- the bits of pairs_bf16_v6_kernel<SPLIT>.  Fragment buffers: the layout of
+// v4_build_queries (bf16_queries.hpp), unchanged.
+#include "common.hpp"
+#include "bf16_queries.hpp"
+#include <atomic>
+#include <cstdlib>
+
+namespace kge {
+
+constexpr int V8_UT = 32;   // targets per unit
+constexpr int V8_PB = 14;   // MFMA slot of the barrier
+constexpr unsigned int V8_DROP = 0x80000000u;  // per-lane store offset beyond every descriptor range
+
+struct V8Args {
+  Operand TG;
+  long long n, m;          // rows per batch and side, targets
+  int rgn1;                // 128-row fragment groups per side (v4_build_queries' layout)
+  int sides;               // 1 / 2 (two-sided: the second side's fragment groups and score block follow the first's)
+  int chunks;              // workgroup chunks (two fragment groups) per side
+  int nbatch;              // batches in the group
+  long long q_stride;      // 16-byte words between the fragments of two batches
+  long long out_stride;    // floats between the score blocks of two batches
+  long long out2_off, ldo;
+  int nunits, su, wpx;     // units in all, per XCD slice; workgroups per XCD
+  float* out;
+  const u32x4* qf;
+  unsigned long long* dbg;
+  NextQ nx;
+};
+
+#define KGE_V8_DMA(D, VO, P) \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0")
+
+template <int SCORER, int SPLIT, int AUX>
+__global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
+  constexpr int HH = 256;
+  constexpr int NKB = 2 * HH / 16;        // 32 K-blocks of 16
+  constexpr int ROWB = 4 * HH;            // 1 KiB per table row = one DMA piece
+  constexpr int UNITB = V8_UT * ROWB;     // 32 KiB
+  constexpr int NBUF = 4;
+  constexpr int SMEM = NBUF * UNITB;      // 128 KiB
+  constexpr int RW = SPLIT ? 16 : 32;     // real query rows per wave
+  constexpr int NST = SPLIT ? 8 : 16;     // stores per unit and wave, in slots 0, 2, ..
+  constexpr int PF = 8;
+  constexpr int FR0 = 12;  // query K-blocks requested before the first chain (cold start)
+  // vector-memory operations a wave issues between the last piece of unit k + 1 (slot 29 of chain k - 2) and the wait
+  // in slot V8_PB of chain k: the stores behind slot 29, chain k - 1 (stores + 4 pieces), the stores of slots < V8_PB
+  // (steady state: 28 / 19 plain / split).  The chain behind the cold one waits for unit 2, requested in slots 1 - 13 of
+  // the cold chain, behind which 9 / 1 stores + 6 fragment loads + 4 pieces + 7 stores = 26 / 18 operations follow: two
+  // less than the steady count serves every chain (the two extra operations waited for are a unit old)
+  constexpr int VMN_STEADY = (NST > 15 ? 1 : 0) + NST + 4 + V8_PB / 2;
+  constexpr int VMN = VMN_STEADY - 2;
+  static_assert(VMN <= (NST > 15 ? 9 : 1) + (NKB - FR0 - 14) + 4 + V8_PB / 2, "the chain behind the cold chain");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  if (a.n < 0) smem[threadIdx.x] = 0;  // (never: keeps the allocation -- only asm names the array)
+
+  const int b = blockIdx.x;
+  const int x = b & 7, j = b >> 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int u_lo = x * a.su;
+  int sux = a.nunits - u_lo;
+  if (sux > a.su) sux = a.su;
+  const int P = a.nbatch * a.sides * a.chunks;
+  int g0 = 0, g1 = 0;  // this workgroup's range of the XCD's list: position g = pair (g / sux), unit u_lo + g % sux
+  if (sux > 0) {
+    const long long T = (long long)P * sux;
+    g0 = (int)(T * j / a.wpx);
+    g1 = (int)(T * (j + 1) / a.wpx);
+  }
+
+  int dbg_i = 0;
+  auto stamp = [&]() {  // optional per-phase timestamps (tools/r4_diag.py); dbg == NULL in production
+    if (a.dbg != nullptr && tid == 0 && dbg_i < 32) a.dbg[(long long)blockIdx.x * 64 + dbg_i] = __builtin_readcyclecounter();
+    ++dbg_i;
+  };
+  auto stamp_at = [&](int slot) {
+    if (a.dbg != nullptr && tid == 0) a.dbg[(long long)blockIdx.x * 64 + slot] = __builtin_readcyclecounter();
+  };
+
+  if (g1 > g0) {
+    stamp();  // 0: start
+    // ---------------- the table stream: this wave's four rows of every unit ----------------
+    const unsigned char* const tgb = (const unsigned char*)a.TG.base;
+    const long long tld2 = a.TG.ld * 2;
+    const long long m = a.m;
+    const unsigned int lane16 = (unsigned int)lane << 4;
+    const int r4 = 4 * wave;
+    // lane l fetches the row's 16-byte slot l ^ (row & 15) into slot l (the consumers read slot s of row fi at
+    // s ^ (fi & 15): conflict-free); rows beyond the table repeat its last row (their scores are never stored)
+    const unsigned int dx0 = (unsigned int)((r4 & 15) << 4);
+    int dq = g0;             // list position of the next unit to request
+    int du = g0 % sux;       // ... its unit within the slice
+    const int ulast = (g1 - 1) % sux;
+    // unit `un` of the slice -> ring buffer `ks & 3`, piece `kk`
+    auto dma_piece = [&](int un, int ks, auto kc) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kc)::value;
+      long long r = (long long)(u_lo + un) * V8_UT + r4 + kk;
+      if (r >= m) r = m - 1;
+      const unsigned char* pk = tgb + r * tld2;
+      const unsigned int dk = (unsigned int)((ks & (NBUF - 1)) * UNITB + (r4 + kk) * ROWB);
+      const unsigned int vo = lane16 ^ (dx0 + (unsigned int)(kk << 4));
+      KGE_V8_DMA(dk, vo, pk);
+    };
+    auto dma_advance = [&]() __attribute__((always_inline)) {
+      ++dq;
+      if (++du == sux) du = 0;
+    };
+    // ring fill: units g0, g0 + 1, g0 + 2 (positions beyond the range: the last unit again, into buffers nobody
+    // reads), interleaved with the first pair's fragment loads below: unit 0 | K-blocks 0-15 | unit 1 | 16-31 | unit 2
+    auto fill_unit = [&](int k) __attribute__((always_inline)) {
+      const int un = dq < g1 ? du : ulast;
+      v4_static_for<0, 4>([&](auto kc) __attribute__((always_inline)) { dma_piece(un, k, kc); });
+      dma_advance();
+    };
+
+    // ---------------- the consumer ----------------
+    const int fi = lane & 31, fh = lane >> 5;
+    bf16x8 afr[NKB];
+    unsigned int boff[8], bp[8];
+    // target fragment kb of row fi: the 16-byte slot 2 kb + fh, stored at slot ^ (fi & 15)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bp[t] = boff[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
+    bf16x8 bq[PF];
+    auto bread = [&](bf16x8& dst, auto kc) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kc)::value;
+      const unsigned int addr = bp[kb & 7];
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256) : "memory");
+    };
+    // ---- stores.  MFMA(queries, targets): acc[r] = score(operand row 8 (r >> 2) + 4 fh + (r & 3), target fi).
+    //   plain queries: operand row = query row of this wave's 32;
+    //   split queries: operand row 16 a + 8 part + jj = real row 8 a + jj of this wave's 16, part 0 = q_hi, 1 = q_lo:
+    //     elements r (r & 4 == 0) and r + 4 are the two partial scores of real row 8 (r >> 3) + 4 fh + (r & 3).
+    // The row part of a store's address travels in the per-lane offset (gfx9 bounds-checks the VGPR offset only): rows
+    // >= n fall outside the descriptor and are dropped by the hardware, the unit's column goes in the scalar offset.
+    const unsigned int ldo4 = (unsigned int)(a.ldo * 4);
+    const unsigned int svo = (unsigned int)(((long long)(4 * fh) * a.ldo + fi) * 4);
+    __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);
+    auto store_q = [&](const f32x16& acc, auto qc, unsigned int vo, unsigned int colb) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;  // q-th store of the unit
+      constexpr int r = SPLIT ? (q & 3) + 8 * (q >> 2) : q;
+      constexpr int rowc = SPLIT ? 8 * (r >> 3) + (r & 3) : 8 * (r >> 2) + (r & 3);
+      const unsigned int vr = vo + (unsigned int)rowc * ldo4;
+      float v = acc[r];  // (a copy first: __builtin_bit_cast straight on the vector element stored element 0 every time)
+      if constexpr (SPLIT) {
+        const float lo = acc[r + 4];
+        v = v + lo;  // score = (sum q_hi t) + (sum q_lo t)
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), srs, vr, colb, AUX);
+    };
+    // per-lane offset of the unit at slice position `cu`: out of range for the columns >= m of the ragged last unit
+    auto unit_vo = [&](int cu, unsigned int& colb) __attribute__((always_inline)) -> unsigned int {
+      const long long col0 = (long long)(u_lo + cu) * V8_UT;
+      colb = (unsigned int)(col0 * 4);
+      return (col0 + V8_UT <= m || col0 + fi < m) ? svo : V8_DROP;
+    };
+
+    f32x16 acc0, acc1;
+    // chain of the unit in ring buffer ks & 3 into `acc`; `prev` (offset vo, column colb) is stored on the way.
+    // `cold` (the workgroup's very first chain): the ring holds units 0 and 1 only and the fragments K-blocks < FR0 --
+    // unit 2 is requested in slots 1, 5, 9, 13, K-block FR0 + j in slot j (FR0 slots ahead of its MFMA); `frag` loads it
+    auto chain = [&](int ks, f32x16& acc, const f32x16& prev, unsigned int vo, unsigned int colb, auto cold, auto&& frag)
+        __attribute__((always_inline)) {
+      constexpr bool COLD = decltype(cold)::value;
+      const unsigned int bn = (unsigned int)(((ks + 1) & (NBUF - 1)) * UNITB);
+      int un = dq < g1 ? du : ulast;  // requested by this chain: the unit three ahead (cold: first the unit two ahead)
+      v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kc)::value;
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        if constexpr (kb == V8_PB) {
+          // this wave's pieces of unit ks + 1 have landed (cold: requested right behind R0; since then 7 stores, 14
+          // fragment loads and unit 2's pieces of slots 1 - 13)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(COLD ? 25 : VMN) : "memory");
+          __builtin_amdgcn_s_barrier();  // P(ks)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kb == 0) {
+          const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bq[0], zero, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kb], bq[kb % PF], acc, 0, 0, 0);
+        }
+        if constexpr (kb + PF == NKB) {  // this unit's reads are all issued: on to the next ring buffer
+#pragma unroll
+          for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %2" : "=v"(bp[t]) : "s"(bn), "v"(boff[t]));
+        }
+        bread(bq[kb % PF], std::integral_constant<int, (kb + PF) % NKB>{});
+        if constexpr ((kb & 1) == 0 && kb / 2 < NST) store_q(prev, std::integral_constant<int, kb / 2>{}, vo, colb);
+        if constexpr (COLD && kb < NKB - FR0) frag(std::integral_constant<int, FR0 + kb>{});
+        if constexpr (COLD && kb < 14 && (kb & 3) == 1) dma_piece(un, ks + 2, std::integral_constant<int, kb / 4>{});
+        if constexpr (COLD && kb == 14) {
+          dma_advance();
+          un = dq < g1 ? du : ulast;
+        }
+        if constexpr (kb >= 17 && ((kb - 17) & 3) == 0) dma_piece(un, ks + 3, std::integral_constant<int, (kb - 17) / 4>{});
+      });
+      dma_advance();
+      stamp();  // chain issued
+    };
+    using Cold = std::true_type;
+    using Warm = std::false_type;
+    auto nofrag = [](auto) {};
+
+    int g = g0, ks = 0;
+    int pair = g0 / sux, cu = g0 - pair * sux;
+    bool first = true;
+    while (g < g1) {
+      int cnt = sux - cu;
+      if (cnt > g1 - g) cnt = g1 - g;
+      // ---- the pair: batch lb, side, chunk of 8 x RW rows -> this wave's rows and fragments
+      const int per = a.sides * a.chunks;
+      const int lb = pair / per, rem = pair - lb * per;
+      const int side = rem / a.chunks, ch = rem - side * a.chunks;
+      const long long rb = (long long)ch * (8 * RW) + RW * wave;  // first row (of the side) of this wave
+      long long rows_here = rb < a.n ? (a.n - rb < RW ? a.n - rb : RW) : 0;
+      float* const ob = a.out + (long long)lb * a.out_stride + (side ? a.out2_off : 0) + (rows_here > 0 ? rb : 0) * a.ldo;
+      srs = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, (int)(rows_here * a.ldo * 4), 0x00020000);
+      // fragments: groups of 128 operand rows (4 blocks of 32 rows x 32 K-blocks x 1 KiB); a chunk = two groups
+      int grp = 2 * ch + (wave >> 2);
+      if (grp >= a.rgn1) grp = a.rgn1 - 1;  // (a side with an odd number of groups: rows_here == 0 there)
+      grp += side * a.rgn1;
+      const unsigned char* const gbase = (const unsigned char*)(a.qf + (long long)lb * a.q_stride + (long long)grp * 4 * NKB * 64);
+      // (compiler-visible loads: the waits land in front of the first MFMA that needs each fragment -- the first chain
+      // of a pair is straight-line code behind them)
+      unsigned int flo;
+      const unsigned char* fb;
+      int frange;
+      if constexpr (SPLIT) {
+        // operand row fi = 16 a + 8 part + jj of wave w: real row 16 (w & 3) + 8 a + jj of the group's 64, whose q_hi
+        // sits in block (row >> 5), its q_lo in block 2 + (row >> 5)
+        const int part = (fi >> 3) & 1, rr = 16 * (wave & 3) + 8 * (fi >> 4) + (fi & 7);
+        flo = (unsigned int)((((2 * part + (rr >> 5)) * NKB) * 64 + (rr & 31) + 32 * fh) * 16);
+        fb = gbase;
+        frange = 4 * NKB * 1024;
+      } else {
+        flo = (unsigned int)(lane * 16);
+        fb = gbase + (wave & 3) * (NKB * 1024);
+        frange = NKB * 1024;
+      }
+      const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, frange, 0x00020000);
+      auto load_fragments = [&](auto lo, auto hi) __attribute__((always_inline)) {
+        v4_static_for<decltype(lo)::value, decltype(hi)::value>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int kb = decltype(kc)::value;
+          afr[kb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, flo + kb * 1024, 0, 16 /* sc1 */));
+        });
+      };
+      using C0 = std::integral_constant<int, 0>;
+      using CF = std::integral_constant<int, FR0>;
+      using C32 = std::integral_constant<int, NKB>;
+      unsigned int pvo = V8_DROP, pcolb = 0;  // the unit before: none yet in this pair
+      // the pair's first chain is peeled: straight-line code behind the fragment loads
+      if (first) {
+        // cold start: what is in the vector-memory queue in front of the first chain delays it (8 waves x 1 KiB per
+        // instruction through one 64 B/clk port: ~16 cycles each) -- unit 0 and FR0 K-blocks only; R0; unit 1; the rest
+        // of the fragments and unit 2 from inside the first chain
+        fill_unit(0);
+        load_fragments(C0{}, CF{});
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(FR0) : "memory");  // unit 0's four pieces: this wave's oldest operations
+        __builtin_amdgcn_s_barrier();  // R0: unit g0 has landed
+        stamp();  // 1
+        fill_unit(1);
+        v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
+        first = false;
+        chain(ks, acc0, acc1, pvo, pcolb, Cold{}, [&](auto kc) __attribute__((always_inline)) {
+          load_fragments(kc, std::integral_constant<int, decltype(kc)::value + 1>{});
+        });
+      } else {
+        load_fragments(C0{}, C32{});
+        chain(ks, acc0, acc1, pvo, pcolb, Warm{}, nofrag);
+      }
+      pvo = unit_vo(cu, pcolb);
+      ++ks;
+      int i = 1;
+      for (; i + 1 < cnt; i += 2) {
+        chain(ks, acc1, acc0, pvo, pcolb, Warm{}, nofrag);
+        pvo = unit_vo(cu + i, pcolb);
+        chain(ks + 1, acc0, acc1, pvo, pcolb, Warm{}, nofrag);
+        pvo = unit_vo(cu + i + 1, pcolb);
+        ks += 2;
+      }
+      if (i < cnt) {
+        chain(ks, acc1, acc0, pvo, pcolb, Warm{}, nofrag);
+        pvo = unit_vo(cu + i, pcolb);
+        ++ks;
+        v4_static_for<0, NST>([&](auto qc) __attribute__((always_inline)) { store_q(acc1, qc, pvo, pcolb); });
+      } else {
+        v4_static_for<0, NST>([&](auto qc) __attribute__((always_inline)) { store_q(acc0, qc, pvo, pcolb); });
+      }
+      g += cnt;
+      cu = 0;
+      ++pair;
+    }
+    // The look-ahead reads behind the last unit return into bq[] whenever the LDS gets to them.  Nobody uses what they
+    // return -- which is exactly why the registers must be kept: to the compiler an asm output is there at once and a
+    // dead one is free at once (pairs_bf16_v7_kernel lost stores that way).  The empty asm "uses" them AFTER the wait.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4]), "v"(bq[5]), "v"(bq[6]), "v"(bq[7]));
+    stamp_at(34);  // last store issued
+  }
+  // the NEXT group's query fragments: a slice per workgroup, behind its last unit
+  if (a.nx.qf != nullptr)
+    v4_build_queries<SCORER, HH, SPLIT>(a.nx, (long long)blockIdx.x * 512 + threadIdx.x, (long long)gridDim.x * 512);
+}
+
+void v6_set_stamps(unsigned long long* p);
+unsigned long long* v6_get_stamps();
+
+static int v8_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) {
+    const int c = cache[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) cache[dev].store(v, std::memory_order_relaxed);
+  return v;
+}
+
+template <int SCORER, int SPLIT>
+static int launch_v8(V8Args& a, int sc1, hipStream_t st) {
+  int cus = v8_cu_count();
+  (void)cus;
+  const dim3 grid(8 * a.wpx), block(512);
+  // cache policy of the score stores: 0 plain (write-back: the lines stay in the XCD's L2), 16 sc1 (write-through, the
+  // line leaves the L2), 2 nt, 18 sc1 nt
+  if (sc1 == 1)
+    hipLaunchKernelGGL((pairs_bf16_v8_kernel<SCORER, SPLIT, 16>), grid, block, 0, st, a);
+  else if (sc1 == 2)
+    hipLaunchKernelGGL((pairs_bf16_v8_kernel<SCORER, SPLIT, 2>), grid, block, 0, st, a);
+  else if (sc1 == 3)
+    hipLaunchKernelGGL((pairs_bf16_v8_kernel<SCORER, SPLIT, 18>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((pairs_bf16_v8_kernel<SCORER, SPLIT, 0>), grid, block, 0, st, a);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// Scores of `nbatch` prepared batches (fragments of batch l at qf + l * q_stride_bytes, n rows per side each) against
+// the identity-indexed bf16 table TG (d = 512, all rows or a contiguous slice) into out + l * out_stride (floats).
+// nx.qf != NULL: the launch also builds the fragments nx describes (the next group).  KGE_ERR_UNSUPPORTED: not this
+// kernel's case (the caller takes pairs_bf16_v6 / v4).  KGE_V8=0 declines everything (A/B measurements).
+int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided, int d, long long n, long long m,
+                      int nbatch, const void* qf, long long q_stride_bytes, float* out, long long out_stride,
+                      long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg, const NextQ& nx,
+                      int reserve_cus) {
+  if (d != 512 || TG.idx.ptr != nullptr || qf == nullptr || nbatch < 1) return KGE_ERR_UNSUPPORTED;
+  // A single batch stays with pairs_bf16_v7 / v6 (a workgroup of this kernel loads the fragments of 256 rows before
+  // its first chain -- 9-12 k cycles against 5 k there -- and a single batch's list gives it 7 units to amortise them
+  // over: FB15k-237 shape two-sided 22.0 us against 19.2, profiles/r4_v8_probe.txt); KGE_V8=1 takes it here too.
+  const char* e = getenv("KGE_V8");
+  if (e && e[0] == '0') return KGE_ERR_UNSUPPORTED;
+  if (nbatch == 1 && !(e && e[0] == '1')) return KGE_ERR_UNSUPPORTED;
+  if (TG.ld * 2 >= (1LL << 28) || ldo >= (1LL << 24)) return KGE_ERR_UNSUPPORTED;
+  if ((q_stride_bytes & 15) || ((uintptr_t)qf & 15)) return KGE_ERR_INVALID_ARG;
+  const long long rgr = split ? 64 : 128;  // real rows per fragment group
+  const long long rgn1 = (n + rgr - 1) / rgr;
+  const long long pairs = (long long)nbatch * (two_sided ? 2 : 1) * ((rgn1 + 1) / 2);
+  const long long nunits = (m + V8_UT - 1) / V8_UT;
+  if (rgn1 > (1 << 20) || pairs * nunits >= (1LL << 30)) return KGE_ERR_UNSUPPORTED;
+  int cus = v8_cu_count() - reserve_cus;
+  if (cus > 256) cus = 256;
+  if (cus < 8) cus = 8;
+  V8Args a{};
+  a.TG = TG;
+  a.n = n;
+  a.m = m;
+  a.rgn1 = (int)rgn1;
+  a.sides = two_sided ? 2 : 1;
+  a.chunks = (int)((rgn1 + 1) / 2);
+  a.nbatch = nbatch;
+  a.q_stride = q_stride_bytes / 16;
+  a.out_stride = out_stride;
+  a.out2_off = out2_off;
+  a.ldo = ldo;
+  a.nunits = (int)nunits;
+  a.su = (int)((nunits + 7) / 8);
+  a.wpx = cus / 8;
+  a.out = out;
+  a.qf = (const u32x4*)qf;
+  a.dbg = dbg != nullptr ? dbg : v6_get_stamps();
+  a.nx = nx;
+  // write-through (sc1) stores only for sector-aligned rows and score blocks that fit the Infinity Cache comfortably:
+  // tools/r4_diag.py -- a rotation of buffers beyond it runs faster through the L2's write-back
+  const char* sc1e = getenv("KGE_V4_STORE_SC1");
+  const bool st_aligned = (ldo & 7) == 0 && (out2_off & 7) == 0 && (out_stride & 7) == 0 && ((uintptr_t)out & 31) == 0;
+  const double bytes = (double)nbatch * (double)n * (double)m * 4.0 * (two_sided ? 2 : 1);
+  // (tools/v8_policy_probe.py, profiles/r4_v8_policy.txt: a group's blocks beyond ~160 MB stream to HBM -- `nt` keeps
+  // them from evicting the table slice from the L2: 22.0 -> 14.7 us per two-sided batch in a group of eight; up to
+  // ~48 MB write-through wins by the end-of-kernel write-back it saves; in between it makes no difference)
+  const int sc1 = sc1e ? (sc1e[0] - '0') : (bytes > 160e6 ? 2 : ((st_aligned && bytes <= 48e6) ? 1 : 0));
+#define KGE_V8L(SC) return split ? launch_v8<SC, 1>(a, sc1, st) : launch_v8<SC, 0>(a, sc1, st)
+  if (scorer == KGE_COMPLEX) { KGE_V8L(KGE_COMPLEX); }
+  if (scorer == KGE_DISTMULT) { KGE_V8L(KGE_DISTMULT); }
+#undef KGE_V8L
+  return KGE_ERR_UNSUPPORTED;
+}
+
+#undef KGE_V8_DMA
+}  // namespace kge

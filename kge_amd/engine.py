@@ -85,7 +85,7 @@ def _workspace(tc, n, device, enable=True, stream=None):
     Stream-ordered reuse: one buffer per stream, grown on demand through torch's allocator."""
     if not enable:
         return None, 0
-    nk = (tc.dtype, tc.scorer, tc.dim, n)
+    nk = (tc.dtype, tc.scorer, tc.dim, n, tc.flags & FLAG_SPLIT_QUERY)  # (split queries: about twice the bytes)
     need = _WS_NEED.get(nk)
     if need is None:
         need = _WS_NEED[nk] = _lib.lib().kge_score_workspace_bytes(ctypes.byref(tc), n)
@@ -328,6 +328,39 @@ def build_queries(t: Tables, combine: str, s, p=None, o=None, flags=None, out: Q
     return q
 
 
+def _check_score_out(t, out, n, m, combine, what):
+    """(ldo, block2_offset) of a caller's score buffer after checking it is one the kernels may write through its
+    raw pointer: float32, on the tables' GPU, `[n, m]` / `[n, 2m]` with unit inner stride, or -- both blocks of
+    "sp_po" on their own aligned columns -- `[n, 2, m]` with stride (ldo, block2_offset, 1)."""
+    _require_gpu(out, "score buffer")
+    if out.device != t.device:
+        raise ValueError(f"kge_amd: {what}: `out` is on {out.device}, the tables on {t.device}")
+    if out.dtype != torch.float32:
+        raise ValueError(f"kge_amd: {what}: `out` must be float32, got {out.dtype}")
+    width = 2 * m if combine == "sp_po" else m
+    b2 = 0
+    if out.dim() == 3:
+        if combine != "sp_po" or tuple(out.shape) != (n, 2, m) or (m > 1 and out.stride(2) != 1):
+            raise ValueError(f"kge_amd: {what}: a 3-D `out` is [n, 2, m] with unit inner stride for combine 'sp_po'")
+        b2 = out.stride(1)
+        if b2 < m:
+            raise ValueError(f"kge_amd: {what}: the two blocks of `out` overlap")
+        need = b2 + m
+    elif out.dim() == 2:
+        if tuple(out.shape) != (n, width) or (width > 1 and out.stride(1) != 1):
+            raise ValueError(f"kge_amd: {what}: `out` must be [{n}, {width}] with unit inner stride, "
+                             f"got {tuple(out.shape)} strides {out.stride()}")
+        need = width
+    else:
+        raise ValueError(f"kge_amd: {what}: `out` must be 2-D (or [n, 2, m])")
+    ldo = out.stride(0)
+    if n == 1:
+        ldo = max(ldo, need)
+    if ldo < need:
+        raise ValueError(f"kge_amd: {what}: the rows of `out` overlap (row stride {ldo} < {need})")
+    return ldo, b2
+
+
 def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None, next_queries: Queries = None,
                   stream=None):
     """[n, m] ("sp_", "_po") or [n, 2m] ("sp_po") scores of the prepared batch `q` against all / the listed
@@ -341,17 +374,11 @@ def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None
     width = 2 * m if q.combine == "sp_po" else m
     if out is None:
         out = _empty((q.n, width), t.device)
-    # `out` may be any row-pitched view: [n, m] / [n, 2m] with stride (ldo, 1), or -- both blocks on their own
-    # aligned columns -- [n, 2, m] with stride (ldo, block2_offset, 1)
-    ldo, b2 = out.stride(0), 0
-    if out.dim() == 3:
-        if q.combine != "sp_po" or out.shape[1] != 2 or out.stride(2) != 1:
-            raise ValueError("kge_amd: score_queries: a 3-D `out` is [n, 2, m] for combine 'sp_po'")
-        b2 = out.stride(1)
-    if q.n == 1:
-        ldo = max(ldo, width if b2 == 0 else b2 + m)
+    ldo, b2 = _check_score_out(t, out, q.n, m, q.combine, "score_queries")
     nxt = None
     if next_batch is not None:
+        if next_queries is None:
+            raise ValueError("kge_amd: score_queries: next_batch needs next_queries (the buffer its queries go to)")
         nkeep = []
         if torch.is_tensor(next_batch):  # [n, 3] triples: one allocation, three strided index vectors
             si, pi, oi, nn = _index3(next_batch, t.device, nkeep)
@@ -369,6 +396,90 @@ def score_queries(t: Tables, q: Queries, targets=None, out=None, next_batch=None
                                           _stream_handle(t.device) if stream is None else stream)
         if rc:
             _lib.check(rc, "kge_score_queries")
+    return out
+
+
+class QueriesGroup:
+    """The prepared query vectors of a GROUP of `num_batches` equally shaped batches (kge_build_queries_multi): batch l
+    of the group at byte offset l * stride of one device buffer."""
+
+    __slots__ = ("buf", "combine", "n", "num_batches", "stride", "flags")
+
+    def __init__(self, t: Tables, combine: str, n: int, num_batches: int, flags=None):
+        tc = t.c(flags)
+        per = _lib.lib().kge_queries_bytes(ctypes.byref(tc), _COMBINE[combine], n)
+        if per <= 0:
+            raise RuntimeError("kge_amd: prepared queries need bf16 ComplEx / DistMult tables of dim 256 / 512")
+        self.stride = (per + 255) // 256 * 256
+        self.buf = _empty((self.stride * num_batches,), t.device, torch.uint8)
+        self.combine, self.n, self.num_batches, self.flags = combine, n, num_batches, flags
+
+
+def _group_index(batch, n, num_batches, device, keep, what):
+    """(s, p, o) index vectors of num_batches * n entries, or one [num_batches * n, 3] triples tensor."""
+    if torch.is_tensor(batch):
+        si, pi, oi, nn = _index3(batch, device, keep)
+    else:
+        k0 = len(keep)
+        si, pi, oi = (_index(x, device, keep) for x in batch)
+        nn = _same_len(keep[k0:], what)
+    if nn != n * num_batches:
+        raise ValueError(f"kge_amd: {what}: a group of {num_batches} batches of {n} rows needs {n * num_batches} "
+                         f"index entries, got {nn}")
+    return si, pi, oi
+
+
+def build_queries_group(t: Tables, combine: str, batch, n: int, num_batches: int, flags=None, out: QueriesGroup = None,
+                        stream=None) -> QueriesGroup:
+    """Query vectors of `num_batches` batches of `n` rows in one launch: batch l = rows [l n, (l + 1) n) of the index
+    vectors `batch` = (s, p, o) (or one [num_batches n, 3] triples tensor)."""
+    keep = []
+    si, pi, oi = _group_index(batch, n, num_batches, t.device, keep, "build_queries_group")
+    q = out if out is not None else QueriesGroup(t, combine, n, num_batches, flags)
+    if q.n != n or q.num_batches != num_batches or q.combine != combine:
+        raise ValueError("kge_amd: build_queries_group: the QueriesGroup buffer was sized for another shape")
+    with _on_device(t.device):
+        tc = t.c(q.flags)
+        rc = _lib.lib().kge_build_queries_multi(ctypes.byref(tc), _COMBINE[combine], si, pi, oi, n, num_batches,
+                                                q.buf.data_ptr(), q.stride, q.buf.numel(),
+                                                _stream_handle(t.device) if stream is None else stream)
+        if rc:
+            _lib.check(rc, "kge_build_queries_multi")
+    return q
+
+
+def score_pitch_group(n: int, m: int, combine: str = "sp_po"):
+    """(row pitch, batch stride) in floats of a group's score buffer on the pitch `score_pitch` recommends."""
+    pitch = score_pitch(m) * (2 if combine == "sp_po" else 1)
+    return pitch, n * pitch
+
+
+def score_queries_group(t: Tables, q: QueriesGroup, out: torch.Tensor, next_batch=None, next_queries: QueriesGroup = None,
+                        stream=None):
+    """Scores of a whole group in ONE persistent launch (kge_score_queries_multi): out[l] receives what
+    score_queries writes for batch l -- `out` is [L, n, m] / [L, n, 2m] (any row pitch, unit inner stride) or
+    [L, n, 2, m].  next_batch + next_queries: the NEXT group's query vectors are built by the same launch."""
+    m = t.num_ent
+    L, n = q.num_batches, q.n
+    if out.dim() < 3 or out.shape[0] != L:
+        raise ValueError(f"kge_amd: score_queries_group: `out` is [{L}, n, ...], one block per batch")
+    ldo, b2 = _check_score_out(t, out[0], n, m, q.combine, "score_queries_group")
+    ostride = out.stride(0) if L > 1 else 0
+    nxt, keep = None, []
+    if next_batch is not None:
+        if next_queries is None or next_queries.num_batches != L or next_queries.combine != q.combine or \
+                next_queries.flags != q.flags:
+            raise ValueError("kge_amd: score_queries_group: next_queries does not match the next group")
+        si, pi, oi = _group_index(next_batch, next_queries.n, L, t.device, keep, "score_queries_group(next_batch)")
+        nxt = KgeNextQueries(si, pi, oi, next_queries.n, next_queries.buf.data_ptr(), next_queries.buf.numel())
+    with _on_device(t.device):
+        tc = t.c(q.flags)
+        rc = _lib.lib().kge_score_queries_multi(
+            ctypes.byref(tc), _COMBINE[q.combine], q.buf.data_ptr(), q.stride, n, L, KgeIndex(None, I64, 0, 1), m,
+            out.data_ptr(), ostride, ldo, b2, ctypes.byref(nxt) if nxt is not None else None,
+            next_queries.stride if nxt is not None else 0, _stream_handle(t.device) if stream is None else stream)
+        if rc:
+            _lib.check(rc, "kge_score_queries_multi")
     return out
 
 

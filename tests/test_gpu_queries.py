@@ -254,3 +254,132 @@ def test_split_queries_at_the_fb15k_shape_keep_the_ranks(eng):
     # strict ranks, no tie band: a neighbour within the ~1e-6 summation noise flips a rank in a few % of the rows
     assert moved_split <= 40 and moved_split * 5 < max(moved_one, 1)
     assert err_split < 4e-6 * max(1.0, float(y.abs().max())) and err_split * 30 < err_one
+
+
+# ---- groups of batches in one persistent launch (kge_score_queries_multi, score_pairs_bf16_v8.hip) -------------------
+def _group_scores_one_by_one(eng, T, combine, trip, n, L, flags=None):
+    want = []
+    for l in range(L):
+        t = trip[l * n:(l + 1) * n]
+        q = eng.build_queries(T, combine, t[:, 0] if combine != "_po" else None, t[:, 1],
+                              t[:, 2] if combine != "sp_" else None, flags=flags)
+        want.append(eng.score_queries(T, q))
+    return want
+
+
+@pytest.mark.parametrize("scorer,combine,n,L,E", [
+    ("complex", "sp_po", 512, 8, 14541),   # the bench group: 32 pairs, one per workgroup of an XCD
+    ("complex", "sp_", 512, 3, 14541),     # pairs split between workgroups, ranges crossing pair boundaries
+    ("distmult", "sp_po", 100, 5, 4099),   # one fragment group per side (the second half of every workgroup idle)
+    ("complex", "_po", 300, 2, 2111),      # ragged rows, ragged last unit, slices of 8-9 units
+    ("complex", "sp_po", 1, 4, 777),       # single rows
+    ("complex", "sp_po", 640, 1, 14541),   # a group of one = kge_score_queries
+])
+def test_group_launch_equals_one_launch_per_batch(eng, scorer, combine, n, L, E, monkeypatch):
+    R, d = 11, 512
+    T, _, _ = _tables(eng, scorer, E, R, d, 60 + n)
+    trip = torch.stack(_batch(E, R, n * L, 61 + L), dim=1).contiguous()
+    monkeypatch.setenv("KGE_V8", "0")      # the reference: one launch per batch on the round-3 kernels
+    want = _group_scores_one_by_one(eng, T, combine, trip, n, L)
+    monkeypatch.delenv("KGE_V8")
+    sides = 2 if combine == "sp_po" else 1
+    P = eng.score_pitch(E)
+    guard = 3
+    big = torch.full((L, n + guard, sides * P), float("nan"), device=DEV)
+    out = big[:, :n].view(L, n, sides, P)[:, :, :, :E] if sides == 2 else big[:, :n, :E]
+    q = eng.build_queries_group(T, combine, trip, n, L)
+    eng.score_queries_group(T, q, out)
+    torch.cuda.synchronize()
+    for l in range(L):
+        _same(out[l].reshape(n, -1), want[l], f"{scorer} {combine} n={n} batch {l}/{L}")
+    assert int((~torch.isnan(big)).sum()) == L * n * sides * E   # nothing outside the L x sides blocks
+    # contiguous blocks (the reference's cat layout, 4-byte alignment only)
+    flat = torch.full((L, n, sides * E), float("nan"), device=DEV)
+    eng.score_queries_group(T, q, flat)
+    for l in range(L):
+        _same(flat[l], want[l], f"contiguous {combine} batch {l}")
+
+
+@pytest.mark.parametrize("n,L", [(512, 4), (200, 3), (64, 2)])
+def test_group_launch_with_split_queries(eng, n, L, monkeypatch):
+    E, R, d = 14541, 7, 512
+    fl = eng.FLAG_SPLIT_QUERY
+    T, _, _ = _tables(eng, "complex", E, R, d, 70 + n, flags=fl)
+    trip = torch.stack(_batch(E, R, n * L, 71), dim=1).contiguous()
+    monkeypatch.setenv("KGE_V8", "0")      # pairs_bf16_v6_kernel<SPLIT>: the staged kernel, one launch per batch
+    want = _group_scores_one_by_one(eng, T, "sp_po", trip, n, L, flags=fl)
+    monkeypatch.delenv("KGE_V8")
+    P = eng.score_pitch(E)
+    big = torch.full((L, n, 2 * P), float("nan"), device=DEV)
+    out = big.view(L, n, 2, P)[:, :, :, :E]
+    q = eng.build_queries_group(T, "sp_po", trip, n, L, flags=fl)
+    eng.score_queries_group(T, q, out)
+    for l in range(L):
+        _same(out[l].reshape(n, -1), want[l], f"split n={n} batch {l}/{L}")
+    assert int((~torch.isnan(big)).sum()) == L * n * 2 * E
+
+
+def test_next_group_is_built_inside_the_launch(eng):
+    """Three groups of four batches: group k + 1's query vectors are built by group k's launch (behind every
+    workgroup's last unit)."""
+    E, R, d, n, L = 14541, 237, 512, 256, 4
+    T, _, _ = _tables(eng, "complex", E, R, d, 80)
+    groups = [torch.stack(_batch(E, R, n * L, 81 + k), dim=1).contiguous() for k in range(3)]
+    qs = [eng.QueriesGroup(T, "sp_po", n, L), eng.QueriesGroup(T, "sp_po", n, L)]
+    eng.build_queries_group(T, "sp_po", groups[0], n, L, out=qs[0])
+    out = torch.empty(L, n, 2 * E, device=DEV)
+    for k in range(3):
+        nxt = groups[k + 1] if k < 2 else None
+        eng.score_queries_group(T, qs[k & 1], out, next_batch=nxt, next_queries=qs[(k + 1) & 1] if nxt is not None else None)
+        want = _group_scores_one_by_one(eng, T, "sp_po", groups[k], n, L)
+        for l in range(L):
+            _same(out[l], want[l], f"group {k} batch {l}")
+
+
+def test_group_arguments_are_checked(eng):
+    E, R, d, n, L = 1000, 5, 512, 64, 2
+    T, _, _ = _tables(eng, "complex", E, R, d, 90)
+    trip = torch.stack(_batch(E, R, n * L, 91), dim=1).contiguous()
+    q = eng.build_queries_group(T, "sp_po", trip, n, L)
+    with pytest.raises(ValueError):
+        eng.build_queries_group(T, "sp_po", trip[:n], n, L)                       # one batch of rows for a group of two
+    with pytest.raises(ValueError):
+        eng.score_queries_group(T, q, torch.empty(L, n, 2 * E, device=DEV, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        eng.score_queries_group(T, q, torch.empty(L, n, 2 * E - 1, device=DEV))  # too narrow
+    with pytest.raises(ValueError):
+        eng.score_queries_group(T, q, torch.empty(L, 2 * E, n, device=DEV).transpose(1, 2))  # transposed view
+    with pytest.raises(ValueError):
+        eng.score_queries(T, eng.build_queries(T, "sp_", trip[:n, 0], trip[:n, 1], None),
+                          out=torch.empty(n, E, device=DEV).bfloat16())
+    with pytest.raises(ValueError):
+        eng.score_queries(T, eng.build_queries(T, "sp_", trip[:n, 0], trip[:n, 1], None),
+                          next_batch=(trip[:n, 0], trip[:n, 1], None))           # next_batch without next_queries
+
+
+@pytest.mark.parametrize("E,n,split", [(2111, 1, 0), (2111, 63, 0), (4099, 300, 1), (14541, 512, 0), (14541, 640, 1), (130, 700, 0)])
+def test_persistent_kernel_on_single_batches(eng, E, n, split, monkeypatch):
+    """KGE_V8=1: a single batch through pairs_bf16_v8_kernel (its default is groups of two or more) = the round-3
+    kernels bit for bit, one- and two-sided, contiguous and pitched rows, nothing written outside the blocks."""
+    R, d = 7, 512
+    fl = eng.FLAG_SPLIT_QUERY if split else None
+    T, _, _ = _tables(eng, "distmult" if split else "complex", E, R, d, E + n, flags=fl or 0)
+    s, p, o = _batch(E, R, n, 3)
+    P = eng.score_pitch(E)
+    for combine, sides in (("sp_", 1), ("sp_po", 2)):
+        q = eng.build_queries(T, combine, s, p, o if sides == 2 else None, flags=fl)
+        for pitched in (False, True):
+            got = {}
+            for v8 in ("0", "1"):
+                monkeypatch.setenv("KGE_V8", v8)
+                guard = 5
+                ld = sides * P if pitched else sides * E + 13
+                big = torch.full((n + 2 * guard, ld), float("nan"), device=DEV)
+                rows = big[guard:guard + n]
+                out = (rows.view(n, 2, P)[:, :, :E] if sides == 2 else rows[:, :E]) if pitched else rows[:, 5:5 + sides * E]
+                eng.score_queries(T, q, out=out)
+                torch.cuda.synchronize()
+                got[v8] = out.reshape(n, -1).clone()
+                assert int((~torch.isnan(big)).sum()) == n * sides * E, (combine, pitched, v8)
+            _same(got["1"], got["0"], f"{combine} pitched={pitched} E={E} n={n} split={split}")
+    monkeypatch.delenv("KGE_V8")
