@@ -55,9 +55,11 @@ def parse():
                     help="skip the reference region of one-sided launches (profiling runs: the kernel "
                          "trace then holds two-sided launches only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--group", type=int, default=8,
+                    help="N = 1: batches per persistent launch (kge_score_queries_multi); 1 = one launch per batch")
     ap.add_argument("--streams", type=int, default=None,
-                    help="batches in flight in the timed region: batch k is launched on HIP stream k %% streams "
-                         "(default 2; the sharded step with ONE rank: 1 -- it is bound by the host issuing it)")
+                    help="N > 1: batches in flight in the sharded step (batch k's exchange and scoring on HIP stream "
+                         "k %% streams; default: 2 with the step as a hipGraph where that has checked out, else 1)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region of K steps is run this many times; the median region is reported")
     ap.add_argument("--shape", choices=["wikidata5m", "fb15k"], default="wikidata5m",
@@ -403,6 +405,8 @@ def main_sharded(a, world, rank, device):
     from kge_amd import engine
     from kge_amd.sharded import ShardedScoreLanes
     td.init_process_group("nccl", device_id=device)
+    if td.get_world_size() != world or (a.gpus != world and os.environ.get("KGE_BENCH_FORCE_DIST") != "1"):
+        raise SystemExit(f"bench: RCCL reports {td.get_world_size()} ranks, --gpus {a.gpus}, WORLD_SIZE {world}")
     n = a.batch
 
     def sync():
@@ -427,7 +431,7 @@ def main_sharded(a, world, rank, device):
         # only with the step captured into a hipGraph (call by call the step is bound by the host: 60 -> 84 us with
         # two lanes, 60 -> 47 us with two lanes + graph, one rank); the capture of a multi-rank RCCL all-gather has
         # not run on this code, so N > 1 takes it only when asked (--streams 2 with KGE_SHARDED_GRAPH=1).
-        lanes = ShardedScoreLanes(sh, 1 if big_slab else max(1, a.streams if a.streams is not None else 1))
+        lanes = ShardedScoreLanes(sh, 1 if big_slab else max(1, a.streams if a.streams is not None else 2))
         tri3 = torch.stack([s.long(), p.long(), o.long()], 1).contiguous()
 
         def run_steps(k, lanes=lanes, tri3=tri3):
@@ -438,7 +442,18 @@ def main_sharded(a, world, rank, device):
                     lanes.join()  # the consumer's wait; the slabs of the two batches are released here
             lanes.join()
 
-        run_steps(a.warmup)
+        run_steps(max(a.warmup, 2 * lanes.L))  # (the first step of a lane captures its hipGraph and checks it)
+        if lanes.L > 1 and not lanes.use_graph and a.streams is None:
+            # the capture did not pass its self-check (ShardedScoreLanes warned): two lanes call by call are bound by
+            # the host (86 against 63 us per step, one rank) -- one batch at a time then
+            if rank == 0:
+                print(f"bench: sharded step not captured ({lanes.graph_error}); one batch at a time", file=sys.stderr)
+            lanes = ShardedScoreLanes(sh, 1, graph=False)
+
+            def run_steps(k, lanes=lanes, tri3=tri3):
+                for _ in range(k):
+                    lanes.score_sp_po_blocks(tri3)
+            run_steps(a.warmup)
         el, regions, host = timed_regions(run_steps, sync, a.steps, a.repeats, reduce_max)
         # the scoring launch alone, on rows already exchanged (HIP events on the launch stream)
         rows, rel_rows = sh.exchange_rows([s, o], p)
@@ -511,8 +526,10 @@ def main_sharded(a, world, rank, device):
                 "parallelism": f"entity-shard x{world} (kge_amd.sharded.ShardedEntityTable)",
                 "exchange": "kge_embed gather -> ONE all_gather_into_tensor (RCCL) -> kge_embed pick, per step",
             },
-            "roofline": {"bound": "hbm", "kernel": "pairs_bf16_v4_kernel on this rank's shard (score_sp + score_po "
-                                                   "launches of one step together)",
+            "rccl_ranks": td.get_world_size(),
+            "roofline": {"bound": "hbm", "kernel": "the scoring launch(es) of one step on this rank's shard after the "
+                                                   "exchange (kge_score_emb_sp_po: pairs_bf16_v4_kernel, two-sided; "
+                                                   "slabs beyond the Infinity Cache: one one-sided launch per direction)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
                          "avg_launch_us": r["scoring_launch_ms"] * 1e3, "traffic": None},
@@ -526,11 +543,74 @@ def main_sharded(a, world, rank, device):
     td.destroy_process_group()
 
 
+def train_leg(device, n, steps):
+    """One whole 1vsAll TRAINING step at the bench shape (kge/job/train_1vsAll.py:48-82 + train.py:471-474): the fused
+    cross-entropy forward of both directions (no score matrix), its backward (d loss / d score recomputed in the
+    scoring kernel, two gradient products) and a one-pass Adagrad step over both tables -- kge_amd.model.loss_sp_po +
+    kge_amd.optim.Adagrad, the path `train.type: hip_1vsAll` drives.  bf16 scoring copies of float32 master tables
+    (mixed precision) and float32 scoring.  Wall clock over `steps` steps, synchronised at both ends."""
+    from kge_amd import model as km, optim as kopt
+    out = {"batch": n, "num_entities": E_FB, "dim": DIM, "loss": "kl (1vsAll cross entropy, both directions)",
+           "optimizer": "Adagrad (one pass: kge_adagrad_step)"}
+    q = torch.Generator().manual_seed(3)
+    s, p, o = (torch.randint(hi, (n,), generator=q).to(device) for hi in (E_FB, R_FB, E_FB))
+    for tag, sd in (("bf16_scoring", torch.bfloat16), ("f32_scoring", torch.float32)):
+        torch.manual_seed(0)
+        m = km.create("complex", E_FB, R_FB, DIM, device=device, score_dtype=sd)
+        opt = kopt.Adagrad(m.parameters(), lr=0.1, bf16_copies=(sd == torch.bfloat16))
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            m.loss_sp_po(s, p, o).sum().backward()
+            opt.step()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        # forward alone (the scoring launch with the loss epilogue), HIP events
+        with torch.no_grad():
+            f_ms = event_avg_ms(lambda: m.loss_sp_po(s, p, o), max(10, steps))
+        flops = 3 * 2.0 * 2.0 * n * DIM * E_FB  # forward + two gradient products, both directions
+        peak = BF16_MFMA_PEAK_TF if sd == torch.bfloat16 else F32_MFMA_PEAK_TF
+        out[tag] = {"ms_per_step": ms, "forward_ms": f_ms, "scored_triples_per_s": 2.0 * n * E_FB / (ms * 1e-3),
+                    "flops_per_step": flops, "achieved_tflops": flops / (ms * 1e-3) / 1e12,
+                    "frac_of_mfma_peak": flops / (ms * 1e-3) / 1e12 / peak}
+        del m, opt
+        torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node
+    (the contract's own command line), so that the line never reports n_gpus = 1 for a request of N."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, KGE_BENCH_SPAWNED="1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    launched = "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not launched:
+        if os.environ.get("KGE_BENCH_SPAWNED") == "1":
+            raise SystemExit("bench: re-executed under torch.distributed.run but WORLD_SIZE is not set")
+        raise SystemExit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and not (world == 1 and os.environ.get("KGE_BENCH_FORCE_DIST") == "1"):
+        raise SystemExit(f"bench: --gpus {a.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to "
+                         f"report a line for another world size")
+    if os.environ.get("KGE_BENCH_DEVICE_CHECK") == "1":  # tests (no GPU): everything up to the device selection
+        print(json.dumps({"rank": rank, "local_rank": local, "world_size": world, "gpus": a.gpus}), flush=True)
+        return
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # KGE_BENCH_FORCE_DIST=1: exercise the sharded step (RCCL init + all-gather) with one rank
@@ -540,176 +620,183 @@ def main():
     from kge_amd import engine
 
     n = a.batch
+    L = max(1, a.group)
     ent, rel, s, p, o = make_inputs(rank, device, n)
-    T = engine.Tables("complex", ent, rel)
-    # Batches are known ahead in every caller of this path (a DataLoader over the split: eval_entity_ranking.py:158-170,
-    # train_1vsAll.py:31-41), so the loop is issued the way such a caller issues it: kge_score_queries scores batch k
-    # from its prepared query vectors while idle workgroups of the SAME launch build batch k + 1's (include/kge_amd.h,
-    # "prepared queries"): one launch per step, all of a step's work inside the timed region (the step that scores
-    # batch k builds batch k + 1's queries; the queries of the very first batch are built by the warm-up).  Two
-    # different batches alternate, so no launch ever reads queries that were not built by the launch before it.
-    q2 = torch.Generator().manual_seed(2)
-    batch_b = tuple(torch.randint(hi, (n,), generator=q2).to(device) for hi in (E_FB, R_FB, E_FB))
-    batches = [(s, p, o), batch_b]
-    tri = [torch.stack(b, 1).contiguous() for b in batches]  # the reference's batch["triples"]: [n, 3], columns s, p, o
-    # Score rows on a 256-byte pitch (the C ABI's `ldo`: 2 x 14,656 floats per row, the two blocks at column 0 and
-    # 14,656; engine.score_pitch): every 16-byte store of the kernel then covers whole 32-byte sectors.  The reference's contiguous
-    # [n, 2E] layout (rows at 4-byte granularity) is measured beside it (`contiguous_pitch`).
     PITCH = engine.score_pitch(E_FB)  # 14,656 floats: whole 256-byte lines, an odd number of them per row
-    out_pad = torch.empty(n, 2 * PITCH, device=device)
-    out_buf = out_pad.view(n, 2, PITCH)[:, :, :E_FB]          # [n, 2, E] view: block b of row i at i*2*PITCH + b*PITCH
-    out_contig = torch.empty(n, 2 * E_FB, device=device)
-    pipe = engine.ScorePipeline(T, "sp_po", n)
-    pipe.start(*batches[0])
-    step_no = [0]
+    ab = algorithmic_bytes(n, E_FB, DIM, sides=2)  # per batch: table once + both sides' query rows, scores, indices
 
-    def one_step():  # KgeModel.score_sp_po of the current batch: both score blocks, one launch
-        step_no[0] += 1
-        pipe.step(next_batch=tri[step_no[0] & 1], out=out_buf)
+    # Batches are known ahead in every caller of this path (a DataLoader over the split: eval_entity_ranking.py:158-170,
+    # train_1vsAll.py:31-41), so the loop is issued the way such a caller can issue it: GROUPS of `--group` batches, one
+    # persistent launch per group (kge_score_queries_multi, pairs_bf16_v8_kernel: the table streams through every
+    # compute unit once per batch; cold start, launch gap and the compute units a single batch's grid cannot fill are
+    # paid once per group), which also builds the NEXT group's query vectors behind its last unit.  One STEP = one batch
+    # = KgeModel.score_sp_po of that batch (both score blocks); K steps = K batches in ceil(K / group) launches (a
+    # remainder of K % group batches goes as one smaller group), all of a step's work inside the timed region.
+    # Score rows on a 256-byte pitch (the C ABI's `ldo`; engine.score_pitch), the po block on a column of its own.
+    class Mode:
+        def __init__(self, flags, tag):
+            self.tag, self.flags = tag, flags
+            self.T = engine.Tables("complex", ent, rel, flags=flags or 0)
+            self.by_size = {}
 
-    # The timed steps: the same launch per batch, batches alternating between `a.streams` HIP streams (lanes), each
-    # with its own score buffer and its own pair of query buffers (a lane's launch builds the queries of that lane's
-    # next batch).  A scoring launch leaves compute units idle at both ends (launch gap, cold first tiles, the last
-    # stores' acknowledgements) and 28 of 256 for its whole duration (228 workgroups); the next batch's launch on
-    # the other stream runs there.  Every step is a complete pass over one batch; the region ends with a device-wide
-    # synchronize, so all K batches are fully scored inside it.
-    L = max(1, a.streams if a.streams is not None else 2)
-    pipeL = engine.ScorePipeline(T, "sp_po", n, streams=L) if L > 1 else pipe
-    outs = [out_buf] + [torch.empty(n, 2 * PITCH, device=device).view(n, 2, PITCH)[:, :, :E_FB] for _ in range(L - 1)]
-    if L > 1:
-        pipeL.start([tri[0]] * L)
-    stepL = [0]
+        def group(self, g):
+            st = self.by_size.get(g)
+            if st is None:
+                q = torch.Generator().manual_seed(100 + g)
+                tri = [torch.stack([torch.randint(hi, (n * g,), generator=q) for hi in (E_FB, R_FB, E_FB)], 1).to(device)
+                       for _ in range(2)]
+                qs = [engine.QueriesGroup(self.T, "sp_po", n, g, flags=self.flags) for _ in range(2)]
+                engine.build_queries_group(self.T, "sp_po", tri[0], n, g, out=qs[0])
+                buf = torch.empty(g, n, 2 * PITCH, device=device)
+                st = self.by_size[g] = {"tri": tri, "qs": qs, "buf": buf, "out": buf.view(g, n, 2, PITCH)[:, :, :, :E_FB],
+                                        "cur": 0}
+            return st
 
-    def run_steps(k):
-        c = stepL[0]
-        for _ in range(k):
-            # lane c % L scores its current batch and builds its next one (alternating the two synthetic batches)
-            pipeL.step(next_batch=tri[(c // L + 1) & 1], out=outs[c % L])
-            c += 1
-        stepL[0] = c
+        def launch(self, g):
+            st = self.group(g)
+            c = st["cur"]
+            engine.score_queries_group(self.T, st["qs"][c], st["out"], next_batch=st["tri"][1 - c],
+                                       next_queries=st["qs"][1 - c])
+            st["cur"] = 1 - c
 
-    run_steps(a.warmup)
-    el, regions, host_el = timed_regions(run_steps, torch.cuda.synchronize, a.steps, a.repeats)
-    if L > 1:  # every lane's last batch, bit for bit against the same batch scored alone on the current stream
-        pipeL.join()
-        torch.cuda.synchronize()
-        for lane in range(L):
-            c = max(k for k in range(stepL[0] - L, stepL[0]) if k % L == lane)
-            want = engine.score_queries(T, engine.build_queries(T, "sp_po", *batches[(c // L) & 1]))
-            if not torch.equal(outs[lane], want.view(n, 2, E_FB)):
-                raise SystemExit("bench: lane %d of the two-stream pipeline differs from the single launch" % lane)
+        def run_steps(self, k):
+            while k > 0:
+                g = min(L, k)
+                self.launch(g)
+                k -= g
 
-    # Duration of one scoring call (= one launch of the dominant kernel pairs_bf16_v4_kernel): HIP
-    # events on the launch stream bracketing a region of the same K steps.  Back-to-back calls
-    # pipeline their launch overhead exactly as in the timed region above.
-    avg_ms = event_avg_ms(one_step, a.steps, a.repeats)
-    # the same step through the one-call entry point (kge_score_sp_po: query build inside the launch, cooperatively)
-    for _ in range(5):
-        engine.score_sp_po(T, s, p, o)
-    coop_ms = event_avg_ms(lambda: engine.score_sp_po(T, s, p, o), a.steps, 3)
-    # the reference's contiguous [n, 2E] score layout
-    def contig_step():
-        step_no[0] += 1
-        pipe.step(next_batch=batches[step_no[0] & 1], out=out_contig)
-    for _ in range(5):
-        contig_step()
-    contig_ms = event_avg_ms(contig_step, a.steps, 3)
-    # isolated calls (event pair around every call; includes un-hidden launch latency)
-    ev = []
-    for k in range(min(a.steps, 50)):
-        x0, x1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        x0.record()
-        one_step()
-        x1.record()
-        ev.append((x0, x1))
-    torch.cuda.synchronize()
-    iso = sorted(x0.elapsed_time(x1) for x0, x1 in ev)
+        def check(self):
+            """The last full group, bit for bit against one launch per batch on the round-3 kernels."""
+            st = self.group(L)
+            c = 1 - st["cur"]  # the queries the last launch scored
+            tri = st["tri"][c]
+            torch.cuda.synchronize()
+            for l in (0, L - 1):
+                t = tri[l * n:(l + 1) * n]
+                want = engine.score_queries(self.T, engine.build_queries(self.T, "sp_po", t[:, 0], t[:, 1], t[:, 2],
+                                                                         flags=self.flags))
+                if not torch.equal(st["out"][l].reshape(n, 2 * E_FB), want):
+                    raise SystemExit(f"bench: batch {l} of the {self.tag} group launch differs from the single launch")
 
+    # `value`: the PARITY-COMPLIANT mode -- split queries (KGE_FLAG_SPLIT_QUERY: q = q_hi + q_lo, f32-level parity on the
+    # bf16 tables: ranks equal to float32 arithmetic's up to its own summation noise, tests/test_gpu_bshape_ranks.py).
+    # The single-pass mode (query vector rounded to ONE bf16: training tolerance, 4 % of the ranks move against that
+    # bar) is timed the same way and reported beside it.
+    modes = {"parity": Mode(engine.FLAG_SPLIT_QUERY, "split-query"), "training": Mode(None, "single-pass")}
+    res = {}
+    for key, md in modes.items():
+        md.run_steps(a.warmup)
+        md.run_steps(L)
+        el, regions, host_el = timed_regions(md.run_steps, torch.cuda.synchronize, a.steps, a.repeats)
+        md.run_steps(L)
+        md.check()
+        # the dominant kernel: HIP events on the launch stream around back-to-back full-group launches
+        launches = max(3, (max(a.steps, 40) + L - 1) // L)
+        k_ms = event_avg_ms(lambda: md.launch(L), launches, a.repeats)
+        res[key] = {"el": el, "regions": regions, "host": host_el, "launch_ms": k_ms}
+
+    def roofline_of(key, kernel):
+        r = res[key]
+        ach = L * ab / (r["launch_ms"] * 1e-3) / 1e9
+        flops = 2.0 * 2.0 * n * DIM * E_FB * L * (2 if key == "parity" else 1)  # executed on the matrix cores
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "batches_per_launch": L, "algorithmic_bytes_per_launch": L * ab,
+                "algorithmic_bytes_per_batch": ab, "avg_launch_us": r["launch_ms"] * 1e3,
+                "us_per_batch": r["launch_ms"] * 1e3 / L,
+                # the table counted once per LAUNCH instead of once per batch (SURVEY.md 8d counts it per call)
+                "frac_table_once_per_launch": (L * ab - (L - 1) * E_FB * DIM * 2) / (r["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "mfma_executed_tflops": flops / (r["launch_ms"] * 1e-3) / 1e12,
+                "mfma_executed_frac": flops / (r["launch_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF,
+                "score_row_pitch_floats": 2 * PITCH, "block2_offset_floats": PITCH,
+                "score_bytes_per_launch": L * n * 2 * E_FB * 4}
+
+    total = 2.0 * n * E_FB * a.steps
     extra = {}
     if not a.no_one_sided:
-        # the same step as two one-sided launches (score_sp, then score_po), as TrainingJob1vsAll issues
-        # them (north_star quotes its roofline target on score_sp) ...
+        # ---- one launch per batch (the round-3 step: kge_score_queries, pairs_bf16_v7_kernel, the next batch's queries
+        # built in the same launch), two- and one-sided, and the one-call entry points
+        T = modes["training"].T
+        q2 = torch.Generator().manual_seed(2)
+        batch_b = tuple(torch.randint(hi, (n,), generator=q2).to(device) for hi in (E_FB, R_FB, E_FB))
+        batches = [(s, p, o), batch_b]
+        tri = [torch.stack(b, 1).contiguous() for b in batches]
+        out_pad = torch.empty(n, 2 * PITCH, device=device)
+        out_buf = out_pad.view(n, 2, PITCH)[:, :, :E_FB]
+        pipe = engine.ScorePipeline(T, "sp_po", n)
+        pipe.start(*batches[0])
+        step_no = [0]
+
+        def one_step():
+            step_no[0] += 1
+            pipe.step(next_batch=tri[step_no[0] & 1], out=out_buf)
+        for _ in range(5):
+            one_step()
+        one2_ms = event_avg_ms(one_step, max(a.steps, 40), a.repeats)
+        for _ in range(5):
+            engine.score_sp_po(T, s, p, o)
+        coop_ms = event_avg_ms(lambda: engine.score_sp_po(T, s, p, o), max(a.steps, 40), 3)
         out1 = torch.empty(n, PITCH, device=device)[:, :E_FB]
         pipe1 = engine.ScorePipeline(T, "sp_", n)
         pipe1.start(*batches[0])
         k1 = [0]
 
-        def one_sp():  # score_sp of the current batch, the next batch's queries built in the same launch
+        def one_sp():
             k1[0] += 1
             pipe1.step(next_batch=tri[k1[0] & 1], out=out1)
         for _ in range(5):
             one_sp()
-        one_ms = event_avg_ms(one_sp, a.steps, a.repeats)
-
-        def one():
+        one_ms = event_avg_ms(one_sp, max(a.steps, 40), a.repeats)
+        for _ in range(3):
             engine.score_sp(T, s, p)
-            engine.score_po(T, p, o)
-        one_coop_ms = event_avg_ms(one, a.steps) / 2
+        one_coop_ms = event_avg_ms(lambda: engine.score_sp(T, s, p), max(a.steps, 40), 3)
         ab1 = algorithmic_bytes(n, E_FB, DIM)
-        extra["one_sided_launch"] = {"avg_launch_us": one_ms * 1e3, "algorithmic_bytes_per_launch": ab1,
-                                     "achieved": ab1 / (one_ms * 1e-3) / 1e9,
-                                     "frac": ab1 / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "one_call_entry_us": one_coop_ms * 1e3,
-                                     "one_call_entry_frac": ab1 / (one_coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if L > 1:  # the one-sided launch with `streams` batches in flight (host-issue bound below ~10 us per step)
-            pipe1L = engine.ScorePipeline(T, "sp_", n, streams=L)
-            outs1 = [torch.empty(n, PITCH, device=device)[:, :E_FB] for _ in range(L)]
-            pipe1L.start([tri[0]] * L)
+        extra["one_launch_per_batch"] = {
+            "kernel": "pairs_bf16_v7_kernel (kge_score_queries: one batch per launch, the next batch's queries built "
+                      "inside it) -- single-pass queries, HIP events over back-to-back launches on one stream",
+            "two_sided": {"avg_launch_us": one2_ms * 1e3, "frac": ab / (one2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "one_call_entry_us": coop_ms * 1e3,
+                          "one_call_entry_frac": ab / (coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "one_sided": {"avg_launch_us": one_ms * 1e3, "algorithmic_bytes_per_launch": ab1,
+                          "frac": ab1 / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "one_call_entry_us": one_coop_ms * 1e3,
+                          "one_call_entry_frac": ab1 / (one_coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        del pipe, pipe1, out_pad, out1
+        # ---- groups of one-sided batches (score_sp alone: north_star quotes its target on score_sp)
+        g1 = {}
+        for key, md in modes.items():
+            q = torch.Generator().manual_seed(7)
+            tri1 = [torch.stack([torch.randint(hi, (n * L,), generator=q) for hi in (E_FB, R_FB, E_FB)], 1).to(device)
+                    for _ in range(2)]
+            qs = [engine.QueriesGroup(md.T, "sp_", n, L, flags=md.flags) for _ in range(2)]
+            engine.build_queries_group(md.T, "sp_", tri1[0], n, L, out=qs[0])
+            b1 = torch.empty(L, n, PITCH, device=device)
             c1 = [0]
 
-            def run1(k):
+            def launch1():
                 c = c1[0]
-                for _ in range(k):
-                    pipe1L.step(next_batch=tri[(c // L + 1) & 1], out=outs1[c % L])
-                    c += 1
-                c1[0] = c
-            run1(20)
-            el1, _, host1 = timed_regions(run1, torch.cuda.synchronize, a.steps, 3)
-            extra["one_sided_launch"]["timed_region"] = {
-                "streams": L, "us_per_step": el1 / a.steps * 1e6, "host_issue_us_per_step": host1 / a.steps * 1e6,
-                "frac": ab1 / (el1 / a.steps) / 1e9 / HBM_PEAK_GBS}
-            del pipe1L, outs1
-        # split queries (KGE_FLAG_SPLIT_QUERY: q = q_hi + q_lo, f32-level parity on the bf16 tables -- the evaluation
-        # setting): the same pipelined step, twice the MFMA work per score
-        TS = engine.Tables("complex", ent, rel, flags=engine.FLAG_SPLIT_QUERY)
-        pipes = engine.ScorePipeline(TS, "sp_po", n, flags=engine.FLAG_SPLIT_QUERY)
-        pipes.start(*batches[0])
-        ks = [0]
-
-        def one_split():
-            ks[0] += 1
-            pipes.step(next_batch=batches[ks[0] & 1], out=out_buf)
-        for _ in range(5):
-            one_split()
-        sp_ms = event_avg_ms(one_split, max(50, a.steps // 2))
-        ab2 = algorithmic_bytes(n, E_FB, DIM, sides=2)
-        extra["split_query_step"] = {"avg_launch_us": sp_ms * 1e3, "algorithmic_bytes_per_launch": ab2,
-                                     "frac": ab2 / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "scored_triples_per_s": 2.0 * n * E_FB / (sp_ms * 1e-3)}
-        del TS, pipes, pipe1, out1
-        # (the legs below are not the timed region: they run at least a few dozen launches each whatever K is -- at the
-        # driver's K = 20 ten launches from a cold start say little)
-        # ... and at the other batch sizes SURVEY.md 8(d) lists (and beyond): the start-up of a launch
-        # (index load -> row gather -> query build -> hand-off, ~8 us) is paid once per call, so the
-        # per-launch fraction of the roofline grows with n
-        by_n = {}
-        for nn in (128, 1024, 2048, 4096):
-            q = torch.Generator().manual_seed(nn)
-            s2 = torch.randint(E_FB, (nn,), generator=q).to(device)
-            p2 = torch.randint(R_FB, (nn,), generator=q).to(device)
-            pn = engine.ScorePipeline(T, "sp_", nn)
-            pn.start(s2, p2, None)
-            outn = torch.empty(nn, PITCH, device=device)[:, :E_FB]
+                engine.score_queries_group(md.T, qs[c], b1[:, :, :E_FB], next_batch=tri1[1 - c], next_queries=qs[1 - c])
+                c1[0] = 1 - c
             for _ in range(3):
-                pn.step(next_batch=(s2, p2, None), out=outn)
-            ms = event_avg_ms(lambda: pn.step(next_batch=(s2, p2, None), out=outn), max(40, a.steps // 4))
-            del pn, outn
-            abn = algorithmic_bytes(nn, E_FB, DIM)
-            by_n[str(nn)] = {"avg_launch_us": ms * 1e3, "algorithmic_bytes_per_launch": abn,
-                             "frac": abn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "scored_triples_per_s": nn * E_FB / (ms * 1e-3)}
-            del s2, p2
-        extra["one_sided_by_batch"] = by_n
+                launch1()
+            ms1 = event_avg_ms(launch1, max(3, (max(a.steps, 40) + L - 1) // L), a.repeats)
+            g1[key] = {"avg_launch_us": ms1 * 1e3, "us_per_batch": ms1 * 1e3 / L, "batches_per_launch": L,
+                       "algorithmic_bytes_per_launch": L * ab1, "frac": L * ab1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "scored_triples_per_s": L * n * E_FB / (ms1 * 1e-3)}
+            del b1, qs
+        extra["score_sp_groups"] = g1
+        by_n = {}
+        for nn in (128, 1024, 2048):
+            q = torch.Generator().manual_seed(nn)
+            trin = torch.stack([torch.randint(hi, (nn * 4,), generator=q) for hi in (E_FB, R_FB, E_FB)], 1).to(device)
+            qn = engine.build_queries_group(T, "sp_", trin, nn, 4)
+            outn = torch.empty(4, nn, PITCH, device=device)
+            for _ in range(3):
+                engine.score_queries_group(T, qn, outn[:, :, :E_FB])
+            ms = event_avg_ms(lambda: engine.score_queries_group(T, qn, outn[:, :, :E_FB]), max(10, a.steps // 4))
+            abn = 4 * algorithmic_bytes(nn, E_FB, DIM)
+            by_n[str(nn)] = {"batches_per_launch": 4, "avg_launch_us": ms * 1e3, "frac": abn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "scored_triples_per_s": 4 * nn * E_FB / (ms * 1e-3)}
+            del qn, outn, trin
+        extra["score_sp_groups_by_batch"] = by_n
         # float32 tables (the dtype of an unmodified LibKGE config; the reference's own precision):
         # the exact f32 chain on v_mfma_f32_32x32x2_f32 -- MFMA-bound, flops = 2 n d m
         T32 = engine.Tables("complex", ent.float(), rel.float())
@@ -722,62 +809,62 @@ def main():
                      "avg_launch_us": f_ms * 1e3, "flops_per_launch": 2.0 * n * DIM * E_FB,
                      "scored_triples_per_s": n * E_FB / (f_ms * 1e-3)}
         del T32
+        for md in modes.values():
+            md.by_size.clear()
+        torch.cuda.empty_cache()
         extra_rank = rank_legs(engine, device, n, max(25, min(a.steps, 400) // 4))
         extra_neg = neg_legs(engine, device, max(20, min(a.steps, 400) // 8))
         extra_eval = eval_leg(engine, device)
+        extra_train = train_leg(device, n, max(10, min(a.steps, 200) // 4))
     else:
-        extra_f32 = extra_rank = extra_neg = extra_eval = None
+        extra_f32 = extra_rank = extra_neg = extra_eval = extra_train = None
 
-    total = 2.0 * n * E_FB * a.steps
-    ab = algorithmic_bytes(n, E_FB, DIM, sides=2)
-    achieved = ab / (avg_ms * 1e-3) / 1e9
+    rp = res["parity"]
+    rt = res["training"]
     out = {
         "metric": "scored triples/sec (1vsAll, ComplEx d=512)",
-        "value": total / el,
+        "value": total / rp["el"],
         "unit": "scored triples/s",
+        "value_mode": "parity-compliant: split queries (q = q_hi + q_lo on the matrix cores; ranks equal to float32 "
+                      "arithmetic on the bf16 tables up to its summation noise).  The single-pass mode is "
+                      "`training_tolerance` below",
         "n_gpus": 1,
         "steps": a.steps,
         "warmup": a.warmup,
         "repeats": a.repeats,
-        "ms_per_step": el / a.steps * 1e3,
-        "regions_ms_per_step": [r / a.steps * 1e3 for r in regions],
-        "host_issue_ms_per_step": host_el / a.steps * 1e3,
+        "ms_per_step": rp["el"] / a.steps * 1e3,
+        "regions_ms_per_step": [r / a.steps * 1e3 for r in rp["regions"]],
+        "host_issue_ms_per_step": rp["host"] / a.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": "FB15k-237 shape ComplEx d=512 1vsAll scoring, bf16 tables, f32 scores: the "
-                        "score_sp and score_po blocks of the batch per step (KgeModel.score_sp_po, one "
-                        "two-sided launch; the next batch's query vectors built inside the same launch; score "
-                        "rows on a 256-byte pitch); `streams` batches in flight, batch k on HIP stream k % streams",
-            "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n,
-            "parallelism": "single GPU",
-            "streams": L,  # batches in flight in the timed region (batch k on HIP stream k % streams)
+            "workload": "FB15k-237 shape ComplEx d=512 1vsAll scoring, bf16 tables, f32 scores: the score_sp and "
+                        "score_po blocks of a batch per step (KgeModel.score_sp_po), batches issued in groups of "
+                        "`group` -- one persistent launch per group (kge_score_queries_multi), which also builds the "
+                        "next group's query vectors; score rows on a 256-byte pitch",
+            "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n, "group": L,
+            "parallelism": "single GPU", "queries": "split (q_hi + q_lo)",
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "pairs_bf16_v7_kernel<ComplEx,d=512>, two-sided, prepared queries (kge_score_queries: one "
-                      "launch = MFMA contraction + store of both score blocks of batch k + gather and query build "
-                      "of batch k+1 on idle workgroups)",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": ab,
-            "avg_launch_us": avg_ms * 1e3,
-            "isolated_call_median_us": iso[len(iso) // 2] * 1e3,
-            "score_row_pitch_floats": 2 * PITCH, "block2_offset_floats": PITCH,
-            "contiguous_pitch": {"avg_launch_us": contig_ms * 1e3, "frac": ab / (contig_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "one_call_entry_us": coop_ms * 1e3,  # kge_score_sp_po: the query build inside the launch (cooperative)
-            "one_call_entry_frac": ab / (coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(),
-            # the timed region of `value`: `streams` launches in flight; chip-level rate = the same bytes / ms_per_step
-            "timed_region": {"streams": L, "us_per_step": el / a.steps * 1e6,
-                             "achieved": ab / (el / a.steps) / 1e9, "frac": ab / (el / a.steps) / 1e9 / HBM_PEAK_GBS},
-            **extra,
-        },
+        "roofline": {**roofline_of("parity", "pairs_bf16_v8_kernel<ComplEx, SPLIT> (kge_score_queries_multi: one "
+                                             "persistent launch = `group` two-sided batches, split queries: twice the "
+                                             "matrix-core work per score)"),
+                     "traffic": pmc_traffic(),
+                     "timed_region": {"us_per_step": rp["el"] / a.steps * 1e6,
+                                      "frac": ab / (rp["el"] / a.steps) / 1e9 / HBM_PEAK_GBS}},
+        # the same step with the query vector rounded to ONE bf16 (what 1vsAll TRAINING needs; 4 % of the ranks of an
+        # evaluation would move against float32 arithmetic on the same tables)
+        "training_tolerance": {
+            "value": total / rt["el"], "unit": "scored triples/s", "ms_per_step": rt["el"] / a.steps * 1e3,
+            "regions_ms_per_step": [r / a.steps * 1e3 for r in rt["regions"]],
+            "host_issue_ms_per_step": rt["host"] / a.steps * 1e3,
+            "roofline": {**roofline_of("training", "pairs_bf16_v8_kernel<ComplEx> (kge_score_queries_multi: one "
+                                                   "persistent launch = `group` two-sided batches, single-pass queries)"),
+                         "timed_region": {"us_per_step": rt["el"] / a.steps * 1e6,
+                                          "frac": ab / (rt["el"] / a.steps) / 1e9 / HBM_PEAK_GBS}}},
+        **extra,
     }
     if extra_f32 is not None:
         out["roofline_f32"] = extra_f32
@@ -787,6 +874,8 @@ def main():
         out["roofline_neg"] = extra_neg
     if extra_eval is not None:
         out["roofline_eval"] = extra_eval
+    if extra_train is not None:
+        out["roofline_train"] = extra_train
     if not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, a.cpu_seconds)
     print(json.dumps(out))

@@ -46,6 +46,8 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
                       int reserve_cus);
 NextQ pairs_bf16_nextq(bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, long long n,
                        int nbatch, void* qf, long long qstride_bytes);
+int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, long long n, long long m, const void* qf,
+                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus);
 bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
 int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
@@ -470,6 +472,8 @@ int kge_score_queries_multi(const kge_tables* t, int combine, const void* querie
                           next->queries, next_stride);
   }
   if (!work) return KGE_OK;
+  if (num_batches == 1)  // a group of one: the single-batch entry (its kernel choice: pairs_bf16_v7 / v6 / v8)
+    return kge_score_queries(t, combine, queries, n, targets, m, out, ldo, block2_offset, next, stream);
   return run_pairs_bf16_v8(t->scorer, split, TG, combine == KGE_SP_PO, (int)t->dim, n, m, (int)num_batches, queries,
                            queries_stride, out, out_stride, ldo, b2, (hipStream_t)stream, nullptr, nx,
                            (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
@@ -790,7 +794,14 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   //   KGE_ERR_UNSUPPORTED, the caller scores and scans.
   const bool dot = t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT;
   const bool exact_path = t->dtype == KGE_F32 || !dot || (t->flags & KGE_FLAG_EXACT);
-  if (t->flags & (KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY)) return KGE_ERR_UNSUPPORTED;
+  const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0 && !exact_path;
+  if (t->flags & (KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
+  if ((t->flags & KGE_FLAG_SPLIT_QUERY) && exact_path) return KGE_ERR_UNSUPPORTED;
+  // split queries are counted by pairs_bf16_v8_rank_kernel only (their two partial scores meet in one lane there)
+  const char* e8 = getenv("KGE_V8_RANK");
+  const bool v8_rank = !exact_path && !(e8 && e8[0] == '0') && (t->dim == 256 || t->dim == 512) && TG.idx.ptr == nullptr &&
+                       workspace_bytes >= PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, split);
+  if (split && !v8_rank) return KGE_ERR_UNSUPPORTED;
   if (!exact_path) {
     if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
         !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
@@ -854,6 +865,19 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
     }
     const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
     return rc != KGE_OK ? rc : rcb;
+  }
+  if (v8_rank) {
+    // query fragments into the workspace (one small launch), then the persistent counting kernel: any n, no co-residency
+    void* qf = (char*)workspace + PAIRS_WS_CTRL_BYTES;
+    rc = run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
+    if (rc == KGE_OK)
+      rc = run_pairs_bf16_v8_rank(t->scorer, split, TG, (int)t->dim, n, m, qf, ce, st, nullptr,
+                                  (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
+    if (rc != KGE_ERR_UNSUPPORTED || split) {
+      const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+      return rc != KGE_OK ? rc : rcb;
+    }
+    rc = KGE_OK;  // declined (nothing counted): the round-3 kernel below
   }
   // one launch holds at most 32 row groups (one workgroup per CU and XCD-aligned column groups): 2,048 rows per
   // side; larger batches go through in row blocks

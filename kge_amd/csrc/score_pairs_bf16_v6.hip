@@ -722,7 +722,8 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
     const char* ens = getenv("KGE_V7_NOSTORE");
     const int probe = (ens && ens[0] == '1') ? 1 : 0;
     if (!(e7 && e7[0] == '0') && (st_aligned || two_sided || (e7 && e7[0] == '1'))) {
-      const char* epr = getenv("KGE_V7_PROBE");  // compile-time timing variants (tools/r4_diag3.py); wrong scores
+#ifdef KGE_V7_PROBES  // make CXXEXTRA=-DKGE_V7_PROBES: compile-time timing variants (tools/r4_diag2.py); wrong scores
+      const char* epr = getenv("KGE_V7_PROBE");
       const int prb = epr ? atoi(epr) : 0;
 #define KGE_V7P(PB)                                                                                               \
   if (prb == PB) {                                                                                               \
@@ -732,6 +733,7 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
   }
       KGE_V7P(1) KGE_V7P(2) KGE_V7P(3) KGE_V7P(4) KGE_V7P(5) KGE_V7P(7) KGE_V7P(8) KGE_V7P(9) KGE_V7P(15)
 #undef KGE_V7P
+#endif
       if (st_sc1)
         hipLaunchKernelGGL((pairs_bf16_v7_kernel<SCORER, 1>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,
                            out2_off, ncg, interleave ? 0 : upc, nunits, out, ldo, dbg, (const u32x4*)qf, nx, probe);

@@ -96,15 +96,33 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
   const int x = b & 7, j = b >> 3;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int u_lo = x * a.su;
+  int u_lo = x * a.su;
   int sux = a.nunits - u_lo;
   if (sux > a.su) sux = a.su;
   const int P = a.nbatch * a.sides * a.chunks;
-  int g0 = 0, g1 = 0;  // this workgroup's range of the XCD's list: position g = pair (g / sux), unit u_lo + g % sux
+  // This workgroup's list: `nseg` segments of `sux` units each -- segment k = pair pair0 + k * pstep over the units
+  // [u_lo, u_lo + sux) -- walked as positions g in [0, nseg * sux): pair pair0 + (g / sux) * pstep, unit u_lo + g % sux.
+  //   P >= workgroups per XCD: workgroup j takes the pairs j, j + wpx, ... over the XCD's whole slice;
+  //   fewer pairs: the slice is cut into wpx / P sub-ranges and workgroup j takes pair j % P over sub-range j / P.
+  // Either way the workgroups of an XCD that run side by side stream the SAME table units at about the same time: a
+  // unit comes from HBM once per XCD and P - 1 times from its L2 (a Wikidata5M shard does not fit the Infinity Cache).
+  const int g0 = 0;
+  int g1 = 0, pair0 = 0, pstep = a.wpx;
   if (sux > 0) {
-    const long long T = (long long)P * sux;
-    g0 = (int)(T * j / a.wpx);
-    g1 = (int)(T * (j + 1) / a.wpx);
+    if (P >= a.wpx) {
+      pair0 = j;
+      g1 = j < P ? ((P - j + a.wpx - 1) / a.wpx) * sux : 0;
+    } else {
+      const int nsub = a.wpx / P;
+      if (j < P * nsub) {
+        pair0 = j % P;
+        const int sub = j / P;
+        const int lo = (int)((long long)sux * sub / nsub), hi = (int)((long long)sux * (sub + 1) / nsub);
+        u_lo += lo;
+        sux = hi - lo;
+        g1 = sux;  // one segment
+      }
+    }
   }
 
   int dbg_i = 0;
@@ -155,10 +173,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
     // ---------------- the consumer ----------------
     const int fi = lane & 31, fh = lane >> 5;
     bf16x8 afr[NKB];
-    unsigned int boff[8], bp[8];
+    unsigned int bp[8];  // read addresses of the current ring buffer; moved on by one buffer per chain
     // target fragment kb of row fi: the 16-byte slot 2 kb + fh, stored at slot ^ (fi & 15)
 #pragma unroll
-    for (int t = 0; t < 8; ++t) bp[t] = boff[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
+    for (int t = 0; t < 8; ++t) bp[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
     bf16x8 bq[PF];
     auto bread = [&](bf16x8& dst, auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
@@ -200,7 +218,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
     auto chain = [&](int ks, f32x16& acc, const f32x16& prev, unsigned int vo, unsigned int colb, auto cold, auto&& frag)
         __attribute__((always_inline)) {
       constexpr bool COLD = decltype(cold)::value;
-      const unsigned int bn = (unsigned int)(((ks + 1) & (NBUF - 1)) * UNITB);
+      // the next ring buffer: + one unit, or back to the first one (unsigned wrap-around)
+      const unsigned int bdelta = ((ks + 1) & (NBUF - 1)) ? (unsigned int)UNITB : (unsigned int)(-(NBUF - 1) * UNITB);
       int un = dq < g1 ? du : ulast;  // requested by this chain: the unit three ahead (cold: first the unit two ahead)
       v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
         constexpr int kb = decltype(kc)::value;
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
         }
         if constexpr (kb + PF == NKB) {  // this unit's reads are all issued: on to the next ring buffer
 #pragma unroll
-          for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %2" : "=v"(bp[t]) : "s"(bn), "v"(boff[t]));
+          for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %0" : "+v"(bp[t]) : "s"(bdelta));
         }
         bread(bq[kb % PF], std::integral_constant<int, (kb + PF) % NKB>{});
         if constexpr ((kb & 1) == 0 && kb / 2 < NST) store_q(prev, std::integral_constant<int, kb / 2>{}, vo, colb);
@@ -240,11 +259,11 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
     auto nofrag = [](auto) {};
 
     int g = g0, ks = 0;
-    int pair = g0 / sux, cu = g0 - pair * sux;
+    int pair = pair0;
+    const int cu = 0;
     bool first = true;
     while (g < g1) {
-      int cnt = sux - cu;
-      if (cnt > g1 - g) cnt = g1 - g;
+      const int cnt = sux;
       // ---- the pair: batch lb, side, chunk of 8 x RW rows -> this wave's rows and fragments
       const int per = a.sides * a.chunks;
       const int lb = pair / per, rem = pair - lb * per;
@@ -325,8 +344,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
         v4_static_for<0, NST>([&](auto qc) __attribute__((always_inline)) { store_q(acc0, qc, pvo, pcolb); });
       }
       g += cnt;
-      cu = 0;
-      ++pair;
+      pair += pstep;
     }
     // The look-ahead reads behind the last unit return into bq[] whenever the LDS gets to them.  Nobody uses what they
     // return -- which is exactly why the registers must be kept: to the compiler an asm output is there at once and a
@@ -433,6 +451,406 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
   if (scorer == KGE_DISTMULT) { KGE_V8L(KGE_DISTMULT); }
 #undef KGE_V8L
   return KGE_ERR_UNSUPPORTED;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// pairs_bf16_v8_rank_kernel: the SAME launch shape with the scores COUNTED instead of stored -- the counts of
+// EntityRankingJob._filter_and_rank / _get_ranks_and_num_ties (kge/job/eval_entity_ranking.py:533-596) for the entity
+// slice, without the [n, 2 m] score matrix (kge_score_rank_sp_po, kge_eval_batch).  Round 3's counting epilogue sat in
+// pairs_bf16_v4_kernel behind ONE consumer wave per SIMD, which alternated a chain with ~1 k cycles of comparisons while
+// the matrix pipe idled (0.17 / 0.25 of the bf16 peak at the FB15k-237 / Wikidata5M-shard shapes, pipe 32 % busy).  Here
+// every SIMD has two consumer waves: one wave's comparisons of unit k - 1 -- issued between the MFMAs of its own chain k,
+// one element per slot (d = 256) / per two slots (d = 512) -- run under the other wave's MFMAs.
+//
+// Orientation: MFMA(targets, queries) as in pairs_bf16_v4: a lane owns ONE query row (operand row fi) and the unit's
+// targets 8 (r >> 2) + 4 fh + (r & 3), so that the row's true score, tolerance, filter words and counters are per-lane
+// state (v8's store orientation would need a cross-lane reduction per element).  Same products, same K order: the
+// counted scores are the bits the store kernels write.
+//
+// Split queries (KGE_FLAG_SPLIT_QUERY: the parity-compliant evaluation mode): operand row fi = 16 a + 8 part + jj holds
+// q_hi (part 0) / q_lo (part 1) of real row 8 a + jj of the wave's 16; the full score is acc(fi) + acc(fi ^ 8) = one
+// DPP add (row_ror:8) per element, (sum q_hi t) + (sum q_lo t) as pairs_bf16_v8_kernel<SPLIT> stores it; the part-1
+// lanes compute the same values and count nothing.
+//
+// Vector-memory operations of a wave per chain, ALL in inline asm so that the counted waits are exact: two filter-word
+// loads in slot 1 (this unit's words, used behind the NEXT chain; a launch with fewer than two filter sets loads a
+// dummy word) and NP table pieces behind the barrier.  No stores.
+struct V8RankArgs {
+  Operand TG;
+  long long n, m;
+  int rgn1, sides, chunks;
+  int nunits, su, wpx;
+  const u32x4* qf;
+  unsigned long long* dbg;
+  CeArgs ce;
+};
+
+template <int SCORER, int HH, int SPLIT>
+__global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a) {
+  constexpr int NKB = 2 * HH / 16;        // 32 / 16 K-blocks
+  constexpr int ROWB = 4 * HH;            // bytes per table row
+  constexpr int SPR = ROWB / 16;          // 16-byte slots per row: 64 / 32
+  constexpr int RPP = 64 / SPR;           // table rows per 1-KiB piece: 1 / 2
+  constexpr int UNITB = V8_UT * ROWB;     // 32 / 16 KiB
+  constexpr int NBUF = 4;
+  constexpr int SMEM = NBUF * UNITB;
+  constexpr int NP = UNITB / 1024 / 8;    // pieces per unit and wave: 4 / 2
+  constexpr int RW = SPLIT ? 16 : 32;     // real query rows per wave
+  constexpr int PF = 8;
+  constexpr int PB = NKB == 32 ? 14 : 6;  // MFMA slot of the barrier
+  constexpr int SPE = NKB / 16;           // MFMA slots per element of the comparison pipeline: 2 / 1
+  // a chain's vector-memory operations, in order: slot 1: two word loads | behind slot PB: NP pieces
+  constexpr int VM_BAR = NP + 4;          // behind the pieces of unit k + 1 (chain k - 2): chain k - 1 (2 + NP), 2 loads
+  constexpr int VM_FIN = 2 * NP + 2;      // behind the words of unit k - 1 (chain k - 1, slot 1): NP, then 2 + NP
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  if (a.n < 0) smem[threadIdx.x] = 0;
+
+  const int b = blockIdx.x;
+  const int x = b & 7, j = b >> 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int u_lo = x * a.su;
+  int sux = a.nunits - u_lo;
+  if (sux > a.su) sux = a.su;
+  const int P = a.sides * a.chunks;
+  // the workgroup's list of (pair, unit) positions: see pairs_bf16_v8_kernel
+  const int g0 = 0;
+  int g1 = 0, pair0 = 0, pstep = a.wpx;
+  if (sux > 0) {
+    if (P >= a.wpx) {
+      pair0 = j;
+      g1 = j < P ? ((P - j + a.wpx - 1) / a.wpx) * sux : 0;
+    } else {
+      const int nsub = a.wpx / P;
+      if (j < P * nsub) {
+        pair0 = j % P;
+        const int sub = j / P;
+        const int lo = (int)((long long)sux * sub / nsub), hi = (int)((long long)sux * (sub + 1) / nsub);
+        u_lo += lo;
+        sux = hi - lo;
+        g1 = sux;
+      }
+    }
+  }
+  if (g1 <= g0) return;
+  int dbg_i = 0;
+  auto stamp = [&]() {
+    if (a.dbg != nullptr && tid == 0 && dbg_i < 32) a.dbg[(long long)blockIdx.x * 64 + dbg_i] = __builtin_readcyclecounter();
+    ++dbg_i;
+  };
+  stamp();
+
+  // ---------------- the table stream ----------------
+  const unsigned char* const tgb = (const unsigned char*)a.TG.base;
+  const long long tld2 = a.TG.ld * 2;
+  const long long m = a.m;
+  const int lr = lane / SPR, slot = lane % SPR;
+  const int rp0 = wave * NP * RPP;  // this wave's first row of every unit
+  int dq = g0, du = g0 % sux;
+  const int ulast = (g1 - 1) % sux;
+  auto dma_piece = [&](int un, int ks, auto kc) __attribute__((always_inline)) {
+    constexpr int kk = decltype(kc)::value;
+    const int ru = rp0 + kk * RPP;  // the piece's first row within the unit
+    const long long r0 = (long long)(u_lo + un) * V8_UT + ru;
+    const unsigned int dk = (unsigned int)((ks & (NBUF - 1)) * UNITB + ru * ROWB);
+    // lane (lr, slot) fetches the 16-byte slot `slot ^ (row & 15)` of row ru + lr into slot `slot` of its LDS row
+    const unsigned int sw = (unsigned int)((slot ^ ((ru + lr) & 15)) << 4);
+    // rows beyond the table repeat its last row (never counted): the scalar base clamped to row m - 1, the lane's
+    // row within the piece clamped against what is left behind the base
+    const long long rb = r0 < m ? r0 : m - 1;
+    const unsigned char* pk = tgb + rb * tld2;
+    unsigned int vo = sw;
+    if constexpr (RPP > 1) {
+      const int left = (int)(m - 1 - rb < RPP - 1 ? m - 1 - rb : RPP - 1);
+      vo += (unsigned int)((lr < left ? lr : left) * (int)tld2);
+    }
+    KGE_V8_DMA(dk, vo, pk);
+  };
+  auto dma_advance = [&]() __attribute__((always_inline)) {
+    ++dq;
+    if (++du == sux) du = 0;
+  };
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int un = dq < g1 ? du : ulast;
+    v4_static_for<0, NP>([&](auto kc) __attribute__((always_inline)) { dma_piece(un, k, kc); });
+    dma_advance();
+  }
+
+  // ---------------- the consumer ----------------
+  const int fi = lane & 31, fh = lane >> 5;
+  bf16x8 afr[NKB];
+  unsigned int bp[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) bp[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
+  bf16x8 bq[PF];
+  auto bread = [&](bf16x8& dst, auto kc) __attribute__((always_inline)) {
+    constexpr int kb = decltype(kc)::value;
+    const unsigned int addr = bp[kb & 7];
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256) : "memory");
+  };
+
+  // ---- per-row state of the counts (rank.hip's arithmetic; see pairs_bf16_v4_kernel<V3_RANK>)
+  const CeArgs& ce = a.ce;
+  const bool counts_here = SPLIT ? ((fi >> 3) & 1) == 0 : true;  // split: the q_lo lanes duplicate their q_hi lane
+  float rk_t = 0.0f, rk_al = 0.0f;
+  bool rk_slow = false;
+  int rk_g = 0, rk_c = 0, rk_fg[2] = {0, 0}, rk_fc[2] = {0, 0}, rk_fn[2] = {0, 0};
+  // filter words: scalar base per filter set (this side's bits; dummy: any readable word) + the row's byte offset
+  const unsigned char* rk_base[2] = {(const unsigned char*)a.qf, (const unsigned char*)a.qf};
+  unsigned int rk_off = 0;
+  int orow_cur = 0;
+  int side_cur = 0;
+  // bits of a lane's 16 elements within the unit's 32 columns: element r at bit 8 (r >> 2) + 4 fh + (r & 3)
+  auto rk_spread = [](unsigned int d) __attribute__((always_inline)) -> unsigned int {
+    return (d & 0xfu) | ((d & 0xf0u) << 4) | ((d & 0xf00u) << 8) | ((d & 0xf000u) << 12);
+  };
+  auto full_score = [&](float v) __attribute__((always_inline)) -> float {
+    if constexpr (SPLIT) {
+      const float o = __builtin_bit_cast(
+          float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+      return v + o;  // (sum q_hi t) + (sum q_lo t): both lanes of the pair hold it (f32 addition commutes)
+    } else {
+      return v;
+    }
+  };
+  // the finished unit at slice position `cu` into the counters; w0 / w1 = the row's filter words of that unit
+  auto rank_unit = [&](const f32x16& pv, int cu, unsigned int w0, unsigned int w1) __attribute__((always_inline)) {
+    unsigned int g, c;
+    if (rk_slow) {  // some row of the wave has an infinite true score / tolerance: the generic arithmetic
+      g = c = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int g0_ = 0, c0_ = 0;
+        count_one(full_score(pv[r]), rk_t, ce.rk_atol, ce.rk_rtol, g0_, c0_);
+        const unsigned int bit = 1u << (8 * (r >> 2) + (r & 3));
+        g |= g0_ ? bit : 0u;
+        c |= c0_ ? bit : 0u;
+      }
+    } else {
+      // finite true score, finite tolerance >= 0:  close <=> |x - t| <= allowed,  greater-and-not-close <=>
+      // x - t > allowed  (NaN and -inf scores fail both, +inf is greater: what count_one gives).  As sign bits:
+      // x' = max(x, -inf) (NaN -> -inf), e = x' - t, sign(allowed - e) = greater, sign(allowed - |e|) = NOT close
+      unsigned int ng = 0u, nc = 0u;
+#pragma unroll
+      for (int r = 15; r >= 0; --r) {  // element r ends up at bit r
+        const float e = __builtin_fmaxf(full_score(pv[r]), -__builtin_inff()) - rk_t;
+        ng = __builtin_amdgcn_alignbit(ng, __builtin_bit_cast(unsigned int, rk_al - e), 31);
+        nc = __builtin_amdgcn_alignbit(nc, __builtin_bit_cast(unsigned int, rk_al - __builtin_fabsf(e)), 31);
+      }
+      g = rk_spread(ng & 0xffffu);
+      c = rk_spread(~nc & 0xffffu);
+    }
+    const long long c0t = (long long)(u_lo + cu) * V8_UT;
+    unsigned int mine = counts_here ? (0x0f0f0f0fu << (4 * fh)) : 0u;
+    const long long rem = m - c0t;
+    if (rem < V8_UT) mine &= (1u << rem) - 1u;  // (rem >= 1: the unit exists)
+    g = (g << (4 * fh)) & mine;
+    c = (c << (4 * fh)) & mine;
+    rk_g += __builtin_popcount(g);
+    rk_c += __builtin_popcount(c);
+    const unsigned int ww[2] = {w0 & mine, w1 & mine};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k < ce.rk_nfilt) {
+        rk_fg[k] += __builtin_popcount(g & ww[k]);
+        rk_fc[k] += __builtin_popcount(c & ww[k]);
+        rk_fn[k] += __builtin_popcount(ww[k]);
+      }
+    }
+  };
+  // the row's counters out (the two lanes fh = 0 / 1 of a row first), then zeroed
+  auto rank_flush = [&]() __attribute__((always_inline)) {
+    const int G = rk_g + __shfl_xor(rk_g, 32, 64), C = rk_c + __shfl_xor(rk_c, 32, 64);
+    const bool wr = counts_here && orow_cur < a.n && fh == 0;
+    unsigned long long* rank = ce.rk_rank[side_cur] + orow_cur;
+    unsigned long long* ties = ce.rk_ties[side_cur] + orow_cur;
+    if (wr && G != 0) atomicAdd(rank, (unsigned long long)G);
+    if (wr && C != 0) atomicAdd(ties, (unsigned long long)C);
+    const int fc = rk_t == -__builtin_inff() ? 1 : 0;  // is -inf (a filtered column's score) close to the true score
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k < ce.rk_nfilt) {
+        const int FG = rk_fg[k] + __shfl_xor(rk_fg[k], 32, 64), FC = rk_fc[k] + __shfl_xor(rk_fc[k], 32, 64);
+        const int FN = rk_fn[k] + __shfl_xor(rk_fn[k], 32, 64);
+        const int Gk = G - FG, Ck = C - FC + fc * FN;
+        if (wr && Gk != 0) atomicAdd(rank + (k + 1) * ce.rk_ld, (unsigned long long)Gk);
+        if (wr && Ck != 0) atomicAdd(ties + (k + 1) * ce.rk_ld, (unsigned long long)Ck);
+      }
+      rk_fg[k] = rk_fc[k] = rk_fn[k] = 0;
+    }
+    rk_g = rk_c = 0;
+  };
+  auto load_words = [&](int cu, unsigned int& w0, unsigned int& w1) __attribute__((always_inline)) {
+    // the row's filter words of the unit at slice position cu: scalar base (the filter set's bits + the unit's 32-bit
+    // half: word index = unit) + the row's offset; fewer than two filter sets: a dummy word
+    const unsigned char* wb0 = rk_base[0] + (ce.rk_nfilt > 0 ? (long long)(u_lo + cu) * 4 : 0);
+    const unsigned char* wb1 = rk_base[1] + (ce.rk_nfilt > 1 ? (long long)(u_lo + cu) * 4 : 0);
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(w0) : "v"(rk_off), "s"(wb0) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(w1) : "v"(rk_off), "s"(wb1) : "memory");
+  };
+
+  // The consumer loop, in two phase-shifted forms.  Per unit a wave runs its MFMA chain and then a BURST of ~140 VALU
+  // operations (the comparisons: interleaved into the chain they cost more than on their own -- an instruction
+  // between two MFMAs on the same accumulator breaks their back-to-back issue: measured 3.05 k cycles per unit against
+  // 2.15 k of matrix time at d = 512).  The burst of one wave is meant to run under the chain of the OTHER wave of its
+  // SIMD (waves w and w + 4), so the two halves of the workgroup stand half a period apart: waves 0-3 pass the unit's
+  // barrier in the middle of their chain, waves 4-7 at the start of theirs.  The barrier's promises hold for both
+  // (see pairs_bf16_v8_kernel): whoever passes P(k) is done reading unit k - 1, and every wave has waited for its own
+  // pieces of unit k + 1 -- which nobody reads before slot NKB - PF of chain k.
+  auto run = [&](auto half) __attribute__((always_inline)) {
+    constexpr int HALF = decltype(half)::value;
+    constexpr int PBH = HALF ? 0 : PB;              // slot of the barrier
+    constexpr int WSH = HALF ? NP + 1 : 1;          // slot of the NEXT unit's filter-word loads
+    // vector-memory operations in order, per chain: HALF 0: words (slot 1) | pieces behind the barrier;  HALF 1: pieces
+    // (slots 1 .. NP) | words.  Behind the pieces of unit k + 1 (chain k - 2) until P(k): NP + 4 operations either way;
+    // behind the words of unit k (chain k - 1) until the burst behind chain k: 2 NP + 2 / NP + 2
+    constexpr int VMB = NP + 4;
+    constexpr int VMF = HALF ? NP + 2 : 2 * NP + 2;
+    f32x16 acc;
+    unsigned int wc0 = 0, wc1 = 0, wn0 = 0, wn1 = 0;  // filter words of the current / the next unit
+    auto chain = [&](int ks, int cu, int cu_next) __attribute__((always_inline)) {
+      const unsigned int bdelta = ((ks + 1) & (NBUF - 1)) ? (unsigned int)UNITB : (unsigned int)(-(NBUF - 1) * UNITB);
+      const int un = dq < g1 ? du : ulast;
+      v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kc)::value;
+        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        if constexpr (kb == PBH) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"i"(VMB) : "memory");  // this wave's pieces of unit ks + 1 have landed
+          __builtin_amdgcn_s_barrier();                               // P(ks)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kb == 0) {
+          const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[0], afr[0], zero, 0, 0, 0);
+        } else {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[kb % PF], afr[kb], acc, 0, 0, 0);
+        }
+        if constexpr (kb + PF == NKB) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %0" : "+v"(bp[t]) : "s"(bdelta));
+        }
+        bread(bq[kb % PF], std::integral_constant<int, (kb + PF) % NKB>{});
+        if constexpr (kb == WSH) load_words(cu_next, wn0, wn1);
+        if constexpr (kb > PBH && kb <= PBH + NP) dma_piece(un, ks + 3, std::integral_constant<int, kb - PBH - 1>{});
+      });
+      dma_advance();
+      // the burst: this unit's comparisons; its words were requested a chain ago
+      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wc0), "+v"(wc1) : "i"(VMF) : "memory");
+      rank_unit(acc, cu, wc0, wc1);
+      wc0 = wn0;
+      wc1 = wn1;
+      if (HALF == 0) stamp();  // (a stamp is a store: with stamps on, the counted waits of this wave wait for more)
+    };
+
+    int g = g0, ks = 0;
+    int pair = pair0;
+    bool first = true;
+    while (g < g1) {
+      const int cnt = sux;
+      const int side = pair / a.chunks, ch = pair - side * a.chunks;
+      // ---- this lane's row of the pair
+      long long lrow;
+      if constexpr (SPLIT) lrow = (long long)ch * (8 * RW) + RW * wave + 8 * (fi >> 4) + (fi & 7);
+      else lrow = (long long)ch * (8 * RW) + RW * wave + fi;
+      const long long orow = lrow < a.n ? lrow : a.n - 1;  // padded rows repeat row n - 1 (and never write)
+      orow_cur = (int)lrow;
+      side_cur = side;
+      rk_t = ce.rk_true[side][orow * ce.rk_true_stride];
+      if (rk_t != rk_t) rk_t = -__builtin_inff();
+      rk_al = ce.rk_atol + __builtin_fabsf(ce.rk_rtol * rk_t);
+      rk_slow = __any(!(__builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al))) != 0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < ce.rk_nfilt) rk_base[k] = (const unsigned char*)ce.rk_bits[side][k];
+      rk_off = ce.rk_nfilt > 0 ? (unsigned int)(orow * ce.rk_bits_ld * 8) : 0u;
+      // ---- fragments (groups of 128 operand rows; a chunk = two groups)
+      int grp = 2 * ch + (wave >> 2);
+      if (grp >= a.rgn1) grp = a.rgn1 - 1;
+      grp += side * a.rgn1;
+      const unsigned char* const gbase = (const unsigned char*)(a.qf + (long long)grp * 4 * NKB * 64);
+      unsigned int flo;
+      const unsigned char* fb;
+      int frange;
+      if constexpr (SPLIT) {
+        const int part = (fi >> 3) & 1, rr = 16 * (wave & 3) + 8 * (fi >> 4) + (fi & 7);
+        flo = (unsigned int)((((2 * part + (rr >> 5)) * NKB) * 64 + (rr & 31) + 32 * fh) * 16);
+        fb = gbase;
+        frange = 4 * NKB * 1024;
+      } else {
+        flo = (unsigned int)(lane * 16);
+        fb = gbase + (wave & 3) * (NKB * 1024);
+        frange = NKB * 1024;
+      }
+      const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, frange, 0x00020000);
+      v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kc)::value;
+        afr[kb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, flo + kb * 1024, 0, 16 /* sc1 */));
+      });
+      load_words(0, wc0, wc1);  // the pair's first unit
+      // fragments, words, pieces of the ring fill, the atomics of the pair before: everything of this wave has landed
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(wc0), "+v"(wc1) : : "memory");
+      if (first) {
+        __builtin_amdgcn_s_barrier();  // R0: units 0 .. 2 of the list have landed
+        if (HALF == 0) stamp();
+        v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
+        first = false;
+      }
+      for (int i = 0; i < cnt; ++i) {
+        chain(ks, i, i + 1 < cnt ? i + 1 : i);
+        ++ks;
+      }
+      rank_flush();
+      g += cnt;
+      pair += pstep;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4]), "v"(bq[5]), "v"(bq[6]), "v"(bq[7]));
+  };
+  if (wave < 4) run(std::integral_constant<int, 0>{});
+  else run(std::integral_constant<int, 1>{});
+}
+
+// Counts of a two-sided batch of `n` rows per side (prepared query fragments `qf`, the layout of v4_build_queries)
+// against the identity-indexed bf16 table TG (d in {256, 512}): ce carries the rk_* arguments.  KGE_ERR_UNSUPPORTED:
+// not this kernel's case (KGE_V8_RANK=0 declines everything: pairs_bf16_v4_kernel<V3_RANK>).
+int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, long long n, long long m, const void* qf,
+                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus) {
+  if ((d != 512 && d != 256) || TG.idx.ptr != nullptr || qf == nullptr) return KGE_ERR_UNSUPPORTED;
+  const char* e = getenv("KGE_V8_RANK");
+  if (e && e[0] == '0') return KGE_ERR_UNSUPPORTED;
+  if (TG.ld * 2 >= (1LL << 28) || ((uintptr_t)qf & 15)) return KGE_ERR_UNSUPPORTED;
+  const long long rgr = split ? 64 : 128;
+  const long long rgn1 = (n + rgr - 1) / rgr;
+  const long long nunits = (m + V8_UT - 1) / V8_UT;
+  if (rgn1 > (1 << 20) || (rgn1 + 1) * nunits >= (1LL << 30)) return KGE_ERR_UNSUPPORTED;
+  int cus = v8_cu_count() - reserve_cus;
+  if (cus > 256) cus = 256;
+  if (cus < 8) cus = 8;
+  V8RankArgs a{};
+  a.TG = TG;
+  a.n = n;
+  a.m = m;
+  a.rgn1 = (int)rgn1;
+  a.sides = 2;
+  a.chunks = (int)((rgn1 + 1) / 2);
+  a.nunits = (int)nunits;
+  a.su = (int)((nunits + 7) / 8);
+  a.wpx = cus / 8;
+  a.qf = (const u32x4*)qf;
+  a.dbg = dbg != nullptr ? dbg : v6_get_stamps();
+  a.ce = ce;
+  const dim3 grid(8 * a.wpx), block(512);
+#define KGE_V8R(SC, HHV, SP) hipLaunchKernelGGL((pairs_bf16_v8_rank_kernel<SC, HHV, SP>), grid, block, 0, st, a)
+#define KGE_V8R2(SC)                                                \
+  if (d == 512) { if (split) KGE_V8R(SC, 256, 1); else KGE_V8R(SC, 256, 0); } \
+  else { if (split) KGE_V8R(SC, 128, 1); else KGE_V8R(SC, 128, 0); }
+  if (scorer == KGE_COMPLEX) { KGE_V8R2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_V8R2(KGE_DISTMULT) }
+  else return KGE_ERR_UNSUPPORTED;
+#undef KGE_V8R2
+#undef KGE_V8R
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
 #undef KGE_V8_DMA

@@ -130,6 +130,7 @@ class EntityRankingEvaluator:
     # score-matrix bytes (both directions of a batch) from which float32 / TransE / RotatE tables are counted inside
     # the exact kernels instead of scored and scanned (see run())
     FUSED_EXACT_MIN_BYTES = 1 << 30
+    TWO_STEP_LANE_BYTES = 128 << 20  # two-step settings: lanes of captured batches only below this score-matrix size
 
 
     def __init__(self, model, splits: Dict[str, np.ndarray], num_entities: int, num_relations: int,
@@ -255,20 +256,23 @@ class EntityRankingEvaluator:
         M = len(rankings)
         st = self._device_state(dev)
         # a captured batch (below) survives from run to run while the tables stay where they are
+        # (everything a capture freezes into its kernel arguments is part of the key: table flags -- split queries,
+        # exact chain --, the tie policy and tolerances, which of the fused / four-launch paths is taken)
         gkey = ((tables.ent.data_ptr(), tables.rel.data_ptr(), tuple(tables.ent.shape), tuple(tables.rel.shape),
-                 tables.ent.stride(0), tables.rel.stride(0), tables.scorer, bool(return_ranks), M)
+                 tables.ent.stride(0), tables.rel.stride(0), tables.scorer, bool(return_ranks), M, int(tables.flags),
+                 bool(self._fused), bool(self.four_launches), self.tie_handling, float(self.tie_atol),
+                 float(self.tie_rtol), os.environ.get("KGE_EVAL_FUSED_EXACT"), int(self.chunk_size))
                 if isinstance(tables, engine.Tables) else None)
         held = self._graph if (self._graph is not None and self._graph["key"] == gkey) else None
         hist = held["hist"].zero_() if held is not None else torch.zeros(M, E, dtype=torch.float, device=dev)
         all_ranks = {f"{d}{r}": [] for r in rankings for d in "so"}
         chunk = E if self.chunk_size < 0 else self.chunk_size
         triples = st["triples"]
-        # (split queries -- engine.FLAG_SPLIT_QUERY, the rank-parity setting of bf16 tables -- score in two steps: the
-        # counting epilogue works on ONE MFMA chain per score)
-        # float32 tables of every scorer and bf16 ComplEx / DistMult at d 256 / 512 have a counting kernel; what the
-        # library declines (other bf16 shapes) is remembered per batch size and scored in two steps
-        fused = (self._fused and isinstance(tables, engine.Tables) and M <= 3
-                 and not (tables.flags & engine.FLAG_SPLIT_QUERY))
+        # float32 tables of every scorer and bf16 ComplEx / DistMult at d 256 / 512 -- one rounded query vector or
+        # split queries (engine.FLAG_SPLIT_QUERY, the rank-parity setting of bf16 tables: pairs_bf16_v8_rank_kernel
+        # adds the two partial scores inside a lane) -- have a counting kernel; what the library declines (other bf16
+        # shapes) is remembered per batch size and scored in two steps
+        fused = self._fused and isinstance(tables, engine.Tables) and M <= 3
         # the exact kernels' counting epilogue (float32 tables, TransE / RotatE) saves the [n, 2E] score matrix, not
         # time: their scoring is compute-bound and the true scores cost a launch pair of their own (C4 shape,
         # float32 DistMult: 0.35 ms per batch against 0.24 for score + scan, tools/eval_f32_probe.py) -- taken when
@@ -373,6 +377,8 @@ class EntityRankingEvaluator:
         use_graph = (self.hip_graph and isinstance(tables, engine.Tables) and chunk >= E and dev.type == "cuda"
                      and N // bs >= 4)
         L = max(1, self.lanes) if use_graph else 1
+        if use_graph and not fused and 8 * bs * E > self.TWO_STEP_LANE_BYTES:
+            L = 1  # every lane's graph pool keeps its own [bs, 2E] score matrix alive: one lane beyond ~128 MiB
         cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         used = set()
         kb = 0

@@ -144,8 +144,9 @@ class HipEntityRankingJob(EntityRankingJob):
                     else 8 * self.batch_size * min(chunk_size, E) >= _Ev.FUSED_EXACT_MIN_BYTES):
                 fused_tables = None
         # hip_entity_ranking.bf16_queries (hip_entity_ranking.yaml): "split" (default) scores bf16 tables with split
-        # queries -- rank parity with float32 arithmetic on those tables -- through the two-step path; "single" takes
-        # the counting kernel (one rounded query vector per row)
+        # queries -- rank parity with float32 arithmetic on those tables; "single": one rounded query vector per row.
+        # Both are counted inside the scoring kernel (pairs_bf16_v8_rank_kernel: no [n, 2E] score matrix); should the
+        # library decline a shape, the two-step path below keeps the split queries
         try:
             split = self.config.get("hip_entity_ranking.bf16_queries") != "single"
         except KeyError:
@@ -153,8 +154,7 @@ class HipEntityRankingJob(EntityRankingJob):
         split_tables = fused_tables if (split and fused_tables is not None
                                         and fused_tables().ent.dtype == torch.bfloat16
                                         and self.model._scorer.name in ("complex", "distmult")) else None
-        if split_tables is not None:
-            fused_tables = None
+        rank_flags = engine.FLAG_SPLIT_QUERY if split_tables is not None else None
 
         metrics = {}
         epoch_time = -time.time()
@@ -186,7 +186,7 @@ class HipEntityRankingJob(EntityRankingJob):
             if ft is not None:
                 # counts straight from the scoring kernel (kge_score_rank_sp_po): the true scores up front, as
                 # the two diagonals of ONE two-sided call against the batch's own targets (o | s)
-                both = engine.score_sp_po(ft, s, p, o, torch.cat([o64, s64]))
+                both = engine.score_sp_po(ft, s, p, o, torch.cat([o64, s64]), flags=rank_flags)
                 o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
                 s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
             elif chunk_size < E and split_tables is not None:
@@ -205,7 +205,7 @@ class HipEntityRankingJob(EntityRankingJob):
                 if ft is not None:
                     if engine.score_rank_sp_po(ft, s, p, o, o_true, s_true, filt_o, filt_s, self.tie_atol,
                                                self.tie_rtol, cnt[0, 0], cnt[0, 1], cnt[1, 0], cnt[1, 1],
-                                               chunk_start, chunk_end):
+                                               chunk_start, chunk_end, flags=rank_flags):
                         continue
                     ft = fused_tables = None  # declined: the two-step path from here on (o_true / s_true stay)
                 sub = None if c == E else torch.arange(chunk_start, chunk_end, device=dev)

@@ -382,12 +382,13 @@ class ShardedScoreLanes:
         self.k = 0
         self._out = []
         if graph is None:
-            # default: on where it has been run -- no collectives, or RCCL with ONE rank (the capture of the
-            # all-gather works there: tools/gpu runs of bench.py with KGE_BENCH_FORCE_DIST=1); with more ranks the
-            # capture of a multi-GPU RCCL collective has never run on this code (no multi-GPU box in the build
-            # loop), so it is opt-in: graph=True or KGE_SHARDED_GRAPH=1
+            # default: ON for every world size (KGE_SHARDED_GRAPH=0 turns it off) behind a self-check: the first
+            # capture of a step shape is replayed once and compared bit for bit with the step issued call by call,
+            # every rank votes (one all-reduce), and a capture that throws, differs or is voted down anywhere turns
+            # the feature off on all ranks -- loudly (warnings.warn + `graph_error`) --, the step going call by call
+            # from then on.  (The capture of a multi-GPU RCCL all-gather has run on ONE rank only in the build loop.)
             want = os.environ.get("KGE_SHARDED_GRAPH")
-            graph = (want == "1") if want is not None else (not table.collectives or table.world == 1)
+            graph = (want != "0") if want is not None else True
             if graph and table.collectives:
                 try:
                     graph = dist.get_backend(table.group) == "nccl"
@@ -397,6 +398,8 @@ class ShardedScoreLanes:
         self._graphs = [dict() for _ in range(self.L)]
         self._cap_stream = None
         self.graph_replays = 0
+        self.graph_error = None
+        self.graph_checked = 0  # captures that passed the self-check
 
     def fork(self):
         """The lanes wait for torch's current stream (producers of the batches; readers of earlier results)."""
@@ -442,15 +445,38 @@ class ShardedScoreLanes:
             if self._cap_stream is None:
                 self._cap_stream = torch.cuda.Stream(device=self.table.ent_local.device)
             st = self._cap_stream
+        err = None
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
                 cap = fn(*static)
-            self._graphs[lane][key] = {"graph": g, "static": static, "res": cap}
-        except Exception as exc:  # not capturable here: call by call from now on
-            self.use_graph = False
-            self.graph_error = f"{type(exc).__name__}: {exc}"
+            # self-check: one replay against the call-by-call result on the same static inputs
+            g.replay()
             torch.cuda.synchronize()
+            flat = lambda r: [t for t in (r if isinstance(r, (tuple, list)) else (r,)) if torch.is_tensor(t)]
+            same = all(torch.equal(a, b) for a, b in zip(flat(res), flat(cap))) and len(flat(res)) == len(flat(cap))
+            if not same:
+                err = "the replayed step differs from the step issued call by call"
+        except Exception as exc:  # not capturable here
+            err = f"{type(exc).__name__}: {exc}"
+            torch.cuda.synchronize()
+        if tb.collectives and tb.world > 1:  # every rank takes the same decision
+            try:
+                vote = torch.tensor([0 if err is None else 1], device=tb.ent_local.device, dtype=torch.int32)
+                dist.all_reduce(vote, op=dist.ReduceOp.MAX, group=tb.group)
+                if int(vote.item()) != 0 and err is None:
+                    err = "another rank's capture failed its self-check"
+            except Exception as exc:  # pragma: no cover
+                err = err or f"vote failed: {type(exc).__name__}: {exc}"
+        if err is None:
+            self._graphs[lane][key] = {"graph": g, "static": static, "res": cap}
+            self.graph_checked += 1
+        else:
+            self.use_graph = False
+            self.graph_error = err
+            import warnings
+            warnings.warn(f"kge_amd.sharded: hipGraph capture of the sharded step disabled ({err}); the step is "
+                          f"issued call by call", RuntimeWarning)
         return res, False
 
     def _run(self, name, fn, *args):

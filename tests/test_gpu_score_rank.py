@@ -11,11 +11,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _tables(eng, model, E, R, d, seed, scale=0.3):
+def _tables(eng, model, E, R, d, seed, scale=0.3, flags=0):
     g = torch.Generator().manual_seed(seed)
     ent = (torch.randn(E, d, generator=g) * scale).to(torch.bfloat16).to(DEV)
     rel = (torch.randn(R, d, generator=g) * scale).to(torch.bfloat16).to(DEV)
-    return eng.Tables(model, ent, rel, 1.0)
+    return eng.Tables(model, ent, rel, 1.0, flags=flags)
 
 
 def _filters(rng, n, E, K, true_col, hub_rows=()):
@@ -85,11 +85,17 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("kernel", ["v8", "v8-split", "v4"])
 @pytest.mark.parametrize("model,E,R,d,n,K,chunks", CASES)
-def test_fused_counts_equal_the_two_step_counts(model, E, R, d, n, K, chunks):
+def test_fused_counts_equal_the_two_step_counts(model, E, R, d, n, K, chunks, kernel, monkeypatch):
+    """kernel: "v8" pairs_bf16_v8_rank_kernel (two consumer waves per SIMD: the default), "v8-split" the same with
+    split queries (KGE_FLAG_SPLIT_QUERY: the parity-compliant evaluation mode; the two-step path stores the split
+    scores), "v4" the round-3 epilogue of pairs_bf16_v4_kernel (KGE_V8_RANK=0: what declined launches fall back to)."""
     from kge_amd import engine as eng
+    if kernel == "v4":
+        monkeypatch.setenv("KGE_V8_RANK", "0")
     rng = np.random.default_rng(E + 31 * n + K)
-    T = _tables(eng, model, E, R, d, seed=E + n)
+    T = _tables(eng, model, E, R, d, seed=E + n, flags=eng.FLAG_SPLIT_QUERY if kernel == "v8-split" else 0)
     s = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
     p = torch.from_numpy(rng.integers(0, R, n)).to(DEV)
     o = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
@@ -147,16 +153,15 @@ def test_fused_counts_with_nan_and_infinite_scores():
 
 
 def test_fused_path_declines_what_it_does_not_cover():
-    """bf16 ComplEx / DistMult at a dim the loader/consumer kernel does not take (its store path is another bf16
-    matrix-core kernel, without a counting epilogue), and split queries: declined, nothing counted."""
+    """bf16 ComplEx / DistMult at a dim the matrix-core counting kernels do not take (its store path is another bf16
+    kernel without a counting epilogue; with split queries the f32 chain scores there): declined, nothing counted."""
     from kge_amd import engine as eng
     g = torch.Generator().manual_seed(1)
     ent, rel = torch.randn(500, 128, generator=g).bfloat16().to(DEV), torch.randn(4, 128, generator=g).bfloat16().to(DEV)
     s = p = o = torch.zeros(4, dtype=torch.int64, device=DEV)
     z = torch.zeros(4, device=DEV)
     for T in (eng.Tables("complex", ent, rel, 1.0),
-              eng.Tables("distmult", ent.repeat(1, 2).contiguous(), rel.repeat(1, 2).contiguous(), 1.0,
-                         eng.FLAG_SPLIT_QUERY)):
+              eng.Tables("distmult", ent, rel, 1.0, eng.FLAG_SPLIT_QUERY)):
         cnt = torch.zeros(4, 1, 4, dtype=torch.int64, device=DEV)
         assert eng.score_rank_sp_po(T, s, p, o, z, z, [], [], 1e-5, 1e-4, cnt[0], cnt[1], cnt[2], cnt[3]) is False
         assert int(cnt.abs().sum()) == 0

@@ -67,3 +67,36 @@ def test_synthetic_dataset_roundtrip(tmp_path):
     assert np.array_equal(back, splits["train"])
     y = open(os.path.join(folder, "dataset.yaml")).read()
     assert "num_entities: 30" in y and "files.valid.size: 10" in y
+
+
+# ---- bench.py --gpus N launches N ranks itself (`a.gpus` was parsed and never read) ----------------------
+def _bench(args, env_extra, timeout=240):
+    import subprocess
+    import sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([_sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+    """`python bench.py --gpus 2` with no launcher re-executes itself under torch.distributed.run: two ranks reach the
+    device selection, each seeing WORLD_SIZE = 2 (KGE_BENCH_DEVICE_CHECK=1 stops there: no GPU here)."""
+    import json
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"], {"KGE_BENCH_DEVICE_CHECK": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert sorted(x["rank"] for x in lines) == [0, 1]
+    assert all(x["world_size"] == 2 and x["gpus"] == 2 for x in lines)
+    assert sorted(x["local_rank"] for x in lines) == [0, 1]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """Launched with WORLD_SIZE = 1 but asked for --gpus 2 (or the other way round): no line, a non-zero exit."""
+    r = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1"],
+               {"KGE_BENCH_DEVICE_CHECK": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    r = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1"],
+               {"KGE_BENCH_DEVICE_CHECK": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)

@@ -2,7 +2,8 @@
 """Round-4 diagnosis, second pass: what sets the 1.44 k-cycle unit period of pairs_bf16_v7_kernel when its stores cost
 nothing (tools/r4_diag.py: the period is the same with every store dropped).  KGE_V7_PROBE = compile-time variants of
 the kernel, bits: 1 no store instructions, 2 no table DMA behind the ring fill (stale units), 4 no fragment reads from
-LDS in the chains (stale registers), 8 no workgroup barrier per unit.  Timing only (wrong scores)."""
+LDS in the chains (stale registers), 8 no workgroup barrier per unit.  Timing only (wrong scores); the variants are
+in the library only when it is built with `make -C kge_amd/csrc -B CXXEXTRA=-DKGE_V7_PROBES`."""
 import json
 import os
 import sys
