@@ -196,6 +196,20 @@ Operand rel_op(const kge_tables* t, const kge_index& ix) {
   return Operand{t->rel, t->rel_ld, make_index(ix)};
 }
 
+// One-call entry points (kge_score_sp / _po / _sp_po) at d = 512 against all entities (or a contiguous slice): a
+// query_build_kernel launch + the direct-store kernel on prepared queries instead of the cooperative in-launch build
+// (tools/one_call_probe.py, profiles/r4_one_call.txt).  KGE_ONE_CALL_PREPARED=0/1 forces either.
+static bool one_call_prepared(const kge_tables* t, const Operand& TG, int64_t n, int64_t m, int64_t ws_bytes, bool two_sided) {
+  const char* e = getenv("KGE_ONE_CALL_PREPARED");
+  if (e && e[0] == '0') return false;
+  if (t->dim != 512 || TG.idx.ptr != nullptr) return false;
+  if (ws_bytes < PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, two_sided, false)) return false;
+  if (e && e[0] == '1') return true;
+  // measured, FB15k-237 shape: two-sided n = 512 27.3 -> 24.9 us, n = 1024 41.8 -> 40.9; one-sided equal (16.8 / 16.7);
+  // n <= 128: the second launch costs more than the round trips it saves (13.1 -> 14.6)
+  return two_sided && m >= 2048 && n >= 256;
+}
+
 int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand& R,
                    const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo,
                    void* ws, int64_t ws_bytes, hipStream_t st) {
@@ -222,6 +236,13 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
     const bool v1 = t->flags & KGE_FLAG_BF16_V1;
     if (!v1 && !(t->flags & KGE_FLAG_BF16_V3) && ws != nullptr &&
         pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
+      if (one_call_prepared(t, TG, n, m, ws_bytes, false)) {
+        const int rcp = run_pairs_bf16_v4_prepared(t->scorer, false, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st,
+                                                   nullptr, nullptr, ws, ws_bytes,
+                                                   (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr,
+                                                   nullptr, 0, nullptr);
+        if (rcp != KGE_ERR_UNSUPPORTED) return rcp;
+      }
       const int rc = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr,
                                        ws, ws_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
       if (rc != KGE_ERR_UNSUPPORTED) return rc;  // else: launch conditions not met, single-role kernel
@@ -516,6 +537,15 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
     }
     if (!split && pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
         pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
+      if (one_call_prepared(t, TG, n, m, workspace_bytes, true)) {
+        // two launches -- the query build, then the scoring launch on prepared queries (pairs_bf16_v7_kernel) -- beat the
+        // one launch with the in-launch cooperative build (five dependent round trips before the first score)
+        const int rcp = run_pairs_bf16_v4_prepared(t->scorer, false, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
+                                                   (hipStream_t)stream, nullptr, nullptr, workspace, workspace_bytes,
+                                                   (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr,
+                                                   nullptr, 0, nullptr);
+        if (rcp != KGE_ERR_UNSUPPORTED) return rcp;
+      }
       const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
                                         (hipStream_t)stream, nullptr, workspace, workspace_bytes,
                                         (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
