@@ -1,0 +1,39 @@
+/*
+ * kge_amd_debug.h -- measurement hooks of libkge_amd.so.  NOT part of the drop-in boundary (include/kge_amd.h): nothing
+ * in kge_amd/ calls them; tools/ (cycle-stamp probes) and two tests do.  They exist in every build of the library so
+ * that a profile in profiles/ can be reproduced on the shipped binary.
+ *
+ * A "stamp buffer" is 64 x uint64 per workgroup of the next launch(es), written with s_memtime by one lane of the
+ * kernel at the points its source marks with stamp(); NULL switches stamping off again.  Stamps are stores: with
+ * stamping on, a kernel's counted vector-memory waits cover more operations and it runs slower than in production.
+ */
+#ifndef KGE_AMD_DEBUG_H
+#define KGE_AMD_DEBUG_H
+
+#include "kge_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* stamp buffer for the scoring launches of kge_ce_fwd / kge_ce_bwd (tools/ce_phases.py) */
+void kge_debug_ce_stamps(unsigned long long* stamps);
+/* stamp buffer for the prepared-query scoring / counting launches (pairs_bf16_v6 / v7 / v8 / v8_rank kernels) that are
+ * given none of their own (tools/v6_probe.py, tools/v8_probe.py, tools/r4_diag.py, tools/rank8_stamps.py) */
+void kge_debug_v6_stamps(unsigned long long* stamps);
+/* stamp buffer for gemm16_kernel (tools/gemm16_phases.py) */
+void kge_debug_gemm16_stamps(unsigned long long* stamps);
+/* one gradient contraction of the mixed-precision backward on its own: which 0 = dQ = G T, 1 = dT = G^T Q; lib 0 =
+ * gemm16_kernel, 1 = gemm32_kernel on the widened operands (tests/test_gpu_bwd_gemm16.py, tools/gemm16_probe.py) */
+int kge_debug_gemm16(int which, int lib, int d, int64_t rows, int64_t m, const void* x, int64_t ldx, const void* g16,
+                     int64_t mp, float* out, float* scratch, int64_t scratch_bytes, void* stream);
+/* kge_score_sp of bf16 tables with a stamp buffer of its own (tools/v2_phases.py, tools/prep_probe.py).  ablate 0: the
+ * one-call path; 100 / 101: builder launch + scoring launch on prepared / prepared split queries */
+int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, int64_t n, int64_t m, float* out,
+                               int64_t ldo, unsigned long long* stamps, int ablate, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGE_AMD_DEBUG_H */

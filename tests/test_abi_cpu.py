@@ -29,6 +29,19 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.kge_status_string(-1) == b"invalid argument"
 
 
+def test_debug_exports_are_exactly_the_declared_ones(lib):
+    """Every exported kge_* symbol is declared: the boundary in include/kge_amd.h, the measurement hooks
+    (kge_debug_*) in include/kge_amd_debug.h -- nothing rides along undeclared."""
+    import subprocess
+    from kge_amd import _lib
+    dbg = open(os.path.join(ROOT, "include", "kge_amd_debug.h")).read()
+    declared_dbg = set(re.findall(r"^(?:int|void)\s+(kge_debug_\w+)\s*\(", dbg, flags=re.M))
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("kge_")}
+    assert exported == set(_lib.PROTOTYPES) | declared_dbg, exported ^ (set(_lib.PROTOTYPES) | declared_dbg)
+    assert declared_dbg and all(n.startswith("kge_debug_") for n in declared_dbg)
+
+
 def test_struct_layout_matches_header():
     import ctypes
     from kge_amd._lib import KgeIndex, KgeTables
