@@ -494,6 +494,33 @@ int kge_ce_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_l
                    float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* KvsAll training over an entity-SHARDED table (BASELINE configs[3]; TrainingJobKvsAll._process_subbatch,
+ * kge/job/train_KvsAll.py:216-294, with the entity table row-sharded as SURVEY.md 8e lays out): kge_kl_weighted_fwd /
+ * _bwd and kge_bce_fwd / _bwd with DENSE query rows (a_rows [n, dim], p_rows [n, rel_dim]: they come out of the
+ * exchange between the shards) against ALL rows of t->ent = this rank's shard, whose rows are the GLOBAL entity ids
+ * [col_lo, col_lo + t->num_ent).  lbl_col holds GLOBAL ids: labels outside the shard are skipped (another rank adds
+ * them), so that
+ *   kl:   loss_rows[i] = lse_shard[i] - w_i * sum_{labels of row i IN this shard} score;  the caller merges the shards'
+ *         lse (log-sum-exp) and sums the label terms; the backward takes the GLOBAL lse;
+ *   bce:  loss_rows[i] = this shard's part of the sum over all entities: the caller adds the shards' values.
+ * Gradients as kge_ce_emb_bwd: g_a / g_p = this shard's part of the query-row gradients, g_tgt = the shard's rows. */
+int kge_kl_weighted_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows,
+                            int64_t p_ld, int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo,
+                            const float* label_weight, float* loss_rows, float* lse, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+int kge_kl_weighted_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows,
+                            int64_t p_ld, int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo,
+                            const float* label_weight, const float* label_bias /* [n] or NULL */, const float* lse,
+                            const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
+                            int64_t workspace_bytes, void* stream);
+int kge_bce_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
+                    int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo, float offset,
+                    float* loss_rows, void* workspace, int64_t workspace_bytes, void* stream);
+int kge_bce_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
+                    int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo, float offset,
+                    const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+
 /* Both directions of a 1vsAll batch at once (train_1vsAll.py:64-81 in one pass): rows [0, n) of
  * loss_rows / lse / g_rows are the (s, p, ?) queries with labels o, rows [n, 2n) the (?, p, o)
  * queries with labels s.  One scoring launch for both sides; the gradient products run once

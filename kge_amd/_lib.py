@@ -121,6 +121,14 @@ PROTOTYPES = {
                                       c_vp, c_i64, c_vp]),
     "kge_ce_emb_bwd": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, KgeIndex, c_i64, c_vp, c_vp,
                                       ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kge_kl_weighted_emb_fwd": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp,
+                                               c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kge_kl_weighted_emb_bwd": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp,
+                                               c_vp, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kge_bce_emb_fwd": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64,
+                                       ctypes.c_float, c_vp, c_vp, c_i64, c_vp]),
+    "kge_bce_emb_bwd": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64,
+                                       ctypes.c_float, c_vp, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_adam_step": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_float, ctypes.c_float, ctypes.c_double,
                                      ctypes.c_double, ctypes.c_float, ctypes.c_float, c_vp, c_vp]),
     "kge_adagrad_step_rows": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64,

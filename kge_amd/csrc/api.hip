@@ -105,10 +105,11 @@ long long ce_workspace_bytes(int d, long long n, long long m);
 void ce_set_stamps(unsigned long long* p);
 int run_bce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                 long long m, const long long* rowptr, const long long* col, float offset, float* loss_rows, void* ws,
-                long long ws_bytes, hipStream_t st);
+                long long ws_bytes, hipStream_t st, long long col_lo = 0);
 int run_bce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                 long long m, const long long* rowptr, const long long* col, float offset, const float* g_rows,
-                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st);
+                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
+                long long col_lo = 0);
 long long ce2_workspace_bytes(int d, long long n, long long m);
 int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, float* loss_rows, float* lse, void* ws, long long ws_bytes,
@@ -126,11 +127,11 @@ int run_adagrad_rows(float* param, long long param_ld, const float* grows, long 
                      unsigned short* copy16, long long c_ld, hipStream_t st);
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, float* loss_rows, float* lse, void* ws,
-               long long ws_bytes, hipStream_t st, const float* label_weight = nullptr);
+               long long ws_bytes, hipStream_t st, const float* label_weight = nullptr, long long col_lo = 0);
 int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, const float* lse, const float* g_rows,
                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
-               const float* label_weight = nullptr, const float* label_bias = nullptr);
+               const float* label_weight = nullptr, const float* label_bias = nullptr, long long col_lo = 0);
 void set_g16_dbg(unsigned long long* p);
 void v6_set_stamps(unsigned long long* p);
 bool pairs_bf16_v4_rank_launchable(int d, long long n, long long m, long long ws_bytes);
@@ -805,7 +806,9 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
                            const int64_t* const* po_begin, const int64_t* const* po_end, const int64_t* const* po_col,
                            float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po,
                            int64_t* ties_po, int64_t ld, void* filter_bits, int64_t filter_bits_bytes, void* workspace,
-                           int64_t workspace_bytes, void* stream, int64_t true_stride = 1, bool manage_bits = true) {
+                           int64_t workspace_bytes, void* stream, int64_t true_stride = 1, bool manage_bits = true,
+                           bool queries_ready = false) {
+  // queries_ready (kge_eval_batch): the batch's query fragments already sit in the workspace (behind its control block)
   // manage_bits = false (kge_eval_batch): the filter bits are set already and are cleared by the caller; the lists
   // are not looked at
   if (!true_sp || !true_po || !rank_sp || !ties_sp || !rank_po || !ties_po || ld < n) return KGE_ERR_INVALID_ARG;
@@ -899,7 +902,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   if (v8_rank) {
     // query fragments into the workspace (one small launch), then the persistent counting kernel: any n, no co-residency
     void* qf = (char*)workspace + PAIRS_WS_CTRL_BYTES;
-    rc = run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
+    if (!queries_ready) rc = run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
     if (rc == KGE_OK)
       rc = run_pairs_bf16_v8_rank(t->scorer, split, TG, (int)t->dim, n, m, qf, ce, st, nullptr,
                                   (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
@@ -1051,26 +1054,51 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
   // (2) the true scores: the batch against its own targets, [n, 4 n] = (sp_ vs o | s, _po vs o | s); the diagonals
   // (i, i) and (i, 3 n + i) are elements of the score matrix bit for bit (each score is its own chain)
   kge_index tgi{tgt, KGE_I64, 0, 1};
-  rc = kge_score_sp_po(t, s, p, o, n, tgi, 2 * n, trueblk, 4 * n, workspace, workspace_bytes, stream);
+  kge_index all{nullptr, KGE_I64, 0, 1};
+  const Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, all);
+  // bf16 ComplEx / DistMult at dim 256 / 512: the batch's query fragments are built ONCE (one small launch) and serve
+  // both the true scores and the counting launch (pairs_bf16_v8_rank_kernel), which then start on prepared queries
+  const bool dot = t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT;
+  const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
+  const char* e8 = getenv("KGE_V8_RANK");
+  bool ready = t->dtype == KGE_BF16 && dot && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) &&
+               (t->dim == 256 || t->dim == 512) && !(e8 && e8[0] == '0') && workspace && !((uintptr_t)workspace & 15) &&
+               workspace_bytes >= PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, split) &&
+               pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
+               pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG);
+  if (ready) {
+    void* qf = (char*)workspace + PAIRS_WS_CTRL_BYTES;
+    rc = run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
+    if (rc == KGE_OK) {
+      const Operand TL = ent_op(t, tgi);
+      rc = run_pairs_bf16_v4_prepared(t->scorer, split, S, &O, P, TL, KGE_SP_, (int)t->dim, n, 2 * n, trueblk, 4 * n, 2 * n,
+                                      st, nullptr, qf, workspace, workspace_bytes, 0, nullptr, nullptr, nullptr, 0, nullptr);
+      if (rc == KGE_ERR_UNSUPPORTED) {  // (a launch the loader/consumer kernel declines: the one-call path)
+        ready = false;
+        rc = kge_score_sp_po(t, s, p, o, n, tgi, 2 * n, trueblk, 4 * n, workspace, workspace_bytes, stream);
+      }
+    }
+  } else {
+    rc = kge_score_sp_po(t, s, p, o, n, tgi, 2 * n, trueblk, 4 * n, workspace, workspace_bytes, stream);
+  }
   // (3) scores + counts against all entities, no score matrix
   const int M = num_filters + 1;
   const int64_t per = (int64_t)M * n;
-  if (rc == KGE_OK) {
-    kge_index all{nullptr, KGE_I64, 0, 1};
-    const Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, all);
+  if (rc == KGE_OK)
     rc = score_rank_core(t, S, O, P, TG, oi, si, n, 0, m, trueblk, trueblk + 3 * n, num_filters, nullptr, nullptr,
                          nullptr, nullptr, nullptr, nullptr, atol, rtol, counts, counts + per, counts + 2 * per,
                          counts + 3 * per, n, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream,
-                         4 * n + 1, /*manage_bits=*/false);
-  }
-  // (4) bits cleared, tie policy + histograms, counters back to zero -- also behind a declined step (3), whose
-  // counters are untouched zeros: the histogram part is then skipped by the caller's fallback (nothing was counted)
-  if (rc == KGE_ERR_UNSUPPORTED) {
+                         4 * n + 1, /*manage_bits=*/false, /*queries_ready=*/ready);
+  // (4) bits cleared, tie policy + histograms, counters back to zero.  Behind a declined step (3) (counters untouched)
+  // and behind ANY failure of steps (2) / (3): the bits are cleared and the counters zeroed all the same -- the buffers
+  // are persistent and the next batch relies on finding them all-zero (advisor, round 3)
+  if (rc != KGE_OK) {
     EvalLists Lc = L;  // clear only
     const int rc2 = run_eval_end(Lc, n, m, bld, 0, tie_policy, (long long*)counts, hist, ldh, E, nullptr, nullptr, st);
-    return rc2 != KGE_OK ? rc2 : KGE_ERR_UNSUPPORTED;
+    if (rc != KGE_ERR_UNSUPPORTED)  // a failed launch may have left partial counts behind
+      (void)hipMemsetAsync(counts, 0, (size_t)(4 * per) * sizeof(int64_t), st);
+    return rc == KGE_ERR_UNSUPPORTED && rc2 != KGE_OK ? rc2 : rc;
   }
-  if (rc != KGE_OK) return rc;
   return run_eval_end(L, n, m, bld, M, tie_policy, (long long*)counts, hist, ldh, E, (long long*)ranks_o,
                       (long long*)ranks_s, st);
 }
@@ -1206,6 +1234,64 @@ int kge_ce_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_l
   if (n > 0 && (!lse || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
   return run_ce_bwd(t->scorer, A, R, TG, dir, (int)t->dim, n, t->num_ent, make_index(label), lse, g_rows, g_scalar, g_a,
                     g_p, g_tgt, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// KvsAll losses on dense query rows against this rank's shard (entity-sharded training): label columns are GLOBAL
+// entity ids, the shard's rows being the ids [col_lo, col_lo + t->num_ent); labels of other shards are skipped.
+int kge_kl_weighted_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows,
+                            int64_t p_ld, int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo,
+                            const float* label_weight, float* loss_rows, float* lse, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+  Operand A, R, TG;
+  const kge_index none = {nullptr, 0, 0, 1};
+  const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, none, n, A, R, TG);
+  if (rc) return rc;
+  if (n > 0 && (!lbl_rowptr || !lbl_col || !label_weight || !loss_rows || !lse)) return KGE_ERR_INVALID_ARG;
+  return run_kl_fwd(t->scorer, A, R, TG, dir, (int)t->dim, n, t->num_ent, (const long long*)lbl_rowptr,
+                    (const long long*)lbl_col, loss_rows, lse, workspace, workspace_bytes, (hipStream_t)stream,
+                    label_weight, col_lo);
+}
+
+int kge_kl_weighted_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows,
+                            int64_t p_ld, int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo,
+                            const float* label_weight, const float* label_bias, const float* lse, const float* g_rows,
+                            float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+  Operand A, R, TG;
+  const kge_index none = {nullptr, 0, 0, 1};
+  const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, none, n, A, R, TG);
+  if (rc) return rc;
+  if (n > 0 && (!lbl_rowptr || !lbl_col || !label_weight || !lse || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
+  return run_kl_bwd(t->scorer, A, R, TG, dir, (int)t->dim, n, t->num_ent, (const long long*)lbl_rowptr,
+                    (const long long*)lbl_col, lse, g_rows, g_scalar, g_a, g_p, g_tgt, workspace, workspace_bytes,
+                    (hipStream_t)stream, label_weight, label_bias, col_lo);
+}
+
+int kge_bce_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
+                    int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo, float offset,
+                    float* loss_rows, void* workspace, int64_t workspace_bytes, void* stream) {
+  Operand A, R, TG;
+  const kge_index none = {nullptr, 0, 0, 1};
+  const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, none, n, A, R, TG);
+  if (rc) return rc;
+  if (n > 0 && (!lbl_rowptr || !lbl_col || !loss_rows)) return KGE_ERR_INVALID_ARG;
+  return run_bce_fwd(t->scorer, A, R, TG, dir, (int)t->dim, n, t->num_ent, (const long long*)lbl_rowptr,
+                     (const long long*)lbl_col, offset, loss_rows, workspace, workspace_bytes, (hipStream_t)stream,
+                     col_lo);
+}
+
+int kge_bce_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
+                    int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo, float offset,
+                    const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
+  Operand A, R, TG;
+  const kge_index none = {nullptr, 0, 0, 1};
+  const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, none, n, A, R, TG);
+  if (rc) return rc;
+  if (n > 0 && (!lbl_rowptr || !lbl_col || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
+  return run_bce_bwd(t->scorer, A, R, TG, dir, (int)t->dim, n, t->num_ent, (const long long*)lbl_rowptr,
+                     (const long long*)lbl_col, offset, g_rows, g_scalar, g_a, g_p, g_tgt, workspace, workspace_bytes,
+                     (hipStream_t)stream, col_lo);
 }
 
 int64_t kge_ce_sp_po_workspace_bytes(const kge_tables* t, int64_t n) {

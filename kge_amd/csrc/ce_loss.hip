@@ -80,7 +80,11 @@ template <int SCORER>
 __global__ __launch_bounds__(256) void kl_label_kernel(Operand A, Operand R, Operand TG, int dir, int d,
                                                        long long n, const long long* __restrict__ rowptr,
                                                        const long long* __restrict__ col,
-                                                       float* __restrict__ label_sum) {
+                                                       float* __restrict__ label_sum, long long col_lo, long long m,
+                                                       float* __restrict__ label_cnt) {
+  // label columns are ids in [col_lo, col_lo + m) of the scored rows TG (entity-sharded training: GLOBAL ids, this
+  // rank's shard starting at col_lo); ids outside the range belong to other shards and are skipped.  label_cnt
+  // (may be NULL): the number of the row's labels inside the range
   const int lane = threadIdx.x & 63;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -94,8 +98,12 @@ __global__ __launch_bounds__(256) void kl_label_kernel(Operand A, Operand R, Ope
     if (c < hp) bf16_qpair<SCORER>(dir, a[c], a[hp + c], r[c], r[hp + c], q0[u], q1[u]);
   }
   float tsum = 0.0f;
+  int cnt = 0;
   for (long long e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-    const unsigned int* t = (const unsigned int*)((const unsigned short*)TG.base + col[e] * TG.ld);
+    const long long cl = col[e] - col_lo;
+    if (cl < 0 || cl >= m) continue;
+    ++cnt;
+    const unsigned int* t = (const unsigned int*)((const unsigned short*)TG.base + cl * TG.ld);
     float acc = 0.0f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -112,7 +120,10 @@ __global__ __launch_bounds__(256) void kl_label_kernel(Operand A, Operand R, Ope
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
     tsum += acc;
   }
-  if (lane == 0) label_sum[i] = tsum;
+  if (lane == 0) {
+    label_sum[i] = tsum;
+    if (label_cnt != nullptr) label_cnt[i] = (float)cnt;
+  }
 }
 
 __global__ __launch_bounds__(256) void kl_combine_kernel(const float* __restrict__ part, int ncg, long long n,
@@ -148,7 +159,8 @@ __global__ __launch_bounds__(256) void kl_sub_kernel(unsigned short* __restrict_
                                                      const long long* __restrict__ rowptr,
                                                      const long long* __restrict__ col,
                                                      const float* __restrict__ g_rows, float g_scalar,
-                                                     const float* __restrict__ label_weight) {
+                                                     const float* __restrict__ label_weight, long long col_lo,
+                                                     long long m) {
   const int lane = threadIdx.x & 63;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -157,7 +169,9 @@ __global__ __launch_bounds__(256) void kl_sub_kernel(unsigned short* __restrict_
   const float gi = g_rows != nullptr ? g_rows[i] : g_scalar;
   const float y = label_weight != nullptr ? gi * label_weight[i] : gi / (float)(e - b);
   for (long long x = b + lane; x < e; x += 64) {
-    unsigned short* p = g16 + i * ld16 + col[x];
+    const long long cl = col[x] - col_lo;
+    if (cl < 0 || cl >= m) continue;  // another shard's column
+    unsigned short* p = g16 + i * ld16 + cl;
     const float v = __uint_as_float((unsigned int)*p << 16) - y;
     *p = (unsigned short)(bf16_pack(v, 0.0f) & 0xffffu);
   }
@@ -173,7 +187,8 @@ __global__ __launch_bounds__(256) void kl_sub_kernel(unsigned short* __restrict_
 __global__ __launch_bounds__(256) void bce_combine_kernel(const float* __restrict__ part, int ncg, long long n,
                                                           const float* __restrict__ label_sum,
                                                           const long long* __restrict__ rowptr, float offset,
-                                                          float* __restrict__ loss_rows) {
+                                                          float* __restrict__ loss_rows,
+                                                          const float* __restrict__ label_cnt) {
   const int lane = threadIdx.x & 63;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
@@ -183,8 +198,8 @@ __global__ __launch_bounds__(256) void bce_combine_kernel(const float* __restric
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) S += __shfl_xor(S, off, 64);
   if (lane == 0) {
-    const long long k = rowptr[i + 1] - rowptr[i];
-    loss_rows[i] = S - (label_sum[i] + (float)k * offset);
+    const float k = label_cnt != nullptr ? label_cnt[i] : (float)(rowptr[i + 1] - rowptr[i]);  // labels in range
+    loss_rows[i] = S - (label_sum[i] + k * offset);
   }
 }
 
@@ -192,13 +207,16 @@ __global__ __launch_bounds__(256) void bce_combine_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bce_sub_kernel(unsigned short* __restrict__ g16, long long ld16, long long n,
                                                       const long long* __restrict__ rowptr,
                                                       const long long* __restrict__ col,
-                                                      const float* __restrict__ g_rows, float g_scalar) {
+                                                      const float* __restrict__ g_rows, float g_scalar,
+                                                      long long col_lo, long long m) {
   const int lane = threadIdx.x & 63;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const float y = g_rows != nullptr ? g_rows[i] : g_scalar;
   for (long long x = rowptr[i] + lane; x < rowptr[i + 1]; x += 64) {
-    unsigned short* p = g16 + i * ld16 + col[x];
+    const long long cl = col[x] - col_lo;
+    if (cl < 0 || cl >= m) continue;  // another shard's column
+    unsigned short* p = g16 + i * ld16 + cl;
     const float v = __uint_as_float((unsigned int)*p << 16) - y;
     *p = (unsigned short)(bf16_pack(v, 0.0f) & 0xffffu);
   }
@@ -249,7 +267,7 @@ static inline long long ce_ld16(long long m) { return (m + 63) & ~63LL; }
 
 long long ce_workspace_bytes(int d, long long n, long long m) {
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
-  const long long fwd = al256(n * pairs_bf16_v3_column_groups(n, m) * 8) + al256(n * 4);
+  const long long fwd = al256(n * pairs_bf16_v3_column_groups(n, m) * 8) + 2 * al256(n * 4);  // partials, label sums, counts
   const long long bwd = al256(n * ce_ld16(m) * 2) + al256(n * (long long)d * 2);
   return coop + (fwd > bwd ? fwd : bwd);
 }
@@ -300,7 +318,7 @@ int run_ce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
 
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, float* loss_rows, float* lse, void* ws,
-               long long ws_bytes, hipStream_t st, const float* label_weight) {
+               long long ws_bytes, hipStream_t st, const float* label_weight, long long col_lo) {
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
@@ -313,10 +331,10 @@ int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   const dim3 grid((unsigned)((n + 3) / 4));
   if (scorer == KGE_COMPLEX)
     hipLaunchKernelGGL(kl_label_kernel<KGE_COMPLEX>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
-                       ce.true_score);
+                       ce.true_score, col_lo, m, (float*)nullptr);
   else
     hipLaunchKernelGGL(kl_label_kernel<KGE_DISTMULT>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
-                       ce.true_score);
+                       ce.true_score, col_lo, m, (float*)nullptr);
   hipLaunchKernelGGL(kl_combine_kernel, grid, dim3(256), 0, st, ce.part, ncg, n, ce.true_score, rowptr, loss_rows,
                      lse, label_weight);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
@@ -325,7 +343,7 @@ int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
 int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                long long m, const long long* rowptr, const long long* col, const float* lse, const float* g_rows,
                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
-               const float* label_weight, const float* label_bias) {
+               const float* label_weight, const float* label_bias, long long col_lo) {
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
@@ -344,14 +362,14 @@ int run_kl_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   const int rc = run_ds_pass(scorer, V3_DS, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(kl_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.g16, ld16, n, rowptr, col,
-                     g_rows, g_scalar, label_weight);
+                     g_rows, g_scalar, label_weight, col_lo, m);
   if (hipGetLastError() != hipSuccess) return KGE_ERR_LAUNCH;
   return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
 }
 
 int run_bce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                 long long m, const long long* rowptr, const long long* col, float offset, float* loss_rows, void* ws,
-                long long ws_bytes, hipStream_t st) {
+                long long ws_bytes, hipStream_t st, long long col_lo) {
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
@@ -363,20 +381,22 @@ int run_bce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& T
   const int rc = run_pairs_bf16_v3_ce(scorer, V3_SPLUS, A, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   const dim3 grid((unsigned)((n + 3) / 4));
+  float* cnt = ce.true_score + al256(n * 4) / 4;  // the rows' counts of labels in range, behind the label sums
   if (scorer == KGE_COMPLEX)
     hipLaunchKernelGGL(kl_label_kernel<KGE_COMPLEX>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
-                       ce.true_score);
+                       ce.true_score, col_lo, m, cnt);
   else
     hipLaunchKernelGGL(kl_label_kernel<KGE_DISTMULT>, grid, dim3(256), 0, st, A, R, TG, dir, d, n, rowptr, col,
-                       ce.true_score);
+                       ce.true_score, col_lo, m, cnt);
   hipLaunchKernelGGL(bce_combine_kernel, grid, dim3(256), 0, st, ce.part, ncg, n, ce.true_score, rowptr, offset,
-                     loss_rows);
+                     loss_rows, (const float*)cnt);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
 int run_bce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
                 long long m, const long long* rowptr, const long long* col, float offset, const float* g_rows,
-                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st) {
+                float g_scalar, float* g_a, float* g_p, float* g_tgt, void* ws, long long ws_bytes, hipStream_t st,
+                long long col_lo) {
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
@@ -391,7 +411,7 @@ int run_bce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& T
   const int rc = run_ds_pass(scorer, V3_DSIG, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(bce_sub_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.g16, ld16, n, rowptr, col,
-                     g_rows, g_scalar);
+                     g_rows, g_scalar, col_lo, m);
   if (hipGetLastError() != hipSuccess) return KGE_ERR_LAUNCH;
   return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
 }

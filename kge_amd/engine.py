@@ -1352,6 +1352,90 @@ def kl_bwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, lse, g_rows=Non
     return g_a, g_p, g_t
 
 
+# ---- KvsAll losses on dense query rows against ONE shard of the entity table (kge_amd.sharded) -----------------------
+def _emb_loss_args(t, a_rows, p_rows, lbl_rowptr, lbl_col):
+    n = a_rows.shape[0]
+    if a_rows.dim() != 2 or p_rows.dim() != 2 or p_rows.shape[0] != n or a_rows.stride(1) != 1 or p_rows.stride(1) != 1:
+        raise ValueError("kge_amd: dense query rows must be [n, dim] / [n, rel_dim] with unit inner stride")
+    if a_rows.dtype != t.ent.dtype or p_rows.dtype != t.rel.dtype:
+        raise ValueError("kge_amd: dense query rows must have the tables' dtype")
+    rp, cl = _csr64(lbl_rowptr, lbl_col, t.device)
+    if rp.numel() != n + 1:
+        raise ValueError(f"kge_amd: label rowptr has {rp.numel()} entries for {n} rows")
+    return n, rp, cl
+
+
+def kl_emb_fwd(t: Tables, direction: str, a_rows, p_rows, lbl_rowptr, lbl_col, col_lo: int, label_weight):
+    """(loss_rows [n], lse [n]) of kge_kl_weighted_emb_fwd: this shard's log-sum-exp and lse - w_i * (sum of the
+    scores of row i's labels INSIDE the shard [col_lo, col_lo + num_ent); lbl_col holds global ids)."""
+    n, rp, cl = _emb_loss_args(t, a_rows, p_rows, lbl_rowptr, lbl_col)
+    lw = _f32c(label_weight, t.device)
+    loss_rows, lse = _empty((n,), t.device), _empty((n,), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_kl_weighted_emb_fwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, a_rows.data_ptr(), a_rows.stride(0), p_rows.data_ptr(),
+            p_rows.stride(0), n, rp.data_ptr(), cl.data_ptr(), int(col_lo), lw.data_ptr(), loss_rows.data_ptr(),
+            lse.data_ptr(), ws, wsb, st), "kge_kl_weighted_emb_fwd")
+    return loss_rows, lse
+
+
+def kl_emb_bwd(t: Tables, direction: str, a_rows, p_rows, lbl_rowptr, lbl_col, col_lo: int, label_weight, lse,
+               g_rows=None, g_scalar: float = 1.0, label_bias=None):
+    """Backward of kl_emb_fwd with the GLOBAL log-sum-exp: (g_a [n, d], g_p [n, d_r], g_shard [num_ent, d])."""
+    n, rp, cl = _emb_loss_args(t, a_rows, p_rows, lbl_rowptr, lbl_col)
+    lw, lse = _f32c(label_weight, t.device), _f32c(lse, t.device)
+    gr = None if g_rows is None else _f32c(g_rows, t.device)
+    lb = None if label_bias is None else _f32c(label_bias, t.device)
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((t.num_ent, d), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_kl_weighted_emb_bwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, a_rows.data_ptr(), a_rows.stride(0), p_rows.data_ptr(),
+            p_rows.stride(0), n, rp.data_ptr(), cl.data_ptr(), int(col_lo), lw.data_ptr(),
+            None if lb is None else lb.data_ptr(), lse.data_ptr(), None if gr is None else gr.data_ptr(), float(g_scalar),
+            g_a.data_ptr(), g_p.data_ptr(), g_t.data_ptr(), ws, wsb, st), "kge_kl_weighted_emb_bwd")
+    return g_a, g_p, g_t
+
+
+def bce_emb_fwd(t: Tables, direction: str, a_rows, p_rows, lbl_rowptr, lbl_col, col_lo: int, offset: float = 0.0):
+    """loss_rows [n]: this shard's part of sum_j BCEWithLogits(score(i, j) + offset, y_ij) (kge_bce_emb_fwd)."""
+    n, rp, cl = _emb_loss_args(t, a_rows, p_rows, lbl_rowptr, lbl_col)
+    loss_rows = _empty((n,), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_bce_emb_fwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, a_rows.data_ptr(), a_rows.stride(0), p_rows.data_ptr(),
+            p_rows.stride(0), n, rp.data_ptr(), cl.data_ptr(), int(col_lo), float(offset), loss_rows.data_ptr(), ws, wsb,
+            st), "kge_bce_emb_fwd")
+    return loss_rows
+
+
+def bce_emb_bwd(t: Tables, direction: str, a_rows, p_rows, lbl_rowptr, lbl_col, col_lo: int, offset: float = 0.0,
+                g_rows=None, g_scalar: float = 1.0):
+    n, rp, cl = _emb_loss_args(t, a_rows, p_rows, lbl_rowptr, lbl_col)
+    gr = None if g_rows is None else _f32c(g_rows, t.device)
+    d, dr = t.ent.shape[1], t.rel.shape[1]
+    g_a, g_p, g_t = _empty((n, d), t.device), _empty((n, dr), t.device), _empty((t.num_ent, d), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_bce_emb_bwd(
+            ctypes.byref(tc), SP_ if direction == "sp" else PO_, a_rows.data_ptr(), a_rows.stride(0), p_rows.data_ptr(),
+            p_rows.stride(0), n, rp.data_ptr(), cl.data_ptr(), int(col_lo), float(offset),
+            None if gr is None else gr.data_ptr(), float(g_scalar), g_a.data_ptr(), g_p.data_ptr(), g_t.data_ptr(), ws,
+            wsb, st), "kge_bce_emb_bwd")
+    return g_a, g_p, g_t
+
+
 def bce_fwd(t: Tables, direction: str, a, p, lbl_rowptr, lbl_col, offset: float = 0.0):
     """Fused score_sp / score_po + BCEWithLogits (summed over all entities) against the rows'
     multi-hot labels (int64 CSR): loss_rows [n]; kge/util/loss.py:137-159, bce_type None."""

@@ -72,19 +72,165 @@ class _ShardedCE(torch.autograd.Function):
         t16 = sh._tables(sh.ent_local, "local")
         g_a, g_p, g_t = sh.backend.ce_emb_bwd(t16, ctx.direction, rows, rel_rows, lab_local, lse,
                                               g_rows=g_rows.contiguous())
-        d = g_a.shape[1]
-        both = torch.cat([g_a, g_p], dim=1)  # this shard's part of the query-row gradients
-        sh._allreduce(both)
-        g_a, g_p = both[:, :d], both[:, d:]
-        gid = ids.reshape(-1).long()
-        own = ((gid >= sh.lo) & (gid < sh.hi)).to(g_a.dtype).unsqueeze(1)
-        local = (gid - sh.lo).clamp_(0, max(sh.hi - sh.lo - 1, 0))
-        ge = g_t  # [E_g, d], fresh: the gradient of this shard's rows as targets ...
-        if sh.hi > sh.lo:
-            ge.index_add_(0, local, g_a * own)  # ... plus the query rows it owns (others add zeros)
-        gr = torch.zeros(rel_shape, dtype=torch.float32, device=g_p.device)
-        gr.index_add_(0, p.reshape(-1).long(), g_p.contiguous())  # the same on every rank
-        return None, None, ge.to(torch.float32).view(ent_shape), gr, None, None, None
+        ge, gr = _merge_query_grads(sh, ids, p, g_a, g_p, g_t, ent_shape, rel_shape)
+        return None, None, ge, gr, None, None, None
+
+
+def _merge_query_grads(sh, ids, p, g_a, g_p, g_t, ent_shape, rel_shape):
+    """The tail of every sharded loss backward: this shard's part of the query-row gradients summed over the shards
+    (ONE all-reduce of [n, d + d_r] floats), the owners scatter-add them into the gradient of their own rows (g_t:
+    fresh, never leaves the rank); the relation gradient comes out identical on every rank."""
+    d = g_a.shape[1]
+    both = torch.cat([g_a, g_p], dim=1)
+    sh._allreduce(both)
+    g_a, g_p = both[:, :d], both[:, d:]
+    gid = ids.reshape(-1).long()
+    own = ((gid >= sh.lo) & (gid < sh.hi)).to(g_a.dtype).unsqueeze(1)
+    local = (gid - sh.lo).clamp_(0, max(sh.hi - sh.lo - 1, 0))
+    ge = g_t
+    if sh.hi > sh.lo:
+        ge.index_add_(0, local, g_a * own)
+    gr = torch.zeros(rel_shape, dtype=torch.float32, device=g_p.device)
+    gr.index_add_(0, p.reshape(-1).long(), g_p.contiguous())
+    return ge.to(torch.float32).view(ent_shape), gr
+
+
+class _ShardedKL(torch.autograd.Function):
+    """Per-row KL divergence of softmax(score(i, .)) over the entities of ALL shards from the row's normalised
+    multi-hot labels (TrainingJobKvsAll with train.loss: kl, kge/job/train_KvsAll.py:244-294, kge/util/loss.py:208-213):
+    loss_i = lse_i - (1 / k_i) sum_{j in labels_i} score(i, j) - log k_i  (0 for a row without labels).  The label CSR
+    holds GLOBAL entity ids and is the same on every rank: each shard's kernel takes the labels it owns."""
+
+    @staticmethod
+    def forward(ctx, sh, direction, ent_master, rel_master, ids, p, rowptr, col):
+        rows, rel_rows = sh.exchange_rows([ids], p)
+        rows, rel_rows = rows.clone(), rel_rows.clone()
+        k = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+        has = k > 0
+        w = torch.where(has, 1.0 / k.clamp(min=1.0), torch.zeros_like(k))
+        t16 = sh._tables(sh.ent_local, "local")
+        loss_loc, lse_loc = sh.backend.kl_emb_fwd(t16, direction, rows, rel_rows, rowptr, col, sh.lo, w)
+        lab = lse_loc - loss_loc  # w_i * (sum of the label scores inside this shard)
+        if sh.collectives:
+            allse = torch.empty(sh.world * lse_loc.numel(), dtype=lse_loc.dtype, device=lse_loc.device)
+            dist.all_gather_into_tensor(allse, lse_loc.contiguous(), group=sh.group)
+            lse = torch.logsumexp(allse.view(sh.world, -1), dim=0)
+            dist.all_reduce(lab, op=dist.ReduceOp.SUM, group=sh.group)
+        else:
+            lse = lse_loc
+        ctx.sh, ctx.direction = sh, direction
+        ctx.meta = (ids, p, rowptr, col, ent_master.shape, rel_master.shape)
+        ctx.save_for_backward(rows, rel_rows, lse, w, has)
+        return torch.where(has, lse - lab - torch.log(k.clamp(min=1.0)), torch.zeros_like(lse))
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        sh = ctx.sh
+        ids, p, rowptr, col, ent_shape, rel_shape = ctx.meta
+        rows, rel_rows, lse, w, has = ctx.saved_tensors
+        g = torch.where(has, g_rows, torch.zeros_like(g_rows)).contiguous()  # rows without labels: no gradient
+        t16 = sh._tables(sh.ent_local, "local")
+        g_a, g_p, g_t = sh.backend.kl_emb_bwd(t16, ctx.direction, rows, rel_rows, rowptr, col, sh.lo, w, lse, g_rows=g)
+        ge, gr = _merge_query_grads(sh, ids, p, g_a, g_p, g_t, ent_shape, rel_shape)
+        return None, None, ge, gr, None, None, None, None
+
+
+class _ShardedBCE(torch.autograd.Function):
+    """Per-row sum over the entities of ALL shards of BCEWithLogits(score(i, j) + offset, y_ij), y = 1 on the row's
+    labels (train.loss: bce; kge/util/loss.py:137-159).  Additive over the shards: one all-reduce of n floats, no
+    statistic to merge."""
+
+    @staticmethod
+    def forward(ctx, sh, direction, ent_master, rel_master, ids, p, rowptr, col, offset):
+        rows, rel_rows = sh.exchange_rows([ids], p)
+        rows, rel_rows = rows.clone(), rel_rows.clone()
+        t16 = sh._tables(sh.ent_local, "local")
+        loss = sh.backend.bce_emb_fwd(t16, direction, rows, rel_rows, rowptr, col, sh.lo, offset)
+        loss = sh._allreduce(loss.clone())
+        ctx.sh, ctx.direction, ctx.offset = sh, direction, float(offset)
+        ctx.meta = (ids, p, rowptr, col, ent_master.shape, rel_master.shape)
+        ctx.save_for_backward(rows, rel_rows)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        sh = ctx.sh
+        ids, p, rowptr, col, ent_shape, rel_shape = ctx.meta
+        rows, rel_rows = ctx.saved_tensors
+        t16 = sh._tables(sh.ent_local, "local")
+        g_a, g_p, g_t = sh.backend.bce_emb_bwd(t16, ctx.direction, rows, rel_rows, rowptr, col, sh.lo, ctx.offset,
+                                               g_rows=g_rows.contiguous())
+        ge, gr = _merge_query_grads(sh, ids, p, g_a, g_p, g_t, ent_shape, rel_shape)
+        return None, None, ge, gr, None, None, None, None, None
+
+
+class _ShardedNeg(torch.autograd.Function):
+    """Scores of a negative-sampling batch over the sharded table (TrainingJobNegativeSampling._process_subbatch,
+    kge/job/train_negative_sampling.py:103-164, with BatchNegativeSample.score, kge/util/sampler.py:263-306): the n
+    positives and, for one slot (0 = s, 2 = o), the [n, K] triples with that slot replaced by negatives (GLOBAL ids,
+    the same on every rank).
+
+    The rank's table has 2 n_max SLACK rows behind its shard (ShardedEntityTable.with_slack): the exchanged s and o
+    rows of the batch are written there, so that the index-level kernels (kge_score_spo, kge_score_neg and their
+    backward twins: fixed side in registers, only the corrupted rows stream) run unchanged on local row ids.  A rank
+    scores the negatives it OWNS (the others: any local row, masked to 0) and one all-reduce of [n, K] floats (x + 0 is
+    exact) gives every rank the slot's score block; the positives come out identical on every rank.  Backward: the
+    corrupted rows' gradients stay on their owner; the slack rows' (= query rows') and the relation gradients are
+    all-reduced, the owners scatter-add."""
+
+    @staticmethod
+    def forward(ctx, sh, ent_master, rel_master, s, p, o, slot, neg):
+        n, K = neg.shape
+        Eg = sh.hi - sh.lo
+        ext = sh.ent_ext  # [E_g + slack, d]: the shard + slack rows, the master's own storage
+        if 2 * n > ext.shape[0] - Eg:
+            raise ValueError("kge_amd: batch larger than the slack rows of the sharded table (with_slack(n_max))")
+        rows, _ = sh.exchange_rows([s, o], None)
+        with torch.no_grad():
+            ext[Eg:Eg + 2 * n].copy_(rows)
+        ar = torch.arange(n, device=neg.device)
+        si, oi = Eg + ar, Eg + n + ar
+        T = sh._tables(ext, "ext")
+        pos = sh.backend.score_spo(T, si, p, oi)
+        own = (neg >= sh.lo) & (neg < sh.hi)
+        local = (neg - sh.lo).clamp(0, max(Eg - 1, 0))
+        sc = sh.backend.score_neg(T, si, p, oi, int(slot), local)
+        sc = torch.where(own, sc, torch.zeros_like(sc))
+        sc = sh._allreduce(sc)
+        ctx.sh, ctx.slot = sh, int(slot)
+        ctx.meta = (s, p, o, ent_master.shape, rel_master.shape)
+        ctx.save_for_backward(si, oi, local, own, pos, sc)
+        return pos, sc
+
+    @staticmethod
+    def backward(ctx, g_pos, g_neg):
+        sh = ctx.sh
+        s, p, o, ent_shape, rel_shape = ctx.meta
+        si, oi, local, own, pos, sc = ctx.saved_tensors
+        n = si.numel()
+        Eg = sh.hi - sh.lo
+        ext = sh.ent_ext
+        T = sh._tables(ext, "ext")
+        ge = torch.zeros(ext.shape, dtype=torch.float32, device=ext.device)
+        gr = torch.zeros(rel_shape, dtype=torch.float32, device=ext.device)
+        gneg = torch.where(own, g_neg, torch.zeros_like(g_neg)).contiguous()
+        if not sh.backend.score_neg_bwd_accum(T, si, p, oi, ctx.slot, local, gneg, sc, ge, gr):
+            raise RuntimeError("kge_amd: kge_score_neg_bwd_accum declined the sharded negative-sampling shape")
+        if sh.rank == 0 or not sh.collectives:  # the positives are the same on every rank: one of them contributes
+            sh.backend.score_spo_bwd_accum(T, si, p, oi, g_pos.contiguous(), pos, ge, gr)
+        # query-row (slack) and relation gradients: summed over the shards, then scatter-added by the owners
+        q = ge[Eg:Eg + 2 * n].clone()
+        d = q.shape[1]
+        pack = torch.cat([q.reshape(-1), gr.reshape(-1)])
+        sh._allreduce(pack)
+        q, gr = pack[:2 * n * d].view(2 * n, d), pack[2 * n * d:].view(rel_shape)
+        gid = torch.cat([s.reshape(-1).long(), o.reshape(-1).long()])
+        ownq = ((gid >= sh.lo) & (gid < sh.hi)).to(q.dtype).unsqueeze(1)
+        loc = (gid - sh.lo).clamp_(0, max(Eg - 1, 0))
+        out = ge[:Eg]
+        if Eg > 0:
+            out.index_add_(0, loc, q * ownq)
+        return None, out.view(ent_shape), gr, None, None, None, None, None
 
 
 class ShardedEntityTable:
@@ -106,6 +252,7 @@ class ShardedEntityTable:
         if ent_local.shape[0] != self.hi - self.lo:
             raise ValueError(f"rank {self.rank} must hold rows [{self.lo},{self.hi}) of the entity table")
         self.ent_local, self.rel = ent_local, rel
+        self.ent_ext = None  # negative sampling: the shard + slack rows (with_slack), set by the training job
         if backend is None:
             from . import engine as backend  # the HIP kernels; no CPU fallback
         self.backend = backend
@@ -240,6 +387,35 @@ class ShardedEntityTable:
         ent_master = self.ent_local if ent_master is None else ent_master
         rel_master = self.rel if rel_master is None else rel_master
         return _ShardedCE.apply(self, direction, ent_master, rel_master, ids, p, labels)
+
+    def kl_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, ent_master=None, rel_master=None):
+        """[n] KvsAll KL loss rows over ALL entities (see _ShardedKL); sum / batch size = the reference's loss."""
+        ent_master = self.ent_local if ent_master is None else ent_master
+        rel_master = self.rel if rel_master is None else rel_master
+        return _ShardedKL.apply(self, direction, ent_master, rel_master, ids, p, lbl_rowptr, lbl_col)
+
+    def bce_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, offset: float = 0.0, ent_master=None,
+                 rel_master=None):
+        """[n] KvsAll BCE loss rows summed over ALL entities (see _ShardedBCE)."""
+        ent_master = self.ent_local if ent_master is None else ent_master
+        rel_master = self.rel if rel_master is None else rel_master
+        return _ShardedBCE.apply(self, direction, ent_master, rel_master, ids, p, lbl_rowptr, lbl_col, offset)
+
+    @staticmethod
+    def with_slack(rows: torch.Tensor, n_max: int):
+        """A shard's rows followed by 2 n_max slack rows in ONE allocation: (buffer [E_g + 2 n_max, d], view of the
+        first E_g rows).  Negative-sampling training keeps its float32 master shard as that view (a Parameter over
+        it shares the storage) and scores on the buffer."""
+        buf = torch.zeros(rows.shape[0] + 2 * int(n_max), rows.shape[1], dtype=rows.dtype, device=rows.device)
+        buf[:rows.shape[0]].copy_(rows)
+        return buf, buf[:rows.shape[0]]
+
+    def neg_scores(self, s, p, o, slot: int, neg, ent_master=None, rel_master=None):
+        """(positives [n], scores [n, K] of the triples with `slot` replaced by neg[i, k]) -- see _ShardedNeg.  Needs
+        `self.ent_ext` (with_slack) whose first rows are this table's `ent_local`."""
+        ent_master = self.ent_local if ent_master is None else ent_master
+        rel_master = self.rel if rel_master is None else rel_master
+        return _ShardedNeg.apply(self, ent_master, rel_master, s, p, o, slot, neg)
 
     @torch.no_grad()
     def refresh_tables(self, ent_master: torch.Tensor, rel_master: torch.Tensor):

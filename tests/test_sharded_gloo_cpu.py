@@ -66,6 +66,91 @@ class OracleBackend:
         return a.grad, pr.grad, T.grad
 
     @staticmethod
+    def _label_matrix(t, rowptr, col, col_lo):
+        """[n, E_g] 0/1 matrix of the labels inside the shard [col_lo, col_lo + E_g)."""
+        n, Eg = rowptr.numel() - 1, t.ent.shape[0]
+        y = torch.zeros(n, Eg)
+        for i in range(n):
+            c = col[rowptr[i]:rowptr[i + 1]] - col_lo
+            c = c[(c >= 0) & (c < Eg)]
+            y[i, c] = 1.0
+        return y
+
+    @staticmethod
+    def kl_emb_fwd(t, direction, a_rows, p_rows, rowptr, col, col_lo, weight):
+        sc = OracleBackend._scores(t, direction, a_rows, p_rows, t.ent)
+        lse = torch.logsumexp(sc, dim=1)
+        y = OracleBackend._label_matrix(t, rowptr, col, col_lo)
+        return lse - weight * (sc * y).sum(1), lse
+
+    @staticmethod
+    def kl_emb_bwd(t, direction, a_rows, p_rows, rowptr, col, col_lo, weight, lse, g_rows=None, g_scalar=1.0,
+                   label_bias=None):
+        with torch.enable_grad():
+            a, pr, T = (x.detach().clone().requires_grad_(True) for x in (a_rows, p_rows, t.ent))
+            sc = OracleBackend._scores(t, direction, a, pr, T)
+            g = g_rows if g_rows is not None else torch.full_like(lse, g_scalar)
+            y = OracleBackend._label_matrix(t, rowptr, col, col_lo)
+            G = (torch.exp(sc.detach() - lse.view(-1, 1)) - weight.view(-1, 1) * y) * g.view(-1, 1)
+            (sc * G).sum().backward()
+        return a.grad, pr.grad, T.grad
+
+    @staticmethod
+    def bce_emb_fwd(t, direction, a_rows, p_rows, rowptr, col, col_lo, offset=0.0):
+        sc = OracleBackend._scores(t, direction, a_rows, p_rows, t.ent)
+        y = OracleBackend._label_matrix(t, rowptr, col, col_lo)
+        return torch.nn.functional.binary_cross_entropy_with_logits(sc + offset, y, reduction="none").sum(1)
+
+    @staticmethod
+    def bce_emb_bwd(t, direction, a_rows, p_rows, rowptr, col, col_lo, offset=0.0, g_rows=None, g_scalar=1.0):
+        with torch.enable_grad():
+            a, pr, T = (x.detach().clone().requires_grad_(True) for x in (a_rows, p_rows, t.ent))
+            sc = OracleBackend._scores(t, direction, a, pr, T)
+            g = g_rows if g_rows is not None else torch.full((sc.shape[0],), g_scalar)
+            y = OracleBackend._label_matrix(t, rowptr, col, col_lo)
+            G = (torch.sigmoid(sc.detach() + offset) - y) * g.view(-1, 1)
+            (sc * G).sum().backward()
+        return a.grad, pr.grad, T.grad
+
+    # negative sampling on the table + slack rows (index-level, as kge_score_spo / kge_score_neg and their twins)
+    @staticmethod
+    def _spo(t, ent, rel, s, p, o):
+        import torch_port as tp
+        return tp.score_emb(t.scorer, ent[s], rel[p], ent[o], "spo", t.l_norm).view(-1)
+
+    @staticmethod
+    def score_spo(t, s, p, o):
+        return OracleBackend._spo(t, t.ent, t.rel, s.long(), p.long(), o.long()).detach()
+
+    @staticmethod
+    def _neg(t, ent, rel, s, p, o, slot, neg):
+        n, K = neg.shape
+        rep = lambda x: x.long().view(-1, 1).expand(n, K).reshape(-1)
+        ss, oo = (neg.reshape(-1), rep(o)) if slot == 0 else (rep(s), neg.reshape(-1))
+        return OracleBackend._spo(t, ent, rel, ss, rep(p), oo).view(n, K)
+
+    @staticmethod
+    def score_neg(t, s, p, o, slot, neg):
+        return OracleBackend._neg(t, t.ent, t.rel, s, p, o, slot, neg).detach()
+
+    @staticmethod
+    def score_neg_bwd_accum(t, s, p, o, slot, neg, gout, scores, grad_ent, grad_rel):
+        with torch.enable_grad():
+            ent, rel = (x.detach().clone().requires_grad_(True) for x in (t.ent, t.rel))
+            (OracleBackend._neg(t, ent, rel, s, p, o, slot, neg) * gout).sum().backward()
+        grad_ent += ent.grad
+        grad_rel += rel.grad
+        return True
+
+    @staticmethod
+    def score_spo_bwd_accum(t, s, p, o, gout, scores, grad_ent, grad_rel):
+        with torch.enable_grad():
+            ent, rel = (x.detach().clone().requires_grad_(True) for x in (t.ent, t.rel))
+            (OracleBackend._spo(t, ent, rel, s.long(), p.long(), o.long()) * gout).sum().backward()
+        grad_ent += ent.grad
+        grad_rel += rel.grad
+
+    @staticmethod
     def score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm=1.0):
         return torch.cat([OracleBackend.score_emb(scorer, s_emb, p_emb, targets, "sp_", l_norm),
                           OracleBackend.score_emb(scorer, targets, p_emb, o_emb, "_po", l_norm)], 1)
@@ -385,9 +470,11 @@ def _job_worker(rank, world, port, model, q):
         job2.load_checkpoint(ck)
         l3 = float(job2.step(batches[2]))
         sd2 = job2.state_dict()
-        q.put((rank, losses, {k: v.numpy() for k, v in sd.items()}, {k: v.numpy() for k, v in ck["model"][1].items()},
-               {k: {kk: (vv.numpy() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
-                for k, v in ck["optimizer_state"].items()}, l3, {k: v.numpy() for k, v in sd2.items()}))
+        assert ck["type"] == "train" and "valid_trace" in ck and isinstance(ck["model"], tuple)   # TrainingJob.save_to's keys
+        q.put((rank, losses, {k: v.numpy() for k, v in sd.items()}, {k: v.numpy() for k, v in ck["model"][0].items()},
+               {pid: {kk: (vv.numpy() if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+                for pid, v in ck["optimizer_state_dict"]["state"].items()}, l3, {k: v.numpy() for k, v in sd2.items()},
+               ck["optimizer_state_dict"]["param_groups"]))
     finally:
         dist.destroy_process_group()
 
@@ -444,23 +531,181 @@ def test_sharded_training_job_equals_the_unsharded_run(model):
             ref_after2 = (ent.detach().clone().numpy(), rel.detach().clone().numpy(),
                           opt.state[ent]["sum"].clone().numpy())
     from kge_amd.sharded_train import ENT_KEY, REL_KEY, ShardedTrainingJob1vsAll
-    for rank, losses, sd, ck_sd, ck_opt, l3, sd2 in outs:
+    for rank, losses, sd, ck_sd, ck_opt, l3, sd2, ck_groups in outs:
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-5, atol=1e-6)
-        assert sd[ENT_KEY].shape == (E, d) and ck_sd[ENT_KEY].shape == (E, d) and ck_opt[ENT_KEY]["sum"].shape == (E, d)
+        assert sd[ENT_KEY].shape == (E, d) and ck_sd[ENT_KEY].shape == (E, d) and ck_opt[0]["sum"].shape == (E, d)
         np.testing.assert_allclose(sd[ENT_KEY], ent.detach().numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(sd[REL_KEY], rel.detach().numpy(), rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(ck_sd[ENT_KEY], ref_after2[0], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(ck_opt[ENT_KEY]["sum"], ref_after2[2], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(ck_opt[0]["sum"], ref_after2[2], rtol=1e-4, atol=1e-7)
         assert abs(l3 - losses[2]) <= 1e-6 * max(1.0, abs(l3))
         np.testing.assert_allclose(sd2[ENT_KEY], sd[ENT_KEY], rtol=1e-6, atol=1e-7)
     assert np.array_equal(outs[0][2][ENT_KEY], outs[1][2][ENT_KEY])  # the gathered parameter is the same everywhere
     # the two-rank checkpoint resumed on ONE rank (no process group): the same third step
-    rank, losses, sd, ck_sd, ck_opt, l3, sd2 = outs[0]
+    rank, losses, sd, ck_sd, ck_opt, l3, sd2, ck_groups = outs[0]
+    opt_sd = {"state": {pid: {kk: (torch.from_numpy(vv) if isinstance(vv, np.ndarray) else vv) for kk, vv in v.items()}
+                        for pid, v in ck_opt.items()}, "param_groups": ck_groups}
+    # the optimizer state is torch's own layout: a reference-style UNSHARDED torch.optim.Adagrad over [entities,
+    # relations] (kge/util/optimizer.py:15-20) loads it as is and holds the reference run's accumulator
+    e2, r2 = torch.zeros(E, d, requires_grad=True), torch.zeros(R, d, requires_grad=True)
+    ref_opt = torch.optim.Adagrad([e2, r2], lr=0.3)
+    ref_opt.load_state_dict(opt_sd)
+    np.testing.assert_allclose(ref_opt.state[e2]["sum"].numpy(), ref_after2[2], rtol=1e-4, atol=1e-7)
     one = ShardedTrainingJob1vsAll(model, E, R, d, seed=1, lr=0.3, optimizer="Adagrad", score_dtype=torch.float32,
                                    backend=OracleBackend)
-    one.load_checkpoint({"epoch": 0, "model": [None, {k: torch.from_numpy(v) for k, v in ck_sd.items()}],
-                         "optimizer_state": {k: {kk: (torch.from_numpy(vv) if isinstance(vv, np.ndarray) else vv)
-                                                 for kk, vv in v.items()} for k, v in ck_opt.items()}})
+    one.load_checkpoint({"type": "train", "epoch": 2, "valid_trace": [],
+                         "model": ({k: torch.from_numpy(v) for k, v in ck_sd.items()}, {}),
+                         "optimizer_state_dict": opt_sd})
     l3_one = float(one.step(batches[2]))
     assert abs(l3_one - losses[2]) <= 1e-5 * max(1.0, abs(l3_one))
     np.testing.assert_allclose(one.state_dict()[ENT_KEY].numpy(), sd[ENT_KEY], rtol=1e-4, atol=1e-6)
+
+
+def _labels(g, n, E, kmax=5):
+    """A label CSR of global entity ids, some rows empty (TrainingJobKvsAll's batch["label_coords"] as CSR)."""
+    cnt = torch.randint(0, kmax + 1, (n,), generator=g)
+    cnt[0] = 0
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(cnt, 0)])
+    col = torch.cat([torch.randperm(E, generator=g)[:int(c)] for c in cnt] + [torch.zeros(0, dtype=torch.int64)])
+    return rowptr, col
+
+
+def _kvs_ns_worker(rank, world, port, model, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kge_amd.sharded_train import ENT_KEY, ShardedTrainingJobKvsAll, ShardedTrainingJobNegativeSampling
+        E, R, d, n, K = 47, 5, 16, 13, 7
+        out = {}
+        for loss in ("kl", "bce"):
+            g = torch.Generator().manual_seed(21)
+            job = ShardedTrainingJobKvsAll(model, E, R, d, seed=4, lr=0.5, optimizer="SGD", score_dtype=torch.float32,
+                                           backend=OracleBackend, loss=loss, loss_arg=0.25 if loss == "bce" else 0.0)
+            losses = []
+            for _ in range(3):
+                qs = []
+                for direction in ("sp", "po"):
+                    ids, p = torch.randint(E, (n,), generator=g), torch.randint(R, (n,), generator=g)
+                    qs.append((direction, ids, p) + _labels(g, n, E))
+                losses.append(float(job.step(qs)))
+            ck = job.checkpoint()
+            job2 = ShardedTrainingJobKvsAll(model, E, R, d, seed=5, lr=0.5, optimizer="SGD", score_dtype=torch.float32,
+                                            backend=OracleBackend, loss=loss, loss_arg=0.25 if loss == "bce" else 0.0)
+            job2.load_checkpoint(ck)
+            assert np.array_equal(job2.state_dict()[ENT_KEY].numpy(), job.state_dict()[ENT_KEY].numpy())
+            out[loss] = (losses, job.state_dict()[ENT_KEY].numpy())
+        for loss in ("kl", "bce"):
+            g = torch.Generator().manual_seed(22)
+            job = ShardedTrainingJobNegativeSampling(model, E, R, d, seed=4, lr=0.5, optimizer="SGD", n_max=n,
+                                                     backend=OracleBackend, loss=loss)
+            losses = []
+            for _ in range(3):
+                tri = torch.stack([torch.randint(hi, (n,), generator=g) for hi in (E, R, E)], 1)
+                ns, no = torch.randint(E, (n, K), generator=g), torch.randint(E, (n, K - 2), generator=g)
+                losses.append(float(job.step(tri, ns, no)))
+            out["ns_" + loss] = (losses, job.state_dict()[ENT_KEY].numpy())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["complex", "transe"])
+def test_sharded_kvsall_and_negative_sampling_jobs_equal_the_unsharded_runs(model):
+    """ShardedTrainingJobKvsAll (train.loss kl / bce) and ShardedTrainingJobNegativeSampling (kl / bce) on two ranks,
+    three SGD steps each (a step linear in the gradient: Adagrad's first steps divide by
+    |g| + 1e-10 and turn float32 summation noise on near-zero gradients into visible parameter differences; the Adagrad
+    path and the checkpoints are the 1vsAll test's), against the unsharded reference steps: TrainingJobKvsAll._process_subbatch
+    (train_KvsAll.py:274-294: score_sp / score_po against all entities, KLDivWithSoftmaxKgeLoss on the normalised
+    multi-hot labels / BCEWithLogitsKgeLoss, sum / number of queries) and TrainingJobNegativeSampling._process_subbatch
+    (train_negative_sampling.py:120-163: per slot the [n, 1 + K] block, loss with label 0, sum / n) with
+    torch.optim.SGD on the full tables.  Losses per step and the gathered entity table after three steps."""
+    import time
+    import torch.nn.functional as F
+    import torch_port as tp
+    if model == "transe":  # (the fused KvsAll losses are ComplEx / DistMult kernels; the fake backend scores any model)
+        pass
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_kvs_ns_worker, args=(r, world, port, model, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs, t0 = [], time.time()
+    while len(outs) < world and time.time() - t0 < 240:
+        if not q.empty():
+            outs.append(q.get())
+        elif any(pr.exitcode not in (None, 0) for pr in procs):
+            break
+        else:
+            time.sleep(0.05)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert len(outs) == world
+    E, R, d, n, K = 47, 5, 16, 13, 7
+
+    def fresh():
+        g = torch.Generator().manual_seed(4)
+        ent = torch.empty(E, d).normal_(0.0, 0.1, generator=g).requires_grad_(True)
+        rel = torch.empty(R, d).normal_(0.0, 0.1, generator=g).requires_grad_(True)
+        return ent, rel, torch.optim.SGD([ent, rel], lr=0.5)
+
+    ref = {}
+    for loss in ("kl", "bce"):
+        ent, rel, opt = fresh()
+        g = torch.Generator().manual_seed(21)
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            total = 0.0
+            groups = []
+            for direction in ("sp", "po"):
+                ids, p = torch.randint(E, (n,), generator=g), torch.randint(R, (n,), generator=g)
+                groups.append((direction, ids, p) + _labels(g, n, E))
+            for direction, ids, p, rowptr, col in groups:
+                sc = tp.score_sp(model, ent, rel, ids, p) if direction == "sp" else tp.score_po(model, ent, rel, p, ids)
+                y = torch.zeros(n, E)
+                for i in range(n):
+                    y[i, col[rowptr[i]:rowptr[i + 1]]] = 1.0
+                if loss == "kl":
+                    yn = F.normalize(y, p=1, dim=1)   # loss.py:208-213
+                    l = F.kl_div(F.log_softmax(sc, dim=1), yn, reduction="sum") / (2 * n)
+                else:
+                    l = F.binary_cross_entropy_with_logits(sc + 0.25, y, reduction="sum") / (2 * n)
+                l.backward()
+                total += float(l)
+            opt.step()
+            losses.append(total)
+        ref[loss] = (losses, ent.detach().numpy().copy())
+    for loss in ("kl", "bce"):
+        ent, rel, opt = fresh()
+        g = torch.Generator().manual_seed(22)
+        losses = []
+        for _ in range(3):
+            tri = torch.stack([torch.randint(hi, (n,), generator=g) for hi in (E, R, E)], 1)
+            ns, no = torch.randint(E, (n, K), generator=g), torch.randint(E, (n, K - 2), generator=g)
+            s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
+            opt.zero_grad()
+            total = 0.0
+            for slot, neg in ((0, ns), (2, no)):
+                kk = neg.shape[1]
+                rep = lambda x: x.view(-1, 1).expand(n, kk).reshape(-1)
+                pos = tp.score_emb(model, ent[s], rel[p], ent[o], "spo").view(-1)
+                ss, oo = (neg.reshape(-1), rep(o)) if slot == 0 else (rep(s), neg.reshape(-1))
+                neg_sc = tp.score_emb(model, ent[ss], rel[rep(p)], ent[oo], "spo").view(n, kk)
+                block = torch.cat([pos.view(-1, 1), neg_sc], 1)
+                if loss == "kl":
+                    l = F.cross_entropy(block, torch.zeros(n, dtype=torch.long), reduction="sum") / n
+                else:
+                    lab = torch.zeros_like(block)
+                    lab[:, 0] = 1.0
+                    l = F.binary_cross_entropy_with_logits(block, lab, reduction="sum") / n
+                l.backward()
+                total += float(l)
+            opt.step()
+            losses.append(total)
+        ref["ns_" + loss] = (losses, ent.detach().numpy().copy())
+    for rank, out in outs:
+        for key, (losses, ent_after) in out.items():
+            np.testing.assert_allclose(losses, ref[key][0], rtol=2e-5, atol=1e-6, err_msg=key)
+            np.testing.assert_allclose(ent_after, ref[key][1], rtol=2e-4, atol=2e-6, err_msg=key)
