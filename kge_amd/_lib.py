@@ -170,13 +170,61 @@ PROTOTYPES = {
 }
 
 
+EXT_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_C.so")
+_EXT_SRC = os.path.join(_CSRC, "torch_ext.cpp")
+
+
+def build_extension(force: bool = False) -> str:
+    """kge_amd/_C.so: the PyTorch-ROCm C++ extension over the C ABI (csrc/torch_ext.cpp), built in-tree with g++
+    against this interpreter's torch headers and linked to libkge_amd.so (rpath $ORIGIN/csrc) -- host code only, the
+    kernels are in the library."""
+    import sysconfig
+    from torch.utils import cpp_extension as ce
+    if not force and os.path.exists(EXT_PATH) and os.path.getmtime(EXT_PATH) >= max(
+            os.path.getmtime(_EXT_SRC), os.path.getmtime(os.path.join(_CSRC, "..", "..", "include", "kge_amd.h"))):
+        return EXT_PATH
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    inc = [sysconfig.get_paths()["include"]] + list(ce.include_paths())
+    for extra in ("/opt/rocm/include",):
+        if extra not in inc and os.path.isdir(extra):
+            inc.append(extra)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-attributes", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-DTORCH_EXTENSION_NAME=_C", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}"]
+    cmd += [f"-I{p}" for p in inc]
+    cmd += [_EXT_SRC, "-o", EXT_PATH, f"-L{tlib}", "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu", "-ltorch_hip",
+            "-ltorch_python", f"-L{_CSRC}", "-lkge_amd", "-Wl,-rpath,$ORIGIN/csrc", f"-Wl,-rpath,{tlib}"]
+    subprocess.check_call(cmd)
+    return EXT_PATH
+
+
 def build(force: bool = False) -> str:
-    """Compile the HIP sources for gfx950 (cross-compiles without a GPU)."""
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU) and the torch extension over them."""
     cmd = ["make", "-C", _CSRC, "-j", str(min(8, os.cpu_count() or 1))]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    build_extension(force)
     return LIB_PATH
+
+
+_ext = None
+
+
+def ext():
+    """The torch extension module kge_amd._C (raises if it has not been built)."""
+    global _ext
+    if _ext is None:
+        lib()  # libkge_amd.so first (the same HIP runtime as torch)
+        if not os.path.exists(EXT_PATH):
+            raise RuntimeError(f"{EXT_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("kge_amd._C", EXT_PATH)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if mod.abi_version() != 1:
+            raise RuntimeError("kge_amd._C: ABI version mismatch with libkge_amd.so")
+        _ext = mod
+    return _ext
 
 
 _lib = None

@@ -11,6 +11,7 @@ Function <-> reference map (paths relative to the reference tree):
   rank_counts                                      EntityRankingJob._filter_and_rank  kge/job/eval_entity_ranking.py:533-596
 """
 import ctypes
+import os
 
 import torch
 
@@ -209,7 +210,32 @@ class Tables:
         return self.ent.shape[0]
 
 
+def _ext():
+    """The torch C++ extension kge_amd._C (csrc/torch_ext.cpp: one C++ call per scoring call, ~2 us of host time
+    against ~9 through ctypes) -- the binding of the index-level scoring calls; KGE_AMD_BINDING=ctypes keeps them on
+    ctypes (the binding of everything else).  Both end in the same C entry points of libkge_amd.so."""
+    global _EXT
+    if _EXT is None:
+        if os.environ.get("KGE_AMD_BINDING", "ext") == "ctypes" or not os.path.exists(_lib.EXT_PATH):
+            _EXT = False
+        else:
+            _EXT = _lib.ext()
+    return _EXT
+
+
+_EXT = None
+
+
+def _workspace_tensor(tc, n, device, enable, st):
+    ws, _ = _workspace(tc, n, device, enable, st)
+    return None if ws is None else _WORKSPACES[(device.index, st)]
+
+
 def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
+    ex = _ext()
+    if ex:
+        with _on_device(t.device):
+            return ex.score_spo(t.ent, t.rel, t.scorer, t.l_norm, t.flags if flags is None else flags, s, p, o)
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
     n = _same_len(keep[:3], "score_spo")
@@ -222,6 +248,14 @@ def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
 
 
 def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
+    ex = _ext()
+    if ex and out is None and not t.pad_pitch and torch.is_tensor(a) and torch.is_tensor(p):
+        with _on_device(t.device):
+            fl = t.flags if flags is None else flags
+            st = _stream_handle(t.device)
+            ws = _workspace_tensor(t.c(fl), a.numel(), t.device, t.use_workspace, st)
+            return ex.score_pairs(t.ent, t.rel, t.scorer, t.l_norm, fl, SP_ if fn_name == "kge_score_sp" else PO_, a, p,
+                                  None, targets, ws)
     keep = []
     ai, pi = _index(a, t.device, keep), _index(p, t.device, keep)
     n = _same_len(keep[:2], "_pairs")
@@ -262,6 +296,13 @@ def score_po(t: Tables, p, o, s=None, flags=None) -> torch.Tensor:
 def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Tensor:
     """[n, 2m]: score_sp and score_po against one shared entity subset, written directly
     into the two halves of the output (no torch.cat copy, kge_model.py:789)."""
+    ex = _ext()
+    if ex and torch.is_tensor(s) and torch.is_tensor(p) and torch.is_tensor(o):
+        with _on_device(t.device):
+            fl = t.flags if flags is None else flags
+            st = _stream_handle(t.device)
+            ws = _workspace_tensor(t.c(fl), s.numel(), t.device, t.use_workspace, st)
+            return ex.score_pairs(t.ent, t.rel, t.scorer, t.l_norm, fl, SP_PO, s, p, o, entity_subset, ws)
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
     n = _same_len(keep[:3], "score_sp_po")

@@ -160,3 +160,17 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_adagrad_step(ctypes.c_void_p(20), ctypes.c_void_p(16), ctypes.c_void_p(16), 8, -0.1, 0.0, 1e-10,
                                 None, None) == -1
     assert lib.kge_adagrad_step(None, None, None, 0, -0.1, 0.0, 1e-10, None, None) == 0
+
+
+def test_torch_extension_builds_and_binds_the_c_abi(lib):
+    """kge_amd._C (csrc/torch_ext.cpp): the PyTorch-ROCm C++ extension north_star names -- builds in-tree against this
+    interpreter's torch, links libkge_amd.so, refuses CPU tensors (no compute without a GPU here)."""
+    from kge_amd import _lib
+    assert os.path.exists(_lib.build_extension())
+    ext = _lib.ext()
+    assert ext.abi_version() == lib.kge_abi_version()
+    for name in ("score_spo", "score_pairs", "queries_bytes", "build_queries_group", "score_queries_group"):
+        assert callable(getattr(ext, name))
+    ent, rel, ix = torch.randn(10, 8), torch.randn(3, 8), torch.zeros(4, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ext.score_spo(ent, rel, 1, 1.0, 0, ix, ix, ix)

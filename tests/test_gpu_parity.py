@@ -761,3 +761,30 @@ def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch):
     O = _oracle_tables("complex", ent, rel, 1.0, bf16=True)
     rows = rng.integers(0, n, 8)
     _close("vs oracle", big[rows], ko.score_sp(O, _np(s)[rows], _np(p)[rows]))
+
+
+def test_torch_extension_path_equals_the_ctypes_path(monkeypatch):
+    """The index-level scoring calls through kge_amd._C (the default binding) and through ctypes (KGE_AMD_BINDING=ctypes)
+    reach the same C entry points: the same bits, int32 / strided indices, listed targets, both table dtypes."""
+    from kge_amd import engine
+    g = torch.Generator().manual_seed(3)
+    E, R, d, n = 1500, 7, 256, 77
+    ent, rel = torch.randn(E, d, generator=g) * 0.3, torch.randn(R, d, generator=g) * 0.3
+    tri = torch.stack([torch.randint(hi, (n,), generator=g) for hi in (E, R, E)], 1).to(DEV)
+    sub = torch.randperm(E, generator=g)[:333].to(torch.int32).to(DEV)
+    got = {}
+    for binding in ("ext", "ctypes"):
+        monkeypatch.setenv("KGE_AMD_BINDING", binding)
+        engine._EXT = None
+        assert bool(engine._ext()) == (binding == "ext")
+        res = []
+        for dt in (torch.float32, torch.bfloat16):
+            for model in ("complex", "transe"):
+                T = engine.Tables(model, ent.to(dt).to(DEV), rel.to(dt).to(DEV))
+                s, p, o = tri[:, 0], tri[:, 1].to(torch.int32), tri[:, 2]
+                res += [engine.score_spo(T, s, p, o), engine.score_sp(T, s, p), engine.score_po(T, p, o, sub),
+                        engine.score_sp_po(T, s, p, o), engine.score_sp_po(T, s, p, o, sub)]
+        got[binding] = res
+    engine._EXT = None
+    for a, b in zip(got["ext"], got["ctypes"]):
+        assert a.shape == b.shape and torch.equal(a, b)
