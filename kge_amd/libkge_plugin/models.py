@@ -9,7 +9,7 @@ from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
 from ..model import (BF16Shadow, _FusedBCE, _FusedCE, _FusedCE2, _FusedKL, _ScoreEmb, _ScoreNeg, _ScorePairs,
-                     _ScoreSPO, bce_fused, kl_fused)
+                     _ScoreSPO, bce_fused, ce_fused_dropout, kl_fused)
 
 
 class _HipScorer(RelationalScorer):
@@ -71,6 +71,26 @@ class _FusedScoring:
         if not se._embeddings.weight.is_cuda:  # job.device: cpu -> KgeModel.score_* with the reference scorer's arithmetic
             return False
         return not (self.training and (se.dropout.p > 0 or pe.dropout.p > 0))
+
+    def _dropout_only(self):
+        """(p_entity, p_relation) if the ONLY thing that keeps `_fused()` from holding is embedder dropout in training
+        mode on float32 ComplEx / DistMult tables scored in bfloat16 -- the fused 1vsAll loss then applies the masks
+        itself (kge_amd.model.ce_fused_dropout: lookup_embedder.py:64-69, 102-105) --, else None."""
+        from kge.model import LookupEmbedder
+        se, oe, pe = self.get_s_embedder(), self.get_o_embedder(), self.get_p_embedder()
+        if se is not oe or type(se) is not LookupEmbedder or type(pe) is not LookupEmbedder:
+            return None
+        ent, rel = self._w()
+        if not (self.training and (se.dropout.p > 0 or pe.dropout.p > 0)) or not ent.is_cuda:
+            return None
+        if self._scorer.name not in ("complex", "distmult") or ent.dtype != torch.float32 or ent.shape[1] not in (128, 256, 512):
+            return None
+        try:
+            if self.get_option("score_dtype") not in ("bfloat16", "bf16"):
+                return None
+        except KeyError:
+            return None
+        return float(se.dropout.p), float(pe.dropout.p)
 
     def _w(self):
         return (self.get_s_embedder()._embeddings.weight, self.get_p_embedder()._embeddings.weight)
@@ -159,23 +179,32 @@ class _FusedScoring:
     def loss_sp(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
         """[n] cross entropy of score_sp(s, p) against o; None if the fused path does not apply."""
         t = self._ce_tables()
-        if t is None:
+        dp = self._dropout_only() if t is None else None
+        if t is None and dp is None:
             return None
         ent, rel = self._w()
+        if dp is not None:  # embedder dropout in training: the masks applied here, the fused kernels on dense rows
+            return ce_fused_dropout(self._scorer.name, self._scorer._norm, "sp", ent, rel, s, p, o, dp[0], dp[1])
         return _FusedCE.apply("sp", ent, rel, s, p, o, t)
 
     def loss_po(self, p: Tensor, o: Tensor, s: Tensor) -> Tensor:
         t = self._ce_tables()
-        if t is None:
+        dp = self._dropout_only() if t is None else None
+        if t is None and dp is None:
             return None
         ent, rel = self._w()
+        if dp is not None:  # embedder dropout in training: the masks applied here, the fused kernels on dense rows
+            return ce_fused_dropout(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, s, dp[0], dp[1])
         return _FusedCE.apply("po", ent, rel, o, p, s, t)
 
     def loss_sp_po(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
         """[2n] loss_sp rows then loss_po rows from one pass over the batch; None if not applicable."""
         t = self._ce_tables()
         if t is None:
-            return None
+            if self._dropout_only() is None:
+                return None
+            # independent masks per direction, as the reference's two score_* calls draw them
+            return torch.cat((self.loss_sp(s, p, o), self.loss_po(p, o, s)))
         ent, rel = self._w()
         return _FusedCE2.apply(ent, rel, s, p, o, t)
 

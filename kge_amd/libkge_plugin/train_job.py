@@ -19,11 +19,16 @@ def _plain_bce(loss):
 
 
 
-def _model_takes_fused_loss(model) -> bool:
+def _model_takes_fused_loss(model, with_dropout: bool = False) -> bool:
     """Decided ONCE per subbatch, before any backward: a decline after the first direction's
-    loss.backward() would make the reference path back-propagate that direction a second time."""
+    loss.backward() would make the reference path back-propagate that direction a second time.
+    with_dropout (the 1vsAll kl loss): embedder dropout in training does not decline -- the fused loss applies the
+    masks itself (_FusedScoring._dropout_only)."""
     f = getattr(model, "_ce_tables", None)
-    return f is not None and f() is not None
+    if f is not None and f() is not None:
+        return True
+    g = getattr(model, "_dropout_only", None)
+    return bool(with_dropout and g is not None and g() is not None)
 
 
 def _declined_late(what):
@@ -74,12 +79,15 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
             result.backward_time += time.time()
 
     def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
-        if not _model_takes_fused_loss(self.model):
+        kl = isinstance(self.loss, KLDivWithSoftmaxKgeLoss) and hasattr(self.model, "loss_sp")
+        if not _model_takes_fused_loss(self.model, with_dropout=kl):
             return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
         offset = _plain_bce(self.loss)
         if offset is not None and hasattr(self.model, "bce_loss_sp"):
+            if not _model_takes_fused_loss(self.model):  # (the bce loss has no dropout form)
+                return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
             return self._process_subbatch_bce(batch_index, batch, subbatch_slice, result, offset)
-        fused = isinstance(self.loss, KLDivWithSoftmaxKgeLoss) and hasattr(self.model, "loss_sp")
+        fused = kl
         if not fused:
             return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
         batch_size = result.size

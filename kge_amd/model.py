@@ -517,6 +517,59 @@ class _FusedCE2(torch.autograd.Function):
         return ge, gr, None, None, None, None
 
 
+# ---- embedder dropout inside the fused 1vsAll loss ------------------------------------------------------------------
+# LookupEmbedder._postprocess (kge/model/embedder/lookup_embedder.py:64-69, 102-105) applies torch.nn.Dropout to the
+# rows it returns: independently to the gathered query rows (embed), to the gathered relation rows and to ALL entity
+# rows (embed_all) -- score_sp(s, p) of a model in training mode scores dropout(E[s]) (x) dropout(R[p]) against
+# dropout(E).  Every tuned LibKGE config sets entity / relation dropout, so a fused loss that declines it trains those
+# configs on the unfused path.  Here the three masks are applied BEFORE the fused kernels -- on the float32 rows and
+# on a masked copy of the table (one elementwise pass over [E, d]: ~15 MB against the [n, E] score matrix the fused loss
+# does not write) --, the kernels take the dense rows (kge_ce_emb_fwd / _bwd) and torch's autograd carries the kernel's
+# gradients back through the masks and the gathers.  The masks are torch's (Philox on the device) unless handed in.
+def embedder_dropout(x: Tensor, p: float, mask: Tensor = None) -> Tensor:
+    """torch.nn.functional.dropout(x, p, training=True) with the mask optionally given: mask (same shape, 0 / 1) keeps
+    the elements where it is 1 and scales them by 1 / (1 - p)."""
+    if p <= 0.0:
+        return x
+    if mask is None:
+        return torch.nn.functional.dropout(x, p, True)
+    return x * (mask.to(x.dtype) * (1.0 / (1.0 - p)))
+
+
+class _FusedCEEmb(torch.autograd.Function):
+    """Per-row 1vsAll cross entropy of dense query rows against all rows of a dense table (kge_ce_emb_fwd / _bwd): the
+    inputs are the float32 (dropped-out) rows; they are rounded to bf16 for the matrix-core kernels inside, gradients
+    come back in float32 w.r.t. the inputs."""
+
+    @staticmethod
+    def forward(ctx, scorer, l_norm, direction, table, a_rows, p_rows, label):
+        t16 = engine.Tables(scorer, table.detach().to(torch.bfloat16), p_rows.detach().to(torch.bfloat16), l_norm)
+        a16 = a_rows.detach().to(torch.bfloat16).contiguous()
+        loss_rows, lse = engine.ce_emb_fwd(t16, direction, a16, t16.rel, label)
+        ctx.t16, ctx.direction, ctx.label = t16, direction, label
+        ctx.save_for_backward(a16, lse)
+        return loss_rows
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        a16, lse = ctx.saved_tensors
+        g_a, g_p, g_t = engine.ce_emb_bwd(ctx.t16, ctx.direction, a16, ctx.t16.rel, ctx.label, lse,
+                                          g_rows=g_rows.contiguous())
+        return None, None, None, g_t, g_a, g_p, None
+
+
+def ce_fused_dropout(scorer: str, l_norm: float, direction: str, ent: Tensor, rel: Tensor, a: Tensor, p: Tensor,
+                     label: Tensor, p_ent: float, p_rel: float, masks: dict = None) -> Tensor:
+    """[n] cross entropy of score_sp(a, p) ("sp") / score_po(p, a) ("po") over all entities with the embedders'
+    dropout applied as the reference applies it (three independent masks: "a" [n, d], "p" [n, d_r], "all" [E, d];
+    `masks` may hand any of them in).  Differentiable w.r.t. the float32 tables `ent` / `rel`."""
+    masks = masks or {}
+    a_rows = embedder_dropout(ent[a.reshape(-1).long()], p_ent, masks.get("a"))
+    p_rows = embedder_dropout(rel[p.reshape(-1).long()], p_rel, masks.get("p"))
+    table = embedder_dropout(ent, p_ent, masks.get("all"))
+    return _FusedCEEmb.apply(scorer, l_norm, direction, table, a_rows, p_rows, label)
+
+
 class _FusedKL(torch.autograd.Function):
     """Per-row KvsAll KL loss fused with the sp_/_po scoring (kge_kl_fwd / kge_kl_bwd); labels as an
     int64 CSR (rowptr [n + 1], col [nnz]) of the rows' known answers."""

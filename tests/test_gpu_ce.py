@@ -500,3 +500,52 @@ def test_model_level_bce_loss_against_composed(ls):
         assert abs(float(lf.detach()) - float(lc.detach())) <= 2e-5 * max(1.0, abs(float(lc.detach())))
         for a_, b_ in zip(gf, gc):
             assert float((a_ - b_).norm() / b_.norm()) <= 2e-3
+
+
+# ---- embedder dropout inside the fused loss (lookup_embedder.py:64-69, 102-105) ---------------------------------------
+@pytest.mark.parametrize("scorer,d", [("complex", 256), ("distmult", 512)])
+def test_fused_ce_with_embedder_dropout_given_masks(scorer, d):
+    """ce_fused_dropout with the three masks handed in, against the reference's op sequence in float32 torch on the same
+    dropped-out rows rounded to bf16: embed(s) / embed(p) / embed_all() with dropout, score_emb "sp_", cross entropy;
+    loss rows and both table gradients (mixed-precision bar of the fused loss: 2e-3 / 1e-2)."""
+    import torch.nn.functional as F
+    import torch_port as tp
+    from kge_amd import model as km
+    E, R, n, pe, pr = 2500, 9, 96, 0.3, 0.2
+    g = torch.Generator().manual_seed(17)
+    ent = (torch.randn(E, d, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    rel = (torch.randn(R, d, generator=g) * 0.3).to(DEV).requires_grad_(True)
+    a, p, lab = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    masks = {"a": (torch.rand(n, d, generator=g) >= pe).to(DEV), "p": (torch.rand(n, d, generator=g) >= pr).to(DEV),
+             "all": (torch.rand(E, d, generator=g) >= pe).to(DEV)}
+    w = (torch.rand(n, generator=g) + 0.5).to(DEV)
+    for direction in ("sp", "po"):
+        ent.grad = rel.grad = None
+        rows = km.ce_fused_dropout(scorer, 1.0, direction, ent, rel, a, p, lab, pe, pr, masks)
+        (rows * w).sum().backward()
+        ge, gr = ent.grad.clone(), rel.grad.clone()
+        ent.grad = rel.grad = None
+        r16 = lambda x: x + (x.detach().bfloat16().float() - x.detach())   # bf16 values, float32 gradients
+        ad = r16(ent[a] * masks["a"] / (1 - pe))
+        pd = r16(rel[p] * masks["p"] / (1 - pr))
+        td = r16(ent * masks["all"] / (1 - pe))
+        sc = tp.score_emb(scorer, ad, pd, td, "sp_") if direction == "sp" else tp.score_emb(scorer, td, pd, ad, "_po")
+        want = F.cross_entropy(sc, lab, reduction="none")
+        (want * w).sum().backward()
+        assert torch.allclose(rows.detach(), want.detach(), rtol=2e-3, atol=2e-3), float((rows - want).abs().max())
+        for got, ref, name in ((ge, ent.grad, "ent"), (gr, rel.grad, "rel")):
+            scale = float(ref.abs().max())
+            assert float((got - ref).abs().max()) <= 1e-2 * scale + 1e-6, (direction, name)
+        assert float(ge[~masks["all"].any(1) & ~torch.isin(torch.arange(E, device=DEV), a)].abs().sum()) == 0.0
+
+
+def test_embedder_dropout_mask_statistics():
+    """Without masks handed in the masks are torch's: keep rate 1 - p, kept elements scaled by 1 / (1 - p), a fresh mask
+    per call (the reference's torch.nn.Dropout)."""
+    from kge_amd import model as km
+    x = torch.ones(2000, 256, device=DEV)
+    y1, y2 = km.embedder_dropout(x, 0.25), km.embedder_dropout(x, 0.25)
+    kept = (y1 != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.01 and torch.allclose(y1[y1 != 0], torch.tensor(1 / 0.75, device=DEV))
+    assert not torch.equal(y1, y2)
+    assert km.embedder_dropout(x, 0.0) is x
