@@ -73,13 +73,13 @@ int run_rank_multi(const float* scores, long long lds, long long n, long long c,
                    float rtol, long long* rank, long long* ties, hipStream_t st);
 int run_rank_hist(const long long* rank, const long long* ties, int M, long long n, int policy, float* hist,
                   long long ldh, long long num_ent, long long* ranks_out, hipStream_t st);
-int run_eval_begin(const EvalLists& L, const Index& s, const Index& o, long long n, long long m, long long bld,
+int run_eval_begin(const EvalLists& L, const Index& s, const Index& o, long long n, long long m, long long rs, long long us,
                    long long* tgt, hipStream_t st);
-int run_eval_end(const EvalLists& L, long long n, long long m, long long bld, int M, int policy, long long* counts,
+int run_eval_end(const EvalLists& L, long long n, long long m, long long rs, long long us, int M, int policy, long long* counts,
                  float* hist, long long ldh, long long num_ent, long long* ranks_o, long long* ranks_s, hipStream_t st);
 int run_rank_bits(int lists, const long long* const* begin, const long long* const* end, const long long* const* col,
-                  const Index* keep, unsigned long long* const* bits, long long n, long long col_begin, long long m,
-                  long long ld, int set, hipStream_t st);
+                  const Index* keep, unsigned int* const* bits, long long n, long long col_begin, long long m,
+                  long long rs, long long us, int set, hipStream_t st);
 int run_pairs_bf16_v4_epi(int scorer, int epi, const Operand& A, const Operand* A2, const Operand& R,
                           const Operand& TG, int dir, int d, long long n, long long m, hipStream_t st, void* ws,
                           long long ws_bytes, const CeArgs& ce, unsigned long long* dbg);
@@ -790,11 +790,23 @@ int kge_rank_counts_multi(const float* scores, int64_t lds, int64_t n, int64_t c
 }
 
 // ---- scoring + rank counting in one kernel (no [n, 2m] score matrix)
-static inline int64_t rank_bits_ld(int64_t m) { return (m + 63) / 64; }
+// The filter bits of one (side, filter set k): bit (j & 31) of the 32-bit word [k + i * rs + (j >> 5) * us] of the
+// side's block says column j of the scored slice is filtered for row i.  WORD-major, the K sets of a side interleaved
+// (rs = K, us = K x pitch; the pitch: n rounded up to 64 rows): the words of columns [32 u, 32 u + 32) of all rows
+// and sets lie side by side.  The counting kernels hold one query row per lane and walk the columns in units of
+// 32: a wave's load of its 32 rows' words (both sets: one 8-byte load) touches one or two lines; row-major (one 72 KB
+// row of bits per query at the Wikidata5M shard) it touched 32 lines in 32 pages, a fifth of that kernel's time.
+struct RankBitsLayout {
+  int64_t rs, us, words;  // words per side (all its sets)
+};
+static inline RankBitsLayout rank_bits_layout(int64_t n, int64_t m, int num_filters) {
+  const int64_t pitch = (n + 63) / 64 * 64, cols = (m + 63) / 64 * 2, K = num_filters;
+  return RankBitsLayout{K, K * pitch, K * pitch * cols};
+}
 
 int64_t kge_score_rank_bits_bytes(int64_t n, int64_t m, int num_filters) {
   if (n <= 0 || m <= 0 || num_filters <= 0) return 0;
-  return 2 * (int64_t)num_filters * n * rank_bits_ld(m) * 8;
+  return 2 * rank_bits_layout(n, m, num_filters).words * 4 + 16;  // (+ 16: the last row's 8-byte load of one set)
 }
 
 // S / O / P: the query operands (table + index, or dense rows); TG: the scored entity rows, m of them, whose global
@@ -841,7 +853,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
       return KGE_ERR_UNSUPPORTED;
     if (!workspace || ((uintptr_t)workspace & 15)) return KGE_ERR_WORKSPACE;
   }
-  const int64_t bld = rank_bits_ld(m);
+  const RankBitsLayout bl = rank_bits_layout(n, m, num_filters);
   if (num_filters > 0 && (!filter_bits || ((uintptr_t)filter_bits & 7) ||
                           filter_bits_bytes < kge_score_rank_bits_bytes(n, m, num_filters)))
     return KGE_ERR_WORKSPACE;
@@ -857,11 +869,12 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   ce.rk_atol = atol;
   ce.rk_rtol = rtol;
   ce.rk_nfilt = num_filters;
-  ce.rk_bits_ld = bld;
+  ce.rk_bits_rs = bl.rs;
+  ce.rk_bits_us = bl.us;
   // lists: [sp side: filter sets][po side: filter sets]; the true column of the sp ranking is o, of the po ranking s
   const long long *lb[4], *le[4], *lc[4];
   Index keep[4];
-  unsigned long long* bits[4];
+  unsigned int* bits[4];
   for (int k = 0; k < num_filters; ++k) {
     for (int side = 0; side < 2; ++side) {
       const int q = side * num_filters + k;
@@ -871,13 +884,13 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
         lc[q] = (const long long*)(side ? po_col[k] : sp_col[k]);
       }
       keep[q] = side ? keep_s : keep_o;
-      bits[q] = (unsigned long long*)filter_bits + (int64_t)q * n * bld;
+      bits[q] = (unsigned int*)filter_bits + (int64_t)side * bl.words + k;
       ce.rk_bits[side][k] = bits[q];
     }
   }
   hipStream_t st = (hipStream_t)stream;
   const int nlists = manage_bits ? 2 * num_filters : 0;
-  int rc = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 1, st);
+  int rc = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 1, st);
   if (rc) return rc;
   if (exact_path) {
     for (int side = 0; side < 2 && rc == KGE_OK; ++side) {
@@ -890,13 +903,14 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
       rk.atol = atol;
       rk.rtol = rtol;
       rk.nfilt = num_filters;
-      rk.bits_ld = bld;
+      rk.bits_rs = bl.rs;
+      rk.bits_us = bl.us;
       for (int k = 0; k < num_filters; ++k) rk.bits[k] = ce.rk_bits[side][k];
       rc = run_pairs_exact(t->scorer, t->dtype, !(t->flags & KGE_FLAG_NO_MFMA), side ? O : S, P, TG,
                            side ? KGE_PO_ : KGE_SP_, (int)t->dim, (int)t->rel_dim, n, m, t->l_norm, nullptr, 1, st,
                            /*round_query=*/true, &rk);
     }
-    const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+    const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 0, st);
     return rc != KGE_OK ? rc : rcb;
   }
   if (v8_rank) {
@@ -907,7 +921,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
       rc = run_pairs_bf16_v8_rank(t->scorer, split, TG, (int)t->dim, n, m, qf, ce, st, nullptr,
                                   (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
     if (rc != KGE_ERR_UNSUPPORTED || split) {
-      const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+      const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 0, st);
       return rc != KGE_OK ? rc : rcb;
     }
     rc = KGE_OK;  // declined (nothing counted): the round-3 kernel below
@@ -924,7 +938,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   constexpr int64_t BLOCK = 2048;
   for (int64_t r0 = 0; r0 < n; r0 += BLOCK)  // every block's launch geometry first: decline before anything counts
     if (!pairs_bf16_v4_rank_launchable((int)t->dim, n - r0 < BLOCK ? n - r0 : BLOCK, m, workspace_bytes)) {
-      const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+      const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 0, st);
       return rcb != KGE_OK ? rcb : KGE_ERR_UNSUPPORTED;
     }
   for (int64_t r0 = 0; r0 < n && rc == KGE_OK; r0 += BLOCK) {
@@ -934,14 +948,14 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
       cb.rk_true[side] += r0 * true_stride;
       cb.rk_rank[side] += r0;
       cb.rk_ties[side] += r0;
-      for (int k = 0; k < num_filters; ++k) cb.rk_bits[side][k] += r0 * bld;
+      for (int k = 0; k < num_filters; ++k) cb.rk_bits[side][k] += r0 * bl.rs;
     }
     const Operand Sb = rows_from(S, r0), Ob = rows_from(O, r0), Pb = rows_from(P, r0);
     rc = run_pairs_bf16_v4_epi(t->scorer, V3_RANK, Sb, &Ob, Pb, TG, KGE_SP_, (int)t->dim, nb, m, st, workspace,
                                workspace_bytes, cb, nullptr);
   }
   // (also after a declined launch: the bits must not outlive the call)
-  const int rc2 = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bld, 0, st);
+  const int rc2 = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 0, st);
   return rc ? rc : rc2;
 }
 
@@ -1016,7 +1030,8 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
   if ((rc = check_index(s, false, n)) || (rc = check_index(p, false, n)) || (rc = check_index(o, false, n))) return rc;
   if (n == 0) return KGE_OK;
   if (!counts || !hist || (num_filters > 0 && !filters)) return KGE_ERR_INVALID_ARG;
-  const int64_t E = t->num_ent, R = t->num_rel, m = E, bld = rank_bits_ld(m);
+  const int64_t E = t->num_ent, R = t->num_rel, m = E;
+  const RankBitsLayout bl = rank_bits_layout(n, m, num_filters);
   int64_t off_tgt, off_true, total;
   eval_scratch_layout(n, num_filters, off_tgt, off_true, total);
   if (!scratch || ((uintptr_t)scratch & 15) || scratch_bytes < total) return KGE_ERR_WORKSPACE;
@@ -1046,11 +1061,11 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
       L.b[q] = side ? oi : pi;
       L.keep[q] = side ? si : oi;      // the row's own true column is never filtered
       L.range[q] = (long long*)sc + (int64_t)q * 2 * n;
-      L.bits[q] = (unsigned long long*)filter_bits + (int64_t)q * n * bld;
+      L.bits[q] = (unsigned int*)filter_bits + (int64_t)side * bl.words + k;
     }
   hipStream_t st = (hipStream_t)stream;
   // (1) filter lookup + filter bits + the target list (o | s)
-  if ((rc = run_eval_begin(L, si, oi, n, m, bld, tgt, st))) return rc;
+  if ((rc = run_eval_begin(L, si, oi, n, m, bl.rs, bl.us, tgt, st))) return rc;
   // (2) the true scores: the batch against its own targets, [n, 4 n] = (sp_ vs o | s, _po vs o | s); the diagonals
   // (i, i) and (i, 3 n + i) are elements of the score matrix bit for bit (each score is its own chain)
   kge_index tgi{tgt, KGE_I64, 0, 1};
@@ -1094,12 +1109,12 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
   // are persistent and the next batch relies on finding them all-zero (advisor, round 3)
   if (rc != KGE_OK) {
     EvalLists Lc = L;  // clear only
-    const int rc2 = run_eval_end(Lc, n, m, bld, 0, tie_policy, (long long*)counts, hist, ldh, E, nullptr, nullptr, st);
+    const int rc2 = run_eval_end(Lc, n, m, bl.rs, bl.us, 0, tie_policy, (long long*)counts, hist, ldh, E, nullptr, nullptr, st);
     if (rc != KGE_ERR_UNSUPPORTED)  // a failed launch may have left partial counts behind
       (void)hipMemsetAsync(counts, 0, (size_t)(4 * per) * sizeof(int64_t), st);
     return rc == KGE_ERR_UNSUPPORTED && rc2 != KGE_OK ? rc2 : rc;
   }
-  return run_eval_end(L, n, m, bld, M, tie_policy, (long long*)counts, hist, ldh, E, (long long*)ranks_o,
+  return run_eval_end(L, n, m, bl.rs, bl.us, M, tie_policy, (long long*)counts, hist, ldh, E, (long long*)ranks_o,
                       (long long*)ranks_s, st);
 }
 

@@ -376,9 +376,11 @@ struct CeArgs {
   long long rk_ld;
   float rk_atol, rk_rtol;
   int rk_nfilt;                      // <= 2
-  // bit (j & 63) of word [i * rk_bits_ld + (j >> 6)]: column j of the scored slice is filtered for row i
-  const unsigned long long* rk_bits[2][2];  // [side][filter set]
-  long long rk_bits_ld;
+  // bit (j & 31) of the 32-bit word [i * rk_bits_rs + (j >> 5) * rk_bits_us]: column j of the scored slice is
+  // filtered for row i.  The library's layout (api.hip: rank_bits_layout) is WORD-major -- rs = 1, us = the row pitch:
+  // the 32 rows of a wave read 32 neighbouring words (two cache lines) per unit of 32 columns, not one line per row
+  const unsigned int* rk_bits[2][2];  // [side][filter set]
+  long long rk_bits_rs, rk_bits_us;
 };
 
 // ---- the tie arithmetic of EntityRankingJob._get_ranks_and_num_ties (eval_entity_ranking.py:571-596), shared by
@@ -409,8 +411,9 @@ struct RankArgs {
   long long ld;
   float atol, rtol;
   int nfilt;                          // <= 2
-  const unsigned long long* bits[2];  // bit (j & 63) of word [i * bits_ld + (j >> 6)]: column j is filtered for row i
-  long long bits_ld;
+  // bit (j & 31) of the 32-bit word [i * bits_rs + (j >> 5) * bits_us]: column j is filtered for row i (FilterBits)
+  const unsigned int* bits[2];
+  long long bits_rs, bits_us;
   int col_tiles;                      // column tiles a workgroup walks (its counts leave it once)
 };
 
@@ -454,11 +457,14 @@ __device__ __forceinline__ void rank_acc_add(RankAcc& a, const float* tile, long
   a.G += G;
   a.C += C;
   const int fc = t == -__builtin_inff() ? 1 : 0;  // is -inf (a filtered column's score) close to the true score
-  const int sh = (int)(c0 & 63);
+  const int sh = (int)(c0 & 31);  // (W = 64: c0 is a multiple of 64)
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (k < rk.nfilt) {
-      const unsigned long long w = (rk.bits[k][orow * rk.bits_ld + (c0 >> 6)] >> sh) & vm;
+      const unsigned int* bw = rk.bits[k] + orow * rk.bits_rs + (c0 >> 5) * rk.bits_us;
+      unsigned long long w = bw[0];
+      if constexpr (W == 64) w |= (unsigned long long)bw[rk.bits_us] << 32;
+      w = (w >> sh) & vm;
       a.Gf[k] += G - __builtin_popcountll(gm & w);
       a.Cf[k] += C - __builtin_popcountll(cm & w) + fc * __builtin_popcountll(w);
     }
@@ -500,7 +506,7 @@ struct EvalLists {
   long long mult[EV_MAXQ];
   Index a[EV_MAXQ], b[EV_MAXQ], keep[EV_MAXQ];
   long long* range[EV_MAXQ];             // [2][n]: begin, end of row i's values (kept for the clearing pass)
-  unsigned long long* bits[EV_MAXQ];     // [n][bld]
+  unsigned int* bits[EV_MAXQ];           // the layout of CeArgs::rk_bits
 };
 
 }  // namespace kge

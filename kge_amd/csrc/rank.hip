@@ -362,29 +362,29 @@ struct RankBitLists {
   const long long* end[4];
   const long long* col[4];
   Index keep[4];
-  unsigned long long* bits[4];
+  unsigned int* bits[4];
 };
 
 __global__ __launch_bounds__(256) void rank_bits_kernel(RankBitLists B, long long n, long long col_begin,
-                                                        long long m, long long ld, int set) {
+                                                        long long m, long long rs, long long us, int set) {
   const int q = blockIdx.y;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const long long keep = index_at(B.keep[q], i);
   const long long* __restrict__ col = B.col[q];
-  unsigned long long* row = B.bits[q] + i * ld;
+  unsigned int* row = B.bits[q] + i * rs;
   for (long long e = B.begin[q][i] + (threadIdx.x & 63); e < B.end[q][i]; e += 64) {
     const long long g = col[e];
     const long long j = g - col_begin;
     if (g == keep || j < 0 || j >= m) continue;
-    if (set) atomicOr(row + (j >> 6), 1ull << (j & 63));
-    else row[j >> 6] = 0ull;
+    if (set) atomicOr(row + (j >> 5) * us, 1u << (j & 31));
+    else row[(j >> 5) * us] = 0u;
   }
 }
 
 int run_rank_bits(int lists, const long long* const* begin, const long long* const* end, const long long* const* col,
-                  const Index* keep, unsigned long long* const* bits, long long n, long long col_begin, long long m,
-                  long long ld, int set, hipStream_t st) {
+                  const Index* keep, unsigned int* const* bits, long long n, long long col_begin, long long m,
+                  long long rs, long long us, int set, hipStream_t st) {
   if (n == 0 || lists == 0) return KGE_OK;
   if (lists < 0 || lists > 4) return KGE_ERR_UNSUPPORTED;
   RankBitLists B{};
@@ -393,7 +393,7 @@ int run_rank_bits(int lists, const long long* const* begin, const long long* con
     B.keep[q] = keep[q]; B.bits[q] = bits[q];
   }
   hipLaunchKernelGGL(rank_bits_kernel, dim3((unsigned)((n + 3) / 4), (unsigned)lists), dim3(256), 0, st, B, n,
-                     col_begin, m, ld, set);
+                     col_begin, m, rs, us, set);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
@@ -404,7 +404,7 @@ int run_rank_bits(int lists, const long long* const* begin, const long long* con
 // blockIdx.y < nq: one WAVE per (row, list): the 64-ary search of filter_lookup_kernel, then the wave sets the bits
 // of the row's filtered columns.  blockIdx.y == nq: the target list of the true-score launch, (o | s) as int64.
 __global__ __launch_bounds__(256) void eval_begin_kernel(EvalLists L, Index s, Index o, long long n, long long m,
-                                                         long long bld, long long* __restrict__ tgt) {
+                                                         long long rs, long long us, long long* __restrict__ tgt) {
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
   const int lane = threadIdx.x & 63;
@@ -444,18 +444,18 @@ __global__ __launch_bounds__(256) void eval_begin_kernel(EvalLists L, Index s, I
   }
   const long long keep = index_at(L.keep[q], i);
   const long long* __restrict__ col = L.values[q];
-  unsigned long long* row = L.bits[q] + i * bld;
+  unsigned int* row = L.bits[q] + i * rs;
   for (long long x = b + lane; x < e; x += 64) {
     const long long g = col[x];
     if (g == keep || g < 0 || g >= m) continue;
-    atomicOr(row + (g >> 6), 1ull << (g & 63));
+    atomicOr(row + (g >> 5) * us, 1u << (g & 31));
   }
 }
 
 // Blocks [0, nq * ceil(n / 4)): the filter bits of (row, list) cleared again (the words that were set: the buffer is
 // all-zero between batches).  The rest: _get_ranks (tie policy) + hist_all of both directions (rank_hist_kernel) on
 // the counters [2 (o | s)][2 (rank | ties)][M][n], which are zeroed for the next batch on the way.
-__global__ __launch_bounds__(256) void eval_end_kernel(EvalLists L, long long n, long long m, long long bld, int M,
+__global__ __launch_bounds__(256) void eval_end_kernel(EvalLists L, long long n, long long m, long long rs, long long us, int M,
                                                        int policy, long long* __restrict__ counts,
                                                        float* __restrict__ hist, long long ldh, long long num_ent,
                                                        long long* __restrict__ ranks_o, long long* __restrict__ ranks_s) {
@@ -469,11 +469,11 @@ __global__ __launch_bounds__(256) void eval_end_kernel(EvalLists L, long long n,
     const long long b = L.range[q][i], e = L.range[q][n + i];
     const long long keep = index_at(L.keep[q], i);
     const long long* __restrict__ col = L.values[q];
-    unsigned long long* row = L.bits[q] + i * bld;
+    unsigned int* row = L.bits[q] + i * rs;
     for (long long x = b + lane; x < e; x += 64) {
       const long long g = col[x];
       if (g == keep || g < 0 || g >= m) continue;
-      row[g >> 6] = 0ull;
+      row[(g >> 5) * us] = 0u;
     }
     return;
   }
@@ -493,19 +493,19 @@ __global__ __launch_bounds__(256) void eval_end_kernel(EvalLists L, long long n,
   if (r >= 0 && r < num_ent) unsafeAtomicAdd(hist + (u / n) * ldh + r, 1.0f);
 }
 
-int run_eval_begin(const EvalLists& L, const Index& s, const Index& o, long long n, long long m, long long bld,
-                   long long* tgt, hipStream_t st) {
+int run_eval_begin(const EvalLists& L, const Index& s, const Index& o, long long n, long long m, long long rs,
+                   long long us, long long* tgt, hipStream_t st) {
   if (n == 0) return KGE_OK;
   hipLaunchKernelGGL(eval_begin_kernel, dim3((unsigned)((n + 3) / 4), (unsigned)(L.nq + 1)), dim3(256), 0, st, L, s, o,
-                     n, m, bld, tgt);
+                     n, m, rs, us, tgt);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
-int run_eval_end(const EvalLists& L, long long n, long long m, long long bld, int M, int policy, long long* counts,
+int run_eval_end(const EvalLists& L, long long n, long long m, long long rs, long long us, int M, int policy, long long* counts,
                  float* hist, long long ldh, long long num_ent, long long* ranks_o, long long* ranks_s, hipStream_t st) {
   if (n == 0) return KGE_OK;
   const long long blocks = (long long)L.nq * ((n + 3) / 4) + (2LL * M * n + 255) / 256;
-  hipLaunchKernelGGL(eval_end_kernel, dim3((unsigned)blocks), dim3(256), 0, st, L, n, m, bld, M, policy, counts, hist,
+  hipLaunchKernelGGL(eval_end_kernel, dim3((unsigned)blocks), dim3(256), 0, st, L, n, m, rs, us, M, policy, counts, hist,
                      ldh, num_ent, ranks_o, ranks_s);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }

@@ -577,12 +577,15 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   int rk_g = 0, rk_c = 0;           // raw: greater-and-not-close, close
   int rk_fg[2] = {0, 0}, rk_fc[2] = {0, 0}, rk_fn[2] = {0, 0};  // per filter set: filtered & greater, & close, filtered
   unsigned long long rk_w[2] = {0, 0};  // the row's filter bits of the NEXT tile (prefetched one tile ahead)
-  const unsigned long long* rk_bp[2] = {nullptr, nullptr};
+  const unsigned int* rk_bp[2] = {nullptr, nullptr};
   auto rk_fetch = [&](int tt) __attribute__((always_inline)) {
-    const long long tl = tile_lo + (long long)tt * tile_st;
+    const long long tl = tile_lo + (long long)tt * tile_st;  // tile of 64 columns = two 32-bit words of the row
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-      if (k < ce.rk_nfilt) rk_w[k] = tt < ntl ? rk_bp[k][tl] : 0ull;
+      if (k < ce.rk_nfilt) {
+        const unsigned int* wp = rk_bp[k] + 2 * tl * ce.rk_bits_us;
+        rk_w[k] = tt < ntl ? (unsigned long long)wp[0] | ((unsigned long long)wp[ce.rk_bits_us] << 32) : 0ull;
+      }
   };
   if constexpr (EPI == V3_RANK) {
     long long orow = (long long)rgl * V4_ROWS + 32 * w4 + fi;
@@ -593,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     rk_slow = __any(!(__builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al))) != 0;
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-      if (k < ce.rk_nfilt) rk_bp[k] = ce.rk_bits[rk_side][k] + orow * ce.rk_bits_ld;
+      if (k < ce.rk_nfilt) rk_bp[k] = ce.rk_bits[rk_side][k] + orow * ce.rk_bits_rs;
     rk_fetch(0);
   }
   // Bit layout of the per-lane masks = the tile's 64 columns: element r of half hf is bit 32 hf + 8 (r >> 2) + 4 fh + (r & 3).

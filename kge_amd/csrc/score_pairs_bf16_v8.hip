@@ -486,23 +486,32 @@ struct V8RankArgs {
   CeArgs ce;
 };
 
-template <int SCORER, int HH, int SPLIT>
+// PROBE (builds with -DKGE_V8_PROBES only; KGE_V8R_PROBE picks one): timing variants that leave work out -- bit 0 the
+// comparisons, 1 the table pieces of the steady state, 2 the unit barrier, 3 the filter-word loads, 4 the LDS reads
+template <int SCORER, int HH, int SPLIT, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a) {
+  // A unit = NACC sub-units of 32 table rows, one accumulator each: one at d = 512, TWO at d = 256 (64 rows x 512
+  // bytes: the same 32 KiB).  With two accumulators consecutive MFMAs are independent (A0 B0 A1 B1 ...): what stands
+  // between them -- LDS reads, table pieces, word loads -- no longer breaks a back-to-back dependent issue (measured
+  // on the one-accumulator d = 256 form, tools/rank8_stamps.py with a -DKGE_V8_PROBES build: 2.5 k cycles per 32
+  // columns against 0.6 k of bare MFMAs), and barrier, waits and pieces are paid once per 64 columns.
+  constexpr int NACC = HH == 128 ? 2 : 1;
+  constexpr int UT = V8_UT * NACC;        // table rows per unit: 32 / 64
   constexpr int NKB = 2 * HH / 16;        // 32 / 16 K-blocks
   constexpr int ROWB = 4 * HH;            // bytes per table row
   constexpr int SPR = ROWB / 16;          // 16-byte slots per row: 64 / 32
   constexpr int RPP = 64 / SPR;           // table rows per 1-KiB piece: 1 / 2
-  constexpr int UNITB = V8_UT * ROWB;     // 32 / 16 KiB
+  constexpr int UNITB = UT * ROWB;        // 32 KiB
+  constexpr int SUBB = V8_UT * ROWB;      // bytes of a sub-unit
   constexpr int NBUF = 4;
   constexpr int SMEM = NBUF * UNITB;
-  constexpr int NP = UNITB / 1024 / 8;    // pieces per unit and wave: 4 / 2
+  constexpr int NP = UNITB / 1024 / 8;    // pieces per unit and wave: 4
   constexpr int RW = SPLIT ? 16 : 32;     // real query rows per wave
-  constexpr int PF = 8;
-  constexpr int PB = NKB == 32 ? 14 : 6;  // MFMA slot of the barrier
-  constexpr int SPE = NKB / 16;           // MFMA slots per element of the comparison pipeline: 2 / 1
-  // a chain's vector-memory operations, in order: slot 1: two word loads | behind slot PB: NP pieces
-  constexpr int VM_BAR = NP + 4;          // behind the pieces of unit k + 1 (chain k - 2): chain k - 1 (2 + NP), 2 loads
-  constexpr int VM_FIN = 2 * NP + 2;      // behind the words of unit k - 1 (chain k - 1, slot 1): NP, then 2 + NP
+  constexpr int PF = 4;                   // K-blocks read ahead (8 at d = 512 cost 16 registers the kernel spilled)
+  constexpr int PB = NKB == 32 ? 14 : 6;  // K-block of the barrier
+  // rank_unit_raw for sub-units without a filtered column: at d = 256, where the comparisons weigh half as much as
+  // the matrix work (at d = 512 the second form costs registers the kernel does not have: scratch, +3 us per launch)
+  constexpr bool RAWFAST = HH == 128;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   if (a.n < 0) smem[threadIdx.x] = 0;
 
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
   auto dma_piece = [&](int un, int ks, auto kc) __attribute__((always_inline)) {
     constexpr int kk = decltype(kc)::value;
     const int ru = rp0 + kk * RPP;  // the piece's first row within the unit
-    const long long r0 = (long long)(u_lo + un) * V8_UT + ru;
+    const long long r0 = (long long)(u_lo + un) * UT + ru;
     const unsigned int dk = (unsigned int)((ks & (NBUF - 1)) * UNITB + ru * ROWB);
     // lane (lr, slot) fetches the 16-byte slot `slot ^ (row & 15)` of row ru + lr into slot `slot` of its LDS row
     const unsigned int sw = (unsigned int)((slot ^ ((ru + lr) & 15)) << 4);
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     if (++du == sux) du = 0;
   };
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
+  for (int k = 0; k < NBUF - 1; ++k) {
     const int un = dq < g1 ? du : ulast;
     v4_static_for<0, NP>([&](auto kc) __attribute__((always_inline)) { dma_piece(un, k, kc); });
     dma_advance();
@@ -584,21 +593,22 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
   unsigned int bp[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) bp[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
-  bf16x8 bq[PF];
-  auto bread = [&](bf16x8& dst, auto kc) __attribute__((always_inline)) {
-    constexpr int kb = decltype(kc)::value;
+  bf16x8 bq[NACC][PF];
+  auto bread = [&](bf16x8& dst, auto kc, auto ac) __attribute__((always_inline)) {
+    constexpr int kb = decltype(kc)::value, sub = decltype(ac)::value;
     const unsigned int addr = bp[kb & 7];
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"((kb >> 3) * 256 + sub * SUBB) : "memory");
   };
 
   // ---- per-row state of the counts (rank.hip's arithmetic; see pairs_bf16_v4_kernel<V3_RANK>)
   const CeArgs& ce = a.ce;
   const bool counts_here = SPLIT ? ((fi >> 3) & 1) == 0 : true;  // split: the q_lo lanes duplicate their q_hi lane
   float rk_t = 0.0f, rk_al = 0.0f;
+  float rk_hi = 0.0f, rk_lo = 0.0f;  // exact thresholds of the raw counts: see rank_unit_raw
   bool rk_slow = false;
   int rk_g = 0, rk_c = 0, rk_fg[2] = {0, 0}, rk_fc[2] = {0, 0}, rk_fn[2] = {0, 0};
   // filter words: scalar base per filter set (this side's bits; dummy: any readable word) + the row's byte offset
-  const unsigned char* rk_base[2] = {(const unsigned char*)a.qf, (const unsigned char*)a.qf};
+  const unsigned char* rk_base = (const unsigned char*)a.qf;
   unsigned int rk_off = 0;
   int orow_cur = 0;
   int side_cur = 0;
@@ -615,8 +625,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       return v;
     }
   };
-  // the finished unit at slice position `cu` into the counters; w0 / w1 = the row's filter words of that unit
-  auto rank_unit = [&](const f32x16& pv, int cu, unsigned int w0, unsigned int w1) __attribute__((always_inline)) {
+  // the finished sub-unit `sub` of the unit at slice position `cu` into the counters; w0 / w1 = the row's filter words
+  auto rank_unit = [&](const f32x16& pv, int cu, int sub, unsigned int w0, unsigned int w1) __attribute__((always_inline)) {
     unsigned int g, c;
     if (rk_slow) {  // some row of the wave has an infinite true score / tolerance: the generic arithmetic
       g = c = 0u;
@@ -635,17 +645,21 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       unsigned int ng = 0u, nc = 0u;
 #pragma unroll
       for (int r = 15; r >= 0; --r) {  // element r ends up at bit r
-        const float e = __builtin_fmaxf(full_score(pv[r]), -__builtin_inff()) - rk_t;
+        // max(x, -inf): NaN -> -inf.  One v_max_f32 (fmaxf compiles to two: it first quiets a signalling NaN, which
+        // an accumulator never holds)
+        float xq;
+        asm("v_max_f32 %0, 0xff800000, %1" : "=v"(xq) : "v"(full_score(pv[r])));
+        const float e = xq - rk_t;
         ng = __builtin_amdgcn_alignbit(ng, __builtin_bit_cast(unsigned int, rk_al - e), 31);
         nc = __builtin_amdgcn_alignbit(nc, __builtin_bit_cast(unsigned int, rk_al - __builtin_fabsf(e)), 31);
       }
       g = rk_spread(ng & 0xffffu);
       c = rk_spread(~nc & 0xffffu);
     }
-    const long long c0t = (long long)(u_lo + cu) * V8_UT;
+    const long long c0t = ((long long)(u_lo + cu) * NACC + sub) * V8_UT;
     unsigned int mine = counts_here ? (0x0f0f0f0fu << (4 * fh)) : 0u;
     const long long rem = m - c0t;
-    if (rem < V8_UT) mine &= (1u << rem) - 1u;  // (rem >= 1: the unit exists)
+    if (rem < V8_UT) mine &= rem > 0 ? (1u << rem) - 1u : 0u;  // (the unit exists; its second sub-unit may not)
     g = (g << (4 * fh)) & mine;
     c = (c << (4 * fh)) & mine;
     rk_g += __builtin_popcount(g);
@@ -659,6 +673,23 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
         rk_fn[k] += __builtin_popcount(ww[k]);
       }
     }
+  };
+  // The raw counts alone, for a sub-unit without a filtered column in any row of the wave (all but ~1 % of them on a
+  // Wikidata5M shard): two compares and two carry-adds per score instead of seven operations.  x - t rounds
+  // monotonically in x, so  x - t > allowed  <=>  x > rk_hi  and  |x - t| <= allowed  <=>  rk_lo <= x <= rk_hi  for
+  // rk_hi = the largest float with fl(rk_hi - t) <= allowed, rk_lo = the smallest with fl(rk_lo - t) >= -allowed
+  // (found per row at the pair's start and CHECKED there -- a row whose thresholds do not verify sends its wave down
+  // the generic path); NaN fails both compares like the -inf it stands for, +inf is greater, -inf nothing.
+  auto rank_unit_raw = [&](const f32x16& pv) __attribute__((always_inline)) {
+    int g = 0, c2 = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float x = full_score(pv[r]);
+      g += x > rk_hi ? 1 : 0;
+      c2 += x >= rk_lo ? 1 : 0;
+    }
+    rk_g += g;
+    rk_c += c2 - g;
   };
   // the row's counters out (the two lanes fh = 0 / 1 of a row first), then zeroed
   auto rank_flush = [&]() __attribute__((always_inline)) {
@@ -682,13 +713,16 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     }
     rk_g = rk_c = 0;
   };
-  auto load_words = [&](int cu, unsigned int& w0, unsigned int& w1) __attribute__((always_inline)) {
-    // the row's filter words of the unit at slice position cu: scalar base (the filter set's bits + the unit's 32-bit
-    // half: word index = unit) + the row's offset; fewer than two filter sets: a dummy word
-    const unsigned char* wb0 = rk_base[0] + (ce.rk_nfilt > 0 ? (long long)(u_lo + cu) * 4 : 0);
-    const unsigned char* wb1 = rk_base[1] + (ce.rk_nfilt > 1 ? (long long)(u_lo + cu) * 4 : 0);
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(w0) : "v"(rk_off), "s"(wb0) : "memory");
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(w1) : "v"(rk_off), "s"(wb1) : "memory");
+  auto load_words = [&](int cu, u32x2 (&w)[NACC]) __attribute__((always_inline)) {
+    // the row's filter words of the unit at slice position cu, BOTH filter sets in one 8-byte load: scalar base (the
+    // side's bits + the sub-unit's word column) + the row's offset (api.hip rank_bits_layout: word-major, the sets
+    // of a side interleaved).  One set: the second word is the next row's (never looked at); none: 8 bytes of the
+    // fragments.
+#pragma unroll
+    for (int sub = 0; sub < NACC; ++sub) {
+      const unsigned char* wb = rk_base + (ce.rk_nfilt > 0 ? ((long long)(u_lo + cu) * NACC + sub) * ce.rk_bits_us * 4 : 0);
+      asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[sub]) : "v"(rk_off), "s"(wb) : "memory");
+    }
   };
 
   // The consumer loop, in two phase-shifted forms.  Per unit a wave runs its MFMA chain and then a BURST of ~140 VALU
@@ -702,46 +736,74 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
   auto run = [&](auto half) __attribute__((always_inline)) {
     constexpr int HALF = decltype(half)::value;
     constexpr int PBH = HALF ? 0 : PB;              // slot of the barrier
-    constexpr int WSH = HALF ? NP + 1 : 1;          // slot of the NEXT unit's filter-word loads
-    // vector-memory operations in order, per chain: HALF 0: words (slot 1) | pieces behind the barrier;  HALF 1: pieces
-    // (slots 1 .. NP) | words.  Behind the pieces of unit k + 1 (chain k - 2) until P(k): NP + 4 operations either way;
-    // behind the words of unit k (chain k - 1) until the burst behind chain k: 2 NP + 2 / NP + 2
-    constexpr int VMB = NP + 4;
-    constexpr int VMF = HALF ? NP + 2 : 2 * NP + 2;
-    f32x16 acc;
-    unsigned int wc0 = 0, wc1 = 0, wn0 = 0, wn1 = 0;  // filter words of the current / the next unit
+    // vector-memory operations in order, per chain: its NP pieces (behind the barrier / in K-blocks 1 .. NP), then --
+    // behind the last MFMA -- the word loads of the NEXT unit.  Behind the pieces of unit k + 1 (chain k - NBUF + 2)
+    // until P(k): that chain's word loads and the NBUF - 3 whole chains between (NP + WV each);  behind the words of
+    // unit k (end of chain k - 1) until the end of chain k: its NP pieces.
+    // The words travel wn -> wc by a register copy BEHIND the wait for wn (a copy of a register whose load is still
+    // in flight reads the old value: nothing interlocks; with the copy at the end of the burst before -- a chain
+    // after the request -- a table from HBM made a hub row's filtered counts differ now and then).
+    constexpr int NPV = (PROBE & 2) ? 0 : NP, WV = (PROBE & 8) ? 0 : NACC;  // (probes: what is really issued)
+    constexpr int VMB = (NBUF - 3) * (NPV + WV) + WV;
+    static_assert(VMB + NP + NACC < 64, "vmcnt is a 6-bit counter");
+    constexpr int VMF = NPV;
+    f32x16 acc[NACC];
+    u32x2 wc[NACC] = {}, wn[NACC] = {};  // filter words (set 0, set 1) of the current / the next unit
     auto chain = [&](int ks, int cu, int cu_next) __attribute__((always_inline)) {
       const unsigned int bdelta = ((ks + 1) & (NBUF - 1)) ? (unsigned int)UNITB : (unsigned int)(-(NBUF - 1) * UNITB);
       const int un = dq < g1 ? du : ulast;
       v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
         constexpr int kb = decltype(kc)::value;
-        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"((PF - 1) * NACC) : "memory");
         if constexpr (kb == PBH) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"i"(VMB) : "memory");  // this wave's pieces of unit ks + 1 have landed
-          __builtin_amdgcn_s_barrier();                               // P(ks)
+          if constexpr (!(PROBE & 4)) __builtin_amdgcn_s_barrier();   // P(ks)
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kb == 0) {
-          const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[0], afr[0], zero, 0, 0, 0);
-        } else {
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[kb % PF], afr[kb], acc, 0, 0, 0);
-        }
+        v4_static_for<0, NACC>([&](auto ac) __attribute__((always_inline)) {
+          constexpr int sub = decltype(ac)::value;
+          if constexpr (kb == 0) {
+            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][0], afr[0], zero, 0, 0, 0);
+          } else {
+            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][kb % PF], afr[kb], acc[sub], 0, 0, 0);
+          }
+        });
         if constexpr (kb + PF == NKB) {
 #pragma unroll
           for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %0" : "+v"(bp[t]) : "s"(bdelta));
         }
-        bread(bq[kb % PF], std::integral_constant<int, (kb + PF) % NKB>{});
-        if constexpr (kb == WSH) load_words(cu_next, wn0, wn1);
-        if constexpr (kb > PBH && kb <= PBH + NP) dma_piece(un, ks + 3, std::integral_constant<int, kb - PBH - 1>{});
+        if constexpr (!(PROBE & 16))
+          v4_static_for<0, NACC>([&](auto ac) __attribute__((always_inline)) {
+            bread(bq[decltype(ac)::value][kb % PF], std::integral_constant<int, (kb + PF) % NKB>{}, ac);
+          });
+        if constexpr (kb > PBH && kb <= PBH + NP && !(PROBE & 2))
+          dma_piece(un, ks + NBUF - 1, std::integral_constant<int, kb - PBH - 1>{});
       });
       dma_advance();
-      // the burst: this unit's comparisons; its words were requested a chain ago
-      asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wc0), "+v"(wc1) : "i"(VMF) : "memory");
-      rank_unit(acc, cu, wc0, wc1);
-      wc0 = wn0;
-      wc1 = wn1;
-      if (HALF == 0) stamp();  // (a stamp is a store: with stamps on, the counted waits of this wave wait for more)
+      // this unit's words (requested behind the chain before) have landed: into wc, then the next unit's request
+      if constexpr (NACC == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wn[0]), "+v"(wn[1]) : "i"(VMF) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wn[0]) : "i"(VMF) : "memory");
+#pragma unroll
+      for (int sub = 0; sub < NACC; ++sub) wc[sub] = wn[sub];
+      // (the copies are instructions in front of the loads: the compiler must not fold wc into wn)
+      if constexpr (NACC == 2) asm volatile("" : "+v"(wc[0]), "+v"(wc[1]) : : "memory");
+      else asm volatile("" : "+v"(wc[0]) : : "memory");
+      if constexpr (!(PROBE & 8)) load_words(cu_next, wn);
+      // the burst: this unit's comparisons -- the raw counts alone where no row of the wave has a filtered column
+      // in the sub-unit and every one of its columns exists
+#pragma unroll
+      for (int sub = 0; sub < NACC; ++sub) {
+        if constexpr (PROBE & 1) {
+          asm volatile("" : : "v"(acc[sub][0]), "v"(acc[sub][15]));
+        } else {
+          const unsigned int wany = (ce.rk_nfilt > 0 ? wc[sub][0] : 0u) | (ce.rk_nfilt > 1 ? wc[sub][1] : 0u);
+          const bool whole = ((long long)(u_lo + cu) * NACC + sub + 1) * V8_UT <= m;
+          if (!RAWFAST || rk_slow || !whole || __any(wany != 0u)) rank_unit(acc[sub], cu, sub, wc[sub][0], wc[sub][1]);
+          else rank_unit_raw(acc[sub]);
+        }
+      }
+      if (HALF == 0 && dbg_i < 32) stamp();  // (a stamp is a store: the counted waits of this wave wait for more)
     };
 
     int g = g0, ks = 0;
@@ -760,11 +822,33 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       rk_t = ce.rk_true[side][orow * ce.rk_true_stride];
       if (rk_t != rk_t) rk_t = -__builtin_inff();
       rk_al = ce.rk_atol + __builtin_fabsf(ce.rk_rtol * rk_t);
-      rk_slow = __any(!(__builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al))) != 0;
+      bool fine = __builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al);
+      if constexpr (RAWFAST) {  // the thresholds of rank_unit_raw: a start one rounding off at most, walked to the exact floats, then checked
+        auto f2u = [](float x) { return __builtin_bit_cast(unsigned int, x); };
+        auto u2f = [](unsigned int x) { return __builtin_bit_cast(float, x); };
+        auto up = [&](float x) { return x == 0.0f ? u2f(1u) : u2f(x > 0.0f ? f2u(x) + 1u : f2u(x) - 1u); };
+        auto down = [&](float x) { return x == 0.0f ? u2f(0x80000001u) : u2f(x > 0.0f ? f2u(x) - 1u : f2u(x) + 1u); };
+        float hi = rk_t + rk_al, lo = rk_t - rk_al;
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
-        if (k < ce.rk_nfilt) rk_base[k] = (const unsigned char*)ce.rk_bits[side][k];
-      rk_off = ce.rk_nfilt > 0 ? (unsigned int)(orow * ce.rk_bits_ld * 8) : 0u;
+        for (int it = 0; it < 3; ++it) {
+          if (hi - rk_t > rk_al) hi = down(hi);
+          if (lo - rk_t < -rk_al) lo = up(lo);
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+          const float u = up(hi), dn = down(lo);
+          if (u - rk_t <= rk_al) hi = u;
+          if (dn - rk_t >= -rk_al) lo = dn;
+        }
+        fine = fine && __builtin_isfinite(hi) && __builtin_isfinite(lo) && hi - rk_t <= rk_al && up(hi) - rk_t > rk_al &&
+               lo - rk_t >= -rk_al && down(lo) - rk_t < -rk_al;
+        rk_hi = hi;
+        rk_lo = lo;
+      }
+      rk_slow = __any(!fine) != 0;
+      // (the sets of a side lie interleaved: one base.  No set at all: the loads read the fragments)
+      if (ce.rk_nfilt > 0) rk_base = (const unsigned char*)ce.rk_bits[side][0];
+      rk_off = ce.rk_nfilt > 0 ? (unsigned int)(orow * ce.rk_bits_rs * 4) : 0u;
       // ---- fragments (groups of 128 operand rows; a chunk = two groups)
       int grp = 2 * ch + (wave >> 2);
       if (grp >= a.rgn1) grp = a.rgn1 - 1;
@@ -788,13 +872,24 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
         constexpr int kb = decltype(kc)::value;
         afr[kb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, flo + kb * 1024, 0, 16 /* sc1 */));
       });
-      load_words(0, wc0, wc1);  // the pair's first unit
+      load_words(0, wn);  // the pair's first unit
       // fragments, words, pieces of the ring fill, the atomics of the pair before: everything of this wave has landed
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(wc0), "+v"(wc1) : : "memory");
+      if constexpr (NACC == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]) : : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wn[0]) : : "memory");
+      // The compiler does not read the wait above: without a use of the fragments HERE it puts its own
+      // s_waitcnt vmcnt(NKB - 1) ... vmcnt(0) in front of their first uses -- inside the chain loop, where they ran in
+      // every chain and drained the table pieces requested for the units ahead (seen in the ISA; the ring's depth
+      // was one chain instead of three, the price of a table that comes from HBM).
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(afr[kb]));
       if (first) {
         __builtin_amdgcn_s_barrier();  // R0: units 0 .. 2 of the list have landed
         if (HALF == 0) stamp();
-        v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
+        v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) {
+          v4_static_for<0, NACC>([&](auto ac) __attribute__((always_inline)) {
+            bread(bq[decltype(ac)::value][decltype(jc)::value], jc, ac);
+          });
+        });
         first = false;
       }
       for (int i = 0; i < cnt; ++i) {
@@ -806,7 +901,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       pair += pstep;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4]), "v"(bq[5]), "v"(bq[6]), "v"(bq[7]));
+#pragma unroll
+    for (int sub = 0; sub < NACC; ++sub)
+#pragma unroll
+      for (int jj = 0; jj < PF; ++jj) asm volatile("" : : "v"(bq[sub][jj]));
+    if (HALF == 0 && a.dbg != nullptr && tid == 0) {  // the end of the workgroup's list and its length in units
+      a.dbg[(long long)blockIdx.x * 64 + 40] = __builtin_readcyclecounter();
+      a.dbg[(long long)blockIdx.x * 64 + 41] = (unsigned long long)(g1 - g0);
+    }
   };
   if (wave < 4) run(std::integral_constant<int, 0>{});
   else run(std::integral_constant<int, 1>{});
@@ -823,8 +925,10 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   if (TG.ld * 2 >= (1LL << 28) || ((uintptr_t)qf & 15)) return KGE_ERR_UNSUPPORTED;
   const long long rgr = split ? 64 : 128;
   const long long rgn1 = (n + rgr - 1) / rgr;
-  const long long nunits = (m + V8_UT - 1) / V8_UT;
+  const long long ut = d == 256 ? 2 * V8_UT : V8_UT;  // table rows per unit (the kernel's NACC sub-units of 32)
+  const long long nunits = (m + ut - 1) / ut;
   if (rgn1 > (1 << 20) || (rgn1 + 1) * nunits >= (1LL << 30)) return KGE_ERR_UNSUPPORTED;
+  if (ce.rk_nfilt > 0 && n * ce.rk_bits_rs * 4 >= (1LL << 32)) return KGE_ERR_UNSUPPORTED;  // (the row's 32-bit offset)
   int cus = v8_cu_count() - reserve_cus;
   if (cus > 256) cus = 256;
   if (cus < 8) cus = 8;
@@ -842,6 +946,20 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   a.dbg = dbg != nullptr ? dbg : v6_get_stamps();
   a.ce = ce;
   const dim3 grid(8 * a.wpx), block(512);
+#ifdef KGE_V8_PROBES
+  if (const char* pe = getenv("KGE_V8R_PROBE")) {
+    const int pr = atoi(pe);
+    if (pr > 0 && scorer == KGE_COMPLEX && !split && d == 256) {
+#define KGE_V8RP(PR)                                                                                          \
+  if (pr == PR) {                                                                                             \
+    hipLaunchKernelGGL((pairs_bf16_v8_rank_kernel<KGE_COMPLEX, 128, 0, PR>), grid, block, 0, st, a);          \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;                                         \
+  }
+      KGE_V8RP(1) KGE_V8RP(2) KGE_V8RP(3) KGE_V8RP(8) KGE_V8RP(9) KGE_V8RP(11) KGE_V8RP(15) KGE_V8RP(31)
+#undef KGE_V8RP
+    }
+  }
+#endif
 #define KGE_V8R(SC, HHV, SP) hipLaunchKernelGGL((pairs_bf16_v8_rank_kernel<SC, HHV, SP>), grid, block, 0, st, a)
 #define KGE_V8R2(SC)                                                \
   if (d == 512) { if (split) KGE_V8R(SC, 256, 1); else KGE_V8R(SC, 256, 0); } \

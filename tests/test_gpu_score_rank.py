@@ -82,6 +82,9 @@ CASES = [
     ("distmult", 20000, 13, 512, 1000, 2, ((0, 10000), (10000, 10001), (10001, 20000))),
     ("distmult", 3000, 5, 256, 1151, 1, None),          # 9 + 9 row groups: column groups in whole groups of eight
     ("complex", 2100, 5, 256, 2500, 2, None),           # more rows than one launch holds: row blocks of 2,048
+    # ONE filter set on a table whose rows of filter bits are 37 KB apart (the unused second word load of a row once
+    # went through the row's offset into a buffer that has no such rows); a table beyond the L2, the deep d = 256 ring
+    ("distmult", 300007, 5, 256, 512, 1, None),
 ]
 
 

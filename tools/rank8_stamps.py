@@ -12,7 +12,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from kge_amd import _lib, engine  # noqa: E402
 
+if os.environ.get("RANK8_LIB"):  # a library built with -DKGE_V8_PROBES (tools/README.md)
+    _lib.LIB_PATH = os.path.abspath(os.environ["RANK8_LIB"])
+    os.environ["KGE_AMD_BINDING"] = "ctypes"
+
 dev = torch.device("cuda", 0)
+# RANK8_PROBES: comma list of KGE_V8R_PROBE values (a library built with -DKGE_V8_PROBES); 0 = the product kernel
+PROBES = [int(x) for x in os.environ.get("RANK8_PROBES", "0").split(",")]
+KS = [int(x) for x in os.environ.get("RANK8_NFILT", "0,2").split(",")]
+SPLIT = os.environ.get("RANK8_SPLIT", "1") == "1"
+SHAPES = os.environ.get("RANK8_SHAPES", "fb15k-237,wikidata5m_shard").split(",")
 
 
 def main():
@@ -22,11 +31,13 @@ def main():
     rng = np.random.default_rng(0)
     n = 512
     for tag, E, R, d in (("fb15k-237", 14541, 237, 512), ("wikidata5m_shard", (4594485 + 7) // 8, 822, 256)):
+        if tag not in SHAPES:
+            continue
         g = torch.Generator(device=dev).manual_seed(7)
         ent = (torch.randn(E, d, generator=g, device=dev) * 0.3).bfloat16()
         rel = (torch.randn(R, d, generator=g, device=dev) * 0.3).bfloat16()
         s, p, o = (torch.from_numpy(rng.integers(0, hi, n)).to(dev) for hi in (E, R, E))
-        for K in (0, 2):
+        for K in KS:
             lists = []
             for tc in (o.cpu().numpy(), s.cpu().numpy()):
                 per = [np.unique(np.append(rng.integers(0, E, 4), c)) for c in tc]
@@ -34,7 +45,8 @@ def main():
                 beg = end - np.array([len(x) for x in per])
                 one = tuple(torch.from_numpy(np.asarray(x, np.int64)).to(dev) for x in (beg, end, np.concatenate(per)))
                 lists.append([one] * K)
-            for flags in (0, engine.FLAG_SPLIT_QUERY):
+            for flags, probe in [(0, pr) for pr in PROBES] + ([(engine.FLAG_SPLIT_QUERY, 0)] if SPLIT else []):
+                os.environ["KGE_V8R_PROBE"] = str(probe)
                 T = engine.Tables("complex", ent, rel, flags=flags)
                 t_sp = engine.score_sp(T, s, p, o).diagonal().contiguous()
                 t_po = engine.score_po(T, p, o, s).diagonal().contiguous()
@@ -59,7 +71,13 @@ def main():
                 nst = int((v[0, :32] != 0).sum())
                 rel_ = (v[:, :nst] - v[:, :1]).double().median(dim=0).values
                 per = [float(rel_[i + 1] - rel_[i]) for i in range(2, nst - 1)]
-                print(f"{tag} filters={K} split={int(bool(flags))}: {v.shape[0]} workgroups; R0 {float(rel_[1]):.0f}; unit periods "
+                whole = ((v[:, 40] - v[:, 1]).double() / v[:, 41].double().clamp(min=1))
+                tot = (v[:, 40] - v[:, 0]).double()
+                print(f"    whole run: cycles per unit (end - R0) / units: median {float(whole.median()):.0f}  "
+                      f"max {float(whole.max()):.0f}; units per workgroup {int(v[:, 41].median())}; workgroup cycles "
+                      f"median {float(tot.median()):.0f} max {float(tot.max()):.0f} -> clock "
+                      f"{float(tot.max()) / (e0.elapsed_time(e1) * 1e3) / 1e3:.2f} GHz if the call were this kernel alone")
+                print(f"{tag} filters={K} split={int(bool(flags))} probe={os.environ.get('KGE_V8R_PROBE', '0')}: {v.shape[0]} workgroups; R0 {float(rel_[1]):.0f}; unit periods "
                       f"{[round(x) for x in per[:10]]} median {statistics.median(per) if per else 0:.0f}; call {e0.elapsed_time(e1) * 1e3:.1f} us",
                       flush=True)
         del ent, rel
