@@ -1,0 +1,122 @@
+"""A whole training step -- forward, backward, optimizer -- as ONE hipGraph replay.
+
+The fused 1vsAll step at the FB15k-237 shape is ~170 us of kernels (profiles/r4_train_step_kernels.txt) issued by
+~300 us of Python: autograd bookkeeping, a dozen launches through ctypes, the optimizer's loop over parameters.  The
+GPU waits for the host.  A batch of a fixed shape is the same launch sequence every time, so it is captured once
+(torch.cuda.CUDAGraph; HIP graphs underneath) and replayed: the host copies the batch's indexes into static buffers and
+issues one graph launch.
+
+    step = GraphedStep(lambda s, p, o: model.loss_sp_po(s, p, o).sum() / len(s), optimizer)
+    for batch in loader:
+        loss = step(batch[:, 0], batch[:, 1], batch[:, 2])     # a 0-d tensor (static: read it before the next call)
+
+Mirrors the step of TrainingJob.run_epoch (kge/job/train.py:452-474: zero_grad, forward + backward of the batch,
+optimizer.step) for the jobs whose batches are index tensors of a fixed shape: 1vsAll and negative sampling; the last,
+shorter batch of an epoch and anything else that does not fit runs eagerly through the same callables.
+
+STATUS: a helper for loops this package drives itself (bench.py's roofline_train leg, tools/graph_step_probe.py);
+it is NOT wired into the LibKGE plugin.  Verified: tests/test_gpu_train_graph.py (losses to 1e-6, SGD parameters to
+2e-5 of an eager run, recapture at a learning-rate change, eager fallback for a short batch) and 200 steps at the
+FB15k-237 shape (tools/graph_step_probe.py: epoch means to 2e-6; single steps differ by up to 3e-4 -- a replay orders
+the float atomics of the gradient scatter differently and Adagrad turns a coordinate whose gradient is that noise
+into a +-lr move).  Under LibKGE's TrainingJob.run_epoch two things spoke against it: the trainer reads the loss back
+after every batch, so the host waits for every replay and a graph launch reaches its first kernel LATER than a plain
+launch (0.088 s per epoch of 100 batches against 0.070 s eager on the box measured), and a second replayed epoch
+drifted from the eager trajectory (loss +0.2 ... 0.7 %, starting at a batch that moved with the allocator's state)
+while the first matched to 1e-7 -- not understood, hence not shipped there.
+
+What a captured step cannot follow, and what is done about it:
+  * a changed learning rate (schedulers; kge/job/train.py:406-431): the kernels take lr as a launch argument, so the
+    graph is captured again when any group's lr differs from the captured one;
+  * Adagrad's lr_decay makes the step size depend on the step count: refused (eager);
+  * the first `warmup` calls run eagerly (they are real steps): lazy allocations -- optimizer state, workspaces, the
+    bf16 scoring copies -- happen there, outside the capture.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+
+__all__ = ["GraphedStep"]
+
+
+class GraphedStep:
+    def __init__(self, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer, warmup: int = 3,
+                 enabled: bool = True):
+        """loss_fn(*index_tensors) -> 0-d loss (its backward() fills the parameters' .grad); optimizer: its step()
+        must be capturable -- kernels only, no host read of device memory (kge_amd.optim.Adagrad and SGD are)."""
+        self.loss_fn = loss_fn
+        self.optimizer = optimizer
+        self.warmup = int(warmup)
+        self.enabled = bool(enabled)
+        self.calls = 0
+        self.replays = 0
+        self.captures = 0
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._static_in: Sequence[torch.Tensor] = ()
+        self._static_loss: Optional[torch.Tensor] = None
+        self._lrs = None
+        self.disabled_reason: Optional[str] = None
+        for g in optimizer.param_groups:
+            if g.get("lr_decay", 0) != 0:
+                self._disable("the optimizer's lr_decay makes the step size a function of the step count")
+
+    def _disable(self, why: str) -> None:
+        self.enabled = False
+        self.disabled_reason = why
+
+    def _eager(self, inputs) -> torch.Tensor:
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.loss_fn(*inputs)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _signature(self, inputs):
+        return tuple((tuple(x.shape), x.dtype, x.device) for x in inputs)
+
+    def _capture(self, inputs) -> None:
+        self._static_in = tuple(torch.empty_like(x, memory_format=torch.contiguous_format) for x in inputs)
+        for dst, src in zip(self._static_in, inputs):
+            dst.copy_(src)
+        self.optimizer.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = self.loss_fn(*self._static_in)
+            loss.backward()
+            self.optimizer.step()
+            self._static_loss = loss.detach()
+        self._graph = graph
+        self._sig = self._signature(inputs)
+        self._lrs = [g["lr"] for g in self.optimizer.param_groups]
+        self.captures += 1
+
+    def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
+        self.calls += 1
+        if not self.enabled or not all(isinstance(x, torch.Tensor) and x.is_cuda for x in inputs):
+            return self._eager(inputs)
+        if self.calls <= self.warmup:
+            return self._eager(inputs)
+        lrs = [g["lr"] for g in self.optimizer.param_groups]
+        if self._graph is None or lrs != self._lrs:
+            if self._graph is not None and self._signature(inputs) != self._sig:
+                return self._eager(inputs)  # (a short batch right at a learning-rate change: the next full one captures)
+            try:
+                self._capture(inputs)
+            except Exception as exc:  # a step that cannot be captured stays eager -- loudly, once
+                import warnings
+                self._graph = None
+                self._disable(f"capture failed: {exc!r}")
+                warnings.warn(f"kge_amd.GraphedStep: {self.disabled_reason}; the step runs eagerly")
+                torch.cuda.synchronize()
+                return self._eager(inputs)
+        elif self._signature(inputs) != self._sig:
+            return self._eager(inputs)  # e.g. the epoch's last, shorter batch
+        else:
+            for dst, src in zip(self._static_in, inputs):
+                dst.copy_(src, non_blocking=True)
+        self._graph.replay()
+        self.replays += 1
+        return self._static_loss
