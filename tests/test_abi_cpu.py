@@ -126,7 +126,11 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_rank_counts_multi(ctypes.c_void_p(16), 5, 2, 5, ctypes.c_void_p(16), 9, None, None, None, 0, None,
                                      1e-5, 1e-4, ctypes.c_void_p(16), ctypes.c_void_p(16), None) == -2  # > KGE_MAX_FILTERS
     # score + rank in one kernel: size arithmetic, argument checks, what it declines (all before any launch)
-    assert lib.kge_score_rank_bits_bytes(512, 14541, 2) == 2 * 2 * 512 * 228 * 8
+    # word-major filter bits: 2 sides x K sets x (n up to whole 64-row lines) x (m up to whole 64-column words, as
+    # 32-bit words) x 4 bytes, + 16 (the last row's 8-byte load when there is ONE set); rows up to 64 cost nothing
+    assert lib.kge_score_rank_bits_bytes(512, 14541, 2) == 2 * 2 * 512 * (228 * 2) * 4 + 16
+    assert lib.kge_score_rank_bits_bytes(500, 14541, 2) == lib.kge_score_rank_bits_bytes(512, 14541, 2)
+    assert lib.kge_score_rank_bits_bytes(512, 14541, 1) == 2 * 1 * 512 * (228 * 2) * 4 + 16
     assert lib.kge_score_rank_bits_bytes(512, 14541, 0) == 0 and lib.kge_score_rank_bits_bytes(0, 64, 2) == 0
     P = ctypes.c_void_p(16)
     rank_args = lambda t_, n, cb, m, k, lists=(None,) * 6: (ctypes.byref(t_), good, good, good, n, cb, m, P, P, k,
