@@ -79,15 +79,16 @@ def make_inputs(rank, device, n):
             s.to(device), p.to(device), o.to(device))
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of
-    this same command (profiles/pmc_latest.json: FETCH_SIZE x2 per the gfx950 correction in
-    MI355X_MICROARCH.md + WRITE_SIZE).  bench.py itself cannot collect PMC counters."""
+def pmc_traffic(mode, group):
+    """HBM bytes per launch of the dominant kernel (one GROUP launch of `group` two-sided batches) in query mode
+    `mode` ("parity" / "training") from the committed rocprofv3 --pmc passes over the same launches
+    (tools/v8_pmc_target.py, tools/gpu_r4prof.sh -> profiles/r4_rocprofv3_pmc_hbm.txt, profiles/pmc_latest.json:
+    FETCH_SIZE x 2 per the gfx950 correction in MI355X_MICROARCH.md + WRITE_SIZE).  bench.py itself cannot collect
+    counters; None when the committed passes are of another group size."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             d = json.load(f)
-        # only a summary of the same launch shape (two-sided score_sp_po launches) applies
-        return d["hbm_bytes_per_launch"] if d.get("launch") == "score_sp_po" else None
+        return d[mode]["hbm_bytes_per_launch"] if d.get("group") == group else None
     except Exception:
         return None
 
@@ -844,6 +845,26 @@ def main():
                      "avg_launch_us": f_ms * 1e3, "flops_per_launch": 2.0 * n * DIM * E_FB,
                      "scored_triples_per_s": n * E_FB / (f_ms * 1e-3)}
         del T32
+        # The distance scorers on the same score_sp call (float32 tables; no matrix-core form: VALU-bound).  Vector
+        # operations per scored coordinate: TransE (l_norm 1) sub, add, |.|+add = 3 per REAL coordinate; RotatE per
+        # COMPLEX coordinate 4 for the rotation (2 mul + 2 fma), 2 sub, 2 for re^2 + im^2, ~13 issue slots for the
+        # correctly rounded sqrt (v_sqrt_f32 is a quarter-rate operation + the fix-up), 1 add: ~22.  Peak: 256 CUs x
+        # 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-operations/s.
+        VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+        exact = {"bound": "valu", "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
+                 "kernel": "pairs_exact_kernel<scorer> (kge_score_sp, float32 tables: the reference's arithmetic chain)"}
+        for name, rdim, ops in (("transe", DIM, 3.0 * DIM), ("rotate", DIM // 2, 22.0 * (DIM // 2))):
+            gq = torch.Generator().manual_seed(11)
+            Tx = engine.Tables(name, ent.float(), torch.empty(R_FB, rdim).normal_(0, 0.1, generator=gq).to(device),
+                               l_norm=1.0)
+            for _ in range(3):
+                engine.score_sp(Tx, s, p)
+            x_ms = event_avg_ms(lambda: engine.score_sp(Tx, s, p), max(10, a.steps // 8))
+            tops = ops * n * E_FB / (x_ms * 1e-3) / 1e12
+            exact[name] = {"avg_launch_us": x_ms * 1e3, "scored_triples_per_s": n * E_FB / (x_ms * 1e-3),
+                           "lane_ops_per_score": ops, "achieved": tops, "frac": tops / VALU_PEAK_TOPS}
+            del Tx
+        extra["roofline_exact"] = exact
         for md in modes.values():
             md.by_size.clear()
         torch.cuda.empty_cache()
@@ -886,7 +907,7 @@ def main():
         "roofline": {**roofline_of("parity", "pairs_bf16_v8_kernel<ComplEx, SPLIT> (kge_score_queries_multi: one "
                                              "persistent launch = `group` two-sided batches, split queries: twice the "
                                              "matrix-core work per score)"),
-                     "traffic": pmc_traffic(),
+                     "traffic": pmc_traffic("parity", L),
                      "timed_region": {"us_per_step": rp["el"] / a.steps * 1e6,
                                       "frac": ab / (rp["el"] / a.steps) / 1e9 / HBM_PEAK_GBS}},
         # the same step with the query vector rounded to ONE bf16 (what 1vsAll TRAINING needs; 4 % of the ranks of an
@@ -897,6 +918,7 @@ def main():
             "host_issue_ms_per_step": rt["host"] / a.steps * 1e3,
             "roofline": {**roofline_of("training", "pairs_bf16_v8_kernel<ComplEx> (kge_score_queries_multi: one "
                                                    "persistent launch = `group` two-sided batches, single-pass queries)"),
+                         "traffic": pmc_traffic("training", L),
                          "timed_region": {"us_per_step": rt["el"] / a.steps * 1e6,
                                           "frac": ab / (rt["el"] / a.steps) / 1e9 / HBM_PEAK_GBS}}},
         **extra,
