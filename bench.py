@@ -205,6 +205,35 @@ def event_avg_ms(fn, steps, repeats=1):
     return got[len(got) // 2]
 
 
+def matrix_pipe_probe(device):
+    """What the matrix pipe sustains on THIS box with nothing beside it: kge_debug_mfma_rate (include/kge_amd_debug.h) --
+    the grid and wave layout of the persistent kernels, bare v_mfma_f32_32x32x16_bf16 on random operands, ~0.3 ms per
+    launch so that the clock settles where it does under matrix load.  The MFMA-bound legs quote their fraction of the
+    NOMINAL dense peak; this is the fraction a kernel of pure MFMAs gets."""
+    import ctypes
+    from kge_amd import _lib
+    L = _lib.lib()
+    fn = L.kge_debug_mfma_rate
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    g = torch.Generator(device=device).manual_seed(3)
+    ops = torch.randn(8 * 4 * 512, generator=g, device=device).bfloat16()  # 8 waves x 4 operands x 64 lanes x 8 values
+    sink = torch.zeros(4, device=device)
+    iters = 400
+    st = torch.cuda.current_stream(device).cuda_stream
+
+    def launch():
+        fl = fn(ops.data_ptr(), iters, sink.data_ptr(), st)
+        assert fl > 0, fl
+        return fl
+    flops = launch()
+    ms = event_avg_ms(launch, 20)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "mfma_rate_kernel (kge_debug_mfma_rate: 2 waves per SIMD, two independent accumulators each, no "
+                      "memory traffic)", "launch_us": ms * 1e3, "achieved": tf, "unit": "TFLOP/s",
+            "frac_of_nominal_peak": tf / BF16_MFMA_PEAK_TF}
+
+
 def rank_legs(engine, device, n, steps):
     """One entity-ranking evaluation batch (raw + filtered + filtered-with-test counts, both directions) with the
     counts taken inside the scoring kernel (kge_score_rank_sp_po: no score matrix) and as score_sp_po + two
@@ -212,14 +241,15 @@ def rank_legs(engine, device, n, steps):
     `parity` = split queries (the default of hip_entity_ranking with score_dtype bfloat16: ranks equal to float32
     arithmetic on the bf16 tables up to its summation noise; twice the matrix work per score) and
     `training_tolerance` = single-pass queries.  MFMA-bound: ALGORITHMIC flops = 2 directions * 2 n E d (the split
-    mode executes twice that; `frac_executed`).  `frac` is against the nominal dense bf16 peak; a kernel of bare
-    v_mfma_f32_32x32x16_bf16 chains holds 0.55 of it on these boxes (1.3-1.4 PFLOP/s: the clock drops to ~1.3 GHz
-    under matrix load -- profiles/r4_rank8_stamps_probes.txt, probe 31)."""
+    mode executes twice that; `frac_executed`).  `frac` is against the nominal dense bf16 peak; `matrix_pipe_probe`
+    (measured in this run) is what a kernel of bare v_mfma_f32_32x32x16_bf16 chains holds of it on this box -- 0.55 on
+    the boxes profiled (1.3-1.4 PFLOP/s: the clock drops to ~1.3 GHz under matrix load;
+    profiles/r4_rank8_stamps_probes.txt, probe 31)."""
     import numpy as np
     out = {"bound": "mfma", "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
            "kernel": "pairs_bf16_v8_rank_kernel<ComplEx, d/2, SPLIT> (kge_score_rank_sp_po = filter-bit set launch + "
                      "query build + the persistent counting kernel + bit clear launch)",
-           "matrix_only_kernel_frac_of_peak": 0.55}
+           "matrix_pipe_probe": matrix_pipe_probe(device)}
     rng = np.random.default_rng(0)
     for tag, E, R, d in (("fb15k-237", E_FB, R_FB, DIM), ("wikidata5m_shard", (E_WD + 7) // 8, R_WD, DIM_WD)):
         g = torch.Generator(device=device).manual_seed(7)

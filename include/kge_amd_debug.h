@@ -33,6 +33,12 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
                                int64_t ldo, unsigned long long* stamps, int ablate, void* workspace,
                                int64_t workspace_bytes, void* stream);
 
+/* The matrix pipe alone (bench.py's `matrix_pipe_probe`): one workgroup of eight waves per compute unit, every wave
+ * `iters` x 16 v_mfma_f32_32x32x16_bf16 on two independent accumulators from `operands` (8 waves x 4 x 1 KiB of bf16
+ * values, 16-byte aligned, loaded once), nothing else.  Returns the launch's flops (time it with events on `stream`), or a
+ * negative kge_status.  `sink`: one float nobody writes. */
+double kge_debug_mfma_rate(const void* operands, int iters, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

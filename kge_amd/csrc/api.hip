@@ -73,6 +73,7 @@ int run_rank_multi(const float* scores, long long lds, long long n, long long c,
                    float rtol, long long* rank, long long* ties, hipStream_t st);
 int run_rank_hist(const long long* rank, const long long* ties, int M, long long n, int policy, float* hist,
                   long long ldh, long long num_ent, long long* ranks_out, hipStream_t st);
+double run_mfma_rate(const void* rnd, int iters, float* sink, hipStream_t st);
 int run_eval_begin(const EvalLists& L, const Index& s, const Index& o, long long n, long long m, long long rs, long long us,
                    long long* tgt, hipStream_t st);
 int run_eval_end(const EvalLists& L, long long n, long long m, long long rs, long long us, int M, int policy, long long* counts,
@@ -1560,6 +1561,9 @@ void kge_debug_ce_stamps(unsigned long long* stamps) { kge::ce_set_stamps(stamps
 // Not part of the public ABI: timestamp buffer (64 x u64 per workgroup) for the next pairs_bf16_v6_kernel launches
 // that carry none of their own (tools/v6_probe.py: stamps of two-sided / pipelined launches); NULL switches it off.
 void kge_debug_v6_stamps(unsigned long long* stamps) { kge::v6_set_stamps(stamps); }
+double kge_debug_mfma_rate(const void* operands, int iters, float* sink, void* stream) {
+  return kge::run_mfma_rate(operands, iters, sink, (hipStream_t)stream);
+}
 
 // Not part of the public ABI: one gradient contraction of the bf16 backward on its own
 // (tests/test_gpu_bwd_gemm16.py, tools/gemm16_probe.py); see run_debug_gemm16 in bwd_gemm.hip.

@@ -972,4 +972,42 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
 }
 
 #undef KGE_V8_DMA
+
+// ---- kge_debug_mfma_rate: the matrix pipe alone.  The grid and wave layout of the kernels above (one workgroup of
+// eight waves per CU = two waves per SIMD), each wave issuing `iters` x 16 v_mfma_f32_32x32x16_bf16 on TWO independent
+// accumulators from operands loaded once (random bf16 values: the pipe's power draw depends on the data) -- no LDS, no
+// vector memory, no comparisons.  What this reaches is what the chip sustains under matrix load (the clock drops to
+// ~1.3 GHz on the boxes measured: 0.55 of the nominal dense peak), i.e. the floor the counting kernel and the split
+// store kernel are compared with.
+__global__ __launch_bounds__(512, 1) void mfma_rate_kernel(const u32x4* __restrict__ rnd, int iters, float* __restrict__ sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16x8 a0 = __builtin_bit_cast(bf16x8, rnd[(wave * 4 + 0) * 64 + lane]);
+  const bf16x8 a1 = __builtin_bit_cast(bf16x8, rnd[(wave * 4 + 1) * 64 + lane]);
+  const bf16x8 b0 = __builtin_bit_cast(bf16x8, rnd[(wave * 4 + 2) * 64 + lane]);
+  const bf16x8 b1 = __builtin_bit_cast(bf16x8, rnd[(wave * 4 + 3) * 64 + lane]);
+  f32x16 c0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c1 = c0;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c1, 0, 0, 0);
+    }
+  }
+  float t = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t += c0[r] + c1[r];
+  if (t == 12345.678f) sink[0] = t;  // (keeps the chains alive; never true for the operands handed in)
+}
+
+// flops of the launch, or a negative kge_status
+double run_mfma_rate(const void* rnd, int iters, float* sink, hipStream_t st) {
+  if (rnd == nullptr || sink == nullptr || iters <= 0 || ((uintptr_t)rnd & 15)) return (double)KGE_ERR_INVALID_ARG;
+  int cus = v8_cu_count();
+  if (cus > 256) cus = 256;
+  hipLaunchKernelGGL(mfma_rate_kernel, dim3(cus), dim3(512), 0, st, (const u32x4*)rnd, iters, sink);
+  if (hipGetLastError() != hipSuccess) return (double)KGE_ERR_LAUNCH;
+  return (double)cus * 8.0 * (double)iters * 16.0 * (2.0 * 32.0 * 32.0 * 16.0);
+}
 }  // namespace kge

@@ -35,7 +35,7 @@ def test_debug_exports_are_exactly_the_declared_ones(lib):
     import subprocess
     from kge_amd import _lib
     dbg = open(os.path.join(ROOT, "include", "kge_amd_debug.h")).read()
-    declared_dbg = set(re.findall(r"^(?:int|void)\s+(kge_debug_\w+)\s*\(", dbg, flags=re.M))
+    declared_dbg = set(re.findall(r"^(?:int|void|double)\s+(kge_debug_\w+)\s*\(", dbg, flags=re.M))
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("kge_")}
     assert exported == set(_lib.PROTOTYPES) | declared_dbg, exported ^ (set(_lib.PROTOTYPES) | declared_dbg)
