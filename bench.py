@@ -880,8 +880,9 @@ def main():
         del T32
         # The distance scorers on the same score_sp call (float32 tables; no matrix-core form: VALU-bound).  Vector
         # operations per scored coordinate: TransE (l_norm 1) sub, add, |.|+add = 3 per REAL coordinate; RotatE per
-        # COMPLEX coordinate 4 for the rotation (2 mul + 2 fma), 2 sub, 2 for re^2 + im^2, ~13 issue slots for the
-        # correctly rounded sqrt (v_sqrt_f32 is a quarter-rate operation + the fix-up), 1 add: ~22.  Peak: 256 CUs x
+        # COMPLEX coordinate 4 for the rotation (2 mul + 2 fma), 2 sub, 2 for re^2 + im^2, 11 issue slots for the
+        # correctly rounded sqrt (common.hpp sqrt_rn_core: the quarter-rate v_rsq_f32 + 7), 2 for the range check's
+        # min / max, 1 add: ~22 (with the compiler's IEEE sqrt sequence it was ~30).  Peak: 256 CUs x
         # 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-operations/s.
         VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
         exact = {"bound": "valu", "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",

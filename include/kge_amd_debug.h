@@ -39,6 +39,11 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
  * negative kge_status.  `sink`: one float nobody writes. */
 double kge_debug_mfma_rate(const void* operands, int iters, float* sink, void* stream);
 
+/* The short form of the correctly rounded float square root the RotatE kernels use (common.hpp: sqrt_rn_fast) against
+ * the compiler's IEEE sequence, bit for bit, over the `count` bit patterns from `first_bits` on (all 2^32 in two calls):
+ * *mismatches (device, zeroed by the caller) += the number that differ, first16 (device) their first 16 patterns. */
+int kge_debug_sqrt_check(uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* first16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1561,6 +1561,26 @@ void kge_debug_ce_stamps(unsigned long long* stamps) { kge::ce_set_stamps(stamps
 // Not part of the public ABI: timestamp buffer (64 x u64 per workgroup) for the next pairs_bf16_v6_kernel launches
 // that carry none of their own (tools/v6_probe.py: stamps of two-sided / pipelined launches); NULL switches it off.
 void kge_debug_v6_stamps(unsigned long long* stamps) { kge::v6_set_stamps(stamps); }
+namespace kge {
+__global__ void sqrt_check_kernel(unsigned int lo, unsigned long long count, unsigned long long* nbad, unsigned int* first) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    const unsigned int b = lo + (unsigned int)i;
+    const float x = __builtin_bit_cast(float, b);
+    const float a = sqrt_rn_fast(x), r = __builtin_sqrtf(x);
+    if (__builtin_bit_cast(unsigned int, a) != __builtin_bit_cast(unsigned int, r)) {
+      const unsigned long long k = atomicAdd(nbad, 1ull);
+      if (k < 16) first[k] = b;
+    }
+  }
+}
+}  // namespace kge
+int kge_debug_sqrt_check(uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* first16, void* stream) {
+  if (mismatches == nullptr || first16 == nullptr || count == 0 || count > (1ull << 32)) return KGE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(kge::sqrt_check_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, first_bits,
+                     (unsigned long long)count, (unsigned long long*)mismatches, first16);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
 double kge_debug_mfma_rate(const void* operands, int iters, float* sink, void* stream) {
   return kge::run_mfma_rate(operands, iters, sink, (hipStream_t)stream);
 }

@@ -38,7 +38,7 @@ __device__ __forceinline__ float transe_w(float e, float dist, float p) {
 template <int NORM>
 __device__ __forceinline__ void rotate_w(float dre, float dim_, float dist, float p, float& wre,
                                          float& wim) {
-  float ab = __builtin_sqrtf(__builtin_fmaf(dim_, dim_, dre * dre));
+  float ab = sqrt_rn_fast(__builtin_fmaf(dim_, dim_, dre * dre));  // (correctly rounded: common.hpp)
   float f;
   if (NORM == NORM_L1) f = ab > 0.f ? 1.f / ab : 0.f;
   else if (NORM == NORM_L2) f = dist > 0.f ? 1.f / dist : 0.f;

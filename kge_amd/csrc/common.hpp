@@ -197,6 +197,30 @@ __device__ __forceinline__ void sincos_canon(float x, float& sn, float& cs) {
 // IEEE-correct sqrt (the oracle uses glibc sqrtf, correctly rounded).
 __device__ __forceinline__ float sqrt_rn(float x) { return __fsqrt_rn(x); }
 
+// The same value in fewer issue slots, for the kernels that take one square root per scored coordinate (RotatE): the
+// compiler's sequence for a correctly rounded float sqrt (no fast-math) is input scaling + v_sqrt_f32 + two one-ulp
+// candidates with their residuals + selects + rescaling -- ~16 operations besides the quarter-rate v_sqrt.  Here:
+// v_rsq_f32 (1 ulp), one coupled Newton step on g ~ sqrt(x) and h ~ 1 / (2 sqrt(x)), and Markstein's final correction
+// g + h (x - g g) with the residual from ONE fma: seven operations + the quarter-rate v_rsq.  Correct rounding holds for
+// x in [2^-96, 2^126] -- checked EXHAUSTIVELY against the compiler's sequence over all 2^32 bit patterns on the device
+// (tools/ubench/sqrt_exhaustive.hip, 0 mismatches; profiles/r4_sqrt_exhaustive.txt); outside that range (zeros,
+// denormal-sized squares, huge values, inf, NaN, negatives: the residual would leave the normal range) the IEEE form.
+constexpr float SQRT_FAST_LO = 0x1p-96f, SQRT_FAST_HI = 0x1p+126f;
+// (the range check is the caller's: the pair kernel checks the minimum and maximum of a 4 x 4 micro-tile once)
+__device__ __forceinline__ float sqrt_rn_core(float x) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  float g = x * y, h = 0.5f * y;
+  const float r = __builtin_fmaf(-g, h, 0.5f);
+  g = __builtin_fmaf(g, r, g);
+  h = __builtin_fmaf(h, r, h);
+  const float d = __builtin_fmaf(-g, g, x);
+  return __builtin_fmaf(d, h, g);
+}
+__device__ __forceinline__ float sqrt_rn_fast(float x) {
+  if (__builtin_expect(!(x >= SQRT_FAST_LO && x <= SQRT_FAST_HI), 0)) return __builtin_sqrtf(x);
+  return sqrt_rn_core(x);
+}
+
 enum { NORM_L1 = 1, NORM_L2 = 2, NORM_LP = 3 };
 __host__ inline int norm_mode(float p) { return p == 1.0f ? NORM_L1 : (p == 2.0f ? NORM_L2 : NORM_LP); }
 

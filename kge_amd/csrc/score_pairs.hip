@@ -136,6 +136,40 @@ __global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operan
         f32x4 q1 = *reinterpret_cast<const f32x4*>(&Qs[1][cc][ty * 4]);
         f32x4 t0v = *reinterpret_cast<const f32x4*>(&Ts[0][cc][tx * 4]);
         f32x4 t1v = *reinterpret_cast<const f32x4*>(&Ts[1][cc][tx * 4]);
+        if constexpr (!DOT && SCORER != KGE_TRANSE) {
+          // RotatE: |q - t| of 16 complex coordinates.  The correctly rounded square root in its short form
+          // (common.hpp: sqrt_rn_core, checked exhaustively) wherever all 16 squares lie in its range -- ONE check
+          // of their minimum and maximum per micro-tile instead of a branch per root; zeros, denormal-sized or huge
+          // squares, inf and NaN (the maximum of a set with a NaN may hide it: NaN in, NaN out either way) send the
+          // micro-tile through the IEEE sequence.
+          float x[4][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float dre = q0[i] - t0v[j], dim_ = q1[i] - t1v[j];
+              x[i][j] = __builtin_fmaf(dim_, dim_, dre * dre);
+            }
+          float mn = x[0][0], mx = x[0][0];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              mn = __builtin_fminf(mn, x[i][j]);
+              mx = __builtin_fmaxf(mx, x[i][j]);
+            }
+          if (__builtin_expect(mn >= SQRT_FAST_LO && mx <= SQRT_FAST_HI, 1)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i][j] = norm_acc<NORM>(acc[i][j], sqrt_rn_core(x[i][j]), lp);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[i][j] = norm_acc<NORM>(acc[i][j], __builtin_sqrtf(x[i][j]), lp);
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -143,15 +177,12 @@ __global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operan
             if (DOT) {
               acc[i][j] = __builtin_fmaf(q0[i], t0v[j], acc[i][j]);
               acc[i][j] = __builtin_fmaf(q1[i], t1v[j], acc[i][j]);
-            } else if (SCORER == KGE_TRANSE) {
+            } else {
               acc[i][j] = norm_acc<NORM>(acc[i][j], __builtin_fabsf(q0[i] - t0v[j]), lp);
               acc[i][j] = norm_acc<NORM>(acc[i][j], __builtin_fabsf(q1[i] - t1v[j]), lp);
-            } else {
-              float dre = q0[i] - t0v[j], dim_ = q1[i] - t1v[j];
-              float ab = __builtin_sqrtf(__builtin_fmaf(dim_, dim_, dre * dre));
-              acc[i][j] = norm_acc<NORM>(acc[i][j], ab, lp);
             }
           }
+        }
       }
     }
     __syncthreads();

@@ -106,7 +106,7 @@ __device__ __forceinline__ float apply_chunk(int slot, float P, const Fixed& F,
           ore = F.f2.v[i]; oim = F.f3.v[i];
         }
         float dre = qre - ore, dim_ = qim - oim;
-        float ab = __builtin_sqrtf(__builtin_fmaf(dim_, dim_, dre * dre));
+        float ab = sqrt_rn_fast(__builtin_fmaf(dim_, dim_, dre * dre));  // (correctly rounded: common.hpp)
         P = norm_acc<NORM>(P, ab, lp);
       }
     }

@@ -537,6 +537,55 @@ def test_duplicates_zero_rows_and_non_finite_values(eng):
             _eq(f"{model} repeated target -> identical columns", got[:, j], got[:, first7])
 
 
+def test_short_square_root_is_correctly_rounded_for_every_float(eng):
+    """common.hpp sqrt_rn_fast against the compiler's IEEE sequence over ALL 2^32 bit patterns (zeros, denormals,
+    both edges of the short form's range, inf, NaNs, negatives), on the device: not one differs."""
+    import ctypes
+    from kge_amd import _lib
+    fn = _lib.lib().kge_debug_sqrt_check
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    first = torch.zeros(16, dtype=torch.int32, device="cuda:0")
+    for lo in (0, 1 << 31):
+        assert fn(lo, 1 << 31, bad.data_ptr(), first.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert int(bad) == 0, [hex(int(x) & 0xffffffff) for x in first.tolist()]
+
+
+def test_rotate_square_roots_at_the_edges_of_the_short_form(eng):
+    """RotatE takes one correctly rounded square root per complex coordinate.  The kernels use a short form
+    (common.hpp sqrt_rn_core: v_rsq_f32 + a Newton step + Markstein's correction, checked exhaustively against the IEEE
+    sequence over all 2^32 bit patterns: tools/ubench/sqrt_exhaustive.hip) for squares in [2^-96, 2^126] and the IEEE
+    sequence outside -- decided per 4 x 4 micro-tile in the pair kernel, per root in the row kernels.  Here the
+    squares sit on both sides of both edges, mixed inside micro-tiles: exact zeros (a query scored against itself
+    under a zero rotation), 1e-52 ... 1e-28, 1e37 ... 3e38, next to ordinary values -- bit for bit against the oracle
+    (glibc sqrtf)."""
+    rng = np.random.default_rng(77)
+    E, R, d, n = 260, 4, 128, 48
+    ent = rng.standard_normal((E, d)).astype(np.float32)
+    scale = np.ones((E, 1), np.float32)
+    scale[0:40] = 1e-26      # squares ~1e-52: far below 2^-96
+    scale[40:80] = 3e-15     # squares ~1e-29: around 2^-96 = 1.26e-29
+    scale[80:120] = 6e18     # squares ~4e37 ... 3e38: around 2^126 = 8.5e37, some sums overflow to inf
+    scale[120:140] = 2e18
+    ent *= scale
+    rel = rng.uniform(-np.pi, np.pi, (R, d // 2)).astype(np.float32)
+    rel[0] = 0.0             # zero rotation: score_sp(s, 0) against entity s has |q - t| = 0 in every coordinate
+    s = rng.integers(0, E, n); s[:8] = [0, 41, 81, 121, 200, 5, 45, 85]
+    p = rng.integers(0, R, n); p[:8] = 0
+    o = rng.integers(0, E, n); o[:8] = s[:8]
+    neg = rng.integers(0, E, (n, 7)); neg[:, 0] = s
+    T = _gpu_tables(eng, "rotate", ent, rel, 1.0)
+    O = _oracle_tables("rotate", ent, rel, 1.0)
+    with np.errstate(over="ignore", invalid="ignore"):
+        _eq("sp_all", _np(eng.score_sp(T, _t(s), _t(p))), ko.score_sp(O, s, p))
+        _eq("po_all", _np(eng.score_po(T, _t(p), _t(o))), ko.score_po(O, p, o))
+        _eq("spo", _np(eng.score_spo(T, _t(s), _t(p), _t(o))), ko.score_spo(O, s, p, o))
+        _eq("neg_o", _np(eng.score_neg(T, _t(s), _t(p), _t(o), 2, _t(neg))), ko.score_neg(O, s, p, o, 2, neg))
+    assert float(_np(eng.score_spo(T, _t(s[:1]), _t(p[:1]), _t(s[:1])))[0]) == 0.0
+
+
 @pytest.mark.parametrize("model,dt", [("complex", torch.bfloat16), ("rotate", torch.float32)])
 def test_embed_rows(eng, model, dt):
     """kge_embed (LookupEmbedder.embed, both tables in one launch) == tensor indexing; strided
