@@ -1112,7 +1112,7 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
     EvalLists Lc = L;  // clear only
     const int rc2 = run_eval_end(Lc, n, m, bl.rs, bl.us, 0, tie_policy, (long long*)counts, hist, ldh, E, nullptr, nullptr, st);
     if (rc != KGE_ERR_UNSUPPORTED)  // a failed launch may have left partial counts behind
-      (void)hipMemsetAsync(counts, 0, (size_t)(4 * per) * sizeof(int64_t), st);
+      (void)kge::fill_words_async(counts, 0, (size_t)(4 * per) * sizeof(int64_t), st);
     return rc == KGE_ERR_UNSUPPORTED && rc2 != KGE_OK ? rc2 : rc;
   }
   return run_eval_end(L, n, m, bl.rs, bl.us, M, tie_policy, (long long*)counts, hist, ldh, E, (long long*)ranks_o,

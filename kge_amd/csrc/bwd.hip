@@ -560,8 +560,8 @@ static int launch_bwd_pairs(int dir, const Operand& A, const Operand& R, const O
     ys = (m + ychunk - 1) / ychunk;
   }
   if (ys > 1) {
-    if (hipMemsetAsync(g_a, 0, (size_t)n * d * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(g_p, 0, (size_t)n * dr * sizeof(float), st) != hipSuccess)
+    if (!fill_words_async(g_a, 0, (size_t)n * d * sizeof(float), st) ||
+        !fill_words_async(g_p, 0, (size_t)n * dr * sizeof(float), st))
       return KGE_ERR_LAUNCH;
   } else {
     ys = 1;

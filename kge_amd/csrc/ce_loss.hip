@@ -288,7 +288,7 @@ int run_ce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));
   // a label outside [0, num_ent) is found by no lane: its row's loss then reads NaN, not stale scratch
-  if (hipMemsetAsync(ce.true_score, 0xff, (size_t)n * sizeof(float), st) != hipSuccess) return KGE_ERR_LAUNCH;
+  if (!fill_words_async(ce.true_score, 0xff, (size_t)n * sizeof(float), st)) return KGE_ERR_LAUNCH;
   const int rc = run_lse_pass(scorer, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, n,
@@ -446,7 +446,7 @@ int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   ce.side2_off = n;
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(2 * n * ncg * 8));
-  if (hipMemsetAsync(ce.true_score, 0xff, (size_t)(2 * n) * sizeof(float), st) != hipSuccess) return KGE_ERR_LAUNCH;
+  if (!fill_words_async(ce.true_score, 0xff, (size_t)(2 * n) * sizeof(float), st)) return KGE_ERR_LAUNCH;
   const int rc = run_lse_pass(scorer, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, 2 * n,
@@ -461,10 +461,10 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   // acc_rel != NULL (kge_ce_sp_po_bwd_accum): g_a / g_p are not returned; the row gradients are added
   // into g_tgt (on top of dT) and into the zeroed acc_rel [acc_rel_rows, acc_rel_ld]
   if (acc_rel != nullptr &&
-      hipMemsetAsync(acc_rel, 0, (size_t)acc_rel_rows * acc_rel_ld * sizeof(float), st) != hipSuccess)
+      !fill_words_async(acc_rel, 0, (size_t)acc_rel_rows * acc_rel_ld * sizeof(float), st))
     return KGE_ERR_LAUNCH;
   if (n == 0) {
-    if (acc_rel != nullptr && hipMemsetAsync(g_tgt, 0, (size_t)m * d * sizeof(float), st) != hipSuccess)
+    if (acc_rel != nullptr && !fill_words_async(g_tgt, 0, (size_t)m * d * sizeof(float), st))
       return KGE_ERR_LAUNCH;
     return KGE_OK;
   }

@@ -533,4 +533,24 @@ struct EvalLists {
   unsigned int* bits[EV_MAXQ];           // the layout of CeArgs::rk_bits
 };
 
+// ---- fill_words_async: what the library uses INSTEAD of hipMemsetAsync.  A hipMemsetAsync captured into a hipGraph
+// becomes a memset node that ROCm replays with its blit fill kernel (__amd_rocclr_fillBufferAligned) from a 16-byte
+// pattern the graph does not own: after ~100 replays of a captured training step the relation-gradient buffer came
+// back filled with a repeating 16-byte pattern of which one dword was garbage (round 4: tools/graph_step_probe.py,
+// DESIGN.md 10.7) -- the zeroed accumulator was not zero, every replayed step added noise to the relation table.
+// A kernel of our own carries its value as a launch argument, which the graph does own.  `bytes` is a multiple of 4.
+__global__ static void fill_words_kernel(unsigned int* __restrict__ p, unsigned int v, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+static inline bool fill_words_async(void* ptr, unsigned char byte, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return true;
+  const long long n = (long long)(bytes / 4);
+  const unsigned int v = 0x01010101u * byte;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned int*)ptr, v, n);
+  return hipGetLastError() == hipSuccess;
+}
+
 }  // namespace kge

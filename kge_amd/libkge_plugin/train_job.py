@@ -52,9 +52,55 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
 
     def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
         super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
+        self._graph_step = None       # kge_amd.train_graph.GraphedStep, built at the first batch that qualifies
+        self._graph_step_ok = None    # decided at the first batch (None: not yet)
+        self._skip_optimizer_step = False
         if self.__class__ == HipTrainingJob1vsAll:
             for f in Job.job_created_hooks:
                 f(self)
+
+    # ---- hip_1vsAll.graph_step: forward + backward + optimizer.step of a full batch as one hipGraph replay.
+    # TrainingJob.run_epoch (kge/job/train.py:452-474) calls optimizer.step() itself after the batch: the replay has
+    # taken that step already, so the job's optimizer skips exactly that one call.
+    def _graph_step_for(self, batch_index, batch, subbatch_slice):
+        if self._graph_step_ok is False or self.is_forward_only:
+            return None
+        if self._graph_step_ok is None:
+            ok = bool(self.config.get_default("hip_1vsAll.graph_step")) and str(self.device).startswith("cuda")
+            ok = ok and _model_takes_fused_loss(self.model) and hasattr(self.model, "loss_sp_po")
+            opt = self.optimizer
+            ok = ok and all(g.get("lr_decay", 0) == 0 for g in opt.param_groups)
+            ok = ok and (type(opt).__module__ == "kge_amd.optim" or type(opt) is torch.optim.SGD)
+            if ok:  # a penalty term back-propagates between the batch and the optimizer's step: eager
+                try:
+                    ok = len(self.model.penalty(epoch=self.epoch, batch_index=batch_index,
+                                                num_batches=len(self.loader), batch=batch)) == 0
+                except Exception:
+                    ok = False
+            self._graph_step_ok = ok
+            if ok:
+                from kge_amd.train_graph import GraphedStep
+                job, real_step = self, opt.step
+
+                class _Opt:  # what GraphedStep needs of the optimizer, with the REAL step
+                    param_groups = opt.param_groups
+                    zero_grad = staticmethod(opt.zero_grad)
+                    step = staticmethod(real_step)
+
+                def step_or_skip(*a, **k):
+                    if job._skip_optimizer_step:
+                        job._skip_optimizer_step = False
+                        return None
+                    return real_step(*a, **k)
+                opt.step = step_or_skip
+                self._graph_step = GraphedStep(
+                    lambda s, p, o, inv: self.model.loss_sp_po(s, p, o).sum() * inv, _Opt, warmup=2)
+        if not self._graph_step_ok:
+            return None
+        n = len(batch["triples"])
+        sl = subbatch_slice
+        whole = sl.start in (0, None) and (sl.stop is None or sl.stop >= n) and sl.step in (1, None)
+        return self._graph_step if whole and _model_takes_fused_loss(self.model) else None
 
     def _process_subbatch_bce(self, batch_index, batch, subbatch_slice, result, offset):
         """train.loss: bce -- every triple's (s, p) row has the single label o (and (p, o) the label s):
@@ -95,6 +141,15 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
         triples = batch["triples"][subbatch_slice].to(self.device)
         result.prepare_time += time.time()
         if hasattr(self.model, "loss_sp_po"):
+            gs = self._graph_step_for(batch_index, batch, subbatch_slice)
+            if gs is not None and gs.enabled:
+                result.forward_time -= time.time()
+                inv = torch.full((), 1.0 / batch_size, device=triples.device)
+                loss_value = gs(triples[:, 0], triples[:, 1], triples[:, 2], inv)
+                self._skip_optimizer_step = True  # (eager or replayed: the step is taken)
+                result.avg_loss += loss_value.item()
+                result.forward_time += time.time()
+                return
             # both directions from one scoring launch and one pair of gradient products; the sum of
             # the two losses is back-propagated once (the reference does it in two passes:
             # the same gradients, accumulated)

@@ -14,16 +14,20 @@ Mirrors the step of TrainingJob.run_epoch (kge/job/train.py:452-474: zero_grad, 
 optimizer.step) for the jobs whose batches are index tensors of a fixed shape: 1vsAll and negative sampling; the last,
 shorter batch of an epoch and anything else that does not fit runs eagerly through the same callables.
 
-STATUS: a helper for loops this package drives itself (bench.py's roofline_train leg, tools/graph_step_probe.py);
-it is NOT wired into the LibKGE plugin.  Verified: tests/test_gpu_train_graph.py (losses to 1e-6, SGD parameters to
-2e-5 of an eager run, recapture at a learning-rate change, eager fallback for a short batch) and 200 steps at the
-FB15k-237 shape (tools/graph_step_probe.py: epoch means to 2e-6; single steps differ by up to 3e-4 -- a replay orders
-the float atomics of the gradient scatter differently and Adagrad turns a coordinate whose gradient is that noise
-into a +-lr move).  Under LibKGE's TrainingJob.run_epoch two things spoke against it: the trainer reads the loss back
-after every batch, so the host waits for every replay and a graph launch reaches its first kernel LATER than a plain
-launch (0.088 s per epoch of 100 batches against 0.070 s eager on the box measured), and a second replayed epoch
-drifted from the eager trajectory (loss +0.2 ... 0.7 %, starting at a batch that moved with the allocator's state)
-while the first matched to 1e-7 -- not understood, hence not shipped there.
+Used by the LibKGE plugin (`hip_1vsAll.graph_step`, default true: kge_amd/libkge_plugin/train_job.py), by bench.py's
+roofline_train leg and by tools/graph_step_probe.py.  Verified: tests/test_gpu_train_graph.py (losses to 1e-6, SGD
+parameters to 2e-5 of an eager run, recapture at a learning-rate change, eager fallback for a short batch), 200 steps
+at the FB15k-237 shape (tools/graph_step_probe.py), and through an unmodified LibKGE two epochs against the eager job
+(tests/test_gpu_libkge_plugin.py test a: second-epoch loss to 1e-5, parameters 5e-5).  Single steps of an Adagrad run
+differ from the eager run's by up to 3e-4 (a replay orders the float atomics of the gradient scatter differently and
+Adagrad turns a coordinate whose gradient is that noise into a +-lr move); epoch means agree to 2e-6.
+
+A trap this module's first version fell into, for whoever captures library calls into graphs: a hipMemsetAsync
+captured into a hipGraph becomes a memset node that ROCm 7 replays with its blit fill kernel from a 16-byte pattern the
+graph does not own.  After ~100 replays the "zeroed" relation-gradient accumulator came back as a repeating 16-byte
+pattern with one garbage dword, and every replayed step added that to the relation table.  The
+library no longer calls hipMemsetAsync anywhere (common.hpp fill_words_async: a kernel carries its value as a launch
+argument, which the graph owns).
 
 What a captured step cannot follow, and what is done about it:
   * a changed learning rate (schedulers; kge/job/train.py:406-431): the kernels take lr as a launch argument, so the
@@ -57,6 +61,7 @@ class GraphedStep:
         self._static_in: Sequence[torch.Tensor] = ()
         self._static_loss: Optional[torch.Tensor] = None
         self._lrs = None
+        self.static_grads = []
         self.disabled_reason: Optional[str] = None
         for g in optimizer.param_groups:
             if g.get("lr_decay", 0) != 0:
@@ -88,6 +93,9 @@ class GraphedStep:
             loss.backward()
             self.optimizer.step()
             self._static_loss = loss.detach()
+        # the gradient buffers the captured backward writes and the captured optimizer reads (static: a replay fills
+        # them again; the parameters' .grad attributes may be set to None by the caller in between)
+        self.static_grads = [p.grad for g in self.optimizer.param_groups for p in g["params"]]
         self._graph = graph
         self._sig = self._signature(inputs)
         self._lrs = [g["lr"] for g in self.optimizer.param_groups]

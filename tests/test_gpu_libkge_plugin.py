@@ -166,10 +166,32 @@ def test_a_hip_complex_under_1vsAll_matches_the_reference_model(data):
          loss_hip=l_fus, rel=_rel(l_fus, l_ref), param_rel_diff=d16)
     assert _rel(l_fus, l_ref) <= 1e-2
     assert d16 <= 5e-2
+    # hip_1vsAll.graph_step (default true): every full batch behind the two warm-up batches was ONE hipGraph replay
+    # (forward + backward + HipAdagrad).  Switched off, the same kernels issued from Python take the same steps: the
+    # first epoch's loss to 1e-6, a SECOND epoch over the same batch order to 1e-5 (that one failed until round 4
+    # replaced hipMemsetAsync inside the library: a memset captured into a hipGraph is replayed from a pattern the graph
+    # does not own, and after ~100 replays the zeroed relation-gradient accumulator was not zero)
+    gs = fus._graph_step
+    assert gs is not None and gs.disabled_reason is None and gs.replays >= 90 and gs.captures == 1, vars(gs)
+    gra = fus
+    eag, l_eag, _ = _train_epoch(
+        root, folder, "a_fused_eager", "hip_complex", "hip_1vsAll", init_from=st,
+        opts={"hip_complex.score_dtype": "bfloat16", "train.optimizer.default.type": "HipAdagrad",
+              "train.optimizer.default.args.bf16_copies": True, "hip_1vsAll.graph_step": False})
+    assert eag._graph_step is None
+    assert _rel(l_fus, l_eag) <= 1e-6, (l_fus, l_eag)
+    second = {}
+    for tag, job in (("graph", gra), ("eager", eag)):
+        torch.manual_seed(29)
+        second[tag] = job.run_epoch()["avg_loss"]
+    _log(case="a: hip_1vsAll.graph_step true / false, loss of the first and of the second epoch",
+         first_graph=l_fus, first_eager=l_eag, second=second, replays=gs.replays, param_rel_diff=_param_diff(gra, eag))
+    assert _rel(second["graph"], second["eager"]) <= 1e-5, second
     # job-level wall time of one more (warm) epoch: 100 batches of 512, E = 14,541, d = 512
     _log(case="a: seconds per epoch (100 batches of 512), TrainingJob1vsAll through LibKGE on the GPU",
          reference_complex=_second_epoch_seconds(ref), hip_complex_f32=_second_epoch_seconds(hip),
-         hip_complex_fused_bf16=_second_epoch_seconds(fus))
+         hip_complex_fused_bf16=_second_epoch_seconds(fus),
+         hip_complex_fused_bf16_without_graph_step=_second_epoch_seconds(eag))
 
 
 @pytest.mark.parametrize("loss", ["bce_mean", "bce_self_adversarial"])

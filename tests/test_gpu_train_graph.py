@@ -61,3 +61,48 @@ def test_graphed_step_refuses_a_step_count_dependent_optimizer():
     for _ in range(3):
         step(b[:, 0], b[:, 1], b[:, 2])
     assert step.replays == 0
+
+
+def test_replayed_gradients_stay_the_eager_gradients_over_many_replays():
+    """260 replays of a captured step with device allocations of assorted sizes, pageable host <-> device copies and a
+    loss read-back in between; from the 100th on the captured step's gradient buffers (GraphedStep.static_grads) are
+    compared with an eager step from the same parameters.
+    Background: round 4's replay bug -- a hipMemsetAsync captured into a hipGraph is replayed from a pattern the graph
+    does not own; under LibKGE's trainer, from the ~100th replay on, the relation-gradient accumulator the library
+    "zeroed" came back as a repeating 16-byte pattern with a garbage dword.  The library fills with its own kernel now
+    (common.hpp fill_words_async).  THIS test did not reproduce the failure with the old library (the trigger needs
+    more of LibKGE's host-side activity than is imitated here); the test that did, deterministically, is plugin test
+    `a` in tests/test_gpu_libkge_plugin.py (second epoch), which needs the reference package on the box."""
+    from kge_amd import model as km
+    from kge_amd.train_graph import GraphedStep
+    E, R, D, N = 3001, 237, 512, 256
+    torch.manual_seed(0)
+    m_g = km.create("complex", E, R, D, device=DEV, score_dtype=torch.bfloat16)
+    m_e = km.create("complex", E, R, D, device=DEV, score_dtype=torch.bfloat16)
+    opt_g = torch.optim.SGD(m_g.parameters(), lr=0.05)
+    step = GraphedStep(lambda s, p, o: m_g.loss_sp_po(s, p, o).sum() / len(s), opt_g, warmup=2)
+    g = torch.Generator().manual_seed(9)
+    churn = []
+    for k in range(260):
+        b = torch.stack([torch.randint(hi, (N,), generator=g) for hi in (E, R, E)], 1).to(DEV)
+        if k >= 100:
+            m_e.load_state_dict(m_g.state_dict())
+            for p in m_e.parameters():
+                p.grad = None
+            (m_e.loss_sp_po(b[:, 0], b[:, 1], b[:, 2]).sum() / N).backward()
+        loss = float(step(b[:, 0], b[:, 1], b[:, 2]))          # (a read-back per step, as LibKGE's trainer does)
+        assert loss == loss
+        if k >= 100:
+            assert step.replays == k - 2 + 1 and len(step.static_grads) == 2
+            for got, p in zip(step.static_grads, m_e.parameters()):
+                err = float((got - p.grad).abs().max())
+                assert err <= 1e-6 * float(p.grad.abs().max()) + 1e-9, (k, tuple(got.shape), err, float(got.abs().max()))
+        # churn between the replays: what a training loop's own temporaries and copies do (device blocks of assorted
+        # sizes; pageable host <-> device copies, which go through the runtime's staging buffers)
+        host = torch.randn(40000 + 997 * (k % 7))
+        dev_copy = host.to(DEV)
+        back = (dev_copy * 2).cpu()
+        assert float(back[0]) == float(host[0]) * 2
+        churn.append([torch.empty(sz, dtype=torch.uint8, device=DEV).fill_(0xAB) for sz in (512, 12288, 485376, 1 << 20, 7 << 20)])
+        if len(churn) > 3:
+            churn.pop(0)
