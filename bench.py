@@ -247,8 +247,8 @@ def rank_legs(engine, device, n, steps):
     profiles/r4_rank8_stamps_probes.txt, probe 31)."""
     import numpy as np
     out = {"bound": "mfma", "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-           "kernel": "pairs_bf16_v8_rank_kernel<ComplEx, d/2, SPLIT> (kge_score_rank_sp_po = filter-bit set launch + "
-                     "query build + the persistent counting kernel + bit clear launch)",
+           "kernel": "pairs_bf16_v8_rank_kernel<ComplEx, d/2, SPLIT> (kge_score_rank_sp_po = ONE launch that builds the "
+                     "query fragments and sets the filter bits + the persistent counting kernel, which clears them)",
            "matrix_pipe_probe": matrix_pipe_probe(device)}
     rng = np.random.default_rng(0)
     for tag, E, R, d in (("fb15k-237", E_FB, R_FB, DIM), ("wikidata5m_shard", (E_WD + 7) // 8, R_WD, DIM_WD)):

@@ -31,6 +31,9 @@ int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Ope
                       long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
                       void* ws, long long ws_bytes, int reserve_cus);
 long long pairs_bf16_v4_query_bytes(int d, long long n, bool two_sided, bool split);
+int run_query_build_bits(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                         long long n, void* qf, const RankBitLists& B, int lists, long long col_begin, long long m,
+                         long long rs, long long us, hipStream_t st);
 int run_query_build(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
                     long long n, void* qf, hipStream_t st);
 int run_pairs_bf16_v4_prepared(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R,
@@ -891,7 +894,11 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   }
   hipStream_t st = (hipStream_t)stream;
   const int nlists = manage_bits ? 2 * num_filters : 0;
-  int rc = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 1, st);
+  // The persistent counting kernel takes its bits from ONE launch together with its query fragments
+  // (query_build_bits_kernel) and clears every word it has read itself: two launches instead of four.
+  const bool fused_front = v8_rank && !exact_path && nlists > 0 && !queries_ready && n > 0 &&
+                           !(getenv("KGE_RANK_FUSED_FRONT") && getenv("KGE_RANK_FUSED_FRONT")[0] == '0');
+  int rc = fused_front ? KGE_OK : run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 1, st);
   if (rc) return rc;
   if (exact_path) {
     for (int side = 0; side < 2 && rc == KGE_OK; ++side) {
@@ -917,15 +924,34 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   if (v8_rank) {
     // query fragments into the workspace (one small launch), then the persistent counting kernel: any n, no co-residency
     void* qf = (char*)workspace + PAIRS_WS_CTRL_BYTES;
-    if (!queries_ready) rc = run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
+    if (fused_front) {
+      RankBitLists B{};
+      for (int q = 0; q < nlists; ++q) {
+        B.begin[q] = lb[q]; B.end[q] = le[q]; B.col[q] = lc[q];
+        B.keep[q] = keep[q]; B.bits[q] = bits[q];
+      }
+      rc = run_query_build_bits(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, B, nlists, col_begin, m, bl.rs,
+                                bl.us, st);
+      if (rc == KGE_ERR_UNSUPPORTED) {  // (not a shape of the fused front: the two launches)
+        rc = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 1, st);
+        if (rc == KGE_OK) rc = run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
+      }
+    } else if (!queries_ready) {
+      rc = run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
+    }
+    // the kernel clears the filter words it reads (every word of rows < n exactly once) when the bits are this
+    // call's to manage: no clearing launch behind it
+    ce.rk_clear_bits = manage_bits && num_filters > 0 ? 1 : 0;
     if (rc == KGE_OK)
       rc = run_pairs_bf16_v8_rank(t->scorer, split, TG, (int)t->dim, n, m, qf, ce, st, nullptr,
                                   (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
+    ce.rk_clear_bits = 0;
+    if (rc == KGE_OK) return KGE_OK;  // counted, bits cleared by the kernel
     if (rc != KGE_ERR_UNSUPPORTED || split) {
       const int rcb = run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 0, st);
       return rc != KGE_OK ? rc : rcb;
     }
-    rc = KGE_OK;  // declined (nothing counted): the round-3 kernel below
+    rc = KGE_OK;  // declined (nothing counted, bits still set): the round-3 kernel below
   }
   // one launch holds at most 32 row groups (one workgroup per CU and XCD-aligned column groups): 2,048 rows per
   // side; larger batches go through in row blocks

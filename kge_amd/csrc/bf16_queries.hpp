@@ -122,4 +122,21 @@ __global__ __launch_bounds__(256) void query_build_kernel(NextQ nx) {
   v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
 }
 
+// The two launches in front of the counting kernel (kge_score_rank_sp_po) in one: blocks [0, build_blocks) build the
+// query fragments, the rest set the filter bits of (row, list) -- independent work, one launch gap less.
+template <int SCORER, int HH, int SPLIT>
+__global__ __launch_bounds__(256) void query_build_bits_kernel(NextQ nx, RankBitLists B, int build_blocks, int row_blocks,
+                                                               long long n, long long col_begin, long long m,
+                                                               long long rs, long long us) {
+  if ((int)blockIdx.x < build_blocks) {
+    v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)build_blocks * 256);
+    return;
+  }
+  const int b = (int)blockIdx.x - build_blocks;
+  const int q = b / row_blocks;
+  const long long i = (long long)(b % row_blocks) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  rank_bits_row(B, q, i, threadIdx.x & 63, col_begin, m, rs, us, 1);
+}
+
 }  // namespace kge

@@ -405,6 +405,7 @@ struct CeArgs {
   // the 32 rows of a wave read 32 neighbouring words (two cache lines) per unit of 32 columns, not one line per row
   const unsigned int* rk_bits[2][2];  // [side][filter set]
   long long rk_bits_rs, rk_bits_us;
+  int rk_clear_bits;                  // pairs_bf16_v8_rank_kernel: store zero over every filter word it has read
 };
 
 // ---- the tie arithmetic of EntityRankingJob._get_ranks_and_num_ties (eval_entity_ranking.py:571-596), shared by
@@ -532,6 +533,30 @@ struct EvalLists {
   long long* range[EV_MAXQ];             // [2][n]: begin, end of row i's values (kept for the clearing pass)
   unsigned int* bits[EV_MAXQ];           // the layout of CeArgs::rk_bits
 };
+
+// ---- the filter sets as per-row column bit masks (kge_score_rank_sp_po): one wave per (row, list) sets (set = 1) the
+// bits of the row's filter columns that fall into the scored slice [col_begin, col_begin + m) -- except the row's own
+// true column, which is never filtered (eval_entity_ranking.py:288-290) -- or clears the words again (set = 0).
+struct RankBitLists {
+  const long long* begin[4];
+  const long long* end[4];
+  const long long* col[4];
+  Index keep[4];
+  unsigned int* bits[4];
+};
+__device__ __forceinline__ void rank_bits_row(const RankBitLists& B, int q, long long i, int lane, long long col_begin,
+                                              long long m, long long rs, long long us, int set) {
+  const long long keep = index_at(B.keep[q], i);
+  const long long* __restrict__ col = B.col[q];
+  unsigned int* row = B.bits[q] + i * rs;
+  for (long long e = B.begin[q][i] + lane; e < B.end[q][i]; e += 64) {
+    const long long g = col[e];
+    const long long j = g - col_begin;
+    if (g == keep || j < 0 || j >= m) continue;
+    if (set) atomicOr(row + (j >> 5) * us, 1u << (j & 31));
+    else row[(j >> 5) * us] = 0u;
+  }
+}
 
 // ---- fill_words_async: what the library uses INSTEAD of hipMemsetAsync.  A hipMemsetAsync captured into a hipGraph
 // becomes a memset node that ROCm replays with its blit fill kernel (__amd_rocclr_fillBufferAligned) from a 16-byte

@@ -357,29 +357,12 @@ int run_rank_multi(const float* scores, long long lds, long long n, long long c,
 // columns that fall into the scored slice [col_begin, col_begin + m) -- except the row's own true column, which
 // is never filtered (eval_entity_ranking.py:288-290) --, set = 0 clears the words again (the buffer is all-zero
 // between calls, so no pass over it ever touches more than the listed entries).
-struct RankBitLists {
-  const long long* begin[4];
-  const long long* end[4];
-  const long long* col[4];
-  Index keep[4];
-  unsigned int* bits[4];
-};
-
 __global__ __launch_bounds__(256) void rank_bits_kernel(RankBitLists B, long long n, long long col_begin,
                                                         long long m, long long rs, long long us, int set) {
   const int q = blockIdx.y;
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  const long long keep = index_at(B.keep[q], i);
-  const long long* __restrict__ col = B.col[q];
-  unsigned int* row = B.bits[q] + i * rs;
-  for (long long e = B.begin[q][i] + (threadIdx.x & 63); e < B.end[q][i]; e += 64) {
-    const long long g = col[e];
-    const long long j = g - col_begin;
-    if (g == keep || j < 0 || j >= m) continue;
-    if (set) atomicOr(row + (j >> 5) * us, 1u << (j & 31));
-    else row[(j >> 5) * us] = 0u;
-  }
+  rank_bits_row(B, q, i, threadIdx.x & 63, col_begin, m, rs, us, set);
 }
 
 int run_rank_bits(int lists, const long long* const* begin, const long long* const* end, const long long* const* col,

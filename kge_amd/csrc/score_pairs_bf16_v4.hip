@@ -1159,6 +1159,36 @@ int run_query_build(int scorer, bool split, const Operand& A, const Operand* A2,
   return KGE_ERR_UNSUPPORTED;
 }
 
+// run_query_build + the filter-bit set launch of kge_score_rank_sp_po as ONE launch (query_build_bits_kernel)
+int run_query_build_bits(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                         long long n, void* qf, const RankBitLists& B, int lists, long long col_begin, long long m,
+                         long long rs, long long us, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (!v4_al16(qf) || lists < 1 || lists > 4) return KGE_ERR_INVALID_ARG;
+  const int row_blocks = (int)((n + 3) / 4);
+#define KGE_QBB(SC, HHV, SP)                                                                                   \
+  {                                                                                                            \
+    const NextQ q = v4_nextq<SC, HHV, SP>(A, A2, R, dir, n, qf);                                               \
+    constexpr int RGR = SP ? 64 : V4_ROWS;                                                                     \
+    long long blocks = ((long long)q.rgn * RGR * (HHV / 8) + 255) / 256;                                       \
+    if (blocks > 1024) blocks = 1024;                                                                          \
+    if (blocks < 1) blocks = 1;                                                                                \
+    hipLaunchKernelGGL((query_build_bits_kernel<SC, HHV, SP>), dim3((unsigned)(blocks + (long long)lists * row_blocks)), \
+                       dim3(256), 0, st, q, B, (int)blocks, row_blocks, n, col_begin, m, rs, us);              \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;                                          \
+  }
+#define KGE_QBB2(SC)                                          \
+  if (d == 256) {                                             \
+    if (split) KGE_QBB(SC, 128, 1) else KGE_QBB(SC, 128, 0)   \
+  } else if (d == 512) {                                      \
+    if (split) KGE_QBB(SC, 256, 1) else KGE_QBB(SC, 256, 0)   \
+  }
+  if (scorer == KGE_COMPLEX) { KGE_QBB2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_QBB2(KGE_DISTMULT) }
+#undef KGE_QBB2
+#undef KGE_QBB
+  return KGE_ERR_UNSUPPORTED;
+}
+
 // A group of `nbatch` equally shaped batches (kge_build_queries_multi / kge_score_queries_multi): batch l = rows
 // [l n, (l + 1) n) of the index vectors, its fragments at qf + l * qstride_bytes.
 NextQ pairs_bf16_nextq(bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, long long n,

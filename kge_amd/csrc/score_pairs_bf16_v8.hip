@@ -799,8 +799,18 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
         } else {
           const unsigned int wany = (ce.rk_nfilt > 0 ? wc[sub][0] : 0u) | (ce.rk_nfilt > 1 ? wc[sub][1] : 0u);
           const bool whole = ((long long)(u_lo + cu) * NACC + sub + 1) * V8_UT <= m;
-          if (!RAWFAST || rk_slow || !whole || __any(wany != 0u)) rank_unit(acc[sub], cu, sub, wc[sub][0], wc[sub][1]);
+          const bool anyw = __any(wany != 0u) != 0;
+          if (!RAWFAST || rk_slow || !whole || anyw) rank_unit(acc[sub], cu, sub, wc[sub][0], wc[sub][1]);
           else rank_unit_raw(acc[sub]);
+          // This word is read by nobody else (every (row, sub-unit) of the batch belongs to one lane pair of one
+          // workgroup): clear it here instead of in a launch behind the kernel.  Rare -- a few filtered columns per
+          // row --, a plain store: one more vector-memory operation in flight only makes the counted waits wait longer.
+          if (anyw && ce.rk_clear_bits) {
+            const bool mine_row = counts_here && fh == 0 && orow_cur < a.n;
+            unsigned int* wp = (unsigned int*)(rk_base + ((long long)(u_lo + cu) * NACC + sub) * ce.rk_bits_us * 4 + rk_off);
+            if (mine_row && wc[sub][0] != 0u && ce.rk_nfilt > 0) wp[0] = 0u;
+            if (mine_row && wc[sub][1] != 0u && ce.rk_nfilt > 1) wp[1] = 0u;
+          }
         }
       }
       if (HALF == 0 && dbg_i < 32) stamp();  // (a stamp is a store: the counted waits of this wave wait for more)
