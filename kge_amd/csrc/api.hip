@@ -31,6 +31,11 @@ int run_pairs_bf16_v4(int scorer, const Operand& A, const Operand* A2, const Ope
                       long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
                       void* ws, long long ws_bytes, int reserve_cus);
 long long pairs_bf16_v4_query_bytes(int d, long long n, bool two_sided, bool split);
+int run_pairs_bf16_true(int scorer, bool split, const Operand& TG, int d, long long n, const void* qf, const Index& t_sp,
+                        const Index& t_po, float* true_sp, float* true_po, hipStream_t st);
+int run_eval_begin_build(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                         long long n, void* qf, const EvalLists& L, const Index& s, const Index& o, long long m,
+                         long long rs, long long us, long long* tgt, hipStream_t st);
 int run_query_build_bits(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
                          long long n, void* qf, const RankBitLists& B, int lists, long long col_begin, long long m,
                          long long rs, long long us, hipStream_t st);
@@ -1091,8 +1096,6 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
       L.bits[q] = (unsigned int*)filter_bits + (int64_t)side * bl.words + k;
     }
   hipStream_t st = (hipStream_t)stream;
-  // (1) filter lookup + filter bits + the target list (o | s)
-  if ((rc = run_eval_begin(L, si, oi, n, m, bl.rs, bl.us, tgt, st))) return rc;
   // (2) the true scores: the batch against its own targets, [n, 4 n] = (sp_ vs o | s, _po vs o | s); the diagonals
   // (i, i) and (i, 3 n + i) are elements of the score matrix bit for bit (each score is its own chain)
   kge_index tgi{tgt, KGE_I64, 0, 1};
@@ -1108,16 +1111,37 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
                workspace_bytes >= PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, split) &&
                pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
                pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG);
+  // (1) filter lookup + filter bits + the target list (o | s) -- with the query fragments of a bf16 batch built by
+  // spare blocks of the same launch (eval_begin_build_kernel)
+  bool built = false;
+  if (ready) {
+    rc = run_eval_begin_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, (char*)workspace + PAIRS_WS_CTRL_BYTES, L,
+                              si, oi, m, bl.rs, bl.us, tgt, st);
+    built = rc == KGE_OK;
+    if (rc != KGE_OK && rc != KGE_ERR_UNSUPPORTED) return rc;
+  }
+  if (!built && (rc = run_eval_begin(L, si, oi, n, m, bl.rs, bl.us, tgt, st))) return rc;
+  // true_sp[i] at trueblk[i * tstride], true_po[i] at true_po0[i * tstride]
+  const float* true_po0 = trueblk + 3 * n;
+  int64_t tstride = 4 * n + 1;
   if (ready) {
     void* qf = (char*)workspace + PAIRS_WS_CTRL_BYTES;
-    rc = run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
+    rc = built ? KGE_OK : run_query_build(t->scorer, split, S, &O, P, KGE_SP_, (int)t->dim, n, qf, st);
     if (rc == KGE_OK) {
-      const Operand TL = ent_op(t, tgi);
-      rc = run_pairs_bf16_v4_prepared(t->scorer, split, S, &O, P, TL, KGE_SP_, (int)t->dim, n, 2 * n, trueblk, 4 * n, 2 * n,
-                                      st, nullptr, qf, workspace, workspace_bytes, 0, nullptr, nullptr, nullptr, 0, nullptr);
-      if (rc == KGE_ERR_UNSUPPORTED) {  // (a launch the loader/consumer kernel declines: the one-call path)
-        ready = false;
-        rc = kge_score_sp_po(t, s, p, o, n, tgi, 2 * n, trueblk, 4 * n, workspace, workspace_bytes, stream);
+      // one chain per triple from the prepared fragments (pairs_bf16_true_kernel): [n] + [n] floats, no score block
+      rc = run_pairs_bf16_true(t->scorer, split, TG, (int)t->dim, n, qf, oi, si, trueblk, trueblk + n, st);
+      if (rc == KGE_OK) {
+        true_po0 = trueblk + n;
+        tstride = 1;
+      } else if (rc == KGE_ERR_UNSUPPORTED) {  // the batch against its listed targets with a scoring launch
+        const Operand TL = ent_op(t, tgi);
+        rc = run_pairs_bf16_v4_prepared(t->scorer, split, S, &O, P, TL, KGE_SP_, (int)t->dim, n, 2 * n, trueblk, 4 * n,
+                                        2 * n, st, nullptr, qf, workspace, workspace_bytes, 0, nullptr, nullptr, nullptr, 0,
+                                        nullptr);
+        if (rc == KGE_ERR_UNSUPPORTED) {  // (a launch the loader/consumer kernel declines: the one-call path)
+          ready = false;
+          rc = kge_score_sp_po(t, s, p, o, n, tgi, 2 * n, trueblk, 4 * n, workspace, workspace_bytes, stream);
+        }
       }
     }
   } else {
@@ -1127,10 +1151,10 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
   const int M = num_filters + 1;
   const int64_t per = (int64_t)M * n;
   if (rc == KGE_OK)
-    rc = score_rank_core(t, S, O, P, TG, oi, si, n, 0, m, trueblk, trueblk + 3 * n, num_filters, nullptr, nullptr,
+    rc = score_rank_core(t, S, O, P, TG, oi, si, n, 0, m, trueblk, true_po0, num_filters, nullptr, nullptr,
                          nullptr, nullptr, nullptr, nullptr, atol, rtol, counts, counts + per, counts + 2 * per,
                          counts + 3 * per, n, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream,
-                         4 * n + 1, /*manage_bits=*/false, /*queries_ready=*/ready);
+                         tstride, /*manage_bits=*/false, /*queries_ready=*/ready);
   // (4) bits cleared, tie policy + histograms, counters back to zero.  Behind a declined step (3) (counters untouched)
   // and behind ANY failure of steps (2) / (3): the bits are cleared and the counters zeroed all the same -- the buffers
   // are persistent and the next batch relies on finding them all-zero (advisor, round 3)

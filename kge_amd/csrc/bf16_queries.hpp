@@ -122,6 +122,23 @@ __global__ __launch_bounds__(256) void query_build_kernel(NextQ nx) {
   v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
 }
 
+// kge_eval_batch's first launch and its query build in one: blocks [0, build_blocks) build the fragments, the rest
+// are eval_begin_kernel's (row block, list) pairs -- the filter lookup is a chain of dependent loads (~10 us of
+// latency at 512 rows), the build overlaps it.
+template <int SCORER, int HH, int SPLIT>
+__global__ __launch_bounds__(256) void eval_begin_build_kernel(NextQ nx, EvalLists L, Index s, Index o, int build_blocks,
+                                                               int row_blocks, long long n, long long m, long long rs,
+                                                               long long us, long long* __restrict__ tgt) {
+  if ((int)blockIdx.x < build_blocks) {
+    v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)build_blocks * 256);
+    return;
+  }
+  const int b = (int)blockIdx.x - build_blocks;
+  const long long i = (long long)(b % row_blocks) * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  eval_begin_row(L, s, o, n, m, rs, us, tgt, b / row_blocks, i, threadIdx.x & 63);
+}
+
 // The two launches in front of the counting kernel (kge_score_rank_sp_po) in one: blocks [0, build_blocks) build the
 // query fragments, the rest set the filter bits of (row, list) -- independent work, one launch gap less.
 template <int SCORER, int HH, int SPLIT>

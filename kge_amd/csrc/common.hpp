@@ -558,6 +558,54 @@ __device__ __forceinline__ void rank_bits_row(const RankBitLists& B, int q, long
   }
 }
 
+// ---- kge_eval_batch, the work in front of the scoring: one WAVE per (row, list q < nq): the 64-ary search of the
+// filter index, then the wave sets the bits of the row's filtered columns; q == nq: the batch's target list (o | s).
+__device__ __forceinline__ void eval_begin_row(const EvalLists& L, const Index& s, const Index& o, long long n, long long m,
+                                               long long rs, long long us, long long* __restrict__ tgt, int q, long long i,
+                                               int lane) {
+  if (q == L.nq) {
+    if (lane == 0) {
+      tgt[i] = index_at(o, i);
+      tgt[n + i] = index_at(s, i);
+    }
+    return;
+  }
+  const long long* __restrict__ keys = L.keys[q];
+  const long long num_keys = L.num_keys[q];
+  const long long key = index_at(L.a[q], i) * L.mult[q] + index_at(L.b[q], i);
+  long long lo = 0, hi = num_keys;
+  while (hi - lo > 64) {
+    const long long step = (hi - lo + 63) >> 6;
+    const long long pos = lo + lane * step;
+    const bool below = pos < hi && keys[pos] < key;
+    const int c = __popcll(__ballot(below));
+    if (c == 0) {
+      hi = lo;
+    } else {
+      const long long nhi = lo + c * step;
+      lo = lo + (c - 1) * step + 1;
+      hi = nhi < hi ? nhi : hi;
+    }
+  }
+  const long long pos = lo + lane;
+  const bool below = pos < hi && keys[pos] < key;
+  lo += __popcll(__ballot(below));
+  const bool hit = lo < num_keys && keys[lo] == key;
+  const long long b = hit ? L.starts[q][lo] : 0, e = hit ? L.starts[q][lo + 1] : 0;
+  if (lane == 0) {
+    L.range[q][i] = b;
+    L.range[q][n + i] = e;
+  }
+  const long long keep = index_at(L.keep[q], i);
+  const long long* __restrict__ col = L.values[q];
+  unsigned int* row = L.bits[q] + i * rs;
+  for (long long x = b + lane; x < e; x += 64) {
+    const long long g = col[x];
+    if (g == keep || g < 0 || g >= m) continue;
+    atomicOr(row + (g >> 5) * us, 1u << (g & 31));
+  }
+}
+
 // ---- fill_words_async: what the library uses INSTEAD of hipMemsetAsync.  A hipMemsetAsync captured into a hipGraph
 // becomes a memset node that ROCm replays with its blit fill kernel (__amd_rocclr_fillBufferAligned) from a 16-byte
 // pattern the graph does not own: after ~100 replays of a captured training step the relation-gradient buffer came

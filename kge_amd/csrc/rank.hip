@@ -390,49 +390,7 @@ __global__ __launch_bounds__(256) void eval_begin_kernel(EvalLists L, Index s, I
                                                          long long rs, long long us, long long* __restrict__ tgt) {
   const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  const int lane = threadIdx.x & 63;
-  const int q = blockIdx.y;
-  if (q == L.nq) {
-    if (lane == 0) {
-      tgt[i] = index_at(o, i);
-      tgt[n + i] = index_at(s, i);
-    }
-    return;
-  }
-  const long long* __restrict__ keys = L.keys[q];
-  const long long num_keys = L.num_keys[q];
-  const long long key = index_at(L.a[q], i) * L.mult[q] + index_at(L.b[q], i);
-  long long lo = 0, hi = num_keys;
-  while (hi - lo > 64) {
-    const long long step = (hi - lo + 63) >> 6;
-    const long long pos = lo + lane * step;
-    const bool below = pos < hi && keys[pos] < key;
-    const int c = __popcll(__ballot(below));
-    if (c == 0) {
-      hi = lo;
-    } else {
-      const long long nhi = lo + c * step;
-      lo = lo + (c - 1) * step + 1;
-      hi = nhi < hi ? nhi : hi;
-    }
-  }
-  const long long pos = lo + lane;
-  const bool below = pos < hi && keys[pos] < key;
-  lo += __popcll(__ballot(below));
-  const bool hit = lo < num_keys && keys[lo] == key;
-  const long long b = hit ? L.starts[q][lo] : 0, e = hit ? L.starts[q][lo + 1] : 0;
-  if (lane == 0) {
-    L.range[q][i] = b;
-    L.range[q][n + i] = e;
-  }
-  const long long keep = index_at(L.keep[q], i);
-  const long long* __restrict__ col = L.values[q];
-  unsigned int* row = L.bits[q] + i * rs;
-  for (long long x = b + lane; x < e; x += 64) {
-    const long long g = col[x];
-    if (g == keep || g < 0 || g >= m) continue;
-    atomicOr(row + (g >> 5) * us, 1u << (g & 31));
-  }
+  eval_begin_row(L, s, o, n, m, rs, us, tgt, (int)blockIdx.y, i, threadIdx.x & 63);
 }
 
 // Blocks [0, nq * ceil(n / 4)): the filter bits of (row, list) cleared again (the words that were set: the buffer is

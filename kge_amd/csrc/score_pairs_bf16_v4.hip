@@ -1159,6 +1159,37 @@ int run_query_build(int scorer, bool split, const Operand& A, const Operand* A2,
   return KGE_ERR_UNSUPPORTED;
 }
 
+// run_query_build + run_eval_begin (kge_eval_batch) as ONE launch (eval_begin_build_kernel)
+int run_eval_begin_build(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                         long long n, void* qf, const EvalLists& L, const Index& s, const Index& o, long long m,
+                         long long rs, long long us, long long* tgt, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (!v4_al16(qf)) return KGE_ERR_INVALID_ARG;
+  const int row_blocks = (int)((n + 3) / 4);
+#define KGE_EBB(SC, HHV, SP)                                                                                   \
+  {                                                                                                            \
+    const NextQ q = v4_nextq<SC, HHV, SP>(A, A2, R, dir, n, qf);                                               \
+    constexpr int RGR = SP ? 64 : V4_ROWS;                                                                     \
+    long long blocks = ((long long)q.rgn * RGR * (HHV / 8) + 255) / 256;                                       \
+    if (blocks > 1024) blocks = 1024;                                                                          \
+    if (blocks < 1) blocks = 1;                                                                                \
+    hipLaunchKernelGGL((eval_begin_build_kernel<SC, HHV, SP>),                                                 \
+                       dim3((unsigned)(blocks + (long long)(L.nq + 1) * row_blocks)), dim3(256), 0, st, q, L, s, o, \
+                       (int)blocks, row_blocks, n, m, rs, us, tgt);                                            \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;                                          \
+  }
+#define KGE_EBB2(SC)                                          \
+  if (d == 256) {                                             \
+    if (split) KGE_EBB(SC, 128, 1) else KGE_EBB(SC, 128, 0)   \
+  } else if (d == 512) {                                      \
+    if (split) KGE_EBB(SC, 256, 1) else KGE_EBB(SC, 256, 0)   \
+  }
+  if (scorer == KGE_COMPLEX) { KGE_EBB2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_EBB2(KGE_DISTMULT) }
+#undef KGE_EBB2
+#undef KGE_EBB
+  return KGE_ERR_UNSUPPORTED;
+}
+
 // run_query_build + the filter-bit set launch of kge_score_rank_sp_po as ONE launch (query_build_bits_kernel)
 int run_query_build_bits(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
                          long long n, void* qf, const RankBitLists& B, int lists, long long col_begin, long long m,

@@ -983,6 +983,114 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
 
 #undef KGE_V8_DMA
 
+// ---- The true scores of a batch from its prepared query fragments: score of (s_i, p_i) against o_i and of (p_i, o_i)
+// against s_i -- the elements (i, o_i) / (i, s_i) of the score matrices, bit for bit (each score is one accumulation
+// chain in K order: the chain of the kernels above; MFMA(table rows, query rows), the counting kernel's orientation).
+// kge_eval_batch spent a whole scoring launch on them (17 us for an [n, 2 n] block per side on listed targets, of
+// which the diagonals were used); here one wave takes the 32 operand rows of a fragment block, gathers their 32 target
+// rows into LDS in the units' swizzled layout, runs ONE chain and keeps the diagonal.
+struct V8TrueArgs {
+  Operand TG;           // the entity table (identity rows)
+  Index tgt[2];         // side 0: the true objects, side 1: the true subjects
+  long long n;
+  int rgn1;
+  const u32x4* qf;
+  float* out[2];        // [n] each
+};
+
+template <int SCORER, int HH, int SPLIT>
+__global__ __launch_bounds__(256) void pairs_bf16_true_kernel(V8TrueArgs a) {
+  constexpr int NKB = 2 * HH / 16, ROWB = 4 * HH, SPR = ROWB / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4][32 * ROWB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int blk = (int)blockIdx.x * 4 + wave;     // fragment block: (side, group of 128 operand rows, 32 of them)
+  const int per_side = a.rgn1 * 4;
+  if (blk >= 2 * per_side) return;
+  const int side = blk / per_side, g = (blk % per_side) >> 2, sub = blk & 3;
+  // ---- the lane's real row and its fragments (the addressing of pairs_bf16_v8_rank_kernel)
+  const int rr = SPLIT ? 8 * (fi >> 4) + (fi & 7) : fi;  // real row within the wave = its target's slot
+  const long long lrow = SPLIT ? (long long)g * 64 + 16 * sub + rr : (long long)g * 128 + 32 * sub + fi;
+  const unsigned char* const gbase = (const unsigned char*)(a.qf + (long long)(side * a.rgn1 + g) * 4 * NKB * 64);
+  unsigned int flo;
+  const unsigned char* fb;
+  if constexpr (SPLIT) {
+    const int part = (fi >> 3) & 1, r64 = 16 * sub + rr;
+    flo = (unsigned int)((((2 * part + (r64 >> 5)) * NKB) * 64 + (r64 & 31) + 32 * fh) * 16);
+    fb = gbase;
+  } else {
+    flo = (unsigned int)(lane * 16);
+    fb = gbase + sub * (NKB * 1024);
+  }
+  bf16x8 afr[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) afr[kb] = *reinterpret_cast<const bf16x8*>(fb + flo + kb * 1024);
+  // ---- the 32 target rows of this wave into its LDS block (slot j = the target of real row j; split: 16 real rows,
+  // slots 16 .. 31 repeat them), 16-byte slot `c ^ (row & 15)` of row `row` as in the units of the kernels above
+  long long myrow = SPLIT ? (long long)g * 64 + 16 * sub + (lane & 15) : (long long)g * 128 + 32 * sub + (lane & 31);
+  if (myrow >= a.n) myrow = a.n - 1;
+  const int my_t = (int)index_at(a.tgt[side], myrow);  // lane j (< 32): the table row of slot j
+  unsigned char* const lds = smem[wave];
+  const unsigned char* const tgb = (const unsigned char*)a.TG.base;
+  const long long tld2 = a.TG.ld * 2;
+#pragma unroll 4
+  for (int it = 0; it < 32 * SPR / 64; ++it) {
+    const int idx = it * 64 + lane, row = idx / SPR, c = idx % SPR;
+    const int trow = __shfl(my_t, row, 64);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(tgb + (long long)trow * tld2 + c * 16);
+    *reinterpret_cast<u32x4*>(lds + row * ROWB + ((c ^ (row & 15)) << 4)) = v;
+  }
+  __syncthreads();  // (every wave of the block reaches it: blocks beyond the work return whole or not at all -- see below)
+  // ---- one chain
+  f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) {
+    const bf16x8 bq = *reinterpret_cast<const bf16x8*>(lds + fi * ROWB + (((2 * kb + fh) ^ (fi & 15)) << 4));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, afr[kb], acc, 0, 0, 0);
+  }
+  // ---- the diagonal: this lane's query row against target slot rr = element 8 (r >> 2) + 4 fh + (r & 3) of its 32
+  const int want_r = 4 * (rr >> 3) + (rr & 3);
+  float v = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v = r == want_r ? acc[r] : v;
+  if constexpr (SPLIT) {  // (sum q_hi t) + (sum q_lo t): the partner lane (fi ^ 8) holds the other part
+    const float o = __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    v = v + o;
+  }
+  const bool owner = fh == ((rr >> 2) & 1) && (SPLIT ? ((fi >> 3) & 1) == 0 : true);
+  if (owner && lrow < a.n) a.out[side][lrow] = v;
+}
+
+// KGE_ERR_UNSUPPORTED: not this kernel's case (the caller scores the listed targets with a scoring launch)
+int run_pairs_bf16_true(int scorer, bool split, const Operand& TG, int d, long long n, const void* qf, const Index& t_sp,
+                        const Index& t_po, float* true_sp, float* true_po, hipStream_t st) {
+  if ((d != 512 && d != 256) || TG.idx.ptr != nullptr || qf == nullptr || ((uintptr_t)qf & 15)) return KGE_ERR_UNSUPPORTED;
+  if (n <= 0) return KGE_OK;
+  const long long rgr = split ? 64 : 128;
+  const long long rgn1 = (n + rgr - 1) / rgr;
+  if (rgn1 > (1 << 20) || TG.ld * 2 >= (1LL << 28)) return KGE_ERR_UNSUPPORTED;
+  V8TrueArgs a{};
+  a.TG = TG;
+  a.tgt[0] = t_sp;
+  a.tgt[1] = t_po;
+  a.n = n;
+  a.rgn1 = (int)rgn1;
+  a.qf = (const u32x4*)qf;
+  a.out[0] = true_sp;
+  a.out[1] = true_po;
+  const dim3 grid((unsigned)(2 * rgn1)), block(256);  // 4 fragment blocks (waves) per workgroup: exactly one group
+#define KGE_V8T(SC, HHV, SP) hipLaunchKernelGGL((pairs_bf16_true_kernel<SC, HHV, SP>), grid, block, 0, st, a)
+#define KGE_V8T2(SC)                                                \
+  if (d == 512) { if (split) KGE_V8T(SC, 256, 1); else KGE_V8T(SC, 256, 0); } \
+  else { if (split) KGE_V8T(SC, 128, 1); else KGE_V8T(SC, 128, 0); }
+  if (scorer == KGE_COMPLEX) { KGE_V8T2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_V8T2(KGE_DISTMULT) }
+  else return KGE_ERR_UNSUPPORTED;
+#undef KGE_V8T2
+#undef KGE_V8T
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
 // ---- kge_debug_mfma_rate: the matrix pipe alone.  The grid and wave layout of the kernels above (one workgroup of
 // eight waves per CU = two waves per SIMD), each wave issuing `iters` x 16 v_mfma_f32_32x32x16_bf16 on TWO independent
 // accumulators from operands loaded once (random bf16 values: the pipe's power draw depends on the data) -- no LDS, no
