@@ -159,6 +159,7 @@ class EntityRankingEvaluator:
         # KGE_EVAL_LAUNCH_BY_LAUNCH=1: the fused loop as separate engine calls (a dozen launches per batch) instead of
         # kge_eval_batch's four
         self.four_launches = os.environ.get("KGE_EVAL_LAUNCH_BY_LAUNCH", "0") != "1"
+        self.reserve_cus = int(os.environ.get("KGE_EVAL_RESERVE_CUS", "0"))
         # replay the fused loop's full batches as one hipGraph (KGE_EVAL_GRAPH=0: issue every launch from Python)
         self.hip_graph = os.environ.get("KGE_EVAL_GRAPH", "1") != "0"
         self.graph_batches = 0  # batches that ran as graph replays (all runs)
@@ -261,7 +262,7 @@ class EntityRankingEvaluator:
         gkey = ((tables.ent.data_ptr(), tables.rel.data_ptr(), tuple(tables.ent.shape), tuple(tables.rel.shape),
                  tables.ent.stride(0), tables.rel.stride(0), tables.scorer, bool(return_ranks), M, int(tables.flags),
                  bool(self._fused), bool(self.four_launches), self.tie_handling, float(self.tie_atol),
-                 float(self.tie_rtol), os.environ.get("KGE_EVAL_FUSED_EXACT"), int(self.chunk_size))
+                 float(self.tie_rtol), os.environ.get("KGE_EVAL_FUSED_EXACT"), int(self.chunk_size), int(self.reserve_cus))
                 if isinstance(tables, engine.Tables) else None)
         held = self._graph if (self._graph is not None and self._graph["key"] == gkey) else None
         hist = held["hist"].zero_() if held is not None else torch.zeros(M, E, dtype=torch.float, device=dev)
@@ -285,6 +286,14 @@ class EntityRankingEvaluator:
             self._declined_for, self._declined = gkey, set()
         declined = self._declined
 
+        # Several batches in flight: the persistent counting kernel fills every compute unit's register file, so the
+        # small launches of the OTHER lanes (filter lookup, true scores, histograms: latency-bound chains) cannot start
+        # beside it unless it leaves some compute units free (KGE_FLAG_RESERVE_CUS): a few per cent of its rate for
+        # the ~20 us per batch those launches otherwise add to it
+        lane_flags = None
+        if isinstance(tables, engine.Tables) and self.lanes > 1 and self.hip_graph and self.reserve_cus > 0:
+            lane_flags = int(tables.flags) | engine.reserve_cus(self.reserve_cus)
+
         def do_batch(batch, rng, cnt, ro, rs):
             """One batch: filter ranges, counts (in place in `cnt`), tie policy + histogram; launches only."""
             s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
@@ -297,7 +306,8 @@ class EntityRankingEvaluator:
                 if c4 is None:  # zero once; every call leaves it zero
                     c4 = st["counts4"][ck] = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)
                 if engine.eval_batch(tables, s, p, o, [(st["sp"][k], st["po"][k]) for k in range(M - 1)],
-                                     self.tie_atol, self.tie_rtol, self.tie_handling, c4, hist, ro, rs):
+                                     self.tie_atol, self.tie_rtol, self.tie_handling, c4, hist, ro, rs,
+                                     flags=lane_flags):
                     return
                 declined.add(n)
             sc_, oc_ = s.contiguous(), o.contiguous()  # true_col of the po / sp rankings
