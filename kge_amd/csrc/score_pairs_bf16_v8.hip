@@ -495,8 +495,16 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
   // between them -- LDS reads, table pieces, word loads -- no longer breaks a back-to-back dependent issue (measured
   // on the one-accumulator d = 256 form, tools/rank8_stamps.py with a -DKGE_V8_PROBES build: 2.5 k cycles per 32
   // columns against 0.6 k of bare MFMAs), and barrier, waits and pieces are paid once per 64 columns.
-  constexpr int NACC = HH == 128 ? 2 : 1;
-  constexpr int UT = V8_UT * NACC;        // table rows per unit: 32 / 64
+  // Split queries (q = q_hi + q_lo) come in two forms.  d = 256: TWO fragment sets and two accumulators per lane
+  // (PARTS = 2: 128 operand registers, what d = 512 needs for one set): one LDS read feeds the q_hi and the q_lo MFMA,
+  // the table streams once per 256 real rows, the comparisons run once per score, and the two MFMAs of a K-block are
+  // independent.  d = 512 has no registers for a second set: the q_hi and q_lo rows of 16 real rows are the 32
+  // operand rows of a wave and the partial scores meet by a DPP add (DUP).  Both give fl(sum q_hi t) + fl(sum q_lo t).
+  constexpr bool DUP = SPLIT && HH == 256;
+  constexpr int PARTS = (SPLIT && HH == 128) ? 2 : 1;
+  constexpr int NT = (HH == 128 && !SPLIT) ? 2 : 1;  // 32-row sub-units of a unit
+  constexpr int NACC = NT * PARTS;                   // accumulators of a chain
+  constexpr int UT = V8_UT * NT;          // table rows per unit: 32 / 64
   constexpr int NKB = 2 * HH / 16;        // 32 / 16 K-blocks
   constexpr int ROWB = 4 * HH;            // bytes per table row
   constexpr int SPR = ROWB / 16;          // 16-byte slots per row: 64 / 32
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
   constexpr int NBUF = 4;
   constexpr int SMEM = NBUF * UNITB;
   constexpr int NP = UNITB / 1024 / 8;    // pieces per unit and wave: 4
-  constexpr int RW = SPLIT ? 16 : 32;     // real query rows per wave
+  constexpr int RW = DUP ? 16 : 32;       // real query rows per wave
   constexpr int PF = 4;                   // K-blocks read ahead (8 at d = 512 cost 16 registers the kernel spilled)
   constexpr int PB = NKB == 32 ? 14 : 6;  // K-block of the barrier
   // rank_unit_raw for sub-units without a filtered column: at d = 256, where the comparisons weigh half as much as
@@ -589,11 +597,11 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
 
   // ---------------- the consumer ----------------
   const int fi = lane & 31, fh = lane >> 5;
-  bf16x8 afr[NKB];
+  bf16x8 afr[PARTS][NKB];
   unsigned int bp[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) bp[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
-  bf16x8 bq[NACC][PF];
+  bf16x8 bq[NT][PF];
   auto bread = [&](bf16x8& dst, auto kc, auto ac) __attribute__((always_inline)) {
     constexpr int kb = decltype(kc)::value, sub = decltype(ac)::value;
     const unsigned int addr = bp[kb & 7];
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
 
   // ---- per-row state of the counts (rank.hip's arithmetic; see pairs_bf16_v4_kernel<V3_RANK>)
   const CeArgs& ce = a.ce;
-  const bool counts_here = SPLIT ? ((fi >> 3) & 1) == 0 : true;  // split: the q_lo lanes duplicate their q_hi lane
+  const bool counts_here = DUP ? ((fi >> 3) & 1) == 0 : true;  // DUP: the q_lo lanes duplicate their q_hi lane
   float rk_t = 0.0f, rk_al = 0.0f;
   float rk_hi = 0.0f, rk_lo = 0.0f;  // exact thresholds of the raw counts: see rank_unit_raw
   bool rk_slow = false;
@@ -617,7 +625,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     return (d & 0xfu) | ((d & 0xf0u) << 4) | ((d & 0xf00u) << 8) | ((d & 0xf000u) << 12);
   };
   auto full_score = [&](float v) __attribute__((always_inline)) -> float {
-    if constexpr (SPLIT) {
+    if constexpr (DUP) {
       const float o = __builtin_bit_cast(
           float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
       return v + o;  // (sum q_hi t) + (sum q_lo t): both lanes of the pair hold it (f32 addition commutes)
@@ -656,7 +664,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       g = rk_spread(ng & 0xffffu);
       c = rk_spread(~nc & 0xffffu);
     }
-    const long long c0t = ((long long)(u_lo + cu) * NACC + sub) * V8_UT;
+    const long long c0t = ((long long)(u_lo + cu) * NT + sub) * V8_UT;
     unsigned int mine = counts_here ? (0x0f0f0f0fu << (4 * fh)) : 0u;
     const long long rem = m - c0t;
     if (rem < V8_UT) mine &= rem > 0 ? (1u << rem) - 1u : 0u;  // (the unit exists; its second sub-unit may not)
@@ -713,14 +721,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     }
     rk_g = rk_c = 0;
   };
-  auto load_words = [&](int cu, u32x2 (&w)[NACC]) __attribute__((always_inline)) {
+  auto load_words = [&](int cu, u32x2 (&w)[NT]) __attribute__((always_inline)) {
     // the row's filter words of the unit at slice position cu, BOTH filter sets in one 8-byte load: scalar base (the
     // side's bits + the sub-unit's word column) + the row's offset (api.hip rank_bits_layout: word-major, the sets
     // of a side interleaved).  One set: the second word is the next row's (never looked at); none: 8 bytes of the
     // fragments.
 #pragma unroll
-    for (int sub = 0; sub < NACC; ++sub) {
-      const unsigned char* wb = rk_base + (ce.rk_nfilt > 0 ? ((long long)(u_lo + cu) * NACC + sub) * ce.rk_bits_us * 4 : 0);
+    for (int sub = 0; sub < NT; ++sub) {
+      const unsigned char* wb = rk_base + (ce.rk_nfilt > 0 ? ((long long)(u_lo + cu) * NT + sub) * ce.rk_bits_us * 4 : 0);
       asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[sub]) : "v"(rk_off), "s"(wb) : "memory");
     }
   };
@@ -743,30 +751,30 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     // The words travel wn -> wc by a register copy BEHIND the wait for wn (a copy of a register whose load is still
     // in flight reads the old value: nothing interlocks; with the copy at the end of the burst before -- a chain
     // after the request -- a table from HBM made a hub row's filtered counts differ now and then).
-    constexpr int NPV = (PROBE & 2) ? 0 : NP, WV = (PROBE & 8) ? 0 : NACC;  // (probes: what is really issued)
+    constexpr int NPV = (PROBE & 2) ? 0 : NP, WV = (PROBE & 8) ? 0 : NT;  // (probes: what is really issued)
     constexpr int VMB = (NBUF - 3) * (NPV + WV) + WV;
-    static_assert(VMB + NP + NACC < 64, "vmcnt is a 6-bit counter");
+    static_assert(VMB + NP + NT < 64, "vmcnt is a 6-bit counter");
     constexpr int VMF = NPV;
     f32x16 acc[NACC];
-    u32x2 wc[NACC] = {}, wn[NACC] = {};  // filter words (set 0, set 1) of the current / the next unit
+    u32x2 wc[NT] = {}, wn[NT] = {};  // filter words (set 0, set 1) of the current / the next unit
     auto chain = [&](int ks, int cu, int cu_next) __attribute__((always_inline)) {
       const unsigned int bdelta = ((ks + 1) & (NBUF - 1)) ? (unsigned int)UNITB : (unsigned int)(-(NBUF - 1) * UNITB);
       const int un = dq < g1 ? du : ulast;
       v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
         constexpr int kb = decltype(kc)::value;
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"((PF - 1) * NACC) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"((PF - 1) * NT) : "memory");
         if constexpr (kb == PBH) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"i"(VMB) : "memory");  // this wave's pieces of unit ks + 1 have landed
           if constexpr (!(PROBE & 4)) __builtin_amdgcn_s_barrier();   // P(ks)
         }
         __builtin_amdgcn_sched_barrier(0);
         v4_static_for<0, NACC>([&](auto ac) __attribute__((always_inline)) {
-          constexpr int sub = decltype(ac)::value;
+          constexpr int ai = decltype(ac)::value, sub = ai / PARTS, part = ai % PARTS;
           if constexpr (kb == 0) {
             const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][0], afr[0], zero, 0, 0, 0);
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][0], afr[part][0], zero, 0, 0, 0);
           } else {
-            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][kb % PF], afr[kb], acc[sub], 0, 0, 0);
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][kb % PF], afr[part][kb], acc[ai], 0, 0, 0);
           }
         });
         if constexpr (kb + PF == NKB) {
@@ -774,7 +782,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
           for (int t = 0; t < 8; ++t) asm volatile("v_add_u32 %0, %1, %0" : "+v"(bp[t]) : "s"(bdelta));
         }
         if constexpr (!(PROBE & 16))
-          v4_static_for<0, NACC>([&](auto ac) __attribute__((always_inline)) {
+          v4_static_for<0, NT>([&](auto ac) __attribute__((always_inline)) {
             bread(bq[decltype(ac)::value][kb % PF], std::integral_constant<int, (kb + PF) % NKB>{}, ac);
           });
         if constexpr (kb > PBH && kb <= PBH + NP && !(PROBE & 2))
@@ -782,32 +790,37 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       });
       dma_advance();
       // this unit's words (requested behind the chain before) have landed: into wc, then the next unit's request
-      if constexpr (NACC == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wn[0]), "+v"(wn[1]) : "i"(VMF) : "memory");
+      if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wn[0]), "+v"(wn[1]) : "i"(VMF) : "memory");
       else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wn[0]) : "i"(VMF) : "memory");
 #pragma unroll
-      for (int sub = 0; sub < NACC; ++sub) wc[sub] = wn[sub];
+      for (int sub = 0; sub < NT; ++sub) wc[sub] = wn[sub];
       // (the copies are instructions in front of the loads: the compiler must not fold wc into wn)
-      if constexpr (NACC == 2) asm volatile("" : "+v"(wc[0]), "+v"(wc[1]) : : "memory");
+      if constexpr (NT == 2) asm volatile("" : "+v"(wc[0]), "+v"(wc[1]) : : "memory");
       else asm volatile("" : "+v"(wc[0]) : : "memory");
       if constexpr (!(PROBE & 8)) load_words(cu_next, wn);
       // the burst: this unit's comparisons -- the raw counts alone where no row of the wave has a filtered column
       // in the sub-unit and every one of its columns exists
 #pragma unroll
-      for (int sub = 0; sub < NACC; ++sub) {
+      for (int sub = 0; sub < NT; ++sub) {
         if constexpr (PROBE & 1) {
-          asm volatile("" : : "v"(acc[sub][0]), "v"(acc[sub][15]));
+          asm volatile("" : : "v"(acc[sub * PARTS][0]), "v"(acc[sub * PARTS + PARTS - 1][15]));
         } else {
+          f32x16 sc = acc[sub * PARTS];
+          if constexpr (PARTS == 2) {  // (sum q_hi t) + (sum q_lo t): one add per score
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = acc[sub * PARTS][r] + acc[sub * PARTS + 1][r];
+          }
           const unsigned int wany = (ce.rk_nfilt > 0 ? wc[sub][0] : 0u) | (ce.rk_nfilt > 1 ? wc[sub][1] : 0u);
-          const bool whole = ((long long)(u_lo + cu) * NACC + sub + 1) * V8_UT <= m;
+          const bool whole = ((long long)(u_lo + cu) * NT + sub + 1) * V8_UT <= m;
           const bool anyw = __any(wany != 0u) != 0;
-          if (!RAWFAST || rk_slow || !whole || anyw) rank_unit(acc[sub], cu, sub, wc[sub][0], wc[sub][1]);
-          else rank_unit_raw(acc[sub]);
+          if (!RAWFAST || rk_slow || !whole || anyw) rank_unit(sc, cu, sub, wc[sub][0], wc[sub][1]);
+          else rank_unit_raw(sc);
           // This word is read by nobody else (every (row, sub-unit) of the batch belongs to one lane pair of one
           // workgroup): clear it here instead of in a launch behind the kernel.  Rare -- a few filtered columns per
           // row --, a plain store: one more vector-memory operation in flight only makes the counted waits wait longer.
           if (anyw && ce.rk_clear_bits) {
             const bool mine_row = counts_here && fh == 0 && orow_cur < a.n;
-            unsigned int* wp = (unsigned int*)(rk_base + ((long long)(u_lo + cu) * NACC + sub) * ce.rk_bits_us * 4 + rk_off);
+            unsigned int* wp = (unsigned int*)(rk_base + ((long long)(u_lo + cu) * NT + sub) * ce.rk_bits_us * 4 + rk_off);
             if (mine_row && wc[sub][0] != 0u && ce.rk_nfilt > 0) wp[0] = 0u;
             if (mine_row && wc[sub][1] != 0u && ce.rk_nfilt > 1) wp[1] = 0u;
           }
@@ -824,7 +837,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       const int side = pair / a.chunks, ch = pair - side * a.chunks;
       // ---- this lane's row of the pair
       long long lrow;
-      if constexpr (SPLIT) lrow = (long long)ch * (8 * RW) + RW * wave + 8 * (fi >> 4) + (fi & 7);
+      if constexpr (DUP) lrow = (long long)ch * (8 * RW) + RW * wave + 8 * (fi >> 4) + (fi & 7);
       else lrow = (long long)ch * (8 * RW) + RW * wave + fi;
       const long long orow = lrow < a.n ? lrow : a.n - 1;  // padded rows repeat row n - 1 (and never write)
       orow_cur = (int)lrow;
@@ -859,44 +872,54 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       // (the sets of a side lie interleaved: one base.  No set at all: the loads read the fragments)
       if (ce.rk_nfilt > 0) rk_base = (const unsigned char*)ce.rk_bits[side][0];
       rk_off = ce.rk_nfilt > 0 ? (unsigned int)(orow * ce.rk_bits_rs * 4) : 0u;
-      // ---- fragments (groups of 128 operand rows; a chunk = two groups)
-      int grp = 2 * ch + (wave >> 2);
+      // ---- fragments: groups of 128 operand rows = four blocks of 32 (bf16_queries.hpp).  Single-pass: a group = 128
+      // real rows, a chunk = two groups, wave w takes block w & 3 of group w >> 2.  Split: a group = 64 real rows as
+      // [hi 0-31 | hi 32-63 | lo 0-31 | lo 32-63]; DUP (d = 512): a chunk = two groups, a wave's 32 operand rows = the
+      // q_hi and q_lo rows of 16 real rows; PARTS (d = 256): a chunk = FOUR groups, wave w takes the q_hi block w & 1
+      // and the q_lo block 2 + (w & 1) of group w >> 1.
+      int grp = PARTS == 2 ? 4 * ch + (wave >> 1) : 2 * ch + (wave >> 2);
       if (grp >= a.rgn1) grp = a.rgn1 - 1;
       grp += side * a.rgn1;
       const unsigned char* const gbase = (const unsigned char*)(a.qf + (long long)grp * 4 * NKB * 64);
-      unsigned int flo;
-      const unsigned char* fb;
-      int frange;
-      if constexpr (SPLIT) {
-        const int part = (fi >> 3) & 1, rr = 16 * (wave & 3) + 8 * (fi >> 4) + (fi & 7);
-        flo = (unsigned int)((((2 * part + (rr >> 5)) * NKB) * 64 + (rr & 31) + 32 * fh) * 16);
-        fb = gbase;
-        frange = 4 * NKB * 1024;
-      } else {
-        flo = (unsigned int)(lane * 16);
-        fb = gbase + (wave & 3) * (NKB * 1024);
-        frange = NKB * 1024;
-      }
-      const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, frange, 0x00020000);
-      v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
-        constexpr int kb = decltype(kc)::value;
-        afr[kb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, flo + kb * 1024, 0, 16 /* sc1 */));
+      v4_static_for<0, PARTS>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int part = decltype(pc)::value;
+        unsigned int flo;
+        const unsigned char* fb;
+        int frange;
+        if constexpr (DUP) {
+          const int pt = (fi >> 3) & 1, rr = 16 * (wave & 3) + 8 * (fi >> 4) + (fi & 7);
+          flo = (unsigned int)((((2 * pt + (rr >> 5)) * NKB) * 64 + (rr & 31) + 32 * fh) * 16);
+          fb = gbase;
+          frange = 4 * NKB * 1024;
+        } else {
+          flo = (unsigned int)(lane * 16);
+          fb = gbase + (PARTS == 2 ? 2 * part + (wave & 1) : (wave & 3)) * (NKB * 1024);
+          frange = NKB * 1024;
+        }
+        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, frange, 0x00020000);
+        v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int kb = decltype(kc)::value;
+          afr[part][kb] =
+              __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, flo + kb * 1024, 0, 16 /* sc1 */));
+        });
       });
       load_words(0, wn);  // the pair's first unit
       // fragments, words, pieces of the ring fill, the atomics of the pair before: everything of this wave has landed
-      if constexpr (NACC == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]) : : "memory");
+      if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wn[0]), "+v"(wn[1]) : : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" : "+v"(wn[0]) : : "memory");
       // The compiler does not read the wait above: without a use of the fragments HERE it puts its own
       // s_waitcnt vmcnt(NKB - 1) ... vmcnt(0) in front of their first uses -- inside the chain loop, where they ran in
       // every chain and drained the table pieces requested for the units ahead (seen in the ISA; the ring's depth
       // was one chain instead of three, the price of a table that comes from HBM).
 #pragma unroll
-      for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(afr[kb]));
+      for (int part = 0; part < PARTS; ++part)
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(afr[part][kb]));
       if (first) {
         __builtin_amdgcn_s_barrier();  // R0: units 0 .. 2 of the list have landed
         if (HALF == 0) stamp();
         v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) {
-          v4_static_for<0, NACC>([&](auto ac) __attribute__((always_inline)) {
+          v4_static_for<0, NT>([&](auto ac) __attribute__((always_inline)) {
             bread(bq[decltype(ac)::value][decltype(jc)::value], jc, ac);
           });
         });
@@ -912,7 +935,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int sub = 0; sub < NACC; ++sub)
+    for (int sub = 0; sub < NT; ++sub)
 #pragma unroll
       for (int jj = 0; jj < PF; ++jj) asm volatile("" : : "v"(bq[sub][jj]));
     if (HALF == 0 && a.dbg != nullptr && tid == 0) {  // the end of the workgroup's list and its length in units
@@ -935,7 +958,7 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   if (TG.ld * 2 >= (1LL << 28) || ((uintptr_t)qf & 15)) return KGE_ERR_UNSUPPORTED;
   const long long rgr = split ? 64 : 128;
   const long long rgn1 = (n + rgr - 1) / rgr;
-  const long long ut = d == 256 ? 2 * V8_UT : V8_UT;  // table rows per unit (the kernel's NACC sub-units of 32)
+  const long long ut = (d == 256 && !split) ? 2 * V8_UT : V8_UT;  // table rows per unit (the kernel's NT sub-units of 32)
   const long long nunits = (m + ut - 1) / ut;
   if (rgn1 > (1 << 20) || (rgn1 + 1) * nunits >= (1LL << 30)) return KGE_ERR_UNSUPPORTED;
   if (ce.rk_nfilt > 0 && n * ce.rk_bits_rs * 4 >= (1LL << 32)) return KGE_ERR_UNSUPPORTED;  // (the row's 32-bit offset)
@@ -948,7 +971,7 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   a.m = m;
   a.rgn1 = (int)rgn1;
   a.sides = 2;
-  a.chunks = (int)((rgn1 + 1) / 2);
+  a.chunks = (int)(split && d == 256 ? (rgn1 + 3) / 4 : (rgn1 + 1) / 2);  // 256 rows (d = 512 split: 128) per chunk
   a.nunits = (int)nunits;
   a.su = (int)((nunits + 7) / 8);
   a.wpx = cus / 8;
