@@ -557,6 +557,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     ++dbg_i;
   };
   stamp();
+  if (a.dbg != nullptr && tid == 0) a.dbg[(long long)blockIdx.x * 64 + 42] = wall_clock64();  // 100 MHz, real time
 
   // ---------------- the table stream ----------------
   const unsigned char* const tgb = (const unsigned char*)a.TG.base;
@@ -941,6 +942,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     if (HALF == 0 && a.dbg != nullptr && tid == 0) {  // the end of the workgroup's list and its length in units
       a.dbg[(long long)blockIdx.x * 64 + 40] = __builtin_readcyclecounter();
       a.dbg[(long long)blockIdx.x * 64 + 41] = (unsigned long long)(g1 - g0);
+      a.dbg[(long long)blockIdx.x * 64 + 43] = wall_clock64();
     }
   };
   if (wave < 4) run(std::integral_constant<int, 0>{});

@@ -73,6 +73,9 @@ def main():
                 per = [float(rel_[i + 1] - rel_[i]) for i in range(2, nst - 1)]
                 whole = ((v[:, 40] - v[:, 1]).double() / v[:, 41].double().clamp(min=1))
                 tot = (v[:, 40] - v[:, 0]).double()
+                real_us = float(v[:, 43].max() - v[:, 42].min()) / 100.0
+                print(f"    kernel by the 100 MHz real-time counter (first workgroup start -> last workgroup end): {real_us:.1f} us "
+                      f"of the {e0.elapsed_time(e1) * 1e3:.1f} us call -> shader clock {float(tot.max()) / real_us / 1e3:.2f} GHz")
                 print(f"    whole run: cycles per unit (end - R0) / units: median {float(whole.median()):.0f}  "
                       f"max {float(whole.max()):.0f}; units per workgroup {int(v[:, 41].median())}; workgroup cycles "
                       f"median {float(tot.median()):.0f} max {float(tot.max()):.0f} -> clock "
