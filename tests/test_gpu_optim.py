@@ -118,8 +118,11 @@ def test_whole_training_step_replayed_as_a_hip_graph():
     for _ in range(k):
         graph.replay()
     torch.cuda.synchronize()
+    # (the same kernels on the same inputs: what differs between a replay and the eager launches is the order of the
+    # float atomics that scatter the query rows' gradients -- a few 1e-7 after k steps; one element in 2,816 was seen
+    # at 4e-7)
     for a, b in zip(m_e.parameters(), m_g.parameters()):
-        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(a.detach(), b.detach(), rtol=1e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("weight_decay", [0.0, 1e-3])
