@@ -100,3 +100,24 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1"],
                {"KGE_BENCH_DEVICE_CHECK": "1", "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+
+
+def test_bench_traffic_comes_from_the_committed_counter_passes():
+    """bench.py cannot collect PMC counters itself: `roofline.traffic` is read from profiles/pmc_latest.json, the
+    summary of the committed rocprofv3 --pmc passes over the SAME group launch (tools/gpu_r4prof.sh) -- per query mode,
+    and only for the group size the passes were taken at."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    d = json.load(open(os.path.join(root, "profiles", "pmc_latest.json")))
+    g = d["group"]
+    alg = g * bench.algorithmic_bytes(512, bench.E_FB, bench.DIM, sides=2)
+    assert d["algorithmic_bytes_per_launch"] == alg
+    for mode in ("parity", "training"):
+        t = bench.pmc_traffic(mode, g)
+        assert t == d[mode]["hbm_bytes_per_launch"] and 0.5 * alg < t < 1.5 * alg
+        assert abs(d[mode]["fetch_bytes_corrected"] + d[mode]["write_bytes"] - t) < 1.0
+        assert bench.pmc_traffic(mode, g + 1) is None     # another group size: no figure rather than a wrong one
+    assert os.path.exists(os.path.join(root, d["source"]))
