@@ -727,6 +727,15 @@ int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, co
       !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY)) &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
+    if (one_call_prepared(t, TG, n, m, workspace_bytes, true)) {
+      // as in kge_score_sp_po: the query build from the dense rows as a launch of its own, then the direct-store kernel
+      // on prepared queries (the per-rank scoring launch of the sharded step at d = 512: 44 -> ~25 us)
+      const int rcp = run_pairs_bf16_v4_prepared(t->scorer, false, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st,
+                                                 nullptr, nullptr, workspace, workspace_bytes,
+                                                 (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr, nullptr,
+                                                 0, nullptr);
+      if (rcp != KGE_ERR_UNSUPPORTED) return rcp;
+    }
     const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr,
                                       workspace, workspace_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
     if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;
