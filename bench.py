@@ -515,9 +515,13 @@ def main_sharded(a, world, rank, device):
                 engine.score_emb("complex", s_rows, rel_rows, sh.ent_local, "sp_", pad_pitch=True)
                 engine.score_emb("complex", sh.ent_local, rel_rows, o_rows, "_po", pad_pitch=True)
             else:
-                engine.score_emb_sp_po("complex", s_rows, rel_rows, o_rows, sh.ent_local)
-        k_ms = event_avg_ms(score_only, max(5, a.steps // 4))
-        x_ms = event_avg_ms(lambda: sh.exchange_rows([s, o], p), max(5, a.steps // 4))
+                engine.score_emb_sp_po("complex", s_rows, rel_rows, o_rows, sh.ent_local, pad_pitch=True)
+        # (at least 40 launches after two untimed ones, median of three regions: five launches right behind a
+        # synchronize measured the first launch's wake-up, 41 us for a 23 us launch)
+        for _ in range(2):
+            score_only()
+        k_ms = event_avg_ms(score_only, max(40, a.steps), repeats=3)
+        x_ms = event_avg_ms(lambda: sh.exchange_rows([s, o], p), max(20, a.steps), repeats=3)
         m = sh.hi - sh.lo
         # one 1vsAll TRAINING step on the same shard shapes (kge_amd.sharded_train.ShardedTrainingJob1vsAll: fused score
         # + loss per shard, statistics exchanged, backward, this rank's Adagrad step, tables re-cast): the job-level

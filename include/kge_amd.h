@@ -273,6 +273,13 @@ int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, co
                         int64_t p_ld, const void* o_emb, int64_t o_ld, int64_t n,
                         const void* tgt_emb, int64_t tgt_ld, int64_t m, float* out, int64_t ldo,
                         void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with the _po block `block2_offset` (>= m) floats behind the sp_ block of a row instead of right behind it
+ * (ldo >= block2_offset + m): with both blocks on whole 256-byte lines -- block2_offset = a padded pitch, ldo twice
+ * that -- the direct-store kernel takes its aligned store path (the per-rank launch of the sharded step). */
+int kge_score_emb_sp_po_blocks(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb,
+                               int64_t p_ld, const void* o_emb, int64_t o_ld, int64_t n,
+                               const void* tgt_emb, int64_t tgt_ld, int64_t m, float* out, int64_t ldo,
+                               int64_t block2_offset, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- ranking ------------------------------------------------------------ */
 /* For each row i of scores[n, c] (leading dim lds) and its true score:

@@ -91,6 +91,8 @@ PROTOTYPES = {
                                       ctypes.POINTER(KgeIndex), ctypes.c_int, c_i64, c_vp, c_i64, c_vp]),
     "kge_score_emb_sp_po": (ctypes.c_int, [_PT, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
                                            c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kge_score_emb_sp_po_blocks": (ctypes.c_int, [_PT, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64,
+                                           c_vp, c_i64, c_i64, c_vp, c_i64, c_vp]),
     "kge_rank_counts": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
                                        ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp]),
     "kge_filter_lookup": (ctypes.c_int, [c_vp, c_i64, c_vp, KgeIndex, KgeIndex, c_i64, c_i64, c_vp, c_vp, c_vp]),

@@ -278,11 +278,12 @@ int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand
 // the q_hi / q_lo fragments.  KGE_ERR_UNSUPPORTED: the caller goes side by side through pairs_dispatch (split again,
 // or the exact f32 chain).
 int split_sp_po(const kge_tables* t, const Operand& S, const Operand& O, const Operand& P, const Operand& TG, int64_t n,
-                int64_t m, float* out, int64_t ldo, void* ws, int64_t ws_bytes, hipStream_t st) {
+                int64_t m, float* out, int64_t ldo, void* ws, int64_t ws_bytes, hipStream_t st, int64_t b2 = -1) {
+  if (b2 < 0) b2 = m;  // the _po block right behind the sp_ block
   if (t->dtype != KGE_BF16 || !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
       !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
     return KGE_ERR_UNSUPPORTED;
-  return run_pairs_bf16_v4_prepared(t->scorer, true, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr,
+  return run_pairs_bf16_v4_prepared(t->scorer, true, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, b2, st, nullptr,
                                     nullptr, ws, ws_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr,
                                     nullptr, nullptr, 0, nullptr);
 }
@@ -706,21 +707,30 @@ int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s
 int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb, int64_t p_ld,
                         const void* o_emb, int64_t o_ld, int64_t n, const void* tgt_emb, int64_t tgt_ld, int64_t m,
                         float* out, int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream) {
+  return kge_score_emb_sp_po_blocks(t, s_emb, s_ld, p_emb, p_ld, o_emb, o_ld, n, tgt_emb, tgt_ld, m, out, ldo, m, workspace,
+                                    workspace_bytes, stream);
+}
+
+int kge_score_emb_sp_po_blocks(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb, int64_t p_ld,
+                               const void* o_emb, int64_t o_ld, int64_t n, const void* tgt_emb, int64_t tgt_ld, int64_t m,
+                               float* out, int64_t ldo, int64_t block2_offset, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
   int rc = check_tables(t, false);
   if (rc) return rc;
   if (!s_emb || !p_emb || !o_emb || !tgt_emb || n < 0 || m < 0) return KGE_ERR_INVALID_ARG;
   if (s_ld < t->dim || o_ld < t->dim || tgt_ld < t->dim || p_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
-  if ((!out && n * m > 0) || ldo < 2 * m) return KGE_ERR_INVALID_ARG;
+  const int64_t b2 = block2_offset;
+  if ((!out && n * m > 0) || b2 < m || ldo < b2 + m) return KGE_ERR_INVALID_ARG;
   const Index ident{nullptr, 1, KGE_I64};
   Operand S{s_emb, s_ld, ident}, P{p_emb, p_ld, ident}, O{o_emb, o_ld, ident}, TG{tgt_emb, tgt_ld, ident};
   hipStream_t st = (hipStream_t)stream;
   if (n > 0 && m > 0 && v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
       pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
-    const int rc5 = run_pairs_bf16_v5(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr);
+    const int rc5 = run_pairs_bf16_v5(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, b2, st, nullptr);
     if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
   }
   if (workspace && n > 0 && m > 0 && (t->flags & KGE_FLAG_SPLIT_QUERY) && !(t->flags & KGE_FLAG_EXACT)) {
-    const int rcs = split_sp_po(t, S, O, P, TG, n, m, out, ldo, workspace, workspace_bytes, st);
+    const int rcs = split_sp_po(t, S, O, P, TG, n, m, out, ldo, workspace, workspace_bytes, st, b2);
     if (rcs != KGE_ERR_UNSUPPORTED) return rcs;
   }
   if (workspace && n > 0 && m > 0 &&
@@ -730,19 +740,19 @@ int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, co
     if (one_call_prepared(t, TG, n, m, workspace_bytes, true)) {
       // as in kge_score_sp_po: the query build from the dense rows as a launch of its own, then the direct-store kernel
       // on prepared queries (the per-rank scoring launch of the sharded step at d = 512: 44 -> ~25 us)
-      const int rcp = run_pairs_bf16_v4_prepared(t->scorer, false, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st,
+      const int rcp = run_pairs_bf16_v4_prepared(t->scorer, false, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, b2, st,
                                                  nullptr, nullptr, workspace, workspace_bytes,
                                                  (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr, nullptr,
                                                  0, nullptr);
       if (rcp != KGE_ERR_UNSUPPORTED) return rcp;
     }
-    const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m, st, nullptr,
+    const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, b2, st, nullptr,
                                       workspace, workspace_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
     if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;
   }
   rc = pairs_dispatch(t, KGE_SP_, S, P, TG, n, m, out, ldo, workspace, workspace_bytes, st);
   if (rc) return rc;
-  return pairs_dispatch(t, KGE_PO_, O, P, TG, n, m, out ? out + m : out, ldo, workspace, workspace_bytes, st);
+  return pairs_dispatch(t, KGE_PO_, O, P, TG, n, m, out ? out + b2 : out, ldo, workspace, workspace_bytes, st);
 }
 
 int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,

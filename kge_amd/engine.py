@@ -24,6 +24,9 @@ __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_
            "FLAG_SPLIT_QUERY", "reserve_cus", "Queries", "build_queries", "score_queries", "ScorePipeline"]
 
 
+PADDED_BLOCKS = True  # score_emb_sp_po(pad_pitch=True) exists (kge_amd.sharded asks its backend)
+
+
 def reserve_cus(n: int) -> int:
     """flags value: leave `n` compute units free for kernels on other streams (KGE_FLAG_RESERVE_CUS)."""
     return (int(n) & 255) << 8
@@ -713,9 +716,12 @@ def score_emb(scorer, s_emb, p_emb, o_emb, combine: str, l_norm: float = 1.0, fl
     return out[:, :m] if out.shape[1] != m else out
 
 
-def score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm: float = 1.0, flags: int = 0, out=None):
+def score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm: float = 1.0, flags: int = 0, out=None,
+                    pad_pitch: bool = False):
     """[n, 2m]: score_emb(.., "sp_") against `targets` followed by score_emb(.., "_po") against
-    `targets`, for dense query rows (one two-sided launch on the bf16 matrix-core path)."""
+    `targets`, for dense query rows (one two-sided launch on the bf16 matrix-core path).
+    pad_pitch=True (no `out`): the two blocks as the [n, 2, m] view of an [n, 2, score_pitch(m)] buffer -- both on whole
+    256-byte lines, the layout the direct-store kernel writes fastest (kge_score_emb_sp_po_blocks)."""
     for x in (s_emb, p_emb, o_emb, targets):
         _require_gpu(x, "embedding")
     if len({s_emb.dtype, p_emb.dtype, o_emb.dtype, targets.dtype}) != 1:
@@ -724,8 +730,13 @@ def score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm: float = 1.0, f
     sc = SCORERS[scorer] if isinstance(scorer, str) else int(scorer)
     n, m = p_emb.shape[0], targets.shape[0]
     d, dr = s_emb.shape[1], p_emb.shape[1]
+    b2 = m
     if out is None:
-        out = _empty((n, 2 * m), s_emb.device)
+        if pad_pitch and m > 0:
+            b2 = score_pitch(m)
+            out = _empty((n, 2 * b2), s_emb.device)
+        else:
+            out = _empty((n, 2 * m), s_emb.device)
     key = (s_emb.dtype, sc, d, dr, float(l_norm), int(flags))
     tc = _EMB_TC.get(key)
     if tc is None:
@@ -734,13 +745,13 @@ def score_emb_sp_po(scorer, s_emb, p_emb, o_emb, targets, l_norm: float = 1.0, f
     with _on_device(s_emb.device):
         st = _stream_handle(s_emb.device)
         ws, wsb = _workspace(tc, n, s_emb.device, True, st)
-        rc = _lib.lib().kge_score_emb_sp_po(
+        rc = _lib.lib().kge_score_emb_sp_po_blocks(
             ctypes.byref(tc), s_emb.data_ptr(), s_emb.stride(0), p_emb.data_ptr(), p_emb.stride(0),
             o_emb.data_ptr(), o_emb.stride(0), n, targets.data_ptr(), targets.stride(0), m, out.data_ptr(),
-            out.stride(0) if n > 1 else max(2 * m, 1), ws, wsb, st)
+            out.stride(0) if n > 1 else max(2 * b2, 1), b2, ws, wsb, st)
         if rc:
-            _lib.check(rc, "kge_score_emb_sp_po")
-    return out
+            _lib.check(rc, "kge_score_emb_sp_po_blocks")
+    return out.view(n, 2, b2)[:, :, :m] if b2 != m else out
 
 
 def embed(t: Tables, ent_idx=None, rel_idx=None, ent_out=None, rel_out=None):

@@ -361,6 +361,11 @@ class ShardedEntityTable:
         s_rows, o_rows = rows[:n], rows[n:]
         big = n * m * 4 > self.BIG_SLAB_BYTES
         if hasattr(self.backend, "score_emb_sp_po") and not big:
+            if getattr(self.backend, "PADDED_BLOCKS", False):
+                # the engine: both blocks on whole 256-byte lines (the direct-store kernel's aligned path)
+                both = self.backend.score_emb_sp_po(self.scorer, s_rows, rel_rows, o_rows, self.ent_local, self.l_norm,
+                                                    pad_pitch=True)
+                return (both[:, 0], both[:, 1]) if both.dim() == 3 else (both[:, :m], both[:, m:])
             both = self.backend.score_emb_sp_po(self.scorer, s_rows, rel_rows, o_rows, self.ent_local, self.l_norm)
             return both[:, :m], both[:, m:]
         kw = {"pad_pitch": True} if big else {}
