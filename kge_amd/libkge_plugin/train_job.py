@@ -90,8 +90,11 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
                 def step_or_skip(*a, **k):
                     if job._skip_optimizer_step:
                         job._skip_optimizer_step = False
+                        opt._opt_called = True  # (what a learning-rate scheduler's wrapper of step() records)
                         return None
                     return real_step(*a, **k)
+                if hasattr(real_step, "_wrapped_by_lr_sched"):  # torch's schedulers look for their mark on step()
+                    step_or_skip._wrapped_by_lr_sched = True
                 opt.step = step_or_skip
                 self._graph_step = GraphedStep(
                     lambda s, p, o, inv: self.model.loss_sp_po(s, p, o).sum() * inv, _Opt, warmup=2)
