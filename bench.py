@@ -581,7 +581,9 @@ def main_sharded(a, world, rank, device):
             },
             "rccl_ranks": td.get_world_size(),
             "roofline": {"bound": "hbm", "kernel": "the scoring launch(es) of one step on this rank's shard after the "
-                                                   "exchange (kge_score_emb_sp_po_blocks: query build on the exchanged rows + pairs_bf16_v7_kernel on the prepared fragments, two-sided, both blocks on 256-byte lines; "
+                                                   "exchange (kge_score_emb_sp_po_blocks: query build on the exchanged rows + "
+                                                   "pairs_bf16_v7_kernel on the prepared fragments, two-sided, both blocks on "
+                                                   "256-byte lines; "
                                                    "slabs beyond the Infinity Cache: one one-sided launch per direction)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"],
