@@ -383,3 +383,56 @@ def test_persistent_kernel_on_single_batches(eng, E, n, split, monkeypatch):
                 assert int((~torch.isnan(big)).sum()) == n * sides * E, (combine, pitched, v8)
             _same(got["1"], got["0"], f"{combine} pitched={pitched} E={E} n={n} split={split}")
     monkeypatch.delenv("KGE_V8")
+
+
+@pytest.mark.parametrize("scorer,E,d,n,split", [
+    ("complex", 14541, 512, 512, False),   # query build launch + direct-store kernel (the sharded step's launch)
+    ("distmult", 14541, 512, 200, False),
+    ("complex", 14541, 512, 300, True),    # split queries through the same block offsets
+    ("complex", 3000, 256, 130, False),    # the loader / consumer kernel
+    ("distmult", 777, 128, 70, False),
+    ("transe", 1000, 128, 70, False),      # float32 tables: one exact launch per direction
+])
+def test_dense_row_entry_with_both_blocks_on_whole_lines(eng, scorer, E, d, n, split):
+    """kge_score_emb_sp_po_blocks (engine.score_emb_sp_po(pad_pitch=True)): dense query rows against dense target rows,
+    the po block starting a padded pitch into each row -- the bits of the index-level entry and of the contiguous
+    [n, 2m] layout, nothing written between or behind the blocks."""
+    R = 11
+    flags = eng.FLAG_SPLIT_QUERY if split else 0
+    if scorer == "transe":
+        g = torch.Generator().manual_seed(21)
+        ent, rel = torch.randn(E, d, generator=g) * 0.3, torch.randn(R, d, generator=g) * 0.3
+        T = eng.Tables(scorer, ent.to(DEV), rel.to(DEV))
+    else:
+        T, ent, rel = _tables(eng, scorer, E, R, d, 21, flags)
+    s, p, o = _batch(E, R, n, 22)
+    want = eng.score_sp_po(T, s, p, o)
+    s_rows, p_rows, o_rows = T.ent[s].contiguous(), T.rel[p].contiguous(), T.ent[o].contiguous()
+    flat = eng.score_emb_sp_po(scorer, s_rows, p_rows, o_rows, T.ent, flags=flags)
+    _same(flat, want, "contiguous blocks")
+    P = eng.score_pitch(E)
+    got = eng.score_emb_sp_po(scorer, s_rows, p_rows, o_rows, T.ent, flags=flags, pad_pitch=True)
+    assert tuple(got.shape) == (n, 2, E) and got.stride() == (2 * P, P, 1)
+    _same(got[:, 0], want[:, :E], "sp block on its own lines")
+    _same(got[:, 1], want[:, E:], "po block on its own lines")
+    # the same launch into a caller's buffer through the C entry: the pads keep their canaries
+    import ctypes
+    from kge_amd import _lib
+    buf = torch.full((n, 2 * P + 64), float("nan"), device=DEV)
+    tc = eng.KgeTables(None, None, eng._dtype_code(s_rows), eng.SCORERS[scorer], 0, 0, d, d, d, d, 1.0, flags)
+    ws, wsb = eng._workspace(tc, n, s_rows.device, True, eng._stream_handle(s_rows.device))
+    rc = _lib.lib().kge_score_emb_sp_po_blocks(
+        ctypes.byref(tc), s_rows.data_ptr(), s_rows.stride(0), p_rows.data_ptr(), p_rows.stride(0), o_rows.data_ptr(),
+        o_rows.stride(0), n, T.ent.data_ptr(), T.ent.stride(0), E, buf.data_ptr(), buf.stride(0), P, ws, wsb,
+        eng._stream_handle(s_rows.device))
+    assert rc == 0
+    torch.cuda.synchronize()
+    _same(buf[:, :E], want[:, :E], "sp block in the caller's buffer")
+    _same(buf[:, P:P + E], want[:, E:], "po block in the caller's buffer")
+    assert bool(torch.isnan(buf[:, E:P]).all()) and bool(torch.isnan(buf[:, P + E:]).all())
+    # a second block that would overlap the first is refused (KGE_ERR_INVALID_ARG), so is a row too short for it
+    for b2, ldo in ((E - 1, buf.stride(0)), (P, P + E - 1)):
+        assert _lib.lib().kge_score_emb_sp_po_blocks(
+            ctypes.byref(tc), s_rows.data_ptr(), s_rows.stride(0), p_rows.data_ptr(), p_rows.stride(0),
+            o_rows.data_ptr(), o_rows.stride(0), n, T.ent.data_ptr(), T.ent.stride(0), E, buf.data_ptr(), ldo, b2, ws,
+            wsb, eng._stream_handle(s_rows.device)) == -1
