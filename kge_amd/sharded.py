@@ -351,17 +351,18 @@ class ShardedEntityTable:
     # written: rows are then 128-byte aligned (padded pitch) and each direction gets its own launch
     BIG_SLAB_BYTES = 96 << 20
 
-    def score_sp_po_blocks(self, s: torch.Tensor, p: torch.Tensor, o: torch.Tensor):
+    def score_sp_po_blocks(self, s: torch.Tensor, p: torch.Tensor, o: torch.Tensor, padded: bool = True):
         """(score_sp slab, score_po slab), each [n, E_g] (row pitch >= E_g): ONE exchange for the s
         and the o rows, then one two-sided launch on the shard (backends with score_emb_sp_po; the
-        blocks are the halves of its [n, 2 E_g] output) or, for slabs that outgrow the Infinity Cache,
-        one launch per direction into matrices with a 128-byte-aligned row pitch."""
+        blocks are the halves of its [n, 2 E_g] output, or -- padded, the engine -- each on whole 256-byte
+        lines) or, for slabs that outgrow the Infinity Cache, one launch per direction into matrices with
+        a 128-byte-aligned row pitch."""
         n, m = s.numel(), self.hi - self.lo
         rows, rel_rows = self.exchange_rows([s, o], p)
         s_rows, o_rows = rows[:n], rows[n:]
         big = n * m * 4 > self.BIG_SLAB_BYTES
         if hasattr(self.backend, "score_emb_sp_po") and not big:
-            if getattr(self.backend, "PADDED_BLOCKS", False):
+            if padded and getattr(self.backend, "PADDED_BLOCKS", False):
                 # the engine: both blocks on whole 256-byte lines (the direct-store kernel's aligned path)
                 both = self.backend.score_emb_sp_po(self.scorer, s_rows, rel_rows, o_rows, self.ent_local, self.l_norm,
                                                     pad_pitch=True)
@@ -374,7 +375,7 @@ class ShardedEntityTable:
 
     def score_sp_po(self, s: torch.Tensor, p: torch.Tensor, o: torch.Tensor):
         """[n, 2 E_g]: the two slabs of score_sp_po_blocks side by side (KgeModel.score_sp_po's layout)."""
-        sp, po = self.score_sp_po_blocks(s, p, o)
+        sp, po = self.score_sp_po_blocks(s, p, o, padded=False)  # (contiguous halves: the view below, no copy)
         if sp.data_ptr() + sp.shape[1] * 4 == po.data_ptr() and sp.stride(0) == 2 * sp.shape[1]:
             return torch.as_strided(sp, (sp.shape[0], 2 * sp.shape[1]), (sp.stride(0), 1))
         return torch.cat([sp, po], dim=1)
