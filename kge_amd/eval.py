@@ -18,7 +18,7 @@ Rankings follow the reference: "_raw", "_filt" (filter_splits + the eval split) 
 filter_with_test, "_filt_test" (additionally the test split).  Because the reference
 applies the filters cumulatively (:305-307), "_filt_test" filters with the union.
 """
-from typing import Dict, List, Optional
+from typing import Dict, List
 
 import os
 

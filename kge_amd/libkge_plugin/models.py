@@ -8,8 +8,8 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import (BF16Shadow, _FusedBCE, _FusedCE, _FusedCE2, _FusedKL, _ScoreEmb, _ScoreNeg, _ScorePairs,
-                     _ScoreSPO, bce_fused, ce_fused_dropout, kl_fused)
+from ..model import (BF16Shadow, _FusedCE, _FusedCE2, _ScoreEmb, _ScoreNeg, _ScorePairs, _ScoreSPO, bce_fused,
+                     ce_fused_dropout, kl_fused)
 
 
 class _HipScorer(RelationalScorer):

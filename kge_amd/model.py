@@ -16,7 +16,6 @@ import torch
 from torch import Tensor
 
 from . import engine
-from ._lib import SCORERS
 
 
 class LookupEmbedder(torch.nn.Module):

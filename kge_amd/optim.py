@@ -8,8 +8,6 @@ not cover (CPU tensors, non-float32, sparse gradients) are stepped by torch's ow
 Adagrad.  kge/util/optimizer.py:15-20 resolves `train.optimizer.default.type` with
 `getattr(torch.optim, ...)`; the LibKGE plugin registers this class there as `HipAdagrad`.
 """
-import ctypes
-
 import torch
 from torch.optim.adagrad import Adagrad as _TorchAdagrad
 from torch.optim.adagrad import adagrad as _functional_adagrad

@@ -36,7 +36,6 @@ How the work is split (BASELINE configs[3] / [4]):
 
 Not overlapped: the row exchange of batch k + 1 with the scoring of batch k.
 """
-import math
 from typing import Optional
 
 import torch

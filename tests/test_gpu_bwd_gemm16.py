@@ -5,7 +5,6 @@ the checker: `lib=1`).  Random (transpose-detecting) operands; ragged shapes on 
 multiple of the 128-row tile or the 64-step, m not a multiple of 8 / 64 / 128, G16 pitch > m."""
 import ctypes
 
-import numpy as np
 import pytest
 import torch
 

@@ -5,7 +5,6 @@ offset, BCEWithLogitsLoss elements, `bce_mean`'s positive / negative averaging, 
 2e-6 relative, gradient within 1e-6 + 1e-5 relative."""
 import pytest
 import torch
-import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

@@ -6,7 +6,6 @@ scoring copies against the reference's step in float32 torch ops on the same bf1
 Bar: mixed precision -- scores from bf16 tables with a bf16-rounded query vector, d loss / d score rounded to bf16 for
 the gradient products: losses within 2e-3 relative, parameters after three steps within 2e-3 of the
 step size."""
-import numpy as np
 import pytest
 import torch
 

@@ -1,5 +1,5 @@
 """bench.py's eval_leg with 1 and 2 captured lanes (KGE_EVAL_LANES): ms per batch of a whole evaluation pass."""
-import json, os, sys
+import os, sys
 import torch
 sys.path.insert(0, ".")
 import bench
