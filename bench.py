@@ -57,6 +57,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--group", type=int, default=8,
                     help="N = 1: batches per persistent launch (kge_score_queries_multi); 1 = one launch per batch")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="N = 1: group launches in flight (group k on HIP stream k %% lanes).  2 pays in sustained issue "
+                         "(16 launches per region: 148 -> 131 us per single-pass group launch, 236 -> 216 us split, "
+                         "tools/group_lanes_probe.py) and not in a region of 20 steps = 3 launches (16.8 against 15.5 us "
+                         "per step: fork / join and two lanes' groups contending for the same write path), hence 1")
     ap.add_argument("--streams", type=int, default=None,
                     help="N > 1: batches in flight in the sharded step (batch k's exchange and scoring on HIP stream "
                          "k %% streams; default: 2 with the step as a hipGraph where that has checked out, else 1)")
@@ -708,67 +713,129 @@ def main():
     # = KgeModel.score_sp_po of that batch (both score blocks); K steps = K batches in ceil(K / group) launches (a
     # remainder of K % group batches goes as one smaller group), all of a step's work inside the timed region.
     # Score rows on a 256-byte pitch (the C ABI's `ldo`; engine.score_pitch), the po block on a column of its own.
+    # `--lanes` L > 1 (default 1, see its help): group k is issued on HIP stream k % L (each lane its own query fragments
+    # and score buffer; a lane's launch builds the queries of THAT lane's next group), so the next persistent launch
+    # moves into the compute units the one before is leaving -- its tail, the drain of its stores, the cold start.  The
+    # results of a region belong to the caller after the join at its end, as with engine.ScorePipeline(streams=2).
+    # `roofline` stays on ONE stream's back-to-back launches (the kernel's own duration); `timed_region` is the
+    # chip-level rate.
     class Mode:
-        def __init__(self, flags, tag):
+        def __init__(self, flags, tag, lanes):
             self.tag, self.flags = tag, flags
             self.T = engine.Tables("complex", ent, rel, flags=flags or 0)
             self.by_size = {}
+            self.lanes = max(1, int(lanes))
+            self.streams = [torch.cuda.Stream(device=device) for _ in range(self.lanes)] if self.lanes > 1 else None
+            self.last = None  # (group size, lane) of the last launch
 
         def group(self, g):
             st = self.by_size.get(g)
             if st is None:
                 q = torch.Generator().manual_seed(100 + g)
-                tri = [torch.stack([torch.randint(hi, (n * g,), generator=q) for hi in (E_FB, R_FB, E_FB)], 1).to(device)
-                       for _ in range(2)]
-                qs = [engine.QueriesGroup(self.T, "sp_po", n, g, flags=self.flags) for _ in range(2)]
-                engine.build_queries_group(self.T, "sp_po", tri[0], n, g, out=qs[0])
-                buf = torch.empty(g, n, 2 * PITCH, device=device)
-                st = self.by_size[g] = {"tri": tri, "qs": qs, "buf": buf, "out": buf.view(g, n, 2, PITCH)[:, :, :, :E_FB],
-                                        "cur": 0}
+                st = self.by_size[g] = []
+                for _ in range(self.lanes):
+                    tri = [torch.stack([torch.randint(hi, (n * g,), generator=q) for hi in (E_FB, R_FB, E_FB)], 1).to(device)
+                           for _ in range(2)]
+                    qs = [engine.QueriesGroup(self.T, "sp_po", n, g, flags=self.flags) for _ in range(2)]
+                    engine.build_queries_group(self.T, "sp_po", tri[0], n, g, out=qs[0])
+                    buf = torch.empty(g, n, 2 * PITCH, device=device)
+                    st.append({"tri": tri, "qs": qs, "buf": buf, "out": buf.view(g, n, 2, PITCH)[:, :, :, :E_FB], "cur": 0})
+                torch.cuda.synchronize()  # (built on the current stream, used on the lanes' streams)
             return st
 
-        def launch(self, g):
-            st = self.group(g)
+        def launch(self, g, lane=0, on_lane=False):
+            """One group launch from lane `lane`'s buffers, on that lane's stream (on_lane) or on the current stream."""
+            st = self.group(g)[lane]
             c = st["cur"]
             engine.score_queries_group(self.T, st["qs"][c], st["out"], next_batch=st["tri"][1 - c],
-                                       next_queries=st["qs"][1 - c])
+                                       next_queries=st["qs"][1 - c],
+                                       stream=self.streams[lane].cuda_stream if on_lane and self.streams else None)
             st["cur"] = 1 - c
+            self.last = (g, lane)
 
         def run_steps(self, k):
+            if self.streams is None:
+                while k > 0:
+                    g = min(L, k)
+                    self.launch(g)
+                    k -= g
+                return
+            for g in {L, k % L} - {0}:
+                self.group(g)
+            cur = torch.cuda.current_stream(device)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            for stm in self.streams:  # fork: the lanes wait for what the current stream has issued
+                stm.wait_event(ev)
+            i = 0
             while k > 0:
                 g = min(L, k)
-                self.launch(g)
+                self.launch(g, i % self.lanes, on_lane=True)
+                i += 1
                 k -= g
+            for stm in self.streams:  # join: the current stream waits for every lane
+                ev = torch.cuda.Event()
+                ev.record(stm)
+                cur.wait_event(ev)
 
         def check(self):
-            """The last full group, bit for bit against one launch per batch on the round-3 kernels."""
-            st = self.group(L)
+            """The last group launched, bit for bit against one launch per batch on the round-3 kernels."""
+            g, lane = self.last
+            st = self.group(g)[lane]
             c = 1 - st["cur"]  # the queries the last launch scored
             tri = st["tri"][c]
             torch.cuda.synchronize()
-            for l in (0, L - 1):
+            for l in (0, g - 1):
                 t = tri[l * n:(l + 1) * n]
                 want = engine.score_queries(self.T, engine.build_queries(self.T, "sp_po", t[:, 0], t[:, 1], t[:, 2],
                                                                          flags=self.flags))
                 if not torch.equal(st["out"][l].reshape(n, 2 * E_FB), want):
-                    raise SystemExit(f"bench: batch {l} of the {self.tag} group launch differs from the single launch")
+                    return f"batch {l} of the {self.tag} group launch (lane {lane}) differs from the single launch"
+            return None
 
     # `value`: the PARITY-COMPLIANT mode -- split queries (KGE_FLAG_SPLIT_QUERY: q = q_hi + q_lo, f32-level parity on the
     # bf16 tables: ranks equal to float32 arithmetic's up to its own summation noise, tests/test_gpu_bshape_ranks.py).
     # The single-pass mode (query vector rounded to ONE bf16: training tolerance, 4 % of the ranks move against that
     # bar) is timed the same way and reported beside it.
-    modes = {"parity": Mode(engine.FLAG_SPLIT_QUERY, "split-query"), "training": Mode(None, "single-pass")}
-    res = {}
-    for key, md in modes.items():
+    def measure(flags, tag, lanes):
+        md = Mode(flags, tag, lanes)
         md.run_steps(a.warmup)
         md.run_steps(L)
         el, regions, host_el = timed_regions(md.run_steps, torch.cuda.synchronize, a.steps, a.repeats)
-        md.run_steps(L)
-        md.check()
-        # the dominant kernel: HIP events on the launch stream around back-to-back full-group launches
+        bad = None
+        md.run_steps(L * md.lanes)  # one full group per lane, in flight together: every lane's scores are checked
+        for lane in range(md.lanes):
+            md.last = (L, lane)
+            bad = bad or md.check()
+        if bad:
+            return md, None, bad
+        # the dominant kernel: HIP events on the launch stream around back-to-back full-group launches of ONE stream
         launches = max(3, (max(a.steps, 40) + L - 1) // L)
         k_ms = event_avg_ms(lambda: md.launch(L), launches, a.repeats)
-        res[key] = {"el": el, "regions": regions, "host": host_el, "launch_ms": k_ms}
+        return md, {"el": el, "regions": regions, "host": host_el, "launch_ms": k_ms, "lanes": md.lanes}, None
+
+    modes, res = {}, {}
+    for key, flags, tag in (("parity", engine.FLAG_SPLIT_QUERY, "split-query"), ("training", None, "single-pass")):
+        r = why = None
+        if a.lanes > 1:
+            try:
+                md, r, why = measure(flags, tag, a.lanes)
+            except Exception as exc:  # lanes are an optimisation of the issue order: never lose the line to them
+                why = f"{type(exc).__name__}: {exc}"
+                torch.cuda.synchronize()
+            if r is None:
+                print(f"bench: {tag}: {a.lanes} lanes failed ({why}); one lane", file=sys.stderr)
+        if r is None:
+            md, r, why = measure(flags, tag, 1)
+            if r is None:
+                raise SystemExit(f"bench: {why}")
+        modes[key], res[key] = md, r
+    if os.environ.get("KGE_BENCH_MAIN_ONLY") == "1":  # a quick check of the timed region alone
+        total = 2.0 * n * E_FB * a.steps
+        print(json.dumps({k: {"value": total / v["el"], "us_per_step": v["el"] / a.steps * 1e6, "lanes": v["lanes"],
+                              "launch_us": v["launch_ms"] * 1e3, "host_us_per_step": v["host"] / a.steps * 1e6}
+                          for k, v in res.items()}))
+        return
 
     def roofline_of(key, kernel):
         r = res[key]
@@ -940,8 +1007,10 @@ def main():
             "workload": "FB15k-237 shape ComplEx d=512 1vsAll scoring, bf16 tables, f32 scores: the score_sp and "
                         "score_po blocks of a batch per step (KgeModel.score_sp_po), batches issued in groups of "
                         "`group` -- one persistent launch per group (kge_score_queries_multi), which also builds the "
-                        "next group's query vectors; score rows on a 256-byte pitch",
+                        "next group's query vectors; group k on HIP stream k % `group_launches_in_flight`; score rows "
+                        "on a 256-byte pitch",
             "num_entities_per_gpu": E_FB, "num_relations": R_FB, "dim": DIM, "batch": n, "group": L,
+            "group_launches_in_flight": rp["lanes"],
             "parallelism": "single GPU", "queries": "split (q_hi + q_lo)",
         },
         "roofline": {**roofline_of("parity", "pairs_bf16_v8_kernel<ComplEx, SPLIT> (kge_score_queries_multi: one "
@@ -955,7 +1024,7 @@ def main():
         "training_tolerance": {
             "value": total / rt["el"], "unit": "scored triples/s", "ms_per_step": rt["el"] / a.steps * 1e3,
             "regions_ms_per_step": [r / a.steps * 1e3 for r in rt["regions"]],
-            "host_issue_ms_per_step": rt["host"] / a.steps * 1e3,
+            "host_issue_ms_per_step": rt["host"] / a.steps * 1e3, "group_launches_in_flight": rt["lanes"],
             "roofline": {**roofline_of("training", "pairs_bf16_v8_kernel<ComplEx> (kge_score_queries_multi: one "
                                                    "persistent launch = `group` two-sided batches, single-pass queries)"),
                          "traffic": pmc_traffic("training", L),
