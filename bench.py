@@ -590,12 +590,12 @@ def main_sharded(a, world, rank, device):
             "scaling_note": ("strong scaling of the Wikidata5M shape (north_star: 'near-linear triples/s to 8 GPUs on "
                              "Wikidata5M-scale entity shards'): the one-GPU point of THIS curve is the whole table on one "
                              "rank -- `KGE_BENCH_FORCE_DIST=1` under torch.distributed.run with one process "
-                             "(profiles/r4_bench_dist1rank.json: 9.6e11 scored triples/s, 4.90 ms per step) -- not the "
+                             "(profiles/r4_bench_dist1rank.json: 9.1-9.6e11 scored triples/s, 4.9-5.2 ms per step, box to box) -- not the "
                              "`--gpus 1` line; the FB15k-237-shape weak-scaling step (one shard per rank, single-pass "
-                             "bf16 queries) is `fb15k_weak`, whose one-rank point is 3.05e11 in the same file"
+                             "bf16 queries) is `fb15k_weak`, whose one-rank point is 3.05-3.08e11 in the same file"
                              if main_shape == "wikidata5m" else
                              "weak scaling of the FB15k-237 shape (one E=14,541 shard per rank, single-pass bf16 queries); "
-                             "one-rank point of this curve: profiles/r4_bench_dist1rank.json (3.05e11 scored triples/s)"),
+                             "one-rank point of this curve: profiles/r4_bench_dist1rank.json (3.05-3.08e11 scored triples/s)"),
             "roofline": {"bound": "hbm", "kernel": "the scoring launch(es) of one step on this rank's shard after the "
                                                    "exchange (kge_score_emb_sp_po_blocks: query build on the exchanged rows + "
                                                    "pairs_bf16_v7_kernel on the prepared fragments, two-sided, both blocks on "
