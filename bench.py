@@ -60,8 +60,8 @@ def parse():
     ap.add_argument("--lanes", type=int, default=1,
                     help="N = 1: group launches in flight (group k on HIP stream k %% lanes).  2 pays in sustained issue "
                          "(16 launches per region: 148 -> 131 us per single-pass group launch, 236 -> 216 us split, "
-                         "tools/group_lanes_probe.py) and not in a region of 20 steps = 3 launches (16.8 against 15.5 us "
-                         "per step: fork / join and two lanes' groups contending for the same write path), hence 1")
+                         "tools/group_lanes_probe.py: the next launch's cold start under the tail of the one before) and "
+                         "not in a region of 20 steps = 3 launches (16.8 against 15.5 us per step), hence 1")
     ap.add_argument("--streams", type=int, default=None,
                     help="N > 1: batches in flight in the sharded step (batch k's exchange and scoring on HIP stream "
                          "k %% streams; default: 2 with the step as a hipGraph where that has checked out, else 1)")
