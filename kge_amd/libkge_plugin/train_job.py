@@ -70,7 +70,9 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
             ok = ok and _model_takes_fused_loss(self.model) and hasattr(self.model, "loss_sp_po")
             opt = self.optimizer
             ok = ok and all(g.get("lr_decay", 0) == 0 for g in opt.param_groups)
-            ok = ok and (type(opt).__module__ == "kge_amd.optim" or type(opt) is torch.optim.SGD)
+            # only optimizers whose captured step() replays correctly: kge_amd.optim.Adagrad says so itself, HipAdam
+            # says no (host-computed bias correction would be frozen at the capture step), of torch's own only SGD
+            ok = ok and bool(getattr(opt, "graph_capturable", type(opt) is torch.optim.SGD))
             if ok:  # a penalty term back-propagates between the batch and the optimizer's step: eager
                 try:
                     ok = len(self.model.penalty(epoch=self.epoch, batch_index=batch_index,
@@ -86,6 +88,8 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
                     param_groups = opt.param_groups
                     zero_grad = staticmethod(opt.zero_grad)
                     step = staticmethod(real_step)
+                    graph_capturable = True  # (checked above on the real optimizer)
+                    after_graph_replay = staticmethod(getattr(opt, "after_graph_replay", lambda params: None))
 
                 def step_or_skip(*a, **k):
                     if job._skip_optimizer_step:

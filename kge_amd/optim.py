@@ -31,6 +31,18 @@ def bf16_copy_of(param: torch.Tensor):
 
 
 class Adagrad(_TorchAdagrad):
+    # kge_amd.train_graph.GraphedStep: the step's launch arguments do not depend on the step count (lr_decay != 0 is
+    # refused there), so a captured step() replays correctly; `after_graph_replay` keeps state["step"] -- which the
+    # checkpoint carries -- counting.
+    graph_capturable = True
+
+    def after_graph_replay(self, params):
+        """`params`: the parameters the captured step() updated."""
+        for p in params:
+            st = self.state.get(p)
+            if st is not None and "step" in st:
+                st["step"] += 1
+
     def __init__(self, params, lr=1e-2, lr_decay=0, weight_decay=0, initial_accumulator_value=0, eps=1e-10,
                  bf16_copies: bool = False, **kw):
         """bf16_copies=True: after every step each 2-D float32 parameter carries a fresh bf16 copy
@@ -142,6 +154,10 @@ class Adam(torch.optim.Adam):
     multi-tensor sequence, optionally writing the bf16 scoring copies in the same pass.  amsgrad,
     maximize, capturable and differentiable are not supported; parameters the kernel does not cover
     are stepped by torch's own Adam."""
+
+    # step() computes lr / (1 - beta1^t) and sqrt(1 - beta2^t) on the host from the step count and hands them to the
+    # kernel as launch arguments: a hipGraph capture would freeze them at the capture step.  GraphedStep refuses.
+    graph_capturable = False
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False,
                  bf16_copies: bool = False, **kw):

@@ -110,7 +110,9 @@ class _ShardedKL(torch.autograd.Function):
         w = torch.where(has, 1.0 / k.clamp(min=1.0), torch.zeros_like(k))
         t16 = sh._tables(sh.ent_local, "local")
         loss_loc, lse_loc = sh.backend.kl_emb_fwd(t16, direction, rows, rel_rows, rowptr, col, sh.lo, w)
-        lab = lse_loc - loss_loc  # w_i * (sum of the label scores inside this shard)
+        # w_i * (sum of the label scores inside this shard).  A rank whose shard is EMPTY (E = 9 over 4 ranks) has
+        # lse = -inf and loss = -inf: the difference would be NaN and the all-reduce below would spread it.
+        lab = torch.where(torch.isfinite(lse_loc), lse_loc - loss_loc, torch.zeros_like(lse_loc))
         if sh.collectives:
             allse = torch.empty(sh.world * lse_loc.numel(), dtype=lse_loc.dtype, device=lse_loc.device)
             dist.all_gather_into_tensor(allse, lse_loc.contiguous(), group=sh.group)
@@ -564,13 +566,16 @@ class ShardedScoreLanes:
         self.k = 0
         self._out = []
         if graph is None:
-            # default: ON for every world size (KGE_SHARDED_GRAPH=0 turns it off) behind a self-check: the first
-            # capture of a step shape is replayed once and compared bit for bit with the step issued call by call,
-            # every rank votes (one all-reduce), and a capture that throws, differs or is voted down anywhere turns
-            # the feature off on all ranks -- loudly (warnings.warn + `graph_error`) --, the step going call by call
-            # from then on.  (The capture of a multi-GPU RCCL all-gather has run on ONE rank only in the build loop.)
+            # default: ON for a single rank, OPT-IN (KGE_SHARDED_GRAPH=1) for world > 1 -- the capture of a step that
+            # contains a multi-GPU RCCL all-gather has run on ONE rank only in the build loop --, OFF with
+            # KGE_SHARDED_GRAPH=0.  Either way behind a self-check in two votes (see _issue): every rank first says
+            # whether its capture went through, BEFORE anything that holds a collective is replayed; only if all did
+            # is the capture replayed once and compared bit for bit with the step issued call by call, and the ranks
+            # vote again.  A capture that throws, differs or is voted down anywhere turns the feature off on all ranks
+            # -- loudly (warnings.warn + `graph_error`) --, the step going call by call from then on.
             want = os.environ.get("KGE_SHARDED_GRAPH")
-            graph = (want != "0") if want is not None else True
+            multi = bool(table.collectives) and table.world > 1
+            graph = (want != "0") if want is not None else (not multi)
             if graph and table.collectives:
                 try:
                     graph = dist.get_backend(table.group) == "nccl"
@@ -627,29 +632,45 @@ class ShardedScoreLanes:
             if self._cap_stream is None:
                 self._cap_stream = torch.cuda.Stream(device=self.table.ent_local.device)
             st = self._cap_stream
+        multi = bool(tb.collectives) and tb.world > 1
+
+        def vote(err):
+            """Every rank takes the same decision: one MAX all-reduce of 'my step failed'."""
+            if not multi:
+                return err
+            try:
+                v = torch.tensor([0 if err is None else 1], device=tb.ent_local.device, dtype=torch.int32)
+                dist.all_reduce(v, op=dist.ReduceOp.MAX, group=tb.group)
+                if int(v.item()) != 0 and err is None:
+                    err = "another rank's capture failed"
+            except Exception as exc:  # pragma: no cover
+                err = err or f"vote failed: {type(exc).__name__}: {exc}"
+            return err
+
         err = None
+        g = cap = None
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
                 cap = fn(*static)
-            # self-check: one replay against the call-by-call result on the same static inputs
-            g.replay()
-            torch.cuda.synchronize()
-            flat = lambda r: [t for t in (r if isinstance(r, (tuple, list)) else (r,)) if torch.is_tensor(t)]
-            same = all(torch.equal(a, b) for a, b in zip(flat(res), flat(cap))) and len(flat(res)) == len(flat(cap))
-            if not same:
-                err = "the replayed step differs from the step issued call by call"
         except Exception as exc:  # not capturable here
             err = f"{type(exc).__name__}: {exc}"
             torch.cuda.synchronize()
-        if tb.collectives and tb.world > 1:  # every rank takes the same decision
-            try:
-                vote = torch.tensor([0 if err is None else 1], device=tb.ent_local.device, dtype=torch.int32)
-                dist.all_reduce(vote, op=dist.ReduceOp.MAX, group=tb.group)
-                if int(vote.item()) != 0 and err is None:
-                    err = "another rank's capture failed its self-check"
-            except Exception as exc:  # pragma: no cover
-                err = err or f"vote failed: {type(exc).__name__}: {exc}"
+        # vote 1, BEFORE any replay: a capture that failed on one rank only must not leave the others replaying a
+        # graph that holds a collective this rank never enters (mismatched collectives hang the job)
+        err = vote(err)
+        if err is None:
+            try:  # self-check: one replay against the call-by-call result on the same static inputs
+                g.replay()
+                torch.cuda.synchronize()
+                flat = lambda r: [t for t in (r if isinstance(r, (tuple, list)) else (r,)) if torch.is_tensor(t)]
+                same = all(torch.equal(a, b) for a, b in zip(flat(res), flat(cap))) and len(flat(res)) == len(flat(cap))
+                if not same:
+                    err = "the replayed step differs from the step issued call by call"
+            except Exception as exc:
+                err = f"{type(exc).__name__}: {exc}"
+                torch.cuda.synchronize()
+            err = vote(err)  # vote 2: the comparison
         if err is None:
             self._graphs[lane][key] = {"graph": g, "static": static, "res": cap}
             self.graph_checked += 1

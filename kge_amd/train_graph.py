@@ -66,6 +66,14 @@ class GraphedStep:
         for g in optimizer.param_groups:
             if g.get("lr_decay", 0) != 0:
                 self._disable("the optimizer's lr_decay makes the step size a function of the step count")
+        # A captured step() freezes every launch argument the host computed.  Adam's bias correction (lr / (1 - b1^t),
+        # sqrt(1 - b2^t)) is such an argument: a replay would keep the values of the capture step for ever.
+        # An optimizer says so itself (`graph_capturable`, kge_amd.optim); of torch's own only SGD is known to be safe.
+        cap = getattr(optimizer, "graph_capturable", None)
+        if cap is None:
+            cap = type(optimizer) is torch.optim.SGD
+        if not cap:
+            self._disable(f"{type(optimizer).__name__}.step() computes launch arguments from the step count on the host")
 
     def _disable(self, why: str) -> None:
         self.enabled = False
@@ -96,6 +104,7 @@ class GraphedStep:
         # the gradient buffers the captured backward writes and the captured optimizer reads (static: a replay fills
         # them again; the parameters' .grad attributes may be set to None by the caller in between)
         self.static_grads = [p.grad for g in self.optimizer.param_groups for p in g["params"]]
+        self._stepped = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
         self._graph = graph
         self._sig = self._signature(inputs)
         self._lrs = [g["lr"] for g in self.optimizer.param_groups]
@@ -108,7 +117,9 @@ class GraphedStep:
         if self.calls <= self.warmup:
             return self._eager(inputs)
         lrs = [g["lr"] for g in self.optimizer.param_groups]
+        fresh = False
         if self._graph is None or lrs != self._lrs:
+            fresh = True
             if self._graph is not None and self._signature(inputs) != self._sig:
                 return self._eager(inputs)  # (a short batch right at a learning-rate change: the next full one captures)
             try:
@@ -127,4 +138,9 @@ class GraphedStep:
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
         self.replays += 1
+        after = getattr(self.optimizer, "after_graph_replay", None)
+        if after is not None and not fresh:
+            # host-side bookkeeping the captured kernels do not carry: the per-parameter step counts of the checkpoint
+            # (the capture itself ran step() once on the host, so the first replay is already counted)
+            after(self._stepped)
         return self._static_loss

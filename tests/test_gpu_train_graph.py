@@ -108,3 +108,36 @@ def test_replayed_gradients_stay_the_eager_gradients_over_many_replays():
         churn.append([torch.empty(sz, dtype=torch.uint8, device=DEV).fill_(0xAB) for sz in (512, 12288, 485376, 1 << 20, 7 << 20)])
         if len(churn) > 3:
             churn.pop(0)
+
+
+def test_graphed_step_refuses_adam_and_counts_adagrad_steps():
+    """kge_amd.optim.Adam computes lr / (1 - beta1^t) and sqrt(1 - beta2^t) on the host and hands them to the
+    kernel as launch arguments -- a capture would freeze them at the capture step.  GraphedStep must refuse it (the step
+    stays eager and equals an eager run bit for bit up to the scatter atomics), and for Adagrad the per-parameter step
+    count of the checkpoint (state["step"]) must keep counting through replays."""
+    from kge_amd import model as km, optim as kopt
+    from kge_amd.train_graph import GraphedStep
+    g = torch.Generator().manual_seed(3)
+    batches = [torch.stack([torch.randint(hi, (128,), generator=g) for hi in (900, 5, 900)], 1).to(DEV) for _ in range(8)]
+
+    def run(graphed):
+        torch.manual_seed(0)
+        m = km.create("complex", 900, 5, 256, device=DEV, score_dtype=torch.bfloat16)
+        opt = kopt.Adam(m.parameters(), lr=0.01, bf16_copies=True)
+        step = GraphedStep(lambda s, p, o: m.loss_sp_po(s, p, o).sum() / len(s), opt, warmup=2, enabled=graphed)
+        return [float(step(b[:, 0], b[:, 1], b[:, 2])) for b in batches], opt, step
+    l_e, _, _ = run(False)
+    l_g, opt, step = run(True)
+    assert not step.enabled and "step count" in step.disabled_reason and step.replays == 0
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 5e-5 * abs(a) + 1e-7
+    assert all(float(st["step"]) == len(batches) for st in opt.state.values())
+
+    torch.manual_seed(0)
+    m = km.create("complex", 900, 5, 256, device=DEV, score_dtype=torch.bfloat16)
+    opt = kopt.Adagrad(m.parameters(), lr=0.1, bf16_copies=True)
+    step = GraphedStep(lambda s, p, o: m.loss_sp_po(s, p, o).sum() / len(s), opt, warmup=2)
+    for b in batches:
+        step(b[:, 0], b[:, 1], b[:, 2])
+    assert step.replays == len(batches) - 2 and step.disabled_reason is None
+    assert all(float(st["step"]) == len(batches) for st in opt.state.values()), [float(st["step"]) for st in opt.state.values()]

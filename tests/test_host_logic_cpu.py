@@ -121,3 +121,21 @@ def test_bench_traffic_comes_from_the_committed_counter_passes():
         assert abs(d[mode]["fetch_bytes_corrected"] + d[mode]["write_bytes"] - t) < 1.0
         assert bench.pmc_traffic(mode, g + 1) is None     # another group size: no figure rather than a wrong one
     assert os.path.exists(os.path.join(root, d["source"]))
+
+
+def test_graphed_step_gate_refuses_step_count_dependent_optimizers():
+    """GraphedStep may capture only optimizers whose step() launch arguments do not depend on the
+    step count.  kge_amd.optim.Adagrad declares itself capturable, kge_amd.optim.Adam (host-side bias correction) does
+    not, of torch's own optimizers only SGD is admitted.  (Decided in the constructor: no GPU needed.)"""
+    import torch
+    from kge_amd import optim as kopt
+    from kge_amd.train_graph import GraphedStep
+    w = [torch.nn.Parameter(torch.zeros(4, 4))]
+    f = lambda *a: None
+    assert GraphedStep(f, kopt.Adagrad(w, lr=0.1)).enabled
+    assert GraphedStep(f, torch.optim.SGD(w, lr=0.1)).enabled
+    for opt in (kopt.Adam(w, lr=0.1), torch.optim.Adam(w, lr=0.1), torch.optim.Adagrad(w, lr=0.1)):
+        st = GraphedStep(f, opt)
+        assert not st.enabled and "step count" in st.disabled_reason, type(opt)
+    st = GraphedStep(f, kopt.Adagrad(w, lr=0.1, lr_decay=0.1))
+    assert not st.enabled and "lr_decay" in st.disabled_reason
