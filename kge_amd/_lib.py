@@ -205,7 +205,16 @@ def build(force: bool = False) -> str:
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
-    build_extension(force)
+    try:
+        build_extension(force)
+    except (subprocess.CalledProcessError, OSError, ImportError) as exc:
+        # the extension is a second binding of the same library: a box without g++ / the torch headers still has the
+        # ctypes binding (engine._ext falls back to it), so the library build does not fail on it -- loudly
+        import warnings
+        if os.path.exists(EXT_PATH):
+            os.remove(EXT_PATH)  # never leave a stale one behind
+        warnings.warn(f"kge_amd: kge_amd._C (torch extension) was not built ({type(exc).__name__}: {exc}); "
+                      "the ctypes binding of libkge_amd.so is used")
     return LIB_PATH
 
 

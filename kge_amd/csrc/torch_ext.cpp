@@ -3,10 +3,12 @@
 // north_star asks for the engine "exposed through a PyTorch-ROCm C++/HIP extension that keeps the RelationalScorer /
 // KgeModel plugin API".  The kernels and the drop-in boundary stay in libkge_amd.so (plain C, no torch types); this
 // file is the thin torch side of it: tensors in, tensors out, outputs from torch's caching allocator, launches on
-// torch's CURRENT HIP stream, C status codes turned into TORCH_CHECK failures (RuntimeError in Python; an allocation
-// failure keeps torch's "CUDA out of memory" text, which the reference's sub-batch auto-tuner greps for:
-// kge/job/train.py:384-391).  One C++ call per scoring call instead of a ctypes call with a dozen boxed arguments:
-// ~2 us of host time instead of ~9 (tools/host_overhead.py).
+// torch's CURRENT HIP stream, C status codes turned into TORCH_CHECK failures (RuntimeError in Python).  An allocation
+// failure of an output is re-raised as RuntimeError("CUDA out of memory ...") -- on ROCm torch's own text is "HIP out
+// of memory", and the reference's sub-batch auto-tuner string-matches the CUDA spelling (kge/job/train.py:384-391):
+// `empty_f32` below; tests/test_gpu_queries.py::test_out_of_memory_keeps_the_text_the_reference_greps_for.
+// One C++ call per scoring call instead of a ctypes call with a dozen boxed arguments: ~2 us of host time instead of ~9
+// (tools/host_overhead.py).
 //
 // Mirrors (paths in the reference tree):
 //   score_spo / score_sp / score_po / score_sp_po   KgeModel.score_*      kge/model/kge_model.py:663-789
@@ -23,6 +25,16 @@ namespace {
 
 void check(int rc, const char* what) {
   TORCH_CHECK(rc == KGE_OK, "kge_amd: ", what, " failed: ", kge_status_string(rc), " (kge_status ", rc, ")");
+}
+
+// Output allocation through torch's caching allocator with the reference's OOM text (SURVEY.md 8b "Error conventions").
+at::Tensor empty_f32(at::IntArrayRef shape, const at::Tensor& like) {
+  try {
+    return at::empty(shape, like.options().dtype(at::kFloat));
+  } catch (const c10::OutOfMemoryError& e) {
+    TORCH_CHECK(false, "CUDA out of memory (kge_amd, ROCm: ", e.what_without_backtrace(), ")");
+  }
+  return at::Tensor();  // not reached
 }
 
 void* stream_of(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
@@ -81,7 +93,7 @@ at::Tensor score_spo(const at::Tensor& ent, const at::Tensor& rel, int64_t score
   std::vector<at::Tensor> keep;
   int64_t n = -1;
   const kge_index si = index_of(s, ent, keep, &n), pi = index_of(p, ent, keep, &n), oi = index_of(o, ent, keep, &n);
-  at::Tensor out = at::empty({n}, ent.options().dtype(at::kFloat));
+  at::Tensor out = empty_f32({n}, ent);
   check(kge_score_spo(&t, si, pi, oi, n, out.data_ptr<float>(), stream_of(ent)), "kge_score_spo");
   return out;
 }
@@ -105,7 +117,7 @@ at::Tensor score_pairs(const at::Tensor& ent, const at::Tensor& rel, int64_t sco
     wsb = workspace->numel() * workspace->element_size();
   }
   const int64_t width = combine == KGE_SP_PO ? 2 * m : m;
-  at::Tensor out = at::empty({n, width}, ent.options().dtype(at::kFloat));
+  at::Tensor out = empty_f32({n, width}, ent);
   const int64_t ldo = width > 0 ? width : 1;
   void* st = stream_of(ent);
   if (combine == KGE_SP_)

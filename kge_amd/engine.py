@@ -222,7 +222,15 @@ def _ext():
         if os.environ.get("KGE_AMD_BINDING", "ext") == "ctypes" or not os.path.exists(_lib.EXT_PATH):
             _EXT = False
         else:
-            _EXT = _lib.ext()
+            try:
+                _EXT = _lib.ext()
+            except (ImportError, OSError, RuntimeError) as exc:
+                # a stale _C.so (built against another torch) or an ABI mismatch: both bindings end in the same C
+                # entry points of libkge_amd.so, so say it once and keep scoring through ctypes
+                import warnings
+                warnings.warn(f"kge_amd: the torch extension kge_amd._C does not load ({type(exc).__name__}: {exc}); "
+                              "scoring calls go through the ctypes binding")
+                _EXT = False
     return _EXT
 
 
@@ -236,7 +244,7 @@ def _workspace_tensor(tc, n, device, enable, st):
 
 def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
     ex = _ext()
-    if ex:
+    if ex and torch.is_tensor(s) and torch.is_tensor(p) and torch.is_tensor(o):
         with _on_device(t.device):
             return ex.score_spo(t.ent, t.rel, t.scorer, t.l_norm, t.flags if flags is None else flags, s, p, o)
     keep = []
@@ -252,7 +260,8 @@ def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
 
 def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
     ex = _ext()
-    if ex and out is None and not t.pad_pitch and torch.is_tensor(a) and torch.is_tensor(p):
+    if ex and out is None and not t.pad_pitch and torch.is_tensor(a) and torch.is_tensor(p) and \
+            (targets is None or torch.is_tensor(targets)):
         with _on_device(t.device):
             fl = t.flags if flags is None else flags
             st = _stream_handle(t.device)
@@ -300,7 +309,8 @@ def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Ten
     """[n, 2m]: score_sp and score_po against one shared entity subset, written directly
     into the two halves of the output (no torch.cat copy, kge_model.py:789)."""
     ex = _ext()
-    if ex and torch.is_tensor(s) and torch.is_tensor(p) and torch.is_tensor(o):
+    if ex and torch.is_tensor(s) and torch.is_tensor(p) and torch.is_tensor(o) and \
+            (entity_subset is None or torch.is_tensor(entity_subset)):
         with _on_device(t.device):
             fl = t.flags if flags is None else flags
             st = _stream_handle(t.device)

@@ -43,7 +43,22 @@ from kge.job.train_negative_sampling import TrainingJobNegativeSampling, S, P, O
 from kge.util.loss import BCEWithLogitsKgeLoss, KLDivWithSoftmaxKgeLoss
 
 
-class HipTrainingJob1vsAll(TrainingJob1vsAll):
+class _CudaOomText:
+    """TrainingJob.run_epoch halves `train.subbatch_size` when a batch fails with a RuntimeError whose text contains
+    "CUDA out of memory" (train.subbatch_auto_tune, kge/job/train.py:384-413).  On ROCm torch's allocator says "HIP out
+    of memory" -- for its own allocations as for ours -- and the tuner never fires.  The hip_* jobs re-raise any
+    out-of-memory error of a batch under the text the trainer matches (error conventions)."""
+
+    def _process_batch(self, batch_index, batch):
+        try:
+            return super()._process_batch(batch_index, batch)
+        except torch.OutOfMemoryError as e:
+            if "CUDA out of memory" in str(e):
+                raise
+            raise RuntimeError("CUDA out of memory (ROCm: " + str(e) + ")") from e
+
+
+class HipTrainingJob1vsAll(_CudaOomText, TrainingJob1vsAll):
     """Overrides only `_process_subbatch` (train_1vsAll.py:48-92).  With `train.loss: kl` and a
     model that offers `loss_sp` / `loss_po` (HipComplEx / HipDistMult scoring in bfloat16), the
     [n, E] score matrix of each direction is never written: one kernel produces the per-row
@@ -187,7 +202,7 @@ class HipTrainingJob1vsAll(TrainingJob1vsAll):
             result.backward_time += time.time()
 
 
-class HipTrainingJobKvsAll(TrainingJobKvsAll):
+class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
     """Overrides only `_process_subbatch` (train_KvsAll.py:216-294).  With `train.loss: kl` or `bce`
     (plain: bce_type None), with or without `KvsAll.label_smoothing`, and a model
     that offers `kl_loss_sp` / `kl_loss_po` (`bce_loss_sp` / `bce_loss_po`), the sp_ and _po queries of a
@@ -333,7 +348,7 @@ def _fusable_ns_loss(loss) -> bool:
     return getattr(inner, "weight", None) is None and getattr(inner, "pos_weight", None) is None
 
 
-class HipTrainingJobNegativeSampling(TrainingJobNegativeSampling):
+class HipTrainingJobNegativeSampling(_CudaOomText, TrainingJobNegativeSampling):
     """`_process_subbatch` is the reference's (train_negative_sampling.py:103-164), called unchanged: labels,
     positive scores, loss, averaging, backward and every timing key are its code.  What changes is what
     `batch["negative_samples"][slot].score` does for the subject and object slots of a model that offers

@@ -1,14 +1,9 @@
 #!/bin/bash
-# Run a command on the MI355X box WITH the reference package `kge` present (never committed):
-# copy /root/reference/kge into the git-ignored oracle/_ref/libkge/ (oracle/ref_harness.py finds it
-# there), call gpurun, remove the copy again.  Usage (build container, repo root):
+# Run a command on the MI355X box WITH the reference package `kge` present (never committed): oracle/make_ref.py
+# (the recipe __graft_entry__.build() also runs) places it in the git-ignored oracle/_ref/libkge/, where
+# oracle/ref_harness.py finds it; the snapshot carries it to the box.  Usage (build container, repo root):
 #   bash tools/gpu_plugin.sh [--timeout S] -- '<command on the GPU box>'
 set -u
 cd "$(dirname "$0")/.."
-mkdir -p oracle/_ref/libkge
-cp -r /root/reference/kge oracle/_ref/libkge/kge
-find oracle/_ref/libkge -name __pycache__ -type d -exec rm -rf {} + 2>/dev/null
-/usr/local/graft/bin/gpurun "$@"
-rc=$?
-rm -rf oracle/_ref/libkge
-exit $rc
+python oracle/make_ref.py
+exec /usr/local/graft/bin/gpurun "$@"
