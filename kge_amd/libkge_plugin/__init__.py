@@ -7,6 +7,9 @@ Usage inside an unmodified LibKGE installation (config-default.yaml:137, README.
     # optional: eval.type: hip_entity_ranking
     # optional: train.type: hip_1vsAll / hip_KvsAll  (kl / bce loss fused into the scoring kernel)
     #           train.type: hip_negative_sampling  (negatives through the fused gather + score kernel)
+    # optional: train.type: hip_sharded_1vsAll / hip_sharded_KvsAll / hip_sharded_negative_sampling and
+    #           eval.type: hip_sharded_entity_ranking  (entity table sharded over the ranks of a torch.distributed job:
+    #           torchrun ... -m kge_amd.libkge_plugin.launch start cfg.yaml; sharded_job.py)
     # optional: train.optimizer.default.type: HipAdagrad / HipAdam  (one-pass update; args as for Adagrad / Adam,
     #           plus bf16_copies: true to keep the bf16 scoring tables fresh without a cast)
 
@@ -30,6 +33,8 @@ from .models import (HipComplEx, HipComplExScorer, HipDistMult, HipDistMultScore
 from .eval_job import HipEntityRankingJob  # noqa: F401
 from .train_job import (HipTrainingJob1vsAll, HipTrainingJobKvsAll,  # noqa: F401
                         HipTrainingJobNegativeSampling)
+from .sharded_job import (HipShardedEntityRankingJob, HipShardedTrainingJob1vsAll,  # noqa: F401
+                          HipShardedTrainingJobKvsAll, HipShardedTrainingJobNegativeSampling)
 
 # kge/util/optimizer.py:15-20 resolves train.optimizer.default.type with getattr(torch.optim, ...)
 import torch.optim as _torch_optim

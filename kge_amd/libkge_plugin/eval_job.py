@@ -106,31 +106,12 @@ class HipEntityRankingJob(EntityRankingJob):
                 pin_memory=self.config.get("eval.pin_memory"),
             )
 
-    @torch.no_grad()
-    def _evaluate(self):
-        if not getattr(self, "_hip_fast", False):
-            return super()._evaluate()
-        E, R = self.dataset.num_entities(), self.dataset.num_relations()
-        dev = torch.device(self.device)
-        filter_with_test = self._hip_filter_with_test
-        rankings = ["_raw", "_filt", "_filt_test"] if filter_with_test else ["_raw", "_filt"]
-        M = len(rankings)
-        suffixes = ["", "_filtered", "_filtered_with_test"][:M]
-        kernel_hist = self.hist_hooks == [hist_all] and not self.head_and_tail
-        hists = [dict() for _ in range(M)]  # raw, filt, filt_test: key -> histogram
-        chunk_size = self.config.get("entity_ranking.chunk_size")
-        if chunk_size <= -1:
-            chunk_size = E
-
-        self.current_trace["epoch"] = dict(
-            type="entity_ranking", scope="epoch", split=self.eval_split, filter_splits=self.filter_splits,
-            epoch=self.epoch, batches=len(self.loader), size=len(self.triples))
-        for f in self.pre_epoch_hooks:
-            f(self)
-
+    def _eval_begin(self, M, chunk_size):
+        """What one evaluation decides once: which tables the counting kernel runs on, split queries or not."""
         # A plain hip_* model (fused gather): scoring and counting in one kernel -- float32 tables of every scorer
         # (the exact kernels' counting epilogue), bf16 ComplEx / DistMult tables with dim 256 / 512 (the loader /
         # consumer kernel's); what the library declines falls back below.  KGE_EVAL_TWO_STEP=1: never.
+        E = self.dataset.num_entities()
         fused_tables = getattr(self.model, "_rank_tables", None)
         if os.environ.get("KGE_EVAL_TWO_STEP", "0") == "1" or M > 3 or fused_tables is None or fused_tables() is None:
             fused_tables = None
@@ -156,6 +137,98 @@ class HipEntityRankingJob(EntityRankingJob):
                                         and self.model._scorer.name in ("complex", "distmult")) else None
         rank_flags = engine.FLAG_SPLIT_QUERY if split_tables is not None else None
 
+        self._ev = {"fused_tables": fused_tables, "split_tables": split_tables, "rank_flags": rank_flags}
+
+    def _batch_counts(self, batch, M, chunk_size):
+        """int64 counts [o | s][rank | ties][ranking][row] of one batch (on the device; launches only).  The sharded
+        job (sharded_job.HipShardedEntityRankingJob) overrides this one method."""
+        ev = self._ev
+        fused_tables, split_tables, rank_flags = ev["fused_tables"], ev["split_tables"], ev["rank_flags"]
+        E, R = self.dataset.num_entities(), self.dataset.num_relations()
+        dev = batch.device
+        s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
+        n = batch.shape[0]
+        s64, o64 = s.long().contiguous(), o.long().contiguous()  # true_col of the po / sp rankings
+        rng = torch.empty(2, M - 1, 2, n, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)  # [o|s][rank|ties][ranking][row]
+        filt_o, filt_s, lookups = [], [], []
+        for k in range(M - 1):
+            uk, start, v = self._hip_sp[k]
+            lookups.append((uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1]))
+            filt_o.append((rng[0, k, 0], rng[0, k, 1], v))
+            uk, start, v = self._hip_po[k]
+            lookups.append((uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1]))
+            filt_s.append((rng[1, k, 0], rng[1, k, 1], v))
+        engine.filter_lookup_multi(lookups)  # kge_filter_lookup_multi: the batch's four lookups, one launch
+
+        o_true = s_true = None
+        ft = fused_tables() if fused_tables is not None else None
+        if ft is not None:
+            # counts straight from the scoring kernel (kge_score_rank_sp_po): the true scores up front, as
+            # the two diagonals of ONE two-sided call against the batch's own targets (o | s)
+            both = engine.score_sp_po(ft, s, p, o, torch.cat([o64, s64]), flags=rank_flags)
+            o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
+            s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
+        elif chunk_size < E and split_tables is not None:
+            both = engine.score_sp_po(split_tables(), s, p, o, torch.cat([o64, s64]), flags=engine.FLAG_SPLIT_QUERY)
+            o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
+            s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
+        elif chunk_size < E:
+            # the subset path of :192-203 without torch.unique: every row against the batch's
+            # own targets, diagonal kept (each score is its own kernel chain)
+            o_true = self.model.score_sp(s, p, o64).diagonal().contiguous()
+            s_true = self.model.score_po(p, o, s64).diagonal().contiguous()
+        for chunk_number in range(math.ceil(E / chunk_size)):
+            chunk_start = chunk_size * chunk_number
+            chunk_end = min(chunk_size * (chunk_number + 1), E)
+            c = chunk_end - chunk_start
+            if ft is not None:
+                if engine.score_rank_sp_po(ft, s, p, o, o_true, s_true, filt_o, filt_s, self.tie_atol,
+                                           self.tie_rtol, cnt[0, 0], cnt[0, 1], cnt[1, 0], cnt[1, 1],
+                                           chunk_start, chunk_end, flags=rank_flags):
+                    continue
+                # declined: the two-step path from here on (o_true / s_true stay)
+                ft = ev["fused_tables"] = fused_tables = None
+            sub = None if c == E else torch.arange(chunk_start, chunk_end, device=dev)
+            if split_tables is not None:
+                scores = engine.score_sp_po(split_tables(), s, p, o, sub, flags=engine.FLAG_SPLIT_QUERY)
+            else:
+                scores = self.model.score_sp_po(s, p, o, sub)
+            scores_sp, scores_po = scores[:, :c], scores[:, c:]
+            if o_true is None:
+                o_true = scores_sp.gather(1, o64.view(-1, 1)).view(-1)
+                s_true = scores_po.gather(1, s64.view(-1, 1)).view(-1)
+            engine.rank_counts_multi(scores_sp, o_true, filt_o, chunk_start, o64, self.tie_atol,
+                                     self.tie_rtol, cnt[0, 0], cnt[0, 1])
+            engine.rank_counts_multi(scores_po, s_true, filt_s, chunk_start, s64, self.tie_atol,
+                                     self.tie_rtol, cnt[1, 0], cnt[1, 1])
+
+        return cnt
+
+    @torch.no_grad()
+    def _evaluate(self):
+        if not getattr(self, "_hip_fast", False):
+            return super()._evaluate()
+        E, R = self.dataset.num_entities(), self.dataset.num_relations()
+        dev = torch.device(self.device)
+        filter_with_test = self._hip_filter_with_test
+        rankings = ["_raw", "_filt", "_filt_test"] if filter_with_test else ["_raw", "_filt"]
+        M = len(rankings)
+        suffixes = ["", "_filtered", "_filtered_with_test"][:M]
+        kernel_hist = self.hist_hooks == [hist_all] and not self.head_and_tail and dev.type == "cuda"
+        hists = [dict() for _ in range(M)]  # raw, filt, filt_test: key -> histogram
+        chunk_size = self.config.get("entity_ranking.chunk_size")
+        if chunk_size <= -1:
+            chunk_size = E
+
+        self.current_trace["epoch"] = dict(
+            type="entity_ranking", scope="epoch", split=self.eval_split, filter_splits=self.filter_splits,
+            epoch=self.epoch, batches=len(self.loader), size=len(self.triples))
+        for f in self.pre_epoch_hooks:
+            f(self)
+
+        self._eval_begin(M, chunk_size)
+
         metrics = {}
         epoch_time = -time.time()
         for batch_number, batch_coords in enumerate(self.loader):
@@ -169,58 +242,7 @@ class HipEntityRankingJob(EntityRankingJob):
             s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
             n = batch.shape[0]
             s64, o64 = s.long().contiguous(), o.long().contiguous()  # true_col of the po / sp rankings
-            rng = torch.empty(2, M - 1, 2, n, dtype=torch.int64, device=dev)
-            cnt = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)  # [o|s][rank|ties][ranking][row]
-            filt_o, filt_s, lookups = [], [], []
-            for k in range(M - 1):
-                uk, start, v = self._hip_sp[k]
-                lookups.append((uk, start, s, p, R, rng[0, k, 0], rng[0, k, 1]))
-                filt_o.append((rng[0, k, 0], rng[0, k, 1], v))
-                uk, start, v = self._hip_po[k]
-                lookups.append((uk, start, p, o, E, rng[1, k, 0], rng[1, k, 1]))
-                filt_s.append((rng[1, k, 0], rng[1, k, 1], v))
-            engine.filter_lookup_multi(lookups)  # kge_filter_lookup_multi: the batch's four lookups, one launch
-
-            o_true = s_true = None
-            ft = fused_tables() if fused_tables is not None else None
-            if ft is not None:
-                # counts straight from the scoring kernel (kge_score_rank_sp_po): the true scores up front, as
-                # the two diagonals of ONE two-sided call against the batch's own targets (o | s)
-                both = engine.score_sp_po(ft, s, p, o, torch.cat([o64, s64]), flags=rank_flags)
-                o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
-                s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
-            elif chunk_size < E and split_tables is not None:
-                both = engine.score_sp_po(split_tables(), s, p, o, torch.cat([o64, s64]), flags=engine.FLAG_SPLIT_QUERY)
-                o_true = both.as_strided((n,), (4 * n + 1,)).contiguous()
-                s_true = both.as_strided((n,), (4 * n + 1,), 3 * n).contiguous()
-            elif chunk_size < E:
-                # the subset path of :192-203 without torch.unique: every row against the batch's
-                # own targets, diagonal kept (each score is its own kernel chain)
-                o_true = self.model.score_sp(s, p, o64).diagonal().contiguous()
-                s_true = self.model.score_po(p, o, s64).diagonal().contiguous()
-            for chunk_number in range(math.ceil(E / chunk_size)):
-                chunk_start = chunk_size * chunk_number
-                chunk_end = min(chunk_size * (chunk_number + 1), E)
-                c = chunk_end - chunk_start
-                if ft is not None:
-                    if engine.score_rank_sp_po(ft, s, p, o, o_true, s_true, filt_o, filt_s, self.tie_atol,
-                                               self.tie_rtol, cnt[0, 0], cnt[0, 1], cnt[1, 0], cnt[1, 1],
-                                               chunk_start, chunk_end, flags=rank_flags):
-                        continue
-                    ft = fused_tables = None  # declined: the two-step path from here on (o_true / s_true stay)
-                sub = None if c == E else torch.arange(chunk_start, chunk_end, device=dev)
-                if split_tables is not None:
-                    scores = engine.score_sp_po(split_tables(), s, p, o, sub, flags=engine.FLAG_SPLIT_QUERY)
-                else:
-                    scores = self.model.score_sp_po(s, p, o, sub)
-                scores_sp, scores_po = scores[:, :c], scores[:, c:]
-                if o_true is None:
-                    o_true = scores_sp.gather(1, o64.view(-1, 1)).view(-1)
-                    s_true = scores_po.gather(1, s64.view(-1, 1)).view(-1)
-                engine.rank_counts_multi(scores_sp, o_true, filt_o, chunk_start, o64, self.tie_atol,
-                                         self.tie_rtol, cnt[0, 0], cnt[0, 1])
-                engine.rank_counts_multi(scores_po, s_true, filt_s, chunk_start, s64, self.tie_atol,
-                                         self.tie_rtol, cnt[1, 0], cnt[1, 1])
+            cnt = self._batch_counts(batch, M, chunk_size)
 
             # final ranks from the counts (inherited tie policy) + histograms
             o_ranks = [self._get_ranks(cnt[0, 0, m], cnt[0, 1, m]) for m in range(M)]

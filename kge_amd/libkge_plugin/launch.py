@@ -1,0 +1,71 @@
+"""`kge` for one rank of a multi-GPU job: `torchrun ... -m kge_amd.libkge_plugin.launch start cfg.yaml [kge options]`.
+
+An unmodified `kge.cli.main()` runs underneath.  What N copies of `kge start` in one node cannot share, and what this
+shim therefore sets per rank before handing over:
+  * the output folder: `kge start` refuses a folder that exists (kge/cli.py:243-245), so N ranks racing for one name
+    fail.  Rank 0 gets the folder the user named (`--folder`, or LibKGE's default local/experiments/<time>-<config>),
+    rank r > 0 gets `<folder>/rank<r>` (its own log and trace; checkpoints are written by rank 0 only);
+  * `job.device`: `cuda` becomes `cuda:<LOCAL_RANK>` unless the command line names a device.
+The process group (RCCL for cuda, gloo for cpu) is created here from torchrun's environment so that the folder name
+can be agreed on; the hip_sharded_* jobs find it initialised.  Without torchrun's environment this is plain `kge`.
+"""
+import datetime
+import os
+import sys
+
+
+def _arg(argv, name):
+    for i, a in enumerate(argv):
+        if a == name and i + 1 < len(argv):
+            return argv[i + 1]
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return None
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and "MASTER_ADDR" in os.environ:
+        import torch
+        import torch.distributed as dist
+        device = _arg(argv, "--job.device")
+        cuda = torch.cuda.is_available() and (device is None or device.startswith("cuda"))
+        if device is None and cuda:
+            argv += ["--job.device", f"cuda:{local}"]
+        if cuda:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
+        if argv and argv[0] == "start":
+            folder = _arg(argv, "--folder")
+            if folder is None:
+                from kge.misc import kge_base_dir
+                cfg = next((a for a in argv[1:] if a.endswith((".yaml", ".yml"))), "config.yaml")
+                name = os.path.splitext(os.path.basename(cfg))[0]
+                names = [os.path.join(kge_base_dir(), "local", "experiments",
+                                      datetime.datetime.now().strftime("%Y%m%d-%H%M%S") + "-" + name)]
+                dist.broadcast_object_list(names, src=0)  # rank 0's clock names the run
+                folder = names[0]
+                argv += ["--folder", folder]
+            if rank > 0:
+                dist.barrier()  # rank 0 creates <folder> first (below), then the others their sub-folders
+                i = next(k for k, a in enumerate(argv) if a == "--folder" or a.startswith("--folder="))
+                mine = os.path.join(folder, f"rank{rank}")
+                if argv[i] == "--folder":
+                    argv[i + 1] = mine
+                else:
+                    argv[i] = "--folder=" + mine
+            else:
+                os.makedirs(os.path.dirname(os.path.abspath(folder)) or ".", exist_ok=True)
+                dist.barrier()
+    sys.argv = ["kge"] + argv
+    from kge.cli import main as kge_main
+    kge_main()
+
+
+if __name__ == "__main__":
+    main()

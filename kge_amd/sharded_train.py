@@ -55,10 +55,15 @@ class _ShardedJob:
     def __init__(self, scorer: str, num_entities: int, num_relations: int, dim: int, *, rel_dim: Optional[int] = None,
                  state_dict: Optional[dict] = None, init_std: float = 0.1, seed: int = 0, lr: float = 0.1,
                  optimizer: str = "Adagrad", optimizer_args: Optional[dict] = None, score_dtype=torch.bfloat16,
-                 device=None, group=None, backend=None, l_norm: float = 1.0, slack_rows: int = 0, config=None):
+                 device=None, group=None, backend=None, l_norm: float = 1.0, slack_rows: int = 0, config=None,
+                 alias_state: bool = False):
         """`state_dict`: full tables under the reference's parameter names (every rank passes the same ones and keeps
         its rows), else normal_(0, init_std) drawn from `seed` for the FULL table on every rank (then sliced): the
-        initial model does not depend on the number of ranks.  `config`: a LibKGE Config to carry in the checkpoints."""
+        initial model does not depend on the number of ranks.  `config`: a LibKGE Config to carry in the checkpoints.
+        `alias_state` (the LibKGE plugin's sharded jobs): the masters are VIEWS of the given float32 tables on this
+        device -- the relation master is the caller's relation table, the entity master its rows [lo, hi) (except with
+        slack rows, which need a buffer of their own) -- so the caller's model sees every update of what this rank
+        owns and no second copy is held; without it the masters are private copies."""
         self.scorer, self.E, self.R, self.d = scorer, int(num_entities), int(num_relations), int(dim)
         self.dr = int(rel_dim) if rel_dim is not None else self.d
         self.group = group
@@ -76,11 +81,21 @@ class _ShardedJob:
         if tuple(ent_full.shape) != (self.E, self.d) or tuple(rel_full.shape) != (self.R, self.dr):
             raise ValueError("kge_amd: state_dict does not match the model's shape")
         mine = ent_full[self.lo:self.hi].to(torch.float32).to(self.device).contiguous()
+        rel_mine = rel_full.to(torch.float32).to(self.device).contiguous()
+        if alias_state:
+            if rel_mine.data_ptr() != rel_full.data_ptr() or (slack_rows <= 0 and self.hi > self.lo
+                                                             and mine.data_ptr() != ent_full[self.lo:self.hi].data_ptr()):
+                raise ValueError("kge_amd: alias_state needs contiguous float32 tables on the job's device")
+        else:  # (`.to` / `.contiguous` return their argument when there is nothing to convert: copy explicitly)
+            if mine.numel() and mine.data_ptr() == ent_full[self.lo:self.hi].data_ptr():
+                mine = mine.clone()
+            if rel_mine.data_ptr() == rel_full.data_ptr():
+                rel_mine = rel_mine.clone()
         self.ent_ext = None
         if slack_rows > 0:  # negative sampling: the master IS the head of a larger buffer (ShardedEntityTable.with_slack)
             self.ent_ext, mine = ShardedEntityTable.with_slack(mine, slack_rows)
         self.ent_master = torch.nn.Parameter(mine)
-        self.rel_master = torch.nn.Parameter(rel_full.to(torch.float32).to(self.device).contiguous())
+        self.rel_master = torch.nn.Parameter(rel_mine)
         self.score_dtype = score_dtype
         if score_dtype == torch.float32:  # the masters are the scoring tables
             self.table = ShardedEntityTable(scorer, self.ent_master.detach(), self.rel_master.detach(), self.E,

@@ -99,3 +99,22 @@ def get_tables(model):
         model.get_s_embedder()._embeddings.weight.detach().clone(),
         model.get_p_embedder()._embeddings.weight.detach().clone(),
     )
+
+
+def load_checkpoint(path: str, device: str = "cpu"):
+    """kge.util.io.load_checkpoint (kge/util/io.py:29-45) under torch >= 2.6, whose torch.load defaults to
+    weights_only=True and refuses the Config object a LibKGE checkpoint carries: the default is switched back for the
+    duration of the call (the reference was written for torch 1.x)."""
+    import_reference()
+    import torch
+    from kge.util.io import load_checkpoint as _load
+    orig = torch.load
+
+    def load(*a, **kw):
+        kw.setdefault("weights_only", False)
+        return orig(*a, **kw)
+    torch.load = load
+    try:
+        return _load(path, device)
+    finally:
+        torch.load = orig

@@ -595,3 +595,61 @@ def test_i_subbatch_auto_tune_fires_on_rocm(data):
     ref, l_ref, _ = _train_epoch(root, folder, "i_fixed", "hip_complex", "hip_1vsAll", init_from=st,
                                  opts={"train.batch_size": 16384, "train.subbatch_size": int(sub)})
     assert _rel(loss, l_ref) <= 1e-5, (loss, l_ref)
+
+
+@pytest.mark.parametrize("case", ["1vsAll", "KvsAll", "negative_sampling"])
+def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case):
+    """train.type: hip_sharded_* + eval.type: hip_sharded_entity_ranking through TrainingJob.create / EvaluationJob.create
+    of an unmodified LibKGE on the MI355X, as ONE rank of an RCCL group (torchrun's environment for a world of one,
+    KGE_SHARDED_FORCE_COLLECTIVES=1: every all-gather / all-reduce of the N > 1 path is issued) with the engine's
+    kernels -- against the unsharded hip_* job of the same config.  (Two ranks: tests/test_libkge_sharded_plugin_cpu.py
+    on gloo; the driver's box has one GPU.)"""
+    if DEVICE == "cpu":
+        pytest.skip("needs the GPU")
+    import socket
+    import torch.distributed as dist
+    root, folder = data
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port)), ("RANK", "0"), ("WORLD_SIZE", "1"),
+                 ("LOCAL_RANK", "0"), ("KGE_SHARDED_FORCE_COLLECTIVES", "1")):
+        monkeypatch.setenv(k, v)
+    if case == "negative_sampling":
+        model, dim, plain = "hip_rotate", 128, "hip_negative_sampling"
+        opts = {"negative_sampling.num_samples.s": 64, "negative_sampling.num_samples.o": 64,
+                "negative_sampling.implementation": "triple"}
+        bound = 1e-4
+    else:
+        model, dim, plain = ("hip_complex", 512, "hip_1vsAll") if case == "1vsAll" else ("hip_distmult", 512, "hip_KvsAll")
+        opts = {f"{model}.score_dtype": "bfloat16"}
+        bound = 2e-3   # both runs score on bf16 copies of the same float32 masters; the kernels' summation orders differ
+    try:
+        ref, l_ref, st = _train_epoch(root, folder, f"j_plain_{case}", model, plain, dim, opts)
+        sopts = dict(opts)
+        sopts["eval.type"] = "hip_sharded_entity_ranking"
+        cfg_imports = _config(root, f"j_tmp_{case}", model, "hip_sharded_" + case, dim, None)
+        cfg_imports._import("hip_sharded_entity_ranking")
+        shd, l_shd, _ = _train_epoch(root, folder, f"j_sharded_{case}", model, "hip_sharded_" + case, dim, sopts, init_from=st)
+        assert type(shd).__name__.startswith("HipShardedTrainingJob") and dist.is_initialized()
+        assert dist.get_backend() == "nccl" and shd._sh.table.collectives
+        d = _param_diff(shd, ref) if case != "negative_sampling" else None
+        _log(case=f"j: hip_sharded_{case} (one RCCL rank, collectives forced) vs {plain}", loss_plain=l_ref,
+             loss_sharded=l_shd, rel=_rel(l_shd, l_ref), param_rel_diff_own_rows=d)
+        assert _rel(l_shd, l_ref) <= bound, (l_shd, l_ref)
+        # validation through the job's own valid_job = the sharded evaluation on the table being trained
+        shd.valid_job.epoch = 1
+        tr = shd.valid_job.run()
+        assert type(shd.valid_job).__name__ == "HipShardedEntityRankingJob"
+        ref.valid_job.epoch = 1
+        tr_ref = ref.valid_job.run()
+        k = "mean_reciprocal_rank_filtered_with_test"
+        _log(case=f"j: validation of hip_sharded_{case} by hip_sharded_entity_ranking vs the plain job's entity_ranking",
+             mrr_sharded=tr[k], mrr_plain=tr_ref[k])
+        assert abs(tr[k] - tr_ref[k]) <= 2e-3 * max(tr_ref[k], 1e-3) + 1e-4
+        # the checkpoint: the reference's layout, ONE [E, d] parameter
+        ck = shd.save_to({})
+        assert ck["model"][0]["_entity_embedder._embeddings.weight"].shape == (E, dim) and ck["type"] == "train"
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()

@@ -1,0 +1,270 @@
+"""The sharded engine behind LibKGE's own job factories (VERDICT r4 "e-plugin"): two gloo ranks run
+`Job.create(config, dataset)` + `job.run()` of an UNMODIFIED LibKGE on the reference's own tests/data/dataset_test with
+`train.type: hip_sharded_1vsAll | hip_sharded_KvsAll | hip_sharded_negative_sampling` and
+`eval.type: hip_sharded_entity_ranking` (kge/job/train.py:118-137, kge/job/eval.py:35-48 resolve them by class_name from
+`modules`), two epochs with a validation after each, and must equal the UNSHARDED run of the same config under
+`hip_1vsAll / hip_KvsAll / hip_negative_sampling` + `hip_entity_ranking`: per-epoch loss, validation metrics, final
+parameters; the checkpoint rank 0 wrote loads into an unsharded reference job and holds ONE [E, d] entity parameter
+and the gathered optimizer state.
+
+job.device cpu: the unsharded run is the reference's arithmetic (the plugin's CPU path IS the reference scorer); the
+sharded ranks score with the test suite's stand-in backend (tests/test_sharded_gloo_cpu.OracleBackend, handed in through
+sharded_job.SHARD_BACKEND -- on a GPU the default is kge_amd.engine).  Needs the reference package (/root/reference
+here, oracle/_ref on a box where build() placed it)."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ref_harness as rh
+
+pytestmark = pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+
+MODULES = ["kge.job", "kge.model", "kge.model.embedder", "kge_amd.libkge_plugin"]
+CASES = {
+    # name: (model, dim, sharded train.type, unsharded train.type, extra options)
+    "1vsAll-complex": ("hip_complex", 16, "hip_sharded_1vsAll", "hip_1vsAll", {}),
+    "KvsAll-distmult-kl": ("hip_distmult", 16, "hip_sharded_KvsAll", "hip_KvsAll", {"train.loss": "kl"}),
+    "KvsAll-complex-bce": ("complex", 16, "hip_sharded_KvsAll", "KvsAll", {"train.loss": "bce"}),
+    "negative_sampling-transe": ("hip_transe", 16, "hip_sharded_negative_sampling", "hip_negative_sampling",
+                                 {"negative_sampling.num_samples.s": 7, "negative_sampling.num_samples.o": 5,
+                                  "negative_sampling.implementation": "triple", "hip_transe.l_norm": 2.0}),
+    "negative_sampling-rotate-bce": ("hip_rotate", 16, "hip_sharded_negative_sampling", "negative_sampling",
+                                     {"negative_sampling.num_samples.s": 6, "negative_sampling.num_samples.o": 6,
+                                      "negative_sampling.implementation": "triple", "train.loss": "bce"}),
+}
+
+
+def _dataset_dir(tmp):
+    """A writable copy of the reference's tests/data/dataset_test (LibKGE drops .pckl caches beside the files)."""
+    src = os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test")
+    dst = os.path.join(tmp, "dataset_test")
+    if not os.path.isdir(dst):
+        shutil.copytree(src, dst)
+    return dst
+
+
+def _config(tmp, tag, model, dim, train_type, eval_type, extra):
+    rh.import_reference()
+    from kge import Config
+    config = Config()
+    config.folder = os.path.join(tmp, tag)
+    shutil.rmtree(config.folder, ignore_errors=True)
+    os.makedirs(config.folder)
+    config.set("console.quiet", True)
+    config.set("modules", MODULES)
+    config.set("model", model)
+    config._import(model)
+    for t in (train_type, eval_type):
+        if t.startswith("hip_"):
+            config._import(t)
+    config.set("dataset.name", "dataset_test")
+    config.set("job.device", "cpu")
+    config.set("job.type", "train")
+    config.set("train.type", train_type)
+    config.set("eval.type", eval_type)
+    config.set("train.max_epochs", 2)
+    config.set("train.batch_size", 16)
+    config.set("train.num_workers", 0)
+    config.set("train.optimizer.default.type", "Adagrad")
+    config.set("train.optimizer.default.args.lr", 0.2, create=True)
+    config.set("eval.batch_size", 8)
+    config.set("valid.every", 1)
+    config.set("valid.metric", "mean_reciprocal_rank_filtered")
+    config.set("lookup_embedder.dim", dim)
+    for k in ("default", "torch", "numpy", "python"):
+        config.set("random_seed." + k, 11)
+    if train_type in ("hip_sharded_1vsAll", "hip_sharded_KvsAll"):
+        config.set(train_type + ".score_dtype", "float32")
+    for k, v in extra.items():
+        config.set(k, v, create=True)
+    return config
+
+
+def _run(config, folder, like_sharded_seeding=False):
+    """Job.create + run, as kge/cli.py:262-290 does; -> (per-epoch avg_loss, valid_trace, state_dict, job)."""
+    import random
+    from kge import Dataset
+    from kge.job import Job
+    from kge.util.seed import seed_from_config
+    seed_from_config(config)
+    dataset = Dataset.create(config, folder=folder)
+    job = Job.create(config, dataset)
+    losses = []
+    job.post_epoch_hooks.append(lambda j: losses.append(j.current_trace["epoch"]["avg_loss"]))
+    if like_sharded_seeding:
+        # the sharded jobs draw ONE number from rank 0's torch generator at job creation and seed the process-wide
+        # generators at the start of every epoch from it and the epoch (sharded_job._seed_epoch): the same draw and
+        # the same seeding here make the two runs see the same batches and the same negatives
+        from kge_amd.libkge_plugin.sharded_job import epoch_seed
+        base = int(torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64))
+        orig = job.run_epoch
+
+        def run_epoch():
+            v = epoch_seed(base, job.epoch)
+            torch.manual_seed(v)
+            np.random.seed(v % (2 ** 32))
+            random.seed(v)
+            return orig()
+        job.run_epoch = run_epoch
+    job.run()
+    return losses, job.valid_trace, {k: v.detach().clone() for k, v in job.model.state_dict().items()}, job
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp, case, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        for pth in (here, os.path.join(os.path.dirname(here), "oracle"), os.path.dirname(here)):
+            if pth not in sys.path:
+                sys.path.insert(0, pth)
+        rh.import_reference()
+        from test_sharded_gloo_cpu import OracleBackend
+        import kge_amd.libkge_plugin.sharded_job as sj
+        sj.SHARD_BACKEND = OracleBackend
+        model, dim, sharded_type, _, extra = CASES[case]
+        config = _config(tmp, f"sharded_rank{rank}", model, dim, sharded_type, "hip_sharded_entity_ranking", extra)
+        losses, valid, state, job = _run(config, _dataset_dir(tmp))  # (the job creates the gloo group from the env)
+        assert dist.is_initialized() and dist.get_world_size() == world
+        assert type(job).__name__.startswith("HipShardedTrainingJob")
+        assert type(job.valid_job).__name__ == "HipShardedEntityRankingJob"
+        sh = job._sh
+        E = job.dataset.num_entities()
+        assert (sh.lo, sh.hi) == ((0, (E + 1) // 2) if rank == 0 else ((E + 1) // 2, E))
+        assert sh.ent_master.shape[0] == sh.hi - sh.lo                       # this rank trains its rows only
+        for st in job.optimizer.state.values():                              # ... and holds their optimizer state only
+            if torch.is_tensor(st.get("sum")) and st["sum"].dim() == 2 and st["sum"].shape[1] == dim:
+                assert st["sum"].shape[0] in (sh.hi - sh.lo, job.dataset.num_relations())
+        ck = os.path.join(config.folder, "checkpoint_00002.pt")
+        q.put((rank, losses, [{k: v for k, v in t.items() if isinstance(v, (int, float))} for t in valid],
+               {k: v.numpy() for k, v in state.items()}, os.path.exists(ck), ck))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_sharded_jobs_through_job_create_equal_the_unsharded_plugin_jobs(case, tmp_path):
+    tmp = str(tmp_path)
+    _dataset_dir(tmp)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tmp, case, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    # the unsharded run, in this process, while the ranks work
+    model, dim, _, plain_type, extra = CASES[case]
+    config = _config(tmp, "unsharded", model, dim, plain_type, "hip_entity_ranking", extra)
+    l_ref, v_ref, s_ref, job_ref = _run(config, _dataset_dir(tmp), like_sharded_seeding=True)
+    outs = []
+    import time
+    t0 = time.time()
+    while len(outs) < world and time.time() - t0 < 600:
+        if not q.empty():
+            outs.append(q.get())
+        elif any(pr.exitcode not in (None, 0) for pr in procs):
+            break
+        else:
+            time.sleep(0.05)
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+    assert len(outs) == world
+    outs.sort(key=lambda x: x[0])
+    assert len(l_ref) == 2 and len(v_ref) == 2
+    for rank, losses, valid, state, has_ck, ck in outs:
+        np.testing.assert_allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
+        assert len(valid) == 2
+        for got, want in zip(valid, v_ref):
+            keys = [k for k in want if k.startswith(("mean_", "hits_at_")) and isinstance(want[k], (int, float))]
+            assert "mean_reciprocal_rank_filtered_with_test" in keys and "hits_at_1_filtered" in keys
+            for k in keys:
+                assert abs(got[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (rank, k, got[k], want[k])
+        for k, v in s_ref.items():                          # the model every rank ends with = the unsharded model
+            np.testing.assert_allclose(state[k], v.numpy(), rtol=2e-4, atol=5e-5)
+        assert has_ck == (rank == 0)                        # rank 0 writes the checkpoints
+    # rank 0's checkpoint is the reference's: an UNSHARDED job of an unmodified LibKGE resumes from it
+    from kge.job import Job
+    checkpoint = rh.load_checkpoint(outs[0][5], "cpu")
+    E, R = job_ref.dataset.num_entities(), job_ref.dataset.num_relations()
+    sd = checkpoint["model"][0]
+    assert sd["_entity_embedder._embeddings.weight"].shape == (E, dim) and checkpoint["epoch"] == 2
+    opt_state = checkpoint["optimizer_state_dict"]["state"]
+    assert opt_state[0]["sum"].shape == (E, dim)
+    np.testing.assert_allclose(opt_state[0]["sum"].numpy(), job_ref.optimizer.state_dict()["state"][0]["sum"].numpy(),
+                               rtol=2e-4, atol=1e-7)
+    new = _config(tmp, "resumed", model, dim, plain_type, "hip_entity_ranking", extra)
+    resumed = Job.create_from(checkpoint, new_config=new, dataset=job_ref.dataset)
+    assert resumed.epoch == 2 and type(resumed).__name__ == type(job_ref).__name__
+    for k, v in s_ref.items():
+        np.testing.assert_allclose(resumed.model.state_dict()[k].numpy(), v.numpy(), rtol=2e-4, atol=5e-5)
+
+
+def test_launcher_runs_kge_start_on_two_ranks(tmp_path):
+    """`torchrun --nproc-per-node 2 -m kge_amd.libkge_plugin.launch start cfg.yaml --folder F --job.device cpu`: an
+    unmodified kge.cli underneath, rank 0 in F, rank 1 in F/rank1, checkpoints written by rank 0 only, the training
+    trace of both ranks carrying the same losses -- and the same as the in-process run of the case above."""
+    import subprocess
+    import sys
+    import yaml
+    tmp = str(tmp_path)
+    # a dataset the CLI can find by name: <base dir of a root module in `modules`>/data/<name> (kge/dataset.py:103-112)
+    os.makedirs(os.path.join(tmp, "dsmod"))
+    open(os.path.join(tmp, "dsmod", "__init__.py"), "w").close()
+    shutil.copytree(os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test"), os.path.join(tmp, "data", "dataset_test"))
+    cfg = {
+        "modules": MODULES + ["dsmod"], "model": "hip_complex", "import": ["hip_complex", "hip_sharded_1vsAll",
+                                                                           "hip_sharded_entity_ranking"],
+        "dataset": {"name": "dataset_test"}, "job": {"type": "train"},
+        "train": {"type": "hip_sharded_1vsAll", "max_epochs": 2, "batch_size": 16, "num_workers": 0,
+                  "optimizer": {"default": {"type": "Adagrad", "args": {"lr": 0.2}}}},
+        "hip_sharded_1vsAll": {"score_dtype": "float32"},
+        "eval": {"type": "hip_sharded_entity_ranking", "batch_size": 8},
+        "valid": {"every": 1, "metric": "mean_reciprocal_rank_filtered"},
+        "lookup_embedder": {"dim": 16}, "random_seed": {"default": 11, "torch": 11, "numpy": 11, "python": 11},
+    }
+    path = os.path.join(tmp, "cfg.yaml")
+    with open(path, "w") as f:
+        yaml.safe_dump(cfg, f)
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    env = dict(os.environ, KGE_AMD_TEST_SHARD_BACKEND="test_sharded_gloo_cpu:OracleBackend", PYTHONDONTWRITEBYTECODE="1",
+               PYTHONPATH=os.pathsep.join([os.path.join(root, "oracle", "ref_stubs"), rh.REFERENCE_ROOT, root, here,
+                                           os.path.join(root, "oracle"), tmp, os.environ.get("PYTHONPATH", "")]))
+    folder = os.path.join(tmp, "run")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "-m", "kge_amd.libkge_plugin.launch", "start", path,
+           "--folder", folder, "--job.device", "cpu", "--console.quiet", "True"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=tmp)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert os.path.isfile(os.path.join(folder, "checkpoint_00002.pt")) and os.path.isfile(os.path.join(folder, "checkpoint_best.pt"))
+    assert os.path.isdir(os.path.join(folder, "rank1")) and not os.path.exists(os.path.join(folder, "rank1", "checkpoint_00002.pt"))
+
+    def epoch_losses(trace_file):
+        import re
+        out = []
+        with open(trace_file) as f:
+            for line in f:  # (one flow-style yaml mapping per line; some carry python tags safe_load refuses)
+                if "scope: epoch" in line and "job: train" in line:
+                    m = re.search(r"avg_loss: ([-+0-9.eE]+)", line)
+                    if m:
+                        out.append(float(m.group(1)))
+        return out
+    l0 = epoch_losses(os.path.join(folder, "trace.yaml"))
+    l1 = epoch_losses(os.path.join(folder, "rank1", "trace.yaml"))
+    assert len(l0) == 2 and l0 == l1, (l0, l1)
+    ck = rh.load_checkpoint(os.path.join(folder, "checkpoint_00002.pt"), "cpu")
+    assert ck["model"][0]["_entity_embedder._embeddings.weight"].shape[1] == 16 and ck["epoch"] == 2
