@@ -4,7 +4,8 @@ An unmodified `kge.cli.main()` runs underneath.  What N copies of `kge start` in
 shim therefore sets per rank before handing over:
   * the output folder: `kge start` refuses a folder that exists (kge/cli.py:243-245), so N ranks racing for one name
     fail.  Rank 0 gets the folder the user named (`--folder`, or LibKGE's default local/experiments/<time>-<config>),
-    rank r > 0 gets `<folder>/rank<r>` (its own log and trace; checkpoints are written by rank 0 only);
+    rank r > 0 gets the sibling `<folder>-rank<r>` (its own log and trace; checkpoints are written by rank 0 only;
+    a sub-folder would create <folder> under rank 0's feet);
   * `job.device`: `cuda` becomes `cuda:<LOCAL_RANK>` unless the command line names a device.
 The process group (RCCL for cuda, gloo for cpu) is created here from torchrun's environment so that the folder name
 can be agreed on; the hip_sharded_* jobs find it initialised.  Without torchrun's environment this is plain `kge`.
@@ -52,16 +53,13 @@ def main(argv=None):
                 folder = names[0]
                 argv += ["--folder", folder]
             if rank > 0:
-                dist.barrier()  # rank 0 creates <folder> first (below), then the others their sub-folders
                 i = next(k for k, a in enumerate(argv) if a == "--folder" or a.startswith("--folder="))
-                mine = os.path.join(folder, f"rank{rank}")
+                mine = folder.rstrip("/") + f"-rank{rank}"
                 if argv[i] == "--folder":
                     argv[i + 1] = mine
                 else:
                     argv[i] = "--folder=" + mine
-            else:
-                os.makedirs(os.path.dirname(os.path.abspath(folder)) or ".", exist_ok=True)
-                dist.barrier()
+            os.makedirs(os.path.dirname(os.path.abspath(folder)) or ".", exist_ok=True)
     sys.argv = ["kge"] + argv
     from kge.cli import main as kge_main
     kge_main()

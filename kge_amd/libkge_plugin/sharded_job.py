@@ -10,7 +10,7 @@ as
 
     torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m kge_amd.libkge_plugin.launch start cfg.yaml
 
-(`launch` = `kge start` with a per-rank output folder and `job.device: cuda:<LOCAL_RANK>`, nothing else; an unmodified
+(`launch` = `kge start` with a per-rank output folder (<folder>, <folder>-rank1, ...) and `job.device: cuda:<LOCAL_RANK>`, nothing else; an unmodified
 `kge.cli` underneath).  Every rank runs the SAME job on the SAME batches (the loader's shuffle and the negative sampler
 are seeded at the start of every epoch from one number rank 0 broadcast at job creation + the epoch, and the first
 batch of every epoch is compared across ranks by a checksum); what is split is the entity table:

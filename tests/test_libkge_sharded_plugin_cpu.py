@@ -215,7 +215,7 @@ def test_sharded_jobs_through_job_create_equal_the_unsharded_plugin_jobs(case, t
 
 def test_launcher_runs_kge_start_on_two_ranks(tmp_path):
     """`torchrun --nproc-per-node 2 -m kge_amd.libkge_plugin.launch start cfg.yaml --folder F --job.device cpu`: an
-    unmodified kge.cli underneath, rank 0 in F, rank 1 in F/rank1, checkpoints written by rank 0 only, the training
+    unmodified kge.cli underneath, rank 0 in F, rank 1 in F-rank1, checkpoints written by rank 0 only, the training
     trace of both ranks carrying the same losses -- and the same as the in-process run of the case above."""
     import subprocess
     import sys
@@ -251,7 +251,7 @@ def test_launcher_runs_kge_start_on_two_ranks(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=tmp)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert os.path.isfile(os.path.join(folder, "checkpoint_00002.pt")) and os.path.isfile(os.path.join(folder, "checkpoint_best.pt"))
-    assert os.path.isdir(os.path.join(folder, "rank1")) and not os.path.exists(os.path.join(folder, "rank1", "checkpoint_00002.pt"))
+    assert os.path.isdir(folder + "-rank1") and not os.path.exists(os.path.join(folder + "-rank1", "checkpoint_00002.pt"))
 
     def epoch_losses(trace_file):
         import re
@@ -264,7 +264,7 @@ def test_launcher_runs_kge_start_on_two_ranks(tmp_path):
                         out.append(float(m.group(1)))
         return out
     l0 = epoch_losses(os.path.join(folder, "trace.yaml"))
-    l1 = epoch_losses(os.path.join(folder, "rank1", "trace.yaml"))
+    l1 = epoch_losses(os.path.join(folder + "-rank1", "trace.yaml"))
     assert len(l0) == 2 and l0 == l1, (l0, l1)
     ck = rh.load_checkpoint(os.path.join(folder, "checkpoint_00002.pt"), "cpu")
     assert ck["model"][0]["_entity_embedder._embeddings.weight"].shape[1] == 16 and ck["epoch"] == 2
