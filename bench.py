@@ -222,21 +222,32 @@ def matrix_pipe_probe(device):
     fn.restype = ctypes.c_double
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     g = torch.Generator(device=device).manual_seed(3)
-    ops = torch.randn(8 * 4 * 512, generator=g, device=device).bfloat16()  # 8 waves x 4 operands x 64 lanes x 8 values
     sink = torch.zeros(4, device=device)
     iters = 400
     st = torch.cuda.current_stream(device).cuda_stream
-
-    def launch():
-        fl = fn(ops.data_ptr(), iters, sink.data_ptr(), st)
-        assert fl > 0, fl
-        return fl
-    flops = launch()
-    ms = event_avg_ms(launch, 20)
-    tf = flops / (ms * 1e-3) / 1e12
+    # 8 waves x 4 operands x 64 lanes x 8 values.  The pipe's power draw -- and with it the clock the chip holds -- depends
+    # on the DATA: random bf16 values toggle every multiplier input, zeros toggle nothing.  Both are measured; the
+    # random-operand rate is what a scoring kernel's matrix work can be compared with, the zero-operand rate is what the
+    # guide's 2.5 PFLOP/s (/opt/skills/guides/MI355X_MICROARCH.md) corresponds to.
+    kinds = {"random": torch.randn(8 * 4 * 512, generator=g, device=device).bfloat16(),
+             "zeros": torch.zeros(8 * 4 * 512, device=device).bfloat16(),
+             "ones": torch.ones(8 * 4 * 512, device=device).bfloat16()}
+    out = {}
+    for kind, ops in kinds.items():
+        def launch(ops=ops):
+            fl = fn(ops.data_ptr(), iters, sink.data_ptr(), st)
+            assert fl > 0, fl
+            return fl
+        flops = launch()
+        ms = event_avg_ms(launch, 20)
+        out[kind] = (ms, flops / (ms * 1e-3) / 1e12)
+    ms, tf = out["random"]
     return {"kernel": "mfma_rate_kernel (kge_debug_mfma_rate: 2 waves per SIMD, two independent accumulators each, no "
-                      "memory traffic)", "launch_us": ms * 1e3, "achieved": tf, "unit": "TFLOP/s",
-            "frac_of_nominal_peak": tf / BF16_MFMA_PEAK_TF}
+                      "memory traffic)", "operands": "random bf16 values (N(0,1))", "launch_us": ms * 1e3, "achieved": tf,
+            "unit": "TFLOP/s", "frac_of_nominal_peak": tf / BF16_MFMA_PEAK_TF,
+            "by_operands_tflops": {k: v[1] for k, v in out.items()},
+            "note": "the same instruction stream on zeros / ones / random values: the difference is the clock the chip "
+                    "holds under the data's switching activity"}
 
 
 def rank_legs(engine, device, n, steps):

@@ -33,6 +33,11 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
                                int64_t ldo, unsigned long long* stamps, int ablate, void* workspace,
                                int64_t workspace_bytes, void* stream);
 
+/* Launches of the persistent kernels issued by this process so far: which 0 = pairs_bf16_v8_kernel (the store kernel:
+ * kge_score_queries_multi, and kge_score_sp / _po / _sp_po with >= 1024 rows at d = 512), 1 = pairs_bf16_v8_rank_kernel
+ * (the counting kernel); -1 for any other `which`.  Tests use it to prove which kernel a product call reached. */
+int kge_debug_launch_count(int which);
+
 /* The matrix pipe alone (bench.py's `matrix_pipe_probe`): one workgroup of eight waves per compute unit, every wave
  * `iters` x 16 v_mfma_f32_32x32x16_bf16 on two independent accumulators from `operands` (8 waves x 4 x 1 KiB of bf16
  * values, 16-byte aligned, loaded once), nothing else.  Returns the launch's flops (time it with events on `stream`), or a

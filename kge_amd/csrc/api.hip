@@ -56,6 +56,7 @@ NextQ pairs_bf16_nextq(bool split, const Operand& A, const Operand* A2, const Op
                        int nbatch, void* qf, long long qstride_bytes);
 int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, long long n, long long m, const void* qf,
                            const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus);
+int v8_launch_count(int which);
 bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
 int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                       int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
@@ -220,10 +221,76 @@ static bool one_call_prepared(const kge_tables* t, const Operand& TG, int64_t n,
   return two_sided && m >= 2048 && n >= 256;
 }
 
+// ---- a one-call entry with MANY rows = a group of 512-row batches of the persistent kernel ------------------------
+// KgeModel.score_sp / score_po / score_sp_po with a large batch (kge_model.py:682-702, 749-789), the sub-batches of one
+// training batch (kge/job/train.py:595-610) and two-step evaluation (eval_entity_ranking.py:143-229) all arrive here as
+// ONE call.  At d = 512 against all entities (or a contiguous slice) rows [0, 512 L) are scored as L batches of ONE
+// launch of pairs_bf16_v8_kernel (score_pairs_bf16_v8.hip: persistent grid, two consumer waves per SIMD, each XCD
+// streaming its own table slice once for all L batches) behind ONE query-build launch; the n % 512 rows left go the way
+// a call of that size goes.  Same fragments, same chains: the bits of the single-batch kernels (tests:
+// test_gpu_queries.py::test_one_call_entry_with_many_rows_takes_the_persistent_kernel).  KGE_ONE_CALL_V8=0 switches the
+// route off, KGE_ONE_CALL_V8_MIN_ROWS (default 1024) moves the threshold.
+constexpr long long ONE_CALL_V8_ROWS = 512;
+
+static long long one_call_v8_min_rows() {
+  const char* e = getenv("KGE_ONE_CALL_V8_MIN_ROWS");
+  if (e && e[0]) {
+    const long long v = atoll(e);
+    if (v >= 2 * ONE_CALL_V8_ROWS) return v;
+  }
+  return 2 * ONE_CALL_V8_ROWS;
+}
+
+static Operand operand_from(const Operand& X, long long k, int esize) {
+  Operand r = X;
+  if (X.idx.ptr != nullptr)
+    r.idx.ptr = (const char*)X.idx.ptr + k * X.idx.stride * (X.idx.itype == KGE_I32 ? 4 : 8);
+  else
+    r.base = (const char*)X.base + k * X.ld * esize;  // dense rows (kge_score_emb): the rows themselves
+  return r;
+}
+
+// rows [0, 512 L) of the call; *done = 512 L.  KGE_ERR_UNSUPPORTED: not this route's case (nothing was launched).
+static int one_call_v8(const kge_tables* t, int dir, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG,
+                       int64_t n, int64_t m, float* out, int64_t ldo, int64_t b2, void* ws, int64_t ws_bytes, hipStream_t st,
+                       int64_t* done) {
+  *done = 0;
+  const char* e = getenv("KGE_ONE_CALL_V8");
+  if (e && e[0] == '0') return KGE_ERR_UNSUPPORTED;
+  if (t->dtype != KGE_BF16 || t->dim != 512 || TG.idx.ptr != nullptr || ws == nullptr || n < one_call_v8_min_rows())
+    return KGE_ERR_UNSUPPORTED;
+  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
+  if (t->scorer != KGE_COMPLEX && t->scorer != KGE_DISTMULT) return KGE_ERR_UNSUPPORTED;
+  const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0, two = A2 != nullptr;
+  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, 512, A, R, TG) ||
+      (two && !pairs_bf16_v4_supported(t->scorer, t->dtype, 512, *A2, R, TG)))
+    return KGE_ERR_UNSUPPORTED;
+  const long long L = n / ONE_CALL_V8_ROWS;
+  const long long per = pairs_bf16_v4_query_bytes(512, ONE_CALL_V8_ROWS, two, split);
+  if (L < 2 || L > (1 << 20) || ws_bytes < PAIRS_WS_CTRL_BYTES + L * per || (((uintptr_t)ws + PAIRS_WS_CTRL_BYTES) & 15))
+    return KGE_ERR_UNSUPPORTED;
+  void* const qf = (char*)ws + PAIRS_WS_CTRL_BYTES;
+  int rc = run_query_build_multi(t->scorer, split, A, A2, R, dir, 512, ONE_CALL_V8_ROWS, (int)L, qf, per, st);
+  if (rc != KGE_OK) return rc;
+  rc = run_pairs_bf16_v8(t->scorer, split, TG, two, 512, ONE_CALL_V8_ROWS, m, (int)L, qf, per, out, ONE_CALL_V8_ROWS * ldo,
+                         ldo, two ? b2 : 0, st, nullptr, NextQ{}, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
+  if (rc == KGE_OK) *done = L * ONE_CALL_V8_ROWS;
+  return rc;  // (UNSUPPORTED behind the build launch: the fragments are simply not used)
+}
+
 int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand& R,
                    const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo,
                    void* ws, int64_t ws_bytes, hipStream_t st) {
   const int d = (int)t->dim, dr = (int)t->rel_dim;
+  {  // many rows: groups of 512-row batches through the persistent kernel, the rest as a call of its own size
+    int64_t done = 0;
+    const int rc8 = one_call_v8(t, dir, A, nullptr, R, TG, n, m, out, ldo, 0, ws, ws_bytes, st, &done);
+    if (rc8 != KGE_ERR_UNSUPPORTED) {
+      if (rc8 != KGE_OK || done == n) return rc8;
+      return pairs_dispatch(t, dir, operand_from(A, done, 2), operand_from(R, done, 2), TG, n - done, m, out + done * ldo,
+                            ldo, ws, ws_bytes, st);
+    }
+  }
   if ((t->flags & KGE_FLAG_SPLIT_QUERY) && !(t->flags & KGE_FLAG_EXACT) && t->dtype == KGE_BF16) {
     // q = q_hi + q_lo on the matrix cores (f32-level parity on the bf16 tables); what the loader/consumer kernel
     // does not take runs the exact f32 chain with the query vector kept in f32 (KGE_FLAG_EXACT rounds it to bf16:
@@ -536,6 +603,20 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
       check_index(targets, true) == KGE_OK && (targets.ptr || m == t->num_ent)) {
     Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, targets);
     const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
+    {  // many rows: both blocks of 512-row batches from ONE launch of the persistent kernel (one_call_v8)
+      int64_t done = 0;
+      const int rc8 = one_call_v8(t, KGE_SP_, S, &O, P, TG, n, m, out, ldo, m, workspace, workspace_bytes,
+                                  (hipStream_t)stream, &done);
+      if (rc8 != KGE_ERR_UNSUPPORTED) {
+        if (rc8 != KGE_OK || done == n) return rc8;
+        auto from = [&](kge_index ix) {
+          ix.ptr = (const char*)ix.ptr + done * ix.stride * (ix.itype == KGE_I32 ? 4 : 8);
+          return ix;
+        };
+        return kge_score_sp_po(t, from(s), from(p), from(o), n - done, targets, m, out + done * ldo, ldo, workspace,
+                               workspace_bytes, stream);
+      }
+    }
     if (split) {  // q_hi + q_lo: one two-sided launch behind a builder launch
       const int rcs = split_sp_po(t, S, O, P, TG, n, m, out, ldo, workspace, workspace_bytes, (hipStream_t)stream);
       if (rcs != KGE_ERR_UNSUPPORTED) return rcs;
@@ -1650,6 +1731,8 @@ int kge_debug_sqrt_check(uint32_t first_bits, uint64_t count, uint64_t* mismatch
                      (unsigned long long)count, (unsigned long long*)mismatches, first16);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
+int kge_debug_launch_count(int which) { return kge::v8_launch_count(which); }
+
 double kge_debug_mfma_rate(const void* operands, int iters, float* sink, void* stream) {
   return kge::run_mfma_rate(operands, iters, sink, (hipStream_t)stream);
 }

@@ -79,7 +79,12 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
   constexpr int SMEM = NBUF * UNITB;      // 128 KiB
   constexpr int RW = SPLIT ? 16 : 32;     // real query rows per wave
   constexpr int NST = SPLIT ? 8 : 16;     // stores per unit and wave, in slots 0, 2, ..
-  constexpr int PF = 8;
+  // LDS reads in flight per wave.  Split queries: 4 -- the 16 registers eight cost were six spilled VGPRs in this
+  // instantiation (scratch reloads, each behind a compiler-made s_waitcnt vmcnt(0), at every pair boundary of a kernel
+  // whose table stream is ordered by counted waits); four slots of >= 32 cycles still cover the LDS latency, as in
+  // pairs_bf16_v8_rank_kernel.  (32 % PF == 0: a read issued in slot kb lands in bq[kb % PF] for slot kb + PF.)
+  constexpr int PF = SPLIT ? 4 : 8;
+  static_assert(NKB % PF == 0 && PF <= 8, "look-ahead depth");
   constexpr int FR0 = 12;  // query K-blocks requested before the first chain (cold start)
   // vector-memory operations a wave issues between the last piece of unit k + 1 (slot 29 of chain k - 2) and the wait
   // in slot V8_PB of chain k: the stores behind slot 29, chain k - 1 (stores + 4 pieces), the stores of slots < V8_PB
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
       int un = dq < g1 ? du : ulast;  // requested by this chain: the unit three ahead (cold: first the unit two ahead)
       v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
         constexpr int kb = decltype(kc)::value;
-        asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(PF - 1) : "memory");
         if constexpr (kb == V8_PB) {
           // this wave's pieces of unit ks + 1 have landed (cold: requested right behind R0; since then 7 stores, 14
           // fragment loads and unit 2's pieces of slots 1 - 13)
@@ -350,7 +355,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
     // return -- which is exactly why the registers must be kept: to the compiler an asm output is there at once and a
     // dead one is free at once (pairs_bf16_v7_kernel lost stores that way).  The empty asm "uses" them AFTER the wait.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4]), "v"(bq[5]), "v"(bq[6]), "v"(bq[7]));
+    if constexpr (PF == 8)
+      asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4]), "v"(bq[5]), "v"(bq[6]), "v"(bq[7]));
+    else
+      asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]));
     stamp_at(34);  // last store issued
   }
   // the NEXT group's query fragments: a slice per workgroup, behind its last unit
@@ -375,10 +383,15 @@ static int v8_cu_count() {
   return v;
 }
 
+// launches issued by this process (kge_debug_launch_count): 0 = pairs_bf16_v8_kernel, 1 = pairs_bf16_v8_rank_kernel
+static int g_v8_launches[2] = {0, 0};
+int v8_launch_count(int which) { return (which == 0 || which == 1) ? __atomic_load_n(&g_v8_launches[which], __ATOMIC_RELAXED) : -1; }
+
 template <int SCORER, int SPLIT>
 static int launch_v8(V8Args& a, int sc1, hipStream_t st) {
   int cus = v8_cu_count();
   (void)cus;
+  __atomic_fetch_add(&g_v8_launches[0], 1, __ATOMIC_RELAXED);
   const dim3 grid(8 * a.wpx), block(512);
   // cache policy of the score stores: 0 plain (write-back: the lines stay in the XCD's L2), 16 sc1 (write-through, the
   // line leaves the L2), 2 nt, 18 sc1 nt
@@ -445,7 +458,12 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
   // (tools/v8_policy_probe.py, profiles/r4_v8_policy.txt: a group's blocks beyond ~160 MB stream to HBM -- `nt` keeps
   // them from evicting the table slice from the L2: 22.0 -> 14.7 us per two-sided batch in a group of eight; up to
   // ~48 MB write-through wins by the end-of-kernel write-back it saves; in between it makes no difference)
-  const int sc1 = sc1e ? (sc1e[0] - '0') : (bytes > 160e6 ? 2 : ((st_aligned && bytes <= 48e6) ? 1 : 0));
+  // Rows that do not start on a 32-byte sector (a contiguous [n, E] block with E = 14,541: the one-call entries) leave
+  // a partial sector at both ends of every 128-byte row segment a store instruction writes; the neighbouring unit's
+  // store completes it one chain later -- in the L2, if the line is still there: plain write-back stores.  `nt` and
+  // write-through push the partial sector out and the memory side reads, merges and writes it (n = 2048 two-sided,
+  // 238 MB: 226 us with nt against 112 for the single-batch kernel's plain stores, tools/one_call_v8_probe.py).
+  const int sc1 = sc1e ? (sc1e[0] - '0') : (!st_aligned ? 0 : (bytes > 160e6 ? 2 : (bytes <= 48e6 ? 1 : 0)));
 #define KGE_V8L(SC) return split ? launch_v8<SC, 1>(a, sc1, st) : launch_v8<SC, 0>(a, sc1, st)
   if (scorer == KGE_COMPLEX) { KGE_V8L(KGE_COMPLEX); }
   if (scorer == KGE_DISTMULT) { KGE_V8L(KGE_DISTMULT); }
@@ -1001,6 +1019,7 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   else { if (split) KGE_V8R(SC, 128, 1); else KGE_V8R(SC, 128, 0); }
   if (scorer == KGE_COMPLEX) { KGE_V8R2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_V8R2(KGE_DISTMULT) }
   else return KGE_ERR_UNSUPPORTED;
+  __atomic_fetch_add(&g_v8_launches[1], 1, __ATOMIC_RELAXED);
 #undef KGE_V8R2
 #undef KGE_V8R
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;

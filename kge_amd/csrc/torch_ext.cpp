@@ -152,8 +152,13 @@ void build_queries_group(const at::Tensor& ent, const at::Tensor& rel, int64_t s
 }
 
 // out: [L, n, m] / [L, n, 2 m] (any row pitch, unit inner stride) or [L, n, 2, m]
+// next_*: the NEXT group's index vectors (num_batches * next_n entries each) and fragment buffer -- built by the same
+// launch behind its last unit (kge_next_queries); next_queries undefined: none
 void score_queries_group(const at::Tensor& ent, const at::Tensor& rel, int64_t scorer, int64_t flags, int64_t combine,
-                         const at::Tensor& queries, int64_t stride, int64_t n, int64_t num_batches, at::Tensor out) {
+                         const at::Tensor& queries, int64_t stride, int64_t n, int64_t num_batches, at::Tensor out,
+                         const c10::optional<at::Tensor>& next_s, const c10::optional<at::Tensor>& next_p,
+                         const c10::optional<at::Tensor>& next_o, int64_t next_n,
+                         const c10::optional<at::Tensor>& next_queries, int64_t next_stride) {
   const kge_tables t = tables_of(ent, rel, scorer, 1.0, flags);
   const int64_t m = t.num_ent;
   TORCH_CHECK_VALUE(out.is_cuda() && out.get_device() == ent.get_device() && out.scalar_type() == at::kFloat,
@@ -174,8 +179,25 @@ void score_queries_group(const at::Tensor& ent, const at::Tensor& rel, int64_t s
   if (n == 1 && ldo < need) ldo = need;
   TORCH_CHECK_VALUE(ldo >= need, "kge_amd: the rows of `out` overlap");
   kge_index all{nullptr, KGE_I64, 0, 1};
+  kge_next_queries nx{};
+  const kge_next_queries* nxp = nullptr;
+  std::vector<at::Tensor> keep;
+  if (next_queries.has_value() && next_queries->defined() && next_n > 0) {
+    const at::Tensor& nq = *next_queries;
+    TORCH_CHECK_VALUE(nq.is_cuda() && nq.is_contiguous() && nq.scalar_type() == at::kByte, "kge_amd: next_queries buffer");
+    int64_t len = -1;
+    nx.s = index_of(next_s, ent, keep, &len);
+    nx.p = index_of(next_p, ent, keep, &len);
+    nx.o = index_of(next_o, ent, keep, &len);
+    TORCH_CHECK_VALUE(len == next_n * num_batches, "kge_amd: the next group needs ", next_n * num_batches, " index entries, got ",
+                      len);
+    nx.n = next_n;
+    nx.queries = nq.data_ptr();
+    nx.queries_bytes = nq.numel();
+    nxp = &nx;
+  }
   check(kge_score_queries_multi(&t, (int)combine, queries.data_ptr(), stride, n, num_batches, all, m, out.data_ptr<float>(),
-                                num_batches > 1 ? out.stride(0) : 0, ldo, b2, nullptr, 0, stream_of(ent)),
+                                num_batches > 1 ? out.stride(0) : 0, ldo, b2, nxp, nxp ? next_stride : 0, stream_of(ent)),
         "kge_score_queries_multi");
 }
 

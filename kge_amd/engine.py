@@ -517,13 +517,33 @@ def score_queries_group(t: Tables, q: QueriesGroup, out: torch.Tensor, next_batc
     L, n = q.num_batches, q.n
     if out.dim() < 3 or out.shape[0] != L:
         raise ValueError(f"kge_amd: score_queries_group: `out` is [{L}, n, ...], one block per batch")
+    if next_batch is not None and (next_queries is None or next_queries.num_batches != L or
+                                   next_queries.combine != q.combine or next_queries.flags != q.flags):
+        raise ValueError("kge_amd: score_queries_group: next_queries does not match the next group")
+    ex = _ext()
+    if ex and stream is None and (next_batch is None or torch.is_tensor(next_batch) or
+                                  all(torch.is_tensor(x) for x in next_batch)):
+        # the torch extension (csrc/torch_ext.cpp): one C++ call, `out` validated there (ValueError), the next group's
+        # index vectors taken as tensors (a [L n, 3] triples tensor as its three strided columns)
+        if next_batch is None:
+            ns = np_ = no = nq = None
+            nn = nstride = 0
+        else:
+            if torch.is_tensor(next_batch):
+                if next_batch.dim() != 2 or next_batch.shape[1] != 3:
+                    raise ValueError("kge_amd: score_queries_group(next_batch): a triples tensor is [rows, 3]")
+                ns, np_, no = next_batch[:, 0], next_batch[:, 1], next_batch[:, 2]
+            else:
+                ns, np_, no = next_batch
+            nq, nn, nstride = next_queries.buf, next_queries.n, next_queries.stride
+        with _on_device(t.device):
+            ex.score_queries_group(t.ent, t.rel, t.scorer, t.flags if q.flags is None else q.flags, _COMBINE[q.combine],
+                                   q.buf, q.stride, n, L, out, ns, np_, no, nn, nq, nstride)
+        return out
     ldo, b2 = _check_score_out(t, out[0], n, m, q.combine, "score_queries_group")
     ostride = out.stride(0) if L > 1 else 0
     nxt, keep = None, []
     if next_batch is not None:
-        if next_queries is None or next_queries.num_batches != L or next_queries.combine != q.combine or \
-                next_queries.flags != q.flags:
-            raise ValueError("kge_amd: score_queries_group: next_queries does not match the next group")
         si, pi, oi = _group_index(next_batch, next_queries.n, L, t.device, keep, "score_queries_group(next_batch)")
         nxt = KgeNextQueries(si, pi, oi, next_queries.n, next_queries.buf.data_ptr(), next_queries.buf.numel())
     with _on_device(t.device):

