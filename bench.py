@@ -832,9 +832,13 @@ def main():
         if bad:
             return md, None, bad
         # the dominant kernel: HIP events on the launch stream around back-to-back full-group launches of ONE stream
-        launches = max(3, (max(a.steps, 40) + L - 1) // L)
-        k_ms = event_avg_ms(lambda: md.launch(L), launches, a.repeats)
-        return md, {"el": el, "regions": regions, "host": host_el, "launch_ms": k_ms, "lanes": md.lanes}, None
+        # SETTLED rate: >= 40 group launches back to back on one stream, no idle gap -- the same launch runs 25-45 %
+        # faster at the start of a burst than sustained (profiles/r4_rocprofv3_kernel_stats.txt, header), and a timed
+        # region of `steps` = 20 batches is 3 launches: a burst.  `roofline` uses this number.
+        launches = max(40, (a.steps + L - 1) // L)
+        k_ms = event_avg_ms(lambda: md.launch(L), launches, min(a.repeats, 3))
+        return md, {"el": el, "regions": regions, "host": host_el, "launch_ms": k_ms, "lanes": md.lanes,
+                    "settled_launches": launches}, None
 
     modes, res = {}, {}
     for key, flags, tag in (("parity", engine.FLAG_SPLIT_QUERY, "split-query"), ("training", None, "single-pass")):
@@ -869,6 +873,14 @@ def main():
                 "us_per_batch": r["launch_ms"] * 1e3 / L,
                 # the table counted once per LAUNCH instead of once per batch (SURVEY.md 8d counts it per call)
                 "frac_table_once_per_launch": (L * ab - (L - 1) * E_FB * DIM * 2) / (r["launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "measured_over": f"{r['settled_launches']} back-to-back group launches on one stream (settled; HIP events)",
+                # what holds the kernel: the split-query mode executes 2 x the algorithmic 2 n d m flops and is bound by
+                # the matrix pipe (profiles/r5_split_store_probe.txt: without its store instructions it is 13 % faster,
+                # no more); the single-pass mode by the HBM write path.  `frac` stays the HBM fraction north_star
+                # states its target in; the matrix-pipe view beside it: executed flops against the nominal dense peak
+                # and against what the bare pipe holds on this box on random operands (roofline_rank.matrix_pipe_probe)
+                "limited_by": "matrix pipe (2 x algorithmic flops executed)" if key == "parity" else "HBM write path",
+                "mfma_algorithmic_tflops": flops / (2 if key == "parity" else 1) / (r["launch_ms"] * 1e-3) / 1e12,
                 "mfma_executed_tflops": flops / (r["launch_ms"] * 1e-3) / 1e12,
                 "mfma_executed_frac": flops / (r["launch_ms"] * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF,
                 "score_row_pitch_floats": 2 * PITCH, "block2_offset_floats": PITCH,
@@ -924,6 +936,31 @@ def main():
                           "frac": ab1 / (one_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "one_call_entry_us": one_coop_ms * 1e3,
                           "one_call_entry_frac": ab1 / (one_coop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         del pipe, pipe1, out_pad, out1
+        # ---- the PRODUCT path: what KgeModel.score_sp / score_sp_po of the plugin executes -- engine.score_sp /
+        # score_sp_po = ONE call of kge_score_sp / kge_score_sp_po with index vectors, a fresh contiguous [n, E] /
+        # [n, 2E] block from torch's allocator (rows NOT sector-aligned: E = 14,541), both query modes.  n >= 1024 runs
+        # as groups of 512-row batches of pairs_bf16_v8_kernel behind one query-build launch (api.hip one_call_v8);
+        # n = 512: query-build launch + the single-batch kernel.  Settled: HIP events over back-to-back calls.
+        one_call = {"entry": "engine.score_sp / engine.score_sp_po (kge_amd._C -> kge_score_sp / kge_score_sp_po), "
+                             "contiguous output rows, allocation inside the timed calls"}
+        for mode_key, md in modes.items():
+            leg = {}
+            for nn in (512, 2048, 4096):
+                q = torch.Generator().manual_seed(1000 + nn)
+                sn, pn, on = (torch.randint(hi, (nn,), generator=q).to(device) for hi in (E_FB, R_FB, E_FB))
+                row = {}
+                for name, call, sides in (("score_sp", lambda: engine.score_sp(md.T, sn, pn), 1),
+                                          ("score_sp_po", lambda: engine.score_sp_po(md.T, sn, pn, on), 2)):
+                    for _ in range(3):
+                        call()
+                    ms = event_avg_ms(call, max(10, min(a.steps, 40)), 3)
+                    abn = algorithmic_bytes(nn, E_FB, DIM, sides=sides)
+                    row[name] = {"us_per_call": ms * 1e3, "frac": abn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "scored_triples_per_s": sides * nn * E_FB / (ms * 1e-3)}
+                leg[str(nn)] = row
+                torch.cuda.empty_cache()
+            one_call[mode_key] = leg
+        extra["one_call_entry"] = one_call
         # ---- groups of one-sided batches (score_sp alone: north_star quotes its target on score_sp)
         g1 = {}
         for key, md in modes.items():
@@ -1010,6 +1047,12 @@ def main():
         "metric": "scored triples/sec (1vsAll, ComplEx d=512)",
         "value": total / rp["el"],
         "unit": "scored triples/s",
+        # `value` / `ms_per_step` come from the contract's timed region: K = `steps` batches = ceil(K / group) launches
+        # behind an idle gap -- a BURST (the first launches of a burst run 25-45 % faster than sustained issue).
+        # `value_settled` is the same step at the settled rate: the average of >= 40 back-to-back group launches.
+        "value_kind": f"burst: {a.steps} steps = {(a.steps + L - 1) // L} group launch(es) per timed region",
+        "value_settled": 2.0 * n * E_FB * L / (rp["launch_ms"] * 1e-3),
+        "ms_per_step_settled": rp["launch_ms"] / L,
         "value_mode": "parity-compliant: split queries (q = q_hi + q_lo on the matrix cores; ranks equal to float32 "
                       "arithmetic on the bf16 tables up to its summation noise).  The single-pass mode is "
                       "`training_tolerance` below",
@@ -1045,6 +1088,8 @@ def main():
         # evaluation would move against float32 arithmetic on the same tables)
         "training_tolerance": {
             "value": total / rt["el"], "unit": "scored triples/s", "ms_per_step": rt["el"] / a.steps * 1e3,
+            "value_kind": "burst (see value_kind)", "value_settled": 2.0 * n * E_FB * L / (rt["launch_ms"] * 1e-3),
+            "ms_per_step_settled": rt["launch_ms"] / L,
             "regions_ms_per_step": [r / a.steps * 1e3 for r in rt["regions"]],
             "host_issue_ms_per_step": rt["host"] / a.steps * 1e3, "group_launches_in_flight": rt["lanes"],
             "roofline": {**roofline_of("training", "pairs_bf16_v8_kernel<ComplEx> (kge_score_queries_multi: one "

@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of libkge_amd.so (include/kge_amd.h): argument validation and
 // kernel selection.  No torch, no allocation, no global state; every call enqueues on the
 // caller's hipStream_t and returns a kge_status.
+#include <dlfcn.h>
 #include "common.hpp"
 #include "bf16_queries.hpp"
 #include <cstdlib>
@@ -160,6 +161,41 @@ int run_ce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
 using namespace kge;
 
 namespace {
+
+// ---- profiler ranges: KGE_ROCTX=1 puts a roctx range around every entry point of the C ABI, so
+// that a `rocprofv3 --marker-trace --kernel-trace` of a LibKGE job attributes kernels and host time per call the way the
+// reference's own timing buckets do per batch (kge/job/train.py:347-350, 536-557: prepare / forward / backward /
+// optimizer).  libroctx64.so is opened on first use; without the variable (or the library) a range is two loads.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    const char* e = getenv("KGE_ROCTX");
+    if (!e || e[0] != '1') return;
+    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return;
+    push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+static const RoctxApi& roctx_api() {
+  static const RoctxApi api;
+  return api;
+}
+struct RoctxRange {
+  const bool on;
+  explicit RoctxRange(const char* name) : on(roctx_api().push != nullptr) {
+    if (on) roctx_api().push(name);
+  }
+  ~RoctxRange() {
+    if (on) roctx_api().pop();
+  }
+};
+#define KGE_RANGE() RoctxRange kge_roctx_range_(__func__)
+
 
 int check_tables(const kge_tables* t, bool need_ptrs) {
   if (!t) return KGE_ERR_INVALID_ARG;
@@ -399,6 +435,7 @@ int kge_device_count(void) {
 
 int kge_score_spo(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
                   float* out, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (n < 0 || (!out && n > 0)) return KGE_ERR_INVALID_ARG;
@@ -454,6 +491,7 @@ static int query_operands(const kge_tables* t, int combine, const kge_index& s, 
 
 int kge_build_queries(const kge_tables* t, int combine, kge_index s, kge_index p, kge_index o, int64_t n,
                       void* queries, int64_t queries_bytes, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
@@ -471,6 +509,7 @@ int kge_build_queries(const kge_tables* t, int combine, kge_index s, kge_index p
 
 int kge_score_queries(const kge_tables* t, int combine, const void* queries, int64_t n, kge_index targets, int64_t m,
                       float* out, int64_t ldo, int64_t block2_offset, const kge_next_queries* next, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
@@ -512,6 +551,7 @@ int kge_score_queries(const kge_tables* t, int combine, const void* queries, int
 int kge_build_queries_multi(const kge_tables* t, int combine, kge_index s, kge_index p, kge_index o, int64_t n,
                             int64_t num_batches, void* queries, int64_t queries_stride, int64_t queries_bytes,
                             void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
@@ -534,6 +574,7 @@ int kge_score_queries_multi(const kge_tables* t, int combine, const void* querie
                             int64_t num_batches, kge_index targets, int64_t m, float* out, int64_t out_stride,
                             int64_t ldo, int64_t block2_offset, const kge_next_queries* next, int64_t next_stride,
                             void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (combine != KGE_SP_ && combine != KGE_PO_ && combine != KGE_SP_PO) return KGE_ERR_INVALID_ARG;
@@ -581,18 +622,21 @@ int kge_score_queries_multi(const kge_tables* t, int combine, const void* querie
 int kge_score_sp(const kge_tables* t, kge_index s, kge_index p, int64_t n, kge_index targets,
                  int64_t m, float* out, int64_t ldo, void* workspace, int64_t workspace_bytes,
                  void* stream) {
+  KGE_RANGE();
   return pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, workspace, workspace_bytes, stream);
 }
 
 int kge_score_po(const kge_tables* t, kge_index p, kge_index o, int64_t n, kge_index targets,
                  int64_t m, float* out, int64_t ldo, void* workspace, int64_t workspace_bytes,
                  void* stream) {
+  KGE_RANGE();
   return pairs_entry(t, KGE_PO_, o, p, n, targets, m, out, ldo, workspace, workspace_bytes, stream);
 }
 
 int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
                     kge_index targets, int64_t m, float* out, int64_t ldo, void* workspace,
                     int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   if (ldo < 2 * m) return KGE_ERR_INVALID_ARG;
   // one two-sided launch of the loader/consumer kernel when it applies: the query build, the
   // kernel start-up and the launch overhead are paid once for both score blocks
@@ -653,6 +697,7 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
 int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
                   int slot, const void* neg, int32_t neg_itype, int64_t neg_ld,
                   int64_t num_neg, float* out, int64_t ldo, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (n < 0 || num_neg < 0 || (slot != 0 && slot != 2)) return KGE_ERR_INVALID_ARG;
@@ -672,6 +717,7 @@ int kge_score_neg(const kge_tables* t, kge_index s, kge_index p, kge_index o, in
 // ---- LookupEmbedder.embed: gathered entity rows and relation rows of a batch, one launch
 int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_out, int64_t ent_ldo,
               kge_index rel_idx, int64_t n_rel, void* rel_out, int64_t rel_ldo, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (n_ent < 0 || n_rel < 0 || (n_ent > 0 && !ent_out) || (n_rel > 0 && !rel_out)) return KGE_ERR_INVALID_ARG;
@@ -696,6 +742,7 @@ int kge_embed(const kge_tables* t, kge_index ent_idx, int64_t n_ent, void* ent_o
 
 int kge_ns_bce_loss(const float* scores, int64_t ld, int64_t n, int64_t c, int kind, float offset, float temperature,
                     float* loss_rows, float* grad, int64_t ldg, void* stream) {
+  KGE_RANGE();
   if (n < 0 || c < 1 || kind < 0 || kind > 2 || ld < c || (grad && ldg < c)) return KGE_ERR_INVALID_ARG;
   if (n > 0 && (!scores || !loss_rows)) return KGE_ERR_INVALID_ARG;
   if (kind != 0 && c < 2) return KGE_ERR_INVALID_ARG;  // the mean / adversarial forms need a negative
@@ -704,6 +751,7 @@ int kge_ns_bce_loss(const float* scores, int64_t ld, int64_t n, int64_t c, int k
 
 int kge_shard_gather(const kge_tables* t, int64_t lo, const kge_index* ids, int num_ids, int64_t n, void* send,
                      int64_t send_ld, kge_index rel_idx, void* rel_out, int64_t rel_ldo, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (num_ids < 1 || num_ids > 2 || !ids || n < 0 || (n > 0 && !send) || lo < 0) return KGE_ERR_INVALID_ARG;
@@ -736,6 +784,7 @@ int kge_shard_gather(const kge_tables* t, int64_t lo, const kge_index* ids, int 
 
 int kge_shard_pick(const void* gathered, int64_t ld, int dtype, int64_t dim, int64_t shard_rows, int world,
                    const kge_index* ids, int num_ids, int64_t n, void* rows, int64_t rows_ld, void* stream) {
+  KGE_RANGE();
   if (num_ids < 1 || num_ids > 2 || !ids || n < 0 || world < 1 || shard_rows < 1 || dim < 1 ||
       (dtype != KGE_BF16 && dtype != KGE_F32) || (n > 0 && (!gathered || !rows)))
     return KGE_ERR_INVALID_ARG;
@@ -765,6 +814,7 @@ int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s
                   const void* p_emb, int64_t p_ld, const void* o_emb, int64_t o_ld, int64_t n,
                   int64_t m, float* out, int64_t ldo, void* workspace, int64_t workspace_bytes,
                   void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, false);
   if (rc) return rc;
   if (!s_emb || !p_emb || !o_emb || n < 0 || m < 0) return KGE_ERR_INVALID_ARG;
@@ -788,6 +838,7 @@ int kge_score_emb(const kge_tables* t, int combine, const void* s_emb, int64_t s
 int kge_score_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb, int64_t p_ld,
                         const void* o_emb, int64_t o_ld, int64_t n, const void* tgt_emb, int64_t tgt_ld, int64_t m,
                         float* out, int64_t ldo, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   return kge_score_emb_sp_po_blocks(t, s_emb, s_ld, p_emb, p_ld, o_emb, o_ld, n, tgt_emb, tgt_ld, m, out, ldo, m, workspace,
                                     workspace_bytes, stream);
 }
@@ -796,6 +847,7 @@ int kge_score_emb_sp_po_blocks(const kge_tables* t, const void* s_emb, int64_t s
                                const void* o_emb, int64_t o_ld, int64_t n, const void* tgt_emb, int64_t tgt_ld, int64_t m,
                                float* out, int64_t ldo, int64_t block2_offset, void* workspace, int64_t workspace_bytes,
                                void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, false);
   if (rc) return rc;
   if (!s_emb || !p_emb || !o_emb || !tgt_emb || n < 0 || m < 0) return KGE_ERR_INVALID_ARG;
@@ -840,6 +892,7 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
                     const float* true_scores, const int64_t* lbl_rowptr,
                     const int64_t* lbl_col, int64_t col_offset, const int64_t* true_col,
                     float atol, float rtol, int64_t* rank, int64_t* ties, void* stream) {
+  KGE_RANGE();
   if (n < 0 || c < 0 || lds < c) return KGE_ERR_INVALID_ARG;
   if (n * c > 0 && (!scores || !true_scores || !rank || !ties)) return KGE_ERR_INVALID_ARG;
   if (lbl_rowptr && !lbl_col) return KGE_ERR_INVALID_ARG;
@@ -851,6 +904,7 @@ int kge_rank_counts(const float* scores, int64_t lds, int64_t n, int64_t c,
 
 int kge_filter_lookup(const int64_t* sorted_keys, int64_t num_keys, const int64_t* starts, kge_index a,
                       kge_index b, int64_t mult, int64_t n, int64_t* begin, int64_t* end, void* stream) {
+  KGE_RANGE();
   if (n < 0 || num_keys < 0) return KGE_ERR_INVALID_ARG;
   if (n > 0 && (!begin || !end || (num_keys > 0 && (!sorted_keys || !starts)))) return KGE_ERR_INVALID_ARG;
   int rc;
@@ -860,6 +914,7 @@ int kge_filter_lookup(const int64_t* sorted_keys, int64_t num_keys, const int64_
 }
 
 int kge_filter_lookup_multi(const kge_filter_query* queries, int num_queries, int64_t n, void* stream) {
+  KGE_RANGE();
   if (n < 0 || num_queries < 0 || (num_queries > 0 && !queries)) return KGE_ERR_INVALID_ARG;
   if (num_queries > KGE_MAX_FILTER_QUERIES) return KGE_ERR_UNSUPPORTED;
   const long long *keys[KGE_MAX_FILTER_QUERIES], *starts[KGE_MAX_FILTER_QUERIES];
@@ -883,6 +938,7 @@ int kge_rank_counts_multi(const float* scores, int64_t lds, int64_t n, int64_t c
                           int num_filters, const int64_t* const* lbl_begin, const int64_t* const* lbl_end,
                           const int64_t* const* lbl_col, int64_t col_offset, const int64_t* true_col,
                           float atol, float rtol, int64_t* rank, int64_t* ties, void* stream) {
+  KGE_RANGE();
   if (n < 0 || c < 0 || lds < c || num_filters < 0) return KGE_ERR_INVALID_ARG;
   if (num_filters > KGE_MAX_FILTERS) return KGE_ERR_UNSUPPORTED;
   if (n * c > 0 && (!scores || !true_scores || !rank || !ties)) return KGE_ERR_INVALID_ARG;
@@ -1098,6 +1154,7 @@ int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_inde
                          float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po,
                          int64_t* ties_po, int64_t ld, void* filter_bits, int64_t filter_bits_bytes, void* workspace,
                          int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (n < 0 || m < 0 || col_begin < 0 || col_begin + m > t->num_ent) return KGE_ERR_INVALID_ARG;
@@ -1120,6 +1177,7 @@ int kge_score_rank_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_l
                              const int64_t* const* po_col, float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp,
                              int64_t* rank_po, int64_t* ties_po, int64_t ld, void* filter_bits,
                              int64_t filter_bits_bytes, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, false);
   if (rc) return rc;
   if (n < 0 || m < 0 || col_begin < 0) return KGE_ERR_INVALID_ARG;
@@ -1154,6 +1212,7 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
                    float* hist, int64_t ldh, int64_t* ranks_o, int64_t* ranks_s, void* filter_bits,
                    int64_t filter_bits_bytes, void* scratch, int64_t scratch_bytes, void* workspace,
                    int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (n < 0 || num_filters < 0 || ldh < t->num_ent) return KGE_ERR_INVALID_ARG;
@@ -1271,6 +1330,7 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
 
 int kge_rank_hist(const int64_t* rank, const int64_t* ties, int num_rankings, int64_t n, int tie_policy,
                   float* hist, int64_t ldh, int64_t num_ent, int64_t* ranks_out, void* stream) {
+  KGE_RANGE();
   if (num_rankings < 0 || n < 0 || num_ent < 0 || ldh < num_ent) return KGE_ERR_INVALID_ARG;
   if (tie_policy < KGE_TIES_ROUNDED_MEAN || tie_policy > KGE_TIES_WORST) return KGE_ERR_INVALID_ARG;
   if ((int64_t)num_rankings * n > 0 && (!rank || !ties || !hist)) return KGE_ERR_INVALID_ARG;
@@ -1287,6 +1347,7 @@ int kge_score_pairs_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
                         kge_index targets, int64_t m, const float* gout, int64_t ldg,
                         const float* scores, int64_t lds, float* g_a, float* g_p, float* g_tgt,
                         void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (t->dtype == KGE_BF16) {  // mixed precision: ComplEx / DistMult on the bf16 matrix cores
@@ -1340,6 +1401,7 @@ int64_t kge_ce_workspace_bytes(const kge_tables* t, int64_t n) {
 
 int kge_ce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index label, int64_t n,
                float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   const int rc = ce_check(t, dir, a, p, label, n);
   if (rc) return rc;
   if (n > 0 && (!loss_rows || !lse)) return KGE_ERR_INVALID_ARG;
@@ -1351,6 +1413,7 @@ int kge_ce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index
 int kge_ce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, kge_index label, int64_t n,
                const float* lse, const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt,
                void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   const int rc = ce_check(t, dir, a, p, label, n);
   if (rc) return rc;
   if (n > 0 && (!lse || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
@@ -1383,6 +1446,7 @@ int ce_emb_check(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld,
 int kge_ce_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
                    kge_index label, int64_t n, float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes,
                    void* stream) {
+  KGE_RANGE();
   Operand A, R, TG;
   const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, label, n, A, R, TG);
   if (rc) return rc;
@@ -1394,6 +1458,7 @@ int kge_ce_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_l
 int kge_ce_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
                    kge_index label, int64_t n, const float* lse, const float* g_rows, float g_scalar, float* g_a,
                    float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   Operand A, R, TG;
   const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, label, n, A, R, TG);
   if (rc) return rc;
@@ -1408,6 +1473,7 @@ int kge_kl_weighted_emb_fwd(const kge_tables* t, int dir, const void* a_rows, in
                             int64_t p_ld, int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo,
                             const float* label_weight, float* loss_rows, float* lse, void* workspace,
                             int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   Operand A, R, TG;
   const kge_index none = {nullptr, 0, 0, 1};
   const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, none, n, A, R, TG);
@@ -1423,6 +1489,7 @@ int kge_kl_weighted_emb_bwd(const kge_tables* t, int dir, const void* a_rows, in
                             const float* label_weight, const float* label_bias, const float* lse, const float* g_rows,
                             float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
                             int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   Operand A, R, TG;
   const kge_index none = {nullptr, 0, 0, 1};
   const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, none, n, A, R, TG);
@@ -1436,6 +1503,7 @@ int kge_kl_weighted_emb_bwd(const kge_tables* t, int dir, const void* a_rows, in
 int kge_bce_emb_fwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_ld, const void* p_rows, int64_t p_ld,
                     int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo, float offset,
                     float* loss_rows, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   Operand A, R, TG;
   const kge_index none = {nullptr, 0, 0, 1};
   const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, none, n, A, R, TG);
@@ -1450,6 +1518,7 @@ int kge_bce_emb_bwd(const kge_tables* t, int dir, const void* a_rows, int64_t a_
                     int64_t n, const int64_t* lbl_rowptr, const int64_t* lbl_col, int64_t col_lo, float offset,
                     const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
                     int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   Operand A, R, TG;
   const kge_index none = {nullptr, 0, 0, 1};
   const int rc = ce_emb_check(t, dir, a_rows, a_ld, p_rows, p_ld, none, n, A, R, TG);
@@ -1467,6 +1536,7 @@ int64_t kge_ce_sp_po_workspace_bytes(const kge_tables* t, int64_t n) {
 
 int kge_ce_sp_po_fwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, float* loss_rows,
                      float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   int rc = ce_check(t, KGE_SP_, s, p, o, n);
   if (rc) return rc;
   if (n > 0 && (!loss_rows || !lse)) return KGE_ERR_INVALID_ARG;
@@ -1478,6 +1548,7 @@ int kge_ce_sp_po_fwd(const kge_tables* t, kge_index s, kge_index p, kge_index o,
 int kge_ce_sp_po_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, const float* lse,
                      const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt, void* workspace,
                      int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   int rc = ce_check(t, KGE_SP_, s, p, o, n);
   if (rc) return rc;
   if (n > 0 && (!lse || !g_a || !g_p || !g_tgt)) return KGE_ERR_INVALID_ARG;
@@ -1490,6 +1561,7 @@ int kge_ce_sp_po_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o,
 int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, const float* lse,
                            const float* g_rows, float g_scalar, float* grad_ent, float* grad_rel, void* workspace,
                            int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   int rc = ce_check(t, KGE_SP_, s, p, o, n);
   if (rc) return rc;
   if (!grad_ent || !grad_rel || (n > 0 && !lse)) return KGE_ERR_INVALID_ARG;
@@ -1502,6 +1574,7 @@ int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_in
 int kge_kl_weighted_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
                         const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
                         float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   const kge_index none = {nullptr, 0, 0, 1};
   int rc = check_tables(t, true);
   if (rc) return rc;
@@ -1519,6 +1592,7 @@ int kge_kl_weighted_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
                         const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
                         const float* label_bias, const float* lse, const float* g_rows, float g_scalar, float* g_a, float* g_p,
                         float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   const kge_index none = {nullptr, 0, 0, 1};
   int rc = check_tables(t, true);
   if (rc) return rc;
@@ -1536,6 +1610,7 @@ int kge_kl_weighted_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
 int kge_kl_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,
                const int64_t* lbl_col, float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes,
                void* stream) {
+  KGE_RANGE();
   const kge_index none = {nullptr, 0, 0, 1};
   int rc = check_tables(t, true);
   if (rc) return rc;
@@ -1552,6 +1627,7 @@ int kge_kl_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n
 int kge_kl_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,
                const int64_t* lbl_col, const float* lse, const float* g_rows, float g_scalar, float* g_a,
                float* g_p, float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   const kge_index none = {nullptr, 0, 0, 1};
   int rc = check_tables(t, true);
   if (rc) return rc;
@@ -1567,6 +1643,7 @@ int kge_kl_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n
 
 int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t count, float minus_clr,
                      float weight_decay, float eps, void* bf16_copy, void* stream) {
+  KGE_RANGE();
   if (count < 0 || (count > 0 && (!param || !grad || !state_sum))) return KGE_ERR_INVALID_ARG;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)state_sum) & 15) return KGE_ERR_INVALID_ARG;
   if (bf16_copy && ((uintptr_t)bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
@@ -1577,6 +1654,7 @@ int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t 
 int kge_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float step_size,
                   float bias_correction2_sqrt, double beta1, double beta2, float weight_decay, float eps,
                   void* bf16_copy, void* stream) {
+  KGE_RANGE();
   if (count < 0 || (count > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return KGE_ERR_INVALID_ARG;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return KGE_ERR_INVALID_ARG;
   if (bf16_copy && ((uintptr_t)bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
@@ -1590,6 +1668,7 @@ int kge_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int kge_adagrad_step_rows(float* param, int64_t param_ld, const float* grad_rows, int64_t grad_ld, float* state_sum,
                           int64_t sum_ld, const int64_t* rows, int64_t num_rows, int64_t dim, float minus_clr,
                           float eps, void* bf16_copy, int64_t copy_ld, void* stream) {
+  KGE_RANGE();
   if (num_rows < 0 || dim < 0 || dim > 0x7fffffff) return KGE_ERR_INVALID_ARG;
   if (num_rows > 0 && dim > 0 && (!param || !grad_rows || !state_sum || !rows)) return KGE_ERR_INVALID_ARG;
   if (param_ld < dim || grad_ld < dim || sum_ld < dim || (bf16_copy && copy_ld < dim)) return KGE_ERR_INVALID_ARG;
@@ -1600,6 +1679,7 @@ int kge_adagrad_step_rows(float* param, int64_t param_ld, const float* grad_rows
 int kge_bce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,
                 const int64_t* lbl_col, float offset, float* loss_rows, void* workspace, int64_t workspace_bytes,
                 void* stream) {
+  KGE_RANGE();
   const kge_index none = {nullptr, 0, 0, 1};
   int rc = check_tables(t, true);
   if (rc) return rc;
@@ -1616,6 +1696,7 @@ int kge_bce_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
 int kge_bce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,
                 const int64_t* lbl_col, float offset, const float* g_rows, float g_scalar, float* g_a, float* g_p,
                 float* g_tgt, void* workspace, int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
   const kge_index none = {nullptr, 0, 0, 1};
   int rc = check_tables(t, true);
   if (rc) return rc;
@@ -1632,6 +1713,7 @@ int kge_bce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
 int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
                       const float* gout, const float* scores, float* g_s, float* g_p, float* g_o,
                       void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
@@ -1646,6 +1728,7 @@ int kge_score_spo_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o
 int kge_score_spo_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
                             const float* gout, const float* scores, float* grad_ent, int64_t grad_ent_ld,
                             float* grad_rel, int64_t grad_rel_ld, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
@@ -1663,6 +1746,7 @@ int kge_score_neg_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_i
                             int64_t num_neg, const float* gout, int64_t ldg, const float* scores,
                             int64_t lds, float* grad_ent, int64_t grad_ent_ld, float* grad_rel,
                             int64_t grad_rel_ld, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
   if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
@@ -1682,6 +1766,7 @@ int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64
                       const void* p_emb, int64_t p_ld, const void* o_emb, int64_t o_ld, int64_t n,
                       int64_t m, const float* gout, int64_t ldg, const float* scores, int64_t lds,
                       float* g_s, float* g_p, float* g_o, void* stream) {
+  KGE_RANGE();
   int rc = check_tables(t, false);
   if (rc) return rc;
   if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;

@@ -69,7 +69,7 @@ struct V8Args {
 #define KGE_V8_DMA(D, VO, P) \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0")
 
-template <int SCORER, int SPLIT, int AUX>
+template <int SCORER, int SPLIT, int AUX, int VAR = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
   constexpr int HH = 256;
   constexpr int NKB = 2 * HH / 16;        // 32 K-blocks of 16
@@ -207,7 +207,11 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
         const float lo = acc[r + 4];
         v = v + lo;  // score = (sum q_hi t) + (sum q_lo t)
       }
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), srs, vr, colb, AUX);
+      if constexpr (VAR & 1) {  // PROBE: the score computed, the store instruction left out
+        asm volatile("" : : "v"(v), "v"(vr));
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), srs, vr, colb, AUX);
+      }
     };
     // per-lane offset of the unit at slice position `cu`: out of range for the columns >= m of the ragged last unit
     auto unit_vo = [&](int cu, unsigned int& colb) __attribute__((always_inline)) -> unsigned int {
@@ -395,6 +399,18 @@ static int launch_v8(V8Args& a, int sc1, hipStream_t st) {
   const dim3 grid(8 * a.wpx), block(512);
   // cache policy of the score stores: 0 plain (write-back: the lines stay in the XCD's L2), 16 sc1 (write-through, the
   // line leaves the L2), 2 nt, 18 sc1 nt
+#ifdef KGE_V8_PROBES
+  // PROBE build only (make CXXEXTRA=-DKGE_V8_PROBES; tools/split_var_probe.py): KGE_V8_VAR=1 = the split-query kernel with
+  // its store INSTRUCTIONS compiled out (profiles/r5_split_store_probe.txt: 222 -> 194 us per group of eight two-sided
+  // batches -- the stores cost 13 %, the rest of the distance to the bare matrix pipe is not theirs)
+  if constexpr (SCORER == KGE_COMPLEX && SPLIT == 1) {
+    const char* ve = getenv("KGE_V8_VAR");
+    if (ve && ve[0] == '1') {
+      hipLaunchKernelGGL((pairs_bf16_v8_kernel<SCORER, SPLIT, 2, 1>), grid, block, 0, st, a);
+      return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+    }
+  }
+#endif
   if (sc1 == 1)
     hipLaunchKernelGGL((pairs_bf16_v8_kernel<SCORER, SPLIT, 16>), grid, block, 0, st, a);
   else if (sc1 == 2)
