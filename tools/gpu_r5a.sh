@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5, first lease: the whole -m gpu suite (no -x: see every failure), smoke, a default bench line
 set -u
-OUT=gpurun_out/r5a
+OUT=gpurun_out/${1:-r5a}
 mkdir -p $OUT
 export TMPDIR=/tmp
 export KGE_PLUGIN_LOG=$OUT/libkge_plugin_gpu.jsonl
@@ -14,8 +14,8 @@ tail -n 2 $OUT/smoke.log
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit: $?" >> $OUT/env.log
 cat $OUT/env.log
-python - <<'PY'
+python - ${1:-r5a} <<'PY'
 import json
-d = json.load(open("gpurun_out/r5a/bench.json"))
+import sys; d = json.load(open(f"gpurun_out/{sys.argv[1]}/bench.json"))
 print({k: d[k] for k in ("value", "ms_per_step")}, d["roofline"]["frac"], d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"])
 PY

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""The split-query group launch (8 two-sided batches, FB15k-237 shape) under KGE_V8_VAR variants and store policies:
-us per launch by HIP events over back-to-back launches on one stream."""
+"""The split-query group launch (8 two-sided batches, FB15k-237 shape) under variants and store policies: us per launch
+by HIP events over back-to-back launches on one stream.  Arguments = variants: "x4=0" / "x4=1" (KGE_V8_X4: dword stores /
+16-byte stores of the split-query kernel), "var=1" (KGE_V8_VAR=1, a -DKGE_V8_PROBES build: store instructions left out)."""
 import json
 import os
 import sys
@@ -19,7 +20,7 @@ P = engine.score_pitch(E)
 g = torch.Generator().manual_seed(0)
 ent = torch.empty(E, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
 rel = torch.empty(R, D).normal_(0, 0.1, generator=g).bfloat16().to(dev)
-variants = sys.argv[1:] or ["0", "1"]
+variants = sys.argv[1:] or ["x4=0", "x4=1"]
 for split in (1, 0):
     fl = engine.FLAG_SPLIT_QUERY if split else None
     T = engine.Tables("complex", ent, rel, flags=fl or 0)
@@ -37,7 +38,10 @@ for split in (1, 0):
     for rep in range(2):
         for var in variants:
             for pol in (None, "0", "1", "2"):
-                os.environ["KGE_V8_VAR"] = var
+                key, val = var.split("=")
+                os.environ.pop("KGE_V8_VAR", None)
+                os.environ.pop("KGE_V8_X4", None)
+                os.environ["KGE_V8_" + key.upper()] = val
                 if pol is None:
                     os.environ.pop("KGE_V4_STORE_SC1", None)
                 else:
@@ -46,4 +50,5 @@ for split in (1, 0):
                 print(json.dumps({"split": split, "var": var, "policy": pol or "default", "rep": rep, "us_per_launch": round(us, 1),
                                   "us_per_batch": round(us / L, 2)}), flush=True)
     os.environ.pop("KGE_V8_VAR", None)
+    os.environ.pop("KGE_V8_X4", None)
     os.environ.pop("KGE_V4_STORE_SC1", None)
