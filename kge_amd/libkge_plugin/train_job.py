@@ -43,6 +43,50 @@ from kge.job.train_negative_sampling import TrainingJobNegativeSampling, S, P, O
 from kge.util.loss import BCEWithLogitsKgeLoss, KLDivWithSoftmaxKgeLoss
 
 
+def _optimizer_is_capturable(opt) -> bool:
+    """Only optimizers whose captured step() replays correctly: kge_amd.optim.Adagrad says so itself (without lr_decay),
+    HipAdam says no (host-computed bias correction would be frozen at the capture step), of torch's own only SGD."""
+    return (all(g.get("lr_decay", 0) == 0 for g in opt.param_groups)
+            and bool(getattr(opt, "graph_capturable", type(opt) is torch.optim.SGD)))
+
+
+def _no_penalty(job, batch_index, batch) -> bool:
+    """A penalty term back-propagates between the batch and the optimizer's step: such a job stays eager."""
+    try:
+        return len(job.model.penalty(epoch=job.epoch, batch_index=batch_index, num_batches=len(job.loader),
+                                     batch=batch)) == 0
+    except Exception:
+        return False
+
+
+def _graphed_step_of(job, loss_fn):
+    """kge_amd.train_graph.GraphedStep over `loss_fn` and the job's optimizer.  TrainingJob.run_epoch
+    (kge/job/train.py:452-474) calls optimizer.step() itself after the batch: a batch that went through the GraphedStep
+    (replayed or eager) has taken that step already, so the job's optimizer skips exactly that one call
+    (`job._skip_optimizer_step`)."""
+    from kge_amd.train_graph import GraphedStep
+    opt = job.optimizer
+    real_step = opt.step
+
+    class _Opt:  # what GraphedStep needs of the optimizer, with the REAL step
+        param_groups = opt.param_groups
+        zero_grad = staticmethod(opt.zero_grad)
+        step = staticmethod(real_step)
+        graph_capturable = True  # (the caller checked the real optimizer: _optimizer_is_capturable)
+        after_graph_replay = staticmethod(getattr(opt, "after_graph_replay", lambda params: None))
+
+    def step_or_skip(*a, **k):
+        if job._skip_optimizer_step:
+            job._skip_optimizer_step = False
+            opt._opt_called = True  # (what a learning-rate scheduler's wrapper of step() records)
+            return None
+        return real_step(*a, **k)
+    if hasattr(real_step, "_wrapped_by_lr_sched"):  # torch's schedulers look for their mark on step()
+        step_or_skip._wrapped_by_lr_sched = True
+    opt.step = step_or_skip
+    return GraphedStep(loss_fn, _Opt, warmup=2)
+
+
 class _CudaOomText:
     """TrainingJob.run_epoch halves `train.subbatch_size` when a batch fails with a RuntimeError whose text contains
     "CUDA out of memory" (train.subbatch_auto_tune, kge/job/train.py:384-413).  On ROCm torch's allocator says "HIP out
@@ -83,40 +127,11 @@ class HipTrainingJob1vsAll(_CudaOomText, TrainingJob1vsAll):
         if self._graph_step_ok is None:
             ok = bool(self.config.get_default("hip_1vsAll.graph_step")) and str(self.device).startswith("cuda")
             ok = ok and _model_takes_fused_loss(self.model) and hasattr(self.model, "loss_sp_po")
-            opt = self.optimizer
-            ok = ok and all(g.get("lr_decay", 0) == 0 for g in opt.param_groups)
-            # only optimizers whose captured step() replays correctly: kge_amd.optim.Adagrad says so itself, HipAdam
-            # says no (host-computed bias correction would be frozen at the capture step), of torch's own only SGD
-            ok = ok and bool(getattr(opt, "graph_capturable", type(opt) is torch.optim.SGD))
-            if ok:  # a penalty term back-propagates between the batch and the optimizer's step: eager
-                try:
-                    ok = len(self.model.penalty(epoch=self.epoch, batch_index=batch_index,
-                                                num_batches=len(self.loader), batch=batch)) == 0
-                except Exception:
-                    ok = False
+            ok = ok and _optimizer_is_capturable(self.optimizer) and _no_penalty(self, batch_index, batch)
             self._graph_step_ok = ok
             if ok:
-                from kge_amd.train_graph import GraphedStep
-                job, real_step = self, opt.step
-
-                class _Opt:  # what GraphedStep needs of the optimizer, with the REAL step
-                    param_groups = opt.param_groups
-                    zero_grad = staticmethod(opt.zero_grad)
-                    step = staticmethod(real_step)
-                    graph_capturable = True  # (checked above on the real optimizer)
-                    after_graph_replay = staticmethod(getattr(opt, "after_graph_replay", lambda params: None))
-
-                def step_or_skip(*a, **k):
-                    if job._skip_optimizer_step:
-                        job._skip_optimizer_step = False
-                        opt._opt_called = True  # (what a learning-rate scheduler's wrapper of step() records)
-                        return None
-                    return real_step(*a, **k)
-                if hasattr(real_step, "_wrapped_by_lr_sched"):  # torch's schedulers look for their mark on step()
-                    step_or_skip._wrapped_by_lr_sched = True
-                opt.step = step_or_skip
-                self._graph_step = GraphedStep(
-                    lambda s, p, o, inv: self.model.loss_sp_po(s, p, o).sum() * inv, _Opt, warmup=2)
+                self._graph_step = _graphed_step_of(
+                    self, lambda s, p, o, inv: self.model.loss_sp_po(s, p, o).sum() * inv)
         if not self._graph_step_ok:
             return None
         n = len(batch["triples"])
@@ -369,11 +384,85 @@ class HipTrainingJobNegativeSampling(_CudaOomText, TrainingJobNegativeSampling):
         if (str(self.device).startswith("cuda") and _fusable_ns_loss(self.loss)
                 and os.environ.get("KGE_NS_FUSED_LOSS", "1") != "0"):
             self.loss = _HipNsBceLoss(self.loss)
+        self._graph_step = None       # kge_amd.train_graph.GraphedStep (hip_negative_sampling.graph_step)
+        self._graph_step_ok = None    # decided at the first batch
+        self._graph_slots = ()
+        self._graph_labels = {}
+        self._skip_optimizer_step = False
         if self.__class__ == HipTrainingJobNegativeSampling:
             for f in Job.job_created_hooks:
                 f(self)
 
+    # ---- hip_negative_sampling.graph_step: the whole step of a full batch -- positives, the slots' negative blocks, the
+    # loss of every slot, backward, optimizer.step -- as ONE hipGraph replay (kge_amd.train_graph.GraphedStep).  Through
+    # the trainer a negative-sampling batch is ~50 launches of a few microseconds each, issued by ~1 ms of Python
+    # (profiles/r5_libkge_plugin_gpu.jsonl, case b); its inputs have fixed shapes: triples [n, 3], negatives [n, K].
+    def _graph_step_for(self, batch_index, batch, subbatch_slice):
+        if self._graph_step_ok is False or self.is_forward_only:
+            return None
+        if self._graph_step_ok is None:
+            from kge.util.sampler import DefaultBatchNegativeSample
+            try:
+                want = bool(self.config.get_default("hip_negative_sampling.graph_step"))
+            except KeyError:
+                want = False
+            ok = want and str(self.device).startswith("cuda") and hasattr(self.model, "score_neg")
+            ok = ok and bool(getattr(self.model, "_fused", lambda: False)())
+            slots = tuple(slot for slot in (S, O) if self._sampler.num_samples[slot] > 0)
+            ok = ok and len(slots) > 0 and self._sampler.num_samples[P] <= 0
+            ok = ok and all(type(batch["negative_samples"][slot]) is DefaultBatchNegativeSample for slot in slots)
+            # losses that are launches only: the kl loss (log_softmax + kl_div), plain bce, the one-kernel bce stand-ins
+            ok = ok and (isinstance(self.loss, (KLDivWithSoftmaxKgeLoss, _HipNsBceLoss))
+                         or (isinstance(self.loss, BCEWithLogitsKgeLoss) and self.loss._bce_type is None))
+            ok = ok and _optimizer_is_capturable(self.optimizer) and _no_penalty(self, batch_index, batch)
+            self._graph_step_ok, self._graph_slots = ok, slots
+            if ok:
+                self._graph_step = _graphed_step_of(self, self._graph_loss)
+        if not self._graph_step_ok:
+            return None
+        n = len(batch["triples"])
+        sl = subbatch_slice
+        whole = sl.start in (0, None) and (sl.stop is None or sl.stop >= n) and sl.step in (1, None)
+        return self._graph_step if whole and self.model._fused() else None
+
+    def _graph_loss(self, triples, *args):
+        """TrainingJobNegativeSampling._process_subbatch (train_negative_sampling.py:120-163) as one function of the
+        batch's tensors: per slot the [n, 1 + K] block (positives | negatives), the job's loss on it / batch size; the
+        slots' losses summed (the reference back-propagates them one after the other: the same gradients, accumulated)."""
+        negs, inv = args[:-1], args[-1]
+        s, p, o = triples[:, S], triples[:, P], triples[:, O]
+        n = triples.shape[0]
+        total = None
+        for slot, neg in zip(self._graph_slots, negs):
+            K = neg.shape[1]
+            labels = self._graph_labels.get((slot, n, K))
+            if labels is None:
+                labels = self._graph_labels[(slot, n, K)] = torch.zeros((n, 1 + K), device=triples.device)
+                labels[:, 0] = 1
+            pos = self.model.score_spo(s, p, o, direction="spo"[slot])
+            sc = self.model.score_neg(s, p, o, slot, neg)
+            if sc is None:
+                _declined_late("score_neg")
+            scores = torch.cat([pos.view(-1, 1), sc], dim=1)
+            part = self.loss(scores, labels, num_negatives=K) * inv
+            total = part if total is None else total + part
+        return total
+
     def _process_subbatch(self, batch_index, batch, subbatch_slice, result):
+        gs = self._graph_step_for(batch_index, batch, subbatch_slice)
+        if gs is not None and gs.enabled:
+            batch_size = result.size
+            result.prepare_time -= time.time()
+            triples = batch["triples"]
+            negs = [batch["negative_samples"][slot].samples() for slot in self._graph_slots]
+            inv = torch.full((), 1.0 / batch_size, device=triples.device)
+            result.prepare_time += time.time()
+            result.forward_time -= time.time()
+            loss_value = gs(triples, *negs, inv)
+            self._skip_optimizer_step = True  # (replayed or eager: GraphedStep has taken the optimizer's step)
+            result.avg_loss += loss_value.item()
+            result.forward_time += time.time()
+            return
         swapped = []
         if hasattr(self.model, "score_neg"):
             from kge.util.sampler import DefaultBatchNegativeSample
