@@ -50,6 +50,9 @@ for mode, split in (("parity", True), ("training", False)):
     summary[mode] = {"hbm_bytes_per_launch": f + w, "fetch_bytes_corrected": f, "write_bytes": w}
     lines.append(f"{mode}: per launch fetch(corrected) {f / 1e6:.1f} MB + write {w / 1e6:.1f} MB = {(f + w) / 1e6:.1f} MB; "
                  f"algorithmic {alg / 1e6:.1f} MB (score matrix {group * 2 * 512 * 14541 * 4 / 1e6:.1f} MB of it)")
-json.dump(summary, open("profiles/pmc_latest.json", "w"))
-open("profiles/r4_rocprofv3_pmc_hbm.txt", "w").write("\n".join(lines) + "\n")
+import os
+OUTP = os.environ.get("PMC_OUT", "profiles")
+summary["source"] = os.environ.get("PMC_SOURCE", summary["source"])
+json.dump(summary, open(OUTP + "/pmc_latest.json", "w"))
+open(OUTP + "/" + os.environ.get("PMC_TXT", "r4_rocprofv3_pmc_hbm.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
