@@ -62,7 +62,18 @@ def main(argv=None):
             os.makedirs(os.path.dirname(os.path.abspath(folder)) or ".", exist_ok=True)
     sys.argv = ["kge"] + argv
     from kge.cli import main as kge_main
-    kge_main()
+    try:
+        kge_main()
+    finally:
+        # every rank reaches the end before any rank closes its sockets (a rank tearing its communicator down while
+        # another is inside its last collective aborts the straggler)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            try:
+                dist.barrier()
+            except Exception:
+                pass
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":
