@@ -622,6 +622,10 @@ def main_sharded(a, world, rank, device):
                 results["fb15k" if main_shape == "wikidata5m" else "wikidata5m"],
         }
         print(json.dumps(out))
+    try:  # every rank reaches the end before any rank tears its communicator down
+        td.barrier()
+    except Exception:
+        pass
     td.destroy_process_group()
 
 
