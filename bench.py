@@ -690,6 +690,70 @@ def train_leg(device, n, steps):
     return out
 
 
+def ns_step_leg(device, n, steps):
+    """One whole NEGATIVE-SAMPLING training step at BASELINE configs[2] (WN18RR shape, RotatE d = 512, 1000 negatives per
+    slot, float32): TrainingJobNegativeSampling._process_subbatch (kge/job/train_negative_sampling.py:103-164) -- per slot
+    the positives (score_spo), the [n, K] negative block (kge_score_neg: fixed side in registers, corrupted rows stream),
+    the kl loss on [n, 1 + K], backward (kge_score_neg_bwd_accum) -- + one-pass Adagrad over both tables, through
+    kge_amd.model + kge_amd.optim: what `train.type: hip_negative_sampling` drives.  Wall clock per step issued call by
+    call and as ONE hipGraph replay (kge_amd.train_graph.GraphedStep; hip_negative_sampling.graph_step).  The negatives'
+    gather is the algorithmic traffic: 2 slots x n x K rows of d floats forward, the same rows read again + their
+    gradient rows scattered in the backward."""
+    from kge_amd import model as km, optim as kopt
+    from kge_amd.train_graph import GraphedStep
+    E, R, d, K = 40943, 11, DIM, 1000
+    q = torch.Generator().manual_seed(5)
+    s, p, o = (torch.randint(hi, (n,), generator=q).to(device) for hi in (E, R, E))
+    negs = [torch.randint(E, (n, K), generator=q).to(device) for _ in range(2)]
+    torch.manual_seed(0)
+    m = km.create("rotate", E, R, d, device=device)
+    opt = kopt.Adagrad(m.parameters(), lr=0.1)
+    labels = torch.zeros(n, K + 1, device=device)
+    labels[:, 0] = 1
+    target = torch.nn.functional.normalize(labels, p=1, dim=1)
+
+    def loss_fn(s_, p_, o_, ns_, no_):
+        total = None
+        for slot, neg in ((0, ns_), (2, no_)):
+            scores = torch.cat([m.score_spo(s_, p_, o_).view(-1, 1), m.score_neg(s_, p_, o_, slot, neg)], dim=1)
+            part = torch.nn.functional.kl_div(torch.log_softmax(scores, 1), target, reduction="sum") / n
+            total = part if total is None else total + part
+        return total
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss_fn(s, p, o, negs[0], negs[1]).backward()
+        opt.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    out = {"model": "rotate", "num_entities": E, "dim": d, "batch": n, "num_negatives_per_slot": K, "dtype": "f32",
+           "loss": "kl on [n, 1 + K] per slot", "optimizer": "Adagrad (one pass: kge_adagrad_step)",
+           "eager": {"ms_per_step": ms, "scored_triples_per_s": 2.0 * n * (K + 1) / (ms * 1e-3)}}
+    gs = GraphedStep(loss_fn, opt, warmup=1)
+    for _ in range(4):
+        gs(s, p, o, negs[0], negs[1])
+    if gs.replays > 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gs(s, p, o, negs[0], negs[1])
+        torch.cuda.synchronize()
+        g_ms = (time.perf_counter() - t0) / steps * 1e3
+        # forward gather of both slots + the same rows again and their gradient rows in the backward (f32 rows of d)
+        abytes = 2 * n * K * d * 4 * 3.0
+        out["graph_replay"] = {"ms_per_step": g_ms, "scored_triples_per_s": 2.0 * n * (K + 1) / (g_ms * 1e-3),
+                               "gather_bytes_per_step": abytes, "frac_of_hbm_peak": abytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    else:
+        out["graph_replay"] = {"disabled": gs.disabled_reason}
+    return out
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node
     (the contract's own command line), so that the line never reports n_gpus = 1 for a request of N."""
@@ -1042,6 +1106,10 @@ def main():
         extra_neg = neg_legs(engine, device, max(20, min(a.steps, 400) // 8))
         extra_eval = eval_leg(engine, device)
         extra_train = train_leg(device, n, max(10, min(a.steps, 200) // 4))
+        try:
+            extra_train["negative_sampling_step"] = ns_step_leg(device, n, max(10, min(a.steps, 200) // 4))
+        except Exception as exc:  # (a secondary leg never costs the line)
+            extra_train["negative_sampling_step"] = {"error": f"{type(exc).__name__}: {exc}"}
     else:
         extra_f32 = extra_rank = extra_neg = extra_eval = extra_train = None
 
