@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 from kge_amd import model as km, optim as ko
 
 dev = torch.device("cuda", 0)
-E, R, d, n, K = 14541, 237, 256, 512, int(os.environ.get("K", "100"))
+E, R, d, n, K = int(os.environ.get("E", "14541")), int(os.environ.get("R", "237")), int(os.environ.get("D", "256")), 512, int(os.environ.get("K", "100"))
 name = os.environ.get("MODEL", "rotate")
 g = torch.Generator().manual_seed(0)
 s = torch.randint(E, (n,), generator=g).to(dev); p = torch.randint(R, (n,), generator=g).to(dev)
