@@ -714,8 +714,9 @@ def ns_step_leg(device, n, steps):
 
     def loss_fn(s_, p_, o_, ns_, no_):
         total = None
-        for slot, neg in ((0, ns_), (2, no_)):
-            scores = torch.cat([m.score_spo(s_, p_, o_).view(-1, 1), m.score_neg(s_, p_, o_, slot, neg)], dim=1)
+        pos, sc_s, sc_o = m.score_neg_blocks(s_, p_, o_, ns_, no_)  # one autograd node: one pair of table gradients
+        for sc in (sc_s, sc_o):
+            scores = torch.cat([pos.view(-1, 1), sc], dim=1)
             part = torch.nn.functional.kl_div(torch.log_softmax(scores, 1), target, reduction="sum") / n
             total = part if total is None else total + part
         return total
@@ -735,6 +736,20 @@ def ns_step_leg(device, n, steps):
     out = {"model": "rotate", "num_entities": E, "dim": d, "batch": n, "num_negatives_per_slot": K, "dtype": "f32",
            "loss": "kl on [n, 1 + K] per slot", "optimizer": "Adagrad (one pass: kge_adagrad_step)",
            "eager": {"ms_per_step": ms, "scored_triples_per_s": 2.0 * n * (K + 1) / (ms * 1e-3)}}
+    # the same eager step with the backward's scatter as one float atomic per element and occurrence
+    # (kge_score_neg_bwd_accum) instead of sorted by entity (kge_score_neg_bwd_accum_sorted: the default at this shape)
+    os.environ["KGE_NEG_BWD_SORTED"] = "0"
+    try:
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        out["eager_with_atomic_scatter"] = {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3}
+    finally:
+        os.environ.pop("KGE_NEG_BWD_SORTED", None)
     gs = GraphedStep(loss_fn, opt, warmup=1)
     for _ in range(4):
         gs(s, p, o, negs[0], negs[1])

@@ -690,6 +690,27 @@ int kge_score_neg_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_i
                             const float* scores, int64_t lds, float* grad_ent,
                             int64_t grad_ent_ld, float* grad_rel, int64_t grad_rel_ld,
                             void* stream);
+/* The same backward with the [n, num_neg] occurrences SORTED by the entity they corrupt: `order` = int64 [n * num_neg]
+ * (device), the positions i * num_neg + k in ascending neg[i, k] (any order among equal ids: kge_neg_order above).  kge_score_neg_bwd_accum issues one float atomic per element and occurrence into
+ * grad_ent (262 M per slot at the WN18RR shape with 512 x 1000 negatives: 73 % of that training step); here a wave keeps
+ * the running sum of an entity's gradient row in registers over consecutive occurrences and writes it where the entity
+ * changes: ~num_entities / 32 + n * num_neg / 32 row flushes instead of n * num_neg.  Same sums in another order
+ * (float rounding apart).  Worth the sort from a few occurrences per entity on.  rel_scratch (may be NULL): RotatE only,
+ * num_rel x 2 rel_dim floats of scratch for the relations' cos / sin (computed once per call instead of per occurrence).  kge/util/sampler.py:263-306 backward,
+ * called at kge/job/train_negative_sampling.py:161-163. */
+/* `order` for the call below: a counting sort of the [n, num_neg] samples by entity id in two calls, no host wait
+ * (capturable).  order == NULL: the histogram -- cursor[e] += the number of samples with id e (int64 [num_ent], zeroed
+ * by the caller).  The caller turns it into exclusive prefix sums (a cumsum: the torch front end's), then order != NULL:
+ * the scatter -- on return order[cursor_in[e] .. cursor_in[e + 1]) holds the positions i * num_neg + k of entity e's
+ * samples in any order; cursor is clobbered. */
+int kge_neg_order(const void* neg, int32_t neg_itype, int64_t neg_ld, int64_t n, int64_t num_neg,
+                  int64_t num_ent, int64_t* cursor, int64_t* order, void* stream);
+int kge_score_neg_bwd_accum_sorted(const kge_tables* t, kge_index s, kge_index p, kge_index o,
+                                   int64_t n, int slot, const void* neg, int32_t neg_itype,
+                                   int64_t neg_ld, int64_t num_neg, const int64_t* order,
+                                   const float* gout, int64_t ldg, const float* scores, int64_t lds,
+                                   float* grad_ent, int64_t grad_ent_ld, float* grad_rel,
+                                   int64_t grad_rel_ld, float* rel_scratch, void* stream);
 
 /* Backward of kge_score_emb (dense embeddings).  SPO: g_s,g_o [n,dim], g_p [n,rel_dim].
  * SP_: g_s [n,dim], g_p [n,rel_dim], g_o [m,dim].  PO_: g_o [n,dim], g_p, g_s [m,dim]. */

@@ -166,6 +166,10 @@ PROTOTYPES = {
     "kge_score_neg_bwd_accum": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int, c_vp,
                                                ctypes.c_int32, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64,
                                                c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kge_neg_order": (ctypes.c_int, [c_vp, ctypes.c_int32, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "kge_score_neg_bwd_accum_sorted": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int, c_vp,
+                                                      ctypes.c_int32, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64,
+                                                      c_vp, c_i64, c_vp, c_i64, c_vp, c_vp]),
     "kge_score_emb_bwd": (ctypes.c_int, [_PT, ctypes.c_int, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                          c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp,
                                          c_vp]),

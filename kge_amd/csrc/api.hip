@@ -109,6 +109,13 @@ int run_neg_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, 
                       int dr, long long n, int slot, const void* neg, int neg_itype, long long neg_ld,
                       long long K, const float* gout, long long ldg, const float* scores, long long lds,
                       float* ge, long long ge_ld, float* gr, long long gr_ld, hipStream_t st);
+int run_neg_order(const void* neg, int neg_itype, long long neg_ld, long long n, long long K, long long num_ent,
+                  long long* cursor, long long* order, hipStream_t st);
+int run_neg_bwd_accum_sorted(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d, int dr,
+                             long long n, int slot, const void* neg, int neg_itype, long long neg_ld, long long K,
+                             const long long* order, const float* gout, long long ldg, const float* scores,
+                             long long lds, float* ge, long long ge_ld, float* gr, long long gr_ld, float* rot,
+                             long long num_rel, hipStream_t st);
 int run_spo_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d,
                       int dr, long long n, const float* gout, const float* scores, float* ge, long long ge_ld,
                       float* gr, long long gr_ld, hipStream_t st);
@@ -1760,6 +1767,38 @@ int kge_score_neg_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_i
   return run_neg_bwd_accum(t->scorer, t->l_norm, ent_op(t, s), rel_op(t, p), ent_op(t, o), (int)t->dim,
                            (int)t->rel_dim, n, slot, neg, neg_itype, neg_ld, num_neg, gout, ldg, scores,
                            lds, grad_ent, grad_ent_ld, grad_rel, grad_rel_ld, (hipStream_t)stream);
+}
+
+int kge_neg_order(const void* neg, int32_t neg_itype, int64_t neg_ld, int64_t n, int64_t num_neg, int64_t num_ent,
+                  int64_t* cursor, int64_t* order, void* stream) {
+  KGE_RANGE();
+  if (n < 0 || num_neg < 0 || num_ent <= 0 || neg_ld < num_neg) return KGE_ERR_INVALID_ARG;
+  if (neg_itype != KGE_I32 && neg_itype != KGE_I64) return KGE_ERR_INVALID_ARG;
+  if (n * num_neg > 0 && (!neg || !cursor)) return KGE_ERR_INVALID_ARG;  // (order == NULL: the histogram step)
+  return run_neg_order(neg, neg_itype, neg_ld, n, num_neg, num_ent, (long long*)cursor, (long long*)order,
+                       (hipStream_t)stream);
+}
+
+int kge_score_neg_bwd_accum_sorted(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                                   int slot, const void* neg, int32_t neg_itype, int64_t neg_ld,
+                                   int64_t num_neg, const int64_t* order, const float* gout, int64_t ldg,
+                                   const float* scores, int64_t lds, float* grad_ent, int64_t grad_ent_ld,
+                                   float* grad_rel, int64_t grad_rel_ld, float* rel_scratch, void* stream) {
+  KGE_RANGE();
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (t->dtype != KGE_F32) return KGE_ERR_UNSUPPORTED;
+  if (n < 0 || num_neg < 0 || (slot != 0 && slot != 2)) return KGE_ERR_INVALID_ARG;
+  if (n * num_neg > 0 && (!gout || !neg || !grad_ent || !grad_rel || !order)) return KGE_ERR_INVALID_ARG;
+  if (neg_ld < num_neg || ldg < num_neg || (scores && lds < num_neg)) return KGE_ERR_INVALID_ARG;
+  if (neg_itype != KGE_I32 && neg_itype != KGE_I64) return KGE_ERR_INVALID_ARG;
+  if (grad_ent_ld < t->dim || grad_rel_ld < t->rel_dim) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s, false)) || (rc = check_index(p, false)) || (rc = check_index(o, false)))
+    return rc;
+  return run_neg_bwd_accum_sorted(t->scorer, t->l_norm, ent_op(t, s), rel_op(t, p), ent_op(t, o), (int)t->dim,
+                                  (int)t->rel_dim, n, slot, neg, neg_itype, neg_ld, num_neg, (const long long*)order,
+                                  gout, ldg, scores, lds, grad_ent, grad_ent_ld, grad_rel, grad_rel_ld, rel_scratch,
+                                  t->num_rel, (hipStream_t)stream);
 }
 
 int kge_score_emb_bwd(const kge_tables* t, int combine, const void* s_emb, int64_t s_ld,

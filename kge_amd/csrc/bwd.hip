@@ -266,7 +266,8 @@ __global__ __launch_bounds__(256) void bwd_pairs_kernel(Operand A, Operand R, Op
 // ---- score_spo backward ---------------------------------------------------------------------
 // gradients of g * score(s, p, o) w.r.t. one coordinate pair (first-half element 0, second-half
 // element 1) of the s, p and o rows
-template <int SCORER, int NORM>
+// (ROTPRE: RotatE with r0 = cos, r1 = sin of the phase, precomputed per relation -- rot_table_kernel)
+template <int SCORER, int NORM, bool ROTPRE = false>
 __device__ __forceinline__ void spo_pair_grads(float s0, float s1, float r0, float r1, float o0, float o1,
                                                bool has1, float g, float dist, float lp, float& ds0,
                                                float& ds1, float& dp0, float& dp1, float& do0, float& do1) {
@@ -286,7 +287,12 @@ __device__ __forceinline__ void spo_pair_grads(float s0, float s1, float r0, flo
     ds0 = w0; ds1 = w1; dp0 = w0; dp1 = w1; do0 = -w0; do1 = -w1;
   } else {
     float sn, cs;
-    sincos_canon(r0, sn, cs);
+    if constexpr (ROTPRE) {
+      cs = r0;
+      sn = r1;
+    } else {
+      sincos_canon(r0, sn, cs);
+    }
     const float q0 = s0 * cs - s1 * sn, q1 = s0 * sn + s1 * cs;
     float wre, wim;
     rotate_w<NORM>(q0 - o0, q1 - o1, dist, lp, wre, wim);
@@ -540,6 +546,333 @@ int run_neg_bwd_accum(int scorer, float lp, const Operand& S, const Operand& R, 
   }
 #undef KGE_NA
 #undef KGE_NA2
+  return KGE_ERR_INVALID_ARG;
+}
+
+// ---- kge_score_neg_bwd_accum_sorted: the backward of the negatives without one atomic per occurrence -------------
+// bwd_neg_accum_kernel adds every (positive i, negative k)'s gradient row to grad_ent[neg[i, k]] with float atomics:
+// n K d of them -- 262 M per slot at the WN18RR shape with 512 x 1000 negatives, 0.86-0.92 ms of a 2.4 ms training
+// step (profiles/r5_ns_step_kernels.txt), the same for TransE and RotatE: not the arithmetic.  Two things hold it:
+// the atomics, and a wave that walks its negatives ONE after the other (index -> row -> use: a dependent round trip
+// per negative; without any atomic the same loop still takes 0.40 ms where the forward's gather of the same rows takes
+// 0.15).  Here:
+//   * `order` = the occurrences sorted by the entity they corrupt (kge_neg_order: a counting sort -- the caller's
+//     histogram + prefix sum give every entity its range, one atomic cursor bump per occurrence places it);
+//   * bwd_neg_sorted_kernel: a wave walks NGS_CH consecutive occurrences of that order, keeps the running sum of the
+//     current entity's gradient row in registers and flushes it (one atomic per element) only where the entity changes
+//     or the chunk ends: ~(E + n K) / NGS_CH row flushes instead of n K.  The fixed rows of an occurrence (relation +
+//     uncorrupted entity of positive i: n distinct rows each) come from the L2, the rows of NGS_U occurrences requested
+//     before the first is used;
+//   * bwd_neg_fixed_kernel: the fixed rows' gradients, a positive's negatives summed in registers as before, the
+//     rows of NGF_U negatives in flight at a time.
+// Sums in another order than the atomics' (which have none): the same values up to float rounding.
+constexpr int NGS_CH = 32, NGS_U = 4, NGF_U = 4;
+
+template <int NC>
+__device__ __forceinline__ void ng_load_row(const float* __restrict__ row, int lane, int hh, int lim1, float (&x0)[NC],
+                                            float (&x1)[NC]) {
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int c = lane + 64 * k;
+    x0[k] = c < hh ? row[c] : 0.f;
+    x1[k] = c < lim1 ? row[hh + c] : 0.f;
+  }
+}
+
+template <int SCORER, int NORM, int SLOT, int NC>
+__global__ __launch_bounds__(256) void bwd_neg_fixed_kernel(
+    Operand S, Operand R, Operand O, int d, int dr, long long n, const void* __restrict__ neg, int neg_itype,
+    long long neg_ld, long long K, int chunks_per_row, int ch, float lp, const float* __restrict__ gout, long long ldg,
+    const float* __restrict__ scores, long long lds, float* __restrict__ ge, long long ge_ld, float* __restrict__ gr,
+    long long gr_ld) {
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long row = w / chunks_per_row;
+  if (row >= n) return;
+  const long long k0 = (w % chunks_per_row) * ch;
+  const int cnt = (int)(k0 + ch < K ? ch : K - k0);  // <= 64
+  const int lane = threadIdx.x & 63;
+  const int hh = (d + 1) / 2, lim1 = d - hh;
+  const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;
+  const int rl1 = (SCORER == KGE_ROTATE) ? 0 : lim1;
+  const long long fi = SLOT == 0 ? index_at(O.idx, row) : index_at(S.idx, row);
+  const long long pi = index_at(R.idx, row);
+  const float* frow = (const float*)S.base + fi * S.ld;  // S.base == O.base: the entity table
+  const float* rrow = (const float*)R.base + pi * R.ld;
+  // the chunk's negatives, one per lane
+  long long m_vi = 0;
+  float m_g = 0.f, m_dist = 0.f;
+  if (lane < cnt) {
+    m_vi = neg_itype ? ((const long long*)neg)[row * neg_ld + k0 + lane] : (long long)((const int*)neg)[row * neg_ld + k0 + lane];
+    m_g = gout[row * ldg + k0 + lane];
+    m_dist = (SCORER == KGE_TRANSE || SCORER == KGE_ROTATE) && NORM != NORM_L1 ? -scores[row * lds + k0 + lane] : 0.f;
+  }
+  float f0[NC], f1[NC], r0[NC], r1[NC], af0[NC], af1[NC], ap0[NC], ap1[NC];
+  ng_load_row<NC>(frow, lane, hh, lim1, f0, f1);
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int c = lane + 64 * k;
+    r0[k] = c < rl0 ? rrow[c] : 0.f;
+    r1[k] = c < rl1 ? rrow[hh + c] : 0.f;
+    af0[k] = af1[k] = ap0[k] = ap1[k] = 0.f;
+  }
+  for (int j = 0; j < cnt; j += NGF_U) {
+    float v0[NGF_U][NC], v1[NGF_U][NC];
+#pragma unroll
+    for (int u = 0; u < NGF_U; ++u) {  // (a negative beyond the chunk: lane j + u holds m_vi = 0, row 0 -- loaded, not used)
+      const long long vi = __shfl(m_vi, (j + u) & 63, 64);
+      ng_load_row<NC>((const float*)S.base + vi * S.ld, lane, hh, lim1, v0[u], v1[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NGF_U; ++u) {
+      if (j + u < cnt) {
+        const float g = __shfl(m_g, (j + u) & 63, 64), dist = __shfl(m_dist, (j + u) & 63, 64);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const int c = lane + 64 * k;
+          if (c >= hh) break;
+          const bool has1 = c < lim1;
+          float ds0, ds1, dp0, dp1, do0, do1;
+          if (SLOT == 0)
+            spo_pair_grads<SCORER, NORM>(v0[u][k], v1[u][k], r0[k], r1[k], f0[k], f1[k], has1, g, dist, lp, ds0, ds1, dp0,
+                                         dp1, do0, do1);
+          else
+            spo_pair_grads<SCORER, NORM>(f0[k], f1[k], r0[k], r1[k], v0[u][k], v1[u][k], has1, g, dist, lp, ds0, ds1, dp0,
+                                         dp1, do0, do1);
+          af0[k] += SLOT == 0 ? do0 : ds0;
+          af1[k] += SLOT == 0 ? do1 : ds1;
+          ap0[k] += dp0;
+          ap1[k] += dp1;
+        }
+      }
+    }
+  }
+  float* gf = ge + fi * ge_ld;
+  float* gp = gr + pi * gr_ld;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int c = lane + 64 * k;
+    if (c < hh) unsafeAtomicAdd(gf + c, af0[k]);
+    if (c < lim1) unsafeAtomicAdd(gf + hh + c, af1[k]);
+    if (c < rl0) unsafeAtomicAdd(gp + c, ap0[k]);
+    if (c < rl1) unsafeAtomicAdd(gp + hh + c, ap1[k]);
+  }
+}
+
+// cos / sin of every relation phase, once per call: table[r][c] = cos, table[r][dr + c] = sin (sincos_canon: the values
+// the scoring and gradient kernels compute themselves) -- in bwd_neg_sorted_kernel the relation changes with every
+// occurrence and RotatE's four sincos per lane and occurrence were half its time
+__global__ __launch_bounds__(256) void rot_table_kernel(const float* __restrict__ rel, long long rel_ld, long long num_rel,
+                                                        int dr, float* __restrict__ table) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= num_rel * dr) return;
+  const long long r = i / dr;
+  const int c = (int)(i - r * dr);
+  float sn, cs;
+  sincos_canon(rel[r * rel_ld + c], sn, cs);
+  table[r * 2 * dr + c] = cs;
+  table[r * 2 * dr + dr + c] = sn;
+}
+
+template <int SCORER, int NORM, int SLOT, int NC, bool ROTPRE>
+__global__ __launch_bounds__(256) void bwd_neg_sorted_kernel(
+    Operand S, Operand R, Operand O, int d, int dr, const void* __restrict__ neg, int neg_itype, long long neg_ld,
+    long long K, const long long* __restrict__ order, long long total, float lp, const float* __restrict__ gout,
+    long long ldg, const float* __restrict__ scores, long long lds, float* __restrict__ ge, long long ge_ld,
+    const float* __restrict__ rot) {
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long j0 = w * NGS_CH;
+  if (j0 >= total) return;
+  const int cnt = (int)(total - j0 < NGS_CH ? total - j0 : NGS_CH);
+  const int lane = threadIdx.x & 63;
+  const int hh = (d + 1) / 2, lim1 = d - hh;
+  const int rl0 = (SCORER == KGE_ROTATE) ? dr : hh;
+  const int rl1 = (SCORER == KGE_ROTATE) ? 0 : lim1;
+  // the chunk's metadata, one occurrence per lane (one round of dependent loads for the whole chunk)
+  long long m_vi = -1, m_fi = 0, m_pi = 0;
+  float m_g = 0.f, m_dist = 0.f;
+  if (lane < cnt) {
+    const long long pos = order[j0 + lane];
+    const long long row = pos / K, kk = pos - row * K;
+    m_vi = neg_itype ? ((const long long*)neg)[row * neg_ld + kk] : (long long)((const int*)neg)[row * neg_ld + kk];
+    m_fi = SLOT == 0 ? index_at(O.idx, row) : index_at(S.idx, row);
+    m_pi = index_at(R.idx, row);
+    m_g = gout[row * ldg + kk];
+    m_dist = (SCORER == KGE_TRANSE || SCORER == KGE_ROTATE) && NORM != NORM_L1 ? -scores[row * lds + kk] : 0.f;
+  }
+  float a0[NC], a1[NC], v0[NC], v1[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) a0[k] = a1[k] = v0[k] = v1[k] = 0.f;
+  long long cur = -1;
+  auto flush = [&]() {
+    if (cur < 0) return;
+    float* gv = ge + cur * ge_ld;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int c = lane + 64 * k;
+      if (c < hh) unsafeAtomicAdd(gv + c, a0[k]);
+      if (c < lim1) unsafeAtomicAdd(gv + hh + c, a1[k]);
+      a0[k] = a1[k] = 0.f;
+    }
+  };
+  for (int j = 0; j < cnt; j += NGS_U) {
+    float f0[NGS_U][NC], f1[NGS_U][NC], r0[NGS_U][NC], r1[NGS_U][NC];
+#pragma unroll
+    for (int u = 0; u < NGS_U; ++u) {  // (an occurrence beyond the chunk: rows 0 -- loaded, not used)
+      const long long fi = __shfl(m_fi, (j + u) & 63, 64), pi = __shfl(m_pi, (j + u) & 63, 64);
+      ng_load_row<NC>((const float*)S.base + fi * S.ld, lane, hh, lim1, f0[u], f1[u]);
+      if constexpr (ROTPRE) {  // (cos | sin) of relation pi
+        const float* trow = rot + pi * 2 * dr;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const int c = lane + 64 * k;
+          r0[u][k] = c < dr ? trow[c] : 1.f;
+          r1[u][k] = c < dr ? trow[dr + c] : 0.f;
+        }
+      } else {
+        const float* rrow = (const float*)R.base + pi * R.ld;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const int c = lane + 64 * k;
+          r0[u][k] = c < rl0 ? rrow[c] : 0.f;
+          r1[u][k] = c < rl1 ? rrow[hh + c] : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NGS_U; ++u) {
+      if (j + u < cnt) {
+        const long long vi = __shfl(m_vi, (j + u) & 63, 64);
+        const float g = __shfl(m_g, (j + u) & 63, 64), dist = __shfl(m_dist, (j + u) & 63, 64);
+        if (vi != cur) {  // (wave-uniform: every lane holds the same vi)
+          flush();
+          cur = vi;
+          ng_load_row<NC>((const float*)S.base + vi * S.ld, lane, hh, lim1, v0, v1);  // S.base == O.base
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          const int c = lane + 64 * k;
+          if (c >= hh) break;
+          const bool has1 = c < lim1;
+          float ds0, ds1, dp0, dp1, do0, do1;
+          if (SLOT == 0)
+            spo_pair_grads<SCORER, NORM, ROTPRE>(v0[k], v1[k], r0[u][k], r1[u][k], f0[u][k], f1[u][k], has1, g, dist, lp, ds0,
+                                                 ds1, dp0, dp1, do0, do1);
+          else
+            spo_pair_grads<SCORER, NORM, ROTPRE>(f0[u][k], f1[u][k], r0[u][k], r1[u][k], v0[k], v1[k], has1, g, dist, lp, ds0,
+                                                 ds1, dp0, dp1, do0, do1);
+          a0[k] += SLOT == 0 ? ds0 : do0;
+          a1[k] += SLOT == 0 ? ds1 : do1;
+        }
+      }
+    }
+  }
+  flush();
+}
+
+// order[cursor[id]++] = position, for every position i K + k of the [n, K] sample matrix: the scatter step of a counting
+// sort by entity id (`cursor` = exclusive prefix sums of the ids' histogram on entry; clobbered).
+__global__ __launch_bounds__(256) void neg_order_kernel(const void* __restrict__ neg, int neg_itype, long long neg_ld,
+                                                        long long K, long long total, long long num_ent,
+                                                        unsigned long long* __restrict__ cursor,
+                                                        long long* __restrict__ order) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= total) return;
+  const long long row = j / K, kk = j - row * K;
+  long long id = neg_itype ? ((const long long*)neg)[row * neg_ld + kk] : (long long)((const int*)neg)[row * neg_ld + kk];
+  if (id < 0) id = 0;
+  if (id >= num_ent) id = num_ent - 1;  // (ids are the caller's contract; never write outside `order`)
+  const unsigned long long pos = atomicAdd(cursor + id, 1ULL);
+  if (pos < (unsigned long long)total) order[pos] = j;
+}
+
+// counts[id] += 1 for every sample (the histogram of the counting sort; `counts` zeroed by the caller)
+__global__ __launch_bounds__(256) void neg_histogram_kernel(const void* __restrict__ neg, int neg_itype, long long neg_ld,
+                                                            long long K, long long total, long long num_ent,
+                                                            unsigned long long* __restrict__ counts) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= total) return;
+  const long long row = j / K, kk = j - row * K;
+  long long id = neg_itype ? ((const long long*)neg)[row * neg_ld + kk] : (long long)((const int*)neg)[row * neg_ld + kk];
+  if (id < 0) id = 0;
+  if (id >= num_ent) id = num_ent - 1;
+  atomicAdd(counts + id, 1ULL);
+}
+
+int run_neg_order(const void* neg, int neg_itype, long long neg_ld, long long n, long long K, long long num_ent,
+                  long long* cursor, long long* order, hipStream_t st) {
+  const long long total = n * K;
+  if (total == 0) return KGE_OK;
+  if ((total + 255) / 256 > 0x7fffffffLL) return KGE_ERR_UNSUPPORTED;
+  if (order == nullptr) {  // first step: the histogram
+    hipLaunchKernelGGL(neg_histogram_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, neg, neg_itype, neg_ld,
+                       K, total, num_ent, (unsigned long long*)cursor);
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(neg_order_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, neg, neg_itype, neg_ld, K,
+                     total, num_ent, (unsigned long long*)cursor, order);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// kge_score_neg_bwd_accum with the occurrences sorted by corrupted entity.  `order`: int64 [n K] (device).
+int run_neg_bwd_accum_sorted(int scorer, float lp, const Operand& S, const Operand& R, const Operand& O, int d, int dr,
+                             long long n, int slot, const void* neg, int neg_itype, long long neg_ld, long long K,
+                             const long long* order, const float* gout, long long ldg, const float* scores,
+                             long long lds, float* ge, long long ge_ld, float* gr, long long gr_ld, float* rot,
+                             long long num_rel, hipStream_t st) {
+  if (n == 0 || K == 0) return KGE_OK;
+  if ((d + 1) / 2 > 64 * SPA_NC) return KGE_ERR_UNSUPPORTED;
+  const bool rotpre = scorer == KGE_ROTATE && rot != nullptr;
+  if (rotpre) {
+    const long long cells = num_rel * dr;
+    hipLaunchKernelGGL(rot_table_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, (const float*)R.base, R.ld,
+                       num_rel, dr, rot);
+  }
+  const int norm = norm_mode(lp);
+  const bool dot = scorer == KGE_COMPLEX || scorer == KGE_DISTMULT;
+  if (!dot && norm != NORM_L1 && !scores) return KGE_ERR_INVALID_ARG;
+  long long chl = n * K / 8192;
+  if (chl < 4) chl = 4;
+  if (chl > NGA_CH) chl = NGA_CH;
+  const int ch = (int)chl;
+  const long long cpr = (K + ch - 1) / ch;
+  const long long waves = n * cpr;
+  const long long total = n * K, swaves = (total + NGS_CH - 1) / NGS_CH;
+  if (cpr > (1LL << 30) || (waves + 3) / 4 > 0x7fffffffLL || (swaves + 3) / 4 > 0x7fffffffLL) return KGE_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)((waves + 3) / 4)), sgrid((unsigned)((swaves + 3) / 4));
+  const bool small = (d + 1) / 2 <= 64 * 4;  // coordinate pairs per lane: 4 (d <= 512) or 8
+#define KGE_NS3(SC, NM, SL, NCV)                                                                                     \
+  hipLaunchKernelGGL((bwd_neg_fixed_kernel<SC, NM, SL, NCV>), grid, dim3(256), 0, st, S, R, O, d, dr, n, neg,        \
+                     neg_itype, neg_ld, K, (int)cpr, ch, lp, gout, ldg, scores, lds, ge, ge_ld, gr, gr_ld);          \
+  if (rotpre && SC == KGE_ROTATE)                                                                                    \
+    hipLaunchKernelGGL((bwd_neg_sorted_kernel<SC, NM, SL, NCV, SC == KGE_ROTATE>), sgrid, dim3(256), 0, st, S, R, O, d, dr, \
+                       neg, neg_itype, neg_ld, K, order, total, lp, gout, ldg, scores, lds, ge, ge_ld, rot);         \
+  else                                                                                                               \
+    hipLaunchKernelGGL((bwd_neg_sorted_kernel<SC, NM, SL, NCV, false>), sgrid, dim3(256), 0, st, S, R, O, d, dr, neg, \
+                       neg_itype, neg_ld, K, order, total, lp, gout, ldg, scores, lds, ge, ge_ld, rot)
+#define KGE_NS2(SC, NM, SL)          \
+  if (small) { KGE_NS3(SC, NM, SL, 4); } \
+  else { KGE_NS3(SC, NM, SL, 8); }
+#define KGE_NS(SC, NM)                                                \
+  {                                                                   \
+    if (slot == 0) { KGE_NS2(SC, NM, 0) }                             \
+    else { KGE_NS2(SC, NM, 2) }                                       \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH; \
+  }
+  switch (scorer) {
+    case KGE_COMPLEX: KGE_NS(KGE_COMPLEX, NORM_L1);
+    case KGE_DISTMULT: KGE_NS(KGE_DISTMULT, NORM_L1);
+    case KGE_TRANSE:
+      if (norm == NORM_L1) KGE_NS(KGE_TRANSE, NORM_L1);
+      if (norm == NORM_L2) KGE_NS(KGE_TRANSE, NORM_L2);
+      KGE_NS(KGE_TRANSE, NORM_LP);
+    case KGE_ROTATE:
+      if (norm == NORM_L1) KGE_NS(KGE_ROTATE, NORM_L1);
+      if (norm == NORM_L2) KGE_NS(KGE_ROTATE, NORM_L2);
+      KGE_NS(KGE_ROTATE, NORM_LP);
+  }
+#undef KGE_NS
+#undef KGE_NS2
+#undef KGE_NS3
   return KGE_ERR_INVALID_ARG;
 }
 

@@ -667,9 +667,24 @@ def score_neg(t: Tables, s, p, o, slot: int, neg: torch.Tensor, flags=None) -> t
     return out
 
 
+# kge_score_neg_bwd_accum_sorted (occurrences sorted by corrupted entity: one gradient-row flush per run of equal ids
+# instead of one float atomic per element and occurrence) from this many occurrences on, when every entity is drawn
+# several times on average; KGE_NEG_BWD_SORTED=0 / 1 forces either.
+NEG_BWD_SORTED_MIN = 1 << 17
+
+
+def _neg_bwd_sorted(n, K, num_ent) -> bool:
+    want = os.environ.get("KGE_NEG_BWD_SORTED")
+    if want is not None:
+        return want == "1"
+    return n * K >= NEG_BWD_SORTED_MIN and n * K >= 4 * num_ent
+
+
 def score_neg_bwd_accum(t: Tables, s, p, o, slot: int, neg: torch.Tensor, gout, scores, grad_ent, grad_rel):
     """Backward of score_neg accumulated straight into the dense table gradients `grad_ent` [E, d] and
-    `grad_rel` [R, d_r] (f32, modified in place); False if the kernel does not take this shape."""
+    `grad_rel` [R, d_r] (f32, modified in place); False if the kernel does not take this shape.  Many occurrences per
+    entity (negative sampling with hundreds of negatives per positive): sorted by entity first (torch.sort on the device:
+    plumbing), then kge_score_neg_bwd_accum_sorted."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
     n = _same_len(keep[:3], "score_neg_bwd_accum")
@@ -686,6 +701,37 @@ def score_neg_bwd_accum(t: Tables, s, p, o, slot: int, neg: torch.Tensor, gout, 
     sc = None
     if scores is not None:
         sc = scores if (scores.dim() == 2 and scores.stride(1) == 1) else scores.contiguous().view(n, K)
+    if n * K > 0 and _neg_bwd_sorted(n, K, t.num_ent):
+        flat = neg if neg.is_contiguous() else neg.contiguous()
+        # counting sort by entity id: histogram + exclusive prefix sums (torch: plumbing), then one cursor bump per sample
+        # (kge_neg_order twice around a cumsum -- torch.bincount would wait for the host: it reads the largest id back)
+        counts = torch.zeros(t.num_ent, dtype=torch.int64, device=t.device)
+        order = torch.empty(n * K, dtype=torch.int64, device=t.device)
+        rot = (torch.empty(t.rel.shape[0], 2 * t.rel.shape[1], dtype=torch.float32, device=t.device)
+               if t.scorer == SCORERS["rotate"] else None)  # scratch for the relations' cos / sin
+        it = I32 if flat.dtype == torch.int32 else I64
+        with _on_device(t.device):
+            tc = t.c()
+            st = _stream_handle(t.device)
+            rc = _lib.lib().kge_neg_order(flat.data_ptr(), it, max(K, 1), n, K, t.num_ent, counts.data_ptr(), None, st)
+            if rc:
+                _lib.check(rc, "kge_neg_order (histogram)")
+            cursor = torch.cumsum(counts, 0).sub_(counts)
+            rc = _lib.lib().kge_neg_order(flat.data_ptr(), it, max(K, 1), n, K, t.num_ent, cursor.data_ptr(),
+                                          order.data_ptr(), st)
+            if rc:
+                _lib.check(rc, "kge_neg_order")
+            rc = _lib.lib().kge_score_neg_bwd_accum_sorted(
+                ctypes.byref(tc), si, pi, oi, n, int(slot), flat.data_ptr(), I32 if flat.dtype == torch.int32 else I64,
+                max(K, 1), K, order.data_ptr(), gout.data_ptr(), gout.stride(0) if n > 1 else max(K, 1),
+                None if sc is None else sc.data_ptr(), 0 if sc is None else (sc.stride(0) if n > 1 else max(K, 1)),
+                grad_ent.data_ptr(), grad_ent.stride(0), grad_rel.data_ptr(), grad_rel.stride(0),
+                None if rot is None else rot.data_ptr(), _stream_handle(t.device))
+        if rc == _lib.KGE_ERR_UNSUPPORTED:
+            return False
+        if rc:
+            _lib.check(rc, "kge_score_neg_bwd_accum_sorted")
+        return True
     with _on_device(t.device):
         tc = t.c()
         rc = _lib.lib().kge_score_neg_bwd_accum(

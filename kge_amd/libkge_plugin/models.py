@@ -8,8 +8,8 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import (BF16Shadow, _FusedCE, _FusedCE2, _ScoreEmb, _ScoreNeg, _ScorePairs, _ScoreSPO, bce_fused,
-                     ce_fused_dropout, kl_fused)
+from ..model import (BF16Shadow, _FusedCE, _FusedCE2, _ScoreEmb, _ScoreNeg, _ScoreNegBlocks, _ScorePairs, _ScoreSPO,
+                     bce_fused, ce_fused_dropout, kl_fused, neg_blocks_fusable)
 
 
 class _HipScorer(RelationalScorer):
@@ -141,6 +141,17 @@ class _FusedScoring:
         if not ent.is_cuda:
             return None
         return _ScoreNeg.apply(self._scorer.name, self._scorer._norm, ent, rel, s, p, o, int(slot), neg)
+
+    def score_neg_blocks(self, s: Tensor, p: Tensor, o: Tensor, neg_s: Tensor = None, neg_o: Tensor = None):
+        """(positives [n], subject-slot block [n, K_s] or None, object-slot block [n, K_o] or None) as ONE autograd node
+        whose backward fills one pair of table gradients (kge_amd.model._ScoreNegBlocks); None if the fused gather does
+        not apply (the caller composes score_spo + score_neg)."""
+        if not self._fused():
+            return None
+        ent, rel = self._w()
+        if not neg_blocks_fusable(ent, rel):
+            return None
+        return _ScoreNegBlocks.apply(self._scorer.name, self._scorer._norm, ent, rel, s, p, o, neg_s, neg_o)
 
     def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
         if not self._fused():

@@ -433,14 +433,21 @@ class HipTrainingJobNegativeSampling(_CudaOomText, TrainingJobNegativeSampling):
         s, p, o = triples[:, S], triples[:, P], triples[:, O]
         n = triples.shape[0]
         total = None
+        by_slot = dict(zip(self._graph_slots, negs))
+        blocks = None
+        if hasattr(self.model, "score_neg_blocks"):  # positives + both slots' blocks as one autograd node
+            blocks = self.model.score_neg_blocks(s, p, o, by_slot.get(S), by_slot.get(O))
         for slot, neg in zip(self._graph_slots, negs):
             K = neg.shape[1]
             labels = self._graph_labels.get((slot, n, K))
             if labels is None:
                 labels = self._graph_labels[(slot, n, K)] = torch.zeros((n, 1 + K), device=triples.device)
                 labels[:, 0] = 1
-            pos = self.model.score_spo(s, p, o, direction="spo"[slot])
-            sc = self.model.score_neg(s, p, o, slot, neg)
+            if blocks is not None:
+                pos, sc = blocks[0], blocks[1 if slot == S else 2]
+            else:
+                pos = self.model.score_spo(s, p, o, direction="spo"[slot])
+                sc = self.model.score_neg(s, p, o, slot, neg)
             if sc is None:
                 _declined_late("score_neg")
             scores = torch.cat([pos.view(-1, 1), sc], dim=1)

@@ -180,6 +180,17 @@ class KgeModel(torch.nn.Module):
         tr[slot] = neg.reshape(-1).long()
         return self.score_spo(tr[0], tr[1], tr[2]).view(-1, K)
 
+    def score_neg_blocks(self, s: Tensor, p: Tensor, o: Tensor, neg_s: Tensor = None, neg_o: Tensor = None):
+        """(positives [n], [n, K_s] scores with the subject replaced by neg_s[i, k] or None, [n, K_o] with the object
+        replaced or None): score_spo + score_neg per slot as ONE autograd node (one pair of table gradients in the
+        backward); composed from the single calls where the fused node does not apply."""
+        ent, rel = self._entity_embedder.weight, self._relation_embedder.weight
+        if self._fused() and neg_blocks_fusable(ent, rel):
+            return _ScoreNegBlocks.apply(self._scorer.name, self._scorer._norm, ent, rel, s, p, o, neg_s, neg_o)
+        pos = self.score_spo(s, p, o)
+        return (pos, None if neg_s is None else self.score_neg(s, p, o, 0, neg_s),
+                None if neg_o is None else self.score_neg(s, p, o, 2, neg_o))
+
     def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
         if self._fused():
             return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp",
@@ -407,6 +418,44 @@ class _ScoreNeg(torch.autograd.Function):
             _scatter_rows(gr, tr[1], g_p)
             ge, gr = ge.to(ctx.t.ent.dtype), gr.to(ctx.t.rel.dtype)
         return None, None, ge, gr, None, None, None, None, None
+
+
+class _ScoreNegBlocks(torch.autograd.Function):
+    """What TrainingJobNegativeSampling._process_subbatch scores for a subbatch (train_negative_sampling.py:120-151) in
+    ONE autograd node: the positives (score_spo) and the negative blocks of the subject and the object slot
+    (BatchNegativeSample.score, sampler.py:263-306).  Its backward accumulates all three into ONE pair of dense table
+    gradients (kge_score_spo_bwd_accum + kge_score_neg_bwd_accum per slot on the same buffers) -- composed from
+    _ScoreSPO / _ScoreNeg every node brings its own zero-filled [E, d] gradient and autograd adds them up: six fills and
+    six adds of the entity table's size per step (0.2 of a 1.6 ms step at the WN18RR shape).  float32 tables, dim <= 1024
+    (the accumulate kernels' domain; the caller checks)."""
+
+    @staticmethod
+    def forward(ctx, name, l_norm, ent, rel, s, p, o, neg_s, neg_o):
+        t = engine.Tables(name, ent.detach(), rel.detach(), l_norm)
+        pos = engine.score_spo(t, s, p, o)
+        sc_s = engine.score_neg(t, s, p, o, 0, neg_s) if neg_s is not None else None
+        sc_o = engine.score_neg(t, s, p, o, 2, neg_o) if neg_o is not None else None
+        ctx.t, ctx.idx = t, (s, p, o, neg_s, neg_o)
+        ctx.save_for_backward(pos, sc_s, sc_o)
+        return pos, sc_s, sc_o
+
+    @staticmethod
+    def backward(ctx, g_pos, g_s, g_o):
+        s, p, o, neg_s, neg_o = ctx.idx
+        pos, sc_s, sc_o = ctx.saved_tensors
+        ge, gr = torch.zeros_like(ctx.t.ent), torch.zeros_like(ctx.t.rel)
+        if g_pos is not None and not engine.score_spo_bwd_accum(ctx.t, s, p, o, g_pos.contiguous(), pos, ge, gr):
+            raise RuntimeError("kge_amd: kge_score_spo_bwd_accum declined a shape score_neg_blocks admitted")
+        for slot, neg, g, sc in ((0, neg_s, g_s, sc_s), (2, neg_o, g_o, sc_o)):
+            if neg is not None and g is not None:
+                if not engine.score_neg_bwd_accum(ctx.t, s, p, o, slot, neg, g, sc, ge, gr):
+                    raise RuntimeError("kge_amd: kge_score_neg_bwd_accum declined a shape score_neg_blocks admitted")
+        return None, None, ge, gr, None, None, None, None, None
+
+
+def neg_blocks_fusable(ent: torch.Tensor, rel: torch.Tensor) -> bool:
+    return (ent.is_cuda and ent.dtype == torch.float32 and rel.dtype == torch.float32 and ent.shape[1] <= 1024
+            and ent.is_contiguous() and rel.is_contiguous())
 
 
 def _bf16_copy_of(param):

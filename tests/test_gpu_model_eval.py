@@ -135,6 +135,80 @@ def test_entity_ranking_matches_reference_golden(name, tag, chunk):
 
 
 # ---- autograd --------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,l_norm", [("complex", 1.0), ("transe", 2.0), ("rotate", 1.0)])
+def test_score_neg_blocks_is_the_composed_calls_in_one_node(name, l_norm):
+    """KgeModel.score_neg_blocks (round 5): positives + both slots' negative blocks of a negative-sampling subbatch
+    (train_negative_sampling.py:120-151) as ONE autograd node whose backward fills ONE pair of table gradients: the
+    values are the single calls' bit for bit, the gradients of a random functional equal the composed calls' (sums in
+    another order: float rounding), one slot may be absent."""
+    E, R, d, n = 300, 5, 64, 41
+    m = _model(name, E, R, d, l_norm=l_norm).train()
+    g = torch.Generator().manual_seed(12)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    neg_s, neg_o = torch.randint(E, (n, 17), generator=g).to(DEV), torch.randint(E, (n, 9), generator=g).to(DEV)
+    w_s, w_o, w_p = torch.randn(n, 17, generator=g).to(DEV), torch.randn(n, 9, generator=g).to(DEV), torch.randn(n, generator=g).to(DEV)
+    pos, sc_s, sc_o = m.score_neg_blocks(s, p, o, neg_s, neg_o)
+    assert torch.equal(pos, m.score_spo(s, p, o)) and torch.equal(sc_s, m.score_neg(s, p, o, 0, neg_s))
+    assert torch.equal(sc_o, m.score_neg(s, p, o, 2, neg_o))
+    m.zero_grad()
+    ((pos * w_p).sum() + (sc_s * w_s).sum() + (sc_o * w_o).sum() + (pos * 2.0).sum()).backward()
+    got = [q.grad.clone() for q in m.parameters()]
+    m.zero_grad()
+    ((m.score_spo(s, p, o) * (w_p + 2.0)).sum() + (m.score_neg(s, p, o, 0, neg_s) * w_s).sum()
+     + (m.score_neg(s, p, o, 2, neg_o) * w_o).sum()).backward()
+    for a, b in zip(got, [q.grad for q in m.parameters()]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+    pos2, none_s, sc_o2 = m.score_neg_blocks(s, p, o, None, neg_o)
+    assert none_s is None and torch.equal(sc_o2, sc_o)
+    m.zero_grad()
+    (sc_o2 * w_o).sum().backward()   # (no gradient reaches the positives)
+    assert all(torch.isfinite(q.grad).all() for q in m.parameters())
+
+
+@pytest.mark.parametrize("name,l_norm,d", [("complex", 1.0, 64), ("distmult", 1.0, 33), ("transe", 1.0, 130),
+                                           ("transe", 2.0, 64), ("rotate", 1.0, 256), ("rotate", 2.0, 66),
+                                           ("rotate", 3.0, 64)])
+def test_score_neg_backward_sorted_by_entity(name, l_norm, d, monkeypatch):
+    """kge_score_neg_bwd_accum_sorted (round 5): the occurrences sorted by the entity they corrupt, an entity's gradient
+    row summed in registers over a run of equal ids and flushed once -- instead of one float atomic per element and
+    occurrence.  Forced on (KGE_NEG_BWD_SORTED=1) at shapes with many occurrences per entity, runs longer than a wave's
+    chunk of 32, chunks that start and end inside a run, int32 / int64 samples, both slots: both table gradients against
+    torch autograd through the reference's op sequence on the expanded triples (BatchNegativeSample.score "triple",
+    kge/util/sampler.py:291-306) at the bar of the atomic kernel's test, and against the atomic kernel itself."""
+    E, R, n, K = 23, 3, 37, 131   # 4,847 occurrences over 23 entities: runs of ~210
+    m = _model(name, E, R, d, l_norm=l_norm).train()
+    ent0 = m.get_s_embedder().weight.detach().cpu().clone()
+    rel0 = m.get_p_embedder().weight.detach().cpu().clone()
+    g = torch.Generator().manual_seed(8)
+    s, p, o = (torch.randint(hi, (n,), generator=g) for hi in (E, R, E))
+    for slot, idt in ((0, torch.int32), (2, torch.int64)):
+        neg = torch.randint(E, (n, K), generator=g)
+        neg[:, :5] = 7                       # a hub entity: every positive draws it five times
+        w = torch.randn(n, K, generator=g)
+        ent, rel = ent0.clone().requires_grad_(), rel0.clone().requires_grad_()
+        tr = [x.repeat_interleave(K) for x in (s, p, o)]
+        tr[slot] = neg.reshape(-1)
+        ref = tp.score_spo(name, ent, rel, tr[0], tr[1], tr[2], l_norm).view(n, K)
+        (ref * w).sum().backward()
+        grads = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("KGE_NEG_BWD_SORTED", mode)
+            m.zero_grad()
+            got = m.score_neg(s.to(DEV), p.to(DEV), o.to(DEV), slot, neg.to(DEV).to(idt))
+            (got * w.to(DEV)).sum().backward()
+            grads[mode] = (m.get_s_embedder().weight.grad.cpu().clone(), m.get_p_embedder().weight.grad.cpu().clone())
+        for gv, want, nm in ((grads["1"][0], ent.grad, "entity"), (grads["1"][1], rel.grad, "relation")):
+            scale = max(1.0, float(want.abs().max()))
+            err = float((gv - want).abs().max())
+            assert err <= 2e-4 * scale, (name, l_norm, slot, nm, err, scale)
+        for a, b, nm in ((grads["1"][0], grads["0"][0], "entity"), (grads["1"][1], grads["0"][1], "relation")):
+            scale = max(1.0, float(b.abs().max()))
+            assert float((a - b).abs().max()) <= 5e-5 * scale, (name, l_norm, slot, nm)
+    monkeypatch.delenv("KGE_NEG_BWD_SORTED")
+    from kge_amd import engine
+    assert engine._neg_bwd_sorted(512, 1000, 40943) and not engine._neg_bwd_sorted(512, 100, 14541)
+
+
 @pytest.mark.parametrize("name,l_norm", [("complex", 1.0), ("distmult", 1.0), ("transe", 1.0),
                                          ("transe", 2.0), ("rotate", 1.0), ("rotate", 2.0)])
 @pytest.mark.parametrize("d", [40, 33])
