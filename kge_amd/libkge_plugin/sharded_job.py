@@ -40,7 +40,6 @@ CPU / gloo: the CPU test (tests/test_libkge_sharded_plugin_cpu.py) runs these jo
 suite's stand-in backend handed in through `SHARD_BACKEND`; the product default is kge_amd.engine (HIP kernels, no CPU
 fallback).
 """
-import math
 import os
 import time
 
@@ -49,7 +48,6 @@ import torch
 import torch.distributed as dist
 
 from kge.job import Job
-from kge.job.train import TrainingJob
 from kge.job.train_1vsAll import TrainingJob1vsAll
 from kge.job.train_KvsAll import TrainingJobKvsAll
 from kge.job.train_negative_sampling import TrainingJobNegativeSampling, S, P, O
