@@ -172,16 +172,22 @@ namespace {
 // ---- profiler ranges: KGE_ROCTX=1 puts a roctx range around every entry point of the C ABI, so
 // that a `rocprofv3 --marker-trace --kernel-trace` of a LibKGE job attributes kernels and host time per call the way the
 // reference's own timing buckets do per batch (kge/job/train.py:347-350, 536-557: prepare / forward / backward /
-// optimizer).  libroctx64.so is opened on first use; without the variable (or the library) a range is two loads.
+// optimizer).  The roctx library is opened on first use; without the variable (or the library) a range is two loads.
 struct RoctxApi {
   int (*push)(const char*) = nullptr;
   int (*pop)() = nullptr;
   RoctxApi() {
     const char* e = getenv("KGE_ROCTX");
     if (!e || e[0] != '1') return;
-    void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    // rocprofv3 records the ranges of the rocprofiler-sdk's roctx library; roctracer's libroctx64 (rocprof v1 / v2) is the
+    // fallback
+    void* h = nullptr;
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1",
+                             "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so", "libroctx64.so.4",
+                             "/opt/rocm/lib/libroctx64.so"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
     if (!h) return;
     push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
     pop = (int (*)())dlsym(h, "roctxRangePop");
