@@ -161,6 +161,19 @@ def _worker(rank, world, port, tmp, case, q):
         for st in job.optimizer.state.values():                              # ... and holds their optimizer state only
             if torch.is_tensor(st.get("sum")) and st["sum"].dim() == 2 and st["sum"].shape[1] == dim:
                 assert st["sum"].shape[0] in (sh.hi - sh.lo, job.dataset.num_relations())
+        # stand-alone evaluation (kge valid / kge test of a checkpoint under the launcher): no parent training job -- the
+        # job cuts this rank's rows out of the (gathered) model and must find the last validation's metrics
+        from kge.job import EvaluationJob
+        sh.sync_model()
+        ev_conf = config.clone()
+        ev_conf.set("job.type", "eval")
+        ev_conf.set("eval.split", "valid")
+        ev = EvaluationJob.create(ev_conf, job.dataset, parent_job=None, model=job.model)
+        ev.epoch = 2
+        alone = ev.run()
+        assert type(ev).__name__ == "HipShardedEntityRankingJob" and getattr(ev, "_own_table", None) is not None
+        for k in ("mean_reciprocal_rank_filtered", "mean_reciprocal_rank_filtered_with_test", "hits_at_1_filtered"):
+            assert abs(alone[k] - valid[-1][k]) <= 1e-6 * max(1.0, abs(valid[-1][k])), (k, alone[k], valid[-1][k])
         ck = os.path.join(config.folder, "checkpoint_00002.pt")
         q.put((rank, losses, [{k: v for k, v in t.items() if isinstance(v, (int, float))} for t in valid],
                {k: v.numpy() for k, v in state.items()}, os.path.exists(ck), ck))
