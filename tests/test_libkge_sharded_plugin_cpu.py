@@ -174,6 +174,18 @@ def _worker(rank, world, port, tmp, case, q):
         assert type(ev).__name__ == "HipShardedEntityRankingJob" and getattr(ev, "_own_table", None) is not None
         for k in ("mean_reciprocal_rank_filtered", "mean_reciprocal_rank_filtered_with_test", "hits_at_1_filtered"):
             assert abs(alone[k] - valid[-1][k]) <= 1e-6 * max(1.0, abs(valid[-1][k])), (k, alone[k], valid[-1][k])
+        # `kge resume` on the same two ranks: Job.create_from(rank 0's checkpoint) builds the sharded job again and
+        # _load scatters the unsharded optimizer state onto this rank's rows
+        from kge.job import Job
+        dist.barrier()
+        ck0 = os.path.join(tmp, "sharded_rank0", "checkpoint_00002.pt")
+        re_conf = _config(tmp, f"resumed_rank{rank}", model, dim, sharded_type, "hip_sharded_entity_ranking", extra)
+        resumed = Job.create_from(rh.load_checkpoint(ck0, "cpu"), new_config=re_conf, dataset=job.dataset)
+        assert type(resumed).__name__ == type(job).__name__ and resumed.epoch == 2
+        assert torch.equal(resumed._sh.ent_master.detach(), sh.ent_master.detach())
+        for pa, pb in zip(resumed.optimizer.param_groups[0]["params"], job.optimizer.param_groups[0]["params"]):
+            sa, sb = resumed.optimizer.state[pa], job.optimizer.state[pb]
+            assert sa["sum"].shape == sb["sum"].shape and torch.allclose(sa["sum"], sb["sum"], rtol=0, atol=0)
         ck = os.path.join(config.folder, "checkpoint_00002.pt")
         q.put((rank, losses, [{k: v for k, v in t.items() if isinstance(v, (int, float))} for t in valid],
                {k: v.numpy() for k, v in state.items()}, os.path.exists(ck), ck))
