@@ -769,6 +769,47 @@ def ns_step_leg(device, n, steps):
     return out
 
 
+def kvsall_step_leg(device, n, steps):
+    """One whole KvsAll TRAINING step at BASELINE configs[3] (FB15k-237 shape, DistMult d = 512, bf16 scoring copies of
+    float32 masters): TrainingJobKvsAll._process_subbatch (kge/job/train_KvsAll.py:216-294) -- n sp_ queries and n _po
+    queries, each with its multi-hot labels as a CSR (1-8 known answers per query, as the KvsAll index hands them over),
+    the kl loss fused into the scoring kernel (kge_kl_fwd / kge_kl_bwd: no [n, E] score or label matrix), one backward per
+    query type -- + one-pass Adagrad, through kge_amd.model + kge_amd.optim: what `train.type: hip_KvsAll` drives.  Wall
+    clock per step issued call by call (label CSRs vary from batch to batch: no graph replay)."""
+    from kge_amd import model as km, optim as kopt
+    q = torch.Generator().manual_seed(9)
+    m = km.create("distmult", E_FB, R_FB, DIM, device=device, score_dtype=torch.bfloat16)
+    opt = kopt.Adagrad(m.parameters(), lr=0.1, bf16_copies=True)
+    a, b = (torch.randint(hi, (n,), generator=q).to(device) for hi in (E_FB, R_FB))
+    c = torch.randint(E_FB, (n,), generator=q).to(device)
+    csr = []
+    for _ in range(2):
+        cnt = torch.randint(1, 9, (n,), generator=q)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(cnt, 0)
+        col = torch.cat([torch.randperm(E_FB, generator=q)[:int(k)].sort().values for k in cnt])
+        csr.append((rowptr.to(device), col.to(device)))
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        (m.kl_loss_sp(a, b, *csr[0]).sum() / (2 * n)).backward()
+        (m.kl_loss_po(b, c, *csr[1]).sum() / (2 * n)).backward()
+        opt.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    flops = 3 * 2.0 * 2.0 * n * DIM * E_FB
+    return {"model": "distmult", "num_entities": E_FB, "dim": DIM, "queries_per_type": n, "labels_per_query": "1-8",
+            "loss": "kl on multi-hot labels (CSR), fused into the scoring kernel", "ms_per_step": ms,
+            "scored_triples_per_s": 2.0 * n * E_FB / (ms * 1e-3), "flops_per_step": flops,
+            "frac_of_mfma_peak": flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node
     (the contract's own command line), so that the line never reports n_gpus = 1 for a request of N."""
@@ -1121,10 +1162,11 @@ def main():
         extra_neg = neg_legs(engine, device, max(20, min(a.steps, 400) // 8))
         extra_eval = eval_leg(engine, device)
         extra_train = train_leg(device, n, max(10, min(a.steps, 200) // 4))
-        try:
-            extra_train["negative_sampling_step"] = ns_step_leg(device, n, max(10, min(a.steps, 200) // 4))
-        except Exception as exc:  # (a secondary leg never costs the line)
-            extra_train["negative_sampling_step"] = {"error": f"{type(exc).__name__}: {exc}"}
+        for key, fn in (("negative_sampling_step", ns_step_leg), ("kvsall_step", kvsall_step_leg)):
+            try:
+                extra_train[key] = fn(device, n, max(10, min(a.steps, 200) // 4))
+            except Exception as exc:  # (a secondary leg never costs the line)
+                extra_train[key] = {"error": f"{type(exc).__name__}: {exc}"}
     else:
         extra_f32 = extra_rank = extra_neg = extra_eval = extra_train = None
 
