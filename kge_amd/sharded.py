@@ -249,6 +249,7 @@ class ShardedEntityTable:
         self.collectives = self.world > 1 or (force and dist.is_initialized())
         self.E = int(num_entities)
         self.shard = (self.E + self.world - 1) // self.world
+        self.check_partition(self.E, self.world)
         self.lo = min(self.rank * self.shard, self.E)
         self.hi = min(self.lo + self.shard, self.E)
         if ent_local.shape[0] != self.hi - self.lo:
@@ -263,6 +264,16 @@ class ShardedEntityTable:
         # rank_batch_multi counts inside the scoring kernel where the backend offers it (no score slabs);
         # False / KGE_EVAL_TWO_STEP=1: score slabs + rank_counts_multi
         self.fused_rank = os.environ.get("KGE_EVAL_TWO_STEP", "0") != "1"
+
+    @staticmethod
+    def check_partition(num_entities: int, world: int):
+        """Every rank must own at least one row: the kernels refuse an empty table (KGE_ERR_INVALID_ARG), and a rank
+        failing alone would leave the others waiting in the next collective.  The split is a function of
+        (num_entities, world) only, so every rank raises here together."""
+        shard = (num_entities + world - 1) // world
+        if num_entities < 1 or (world - 1) * shard >= num_entities:
+            raise ValueError(f"kge_amd: {num_entities} entities in shards of {shard} rows leave rank(s) from "
+                             f"{(num_entities + shard - 1) // max(shard, 1)} of {world} without rows; use fewer ranks")
 
     @staticmethod
     def partition(num_entities: int, world: int, rank: int):

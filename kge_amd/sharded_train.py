@@ -71,6 +71,7 @@ class _ShardedJob:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device(device) if device is not None else torch.device("cpu")
+        ShardedEntityTable.check_partition(self.E, self.world)
         self.lo, self.hi = ShardedEntityTable.partition(self.E, self.world, self.rank)
         if state_dict is not None:
             ent_full, rel_full = state_dict[ENT_KEY], state_dict[REL_KEY]

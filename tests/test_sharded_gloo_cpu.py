@@ -723,3 +723,23 @@ def test_sharded_kvsall_and_negative_sampling_jobs_equal_the_unsharded_runs(mode
         for key, (losses, ent_after) in out.items():
             np.testing.assert_allclose(losses, ref[key][0], rtol=2e-5, atol=1e-6, err_msg=key)
             np.testing.assert_allclose(ent_after, ref[key][1], rtol=2e-4, atol=2e-6, err_msg=key)
+
+
+def test_a_split_that_leaves_a_rank_without_rows_is_refused_on_every_rank():
+    """E = 9 over 4 ranks = 3 rows each, rank 3 owns [9, 9).  The kernels refuse an empty table, and one rank
+    raising alone leaves the others in the next all-gather; the split depends on (E, world) only, so the constructor
+    refuses it everywhere.  (The `isfinite` guard on the kl labels in _ShardedKL stays: a shard's lse may also be -inf
+    because all its scores are.)"""
+    from kge_amd.sharded import ShardedEntityTable
+    from kge_amd.sharded_train import ShardedTrainingJob1vsAll
+    with pytest.raises(ValueError, match="without rows"):
+        ShardedEntityTable.check_partition(9, 4)
+    with pytest.raises(ValueError, match="without rows"):
+        ShardedEntityTable.check_partition(1, 2)
+    for E, world in ((9, 3), (10, 4), (9, 9), (14541, 8), (4818298, 8), (7, 1)):
+        ShardedEntityTable.check_partition(E, world)
+        parts = [ShardedEntityTable.partition(E, world, r) for r in range(world)]
+        assert all(hi > lo for lo, hi in parts) and parts[0][0] == 0 and parts[-1][1] == E
+        assert all(parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+    with pytest.raises(ValueError, match="without rows"):  # (no process group: one rank, zero entities)
+        ShardedTrainingJob1vsAll("distmult", 0, 3, 8, backend=OracleBackend)
