@@ -632,7 +632,7 @@ def main_sharded(a, world, rank, device):
 def train_leg(device, n, steps):
     """One whole 1vsAll TRAINING step at the bench shape (kge/job/train_1vsAll.py:48-82 + train.py:471-474): the fused
     cross-entropy forward of both directions (no score matrix), its backward (d loss / d score recomputed in the
-    scoring kernel, two gradient products) and a one-pass Adagrad step over both tables -- kge_amd.model.loss_sp_po +
+    scoring kernel, two gradient products) and a one-pass Adagrad step over both tables -- kge_amd.model.loss_sp_po_sum +
     kge_amd.optim.Adagrad, the path `train.type: hip_1vsAll` drives.  bf16 scoring copies of float32 master tables
     (mixed precision) and float32 scoring.  Wall clock over `steps` steps, synchronised at both ends."""
     from kge_amd import model as km, optim as kopt
@@ -647,7 +647,7 @@ def train_leg(device, n, steps):
 
         def step():
             opt.zero_grad(set_to_none=True)
-            m.loss_sp_po(s, p, o).sum().backward()
+            m.loss_sp_po_sum(s, p, o).backward()
             opt.step()
         for _ in range(3):
             step()
@@ -665,14 +665,15 @@ def train_leg(device, n, steps):
         g_ms = None
         if sd == torch.bfloat16:
             from kge_amd.train_graph import GraphedStep
-            gs = GraphedStep(lambda a_, b_, c_: m.loss_sp_po(a_, b_, c_).sum(), opt, warmup=1)
+            tri = torch.stack([s, p, o], 1)  # the batch as LibKGE hands it over: one [n, 3] tensor, one copy per replay
+            gs = GraphedStep(lambda t_: m.loss_sp_po_sum(t_[:, 0], t_[:, 1], t_[:, 2]), opt, warmup=1)
             for _ in range(4):
-                gs(s, p, o)
+                gs(tri)
             if gs.replays > 0:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(steps):
-                    gs(s, p, o)
+                    gs(tri)
                 torch.cuda.synchronize()
                 g_ms = (time.perf_counter() - t0) / steps * 1e3
             del gs

@@ -554,6 +554,22 @@ int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_in
                            float* grad_ent, float* grad_rel, void* workspace,
                            int64_t workspace_bytes, void* stream);
 
+/* The batch loss as ONE device scalar, for a training step that is captured into a hipGraph and replayed
+ * (kge_amd/train_graph.py): TrainingJob1vsAll sums the rows and divides by the batch size
+ * (kge/job/train_1vsAll.py:64-82, kge/util/loss.py:192-207 reduction "sum"), three more launches and as many
+ * autograd nodes around the two calls above.  kge_ce_sp_po_fwd_sum: kge_ce_sp_po_fwd, and in the same launches
+ *   loss_sum[0] = scale * scale_dev[0] * sum_i loss_rows[i]      (scale_dev == NULL: factor 1; device float)
+ * summed in a fixed order (bitwise reproducible).  kge_ce_sp_po_bwd_accum_sum: kge_ce_sp_po_bwd_accum with the
+ * SAME gradient for every row, g = scale * g_dev[0] * scale_dev[0] (NULL: factor 1) -- the upstream gradient of
+ * loss_sum and the scale as device scalars: nothing of the step is a host value, so a replay follows both. */
+int kge_ce_sp_po_fwd_sum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                         float* loss_rows, float* lse, const float* scale_dev, float scale,
+                         float* loss_sum, void* workspace, int64_t workspace_bytes, void* stream);
+int kge_ce_sp_po_bwd_accum_sum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                               const float* lse, const float* g_dev, const float* scale_dev, float scale,
+                               float* grad_ent, float* grad_rel, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
 /* KvsAll variant: KL divergence of softmax(score(i, .)) from the row's normalised multi-hot
  * labels, lbl_col[lbl_rowptr[i] .. lbl_rowptr[i+1]) (int64 CSR on the device, entity ids unique
  * per row), y_ij = 1/k_i:
@@ -618,6 +634,20 @@ int kge_bce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
 int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t count,
                      float minus_clr, float weight_decay, float eps, void* bf16_copy,
                      void* stream);
+
+/* kge_adagrad_step on up to KGE_ADAGRAD_MAX_SEGS tables in ONE launch (the entity and the relation table of a
+ * training step; kge/job/train.py:471-474 optimizer.step() over all parameters): the same arithmetic per
+ * element, one launch latency instead of one per parameter. */
+#define KGE_ADAGRAD_MAX_SEGS 8
+typedef struct kge_adagrad_seg {
+  float* param;
+  const float* grad;
+  float* state_sum;
+  void* bf16_copy;      /* or NULL */
+  int64_t count;
+  float minus_clr, weight_decay, eps;
+} kge_adagrad_seg;
+int kge_adagrad_step_multi(const kge_adagrad_seg* segs, int num_segs, void* stream);
 
 /* One dense Adam step (torch.optim.Adam, amsgrad / maximize off) on `count` contiguous f32 elements,
  * in place, one pass:  g = grad + weight_decay * param (if != 0);  exp_avg += (g - exp_avg)(1 - beta1);

@@ -49,6 +49,14 @@ class KgeNextQueries(ctypes.Structure):
                 ("queries_bytes", c_i64)]
 
 
+class KgeAdagradSeg(ctypes.Structure):
+    _fields_ = [("param", c_vp), ("grad", c_vp), ("state_sum", c_vp), ("bf16_copy", c_vp), ("count", c_i64),
+                ("minus_clr", ctypes.c_float), ("weight_decay", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
+ADAGRAD_MAX_SEGS = 8
+
+
 class KgeEvalFilter(ctypes.Structure):
     _fields_ = [("sp_keys", c_vp), ("sp_num_keys", c_i64), ("sp_starts", c_vp), ("sp_values", c_vp),
                 ("po_keys", c_vp), ("po_num_keys", c_i64), ("po_starts", c_vp), ("po_values", c_vp)]
@@ -149,6 +157,11 @@ PROTOTYPES = {
                                         c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_ce_sp_po_bwd_accum": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, ctypes.c_float,
                                               c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kge_ce_sp_po_fwd_sum": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp,
+                                            ctypes.c_float, c_vp, c_vp, c_i64, c_vp]),
+    "kge_ce_sp_po_bwd_accum_sum": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp,
+                                                  ctypes.c_float, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "kge_adagrad_step_multi": (ctypes.c_int, [ctypes.POINTER(KgeAdagradSeg), ctypes.c_int, c_vp]),
     "kge_kl_fwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
     "kge_kl_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp,

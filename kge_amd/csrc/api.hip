@@ -131,11 +131,12 @@ int run_bce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& T
 long long ce2_workspace_bytes(int d, long long n, long long m);
 int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, float* loss_rows, float* lse, void* ws, long long ws_bytes,
-                hipStream_t st);
+                hipStream_t st, float* loss_sum = nullptr, const float* scale_dev = nullptr, float scale = 1.0f);
 int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, const float* lse, const float* g_rows, float g_scalar, float* g_a,
                 float* g_p, float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, void* ws,
-                long long ws_bytes, hipStream_t st);
+                long long ws_bytes, hipStream_t st, const float* g_dev = nullptr, const float* g_dev2 = nullptr);
+int run_adagrad_multi(const kge_adagrad_seg* segs, int num, hipStream_t st);
 int run_adagrad(float* param, const float* grad, float* sum, long long count, float minus_clr, float weight_decay,
                 float eps, unsigned short* copy16, hipStream_t st);
 int run_adam(float* param, const float* grad, float* m1, float* m2, long long count, float step_size, float bc2_sqrt,
@@ -1584,6 +1585,33 @@ int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_in
                      t->rel_dim, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int kge_ce_sp_po_fwd_sum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, float* loss_rows,
+                         float* lse, const float* scale_dev, float scale, float* loss_sum, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
+  int rc = ce_check(t, KGE_SP_, s, p, o, n);
+  if (rc) return rc;
+  if (!loss_sum || (n > 0 && (!loss_rows || !lse))) return KGE_ERR_INVALID_ARG;
+  const kge_index all = {nullptr, 0, 0, 1};
+  return run_ce2_fwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
+                     t->num_ent, loss_rows, lse, workspace, workspace_bytes, (hipStream_t)stream, loss_sum, scale_dev,
+                     scale);
+}
+
+int kge_ce_sp_po_bwd_accum_sum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                               const float* lse, const float* g_dev, const float* scale_dev, float scale,
+                               float* grad_ent, float* grad_rel, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+  KGE_RANGE();
+  int rc = ce_check(t, KGE_SP_, s, p, o, n);
+  if (rc) return rc;
+  if (!grad_ent || !grad_rel || (n > 0 && !lse)) return KGE_ERR_INVALID_ARG;
+  const kge_index all = {nullptr, 0, 0, 1};
+  return run_ce2_bwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
+                     t->num_ent, lse, nullptr, scale, nullptr, nullptr, grad_ent, grad_rel, t->num_rel, t->rel_dim,
+                     workspace, workspace_bytes, (hipStream_t)stream, g_dev, scale_dev);
+}
+
 int kge_kl_weighted_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
                         const int64_t* lbl_rowptr, const int64_t* lbl_col, const float* label_weight,
                         float* loss_rows, float* lse, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -1662,6 +1690,18 @@ int kge_adagrad_step(float* param, const float* grad, float* state_sum, int64_t 
   if (bf16_copy && ((uintptr_t)bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
   return run_adagrad(param, grad, state_sum, count, minus_clr, weight_decay, eps, (unsigned short*)bf16_copy,
                      (hipStream_t)stream);
+}
+
+int kge_adagrad_step_multi(const kge_adagrad_seg* segs, int num_segs, void* stream) {
+  KGE_RANGE();
+  if (num_segs < 0 || num_segs > KGE_ADAGRAD_MAX_SEGS || (num_segs > 0 && !segs)) return KGE_ERR_INVALID_ARG;
+  for (int j = 0; j < num_segs; ++j) {
+    const kge_adagrad_seg& g = segs[j];
+    if (g.count < 0 || (g.count > 0 && (!g.param || !g.grad || !g.state_sum))) return KGE_ERR_INVALID_ARG;
+    if (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.state_sum) & 15) return KGE_ERR_INVALID_ARG;
+    if (g.bf16_copy && ((uintptr_t)g.bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
+  }
+  return run_adagrad_multi(segs, num_segs, (hipStream_t)stream);
 }
 
 int kge_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float step_size,

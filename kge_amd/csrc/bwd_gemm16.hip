@@ -386,6 +386,16 @@ bool bwd_gemm16_enabled() {
   return !lib;
 }
 
+// bytes of split-K scratch with which run_gemm16_dq takes as many splits as it wants (0: it would not split)
+long long gemm16_dq_scratch_bytes(int d, long long rows, long long m) {
+  if ((d % G16_BN) || rows <= 0 || m <= 0) return 0;
+  const long long per = ((rows + G16_BM - 1) / G16_BM) * (d / G16_BN);
+  long long splits = 256 / per;
+  const long long ksteps = (m + G16_BK - 1) / G16_BK;
+  if (splits > ksteps) splits = ksteps;
+  return splits < 2 ? 0 : splits * rows * (long long)d * (long long)sizeof(float);
+}
+
 // dQ[rows, d] = G16[rows, :m] * T[m, d].  Returns the number of split-K partials written to `scratch`
 // ([splits][rows, d]; the caller sums them into C: bwdg_reduce_kernel), 1 if the product went straight
 // to C (no split), 0 if the shape is not handled (the caller's library path).

@@ -40,29 +40,81 @@ int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operan
 int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A2, const Operand& R,
                                  const Operand& TG, int d, long long n, long long m, const unsigned short* G16,
                                  long long mp, unsigned short* Q16, float* g_a, float* g_p, float* g_tgt,
-                                 float* acc_rel, long long acc_rel_ld, hipStream_t st);
+                                 float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, float* dq_scratch,
+                                 long long dq_scratch_bytes, hipStream_t st);
+long long gemm16_dq_scratch_bytes(int d, long long rows, long long m);
 
 // merge the column groups of a row: M = max_c m_c, L = sum_c l_c exp(m_c - M).  One wave per row,
 // lanes over the column groups, xor-butterfly reductions (fixed order: deterministic).
-__global__ __launch_bounds__(256) void ce_combine_kernel(const float* __restrict__ part, int ncg, long long n,
+//   * A label outside [0, m) was found by no lane of the scoring kernel -- its true_score slot is stale scratch --:
+//     the row's loss reads NaN (another shard owns the label: the sharded loss takes the owner's value).  The labels
+//     are checked HERE; until round 5 a fill launch wrote NaN over the slots before every scoring launch.
+//   * sum.out != NULL: scale * sum_i loss_rows[i] as well, in the same launch: every workgroup leaves the sum of its
+//     rows in sum.blk, the workgroup that arrives last (a wrapping counter in the workspace's control block,
+//     zero between calls) adds them up in a fixed order -- the same bits whatever the arrival order.
+struct CeSum {
+  float* out;              // [1], or NULL: no sum
+  float* blk;              // [gridDim.x] scratch
+  unsigned int* counter;   // zero before the launch, zero after it
+  const float* scale_dev;  // [1] or NULL
+  float scale;
+};
+
+__global__ __launch_bounds__(1024) void ce_combine_kernel(const float* __restrict__ part, int ncg, long long n,
                                                          const float* __restrict__ true_score,
-                                                         float* __restrict__ loss_rows, float* __restrict__ lse) {
-  const int lane = threadIdx.x & 63;
-  const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n) return;
-  const float* p = part + i * ncg * 2;
-  float M = -__builtin_inff();
-  for (int c = lane; c < ncg; c += 64) M = fmaxf(M, p[2 * c]);
+                                                         float* __restrict__ loss_rows, float* __restrict__ lse,
+                                                         Index label, Index label2, long long side2_off, long long m,
+                                                         CeSum sum) {
+  // one wave per row, blockDim.x / 64 rows per workgroup: 4 (256 threads), or 16 with the sum -- a quarter of the
+  // arrivals (fence + counter) of the 4-row launch, which cost as much as the launch they replaced
+  __shared__ float sh_row[16];
+  __shared__ int sh_last;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const long long i = (long long)blockIdx.x * nw + w;
+  float li = 0.0f;
+  if (i < n) {
+    const float* p = part + i * ncg * 2;
+    float M = -__builtin_inff();
+    for (int c = lane; c < ncg; c += 64) M = fmaxf(M, p[2 * c]);
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
-  float L = 0.0f;
-  for (int c = lane; c < ncg; c += 64) L += p[2 * c + 1] * expf(p[2 * c] - M);
+    for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    float L = 0.0f;
+    for (int c = lane; c < ncg; c += 64) L += p[2 * c + 1] * expf(p[2 * c] - M);
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) L += __shfl_xor(L, off, 64);
+    for (int off = 32; off >= 1; off >>= 1) L += __shfl_xor(L, off, 64);
+    if (lane == 0) {
+      const float z = M + logf(L);
+      const Index& lix = i < side2_off ? label : label2;
+      const long long lab = lix.ptr != nullptr ? index_at(lix, i < side2_off ? i : i - side2_off) : -1;
+      li = lab >= 0 && lab < m ? z - true_score[i] : __builtin_nanf("");
+      lse[i] = z;
+      loss_rows[i] = li;
+    }
+  }
+  if (sum.out == nullptr) return;  // (uniform over the launch)
+  if (lane == 0) sh_row[w] = li;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sb = sh_row[0];
+    for (int k = 1; k < nw; ++k) sb += sh_row[k];
+    __hip_atomic_store(sum.blk + blockIdx.x, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();  // the partial is visible device-wide before this workgroup counts as arrived
+    // atomicInc wraps: the counter is back at zero once the last workgroup has arrived (and a counter that was
+    // not zero -- a workspace that was never cleared -- is after one call)
+    sh_last = atomicInc(sum.counter, gridDim.x - 1) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (sh_last == 0 || w != 0) return;
+  __threadfence();
+  float acc = 0.0f;
+  for (unsigned int b = lane; b < gridDim.x; b += 64)
+    acc += __hip_atomic_load(sum.blk + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (lane == 0) {
-    const float z = M + logf(L);
-    lse[i] = z;
-    loss_rows[i] = z - true_score[i];
+    float r = acc * sum.scale;
+    if (sum.scale_dev != nullptr) r = r * sum.scale_dev[0];
+    sum.out[0] = r;
   }
 }
 
@@ -287,12 +339,11 @@ int run_ce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   ce.label = label;
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));
-  // a label outside [0, num_ent) is found by no lane: its row's loss then reads NaN, not stale scratch
-  if (!fill_words_async(ce.true_score, 0xff, (size_t)n * sizeof(float), st)) return KGE_ERR_LAUNCH;
+  // (a label outside [0, num_ent) is found by no lane: ce_combine_kernel makes its row's loss NaN, not stale scratch)
   const int rc = run_lse_pass(scorer, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, n,
-                     ce.true_score, loss_rows, lse);
+                     ce.true_score, loss_rows, lse, label, label, n, m, CeSum{});
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
@@ -425,16 +476,24 @@ static inline long long ce2_rows(long long n) { return 2 * ((n + 127) / 128) * 1
 
 long long ce2_workspace_bytes(int d, long long n, long long m) {
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));  // sized for two sides
-  const long long fwd = al256(2 * n * pairs_bf16_v3_column_groups(ce2_rows(n), m) * 8) + al256(2 * n * 4);
-  // backward: G16, Q16 and (kge_ce_sp_po_bwd_accum) the f32 dQ rows
-  const long long bwd = al256(2 * n * ce_ld16(m) * 2) + al256(2 * n * (long long)d * 2) + al256(2 * n * (long long)d * 4);
+  // forward: column-group partials, label scores, the combine launch's per-workgroup sums (kge_ce_sp_po_fwd_sum)
+  const long long fwd = al256(2 * n * pairs_bf16_v3_column_groups(ce2_rows(n), m) * 8) + al256(2 * n * 4) +
+                        al256((2 * n + 3) / 4 * 4);
+  // backward: G16, Q16 and (kge_ce_sp_po_bwd_accum) the f32 dQ rows + the split-K partials of that product
+  const long long bwd = al256(2 * n * ce_ld16(m) * 2) + al256(2 * n * (long long)d * 2) +
+                        al256(2 * n * (long long)d * 4) + al256(gemm16_dq_scratch_bytes(d, 2 * n, m));
   return coop + (fwd > bwd ? fwd : bwd);
 }
 
 int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, float* loss_rows, float* lse, void* ws, long long ws_bytes,
-                hipStream_t st) {
-  if (n == 0) return KGE_OK;
+                hipStream_t st, float* loss_sum, const float* scale_dev, float scale) {
+  // loss_sum != NULL (kge_ce_sp_po_fwd_sum): loss_sum[0] = scale * scale_dev[0] * sum of the 2n loss rows, from
+  // the combine launch itself
+  if (n == 0) {
+    if (loss_sum != nullptr && !fill_words_async(loss_sum, 0, sizeof(float), st)) return KGE_ERR_LAUNCH;
+    return KGE_OK;
+  }
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce2_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
   const int ncg = pairs_bf16_v3_column_groups(ce2_rows(n), m);
@@ -446,33 +505,42 @@ int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   ce.side2_off = n;
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(2 * n * ncg * 8));
-  if (!fill_words_async(ce.true_score, 0xff, (size_t)(2 * n) * sizeof(float), st)) return KGE_ERR_LAUNCH;
   const int rc = run_lse_pass(scorer, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
-  hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((2 * n + 3) / 4)), dim3(256), 0, st, ce.part, ncg, 2 * n,
-                     ce.true_score, loss_rows, lse);
+  CeSum sum{};
+  if (loss_sum != nullptr) {
+    sum.out = loss_sum;
+    sum.blk = ce.true_score + al256(2 * n * 4) / 4;
+    sum.counter = (unsigned int*)((char*)ws + PAIRS_WS_CE_COUNTER_OFF);
+    sum.scale_dev = scale_dev;
+    sum.scale = scale;
+  }
+  const int rpb = loss_sum != nullptr ? 16 : 4;  // rows per workgroup
+  hipLaunchKernelGGL(ce_combine_kernel, dim3((unsigned)((2 * n + rpb - 1) / rpb)), dim3(64 * rpb), 0, st, ce.part, ncg,
+                     2 * n, ce.true_score, loss_rows, lse, ce.label, ce.label2, n, m, sum);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
 int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, const float* lse, const float* g_rows, float g_scalar, float* g_a,
                 float* g_p, float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, void* ws,
-                long long ws_bytes, hipStream_t st) {
+                long long ws_bytes, hipStream_t st, const float* g_dev, const float* g_dev2) {
   // acc_rel != NULL (kge_ce_sp_po_bwd_accum): g_a / g_p are not returned; the row gradients are added
-  // into g_tgt (on top of dT) and into the zeroed acc_rel [acc_rel_rows, acc_rel_ld]
-  if (acc_rel != nullptr &&
-      !fill_words_async(acc_rel, 0, (size_t)acc_rel_rows * acc_rel_ld * sizeof(float), st))
-    return KGE_ERR_LAUNCH;
+  // into g_tgt (on top of dT) and into acc_rel [acc_rel_rows, acc_rel_ld], which the query-build launch of the
+  // products clears on its way (a launch of its own until round 5)
   if (n == 0) {
-    if (acc_rel != nullptr && !fill_words_async(g_tgt, 0, (size_t)m * d * sizeof(float), st))
+    if (acc_rel != nullptr && (!fill_words_async(acc_rel, 0, (size_t)acc_rel_rows * acc_rel_ld * sizeof(float), st) ||
+                               !fill_words_async(g_tgt, 0, (size_t)m * d * sizeof(float), st)))
       return KGE_ERR_LAUNCH;
     return KGE_OK;
   }
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce2_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
   const long long ld16 = ce_ld16(m);
-  if (acc_rel != nullptr)
-    g_a = (float*)((char*)ws + coop + al256(2 * n * ld16 * 2) + al256(2 * n * (long long)d * 2));
+  float* const dq_rows = (float*)((char*)ws + coop + al256(2 * n * ld16 * 2) + al256(2 * n * (long long)d * 2));
+  const long long dq_scratch_bytes = gemm16_dq_scratch_bytes(d, 2 * n, m);
+  float* const dq_scratch = dq_scratch_bytes > 0 ? dq_rows + al256(2 * n * (long long)d * 4) / 4 : nullptr;
+  if (acc_rel != nullptr) g_a = dq_rows;
   CeArgs ce{};
   ce.label = O.idx;
   ce.label2 = S.idx;
@@ -482,13 +550,15 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   ce.lse = lse;
   ce.g_rows = g_rows;
   ce.g_scalar = g_scalar;
+  ce.g_dev = g_dev;
+  ce.g_dev2 = g_dev2;
   ce.g16 = (unsigned short*)((char*)ws + coop);
   ce.ld16 = ld16;
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(2 * n * ld16 * 2));
   const int rc = run_ds_pass(scorer, V3_DS, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
   return run_pairs_bwd_products16_two(scorer, S, O, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, acc_rel,
-                                      acc_rel_ld, st);
+                                      acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st);
 }
 
 void ce_set_stamps(unsigned long long* p) { g_ce_stamps = p; }

@@ -14,6 +14,8 @@ namespace kge {
 
 // control block at the start of the cooperative-build workspace: 512 flag lines of 64 B + the degraded word
 constexpr long long PAIRS_WS_CTRL_BYTES = 512 * 8 * 8 + 256;
+// inside its last 256 bytes: +0 the degraded word (8 B), +64 the arrival counter of ce_combine_kernel's sum (4 B)
+constexpr long long PAIRS_WS_CE_COUNTER_OFF = 512 * 8 * 8 + 64;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -383,6 +385,11 @@ struct CeArgs {
                             // the uniform part of smoothed labels (kge_kl_weighted_bwd)
   const float* g_rows;      // V3_DS / V3_DSIG: [n] upstream gradient of row i's loss, or NULL: g_scalar
   float g_scalar;
+  // g_rows == NULL: every row's gradient is g_scalar * g_dev[0] * g_dev2[0] (each factor 1 where the pointer is
+  // NULL) -- the gradient of scale * sum(loss_rows) with the upstream gradient and the scale as DEVICE scalars
+  // (kge_ce_sp_po_bwd_accum_sum: nothing of a captured training step is a host value)
+  const float* g_dev;
+  const float* g_dev2;
   float offset;             // V3_SPLUS / V3_DSIG: added to every score (train.loss_arg of the bce loss)
   unsigned short* g16;      // V3_DS: [n][ld16] bf16, ld16 % 64 == 0 and ld16 >= 64 * ntiles
   long long ld16;
@@ -407,6 +414,14 @@ struct CeArgs {
   long long rk_bits_rs, rk_bits_us;
   int rk_clear_bits;                  // pairs_bf16_v8_rank_kernel: store zero over every filter word it has read
 };
+
+__device__ __forceinline__ float ce_row_gradient(const CeArgs& ce, long long row) {
+  if (ce.g_rows != nullptr) return ce.g_rows[row];
+  float g = ce.g_scalar;
+  if (ce.g_dev != nullptr) g = g * ce.g_dev[0];
+  if (ce.g_dev2 != nullptr) g = g * ce.g_dev2[0];
+  return g;
+}
 
 // ---- the tie arithmetic of EntityRankingJob._get_ranks_and_num_ties (eval_entity_ranking.py:571-596), shared by
 // rank.hip and the counting epilogue of the scoring kernel

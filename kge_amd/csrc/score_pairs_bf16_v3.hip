@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     if (lab_ix.ptr != nullptr) lab = index_at(lab_ix, orow);
     if constexpr (IS_DS) {
       if constexpr (EPI == V3_DS) lse_i = ce.lse[orow + roff];
-      g_i = ce.g_rows != nullptr ? ce.g_rows[orow + roff] : ce.g_scalar;
+      g_i = ce_row_gradient(ce, orow + roff);
       if (ce.rowptr != nullptr && ce.rowptr[orow + 1] == ce.rowptr[orow]) g_i = 0.0f;
       if (EPI == V3_DS && ce.row_bias != nullptr) gb_i = g_i * ce.row_bias[orow + roff];
     }

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     if (orow >= n) orow = n - 1;
     if (lix.ptr != nullptr) lab = index_at(lix, orow);
     if constexpr (EPI == V3_DS) lse_i = ce.lse[orow + roff];
-    g_i = ce.g_rows != nullptr ? ce.g_rows[orow + roff] : ce.g_scalar;
+    g_i = ce_row_gradient(ce, orow + roff);
     if (ce.rowptr != nullptr && ce.rowptr[orow + 1] == ce.rowptr[orow]) g_i = 0.0f;  // (one-sided multi-label loss)
     if (EPI == V3_DS && ce.row_bias != nullptr) gb_i = g_i * ce.row_bias[orow + roff];
   }

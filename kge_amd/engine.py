@@ -1408,6 +1408,57 @@ def ce_sp_po_bwd_accum(t: Tables, s, p, o, lse, g_rows=None, g_scalar: float = 1
     return ge, grel
 
 
+def _dev_scalar(x, device, what):
+    """A float32 device scalar (0-d or one element) as the kernels read it, or None."""
+    if x is None:
+        return None
+    if not (torch.is_tensor(x) and x.numel() == 1 and x.dtype == torch.float32 and x.device == device):
+        raise ValueError(f"{what}: a float32 tensor of one element on {device} expected")
+    return x
+
+
+def ce_sp_po_fwd_sum(t: Tables, s, p, o, scale=None):
+    """ce_sp_po_fwd and, from the same launches, the batch loss as a device scalar:
+    (loss_sum 0-d = scale * sum(loss_rows), loss_rows [2n], lse [2n]).  `scale`: None, a Python float, or a float32
+    device scalar (read by the kernel at run time: a captured step follows it)."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = _same_len(keep[:3], "ce_sp_po_fwd_sum")
+    sd = _dev_scalar(scale, t.device, "ce_sp_po_fwd_sum(scale)") if torch.is_tensor(scale) else None
+    sh = 1.0 if scale is None or sd is not None else float(scale)
+    loss_rows, lse, total = _empty((2 * n,), t.device), _empty((2 * n,), t.device), _empty((), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce2_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_sp_po_fwd_sum(
+            ctypes.byref(tc), si, pi, oi, n, loss_rows.data_ptr(), lse.data_ptr(),
+            None if sd is None else sd.data_ptr(), sh, total.data_ptr(), ws, wsb, st), "kge_ce_sp_po_fwd_sum")
+    return total, loss_rows, lse
+
+
+def ce_sp_po_bwd_accum_sum(t: Tables, s, p, o, lse, g=None, scale=None):
+    """Backward of ce_sp_po_fwd_sum: the complete (grad_entities, grad_relations) for the upstream gradient `g` of
+    loss_sum (a float32 device scalar, or None = 1) and the forward's `scale`; neither is read by the host."""
+    keep = []
+    si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
+    n = _same_len(keep[:3], "ce_sp_po_bwd_accum_sum")
+    lse = _f32c(lse, t.device)
+    gd = _dev_scalar(g, t.device, "ce_sp_po_bwd_accum_sum(g)")
+    sd = _dev_scalar(scale, t.device, "ce_sp_po_bwd_accum_sum(scale)") if torch.is_tensor(scale) else None
+    sh = 1.0 if scale is None or sd is not None else float(scale)
+    ge, grel = _empty(tuple(t.ent.shape), t.device), _empty(tuple(t.rel.shape), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        ws, wsb = _ce2_workspace(tc, max(n, 1), t.device, st)
+        _lib.check(_lib.lib().kge_ce_sp_po_bwd_accum_sum(
+            ctypes.byref(tc), si, pi, oi, n, lse.data_ptr(), None if gd is None else gd.data_ptr(),
+            None if sd is None else sd.data_ptr(), sh, ge.data_ptr(), grel.data_ptr(), ws, wsb, st),
+            "kge_ce_sp_po_bwd_accum_sum")
+    return ge, grel
+
+
 def _csr64(rowptr, col, dev):
     rp = rowptr.to(device=dev, dtype=torch.int64).contiguous()
     cl = col.to(device=dev, dtype=torch.int64).contiguous()

@@ -8,8 +8,8 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import (BF16Shadow, _FusedCE, _FusedCE2, _ScoreEmb, _ScoreNeg, _ScoreNegBlocks, _ScorePairs, _ScoreSPO,
-                     bce_fused, ce_fused_dropout, kl_fused, neg_blocks_fusable)
+from ..model import (BF16Shadow, _FusedCE, _FusedCE2, _FusedCE2Sum, _ScoreEmb, _ScoreNeg, _ScoreNegBlocks, _ScorePairs,
+                     _ScoreSPO, bce_fused, ce_fused_dropout, kl_fused, neg_blocks_fusable)
 
 
 class _HipScorer(RelationalScorer):
@@ -218,6 +218,18 @@ class _FusedScoring:
             return torch.cat((self.loss_sp(s, p, o), self.loss_po(p, o, s)))
         ent, rel = self._w()
         return _FusedCE2.apply(ent, rel, s, p, o, t)
+
+    def loss_sp_po_sum(self, s: Tensor, p: Tensor, o: Tensor, scale=None) -> Tensor:
+        """0-d: scale * loss_sp_po(s, p, o).sum(), summed and back-propagated inside the library's launches
+        (kge_amd.model._FusedCE2Sum; the step HipTrainingJob1vsAll captures); None if not applicable."""
+        t = self._ce_tables()
+        if t is None:
+            rows = self.loss_sp_po(s, p, o)
+            if rows is None:
+                return None
+            return rows.sum() if scale is None else rows.sum() * scale
+        ent, rel = self._w()
+        return _FusedCE2Sum.apply(ent, rel, s, p, o, t, scale)
 
     def kl_loss_sp(self, s: Tensor, p: Tensor, lbl_rowptr: Tensor, lbl_col: Tensor,
                    label_smoothing: float = 0.0) -> Tensor:

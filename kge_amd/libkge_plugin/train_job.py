@@ -130,8 +130,12 @@ class HipTrainingJob1vsAll(_CudaOomText, TrainingJob1vsAll):
             ok = ok and _optimizer_is_capturable(self.optimizer) and _no_penalty(self, batch_index, batch)
             self._graph_step_ok = ok
             if ok:
+                # the batch goes in as ONE tensor (one copy into the static buffer per replay, not three); the captured
+                # batches all have the size of the first (another size runs eagerly), so 1 / batch size is a constant
                 self._graph_step = _graphed_step_of(
-                    self, lambda s, p, o, inv: self.model.loss_sp_po(s, p, o).sum() * inv)
+                    self, (lambda t: self.model.loss_sp_po_sum(t[:, 0], t[:, 1], t[:, 2], 1.0 / len(t)))
+                    if hasattr(self.model, "loss_sp_po_sum")
+                    else (lambda t: self.model.loss_sp_po(t[:, 0], t[:, 1], t[:, 2]).sum() / len(t)))
         if not self._graph_step_ok:
             return None
         n = len(batch["triples"])
@@ -181,8 +185,7 @@ class HipTrainingJob1vsAll(_CudaOomText, TrainingJob1vsAll):
             gs = self._graph_step_for(batch_index, batch, subbatch_slice)
             if gs is not None and gs.enabled:
                 result.forward_time -= time.time()
-                inv = torch.full((), 1.0 / batch_size, device=triples.device)
-                loss_value = gs(triples[:, 0], triples[:, 1], triples[:, 2], inv)
+                loss_value = gs(triples)  # (whole batch: len(triples) == batch_size)
                 self._skip_optimizer_step = True  # (eager or replayed: the step is taken)
                 result.avg_loss += loss_value.item()
                 result.forward_time += time.time()

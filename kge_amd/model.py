@@ -237,6 +237,17 @@ class KgeModel(torch.nn.Module):
             return _FusedCE2.apply(self._entity_embedder.weight, self._relation_embedder.weight, s, p, o, t)
         return torch.cat([self.loss_sp(s, p, o), self.loss_po(p, o, s)])
 
+    def loss_sp_po_sum(self, s: Tensor, p: Tensor, o: Tensor, scale=None) -> Tensor:
+        """0-d: scale * loss_sp_po(s, p, o).sum() -- the batch loss of TrainingJob1vsAll (train_1vsAll.py:64-82 with
+        scale = 1 / batch_size) -- summed inside the loss kernels' own launches, its backward taking the upstream
+        gradient and `scale` (None, a float, or a float32 device scalar) as device scalars: three launches and three
+        autograd nodes fewer per step than `.sum() * scale` around loss_sp_po."""
+        t = self._ce_tables()
+        if t is not None:
+            return _FusedCE2Sum.apply(self._entity_embedder.weight, self._relation_embedder.weight, s, p, o, t, scale)
+        total = self.loss_sp_po(s, p, o).sum()
+        return total if scale is None else total * scale
+
     def loss_po(self, p: Tensor, o: Tensor, s: Tensor) -> Tensor:
         """Per-row cross entropy of score_po(p, o) against the true subjects s."""
         t = self._ce_tables()
@@ -563,6 +574,27 @@ class _FusedCE2(torch.autograd.Function):
         # complete table gradients from the library (the scatter-add of the gathered rows included)
         ge, gr = engine.ce_sp_po_bwd_accum(ctx.t16, s, p, o, lse, g_rows=g_rows.contiguous())
         return ge, gr, None, None, None, None
+
+
+class _FusedCE2Sum(torch.autograd.Function):
+    """scale * sum of _FusedCE2's rows as a 0-d tensor (kge_ce_sp_po_fwd_sum / kge_ce_sp_po_bwd_accum_sum): the sum
+    leaves the combine launch, the backward reads the upstream gradient and the scale from device memory.  `scale`
+    is a constant of the graph (no gradient flows into it)."""
+
+    @staticmethod
+    def forward(ctx, ent, rel, s, p, o, tables16, scale):
+        total, _rows, lse = engine.ce_sp_po_fwd_sum(tables16, s, p, o, scale)
+        ctx.t16, ctx.idx, ctx.scale = tables16, (s, p, o), scale
+        ctx.save_for_backward(lse)
+        return total
+
+    @staticmethod
+    def backward(ctx, gout):
+        s, p, o = ctx.idx
+        (lse,) = ctx.saved_tensors
+        g = gout if gout.dtype == torch.float32 and gout.is_contiguous() else gout.float().contiguous()
+        ge, gr = engine.ce_sp_po_bwd_accum_sum(ctx.t16, s, p, o, lse, g=g, scale=ctx.scale)
+        return ge, gr, None, None, None, None, None
 
 
 # ---- embedder dropout inside the fused 1vsAll loss ------------------------------------------------------------------

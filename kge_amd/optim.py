@@ -107,6 +107,7 @@ class Adagrad(_TorchAdagrad):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        dense = {}  # device -> [(p, copy, segment)]: every dense table of a device in ONE launch (kge_adagrad_step_multi)
         for group in self.param_groups:
             if group.get("maximize") or group.get("differentiable"):
                 raise NotImplementedError("kge_amd.optim.Adagrad: maximize / differentiable are not supported")
@@ -130,14 +131,10 @@ class Adagrad(_TorchAdagrad):
                     rec = getattr(p, BF16_ATTR, None)
                     copy = rec[0] if rec is not None and rec[0].shape == p.shape else \
                         torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
-                with torch.cuda.device(p.device):
-                    _lib.check(_lib.lib().kge_adagrad_step(
-                        p.data_ptr(), p.grad.data_ptr(), s.data_ptr(), p.numel(), minus_clr,
-                        float(group["weight_decay"]), float(group["eps"]),
-                        None if copy is None else copy.data_ptr(), engine._stream(p.device)), "kge_adagrad_step")
-                torch.autograd.graph.increment_version(p)  # the kernel wrote through the raw pointer
-                if copy is not None:
-                    setattr(p, BF16_ATTR, (copy, p._version, p.data_ptr()))
+                seg = _lib.KgeAdagradSeg(p.data_ptr(), p.grad.data_ptr(), s.data_ptr(),
+                                         None if copy is None else copy.data_ptr(), p.numel(), minus_clr,
+                                         float(group["weight_decay"]), float(group["eps"]))
+                dense.setdefault(p.device, []).append((p, copy, seg))
             if rest:  # torch's own update for everything else
                 grads = [p.grad for p in rest]
                 sums = [self.state[p]["sum"] for p in rest]
@@ -145,6 +142,17 @@ class Adagrad(_TorchAdagrad):
                 _functional_adagrad(rest, grads, sums, steps, has_sparse_grad=any(g.is_sparse for g in grads),
                                     foreach=False, lr=group["lr"], weight_decay=group["weight_decay"],
                                     lr_decay=group["lr_decay"], eps=group["eps"], maximize=False)
+        for device, items in dense.items():
+            with torch.cuda.device(device):
+                for i in range(0, len(items), _lib.ADAGRAD_MAX_SEGS):
+                    chunk = items[i:i + _lib.ADAGRAD_MAX_SEGS]
+                    segs = (_lib.KgeAdagradSeg * len(chunk))(*(c[2] for c in chunk))
+                    _lib.check(_lib.lib().kge_adagrad_step_multi(segs, len(chunk), engine._stream(device)),
+                               "kge_adagrad_step_multi")
+            for p, copy, _seg in items:
+                torch.autograd.graph.increment_version(p)  # the kernel wrote through the raw pointer
+                if copy is not None:
+                    setattr(p, BF16_ATTR, (copy, p._version, p.data_ptr()))
         return loss
 
 

@@ -6,9 +6,9 @@ GPU waits for the host.  A batch of a fixed shape is the same launch sequence ev
 (torch.cuda.CUDAGraph; HIP graphs underneath) and replayed: the host copies the batch's indexes into static buffers and
 issues one graph launch.
 
-    step = GraphedStep(lambda s, p, o: model.loss_sp_po(s, p, o).sum() / len(s), optimizer)
-    for batch in loader:
-        loss = step(batch[:, 0], batch[:, 1], batch[:, 2])     # a 0-d tensor (static: read it before the next call)
+    step = GraphedStep(lambda t: model.loss_sp_po_sum(t[:, 0], t[:, 1], t[:, 2], 1.0 / len(t)), optimizer)
+    for batch in loader:                                       # batch: [n, 3] triples on the device
+        loss = step(batch)                                     # a 0-d tensor (static: read it before the next call)
 
 Mirrors the step of TrainingJob.run_epoch (kge/job/train.py:452-474: zero_grad, forward + backward of the batch,
 optimizer.step) for the jobs whose batches are index tensors of a fixed shape: 1vsAll and negative sampling; the last,
@@ -33,8 +33,9 @@ What a captured step cannot follow, and what is done about it:
   * a changed learning rate (schedulers; kge/job/train.py:406-431): the kernels take lr as a launch argument, so the
     graph is captured again when any group's lr differs from the captured one;
   * Adagrad's lr_decay makes the step size depend on the step count: refused (eager);
-  * the first `warmup` calls run eagerly (they are real steps): lazy allocations -- optimizer state, workspaces, the
-    bf16 scoring copies -- happen there, outside the capture.
+  * the first `warmup` calls run eagerly (they are real steps), on the stream the capture will use: lazy allocations
+    -- optimizer state, the engine's per-stream workspaces and their one-time clearing, the bf16 scoring copies --
+    happen there, outside the capture.
 """
 from __future__ import annotations
 
@@ -61,6 +62,7 @@ class GraphedStep:
         self._static_in: Sequence[torch.Tensor] = ()
         self._static_loss: Optional[torch.Tensor] = None
         self._lrs = None
+        self._stream: Optional[torch.cuda.Stream] = None  # the capture stream; the warm-up steps run on it too
         self.static_grads = []
         self.disabled_reason: Optional[str] = None
         for g in optimizer.param_groups:
@@ -86,6 +88,25 @@ class GraphedStep:
         self.optimizer.step()
         return loss.detach()
 
+    def _side_stream(self, device) -> torch.cuda.Stream:
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device)
+        return self._stream
+
+    def _eager_on_capture_stream(self, inputs) -> torch.Tensor:
+        """A warm-up step on the stream the capture will run on.  The engine keeps its scratch per (device, stream)
+        -- workspaces that must be ZEROED ONCE before their first use --: what the warm-up allocates and clears there
+        is what the captured calls find.  Warmed up on the caller's stream instead, the capture allocated a second
+        set and the clearing fill (60-100 MB) became a node of the graph: 7-10 us of every replay until round 5."""
+        dev = inputs[0].device
+        side, cur = self._side_stream(dev), torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            loss = self._eager(inputs)
+        cur.wait_stream(side)
+        loss.record_stream(cur)
+        return loss
+
     def _signature(self, inputs):
         return tuple((tuple(x.shape), x.dtype, x.device) for x in inputs)
 
@@ -94,11 +115,16 @@ class GraphedStep:
         for dst, src in zip(self._static_in, inputs):
             dst.copy_(src)
         self.optimizer.zero_grad(set_to_none=True)
+        # the root gradient of backward(): a static 1, filled here, instead of the ones_like launch of every replay
+        one = torch.ones((), dtype=torch.float32, device=inputs[0].device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=self._side_stream(inputs[0].device)):
             self.optimizer.zero_grad(set_to_none=True)
             loss = self.loss_fn(*self._static_in)
-            loss.backward()
+            if loss.dim() == 0 and loss.dtype == one.dtype and loss.device == one.device:
+                loss.backward(gradient=one)
+            else:
+                loss.backward()
             self.optimizer.step()
             self._static_loss = loss.detach()
         # the gradient buffers the captured backward writes and the captured optimizer reads (static: a replay fills
@@ -106,6 +132,7 @@ class GraphedStep:
         self.static_grads = [p.grad for g in self.optimizer.param_groups for p in g["params"]]
         self._stepped = [p for g in self.optimizer.param_groups for p in g["params"] if p.grad is not None]
         self._graph = graph
+        self._root_one = one
         self._sig = self._signature(inputs)
         self._lrs = [g["lr"] for g in self.optimizer.param_groups]
         self.captures += 1
@@ -115,7 +142,7 @@ class GraphedStep:
         if not self.enabled or not all(isinstance(x, torch.Tensor) and x.is_cuda for x in inputs):
             return self._eager(inputs)
         if self.calls <= self.warmup:
-            return self._eager(inputs)
+            return self._eager_on_capture_stream(inputs)
         lrs = [g["lr"] for g in self.optimizer.param_groups]
         fresh = False
         if self._graph is None or lrs != self._lrs:
@@ -133,6 +160,10 @@ class GraphedStep:
                 return self._eager(inputs)
         elif self._signature(inputs) != self._sig:
             return self._eager(inputs)  # e.g. the epoch's last, shorter batch
+        elif len(inputs) > 1 and hasattr(torch, "_foreach_copy_"):
+            # one multi-tensor launch where torch can (dense tensors of one layout), else its own loop of copies.  Each
+            # copy is a launch of ~4.7 us in front of the replay: hand a batch over as ONE tensor where there is a choice
+            torch._foreach_copy_(list(self._static_in), list(inputs), non_blocking=True)
         else:
             for dst, src in zip(self._static_in, inputs):
                 dst.copy_(src, non_blocking=True)

@@ -164,6 +164,20 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_adagrad_step(ctypes.c_void_p(20), ctypes.c_void_p(16), ctypes.c_void_p(16), 8, -0.1, 0.0, 1e-10,
                                 None, None) == -1
     assert lib.kge_adagrad_step(None, None, None, 0, -0.1, 0.0, 1e-10, None, None) == 0
+    from kge_amd._lib import KgeAdagradSeg
+    seg = lambda p, cnt: KgeAdagradSeg(p, 16, 16, None, cnt, -0.1, 0.0, 1e-10)
+    assert lib.kge_adagrad_step_multi(None, 0, None) == 0
+    assert lib.kge_adagrad_step_multi(None, 1, None) == -1
+    assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 9)(*[seg(None, 0)] * 9), 9, None) == -1   # at most 8 segments
+    assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 2)(seg(None, 0), seg(20, 8)), 2, None) == -1  # misaligned
+    assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 2)(seg(None, 0), seg(None, 0)), 2, None) == 0  # nothing to do
+    # the summed forms of the two-sided loss: same checks as kge_ce_sp_po_fwd, and the sum's address is required
+    assert lib.kge_ce_sp_po_fwd_sum(ctypes.byref(transe), good, good, good, 4, None, None, None, 1.0,
+                                    ctypes.c_void_p(16), None, 0, None) == -2
+    assert lib.kge_ce_sp_po_fwd_sum(ctypes.byref(bf16), good, good, good, 4, ctypes.c_void_p(16), ctypes.c_void_p(16),
+                                    None, 1.0, None, None, 0, None) == -1
+    assert lib.kge_ce_sp_po_bwd_accum_sum(ctypes.byref(bf16), good, good, good, 4, ctypes.c_void_p(16), None, None,
+                                          1.0, None, None, None, 0, None) == -1
 
 
 def test_torch_extension_builds_and_binds_the_c_abi(lib):

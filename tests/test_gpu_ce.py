@@ -434,6 +434,84 @@ def test_ce_sp_po_bwd_accum_equals_scatter_of_row_gradients(eng):
         assert rel_err <= 1e-5, (nm, rel_err)
 
 
+@pytest.mark.parametrize("n", [7, 300, 512])
+def test_ce_sp_po_sum_forms(eng, n):
+    """kge_ce_sp_po_fwd_sum / kge_ce_sp_po_bwd_accum_sum (the step a hipGraph replays: batch loss and its gradient
+    without a host value in between): rows and lse are kge_ce_sp_po_fwd's bit for bit, the sum is scale * their float64
+    sum to 1e-6 and THE SAME BITS on every call (fixed summation order, whichever workgroup arrives last), with the
+    scale as a float, as a device scalar, or absent; the gradients are kge_ce_sp_po_bwd_accum's with every row's
+    gradient = g * scale (up to the order of that call's float atomics).  n = 7: the last workgroup of the combine
+    launch holds two rows; a second call on the same workspace finds the arrival counter back at zero."""
+    ent, rel, s, p, o = _case(77 + n, "complex", 256, 2000 + 3, 5, n, 0.3)
+    T = _tables(eng, "complex", ent, rel)
+    ts, tp, to = _t(s), _t(p), _t(o)
+    rows0, lse0 = eng.ce_sp_po_fwd(T, ts, tp, to)
+    want = float(rows0.double().sum())
+    for scale, sv in ((None, 1.0), (0.25, 0.25), (torch.full((), 1.0 / n, device=DEV), 1.0 / n)):
+        first = None
+        for _ in range(4):
+            tot, rows, lse = eng.ce_sp_po_fwd_sum(T, ts, tp, to, scale)
+            assert torch.equal(rows, rows0) and torch.equal(lse, lse0)
+            assert tot.shape == () and abs(float(tot) - sv * want) <= 1e-6 * abs(sv * want) + 1e-7
+            first = tot.clone() if first is None else first
+            assert torch.equal(tot, first)
+    g, scale = torch.full((), 0.5, device=DEV), torch.full((), 0.25, device=DEV)
+    ge0, gr0 = eng.ce_sp_po_bwd_accum(T, ts, tp, to, lse0, g_rows=torch.full((2 * n,), 0.125, device=DEV))
+    for kw in (dict(g=g, scale=scale), dict(g=g, scale=0.25), dict(g=None, scale=0.125),
+               dict(g=torch.full((1,), 0.125, device=DEV))):
+        ge, gr = eng.ce_sp_po_bwd_accum_sum(T, ts, tp, to, lse0, **kw)
+        for nm, got, ref in (("ent", ge, ge0), ("rel", gr, gr0)):
+            assert float((got - ref).norm() / ref.norm()) <= 1e-5, (nm, kw)
+    with pytest.raises(ValueError):
+        eng.ce_sp_po_bwd_accum_sum(T, ts, tp, to, lse0, g=torch.ones((), device=DEV, dtype=torch.float64))
+
+
+def test_model_level_summed_loss_and_its_captured_step():
+    """KgeModel.loss_sp_po_sum == loss_sp_po(...).sum() * scale (value to 1e-6, gradients to the atomics' order), and
+    the step GraphedStep captures around it (static root gradient, one multi-table Adagrad launch) follows an eager
+    run of the composed form."""
+    from kge_amd import model as km, optim as kopt
+    from kge_amd.train_graph import GraphedStep
+    E, R, d, n = 3000 + 5, 11, 256, 300
+    g = torch.Generator().manual_seed(2)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    inv = torch.full((), 1.0 / n, device=DEV)
+    torch.manual_seed(0)
+    m = km.create("complex", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    m.zero_grad()
+    a = m.loss_sp_po_sum(s, p, o, inv)
+    a.backward()
+    ga = [x.grad.clone() for x in m.parameters()]
+    m.zero_grad()
+    b = m.loss_sp_po(s, p, o).sum() * inv
+    b.backward()
+    assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
+    for x, y in zip(ga, [x.grad for x in m.parameters()]):
+        assert float((x - y).norm() / y.norm()) <= 1e-5
+    runs = {}
+    for tag in ("eager", "graph"):
+        torch.manual_seed(0)
+        m = km.create("complex", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+        opt = kopt.Adagrad(m.parameters(), lr=0.1, bf16_copies=True)
+        losses = []
+        if tag == "eager":
+            for _ in range(6):
+                opt.zero_grad(set_to_none=True)
+                l = m.loss_sp_po(s, p, o).sum() * inv
+                l.backward()
+                opt.step()
+                losses.append(float(l))
+        else:
+            gs = GraphedStep(lambda s_, p_, o_, i_: m.loss_sp_po_sum(s_, p_, o_, i_), opt, warmup=1)
+            for _ in range(6):
+                losses.append(float(gs(s, p, o, inv)))
+            assert gs.replays >= 4, gs.disabled_reason
+        runs[tag] = (losses, [x.detach().clone() for x in m.parameters()])
+    np.testing.assert_allclose(runs["graph"][0], runs["eager"][0], rtol=2e-5)
+    for x, y in zip(runs["graph"][1], runs["eager"][1]):
+        assert float((x - y).norm() / y.norm()) <= 2e-3  # (Adagrad's first steps amplify atomics-order noise)
+
+
 # ---- bce loss (kge_bce_fwd / kge_bce_bwd) ------------------------------------------------------------
 @pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5] + CASES[6:8])
 @pytest.mark.parametrize("offset", [0.0, -1.5])

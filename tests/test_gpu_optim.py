@@ -50,6 +50,42 @@ def test_adagrad_matches_torch(lr_decay, weight_decay, init_acc):
     o_got.load_state_dict(o_ref.state_dict())
 
 
+def test_adagrad_multi_is_the_single_launches_bit_for_bit():
+    """kge_adagrad_step_multi (all dense tables of a step in one launch) against one kge_adagrad_step per table:
+    the same bits in parameters, accumulators and bf16 copies; eleven tables = two launches of the optimizer (eight
+    segments per launch), sizes with scalar tails and an empty one."""
+    import ctypes
+    from kge_amd import _lib
+    from kge_amd.engine import _stream
+    torch.manual_seed(1)
+    sizes = [4096 * 3 + 1, 5, 0, 1024, 1023, 1025, 231, 64 * 512, 8, 12, 100003]
+    mk = lambda: [torch.randn(max(k, 1), device=DEV)[:k] for k in sizes]
+    p0, g0, s0 = mk(), mk(), [x.abs() for x in mk()]
+    res = {}
+    for mode in ("single", "multi"):
+        ps, ss = [x.clone() for x in p0], [x.clone() for x in s0]
+        cs = [torch.zeros(k, dtype=torch.bfloat16, device=DEV) if i % 2 == 0 else None for i, k in enumerate(sizes)]
+        ptr = lambda t: None if t is None or t.numel() == 0 else t.data_ptr()
+        if mode == "single":
+            for p_, g_, s_, c_ in zip(ps, g0, ss, cs):
+                _lib.check(_lib.lib().kge_adagrad_step(ptr(p_), ptr(g_), ptr(s_), p_.numel(), -0.05, 1e-3, 1e-10,
+                                                       ptr(c_), _stream(torch.device(DEV))), "kge_adagrad_step")
+        else:
+            segs = [_lib.KgeAdagradSeg(ptr(p_), ptr(g_), ptr(s_), ptr(c_), p_.numel(), -0.05, 1e-3, 1e-10)
+                    for p_, g_, s_, c_ in zip(ps, g0, ss, cs)]
+            assert _lib.lib().kge_adagrad_step_multi((_lib.KgeAdagradSeg * 9)(*segs[:9]), 9, None) == -1  # > 8 segments
+            for i in range(0, len(segs), 8):
+                chunk = segs[i:i + 8]
+                _lib.check(_lib.lib().kge_adagrad_step_multi((_lib.KgeAdagradSeg * len(chunk))(*chunk), len(chunk),
+                                                             _stream(torch.device(DEV))), "kge_adagrad_step_multi")
+        torch.cuda.synchronize()
+        res[mode] = (ps, ss, cs)
+    for a, b in zip(res["single"], res["multi"]):
+        for x, y in zip(a, b):
+            assert (x is None and y is None) or torch.equal(x, y)
+    assert not torch.equal(res["multi"][0][0], p0[0])
+
+
 def test_mixed_precision_model_uses_the_optimizer_copies():
     """score_dtype=bfloat16 + Adagrad(bf16_copies=True): after a step the scoring tables ARE the
     optimizer's copies (no cast kernels), and the scores equal those of freshly cast tables."""

@@ -14,7 +14,13 @@ python - <<PY
 import csv, glob
 for f in glob.glob("$OUT/prof/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
+    # one adagrad_multi_kernel launch per step (eager and replayed alike): the step count of the trace
+    steps = sum(int(r["Calls"]) for r in rows if "adagrad_multi_kernel" in r.get("Name", ""))
+    total_us = sum(float(r.get("TotalDurationNs", 0)) for r in rows) / 1e3
     with open("$OUT/kernel_stats.txt", "w") as o:
+        if steps:
+            line = f"# {steps} steps in the trace, {total_us / steps:.1f} us of kernels per step, {len(rows)} kernel names"
+            print(line); o.write(line + "\n")
         for r in rows[:25]:
             line = f"{r.get('Name', '')[:110]:110s} calls {r.get('Calls'):>6s} avg_ns {float(r.get('AverageNs', 0)):10.0f} pct {r.get('Percentage')}"
             print(line); o.write(line + "\n")
