@@ -637,12 +637,21 @@ class ShardedScoreLanes:
         static = [torch.empty(a.shape, dtype=a.dtype, device=a.device) for a in args]
         for d, x in zip(static, args):
             d.copy_(x)
-        res = fn(*static)  # once call by call: per-stream scratch gets allocated, the communicator warmed up
-        st = torch.cuda.current_stream(self.table.ent_local.device)
+        cur = st = torch.cuda.current_stream(self.table.ent_local.device)
         if self.streams is None:  # a capture needs a stream of its own
             if self._cap_stream is None:
                 self._cap_stream = torch.cuda.Stream(device=self.table.ent_local.device)
             st = self._cap_stream
+        # once call by call ON THE CAPTURE STREAM: the engine's scratch is per (device, stream) and cleared once at
+        # allocation -- allocated by the capture itself, that clearing fill would be a node of every replay --; the
+        # communicator gets warmed up
+        if st is not cur:
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                res = fn(*static)
+            cur.wait_stream(st)
+        else:
+            res = fn(*static)
         multi = bool(tb.collectives) and tb.world > 1
 
         def vote(err):
