@@ -194,10 +194,15 @@ class HipTrainingJob1vsAll(_CudaOomText, TrainingJob1vsAll):
             # the two losses is back-propagated once (the reference does it in two passes:
             # the same gradients, accumulated)
             result.forward_time -= time.time()
-            rows = self.model.loss_sp_po(triples[:, 0], triples[:, 1], triples[:, 2])
-            if rows is None:
-                _declined_late("loss_sp_po")
-            loss_value = rows.sum() / batch_size
+            if hasattr(self.model, "loss_sp_po_sum"):  # the sum (and its gradient) inside the loss kernels' launches
+                loss_value = self.model.loss_sp_po_sum(triples[:, 0], triples[:, 1], triples[:, 2], 1.0 / batch_size)
+                if loss_value is None:
+                    _declined_late("loss_sp_po_sum")
+            else:
+                rows = self.model.loss_sp_po(triples[:, 0], triples[:, 1], triples[:, 2])
+                if rows is None:
+                    _declined_late("loss_sp_po")
+                loss_value = rows.sum() / batch_size
             result.avg_loss += loss_value.item()
             result.forward_time += time.time()
             result.backward_time -= time.time()
