@@ -781,9 +781,10 @@ def kvsall_step_leg(device, n, steps):
     """One whole KvsAll TRAINING step at BASELINE configs[3] (FB15k-237 shape, DistMult d = 512, bf16 scoring copies of
     float32 masters): TrainingJobKvsAll._process_subbatch (kge/job/train_KvsAll.py:216-294) -- n sp_ queries and n _po
     queries, each with its multi-hot labels as a CSR (1-8 known answers per query, as the KvsAll index hands them over),
-    the kl loss fused into the scoring kernel (kge_kl_fwd / kge_kl_bwd: no [n, E] score or label matrix), one backward per
-    query type -- + one-pass Adagrad, through kge_amd.model + kge_amd.optim: what `train.type: hip_KvsAll` drives.  Wall
-    clock per step issued call by call (label CSRs vary from batch to batch: no graph replay)."""
+    the kl loss fused into the scoring kernel (kge_kl_fwd: no [n, E] score or label matrix), ONE backward for both query
+    types (kge_multilabel2_bwd_accum; `ms_per_step_one_backward_per_type`: kge_kl_bwd per type, autograd assembling the
+    table gradients) -- + one-pass Adagrad, through kge_amd.model + kge_amd.optim: what `train.type: hip_KvsAll` drives.
+    Wall clock per step issued call by call, and as one hipGraph replay."""
     from kge_amd import model as km, optim as kopt
     q = torch.Generator().manual_seed(9)
     m = km.create("distmult", E_FB, R_FB, DIM, device=device, score_dtype=torch.bfloat16)
@@ -798,11 +799,28 @@ def kvsall_step_leg(device, n, steps):
         col = torch.cat([torch.randperm(E_FB, generator=q)[:int(k)].sort().values for k in cnt])
         csr.append((rowptr.to(device), col.to(device)))
 
+    def both(a_, b_, c_, rp0, cl0, rp1, cl1):  # both query types, one backward (kge_multilabel2_bwd_accum)
+        rows_sp, rows_po = m.multilabel_loss_sp_po("kl", a_, b_, rp0, cl0, c_, b_, rp1, cl1)
+        return (rows_sp.sum() + rows_po.sum()) / (2 * n)
+
     def step():
+        opt.zero_grad(set_to_none=True)
+        both(a, b, c, *csr[0], *csr[1]).backward()
+        opt.step()
+
+    def step_per_type():  # the reference's order: each type's loss back-propagated on its own
         opt.zero_grad(set_to_none=True)
         (m.kl_loss_sp(a, b, *csr[0]).sum() / (2 * n)).backward()
         (m.kl_loss_po(b, c, *csr[1]).sum() / (2 * n)).backward()
         opt.step()
+    for _ in range(3):
+        step_per_type()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_per_type()
+    torch.cuda.synchronize()
+    ms_per_type = (time.perf_counter() - t0) / steps * 1e3
     for _ in range(3):
         step()
     torch.cuda.synchronize()
@@ -814,6 +832,7 @@ def kvsall_step_leg(device, n, steps):
     flops = 3 * 2.0 * 2.0 * n * DIM * E_FB
     out = {"model": "distmult", "num_entities": E_FB, "dim": DIM, "queries_per_type": n, "labels_per_query": "1-8",
            "loss": "kl on multi-hot labels (CSR), fused into the scoring kernel", "ms_per_step": ms,
+           "ms_per_step_one_backward_per_type": ms_per_type,
            "scored_triples_per_s": 2.0 * n * E_FB / (ms * 1e-3), "flops_per_step": flops,
            "frac_of_mfma_peak": flops / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
     # The same step as ONE hipGraph replay: what the GPU needs for it once the host is out of the way.  (The kernels
@@ -821,9 +840,7 @@ def kvsall_step_leg(device, n, steps):
     # this yet -- its batches also differ in how many sp_ and _po queries they hold: DESIGN 11.7.)
     from kge_amd.train_graph import GraphedStep
 
-    def loss_fn(a_, b_, c_, rp0, cl0, rp1, cl1):
-        return (m.kl_loss_sp(a_, b_, rp0, cl0).sum() + m.kl_loss_po(b_, c_, rp1, cl1).sum()) / (2 * n)
-    gs = GraphedStep(loss_fn, opt, warmup=1)
+    gs = GraphedStep(both, opt, warmup=1)
     args = (a, b, c, csr[0][0], csr[0][1], csr[1][0], csr[1][1])
     for _ in range(4):
         gs(*args)

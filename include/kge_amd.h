@@ -623,6 +623,34 @@ int kge_bce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
                 const float* g_rows, float g_scalar, float* g_a, float* g_p, float* g_tgt,
                 void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Both query types of a KvsAll batch, backward, with COMPLETE table gradients.  TrainingJobKvsAll scores the sp_ and
+ * the _po queries of a batch one after the other and back-propagates each loss on its own
+ * (kge/job/train_KvsAll.py:274-294): two d loss / d score passes, four gradient products, and autograd's index_add and
+ * accumulation passes over the [num_ent, dim] gradient between them.  Here each type's pass (that of kge_kl_bwd /
+ * kge_bce_bwd, no label smoothing) fills its rows of one gradient matrix and the two products run once over the
+ * n_sp + n_po rows: grad_ent [num_ent, dim] and grad_rel [num_rel, rel_dim] (contiguous f32, OVERWRITTEN) receive what
+ * `.grad` holds after the reference's two backward calls -- the dense target gradient of both types plus the
+ * gathered entity and relation rows' gradients (float atomics: equal up to their order).
+ *   sp: a = subjects, p = relations of the sp_ queries; po: a = OBJECTS, p = relations of the _po queries;
+ *   lse: kge_kl_fwd's (KGE_LOSS_KL; unused for KGE_LOSS_BCE); g_rows / g_scalar: upstream gradient of loss_rows;
+ *   offset: kge_bce_fwd's (KGE_LOSS_BCE).  Either side may be empty (n = 0).
+ * Workspace: kge_multilabel2_workspace_bytes(t, n_sp, n_po) (0: unsupported tables), 256-byte aligned, zeroed once. */
+#define KGE_LOSS_KL 0
+#define KGE_LOSS_BCE 1
+typedef struct kge_label_queries {
+  kge_index a, p;
+  int64_t n;
+  const int64_t* lbl_rowptr;   /* [n + 1] */
+  const int64_t* lbl_col;
+  const float* lse;            /* [n] or NULL (bce) */
+  const float* g_rows;         /* [n] or NULL: g_scalar for every row */
+  float g_scalar;
+} kge_label_queries;
+int64_t kge_multilabel2_workspace_bytes(const kge_tables* t, int64_t n_sp, int64_t n_po);
+int kge_multilabel2_bwd_accum(const kge_tables* t, int loss, float offset, const kge_label_queries* sp,
+                              const kge_label_queries* po, float* grad_ent, float* grad_rel,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- optimizer step over a table ---------------------- */
 /* One dense Adagrad step on `count` contiguous f32 elements (16-byte aligned arrays), in place:
  *   g = grad + weight_decay * param (if weight_decay != 0);  state_sum += g*g;

@@ -49,6 +49,14 @@ class KgeNextQueries(ctypes.Structure):
                 ("queries_bytes", c_i64)]
 
 
+class KgeLabelQueries(ctypes.Structure):
+    _fields_ = [("a", KgeIndex), ("p", KgeIndex), ("n", c_i64), ("lbl_rowptr", c_vp), ("lbl_col", c_vp), ("lse", c_vp),
+                ("g_rows", c_vp), ("g_scalar", ctypes.c_float)]
+
+
+LOSS_KL, LOSS_BCE = 0, 1
+
+
 class KgeAdagradSeg(ctypes.Structure):
     _fields_ = [("param", c_vp), ("grad", c_vp), ("state_sum", c_vp), ("bf16_copy", c_vp), ("count", c_i64),
                 ("minus_clr", ctypes.c_float), ("weight_decay", ctypes.c_float), ("eps", ctypes.c_float)]
@@ -162,6 +170,9 @@ PROTOTYPES = {
     "kge_ce_sp_po_bwd_accum_sum": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp,
                                                   ctypes.c_float, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_adagrad_step_multi": (ctypes.c_int, [ctypes.POINTER(KgeAdagradSeg), ctypes.c_int, c_vp]),
+    "kge_multilabel2_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),
+    "kge_multilabel2_bwd_accum": (ctypes.c_int, [_PT, ctypes.c_int, ctypes.c_float, ctypes.POINTER(KgeLabelQueries),
+                                                 ctypes.POINTER(KgeLabelQueries), c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_kl_fwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                   c_i64, c_vp]),
     "kge_kl_bwd": (ctypes.c_int, [_PT, ctypes.c_int, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp, c_vp,

@@ -137,6 +137,10 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
                 float* g_p, float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, void* ws,
                 long long ws_bytes, hipStream_t st, const float* g_dev = nullptr, const float* g_dev2 = nullptr);
 int run_adagrad_multi(const kge_adagrad_seg* segs, int num, hipStream_t st);
+long long multilabel2_workspace_bytes(int d, long long n1, long long n2, long long m);
+int run_multilabel2_bwd_accum(int scorer, int kind, float offset, const LossSide& sp, const LossSide& po,
+                              const Operand& TG, int d, long long m, float* grad_ent, float* grad_rel,
+                              long long rel_rows, long long rel_ld, void* ws, long long ws_bytes, hipStream_t st);
 int run_adagrad(float* param, const float* grad, float* sum, long long count, float minus_clr, float weight_decay,
                 float eps, unsigned short* copy16, hipStream_t st);
 int run_adam(float* param, const float* grad, float* m1, float* m2, long long count, float step_size, float bc2_sqrt,
@@ -1646,6 +1650,34 @@ int kge_kl_weighted_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, 
   return run_kl_bwd(t->scorer, ent_op(t, a), rel_op(t, p), ent_op(t, none), dir, (int)t->dim, n, t->num_ent,
                     (const long long*)lbl_rowptr, (const long long*)lbl_col, lse, g_rows, g_scalar, g_a, g_p, g_tgt,
                     workspace, workspace_bytes, (hipStream_t)stream, label_weight, label_bias);
+}
+
+int64_t kge_multilabel2_workspace_bytes(const kge_tables* t, int64_t n_sp, int64_t n_po) {
+  if (n_sp < 0 || n_po < 0 || kge_ce_workspace_bytes(t, n_sp > n_po ? n_sp : n_po) <= 0) return 0;
+  return multilabel2_workspace_bytes((int)t->dim, n_sp, n_po, t->num_ent);
+}
+
+int kge_multilabel2_bwd_accum(const kge_tables* t, int loss, float offset, const kge_label_queries* sp,
+                              const kge_label_queries* po, float* grad_ent, float* grad_rel, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  KGE_RANGE();
+  const kge_index none = {nullptr, 0, 0, 1};
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if ((loss != KGE_LOSS_KL && loss != KGE_LOSS_BCE) || !sp || !po || !grad_ent || !grad_rel) return KGE_ERR_INVALID_ARG;
+  LossSide side[2];
+  for (int k = 0; k < 2; ++k) {
+    const kge_label_queries& q = k ? *po : *sp;
+    if (q.n < 0 || (q.n > 0 && (!q.lbl_rowptr || !q.lbl_col || (loss == KGE_LOSS_KL && !q.lse)))) return KGE_ERR_INVALID_ARG;
+    if ((rc = check_index(q.a, false, q.n)) || (rc = check_index(q.p, false, q.n))) return rc;
+    if (!ce_supported(t->scorer, t->dtype, (int)t->dim, ent_op(t, q.a), rel_op(t, q.p), ent_op(t, none)))
+      return KGE_ERR_UNSUPPORTED;
+    side[k] = LossSide{ent_op(t, q.a), rel_op(t, q.p), q.n, (const long long*)q.lbl_rowptr, (const long long*)q.lbl_col,
+                       q.lse, q.g_rows, q.g_scalar, nullptr, nullptr};
+  }
+  return run_multilabel2_bwd_accum(t->scorer, loss, offset, side[0], side[1], ent_op(t, none), (int)t->dim, t->num_ent,
+                                   grad_ent, grad_rel, t->num_rel, t->rel_dim, workspace, workspace_bytes,
+                                   (hipStream_t)stream);
 }
 
 int kge_kl_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n, const int64_t* lbl_rowptr,

@@ -160,8 +160,9 @@ __device__ __forceinline__ float bwdg_w(const unsigned short* p, long long k) {
 
 template <int SCORER>
 __global__ __launch_bounds__(256) void bwdg_build_q16_kernel(Operand A, Operand R, int dir, int d, long long n,
-                                                             unsigned short* __restrict__ Q, Operand A2,
-                                                             float* __restrict__ zero, long long zero_cnt) {
+                                                             unsigned short* __restrict__ Q, Operand A2, Operand R2,
+                                                             long long n2, float* __restrict__ zero,
+                                                             long long zero_cnt) {
   // `zero` (may be NULL): zero_cnt floats cleared on the way -- the relation-gradient accumulator the chain launch
   // behind the two products adds into (kge_ce_sp_po_bwd_accum); every thread of the grid takes its share
   if (zero != nullptr) {
@@ -169,10 +170,12 @@ __global__ __launch_bounds__(256) void bwdg_build_q16_kernel(Operand A, Operand 
     for (long long k = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; k < zero_cnt; k += nthreads)
       zero[k] = 0.0f;
   }
-  if (blockIdx.y == 1) {  // two-sided launch: the _po queries, rows [n, 2n)
+  if (blockIdx.y == 1) {  // two-sided launch: the n2 _po queries (entity rows A2, relation rows R2), rows [n, n + n2)
     A = A2;
+    R = R2;
     dir = KGE_PO_;
     Q += n * d;
+    n = n2;
   }
   const int h = SCORER == KGE_COMPLEX ? d / 2 : d;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -203,14 +206,16 @@ __global__ __launch_bounds__(256) void bwdg_build_q16_kernel(Operand A, Operand 
 template <int SCORER>
 __global__ __launch_bounds__(256) void bwdg_chain16_kernel(Operand A, Operand R, int dir, int d, long long n,
                                                            float* __restrict__ g_a, float* __restrict__ g_p,
-                                                           Operand A2, float* __restrict__ acc_ent,
-                                                           long long acc_ent_ld, float* __restrict__ acc_rel,
-                                                           long long acc_rel_ld) {
-  if (blockIdx.y == 1) {  // two-sided launch: the _po queries, rows [n, 2n)
+                                                           Operand A2, Operand R2, long long n2,
+                                                           float* __restrict__ acc_ent, long long acc_ent_ld,
+                                                           float* __restrict__ acc_rel, long long acc_rel_ld) {
+  if (blockIdx.y == 1) {  // two-sided launch: the n2 _po queries, rows [n, n + n2)
     A = A2;
+    R = R2;
     dir = KGE_PO_;
     g_a += n * d;
     if (g_p != nullptr) g_p += n * d;
+    n = n2;
   }
   const int h = SCORER == KGE_COMPLEX ? d / 2 : d;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -322,7 +327,7 @@ static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Op
                            float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
   const unsigned qblocks = (unsigned)((n * half + 255) / 256);
-  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, Q16, A,
+  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, Q16, A, R, n,
                      (float*)nullptr, 0LL);
   const unsigned short* T = (const unsigned short*)TG.base;
   long long ldt = TG.ld;
@@ -338,54 +343,55 @@ static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Op
   const size_t lws_bytes = TG.idx.ptr == nullptr ? (size_t)m * d * sizeof(float) : 0;
   if (!bwdg_dq16(d, n, m, T, ldt, G16, mp, g_a, (float*)lws, lws_bytes, st)) return KGE_ERR_UNSUPPORTED;
   if (!bwdg_dt16(d, n, m, Q16, G16, mp, g_tgt, st)) return KGE_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p, A,
+  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, g_a, g_p, A, R, n,
                      (float*)nullptr, 0LL, (float*)nullptr, 0LL);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
-// Two-sided variant (kge_ce_sp_po_bwd): rows [0, n) of G16 / Q16 / g_a / g_p belong to the sp_ queries
-// (entity operand A1), rows [n, 2n) to the _po queries (A2); both products run ONCE over the 2n
-// rows (dT sums the two sides inside the product instead of in a separate accumulation pass).
+// Two-sided variant (kge_ce_sp_po_bwd, kge_kl2_bwd_accum): rows [0, n) of G16 / Q16 / g_a / g_p belong to the n sp_
+// queries (entity rows A1, relation rows R), rows [n, n + n2) to the n2 _po queries (A2, R2); both products run ONCE
+// over the n + n2 rows (dT sums the two sides inside the product instead of in a separate accumulation pass).
 template <int SCORER>
-static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Operand& R, const Operand& TG, int d,
-                               long long n, long long m, const unsigned short* G16, long long mp,
-                               unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, float* acc_rel,
-                               long long acc_rel_rows, long long acc_rel_ld, float* dq_scratch,
-                               long long dq_scratch_bytes, hipStream_t st) {
+static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Operand& R, const Operand& R2,
+                               const Operand& TG, int d, long long n, long long n2, long long m,
+                               const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
+                               float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
+                               float* dq_scratch, long long dq_scratch_bytes, hipStream_t st) {
   if (TG.idx.ptr != nullptr) return KGE_ERR_UNSUPPORTED;  // all entities only
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
-  const dim3 qgrid((unsigned)((n * half + 255) / 256), 2);  // y = side
-  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, Q16, A2, acc_rel,
-                     acc_rel != nullptr ? acc_rel_rows * acc_rel_ld : 0LL);
+  const long long nrows = n + n2, nmax = n > n2 ? n : n2;
+  const dim3 qgrid((unsigned)((nmax * half + 255) / 256), 2);  // y = side
+  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, Q16, A2, R2, n2,
+                     acc_rel, acc_rel != nullptr ? acc_rel_rows * acc_rel_ld : 0LL);
   const unsigned short* T = (const unsigned short*)TG.base;
   // split-K scratch of dQ: the caller's (sized for as many splits as the product wants: 16 at the FB15k-237 shape),
   // else g_tgt, which dT overwrites afterwards (14 fit).  [Summing the partials inside the chain launch instead of
   // in bwdg_reduce_kernel was tried in round 5: 13.3 us scalar / 17+ us with 16-byte loads against 6.1 + 5.8 us.]
   float* lws = dq_scratch != nullptr ? dq_scratch : g_tgt;
   const size_t lws_bytes = dq_scratch != nullptr ? (size_t)dq_scratch_bytes : (size_t)m * d * sizeof(float);
-  if (!bwdg_dq16(d, 2 * n, m, T, TG.ld, G16, mp, g_a, lws, lws_bytes, st)) return KGE_ERR_UNSUPPORTED;
-  if (!bwdg_dt16(d, 2 * n, m, Q16, G16, mp, g_tgt, st)) return KGE_ERR_UNSUPPORTED;
+  if (!bwdg_dq16(d, nrows, m, T, TG.ld, G16, mp, g_a, lws, lws_bytes, st)) return KGE_ERR_UNSUPPORTED;
+  if (!bwdg_dt16(d, nrows, m, Q16, G16, mp, g_tgt, st)) return KGE_ERR_UNSUPPORTED;
   // acc_rel != NULL: the row gradients go straight into the table gradients -- the entity rows
   // on top of dT in g_tgt [m, d] (all entities: row ids are table rows), the relation rows into acc_rel
-  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, g_a, g_p, A2,
+  hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, g_a, g_p, A2, R2, n2,
                      acc_rel != nullptr ? g_tgt : (float*)nullptr, (long long)d, acc_rel, acc_rel_ld);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
 int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A2, const Operand& R,
-                                 const Operand& TG, int d, long long n, long long m, const unsigned short* G16,
-                                 long long mp, unsigned short* Q16, float* g_a, float* g_p, float* g_tgt,
-                                 float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, float* dq_scratch,
-                                 long long dq_scratch_bytes, hipStream_t st) {
-  if (n == 0 || m == 0) return KGE_OK;  // (ce_loss.hip handles n == 0 itself: acc_rel is cleared there)
-  if (2 * n >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31))
+                                 const Operand& R2, const Operand& TG, int d, long long n, long long n2, long long m,
+                                 const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
+                                 float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
+                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st) {
+  if (n + n2 == 0 || m == 0) return KGE_OK;  // (ce_loss.hip handles empty batches itself: acc_rel is cleared there)
+  if (n + n2 >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31))
     return KGE_ERR_UNSUPPORTED;
   int rc = KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
-    rc = bwdg_products16_two<KGE_COMPLEX>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
+    rc = bwdg_products16_two<KGE_COMPLEX>(A1, A2, R, R2, TG, d, n, n2, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
                                           acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st);
   else if (scorer == KGE_DISTMULT)
-    rc = bwdg_products16_two<KGE_DISTMULT>(A1, A2, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
+    rc = bwdg_products16_two<KGE_DISTMULT>(A1, A2, R, R2, TG, d, n, n2, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
                                            acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st);
   return rc;
 }

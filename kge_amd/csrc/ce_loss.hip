@@ -38,10 +38,10 @@ int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operan
                              unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st);
 
 int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A2, const Operand& R,
-                                 const Operand& TG, int d, long long n, long long m, const unsigned short* G16,
-                                 long long mp, unsigned short* Q16, float* g_a, float* g_p, float* g_tgt,
-                                 float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, float* dq_scratch,
-                                 long long dq_scratch_bytes, hipStream_t st);
+                                 const Operand& R2, const Operand& TG, int d, long long n, long long n2, long long m,
+                                 const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
+                                 float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
+                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st);
 long long gemm16_dq_scratch_bytes(int d, long long rows, long long m);
 
 // merge the column groups of a row: M = max_c m_c, L = sum_c l_c exp(m_c - M).  One wave per row,
@@ -149,28 +149,55 @@ __global__ __launch_bounds__(256) void kl_label_kernel(Operand A, Operand R, Ope
     const int c = lane + 64 * u;
     if (c < hp) bf16_qpair<SCORER>(dir, a[c], a[hp + c], r[c], r[hp + c], q0[u], q1[u]);
   }
+  // four labels at a time: their row loads are in flight together (one label after the other was a chain of
+  // dependent gathers, 11 us per launch for <= 8 labels per row); the sums are taken in label order as before --
+  // the same bits
   float tsum = 0.0f;
   int cnt = 0;
-  for (long long e = rowptr[i]; e < rowptr[i + 1]; ++e) {
-    const long long cl = col[e] - col_lo;
-    if (cl < 0 || cl >= m) continue;
-    ++cnt;
-    const unsigned int* t = (const unsigned int*)((const unsigned short*)TG.base + cl * TG.ld);
-    float acc = 0.0f;
+  const long long e1 = rowptr[i + 1];
+  for (long long e = rowptr[i]; e < e1; e += 4) {
+    bool ok[4];
+    unsigned int t0[4][2] = {}, t1[4][2] = {};
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int c = lane + 64 * u;
-      if (c < hp) {
-        const unsigned int t0 = t[c], t1 = t[hp + c];
-        acc = __builtin_fmaf(__uint_as_float(q0[u] << 16), __uint_as_float(t0 << 16), acc);
-        acc = __builtin_fmaf(__uint_as_float(q0[u] & 0xffff0000u), __uint_as_float(t0 & 0xffff0000u), acc);
-        acc = __builtin_fmaf(__uint_as_float(q1[u] << 16), __uint_as_float(t1 << 16), acc);
-        acc = __builtin_fmaf(__uint_as_float(q1[u] & 0xffff0000u), __uint_as_float(t1 & 0xffff0000u), acc);
+    for (int k = 0; k < 4; ++k) {
+      const long long cl = e + k < e1 ? col[e + k] - col_lo : -1;
+      ok[k] = cl >= 0 && cl < m;
+      const unsigned int* t = (const unsigned int*)((const unsigned short*)TG.base + (ok[k] ? cl : 0) * TG.ld);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = lane + 64 * u;
+        if (c < hp) {
+          t0[k][u] = t[c];
+          t1[k][u] = t[hp + c];
+        }
+      }
+    }
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = lane + 64 * u;
+        if (c < hp) {
+          acc[k] = __builtin_fmaf(__uint_as_float(q0[u] << 16), __uint_as_float(t0[k][u] << 16), acc[k]);
+          acc[k] = __builtin_fmaf(__uint_as_float(q0[u] & 0xffff0000u), __uint_as_float(t0[k][u] & 0xffff0000u), acc[k]);
+          acc[k] = __builtin_fmaf(__uint_as_float(q1[u] << 16), __uint_as_float(t1[k][u] << 16), acc[k]);
+          acc[k] = __builtin_fmaf(__uint_as_float(q1[u] & 0xffff0000u), __uint_as_float(t1[k][u] & 0xffff0000u), acc[k]);
+        }
       }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    tsum += acc;
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (ok[k]) {
+        tsum += acc[k];
+        ++cnt;
+      }
+    }
   }
   if (lane == 0) {
     label_sum[i] = tsum;
@@ -557,8 +584,73 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(2 * n * ld16 * 2));
   const int rc = run_ds_pass(scorer, V3_DS, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
   if (rc != KGE_OK) return rc;
-  return run_pairs_bwd_products16_two(scorer, S, O, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, acc_rel,
+  return run_pairs_bwd_products16_two(scorer, S, O, R, R, TG, d, n, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, acc_rel,
                                       acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st);
+}
+
+// ---- both query types of a KvsAll batch, backward (kge_kl2_bwd_accum / kge_bce2_bwd_accum) ------------------------
+// TrainingJobKvsAll scores the sp_ queries and the _po queries of a batch one after the other and back-propagates each
+// loss on its own (train_KvsAll.py:274-294): two d loss / d score passes, FOUR gradient products, and autograd's
+// index_add / accumulate passes over the [E, d] gradient in between (a third of the step's kernel time at the
+// FB15k-237 shape).  Here each type's d loss / d score pass writes its rows of ONE G16 matrix (sp_ rows first), and the
+// two-sided products of the 1vsAll step run once over the n1 + n2 rows: dT sums both types inside the product, the
+// chain launch scatters the row gradients on top of it and into the relation gradient -- complete table gradients,
+// as kge_ce_sp_po_bwd_accum returns them.  kind 0: kl (lse given; label_weight / label_bias for smoothed labels),
+// kind 1: bce with logits (offset).
+long long multilabel2_workspace_bytes(int d, long long n1, long long n2, long long m) {
+  const long long nmax = n1 > n2 ? n1 : n2, rows = n1 + n2;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, nmax));
+  return coop + al256(rows * ce_ld16(m) * 2) + al256(rows * (long long)d * 2) + al256(rows * (long long)d * 4) +
+         al256(gemm16_dq_scratch_bytes(d, rows, m));
+}
+
+int run_multilabel2_bwd_accum(int scorer, int kind, float offset, const LossSide& sp, const LossSide& po,
+                              const Operand& TG, int d, long long m, float* grad_ent, float* grad_rel,
+                              long long rel_rows, long long rel_ld, void* ws, long long ws_bytes, hipStream_t st) {
+  const long long n1 = sp.n, n2 = po.n, rows = n1 + n2;
+  if (rows == 0) {
+    if (!fill_words_async(grad_rel, 0, (size_t)rel_rows * rel_ld * sizeof(float), st) ||
+        !fill_words_async(grad_ent, 0, (size_t)m * d * sizeof(float), st))
+      return KGE_ERR_LAUNCH;
+    return KGE_OK;
+  }
+  if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < multilabel2_workspace_bytes(d, n1, n2, m)) return KGE_ERR_WORKSPACE;
+  const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n1 > n2 ? n1 : n2));
+  const long long ld16 = ce_ld16(m);
+  unsigned short* const G16 = (unsigned short*)((char*)ws + coop);
+  unsigned short* const Q16 = (unsigned short*)((char*)ws + coop + al256(rows * ld16 * 2));
+  float* const dq_rows = (float*)((char*)Q16 + al256(rows * (long long)d * 2));
+  const long long dq_scratch_bytes = gemm16_dq_scratch_bytes(d, rows, m);
+  float* const dq_scratch = dq_scratch_bytes > 0 ? dq_rows + al256(rows * (long long)d * 4) / 4 : nullptr;
+  for (int side = 0; side < 2; ++side) {
+    const LossSide& x = side ? po : sp;
+    if (x.n == 0) continue;
+    CeArgs ce{};
+    ce.g_rows = x.g_rows;
+    ce.g_scalar = x.g_scalar;
+    ce.g16 = G16 + (side ? n1 : 0) * ld16;
+    ce.ld16 = ld16;
+    if (kind == 0) {
+      ce.rowptr = x.label_weight != nullptr ? nullptr : x.rowptr;  // (see run_kl_bwd)
+      ce.row_bias = x.label_bias;
+      ce.lse = x.lse;
+    } else {
+      ce.offset = offset;
+    }
+    const int rc = run_ds_pass(scorer, kind == 0 ? V3_DS : V3_DSIG, x.A, nullptr, x.R, TG, side ? KGE_PO_ : KGE_SP_, d,
+                               x.n, m, st, ws, coop, ce, g_ce_stamps);
+    if (rc != KGE_OK) return rc;
+    const dim3 grid((unsigned)((x.n + 3) / 4));
+    if (kind == 0)
+      hipLaunchKernelGGL(kl_sub_kernel, grid, dim3(256), 0, st, ce.g16, ld16, x.n, x.rowptr, x.col, x.g_rows, x.g_scalar,
+                         x.label_weight, 0LL, m);
+    else
+      hipLaunchKernelGGL(bce_sub_kernel, grid, dim3(256), 0, st, ce.g16, ld16, x.n, x.rowptr, x.col, x.g_rows,
+                         x.g_scalar, 0LL, m);
+    if (hipGetLastError() != hipSuccess) return KGE_ERR_LAUNCH;
+  }
+  return run_pairs_bwd_products16_two(scorer, sp.A, po.A, sp.R, po.R, TG, d, n1, n2, m, G16, ld16, Q16, dq_rows, nullptr,
+                                      grad_ent, grad_rel, rel_rows, rel_ld, dq_scratch, dq_scratch_bytes, st);
 }
 
 void ce_set_stamps(unsigned long long* p) { g_ce_stamps = p; }

@@ -415,6 +415,19 @@ struct CeArgs {
   int rk_clear_bits;                  // pairs_bf16_v8_rank_kernel: store zero over every filter word it has read
 };
 
+// one query type of a multi-label (KvsAll) batch: ce_loss.hip run_multilabel2_bwd_accum
+struct LossSide {
+  Operand A, R;             // entity rows (s of sp_ / o of _po queries), relation rows
+  long long n;
+  const long long* rowptr;  // [n + 1] label CSR
+  const long long* col;
+  const float* lse;         // kl: [n]
+  const float* g_rows;      // [n] upstream gradients, or NULL: g_scalar
+  float g_scalar;
+  const float* label_weight;  // kl with label smoothing: [n], and the rows' uniform mass; else NULL
+  const float* label_bias;
+};
+
 __device__ __forceinline__ float ce_row_gradient(const CeArgs& ce, long long row) {
   if (ce.g_rows != nullptr) return ce.g_rows[row];
   float g = ce.g_scalar;

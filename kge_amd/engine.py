@@ -1459,6 +1459,43 @@ def ce_sp_po_bwd_accum_sum(t: Tables, s, p, o, lse, g=None, scale=None):
     return ge, grel
 
 
+def multilabel2_bwd_accum(t: Tables, kind: str, offset: float, sp, po):
+    """Backward of BOTH query types of a KvsAll batch with complete table gradients (kge_multilabel2_bwd_accum):
+    `sp` = (s, p, lbl_rowptr, lbl_col, lse, g_rows) of the sp_ queries, `po` = (o, p, lbl_rowptr, lbl_col, lse, g_rows) of
+    the _po queries (lse: kl_fwd's, None for kind "bce"; g_rows: upstream gradients of the loss rows); returns
+    (grad_entities [E, d], grad_relations [R, d_r]).  Either side may have no rows."""
+    keep, sides, n = [], [], []
+    for name, (a, p, rowptr, col, lse, g_rows) in (("sp", sp), ("po", po)):
+        k0 = len(keep)
+        ai, pi = (_index(x, t.device, keep) for x in (a, p))
+        nk = _same_len(keep[k0:k0 + 2], "multilabel2_bwd_accum")
+        rp, cl = _csr64(rowptr, col, t.device)
+        ls = None if lse is None else _f32c(lse, t.device)
+        gr = None if g_rows is None else _f32c(g_rows, t.device)
+        if kind == "kl" and nk > 0 and ls is None:
+            raise ValueError("multilabel2_bwd_accum: the kl loss needs kl_fwd's lse")
+        keep += [rp, cl, ls, gr]
+        sides.append(_lib.KgeLabelQueries(ai, pi, nk, rp.data_ptr(), cl.data_ptr(), None if ls is None else ls.data_ptr(),
+                                          None if gr is None else gr.data_ptr(), 1.0))
+        n.append(nk)
+    ge, grel = _empty(tuple(t.ent.shape), t.device), _empty(tuple(t.rel.shape), t.device)
+    with _on_device(t.device):
+        tc = t.c()
+        st = _stream_handle(t.device)
+        need = _lib.lib().kge_multilabel2_workspace_bytes(ctypes.byref(tc), n[0], n[1])
+        if need <= 0:
+            raise RuntimeError("kge_multilabel2_bwd_accum: bf16 ComplEx/DistMult tables with dim in {128, 256, 512} only")
+        key = (t.device.index, st, "ml2")
+        buf = _WORKSPACES.get(key)
+        if buf is None or buf.numel() < need:
+            buf = _WORKSPACES[key] = torch.zeros((need,), device=t.device, dtype=torch.uint8)  # (zeroed once)
+        _lib.check(_lib.lib().kge_multilabel2_bwd_accum(
+            ctypes.byref(tc), _lib.LOSS_KL if kind == "kl" else _lib.LOSS_BCE, float(offset), ctypes.byref(sides[0]),
+            ctypes.byref(sides[1]), ge.data_ptr(), grel.data_ptr(), buf.data_ptr(), buf.numel(), st),
+            "kge_multilabel2_bwd_accum")
+    return ge, grel
+
+
 def _csr64(rowptr, col, dev):
     rp = rowptr.to(device=dev, dtype=torch.int64).contiguous()
     cl = col.to(device=dev, dtype=torch.int64).contiguous()

@@ -8,8 +8,8 @@ from kge.model.rotate import RotatE as _RefRotatE
 from kge.model.transe import TransE as _RefTransE
 
 from .. import engine
-from ..model import (BF16Shadow, _FusedCE, _FusedCE2, _FusedCE2Sum, _ScoreEmb, _ScoreNeg, _ScoreNegBlocks, _ScorePairs,
-                     _ScoreSPO, bce_fused, ce_fused_dropout, kl_fused, neg_blocks_fusable)
+from ..model import (BF16Shadow, _FusedCE, _FusedCE2, _FusedCE2Sum, _FusedMultiLabel2, _ScoreEmb, _ScoreNeg,
+                     _ScoreNegBlocks, _ScorePairs, _ScoreSPO, bce_fused, ce_fused_dropout, kl_fused, neg_blocks_fusable)
 
 
 class _HipScorer(RelationalScorer):
@@ -271,6 +271,17 @@ class _FusedScoring:
         ent, rel = self._w()
         return bce_fused(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, lbl_rowptr, lbl_col,
                          float(offset), float(label_smoothing), t)
+
+    def multilabel_loss_sp_po(self, kind: str, s: Tensor, p_sp: Tensor, rowptr_sp: Tensor, col_sp: Tensor, o: Tensor,
+                              p_po: Tensor, rowptr_po: Tensor, col_po: Tensor, offset: float = 0.0):
+        """(loss rows of the sp_ queries, loss rows of the _po queries) of a KvsAll subbatch with ONE backward for both
+        types (kge_amd.model._FusedMultiLabel2: no label smoothing); None if the fused path does not apply."""
+        t = self._ce_tables()
+        if t is None:
+            return None
+        ent, rel = self._w()
+        return _FusedMultiLabel2.apply(kind, float(offset), ent, rel, s, p_sp, rowptr_sp, col_sp, o, p_po, rowptr_po,
+                                       col_po, t)
 
     def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
         if not self._fused():

@@ -260,11 +260,12 @@ class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
         offsets = torch.zeros(batch_size + 1, dtype=torch.long, device=coords.device)
         torch.cumsum(counts, 0, out=offsets[1:])
         result.prepare_time += time.time()
+        offset, ls = _plain_bce(self.loss), float(self.label_smoothing)
+        per_type = {}
         for query_type_index, query_type in enumerate(self.query_types):
             examples = (qtype == query_type_index).nonzero(as_tuple=False).view(-1)
             if len(examples) == 0:
                 continue
-            result.forward_time -= time.time()
             rows = examples + row0
             cnt = counts[rows]
             rowptr = torch.zeros(len(rows) + 1, dtype=torch.long, device=cnt.device)
@@ -272,9 +273,27 @@ class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
             total = int(rowptr[-1])
             idx = torch.repeat_interleave(offsets[rows] - rowptr[:-1], cnt, output_size=total) \
                 + torch.arange(total, device=cnt.device)
-            col = coords[idx, 1].long()
-            q0, q1 = queries[examples, 0], queries[examples, 1]
-            offset, ls = _plain_bce(self.loss), float(self.label_smoothing)
+            per_type[query_type] = (queries[examples, 0], queries[examples, 1], rowptr, coords[idx, 1].long())
+        # both query types of the subbatch: their loss rows with ONE backward (two d loss / d score passes, the gradient
+        # products once over all rows, no index_add / accumulation passes of autograd in between); the reference
+        # back-propagates the two losses one after the other -- the same gradients, accumulated
+        if ls == 0.0 and len(per_type) == 2 and hasattr(self.model, "multilabel_loss_sp_po"):
+            result.forward_time -= time.time()
+            (s_, p_sp, rp_sp, cl_sp), (p_po, o_, rp_po, cl_po) = per_type["sp_"], per_type["_po"]
+            both = self.model.multilabel_loss_sp_po("kl" if offset is None else "bce", s_, p_sp, rp_sp, cl_sp, o_, p_po,
+                                                    rp_po, cl_po, 0.0 if offset is None else offset)
+            if both is None:
+                _declined_late("multilabel_loss_sp_po")
+            loss_value = (both[0].sum() + both[1].sum()) / batch_size  # averaged over the batch, not the subbatch
+            result.avg_loss += loss_value.item()
+            result.forward_time += time.time()
+            result.backward_time -= time.time()
+            if not self.is_forward_only:
+                loss_value.backward()
+            result.backward_time += time.time()
+            return
+        for query_type, (q0, q1, rowptr, col) in per_type.items():
+            result.forward_time -= time.time()
             if offset is None:
                 loss_rows = (self.model.kl_loss_sp(q0, q1, rowptr, col, ls) if query_type == "sp_"
                              else self.model.kl_loss_po(q0, q1, rowptr, col, ls))

@@ -290,6 +290,22 @@ class KgeModel(torch.nn.Module):
             return self._kl_fused("po", o, p, lbl_rowptr, lbl_col, float(label_smoothing), t)
         return self._kl_composed(self.score_po(p, o), lbl_rowptr, lbl_col, label_smoothing)
 
+    def multilabel_loss_sp_po(self, kind: str, s: Tensor, p_sp: Tensor, rowptr_sp: Tensor, col_sp: Tensor, o: Tensor,
+                              p_po: Tensor, rowptr_po: Tensor, col_po: Tensor, offset: float = 0.0,
+                              label_smoothing: float = 0.0):
+        """(loss rows of the sp_ queries (s, p_sp), loss rows of the _po queries (p_po, o)) of a KvsAll batch, `kind`
+        "kl" or "bce": kl_loss_sp + kl_loss_po (bce_loss_sp + bce_loss_po) with ONE backward for both types where the
+        fused path applies (_FusedMultiLabel2; no label smoothing), else the two per-type calls."""
+        t = self._ce_tables()
+        if t is not None and label_smoothing == 0.0:
+            return _FusedMultiLabel2.apply(kind, float(offset), self._entity_embedder.weight, self._relation_embedder.weight,
+                                           s, p_sp, rowptr_sp, col_sp, o, p_po, rowptr_po, col_po, t)
+        if kind == "kl":
+            return (self.kl_loss_sp(s, p_sp, rowptr_sp, col_sp, label_smoothing),
+                    self.kl_loss_po(p_po, o, rowptr_po, col_po, label_smoothing))
+        return (self.bce_loss_sp(s, p_sp, rowptr_sp, col_sp, offset, label_smoothing),
+                self.bce_loss_po(p_po, o, rowptr_po, col_po, offset, label_smoothing))
+
     # -- bce loss (train.loss: bce, loss.py:137-159 with bce_type None) on multi-hot labels
     @staticmethod
     def _bce_composed(scores: Tensor, rowptr: Tensor, col: Tensor, offset: float = 0.0,
@@ -672,6 +688,36 @@ class _FusedKL(torch.autograd.Function):
         _scatter_rows(gr, p, g_p)
         _scatter_rows(ge, a, g_a)
         return None, ge, gr, None, None, None, None, None, None, None
+
+
+class _FusedMultiLabel2(torch.autograd.Function):
+    """Both query types of a KvsAll batch: (loss rows of the sp_ queries, loss rows of the _po queries), each from its
+    fused forward (kge_kl_fwd / kge_bce_fwd), and ONE backward for both (kge_multilabel2_bwd_accum): two d loss / d score
+    passes into one gradient matrix, the two gradient products once over all rows, the gathered rows' gradients
+    scattered by the library -- where two _FusedKL nodes run four products and leave two index_add passes and a
+    gradient accumulation over [E, d] to autograd (train_KvsAll.py:274-294 back-propagates the two losses separately:
+    the same gradients, accumulated).  No label smoothing (its extra terms are torch ops around the per-type nodes)."""
+
+    @staticmethod
+    def forward(ctx, kind, offset, ent, rel, s, p_sp, rowptr_sp, col_sp, o, p_po, rowptr_po, col_po, tables16):
+        lse = (None, None)
+        if kind == "kl":
+            rows_sp, lse_sp = engine.kl_fwd(tables16, "sp", s, p_sp, rowptr_sp, col_sp, None)
+            rows_po, lse_po = engine.kl_fwd(tables16, "po", o, p_po, rowptr_po, col_po, None)
+            lse = (lse_sp, lse_po)
+        else:
+            rows_sp = engine.bce_fwd(tables16, "sp", s, p_sp, rowptr_sp, col_sp, offset)
+            rows_po = engine.bce_fwd(tables16, "po", o, p_po, rowptr_po, col_po, offset)
+        ctx.t16, ctx.kind, ctx.offset, ctx.lse = tables16, kind, offset, lse
+        ctx.idx = ((s, p_sp, rowptr_sp, col_sp), (o, p_po, rowptr_po, col_po))
+        return rows_sp, rows_po
+
+    @staticmethod
+    def backward(ctx, g_sp, g_po):
+        sp, po = ctx.idx
+        ge, gr = engine.multilabel2_bwd_accum(ctx.t16, ctx.kind, ctx.offset, sp + (ctx.lse[0], g_sp.contiguous()),
+                                              po + (ctx.lse[1], g_po.contiguous()))
+        return (None, None, ge, gr) + (None,) * 9
 
 
 def kl_fused(name: str, l_norm, direction: str, ent: Tensor, rel: Tensor, a: Tensor, p: Tensor, rowptr: Tensor,

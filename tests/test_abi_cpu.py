@@ -171,6 +171,18 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 9)(*[seg(None, 0)] * 9), 9, None) == -1   # at most 8 segments
     assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 2)(seg(None, 0), seg(20, 8)), 2, None) == -1  # misaligned
     assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 2)(seg(None, 0), seg(None, 0)), 2, None) == 0  # nothing to do
+    # both query types of a KvsAll batch in one backward: unsupported tables, unknown loss, missing pieces
+    from kge_amd._lib import KgeLabelQueries
+    lq = lambda n, lse=16: KgeLabelQueries(good, good, n, 16, 16, lse, None, 1.0)
+    assert lib.kge_multilabel2_workspace_bytes(ctypes.byref(bf16), 512, 300) > lib.kge_ce_workspace_bytes(ctypes.byref(bf16), 512)
+    assert lib.kge_multilabel2_workspace_bytes(ctypes.byref(transe), 512, 300) == 0
+    two = lambda t, loss, a, b, ge=ctypes.c_void_p(16): lib.kge_multilabel2_bwd_accum(
+        ctypes.byref(t), loss, 0.0, ctypes.byref(a), ctypes.byref(b), ge, ctypes.c_void_p(16), None, 0, None)
+    assert two(transe, 0, lq(4), lq(4)) == -2
+    assert two(bf16, 2, lq(4), lq(4)) == -1                  # neither kl nor bce
+    assert two(bf16, 0, lq(4, None), lq(4)) == -1            # kl without its lse
+    assert two(bf16, 0, lq(4), lq(4), None) == -1            # no gradient output
+    assert two(bf16, 1, lq(4, None), lq(4, None)) == -5      # (bce needs no lse; no workspace: KGE_ERR_WORKSPACE)
     # the summed forms of the two-sided loss: same checks as kge_ce_sp_po_fwd, and the sum's address is required
     assert lib.kge_ce_sp_po_fwd_sum(ctypes.byref(transe), good, good, good, 4, None, None, None, 1.0,
                                     ctypes.c_void_p(16), None, 0, None) == -2

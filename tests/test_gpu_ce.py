@@ -512,6 +512,73 @@ def test_model_level_summed_loss_and_its_captured_step():
         assert float((x - y).norm() / y.norm()) <= 2e-3  # (Adagrad's first steps amplify atomics-order noise)
 
 
+@pytest.mark.parametrize("model,d,E,R", [("complex", 256, 1037, 13), ("distmult", 512, 2000 + 3, 7)])
+@pytest.mark.parametrize("n1,n2", [(203, 131), (64, 300), (37, 0), (0, 90)])
+@pytest.mark.parametrize("kind", ["kl", "bce"])
+def test_multilabel2_bwd_accum_equals_the_two_one_sided_backwards(eng, model, d, E, R, n1, n2, kind):
+    """kge_multilabel2_bwd_accum (both query types of a KvsAll batch: two d loss / d score passes into one gradient
+    matrix, the two-sided products once over n1 + n2 rows, the rows' gradients scattered by the library) against what
+    autograd assembles from kge_kl_bwd / kge_bce_bwd per type: dT + index_add of the entity rows, index_add of the
+    relation rows, the two types added.  Same d loss / d score bits; the products sum over all rows at once and the
+    scatter is float atomics: relative Frobenius error <= 1e-4.  Unequal, and empty, sides."""
+    ent, rel, s, p1, o, rp1, cl1 = _kl_case(31 * d + n1, model, d, E, R, max(n1, 1), 0.3)
+    _e, _r, _s, p2, o2, rp2, cl2 = _kl_case(37 * d + n2, model, d, E, R, max(n2, 1), 0.3)
+    T = _tables(eng, model, ent, rel)
+    cut = lambda n, *xs: [x[:n] for x in xs]
+    (s, p1), (o2, p2) = cut(n1, s, p1), cut(n2, o2, p2)
+    rp1, cl1 = (rp1, cl1) if n1 else (np.zeros(1, np.int64), np.zeros(0, np.int64))
+    rp2, cl2 = (rp2, cl2) if n2 else (np.zeros(1, np.int64), np.zeros(0, np.int64))
+    rng = np.random.default_rng(4)
+    g1, g2 = ((rng.random(n).astype(np.float32) + 0.5) / max(n1 + n2, 1) for n in (n1, n2))
+    want_e, want_r = torch.zeros(E, d, device=DEV), torch.zeros(R, d, device=DEV)
+    sides = []
+    for direction, a, p, rp, cl, g in (("sp", s, p1, rp1, cl1, g1), ("po", o2, p2, rp2, cl2, g2)):
+        ta, tp, trp, tcl, tg = _t(a), _t(p), _t(rp), _t(cl), _t(g)
+        lse = None
+        if len(a):
+            if kind == "kl":
+                _loss, lse = eng.kl_fwd(T, direction, ta, tp, trp, tcl)
+                g_a, g_p, g_t = eng.kl_bwd(T, direction, ta, tp, trp, tcl, lse, g_rows=tg)
+            else:
+                g_a, g_p, g_t = eng.bce_bwd(T, direction, ta, tp, trp, tcl, -0.25, g_rows=tg)
+            want_e += g_t
+            want_e.index_add_(0, ta, g_a)
+            want_r.index_add_(0, tp, g_p)
+        sides.append((ta, tp, trp, tcl, lse, tg))
+    for _ in range(2):  # (the second call finds the workspace as the first left it)
+        ge, gr = eng.multilabel2_bwd_accum(T, kind, -0.25 if kind == "bce" else 0.0, sides[0], sides[1])
+        for nm, got, want in (("ent", ge, want_e), ("rel", gr, want_r)):
+            assert float((got - want).norm() / want.norm()) <= 1e-4, (nm, float((got - want).norm() / want.norm()))
+
+
+def test_model_level_paired_kvsall_loss():
+    """KgeModel.multilabel_loss_sp_po == (kl_loss_sp, kl_loss_po) / (bce_loss_sp, bce_loss_po): the loss rows bit for
+    bit (the same forward launches), the parameters' gradients of the summed loss to 1e-4 (one backward for both
+    types against two)."""
+    from kge_amd import model as km
+    E, R, d, n = 3000 + 5, 11, 256, 300
+    ent, rel, s, p, o, rp, cl = _kl_case(23, "complex", d, E, R, n, 0.3)
+    _e, _r, _s, p2, o2, rp2, cl2 = _kl_case(29, "complex", d, E, R, n - 50, 0.3)
+    ts, tp, trp, tcl, tp2, to2, trp2, tcl2 = (_t(x) for x in (s, p, rp, cl, p2, o2, rp2, cl2))
+    torch.manual_seed(0)
+    m = km.create("complex", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    for kind in ("kl", "bce"):
+        m.zero_grad()
+        a, b = m.multilabel_loss_sp_po(kind, ts, tp, trp, tcl, to2, tp2, trp2, tcl2, offset=-0.5)
+        ((a.sum() + b.sum()) / (2 * n)).backward()
+        got = [x.grad.clone() for x in m.parameters()]
+        m.zero_grad()
+        if kind == "kl":
+            a2, b2 = m.kl_loss_sp(ts, tp, trp, tcl), m.kl_loss_po(tp2, to2, trp2, tcl2)
+        else:
+            a2, b2 = m.bce_loss_sp(ts, tp, trp, tcl, -0.5), m.bce_loss_po(tp2, to2, trp2, tcl2, -0.5)
+        assert torch.equal(a.detach(), a2.detach()) and torch.equal(b.detach(), b2.detach())
+        (a2.sum() / (2 * n)).backward()
+        (b2.sum() / (2 * n)).backward()
+        for x, y in zip(got, [x.grad for x in m.parameters()]):
+            assert float((x - y).norm() / y.norm()) <= 1e-4, kind
+
+
 # ---- bce loss (kge_bce_fwd / kge_bce_bwd) ------------------------------------------------------------
 @pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5] + CASES[6:8])
 @pytest.mark.parametrize("offset", [0.0, -1.5])
