@@ -800,8 +800,7 @@ def kvsall_step_leg(device, n, steps):
         csr.append((rowptr.to(device), col.to(device)))
 
     def both(a_, b_, c_, rp0, cl0, rp1, cl1):  # both query types, one backward (kge_multilabel2_bwd_accum)
-        rows_sp, rows_po = m.multilabel_loss_sp_po("kl", a_, b_, rp0, cl0, c_, b_, rp1, cl1)
-        return (rows_sp.sum() + rows_po.sum()) / (2 * n)
+        return m.multilabel_loss_sp_po("kl", a_, b_, rp0, cl0, c_, b_, rp1, cl1, sum_scale=1.0 / (2 * n))
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -632,7 +632,7 @@ int kge_bce_bwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
  * `.grad` holds after the reference's two backward calls -- the dense target gradient of both types plus the
  * gathered entity and relation rows' gradients (float atomics: equal up to their order).
  *   sp: a = subjects, p = relations of the sp_ queries; po: a = OBJECTS, p = relations of the _po queries;
- *   lse: kge_kl_fwd's (KGE_LOSS_KL; unused for KGE_LOSS_BCE); g_rows / g_scalar: upstream gradient of loss_rows;
+ *   lse: kge_kl_fwd's (KGE_LOSS_KL; unused for KGE_LOSS_BCE); g_rows / g_scalar / g_dev: upstream gradient of loss_rows;
  *   offset: kge_bce_fwd's (KGE_LOSS_BCE).  Either side may be empty (n = 0).
  * Workspace: kge_multilabel2_workspace_bytes(t, n_sp, n_po) (0: unsupported tables), 256-byte aligned, zeroed once. */
 #define KGE_LOSS_KL 0
@@ -643,8 +643,10 @@ typedef struct kge_label_queries {
   const int64_t* lbl_rowptr;   /* [n + 1] */
   const int64_t* lbl_col;
   const float* lse;            /* [n] or NULL (bce) */
-  const float* g_rows;         /* [n] or NULL: g_scalar for every row */
+  const float* g_rows;         /* [n] or NULL: g_scalar (x g_dev[0]) for every row */
   float g_scalar;
+  const float* g_dev;          /* [1] device float or NULL: the upstream gradient of a SUMMED loss (a captured step
+                                * holds no host value: kge_ce_sp_po_bwd_accum_sum) */
 } kge_label_queries;
 int64_t kge_multilabel2_workspace_bytes(const kge_tables* t, int64_t n_sp, int64_t n_po);
 int kge_multilabel2_bwd_accum(const kge_tables* t, int loss, float offset, const kge_label_queries* sp,

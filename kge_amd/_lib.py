@@ -51,7 +51,7 @@ class KgeNextQueries(ctypes.Structure):
 
 class KgeLabelQueries(ctypes.Structure):
     _fields_ = [("a", KgeIndex), ("p", KgeIndex), ("n", c_i64), ("lbl_rowptr", c_vp), ("lbl_col", c_vp), ("lse", c_vp),
-                ("g_rows", c_vp), ("g_scalar", ctypes.c_float)]
+                ("g_rows", c_vp), ("g_scalar", ctypes.c_float), ("g_dev", c_vp)]
 
 
 LOSS_KL, LOSS_BCE = 0, 1

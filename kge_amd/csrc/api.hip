@@ -1673,7 +1673,7 @@ int kge_multilabel2_bwd_accum(const kge_tables* t, int loss, float offset, const
     if (!ce_supported(t->scorer, t->dtype, (int)t->dim, ent_op(t, q.a), rel_op(t, q.p), ent_op(t, none)))
       return KGE_ERR_UNSUPPORTED;
     side[k] = LossSide{ent_op(t, q.a), rel_op(t, q.p), q.n, (const long long*)q.lbl_rowptr, (const long long*)q.lbl_col,
-                       q.lse, q.g_rows, q.g_scalar, nullptr, nullptr};
+                       q.lse, q.g_rows, q.g_scalar, nullptr, nullptr, q.g_dev};
   }
   return run_multilabel2_bwd_accum(t->scorer, loss, offset, side[0], side[1], ent_op(t, none), (int)t->dim, t->num_ent,
                                    grad_ent, grad_rel, t->num_rel, t->rel_dim, workspace, workspace_bytes,

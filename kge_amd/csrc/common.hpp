@@ -422,10 +422,11 @@ struct LossSide {
   const long long* rowptr;  // [n + 1] label CSR
   const long long* col;
   const float* lse;         // kl: [n]
-  const float* g_rows;      // [n] upstream gradients, or NULL: g_scalar
+  const float* g_rows;      // [n] upstream gradients, or NULL: g_scalar (x g_dev[0])
   float g_scalar;
   const float* label_weight;  // kl with label smoothing: [n], and the rows' uniform mass; else NULL
   const float* label_bias;
+  const float* g_dev;       // [1] device scalar or NULL: with g_rows == NULL every row's gradient is g_scalar * g_dev[0]
 };
 
 __device__ __forceinline__ float ce_row_gradient(const CeArgs& ce, long long row) {

@@ -1459,12 +1459,14 @@ def ce_sp_po_bwd_accum_sum(t: Tables, s, p, o, lse, g=None, scale=None):
     return ge, grel
 
 
-def multilabel2_bwd_accum(t: Tables, kind: str, offset: float, sp, po):
+def multilabel2_bwd_accum(t: Tables, kind: str, offset: float, sp, po, g=None, scale: float = 1.0):
     """Backward of BOTH query types of a KvsAll batch with complete table gradients (kge_multilabel2_bwd_accum):
     `sp` = (s, p, lbl_rowptr, lbl_col, lse, g_rows) of the sp_ queries, `po` = (o, p, lbl_rowptr, lbl_col, lse, g_rows) of
-    the _po queries (lse: kl_fwd's, None for kind "bce"; g_rows: upstream gradients of the loss rows); returns
-    (grad_entities [E, d], grad_relations [R, d_r]).  Either side may have no rows."""
+    the _po queries (lse: kl_fwd's, None for kind "bce"; g_rows: upstream gradients of the loss rows, or None: every
+    row's gradient is `scale` x the float32 device scalar `g` -- the backward of scale * (sum of all loss rows));
+    returns (grad_entities [E, d], grad_relations [R, d_r]).  Either side may have no rows."""
     keep, sides, n = [], [], []
+    gd = _dev_scalar(g, t.device, "multilabel2_bwd_accum(g)")
     for name, (a, p, rowptr, col, lse, g_rows) in (("sp", sp), ("po", po)):
         k0 = len(keep)
         ai, pi = (_index(x, t.device, keep) for x in (a, p))
@@ -1476,7 +1478,8 @@ def multilabel2_bwd_accum(t: Tables, kind: str, offset: float, sp, po):
             raise ValueError("multilabel2_bwd_accum: the kl loss needs kl_fwd's lse")
         keep += [rp, cl, ls, gr]
         sides.append(_lib.KgeLabelQueries(ai, pi, nk, rp.data_ptr(), cl.data_ptr(), None if ls is None else ls.data_ptr(),
-                                          None if gr is None else gr.data_ptr(), 1.0))
+                                          None if gr is None else gr.data_ptr(), float(scale) if gr is None else 1.0,
+                                          None if gd is None or gr is not None else gd.data_ptr()))
         n.append(nk)
     ge, grel = _empty(tuple(t.ent.shape), t.device), _empty(tuple(t.rel.shape), t.device)
     with _on_device(t.device):

@@ -273,15 +273,17 @@ class _FusedScoring:
                          float(offset), float(label_smoothing), t)
 
     def multilabel_loss_sp_po(self, kind: str, s: Tensor, p_sp: Tensor, rowptr_sp: Tensor, col_sp: Tensor, o: Tensor,
-                              p_po: Tensor, rowptr_po: Tensor, col_po: Tensor, offset: float = 0.0):
-        """(loss rows of the sp_ queries, loss rows of the _po queries) of a KvsAll subbatch with ONE backward for both
-        types (kge_amd.model._FusedMultiLabel2: no label smoothing); None if the fused path does not apply."""
+                              p_po: Tensor, rowptr_po: Tensor, col_po: Tensor, offset: float = 0.0,
+                              sum_scale: float = None):
+        """(loss rows of the sp_ queries, loss rows of the _po queries) of a KvsAll subbatch -- or, with `sum_scale`,
+        the 0-d sum_scale * (sum of all rows) -- with ONE backward for both types (kge_amd.model._FusedMultiLabel2: no
+        label smoothing); None if the fused path does not apply."""
         t = self._ce_tables()
         if t is None:
             return None
         ent, rel = self._w()
         return _FusedMultiLabel2.apply(kind, float(offset), ent, rel, s, p_sp, rowptr_sp, col_sp, o, p_po, rowptr_po,
-                                       col_po, t)
+                                       col_po, t, sum_scale)
 
     def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
         if not self._fused():

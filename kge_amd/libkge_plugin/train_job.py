@@ -280,11 +280,12 @@ class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
         if ls == 0.0 and len(per_type) == 2 and hasattr(self.model, "multilabel_loss_sp_po"):
             result.forward_time -= time.time()
             (s_, p_sp, rp_sp, cl_sp), (p_po, o_, rp_po, cl_po) = per_type["sp_"], per_type["_po"]
-            both = self.model.multilabel_loss_sp_po("kl" if offset is None else "bce", s_, p_sp, rp_sp, cl_sp, o_, p_po,
-                                                    rp_po, cl_po, 0.0 if offset is None else offset)
-            if both is None:
+            # (averaged over the batch, not the subbatch)
+            loss_value = self.model.multilabel_loss_sp_po("kl" if offset is None else "bce", s_, p_sp, rp_sp, cl_sp, o_, p_po,
+                                                          rp_po, cl_po, 0.0 if offset is None else offset,
+                                                          sum_scale=1.0 / batch_size)
+            if loss_value is None:
                 _declined_late("multilabel_loss_sp_po")
-            loss_value = (both[0].sum() + both[1].sum()) / batch_size  # averaged over the batch, not the subbatch
             result.avg_loss += loss_value.item()
             result.forward_time += time.time()
             result.backward_time -= time.time()

@@ -292,19 +292,22 @@ class KgeModel(torch.nn.Module):
 
     def multilabel_loss_sp_po(self, kind: str, s: Tensor, p_sp: Tensor, rowptr_sp: Tensor, col_sp: Tensor, o: Tensor,
                               p_po: Tensor, rowptr_po: Tensor, col_po: Tensor, offset: float = 0.0,
-                              label_smoothing: float = 0.0):
+                              label_smoothing: float = 0.0, sum_scale: float = None):
         """(loss rows of the sp_ queries (s, p_sp), loss rows of the _po queries (p_po, o)) of a KvsAll batch, `kind`
         "kl" or "bce": kl_loss_sp + kl_loss_po (bce_loss_sp + bce_loss_po) with ONE backward for both types where the
-        fused path applies (_FusedMultiLabel2; no label smoothing), else the two per-type calls."""
+        fused path applies (_FusedMultiLabel2; no label smoothing), else the two per-type calls.  `sum_scale` given:
+        the 0-d batch loss sum_scale * (sum of all rows) instead of the two row vectors."""
         t = self._ce_tables()
         if t is not None and label_smoothing == 0.0:
             return _FusedMultiLabel2.apply(kind, float(offset), self._entity_embedder.weight, self._relation_embedder.weight,
-                                           s, p_sp, rowptr_sp, col_sp, o, p_po, rowptr_po, col_po, t)
+                                           s, p_sp, rowptr_sp, col_sp, o, p_po, rowptr_po, col_po, t, sum_scale)
         if kind == "kl":
-            return (self.kl_loss_sp(s, p_sp, rowptr_sp, col_sp, label_smoothing),
+            both = (self.kl_loss_sp(s, p_sp, rowptr_sp, col_sp, label_smoothing),
                     self.kl_loss_po(p_po, o, rowptr_po, col_po, label_smoothing))
-        return (self.bce_loss_sp(s, p_sp, rowptr_sp, col_sp, offset, label_smoothing),
-                self.bce_loss_po(p_po, o, rowptr_po, col_po, offset, label_smoothing))
+        else:
+            both = (self.bce_loss_sp(s, p_sp, rowptr_sp, col_sp, offset, label_smoothing),
+                    self.bce_loss_po(p_po, o, rowptr_po, col_po, offset, label_smoothing))
+        return both if sum_scale is None else (both[0].sum() + both[1].sum()) * float(sum_scale)
 
     # -- bce loss (train.loss: bce, loss.py:137-159 with bce_type None) on multi-hot labels
     @staticmethod
@@ -699,7 +702,10 @@ class _FusedMultiLabel2(torch.autograd.Function):
     the same gradients, accumulated).  No label smoothing (its extra terms are torch ops around the per-type nodes)."""
 
     @staticmethod
-    def forward(ctx, kind, offset, ent, rel, s, p_sp, rowptr_sp, col_sp, o, p_po, rowptr_po, col_po, tables16):
+    def forward(ctx, kind, offset, ent, rel, s, p_sp, rowptr_sp, col_sp, o, p_po, rowptr_po, col_po, tables16,
+                sum_scale=None):
+        # sum_scale (a float): ONE output, sum_scale * (sum of all loss rows) -- the batch loss of the training job; its
+        # backward hands the upstream gradient to the kernels as a device scalar (no expand / copy / scale launches)
         lse = (None, None)
         if kind == "kl":
             rows_sp, lse_sp = engine.kl_fwd(tables16, "sp", s, p_sp, rowptr_sp, col_sp, None)
@@ -708,16 +714,23 @@ class _FusedMultiLabel2(torch.autograd.Function):
         else:
             rows_sp = engine.bce_fwd(tables16, "sp", s, p_sp, rowptr_sp, col_sp, offset)
             rows_po = engine.bce_fwd(tables16, "po", o, p_po, rowptr_po, col_po, offset)
-        ctx.t16, ctx.kind, ctx.offset, ctx.lse = tables16, kind, offset, lse
+        ctx.t16, ctx.kind, ctx.offset, ctx.lse, ctx.sum_scale = tables16, kind, offset, lse, sum_scale
         ctx.idx = ((s, p_sp, rowptr_sp, col_sp), (o, p_po, rowptr_po, col_po))
+        if sum_scale is not None:
+            return (rows_sp.sum() + rows_po.sum()) * float(sum_scale)
         return rows_sp, rows_po
 
     @staticmethod
-    def backward(ctx, g_sp, g_po):
+    def backward(ctx, *gout):
         sp, po = ctx.idx
-        ge, gr = engine.multilabel2_bwd_accum(ctx.t16, ctx.kind, ctx.offset, sp + (ctx.lse[0], g_sp.contiguous()),
-                                              po + (ctx.lse[1], g_po.contiguous()))
-        return (None, None, ge, gr) + (None,) * 9
+        if ctx.sum_scale is not None:
+            g = gout[0] if gout[0].dtype == torch.float32 and gout[0].is_contiguous() else gout[0].float().contiguous()
+            ge, gr = engine.multilabel2_bwd_accum(ctx.t16, ctx.kind, ctx.offset, sp + (ctx.lse[0], None),
+                                                  po + (ctx.lse[1], None), g=g, scale=float(ctx.sum_scale))
+        else:
+            ge, gr = engine.multilabel2_bwd_accum(ctx.t16, ctx.kind, ctx.offset, sp + (ctx.lse[0], gout[0].contiguous()),
+                                                  po + (ctx.lse[1], gout[1].contiguous()))
+        return (None, None, ge, gr) + (None,) * 10
 
 
 def kl_fused(name: str, l_norm, direction: str, ent: Tensor, rel: Tensor, a: Tensor, p: Tensor, rowptr: Tensor,

@@ -173,7 +173,7 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 2)(seg(None, 0), seg(None, 0)), 2, None) == 0  # nothing to do
     # both query types of a KvsAll batch in one backward: unsupported tables, unknown loss, missing pieces
     from kge_amd._lib import KgeLabelQueries
-    lq = lambda n, lse=16: KgeLabelQueries(good, good, n, 16, 16, lse, None, 1.0)
+    lq = lambda n, lse=16: KgeLabelQueries(good, good, n, 16, 16, lse, None, 1.0, None)
     assert lib.kge_multilabel2_workspace_bytes(ctypes.byref(bf16), 512, 300) > lib.kge_ce_workspace_bytes(ctypes.byref(bf16), 512)
     assert lib.kge_multilabel2_workspace_bytes(ctypes.byref(transe), 512, 300) == 0
     two = lambda t, loss, a, b, ge=ctypes.c_void_p(16): lib.kge_multilabel2_bwd_accum(

@@ -575,8 +575,17 @@ def test_model_level_paired_kvsall_loss():
         assert torch.equal(a.detach(), a2.detach()) and torch.equal(b.detach(), b2.detach())
         (a2.sum() / (2 * n)).backward()
         (b2.sum() / (2 * n)).backward()
-        for x, y in zip(got, [x.grad for x in m.parameters()]):
+        want = [x.grad.clone() for x in m.parameters()]
+        for x, y in zip(got, want):
             assert float((x - y).norm() / y.norm()) <= 1e-4, kind
+        # the summed form: the value, and the gradients for an upstream gradient that is not 1
+        m.zero_grad()
+        tot = m.multilabel_loss_sp_po(kind, ts, tp, trp, tcl, to2, tp2, trp2, tcl2, offset=-0.5, sum_scale=1.0 / (2 * n))
+        ref = (a2.detach().double().sum() + b2.detach().double().sum()) / (2 * n)
+        assert tot.shape == () and abs(float(tot) - float(ref)) <= 2e-6 * abs(float(ref))
+        (tot * 0.5).backward()
+        for x, y in zip([x.grad for x in m.parameters()], want):
+            assert float((x - 0.5 * y).norm() / (0.5 * y).norm()) <= 1e-4, kind
 
 
 # ---- bce loss (kge_bce_fwd / kge_bce_bwd) ------------------------------------------------------------
