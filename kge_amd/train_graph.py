@@ -1,7 +1,7 @@
 """A whole training step -- forward, backward, optimizer -- as ONE hipGraph replay.
 
-The fused 1vsAll step at the FB15k-237 shape is ~170 us of kernels (profiles/r4_train_step_kernels.txt) issued by
-~300 us of Python: autograd bookkeeping, a dozen launches through ctypes, the optimizer's loop over parameters.  The
+The fused 1vsAll step at the FB15k-237 shape is ~150 us of kernels (profiles/r5_train_step_kernels.txt) issued by
+~240 us of Python: autograd bookkeeping, nine launches through ctypes, the optimizer's loop over parameters.  The
 GPU waits for the host.  A batch of a fixed shape is the same launch sequence every time, so it is captured once
 (torch.cuda.CUDAGraph; HIP graphs underneath) and replayed: the host copies the batch's indexes into static buffers and
 issues one graph launch.
