@@ -512,7 +512,8 @@ def test_model_level_summed_loss_and_its_captured_step():
         assert float((x - y).norm() / y.norm()) <= 2e-3  # (Adagrad's first steps amplify atomics-order noise)
 
 
-@pytest.mark.parametrize("model,d,E,R", [("complex", 256, 1037, 13), ("distmult", 512, 2000 + 3, 7)])
+@pytest.mark.parametrize("model,d,E,R", [("complex", 256, 1037, 13), ("distmult", 512, 2000 + 3, 7),
+                                         ("complex", 128, 500, 5)])   # (d = 128: the products' float32 form)
 @pytest.mark.parametrize("n1,n2", [(203, 131), (64, 300), (37, 0), (0, 90)])
 @pytest.mark.parametrize("kind", ["kl", "bce"])
 def test_multilabel2_bwd_accum_equals_the_two_one_sided_backwards(eng, model, d, E, R, n1, n2, kind):
