@@ -469,7 +469,20 @@ def main_sharded(a, world, rank, device):
     import torch.distributed as td
     from kge_amd import engine
     from kge_amd.sharded import ShardedScoreLanes
-    td.init_process_group("nccl", device_id=device)
+    # This RCCL build prints a version banner (five lines) on STDOUT when its communicator comes up; the contract is
+    # ONE JSON line there.  File descriptor 1 points at stderr until the communicator exists.
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        td.init_process_group("nccl", device_id=device)
+        warm = torch.zeros(1, device=device)
+        td.all_reduce(warm)
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
     if td.get_world_size() != world or (a.gpus != world and os.environ.get("KGE_BENCH_FORCE_DIST") != "1"):
         raise SystemExit(f"bench: RCCL reports {td.get_world_size()} ranks, --gpus {a.gpus}, WORLD_SIZE {world}")
     n = a.batch
