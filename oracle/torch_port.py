@@ -15,6 +15,10 @@ itself cannot travel to the GPU box.
                      (LookupEmbedder.embed / embed_all, lookup_embedder.py:96-112)
   ns_bce_loss     <- BCEWithLogitsKgeLoss.__call__  kge/util/loss.py:153-186 on the label matrix of
                      TrainingJobNegativeSampling (column 0 = 1, train_negative_sampling.py:128-137)
+  kl_loss         <- KLDivWithSoftmaxKgeLoss.__call__  kge/util/loss.py:192-213 (index labels: TrainingJob1vsAll;
+                     label matrix: TrainingJobKvsAll)
+  bce_loss        <- BCEWithLogitsKgeLoss.__call__ with bce_type None  kge/util/loss.py:137-159
+  smooth_labels   <- TrainingJobKvsAll's label smoothing  kge/job/train_KvsAll.py:260-266
 """
 import torch
 import torch.nn.functional as F
@@ -129,3 +133,39 @@ def ns_bce_loss(scores, kind, offset=0.0, temperature=1.0):
     losses_negatives = losses.view(-1)[negative_indexes].view((n, c - 1))
     losses_negatives = (F.softmax(scores_negatives * temperature, dim=1) * losses_negatives).sum(dim=1)
     return (losses_positives.sum() + losses_negatives.sum()) / 2.0
+
+
+def kl_loss(scores, labels, reduction="sum"):
+    """KLDivWithSoftmaxKgeLoss (kge/util/loss.py:192-213), the loss of TrainingJob1vsAll (index labels, [n]:
+    CrossEntropyLoss, loss.py:196-207) and of TrainingJobKvsAll (a label matrix, [n, E]: KLDivLoss of log_softmax against
+    the L1-normalised labels, loss.py:208-213).  reduction "sum" is what the jobs use; "rows" gives the per-row terms the
+    fused kernels return (kge_ce_fwd / kge_kl_fwd: loss_rows) -- the same torch functions with reduction "none"."""
+    red = "none" if reduction == "rows" else reduction
+    if labels.dim() == 1:
+        return torch.nn.CrossEntropyLoss(reduction=red)(scores, labels)
+    out = torch.nn.KLDivLoss(reduction=red)(F.log_softmax(scores, dim=1), F.normalize(labels.float(), p=1, dim=1))
+    return out.sum(dim=1) if reduction == "rows" else out
+
+
+def bce_loss(scores, labels, offset=0.0, reduction="sum"):
+    """BCEWithLogitsKgeLoss with bce_type None (kge/util/loss.py:137-159) on a label matrix [n, E] (TrainingJobKvsAll;
+    index labels [n] become a one-hot matrix first, loss.py:105-116: TrainingJob1vsAll): offset, then BCEWithLogitsLoss
+    over the flattened matrices.  reduction "rows": the per-row sums kge_bce_fwd returns."""
+    if labels.dim() == 1:
+        x = torch.zeros(scores.shape, device=scores.device, dtype=torch.float)
+        x[range(len(scores)), labels] = 1.0
+        labels = x
+    if offset != 0.0:
+        scores = scores + offset
+    if reduction == "rows":
+        return torch.nn.BCEWithLogitsLoss(reduction="none")(scores.view(-1), labels.view(-1)).view(scores.shape).sum(dim=1)
+    return torch.nn.BCEWithLogitsLoss(reduction=reduction)(scores.view(-1), labels.view(-1))
+
+
+def smooth_labels(labels, label_smoothing):
+    """TrainingJobKvsAll's label smoothing (kge/job/train_KvsAll.py:260-266, as in ConvE): applied to the multi-hot
+    label matrix before the loss."""
+    if label_smoothing > 0.0:
+        return (1.0 - label_smoothing) * labels + 1.0 / labels.size(1)
+    return labels
+

@@ -512,6 +512,38 @@ def test_model_level_summed_loss_and_its_captured_step():
         assert float((x - y).norm() / y.norm()) <= 2e-3  # (Adagrad's first steps amplify atomics-order noise)
 
 
+@pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:6])
+def test_fused_losses_against_the_oracles_loss_restatements(eng, model, d, E, R, n, scale):
+    """The three fused training losses against oracle/torch_port.kl_loss / bce_loss (pinned bit for bit to the reference's
+    KLDivWithSoftmaxKgeLoss / BCEWithLogitsKgeLoss: tests/test_oracle_vs_reference.py) evaluated on the scores the
+    scoring entry writes for the same inputs (the same bits inside the fused kernels): index labels (1vsAll), a
+    multi-hot matrix (KvsAll kl), the same with an offset (KvsAll bce).  f32 exp / log / summation order differ:
+    |diff| <= 1e-5 + 1e-5 |lse| + 2e-6 max|score| per label (kl), 1e-5 |ref| + 1e-4 (bce: a sum over E softplus terms)."""
+    import torch_port as tp
+    ent, rel, s, p, o, rowptr, col = _kl_case(41 * d + n, model, d, E, R, n, scale)
+    T = _tables(eng, model, ent, rel)
+    ts, tp_, to, trp, tcl = _t(s), _t(p), _t(o), _t(rowptr), _t(col)
+    lab = torch.zeros(n, E)
+    lab[torch.from_numpy(np.repeat(np.arange(n), np.diff(rowptr))), torch.from_numpy(col)] = 1.0
+    for direction, a, other in (("sp", ts, to), ("po", to, ts)):
+        sc = (eng.score_sp(T, a, tp_) if direction == "sp" else eng.score_po(T, tp_, a)).cpu()
+        amax = sc.abs().max(dim=1).values.double()
+        lse = torch.logsumexp(sc.double(), 1).abs()
+        # 1vsAll: index labels
+        got, _lse = eng.ce_fwd(T, direction, a, tp_, other)
+        want = tp.kl_loss(sc.double(), other.cpu().long(), "rows")
+        assert bool(((got.cpu().double() - want).abs() <= 1e-5 + 1e-5 * lse + 2e-6 * amax).all()), direction
+        # KvsAll, kl on the multi-hot matrix
+        got, _lse = eng.kl_fwd(T, direction, a, tp_, trp, tcl)
+        want = tp.kl_loss(sc.double(), lab.double(), "rows")
+        k = torch.from_numpy(np.maximum(1, np.diff(rowptr))).double()
+        assert bool(((got.cpu().double() - want).abs() <= 1e-5 + 1e-5 * lse + 2e-6 * amax * k).all()), direction
+        # KvsAll, bce with an offset
+        got = eng.bce_fwd(T, direction, a, tp_, trp, tcl, -0.5)
+        want = tp.bce_loss(sc.double(), lab.double(), -0.5, "rows")
+        assert bool(((got.cpu().double() - want).abs() <= 1e-5 * want.abs() + 1e-4 + 2e-6 * amax * k).all()), direction
+
+
 @pytest.mark.parametrize("model,d,E,R", [("complex", 256, 1037, 13), ("distmult", 512, 2000 + 3, 7),
                                          ("complex", 128, 500, 5)])   # (d = 128: the products' float32 form)
 @pytest.mark.parametrize("n1,n2", [(203, 131), (64, 300), (37, 0), (0, 90)])

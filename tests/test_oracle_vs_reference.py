@@ -74,3 +74,38 @@ def test_ns_bce_port_is_bit_identical_to_the_reference_loss(kind, bce_type, offs
     la.backward()
     lb.backward()
     assert torch.equal(la, lb) and torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("loss,offset", [("kl", 0.0), ("bce", 0.0), ("bce", -0.75)])
+@pytest.mark.parametrize("labels_as", ["index", "matrix", "smoothed"])
+def test_training_loss_ports_are_bit_identical_to_the_reference_losses(loss, offset, labels_as):
+    """oracle/torch_port.kl_loss / bce_loss (+ smooth_labels) against the reference's own loss objects
+    (KLDivWithSoftmaxKgeLoss, BCEWithLogitsKgeLoss: kge/util/loss.py:137-159, 192-213) on the labels the 1vsAll job
+    (indexes) and the KvsAll job (multi-hot matrix, smoothed or not: train_KvsAll.py:260-266) hand them: value and
+    gradient bit for bit (the same torch ops), and the per-row form sums to the reduced one."""
+    rh.import_reference()
+    from kge.util.loss import BCEWithLogitsKgeLoss, KLDivWithSoftmaxKgeLoss
+    config = rh.make_config("complex", 16)  # (job.device: cpu -- _labels_as_matrix allocates there)
+    ref = KLDivWithSoftmaxKgeLoss(config) if loss == "kl" else BCEWithLogitsKgeLoss(config, offset=offset)
+    g = torch.Generator().manual_seed(11)
+    n, E = 29, 83
+    scores = torch.randn(n, E, generator=g) * 4.0
+    if labels_as == "index":
+        labels = torch.randint(E, (n,), generator=g)
+    else:
+        labels = (torch.rand(n, E, generator=g) < 0.06).float()
+        labels[3] = 0.0                      # a row without labels
+        labels[5, :40] = 1.0                 # a row with many
+        if labels_as == "smoothed":
+            labels = tp.smooth_labels(labels, 0.1)
+    a = scores.clone().requires_grad_(True)
+    b = scores.clone().requires_grad_(True)
+    la = ref(a, labels)
+    lb = tp.kl_loss(b, labels) if loss == "kl" else tp.bce_loss(b, labels, offset)
+    la.backward()
+    lb.backward()
+    assert torch.equal(la, lb) and torch.equal(a.grad, b.grad)
+    rows = tp.kl_loss(scores, labels, "rows") if loss == "kl" else tp.bce_loss(scores, labels, offset, "rows")
+    assert rows.shape == (n,)
+    torch.testing.assert_close(rows.double().sum(), la.detach().double(), rtol=2e-6, atol=1e-6)
+
