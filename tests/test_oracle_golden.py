@@ -191,3 +191,35 @@ def test_oracle_ranks_at_the_wn18rr_shape(model):
             assert abs(float((1.0 / (got + 1)).mean() - (1.0 / (ref + 1)).mean())) <= 1e-5
             bad += int((d != 0).sum())
     assert bad <= (12 if model in ("transe", "rotate") else 1), bad
+
+
+def test_training_losses_match_the_reference_golden_vectors():
+    """oracle/torch_port.kl_loss / bce_loss / ns_bce_loss (+ smooth_labels) against tests/golden/losses.npz -- values and
+    gradients of the reference's own KLDivWithSoftmaxKgeLoss / BCEWithLogitsKgeLoss objects on seeded scores
+    (tests/golden/make_golden_losses.py), for the label forms of the 1vsAll, KvsAll and negative-sampling jobs.  The same
+    torch ops: equal to float32 rounding of whatever torch build runs them (rtol 1e-6 on the values, 1e-5 on gradients)."""
+    import torch
+    import torch_port as tp
+    g = np.load(os.path.join(GOLDEN, "losses.npz"))
+    scores = torch.from_numpy(g["scores"])
+    labels = {"index": torch.from_numpy(g["idx"]), "multi": torch.from_numpy(g["multi"]),
+              "smoothed": tp.smooth_labels(torch.from_numpy(g["multi"]), 0.1)}
+    np.testing.assert_allclose(labels["smoothed"].numpy(), g["smoothed"], rtol=1e-6)
+
+    def check(name, fn, x):
+        a = x.clone().requires_grad_(True)
+        v = fn(a)
+        v.backward()
+        np.testing.assert_allclose(float(v), float(g[name + "_value"]), rtol=1e-6, err_msg=name)
+        np.testing.assert_allclose(a.grad.numpy(), g[name + "_grad"], rtol=1e-5, atol=1e-7, err_msg=name)
+
+    for form, lab in labels.items():
+        check("kl_" + form, lambda a, lab=lab: tp.kl_loss(a, lab), scores)
+        check("bce_" + form, lambda a, lab=lab: tp.bce_loss(a, lab, 0.0), scores)
+        check("bce_off_" + form, lambda a, lab=lab: tp.bce_loss(a, lab, -0.75), scores)
+        rows = tp.kl_loss(scores, lab, "rows")          # the per-row form the fused kernels return sums to the loss
+        np.testing.assert_allclose(float(rows.double().sum()), float(g["kl_" + form + "_value"]), rtol=2e-6)
+    block = torch.from_numpy(g["block"])
+    for kind, (off, temp) in zip(("bce", "bce_mean", "bce_self_adversarial"), g["ns_params"]):
+        check("ns_" + kind, lambda a, kind=kind, off=off, temp=temp: tp.ns_bce_loss(a, kind, float(off), float(temp)), block)
+
