@@ -49,6 +49,16 @@ double kge_debug_mfma_rate(const void* operands, int iters, float* sink, void* s
  * *mismatches (device, zeroed by the caller) += the number that differ, first16 (device) their first 16 patterns. */
 int kge_debug_sqrt_check(uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* first16, void* stream);
 
+/* The library's measurement switches (kge_amd/csrc/switches.hpp lists them with their meanings): which kernel generation a
+ * call takes, the cache policy of score stores, probe variants.  The library reads NO environment variable for them
+ * (only KGE_ROCTX, for the roctx ranges): a switch is process-local state that only this call changes -- tests flip
+ * "V8", "CE_V8", "V5" ... for cross-checks between kernel generations, tools/ for A/B timings.  `name` without the
+ * KGE_ prefix; value < 0 = unset (the library's own choice, the state of every switch at load).  Returns KGE_OK, or
+ * KGE_ERR_INVALID_ARG for an unknown name.  Not synchronised with calls in flight on other threads. */
+int kge_debug_set_switch(const char* name, int64_t value);
+/* the switch's value (-1: unset), -2 for an unknown name */
+int64_t kge_debug_get_switch(const char* name);
+
 #ifdef __cplusplus
 }
 #endif

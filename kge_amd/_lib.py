@@ -292,3 +292,49 @@ def check(status: int, what: str):
     if status != KGE_OK:
         msg = lib().kge_status_string(status).decode()
         raise RuntimeError(f"{what} failed: {msg} (kge_status {status})")
+
+
+# ---- measurement switches (include/kge_amd_debug.h: kge_debug_set_switch; kge_amd/csrc/switches.hpp lists them) ----
+# The library reads no environment variable for kernel selection: tests and tools/ flip a switch through this call.
+def set_switch(name: str, value=None) -> None:
+    """value None (or < 0) = unset: the library's own choice."""
+    L = lib()
+    L.kge_debug_set_switch.restype = ctypes.c_int
+    L.kge_debug_set_switch.argtypes = [ctypes.c_char_p, c_i64]
+    check(L.kge_debug_set_switch(name.encode(), -1 if value is None else int(value)), f"kge_debug_set_switch({name})")
+
+
+def get_switch(name: str):
+    L = lib()
+    L.kge_debug_get_switch.restype = c_i64
+    L.kge_debug_get_switch.argtypes = [ctypes.c_char_p]
+    v = L.kge_debug_get_switch(name.encode())
+    if v == -2:
+        raise KeyError(name)
+    return None if v < 0 else int(v)
+
+
+class switches:
+    """with _lib.switches(V8=0, CE_V3=1): ...   -- restores the previous values on exit (names without KGE_)."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = {k: get_switch(k) for k in self.kw}
+        for k, v in self.kw.items():
+            set_switch(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_switch(k, v)
+        return False
+
+
+def apply_switch_spec(spec: str) -> None:
+    """'V8=0,CE_V3=1' -> set_switch calls; what tools/ scripts take on their command line (--switches) or, for the shell
+    wrappers, from KGE_AMD_TOOL_SWITCHES -- read by the TOOL, never by the library or the package."""
+    for item in filter(None, (x.strip() for x in spec.split(","))):
+        k, _, v = item.partition("=")
+        set_switch(k.strip(), int(v))

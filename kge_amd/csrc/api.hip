@@ -243,8 +243,8 @@ constexpr bool V5_DEFAULT = false;
 bool v5_on(const kge_tables* t) {
   if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
     return false;
-  const char* e = getenv("KGE_V5");
-  return e ? e[0] == '1' : V5_DEFAULT;
+  const long long e = sw(SW_V5);
+  return e >= 0 ? e == 1 : V5_DEFAULT;
 }
 
 int check_index(const kge_index& ix, bool allow_null, int64_t len = 1) {
@@ -265,11 +265,11 @@ Operand rel_op(const kge_tables* t, const kge_index& ix) {
 // query_build_kernel launch + the direct-store kernel on prepared queries instead of the cooperative in-launch build
 // (tools/one_call_probe.py, profiles/r4_one_call.txt).  KGE_ONE_CALL_PREPARED=0/1 forces either.
 static bool one_call_prepared(const kge_tables* t, const Operand& TG, int64_t n, int64_t m, int64_t ws_bytes, bool two_sided) {
-  const char* e = getenv("KGE_ONE_CALL_PREPARED");
-  if (e && e[0] == '0') return false;
+  const long long e = sw(SW_ONE_CALL_PREPARED);
+  if (e == 0) return false;
   if (t->dim != 512 || TG.idx.ptr != nullptr) return false;
   if (ws_bytes < PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, two_sided, false)) return false;
-  if (e && e[0] == '1') return true;
+  if (e == 1) return true;
   // measured, FB15k-237 shape: two-sided n = 512 27.3 -> 24.9 us, n = 1024 41.8 -> 40.9; one-sided equal (16.8 / 16.7);
   // n <= 128: the second launch costs more than the round trips it saves (13.1 -> 14.6)
   return two_sided && m >= 2048 && n >= 256;
@@ -287,11 +287,8 @@ static bool one_call_prepared(const kge_tables* t, const Operand& TG, int64_t n,
 constexpr long long ONE_CALL_V8_ROWS = 512;
 
 static long long one_call_v8_min_rows() {
-  const char* e = getenv("KGE_ONE_CALL_V8_MIN_ROWS");
-  if (e && e[0]) {
-    const long long v = atoll(e);
-    if (v >= 2 * ONE_CALL_V8_ROWS) return v;
-  }
+  const long long v = sw(SW_ONE_CALL_V8_MIN_ROWS);
+  if (v >= 2 * ONE_CALL_V8_ROWS) return v;
   return 2 * ONE_CALL_V8_ROWS;
 }
 
@@ -309,8 +306,7 @@ static int one_call_v8(const kge_tables* t, int dir, const Operand& A, const Ope
                        int64_t n, int64_t m, float* out, int64_t ldo, int64_t b2, void* ws, int64_t ws_bytes, hipStream_t st,
                        int64_t* done) {
   *done = 0;
-  const char* e = getenv("KGE_ONE_CALL_V8");
-  if (e && e[0] == '0') return KGE_ERR_UNSUPPORTED;
+  if (sw(SW_ONE_CALL_V8) == 0) return KGE_ERR_UNSUPPORTED;
   if (t->dtype != KGE_BF16 || t->dim != 512 || TG.idx.ptr != nullptr || ws == nullptr || n < one_call_v8_min_rows())
     return KGE_ERR_UNSUPPORTED;
   if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
@@ -425,6 +421,27 @@ int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
 }
 
 }  // namespace
+
+// ---- measurement switches (switches.hpp, include/kge_amd_debug.h) ----
+namespace kge {
+static long long g_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static_assert(SW_COUNT == 19, "g_switch's initialiser");
+static const char* const g_switch_name[SW_COUNT] = {
+    "V5", "ONE_CALL_PREPARED", "ONE_CALL_V8", "ONE_CALL_V8_MIN_ROWS", "V8_RANK", "RANK_FUSED_FRONT", "BWD_GEMM_LIB",
+    "CE_V3", "CE_V8", "V4_OWN_BUILD", "V4_INTERLEAVE", "V4_STORE_SC1", "V6", "V7", "V7_NOSTORE", "V7_PROBE", "V8",
+    "V8_VAR", "V8R_PROBE"};
+long long sw(Switch s) { return __atomic_load_n(&g_switch[(int)s], __ATOMIC_RELAXED); }
+static int switch_index(const char* name) {
+  if (name == nullptr) return -1;
+  if (name[0] == 'K' && name[1] == 'G' && name[2] == 'E' && name[3] == '_') name += 4;  // (the old variable names)
+  for (int i = 0; i < SW_COUNT; ++i) {
+    const char *a = g_switch_name[i], *b = name;
+    while (*a && *a == *b) ++a, ++b;
+    if (*a == 0 && *b == 0) return i;
+  }
+  return -1;
+}
+}  // namespace kge
 
 extern "C" {
 
@@ -1026,8 +1043,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   if (t->flags & (KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
   if ((t->flags & KGE_FLAG_SPLIT_QUERY) && exact_path) return KGE_ERR_UNSUPPORTED;
   // split queries are counted by pairs_bf16_v8_rank_kernel only (their two partial scores meet in one lane there)
-  const char* e8 = getenv("KGE_V8_RANK");
-  const bool v8_rank = !exact_path && !(e8 && e8[0] == '0') && (t->dim == 256 || t->dim == 512) && TG.idx.ptr == nullptr &&
+  const bool v8_rank = !exact_path && sw(SW_V8_RANK) != 0 && (t->dim == 256 || t->dim == 512) && TG.idx.ptr == nullptr &&
                        workspace_bytes >= PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, split);
   if (split && !v8_rank) return KGE_ERR_UNSUPPORTED;
   if (!exact_path) {
@@ -1076,7 +1092,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   // The persistent counting kernel takes its bits from ONE launch together with its query fragments
   // (query_build_bits_kernel) and clears every word it has read itself: two launches instead of four.
   const bool fused_front = v8_rank && !exact_path && nlists > 0 && !queries_ready && n > 0 &&
-                           !(getenv("KGE_RANK_FUSED_FRONT") && getenv("KGE_RANK_FUSED_FRONT")[0] == '0');
+                           sw(SW_RANK_FUSED_FRONT) != 0;
   int rc = fused_front ? KGE_OK : run_rank_bits(nlists, lb, le, lc, keep, bits, n, col_begin, m, bl.rs, bl.us, 1, st);
   if (rc) return rc;
   if (exact_path) {
@@ -1282,9 +1298,8 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
   // both the true scores and the counting launch (pairs_bf16_v8_rank_kernel), which then start on prepared queries
   const bool dot = t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT;
   const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
-  const char* e8 = getenv("KGE_V8_RANK");
   bool ready = t->dtype == KGE_BF16 && dot && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) &&
-               (t->dim == 256 || t->dim == 512) && !(e8 && e8[0] == '0') && workspace && !((uintptr_t)workspace & 15) &&
+               (t->dim == 256 || t->dim == 512) && sw(SW_V8_RANK) != 0 && workspace && !((uintptr_t)workspace & 15) &&
                workspace_bytes >= PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, split) &&
                pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
                pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG);
@@ -1934,6 +1949,17 @@ int kge_debug_sqrt_check(uint32_t first_bits, uint64_t count, uint64_t* mismatch
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 int kge_debug_launch_count(int which) { return kge::v8_launch_count(which); }
+
+int kge_debug_set_switch(const char* name, int64_t value) {
+  const int i = kge::switch_index(name);
+  if (i < 0) return KGE_ERR_INVALID_ARG;
+  __atomic_store_n(&kge::g_switch[i], value < 0 ? -1LL : (long long)value, __ATOMIC_RELAXED);
+  return KGE_OK;
+}
+int64_t kge_debug_get_switch(const char* name) {
+  const int i = kge::switch_index(name);
+  return i < 0 ? -2 : (int64_t)kge::sw((kge::Switch)i);
+}
 
 double kge_debug_mfma_rate(const void* operands, int iters, float* sink, void* stream) {
   return kge::run_mfma_rate(operands, iters, sink, (hipStream_t)stream);

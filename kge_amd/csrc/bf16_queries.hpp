@@ -64,9 +64,24 @@ __device__ __forceinline__ void v4_q_f32(int dir, unsigned int a0, unsigned int 
   }
 }
 
+// The row-major bf16 query matrix Q16 [rows, 2 HH] of the gradient products (bwd_gemm.hip: dT = G16^T Q16) written by
+// the same pass that builds the fragments -- the same rounded values in another order (rows of the second side behind
+// the n rows of the first) -- and a float buffer cleared on the way (the relation-gradient accumulator of
+// kge_ce_sp_po_bwd_accum): what bwdg_build_q16_kernel did in a launch of its own (round 6: one launch less per step).
+struct Q16Out {
+  unsigned short* q16;   // NULL: none
+  float* zero;           // NULL: none
+  long long zero_cnt;
+};
+
 // items [item0, item0 + stride, ...) of the batch: one item = 8 coordinates of both halves of one query row
-template <int SCORER, int HH, int SPLIT>
-__device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item0, long long stride) {
+template <int SCORER, int HH, int SPLIT, bool WITH_Q16 = false>
+__device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item0, long long stride,
+                                                 const Q16Out* qo = nullptr) {
+  if constexpr (WITH_Q16) {
+    if (qo->zero != nullptr)
+      for (long long k = item0; k < qo->zero_cnt; k += stride) qo->zero[k] = 0.0f;
+  }
   constexpr int NKB = 2 * HH / 16, NKH = HH / 16, CGR = HH / 8;
   constexpr int RGR = SPLIT ? 64 : 128;  // real rows per row group
   const int nb = nx.nbatch > 1 ? nx.nbatch : 1;
@@ -109,6 +124,13 @@ __device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item
     u32x4* dst = nx.qf + (long long)lb * nx.qstride + ((row >> 5) * NKB) * 64 + (row & 31) + 32 * (c8 & 1);
     dst[(c8 >> 1) * 64] = q0;
     dst[(NKH + (c8 >> 1)) * 64] = q1;
+    if constexpr (WITH_Q16) {
+      if (qo->q16 != nullptr && lrow < nx.n) {
+        unsigned short* qr = qo->q16 + ((second ? nx.n : 0) + lrow) * (2 * HH) + c8 * 8;
+        *reinterpret_cast<u32x4*>(qr) = q0;
+        *reinterpret_cast<u32x4*>(qr + HH) = q1;
+      }
+    }
     if constexpr (SPLIT) {
       u32x4* dl = dst + 2 * NKB * 64;  // two 32-row blocks further
       dl[(c8 >> 1) * 64] = l0;
@@ -120,6 +142,12 @@ __device__ __forceinline__ void v4_build_queries(const NextQ& nx, long long item
 template <int SCORER, int HH, int SPLIT>
 __global__ __launch_bounds__(256) void query_build_kernel(NextQ nx) {
   v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256);
+}
+
+// fragments + Q16 + the cleared accumulator in one launch (single batch, plain queries): run_query_build_q16
+template <int SCORER, int HH>
+__global__ __launch_bounds__(256) void query_build_q16_kernel(NextQ nx, Q16Out qo) {
+  v4_build_queries<SCORER, HH, 0, true>(nx, (long long)blockIdx.x * 256 + threadIdx.x, (long long)gridDim.x * 256, &qo);
 }
 
 // kge_eval_batch's first launch and its query build in one: blocks [0, build_blocks) build the fragments, the rest

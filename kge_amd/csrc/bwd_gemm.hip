@@ -324,11 +324,12 @@ int run_debug_gemm16(int which, int lib, int d, long long rows, long long m, con
 template <int SCORER>
 static int bwdg_products16(int dir, const Operand& A, const Operand& R, const Operand& TG, int d, long long n,
                            long long m, const unsigned short* G16, long long mp, unsigned short* Q16,
-                           float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
+                           float* g_a, float* g_p, float* g_tgt, hipStream_t st, bool q16_ready = false) {
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
   const unsigned qblocks = (unsigned)((n * half + 255) / 256);
-  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, Q16, A, R, n,
-                     (float*)nullptr, 0LL);
+  if (!q16_ready)
+    hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), dim3(qblocks), dim3(256), 0, st, A, R, dir, d, n, Q16, A, R, n,
+                       (float*)nullptr, 0LL);
   const unsigned short* T = (const unsigned short*)TG.base;
   long long ldt = TG.ld;
   if (TG.idx.ptr != nullptr) {  // gathered target rows live in g_tgt until dT overwrites it
@@ -356,13 +357,16 @@ static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Opera
                                const Operand& TG, int d, long long n, long long n2, long long m,
                                const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
                                float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
-                               float* dq_scratch, long long dq_scratch_bytes, hipStream_t st) {
+                               float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready) {
   if (TG.idx.ptr != nullptr) return KGE_ERR_UNSUPPORTED;  // all entities only
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
   const long long nrows = n + n2, nmax = n > n2 ? n : n2;
   const dim3 qgrid((unsigned)((nmax * half + 255) / 256), 2);  // y = side
-  hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, Q16, A2, R2, n2,
-                     acc_rel, acc_rel != nullptr ? acc_rel_rows * acc_rel_ld : 0LL);
+  // (q16_ready: Q16 was written and acc_rel cleared by the launch that built the query fragments of the gradient
+  // pass -- run_query_build_q16, ce_loss.hip)
+  if (!q16_ready)
+    hipLaunchKernelGGL((bwdg_build_q16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, Q16, A2, R2, n2,
+                       acc_rel, acc_rel != nullptr ? acc_rel_rows * acc_rel_ld : 0LL);
   const unsigned short* T = (const unsigned short*)TG.base;
   // split-K scratch of dQ: the caller's (sized for as many splits as the product wants: 16 at the FB15k-237 shape),
   // else g_tgt, which dT overwrites afterwards (14 fit).  [Summing the partials inside the chain launch instead of
@@ -382,17 +386,17 @@ int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A
                                  const Operand& R2, const Operand& TG, int d, long long n, long long n2, long long m,
                                  const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
                                  float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
-                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st) {
+                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready) {
   if (n + n2 == 0 || m == 0) return KGE_OK;  // (ce_loss.hip handles empty batches itself: acc_rel is cleared there)
   if (n + n2 >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31))
     return KGE_ERR_UNSUPPORTED;
   int rc = KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
     rc = bwdg_products16_two<KGE_COMPLEX>(A1, A2, R, R2, TG, d, n, n2, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
-                                          acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st);
+                                          acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st, q16_ready);
   else if (scorer == KGE_DISTMULT)
     rc = bwdg_products16_two<KGE_DISTMULT>(A1, A2, R, R2, TG, d, n, n2, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
-                                           acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st);
+                                           acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st, q16_ready);
   return rc;
 }
 
@@ -413,14 +417,14 @@ static int bwdg_run16(int dir, const Operand& A, const Operand& R, const Operand
 // ce_loss.hip: G16 (pitch mp) was written by the scoring kernel; Q16 = n * d * 2 bytes of scratch
 int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
                              long long n, long long m, const unsigned short* G16, long long mp,
-                             unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st) {
+                             unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st, bool q16_ready) {
   if (n == 0 || m == 0) return KGE_OK;
   if (n >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31)) return KGE_ERR_UNSUPPORTED;
   int rc = KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
-    rc = bwdg_products16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+    rc = bwdg_products16<KGE_COMPLEX>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st, q16_ready);
   else if (scorer == KGE_DISTMULT)
-    rc = bwdg_products16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st);
+    rc = bwdg_products16<KGE_DISTMULT>(dir, A, R, TG, d, n, m, G16, mp, Q16, g_a, g_p, g_tgt, st, q16_ready);
   return rc;
 }
 
@@ -445,9 +449,9 @@ int run_pairs_bwd_gemm(int scorer, int dir, const Operand& A, const Operand& R, 
   if (dr != d || !g_a || !g_p || !g_tgt) return KGE_ERR_UNSUPPORTED;
   if (n >= (1LL << 31) || m >= (1LL << 31) || ldg >= (1LL << 31) || TG.ld >= (1LL << 31))
     return KGE_ERR_UNSUPPORTED;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;  // rocBLAS may allocate: not under capture
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
-    return KGE_ERR_UNSUPPORTED;
+  // (Until round 6 this declined under stream capture -- a leftover of the rounds that called a BLAS library, which
+  // may allocate.  Nothing below allocates; with the check a CAPTURED float32 step fell through to the VALU kernels of
+  // bwd.hip and replayed slower than the eager step ran: 1.22 against 0.86 ms, profiles/r5_train_step_kernels.txt.)
   if (scorer == KGE_COMPLEX) return bwdg_run<KGE_COMPLEX>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, st);
   return bwdg_run<KGE_DISTMULT>(dir, A, R, TG, d, n, m, gout, ldg, g_a, g_p, g_tgt, st);
 }

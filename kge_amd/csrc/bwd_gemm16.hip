@@ -379,11 +379,7 @@ static unsigned long long* g16_dbg = nullptr;  // set by kge_debug_gemm16_stamps
 void set_g16_dbg(unsigned long long* p) { g16_dbg = p; }
 
 bool bwd_gemm16_enabled() {
-  static const bool lib = [] {
-    const char* e = getenv("KGE_BWD_GEMM_LIB");
-    return e && e[0] == '1';
-  }();
-  return !lib;
+  return sw(SW_BWD_GEMM_LIB) != 1;
 }
 
 // bytes of split-K scratch with which run_gemm16_dq takes as many splits as it wants (0: it would not split)

@@ -35,14 +35,24 @@ int run_pairs_bf16_v3_ce(int scorer, int epi, const Operand& A, const Operand& R
                          const CeArgs& ce, unsigned long long* dbg);
 int run_pairs_bwd_products16(int scorer, int dir, const Operand& A, const Operand& R, const Operand& TG, int d,
                              long long n, long long m, const unsigned short* G16, long long mp,
-                             unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st);
+                             unsigned short* Q16, float* g_a, float* g_p, float* g_tgt, hipStream_t st,
+                             bool q16_ready = false);
 
 int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A2, const Operand& R,
                                  const Operand& R2, const Operand& TG, int d, long long n, long long n2, long long m,
                                  const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
                                  float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
-                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st);
+                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready = false);
 long long gemm16_dq_scratch_bytes(int d, long long rows, long long m);
+// ce_pairs_v8.hip: the loss passes on the persistent two-consumer-wave structure, from prepared query fragments
+bool pairs_bf16_v8_ce_takes(int d, long long n, long long m);
+int pairs_bf16_v8_ce_column_groups(int d, long long n, long long m, bool two_sided);
+int run_pairs_bf16_v8_ce(int epi, const Operand& TG, int d, long long n, long long m, bool two_sided, const void* qf,
+                         const CeArgs& ce, hipStream_t st);
+int run_query_build(int scorer, bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, int d,
+                    long long n, void* qf, hipStream_t st);
+int run_query_build_q16(int scorer, const Operand& A, const Operand* A2, const Operand& R, int dir, int d, long long n,
+                        void* qf, unsigned short* q16, float* zero, long long zero_cnt, hipStream_t st);
 
 // merge the column groups of a row: M = max_c m_c, L = sum_c l_c exp(m_c - M).  One wave per row,
 // lanes over the column groups, xor-butterfly reductions (fixed order: deterministic).
@@ -358,12 +368,63 @@ int run_pairs_bf16_v4_epi(int scorer, int epi, const Operand& A, const Operand* 
                           const Operand& TG, int dir, int d, long long n, long long m, hipStream_t st, void* ws,
                           long long ws_bytes, const CeArgs& ce, unsigned long long* dbg);
 
-// the G16 pass of a backward (V3_DS / V3_DSIG): the loader/consumer kernel, else the single-role one
+// Which kernel runs a loss pass over n rows per side:
+//   pairs_bf16_v8_ce_kernel (ce_pairs_v8.hip; round 6) -- V3_LSE / V3_DS at d in {256, 512} for more than half a 256-row
+//     chunk of rows: a query-build launch into the workspace's fragment area, then the persistent kernel;
+//   pairs_bf16_v4_kernel -- the other shapes at d in {256, 512} and V3_DSIG; in-launch cooperative build;
+//   pairs_bf16_v3_kernel -- d = 128, V3_SPLUS, and whatever v4 declines.
+// Switches (kge_debug_set_switch): CE_V8 = 0 never the persistent kernel, 1 whenever its geometry allows; CE_V3 = 1
+// forces the single-role kernel (tests, profiling).
+static bool ce_takes_v8(int epi, int d, long long n, long long m, const Operand& TG) {
+  if ((epi != V3_LSE && epi != V3_DS) || TG.idx.ptr != nullptr || TG.ld * 2 >= (1LL << 28) || sw(SW_CE_V3) == 1) return false;
+  const long long e = sw(SW_CE_V8);
+  if (e == 0) return false;
+  if (e == 1) return (d == 256 || d == 512) && n >= 1 && m >= 1;
+  return pairs_bf16_v8_ce_takes(d, n, m);
+}
+
+// column groups of the (max, sum exp) partials of a forward pass over n rows per side
+static int ce_column_groups(int d, long long n, long long m, bool two_sided, const Operand& TG) {
+  if (ce_takes_v8(V3_LSE, d, n, m, TG)) {
+    const int ncg = pairs_bf16_v8_ce_column_groups(d, n, m, two_sided);
+    if (ncg > 0) return ncg;
+  }
+  return pairs_bf16_v3_column_groups(two_sided ? 2 * ((n + 127) / 128) * 128 : n, m);
+}
+// the most column groups any kernel choice writes for this shape (workspace sizes)
+static int ce_column_groups_max(int d, long long n, long long m, bool two_sided) {
+  const int a = pairs_bf16_v3_column_groups(two_sided ? 2 * ((n + 127) / 128) * 128 : n, m);
+  const int b = pairs_bf16_v8_ce_column_groups(d, n, m, two_sided);
+  return a > b ? a : b;
+}
+
+// q16 != NULL (gradient pass): the launch that builds the fragments also writes the products' query matrix Q16 and
+// clears `zero` (the relation-gradient accumulator) -- the products then skip their own build launch (*q16_done)
+static int run_v8_ce_pass(int scorer, int epi, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG,
+                          int dir, int d, long long n, long long m, hipStream_t st, void* ws, long long coop,
+                          const CeArgs& ce, unsigned short* q16 = nullptr, float* zero = nullptr,
+                          long long zero_cnt = 0, bool* q16_done = nullptr) {
+  // the fragment area of the workspace (behind the control block) holds whole 128-row groups of both sides
+  if (ws == nullptr || coop < PAIRS_WS_CTRL_BYTES + (A2 ? 2 : 1) * ((n + 127) / 128) * 128 * (long long)d * 2)
+    return KGE_ERR_UNSUPPORTED;
+  void* const qf = (char*)ws + PAIRS_WS_CTRL_BYTES;
+  int rc = q16 != nullptr ? run_query_build_q16(scorer, A, A2, R, dir, d, n, qf, q16, zero, zero_cnt, st)
+                          : run_query_build(scorer, false, A, A2, R, dir, d, n, qf, st);
+  if (rc != KGE_OK) return rc;
+  if (q16 != nullptr && q16_done != nullptr) *q16_done = true;
+  return run_pairs_bf16_v8_ce(epi, TG, d, n, m, A2 != nullptr, qf, ce, st);
+}
+
+// the G16 pass of a backward (V3_DS / V3_DSIG)
 static int run_ds_pass(int scorer, int epi, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG,
                        int dir, int d, long long n, long long m, hipStream_t st, void* ws, long long coop,
-                       const CeArgs& ce, unsigned long long* dbg) {
-  const char* f = getenv("KGE_CE_V3");
-  if (!(f && f[0] == '1')) {
+                       const CeArgs& ce, unsigned long long* dbg, unsigned short* q16 = nullptr, float* zero = nullptr,
+                       long long zero_cnt = 0, bool* q16_done = nullptr) {
+  if (ce_takes_v8(epi, d, n, m, TG)) {
+    const int rc = run_v8_ce_pass(scorer, epi, A, A2, R, TG, dir, d, n, m, st, ws, coop, ce, q16, zero, zero_cnt, q16_done);
+    if (rc != KGE_ERR_UNSUPPORTED || (q16_done != nullptr && *q16_done)) return rc == KGE_ERR_UNSUPPORTED ? KGE_ERR_LAUNCH : rc;
+  }
+  if (sw(SW_CE_V3) != 1) {
     CeArgs c4 = ce;
     if (A2 != nullptr) c4.rgn1 = 0;  // the v4 launcher takes the second side as an operand, not a marker
     const int rc = run_pairs_bf16_v4_epi(scorer, epi, A, A2, R, TG, dir, d, n, m, st, ws, coop, c4, dbg);
@@ -372,11 +433,17 @@ static int run_ds_pass(int scorer, int epi, const Operand& A, const Operand* A2,
   return run_pairs_bf16_v3_ce(scorer, epi, A, R, TG, dir, d, n, m, st, ws, coop, ce, dbg);
 }
 
+// the V3_LSE pass (row statistics of softmax over all entities + the label's score); ce.part holds
+// ce_column_groups(...) column groups per row
 static int run_lse_pass(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                         int d, long long n, long long m, hipStream_t st, void* ws, long long coop, const CeArgs& ce,
                         unsigned long long* dbg) {
-  const char* f = getenv("KGE_CE_V3");
-  if (!(f && f[0] == '1')) {
+  if (ce_takes_v8(V3_LSE, d, n, m, TG) && pairs_bf16_v8_ce_column_groups(d, n, m, A2 != nullptr) > 0) {
+    const int rc = run_v8_ce_pass(scorer, V3_LSE, A, A2, R, TG, dir, d, n, m, st, ws, coop, ce);
+    if (rc != KGE_ERR_UNSUPPORTED) return rc;
+    return KGE_ERR_LAUNCH;  // (the caller sized ce.part for this kernel's column groups: no other kernel may fill it)
+  }
+  if (sw(SW_CE_V3) != 1) {
     CeArgs c4 = ce;
     if (A2 != nullptr) c4.rgn1 = 0;  // the v4 launcher takes the second side as an operand, not a marker
     const int rc = run_pairs_bf16_v4_lse(scorer, A, A2, R, TG, dir, d, n, m, st, ws, coop, c4, dbg);
@@ -391,7 +458,7 @@ static inline long long ce_ld16(long long m) { return (m + 63) & ~63LL; }
 
 long long ce_workspace_bytes(int d, long long n, long long m) {
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
-  const long long fwd = al256(n * pairs_bf16_v3_column_groups(n, m) * 8) + 2 * al256(n * 4);  // partials, label sums, counts
+  const long long fwd = al256(n * ce_column_groups_max(d, n, m, false) * 8) + 2 * al256(n * 4);  // partials, label sums, counts
   const long long bwd = al256(n * ce_ld16(m) * 2) + al256(n * (long long)d * 2);
   return coop + (fwd > bwd ? fwd : bwd);
 }
@@ -406,7 +473,7 @@ int run_ce_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
-  const int ncg = pairs_bf16_v3_column_groups(n, m);
+  const int ncg = ce_column_groups(d, n, m, false, TG);
   CeArgs ce{};
   ce.label = label;
   ce.part = (float*)((char*)ws + coop);
@@ -434,9 +501,11 @@ int run_ce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   ce.g16 = (unsigned short*)((char*)ws + coop);
   ce.ld16 = ld16;
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(n * ld16 * 2));
-  const int rc = run_ds_pass(scorer, V3_DS, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  bool q16_done = false;
+  const int rc = run_ds_pass(scorer, V3_DS, A, nullptr, R, TG, dir, d, n, m, st, ws, coop, ce, g_ce_stamps, Q16, nullptr, 0,
+                             &q16_done);
   if (rc != KGE_OK) return rc;
-  return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st);
+  return run_pairs_bwd_products16(scorer, dir, A, R, TG, d, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, st, q16_done);
 }
 
 int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir, int d, long long n,
@@ -445,7 +514,7 @@ int run_kl_fwd(int scorer, const Operand& A, const Operand& R, const Operand& TG
   if (n == 0) return KGE_OK;
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
-  const int ncg = pairs_bf16_v3_column_groups(n, m);
+  const int ncg = ce_column_groups(d, n, m, false, TG);
   CeArgs ce{};
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(n * ncg * 8));  // here: the rows' label-score sums
@@ -558,7 +627,7 @@ static inline long long ce2_rows(long long n) { return 2 * ((n + 127) / 128) * 1
 long long ce2_workspace_bytes(int d, long long n, long long m) {
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));  // sized for two sides
   // forward: column-group partials, label scores, the combine launch's per-workgroup sums (kge_ce_sp_po_fwd_sum)
-  const long long fwd = al256(2 * n * pairs_bf16_v3_column_groups(ce2_rows(n), m) * 8) + al256(2 * n * 4) +
+  const long long fwd = al256(2 * n * ce_column_groups_max(d, n, m, true) * 8) + al256(2 * n * 4) +
                         al256((2 * n + 3) / 4 * 4);
   // backward: G16, Q16 and (kge_ce_sp_po_bwd_accum) the f32 dQ rows + the split-K partials of that product
   const long long bwd = al256(2 * n * ce_ld16(m) * 2) + al256(2 * n * (long long)d * 2) +
@@ -577,7 +646,7 @@ int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   }
   if (ws == nullptr || ((uintptr_t)ws & 255) || ws_bytes < ce2_workspace_bytes(d, n, m)) return KGE_ERR_WORKSPACE;
   const long long coop = al256(pairs_bf16_v3_workspace_bytes(d, n));
-  const int ncg = pairs_bf16_v3_column_groups(ce2_rows(n), m);
+  const int ncg = ce_column_groups(d, n, m, true, TG);
   CeArgs ce{};
   ce.label = O.idx;   // side 1: true objects
   ce.label2 = S.idx;  // side 2: true subjects
@@ -636,10 +705,12 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   ce.g16 = (unsigned short*)((char*)ws + coop);
   ce.ld16 = ld16;
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(2 * n * ld16 * 2));
-  const int rc = run_ds_pass(scorer, V3_DS, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  bool q16_done = false;
+  const int rc = run_ds_pass(scorer, V3_DS, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps, Q16, acc_rel,
+                             acc_rel != nullptr ? acc_rel_rows * acc_rel_ld : 0LL, &q16_done);
   if (rc != KGE_OK) return rc;
   return run_pairs_bwd_products16_two(scorer, S, O, R, R, TG, d, n, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, acc_rel,
-                                      acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st);
+                                      acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st, q16_done);
 }
 
 // ---- both query types of a KvsAll batch, backward (kge_kl2_bwd_accum / kge_bce2_bwd_accum) ------------------------

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "../../include/kge_amd.h"
+#include "switches.hpp"
 
 namespace kge {
 

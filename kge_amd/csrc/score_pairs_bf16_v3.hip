@@ -748,8 +748,7 @@ static int launch_v3(const Operand& A, const Operand& R, const Operand& TG, int 
     while (nbuild > 1 && nbuild * 256 > items) --nbuild;
     // KGE_V4_OWN_BUILD=1 (tests): nobody builds for anybody -- every wave takes the path it otherwise only takes
     // after a time-out or on a degraded workspace
-    const char* own = getenv("KGE_V4_OWN_BUILD");
-    if (own && own[0] == '1') nbuild = 0;
+    if (sw(SW_V4_OWN_BUILD) == 1) nbuild = 0;
   }
 #define KGE_V3L(MODE)                                                                                 \
   if (coop)                                                                                           \

@@ -1045,8 +1045,7 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
       while (nbuild > 1 && nbuild * 512 > items) --nbuild;
       // KGE_V4_OWN_BUILD=1 (tests): no cooperative build, every consumer wave builds its own fragments --
       // the path a consumer otherwise only takes after a time-out or on a degraded workspace
-      const char* own = getenv("KGE_V4_OWN_BUILD");
-      if (own && own[0] == '1') nbuild = 0;
+      if (sw(SW_V4_OWN_BUILD) == 1) nbuild = 0;
     }
   }
   // d = 512, prepared queries, score store, all entities (or a contiguous slice): the unit-pipelined kernel
@@ -1082,11 +1081,11 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   }
   const Operand& AA2 = A2 ? *A2 : A;
   // interleaved tiles (tiles_per_cg = 0) once a launch's score block outgrows the Infinity Cache
-  const char* il = getenv("KGE_V4_INTERLEAVE");
+  const long long il = sw(SW_V4_INTERLEAVE);
   // AND the output pitch is sector-aligned (padded pitch: 433 -> 417 us on a 574,311-column shard; with an
   // unpadded pitch the partial sectors at tile edges then come from two XCDs' L2s: 9.9 -> 10.5 ms, so no)
   const bool interleave =
-      il ? il[0] == '1' : ((double)n * (double)m * 4.0 * (A2 ? 2 : 1) > 192e6 && (ldo & 7) == 0);
+      il >= 0 ? il == 1 : ((double)n * (double)m * 4.0 * (A2 ? 2 : 1) > 192e6 && (ldo & 7) == 0);
   const int tpc_arg = interleave ? 0 : tpc;
   // Score stores: plain (the lines stay dirty in the 32 MB of L2 until they are evicted or the end-of-kernel
   // write-back flushes them: ~3 us behind a launch whose 30 MB score block fits) or agent-scope write-through (sc1:
@@ -1095,10 +1094,10 @@ static int launch_v4(const Operand& A, const Operand* A2, const Operand& R, cons
   // round 3): write-through wins whenever the rows are sector-aligned (FB15k-237 shape one-sided 13.9 -> 12.8 us,
   // a 574,311-column Wikidata5M shard 394 -> 353 us) and for blocks that fit the L2 even when they are not (14.5 ->
   // 14.0 us); it loses 7 % on a 1.2 GB slab with an unaligned pitch.  KGE_V4_STORE_SC1=0/1 forces either.
-  const char* sc1e = getenv("KGE_V4_STORE_SC1");
+  const long long sc1e = sw(SW_V4_STORE_SC1);
   const bool st_aligned = (ldo & 7) == 0 && (out2_off & 7) == 0 && ((uintptr_t)out & 31) == 0;
   const bool st_small = (double)n * (double)m * 4.0 * (A2 ? 2 : 1) <= 48e6;
-  const int st_sc1 = sc1e ? (sc1e[0] - '0') : ((st_aligned || st_small) ? 1 : 0);
+  const int st_sc1 = sc1e >= 0 ? (int)sc1e : ((st_aligned || st_small) ? 1 : 0);
 #define KGE_V4L(MODE)                                                                                  \
   hipLaunchKernelGGL((pairs_bf16_v4_kernel<SCORER, HH, MODE, EPI, SPLIT>), dim3(grid), dim3(512), 0, st, A, \
                      AA2, R, TG, dir, n, m, rgn, rgn1, out2_off, ncg, tpc_arg, ntiles, out, ldo, dbg, qf, flags, \
@@ -1156,6 +1155,29 @@ int run_query_build(int scorer, bool split, const Operand& A, const Operand* A2,
   if (scorer == KGE_COMPLEX) { KGE_QB2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_QB2(KGE_DISTMULT) }
 #undef KGE_QB2
 #undef KGE_QB
+  return KGE_ERR_UNSUPPORTED;
+}
+
+// run_query_build + the row-major query matrix Q16 [rows of side 1, rows of side 2][d] of the gradient products + a
+// cleared float buffer, in ONE launch (the backward of the fused losses: ce_loss.hip).  d in {256, 512}.
+int run_query_build_q16(int scorer, const Operand& A, const Operand* A2, const Operand& R, int dir, int d, long long n,
+                        void* qf, unsigned short* q16, float* zero, long long zero_cnt, hipStream_t st) {
+  if (n == 0) return KGE_OK;
+  if (!v4_al16(qf) || !v4_al16(q16)) return KGE_ERR_INVALID_ARG;
+  Q16Out qo{q16, zero, zero_cnt};
+#define KGE_QB16(SC, HHV)                                                                                  \
+  {                                                                                                        \
+    const NextQ q = v4_nextq<SC, HHV, 0>(A, A2, R, dir, n, qf);                                            \
+    long long blocks = ((long long)q.rgn * V4_ROWS * (HHV / 8) + 255) / 256;                               \
+    if (blocks > 1024) blocks = 1024;                                                                      \
+    hipLaunchKernelGGL((query_build_q16_kernel<SC, HHV>), dim3((unsigned)blocks), dim3(256), 0, st, q, qo); \
+    return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;                                      \
+  }
+#define KGE_QB16B(SC) \
+  if (d == 256) KGE_QB16(SC, 128) else if (d == 512) KGE_QB16(SC, 256)
+  if (scorer == KGE_COMPLEX) { KGE_QB16B(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_QB16B(KGE_DISTMULT) }
+#undef KGE_QB16B
+#undef KGE_QB16
   return KGE_ERR_UNSUPPORTED;
 }
 

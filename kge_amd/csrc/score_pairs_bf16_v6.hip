@@ -702,29 +702,27 @@ static int launch_v6(const Operand& TG, bool two_sided, long long n, long long m
       nx.nblocks = rgn * ncg;
     }
   }
-  const char* il = getenv("KGE_V4_INTERLEAVE");
+  const long long il = sw(SW_V4_INTERLEAVE);
   const bool interleave =
-      il ? il[0] == '1' : ((double)n * (double)m * 4.0 * (two_sided ? 2 : 1) > 192e6 && (ldo & 7) == 0);
-  const char* sc1e = getenv("KGE_V4_STORE_SC1");
+      il >= 0 ? il == 1 : ((double)n * (double)m * 4.0 * (two_sided ? 2 : 1) > 192e6 && (ldo & 7) == 0);
+  const long long sc1e = sw(SW_V4_STORE_SC1);
   const bool st_aligned = (ldo & 7) == 0 && (out2_off & 7) == 0 && ((uintptr_t)out & 31) == 0;
   const bool st_small = (double)n * (double)m * 4.0 * (two_sided ? 2 : 1) <= 48e6;
   // write-through only for sector-aligned rows: this kernel's 128-byte row segments straddle a sector at each end
   // otherwise, and a partial sector written through is a read-modify-write at the memory (FB15k-237 shape, contiguous
   // pitch, two-sided: 27.2 us written through, 21.1 us through the L2's write-back; aligned: 20.3 / 20.6)
-  const int st_sc1 = sc1e ? (sc1e[0] != '0') : (st_aligned ? 1 : 0);
+  const int st_sc1 = sc1e >= 0 ? (sc1e != 0) : (st_aligned ? 1 : 0);
   (void)st_small;
   if constexpr (!SPLIT) {
     // one rounded query vector per row: scores stored straight from the accumulators (pairs_bf16_v7_kernel);
     // KGE_V7=0: the staged kernel (A/B measurements)
     // (one-sided launches into rows that are not sector-aligned stay with the staged kernel: 12.4 against 13.3 us at
     // the FB15k-237 shape -- dword stores of unaligned 128-byte segments; KGE_V7=1 takes v7 there too)
-    const char* e7 = getenv("KGE_V7");
-    const char* ens = getenv("KGE_V7_NOSTORE");
-    const int probe = (ens && ens[0] == '1') ? 1 : 0;
-    if (!(e7 && e7[0] == '0') && (st_aligned || two_sided || (e7 && e7[0] == '1'))) {
+    const long long e7 = sw(SW_V7);
+    const int probe = sw(SW_V7_NOSTORE) == 1 ? 1 : 0;
+    if (e7 != 0 && (st_aligned || two_sided || e7 == 1)) {
 #ifdef KGE_V7_PROBES  // make CXXEXTRA=-DKGE_V7_PROBES: compile-time timing variants (tools/r4_diag2.py); wrong scores
-      const char* epr = getenv("KGE_V7_PROBE");
-      const int prb = epr ? atoi(epr) : 0;
+      const int prb = sw(SW_V7_PROBE) > 0 ? (int)sw(SW_V7_PROBE) : 0;
 #define KGE_V7P(PB)                                                                                               \
   if (prb == PB) {                                                                                               \
     hipLaunchKernelGGL((pairs_bf16_v7_kernel<SCORER, 0, PB>), dim3(grid), dim3(512), 0, st, TG, n, m, rgn, rgn1,  \
@@ -755,8 +753,7 @@ int run_pairs_bf16_v6(int scorer, bool split, const Operand& TG, bool two_sided,
                       float* out, long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg,
                       const void* qf, const NextQ& nx, int reserve_cus) {
   if (d != 512 || TG.idx.ptr != nullptr || qf == nullptr) return KGE_ERR_UNSUPPORTED;
-  const char* e = getenv("KGE_V6");
-  if (e && e[0] == '0') return KGE_ERR_UNSUPPORTED;
+  if (sw(SW_V6) == 0) return KGE_ERR_UNSUPPORTED;
   if (TG.ld * 2 >= (1LL << 28)) return KGE_ERR_UNSUPPORTED;
 #define KGE_V6L(SC)                                                                                            \
   return split ? launch_v6<SC, 1>(TG, two_sided, n, m, out, ldo, out2_off, st, dbg, qf, nx, reserve_cus)       \

@@ -404,8 +404,7 @@ static int launch_v8(V8Args& a, int sc1, hipStream_t st) {
   // its store INSTRUCTIONS compiled out (profiles/r5_split_store_probe.txt: 222 -> 194 us per group of eight two-sided
   // batches -- the stores cost 13 %, the rest of the distance to the bare matrix pipe is not theirs)
   if constexpr (SCORER == KGE_COMPLEX && SPLIT == 1) {
-    const char* ve = getenv("KGE_V8_VAR");
-    if (ve && ve[0] == '1') {
+    if (sw(SW_V8_VAR) == 1) {
       hipLaunchKernelGGL((pairs_bf16_v8_kernel<SCORER, SPLIT, 2, 1>), grid, block, 0, st, a);
       return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
     }
@@ -434,9 +433,9 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
   // A single batch stays with pairs_bf16_v7 / v6 (a workgroup of this kernel loads the fragments of 256 rows before
   // its first chain -- 9-12 k cycles against 5 k there -- and a single batch's list gives it 7 units to amortise them
   // over: FB15k-237 shape two-sided 22.0 us against 19.2, profiles/r4_v8_probe.txt); KGE_V8=1 takes it here too.
-  const char* e = getenv("KGE_V8");
-  if (e && e[0] == '0') return KGE_ERR_UNSUPPORTED;
-  if (nbatch == 1 && !(e && e[0] == '1')) return KGE_ERR_UNSUPPORTED;
+  const long long e = sw(SW_V8);
+  if (e == 0) return KGE_ERR_UNSUPPORTED;
+  if (nbatch == 1 && e != 1) return KGE_ERR_UNSUPPORTED;
   if (TG.ld * 2 >= (1LL << 28) || ldo >= (1LL << 24)) return KGE_ERR_UNSUPPORTED;
   if ((q_stride_bytes & 15) || ((uintptr_t)qf & 15)) return KGE_ERR_INVALID_ARG;
   const long long rgr = split ? 64 : 128;  // real rows per fragment group
@@ -468,7 +467,7 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
   a.nx = nx;
   // write-through (sc1) stores only for sector-aligned rows and score blocks that fit the Infinity Cache comfortably:
   // tools/r4_diag.py -- a rotation of buffers beyond it runs faster through the L2's write-back
-  const char* sc1e = getenv("KGE_V4_STORE_SC1");
+  const long long sc1e = sw(SW_V4_STORE_SC1);
   const bool st_aligned = (ldo & 7) == 0 && (out2_off & 7) == 0 && (out_stride & 7) == 0 && ((uintptr_t)out & 31) == 0;
   const double bytes = (double)nbatch * (double)n * (double)m * 4.0 * (two_sided ? 2 : 1);
   // (tools/v8_policy_probe.py, profiles/r4_v8_policy.txt: a group's blocks beyond ~160 MB stream to HBM -- `nt` keeps
@@ -479,7 +478,7 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
   // store completes it one chain later -- in the L2, if the line is still there: plain write-back stores.  `nt` and
   // write-through push the partial sector out and the memory side reads, merges and writes it (n = 2048 two-sided,
   // 238 MB: 226 us with nt against 112 for the single-batch kernel's plain stores, tools/one_call_v8_probe.py).
-  const int sc1 = sc1e ? (sc1e[0] - '0') : (!st_aligned ? 0 : (bytes > 160e6 ? 2 : (bytes <= 48e6 ? 1 : 0)));
+  const int sc1 = sc1e >= 0 ? (int)sc1e : (!st_aligned ? 0 : (bytes > 160e6 ? 2 : (bytes <= 48e6 ? 1 : 0)));
 #define KGE_V8L(SC) return split ? launch_v8<SC, 1>(a, sc1, st) : launch_v8<SC, 0>(a, sc1, st)
   if (scorer == KGE_COMPLEX) { KGE_V8L(KGE_COMPLEX); }
   if (scorer == KGE_DISTMULT) { KGE_V8L(KGE_DISTMULT); }
@@ -989,8 +988,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
 int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, long long n, long long m, const void* qf,
                            const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus) {
   if ((d != 512 && d != 256) || TG.idx.ptr != nullptr || qf == nullptr) return KGE_ERR_UNSUPPORTED;
-  const char* e = getenv("KGE_V8_RANK");
-  if (e && e[0] == '0') return KGE_ERR_UNSUPPORTED;
+  if (sw(SW_V8_RANK) == 0) return KGE_ERR_UNSUPPORTED;
   if (TG.ld * 2 >= (1LL << 28) || ((uintptr_t)qf & 15)) return KGE_ERR_UNSUPPORTED;
   const long long rgr = split ? 64 : 128;
   const long long rgn1 = (n + rgr - 1) / rgr;
@@ -1016,8 +1014,8 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   a.ce = ce;
   const dim3 grid(8 * a.wpx), block(512);
 #ifdef KGE_V8_PROBES
-  if (const char* pe = getenv("KGE_V8R_PROBE")) {
-    const int pr = atoi(pe);
+  if (sw(SW_V8R_PROBE) > 0) {
+    const int pr = (int)sw(SW_V8R_PROBE);
     if (pr > 0 && scorer == KGE_COMPLEX && !split && d == 256) {
 #define KGE_V8RP(PR)                                                                                          \
   if (pr == PR) {                                                                                             \

@@ -35,11 +35,33 @@ def test_debug_exports_are_exactly_the_declared_ones(lib):
     import subprocess
     from kge_amd import _lib
     dbg = open(os.path.join(ROOT, "include", "kge_amd_debug.h")).read()
-    declared_dbg = set(re.findall(r"^(?:int|void|double)\s+(kge_debug_\w+)\s*\(", dbg, flags=re.M))
+    declared_dbg = set(re.findall(r"^(?:int|int64_t|void|double)\s+(kge_debug_\w+)\s*\(", dbg, flags=re.M))
     out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith("kge_")}
     assert exported == set(_lib.PROTOTYPES) | declared_dbg, exported ^ (set(_lib.PROTOTYPES) | declared_dbg)
     assert declared_dbg and all(n.startswith("kge_debug_") for n in declared_dbg)
+
+
+def test_kernel_selection_reads_no_environment_variable(lib):
+    """The library's measurement switches are process-local state behind kge_debug_set_switch (round 6; until then ~25
+    getenv() calls read on every launch): every name of kge_amd/csrc/switches.hpp is settable, unset by default, an
+    unknown name is refused -- and the only getenv left in the sources is KGE_ROCTX (the roctx ranges)."""
+    import glob
+    from kge_amd import _lib
+    names = re.findall(r"^\s+SW_(\w+?)(?: = 0)?,", open(os.path.join(ROOT, "kge_amd", "csrc", "switches.hpp")).read(), flags=re.M)
+    assert len(names) >= 19 and "V8" in names and "CE_V8" in names
+    for nm in names:
+        assert _lib.get_switch(nm) is None, nm
+        with _lib.switches(**{nm: 1}):
+            assert _lib.get_switch(nm) == 1 and _lib.get_switch("KGE_" + nm) == 1
+        assert _lib.get_switch(nm) is None
+    assert lib.kge_debug_set_switch(b"NO_SUCH_SWITCH", 1) == -1
+    envs = []
+    for f in glob.glob(os.path.join(ROOT, "kge_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "kge_amd", "csrc", "*.cpp")):
+        for line in open(f):
+            code = line.split("//")[0]
+            envs += re.findall(r'getenv\("(\w+)"\)', code)
+    assert sorted(set(envs)) == ["KGE_ROCTX"], envs
 
 
 def test_struct_layout_matches_header():

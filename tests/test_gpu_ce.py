@@ -163,7 +163,7 @@ def test_ce_bwd(eng, model, d, E, R, n, scale):
 
 
 @pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:5] + CASES[6:8])
-def test_fused_loss_on_both_kernel_generations(eng, monkeypatch, model, d, E, R, n, scale):
+def test_fused_loss_on_both_kernel_generations(eng, monkeypatch, model, d, E, R, n, scale, kge_switch):
     """The forward (V3_LSE) and the gradient pass (V3_DS / V3_DSIG) run on the loader/consumer kernel for
     d in {256, 512} and on the single-role kernel otherwise; KGE_CE_V3=1 forces the latter.  Same tiles, same
     chains, same per-lane order: the two must agree to float32 rounding of the merged row statistics, one-
@@ -182,14 +182,77 @@ def test_fused_loss_on_both_kernel_generations(eng, monkeypatch, model, d, E, R,
         bg = eng.bce_bwd(T, "po", to, tp, rowptr, ts, -0.25, g_scalar=1.0 / n)
         return [loss, lse, *grads, l2, z2, *g2, bl, *bg]
 
-    monkeypatch.setenv("KGE_CE_V3", "0")
+    kge_switch.set("CE_V3", "0")
     new = run()
-    monkeypatch.setenv("KGE_CE_V3", "1")
+    kge_switch.set("CE_V3", "1")
     old = run()
+    # (round 6: for more than 128 rows at d in {256, 512} the default is pairs_bf16_v8_ce_kernel, whose exponentials are
+    # taken in the log2 domain -- values that were rounded to bf16 (the gradients' G16) then differ in a few elements per
+    # row by one bf16 step: 2e-4 of the largest entry; see test_persistent_loss_kernel_equals_the_loader_consumer_kernel)
+    v8 = n > 128 and d in (256, 512)
     for k, (a_, b_) in enumerate(zip(new, old)):
         assert a_.shape == b_.shape and not torch.isnan(a_).any(), k
         den = float(b_.abs().max()) + 1e-30
-        assert float((a_ - b_).abs().max()) <= 2e-6 * den + 1e-7, (k, float((a_ - b_).abs().max()), den)
+        grad = a_.dim() == 2
+        tol = (2e-4 * den if grad else 3e-6 * den + 2e-6) if v8 else 2e-6 * den + 1e-7
+        assert float((a_ - b_).abs().max()) <= tol, (k, float((a_ - b_).abs().max()), den)
+
+
+V8_CASES = [
+    ("complex", 512, 14541, 237, 512, 0.1),   # BASELINE configs[1] shape: 4 (side, chunk) pairs x 64 column groups
+    ("complex", 512, 1037, 13, 203, 0.3),     # a table of 33 units: most workgroups' ranges are empty
+    ("distmult", 256, 1037, 13, 203, 0.5),    # d = 256: two sub-units per unit, ragged second sub-unit
+    ("complex", 256, 20000, 50, 700, 0.2),    # three chunks per side
+    ("distmult", 512, 14 * 64 + 1, 5, 130, 0.3),
+    ("complex", 512, 100, 3, 40, 0.5),        # (forced) four units, 40 of a chunk's 256 rows
+    ("complex", 256, 33, 3, 300, 0.5),        # (forced) ONE ragged unit, two chunks
+    ("distmult", 512, 4097, 7, 1100, 0.2),    # more pairs than workgroups per XCD would be n > 4096: here 10 pairs
+]
+
+
+@pytest.mark.parametrize("model,d,E,R,n,scale", V8_CASES)
+def test_persistent_loss_kernel_equals_the_loader_consumer_kernel(eng, model, d, E, R, n, scale, kge_switch):
+    """Round 6: the forward (V3_LSE) and gradient (V3_DS) passes of the fused 1vsAll / KvsAll losses on
+    pairs_bf16_v8_ce_kernel (ce_pairs_v8.hip: prepared query fragments, persistent grid, two consumer waves per SIMD,
+    online softmax in the log2 domain) against pairs_bf16_v4_kernel's (switch CE_V8 = 0): the same score bits inside
+    both; the row statistics differ by float32 rounding of exp2 / the merge order of the column groups (<= 3e-6
+    relative), d loss / d score by that before its rounding to bf16 -- a few elements per row land on the other side
+    of a bf16 rounding boundary (2^-8 of ONE element of a sum over all entities): gradients to 2e-4 of their largest
+    entry.  One- and two-sided, index labels at the table's first and last column, multi-label (KvsAll) rows."""
+    ent, rel, s, p, o = _case(11 * d + n + E, model, d, E, R, n, scale)
+    o[0], o[-1], s[0], s[-1] = 0, E - 1, E - 1, 0  # labels at both ends of the table
+    T = _tables(eng, model, ent, rel)
+    ts, tp, to = _t(s), _t(p), _t(o)
+    rng = np.random.default_rng(n)
+    cnt = rng.integers(0, 4, n)
+    cnt[0] = 0  # a row without labels
+    rowptr = torch.from_numpy(np.concatenate([[0], np.cumsum(cnt)])).to(DEV)
+    col = torch.from_numpy(np.concatenate([np.sort(rng.choice(E, c, replace=False)) for c in cnt] + [np.zeros(0, int)])
+                           .astype(np.int64)).to(DEV)
+
+    def run():
+        loss, lse = eng.ce_fwd(T, "sp", ts, tp, to)
+        grads = eng.ce_bwd(T, "sp", ts, tp, to, lse, g_scalar=1.0 / n)
+        lp, zp = eng.ce_fwd(T, "po", to, tp, ts)
+        l2, z2 = eng.ce_sp_po_fwd(T, ts, tp, to)
+        g2 = eng.ce_sp_po_bwd(T, ts, tp, to, z2, g_rows=torch.linspace(0.5, 1.5, 2 * n, device=DEV) / n)
+        kl, kz = eng.kl_fwd(T, "sp", ts, tp, rowptr, col)
+        kg = eng.kl_bwd(T, "sp", ts, tp, rowptr, col, kz, g_scalar=1.0 / n)
+        return [loss, lse, lp, zp, l2, z2, kl, kz], [*grads, *g2, *kg]
+
+    kge_switch.set("CE_V8", 1)
+    new_f, new_g = run()
+    kge_switch.set("CE_V8", 0)
+    old_f, old_g = run()
+    for k, (a_, b_) in enumerate(zip(new_f, old_f)):
+        assert a_.shape == b_.shape and torch.isfinite(a_).all(), k
+        err = (a_.double() - b_.double()).abs()
+        assert bool((err <= 3e-6 * b_.double().abs() + 2e-6).all()), (k, float(err.max()))
+    for k, (a_, b_) in enumerate(zip(new_g, old_g)):
+        assert a_.shape == b_.shape and torch.isfinite(a_).all(), k
+        den = float(b_.abs().max()) + 1e-30
+        assert float((a_ - b_).abs().max()) <= 2e-4 * den, (k, float((a_ - b_).abs().max()), den)
+    assert torch.equal(new_f[1][:n], new_f[5][:n]) or float((new_f[1] - new_f[5][:n]).abs().max()) <= 3e-6 * float(new_f[1].abs().max()) + 2e-6
 
 
 def test_ce_unsupported_tables_fail_loudly(eng):

@@ -673,7 +673,7 @@ def test_bf16_random_shapes_against_the_single_role_kernel(eng):
 
 
 @pytest.mark.parametrize("d,n,E", [(512, 512, 14541), (256, 130, 700), (128, 300, 5000)])
-def test_bf16_own_build_fallback_is_bit_identical(eng, monkeypatch, d, n, E):
+def test_bf16_own_build_fallback_is_bit_identical(eng, monkeypatch, d, n, E, kge_switch):
     """A consumer workgroup of the loader/consumer kernel (d = 128: a wave of the single-role kernel, which used to
     trap here) whose builders do not show up within a bounded wait (their CUs busy with another kernel) builds
     its own query fragments and marks the workspace degraded; KGE_V4_OWN_BUILD=1 forces that path.  The scores
@@ -692,9 +692,9 @@ def test_bf16_own_build_fallback_is_bit_identical(eng, monkeypatch, d, n, E):
             return [_np(eng.score_sp(T, s, p)), _np(eng.score_po(T, p, o)), _np(eng.score_sp_po(T, s, p, o))]
         coop = calls()
         for rep in range(2):
-            monkeypatch.setenv("KGE_V4_OWN_BUILD", "1")
+            kge_switch.set("V4_OWN_BUILD", "1")
             own = calls()
-            monkeypatch.setenv("KGE_V4_OWN_BUILD", "0")
+            kge_switch.set("V4_OWN_BUILD", "0")
             again = calls()
             for k, (a, b, c) in enumerate(zip(coop, own, again)):
                 _eq(f"{model} own build, call {k}, rep {rep}", b, a)
@@ -768,7 +768,7 @@ def test_degraded_workspace_recovers(eng):
     assert seen == [2, 1, 0, 0, 0], seen
 
 
-def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch):
+def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch, kge_switch):
     """score_pairs_bf16_v5.hip (every workgroup builds the query vectors of its own 64 rows: no workspace,
     no hand-off, any n) takes the calls the cooperative kernel declines.  Forced in front of it
     (KGE_V5=1) it must give the same bits -- all / listed targets, one- and two-sided, dense rows, d = 256
@@ -786,15 +786,15 @@ def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch):
         s, p, o = (_t(rng.integers(0, hi, n)) for hi in (E, R, E))
         sub = None if it % 3 else _t(rng.integers(0, E, int(rng.integers(1, E + 1))))
         want = (_np(eng.score_sp(T, s, p, sub)), _np(eng.score_po(T, p, o, sub)), _np(eng.score_sp_po(T, s, p, o, sub)))
-        monkeypatch.setenv("KGE_V5", "1")
+        kge_switch.set("V5", "1")
         got = (_np(eng.score_sp(T, s, p, sub)), _np(eng.score_po(T, p, o, sub)), _np(eng.score_sp_po(T, s, p, o, sub)))
         dense = _np(eng.score_emb(model, T.ent[s.long()], T.rel[p.long()], T.ent if sub is None else T.ent[sub.long()], "sp_"))
-        monkeypatch.setenv("KGE_V5", "0")
+        kge_switch.set("V5", "0")
         tag = f"it={it} {model} d={d} n={n} E={E} sub={None if sub is None else int(sub.numel())}"
         for k, (a, b) in enumerate(zip(got, want)):
             _eq(f"local build, call {k}, {tag}", a, b)
         _eq(f"local build, dense rows, {tag}", dense, want[0])
-    monkeypatch.delenv("KGE_V5")
+    kge_switch.unset("V5")
     # the calls it takes on its own
     E, d, n = 3000, 512, 4500
     ent = rng.standard_normal((E, d)).astype(np.float32)

@@ -140,7 +140,7 @@ def test_batches_in_flight_on_several_streams(eng, combine, lanes):
 
 
 @pytest.mark.parametrize("E,n", [(2111, 1), (2111, 63), (4099, 300), (14541, 512), (14541, 640)])
-def test_direct_store_kernel_equals_the_staged_kernel(eng, E, n, monkeypatch):
+def test_direct_store_kernel_equals_the_staged_kernel(eng, E, n, monkeypatch, kge_switch):
     """pairs_bf16_v7_kernel (scores stored straight from the accumulators, KGE_V7=1 forces it for every layout)
     against pairs_bf16_v6_kernel (staged stores, KGE_V7=0): the same bits, one- and two-sided, contiguous and
     256-byte-pitched rows -- and nothing written outside the [n, m] blocks: the padded query rows (>= n) are dropped
@@ -154,7 +154,7 @@ def test_direct_store_kernel_equals_the_staged_kernel(eng, E, n, monkeypatch):
         for pitched in (False, True):
             got = {}
             for v7 in ("0", "1"):
-                monkeypatch.setenv("KGE_V7", v7)
+                kge_switch.set("V7", v7)
                 guard = 36
                 ld = sides * P if pitched else sides * E + 13
                 big = torch.full((n + 2 * guard, ld), float("nan"), device=DEV)
@@ -169,7 +169,7 @@ def test_direct_store_kernel_equals_the_staged_kernel(eng, E, n, monkeypatch):
                 written = ~torch.isnan(big)
                 assert int(written.sum()) == n * sides * E, (combine, pitched, v7, int(written.sum()))
             _same(got["1"], got["0"], f"{combine} pitched={pitched} E={E} n={n}")
-    monkeypatch.delenv("KGE_V7")
+    kge_switch.unset("V7")
 
 
 def test_empty_and_mismatched_arguments(eng):
@@ -275,13 +275,13 @@ def _group_scores_one_by_one(eng, T, combine, trip, n, L, flags=None):
     ("complex", "sp_po", 1, 4, 777),       # single rows
     ("complex", "sp_po", 640, 1, 14541),   # a group of one = kge_score_queries
 ])
-def test_group_launch_equals_one_launch_per_batch(eng, scorer, combine, n, L, E, monkeypatch):
+def test_group_launch_equals_one_launch_per_batch(eng, scorer, combine, n, L, E, monkeypatch, kge_switch):
     R, d = 11, 512
     T, _, _ = _tables(eng, scorer, E, R, d, 60 + n)
     trip = torch.stack(_batch(E, R, n * L, 61 + L), dim=1).contiguous()
-    monkeypatch.setenv("KGE_V8", "0")      # the reference: one launch per batch on the round-3 kernels
+    kge_switch.set("V8", "0")      # the reference: one launch per batch on the round-3 kernels
     want = _group_scores_one_by_one(eng, T, combine, trip, n, L)
-    monkeypatch.delenv("KGE_V8")
+    kge_switch.unset("V8")
     sides = 2 if combine == "sp_po" else 1
     P = eng.score_pitch(E)
     guard = 3
@@ -301,14 +301,14 @@ def test_group_launch_equals_one_launch_per_batch(eng, scorer, combine, n, L, E,
 
 
 @pytest.mark.parametrize("n,L", [(512, 4), (200, 3), (64, 2)])
-def test_group_launch_with_split_queries(eng, n, L, monkeypatch):
+def test_group_launch_with_split_queries(eng, n, L, monkeypatch, kge_switch):
     E, R, d = 14541, 7, 512
     fl = eng.FLAG_SPLIT_QUERY
     T, _, _ = _tables(eng, "complex", E, R, d, 70 + n, flags=fl)
     trip = torch.stack(_batch(E, R, n * L, 71), dim=1).contiguous()
-    monkeypatch.setenv("KGE_V8", "0")      # pairs_bf16_v6_kernel<SPLIT>: the staged kernel, one launch per batch
+    kge_switch.set("V8", "0")      # pairs_bf16_v6_kernel<SPLIT>: the staged kernel, one launch per batch
     want = _group_scores_one_by_one(eng, T, "sp_po", trip, n, L, flags=fl)
-    monkeypatch.delenv("KGE_V8")
+    kge_switch.unset("V8")
     P = eng.score_pitch(E)
     big = torch.full((L, n, 2 * P), float("nan"), device=DEV)
     out = big.view(L, n, 2, P)[:, :, :, :E]
@@ -358,7 +358,7 @@ def test_group_arguments_are_checked(eng):
 
 
 @pytest.mark.parametrize("E,n,split", [(2111, 1, 0), (2111, 63, 0), (4099, 300, 1), (14541, 512, 0), (14541, 640, 1), (130, 700, 0)])
-def test_persistent_kernel_on_single_batches(eng, E, n, split, monkeypatch):
+def test_persistent_kernel_on_single_batches(eng, E, n, split, monkeypatch, kge_switch):
     """KGE_V8=1: a single batch through pairs_bf16_v8_kernel (its default is groups of two or more) = the round-3
     kernels bit for bit, one- and two-sided, contiguous and pitched rows, nothing written outside the blocks."""
     R, d = 7, 512
@@ -371,7 +371,7 @@ def test_persistent_kernel_on_single_batches(eng, E, n, split, monkeypatch):
         for pitched in (False, True):
             got = {}
             for v8 in ("0", "1"):
-                monkeypatch.setenv("KGE_V8", v8)
+                kge_switch.set("V8", v8)
                 guard = 5
                 ld = sides * P if pitched else sides * E + 13
                 big = torch.full((n + 2 * guard, ld), float("nan"), device=DEV)
@@ -382,7 +382,7 @@ def test_persistent_kernel_on_single_batches(eng, E, n, split, monkeypatch):
                 got[v8] = out.reshape(n, -1).clone()
                 assert int((~torch.isnan(big)).sum()) == n * sides * E, (combine, pitched, v8)
             _same(got["1"], got["0"], f"{combine} pitched={pitched} E={E} n={n} split={split}")
-    monkeypatch.delenv("KGE_V8")
+    kge_switch.unset("V8")
 
 
 @pytest.mark.parametrize("scorer,E,d,n,split", [
@@ -494,7 +494,7 @@ def _v8_launches(which=0):
 @pytest.mark.parametrize("scorer", ["complex", "distmult"])
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("n", [1024, 1500, 2048 + 37, 4096])
-def test_one_call_entry_with_many_rows_takes_the_persistent_kernel(eng, scorer, split, n, monkeypatch):
+def test_one_call_entry_with_many_rows_takes_the_persistent_kernel(eng, scorer, split, n, monkeypatch, kge_switch):
     """VERDICT r4 (missing 2, next 2): KgeModel.score_sp / score_po / score_sp_po with a large batch
     (kge/model/kge_model.py:682-702, 749-789) -- ONE call of kge_score_sp / _po / _sp_po with n >= 1024 rows at d = 512
     against all entities -- runs its rows [0, 512 L) as L batches of ONE pairs_bf16_v8_kernel launch (counted:
@@ -508,14 +508,14 @@ def test_one_call_entry_with_many_rows_takes_the_persistent_kernel(eng, scorer, 
     s, p, o = tri[:, 0], tri[:, 1], tri[:, 2]
     calls = (("sp", lambda: eng.score_sp(T, s, p)), ("po", lambda: eng.score_po(T, p, o)),
              ("sp_po", lambda: eng.score_sp_po(T, s, p, o)))
-    monkeypatch.setenv("KGE_ONE_CALL_V8", "0")
+    kge_switch.set("ONE_CALL_V8", "0")
     want = {}
     before = _v8_launches()
     for name, call in calls:
         want[name] = call()
     torch.cuda.synchronize()
     assert _v8_launches() == before, "KGE_ONE_CALL_V8=0 must keep the call off the persistent kernel"
-    monkeypatch.delenv("KGE_ONE_CALL_V8")
+    kge_switch.unset("ONE_CALL_V8")
     for name, call in calls:
         before = _v8_launches()
         got = call()

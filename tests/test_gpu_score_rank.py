@@ -90,13 +90,13 @@ CASES = [
 
 @pytest.mark.parametrize("kernel", ["v8", "v8-split", "v4"])
 @pytest.mark.parametrize("model,E,R,d,n,K,chunks", CASES)
-def test_fused_counts_equal_the_two_step_counts(model, E, R, d, n, K, chunks, kernel, monkeypatch):
+def test_fused_counts_equal_the_two_step_counts(model, E, R, d, n, K, chunks, kernel, monkeypatch, kge_switch):
     """kernel: "v8" pairs_bf16_v8_rank_kernel (two consumer waves per SIMD: the default), "v8-split" the same with
     split queries (KGE_FLAG_SPLIT_QUERY: the parity-compliant evaluation mode; the two-step path stores the split
     scores), "v4" the round-3 epilogue of pairs_bf16_v4_kernel (KGE_V8_RANK=0: what declined launches fall back to)."""
     from kge_amd import engine as eng
     if kernel == "v4":
-        monkeypatch.setenv("KGE_V8_RANK", "0")
+        kge_switch.set("V8_RANK", "0")
     rng = np.random.default_rng(E + 31 * n + K)
     T = _tables(eng, model, E, R, d, seed=E + n, flags=eng.FLAG_SPLIT_QUERY if kernel == "v8-split" else 0)
     s = torch.from_numpy(rng.integers(0, E, n)).to(DEV)

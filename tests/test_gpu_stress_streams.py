@@ -28,12 +28,12 @@ def _bad(a, b):
 
 @pytest.mark.parametrize("combine,lanes,kernel", [("sp_", 3, "v7"), ("sp_po", 2, "v7"), ("sp_po", 2, "v6-split"),
                                                  ("sp_", 2, "v8")])
-def test_pipelined_launches_in_flight(combine, lanes, kernel, monkeypatch):
+def test_pipelined_launches_in_flight(combine, lanes, kernel, monkeypatch, kge_switch):
     """ScorePipeline(streams = L): 7 batches x 30 rounds = 210 launches per case, L in flight; kernel "v8" forces the
     persistent kernel onto single batches (KGE_V8=1)."""
     from kge_amd import engine as eng
     if kernel == "v8":
-        monkeypatch.setenv("KGE_V8", "1")
+        kge_switch.set("V8", "1")
     fl = eng.FLAG_SPLIT_QUERY if kernel == "v6-split" else None
     T = _tables(eng, fl or 0)
     nb = 7
