@@ -31,7 +31,13 @@ batch of every epoch is compared across ranks by a checksum); what is split is t
     the per-row optimizer state into torch's unsharded layout; rank 0 writes the file.  It resumes on any number of
     ranks, sharded or not (`kge resume`, `kge valid`, `kge test` of an unmodified LibKGE included).
 
-What it declines, loudly (ValueError at job creation): embedder dropout, a penalty term (regularize_weight != 0),
+Penalty terms (lookup_embedder.regularize lp / n3, weighted or not: lookup_embedder.py:122-177, kge_model.py:603-649)
+are computed per shard -- every rank sums the terms of the entity rows it owns, ONE scalar all-reduce gives the value
+the trace shows, the gradient lands on the owned rows; the relation embedder's term is the same on every rank -- and
+embedder dropout (lookup_embedder.py:64-69, 102-105) is applied in front of the dense-row loss kernels (1vsAll and
+KvsAll; kge_amd.sharded: _dropout_loss).  Every rank starts from rank 0's parameters (one broadcast at job creation).
+
+What it declines, loudly (ValueError at job creation): embedder dropout under negative sampling,
 entity and relation embedders that are not plain LookupEmbedders shared between the s and o slot, reciprocal-relations
 wrappers, optimizer parameter groups, `train.loss` other than kl (1vsAll, KvsAll, negative sampling) or plain bce
 (KvsAll, negative sampling), s_o queries, negatives for the relation slot.
@@ -106,7 +112,7 @@ def _scorer_of(model):
     return name, l_norm
 
 
-def _check_model(model):
+def _check_model(model, allow_dropout=True):
     """The model shapes the sharded table can stand in for (module docstring); -> (entity weight, relation weight)."""
     from kge.model import LookupEmbedder
     se, oe, pe = model.get_s_embedder(), model.get_o_embedder(), model.get_p_embedder()
@@ -114,11 +120,10 @@ def _check_model(model):
         raise ValueError("kge_amd: hip_sharded_* jobs need plain lookup embedders, the entity embedder shared by the "
                          "subject and object slot (no reciprocal-relations wrapper)")
     for e, what in ((se, "entity"), (pe, "relation")):
-        if e.dropout.p > 0:
-            raise ValueError(f"kge_amd: hip_sharded_* jobs do not support {what} embedder dropout")
-        if e.regularize != "" and e.get_option("regularize_weight") != 0.0:
-            raise ValueError(f"kge_amd: hip_sharded_* jobs do not support a penalty term ({what} embedder "
-                             "regularize_weight != 0)")
+        if e.dropout.p > 0 and not allow_dropout:
+            raise ValueError(f"kge_amd: this hip_sharded_* job does not support {what} embedder dropout")
+        if e.regularize not in ("", "lp", "n3"):
+            raise ValueError(f"Invalid value regularize={e.regularize}")  # (the reference's text, at the first penalty)
     return se._embeddings.weight, pe._embeddings.weight
 
 
@@ -147,13 +152,20 @@ class _ShardState(_ShardedJob):
 
     def __init__(self, job, slack_rows=0):
         cfg, model = job.config, job.model
-        ent_w, rel_w = _check_model(model)
+        ent_w, rel_w = _check_model(model, allow_dropout=slack_rows <= 0)
         scorer, l_norm = _scorer_of(model)
         dev = torch.device(job.device)
         if ent_w.device != dev and not (dev.type == "cuda" and dev.index is None and ent_w.is_cuda):
             raise ValueError(f"kge_amd: the model is on {ent_w.device}, job.device is {job.device}")
         dev = ent_w.device
         init_process_group(dev)
+        # Every rank built its own model: LibKGE's default is random_seed -1, and nothing else makes the ranks' initial
+        # parameters equal.  Rank 0's are everybody's (the relation table is replicated and its gradient is assumed
+        # identical on every rank; only rank 0's copy reaches the checkpoint) -- ADVICE r5.
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            with torch.no_grad():
+                for w in (ent_w, rel_w):
+                    dist.broadcast(w.data, src=0)
         E, d = ent_w.shape
         R, dr = rel_w.shape
         key = cfg.get("train.type")
@@ -215,6 +227,76 @@ class _ShardState(_ShardedJob):
         self._after_step()
 
 
+def _lookup_penalty(emb, rows, lo, indexes, allreduce):
+    """LookupEmbedder.penalty (kge/model/embedder/lookup_embedder.py:122-177) over `rows` = the rows [lo, lo + len(rows))
+    of the embedder's table that THIS rank owns (a leaf the optimizer steps): the same torch operations on the owned
+    rows only.  The Lp / N3 penalty is a sum of per-row terms, so the shards' sums add up to the reference's value:
+    `allreduce` (None for the replicated relation table) makes the returned VALUE global while the gradient stays on
+    the owned rows (value = local + (global - local).detach()).  -> [] or [(key, 0-d tensor)]."""
+    if emb.regularize == "" or emb.get_option("regularize_weight") == 0.0:
+        return []
+    if emb.regularize not in ("lp", "n3"):
+        raise ValueError(f"Invalid value regularize={emb.regularize}")
+    if emb.regularize == "n3":
+        p = 3
+    else:
+        p = emb.get_option("regularize_args.p") if emb.has_option("regularize_args.p") else 2
+    weight = emb._get_regularize_weight()
+    if not emb.get_option("regularize_args.weighted"):
+        parameters = rows
+        if emb.regularize == "n3" and emb.space == "complex":
+            parameters = emb._abs_complex(parameters)
+        local = (weight / p * parameters.norm(p=p) ** p).sum()
+    else:
+        if indexes is None:
+            raise KeyError("indexes")  # (the reference's failure for a weighted penalty on a batch without triples)
+        unique_indexes, counts = torch.unique(indexes, return_counts=True)
+        mine = (unique_indexes >= lo) & (unique_indexes < lo + rows.shape[0])
+        parameters = rows[(unique_indexes[mine] - lo).long()]
+        counts = counts[mine]
+        if emb.regularize == "n3" and emb.space == "complex":
+            parameters = emb._abs_complex(parameters)
+        if (p % 2 == 1) and (emb.regularize != "n3"):
+            parameters = torch.abs(parameters)
+        local = (weight / p * (parameters ** p * counts.float().view(-1, 1))).sum() / len(indexes)
+    if allreduce is not None:
+        total = local.detach().clone().view(1)
+        allreduce(total)
+        local = local + (total.view(()) - local.detach())
+    return [(f"{emb.configuration_key}.L{p}_penalty", local)]
+
+
+def sharded_model_penalty(model, sh, **kwargs):
+    """KgeModel.penalty (kge/model/kge_model.py:603-649) for a model whose entity rows are trained as shards: the
+    relation embedder's terms on the replicated table, the (shared) entity embedder's on this rank's rows -- weighted:
+    the batch's s and o ids, unweighted: all rows, doubled as the reference doubles it."""
+    from kge.job.train_negative_sampling import S as _S, P as _P, O as _O
+    pe, se = model.get_p_embedder(), model.get_s_embedder()
+    Eg = sh.hi - sh.lo
+    ent_rows, rel_rows = sh.ent_master[:Eg], sh.rel_master
+
+    def allreduce(t):
+        if sh.world > 1:
+            dev = t.device
+            buf = t if dist.get_backend(sh.group) != "gloo" else t.cpu()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=sh.group)
+            if buf is not t:
+                t.copy_(buf.to(dev))
+        return t
+    triples = None
+    if "batch" in kwargs and "triples" in kwargs["batch"]:
+        triples = kwargs["batch"]["triples"].to(ent_rows.device)
+    result = _lookup_penalty(pe, rel_rows, 0, None if triples is None else triples[:, _P], None)
+    weighted = se.get_option("regularize_args.weighted")
+    entity_indexes = None
+    if triples is not None and weighted:
+        entity_indexes = torch.cat((triples[:, _S].view(-1, 1), triples[:, _O].view(-1, 1)), dim=1)
+    ent_pen = _lookup_penalty(se, ent_rows, sh.lo, entity_indexes, allreduce)
+    if not (triples is not None and weighted):
+        ent_pen = [(k, v * 2) for k, v in ent_pen]  # (kge_model.py:620-625 / 636-640: "backwards compatibility")
+    return result + ent_pen
+
+
 def _batch_checksum(batch) -> torch.Tensor:
     acc = []
     for key in ("triples", "queries"):
@@ -249,6 +331,16 @@ class _ShardedTrainMixin(_CudaOomText):
         for group in self.optimizer.param_groups:
             group["initial_lr"] = group["lr"]
         self.optimizer.register_step_post_hook(lambda opt, a, k: sh._after_step())
+        # TrainingJob.run_epoch calls self.model.penalty(...) and back-propagates every term (train.py:417-436): on this
+        # job the terms are the shards' (sharded_model_penalty)
+        model = self.model
+        model.penalty = lambda **kw: sharded_model_penalty(model, sh, **kw)
+        # embedder dropout of a training step (1vsAll, KvsAll: kge_amd.sharded._dropout_loss); the table's mask of a
+        # multi-rank job from a generator of this rank's own (the default generators draw alike on every rank)
+        self._dropout = (float(model.get_s_embedder().dropout.p), float(model.get_p_embedder().dropout.p))
+        if max(self._dropout) > 0 and sh.world > 1:
+            dev = sh.ent_master.device
+            sh.table.table_generator = torch.Generator(device=dev)
         self._epoch_checked = -1
         self._seed_base = self._draw_seed_base()
         # validation: a sharded evaluation job finds the table through its parent; any other evaluation job reads the
@@ -282,6 +374,9 @@ class _ShardedTrainMixin(_CudaOomText):
         import random
         v = epoch_seed(self._seed_base, self.epoch)
         torch.manual_seed(v)
+        tg = getattr(self._sh.table, "table_generator", None)
+        if tg is not None:
+            tg.manual_seed((v * 131 + 7919 * (self._sh.rank + 1)) % (2 ** 31 - 1))
         np.random.seed(v % (2 ** 32))
         random.seed(v)
 
@@ -375,7 +470,8 @@ class HipShardedTrainingJob1vsAll(_ShardedTrainMixin, TrainingJob1vsAll):
         s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
         for direction, ids, labels in (("sp", s, o), ("po", o, s)):
             result.forward_time -= time.time()
-            rows = sh.table.ce_loss(direction, ids, p, labels, sh.ent_master, sh.rel_master)
+            rows = sh.table.ce_loss(direction, ids, p, labels, sh.ent_master, sh.rel_master,
+                                    dropout=self._dropout if self.model.training else None)
             loss_value = rows.sum() / batch_size
             result.avg_loss += loss_value.item()
             result.forward_time += time.time()
@@ -438,9 +534,11 @@ class HipShardedTrainingJobKvsAll(_ShardedTrainMixin, TrainingJobKvsAll):
             # sp_: (s, p) rows, labels = objects;  _po: (p, o) rows, labels = subjects
             direction, ids, p = ("sp", q0, q1) if query_type == "sp_" else ("po", q1, q0)
             if self._bce_offset is None:
-                rows = sh.table.kl_loss(direction, ids, p, rowptr, col, sh.ent_master, sh.rel_master)
+                rows = sh.table.kl_loss(direction, ids, p, rowptr, col, sh.ent_master, sh.rel_master,
+                                        dropout=self._dropout if self.model.training else None)
             else:
-                rows = sh.table.bce_loss(direction, ids, p, rowptr, col, self._bce_offset, sh.ent_master, sh.rel_master)
+                rows = sh.table.bce_loss(direction, ids, p, rowptr, col, self._bce_offset, sh.ent_master, sh.rel_master,
+                                         dropout=self._dropout if self.model.training else None)
             loss_value = rows.sum() / batch_size
             result.avg_loss += loss_value.item()
             result.forward_time += time.time()
@@ -552,6 +650,11 @@ class HipShardedEntityRankingJob(HipEntityRankingJob):
             self._host_index.append(FilterIndex(splits + [self.dataset.split("test").numpy()], E, R))
 
     def _eval_begin(self, M, chunk_size):
+        # Without a sharded parent job the table is a SNAPSHOT of the model's rows (a bf16 copy under score_dtype auto
+        # on a GPU): taken anew at every run -- a training job validating through this job moves the weights between
+        # runs, and a table kept from the first validation froze every later metric.
+        if getattr(getattr(self, "parent_job", None), "_sh", None) is None:
+            self._own_table = None
         E = self.dataset.num_entities()
         if chunk_size < E:
             self.config.log("hip_sharded_entity_ranking: entity_ranking.chunk_size is ignored (a rank's chunk is its shard)")

@@ -178,18 +178,21 @@ class HipTrainingJob1vsAll(_CudaOomText, TrainingJob1vsAll):
         if not fused:
             return super()._process_subbatch(batch_index, batch, subbatch_slice, result)
         batch_size = result.size
-        result.prepare_time -= time.time()
-        triples = batch["triples"][subbatch_slice].to(self.device)
-        result.prepare_time += time.time()
         if hasattr(self.model, "loss_sp_po"):
             gs = self._graph_step_for(batch_index, batch, subbatch_slice)
             if gs is not None and gs.enabled:
                 result.forward_time -= time.time()
-                loss_value = gs(triples)  # (whole batch: len(triples) == batch_size)
+                # the batch as the loader made it (a host tensor): GraphedStep copies it host-to-device straight into the
+                # captured step's input buffer -- no device-side hop in front of the replay
+                loss_value = gs(batch["triples"][subbatch_slice])  # (whole batch: len(triples) == batch_size)
                 self._skip_optimizer_step = True  # (eager or replayed: the step is taken)
                 result.avg_loss += loss_value.item()
                 result.forward_time += time.time()
                 return
+        result.prepare_time -= time.time()
+        triples = batch["triples"][subbatch_slice].to(self.device)
+        result.prepare_time += time.time()
+        if hasattr(self.model, "loss_sp_po"):
             # both directions from one scoring launch and one pair of gradient products; the sum of
             # the two losses is back-propagated once (the reference does it in two passes:
             # the same gradients, accumulated)

@@ -166,6 +166,135 @@ class _ShardedBCE(torch.autograd.Function):
         return None, None, ge, gr, None, None, None, None, None
 
 
+# ---- embedder dropout on the sharded table (round 6) ----------------------------------------------------------------
+# LookupEmbedder._postprocess (kge/model/embedder/lookup_embedder.py:64-69, 102-105) applies torch.nn.Dropout to what
+# embed() / embed_all() return: in a training step score_sp(s, p) scores dropout(E[s]) (x) dropout(R[p]) against
+# dropout(E) -- three independent masks (kge_model.py:682-725: s rows, p rows, all entities for sp_; all entities, o
+# rows, p rows for _po).  Over a sharded table: the batch's query rows are brought to every rank in FLOAT32 from their
+# owners' masters (_OwnerRows: one all-reduce of [n, d], x + 0 is exact), masked identically on every rank (the ranks
+# draw from generators seeded alike, sharded_job._seed_epoch), every rank masks ITS rows of the table, and the dense-row
+# loss kernels (kge_ce_emb_* / kge_kl_weighted_emb_* / kge_bce_emb_*) run on the masked rows (_ShardedDense: the
+# per-shard step and merges of _ShardedCE / _ShardedKL / _ShardedBCE with the rows handed in); autograd carries the
+# gradients back through the masks, sums the query rows' over the shards and scatters them on their owners.
+def _drop(x, p, mask=None, generator=None):
+    """torch.nn.functional.dropout(x, p, training=True), the mask optionally handed in (0 / 1, same shape) or drawn
+    from `generator` (the table's per-rank generator)."""
+    if p <= 0.0:
+        return x
+    if mask is None:
+        if generator is None:
+            return torch.nn.functional.dropout(x, p, True)
+        mask = torch.empty_like(x, dtype=torch.float32).bernoulli_(1.0 - p, generator=generator)
+    return x * (mask.to(x.dtype) * (1.0 / (1.0 - p)))
+
+
+class _OwnerRows(torch.autograd.Function):
+    """[n, d] float32 rows of the GLOBAL ids `ids` from the sharded master, on every rank."""
+
+    @staticmethod
+    def forward(ctx, sh, ent_master, ids):
+        gid = ids.reshape(-1).long()
+        own = ((gid >= sh.lo) & (gid < sh.hi)).to(ent_master.dtype).unsqueeze(1)
+        local = (gid - sh.lo).clamp_(0, max(sh.hi - sh.lo - 1, 0))
+        rows = ent_master.detach()[local] * own if sh.hi > sh.lo else torch.zeros(
+            gid.numel(), ent_master.shape[1], dtype=ent_master.dtype, device=ent_master.device)
+        sh._allreduce(rows)  # every id has one owner: value + zeros
+        ctx.sh, ctx.shape = sh, ent_master.shape
+        ctx.save_for_backward(local, own)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        sh = ctx.sh
+        local, own = ctx.saved_tensors
+        g = g.contiguous().clone()
+        sh._allreduce(g)  # every shard's part of the query rows' gradient
+        ge = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        if sh.hi > sh.lo:
+            ge.index_add_(0, local, g * own)
+        return None, ge, None
+
+
+class _SumOverShards(torch.autograd.Function):
+    """Identity whose gradient is summed over the ranks (the relation rows' gradient: every shard contributes)."""
+
+    @staticmethod
+    def forward(ctx, sh, x):
+        ctx.sh = sh
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.sh._allreduce(g)
+        return None, g
+
+
+class _ShardedDense(torch.autograd.Function):
+    """The per-shard step of _ShardedCE / _ShardedKL / _ShardedBCE on rows that are handed in: `table` [E_g, d] (this
+    rank's rows), `a_rows` [n, d], `p_rows` [n, d_r] -- float32, rounded to the scoring dtype inside; gradients come
+    back in float32 w.r.t. all three (this SHARD's part of them: the callers' _OwnerRows / _SumOverShards sum)."""
+
+    @staticmethod
+    def forward(ctx, sh, kind, direction, table, a_rows, p_rows, extra):
+        sd = sh.ent_local.dtype
+        t16 = sh.backend.Tables(sh.scorer, table.detach().to(sd).contiguous(), sh.rel, sh.l_norm)
+        a16, p16 = a_rows.detach().to(sd).contiguous(), p_rows.detach().to(sd).contiguous()
+        ctx.sh, ctx.kind, ctx.direction, ctx.t16 = sh, kind, direction, t16
+
+        def merge(lse_loc):
+            if not sh.collectives:
+                return lse_loc
+            allse = torch.empty(sh.world * lse_loc.numel(), dtype=lse_loc.dtype, device=lse_loc.device)
+            dist.all_gather_into_tensor(allse, lse_loc.contiguous(), group=sh.group)
+            return torch.logsumexp(allse.view(sh.world, -1), dim=0)
+        if kind == "ce":
+            lab = extra[0].reshape(-1).long()
+            own = (lab >= sh.lo) & (lab < sh.hi)
+            lab_local = torch.where(own, lab - sh.lo, torch.full_like(lab, -1))
+            loss_loc, lse_loc = sh.backend.ce_emb_fwd(t16, direction, a16, p16, lab_local)
+            true = torch.where(own, lse_loc - loss_loc, torch.zeros_like(lse_loc))
+            lse = merge(lse_loc)
+            sh._allreduce(true)
+            ctx.extra = (lab_local,)
+            ctx.save_for_backward(a16, p16, lse)
+            return lse - true
+        rowptr, col = extra[0], extra[1]
+        if kind == "kl":
+            k = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+            has = k > 0
+            w = torch.where(has, 1.0 / k.clamp(min=1.0), torch.zeros_like(k))
+            loss_loc, lse_loc = sh.backend.kl_emb_fwd(t16, direction, a16, p16, rowptr, col, sh.lo, w)
+            lab = torch.where(torch.isfinite(lse_loc), lse_loc - loss_loc, torch.zeros_like(lse_loc))
+            lse = merge(lse_loc)
+            sh._allreduce(lab)
+            ctx.extra = (rowptr, col)
+            ctx.save_for_backward(a16, p16, lse, w, has)
+            return torch.where(has, lse - lab - torch.log(k.clamp(min=1.0)), torch.zeros_like(lse))
+        offset = float(extra[2])
+        loss = sh.backend.bce_emb_fwd(t16, direction, a16, p16, rowptr, col, sh.lo, offset)
+        loss = sh._allreduce(loss.clone())
+        ctx.extra = (rowptr, col, offset)
+        ctx.save_for_backward(a16, p16)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_rows):
+        sh, t16 = ctx.sh, ctx.t16
+        if ctx.kind == "ce":
+            a16, p16, lse = ctx.saved_tensors
+            g_a, g_p, g_t = sh.backend.ce_emb_bwd(t16, ctx.direction, a16, p16, ctx.extra[0], lse, g_rows=g_rows.contiguous())
+        elif ctx.kind == "kl":
+            a16, p16, lse, w, has = ctx.saved_tensors
+            g = torch.where(has, g_rows, torch.zeros_like(g_rows)).contiguous()
+            g_a, g_p, g_t = sh.backend.kl_emb_bwd(t16, ctx.direction, a16, p16, ctx.extra[0], ctx.extra[1], sh.lo, w, lse, g_rows=g)
+        else:
+            a16, p16 = ctx.saved_tensors
+            g_a, g_p, g_t = sh.backend.bce_emb_bwd(t16, ctx.direction, a16, p16, ctx.extra[0], ctx.extra[1], sh.lo,
+                                                   ctx.extra[2], g_rows=g_rows.contiguous())
+        return None, None, None, g_t.to(torch.float32), g_a.to(torch.float32), g_p.to(torch.float32), None
+
+
 class _ShardedNeg(torch.autograd.Function):
     """Scores of a negative-sampling batch over the sharded table (TrainingJobNegativeSampling._process_subbatch,
     kge/job/train_negative_sampling.py:103-164, with BatchNegativeSample.score, kge/util/sampler.py:263-306): the n
@@ -395,7 +524,8 @@ class ShardedEntityTable:
 
     # ---- training: 1vsAll cross entropy over the entities of all shards -----------------------------
     def ce_loss(self, direction: str, ids: torch.Tensor, p: torch.Tensor, labels: torch.Tensor,
-                ent_master: Optional[torch.Tensor] = None, rel_master: Optional[torch.Tensor] = None):
+                ent_master: Optional[torch.Tensor] = None, rel_master: Optional[torch.Tensor] = None,
+                dropout=None, masks=None):
         """[n] cross entropy of score_sp(ids, p) ("sp": ids = subjects, labels = true objects) or
         score_po(p, ids) ("po": ids = objects, labels = true subjects) over ALL entities; sum / batch
         size = the reference's 1vsAll loss (train_1vsAll.py:64-81, loss.py:192-207).  Differentiable
@@ -405,20 +535,49 @@ class ShardedEntityTable:
         themselves are the parameters."""
         ent_master = self.ent_local if ent_master is None else ent_master
         rel_master = self.rel if rel_master is None else rel_master
+        if dropout is not None and max(dropout) > 0.0:
+            return self._dropout_loss("ce", direction, ids, p, ent_master, rel_master, (labels,), dropout, masks)
         return _ShardedCE.apply(self, direction, ent_master, rel_master, ids, p, labels)
 
-    def kl_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, ent_master=None, rel_master=None):
+    def kl_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, ent_master=None, rel_master=None, dropout=None,
+                masks=None):
         """[n] KvsAll KL loss rows over ALL entities (see _ShardedKL); sum / batch size = the reference's loss."""
         ent_master = self.ent_local if ent_master is None else ent_master
         rel_master = self.rel if rel_master is None else rel_master
+        if dropout is not None and max(dropout) > 0.0:
+            return self._dropout_loss("kl", direction, ids, p, ent_master, rel_master, (lbl_rowptr, lbl_col), dropout, masks)
         return _ShardedKL.apply(self, direction, ent_master, rel_master, ids, p, lbl_rowptr, lbl_col)
 
     def bce_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, offset: float = 0.0, ent_master=None,
-                 rel_master=None):
+                 rel_master=None, dropout=None, masks=None):
         """[n] KvsAll BCE loss rows summed over ALL entities (see _ShardedBCE)."""
         ent_master = self.ent_local if ent_master is None else ent_master
         rel_master = self.rel if rel_master is None else rel_master
+        if dropout is not None and max(dropout) > 0.0:
+            return self._dropout_loss("bce", direction, ids, p, ent_master, rel_master, (lbl_rowptr, lbl_col, offset),
+                                      dropout, masks)
         return _ShardedBCE.apply(self, direction, ent_master, rel_master, ids, p, lbl_rowptr, lbl_col, offset)
+
+    def _dropout_loss(self, kind, direction, ids, p, ent_master, rel_master, extra, dropout, masks):
+        """The three losses with the embedders' dropout (p_entity, p_relation) as the reference applies it in a
+        training step -- masks "a" [n, d], "p" [n, d_r], "all" [E_g, d] (this rank's rows), drawn in the reference's
+        order (kge_model.py:682-725) or handed in (tests).  With more than one rank the table's mask comes from a
+        generator of this rank's own (`table_generator`, seeded by the caller): the default generator must see the
+        same draws on every rank, and the last shard may be shorter than the others."""
+        p_ent, p_rel = float(dropout[0]), float(dropout[1])
+        masks = masks or {}
+        gen = getattr(self, "table_generator", None) if self.world > 1 else None
+        Eg = self.hi - self.lo
+        shard = ent_master[:Eg]
+
+        def drop_all():
+            return _drop(shard, p_ent, masks.get("all"), gen)
+        table = drop_all() if direction == "po" else None
+        a_rows = _drop(_OwnerRows.apply(self, ent_master, ids), p_ent, masks.get("a"))
+        p_rows = _drop(_SumOverShards.apply(self, rel_master[p.reshape(-1).long()]), p_rel, masks.get("p"))
+        if table is None:
+            table = drop_all()
+        return _ShardedDense.apply(self, kind, direction, table, a_rows, p_rows, extra)
 
     @staticmethod
     def with_slack(rows: torch.Tensor, n_max: int):
