@@ -368,6 +368,44 @@ int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_inde
                          void* filter_bits, int64_t filter_bits_bytes, void* workspace,
                          int64_t workspace_bytes, void* stream);
 
+/* Band-and-rescore: the counts of kge_score_rank_sp_po / kge_eval_batch under KGE_FLAG_SPLIT_QUERY --
+ * the parity-compliant evaluation mode, EntityRankingJob._get_ranks_and_num_ties' tie band honoured on full-precision
+ * query vectors (eval_entity_ranking.py:571-596) -- from a SINGLE-PASS counting launch plus a second launch over the
+ * few pairs the first could not decide.  The single-pass score x_hi is the hi half of the split score
+ * x = fl(x_hi + x_lo), and |x_lo| <= ||q_lo_i|| * max_j ||t_j||: with row i's tolerance widened by that bound, a score
+ * outside the widened band compares with the true score the same way under x_hi and under x.  Launch 1 counts those
+ * and LISTS the 32 x 32 tiles holding a score inside the band; launch 2 scores the listed tiles with both chains (the
+ * bits the split kernel counts) and finishes the counts.  Identical (rank, ties) to the split kernel, by construction
+ * and by test; on a trained model (true scores in the tail of their rows) ~5 % of the tiles are listed.
+ *   table_max_norm  [1] device float: kge_table_max_row_norm of the scored rows [col_begin, col_begin + m);
+ *   list            device scratch, 16-byte aligned, KGE_RANK_BAND_ENTRY_BYTES per tile it can hold;
+ *   status          [8] device uint32, ZEROED ONCE by the caller before the first call: [0] tiles listed by the last
+ *                   call, [1] tiles DROPPED because the list was full, summed over all calls (sticky), [2] calls
+ *                   completed, [3] unused, [4..7] the library's counters (zero between calls).
+ * status[1] != 0 means some call's counts are INCOMPLETE: the caller must redo those batches without `band` (the
+ * evaluator reads the words once at the end of a run -- no host wait per batch -- and falls back to the split kernel
+ * for the run; it also drops the band when the first batches list most tiles: nothing to gain on such tables).
+ * band == NULL: the plain entry points.  KGE_ERR_INVALID_ARG: band without KGE_FLAG_SPLIT_QUERY, missing pieces;
+ * KGE_ERR_UNSUPPORTED as for kge_score_rank_sp_po. */
+#define KGE_RANK_BAND_ENTRY_BYTES 528
+typedef struct kge_rank_band {
+  const float* table_max_norm;
+  void* list;
+  int64_t list_bytes;
+  uint32_t* status;
+} kge_rank_band;
+/* 1.001 x the largest Euclidean norm of the rows [row_begin, row_begin + m) of the bf16 entity table, into out[0]
+ * (device).  Once per table state (an evaluation run), not per batch. */
+int kge_table_max_row_norm(const kge_tables* t, int64_t row_begin, int64_t m, float* out, void* stream);
+int kge_score_rank_sp_po_band(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
+                              int64_t col_begin, int64_t m, const float* true_sp, const float* true_po,
+                              int num_filters, const int64_t* const* sp_begin, const int64_t* const* sp_end,
+                              const int64_t* const* sp_col, const int64_t* const* po_begin,
+                              const int64_t* const* po_end, const int64_t* const* po_col, float atol, float rtol,
+                              int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po, int64_t* ties_po, int64_t ld,
+                              void* filter_bits, int64_t filter_bits_bytes, void* workspace,
+                              int64_t workspace_bytes, void* stream, const kge_rank_band* band);
+
 /* The same for dense query rows (the row-sharded multi-GPU path: s / p / o rows come out of the exchange, the
  * scored rows tgt_emb[m] are this rank's shard, whose global entity ids start at col_begin; s_ids / o_ids =
  * the global ids of the rows' true subject / object, which the filters never remove).  Counts of the shard's
@@ -406,6 +444,13 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
                    float* hist, int64_t ldh, int64_t* ranks_o, int64_t* ranks_s, void* filter_bits,
                    int64_t filter_bits_bytes, void* scratch, int64_t scratch_bytes, void* workspace,
                    int64_t workspace_bytes, void* stream);
+
+/* kge_eval_batch with band-and-rescore in step (3) (see kge_score_rank_sp_po_band); band == NULL: kge_eval_batch. */
+int kge_eval_batch_band(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, int num_filters,
+                        const kge_eval_filter* filters, float atol, float rtol, int tie_policy, int64_t* counts,
+                        float* hist, int64_t ldh, int64_t* ranks_o, int64_t* ranks_s, void* filter_bits,
+                        int64_t filter_bits_bytes, void* scratch, int64_t scratch_bytes, void* workspace,
+                        int64_t workspace_bytes, void* stream, const kge_rank_band* band);
 
 /* hist[m*ldh + r] += 1.0f with r = rank of the tie policy, for all [num_rankings][n] counts;
  * ranks_out (may be NULL) receives r.  EntityRankingJob._get_ranks (:598-618) + hist_all
@@ -678,6 +723,25 @@ typedef struct kge_adagrad_seg {
   float minus_clr, weight_decay, eps;
 } kge_adagrad_seg;
 int kge_adagrad_step_multi(const kge_adagrad_seg* segs, int num_segs, void* stream);
+
+/* kge_adagrad_step_multi with the embedders' UNWEIGHTED penalty terms folded into the pass
+ * (LookupEmbedder.penalty, kge/model/embedder/lookup_embedder.py:122-147, back-propagated by TrainingJob.run_epoch
+ * between the batch and optimizer.step(), kge/job/train.py:417-436): segment j adds the gradient of
+ *   kind 1 (regularize lp):          weight / p * sum |x|^p             (p = 1, 2, 3)   -> weight * sign(x) |x|^(p-1)
+ *   kind 2 (regularize n3, complex): weight / 3 * sum |z|^3, |z| = sqrt(re^2 + im^2 + 1e-14), im = col + row_dim / 2
+ * to grad before the update (grad itself is not written), and adds sum |x|^p (sum |z|^3) of the PRE-step parameters
+ * to *value (a device double the caller zeroed; the term the reference's trace shows is weight / p times it).
+ * `weight` is the gradient's factor: regularize_weight, doubled for an entity embedder shared by the subject and
+ * object slot (kge_model.py:620-625).  kind 0: the plain step.  kind 2 needs count % row_dim == 0 and
+ * row_dim % 8 == 0.  pens == NULL: kge_adagrad_step_multi. */
+typedef struct kge_penalty_seg {
+  int32_t kind, p;
+  float weight;
+  int64_t row_dim;
+  double* value;        /* [1] device, or NULL for kind 0 */
+} kge_penalty_seg;
+int kge_adagrad_step_multi_penalty(const kge_adagrad_seg* segs, const kge_penalty_seg* pens, int num_segs,
+                                   void* stream);
 
 /* One dense Adam step (torch.optim.Adam, amsgrad / maximize off) on `count` contiguous f32 elements,
  * in place, one pass:  g = grad + weight_decay * param (if != 0);  exp_avg += (g - exp_avg)(1 - beta1);

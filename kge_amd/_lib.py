@@ -65,6 +65,11 @@ class KgeAdagradSeg(ctypes.Structure):
 ADAGRAD_MAX_SEGS = 8
 
 
+class KgePenaltySeg(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("p", ctypes.c_int32), ("weight", ctypes.c_float), ("row_dim", c_i64),
+                ("value", c_vp)]
+
+
 class KgeEvalFilter(ctypes.Structure):
     _fields_ = [("sp_keys", c_vp), ("sp_num_keys", c_i64), ("sp_starts", c_vp), ("sp_values", c_vp),
                 ("po_keys", c_vp), ("po_num_keys", c_i64), ("po_starts", c_vp), ("po_values", c_vp)]
@@ -170,6 +175,8 @@ PROTOTYPES = {
     "kge_ce_sp_po_bwd_accum_sum": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_vp, c_vp, c_vp,
                                                   ctypes.c_float, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "kge_adagrad_step_multi": (ctypes.c_int, [ctypes.POINTER(KgeAdagradSeg), ctypes.c_int, c_vp]),
+    "kge_adagrad_step_multi_penalty": (ctypes.c_int, [ctypes.POINTER(KgeAdagradSeg), ctypes.POINTER(KgePenaltySeg),
+                                                      ctypes.c_int, c_vp]),
     "kge_multilabel2_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),
     "kge_multilabel2_bwd_accum": (ctypes.c_int, [_PT, ctypes.c_int, ctypes.c_float, ctypes.POINTER(KgeLabelQueries),
                                                  ctypes.POINTER(KgeLabelQueries), c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -55,8 +55,11 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
                       int reserve_cus);
 NextQ pairs_bf16_nextq(bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, long long n,
                        int nbatch, void* qf, long long qstride_bytes);
+int run_pairs_bf16_rescore(const Operand& TG, int d, long long n, long long m, const void* qf, const CeArgs& ce,
+                           unsigned int* done, hipStream_t st);
+int run_table_max_norm(const Operand& TG, long long m, int d, float* out, hipStream_t st);
 int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, long long n, long long m, const void* qf,
-                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus);
+                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus, bool band = false);
 int v8_launch_count(int which);
 bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
 int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
@@ -137,6 +140,7 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
                 float* g_p, float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, void* ws,
                 long long ws_bytes, hipStream_t st, const float* g_dev = nullptr, const float* g_dev2 = nullptr);
 int run_adagrad_multi(const kge_adagrad_seg* segs, int num, hipStream_t st);
+int run_adagrad_multi_pen(const kge_adagrad_seg* segs, const kge_penalty_seg* pens, int num, hipStream_t st);
 long long multilabel2_workspace_bytes(int d, long long n1, long long n2, long long m);
 int run_multilabel2_bwd_accum(int scorer, int kind, float offset, const LossSide& sp, const LossSide& po,
                               const Operand& TG, int d, long long m, float* grad_ent, float* grad_rel,
@@ -1019,7 +1023,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
                            float atol, float rtol, int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po,
                            int64_t* ties_po, int64_t ld, void* filter_bits, int64_t filter_bits_bytes, void* workspace,
                            int64_t workspace_bytes, void* stream, int64_t true_stride = 1, bool manage_bits = true,
-                           bool queries_ready = false) {
+                           bool queries_ready = false, const kge_rank_band* band = nullptr) {
   // queries_ready (kge_eval_batch): the batch's query fragments already sit in the workspace (behind its control block)
   // manage_bits = false (kge_eval_batch): the filter bits are set already and are cleared by the caller; the lists
   // are not looked at
@@ -1046,6 +1050,14 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   const bool v8_rank = !exact_path && sw(SW_V8_RANK) != 0 && (t->dim == 256 || t->dim == 512) && TG.idx.ptr == nullptr &&
                        workspace_bytes >= PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, split);
   if (split && !v8_rank) return KGE_ERR_UNSUPPORTED;
+  // band-and-rescore: the split counts from a single-pass launch over the q_hi blocks + a second launch over the tiles
+  // it lists (pairs_bf16_v8_rank_kernel<BAND>, pairs_bf16_rescore_kernel)
+  if (band != nullptr) {
+    if (!split) return KGE_ERR_INVALID_ARG;  // (a single-pass count has nothing to resolve)
+    if (!band->table_max_norm || !band->status || !band->list || ((uintptr_t)band->list & 15) ||
+        ((uintptr_t)band->status & 3) || band->list_bytes < KGE_RANK_BAND_ENTRY_BYTES)
+      return KGE_ERR_INVALID_ARG;
+  }
   if (!exact_path) {
     if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
         !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
@@ -1070,6 +1082,14 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   ce.rk_nfilt = num_filters;
   ce.rk_bits_rs = bl.rs;
   ce.rk_bits_us = bl.us;
+  if (band != nullptr) {
+    const int64_t cap = band->list_bytes / KGE_RANK_BAND_ENTRY_BYTES;
+    ce.rk_tmax = band->table_max_norm;
+    ce.rk_list = (u32x4*)band->list;
+    ce.rk_list_cap = (unsigned int)(cap > 0x7fffffffLL ? 0x7fffffffLL : cap);
+    ce.rk_status = band->status;
+    ce.rk_list_count = band->status + 4;
+  }
   // lists: [sp side: filter sets][po side: filter sets]; the true column of the sp ranking is o, of the po ranking s
   const long long *lb[4], *le[4], *lc[4];
   Index keep[4];
@@ -1139,7 +1159,9 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
     ce.rk_clear_bits = manage_bits && num_filters > 0 ? 1 : 0;
     if (rc == KGE_OK)
       rc = run_pairs_bf16_v8_rank(t->scorer, split, TG, (int)t->dim, n, m, qf, ce, st, nullptr,
-                                  (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
+                                  (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, band != nullptr);
+    if (rc == KGE_OK && band != nullptr)
+      rc = run_pairs_bf16_rescore(TG, (int)t->dim, n, m, qf, ce, band->status + 5, st);
     ce.rk_clear_bits = 0;
     if (rc == KGE_OK) return KGE_OK;  // counted, bits cleared by the kernel
     if (rc != KGE_ERR_UNSUPPORTED || split) {
@@ -1202,6 +1224,41 @@ int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_inde
                          ties_po, ld, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream);
 }
 
+int kge_score_rank_sp_po_band(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, int64_t col_begin,
+                              int64_t m, const float* true_sp, const float* true_po, int num_filters,
+                              const int64_t* const* sp_begin, const int64_t* const* sp_end,
+                              const int64_t* const* sp_col, const int64_t* const* po_begin,
+                              const int64_t* const* po_end, const int64_t* const* po_col, float atol, float rtol,
+                              int64_t* rank_sp, int64_t* ties_sp, int64_t* rank_po, int64_t* ties_po, int64_t ld,
+                              void* filter_bits, int64_t filter_bits_bytes, void* workspace, int64_t workspace_bytes,
+                              void* stream, const kge_rank_band* band) {
+  KGE_RANGE();
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (n < 0 || m < 0 || col_begin < 0 || col_begin + m > t->num_ent) return KGE_ERR_INVALID_ARG;
+  if ((rc = check_index(s, false, n)) || (rc = check_index(p, false, n)) || (rc = check_index(o, false, n))) return rc;
+  if (n == 0 || m == 0) return KGE_OK;
+  const kge_index all = {nullptr, 0, 0, 1};
+  Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, all);
+  TG.base = (const char*)TG.base + col_begin * TG.ld * (t->dtype == KGE_BF16 ? 2 : 4);
+  return score_rank_core(t, S, O, P, TG, make_index(o), make_index(s), n, col_begin, m, true_sp, true_po, num_filters,
+                         sp_begin, sp_end, sp_col, po_begin, po_end, po_col, atol, rtol, rank_sp, ties_sp, rank_po,
+                         ties_po, ld, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream, 1, true, false,
+                         band);
+}
+
+int kge_table_max_row_norm(const kge_tables* t, int64_t row_begin, int64_t m, float* out, void* stream) {
+  KGE_RANGE();
+  int rc = check_tables(t, true);
+  if (rc) return rc;
+  if (!out || row_begin < 0 || m < 0 || row_begin + m > t->num_ent) return KGE_ERR_INVALID_ARG;
+  if (t->dtype != KGE_BF16) return KGE_ERR_UNSUPPORTED;
+  const kge_index all = {nullptr, 0, 0, 1};
+  Operand TG = ent_op(t, all);
+  TG.base = (const char*)TG.base + row_begin * TG.ld * 2;
+  return run_table_max_norm(TG, m, (int)t->dim, out, (hipStream_t)stream);
+}
+
 int kge_score_rank_emb_sp_po(const kge_tables* t, const void* s_emb, int64_t s_ld, const void* p_emb, int64_t p_ld,
                              const void* o_emb, int64_t o_ld, kge_index s_ids, kge_index o_ids, int64_t n,
                              const void* tgt_emb, int64_t tgt_ld, int64_t col_begin, int64_t m, const float* true_sp,
@@ -1246,6 +1303,16 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
                    float* hist, int64_t ldh, int64_t* ranks_o, int64_t* ranks_s, void* filter_bits,
                    int64_t filter_bits_bytes, void* scratch, int64_t scratch_bytes, void* workspace,
                    int64_t workspace_bytes, void* stream) {
+  return kge_eval_batch_band(t, s, p, o, n, num_filters, filters, atol, rtol, tie_policy, counts, hist, ldh, ranks_o,
+                             ranks_s, filter_bits, filter_bits_bytes, scratch, scratch_bytes, workspace,
+                             workspace_bytes, stream, nullptr);
+}
+
+int kge_eval_batch_band(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, int num_filters,
+                        const kge_eval_filter* filters, float atol, float rtol, int tie_policy, int64_t* counts,
+                        float* hist, int64_t ldh, int64_t* ranks_o, int64_t* ranks_s, void* filter_bits,
+                        int64_t filter_bits_bytes, void* scratch, int64_t scratch_bytes, void* workspace,
+                        int64_t workspace_bytes, void* stream, const kge_rank_band* band) {
   KGE_RANGE();
   int rc = check_tables(t, true);
   if (rc) return rc;
@@ -1346,7 +1413,7 @@ int kge_eval_batch(const kge_tables* t, kge_index s, kge_index p, kge_index o, i
     rc = score_rank_core(t, S, O, P, TG, oi, si, n, 0, m, trueblk, true_po0, num_filters, nullptr, nullptr,
                          nullptr, nullptr, nullptr, nullptr, atol, rtol, counts, counts + per, counts + 2 * per,
                          counts + 3 * per, n, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream,
-                         tstride, /*manage_bits=*/false, /*queries_ready=*/ready);
+                         tstride, /*manage_bits=*/false, /*queries_ready=*/ready, band);
   // (4) bits cleared, tie policy + histograms, counters back to zero.  Behind a declined step (3) (counters untouched)
   // and behind ANY failure of steps (2) / (3): the bits are cleared and the counters zeroed all the same -- the buffers
   // are persistent and the next batch relies on finding them all-zero (advisor, round 3)
@@ -1749,6 +1816,25 @@ int kge_adagrad_step_multi(const kge_adagrad_seg* segs, int num_segs, void* stre
     if (g.bf16_copy && ((uintptr_t)g.bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
   }
   return run_adagrad_multi(segs, num_segs, (hipStream_t)stream);
+}
+
+int kge_adagrad_step_multi_penalty(const kge_adagrad_seg* segs, const kge_penalty_seg* pens, int num_segs,
+                                   void* stream) {
+  if (!pens) return kge_adagrad_step_multi(segs, num_segs, stream);
+  KGE_RANGE();
+  if (num_segs < 0 || num_segs > KGE_ADAGRAD_MAX_SEGS || (num_segs > 0 && !segs)) return KGE_ERR_INVALID_ARG;
+  for (int j = 0; j < num_segs; ++j) {
+    const kge_adagrad_seg& g = segs[j];
+    const kge_penalty_seg& q = pens[j];
+    if (g.count < 0 || (g.count > 0 && (!g.param || !g.grad || !g.state_sum))) return KGE_ERR_INVALID_ARG;
+    if (((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.state_sum) & 15) return KGE_ERR_INVALID_ARG;
+    if (g.bf16_copy && ((uintptr_t)g.bf16_copy & 7)) return KGE_ERR_INVALID_ARG;
+    if (q.kind < 0 || q.kind > 2) return KGE_ERR_INVALID_ARG;
+    if (q.kind != 0 && (!q.value || ((uintptr_t)q.value & 7))) return KGE_ERR_INVALID_ARG;
+    if (q.kind == 1 && (q.p < 1 || q.p > 3)) return KGE_ERR_UNSUPPORTED;
+    if (q.kind == 2 && (q.row_dim <= 0 || q.row_dim % 8 != 0 || g.count % q.row_dim != 0)) return KGE_ERR_INVALID_ARG;
+  }
+  return run_adagrad_multi_pen(segs, pens, num_segs, (hipStream_t)stream);
 }
 
 int kge_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count, float step_size,

@@ -521,8 +521,21 @@ struct V8RankArgs {
 
 // PROBE (builds with -DKGE_V8_PROBES only; KGE_V8R_PROBE picks one): timing variants that leave work out -- bit 0 the
 // comparisons, 1 the table pieces of the steady state, 2 the unit barrier, 3 the filter-word loads, 4 the LDS reads
-template <int SCORER, int HH, int SPLIT, int PROBE = 0>
+//
+// BAND (round 6): the first launch of band-and-rescore, the parity-compliant counts at close to the
+// single-pass price.  The fragments are the SPLIT set's (groups of 64 real rows [hi | hi | lo | lo]); the chains run on
+// the q_hi blocks only -- the single-pass score x_hi, the hi half of the split score x = fl(x_hi + x_lo) bit for bit.
+// |x - x_hi| <= |x_lo| + an ulp, |x_lo| <= ||q_lo_i|| max_j ||t_j|| (Cauchy-Schwarz; ||q_lo_i|| from the row's lo block
+// at the pair's start, the table's largest row norm from kge_table_max_row_norm), so with the row's tolerance widened
+// by that bound every score OUTSIDE the widened band is decided by x_hi as the split kernel decides it by x: greater
+// ones are counted here, smaller ones ignored.  Scores INSIDE the band (a trained model's true score sits in the far
+// tail of its row: ~2e-5 of the pairs, profiles/r5_band_fraction.txt) are not counted; the wave appends the tile --
+// (side, first row, 32-column sub-unit) + per row (band columns, filter words) -- to a list, and
+// pairs_bf16_rescore_kernel counts exactly those pairs with both chains.  The list append is an atomic and two stores
+// in a rarely taken branch: more vector-memory operations in flight only make the counted waits wait longer.
+template <int SCORER, int HH, int SPLIT, int PROBE = 0, int BAND = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a) {
+  static_assert(!BAND || !SPLIT, "the band launch runs the q_hi chains only");
   // A unit = NACC sub-units of 32 table rows, one accumulator each: one at d = 512, TWO at d = 256 (64 rows x 512
   // bytes: the same 32 KiB).  With two accumulators consecutive MFMAs are independent (A0 B0 A1 B1 ...): what stands
   // between them -- LDS reads, table pieces, word loads -- no longer breaks a back-to-back dependent issue (measured
@@ -668,9 +681,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     }
   };
   // the finished sub-unit `sub` of the unit at slice position `cu` into the counters; w0 / w1 = the row's filter words
-  auto rank_unit = [&](const f32x16& pv, int cu, int sub, unsigned int w0, unsigned int w1) __attribute__((always_inline)) {
+  // -> the lane's "close" columns of the sub-unit (BAND: the columns inside the widened band, which are NOT counted)
+  auto rank_unit = [&](const f32x16& pv, int cu, int sub, unsigned int w0, unsigned int w1, bool count_g = true)
+      __attribute__((always_inline)) -> unsigned int {
     unsigned int g, c;
-    if (rk_slow) {  // some row of the wave has an infinite true score / tolerance: the generic arithmetic
+    if (BAND && rk_slow) {  // no finite band for some row of the wave: every pair of the tile goes to the second launch
+      g = 0u;
+      c = 0x0f0f0f0fu;
+    } else if (rk_slow) {  // some row of the wave has an infinite true score / tolerance: the generic arithmetic
       g = c = 0u;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -704,17 +722,19 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
     if (rem < V8_UT) mine &= rem > 0 ? (1u << rem) - 1u : 0u;  // (the unit exists; its second sub-unit may not)
     g = (g << (4 * fh)) & mine;
     c = (c << (4 * fh)) & mine;
+    if (!count_g) return c;  // (BAND, behind rank_unit_raw: the greater ones are counted, the band's columns wanted)
     rk_g += __builtin_popcount(g);
-    rk_c += __builtin_popcount(c);
+    if constexpr (!BAND) rk_c += __builtin_popcount(c);
     const unsigned int ww[2] = {w0 & mine, w1 & mine};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       if (k < ce.rk_nfilt) {
         rk_fg[k] += __builtin_popcount(g & ww[k]);
-        rk_fc[k] += __builtin_popcount(c & ww[k]);
+        if constexpr (!BAND) rk_fc[k] += __builtin_popcount(c & ww[k]);
         rk_fn[k] += __builtin_popcount(ww[k]);
       }
     }
+    return c;
   };
   // The raw counts alone, for a sub-unit without a filtered column in any row of the wave (all but ~1 % of them on a
   // Wikidata5M shard): two compares and two carry-adds per score instead of seven operations.  x - t rounds
@@ -722,7 +742,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
   // rk_hi = the largest float with fl(rk_hi - t) <= allowed, rk_lo = the smallest with fl(rk_lo - t) >= -allowed
   // (found per row at the pair's start and CHECKED there -- a row whose thresholds do not verify sends its wave down
   // the generic path); NaN fails both compares like the -inf it stands for, +inf is greater, -inf nothing.
-  auto rank_unit_raw = [&](const f32x16& pv) __attribute__((always_inline)) {
+  auto rank_unit_raw = [&](const f32x16& pv) __attribute__((always_inline)) -> int {
     int g = 0, c2 = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -731,7 +751,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       c2 += x >= rk_lo ? 1 : 0;
     }
     rk_g += g;
-    rk_c += c2 - g;
+    if constexpr (!BAND) rk_c += c2 - g;
+    return c2 - g;  // (BAND: the lane's scores inside the widened band)
   };
   // the row's counters out (the two lanes fh = 0 / 1 of a row first), then zeroed
   auto rank_flush = [&]() __attribute__((always_inline)) {
@@ -847,7 +868,38 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
           const unsigned int wany = (ce.rk_nfilt > 0 ? wc[sub][0] : 0u) | (ce.rk_nfilt > 1 ? wc[sub][1] : 0u);
           const bool whole = ((long long)(u_lo + cu) * NT + sub + 1) * V8_UT <= m;
           const bool anyw = __any(wany != 0u) != 0;
-          if (!RAWFAST || rk_slow || !whole || anyw) rank_unit(sc, cu, sub, wc[sub][0], wc[sub][1]);
+          if constexpr (BAND) {
+            unsigned int cm;
+            if (!RAWFAST || rk_slow || !whole || anyw) {
+              cm = rank_unit(sc, cu, sub, wc[sub][0], wc[sub][1]);
+            } else {
+              const int nb = rank_unit_raw(sc);
+              cm = 0u;
+              if (__any(nb != 0) != 0) cm = rank_unit(sc, cu, sub, 0u, 0u, false);
+            }
+            if (orow_cur >= a.n) cm = 0u;  // (padded rows)
+            if (__any(cm != 0u) != 0) {
+              // the tile onto the list: header + one 16-byte record per row (its band columns, its filter words)
+              const unsigned int rowmask = cm | (unsigned int)__shfl_xor((int)cm, 32, 64);
+              unsigned int idx = 0u;
+              if (lane == 0) idx = atomicAdd(ce.rk_list_count, 1u);
+              idx = (unsigned int)__builtin_amdgcn_readfirstlane((int)idx);
+              if (idx < ce.rk_list_cap) {
+                u32x4* const e = ce.rk_list + (long long)idx * 33;
+                if (lane == 0) {
+                  const u32x4 h = {(unsigned int)side_cur, (unsigned int)(orow_cur - fi),
+                                   (unsigned int)((u_lo + cu) * NT + sub), 0u};
+                  e[0] = h;
+                }
+                if (fh == 0) {
+                  const u32x4 rec = {rowmask, ce.rk_nfilt > 0 ? wc[sub][0] : 0u, ce.rk_nfilt > 1 ? wc[sub][1] : 0u, 0u};
+                  e[1 + fi] = rec;
+                }
+              } else if (lane == 0) {
+                atomicAdd(ce.rk_status + 1, 1u);  // dropped: the caller must count this batch with the split kernel
+              }
+            }
+          } else if (!RAWFAST || rk_slow || !whole || anyw) rank_unit(sc, cu, sub, wc[sub][0], wc[sub][1]);
           else rank_unit_raw(sc);
           // This word is read by nobody else (every (row, sub-unit) of the batch belongs to one lane pair of one
           // workgroup): clear it here instead of in a launch behind the kernel.  Rare -- a few filtered columns per
@@ -879,6 +931,33 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       rk_t = ce.rk_true[side][orow * ce.rk_true_stride];
       if (rk_t != rk_t) rk_t = -__builtin_inff();
       rk_al = ce.rk_atol + __builtin_fabsf(ce.rk_rtol * rk_t);
+      // fragment group of this wave (see below)
+      int grp = (PARTS == 2 || BAND) ? 4 * ch + (wave >> 1) : 2 * ch + (wave >> 2);
+      if (grp >= a.rgn1) grp = a.rgn1 - 1;
+      grp += side * a.rgn1;
+      const unsigned char* const gbase = (const unsigned char*)(a.qf + (long long)grp * 4 * NKB * 64);
+      if constexpr (BAND) {
+        // ||q_lo|| of this lane's row from its lo block, then the widened tolerance: 1.001 covers the rounding of the
+        // norms and of the lo chain (K <= 512 products), 2^-21 (|t| + allowed + band) the rounding of x_hi + x_lo and
+        // of x - t near the band
+        const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(gbase + (2 + (wave & 1)) * (NKB * 1024)), 0, NKB * 1024, 0x00020000);
+        float n2 = 0.0f;
+#pragma unroll 4
+        for (int kb = 0; kb < NKB; ++kb) {
+          const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(lrs, lane * 16 + kb * 1024, 0, 0));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float f0 = __uint_as_float(v[e] << 16), f1 = __uint_as_float(v[e] & 0xffff0000u);
+            n2 += f0 * f0;
+            n2 += f1 * f1;
+          }
+        }
+        n2 += __shfl_xor(n2, 32, 64);
+        float band = 1.001f * (__builtin_sqrtf(n2) * ce.rk_tmax[0]);
+        band = band + 4.76837158203125e-7f * (__builtin_fabsf(rk_t) + rk_al + band);
+        rk_al = rk_al + band;
+      }
       bool fine = __builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al);
       if constexpr (RAWFAST) {  // the thresholds of rank_unit_raw: a start one rounding off at most, walked to the exact floats, then checked
         auto f2u = [](float x) { return __builtin_bit_cast(unsigned int, x); };
@@ -911,10 +990,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       // [hi 0-31 | hi 32-63 | lo 0-31 | lo 32-63]; DUP (d = 512): a chunk = two groups, a wave's 32 operand rows = the
       // q_hi and q_lo rows of 16 real rows; PARTS (d = 256): a chunk = FOUR groups, wave w takes the q_hi block w & 1
       // and the q_lo block 2 + (w & 1) of group w >> 1.
-      int grp = PARTS == 2 ? 4 * ch + (wave >> 1) : 2 * ch + (wave >> 2);
-      if (grp >= a.rgn1) grp = a.rgn1 - 1;
-      grp += side * a.rgn1;
-      const unsigned char* const gbase = (const unsigned char*)(a.qf + (long long)grp * 4 * NKB * 64);
+      // BAND: the split layout, of which this launch reads the q_hi block w & 1 of group w >> 1 (and the lo block's norm).
       v4_static_for<0, PARTS>([&](auto pc) __attribute__((always_inline)) {
         constexpr int part = decltype(pc)::value;
         unsigned int flo;
@@ -927,7 +1003,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
           frange = 4 * NKB * 1024;
         } else {
           flo = (unsigned int)(lane * 16);
-          fb = gbase + (PARTS == 2 ? 2 * part + (wave & 1) : (wave & 3)) * (NKB * 1024);
+          fb = gbase + ((PARTS == 2 || BAND) ? 2 * part + (wave & 1) : (wave & 3)) * (NKB * 1024);
           frange = NKB * 1024;
         }
         const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, frange, 0x00020000);
@@ -986,11 +1062,18 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
 // against the identity-indexed bf16 table TG (d in {256, 512}): ce carries the rk_* arguments.  KGE_ERR_UNSUPPORTED:
 // not this kernel's case (KGE_V8_RANK=0 declines everything: pairs_bf16_v4_kernel<V3_RANK>).
 int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, long long n, long long m, const void* qf,
-                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus) {
+                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus, bool band) {
+  // band: `qf` holds the SPLIT fragments, the launch runs their q_hi chains (single-pass geometry) and lists the tiles
+  // pairs_bf16_rescore_kernel has to finish (ce.rk_list*, ce.rk_tmax)
   if ((d != 512 && d != 256) || TG.idx.ptr != nullptr || qf == nullptr) return KGE_ERR_UNSUPPORTED;
+  if (band) {
+    if (!split || !ce.rk_list || !ce.rk_list_count || !ce.rk_status || !ce.rk_tmax || ce.rk_list_cap == 0)
+      return KGE_ERR_INVALID_ARG;
+    split = false;  // the geometry of the single-pass launch ...
+  }
   if (sw(SW_V8_RANK) == 0) return KGE_ERR_UNSUPPORTED;
   if (TG.ld * 2 >= (1LL << 28) || ((uintptr_t)qf & 15)) return KGE_ERR_UNSUPPORTED;
-  const long long rgr = split ? 64 : 128;
+  const long long rgr = (split || band) ? 64 : 128;  // ... on the split set's 64-row fragment groups
   const long long rgn1 = (n + rgr - 1) / rgr;
   const long long ut = (d == 256 && !split) ? 2 * V8_UT : V8_UT;  // table rows per unit (the kernel's NT sub-units of 32)
   const long long nunits = (m + ut - 1) / ut;
@@ -1005,7 +1088,7 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   a.m = m;
   a.rgn1 = (int)rgn1;
   a.sides = 2;
-  a.chunks = (int)(split && d == 256 ? (rgn1 + 3) / 4 : (rgn1 + 1) / 2);  // 256 rows (d = 512 split: 128) per chunk
+  a.chunks = (int)((split && d == 256) || band ? (rgn1 + 3) / 4 : (rgn1 + 1) / 2);  // 256 rows (d = 512 split: 128) per chunk
   a.nunits = (int)nunits;
   a.su = (int)((nunits + 7) / 8);
   a.wpx = cus / 8;
@@ -1028,13 +1111,16 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   }
 #endif
 #define KGE_V8R(SC, HHV, SP) hipLaunchKernelGGL((pairs_bf16_v8_rank_kernel<SC, HHV, SP>), grid, block, 0, st, a)
+#define KGE_V8RB(SC, HHV) hipLaunchKernelGGL((pairs_bf16_v8_rank_kernel<SC, HHV, 0, 0, 1>), grid, block, 0, st, a)
 #define KGE_V8R2(SC)                                                \
-  if (d == 512) { if (split) KGE_V8R(SC, 256, 1); else KGE_V8R(SC, 256, 0); } \
+  if (band) { if (d == 512) KGE_V8RB(SC, 256); else KGE_V8RB(SC, 128); } \
+  else if (d == 512) { if (split) KGE_V8R(SC, 256, 1); else KGE_V8R(SC, 256, 0); } \
   else { if (split) KGE_V8R(SC, 128, 1); else KGE_V8R(SC, 128, 0); }
   if (scorer == KGE_COMPLEX) { KGE_V8R2(KGE_COMPLEX) } else if (scorer == KGE_DISTMULT) { KGE_V8R2(KGE_DISTMULT) }
   else return KGE_ERR_UNSUPPORTED;
   __atomic_fetch_add(&g_v8_launches[1], 1, __ATOMIC_RELAXED);
 #undef KGE_V8R2
+#undef KGE_V8RB
 #undef KGE_V8R
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
@@ -1146,6 +1232,181 @@ int run_pairs_bf16_true(int scorer, bool split, const Operand& TG, int d, long l
   else return KGE_ERR_UNSUPPORTED;
 #undef KGE_V8T2
 #undef KGE_V8T
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// ---- Band-and-rescore, second launch: the pairs the band launch left undecided, counted with BOTH chains.
+// One wave per listed tile = 32 query rows x 32 consecutive table rows.  The wave copies the sub-unit's rows into LDS
+// in the units' swizzled layout (as pairs_bf16_true_kernel does for gathered rows), runs the q_hi chain and the q_lo
+// chain of its rows' split fragments -- each chain the K order and the instruction of pairs_bf16_v8_rank_kernel<SPLIT>,
+// so every score is fl(sum q_hi t) + fl(sum q_lo t), the bits that kernel counts -- and applies count_one to the
+// columns the list names, against the row's filter words that travelled with the entry.  Waves stride over the list;
+// the last workgroup to finish publishes the list length to the caller's status words and zeroes the counters for the
+// next call.
+struct V8RescoreArgs {
+  Operand TG;
+  long long n, m;
+  int rgn1;              // 64-row split fragment groups per side
+  const u32x4* qf;
+  CeArgs ce;
+  unsigned int* done;    // workgroups that have finished (zero between calls)
+};
+
+template <int HH>
+__global__ __launch_bounds__(256) void pairs_bf16_rescore_kernel(V8RescoreArgs a) {
+  constexpr int NKB = 2 * HH / 16, ROWB = 4 * HH, SPR = ROWB / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4][32 * ROWB];
+  __shared__ int sh_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fi = lane & 31, fh = lane >> 5;
+  const CeArgs& ce = a.ce;
+  unsigned int count = __hip_atomic_load(ce.rk_list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned int listed = count;
+  if (count > ce.rk_list_cap) count = ce.rk_list_cap;
+  unsigned char* const lds = smem[wave];
+  const unsigned char* const tgb = (const unsigned char*)a.TG.base;
+  const long long tld2 = a.TG.ld * 2;
+  for (unsigned int e = blockIdx.x * 4 + wave; e < count; e += gridDim.x * 4) {
+    const u32x4* const ent = ce.rk_list + (long long)e * 33;
+    const u32x4 h = ent[0];
+    const int side = (int)h[0];
+    const long long row0 = (long long)h[1];
+    const long long c0 = (long long)h[2] * 32;
+    const u32x4 rec = ent[1 + fi];
+    const long long lrow = row0 + fi;
+    const long long orow = lrow < a.n ? lrow : a.n - 1;
+    float t = ce.rk_true[side][orow * ce.rk_true_stride];
+    if (t != t) t = -__builtin_inff();
+    // ---- the sub-unit's 32 table rows (rows beyond the table repeat its last row: their columns are never named)
+#pragma unroll 4
+    for (int it = 0; it < 32 * SPR / 64; ++it) {
+      const int idx = it * 64 + lane, row = idx / SPR, c = idx % SPR;
+      long long tr = c0 + row;
+      if (tr >= a.m) tr = a.m - 1;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(tgb + tr * tld2 + c * 16);
+      *reinterpret_cast<u32x4*>(lds + row * ROWB + ((c ^ (row & 15)) << 4)) = v;
+    }
+    // ---- both chains (split fragment groups of 64 real rows: [hi 0-31 | hi 32-63 | lo 0-31 | lo 32-63])
+    long long grp = row0 >> 6;
+    if (grp >= a.rgn1) grp = a.rgn1 - 1;
+    const unsigned char* const gbase = (const unsigned char*)(a.qf + ((long long)side * a.rgn1 + grp) * 4 * NKB * 64);
+    const int blk = (int)((row0 >> 5) & 1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      const unsigned char* fb = gbase + (2 * part + blk) * (NKB * 1024) + lane * 16;
+      f32x16 ac = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(fb + kb * 1024);
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(lds + fi * ROWB + (((2 * kb + fh) ^ (fi & 15)) << 4));
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, af, ac, 0, 0, 0);
+      }
+      acc[part] = ac;
+    }
+    // ---- the named columns of this lane's row: element r = column 8 (r >> 2) + 4 fh + (r & 3) of the sub-unit
+    int G = 0, C = 0, FG[2] = {0, 0}, FC[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int bit = 8 * (r >> 2) + 4 * fh + (r & 3);
+      if (((rec[0] >> bit) & 1u) != 0u && c0 + bit < a.m) {
+        int g1 = 0, c1 = 0;
+        count_one(acc[0][r] + acc[1][r], t, ce.rk_atol, ce.rk_rtol, g1, c1);
+        G += g1;
+        C += c1;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k < ce.rk_nfilt && ((rec[1 + k] >> bit) & 1u) != 0u) {
+            FG[k] += g1;
+            FC[k] += c1;
+          }
+      }
+    }
+    G += __shfl_xor(G, 32, 64);
+    C += __shfl_xor(C, 32, 64);
+    const bool wr = fh == 0 && lrow < a.n;
+    unsigned long long* rank = ce.rk_rank[side] + lrow;
+    unsigned long long* ties = ce.rk_ties[side] + lrow;
+    if (wr && G != 0) atomicAdd(rank, (unsigned long long)G);
+    if (wr && C != 0) atomicAdd(ties, (unsigned long long)C);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k < ce.rk_nfilt) {
+        const int fg = FG[k] + __shfl_xor(FG[k], 32, 64), fc = FC[k] + __shfl_xor(FC[k], 32, 64);
+        // (a filtered column inside the band leaves the filtered ranking: the first launch has added "-inf is close
+        // to a true score of -inf" for ALL filtered columns already)
+        if (wr && G - fg != 0) atomicAdd(rank + (k + 1) * ce.rk_ld, (unsigned long long)(long long)(G - fg));
+        if (wr && C - fc != 0) atomicAdd(ties + (k + 1) * ce.rk_ld, (unsigned long long)(long long)(C - fc));
+      }
+    }
+  }
+  // ---- the last workgroup: list length out, counters back to zero
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    sh_last = atomicInc(a.done, gridDim.x - 1) == gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (sh_last != 0 && threadIdx.x == 0) {
+    ce.rk_status[0] = listed;
+    atomicAdd(ce.rk_status + 2, 1u);
+    __hip_atomic_store(ce.rk_list_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+int run_pairs_bf16_rescore(const Operand& TG, int d, long long n, long long m, const void* qf, const CeArgs& ce,
+                           unsigned int* done, hipStream_t st) {
+  if ((d != 512 && d != 256) || TG.idx.ptr != nullptr || qf == nullptr || ((uintptr_t)qf & 15)) return KGE_ERR_UNSUPPORTED;
+  V8RescoreArgs a{};
+  a.TG = TG;
+  a.n = n;
+  a.m = m;
+  a.rgn1 = (int)((n + 63) / 64);
+  a.qf = (const u32x4*)qf;
+  a.ce = ce;
+  a.done = done;
+  // four tiles in flight per workgroup; enough workgroups to cover a long list several deep, few enough that an empty
+  // list costs a launch and nothing else
+  const dim3 grid(1024), block(256);
+  if (d == 512) hipLaunchKernelGGL((pairs_bf16_rescore_kernel<256>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((pairs_bf16_rescore_kernel<128>), grid, block, 0, st, a);
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// ---- kge_table_max_row_norm: the largest Euclidean row norm of a bf16 table, x 1.001 (the rounding of the sums), as
+// one float -- the table-wide factor of the band's Cauchy-Schwarz bound.  One wave per row, float atomicMax on the
+// bits (norms are >= 0: the integer order is the float order); `out` zeroed by the launcher's fill.
+__global__ __launch_bounds__(256) void table_max_norm_kernel(Operand TG, long long m, int d, unsigned int* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  float best = 0.0f;
+  for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < m; row += (long long)gridDim.x * 4) {
+    const unsigned short* p = (const unsigned short*)TG.base + row * TG.ld;
+    float s2 = 0.0f;
+    for (int c = lane * 8; c < d; c += 512) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(p + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float f0 = __uint_as_float(v[e] << 16), f1 = __uint_as_float(v[e] & 0xffff0000u);
+        s2 += f0 * f0;
+        s2 += f1 * f1;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s2 += __shfl_xor(s2, off, 64);
+    float nrm = 1.001f * __builtin_sqrtf(s2);
+    if (nrm != nrm) nrm = __builtin_inff();  // a NaN in the table: no finite band
+    best = fmaxf(best, nrm);
+  }
+  if (lane == 0) atomicMax(out, __float_as_uint(best));
+}
+
+int run_table_max_norm(const Operand& TG, long long m, int d, float* out, hipStream_t st) {
+  if (TG.idx.ptr != nullptr || (d % 8) != 0 || (TG.ld % 8) != 0 || ((uintptr_t)TG.base & 15)) return KGE_ERR_UNSUPPORTED;
+  if (!fill_words_async(out, 0, sizeof(float), st)) return KGE_ERR_LAUNCH;
+  if (m <= 0) return KGE_OK;
+  long long blocks = (m + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(table_max_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, TG, m, d, (unsigned int*)out);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 

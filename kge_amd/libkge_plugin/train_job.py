@@ -51,12 +51,77 @@ def _optimizer_is_capturable(opt) -> bool:
 
 
 def _no_penalty(job, batch_index, batch) -> bool:
-    """A penalty term back-propagates between the batch and the optimizer's step: such a job stays eager."""
+    """A penalty term back-propagates between the batch and the optimizer's step: such a job stays eager -- unless the
+    terms are folded into the optimizer's pass (_fold_penalties)."""
+    if getattr(job, "_folded_penalties", None):
+        return True
     try:
         return len(job.model.penalty(epoch=job.epoch, batch_index=batch_index, num_batches=len(job.loader),
                                      batch=batch)) == 0
     except Exception:
         return False
+
+
+def _fold_penalties(job) -> bool:
+    """The embedders' UNWEIGHTED Lp / N3 penalty terms (lookup_embedder.py:122-147 through KgeModel.penalty,
+    kge_model.py:603-649) folded into HipAdagrad's pass: their gradient is a function of the element alone, so the
+    optimizer adds it in registers and sums the term's value on the way (kge_adagrad_step_multi_penalty).  A step taken
+    inside `_process_batch` (a GraphedStep, replayed or eager) then carries the penalty; TrainingJob.run_epoch still
+    calls `model.penalty()` afterwards, back-propagates what it gets and writes the values to the trace
+    (train.py:417-436): it gets leaf scalars holding the values the step computed -- their backward is a no-op.  A
+    batch whose step was NOT taken yet (subbatches, a declined fused loss) gets the reference's terms and the
+    optimizer skips its folded ones for that step.
+
+    -> True if every term of this model is folded (the job may capture its step), False if the model has no foldable
+    shape (weighted terms, other embedders, other regularizers, another optimizer): nothing is changed then."""
+    from kge.model import KgeModel, LookupEmbedder
+    from ..optim import Adagrad as HipAdagrad
+    model, opt = job.model, job.optimizer
+    if getattr(job, "_folded_penalties", None) is not None:
+        return bool(job._folded_penalties)
+    job._folded_penalties = []
+    from .models import _FusedScoring  # (its penalty() is KgeModel.penalty behind a shortcut for "no terms")
+    if not isinstance(opt, HipAdagrad) or type(model).penalty not in (KgeModel.penalty, _FusedScoring.penalty):
+        return False
+    pe, se, oe = model.get_p_embedder(), model.get_s_embedder(), model.get_o_embedder()
+    plan = []
+    for emb, times in ((pe, 1.0),) + (((se, 2.0),) if se is oe else ((se, 1.0), (oe, 1.0))):
+        if type(emb).penalty is not LookupEmbedder.penalty:
+            return False
+        if emb.regularize == "" or emb.get_option("regularize_weight") == 0.0:
+            continue
+        if emb.regularize not in ("lp", "n3") or emb.get_option("regularize_args.weighted"):
+            return False
+        if emb.regularize == "n3":
+            p, kind = 3, ("n3_complex" if emb.space == "complex" else "lp")
+        else:
+            p = emb.get_option("regularize_args.p") if emb.has_option("regularize_args.p") else 2
+            kind = "lp"
+        if p not in (1, 2, 3) or float(p) != int(p):
+            return False
+        w = emb._embeddings.weight
+        if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            return False
+        if kind == "n3_complex" and w.shape[1] % 8 != 0:
+            return False
+        if not any(w is q for g in opt.param_groups for q in g["params"]):
+            return False
+        plan.append((emb, w, kind, int(p), float(emb._get_regularize_weight()), times))
+    if not plan:
+        return False  # (nothing to fold: _no_penalty's own check decides)
+    for emb, w, kind, p, weight, times in plan:
+        opt.set_penalty(w, kind, p, weight, times)
+    job._folded_penalties = plan
+    reference_penalty = model.penalty
+
+    def penalty(**kwargs):
+        if job._skip_optimizer_step:  # the step -- with the terms' gradient in it -- is taken: hand over its values
+            return [(f"{emb.configuration_key}.L{p}_penalty", opt.penalty_value(w).detach().requires_grad_(True))
+                    for emb, w, kind, p, weight, times in plan]
+        opt.skip_penalties_once()
+        return reference_penalty(**kwargs)
+    model.penalty = penalty
+    return True
 
 
 def _graphed_step_of(job, loss_fn):
@@ -127,7 +192,8 @@ class HipTrainingJob1vsAll(_CudaOomText, TrainingJob1vsAll):
         if self._graph_step_ok is None:
             ok = bool(self.config.get_default("hip_1vsAll.graph_step")) and str(self.device).startswith("cuda")
             ok = ok and _model_takes_fused_loss(self.model) and hasattr(self.model, "loss_sp_po")
-            ok = ok and _optimizer_is_capturable(self.optimizer) and _no_penalty(self, batch_index, batch)
+            ok = ok and _optimizer_is_capturable(self.optimizer)
+            ok = ok and (_fold_penalties(self) or _no_penalty(self, batch_index, batch))
             self._graph_step_ok = ok
             if ok:
                 # the batch goes in as ONE tensor (one copy into the static buffer per replay, not three); the captured
@@ -445,7 +511,8 @@ class HipTrainingJobNegativeSampling(_CudaOomText, TrainingJobNegativeSampling):
             # losses that are launches only: the kl loss (log_softmax + kl_div), plain bce, the one-kernel bce stand-ins
             ok = ok and (isinstance(self.loss, (KLDivWithSoftmaxKgeLoss, _HipNsBceLoss))
                          or (isinstance(self.loss, BCEWithLogitsKgeLoss) and self.loss._bce_type is None))
-            ok = ok and _optimizer_is_capturable(self.optimizer) and _no_penalty(self, batch_index, batch)
+            ok = ok and _optimizer_is_capturable(self.optimizer)
+            ok = ok and (_fold_penalties(self) or _no_penalty(self, batch_index, batch))
             self._graph_step_ok, self._graph_slots = ok, slots
             if ok:
                 self._graph_step = _graphed_step_of(self, self._graph_loss)

@@ -53,6 +53,50 @@ class Adagrad(_TorchAdagrad):
         super().__init__(params, lr=lr, lr_decay=lr_decay, weight_decay=weight_decay,
                          initial_accumulator_value=initial_accumulator_value, eps=eps, foreach=False, **kw)
         self.bf16_copies = bool(bf16_copies)
+        self._penalties = {}       # parameter -> (kind, p, gradient factor, row_dim, value factor)
+        self._pen_acc = {}         # device -> float64 accumulators, one per parameter with a penalty
+        self._pen_slot = {}        # parameter -> index into its device's accumulators
+        self._pen_off_once = False
+
+    # ---- the embedders' unweighted penalty terms inside the step (kge_adagrad_step_multi_penalty) ------------------
+    def set_penalty(self, param, kind: str, p: int, weight: float, times: float = 1.0):
+        """From now on every step() adds to `param`'s gradient the gradient of
+            times * weight / p * sum |x|^p                      kind "lp", p in (1, 2, 3)
+            times * weight / 3 * sum |z|^3 over complex coordinates   kind "n3_complex" (z = row[c] + i row[c + dim / 2])
+        (LookupEmbedder.penalty unweighted, lookup_embedder.py:122-147; `times` = 2 for an entity embedder that serves the
+        subject and the object slot, kge_model.py:620-625) inside the update's own pass, and `penalty_value(param)`
+        holds the term's value at the parameters the step started from.  The caller must then NOT back-propagate the
+        term itself.  kind None removes it."""
+        if kind is None:
+            self._penalties.pop(param, None)
+        else:
+            if kind not in ("lp", "n3_complex") or (kind == "lp" and p not in (1, 2, 3)):
+                raise ValueError(f"kge_amd.optim.Adagrad: no fused form of penalty {kind} p={p}")
+            if not (param.is_cuda and param.dtype == torch.float32 and param.is_contiguous()):
+                raise ValueError("kge_amd.optim.Adagrad: fused penalties are for dense float32 GPU parameters")
+            if kind == "n3_complex":
+                p = 3
+                if param.dim() != 2 or param.shape[1] % 8 != 0:
+                    raise ValueError("kge_amd.optim.Adagrad: n3_complex needs a [*, dim] table with dim % 8 == 0")
+            self._penalties[param] = (1 if kind == "lp" else 2, int(p), float(times) * float(weight),
+                                      int(param.shape[-1]), float(times) * float(weight) / float(p))
+        self._pen_acc, self._pen_slot = {}, {}
+        for q in self._penalties:
+            acc = self._pen_acc.get(q.device)
+            self._pen_slot[q] = 0 if acc is None else acc.numel()
+            self._pen_acc[q.device] = torch.zeros(self._pen_slot[q] + 1, dtype=torch.float64, device=q.device)
+
+    def has_penalties(self) -> bool:
+        return bool(self._penalties)
+
+    def skip_penalties_once(self):
+        """The next step() is the plain update (the caller back-propagated the terms itself for that batch)."""
+        self._pen_off_once = True
+
+    def penalty_value(self, param) -> torch.Tensor:
+        """0-d float32 device tensor: the term's value the LAST step() saw (pre-step parameters)."""
+        spec = self._penalties[param]
+        return (self._pen_acc[param.device][self._pen_slot[param]] * spec[4]).to(torch.float32)
 
     @staticmethod
     def _kernel_ok(p: torch.Tensor) -> bool:
@@ -136,17 +180,38 @@ class Adagrad(_TorchAdagrad):
                                          float(group["weight_decay"]), float(group["eps"]))
                 dense.setdefault(p.device, []).append((p, copy, seg))
             if rest:  # torch's own update for everything else
+                if any(p in self._penalties for p in rest) and not self._pen_off_once:
+                    raise RuntimeError("kge_amd.optim.Adagrad: a parameter with a fused penalty left the kernel path")
                 grads = [p.grad for p in rest]
                 sums = [self.state[p]["sum"] for p in rest]
                 steps = [self.state[p]["step"] for p in rest]
                 _functional_adagrad(rest, grads, sums, steps, has_sparse_grad=any(g.is_sparse for g in grads),
                                     foreach=False, lr=group["lr"], weight_decay=group["weight_decay"],
                                     lr_decay=group["lr_decay"], eps=group["eps"], maximize=False)
+        with_pen = bool(self._penalties) and not self._pen_off_once
+        self._pen_off_once = False
+        if with_pen:
+            for acc in self._pen_acc.values():
+                acc.zero_()  # (a fill kernel: captured with the step)
         for device, items in dense.items():
             with torch.cuda.device(device):
                 for i in range(0, len(items), _lib.ADAGRAD_MAX_SEGS):
                     chunk = items[i:i + _lib.ADAGRAD_MAX_SEGS]
                     segs = (_lib.KgeAdagradSeg * len(chunk))(*(c[2] for c in chunk))
+                    if with_pen and any(c[0] in self._penalties for c in chunk):
+                        pens = []
+                        for c in chunk:
+                            spec = self._penalties.get(c[0])
+                            if spec is None:
+                                pens.append(_lib.KgePenaltySeg(0, 0, 0.0, 0, None))
+                            else:
+                                acc = self._pen_acc[device]
+                                pens.append(_lib.KgePenaltySeg(spec[0], spec[1], spec[2], spec[3],
+                                                               acc.data_ptr() + 8 * self._pen_slot[c[0]]))
+                        _lib.check(_lib.lib().kge_adagrad_step_multi_penalty(
+                            segs, (_lib.KgePenaltySeg * len(chunk))(*pens), len(chunk), engine._stream(device)),
+                            "kge_adagrad_step_multi_penalty")
+                        continue
                     _lib.check(_lib.lib().kge_adagrad_step_multi(segs, len(chunk), engine._stream(device)),
                                "kge_adagrad_step_multi")
             for p, copy, _seg in items:

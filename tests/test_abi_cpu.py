@@ -193,6 +193,18 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 9)(*[seg(None, 0)] * 9), 9, None) == -1   # at most 8 segments
     assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 2)(seg(None, 0), seg(20, 8)), 2, None) == -1  # misaligned
     assert lib.kge_adagrad_step_multi((KgeAdagradSeg * 2)(seg(None, 0), seg(None, 0)), 2, None) == 0  # nothing to do
+    # ... with folded penalty terms: kind / exponent / accumulator / complex-row geometry are checked before any launch
+    from kge_amd._lib import KgePenaltySeg
+    import ctypes as _ct
+    assert _ct.sizeof(KgePenaltySeg) == 32 and KgePenaltySeg.row_dim.offset == 16 and KgePenaltySeg.value.offset == 24
+    one = lambda pen: lib.kge_adagrad_step_multi_penalty((KgeAdagradSeg * 1)(seg(16, 64)), (KgePenaltySeg * 1)(pen), 1, None)
+    assert lib.kge_adagrad_step_multi_penalty(None, None, 0, None) == 0
+    assert one(KgePenaltySeg(3, 2, 0.1, 0, 8)) == -1          # unknown kind
+    assert one(KgePenaltySeg(1, 2, 0.1, 0, None)) == -1       # no accumulator
+    assert one(KgePenaltySeg(1, 2, 0.1, 0, 12)) == -1         # misaligned accumulator
+    assert one(KgePenaltySeg(1, 4, 0.1, 0, 8)) == -2          # exponent outside 1..3: unsupported
+    assert one(KgePenaltySeg(2, 3, 0.1, 12, 8)) == -1         # complex rows: row_dim % 8 != 0
+    assert one(KgePenaltySeg(2, 3, 0.1, 48, 8)) == -1         # ... count not a multiple of row_dim
     # both query types of a KvsAll batch in one backward: unsupported tables, unknown loss, missing pieces
     from kge_amd._lib import KgeLabelQueries
     lq = lambda n, lse=16: KgeLabelQueries(good, good, n, 16, 16, lse, None, 1.0, None)

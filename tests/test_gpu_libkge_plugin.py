@@ -114,6 +114,7 @@ def _train_epoch(root, folder, tag, model, train_type="1vsAll", dim=512, opts=No
     if before_epoch is not None:
         before_epoch(job)
     trace = job.run_epoch()
+    job.last_epoch_trace = trace
     if DEVICE != "cpu":
         torch.cuda.synchronize()
     job.first_epoch_seconds = trace.get("epoch_time", float("nan"))
@@ -730,3 +731,51 @@ def test_b3_negative_sampling_step_as_one_hipgraph(data, model, loss):
          seconds_eager=_second_epoch_seconds(eag))
     assert _rel(l_gra, l_eag) <= 1e-5, (l_gra, l_eag)
     assert _rel(l_gra, l_ref) <= 1e-4, (l_gra, l_ref)
+
+
+@pytest.mark.parametrize("regularize,space,weights", [("lp", "euclidean", (0.8e-7, 0.8e-7)), ("lp", "euclidean", (2e-4, 5e-3)),
+                                                      ("lp3", "euclidean", (2e-4, 5e-3)), ("n3", "complex", (2e-4, 5e-3))])
+def test_l_unweighted_penalty_terms_stay_on_the_captured_step(data, regularize, space, weights):
+    """BASELINE configs[0] (examples/toy-complex-train.yaml) sets lookup_embedder.regularize_weight 0.8e-7: an unweighted
+    L2 term over both tables, back-propagated by TrainingJob.run_epoch between the batch and optimizer.step()
+    (kge/job/train.py:417-436, lookup_embedder.py:122-147, kge_model.py:603-649).  Until round 6 any penalty switched
+    hip_1vsAll.graph_step off.  Now HipAdagrad folds the terms into its pass (kge_adagrad_step_multi_penalty) and the
+    captured step carries them: the job replays, the trace shows the reference's penalty values, and the parameters
+    follow the reference job (complex + 1vsAll + torch Adagrad, the terms through autograd) at the bf16-scoring bar of
+    test a and the eager hip_1vsAll job (the reference's autograd terms on the same kernels) at float rounding; also at
+    weights where the terms move the parameters, L3, and N3 over complex coordinates (lookup_embedder.space complex)."""
+    if DEVICE == "cpu":
+        pytest.skip("needs the GPU")
+    root, folder = data
+    tag = f"{regularize}_{space}_{weights[0]}"
+    pen = {"lookup_embedder.regularize": regularize[:2], "lookup_embedder.space": space,
+           "lookup_embedder.regularize_args.p": 3 if regularize == "lp3" else 2, "complex.entity_embedder.regularize_weight": weights[0],
+           "complex.relation_embedder.regularize_weight": weights[1]}
+    ref, l_ref, st = _train_epoch(root, folder, f"l_ref_{tag}", "complex", opts=pen)
+    hpen = {k.replace("complex.", "hip_complex."): v for k, v in pen.items()}
+    hpen.update({"train.optimizer.default.type": "HipAdagrad", "hip_complex.score_dtype": "bfloat16",
+                 "train.optimizer.default.args.bf16_copies": True})
+    gra, l_gra, _ = _train_epoch(root, folder, f"l_graph_{tag}", "hip_complex", "hip_1vsAll", opts=hpen, init_from=st)
+    eag, l_eag, _ = _train_epoch(root, folder, f"l_eager_{tag}", "hip_complex", "hip_1vsAll", init_from=st,
+                                 opts=dict(hpen, **{"hip_1vsAll.graph_step": False}))
+    gs = gra._graph_step
+    assert gs is not None and gs.disabled_reason is None and gs.replays >= 90 and gs.captures == 1, vars(gs)
+    assert gra.optimizer.has_penalties() and len(gra._folded_penalties) == 2
+    assert eag._graph_step is None and not eag.optimizer.has_penalties()   # the eager job: the reference's autograd terms
+    tr_ref, tr_gra, tr_eag = (j.last_epoch_trace for j in (ref, gra, eag))
+    # (the keys carry the model's configuration key: complex.entity_embedder.L2_penalty / hip_complex.entity_...)
+    tr_ref, tr_gra, tr_eag = (dict(tr, avg_penalties={k.split(".", 1)[1]: v for k, v in tr["avg_penalties"].items()})
+                              for tr in (tr_ref, tr_gra, tr_eag))
+    keys = sorted(tr_ref["avg_penalties"])
+    assert keys == sorted(tr_gra["avg_penalties"]) == sorted(tr_eag["avg_penalties"]) and len(keys) == 2, (keys, tr_gra["avg_penalties"])
+    assert [k_[2] for k_ in gra._folded_penalties] == ["n3_complex" if (regularize, space) == ("n3", "complex") else "lp"] * 2
+    _log(case=f"l: hip_1vsAll.graph_step with unweighted {regularize} ({space}) penalties {weights} folded into HipAdagrad",
+         loss_ref=l_ref, loss_graph=l_gra, loss_eager=l_eag, penalties_ref=tr_ref["avg_penalties"],
+         penalties_graph=tr_gra["avg_penalties"], penalties_eager=tr_eag["avg_penalties"], replays=gs.replays,
+         param_rel_diff_graph_vs_eager=_param_diff(gra, eag), param_rel_diff_graph_vs_ref=_param_diff(gra, ref))
+    for k in keys:   # the trace's penalty values: the folded ones against autograd on the same kernels, and the reference
+        assert _rel(tr_gra["avg_penalties"][k], tr_eag["avg_penalties"][k]) <= 1e-5 * max(1.0, abs(tr_eag["avg_penalties"][k]))
+        assert abs(tr_gra["avg_penalties"][k] - tr_ref["avg_penalties"][k]) <= 2e-2 * abs(tr_ref["avg_penalties"][k])
+    assert _rel(l_gra, l_eag) <= 1e-5, (l_gra, l_eag)
+    assert _param_diff(gra, eag) <= 1e-4
+    assert _rel(l_gra, l_ref) <= 1e-2 and _param_diff(gra, ref) <= 5e-2   # (bf16 scoring: the bar of test a)

@@ -246,3 +246,56 @@ def test_adagrad_row_sparse_step_refreshes_a_stale_bf16_copy():
     sparse_step()
     c = bf16_copy_of(emb.weight)
     assert c is not None and torch.equal(c, emb.weight.detach().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("kind,p", [("lp", 2), ("lp", 1), ("lp", 3), ("n3_complex", 3)])
+def test_adagrad_with_folded_penalty_equals_backpropagating_the_reference_term(kind, p):
+    """kge_adagrad_step_multi_penalty: the unweighted penalty of LookupEmbedder.penalty
+    (kge/model/embedder/lookup_embedder.py:122-147: weight / p * norm(p) ** p, n3 over sqrt(re^2 + im^2 + 1e-14); the entity
+    table's term doubled, kge_model.py:620-625) added to the gradient inside the update's pass == torch autograd of the
+    term followed by the plain step; the value the pass sums == the term (of the pre-step parameters)."""
+    from kge_amd.optim import Adagrad
+    torch.manual_seed(3)
+    shapes = [(1003, 64), (37, 64)]      # "entity" table (times 2), "relation" table; the first has a scalar tail for lp
+    weights = [0.013, 0.4]
+    times = [2.0, 1.0]
+    ref = [torch.randn(s, device=DEV).requires_grad_(True) for s in shapes]
+    with torch.no_grad():
+        ref[0][5, :8] = 0.0              # exact zeros: sign(0) = 0, |z| = 1e-7
+    got = [r.detach().clone().requires_grad_(True) for r in ref]
+    o_ref = Adagrad(ref, lr=0.1, bf16_copies=True)
+    o_got = Adagrad(got, lr=0.1, bf16_copies=True)
+    for g, w, t in zip(got, weights, times):
+        o_got.set_penalty(g, kind, p, w, t)
+
+    def term(x, w, t):
+        if kind == "n3_complex":
+            re, im = (c.contiguous() for c in x.chunk(2, dim=1))
+            x = torch.sqrt(re ** 2 + im ** 2 + 1e-14)
+        return (w / p * x.norm(p=p) ** p).sum() * t
+    for step in range(3):
+        for r, g in zip(ref, got):
+            grad = torch.randn_like(r) * 0.1
+            r.grad, g.grad = grad.clone(), grad.clone()
+        values = []
+        for r, w, t in zip(ref, weights, times):
+            v = term(r, w, t)
+            v.backward()
+            values.append(float(v))
+        o_ref.step()
+        o_got.step()
+        for r, g, v in zip(ref, got, values):
+            torch.testing.assert_close(g.detach(), r.detach(), rtol=1e-5, atol=2e-6)
+            assert abs(float(o_got.penalty_value(g)) - v) <= 2e-6 * abs(v)
+        for sr, sg in zip(o_ref.state.values(), o_got.state.values()):
+            torch.testing.assert_close(sg["sum"], sr["sum"], rtol=1e-5, atol=1e-9)
+    # the plain step on request (the caller back-propagated the term itself), the terms again afterwards
+    for r, g in zip(ref, got):
+        grad = torch.randn_like(r) * 0.1
+        r.grad, g.grad = grad.clone(), grad.clone()
+    o_got.skip_penalties_once()
+    o_ref.step()
+    o_got.step()
+    for r, g in zip(ref, got):
+        torch.testing.assert_close(g.detach(), r.detach(), rtol=1e-5, atol=2e-6)
+    assert o_got._pen_off_once is False

@@ -36,7 +36,29 @@ CASES = {
     "negative_sampling-rotate-bce": ("hip_rotate", 16, "hip_sharded_negative_sampling", "negative_sampling",
                                      {"negative_sampling.num_samples.s": 6, "negative_sampling.num_samples.o": 6,
                                       "negative_sampling.implementation": "triple", "train.loss": "bce"}),
+    # ---- penalty terms (round 6; VERDICT r5 "e-plugin": BASELINE configs[0] sets regularize_weight 0.8e-7) ----
+    # the options of the reference's examples/toy-complex-train.yaml (unweighted L2 at 0.8e-7, normal_ initialisation,
+    # ReduceLROnPlateau) against the REFERENCE's own model and job
+    "1vsAll-complex-toy-yaml": ("complex", 16, "hip_sharded_1vsAll", "1vsAll", {
+        "lookup_embedder.regularize_weight": 0.8e-7, "lookup_embedder.initialize": "normal_",
+        "lookup_embedder.initialize_args.normal_.mean": 0.0, "lookup_embedder.initialize_args.normal_.std": 0.1,
+        "train.lr_scheduler": "ReduceLROnPlateau", "train.lr_scheduler_args.mode": "max",
+        "train.lr_scheduler_args.patience": 4}),
+    # unweighted L3 at weights where the terms move the parameters (entity term doubled: kge_model.py:620-625)
+    "1vsAll-distmult-l3": ("distmult", 16, "hip_sharded_1vsAll", "1vsAll", {
+        "lookup_embedder.regularize_args.p": 3, "distmult.entity_embedder.regularize_weight": 0.02,
+        "distmult.relation_embedder.regularize_weight": 0.3}),
+    # weighted N3 over complex coordinates (what LibKGE's tuned ComplEx configs use): the batch's unique rows x counts
+    "KvsAll-complex-n3-weighted": ("complex", 16, "hip_sharded_KvsAll", "KvsAll", {
+        "train.loss": "kl", "lookup_embedder.space": "complex", "lookup_embedder.regularize": "n3",
+        "lookup_embedder.regularize_args.weighted": True, "complex.entity_embedder.regularize_weight": 0.5,
+        "complex.relation_embedder.regularize_weight": 0.8}),
+    "negative_sampling-transe-l2-weighted": ("transe", 16, "hip_sharded_negative_sampling", "negative_sampling", {
+        "negative_sampling.num_samples.s": 7, "negative_sampling.num_samples.o": 5,
+        "negative_sampling.implementation": "triple", "lookup_embedder.regularize_args.weighted": True,
+        "transe.entity_embedder.regularize_weight": 0.4, "transe.relation_embedder.regularize_weight": 0.1}),
 }
+PENALTY_CASES = [c for c in CASES if any("regularize" in k for k in CASES[c][4])]
 
 
 
@@ -110,6 +132,8 @@ def _run(config, folder, like_sharded_seeding=False):
     job = Job.create(config, dataset)
     losses = []
     job.post_epoch_hooks.append(lambda j: losses.append(j.current_trace["epoch"]["avg_loss"]))
+    job.penalty_trace = []   # per epoch: {key: average value} as the trace shows it (train.py:417-436, 497-499)
+    job.post_epoch_hooks.append(lambda j: j.penalty_trace.append(dict(j.current_trace["epoch"]["avg_penalties"])))
     if like_sharded_seeding:
         # the sharded jobs draw ONE number from rank 0's torch generator at job creation and seed the process-wide
         # generators at the start of every epoch from it and the epoch (sharded_job._seed_epoch): the same draw and
@@ -188,7 +212,7 @@ def _worker(rank, world, port, tmp, case, q):
             assert sa["sum"].shape == sb["sum"].shape and torch.allclose(sa["sum"], sb["sum"], rtol=0, atol=0)
         ck = os.path.join(config.folder, "checkpoint_00002.pt")
         q.put((rank, losses, [{k: v for k, v in t.items() if isinstance(v, (int, float))} for t in valid],
-               {k: v.numpy() for k, v in state.items()}, os.path.exists(ck), ck))
+               {k: v.numpy() for k, v in state.items()}, os.path.exists(ck), ck, job.penalty_trace))
     finally:
         if dist.is_initialized():
             _quiet_teardown()
@@ -224,8 +248,14 @@ def test_sharded_jobs_through_job_create_equal_the_unsharded_plugin_jobs(case, t
     assert len(outs) == world
     outs.sort(key=lambda x: x[0])
     assert len(l_ref) == 2 and len(v_ref) == 2
-    for rank, losses, valid, state, has_ck, ck in outs:
+    for rank, losses, valid, state, has_ck, ck, pens in outs:
         np.testing.assert_allclose(losses, l_ref, rtol=2e-5, atol=1e-6)
+        # the penalty terms of the trace: every shard's part summed == the reference's value over the whole table
+        assert len(pens) == len(job_ref.penalty_trace) == 2
+        for got, want in zip(pens, job_ref.penalty_trace):
+            assert sorted(got) == sorted(want) and (len(want) == 2) == (case in PENALTY_CASES), (got, want)
+            for k in want:
+                assert abs(got[k] - want[k]) <= 2e-5 * abs(want[k]) + 1e-12, (rank, k, got[k], want[k])
         assert len(valid) == 2
         for got, want in zip(valid, v_ref):
             keys = [k for k in want if k.startswith(("mean_", "hits_at_")) and isinstance(want[k], (int, float))]
@@ -245,11 +275,50 @@ def test_sharded_jobs_through_job_create_equal_the_unsharded_plugin_jobs(case, t
     assert opt_state[0]["sum"].shape == (E, dim)
     np.testing.assert_allclose(opt_state[0]["sum"].numpy(), job_ref.optimizer.state_dict()["state"][0]["sum"].numpy(),
                                rtol=2e-4, atol=1e-7)
+    if case in PENALTY_CASES:
+        assert all(v > 0 for v in job_ref.penalty_trace[-1].values())
     new = _config(tmp, "resumed", model, dim, plain_type, "hip_entity_ranking", extra)
     resumed = Job.create_from(checkpoint, new_config=new, dataset=job_ref.dataset)
     assert resumed.epoch == 2 and type(resumed).__name__ == type(job_ref).__name__
     for k, v in s_ref.items():
         np.testing.assert_allclose(resumed.model.state_dict()[k].numpy(), v.numpy(), rtol=2e-4, atol=5e-5)
+
+
+def test_one_shard_job_with_embedder_dropout_equals_the_reference_job(tmp_path):
+    """Embedder dropout under hip_sharded_1vsAll / hip_sharded_KvsAll (lookup_embedder.py:64-69, 102-105): with ONE
+    shard the masks are drawn from the process's generator in the reference's order (kge_model.py:682-725: s rows, p
+    rows, all entities for sp_; all entities, o rows, p rows for _po), so the job must take the reference job's steps
+    -- `complex` + `1vsAll` / `KvsAll` with entity dropout 0.3 and relation dropout 0.2, plus a penalty term --: epoch
+    losses, penalties, validation metrics, final parameters.  (Two shards draw their table masks per rank: the masks
+    handed in, tests/test_sharded_gloo_cpu.py.)"""
+    import kge_amd.libkge_plugin.sharded_job as sj
+    from test_sharded_gloo_cpu import OracleBackend
+    tmp = str(tmp_path)
+    extra = {"complex.entity_embedder.dropout": 0.3, "complex.relation_embedder.dropout": 0.2,
+             "lookup_embedder.regularize_weight": 0.01}
+    for sharded_type, plain_type, more in (("hip_sharded_1vsAll", "1vsAll", {}),
+                                           ("hip_sharded_KvsAll", "KvsAll", {"train.loss": "kl"}),
+                                           ("hip_sharded_KvsAll", "KvsAll", {"train.loss": "bce"})):
+        opts = dict(extra, **more)
+        config = _config(tmp, "dropout_ref", "complex", 16, plain_type, "entity_ranking", opts)
+        l_ref, v_ref, s_ref, job_ref = _run(config, _dataset_dir(tmp), like_sharded_seeding=True)
+        assert job_ref.model.get_s_embedder().dropout.p == 0.3 and job_ref.model.get_p_embedder().dropout.p == 0.2
+        sj.SHARD_BACKEND = OracleBackend
+        try:
+            config = _config(tmp, "dropout_sharded", "complex", 16, sharded_type, "hip_sharded_entity_ranking", opts)
+            l_got, v_got, s_got, job = _run(config, _dataset_dir(tmp))
+        finally:
+            sj.SHARD_BACKEND = None
+        assert type(job).__name__.startswith("HipShardedTrainingJob") and job._sh.world == 1 and job._dropout == (0.3, 0.2)
+        np.testing.assert_allclose(l_got, l_ref, rtol=2e-5, atol=1e-6)
+        for got, want in zip(job.penalty_trace, job_ref.penalty_trace):
+            for k in want:
+                assert abs(got[k] - want[k]) <= 2e-5 * abs(want[k]), (k, got[k], want[k])
+        for got, want in zip(v_got, v_ref):
+            for k in ("mean_reciprocal_rank_filtered", "hits_at_1_filtered"):
+                assert abs(got[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), (k, got[k], want[k])
+        for k, v in s_ref.items():
+            np.testing.assert_allclose(s_got[k].numpy(), v.numpy(), rtol=2e-4, atol=5e-5)
 
 
 def test_launcher_runs_kge_start_on_two_ranks(tmp_path):

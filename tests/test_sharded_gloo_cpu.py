@@ -743,3 +743,110 @@ def test_a_split_that_leaves_a_rank_without_rows_is_refused_on_every_rank():
         assert all(parts[r][1] == parts[r + 1][0] for r in range(world - 1))
     with pytest.raises(ValueError, match="without rows"):  # (no process group: one rank, zero entities)
         ShardedTrainingJob1vsAll("distmult", 0, 3, 8, backend=OracleBackend)
+
+
+# ---- embedder dropout over the sharded table (round 6) ---------------------------------------------------------------
+def _dropout_worker(rank, world, port, model, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kge_amd.sharded import ShardedEntityTable
+        E, R, d, n = 47, 5, 16, 21
+        g = torch.Generator().manual_seed(5)
+        ent = torch.randn(E, d, generator=g)
+        rel = torch.randn(R, d, generator=g)
+        s, p, o = (torch.randint(hi, (n,), generator=g) for hi in (E, R, E))
+        w = torch.rand(n, generator=g) + 0.5
+        rowptr, col = _labels(g, n, E)
+        pe, pr = 0.3, 0.2
+        m_all, m_a, m_p = ((torch.rand(shape, generator=g) >= prob).float()
+                           for shape, prob in (((E, d), pe), ((n, d), pe), ((n, d), pr)))
+        lo, hi = ShardedEntityTable.partition(E, world, rank)
+        out = {}
+        for kind in ("ce", "kl", "bce"):
+            for direction in ("sp", "po"):
+                ent_master = ent[lo:hi].clone().requires_grad_(True)
+                rel_master = rel.clone().requires_grad_(True)
+                sh = ShardedEntityTable(model, ent_master.detach().clone(), rel_master.detach().clone(), E,
+                                        backend=OracleBackend)
+                masks = {"all": m_all[lo:hi], "a": m_a, "p": m_p}
+                ids = s if direction == "sp" else o
+                if kind == "ce":
+                    rows = sh.ce_loss(direction, ids, p, o if direction == "sp" else s, ent_master, rel_master,
+                                      dropout=(pe, pr), masks=masks)
+                elif kind == "kl":
+                    rows = sh.kl_loss(direction, ids, p, rowptr, col, ent_master, rel_master, dropout=(pe, pr), masks=masks)
+                else:
+                    rows = sh.bce_loss(direction, ids, p, rowptr, col, 0.25, ent_master, rel_master, dropout=(pe, pr),
+                                       masks=masks)
+                (rows * w).sum().backward()
+                out[(kind, direction)] = (rows.detach().numpy(), ent_master.grad.numpy(), rel_master.grad.numpy())
+        q.put((rank, lo, hi, out, dict(ent=ent.numpy(), rel=rel.numpy(), s=s.numpy(), p=p.numpy(), o=o.numpy(), w=w.numpy(),
+                                       rowptr=rowptr.numpy(), col=col.numpy(), m_all=m_all.numpy(), m_a=m_a.numpy(),
+                                       m_p=m_p.numpy(), pe=pe, pr=pr)))
+    finally:
+        _quiet_teardown()
+
+
+@pytest.mark.parametrize("model", ["complex", "distmult"])
+def test_sharded_losses_with_embedder_dropout_equal_the_unsharded_ops_on_the_same_masks(model):
+    """LookupEmbedder._postprocess (kge/model/embedder/lookup_embedder.py:64-69, 102-105) applies dropout to the query
+    rows, the relation rows and ALL entity rows of a training step (kge_model.py:682-725).  ShardedEntityTable's three
+    losses with `dropout=`: query rows fetched in float32 from their owners, masked alike on every rank, every rank
+    masking its own rows of the table; gradients through the masks, the query rows' summed over the shards and
+    scattered on their owners.  Two gloo ranks with the masks handed in == the reference's op sequence on the unsharded
+    tables with the same masks: per-row losses of 1vsAll CE, KvsAll KL and KvsAll BCE, both directions, the entity
+    gradient (the shards' rows side by side) and the relation gradient (identical on every rank)."""
+    import torch.nn.functional as F
+    import torch_port as tp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    procs = [ctx.Process(target=_dropout_worker, args=(r, world, port, model, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    outs = []
+    import time
+    t0 = time.time()
+    while len(outs) < world and time.time() - t0 < 180:
+        if not q.empty():
+            outs.append(q.get())
+        elif any(pr.exitcode not in (None, 0) for pr in procs):
+            break
+        else:
+            time.sleep(0.05)
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    assert len(outs) == world
+    outs.sort(key=lambda x: x[0])
+    c = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in outs[0][4].items()}
+    E, n = c["ent"].shape[0], c["s"].shape[0]
+    y = torch.zeros(n, E)
+    for i in range(n):
+        y[i, c["col"][c["rowptr"][i]:c["rowptr"][i + 1]]] = 1.0
+    k = y.sum(1)
+    for kind in ("ce", "kl", "bce"):
+        for direction in ("sp", "po"):
+            ent_t, rel_t = c["ent"].clone().requires_grad_(True), c["rel"].clone().requires_grad_(True)
+            ids = c["s"] if direction == "sp" else c["o"]
+            a = ent_t[ids] * c["m_a"] / (1 - c["pe"])
+            pr_ = rel_t[c["p"]] * c["m_p"] / (1 - c["pr"])
+            T = ent_t * c["m_all"] / (1 - c["pe"])
+            sc = tp.score_emb(model, a, pr_, T, "sp_") if direction == "sp" else tp.score_emb(model, T, pr_, a, "_po")
+            if kind == "ce":
+                ref = F.cross_entropy(sc, c["o"] if direction == "sp" else c["s"], reduction="none")
+            elif kind == "kl":
+                # KLDivWithSoftmaxKgeLoss (kge/util/loss.py:192-207) per row: labels normalised to a distribution
+                lp = F.log_softmax(sc, 1)
+                yn = y / k.clamp(min=1.0).view(-1, 1)
+                ref = torch.where(k > 0, (torch.xlogy(yn, yn) - yn * lp).sum(1), torch.zeros(n))
+            else:
+                ref = F.binary_cross_entropy_with_logits(sc + 0.25, y, reduction="none").sum(1)
+            (ref * c["w"]).sum().backward()
+            for out in outs:
+                rows, _, gr = out[3][(kind, direction)]
+                np.testing.assert_allclose(rows, ref.detach().numpy(), rtol=2e-5, atol=2e-5, err_msg=f"{kind} {direction}")
+                np.testing.assert_allclose(gr, rel_t.grad.numpy(), rtol=1e-4, atol=2e-5, err_msg=f"{kind} {direction}")
+            ge = np.concatenate([out[3][(kind, direction)][1] for out in outs])
+            np.testing.assert_allclose(ge, ent_t.grad.numpy(), rtol=1e-4, atol=2e-5, err_msg=f"{kind} {direction}")
