@@ -370,30 +370,31 @@ int kge_score_rank_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_inde
 
 /* Band-and-rescore: the counts of kge_score_rank_sp_po / kge_eval_batch under KGE_FLAG_SPLIT_QUERY --
  * the parity-compliant evaluation mode, EntityRankingJob._get_ranks_and_num_ties' tie band honoured on full-precision
- * query vectors (eval_entity_ranking.py:571-596) -- from a SINGLE-PASS counting launch plus a second launch over the
- * few pairs the first could not decide.  The single-pass score x_hi is the hi half of the split score
- * x = fl(x_hi + x_lo), and |x_lo| <= ||q_lo_i|| * max_j ||t_j||: with row i's tolerance widened by that bound, a score
- * outside the widened band compares with the true score the same way under x_hi and under x.  Launch 1 counts those
- * and LISTS the 32 x 32 tiles holding a score inside the band; launch 2 scores the listed tiles with both chains (the
- * bits the split kernel counts) and finishes the counts.  Identical (rank, ties) to the split kernel, by construction
- * and by test; on a trained model (true scores in the tail of their rows) ~5 % of the tiles are listed.
+ * query vectors (eval_entity_ranking.py:571-596) -- at close to the price of the SINGLE-PASS counting kernel.  The
+ * single-pass score x_hi is the hi half of the split score x = fl(x_hi + x_lo), and |x_lo| <= ||q_lo_i|| * max_j ||t_j||:
+ * with row i's tolerance widened by that bound, a score outside the widened band compares with the true score the same
+ * way under x_hi and under x.  Launch 1 (the single-pass counting kernel on the q_hi fragments) counts those and LISTS
+ * the (row, column) pairs inside the band -- per wave, no atomics --; launch 2 gathers the listed columns' table rows,
+ * scores them with both chains (the bits the split kernel counts) and finishes the counts.  Identical (rank, ties) to
+ * the split kernel by construction and by test WHEN NO PAIR WAS DROPPED; on a trained model (true scores in the tail of
+ * their rows) ~2e-5 of the pairs are listed, on random tables ~1.5 % -- far more than the lists hold.
  *   table_max_norm  [1] device float: kge_table_max_row_norm of the scored rows [col_begin, col_begin + m);
- *   list            device scratch, 16-byte aligned, KGE_RANK_BAND_ENTRY_BYTES per tile it can hold;
- *   status          [8] device uint32, ZEROED ONCE by the caller before the first call: [0] tiles listed by the last
- *                   call, [1] tiles DROPPED because the list was full, summed over all calls (sticky), [2] calls
- *                   completed, [3] unused, [4..7] the library's counters (zero between calls).
+ *   list            device scratch, 16-byte aligned, >= kge_rank_band_list_bytes(n) bytes, ZEROED ONCE by the caller
+ *                   before the first call (the calls leave every list empty); 255 pairs per wave and 256-row chunk;
+ *   status          [2] device uint32 or NULL, zeroed by the caller: [0] += pairs listed, [1] += pairs DROPPED because
+ *                   a wave's list was full (sticky).
  * status[1] != 0 means some call's counts are INCOMPLETE: the caller must redo those batches without `band` (the
  * evaluator reads the words once at the end of a run -- no host wait per batch -- and falls back to the split kernel
- * for the run; it also drops the band when the first batches list most tiles: nothing to gain on such tables).
+ * for the run; it also probes the first batch and drops the band when it lists too much: nothing to gain there).
  * band == NULL: the plain entry points.  KGE_ERR_INVALID_ARG: band without KGE_FLAG_SPLIT_QUERY, missing pieces;
- * KGE_ERR_UNSUPPORTED as for kge_score_rank_sp_po. */
-#define KGE_RANK_BAND_ENTRY_BYTES 528
+ * KGE_ERR_WORKSPACE: list too small for n; KGE_ERR_UNSUPPORTED as for kge_score_rank_sp_po. */
 typedef struct kge_rank_band {
   const float* table_max_norm;
   void* list;
   int64_t list_bytes;
   uint32_t* status;
 } kge_rank_band;
+int64_t kge_rank_band_list_bytes(int64_t n);
 /* 1.001 x the largest Euclidean norm of the rows [row_begin, row_begin + m) of the bf16 entity table, into out[0]
  * (device).  Once per table state (an evaluation run), not per batch. */
 int kge_table_max_row_norm(const kge_tables* t, int64_t row_begin, int64_t m, float* out, void* stream);

@@ -70,6 +70,10 @@ class KgePenaltySeg(ctypes.Structure):
                 ("value", c_vp)]
 
 
+class KgeRankBand(ctypes.Structure):
+    _fields_ = [("table_max_norm", c_vp), ("list", c_vp), ("list_bytes", c_i64), ("status", c_vp)]
+
+
 class KgeEvalFilter(ctypes.Structure):
     _fields_ = [("sp_keys", c_vp), ("sp_num_keys", c_i64), ("sp_starts", c_vp), ("sp_values", c_vp),
                 ("po_keys", c_vp), ("po_num_keys", c_i64), ("po_starts", c_vp), ("po_values", c_vp)]
@@ -125,6 +129,12 @@ PROTOTYPES = {
                                             ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float,
                                             ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
                                             c_vp]),
+    "kge_score_rank_sp_po_band": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, c_i64, c_i64, c_vp, c_vp,
+                                                 ctypes.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float,
+                                                 ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64,
+                                                 c_vp, ctypes.POINTER(KgeRankBand)]),
+    "kge_table_max_row_norm": (ctypes.c_int, [_PT, c_i64, c_i64, c_vp, c_vp]),
+    "kge_rank_band_list_bytes": (c_i64, [c_i64]),
     "kge_score_rank_emb_sp_po": (ctypes.c_int, [_PT, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, KgeIndex, KgeIndex, c_i64,
                                                 c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, ctypes.c_int, c_vp, c_vp, c_vp,
                                                 c_vp, c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp,
@@ -133,6 +143,10 @@ PROTOTYPES = {
     "kge_eval_batch": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int,
                                       ctypes.POINTER(KgeEvalFilter), ctypes.c_float, ctypes.c_float, ctypes.c_int, c_vp,
                                       c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "kge_eval_batch_band": (ctypes.c_int, [_PT, KgeIndex, KgeIndex, KgeIndex, c_i64, ctypes.c_int,
+                                           ctypes.POINTER(KgeEvalFilter), ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                                           c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp,
+                                           ctypes.POINTER(KgeRankBand)]),
     "kge_rank_hist": (ctypes.c_int, [c_vp, c_vp, ctypes.c_int, c_i64, ctypes.c_int, c_vp, c_i64, c_i64, c_vp,
                                      c_vp]),
     "kge_score_bwd_workspace_bytes": (c_i64, [_PT, c_i64, c_i64]),

@@ -55,11 +55,13 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
                       int reserve_cus);
 NextQ pairs_bf16_nextq(bool split, const Operand& A, const Operand* A2, const Operand& R, int dir, long long n,
                        int nbatch, void* qf, long long qstride_bytes);
-int run_pairs_bf16_rescore(const Operand& TG, int d, long long n, long long m, const void* qf, const CeArgs& ce,
-                           unsigned int* done, hipStream_t st);
 int run_table_max_norm(const Operand& TG, long long m, int d, float* out, hipStream_t st);
+long long pairs_bf16_band_list_bytes(long long n);
+int run_pairs_bf16_rescore(const Operand& TG, int d, long long n, long long m, const void* qf, const CeArgs& ce,
+                           long long nlists, hipStream_t st);
 int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, long long n, long long m, const void* qf,
-                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus, bool band = false);
+                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus, bool band = false,
+                           long long* band_lists = nullptr);
 int v8_launch_count(int which);
 bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
 int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
@@ -1050,13 +1052,13 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   const bool v8_rank = !exact_path && sw(SW_V8_RANK) != 0 && (t->dim == 256 || t->dim == 512) && TG.idx.ptr == nullptr &&
                        workspace_bytes >= PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, split);
   if (split && !v8_rank) return KGE_ERR_UNSUPPORTED;
-  // band-and-rescore: the split counts from a single-pass launch over the q_hi blocks + a second launch over the tiles
-  // it lists (pairs_bf16_v8_rank_kernel<BAND>, pairs_bf16_rescore_kernel)
+  // band-and-rescore: the split counts from a single-pass launch over the q_hi blocks + a small second launch over the
+  // pairs it lists (pairs_bf16_v8_rank_kernel<BAND>, pairs_bf16_rescore_kernel)
   if (band != nullptr) {
     if (!split) return KGE_ERR_INVALID_ARG;  // (a single-pass count has nothing to resolve)
-    if (!band->table_max_norm || !band->status || !band->list || ((uintptr_t)band->list & 15) ||
-        ((uintptr_t)band->status & 3) || band->list_bytes < KGE_RANK_BAND_ENTRY_BYTES)
+    if (!band->table_max_norm || !band->list || ((uintptr_t)band->list & 15) || ((uintptr_t)band->status & 3))
       return KGE_ERR_INVALID_ARG;
+    if (band->list_bytes < pairs_bf16_band_list_bytes(n)) return KGE_ERR_WORKSPACE;
   }
   if (!exact_path) {
     if (!pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
@@ -1083,12 +1085,10 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   ce.rk_bits_rs = bl.rs;
   ce.rk_bits_us = bl.us;
   if (band != nullptr) {
-    const int64_t cap = band->list_bytes / KGE_RANK_BAND_ENTRY_BYTES;
     ce.rk_tmax = band->table_max_norm;
     ce.rk_list = (u32x4*)band->list;
-    ce.rk_list_cap = (unsigned int)(cap > 0x7fffffffLL ? 0x7fffffffLL : cap);
+    ce.rk_list_bytes = band->list_bytes;
     ce.rk_status = band->status;
-    ce.rk_list_count = band->status + 4;
   }
   // lists: [sp side: filter sets][po side: filter sets]; the true column of the sp ranking is o, of the po ranking s
   const long long *lb[4], *le[4], *lc[4];
@@ -1157,11 +1157,12 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
     // the kernel clears the filter words it reads (every word of rows < n exactly once) when the bits are this
     // call's to manage: no clearing launch behind it
     ce.rk_clear_bits = manage_bits && num_filters > 0 ? 1 : 0;
+    long long band_lists = 0;
     if (rc == KGE_OK)
       rc = run_pairs_bf16_v8_rank(t->scorer, split, TG, (int)t->dim, n, m, qf, ce, st, nullptr,
-                                  (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, band != nullptr);
+                                  (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, band != nullptr, &band_lists);
     if (rc == KGE_OK && band != nullptr)
-      rc = run_pairs_bf16_rescore(TG, (int)t->dim, n, m, qf, ce, band->status + 5, st);
+      rc = run_pairs_bf16_rescore(TG, (int)t->dim, n, m, qf, ce, band_lists, st);
     ce.rk_clear_bits = 0;
     if (rc == KGE_OK) return KGE_OK;  // counted, bits cleared by the kernel
     if (rc != KGE_ERR_UNSUPPORTED || split) {
@@ -1246,6 +1247,8 @@ int kge_score_rank_sp_po_band(const kge_tables* t, kge_index s, kge_index p, kge
                          ties_po, ld, filter_bits, filter_bits_bytes, workspace, workspace_bytes, stream, 1, true, false,
                          band);
 }
+
+int64_t kge_rank_band_list_bytes(int64_t n) { return pairs_bf16_band_list_bytes(n); }
 
 int kge_table_max_row_norm(const kge_tables* t, int64_t row_begin, int64_t m, float* out, void* stream) {
   KGE_RANGE();

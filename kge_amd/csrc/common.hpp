@@ -414,12 +414,11 @@ struct CeArgs {
   const unsigned int* rk_bits[2][2];  // [side][filter set]
   long long rk_bits_rs, rk_bits_us;
   int rk_clear_bits;                  // pairs_bf16_v8_rank_kernel: store zero over every filter word it has read
-  // band-and-rescore (pairs_bf16_v8_rank_kernel<BAND> lists, pairs_bf16_rescore_kernel finishes)
+  // band-and-rescore (pairs_bf16_v8_rank_kernel<BAND>)
   const float* rk_tmax;               // [1] the table's largest row norm (kge_table_max_row_norm)
-  u32x4* rk_list;                     // listed tiles: 33 x 16 bytes each (header + one record per row of the wave)
-  unsigned int* rk_list_count;        // tiles appended by this call (zero before it; the rescore launch zeroes it again)
-  unsigned int rk_list_cap;           // entries `rk_list` holds
-  unsigned int* rk_status;            // [4] caller's: tiles listed by the last call, tiles DROPPED so far (sticky), calls, --
+  u32x4* rk_list;                     // the waves' pair lists (1 + 255 records of 16 bytes each; headers zero between calls)
+  long long rk_list_bytes;
+  unsigned int* rk_status;            // [2] or NULL: [0] += pairs listed, [1] += pairs DROPPED (a full list)
 };
 
 // one query type of a multi-label (KvsAll) batch: ce_loss.hip run_multilabel2_bwd_accum

@@ -46,6 +46,7 @@
 namespace kge {
 
 constexpr int V8_UT = 32;   // targets per unit
+constexpr int V8_BAND_CAP = 255;  // pairs a wave can list per (side, 256-row chunk): a list = 1 + 255 records of 16 bytes
 constexpr int V8_PB = 14;   // MFMA slot of the barrier
 constexpr unsigned int V8_DROP = 0x80000000u;  // per-lane store offset beyond every descriptor range
 
@@ -522,17 +523,20 @@ struct V8RankArgs {
 // PROBE (builds with -DKGE_V8_PROBES only; KGE_V8R_PROBE picks one): timing variants that leave work out -- bit 0 the
 // comparisons, 1 the table pieces of the steady state, 2 the unit barrier, 3 the filter-word loads, 4 the LDS reads
 //
-// BAND (round 6): the first launch of band-and-rescore, the parity-compliant counts at close to the
+// BAND (round 6): band-and-rescore, first launch -- the parity-compliant counts at close to the
 // single-pass price.  The fragments are the SPLIT set's (groups of 64 real rows [hi | hi | lo | lo]); the chains run on
-// the q_hi blocks only -- the single-pass score x_hi, the hi half of the split score x = fl(x_hi + x_lo) bit for bit.
-// |x - x_hi| <= |x_lo| + an ulp, |x_lo| <= ||q_lo_i|| max_j ||t_j|| (Cauchy-Schwarz; ||q_lo_i|| from the row's lo block
-// at the pair's start, the table's largest row norm from kge_table_max_row_norm), so with the row's tolerance widened
-// by that bound every score OUTSIDE the widened band is decided by x_hi as the split kernel decides it by x: greater
-// ones are counted here, smaller ones ignored.  Scores INSIDE the band (a trained model's true score sits in the far
-// tail of its row: ~2e-5 of the pairs, profiles/r5_band_fraction.txt) are not counted; the wave appends the tile --
-// (side, first row, 32-column sub-unit) + per row (band columns, filter words) -- to a list, and
-// pairs_bf16_rescore_kernel counts exactly those pairs with both chains.  The list append is an atomic and two stores
-// in a rarely taken branch: more vector-memory operations in flight only make the counted waits wait longer.
+// the q_hi blocks only: the single-pass score x_hi, the hi half of the split score x = fl(x_hi + x_lo) bit for bit.
+// |x - x_hi| <= |x_lo| + an ulp and |x_lo| <= ||q_lo_i|| max_j ||t_j|| (Cauchy-Schwarz; ||q_lo_i|| from the row's lo
+// block at the pair's start, the table's largest row norm from kge_table_max_row_norm), so with the row's tolerance
+// widened by that bound every score OUTSIDE the widened band compares with the true score under x_hi as it does under
+// x: greater ones are counted here, smaller ones ignored.  A score INSIDE the band (a trained model's true score sits
+// in the far tail of its row: ~2e-5 of the pairs, profiles/r5_band_fraction.txt) is not counted: the lane appends the
+// PAIR -- (row within the wave's 32, column, the row's filter bits of that column) -- to a list that belongs to this
+// wave and this (side, 256-row chunk) alone: a running count in a scalar register, one 16-byte store per pair, no
+// atomic, nothing to wait for (the workgroup's other seven waves stand at the next unit's barrier meanwhile: two
+// forms that rescored the tile on the spot lost 200 us on a Wikidata5M shard to exactly that --
+// profiles/r6_rank_band_inline_*_form.txt).  pairs_bf16_rescore_kernel gathers the listed columns' table rows 32 at a
+// time and counts them with both chains.
 template <int SCORER, int HH, int SPLIT, int PROBE = 0, int BAND = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a) {
   static_assert(!BAND || !SPLIT, "the band launch runs the q_hi chains only");
@@ -548,6 +552,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
   // operand rows of a wave and the partial scores meet by a DPP add (DUP).  Both give fl(sum q_hi t) + fl(sum q_lo t).
   constexpr bool DUP = SPLIT && HH == 256;
   constexpr int PARTS = (SPLIT && HH == 128) ? 2 : 1;
+  constexpr int FSETS = PARTS;            // fragment sets a lane holds
   constexpr int NT = (HH == 128 && !SPLIT) ? 2 : 1;  // 32-row sub-units of a unit
   constexpr int NACC = NT * PARTS;                   // accumulators of a chain
   constexpr int UT = V8_UT * NT;          // table rows per unit: 32 / 64
@@ -644,7 +649,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
 
   // ---------------- the consumer ----------------
   const int fi = lane & 31, fh = lane >> 5;
-  bf16x8 afr[PARTS][NKB];
+  bf16x8 afr[FSETS][NKB];
   unsigned int bp[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) bp[t] = (unsigned int)(fi * ROWB + (((2 * t + fh) ^ (fi & 15)) << 4));
@@ -660,7 +665,9 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
   const bool counts_here = DUP ? ((fi >> 3) & 1) == 0 : true;  // DUP: the q_lo lanes duplicate their q_hi lane
   float rk_t = 0.0f, rk_al = 0.0f;
   float rk_hi = 0.0f, rk_lo = 0.0f;  // exact thresholds of the raw counts: see rank_unit_raw
-  bool rk_slow = false;
+  int bl_cnt = 0;                    // BAND: pairs this wave has listed for the current (side, chunk)
+  u32x4* bl_list = nullptr;          // ... and its list (header + V8_BAND_CAP entries)
+  bool rk_slow = false, rk_noraw = false;
   int rk_g = 0, rk_c = 0, rk_fg[2] = {0, 0}, rk_fc[2] = {0, 0}, rk_fn[2] = {0, 0};
   // filter words: scalar base per filter set (this side's bits; dummy: any readable word) + the row's byte offset
   const unsigned char* rk_base = (const unsigned char*)a.qf;
@@ -870,7 +877,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
           const bool anyw = __any(wany != 0u) != 0;
           if constexpr (BAND) {
             unsigned int cm;
-            if (!RAWFAST || rk_slow || !whole || anyw) {
+            if (!RAWFAST || rk_slow || rk_noraw || !whole || anyw) {
               cm = rank_unit(sc, cu, sub, wc[sub][0], wc[sub][1]);
             } else {
               const int nb = rank_unit_raw(sc);
@@ -879,27 +886,29 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
             }
             if (orow_cur >= a.n) cm = 0u;  // (padded rows)
             if (__any(cm != 0u) != 0) {
-              // the tile onto the list: header + one 16-byte record per row (its band columns, its filter words)
-              const unsigned int rowmask = cm | (unsigned int)__shfl_xor((int)cm, 32, 64);
-              unsigned int idx = 0u;
-              if (lane == 0) idx = atomicAdd(ce.rk_list_count, 1u);
-              idx = (unsigned int)__builtin_amdgcn_readfirstlane((int)idx);
-              if (idx < ce.rk_list_cap) {
-                u32x4* const e = ce.rk_list + (long long)idx * 33;
-                if (lane == 0) {
-                  const u32x4 h = {(unsigned int)side_cur, (unsigned int)(orow_cur - fi),
-                                   (unsigned int)((u_lo + cu) * NT + sub), 0u};
-                  e[0] = h;
+              // ---- RARE: some row of the wave has a score of this sub-unit inside its widened band: the pairs onto
+              // the wave's list.  One pass per bit position a lane still holds (one, nearly always): the lanes that
+              // hold a pair take consecutive entries behind the wave's running count.
+              const long long c0t = ((long long)(u_lo + cu) * NT + sub) * V8_UT;
+              unsigned int mm = cm;
+              while (true) {
+                const unsigned long long bal = __ballot(mm != 0u);
+                if (bal == 0ull) break;
+                if (mm != 0u) {
+                  const int bit = __builtin_ctz(mm);
+                  const int slot = bl_cnt + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                  if (slot < V8_BAND_CAP) {
+                    const unsigned int fw = (ce.rk_nfilt > 0 ? (wc[sub][0] >> bit) & 1u : 0u) |
+                                            (ce.rk_nfilt > 1 ? ((wc[sub][1] >> bit) & 1u) << 1 : 0u);
+                    const u32x4 rec = {(unsigned int)fi, (unsigned int)(c0t + bit), fw, 0u};
+                    bl_list[1 + slot] = rec;
+                  }
+                  mm &= mm - 1u;
                 }
-                if (fh == 0) {
-                  const u32x4 rec = {rowmask, ce.rk_nfilt > 0 ? wc[sub][0] : 0u, ce.rk_nfilt > 1 ? wc[sub][1] : 0u, 0u};
-                  e[1 + fi] = rec;
-                }
-              } else if (lane == 0) {
-                atomicAdd(ce.rk_status + 1, 1u);  // dropped: the caller must count this batch with the split kernel
+                bl_cnt += __builtin_popcountll(bal);
               }
             }
-          } else if (!RAWFAST || rk_slow || !whole || anyw) rank_unit(sc, cu, sub, wc[sub][0], wc[sub][1]);
+          } else if (!RAWFAST || rk_slow || rk_noraw || !whole || anyw) rank_unit(sc, cu, sub, wc[sub][0], wc[sub][1]);
           else rank_unit_raw(sc);
           // This word is read by nobody else (every (row, sub-unit) of the batch belongs to one lane pair of one
           // workgroup): clear it here instead of in a launch behind the kernel.  Rare -- a few filtered columns per
@@ -936,10 +945,42 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       if (grp >= a.rgn1) grp = a.rgn1 - 1;
       grp += side * a.rgn1;
       const unsigned char* const gbase = (const unsigned char*)(a.qf + (long long)grp * 4 * NKB * 64);
+      auto set_thresholds = [&]() __attribute__((always_inline)) {
+        bool fine = __builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al);
+        if constexpr (RAWFAST) {  // the thresholds of rank_unit_raw: a start one rounding off at most, walked to the exact floats, then checked
+          auto f2u = [](float x) { return __builtin_bit_cast(unsigned int, x); };
+          auto u2f = [](unsigned int x) { return __builtin_bit_cast(float, x); };
+          auto up = [&](float x) { return x == 0.0f ? u2f(1u) : u2f(x > 0.0f ? f2u(x) + 1u : f2u(x) - 1u); };
+          auto down = [&](float x) { return x == 0.0f ? u2f(0x80000001u) : u2f(x > 0.0f ? f2u(x) - 1u : f2u(x) + 1u); };
+          float hi = rk_t + rk_al, lo = rk_t - rk_al;
+  #pragma unroll
+          for (int it = 0; it < 3; ++it) {
+            if (hi - rk_t > rk_al) hi = down(hi);
+            if (lo - rk_t < -rk_al) lo = up(lo);
+          }
+  #pragma unroll
+          for (int it = 0; it < 3; ++it) {
+            const float u = up(hi), dn = down(lo);
+            if (u - rk_t <= rk_al) hi = u;
+            if (dn - rk_t >= -rk_al) lo = dn;
+          }
+          // A row whose thresholds do not verify keeps its wave off the raw counts (rank_unit's sign-bit arithmetic on
+          // x - t needs no thresholds), it does not make it `slow`: with a tolerance that is not tiny against |t| --
+          // the band launch's widened one, true scores near zero -- t - allowed has a smaller exponent than t and the
+          // smallest float with fl(lo - t) >= -allowed lies many of ITS ulps from the start of the walk.
+          const bool verified = __builtin_isfinite(hi) && __builtin_isfinite(lo) && hi - rk_t <= rk_al &&
+                                up(hi) - rk_t > rk_al && lo - rk_t >= -rk_al && down(lo) - rk_t < -rk_al;
+          rk_noraw = __any(fine && !verified) != 0;
+          rk_hi = hi;
+          rk_lo = lo;
+        }
+        rk_slow = __any(!fine) != 0;
+      };
       if constexpr (BAND) {
-        // ||q_lo|| of this lane's row from its lo block, then the widened tolerance: 1.001 covers the rounding of the
-        // norms and of the lo chain (K <= 512 products), 2^-21 (|t| + allowed + band) the rounding of x_hi + x_lo and
-        // of x - t near the band
+        // ||q_lo|| of this lane's row from its lo block (read once, not kept), then the widened tolerance: 1.001 covers
+        // the rounding of the norms and of the lo chain (K <= 512 products), 2^-21 (|t| + allowed + band) the
+        // rounding of x_hi + x_lo and of x - t near the band.  A band that is not finite (a NaN / infinite table entry
+        // or true score) makes the wave list every pair: rk_slow.
         const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(gbase + (2 + (wave & 1)) * (NKB * 1024)), 0, NKB * 1024, 0x00020000);
         float n2 = 0.0f;
@@ -956,32 +997,13 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
         n2 += __shfl_xor(n2, 32, 64);
         float band = 1.001f * (__builtin_sqrtf(n2) * ce.rk_tmax[0]);
         band = band + 4.76837158203125e-7f * (__builtin_fabsf(rk_t) + rk_al + band);
+        if (lrow >= a.n) band = 0.0f;  // (a padded row: its fragments are whatever the workspace held; it lists nothing)
         rk_al = rk_al + band;
+        // this wave's list of the pair: the k-th pair of workgroup b, wave w (header {pairs, side, first row, 0})
+        bl_cnt = 0;
+        bl_list = ce.rk_list + (((long long)((pair - pair0) / pstep) * gridDim.x + blockIdx.x) * 8 + wave) * (V8_BAND_CAP + 1);
       }
-      bool fine = __builtin_isfinite(rk_t) && rk_al >= 0.0f && __builtin_isfinite(rk_al);
-      if constexpr (RAWFAST) {  // the thresholds of rank_unit_raw: a start one rounding off at most, walked to the exact floats, then checked
-        auto f2u = [](float x) { return __builtin_bit_cast(unsigned int, x); };
-        auto u2f = [](unsigned int x) { return __builtin_bit_cast(float, x); };
-        auto up = [&](float x) { return x == 0.0f ? u2f(1u) : u2f(x > 0.0f ? f2u(x) + 1u : f2u(x) - 1u); };
-        auto down = [&](float x) { return x == 0.0f ? u2f(0x80000001u) : u2f(x > 0.0f ? f2u(x) - 1u : f2u(x) + 1u); };
-        float hi = rk_t + rk_al, lo = rk_t - rk_al;
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-          if (hi - rk_t > rk_al) hi = down(hi);
-          if (lo - rk_t < -rk_al) lo = up(lo);
-        }
-#pragma unroll
-        for (int it = 0; it < 3; ++it) {
-          const float u = up(hi), dn = down(lo);
-          if (u - rk_t <= rk_al) hi = u;
-          if (dn - rk_t >= -rk_al) lo = dn;
-        }
-        fine = fine && __builtin_isfinite(hi) && __builtin_isfinite(lo) && hi - rk_t <= rk_al && up(hi) - rk_t > rk_al &&
-               lo - rk_t >= -rk_al && down(lo) - rk_t < -rk_al;
-        rk_hi = hi;
-        rk_lo = lo;
-      }
-      rk_slow = __any(!fine) != 0;
+      set_thresholds();
       // (the sets of a side lie interleaved: one base.  No set at all: the loads read the fragments)
       if (ce.rk_nfilt > 0) rk_base = (const unsigned char*)ce.rk_bits[side][0];
       rk_off = ce.rk_nfilt > 0 ? (unsigned int)(orow * ce.rk_bits_rs * 4) : 0u;
@@ -991,7 +1013,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       // q_hi and q_lo rows of 16 real rows; PARTS (d = 256): a chunk = FOUR groups, wave w takes the q_hi block w & 1
       // and the q_lo block 2 + (w & 1) of group w >> 1.
       // BAND: the split layout, of which this launch reads the q_hi block w & 1 of group w >> 1 (and the lo block's norm).
-      v4_static_for<0, PARTS>([&](auto pc) __attribute__((always_inline)) {
+      v4_static_for<0, FSETS>([&](auto pc) __attribute__((always_inline)) {
         constexpr int part = decltype(pc)::value;
         unsigned int flo;
         const unsigned char* fb;
@@ -1022,7 +1044,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
       // every chain and drained the table pieces requested for the units ahead (seen in the ISA; the ring's depth
       // was one chain instead of three, the price of a table that comes from HBM).
 #pragma unroll
-      for (int part = 0; part < PARTS; ++part)
+      for (int part = 0; part < FSETS; ++part)
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(afr[part][kb]));
       if (first) {
@@ -1040,6 +1062,17 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
         ++ks;
       }
       rank_flush();
+      if constexpr (BAND) {
+        if (lane == 0) {
+          const int kept = bl_cnt < V8_BAND_CAP ? bl_cnt : V8_BAND_CAP;
+          const u32x4 h = {(unsigned int)kept, (unsigned int)side_cur, (unsigned int)(orow_cur - fi), 0u};
+          bl_list[0] = h;
+          if (ce.rk_status != nullptr) {
+            if (bl_cnt != 0) atomicAdd(ce.rk_status, (unsigned int)bl_cnt);                        // pairs listed
+            if (bl_cnt > V8_BAND_CAP) atomicAdd(ce.rk_status + 1, (unsigned int)(bl_cnt - V8_BAND_CAP));  // ... dropped
+          }
+        }
+      }
       g += cnt;
       pair += pstep;
     }
@@ -1062,13 +1095,13 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
 // against the identity-indexed bf16 table TG (d in {256, 512}): ce carries the rk_* arguments.  KGE_ERR_UNSUPPORTED:
 // not this kernel's case (KGE_V8_RANK=0 declines everything: pairs_bf16_v4_kernel<V3_RANK>).
 int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, long long n, long long m, const void* qf,
-                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus, bool band) {
-  // band: `qf` holds the SPLIT fragments, the launch runs their q_hi chains (single-pass geometry) and lists the tiles
-  // pairs_bf16_rescore_kernel has to finish (ce.rk_list*, ce.rk_tmax)
+                           const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus, bool band,
+                           long long* band_lists) {
+  // band: `qf` holds the SPLIT fragments, the launch runs their q_hi chains (single-pass geometry) and rescores the
+  // sub-units that hold a score inside a row's widened band (ce.rk_tmax; ce.rk_status counts them)
   if ((d != 512 && d != 256) || TG.idx.ptr != nullptr || qf == nullptr) return KGE_ERR_UNSUPPORTED;
   if (band) {
-    if (!split || !ce.rk_list || !ce.rk_list_count || !ce.rk_status || !ce.rk_tmax || ce.rk_list_cap == 0)
-      return KGE_ERR_INVALID_ARG;
+    if (!split || !ce.rk_tmax || !ce.rk_list) return KGE_ERR_INVALID_ARG;
     split = false;  // the geometry of the single-pass launch ...
   }
   if (sw(SW_V8_RANK) == 0) return KGE_ERR_UNSUPPORTED;
@@ -1096,6 +1129,11 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
   a.dbg = dbg != nullptr ? dbg : v6_get_stamps();
   a.ce = ce;
   const dim3 grid(8 * a.wpx), block(512);
+  if (band) {  // the lists: one per (pair index of a workgroup, workgroup, wave)
+    const long long P = 2LL * a.chunks, kmax = P >= a.wpx ? (P + a.wpx - 1) / a.wpx : 1;
+    if (kmax * grid.x * 8 * (V8_BAND_CAP + 1) * 16 > ce.rk_list_bytes) return KGE_ERR_WORKSPACE;
+    if (band_lists != nullptr) *band_lists = kmax * grid.x * 8;
+  }
 #ifdef KGE_V8_PROBES
   if (sw(SW_V8R_PROBE) > 0) {
     const int pr = (int)sw(SW_V8R_PROBE);
@@ -1236,61 +1274,68 @@ int run_pairs_bf16_true(int scorer, bool split, const Operand& TG, int d, long l
 }
 
 // ---- Band-and-rescore, second launch: the pairs the band launch left undecided, counted with BOTH chains.
-// One wave per listed tile = 32 query rows x 32 consecutive table rows.  The wave copies the sub-unit's rows into LDS
-// in the units' swizzled layout (as pairs_bf16_true_kernel does for gathered rows), runs the q_hi chain and the q_lo
-// chain of its rows' split fragments -- each chain the K order and the instruction of pairs_bf16_v8_rank_kernel<SPLIT>,
-// so every score is fl(sum q_hi t) + fl(sum q_lo t), the bits that kernel counts -- and applies count_one to the
-// columns the list names, against the row's filter words that travelled with the entry.  Waves stride over the list;
-// the last workgroup to finish publishes the list length to the caller's status words and zeroes the counters for the
-// next call.
+// One wave per list (= one wave of the first launch and one (side, 256-row chunk): 32 query rows).  Per batch of up to
+// 32 listed pairs the wave gathers the pairs' table rows into LDS in the units' swizzled layout (slot k = the column of
+// pair k: pairs_bf16_true_kernel's gather), runs the q_hi and the q_lo chain of its 32 rows' split fragments -- each
+// chain the K order and the instruction of pairs_bf16_v8_rank_kernel<SPLIT>, so element (row, slot) is
+// fl(sum q_hi t) + fl(sum q_lo t), the bits that kernel counts -- and applies count_one to element (row_k, k) of every
+// listed pair, with the filter bits that travelled with it.  ~15 pairs per list on a trained model: one batch, one
+// gather of 32 x 512 bytes.  The header's count is zeroed on the way out (lists are all-empty between calls).
 struct V8RescoreArgs {
   Operand TG;
   long long n, m;
   int rgn1;              // 64-row split fragment groups per side
+  long long nlists;
   const u32x4* qf;
   CeArgs ce;
-  unsigned int* done;    // workgroups that have finished (zero between calls)
 };
 
 template <int HH>
 __global__ __launch_bounds__(256) void pairs_bf16_rescore_kernel(V8RescoreArgs a) {
   constexpr int NKB = 2 * HH / 16, ROWB = 4 * HH, SPR = ROWB / 16;
   __shared__ __attribute__((aligned(16))) unsigned char smem[4][32 * ROWB];
-  __shared__ int sh_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fi = lane & 31, fh = lane >> 5;
   const CeArgs& ce = a.ce;
-  unsigned int count = __hip_atomic_load(ce.rk_list_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned int listed = count;
-  if (count > ce.rk_list_cap) count = ce.rk_list_cap;
+  const long long id = (long long)blockIdx.x * 4 + wave;
+  if (id >= a.nlists) return;
+  u32x4* const list = ce.rk_list + id * (V8_BAND_CAP + 1);
+  const u32x4 h = list[0];
+  const int cnt = (int)h[0];
+  if (cnt <= 0) return;  // (wave-uniform; no workgroup barrier below)
+  const int side = (int)h[1];
+  const long long row0 = (long long)h[2];
+  const long long lrow = row0 + fi;
+  const long long orow = lrow < a.n ? lrow : a.n - 1;
+  float t = ce.rk_true[side][orow * ce.rk_true_stride];
+  if (t != t) t = -__builtin_inff();
   unsigned char* const lds = smem[wave];
   const unsigned char* const tgb = (const unsigned char*)a.TG.base;
   const long long tld2 = a.TG.ld * 2;
-  for (unsigned int e = blockIdx.x * 4 + wave; e < count; e += gridDim.x * 4) {
-    const u32x4* const ent = ce.rk_list + (long long)e * 33;
-    const u32x4 h = ent[0];
-    const int side = (int)h[0];
-    const long long row0 = (long long)h[1];
-    const long long c0 = (long long)h[2] * 32;
-    const u32x4 rec = ent[1 + fi];
-    const long long lrow = row0 + fi;
-    const long long orow = lrow < a.n ? lrow : a.n - 1;
-    float t = ce.rk_true[side][orow * ce.rk_true_stride];
-    if (t != t) t = -__builtin_inff();
-    // ---- the sub-unit's 32 table rows (rows beyond the table repeat its last row: their columns are never named)
+  long long grp = row0 >> 6;
+  if (grp >= a.rgn1) grp = a.rgn1 - 1;
+  const unsigned char* const gbase = (const unsigned char*)(a.qf + ((long long)side * a.rgn1 + grp) * 4 * NKB * 64);
+  const int blk = (int)((row0 >> 5) & 1);
+  int G = 0, C = 0, FG[2] = {0, 0}, FC[2] = {0, 0};
+  for (int b0 = 0; b0 < cnt; b0 += 32) {
+    // lane k (and k + 32) holds pair b0 + k: (row within the wave's 32, column, filter bits); beyond the list: none
+    const int k = b0 + (lane & 31);
+    const u32x4 rec = k < cnt ? list[1 + k] : u32x4{0xffffffffu, 0u, 0u, 0u};
+    long long col = (long long)rec[1];
+    if (col >= a.m) col = a.m - 1;
+    const int my_t = (int)col;
 #pragma unroll 4
     for (int it = 0; it < 32 * SPR / 64; ++it) {
       const int idx = it * 64 + lane, row = idx / SPR, c = idx % SPR;
-      long long tr = c0 + row;
-      if (tr >= a.m) tr = a.m - 1;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(tgb + tr * tld2 + c * 16);
+      const int trow = __shfl(my_t, row, 64);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(tgb + (long long)trow * tld2 + c * 16);
       *reinterpret_cast<u32x4*>(lds + row * ROWB + ((c ^ (row & 15)) << 4)) = v;
     }
-    // ---- both chains (split fragment groups of 64 real rows: [hi 0-31 | hi 32-63 | lo 0-31 | lo 32-63])
-    long long grp = row0 >> 6;
-    if (grp >= a.rgn1) grp = a.rgn1 - 1;
-    const unsigned char* const gbase = (const unsigned char*)(a.qf + ((long long)side * a.rgn1 + grp) * 4 * NKB * 64);
-    const int blk = (int)((row0 >> 5) & 1);
+    // (the block is this wave's own and a wave's LDS operations execute in order: the compiler must keep the other
+    // lanes' stores in front of this lane's reads, and the reads in front of the next batch's stores)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     f32x16 acc[2];
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
@@ -1304,70 +1349,66 @@ __global__ __launch_bounds__(256) void pairs_bf16_rescore_kernel(V8RescoreArgs a
       }
       acc[part] = ac;
     }
-    // ---- the named columns of this lane's row: element r = column 8 (r >> 2) + 4 fh + (r & 3) of the sub-unit
-    int G = 0, C = 0, FG[2] = {0, 0}, FC[2] = {0, 0};
+    // element r of this lane = (query row fi, slot 8 (r >> 2) + 4 fh + (r & 3)): counted if that slot's pair names row fi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int bit = 8 * (r >> 2) + 4 * fh + (r & 3);
-      if (((rec[0] >> bit) & 1u) != 0u && c0 + bit < a.m) {
+      const int slot = 8 * (r >> 2) + 4 * fh + (r & 3);
+      const unsigned int prow = (unsigned int)__shfl((int)rec[0], slot, 64);
+      const unsigned int pfw = (unsigned int)__shfl((int)rec[2], slot, 64);
+      if (prow == (unsigned int)fi) {
         int g1 = 0, c1 = 0;
         count_one(acc[0][r] + acc[1][r], t, ce.rk_atol, ce.rk_rtol, g1, c1);
         G += g1;
         C += c1;
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-          if (k < ce.rk_nfilt && ((rec[1 + k] >> bit) & 1u) != 0u) {
-            FG[k] += g1;
-            FC[k] += c1;
+        for (int q = 0; q < 2; ++q)
+          if (q < ce.rk_nfilt && ((pfw >> q) & 1u) != 0u) {
+            FG[q] += g1;
+            FC[q] += c1;
           }
       }
     }
-    G += __shfl_xor(G, 32, 64);
-    C += __shfl_xor(C, 32, 64);
-    const bool wr = fh == 0 && lrow < a.n;
-    unsigned long long* rank = ce.rk_rank[side] + lrow;
-    unsigned long long* ties = ce.rk_ties[side] + lrow;
-    if (wr && G != 0) atomicAdd(rank, (unsigned long long)G);
-    if (wr && C != 0) atomicAdd(ties, (unsigned long long)C);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  G += __shfl_xor(G, 32, 64);
+  C += __shfl_xor(C, 32, 64);
+  const bool wr = fh == 0 && lrow < a.n;
+  unsigned long long* rank = ce.rk_rank[side] + lrow;
+  unsigned long long* ties = ce.rk_ties[side] + lrow;
+  if (wr && G != 0) atomicAdd(rank, (unsigned long long)G);
+  if (wr && C != 0) atomicAdd(ties, (unsigned long long)C);
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      if (k < ce.rk_nfilt) {
-        const int fg = FG[k] + __shfl_xor(FG[k], 32, 64), fc = FC[k] + __shfl_xor(FC[k], 32, 64);
-        // (a filtered column inside the band leaves the filtered ranking: the first launch has added "-inf is close
-        // to a true score of -inf" for ALL filtered columns already)
-        if (wr && G - fg != 0) atomicAdd(rank + (k + 1) * ce.rk_ld, (unsigned long long)(long long)(G - fg));
-        if (wr && C - fc != 0) atomicAdd(ties + (k + 1) * ce.rk_ld, (unsigned long long)(long long)(C - fc));
-      }
+  for (int q = 0; q < 2; ++q) {
+    if (q < ce.rk_nfilt) {
+      const int fg = FG[q] + __shfl_xor(FG[q], 32, 64), fc = FC[q] + __shfl_xor(FC[q], 32, 64);
+      // (a filtered column inside the band leaves the filtered ranking; "-inf is close to a true score of -inf" was
+      // added for ALL filtered columns by the first launch)
+      if (wr && G - fg != 0) atomicAdd(rank + (q + 1) * ce.rk_ld, (unsigned long long)(long long)(G - fg));
+      if (wr && C - fc != 0) atomicAdd(ties + (q + 1) * ce.rk_ld, (unsigned long long)(long long)(C - fc));
     }
   }
-  // ---- the last workgroup: list length out, counters back to zero
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    sh_last = atomicInc(a.done, gridDim.x - 1) == gridDim.x - 1 ? 1 : 0;
-  }
-  __syncthreads();
-  if (sh_last != 0 && threadIdx.x == 0) {
-    ce.rk_status[0] = listed;
-    atomicAdd(ce.rk_status + 2, 1u);
-    __hip_atomic_store(ce.rk_list_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (lane == 0) list[0] = u32x4{0u, 0u, 0u, 0u};
+}
+
+// Bytes of list space that hold the lists of a batch of n rows per side whatever the launch geometry: a launch of
+// 8 wpx workgroups (wpx <= 32) writes ceil(P / wpx) * 8 wpx * 8 <= 64 (P + 32) lists for its P = 2 ceil(n / 256) pairs.
+long long pairs_bf16_band_list_bytes(long long n) {
+  return n <= 0 ? 0 : 64 * (2 * ((n + 255) / 256) + 32) * (long long)(V8_BAND_CAP + 1) * 16;
 }
 
 int run_pairs_bf16_rescore(const Operand& TG, int d, long long n, long long m, const void* qf, const CeArgs& ce,
-                           unsigned int* done, hipStream_t st) {
+                           long long nlists, hipStream_t st) {
   if ((d != 512 && d != 256) || TG.idx.ptr != nullptr || qf == nullptr || ((uintptr_t)qf & 15)) return KGE_ERR_UNSUPPORTED;
   V8RescoreArgs a{};
   a.TG = TG;
   a.n = n;
   a.m = m;
   a.rgn1 = (int)((n + 63) / 64);
+  a.nlists = nlists;
   a.qf = (const u32x4*)qf;
   a.ce = ce;
-  a.done = done;
-  // four tiles in flight per workgroup; enough workgroups to cover a long list several deep, few enough that an empty
-  // list costs a launch and nothing else
-  const dim3 grid(1024), block(256);
+  const dim3 grid((unsigned)((a.nlists + 3) / 4)), block(256);
   if (d == 512) hipLaunchKernelGGL((pairs_bf16_rescore_kernel<256>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((pairs_bf16_rescore_kernel<128>), grid, block, 0, st, a);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;

@@ -1036,8 +1036,52 @@ def _rank_args(n, true_sp, true_po, filters_sp, filters_po, rank_sp, ties_sp, ra
     return K, ld, lists
 
 
+class RankBand:
+    """Band-and-rescore state of one table slice (include/kge_amd.h: kge_rank_band): the slice's largest
+    row norm (one launch, at construction and at every `refresh`: the bound must be the CURRENT table's), the waves'
+    pair lists for batches of up to `n_max` rows and the status words.  Handed to score_rank_sp_po / eval_batch together
+    with split-query flags, the counts are the split kernel's, from a single-pass launch plus a small launch over the
+    listed pairs -- PROVIDED no pair was dropped.
+
+    `status()` -> (pairs listed, pairs dropped) since the last `reset()` -- a host read, i.e. a wait: once per
+    evaluation run, not per batch.  dropped != 0: some call's counts are incomplete (a wave's list was full); the caller
+    counts those batches again without the band."""
+
+    def __init__(self, t: "Tables", n_max: int, col_begin: int = 0, col_end=None):
+        col_end = t.num_ent if col_end is None else int(col_end)
+        self.col_begin, self.m, self.n_max = int(col_begin), col_end - int(col_begin), int(n_max)
+        dev = t.device
+        self.tmax = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.status_words = torch.zeros(4, dtype=torch.int32, device=dev)
+        need = int(_lib.lib().kge_rank_band_list_bytes(self.n_max))
+        self.list = torch.zeros(max(need, 16), dtype=torch.uint8, device=dev)  # zeroed ONCE: calls leave the lists empty
+        self.c = _lib.KgeRankBand(self.tmax.data_ptr(), self.list.data_ptr(), self.list.numel(),
+                                  self.status_words.data_ptr())
+        self.refresh(t)
+
+    def refresh(self, t: "Tables"):
+        """The row-norm bound again (the table's values changed: a training step between two validations), on the
+        current stream; the status words cleared."""
+        with _on_device(t.device):
+            tc = t.c(None)
+            _lib.check(_lib.lib().kge_table_max_row_norm(ctypes.byref(tc), self.col_begin, self.m, self.tmax.data_ptr(),
+                                                         _stream_handle(t.device)), "kge_table_max_row_norm")
+        self.status_words.zero_()
+
+    def pairs_of(self, n: int) -> int:
+        """(row, column) pairs of a two-sided batch of n rows against this slice."""
+        return 2 * int(n) * self.m
+
+    def status(self):
+        w = self.status_words.cpu()
+        return int(w[0]) & 0xffffffff, int(w[1]) & 0xffffffff
+
+    def reset(self):
+        self.status_words.zero_()
+
+
 def score_rank_sp_po(t: Tables, s, p, o, true_sp, true_po, filters_sp, filters_po, atol, rtol, rank_sp, ties_sp,
-                     rank_po, ties_po, col_begin: int = 0, col_end=None, flags=None) -> bool:
+                     rank_po, ties_po, col_begin: int = 0, col_end=None, flags=None, band: "RankBand" = None) -> bool:
     """Raw + filtered (rank, ties) counts of both directions of a batch against the entity rows
     [col_begin, col_end), counted inside the scoring kernel: what score_sp_po + two rank_counts_multi calls
     give, without the [n, 2m] score matrix.  true_sp / true_po: float32 [n] scores of the triples
@@ -1056,10 +1100,13 @@ def score_rank_sp_po(t: Tables, s, p, o, true_sp, true_po, filters_sp, filters_p
         st = _stream_handle(t.device)
         ws, wsb = _workspace(tc, n, t.device, True, st)
         bits, bits_bytes = _rank_bits(_lib.lib().kge_score_rank_bits_bytes(n, m, K), t.device, st)
-        rc = _lib.lib().kge_score_rank_sp_po(
-            ctypes.byref(tc), si, pi, oi, n, int(col_begin), m, true_sp.data_ptr(), true_po.data_ptr(), K,
-            *lists, float(atol), float(rtol), rank_sp.data_ptr(), ties_sp.data_ptr(), rank_po.data_ptr(),
-            ties_po.data_ptr(), ld, bits, bits_bytes, ws, wsb, st)
+        if band is not None and ((band.col_begin, band.m) != (int(col_begin), m) or n > band.n_max):
+            raise ValueError("kge_amd: this RankBand was made for another column range or smaller batches")
+        args = (ctypes.byref(tc), si, pi, oi, n, int(col_begin), m, true_sp.data_ptr(), true_po.data_ptr(), K,
+                *lists, float(atol), float(rtol), rank_sp.data_ptr(), ties_sp.data_ptr(), rank_po.data_ptr(),
+                ties_po.data_ptr(), ld, bits, bits_bytes, ws, wsb, st)
+        rc = _lib.lib().kge_score_rank_sp_po(*args) if band is None else \
+            _lib.lib().kge_score_rank_sp_po_band(*args, ctypes.byref(band.c))
         if rc == _lib.KGE_ERR_UNSUPPORTED:
             return False
         _lib.check(rc, "kge_score_rank_sp_po")
@@ -1110,7 +1157,7 @@ _EVAL_SCRATCH = {}  # (device index, stream) -> scratch of kge_eval_batch (range
 
 
 def eval_batch(t: Tables, s, p, o, filters, atol, rtol, tie_policy, counts, hist, ranks_o=None, ranks_s=None,
-               flags=None) -> bool:
+               flags=None, band: "RankBand" = None) -> bool:
     """One evaluation batch against all entities in four launches (kge_eval_batch): filter lookup + filter bits,
     true scores, scoring + counting, bits cleared + tie policy + histograms.  filters = [((sp_keys, sp_starts,
     sp_values), (po_keys, po_starts, po_values)), ...] (at most two: the device-resident filter indexes of
@@ -1143,11 +1190,14 @@ def eval_batch(t: Tables, s, p, o, filters, atol, rtol, tie_policy, counts, hist
         buf = _EVAL_SCRATCH.get(key)
         if buf is None or buf.numel() < need:
             buf = _EVAL_SCRATCH[key] = torch.empty((max(need, 1 << 20),), device=t.device, dtype=torch.uint8)
-        rc = _lib.lib().kge_eval_batch(
-            ctypes.byref(tc), si, pi, oi, n, K, arr, float(atol), float(rtol), TIE_POLICIES.get(tie_policy, tie_policy)
-            if isinstance(tie_policy, str) else int(tie_policy), counts.data_ptr(), hist.data_ptr(), hist.stride(0),
-            None if ranks_o is None else ranks_o.data_ptr(), None if ranks_s is None else ranks_s.data_ptr(),
-            bits, bits_bytes, buf.data_ptr(), buf.numel(), ws, wsb, st)
+        if band is not None and ((band.col_begin, band.m) != (0, t.num_ent) or n > band.n_max):
+            raise ValueError("kge_amd: eval_batch scores all entities; this RankBand was made for another range or smaller batches")
+        args = (ctypes.byref(tc), si, pi, oi, n, K, arr, float(atol), float(rtol), TIE_POLICIES.get(tie_policy, tie_policy)
+                if isinstance(tie_policy, str) else int(tie_policy), counts.data_ptr(), hist.data_ptr(), hist.stride(0),
+                None if ranks_o is None else ranks_o.data_ptr(), None if ranks_s is None else ranks_s.data_ptr(),
+                bits, bits_bytes, buf.data_ptr(), buf.numel(), ws, wsb, st)
+        rc = _lib.lib().kge_eval_batch(*args) if band is None else \
+            _lib.lib().kge_eval_batch_band(*args, ctypes.byref(band.c))
         if rc == _lib.KGE_ERR_UNSUPPORTED:
             return False
         _lib.check(rc, "kge_eval_batch")

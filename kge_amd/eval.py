@@ -131,6 +131,9 @@ class EntityRankingEvaluator:
     # the exact kernels instead of scored and scanned (see run())
     FUSED_EXACT_MIN_BYTES = 1 << 30
     TWO_STEP_LANE_BYTES = 128 << 20  # two-step settings: lanes of captured batches only below this score-matrix size
+    # band-and-rescore (engine.RankBand): taken for a run when its first batch lists at most this share
+    # of its (row, column) pairs -- a trained model: ~5e-5; random tables list 1.5e-2 and keep the split kernel
+    BAND_MAX_LISTED = 5e-4
 
 
     def __init__(self, model, splits: Dict[str, np.ndarray], num_entities: int, num_relations: int,
@@ -138,8 +141,14 @@ class EntityRankingEvaluator:
                  filter_with_test: bool = True, batch_size: int = 100, chunk_size: int = -1,
                  tie_handling: str = "rounded_mean_rank", tie_atol: float = 1e-5,
                  tie_rtol: float = 1e-4,
-                 hits_at_k_s=(1, 3, 10, 50, 100, 200, 300, 400, 500, 1000)):
+                 hits_at_k_s=(1, 3, 10, 50, 100, 200, 300, 400, 500, 1000), band_rescore="auto"):
         self.model = model
+        # split-query evaluation of bf16 ComplEx / DistMult tables through band-and-rescore: "auto" (probe the first
+        # batch of every run), True (no probe; a run that dropped pairs still falls back), False (the split kernel)
+        self.band_rescore = band_rescore
+        self.band_runs = 0       # runs that counted through band-and-rescore (complete: no dropped pair)
+        self.band_listed = None  # (pairs listed, pairs) of the last run's probe batch
+        self._band_off = False
         self.E, self.R = num_entities, num_relations
         self.triples = np.asarray(splits[eval_split]).reshape(-1, 3)
         fs = list(filter_splits)
@@ -165,6 +174,14 @@ class EntityRankingEvaluator:
         self.graph_batches = 0  # batches that ran as graph replays (all runs)
         self.lanes = int(os.environ.get("KGE_EVAL_LANES", "3"))  # captured batches in flight (one HIP stream each)
         self._graph = None
+
+    @staticmethod
+    def _band_for(st, tables, which):
+        """The RankBand of the probe / of the eager (ragged last) batches, made at first use."""
+        b = st.setdefault("bands", {}).get(which)
+        if b is None:
+            b = st["bands"][which] = engine.RankBand(tables, st["ranges"].shape[-1])
+        return b
 
     def _device_state(self, dev):
         """Everything the loop needs, resident on `dev` (built once): the eval triples, the filter
@@ -264,6 +281,31 @@ class EntityRankingEvaluator:
                  bool(self._fused), bool(self.four_launches), self.tie_handling, float(self.tie_atol),
                  float(self.tie_rtol), os.environ.get("KGE_EVAL_FUSED_EXACT"), int(self.chunk_size), int(self.reserve_cus))
                 if isinstance(tables, engine.Tables) else None)
+        # ---- band-and-rescore for this run?
+        chunk0 = E if self.chunk_size < 0 else self.chunk_size
+        use_band = (self.band_rescore in ("auto", True) and not self._band_off and self._fused and self.four_launches
+                    and isinstance(tables, engine.Tables) and M <= 3 and chunk0 >= E and dev.type == "cuda"
+                    and bool(int(tables.flags) & engine.FLAG_SPLIT_QUERY) and tables.ent.dtype == torch.bfloat16
+                    and tables.ent.shape[1] in (256, 512) and len(self.triples) > 0
+                    and tables.scorer in (engine.SCORERS["complex"], engine.SCORERS["distmult"]))
+        if use_band:
+            for b in st.setdefault("bands", {}).values():
+                b.refresh(tables)
+            if self.band_rescore == "auto":
+                n0 = min(self.batch_size, len(self.triples))
+                pb = self._band_for(st, tables, "probe")
+                t0 = st["triples"][:n0]
+                c0 = torch.zeros(2, 2, M, n0, dtype=torch.int64, device=dev)
+                ok = engine.eval_batch(tables, t0[:, 0], t0[:, 1], t0[:, 2],
+                                       [(st["sp"][k], st["po"][k]) for k in range(M - 1)], self.tie_atol, self.tie_rtol,
+                                       self.tie_handling, c0, torch.zeros(M, E, dtype=torch.float, device=dev), None,
+                                       None, band=pb)
+                listed, dropped = pb.status()  # (the run's one host wait besides its result)
+                self.band_listed = (listed, pb.pairs_of(n0))
+                use_band = bool(ok) and dropped == 0 and listed <= self.BAND_MAX_LISTED * pb.pairs_of(n0)
+                pb.reset()
+        if gkey is not None:
+            gkey = gkey + (bool(use_band),)
         held = self._graph if (self._graph is not None and self._graph["key"] == gkey) else None
         hist = held["hist"].zero_() if held is not None else torch.zeros(M, E, dtype=torch.float, device=dev)
         all_ranks = {f"{d}{r}": [] for r in rankings for d in "so"}
@@ -294,7 +336,9 @@ class EntityRankingEvaluator:
         if isinstance(tables, engine.Tables) and self.lanes > 1 and self.hip_graph and self.reserve_cus > 0:
             lane_flags = int(tables.flags) | engine.reserve_cus(self.reserve_cus)
 
-        def do_batch(batch, rng, cnt, ro, rs):
+        bands_used = []
+
+        def do_batch(batch, rng, cnt, ro, rs, band=None):
             """One batch: filter ranges, counts (in place in `cnt`), tie policy + histogram; launches only."""
             s, p, o = batch[:, 0], batch[:, 1], batch[:, 2]
             n = batch.shape[0]
@@ -307,7 +351,7 @@ class EntityRankingEvaluator:
                     c4 = st["counts4"][ck] = torch.zeros(2, 2, M, n, dtype=torch.int64, device=dev)
                 if engine.eval_batch(tables, s, p, o, [(st["sp"][k], st["po"][k]) for k in range(M - 1)],
                                      self.tie_atol, self.tie_rtol, self.tie_handling, c4, hist, ro, rs,
-                                     flags=lane_flags):
+                                     flags=lane_flags, band=band):
                     return
                 declined.add(n)
             sc_, oc_ = s.contiguous(), o.contiguous()  # true_col of the po / sp rankings
@@ -402,12 +446,18 @@ class EntityRankingEvaluator:
                                   "ro": torch.empty(M, bs, dtype=torch.int64, device=dev) if return_ranks else None,
                                   "rs": torch.empty(M, bs, dtype=torch.int64, device=dev) if return_ranks else None,
                                   "ranges": torch.empty_like(st["ranges"]), "counts": torch.zeros_like(st["counts"]),
-                                  "stream": torch.cuda.Stream(dev), "graph": None})
+                                  "stream": torch.cuda.Stream(dev), "graph": None,
+                                  "band": engine.RankBand(tables, bs) if use_band else None, "band_fresh": True})
                 ln = lanes[li]
+                if ln["band"] is not None and li not in used:
+                    if not ln["band_fresh"]:
+                        ln["band"].refresh(tables)  # (a held lane: the table's values may have moved since its capture)
+                    ln["band_fresh"] = False
+                    bands_used.append(ln["band"])
                 if li not in used:  # the lane waits for whatever produced the tables / zeroed the histograms
                     ln["stream"].wait_stream(cur)
                     used.add(li)
-                args = (ln["batch"], ln["ranges"], ln["counts"], ln["ro"], ln["rs"])
+                args = (ln["batch"], ln["ranges"], ln["counts"], ln["ro"], ln["rs"], ln["band"])
                 with torch.cuda.stream(ln["stream"]):
                     ln["batch"].copy_(triples[b0:b0 + bs])
                     if ln["graph"] is None:
@@ -438,12 +488,22 @@ class EntityRankingEvaluator:
             cnt = st["counts"][:, :, :, :n].contiguous() if n != bs else st["counts"]
             ro = torch.empty(M, n, dtype=torch.int64, device=dev) if return_ranks else None
             rs = torch.empty(M, n, dtype=torch.int64, device=dev) if return_ranks else None
-            do_batch(batch, rng, cnt, ro, rs)
+            eb = self._band_for(st, tables, "eager") if use_band else None
+            if eb is not None and not any(eb is b for b in bands_used):
+                bands_used.append(eb)
+            do_batch(batch, rng, cnt, ro, rs, eb)
             if return_ranks:
                 keep_ranks(ro, rs, False)
 
         for li in used:
             cur.wait_stream(lanes[li]["stream"])
+        if use_band:
+            # a pair dropped anywhere (a wave's list was full): some batch's counts are incomplete -- the whole run again
+            # on the split kernel, and no band for this evaluator from here on
+            if any(b.status()[1] != 0 for b in bands_used):
+                self._band_off = True
+                return self.run(return_ranks)
+            self.band_runs += 1
         suffix = {"_raw": "", "_filt": "_filtered", "_filt_test": "_filtered_with_test"}
         metrics = {}
         for m_, r in enumerate(rankings):

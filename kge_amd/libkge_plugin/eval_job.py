@@ -137,7 +137,25 @@ class HipEntityRankingJob(EntityRankingJob):
                                         and self.model._scorer.name in ("complex", "distmult")) else None
         rank_flags = engine.FLAG_SPLIT_QUERY if split_tables is not None else None
 
-        self._ev = {"fused_tables": fused_tables, "split_tables": split_tables, "rank_flags": rank_flags}
+        self._ev = {"fused_tables": fused_tables, "split_tables": split_tables, "rank_flags": rank_flags, "band": None}
+        # hip_entity_ranking.band_rescore (hip_entity_ranking.yaml): the split counts from a single-pass launch + a
+        # small launch over the pairs it could not decide (engine.RankBand).  Unchunked evaluation only.
+        # The status words are read after every batch (this loop waits for every batch's ranks anyway): a batch that
+        # dropped pairs is counted again by the split kernel, and under "auto" a batch that lists more than
+        # BAND_MAX_LISTED of its pairs -- an untrained model -- ends the band for this evaluation.
+        try:
+            want_band = self.config.get("hip_entity_ranking.band_rescore")
+        except KeyError:
+            want_band = "auto"
+        if (split_tables is not None and rank_flags and chunk_size >= E and want_band in ("auto", True, "true", "True")
+                and fused_tables().ent.is_cuda and fused_tables().ent.shape[1] in (256, 512)):
+            band = getattr(self, "_rank_band", None)
+            ft = fused_tables()
+            if band is None or band.m != E or band.n_max < self.batch_size or band.tmax.device != ft.ent.device:
+                band = self._rank_band = engine.RankBand(ft, self.batch_size)
+            else:
+                band.refresh(ft)  # (the tables moved since the last validation)
+            self._ev.update(band=band, band_auto=want_band == "auto", band_batches=0)
 
     def _batch_counts(self, batch, M, chunk_size):
         """int64 counts [o | s][rank | ties][ranking][row] of one batch (on the device; launches only).  The sharded
@@ -182,6 +200,22 @@ class HipEntityRankingJob(EntityRankingJob):
             chunk_start = chunk_size * chunk_number
             chunk_end = min(chunk_size * (chunk_number + 1), E)
             c = chunk_end - chunk_start
+            band = ev.get("band") if ft is not None and c == E else None
+            if band is not None:
+                from ..eval import EntityRankingEvaluator as _Ev
+                cb = torch.zeros_like(cnt)
+                listed0, dropped0 = band.status()
+                ok = engine.score_rank_sp_po(ft, s, p, o, o_true, s_true, filt_o, filt_s, self.tie_atol, self.tie_rtol,
+                                             cb[0, 0], cb[0, 1], cb[1, 0], cb[1, 1], chunk_start, chunk_end,
+                                             flags=rank_flags, band=band)
+                listed, dropped = band.status()
+                if ok and dropped == dropped0:
+                    cnt += cb
+                    ev["band_batches"] += 1
+                    if ev["band_auto"] and listed - listed0 > _Ev.BAND_MAX_LISTED * band.pairs_of(n):
+                        ev["band"] = None  # complete, but no gain on these tables: the split kernel from here on
+                    continue
+                ev["band"] = None  # pairs were dropped (or the library declined): this batch again, without the band
             if ft is not None:
                 if engine.score_rank_sp_po(ft, s, p, o, o_true, s_true, filt_o, filt_s, self.tie_atol,
                                            self.tie_rtol, cnt[0, 0], cnt[0, 1], cnt[1, 0], cnt[1, 1],

@@ -179,6 +179,27 @@ def test_new_entries_validate_arguments_without_a_device(lib):
     assert lib.kge_eval_batch(*ev_args(bf16, 4, 0, sb=64)) == -5           # scratch too small
     assert lib.kge_eval_batch(*ev_args(bf16, 0, 0)) == 0                   # empty batch
     assert lib.kge_score_rank_sp_po(*rank_args(bf16, 0, 0, bf16.num_ent, 0)) == 0          # empty batch
+    # band-and-rescore: the band needs split queries and a row-norm bound; NULL band = the plain entry points
+    from kge_amd._lib import KgeRankBand
+    assert ctypes.sizeof(KgeRankBand) == 32 and KgeRankBand.list_bytes.offset == 16 and KgeRankBand.status.offset == 24
+    assert lib.kge_rank_band_list_bytes(0) == 0 and lib.kge_rank_band_list_bytes(512) == 64 * (4 + 32) * 4096
+    assert lib.kge_rank_band_list_bytes(100000) == 64 * (2 * 391 + 32) * 4096
+    band = KgeRankBand(16, 16, 1 << 30, 16)
+    split512 = KgeTables(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 0, 10, 3, 512, 512, 512, 512, 1.0, 32)
+    assert lib.kge_score_rank_sp_po_band(*rank_args(bf16, 4, 0, bf16.num_ent, 0), ctypes.byref(band)) == -1   # no split flag
+    assert lib.kge_score_rank_sp_po_band(*rank_args(split512, 4, 0, 10, 0), ctypes.byref(KgeRankBand(None, 16, 1 << 30, 16))) == -1
+    assert lib.kge_score_rank_sp_po_band(*rank_args(split512, 4, 0, 10, 0), ctypes.byref(KgeRankBand(16, 16, 1 << 30, 18))) == -1  # misaligned status
+    assert lib.kge_score_rank_sp_po_band(*rank_args(split512, 4, 0, 10, 0), ctypes.byref(KgeRankBand(16, 24, 1 << 30, 16))) == -1  # misaligned list
+    assert lib.kge_score_rank_sp_po_band(*rank_args(split512, 4, 0, 10, 0), ctypes.byref(KgeRankBand(16, 16, 4096, 16))) == -5    # list too small
+    assert lib.kge_score_rank_sp_po_band(*rank_args(split, 4, 0, split.num_ent, 0), ctypes.byref(band)) == -2   # dim 128
+    assert lib.kge_score_rank_sp_po_band(*rank_args(bf16, 0, 0, bf16.num_ent, 0), ctypes.byref(band)) == 0      # empty batch
+    assert lib.kge_score_rank_sp_po_band(*rank_args(bf16, 4, 0, bf16.num_ent, 3), None) == -2                   # = the plain entry
+    assert lib.kge_eval_batch_band(*ev_args(bf16, 4, 0, pol=9), ctypes.byref(band)) == -1
+    assert lib.kge_eval_batch_band(*ev_args(bf16, 0, 0), ctypes.byref(band)) == 0
+    assert lib.kge_table_max_row_norm(ctypes.byref(bf16), 0, bf16.num_ent, None, None) == -1               # no output
+    assert lib.kge_table_max_row_norm(ctypes.byref(bf16), 1, bf16.num_ent, P, None) == -1                  # rows beyond the table
+    f32t = KgeTables(ctypes.c_void_p(16), ctypes.c_void_p(16), 0, 0, 10, 3, 512, 512, 512, 512, 1.0, 0)
+    assert lib.kge_table_max_row_norm(ctypes.byref(f32t), 0, 10, P, None) == -2                            # bf16 tables only
     assert lib.kge_rank_hist(None, None, 3, 4, 7, None, 10, 10, None, None) == -1   # unknown tie policy
     assert lib.kge_rank_hist(None, None, 0, 0, 0, None, 10, 10, None, None) == 0
     # optimizer step: null / misaligned arrays

@@ -316,3 +316,203 @@ def test_fused_counts_against_the_oracle():
             col = np.concatenate([vals[b:e] for b, e in zip(beg, end)] + [np.zeros(0, np.int64)]).astype(np.int64)
             r1, t1 = ko.rank_counts(blk, true, rp, col, 0, tcol, 1e-5, 1e-4)
             assert np.array_equal(got[side, 0, k + 1], r1) and np.array_equal(got[side, 1, k + 1], t1), (k, side)
+
+
+# ---- band-and-rescore (round 6) -------------------------------------------------------------------------
+def _split_vs_band(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol):
+    """(counts of the split kernel, counts with band-and-rescore, [(pairs listed, pairs dropped, pairs) per chunk])."""
+    n, K = s.numel(), len(f_sp)
+    want = _fused(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol)
+    got = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=DEV)
+    stats = []
+    for lo, hi in chunks:
+        band = eng.RankBand(T, n, lo, hi)
+        ok = eng.score_rank_sp_po(T, s, p, o, t_sp, t_po, f_sp, f_po, atol, rtol, got[0, 0], got[0, 1], got[1, 0],
+                                  got[1, 1], lo, hi, band=band)
+        assert ok
+        stats.append(band.status() + (band.pairs_of(n),))
+        # every list is empty again (header word 0 of every 4096-byte list)
+        assert int(band.list.view(torch.int32).view(-1, 1024)[:, 0].abs().sum()) == 0
+    return want, got, stats
+
+
+def _planted(eng, T, rng, E, R, n, kth):
+    """(s, p, o) whose true object is the kth best entity of (s, p) -- which puts the same score into the tail of
+    (p, o)'s row: a trained model's evaluation triples."""
+    s = torch.from_numpy(rng.integers(0, E, n)).to(DEV)
+    p = torch.from_numpy(rng.integers(0, R, n)).to(DEV)
+    o = torch.empty(n, dtype=torch.int64, device=DEV)
+    for i0 in range(0, n, 128):
+        o[i0:i0 + 128] = eng.score_sp(T, s[i0:i0 + 128], p[i0:i0 + 128]).topk(kth, dim=1).indices[:, -1]
+    return s, p, o
+
+
+@pytest.mark.parametrize("model,E,R,d,n,K,chunks", CASES)
+def test_band_and_rescore_counts_equal_the_split_kernels(model, E, R, d, n, K, chunks):
+    """kge_score_rank_sp_po_band against kge_score_rank_sp_po under KGE_FLAG_SPLIT_QUERY on the shapes of the table
+    above (ragged tiles and row groups, chunks, hub rows, one / two / no filter sets, duplicate entity rows = exact
+    ties), on triples that rank high (the k-th best entity of (s, p): what the band is for): every count equal, no pair
+    dropped, every list empty afterwards.  With the wide tie band (0.05) of the second pass -- and on the small tables,
+    where the k-th best of a few hundred entities is not far out -- the lists overflow: then the dropped pairs must be
+    REPORTED (the caller's signal to count the batch again), and the counts must not exceed the split kernel's."""
+    from kge_amd import engine as eng
+    rng = np.random.default_rng(E + 31 * n + K)
+    T = _tables(eng, model, E, R, d, seed=E + n, flags=eng.FLAG_SPLIT_QUERY)
+    s, p, o = _planted(eng, T, rng, E, R, n, max(2, E // 10000))
+    dup = rng.integers(0, E, min(E // 2, 40))
+    T.ent[dup] = T.ent[rng.integers(0, E, len(dup))]
+    T.ent[rng.integers(0, E, min(4, n))] = T.ent[o[:4]]       # exact ties with true rows
+    t_sp, t_po = _true_scores(eng, T, s, p, o)
+    f_sp = _filters(rng, n, E, K, o.cpu().numpy(), hub_rows=(n // 2,))
+    f_po = _filters(rng, n, E, K, s.cpu().numpy(), hub_rows=(0,))
+    chunks = chunks or ((0, E),)
+    complete, seen = 0, []
+    for atol, rtol in ((1e-5, 1e-4), (0.05, 0.0)):
+        want, got, stats = _split_vs_band(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, chunks, atol, rtol)
+        seen.append(stats)
+        if all(st[1] == 0 for st in stats):
+            complete += 1
+            assert all(st[0] > 0 for st in stats), stats   # (the true column itself is always inside its band)
+            assert torch.equal(got, want), (model, E, n, K, atol, stats, (got != want).nonzero()[:5].tolist(),
+                                            got[got != want][:5].tolist(), want[got != want][:5].tolist())
+        else:
+            assert bool((got <= want).all()), (model, E, n, K, atol, stats)
+    assert complete >= (1 if E >= 2000 else 0), (model, E, n, K, seen)
+    for buf in eng._RANK_BITS.values():
+        assert int(buf.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("model,E,d,n", [("complex", 60000, 256, 512), ("distmult", 14541, 512, 512),
+                                         ("complex", 300007, 256, 300), ("distmult", 100003, 512, 1100)])
+def test_band_and_rescore_on_planted_true_scores_lists_few_pairs(model, E, d, n):
+    """The band's regime at size: ~5e-5 of the pairs listed, none dropped, counts == the split kernel's."""
+    from kge_amd import engine as eng
+    R, K = 7, 2
+    rng = np.random.default_rng(E + d)
+    T = _tables(eng, model, E, R, d, seed=E + d, flags=eng.FLAG_SPLIT_QUERY)
+    s, p, o = _planted(eng, T, rng, E, R, n, max(2, E // 10000))
+    T.ent[rng.integers(0, E, 8)] = T.ent[o[:8]]       # exact ties with true rows
+    t_sp, t_po = _true_scores(eng, T, s, p, o)
+    f_sp = _filters(rng, n, E, K, o.cpu().numpy(), hub_rows=(n // 2,))
+    f_po = _filters(rng, n, E, K, s.cpu().numpy(), hub_rows=(0,))
+    want, got, stats = _split_vs_band(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, ((0, E),), 1e-5, 1e-4)
+    listed, dropped, pairs = stats[0]
+    assert dropped == 0 and 2 * n <= listed < 5e-4 * pairs, stats
+    assert torch.equal(got, want), ((got != want).nonzero()[:5].tolist(), got[got != want][:5].tolist(),
+                                    want[got != want][:5].tolist())
+    # a band without split queries is an argument error
+    T1 = _tables(eng, model, E, R, d, seed=E + d)
+    cnt = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=DEV)
+    with pytest.raises(Exception):
+        eng.score_rank_sp_po(T1, s, p, o, t_sp, t_po, f_sp, f_po, 1e-5, 1e-4, cnt[0, 0], cnt[0, 1], cnt[1, 0], cnt[1, 1],
+                             band=eng.RankBand(T1, n))
+    assert int(cnt.abs().sum()) == 0
+
+
+def test_band_on_random_triples_reports_the_pairs_it_drops():
+    """Random triples put the true score into the bulk of its row: 1.5 % of the pairs are inside the band, the waves'
+    lists (255 pairs each) overflow, and the status words say so -- sticky over calls; lists and filter bits are clean
+    afterwards and a following call on triples that rank high is complete and exact."""
+    from kge_amd import engine as eng
+    E, R, d, n, K = 14541, 11, 512, 512, 2
+    rng = np.random.default_rng(3)
+    T = _tables(eng, "complex", E, R, d, seed=3, flags=eng.FLAG_SPLIT_QUERY)
+    s, p, o = (torch.from_numpy(rng.integers(0, hi, n)).to(DEV) for hi in (E, R, E))
+    t_sp, t_po = _true_scores(eng, T, s, p, o)
+    f_sp = _filters(rng, n, E, K, o.cpu().numpy())
+    f_po = _filters(rng, n, E, K, s.cpu().numpy())
+    band = eng.RankBand(T, n)
+    cnt = torch.zeros(2, 2, K + 1, n, dtype=torch.int64, device=DEV)
+    seen = []
+    for call in (1, 2):
+        assert eng.score_rank_sp_po(T, s, p, o, t_sp, t_po, f_sp, f_po, 1e-5, 1e-4, cnt[0, 0], cnt[0, 1], cnt[1, 0],
+                                    cnt[1, 1], band=band)
+        seen.append(band.status())
+    assert seen[0][1] > 0 and seen[1] == (2 * seen[0][0], 2 * seen[0][1]), seen
+    assert seen[0][0] > 1e-3 * band.pairs_of(n)
+    assert int(band.list.view(torch.int32).view(-1, 1024)[:, 0].abs().sum()) == 0
+    for buf in eng._RANK_BITS.values():
+        assert int(buf.count_nonzero()) == 0
+    s, p, o = _planted(eng, T, rng, E, R, n, 2)
+    t_sp, t_po = _true_scores(eng, T, s, p, o)
+    want, got, stats = _split_vs_band(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, ((0, E),), 1e-5, 1e-4)
+    assert stats[0][1] == 0 and torch.equal(got, want)
+
+
+def test_band_and_rescore_with_nan_and_infinite_scores():
+    """Rows without a finite band (true score NaN / +-inf) list every pair of their wave -- dropped pairs, reported --;
+    finite rows of OTHER waves are unaffected; a table with an infinite entry has no finite row-norm bound at all."""
+    from kge_amd import engine as eng
+    E, R, d, n = 3000, 5, 256, 160
+    rng = np.random.default_rng(5)
+    T = _tables(eng, "distmult", E, R, d, seed=9, flags=eng.FLAG_SPLIT_QUERY)
+    s, p, o = _planted(eng, T, rng, E, R, n, 2)
+    t_sp, t_po = _true_scores(eng, T, s, p, o)
+    f_sp = _filters(rng, n, E, 2, o.cpu().numpy())
+    f_po = _filters(rng, n, E, 2, s.cpu().numpy())
+    want, got, stats = _split_vs_band(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, ((0, E),), 1e-5, 1e-4)
+    assert stats[0][1] == 0 and torch.equal(got, want)
+    t_bad = t_sp.clone()
+    t_bad[:3] = torch.tensor([float("inf"), float("-inf"), float("nan")], device=DEV)   # rows of the first wave
+    want, got, stats = _split_vs_band(eng, T, s, p, o, t_bad, t_po, f_sp, f_po, ((0, E),), 1e-5, 1e-4)
+    assert stats[0][1] > 0                                   # the first wave's lists overflowed: reported
+    assert torch.equal(got[:, :, :, 32:], want[:, :, :, 32:])   # the other waves' rows are complete and exact
+    assert torch.equal(got[1], want[1])                      # ... and the whole po side
+    T.ent[10, 0] = float("inf")
+    band = eng.RankBand(T, n)
+    assert not bool(torch.isfinite(band.tmax).all())
+    want, got, stats = _split_vs_band(eng, T, s, p, o, t_sp, t_po, f_sp, f_po, ((0, E),), 1e-5, 1e-4)
+    assert stats[0][1] > 0 and bool((got <= want).all())
+
+
+@pytest.mark.parametrize("model,E,d,bs", [("complex", 60000, 256, 256), ("distmult", 30000, 512, 200)])
+def test_evaluator_takes_band_and_rescore_on_tables_that_rank_their_triples_high(model, E, d, bs, monkeypatch):
+    """EntityRankingEvaluator with split queries (the parity-compliant setting) and band_rescore "auto": on an
+    evaluation split whose triples score in the tail of their rows (a trained model) the probe batch lists ~5e-5 of its
+    pairs, the run counts through kge_eval_batch_band (lanes, captured batches, ragged last batch), and per-example
+    ranks and metrics are those of the split kernel.  On random triples the probe lists 1.5 % and the evaluator keeps
+    the split kernel; forced on (band_rescore=True) such a run drops pairs, notices at its end, and runs again on the
+    split kernel -- the same result."""
+    from kge_amd import engine as eng
+    from kge_amd.eval import EntityRankingEvaluator
+    from kge_amd.synthetic import make_splits
+    R = 9
+    rng = np.random.default_rng(E)
+    T = _tables(eng, model, E, R, d, seed=d + E, flags=eng.FLAG_SPLIT_QUERY)
+    splits = make_splits(E, R, 6000, 8 * bs + 37, 300, seed=E)
+    random_valid = splits["valid"].copy()
+    s, p, o = _planted(eng, T, rng, E, R, len(splits["valid"]), max(2, E // 10000))
+    splits["valid"] = torch.stack([s, p, o], 1).cpu().numpy()
+    calls = {"band": 0, "plain": 0}
+    orig = eng.eval_batch
+
+    def counting(*a, **k):
+        calls["band" if k.get("band") is not None else "plain"] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(eng, "eval_batch", counting)
+    ev = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs)
+    m1, r1 = ev.run(return_ranks=True)
+    assert ev.band_runs == 1 and not ev._band_off and calls["band"] >= 3, (ev.band_listed, calls)
+    listed, pairs = ev.band_listed
+    assert 0 < listed <= ev.BAND_MAX_LISTED * pairs
+    m1b, r1b = ev.run(return_ranks=True)   # a second run: held graphs, refreshed bands
+    assert ev.band_runs == 2 and m1b == m1 and all(np.array_equal(r1[k], r1b[k]) for k in r1)
+    ref = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, band_rescore=False)
+    before = calls["band"]
+    m2, r2 = ref.run(return_ranks=True)
+    assert calls["band"] == before and ref.band_runs == 0
+    assert m1 == m2
+    for k in r2:
+        assert np.array_equal(r1[k], r2[k]), (k, np.nonzero(r1[k] != r2[k])[0][:5])
+    assert float(m1["mean_reciprocal_rank"]) > 0.1   # (the planted triples do rank high)
+    # random triples: the probe sees a bulk true score in every row
+    splits["valid"] = random_valid
+    ev2 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs)
+    m5 = ev2.run()
+    assert ev2.band_runs == 0 and ev2.band_listed[0] > ev2.BAND_MAX_LISTED * ev2.band_listed[1]
+    # ... forced on: pairs are dropped, the run notices and repeats itself on the split kernel
+    ev3 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, band_rescore=True)
+    m3, r3 = ev3.run(return_ranks=True)
+    ref3 = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs, band_rescore=False)
+    m4, r4 = ref3.run(return_ranks=True)
+    assert ev3._band_off and ev3.band_runs == 0 and m3 == m4 == m5 and all(np.array_equal(r3[k], r4[k]) for k in r4)
