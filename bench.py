@@ -1187,11 +1187,15 @@ def main():
                              "contiguous output rows, allocation inside the timed calls"}
         for mode_key, md in modes.items():
             leg = {}
-            for nn in (512, 2048, 4096):
+            # (100 / 128 / 256: LibKGE's default train.batch_size / eval.batch_size is 100, config-default.yaml:214,417)
+            for nn in (100, 128, 256, 512, 2048, 4096):
                 q = torch.Generator().manual_seed(1000 + nn)
                 sn, pn, on = (torch.randint(hi, (nn,), generator=q).to(device) for hi in (E_FB, R_FB, E_FB))
                 row = {}
+                # score_sp_padded: what the plugin's models return without a recorded gradient (`padded_scores`, default
+                # true): the [:, :E] view of rows on the pitch engine.score_pitch(E) -- the same C entry with that ldo
                 for name, call, sides in (("score_sp", lambda: engine.score_sp(md.T, sn, pn), 1),
+                                          ("score_sp_padded", lambda: engine.score_sp(md.T, sn, pn, padded=True), 1),
                                           ("score_sp_po", lambda: engine.score_sp_po(md.T, sn, pn, on), 2)):
                     for _ in range(3):
                         call()

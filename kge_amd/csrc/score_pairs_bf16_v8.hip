@@ -1324,28 +1324,37 @@ __global__ __launch_bounds__(256) void pairs_bf16_rescore_kernel(V8RescoreArgs a
     long long col = (long long)rec[1];
     if (col >= a.m) col = a.m - 1;
     const int my_t = (int)col;
-#pragma unroll 4
+    // (all of a batch's row pieces requested before the first is stored: one memory latency per batch)
+    u32x4 gv[32 * SPR / 64];
+#pragma unroll
     for (int it = 0; it < 32 * SPR / 64; ++it) {
       const int idx = it * 64 + lane, row = idx / SPR, c = idx % SPR;
       const int trow = __shfl(my_t, row, 64);
-      const u32x4 v = *reinterpret_cast<const u32x4*>(tgb + (long long)trow * tld2 + c * 16);
-      *reinterpret_cast<u32x4*>(lds + row * ROWB + ((c ^ (row & 15)) << 4)) = v;
+      gv[it] = *reinterpret_cast<const u32x4*>(tgb + (long long)trow * tld2 + c * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < 32 * SPR / 64; ++it) {
+      const int idx = it * 64 + lane, row = idx / SPR, c = idx % SPR;
+      *reinterpret_cast<u32x4*>(lds + row * ROWB + ((c ^ (row & 15)) << 4)) = gv[it];
     }
     // (the block is this wave's own and a wave's LDS operations execute in order: the compiler must keep the other
     // lanes' stores in front of this lane's reads, and the reads in front of the next batch's stores)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // both chains; a chain's NKB fragments are requested back to back (one L2 latency per chain, not one per K-block)
     f32x16 acc[2];
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       const unsigned char* fb = gbase + (2 * part + blk) * (NKB * 1024) + lane * 16;
+      bf16x8 af[NKB];
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) af[kb] = *reinterpret_cast<const bf16x8*>(fb + kb * 1024);
       f32x16 ac = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int kb = 0; kb < NKB; ++kb) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(fb + kb * 1024);
         const bf16x8 bq = *reinterpret_cast<const bf16x8*>(lds + fi * ROWB + (((2 * kb + fh) ^ (fi & 15)) << 4));
-        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, af, ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq, af[kb], ac, 0, 0, 0);
       }
       acc[part] = ac;
     }

@@ -258,9 +258,10 @@ def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
     return out
 
 
-def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
+def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None, padded=None):
     ex = _ext()
-    if ex and out is None and not t.pad_pitch and torch.is_tensor(a) and torch.is_tensor(p) and \
+    padded = t.pad_pitch if padded is None else bool(padded)
+    if ex and out is None and not padded and torch.is_tensor(a) and torch.is_tensor(p) and \
             (targets is None or torch.is_tensor(targets)):
         with _on_device(t.device):
             fl = t.flags if flags is None else flags
@@ -275,8 +276,10 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
     m = t.num_ent if targets is None else keep[-1].numel()
     ret = None
     if out is None:
-        if t.pad_pitch and m % 32:
-            ldo = (m + 31) // 32 * 32
+        if padded and m > 0:
+            # whole 256-byte lines per row, an odd number of them (score_pitch): every 16-byte lane store of the kernels
+            # stays inside a 32-byte sector and the rows spread over the memory channels; the caller gets the [:, :m] view
+            ldo = score_pitch(m)
             out = _empty((n, ldo), t.device)
             ret = out[:, :m]
         else:
@@ -295,14 +298,17 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None):
     return out if ret is None else ret
 
 
-def score_sp(t: Tables, s, p, o=None, flags=None) -> torch.Tensor:
-    """[n, E|m] scores of (s_i, p_i, ·) against all / the listed objects."""
-    return _pairs("kge_score_sp", t, s, p, o, flags)
+def score_sp(t: Tables, s, p, o=None, flags=None, padded=None) -> torch.Tensor:
+    """[n, E|m] scores of (s_i, p_i, ·) against all / the listed objects.  padded=True (default: the tables'
+    `pad_pitch`): the [:, :m] view of a matrix on the row pitch `score_pitch(m)` -- sector-aligned rows, what the store
+    kernels are measured on (E = 14,541 is odd: rows of a contiguous matrix start at 4-byte granularity); the reference
+    returns a contiguous tensor, so this is an option."""
+    return _pairs("kge_score_sp", t, s, p, o, flags, padded=padded)
 
 
-def score_po(t: Tables, p, o, s=None, flags=None) -> torch.Tensor:
-    """[n, E|m] scores of (·, p_i, o_i) against all / the listed subjects."""
-    return _pairs("kge_score_po", t, o, p, s, flags)
+def score_po(t: Tables, p, o, s=None, flags=None, padded=None) -> torch.Tensor:
+    """[n, E|m] scores of (·, p_i, o_i) against all / the listed subjects; `padded` as for score_sp."""
+    return _pairs("kge_score_po", t, o, p, s, flags, padded=padded)
 
 
 def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Tensor:

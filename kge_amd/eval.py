@@ -134,6 +134,9 @@ class EntityRankingEvaluator:
     # band-and-rescore (engine.RankBand): taken for a run when its first batch lists at most this share
     # of its (row, column) pairs -- a trained model: ~5e-5; random tables list 1.5e-2 and keep the split kernel
     BAND_MAX_LISTED = 5e-4
+    # ... and, under "auto", only from this many entities on: the form costs two launches and a read of every row's q_lo
+    # block per (side, chunk) -- ~14 us at the FB15k-237 shape, where the split kernel's whole second chain is 16 us
+    BAND_MIN_ENTITIES = 100000
 
 
     def __init__(self, model, splits: Dict[str, np.ndarray], num_entities: int, num_relations: int,
@@ -288,6 +291,8 @@ class EntityRankingEvaluator:
                     and bool(int(tables.flags) & engine.FLAG_SPLIT_QUERY) and tables.ent.dtype == torch.bfloat16
                     and tables.ent.shape[1] in (256, 512) and len(self.triples) > 0
                     and tables.scorer in (engine.SCORERS["complex"], engine.SCORERS["distmult"]))
+        if use_band and self.band_rescore == "auto" and E < self.BAND_MIN_ENTITIES:
+            use_band = False
         if use_band:
             for b in st.setdefault("bands", {}).values():
                 b.refresh(tables)

@@ -147,7 +147,9 @@ class HipEntityRankingJob(EntityRankingJob):
             want_band = self.config.get("hip_entity_ranking.band_rescore")
         except KeyError:
             want_band = "auto"
-        if (split_tables is not None and rank_flags and chunk_size >= E and want_band in ("auto", True, "true", "True")
+        from ..eval import EntityRankingEvaluator as _Ev
+        if (split_tables is not None and rank_flags and chunk_size >= E and want_band in ("auto", "always")
+                and (want_band != "auto" or E >= _Ev.BAND_MIN_ENTITIES)
                 and fused_tables().ent.is_cuda and fused_tables().ent.shape[1] in (256, 512)):
             band = getattr(self, "_rank_band", None)
             ft = fused_tables()

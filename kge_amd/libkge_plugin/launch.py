@@ -6,7 +6,8 @@ shim therefore sets per rank before handing over:
     fail.  Rank 0 gets the folder the user named (`--folder`, or LibKGE's default local/experiments/<time>-<config>),
     rank r > 0 gets the sibling `<folder>-rank<r>` (its own log and trace; checkpoints are written by rank 0 only;
     a sub-folder would create <folder> under rank 0's feet);
-  * `job.device`: `cuda` becomes `cuda:<LOCAL_RANK>` unless the command line names a device.
+  * `job.device`: the config file's `cuda` (or no setting) becomes `cuda:<LOCAL_RANK>`; a device named on the command
+    line, or anything else in the config file (`cpu`, `cuda:3`), stands.
 The process group (RCCL for cuda, gloo for cpu) is created here from torchrun's environment so that the folder name
 can be agreed on; the hip_sharded_* jobs find it initialised.  Without torchrun's environment this is plain `kge`.
 """
@@ -24,6 +25,25 @@ def _arg(argv, name):
     return None
 
 
+def _config_device(argv):
+    """`job.device` of the config file named on the command line (flat `job.device:` or nested `job: {device: }`), or None."""
+    cfg = next((a for a in argv[1:] if a.endswith((".yaml", ".yml")) and os.path.isfile(a)), None)
+    if cfg is None:
+        return None
+    try:
+        import yaml
+        with open(cfg) as f:
+            doc = yaml.safe_load(f) or {}
+    except Exception:
+        return None
+    if isinstance(doc.get("job.device"), str):
+        return doc["job.device"]
+    job = doc.get("job")
+    if isinstance(job, dict) and isinstance(job.get("device"), str):
+        return job["device"]
+    return None
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -32,9 +52,12 @@ def main(argv=None):
     if world > 1 and "MASTER_ADDR" in os.environ:
         import torch
         import torch.distributed as dist
-        device = _arg(argv, "--job.device")
+        device = on_cli = _arg(argv, "--job.device")
+        if device is None:  # not on the command line: what the config file says (a YAML `job.device: cpu` must stand)
+            device = _config_device(argv)
         cuda = torch.cuda.is_available() and (device is None or device.startswith("cuda"))
-        if device is None and cuda:
+        # the config's bare `cuda` (LibKGE's default) becomes this rank's device; a device the command line names stands
+        if cuda and on_cli is None and device in (None, "cuda"):
             argv += ["--job.device", f"cuda:{local}"]
         if cuda:
             torch.cuda.set_device(local)

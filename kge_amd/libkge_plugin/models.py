@@ -153,19 +153,32 @@ class _FusedScoring:
             return None
         return _ScoreNegBlocks.apply(self._scorer.name, self._scorer._norm, ent, rel, s, p, o, neg_s, neg_o)
 
+    def _padded(self) -> bool:
+        """`padded_scores` (hip_*.yaml, default true): where no gradient is recorded -- evaluation, scoring under
+        torch.no_grad() -- score_sp / score_po return the [:, :E] view of a matrix whose rows start on whole 256-byte
+        lines (engine.score_pitch): what the store kernels are measured on (E is odd on most datasets: the rows of a
+        contiguous [n, E] float matrix start at 4-byte granularity and every 16-byte lane store straddles sectors).
+        The values are the same; a caller that needs contiguous memory calls .contiguous()."""
+        if torch.is_grad_enabled():
+            return False
+        try:
+            return bool(self.get_option("padded_scores"))
+        except KeyError:
+            return False
+
     def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
         if not self._fused():
             return super().score_sp(s, p, o)
         ent, rel = self._w()
         return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp", ent, rel, s, p, o,
-                                 self._fwd_tables())
+                                 self._fwd_tables(), self._padded())
 
     def score_po(self, p: Tensor, o: Tensor, s: Tensor = None) -> Tensor:
         if not self._fused():
             return super().score_po(p, o, s)
         ent, rel = self._w()
         return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, s,
-                                 self._fwd_tables())
+                                 self._fwd_tables(), self._padded())
 
     # 1vsAll loss fused with the scoring (HipTrainingJob1vsAll; kge_ce_fwd / kge_ce_bwd)
     def _ce_tables(self):

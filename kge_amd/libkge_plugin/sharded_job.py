@@ -66,24 +66,17 @@ from ..sharded_train import ENT_KEY, REL_KEY, _ShardedJob
 from .eval_job import HipEntityRankingJob
 from .train_job import _CudaOomText, _plain_bce
 
-# tests hand in their stand-in backend here (None: kge_amd.engine, the HIP kernels)
+# The scoring backend of a job.device cpu job (None: kge_amd.engine, the HIP kernels -- which have no CPU path, so such a
+# job fails loudly).  The CPU test suite assigns its oracle-backed stand-in to this attribute in the processes it starts
+# (tests/_launch_with_oracle_backend.py for jobs under torchrun); nothing in the package reads the environment for it,
+# and on a GPU it is never looked at.
 SHARD_BACKEND = None
 
 
 def _backend_for(device):
-    """None (= kge_amd.engine) on a GPU, always.  job.device cpu has no kernels to run on: the CPU tests name their
-    stand-in either in SHARD_BACKEND or, for jobs started through the launcher in processes of their own, in the
-    environment (KGE_AMD_TEST_SHARD_BACKEND=module:attribute) -- honoured for CPU jobs ONLY."""
     if torch.device(device).type == "cuda":
         return None
-    if SHARD_BACKEND is not None:
-        return SHARD_BACKEND
-    spec = os.environ.get("KGE_AMD_TEST_SHARD_BACKEND")
-    if spec:
-        import importlib
-        mod, attr = spec.split(":")
-        return getattr(importlib.import_module(mod), attr)
-    return None
+    return SHARD_BACKEND
 
 _SCORER_BY_CLASS = {"ComplExScorer": "complex", "DistMultScorer": "distmult", "TransEScorer": "transe",
                     "RotatEScorer": "rotate", "HipComplExScorer": "complex", "HipDistMultScorer": "distmult",

@@ -191,11 +191,16 @@ class KgeModel(torch.nn.Module):
         return (pos, None if neg_s is None else self.score_neg(s, p, o, 0, neg_s),
                 None if neg_o is None else self.score_neg(s, p, o, 2, neg_o))
 
+    # score_sp / score_po without a recorded gradient return the [:, :E] view of a matrix with sector-aligned rows
+    # (engine.score_pitch) instead of a contiguous tensor: see the plugin's `padded_scores` option
+    padded_scores = True
+
     def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
         if self._fused():
             return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp",
                                      self._entity_embedder.weight,
-                                     self._relation_embedder.weight, s, p, o, self._fwd_tables())
+                                     self._relation_embedder.weight, s, p, o, self._fwd_tables(),
+                                     self.padded_scores and not torch.is_grad_enabled())
         se, pe = self._entity_embedder.embed(s), self._relation_embedder.embed(p)
         oe = self._entity_embedder.embed_all() if o is None else self._entity_embedder.embed(o)
         return self._scorer.score_emb(se, pe, oe, combine="sp_")
@@ -204,7 +209,8 @@ class KgeModel(torch.nn.Module):
         if self._fused():
             return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po",
                                      self._entity_embedder.weight,
-                                     self._relation_embedder.weight, o, p, s, self._fwd_tables())
+                                     self._relation_embedder.weight, o, p, s, self._fwd_tables(),
+                                     self.padded_scores and not torch.is_grad_enabled())
         se = self._entity_embedder.embed_all() if s is None else self._entity_embedder.embed(s)
         oe, pe = self._entity_embedder.embed(o), self._relation_embedder.embed(p)
         return self._scorer.score_emb(se, pe, oe, combine="_po")
@@ -523,10 +529,13 @@ class BF16Shadow:
 
 class _ScorePairs(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, name, l_norm, direction, ent, rel, a, p, targets, fwd_tables=None):
+    def forward(ctx, name, l_norm, direction, ent, rel, a, p, targets, fwd_tables=None, padded=False):
         t = engine.Tables(name, ent.detach(), rel.detach(), l_norm)
         tf = t if fwd_tables is None else fwd_tables  # mixed precision: bf16 copies, forward only
-        out = (engine.score_sp if direction == "sp" else engine.score_po)(tf, *((a, p) if direction == "sp" else (p, a)), targets)
+        # padded (the models' `padded_scores` option, honoured where no gradient is recorded): the scores as the [:, :m]
+        # view of a matrix with sector-aligned rows (engine.score_pitch)
+        out = (engine.score_sp if direction == "sp" else engine.score_po)(tf, *((a, p) if direction == "sp" else (p, a)), targets,
+                                                                          padded=bool(padded))
         ctx.t, ctx.direction, ctx.idx = t, direction, (a, p, targets)
         ctx.tf = fwd_tables
         ctx.save_for_backward(out)
@@ -548,7 +557,7 @@ class _ScorePairs(torch.autograd.Function):
             ge = torch.zeros_like(ctx.t.ent)
             _scatter_rows(ge, targets, g_t)
         _scatter_rows(ge, a, g_a)
-        return None, None, None, ge, gr, None, None, None, None
+        return None, None, None, ge, gr, None, None, None, None, None
 
 
 class _FusedCE(torch.autograd.Function):

@@ -490,6 +490,7 @@ def test_evaluator_takes_band_and_rescore_on_tables_that_rank_their_triples_high
         calls["band" if k.get("band") is not None else "plain"] += 1
         return orig(*a, **k)
     monkeypatch.setattr(eng, "eval_batch", counting)
+    monkeypatch.setattr(EntityRankingEvaluator, "BAND_MIN_ENTITIES", 1000)   # (auto takes effect from 100,000 entities on)
     ev = EntityRankingEvaluator(T, splits, E, R, eval_split="valid", batch_size=bs)
     m1, r1 = ev.run(return_ranks=True)
     assert ev.band_runs == 1 and not ev._band_off and calls["band"] >= 3, (ev.band_listed, calls)

@@ -322,7 +322,8 @@ def test_one_shard_job_with_embedder_dropout_equals_the_reference_job(tmp_path):
 
 
 def test_launcher_runs_kge_start_on_two_ranks(tmp_path):
-    """`torchrun --nproc-per-node 2 -m kge_amd.libkge_plugin.launch start cfg.yaml --folder F --job.device cpu`: an
+    """`torchrun --nproc-per-node 2 -m kge_amd.libkge_plugin.launch start cfg.yaml --folder F --job.device cpu` (through
+    tests/_launch_with_oracle_backend.py, which hands the CPU stand-in backend to the plugin and calls that launcher): an
     unmodified kge.cli underneath, rank 0 in F, rank 1 in F-rank1, checkpoints written by rank 0 only, the training
     trace of both ranks carrying the same losses -- and the same as the in-process run of the case above."""
     import subprocess
@@ -349,12 +350,12 @@ def test_launcher_runs_kge_start_on_two_ranks(tmp_path):
         yaml.safe_dump(cfg, f)
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
-    env = dict(os.environ, KGE_AMD_TEST_SHARD_BACKEND="test_sharded_gloo_cpu:OracleBackend", PYTHONDONTWRITEBYTECODE="1",
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1",
                PYTHONPATH=os.pathsep.join([os.path.join(root, "oracle", "ref_stubs"), rh.REFERENCE_ROOT, root, here,
                                            os.path.join(root, "oracle"), tmp, os.environ.get("PYTHONPATH", "")]))
     folder = os.path.join(tmp, "run")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), "-m", "kge_amd.libkge_plugin.launch", "start", path,
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(here, "_launch_with_oracle_backend.py"), "start", path,
            "--folder", folder, "--job.device", "cpu", "--console.quiet", "True"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=tmp)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -376,3 +377,31 @@ def test_launcher_runs_kge_start_on_two_ranks(tmp_path):
     assert len(l0) == 2 and l0 == l1, (l0, l1)
     ck = rh.load_checkpoint(os.path.join(folder, "checkpoint_00002.pt"), "cpu")
     assert ck["model"][0]["_entity_embedder._embeddings.weight"].shape[1] == 16 and ck["epoch"] == 2
+
+
+def test_the_plugin_imports_nothing_named_by_the_environment():
+    """until round 6 `sharded_job._backend_for` imported `module:attr` from KGE_AMD_TEST_SHARD_BACKEND.
+    The package reads the environment for switches of its own behaviour only -- never for a module, attribute or path
+    to import: no importlib / __import__ / exec / eval next to an environment read anywhere under kge_amd/."""
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "kge_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            src = open(os.path.join(dirpath, f)).read()
+            if "KGE_AMD_TEST_SHARD_BACKEND" in src:
+                offenders.append((f, "KGE_AMD_TEST_SHARD_BACKEND"))
+            if re.search(r"importlib\.import_module|__import__\(|\bexec\(|\beval\(", src) and "os.environ" in src:
+                for m in re.finditer(r"importlib\.import_module\(([^)]*)\)|__import__\(([^)]*)\)", src):
+                    arg = (m.group(1) or m.group(2) or "")
+                    if "environ" in arg or "getenv" in arg or "spec" in arg:
+                        offenders.append((f, m.group(0)))
+    assert offenders == [], offenders
+    import kge_amd.libkge_plugin.sharded_job as sj
+    os.environ["KGE_AMD_TEST_SHARD_BACKEND"] = "os:path"
+    try:
+        assert sj._backend_for("cpu") is sj.SHARD_BACKEND
+    finally:
+        del os.environ["KGE_AMD_TEST_SHARD_BACKEND"]

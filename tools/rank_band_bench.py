@@ -40,3 +40,19 @@ for tag, T_, b in (("split", Tsp, None), ("single_pass", T1, None), ("band_nothi
         fn()
     print("far true scores, no filters:", tag, "%.1f us" % (bench.event_avg_ms(fn, steps) * 1e3))
 print("pairs listed, dropped:", band.status())
+
+# the same at the FB15k-237 shape (d = 512): where the band form's fixed costs show
+E, R, d = bench.E_FB, bench.R_FB, bench.DIM
+g = torch.Generator(device=dev).manual_seed(7)
+ent = (torch.randn(E, d, generator=g, device=dev) * 0.3).bfloat16()
+rel = (torch.randn(R, d, generator=g, device=dev) * 0.3).bfloat16()
+s, p, o = (torch.from_numpy(rng.integers(0, hi, n)).to(dev) for hi in (E, R, E))
+Tsp = engine.Tables("complex", ent, rel, flags=engine.FLAG_SPLIT_QUERY)
+T1 = engine.Tables("complex", ent, rel, flags=0)
+band = engine.RankBand(Tsp, n)
+for tag, T_, b in (("split", Tsp, None), ("single_pass", T1, None), ("band_nothing_to_rescore", Tsp, band)):
+    fn = lambda: engine.score_rank_sp_po(T_, s, p, o, far, far, [], [], 1e-5, 1e-4, cnt[0, 0], cnt[0, 1], cnt[1, 0],
+                                         cnt[1, 1], band=b)
+    for _ in range(3):
+        fn()
+    print("FB15k-237 shape, far true scores, no filters:", tag, "%.1f us" % (bench.event_avg_ms(fn, steps) * 1e3))
