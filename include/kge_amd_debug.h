@@ -59,6 +59,12 @@ int kge_debug_set_switch(const char* name, int64_t value);
 /* the switch's value (-1: unset), -2 for an unknown name */
 int64_t kge_debug_get_switch(const char* name);
 
+/* 1: this library was built with -DKGE_STALL_INJECT -- in front of every workgroup barrier and every LDS-DMA piece of
+ * the hand-synchronised matrix-core kernels a wave sleeps, with probability 1/4, for a pseudo-random 0 .. ~2,000 cycles
+ * (common.hpp: kge_stall).  The race / timing pass of SURVEY.md 5: tools/gpu_stall_inject.sh rebuilds the library that
+ * way on the GPU box and runs the bit-equality tests under it (profiles/r6_stall_injection.txt).  0: the product build. */
+int kge_debug_stall_build(void);
+
 #ifdef __cplusplus
 }
 #endif

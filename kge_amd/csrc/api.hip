@@ -1248,6 +1248,16 @@ int kge_score_rank_sp_po_band(const kge_tables* t, kge_index s, kge_index p, kge
                          band);
 }
 
+// 1: this library was built with -DKGE_STALL_INJECT (random sleeps in front of the barriers and LDS-DMA pieces of the
+// hand-synchronised kernels: tools/gpu_stall_inject.sh); 0: the product build
+int kge_debug_stall_build() {
+#ifdef KGE_STALL_INJECT
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 int64_t kge_rank_band_list_bytes(int64_t n) { return pairs_bf16_band_list_bytes(n); }
 
 int kge_table_max_row_norm(const kge_tables* t, int64_t row_begin, int64_t m, float* out, void* stream) {

@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
     // the DMA with vmcnt(0) (it cannot tell the ring's buffers apart) -- no latency hiding at all, 4.9 k
     // cycles per K step measured.  The waits are placed by hand below.
     const unsigned int dst = lds0 + (unsigned int)(buf * G16_STAGE + (wave * G16_DMA_PER_WAVE + u) * 1024);
+    KGE_STALL(__LINE__ + 5000);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(dst), "v"(src) : "memory", "m0");
   };
   auto issue_range = [&](int step, int buf, auto lo, auto hi) __attribute__((always_inline)) {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    KGE_BARRIER();
     pend_step = st + 2 < nsteps ? st_lo + st + 2 : -1;
     pend_buf = (st + 2) % G16_NST;
   };
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
   // group 0 ends up with columns 0-63 of its 64 x 128 block (j = 0, 1), its partner w + 4 with columns 64-127
   stamp();  // 2: K loop done (MFMAs issued)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA may outlive the workgroup's LDS
-  __builtin_amdgcn_s_barrier();                      // every wave has read its last fragments
+  KGE_BARRIER();                      // every wave has read its last fragments
   auto exchange = [&](auto kg) __attribute__((always_inline)) {  // kg = this wave's K group, compile-time:
     constexpr int KG = decltype(kg)::value;                       // no dynamic indexing of the accumulators
     unsigned char* give = smem + ((wq * 2 + KG) * 16) * 1024 + lane * 16;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
         }
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    KGE_BARRIER();
     stamp();  // 3: halves exchanged
     // the sums of this wave's 64 x 64 block, in place of the half it keeps
     constexpr int KOFF = KG ? 2 : 0;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(512, 1) void gemm16_kernel(G16Args g) {
           for (int e = 0; e < 4; ++e) acc[i][jj + KOFF][4 * q + e] += v[e];
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave has taken its partner's half: the exchange area is free
+    KGE_BARRIER();  // every wave has taken its partner's half: the exchange area is free
     // Store through a wave-private row-major image of the block (64 rows x 272 B): the accumulator layout
     // puts one column per lane (64 dword stores of 2 x 128 B each, 5.7 k cycles to issue); from the image every
     // store instruction writes 4 rows x 256 contiguous bytes, 16 bytes per lane.

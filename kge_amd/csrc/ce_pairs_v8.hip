@@ -46,6 +46,7 @@ struct V8CeArgs {
 };
 
 #define KGE_V8C_DMA(D, VO, P) \
+  KGE_STALL(__LINE__ + 8000); \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0")
 
 template <int HH, int EPI>
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"((PF - 1) * NT) : "memory");
         if constexpr (kb == PBH) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"i"(VMB) : "memory");  // this wave's pieces of unit ks + 1 have landed
-          __builtin_amdgcn_s_barrier();                                // P(ks)
+          KGE_BARRIER();                                // P(ks)
         }
         __builtin_amdgcn_sched_barrier(0);
         v4_static_for<0, NT>([&](auto ac) __attribute__((always_inline)) {
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
         lab = ((long long)lab_hi << 32) | (unsigned int)lab_lo;
       }
       if (first) {
-        __builtin_amdgcn_s_barrier();  // R0: units 0 .. 2 of the list have landed
+        KGE_BARRIER();  // R0: units 0 .. 2 of the list have landed
         v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) {
           v4_static_for<0, NT>([&](auto ac) __attribute__((always_inline)) {
             bread(bq[decltype(ac)::value][decltype(jc)::value], jc, ac);

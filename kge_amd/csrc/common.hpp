@@ -641,6 +641,34 @@ __device__ __forceinline__ void eval_begin_row(const EvalLists& L, const Index& 
   }
 }
 
+// ---- Stall injection (builds with -DKGE_STALL_INJECT only; tools/gpu_stall_inject.sh; SURVEY.md 5 "Race detection").
+// The matrix-core kernels synchronise their LDS rings by hand: one workgroup barrier per unit and counted
+// `s_waitcnt vmcnt(N)`, N = the vector-memory operations a wave has issued since the piece it waits for.  Both silent-
+// corruption bugs of earlier rounds lived there and both needed a particular TIMING (a table from HBM instead of L2).
+// This build perturbs the timing: in front of every workgroup barrier and every LDS-DMA piece of those kernels a wave
+// sleeps, with probability 1/4, for a pseudo-random 0 .. ~2,000 cycles (a hash of the cycle counter, the wave and the
+// site) -- producers fall behind consumers and the other way round, waves of a workgroup drift apart by whole units.
+// s_sleep is not a memory operation: the counted waits see the same counts.  The bit-equality tests (every kernel
+// against the oracle and against its sibling kernels) must pass unchanged under it.
+#ifdef KGE_STALL_INJECT
+__device__ __forceinline__ void kge_stall(unsigned int site) {
+  const unsigned long long c = __builtin_readcyclecounter();
+  unsigned int h = (unsigned int)c * 2654435761u ^ site * 40503u ^ ((blockIdx.x << 3) + (threadIdx.x >> 6)) * 9176u;
+  h ^= h >> 13;
+  h *= 0x5bd1e995u;
+  h ^= h >> 15;
+  h = (unsigned int)__builtin_amdgcn_readfirstlane((int)h);  // one decision per wave
+  if ((h & 3u) == 0u) {
+    const unsigned int reps = (h >> 2) & 31u;
+    for (unsigned int i = 0; i < reps; ++i) __builtin_amdgcn_s_sleep(1);  // 64 cycles each
+  }
+}
+#define KGE_STALL(site) kge_stall((unsigned int)(site))
+#else
+#define KGE_STALL(site) do { } while (0)
+#endif
+#define KGE_BARRIER() do { KGE_STALL(__LINE__); __builtin_amdgcn_s_barrier(); } while (0)
+
 // ---- fill_words_async: what the library uses INSTEAD of hipMemsetAsync.  A hipMemsetAsync captured into a hipGraph
 // becomes a memset node that ROCm replays with its blit fill kernel (__amd_rocclr_fillBufferAligned) from a 16-byte
 // pattern the graph does not own: after ~100 replays of a captured training step the relation-gradient buffer came

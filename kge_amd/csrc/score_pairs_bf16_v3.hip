@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     }
     // staging overlaps ring buffer 1: everyone must be done before tile 1 streams in
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    KGE_BARRIER();
     __builtin_amdgcn_sched_barrier(0);
     tile_dma(1, 1);
     stamp();  // 3+2*PASSES: prologue done, all waves synchronised
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void pairs_bf16_v3_kernel(
     if (tt == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NL) : "memory");
     else if (tt == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(NST) : "memory");
-    __builtin_amdgcn_s_barrier();  // tile tt visible to all; everyone finished reading tile tt-1
+    KGE_BARRIER();  // tile tt visible to all; everyone finished reading tile tt-1
     __builtin_amdgcn_sched_barrier(0);
     stamp();  // tile tt released
     // B fragment (K-block kb, half hf) of target row 32*hf + fi: 16-B slot s = s0(kb) + fh, stored

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
         if (k < ntl) tile_dma(k, ra[k], j2);
       long long rna = load_rows(NBUF, j2), rnb = load_rows(NBUF, j2 + 1);
       if (wave == 4) stamp_at(32);  // first tiles issued
-      if (!prebuilt) __builtin_amdgcn_s_barrier();  // B0
+      if (!prebuilt) KGE_BARRIER();  // B0
       for (int tt = 0; tt <= ntl; ++tt) {
         // VMEM queue of this wave: tile pieces, in order (index loads of the gathered-target modes only make a wait
         // longer): NL per tile for tiles 0 and 1 (the partner issued the other quarter), 2 NL from tile 2 on.  Tile
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (tt == 0 && wave == 4) stamp_at(37);  // this wave's pieces of tile 0 have landed
-        __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; the buffer of tile tt - 1 is free
+        KGE_BARRIER();  // B1(tt): tile tt landed; the buffer of tile tt - 1 is free
         if (tt == 0) {  // the rest of the ring
 #pragma unroll
           for (int k = FUP; k < NBUF; ++k) {
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
           rna = load_rows(tt + NBUF, j2);
           rnb = load_rows(tt + NBUF, j2 + 1);
         }
-        __builtin_amdgcn_s_barrier();  // B2(tt)
+        KGE_BARRIER();  // B2(tt)
       }
       // B2(ntl) is behind: the last tile's scores are staged and this wave has nothing left to stream -- it stores
       // them, while the store waves are still issuing the stores of the tile before (4.8 k -> 3.4 k cycles of tail)
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     }
     const long long h1 = load_rows(1, j2 + 1);
     if (wave == 6) stamp_at(38);  // its share of the first tiles issued
-    if (!prebuilt) __builtin_amdgcn_s_barrier();  // B0
+    if (!prebuilt) KGE_BARRIER();  // B0
     for (int tt = 0; tt <= ntl; ++tt) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the staging reads of the previous step are in registers
       // this wave's pieces of tiles 0 / 1 have landed (its first score stores are issued behind B1(2))
@@ -431,18 +431,18 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       if (tt == 0 && wave == 6) stamp_at(39);  // landed
-      __builtin_amdgcn_s_barrier();  // B1(tt): the consumers may overwrite the staging buffer
+      KGE_BARRIER();  // B1(tt): the consumers may overwrite the staging buffer
       if (tt == 0 && FUP == 1 && ntl > 1) tile_dma(1, h1, j2 + 1);  // its quarter of tile 1, with the rest of the ring
       if (tt == ntl) {
         // last round: nothing is staged behind this barrier pair for THIS wave (the DMA waves store the last tile)
-        __builtin_amdgcn_s_barrier();  // B2(ntl)
+        KGE_BARRIER();  // B2(ntl)
         if constexpr (STAGED)
           if (tt >= 2) store_tile(tt - 2);
         break;
       }
       if constexpr (STAGED)
         if (tt >= 2) store_tile(tt - 2);  // from registers, while the DMA waves issue tile tt+1
-      __builtin_amdgcn_s_barrier();  // B2(tt): scores of tile tt-1 are staged
+      KGE_BARRIER();  // B2(tt): scores of tile tt-1 are staged
       if constexpr (STAGED)
         if (tt >= 1) read_staging();
     }
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       if (lane == 0) *sb_flag = ok ? 1 : 0;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LDS write has landed before the barrier
     }
-    __builtin_amdgcn_s_barrier();  // B0: the shares of this row group are published (or given up on)
+    KGE_BARRIER();  // B0: the shares of this row group are published (or given up on)
     stamp();  // 2: all shares of this row group published
     const bool coop = *reinterpret_cast<volatile int*>(sb_flag) != 0;
     if (!coop) {
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   // front of its first MFMA (inside a loop it waits for all of them at the loop entry)
   auto tile = [&](int tt, auto first) __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // B1(tt): tile tt landed; staging drained
+    KGE_BARRIER();  // B1(tt): tile tt landed; staging drained
     __builtin_amdgcn_sched_barrier(0);
     stamp();  // tile tt released
     const unsigned int bt = (unsigned int)((tt % NBUF) * TILEB);
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(younger) : "memory");
       // first tile: fragment kb has arrived (in-order returns: at most NKB-1-kb younger loads
       // outstanding); a no-op afterwards
-      if constexpr (q == QB2) __builtin_amdgcn_s_barrier();  // B2(tt): the scores of tile tt-1 are staged
+      if constexpr (q == QB2) KGE_BARRIER();  // B2(tt): the scores of tile tt-1 are staged
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (q == 0) {
         const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
   if constexpr (RK_PIPE) rank_tile(ntl - 1);  // the last tile has no chain to hide behind
   // the last tile's scores: stage them for the loaders' final pass
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // B1(ntl)
+  KGE_BARRIER();  // B1(ntl)
   if constexpr (STAGED) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) c_write(acc0, 0, g);
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v4_kernel(
     for (int g = 0; g < 4; ++g) c_write(acc1, 1, g);
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // B2(ntl)
+  KGE_BARRIER();  // B2(ntl)
   if (nx.qf != nullptr && nx.mode == 2)  // no idle workgroups in this geometry: a slice of the next batch's queries
     v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)(rg * ncg + cg) * 256 + tid, (long long)nx.nblocks * 256);
   if constexpr (EPI == V3_LSE) {

@@ -44,6 +44,7 @@ typedef float f32x4v6u __attribute__((ext_vector_type(4), aligned(4)));
 
 // one LDS-DMA piece: 64 lanes x 16 B from row pointer P (SGPR pair) + per-lane offset VO to LDS address D (m0)
 #define KGE_V6_DMA(D, VO, P) \
+  KGE_STALL(__LINE__ + 6000); \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0")
 
 // LDS operations younger than the fragment read of slot kb when slot kb waits for it: the reads of the next seven
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
       if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (wave == 4) stamp_at(37);  // unit 0: this wave's pieces have landed
-      __builtin_amdgcn_s_barrier();  // R0
+      KGE_BARRIER();  // R0
       // (unit 2 is the store waves', behind P(0): they have nothing to move before P(1), and whoever issues 16 more
       // pieces before P(0) holds the consumers there -- the pieces queue behind the query fragments in the
       // vector-memory path: P(0) passed at 5.1 k cycles instead of 3.7 k)
@@ -256,10 +257,10 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
         if (u >= 1 && u + 2 < NU) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (wave == 4 && u < 8) stamp_at(40 + u);  // arrival at P(u)
-        __builtin_amdgcn_s_barrier();  // P(u)
+        KGE_BARRIER();  // P(u)
         if (u + 3 < NU) dma_rows(u + 3, r16, C16{});  // into the buffer of unit u - 1
       }
-      __builtin_amdgcn_s_barrier();  // F
+      KGE_BARRIER();  // F
       last_unit();
       if (wave == 4) stamp_at(36);  // last unit's stores issued
       return;
@@ -270,15 +271,15 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
     if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave == 6) stamp_at(39);
-    __builtin_amdgcn_s_barrier();  // R0
+    KGE_BARRIER();  // R0
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // its rows of unit 1
     if (wave == 6) stamp_at(48);
-    __builtin_amdgcn_s_barrier();  // P(0)
+    KGE_BARRIER();  // P(0)
     if (NU > 2) dma_rows(2, 16 * (wave & 1), C16{});  // unit 2: due at P(1), ~30 MFMA slots away
     for (int u = 1; u < NU; ++u) {
       if (u == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // unit 2 (no store has been issued yet)
       if (wave == 6 && u < 8) stamp_at(48 + u);  // arrival at P(u)
-      __builtin_amdgcn_s_barrier();  // P(u): unit u - 1 is staged in staging[(u - 1) & 1]
+      KGE_BARRIER();  // P(u): unit u - 1 is staged in staging[(u - 1) & 1]
       const int sb = (u - 1) & 1;
       if constexpr (SPLIT) {
         read_block(sb, wave & 1, cv[0]);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
       }
       if (u == 1 && wave == 6) stamp_at(33);  // first stores issued
     }
-    __builtin_amdgcn_s_barrier();  // F
+    KGE_BARRIER();  // F
     last_unit();
     if (wave == 6) stamp_at(34);  // last store issued
     if (wave == 6 && dbg != nullptr) {
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
     v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(v6_younger(kb, !FIRST)) : "memory");
-      if constexpr (kb == V6_PB) __builtin_amdgcn_s_barrier();  // P(u)
+      if constexpr (kb == V6_PB) KGE_BARRIER();  // P(u)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kb == 0) {
         const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
   };
   using T = std::true_type;
   using Fz = std::false_type;
-  __builtin_amdgcn_s_barrier();  // R0: unit 0 landed
+  KGE_BARRIER();  // R0: unit 0 landed
   stamp();  // 2
   v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
   chain(0, acc0, acc1, T{});
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v6_kernel(
   // (the look-ahead reads issued by the last chain land in bq[] until this wait: the registers stay "in use" up to
   // here, or the compiler hands them out as temporaries while a read is still on its way -- see pairs_bf16_v7_kernel)
   asm volatile("" : : "v"(bq[0]), "v"(bq[1]), "v"(bq[2]), "v"(bq[3]), "v"(bq[4]), "v"(bq[5]), "v"(bq[6]), "v"(bq[7]));
-  __builtin_amdgcn_s_barrier();  // F
+  KGE_BARRIER();  // F
   if (nx.qf != nullptr && nx.mode == 2)  // no idle workgroups in this geometry: a slice of the next batch's queries
     v4_build_queries<SCORER, HH, SPLIT>(nx, (long long)(rg * ncg + cg) * 256 + tid, (long long)nx.nblocks * 256);
 }
@@ -518,14 +519,14 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
     if (NU > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wave == 4) stamp_at(37);  // unit 0: this wave's pieces have landed
-    __builtin_amdgcn_s_barrier();  // R0
+    KGE_BARRIER();  // R0
     for (int u = 0; u < NU; ++u) {
       // unit u + 1 has landed: behind it in this wave's queue only unit u + 2 (from u = 1 on, while it exists)
       if (u >= 1 && u + 2 < NU) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (wave == 4 && u < 8) stamp_at(40 + u);  // arrival at P(u)
       if (wave == 6 && u < 8) stamp_at(48 + u);
-      if constexpr (!(PROBE & 8)) __builtin_amdgcn_s_barrier();  // P(u)
+      if constexpr (!(PROBE & 8)) KGE_BARRIER();  // P(u)
       if (u == 0 && NU > 2) dma8(2);
       if constexpr (!(PROBE & 2))
         if (u + 3 < NU) dma8(u + 3);  // into the buffer of unit u - 1
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
     v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
       constexpr int kb = decltype(kc)::value;
       asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-      if constexpr (kb == V6_PB && !(PROBE & 8)) __builtin_amdgcn_s_barrier();  // P(u)
+      if constexpr (kb == V6_PB && !(PROBE & 8)) KGE_BARRIER();  // P(u)
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kb == 0) {
         const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v7_kernel(
   };
   using T = std::true_type;
   using Fz = std::false_type;
-  __builtin_amdgcn_s_barrier();  // R0: unit 0 landed
+  KGE_BARRIER();  // R0: unit 0 landed
   stamp();  // 2
   v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
   chain(0, acc0, acc1, T{});

@@ -68,6 +68,7 @@ struct V8Args {
 };
 
 #define KGE_V8_DMA(D, VO, P) \
+  KGE_STALL(__LINE__ + 7000); \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0")
 
 template <int SCORER, int SPLIT, int AUX, int VAR = 0>
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
           // this wave's pieces of unit ks + 1 have landed (cold: requested right behind R0; since then 7 stores, 14
           // fragment loads and unit 2's pieces of slots 1 - 13)
           asm volatile("s_waitcnt vmcnt(%0)" ::"i"(COLD ? 25 : VMN) : "memory");
-          __builtin_amdgcn_s_barrier();  // P(ks)
+          KGE_BARRIER();  // P(ks)
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (kb == 0) {
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
         fill_unit(0);
         load_fragments(C0{}, CF{});
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(FR0) : "memory");  // unit 0's four pieces: this wave's oldest operations
-        __builtin_amdgcn_s_barrier();  // R0: unit g0 has landed
+        KGE_BARRIER();  // R0: unit g0 has landed
         stamp();  // 1
         fill_unit(1);
         v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { bread(bq[decltype(jc)::value], jc); });
@@ -827,7 +828,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"((PF - 1) * NT) : "memory");
         if constexpr (kb == PBH) {
           asm volatile("s_waitcnt vmcnt(%0)" ::"i"(VMB) : "memory");  // this wave's pieces of unit ks + 1 have landed
-          if constexpr (!(PROBE & 4)) __builtin_amdgcn_s_barrier();   // P(ks)
+          if constexpr (!(PROBE & 4)) KGE_BARRIER();   // P(ks)
         }
         __builtin_amdgcn_sched_barrier(0);
         v4_static_for<0, NACC>([&](auto ac) __attribute__((always_inline)) {
@@ -1048,7 +1049,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_rank_kernel(V8RankArgs a
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) asm volatile("" : "+v"(afr[part][kb]));
       if (first) {
-        __builtin_amdgcn_s_barrier();  // R0: units 0 .. 2 of the list have landed
+        KGE_BARRIER();  // R0: units 0 .. 2 of the list have landed
         if (HALF == 0) stamp();
         v4_static_for<0, PF>([&](auto jc) __attribute__((always_inline)) {
           v4_static_for<0, NT>([&](auto ac) __attribute__((always_inline)) {
