@@ -1257,15 +1257,18 @@ def main():
                      "scored_triples_per_s": n * E_FB / (f_ms * 1e-3)}
         del T32
         # The distance scorers on the same score_sp call (float32 tables; no matrix-core form: VALU-bound).  Vector
-        # operations per scored coordinate: TransE (l_norm 1) sub, add, |.|+add = 3 per REAL coordinate; RotatE per
+        # operations per scored coordinate: TransE (l_norm 1) ONE subtract + ONE add with the |x| source modifier = 2 per
+        # REAL coordinate (round 6: pairs_transe_kernel issues exactly those, the subtracts of two rows packed; until
+        # round 5 this leg counted 3 and the kernel spent ~2.7 issue slots); RotatE per
         # COMPLEX coordinate 4 for the rotation (2 mul + 2 fma), 2 sub, 2 for re^2 + im^2, 11 issue slots for the
         # correctly rounded sqrt (common.hpp sqrt_rn_core: the quarter-rate v_rsq_f32 + 7), 2 for the range check's
         # min / max, 1 add: ~22 (with the compiler's IEEE sqrt sequence it was ~30).  Peak: 256 CUs x
         # 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-operations/s.
         VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
         exact = {"bound": "valu", "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
-                 "kernel": "pairs_exact_kernel<scorer> (kge_score_sp, float32 tables: the reference's arithmetic chain)"}
-        for name, rdim, ops in (("transe", DIM, 3.0 * DIM), ("rotate", DIM // 2, 22.0 * (DIM // 2))):
+                 "kernel": "pairs_transe_kernel (TransE, l_norm 1) / pairs_kernel<RotatE> (kge_score_sp, float32 tables: the "
+                           "reference's arithmetic chain)"}
+        for name, rdim, ops in (("transe", DIM, 2.0 * DIM), ("rotate", DIM // 2, 22.0 * (DIM // 2))):
             gq = torch.Generator().manual_seed(11)
             Tx = engine.Tables(name, ent.float(), torch.empty(R_FB, rdim).normal_(0, 0.1, generator=gq).to(device),
                                l_norm=1.0)

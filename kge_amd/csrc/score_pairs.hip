@@ -18,6 +18,7 @@
 //             k-ordered fmaf chain (cdna guide section 3), i.e. the canonical order.
 //             TransE/RotatE: 4x4 register micro-tile per thread on the VALU.
 #include "common.hpp"
+#include "switches.hpp"
 
 namespace kge {
 
@@ -245,6 +246,147 @@ __global__ __launch_bounds__(256) void pairs_kernel(Operand A, Operand R, Operan
   if constexpr (RANK) rank_acc_flush<PT_BM>(racc, row0, n, rk, tid);
 }
 
+// ---- TransE store path (round 6) ----------------------------------------------------------------
+// score = -|| q - t ||_p with q = s + r (sp_) / o - r (_po), transe.py:22-34: per element ONE subtract and ONE
+// accumulate -- `acc + |x|` (L1; the absolute value is a source modifier) or fma(x, x, acc) (L2).  The generic kernel
+// above spends 2.7 instruction slots per element on it (4 x 4 micro-tile: an LDS read per 8 elements, scalar
+// subtracts).  Here: 128 query rows x 64 targets per workgroup, 8 x 4 outputs per thread, the subtracts of two rows as
+// one packed instruction (float2 arithmetic: v_pk_add_f32 with a negated operand; L2: v_pk_fma_f32 as well), six
+// ds_read_b128 per 64 elements.  The chain of every output is the canonical one (coordinate pairs in order, first-half
+// element then second-half element: oracle/kge_oracle.c pair_score) -- packing changes which LANE-SLOT computes an
+// element, not its operands or its order: the same bits as pairs_kernel<KGE_TRANSE>.
+constexpr int TE_BM = 128, TE_BN = 64, TE_KC = 16, TE_LDQ = 132, TE_LDT = 68;
+typedef float te_f2 __attribute__((ext_vector_type(2)));
+
+template <typename T, int NORM>
+__global__ __launch_bounds__(256, 4) void pairs_transe_kernel(Operand A, Operand R, Operand TG, int dir, int d,
+                                                           long long n, long long m, float* __restrict__ out,
+                                                           long long ldo) {
+  static_assert(NORM == NORM_L1 || NORM == NORM_L2, "general p keeps the generic kernel (libm pow)");
+  __shared__ __attribute__((aligned(16))) float Qs[2][TE_KC][TE_LDQ];
+  __shared__ __attribute__((aligned(16))) float Ts[2][TE_KC][TE_LDT];
+  const int tid = threadIdx.x;
+  const long long row0 = (long long)blockIdx.y * TE_BM, col0 = (long long)blockIdx.x * TE_BN;
+  const int hh = d / 2;  // d % 8 == 0 on this path: hh % 4 == 0
+  const int nchunk = (hh + TE_KC - 1) / TE_KC;
+  // staging roles.  Queries: row qs_r, the coordinate quads qs_c and qs_c + 2 of the chunk's four (the two lanes of a
+  // row write LDS rows four apart: different banks).  Targets: row ts_r, quad ts_c.
+  const int qs_r = tid >> 1, qs_c = tid & 1;
+  const int ts_r = tid >> 2, ts_c = tid & 3;
+  long long qrow = row0 + qs_r;
+  if (qrow >= n) qrow = n - 1;  // rows beyond n are computed and never stored
+  long long trow = col0 + ts_r;
+  if (trow >= m) trow = m - 1;
+  const T* arow = (const T*)A.base + index_at(A.idx, qrow) * A.ld;
+  const T* rrow = (const T*)R.base + index_at(R.idx, qrow) * R.ld;
+  const T* tgrow = (const T*)TG.base + index_at(TG.idx, trow) * TG.ld;
+  f32x4 a0[2], a1[2], r0[2], r1[2], t0, t1;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto gload = [&](int ch) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int c = ch * TE_KC + (qs_c + 2 * k) * 4;
+      if (c >= hh) {  // chunk tail beyond the row: zeros (|0 - 0| adds nothing)
+        a0[k] = a1[k] = r0[k] = r1[k] = zero4;
+      } else {
+        a0[k] = ld4<T>(arow + c);
+        a1[k] = ld4<T>(arow + hh + c);
+        r0[k] = ld4<T>(rrow + c);
+        r1[k] = ld4<T>(rrow + hh + c);
+      }
+    }
+    const int c = ch * TE_KC + ts_c * 4;
+    if (c >= hh) {
+      t0 = t1 = zero4;
+    } else {
+      t0 = ld4<T>(tgrow + c);
+      t1 = ld4<T>(tgrow + hh + c);
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      f32x4 q0, q1;
+      build_q4<KGE_TRANSE>(dir, a0[k], a1[k], r0[k], r1[k], q0, q1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Qs[0][(qs_c + 2 * k) * 4 + i][qs_r] = q0[i];
+        Qs[1][(qs_c + 2 * k) * 4 + i][qs_r] = q1[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Ts[0][ts_c * 4 + i][ts_r] = t0[i];
+      Ts[1][ts_c * 4 + i][ts_r] = t1[i];
+    }
+  };
+  const int tx = tid & 15, ty = tid >> 4;  // outputs: rows ty * 8 .. + 7, columns tx * 4 .. + 3
+  // L1: scalar accumulators (v_add_f32 with the |x| source modifier: the packed add has no such modifier);
+  // L2: packed ones (v_pk_fma_f32).  acc2[i][j] / (accs[2 i][j], accs[2 i + 1][j]) = rows (2 i, 2 i + 1) x column j
+  te_f2 acc2[4][4];
+  float accs[8][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc2[i][j] = te_f2{0.0f, 0.0f};
+      accs[2 * i][j] = accs[2 * i + 1][j] = 0.0f;
+    }
+  gload(0);
+  sstore();
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ++ch) {
+    if (ch + 1 < nchunk) gload(ch + 1);
+#pragma unroll 4
+    for (int cc = 0; cc < TE_KC; ++cc) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // first-half element, then second-half element: the canonical order
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(&Qs[h][cc][ty * 8]);
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(&Qs[h][cc][ty * 8 + 4]);
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(&Ts[h][cc][tx * 4]);
+        const te_f2 q2[4] = {te_f2{qa[0], qa[1]}, te_f2{qa[2], qa[3]}, te_f2{qb[0], qb[1]}, te_f2{qb[2], qb[3]}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const te_f2 x = q2[i] - te_f2{tv[j], tv[j]};
+            if (NORM == NORM_L1) {
+              // acc + |x| as ONE instruction each (the source modifier): written as asm because the vectoriser pairs the
+              // two adds into a v_pk_add_f32 behind two v_and_b32 -- four slots per two elements instead of three
+              asm("v_add_f32 %0, |%1|, %0" : "+v"(accs[2 * i][j]) : "v"(x[0]));
+              asm("v_add_f32 %0, |%1|, %0" : "+v"(accs[2 * i + 1][j]) : "v"(x[1]));
+            } else {
+              acc2[i][j] = __builtin_elementwise_fma(x, x, acc2[i][j]);
+            }
+          }
+      }
+    }
+    __syncthreads();
+    if (ch + 1 < nchunk) sstore();
+    __syncthreads();
+  }
+  const bool vec_out = (ldo % 4) == 0 && (((uintptr_t)out) & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long orow = row0 + ty * 8 + i;
+    if (orow >= n) continue;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = NORM == NORM_L1 ? accs[i][j] : acc2[i >> 1][j][i & 1];
+      v[j] = NORM == NORM_L1 ? -a : -__builtin_sqrtf(a);
+    }
+    const long long ocol = col0 + tx * 4;
+    if (vec_out && ocol + 4 <= m) {
+      *reinterpret_cast<f32x4*>(out + orow * ldo + ocol) = v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (ocol + j < m) out[orow * ldo + ocol + j] = v[j];
+    }
+  }
+}
+
 // ---- host dispatch ------------------------------------------------------------------------
 static inline bool aligned16p(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -263,6 +405,18 @@ template <int SCORER, typename T, int NORM>
 static int launch_pairs(bool vec, bool mfma, const Operand& A, const Operand& R,
                         const Operand& TG, int dir, int d, int dr, long long n, long long m,
                         float lp, int round_q, float* out, long long ldo, hipStream_t st, const RankArgs* rk) {
+  if constexpr (SCORER == KGE_TRANSE && (NORM == NORM_L1 || NORM == NORM_L2)) {
+    // the store path on aligned rows: the 8 x 4 packed kernel (same bits; the counting epilogue and ragged rows keep
+    // the generic kernel).  L1 (transe.yaml's default l_norm) by default: 316 -> 244 us (float32) / 292 -> 217 us (bf16)
+    // at the FB15k-237 shape; L2 gains nothing (its subtract + fma pair is not what bounds the generic kernel) and
+    // takes this kernel only under SW_TRANSE_GENERIC = 0 (tests).  SW_TRANSE_GENERIC = 1 (tests): never.
+    const long long tsw = sw(SW_TRANSE_GENERIC);
+    if (vec && rk == nullptr && tsw != 1 && (NORM == NORM_L1 || tsw == 0)) {
+      dim3 tgrid((unsigned)((m + TE_BN - 1) / TE_BN), (unsigned)((n + TE_BM - 1) / TE_BM));
+      hipLaunchKernelGGL((pairs_transe_kernel<T, NORM>), tgrid, dim3(256), 0, st, A, R, TG, dir, d, n, m, out, ldo);
+      return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+    }
+  }
   dim3 grid((unsigned)((m + PT_BN - 1) / PT_BN), (unsigned)((n + PT_BM - 1) / PT_BM));
   constexpr bool DOT = (SCORER == KGE_COMPLEX || SCORER == KGE_DISTMULT);
   // counting launch: column tiles per workgroup -- as many as still leave four workgroups per compute unit (<= 16)

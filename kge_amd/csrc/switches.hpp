@@ -28,6 +28,7 @@ enum Switch : int {
   SW_V8,                   // 0: the persistent store kernel declines everything; 1: takes single batches too
   SW_V8_VAR,               // probe builds (-DKGE_V8_PROBES)
   SW_V8R_PROBE,            // probe builds (-DKGE_V8_PROBES)
+  SW_TRANSE_GENERIC,       // 1: TransE score_sp / score_po on the generic 4 x 4 kernel (the cross-check of pairs_transe_kernel)
   SW_COUNT
 };
 

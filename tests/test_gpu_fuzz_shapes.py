@@ -318,3 +318,36 @@ def test_random_shape_counts_inside_the_scoring_kernel(seed):
     assert torch.equal(got, want), (model, d, E, n, K, chunks, (got != want).nonzero()[:5].tolist())
     for buf in eng._RANK_BITS.values():
         assert int(buf.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_packed_transe_kernel_gives_the_generic_kernels_bits(seed, kge_switch):
+    """pairs_transe_kernel (round 6: 128 x 64 tiles, 8 x 4 outputs per thread, packed subtracts, |x| as a source
+    modifier) against pairs_kernel<KGE_TRANSE> (the 4 x 4 micro-tile it replaces on aligned rows; switch TRANSE_GENERIC)
+    and against the oracle: seeded shapes around the tile edges (n mod 128, E mod 64), d with and without a ragged last
+    chunk (hh mod 16), L1 and L2, float32 and bf16 tables, both directions, listed targets, padded and contiguous
+    output rows (vector and scalar stores).  Bit-exact: the chain of every output is the canonical one either way."""
+    from kge_amd import engine as eng
+    rng = np.random.default_rng(7000 + seed)
+    d = int(rng.choice([8, 24, 64, 104, 128, 256, 512]))
+    E = max(2, int(rng.integers(0, 12)) * 64 + RES[int(rng.integers(0, len(RES)))])
+    n = NS[int(rng.integers(0, len(NS)))]
+    R = 5
+    l_norm = float(rng.choice([1.0, 2.0]))
+    dtype = (torch.float32, torch.bfloat16)[seed % 2]
+    ent = torch.from_numpy((rng.standard_normal((E, d)) * 0.5).astype(np.float32)).to(dtype).to(DEV)
+    rel = torch.from_numpy((rng.standard_normal((R, d)) * 0.5).astype(np.float32)).to(dtype).to(DEV)
+    s, p, o = (torch.from_numpy(rng.integers(0, hi, n)).to(DEV) for hi in (E, R, E))
+    sub = torch.from_numpy(rng.integers(0, E, 97)).to(DEV) if seed % 3 == 0 else None
+    T = eng.Tables("transe", ent, rel, l_norm)
+    got = {}
+    for which in ("packed", "generic"):
+        kge_switch.set("TRANSE_GENERIC", 1 if which == "generic" else 0)   # (0: the packed kernel for L2 as well)
+        got[which] = (eng.score_sp(T, s, p, sub), eng.score_po(T, p, o, sub), eng.score_sp(T, s, p, sub, padded=True),
+                      eng.score_sp_po(T, s, p, o, sub))
+    for a, b in zip(got["packed"], got["generic"]):
+        assert a.shape == b.shape and torch.equal(a, b), (d, E, n, l_norm, dtype, (a != b).nonzero()[:4].tolist())
+    to = ko.Tables("transe", ent.float().cpu().numpy(), rel.float().cpu().numpy(), l_norm)
+    tg = None if sub is None else sub.cpu().numpy()
+    want = ko.score_sp(to, s.cpu().numpy(), p.cpu().numpy(), tg)
+    assert np.array_equal(got["packed"][0].cpu().numpy(), want), (d, E, n, l_norm, dtype)
