@@ -1244,6 +1244,32 @@ def main():
                              "scored_triples_per_s": 4 * nn * E_FB / (ms * 1e-3)}
             del qn, outn, trin
         extra["score_sp_groups_by_batch"] = by_n
+        # d = 256 -- BASELINE configs[4]'s dimension (Wikidata5M ComplEx d = 256).  Until round 6 the persistent store
+        # kernel existed for d = 512 only and these groups ran one launch per batch on the round-3 kernels; now
+        # pairs_bf16_v8_ce_kernel<128, V3_STORE> (the parametric persistent structure with a score-store epilogue:
+        # 16-byte stores, whole sectors per instruction).  Single-pass queries; one-sided groups on the padded pitch.
+        by_d = {}
+        for tag, Ed, Ld in (("fb15k-237_shape", E_FB, 8), ("wikidata5m_shard", (E_WD + 7) // 8, 2)):
+            gd = torch.Generator(device=device).manual_seed(256)
+            e256 = (torch.randn(Ed, 256, generator=gd, device=device) * 0.1).bfloat16()
+            r256 = (torch.randn(R_FB, 256, generator=gd, device=device) * 0.1).bfloat16()
+            T256 = engine.Tables("complex", e256, r256)
+            q = torch.Generator().manual_seed(257)
+            trid = torch.stack([torch.randint(hi, (n * Ld,), generator=q) for hi in (Ed, R_FB, Ed)], 1).to(device)
+            qd = engine.build_queries_group(T256, "sp_", trid, n, Ld)
+            pd = engine.score_pitch(Ed)
+            outd = torch.empty(Ld, n, pd, device=device)
+            for _ in range(3):
+                engine.score_queries_group(T256, qd, outd[:, :, :Ed])
+            ms = event_avg_ms(lambda: engine.score_queries_group(T256, qd, outd[:, :, :Ed]), max(5, a.steps // 4))
+            abd = Ld * algorithmic_bytes(n, Ed, 256)
+            by_d[tag] = {"num_entities": Ed, "dim": 256, "batch": n, "batches_per_launch": Ld, "avg_launch_us": ms * 1e3,
+                         "us_per_batch": ms * 1e3 / Ld, "algorithmic_bytes_per_launch": abd,
+                         "frac": abd / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "scored_triples_per_s": Ld * n * Ed / (ms * 1e-3)}
+            del T256, qd, outd, e256, r256, trid
+            torch.cuda.empty_cache()
+        extra["score_sp_groups_d256"] = by_d
         # float32 tables (the dtype of an unmodified LibKGE config; the reference's own precision):
         # the exact f32 chain on v_mfma_f32_32x32x2_f32 -- MFMA-bound, flops = 2 n d m
         T32 = engine.Tables("complex", ent.float(), rel.float())

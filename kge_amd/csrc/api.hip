@@ -313,22 +313,25 @@ static int one_call_v8(const kge_tables* t, int dir, const Operand& A, const Ope
                        int64_t* done) {
   *done = 0;
   if (sw(SW_ONE_CALL_V8) == 0) return KGE_ERR_UNSUPPORTED;
-  if (t->dtype != KGE_BF16 || t->dim != 512 || TG.idx.ptr != nullptr || ws == nullptr || n < one_call_v8_min_rows())
+  const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0, two = A2 != nullptr;
+  const int d = (int)t->dim;
+  // d = 512, or -- single-pass queries -- d = 256 (round 6: the persistent structure's score-store epilogue)
+  if (t->dtype != KGE_BF16 || (d != 512 && !(d == 256 && !split)) || TG.idx.ptr != nullptr || ws == nullptr ||
+      n < one_call_v8_min_rows())
     return KGE_ERR_UNSUPPORTED;
   if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
   if (t->scorer != KGE_COMPLEX && t->scorer != KGE_DISTMULT) return KGE_ERR_UNSUPPORTED;
-  const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0, two = A2 != nullptr;
-  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, 512, A, R, TG) ||
-      (two && !pairs_bf16_v4_supported(t->scorer, t->dtype, 512, *A2, R, TG)))
+  if (!pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG) ||
+      (two && !pairs_bf16_v4_supported(t->scorer, t->dtype, d, *A2, R, TG)))
     return KGE_ERR_UNSUPPORTED;
   const long long L = n / ONE_CALL_V8_ROWS;
-  const long long per = pairs_bf16_v4_query_bytes(512, ONE_CALL_V8_ROWS, two, split);
+  const long long per = pairs_bf16_v4_query_bytes(d, ONE_CALL_V8_ROWS, two, split);
   if (L < 2 || L > (1 << 20) || ws_bytes < PAIRS_WS_CTRL_BYTES + L * per || (((uintptr_t)ws + PAIRS_WS_CTRL_BYTES) & 15))
     return KGE_ERR_UNSUPPORTED;
   void* const qf = (char*)ws + PAIRS_WS_CTRL_BYTES;
-  int rc = run_query_build_multi(t->scorer, split, A, A2, R, dir, 512, ONE_CALL_V8_ROWS, (int)L, qf, per, st);
+  int rc = run_query_build_multi(t->scorer, split, A, A2, R, dir, d, ONE_CALL_V8_ROWS, (int)L, qf, per, st);
   if (rc != KGE_OK) return rc;
-  rc = run_pairs_bf16_v8(t->scorer, split, TG, two, 512, ONE_CALL_V8_ROWS, m, (int)L, qf, per, out, ONE_CALL_V8_ROWS * ldo,
+  rc = run_pairs_bf16_v8(t->scorer, split, TG, two, d, ONE_CALL_V8_ROWS, m, (int)L, qf, per, out, ONE_CALL_V8_ROWS * ldo,
                          ldo, two ? b2 : 0, st, nullptr, NextQ{}, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
   if (rc == KGE_OK) *done = L * ONE_CALL_V8_ROWS;
   return rc;  // (UNSUPPORTED behind the build launch: the fragments are simply not used)
@@ -629,8 +632,9 @@ int kge_score_queries_multi(const kge_tables* t, int combine, const void* querie
   if (work && num_batches > 1 && out_stride < (n - 1) * ldo + width) return KGE_ERR_INVALID_ARG;  // blocks overlap
   if ((rc = check_index(targets, true))) return rc;
   if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
-  if (!queries_supported(t) || t->dim != 512 || targets.ptr) return KGE_ERR_UNSUPPORTED;
   const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
+  // groups: d = 512 (pairs_bf16_v8_kernel), d = 256 with single-pass queries (its parametric sibling's store epilogue)
+  if (!queries_supported(t) || (t->dim != 512 && !(t->dim == 256 && !split)) || targets.ptr) return KGE_ERR_UNSUPPORTED;
   const int64_t per = kge_queries_bytes(t, combine, n);
   if (work && num_batches > 1 && ((queries_stride & 15) || queries_stride < per)) return KGE_ERR_INVALID_ARG;
   Operand TG = ent_op(t, targets);
@@ -649,8 +653,16 @@ int kge_score_queries_multi(const kge_tables* t, int combine, const void* querie
       return run_query_build_multi(t->scorer, split, nA, combine == KGE_SP_PO ? &nA2 : nullptr, nR, ndir, (int)t->dim,
                                    next->n, (int)(num_batches > 0 ? num_batches : 1), next->queries, next_stride,
                                    (hipStream_t)stream);
-    nx = pairs_bf16_nextq(split, nA, combine == KGE_SP_PO ? &nA2 : nullptr, nR, ndir, next->n, (int)num_batches,
-                          next->queries, next_stride);
+    if (t->dim == 256 && num_batches > 1) {
+      // d = 256 groups: the store kernel has no in-launch build -- the next group's fragments by a launch of their own,
+      // in front of the scoring launch (independent work: the fragments live in another buffer)
+      rc = run_query_build_multi(t->scorer, split, nA, combine == KGE_SP_PO ? &nA2 : nullptr, nR, ndir, (int)t->dim, next->n,
+                                 (int)num_batches, next->queries, next_stride, (hipStream_t)stream);
+      if (rc != KGE_OK) return rc;
+    } else {
+      nx = pairs_bf16_nextq(split, nA, combine == KGE_SP_PO ? &nA2 : nullptr, nR, ndir, next->n, (int)num_batches,
+                            next->queries, next_stride);
+    }
   }
   if (!work) return KGE_OK;
   if (num_batches == 1)  // a group of one: the single-batch entry (its kernel choice: pairs_bf16_v7 / v6 / v8)

