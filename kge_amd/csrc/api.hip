@@ -319,9 +319,9 @@ static int one_call_v8(const kge_tables* t, int dir, const Operand& A, const Ope
   if (t->dtype != KGE_BF16 || (d != 512 && !(d == 256 && !split)) || TG.idx.ptr != nullptr || ws == nullptr ||
       n < one_call_v8_min_rows())
     return KGE_ERR_UNSUPPORTED;
-  // (d = 256 is store-bound -- half the matrix work per stored byte -- and its group kernel writes 32-byte sectors: it
-  // beats one launch per batch on the single-batch kernels at the FB15k-237 shape, 9.9 against 11.0 us per batch, and
-  // loses on a Wikidata5M shard, 377 against 339: tools/d256_store_probe.py, profiles/r6_d256_store_policies.txt)
+  // (d = 256: the group kernel is 2 x the single-batch kernels at the FB15k-237 shape -- 5.4-7.0 against 11-14.5 us per
+  // one-sided batch -- and on a par with them on a Wikidata5M shard, 291-326 against 305-339 us, where a "group" is two
+  // batches of 1.2 GB each: tools/d256_store_probe.py, profiles/r6_d256_store_policies.txt)
   if (d == 256 && m > 65536) return KGE_ERR_UNSUPPORTED;
   if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
   if (t->scorer != KGE_COMPLEX && t->scorer != KGE_DISTMULT) return KGE_ERR_UNSUPPORTED;

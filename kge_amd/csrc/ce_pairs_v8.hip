@@ -57,13 +57,17 @@ struct V8CeArgs {
 
 // EPI == V3_STORE (round 6; VERDICT r5 missing 3): the same structure as the score STORE path of d = 256 tables -- the
 // persistent store kernel pairs_bf16_v8_kernel is scheduled by hand for d = 512's 32-slot chains and had no d = 256 form,
-// so `configs[4]` (Wikidata5M, d = 256) stored its scores through the round-2/3 kernels.  A lane holds, per 32-column
-// sub-unit, four runs of four consecutive columns of ITS query row (MFMA(targets, queries)): four 16-byte stores, the
-// two lanes of a row filling whole 32-byte sectors between them in one instruction.  AUX: the stores' cache policy.
+// so `configs[4]` (Wikidata5M, d = 256) stored its scores through the round-2/3 kernels.  The operands are swapped for
+// this epilogue -- MFMA(queries, targets), the store kernel's orientation: a lane holds ONE column and sixteen rows, a
+// dword store writes two rows x 128 contiguous bytes (whole lines; the first form kept the loss kernels' orientation
+// and wrote 32 rows x 32 bytes per instruction: 9.9 us per one-sided batch at the FB15k-237 shape, of which the L2's
+// merging of partial lines was the larger part) -- and a unit is ONE 32-column sub-unit: 16 stores per burst keep the
+// count of operations in flight across two bursts inside the 6-bit vmcnt.  AUX: the stores' cache policy.
 template <int HH, int EPI, int AUX = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
   static_assert(EPI == V3_LSE || EPI == V3_DS || EPI == V3_STORE, "forward row statistics, the gradient of the scores, or the scores");
-  constexpr int NT = HH == 128 ? 2 : 1;   // 32-row sub-units of a unit, one accumulator each
+  constexpr bool ST = EPI == V3_STORE;
+  constexpr int NT = (HH == 128 && !ST) ? 2 : 1;   // 32-row sub-units of a unit, one accumulator each
   constexpr int UT = V8C_UT * NT;         // table rows per unit: 32 / 64
   constexpr int NKB = 2 * HH / 16;        // 32 / 16 K-blocks
   constexpr int ROWB = 4 * HH;            // bytes per table row
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
   constexpr int NP = UNITB / 1024 / 8;    // pieces per unit and wave: 4
   constexpr int PF = 4;                   // K-blocks read ahead
   constexpr int PB = NKB == 32 ? 14 : 6;  // K-block of the barrier (first half of the workgroup)
-  constexpr int NSTORE = EPI == V3_DS ? 2 * NT : (EPI == V3_STORE ? 4 * NT : 0);  // vector stores of a burst (at least)
+  constexpr int NSTORE = EPI == V3_DS ? 2 * NT : (ST ? 16 * NT : 0);  // vector stores of a burst (at least)
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   if (a.n < 0) smem[threadIdx.x] = 0;  // (never: keeps the allocation -- only asm names the array)
 
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
   float l2 = 0.0f, g_i = 0.0f, gb_i = 0.0f;
   __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)a.qf, 0, 0, 0x00020000);
   unsigned int gvo = 0;  // the lane's byte offset in the pair's G16 rows: row fi, 8 fh columns in
+  const unsigned int gld4 = ST ? (unsigned int)(a.ldo * 4) : 0u;  // V3_STORE: bytes per score row
 
   auto lse_sub = [&](f32x16& v, long long c0u) __attribute__((always_inline)) {
     // c0u: first column of the sub-unit
@@ -249,26 +254,17 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
       __builtin_amdgcn_raw_buffer_store_b128(o, grs, gvo + (unsigned int)(32 * h), colb, 0);
     }
   };
-  // V3_STORE: the sub-unit's 16 scores of this lane's row.  Every store instruction is issued UNCONDITIONALLY (the
-  // counted waits count them): rows beyond n fall outside the descriptor, and in the table's ragged last sub-unit the
-  // columns beyond m go through an offset beyond every descriptor (the hardware drops both).
+  // V3_STORE: acc[r] = score(row 8 (r >> 2) + 4 fh + (r & 3) of the wave's 32, column c0u + fi).  Every store instruction
+  // is issued UNCONDITIONALLY (the counted waits count them): rows beyond n fall outside the descriptor, and a lane whose
+  // column lies beyond m (the table's ragged last unit) stores through an offset beyond every descriptor -- the hardware
+  // drops both.  gvo = the lane's byte offset ((4 fh) rows down, fi columns in); the row of element r rides on top.
   auto sc_sub = [&](const f32x16& v, long long c0u, unsigned int colb) __attribute__((always_inline)) {
-    if (c0u + V8C_UT <= m) {
+    const unsigned int vo = (c0u + V8C_UT <= m || c0u + fi < m) ? gvo : 0x80000000u;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        // (copies first: __builtin_bit_cast straight on a vector element takes element 0 every time)
-        const f32x4 run = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, run), grs, gvo + (unsigned int)(32 * q), colb, AUX);
-      }
-    } else {
-      const long long c0 = c0u + 4 * fh;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int cc = 8 * (r >> 2) + (r & 3);
-        const unsigned int off = c0 + cc < m ? gvo + (unsigned int)(4 * cc) : 0x80000000u;
-        const float x = v[r];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), grs, off, colb, AUX);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float x = v[r];  // (a copy first: __builtin_bit_cast straight on a vector element takes element 0 every time)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), grs,
+                                            vo + (unsigned int)(8 * (r >> 2) + (r & 3)) * gld4, colb, AUX);
     }
   };
   // the row's results out (V3_LSE): the two lanes of a row -> one (max, sum exp) per row and column group
@@ -320,9 +316,11 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
           constexpr int sub = decltype(ac)::value;
           if constexpr (kb == 0) {
             const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][0], afr[0], zero, 0, 0, 0);
+            if constexpr (ST) acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[0], bq[sub][0], zero, 0, 0, 0);
+            else acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][0], afr[0], zero, 0, 0, 0);
           } else {
-            acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][kb % PF], afr[kb], acc[sub], 0, 0, 0);
+            if constexpr (ST) acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[kb], bq[sub][kb % PF], acc[sub], 0, 0, 0);
+            else acc[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bq[sub][kb % PF], afr[kb], acc[sub], 0, 0, 0);
           }
         });
         if constexpr (kb + PF == NKB) {
@@ -374,7 +372,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
         const long long rows_here = rb < a.n ? (a.n - rb < 32 ? a.n - rb : 32) : 0;
         float* const ob = a.out + (long long)lb * a.out_stride + (side ? a.out2_off : 0) + (rows_here > 0 ? rb : 0) * a.ldo;
         grs = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, (int)(rows_here * a.ldo * 4), 0x00020000);
-        gvo = (unsigned int)(((long long)fi * a.ldo + 4 * fh) * 4);
+        gvo = (unsigned int)(((long long)(4 * fh) * a.ldo + fi) * 4);
       }
       if constexpr (EPI == V3_DS) {
         l2 = ce.lse[orow + roff] * V3_LOG2E;
@@ -461,7 +459,7 @@ static bool v8c_geometry(int d, long long n, long long m, bool two_sided, int ep
                          int nbatch = 1, int reserve_cus = 0) {
   if ((d != 512 && d != 256) || n < 1 || m < 1) return false;
   const long long rgn1 = (n + 127) / 128;
-  const long long ut = d == 256 ? 2 * V8C_UT : V8C_UT;
+  const long long ut = (d == 256 && epi != V3_STORE) ? 2 * V8C_UT : V8C_UT;
   const long long cols = epi == V3_DS ? ld16 : m;  // the gradient pass also writes the pad columns of the pitch
   const long long nunits = (cols + ut - 1) / ut;
   if (rgn1 > (1 << 20) || (rgn1 + 1) * nunits >= (1LL << 30)) return false;

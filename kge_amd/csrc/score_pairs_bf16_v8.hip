@@ -489,12 +489,12 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
     // d = 256, single-pass queries: the parametric structure of ce_pairs_v8.hip with a score-store epilogue (the
     // kernel below is scheduled by hand for d = 512's 32-slot chains).  No in-launch build of the next group there.
     if (nx.qf != nullptr) return KGE_ERR_INVALID_ARG;
-    // Its stores are 16 bytes per lane = whole 32-byte sectors per row and instruction, four instructions of a wave per
-    // 128-byte line: PLAIN write-back stores let the L2 put the line together (7.1 us per one-sided batch of a group
-    // of eight at the FB15k-237 shape = 0.67 of the HBM roofline); write-through 12.1 us, `nt` 20.2 us -- they push the
-    // partial lines out (tools/d256_store_probe.py, profiles/r6_d256_store_policies.txt).  The switch still overrides.
+    // cache policy of its stores (tools/d256_store_probe.py, profiles/r6_d256_store_policies.txt): plain write-back up to
+    // ~1 GB of scores per launch (FB15k-237 shape, 8 one-sided batches = 238 MB: 5.4 us per batch against 5.9 write-
+    // through and 6.1-7.0 nt), write-through beyond (a Wikidata5M shard, 2.3 GB: 291 us per batch against 315)
+    const int pol = sc1e >= 0 ? (int)(sc1e & 3) : (st_aligned && bytes > 1e9 ? 1 : 0);
     const int rc = run_pairs_bf16_v8_store256(TG, two_sided, n, m, nbatch, qf, q_stride_bytes, out, out_stride, ldo,
-                                              out2_off, sc1e >= 0 ? (int)(sc1e & 3) : 0, reserve_cus, st);
+                                              out2_off, pol, reserve_cus, st);
     if (rc == KGE_OK) __atomic_fetch_add(&g_v8_launches[0], 1, __ATOMIC_RELAXED);
     return rc;
   }

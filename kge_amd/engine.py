@@ -261,6 +261,10 @@ def score_spo(t: Tables, s, p, o, flags=None) -> torch.Tensor:
 def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None, padded=None):
     ex = _ext()
     padded = t.pad_pitch if padded is None else bool(padded)
+    # (small batches gain nothing from aligned rows and lose the extension's shorter host path: 12.7 -> 15.3 us at
+    # n = 100, FB15k-237 shape; from n = 512 on the padded rows win: profiles/r6_bench_mid.json one_call_entry)
+    if padded and torch.is_tensor(a) and a.numel() < 512:
+        padded = False
     if ex and out is None and not padded and torch.is_tensor(a) and torch.is_tensor(p) and \
             (targets is None or torch.is_tensor(targets)):
         with _on_device(t.device):
