@@ -131,7 +131,9 @@ def _graphed_step_of(job, loss_fn):
     (`job._skip_optimizer_step`)."""
     from kge_amd.train_graph import GraphedStep
     opt = job.optimizer
-    real_step = opt.step
+    # (a job may build a second GraphedStep -- hip_KvsAll when its capacities grow --: always around the optimizer's OWN step)
+    real_step = getattr(job, "_real_optimizer_step", None) or opt.step
+    job._real_optimizer_step = real_step
 
     class _Opt:  # what GraphedStep needs of the optimizer, with the REAL step
         param_groups = opt.param_groups
@@ -304,9 +306,92 @@ class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
 
     def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
         super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
+        self._graph_step = None       # kge_amd.train_graph.GraphedStep over padded inputs (hip_KvsAll.graph_step)
+        self._graph_step_ok = None    # decided at the first batch that could take it (None: not yet)
+        self._graph_caps = None       # (rows per query type, label entries per query type) the captured step holds
+        self._graph_overflows = 0     # batches in a row that did not fit the capacities
+        self.graph_batches = 0        # batches that went through the GraphedStep (replayed or eager)
+        self._skip_optimizer_step = False
         if self.__class__ == HipTrainingJobKvsAll:
             for f in Job.job_created_hooks:
                 f(self)
+
+    # ---- hip_KvsAll.graph_step: forward + ONE backward for both query types + optimizer.step of a whole batch as one
+    # hipGraph replay (train_KvsAll.py:216-294 issues ~40 launches per batch from ~0.3 ms of Python; the kernel-level
+    # step replays in 0.2 ms: bench.py roofline_train.kvsall_step).  A batch's shapes vary -- how many of its queries
+    # are sp_ / _po, how many labels each has -- so the captured step works on PADDED inputs: `rows` queries per type
+    # and `labels` label entries per type; a padding row is query (0, 0) with the single label 0 and weight 0 in the
+    # batch loss (its loss row is finite, its gradient row exactly zero).  A batch that does not fit runs as before;
+    # three such batches in a row grow the capacities and capture again.
+    def _graph_inputs(self, per_type, batch_size, dev):
+        """-> the eight padded input tensors of the captured step, or None if the batch does not fit."""
+        rows_cap, lab_cap = self._graph_caps
+        out = []
+        for qt in ("sp_", "_po"):
+            if qt in per_type:
+                q0, q1, rowptr, col = per_type[qt]
+                n, nnz = len(q0), int(col.numel())
+            else:
+                q0 = q1 = col = torch.zeros(0, dtype=torch.long, device=dev)
+                rowptr = torch.zeros(1, dtype=torch.long, device=dev)
+                n, nnz = 0, 0
+            pad = rows_cap - n
+            if pad < 0 or nnz + pad > lab_cap:
+                return None
+            ids = torch.zeros(rows_cap, 2, dtype=torch.long, device=dev)
+            ids[:n, 0], ids[:n, 1] = q0, q1
+            rp = torch.empty(rows_cap + 1, dtype=torch.long, device=dev)
+            rp[:n + 1] = rowptr
+            if pad:
+                rp[n + 1:] = nnz + torch.arange(1, pad + 1, device=dev)
+            cl = torch.zeros(lab_cap, dtype=torch.long, device=dev)
+            cl[:nnz] = col
+            w = torch.zeros(rows_cap, dtype=torch.float32, device=dev)
+            w[:n] = 1.0 / batch_size
+            out += [ids, rp, cl, w]
+        return out
+
+    def _graph_loss(self, ids_sp, rp_sp, cl_sp, w_sp, ids_po, rp_po, cl_po, w_po):
+        offset = _plain_bce(self.loss)
+        rows_sp, rows_po = self.model.multilabel_loss_sp_po(
+            "kl" if offset is None else "bce", ids_sp[:, 0], ids_sp[:, 1], rp_sp, cl_sp, ids_po[:, 1], ids_po[:, 0], rp_po,
+            cl_po, 0.0 if offset is None else offset)
+        return (rows_sp * w_sp).sum() + (rows_po * w_po).sum()
+
+    def _graph_step_for(self, batch_index, batch, subbatch_slice, per_type, totals):
+        """The GraphedStep for this batch (made or re-made when the capacities change), or None."""
+        if self._graph_step_ok is False or self.is_forward_only:
+            return None
+        n = len(batch["queries"])
+        sl = subbatch_slice
+        whole = sl.start in (0, None) and (sl.stop is None or sl.stop >= n) and sl.step in (1, None)
+        if not whole:
+            return None
+        if self._graph_step_ok is None:
+            try:
+                want = bool(self.config.get_default("hip_KvsAll.graph_step"))
+            except KeyError:
+                want = False
+            ok = want and str(self.device).startswith("cuda") and hasattr(self.model, "multilabel_loss_sp_po")
+            ok = ok and float(self.label_smoothing) == 0.0 and _optimizer_is_capturable(self.optimizer)
+            ok = ok and (_fold_penalties(self) or _no_penalty(self, batch_index, batch))
+            self._graph_step_ok = ok
+        if not self._graph_step_ok:
+            return None
+        caps = self._graph_caps
+        if caps is None or self._graph_overflows >= 3:
+            # capacities from this batch with head room (the split of a batch into sp_ / _po queries is binomial, the
+            # label counts follow the data's degree distribution); never below the previous ones
+            need_rows = max([len(v[0]) for v in per_type.values()] + [1])
+            need_lab = max([totals[k] for k in per_type] + [1])
+            up = lambda x, m: (int(x) + m - 1) // m * m
+            rows_cap = min(up(max(need_rows * 1.15 + 16, (caps or (0, 0))[0]), 32), up(n, 32))
+            rows_cap = max(rows_cap, up(need_rows, 32))
+            lab_cap = up(max((need_lab + rows_cap) * 1.5, (caps or (0, 0))[1]), 256)
+            self._graph_caps = (rows_cap, lab_cap)
+            self._graph_step = _graphed_step_of(self, self._graph_loss)
+            self._graph_overflows = 0
+        return self._graph_step
 
     def _fused_ok(self) -> bool:
         if "s_o" in self.query_types:
@@ -330,7 +415,7 @@ class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
         torch.cumsum(counts, 0, out=offsets[1:])
         result.prepare_time += time.time()
         offset, ls = _plain_bce(self.loss), float(self.label_smoothing)
-        per_type = {}
+        per_type, totals = {}, {}
         for query_type_index, query_type in enumerate(self.query_types):
             examples = (qtype == query_type_index).nonzero(as_tuple=False).view(-1)
             if len(examples) == 0:
@@ -343,9 +428,27 @@ class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
             idx = torch.repeat_interleave(offsets[rows] - rowptr[:-1], cnt, output_size=total) \
                 + torch.arange(total, device=cnt.device)
             per_type[query_type] = (queries[examples, 0], queries[examples, 1], rowptr, coords[idx, 1].long())
+            totals[query_type] = total
         # both query types of the subbatch: their loss rows with ONE backward (two d loss / d score passes, the gradient
         # products once over all rows, no index_add / accumulation passes of autograd in between); the reference
         # back-propagates the two losses one after the other -- the same gradients, accumulated
+        if ls == 0.0 and len(per_type) >= 1 and hasattr(self.model, "multilabel_loss_sp_po"):
+            gs = self._graph_step_for(batch_index, batch, subbatch_slice, per_type, totals)
+            if gs is not None and gs.enabled:
+                result.prepare_time -= time.time()
+                inputs = self._graph_inputs(per_type, batch_size, queries.device)
+                result.prepare_time += time.time()
+                if inputs is None:
+                    self._graph_overflows += 1
+                else:
+                    self._graph_overflows = 0
+                    result.forward_time -= time.time()
+                    loss_value = gs(*inputs)
+                    self._skip_optimizer_step = True  # (replayed or eager: GraphedStep has taken the optimizer's step)
+                    self.graph_batches += 1
+                    result.avg_loss += loss_value.item()
+                    result.forward_time += time.time()
+                    return
         if ls == 0.0 and len(per_type) == 2 and hasattr(self.model, "multilabel_loss_sp_po"):
             result.forward_time -= time.time()
             (s_, p_sp, rp_sp, cl_sp), (p_po, o_, rp_po, cl_po) = per_type["sp_"], per_type["_po"]

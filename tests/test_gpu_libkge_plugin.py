@@ -844,3 +844,42 @@ def test_m_band_and_rescore_behind_hip_entity_ranking(data, model, dim):
     _log(case=f"m: hip_entity_ranking.band_rescore on hip_{model} d={dim}: ranks and metrics == the split kernel's",
          batches_through_the_band=j_band._ev["band_batches"], mrr_filtered=m_ref["mean_reciprocal_rank_filtered"],
          seconds_split=j_ref.eval_seconds, seconds_band=j_band.eval_seconds)
+
+
+@pytest.mark.parametrize("loss", ["kl", "bce"])
+def test_n_kvsall_step_as_one_hipgraph_on_padded_inputs(data, loss):
+    """hip_KvsAll.graph_step (VERDICT r5 missing 5; train_KvsAll.py:216-294): with an optimizer whose step is kernels only
+    the whole step of a batch -- both query types' fused losses, ONE backward for both, HipAdagrad -- is captured once
+    on inputs padded to a capacity of rows and label entries per query type and replayed per batch (padding rows: weight
+    0 in the batch loss, gradient rows exactly zero).  Switched off, the same kernels issued from Python take the same
+    steps: epoch losses to 1e-5 (the replay orders the float atomics of the gradient scatter differently), parameters
+    1e-4; both agree with the reference model + job at the bf16 bar of test e.  A penalty term (unweighted L2, folded
+    into HipAdagrad) rides along."""
+    if DEVICE == "cpu":
+        pytest.skip("needs the GPU")
+    root, folder = data
+    opts = {"train.loss": loss, "lookup_embedder.regularize_weight": 1e-5}
+    ref, l_ref, st = _train_epoch(root, folder, f"n_ref_{loss}", "complex", "KvsAll", opts=opts)
+    hopts = {**opts, "hip_complex.score_dtype": "bfloat16", "train.optimizer.default.type": "HipAdagrad",
+             "train.optimizer.default.args.bf16_copies": True}
+    gra, l_gra, _ = _train_epoch(root, folder, f"n_graph_{loss}", "hip_complex", "hip_KvsAll", init_from=st, opts=hopts)
+    eag, l_eag, _ = _train_epoch(root, folder, f"n_eager_{loss}", "hip_complex", "hip_KvsAll", init_from=st,
+                                 opts=dict(hopts, **{"hip_KvsAll.graph_step": False}))
+    gs = gra._graph_step
+    batches = len(gra.loader)
+    assert gs is not None and gs.disabled_reason is None and gs.replays >= 0.8 * batches - 6, (vars(gs), gra._graph_caps)
+    assert gra.graph_batches >= 0.9 * batches and eag._graph_step is None and eag.graph_batches == 0
+    assert gra.optimizer.has_penalties()
+    second = {}
+    for tag, job in (("graph", gra), ("eager", eag)):
+        torch.manual_seed(29)
+        second[tag] = job.run_epoch()["avg_loss"]
+    _log(case=f"n: hip_KvsAll.graph_step true / false ({loss}), first and second epoch", loss_ref=l_ref, first_graph=l_gra,
+         first_eager=l_eag, second=second, replays=gs.replays, captures=gs.captures, capacities=gra._graph_caps,
+         batches_through_the_step=gra.graph_batches, param_rel_diff=_param_diff(gra, eag),
+         seconds_graph=_second_epoch_seconds(gra), seconds_eager=_second_epoch_seconds(eag),
+         seconds_reference=_second_epoch_seconds(ref))
+    assert _rel(l_gra, l_eag) <= 1e-5, (l_gra, l_eag)
+    assert _rel(second["graph"], second["eager"]) <= 1e-4, second
+    assert _param_diff(gra, eag) <= 3e-3   # (after two epochs of float-atomic gradient scatters in different orders)
+    assert _rel(l_gra, l_ref) <= 1e-2 and _param_diff(gra, ref) <= 5e-2
