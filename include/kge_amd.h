@@ -607,7 +607,11 @@ int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_in
  *   loss_sum[0] = scale * scale_dev[0] * sum_i loss_rows[i]      (scale_dev == NULL: factor 1; device float)
  * summed in a fixed order (bitwise reproducible).  kge_ce_sp_po_bwd_accum_sum: kge_ce_sp_po_bwd_accum with the
  * SAME gradient for every row, g = scale * g_dev[0] * scale_dev[0] (NULL: factor 1) -- the upstream gradient of
- * loss_sum and the scale as device scalars: nothing of the step is a host value, so a replay follows both. */
+ * loss_sum and the scale as device scalars: nothing of the step is a host value, so a replay follows both.
+ * The workspace's control block (its first 33,024 bytes: flags of the cooperative build, the arrival counter of the
+ * summing launch) must be ZERO before
+ * the first call with a given workspace; every call leaves them zero.  A control block that was never cleared gives a
+ * wrong loss_sum on every call. */
 int kge_ce_sp_po_fwd_sum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
                          float* loss_rows, float* lse, const float* scale_dev, float scale,
                          float* loss_sum, void* workspace, int64_t workspace_bytes, void* stream);

@@ -109,8 +109,11 @@ __global__ __launch_bounds__(1024) void ce_combine_kernel(const float* __restric
     for (int k = 1; k < nw; ++k) sb += sh_row[k];
     __hip_atomic_store(sum.blk + blockIdx.x, sb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence();  // the partial is visible device-wide before this workgroup counts as arrived
-    // atomicInc wraps: the counter is back at zero once the last workgroup has arrived (and a counter that was
-    // not zero -- a workspace that was never cleared -- is after one call)
+    // atomicInc wraps at gridDim.x - 1: a counter that was ZERO before the launch is zero again once the last workgroup
+    // has arrived.  A counter that was NOT zero (a workspace whose control block was never cleared) has period
+    // gridDim.x too, but some workgroup then sees "last" before the others have written their partials: the sum would
+    // be wrong on EVERY call, not only the first.  The control block must be zeroed by the caller before first use
+    // (include/kge_amd.h: kge_ce_sp_po_fwd_sum; engine._ce_workspace allocates it with torch.zeros) -- ADVICE r5.
     sh_last = atomicInc(sum.counter, gridDim.x - 1) == gridDim.x - 1 ? 1 : 0;
   }
   __syncthreads();
