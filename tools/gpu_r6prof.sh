@@ -85,3 +85,7 @@ print("training", d["training_tolerance"]["roofline"]["frac"])
 print("train", json.dumps(d.get("roofline_train"))[:600])
 print("cpu", d["cpu_baseline"]["kind"], d["cpu_baseline"]["value"])
 PY
+# the raw traces stay on the box (gpurun merges at most 64 MiB back): the summaries above are what travels
+find $OUT -name "*.db" -delete 2>/dev/null
+find $OUT -type f -size +2M -delete 2>/dev/null
+du -sh $OUT

@@ -11,17 +11,20 @@ ONLY=bf16_scoring STEPS=100 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT
 echo "rocprof exit: $?"
 cd $GRAFT_REPO_ROOT
 python - <<PY
-import csv, glob
-for f in glob.glob("$OUT/prof/**/*kernel_stats.csv", recursive=True):
-    rows = list(csv.DictReader(open(f)))
+import glob, sqlite3
+for db in glob.glob("$OUT/prof/**/*_results.db", recursive=True):
+    con = sqlite3.connect(db)
+    rows = list(con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
     # one adagrad_multi_kernel launch per step (eager and replayed alike): the step count of the trace
-    steps = sum(int(r["Calls"]) for r in rows if "adagrad_multi_kernel" in r.get("Name", ""))
-    total_us = sum(float(r.get("TotalDurationNs", 0)) for r in rows) / 1e3
+    steps = sum(int(r[1]) for r in rows if "adagrad_multi" in r[0])
+    total_us = sum(float(r[2]) for r in rows)
     with open("$OUT/kernel_stats.txt", "w") as o:
+        def P(line):
+            print(line); o.write(line + "\n")
+        P("# rocprofv3 --kernel-trace --stats -- ONLY=bf16_scoring STEPS=100 python tools/train_step_prof.py (durations in us):")
+        P("# the fused 1vsAll step at the FB15k-237 shape (n = 512, ComplEx d = 512, bf16 scoring copies, HipAdagrad), eager steps and graph replays mixed")
         if steps:
-            line = f"# {steps} steps in the trace, {total_us / steps:.1f} us of kernels per step, {len(rows)} kernel names"
-            print(line); o.write(line + "\n")
+            P(f"# {steps} steps in the trace, {total_us / steps:.1f} us of kernels per step, {len(rows)} kernel names")
         for r in rows[:25]:
-            line = f"{r.get('Name', '')[:110]:110s} calls {r.get('Calls'):>6s} avg_ns {float(r.get('AverageNs', 0)):10.0f} pct {r.get('Percentage')}"
-            print(line); o.write(line + "\n")
+            P(f"{r[0][:110]:110s} calls {r[1]:>6} avg_us {float(r[3]):8.2f} pct {float(r[4]):6.2f}")
 PY
