@@ -125,6 +125,13 @@ typedef enum kge_flags {
 /* Bits 8..15 of `flags`: number of compute units the persistent bf16 scoring kernel leaves
  * free (it launches one workgroup per remaining CU), so that kernels on other streams -- the
  * RCCL kernels of an overlapped exchange -- run beside it.  0 = all.  */
+/* kge_ce_sp_po_fwd(_sum) / kge_ce_sp_po_bwd_accum(_sum) only -- the caller's promise that the backward call follows
+ * the forward call with the SAME tables, index vectors, n and workspace, and that no other call used that workspace in
+ * between (a captured training step; kge_amd.model checks it with a per-workspace generation count): the forward then
+ * also leaves the gradient products' query matrix in the workspace and the backward starts from the forward's query
+ * fragments instead of building them again (one launch less per step).  Without the promise kept the backward reads
+ * stale fragments: set it on BOTH calls or on neither. */
+#define KGE_FLAG_CE_KEEP_QUERIES (1 << 16)
 #define KGE_FLAG_RESERVE_CUS_SHIFT 8
 #define KGE_FLAG_RESERVE_CUS(n) (((n) & 255) << KGE_FLAG_RESERVE_CUS_SHIFT)
 

@@ -136,11 +136,13 @@ int run_bce_bwd(int scorer, const Operand& A, const Operand& R, const Operand& T
 long long ce2_workspace_bytes(int d, long long n, long long m);
 int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, float* loss_rows, float* lse, void* ws, long long ws_bytes,
-                hipStream_t st, float* loss_sum = nullptr, const float* scale_dev = nullptr, float scale = 1.0f);
+                hipStream_t st, float* loss_sum = nullptr, const float* scale_dev = nullptr, float scale = 1.0f,
+                bool keep = false);
 int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, const float* lse, const float* g_rows, float g_scalar, float* g_a,
                 float* g_p, float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, void* ws,
-                long long ws_bytes, hipStream_t st, const float* g_dev = nullptr, const float* g_dev2 = nullptr);
+                long long ws_bytes, hipStream_t st, const float* g_dev = nullptr, const float* g_dev2 = nullptr,
+                bool kept = false);
 int run_adagrad_multi(const kge_adagrad_seg* segs, int num, hipStream_t st);
 int run_adagrad_multi_pen(const kge_adagrad_seg* segs, const kge_penalty_seg* pens, int num, hipStream_t st);
 long long multilabel2_workspace_bytes(int d, long long n1, long long n2, long long m);
@@ -1671,7 +1673,8 @@ int kge_ce_sp_po_fwd(const kge_tables* t, kge_index s, kge_index p, kge_index o,
   if (n > 0 && (!loss_rows || !lse)) return KGE_ERR_INVALID_ARG;
   const kge_index all = {nullptr, 0, 0, 1};
   return run_ce2_fwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
-                     t->num_ent, loss_rows, lse, workspace, workspace_bytes, (hipStream_t)stream);
+                     t->num_ent, loss_rows, lse, workspace, workspace_bytes, (hipStream_t)stream, nullptr, nullptr, 1.0f,
+                     (t->flags & KGE_FLAG_CE_KEEP_QUERIES) != 0);
 }
 
 int kge_ce_sp_po_bwd(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, const float* lse,
@@ -1697,7 +1700,8 @@ int kge_ce_sp_po_bwd_accum(const kge_tables* t, kge_index s, kge_index p, kge_in
   const kge_index all = {nullptr, 0, 0, 1};
   return run_ce2_bwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
                      t->num_ent, lse, g_rows, g_scalar, nullptr, nullptr, grad_ent, grad_rel, t->num_rel,
-                     t->rel_dim, workspace, workspace_bytes, (hipStream_t)stream);
+                     t->rel_dim, workspace, workspace_bytes, (hipStream_t)stream, nullptr, nullptr,
+                     (t->flags & KGE_FLAG_CE_KEEP_QUERIES) != 0);
 }
 
 int kge_ce_sp_po_fwd_sum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n, float* loss_rows,
@@ -1710,7 +1714,7 @@ int kge_ce_sp_po_fwd_sum(const kge_tables* t, kge_index s, kge_index p, kge_inde
   const kge_index all = {nullptr, 0, 0, 1};
   return run_ce2_fwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
                      t->num_ent, loss_rows, lse, workspace, workspace_bytes, (hipStream_t)stream, loss_sum, scale_dev,
-                     scale);
+                     scale, (t->flags & KGE_FLAG_CE_KEEP_QUERIES) != 0);
 }
 
 int kge_ce_sp_po_bwd_accum_sum(const kge_tables* t, kge_index s, kge_index p, kge_index o, int64_t n,
@@ -1724,7 +1728,8 @@ int kge_ce_sp_po_bwd_accum_sum(const kge_tables* t, kge_index s, kge_index p, kg
   const kge_index all = {nullptr, 0, 0, 1};
   return run_ce2_bwd(t->scorer, ent_op(t, s), ent_op(t, o), rel_op(t, p), ent_op(t, all), (int)t->dim, n,
                      t->num_ent, lse, nullptr, scale, nullptr, nullptr, grad_ent, grad_rel, t->num_rel, t->rel_dim,
-                     workspace, workspace_bytes, (hipStream_t)stream, g_dev, scale_dev);
+                     workspace, workspace_bytes, (hipStream_t)stream, g_dev, scale_dev,
+                     (t->flags & KGE_FLAG_CE_KEEP_QUERIES) != 0);
 }
 
 int kge_kl_weighted_fwd(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,

@@ -98,8 +98,15 @@ __global__ __launch_bounds__(256) void bwdg_gather_kernel(Operand TG, int d, lon
   out[j * d + c] = ((const float*)TG.base + index_at(TG.idx, j) * TG.ld)[c];
 }
 
+// `zero` (may be NULL): zero_cnt floats cleared on the way -- the relation-gradient accumulator the chain launch behind
+// the products adds into, when no query-build launch of the backward is there to do it (KGE_FLAG_CE_KEEP_QUERIES)
 __global__ __launch_bounds__(256) void bwdg_reduce_kernel(const float* __restrict__ part, long long cnt, int P,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, float* __restrict__ zero,
+                                                          long long zero_cnt) {
+  if (zero != nullptr) {
+    const long long nthreads = (long long)gridDim.x * 256;
+    for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < zero_cnt; k += nthreads) zero[k] = 0.0f;
+  }
   const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= cnt) return;
   f32x4 acc = *reinterpret_cast<const f32x4*>(part + i);
@@ -285,12 +292,14 @@ long long pairs_bwd_workspace_bytes(int dtype, int scorer, int d, long long n, l
 // split-K partials of dQ (g_tgt before dT overwrites it) or NULL.
 static bool bwdg_dq16(int d, long long rows, long long m, const unsigned short* T, long long ldt,
                       const unsigned short* G16, long long mp, float* g_a, float* lws, size_t lws_bytes,
-                      hipStream_t st) {
+                      hipStream_t st, float* zero = nullptr, long long zero_cnt = 0) {
   const int sp = run_gemm16_dq(d, rows, m, T, ldt, G16, mp, g_a, lws, lws_bytes, st);
   if (sp > 1) {
     const long long cnt = rows * d;  // d % 256 == 0: cnt % 4 == 0
     hipLaunchKernelGGL(bwdg_reduce_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, st, lws, cnt, sp,
-                       g_a);
+                       g_a, zero, zero_cnt);
+  } else if (zero != nullptr && zero_cnt > 0) {  // (no split-K sum to ride in: a fill of its own)
+    if (!fill_words_async(zero, 0, (size_t)zero_cnt * sizeof(float), st)) return false;
   }
   if (sp >= 1) return true;
   return run_gemm32(true, 1, rows, d, m, G16, mp, T, ldt, g_a, d, lws, lws_bytes, st);
@@ -357,7 +366,10 @@ static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Opera
                                const Operand& TG, int d, long long n, long long n2, long long m,
                                const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
                                float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
-                               float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready) {
+                               float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready,
+                               bool clear_acc_rel = false) {
+  // clear_acc_rel (with q16_ready): Q16 was left by the FORWARD's build launch (KGE_FLAG_CE_KEEP_QUERIES) and nothing
+  // has cleared acc_rel yet -- the split-K sum's launch does it on its way
   if (TG.idx.ptr != nullptr) return KGE_ERR_UNSUPPORTED;  // all entities only
   const int half = SCORER == KGE_COMPLEX ? d / 2 : d;
   const long long nrows = n + n2, nmax = n > n2 ? n : n2;
@@ -373,7 +385,10 @@ static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Opera
   // in bwdg_reduce_kernel was tried in round 5: 13.3 us scalar / 17+ us with 16-byte loads against 6.1 + 5.8 us.]
   float* lws = dq_scratch != nullptr ? dq_scratch : g_tgt;
   const size_t lws_bytes = dq_scratch != nullptr ? (size_t)dq_scratch_bytes : (size_t)m * d * sizeof(float);
-  if (!bwdg_dq16(d, nrows, m, T, TG.ld, G16, mp, g_a, lws, lws_bytes, st)) return KGE_ERR_UNSUPPORTED;
+  const bool clr = clear_acc_rel && acc_rel != nullptr;
+  if (!bwdg_dq16(d, nrows, m, T, TG.ld, G16, mp, g_a, lws, lws_bytes, st, clr ? acc_rel : nullptr,
+                 clr ? acc_rel_rows * acc_rel_ld : 0LL))
+    return KGE_ERR_UNSUPPORTED;
   if (!bwdg_dt16(d, nrows, m, Q16, G16, mp, g_tgt, st)) return KGE_ERR_UNSUPPORTED;
   // acc_rel != NULL: the row gradients go straight into the table gradients -- the entity rows
   // on top of dT in g_tgt [m, d] (all entities: row ids are table rows), the relation rows into acc_rel
@@ -386,17 +401,18 @@ int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A
                                  const Operand& R2, const Operand& TG, int d, long long n, long long n2, long long m,
                                  const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
                                  float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
-                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready) {
+                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready,
+                                 bool clear_acc_rel) {
   if (n + n2 == 0 || m == 0) return KGE_OK;  // (ce_loss.hip handles empty batches itself: acc_rel is cleared there)
   if (n + n2 >= (1LL << 31) || m >= (1LL << 31) || mp >= (1LL << 31) || TG.ld >= (1LL << 31))
     return KGE_ERR_UNSUPPORTED;
   int rc = KGE_ERR_UNSUPPORTED;
   if (scorer == KGE_COMPLEX)
     rc = bwdg_products16_two<KGE_COMPLEX>(A1, A2, R, R2, TG, d, n, n2, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
-                                          acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st, q16_ready);
+                                          acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st, q16_ready, clear_acc_rel);
   else if (scorer == KGE_DISTMULT)
     rc = bwdg_products16_two<KGE_DISTMULT>(A1, A2, R, R2, TG, d, n, n2, m, G16, mp, Q16, g_a, g_p, g_tgt, acc_rel,
-                                           acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st, q16_ready);
+                                           acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st, q16_ready, clear_acc_rel);
   return rc;
 }
 

@@ -22,7 +22,8 @@ namespace kge {
 constexpr int G32_BN = 128, G32_KC = 32;
 typedef float f32x2g __attribute__((ext_vector_type(2)));
 
-__global__ void bwdg_reduce_kernel(const float* __restrict__ part, long long cnt, int P, float* __restrict__ out);
+__global__ void bwdg_reduce_kernel(const float* __restrict__ part, long long cnt, int P, float* __restrict__ out,
+                                   float* __restrict__ zero, long long zero_cnt);
 
 // 4 consecutive elements from p (valid: how many of them exist), widened to f32
 template <typename T>
@@ -223,7 +224,7 @@ bool run_gemm32(bool a_kcont, int in16, long long M, long long N, long long K, c
   if (P > 1) {
     const long long cnt = M * N;
     hipLaunchKernelGGL(bwdg_reduce_kernel, dim3((unsigned)((cnt / 4 + 255) / 256)), dim3(256), 0, st, scratch, cnt,
-                       (int)P, C);
+                       (int)P, C, (float*)nullptr, 0LL);
   }
   return hipGetLastError() == hipSuccess;
 }

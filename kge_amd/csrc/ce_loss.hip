@@ -42,7 +42,8 @@ int run_pairs_bwd_products16_two(int scorer, const Operand& A1, const Operand& A
                                  const Operand& R2, const Operand& TG, int d, long long n, long long n2, long long m,
                                  const unsigned short* G16, long long mp, unsigned short* Q16, float* g_a, float* g_p,
                                  float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld,
-                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready = false);
+                                 float* dq_scratch, long long dq_scratch_bytes, hipStream_t st, bool q16_ready = false,
+                                 bool clear_acc_rel = false);
 long long gemm16_dq_scratch_bytes(int d, long long rows, long long m);
 // ce_pairs_v8.hip: the loss passes on the persistent two-consumer-wave structure, from prepared query fragments
 bool pairs_bf16_v8_ce_takes(int d, long long n, long long m);
@@ -440,9 +441,10 @@ static int run_ds_pass(int scorer, int epi, const Operand& A, const Operand* A2,
 // ce_column_groups(...) column groups per row
 static int run_lse_pass(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
                         int d, long long n, long long m, hipStream_t st, void* ws, long long coop, const CeArgs& ce,
-                        unsigned long long* dbg) {
+                        unsigned long long* dbg, unsigned short* keep_q16 = nullptr) {
+  // keep_q16 (KGE_FLAG_CE_KEEP_QUERIES): the build launch also writes the gradient products' query matrix there
   if (ce_takes_v8(V3_LSE, d, n, m, TG) && pairs_bf16_v8_ce_column_groups(d, n, m, A2 != nullptr) > 0) {
-    const int rc = run_v8_ce_pass(scorer, V3_LSE, A, A2, R, TG, dir, d, n, m, st, ws, coop, ce);
+    const int rc = run_v8_ce_pass(scorer, V3_LSE, A, A2, R, TG, dir, d, n, m, st, ws, coop, ce, keep_q16);
     if (rc != KGE_ERR_UNSUPPORTED) return rc;
     return KGE_ERR_LAUNCH;  // (the caller sized ce.part for this kernel's column groups: no other kernel may fill it)
   }
@@ -638,9 +640,16 @@ long long ce2_workspace_bytes(int d, long long n, long long m) {
   return coop + (fwd > bwd ? fwd : bwd);
 }
 
+// Does the backward of this shape start from fragments the forward left (both calls under KGE_FLAG_CE_KEEP_QUERIES)?
+// Only where BOTH passes run on the persistent kernel: its fragment area is written by the build launch alone.
+static bool ce2_keeps(int d, long long n, long long m, const Operand& TG) {
+  return ce_takes_v8(V3_LSE, d, n, m, TG) && ce_takes_v8(V3_DS, d, n, m, TG) &&
+         pairs_bf16_v8_ce_column_groups(d, n, m, true) > 0;
+}
+
 int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, float* loss_rows, float* lse, void* ws, long long ws_bytes,
-                hipStream_t st, float* loss_sum, const float* scale_dev, float scale) {
+                hipStream_t st, float* loss_sum, const float* scale_dev, float scale, bool keep) {
   // loss_sum != NULL (kge_ce_sp_po_fwd_sum): loss_sum[0] = scale * scale_dev[0] * sum of the 2n loss rows, from
   // the combine launch itself
   if (n == 0) {
@@ -658,7 +667,11 @@ int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   ce.side2_off = n;
   ce.part = (float*)((char*)ws + coop);
   ce.true_score = (float*)((char*)ws + coop + al256(2 * n * ncg * 8));
-  const int rc = run_lse_pass(scorer, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps);
+  // keep: the backward's Q16 (its place in the BACKWARD's layout of the same workspace: behind G16, beyond everything the
+  // forward uses) is written by this call's build launch
+  unsigned short* const keep_q16 =
+      keep && ce2_keeps(d, n, m, TG) ? (unsigned short*)((char*)ws + coop + al256(2 * n * ce_ld16(m) * 2)) : nullptr;
+  const int rc = run_lse_pass(scorer, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps, keep_q16);
   if (rc != KGE_OK) return rc;
   CeSum sum{};
   if (loss_sum != nullptr) {
@@ -677,7 +690,7 @@ int run_ce2_fwd(int scorer, const Operand& S, const Operand& O, const Operand& R
 int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R, const Operand& TG, int d,
                 long long n, long long m, const float* lse, const float* g_rows, float g_scalar, float* g_a,
                 float* g_p, float* g_tgt, float* acc_rel, long long acc_rel_rows, long long acc_rel_ld, void* ws,
-                long long ws_bytes, hipStream_t st, const float* g_dev, const float* g_dev2) {
+                long long ws_bytes, hipStream_t st, const float* g_dev, const float* g_dev2, bool kept) {
   // acc_rel != NULL (kge_ce_sp_po_bwd_accum): g_a / g_p are not returned; the row gradients are added
   // into g_tgt (on top of dT) and into acc_rel [acc_rel_rows, acc_rel_ld], which the query-build launch of the
   // products clears on its way (a launch of its own until round 5)
@@ -709,6 +722,14 @@ int run_ce2_bwd(int scorer, const Operand& S, const Operand& O, const Operand& R
   ce.ld16 = ld16;
   unsigned short* Q16 = (unsigned short*)((char*)ws + coop + al256(2 * n * ld16 * 2));
   bool q16_done = false;
+  if (kept && acc_rel != nullptr && ce2_keeps(d, n, m, TG)) {
+    // KGE_FLAG_CE_KEEP_QUERIES: the fragments and Q16 are the forward's -- straight to the gradient pass; acc_rel is
+    // cleared by the split-K sum's launch
+    const int rc = run_pairs_bf16_v8_ce(V3_DS, TG, d, n, m, true, (char*)ws + PAIRS_WS_CTRL_BYTES, ce, st);
+    if (rc != KGE_OK) return rc == KGE_ERR_UNSUPPORTED ? KGE_ERR_LAUNCH : rc;
+    return run_pairs_bwd_products16_two(scorer, S, O, R, R, TG, d, n, n, m, ce.g16, ld16, Q16, g_a, g_p, g_tgt, acc_rel,
+                                        acc_rel_rows, acc_rel_ld, dq_scratch, dq_scratch_bytes, st, true, true);
+  }
   const int rc = run_ds_pass(scorer, V3_DS, S, &O, R, TG, KGE_SP_, d, n, m, st, ws, coop, ce, g_ce_stamps, Q16, acc_rel,
                              acc_rel != nullptr ? acc_rel_rows * acc_rel_ld : 0LL, &q16_done);
   if (rc != KGE_OK) return rc;

@@ -1402,11 +1402,25 @@ def ce_emb_bwd(t: Tables, direction: str, a_rows, p_rows, label, lse, g_rows=Non
     return g_a, g_p, g_t
 
 
+FLAG_CE_KEEP_QUERIES = 1 << 16  # include/kge_amd.h: the backward starts from the forward's query fragments
+_CE2_GENERATION = {}  # (device index, stream) -> how often the two-sided loss workspace was handed to a call
+
+
+def ce2_generation(device, stream=None) -> int:
+    """How often the workspace of the kge_ce_sp_po_* entries (of this device and stream) has been handed to a call.  A
+    forward that was the LAST call on it may be followed by a backward under FLAG_CE_KEEP_QUERIES (kge_amd.model's
+    _FusedCE2Sum compares the count it saw after its forward with the count at its backward)."""
+    with _on_device(device):
+        st = _stream_handle(device) if stream is None else stream
+    return _CE2_GENERATION.get((device.index, st), 0)
+
+
 def _ce2_workspace(tc, n, device, st):
     need = _lib.lib().kge_ce_sp_po_workspace_bytes(ctypes.byref(tc), n)
     if need <= 0:
         raise RuntimeError("kge_ce_sp_po_*: bf16 ComplEx/DistMult tables with dim in {128, 256, 512} only")
     key = (device.index, st, "ce2")
+    _CE2_GENERATION[(device.index, st)] = _CE2_GENERATION.get((device.index, st), 0) + 1
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < need:
         buf = _WORKSPACES[key] = torch.zeros((need,), device=device, dtype=torch.uint8)
@@ -1477,10 +1491,12 @@ def _dev_scalar(x, device, what):
     return x
 
 
-def ce_sp_po_fwd_sum(t: Tables, s, p, o, scale=None):
+def ce_sp_po_fwd_sum(t: Tables, s, p, o, scale=None, keep_queries: bool = False):
     """ce_sp_po_fwd and, from the same launches, the batch loss as a device scalar:
     (loss_sum 0-d = scale * sum(loss_rows), loss_rows [2n], lse [2n]).  `scale`: None, a Python float, or a float32
-    device scalar (read by the kernel at run time: a captured step follows it)."""
+    device scalar (read by the kernel at run time: a captured step follows it).  keep_queries: also leave the gradient
+    products' query matrix in the workspace (FLAG_CE_KEEP_QUERIES) for a backward called with keep_queries=True -- which
+    the caller may only do if no other call used the workspace in between (ce2_generation)."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
     n = _same_len(keep[:3], "ce_sp_po_fwd_sum")
@@ -1488,7 +1504,7 @@ def ce_sp_po_fwd_sum(t: Tables, s, p, o, scale=None):
     sh = 1.0 if scale is None or sd is not None else float(scale)
     loss_rows, lse, total = _empty((2 * n,), t.device), _empty((2 * n,), t.device), _empty((), t.device)
     with _on_device(t.device):
-        tc = t.c()
+        tc = t.c(int(t.flags) | FLAG_CE_KEEP_QUERIES) if keep_queries else t.c()
         st = _stream_handle(t.device)
         ws, wsb = _ce2_workspace(tc, max(n, 1), t.device, st)
         _lib.check(_lib.lib().kge_ce_sp_po_fwd_sum(
@@ -1497,9 +1513,11 @@ def ce_sp_po_fwd_sum(t: Tables, s, p, o, scale=None):
     return total, loss_rows, lse
 
 
-def ce_sp_po_bwd_accum_sum(t: Tables, s, p, o, lse, g=None, scale=None):
+def ce_sp_po_bwd_accum_sum(t: Tables, s, p, o, lse, g=None, scale=None, keep_queries: bool = False):
     """Backward of ce_sp_po_fwd_sum: the complete (grad_entities, grad_relations) for the upstream gradient `g` of
-    loss_sum (a float32 device scalar, or None = 1) and the forward's `scale`; neither is read by the host."""
+    loss_sum (a float32 device scalar, or None = 1) and the forward's `scale`; neither is read by the host.
+    keep_queries: the forward was called with keep_queries=True, on the same tables / indexes, and was the last call on
+    the workspace: its query fragments are used instead of building them again."""
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
     n = _same_len(keep[:3], "ce_sp_po_bwd_accum_sum")
@@ -1509,7 +1527,7 @@ def ce_sp_po_bwd_accum_sum(t: Tables, s, p, o, lse, g=None, scale=None):
     sh = 1.0 if scale is None or sd is not None else float(scale)
     ge, grel = _empty(tuple(t.ent.shape), t.device), _empty(tuple(t.rel.shape), t.device)
     with _on_device(t.device):
-        tc = t.c()
+        tc = t.c(int(t.flags) | FLAG_CE_KEEP_QUERIES) if keep_queries else t.c()
         st = _stream_handle(t.device)
         ws, wsb = _ce2_workspace(tc, max(n, 1), t.device, st)
         _lib.check(_lib.lib().kge_ce_sp_po_bwd_accum_sum(

@@ -611,8 +611,14 @@ class _FusedCE2Sum(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ent, rel, s, p, o, tables16, scale):
-        total, _rows, lse = engine.ce_sp_po_fwd_sum(tables16, s, p, o, scale)
+        # keep_queries: the forward's build launch also leaves the gradient products' query matrix in the workspace, and
+        # the backward -- if it is the NEXT call on that workspace (the generation count says so: a training step's
+        # loss.backward() right behind the loss; always true inside a captured step) -- starts from the forward's query
+        # fragments instead of building them again: one launch less per step
+        total, _rows, lse = engine.ce_sp_po_fwd_sum(tables16, s, p, o, scale, keep_queries=True)
         ctx.t16, ctx.idx, ctx.scale = tables16, (s, p, o), scale
+        ctx.generation = engine.ce2_generation(tables16.device)
+        ctx.versions = tuple(x._version for x in (s, p, o) if torch.is_tensor(x))
         ctx.save_for_backward(lse)
         return total
 
@@ -621,7 +627,9 @@ class _FusedCE2Sum(torch.autograd.Function):
         s, p, o = ctx.idx
         (lse,) = ctx.saved_tensors
         g = gout if gout.dtype == torch.float32 and gout.is_contiguous() else gout.float().contiguous()
-        ge, gr = engine.ce_sp_po_bwd_accum_sum(ctx.t16, s, p, o, lse, g=g, scale=ctx.scale)
+        kept = (engine.ce2_generation(ctx.t16.device) == ctx.generation
+                and ctx.versions == tuple(x._version for x in (s, p, o) if torch.is_tensor(x)))
+        ge, gr = engine.ce_sp_po_bwd_accum_sum(ctx.t16, s, p, o, lse, g=g, scale=ctx.scale, keep_queries=kept)
         return ge, gr, None, None, None, None, None
 
 

@@ -575,6 +575,47 @@ def test_model_level_summed_loss_and_its_captured_step():
         assert float((x - y).norm() / y.norm()) <= 2e-3  # (Adagrad's first steps amplify atomics-order noise)
 
 
+@pytest.mark.parametrize("d,n,E", [(512, 512, 14541), (256, 300, 3005), (512, 100, 2000)])
+def test_backward_from_the_forwards_query_fragments(eng, d, n, E):
+    """KGE_FLAG_CE_KEEP_QUERIES (round 6): the forward of the summed two-sided loss also leaves the gradient products' query
+    matrix in the workspace, and a backward that is the NEXT call on that workspace starts from the forward's query
+    fragments -- no build launch of its own, the relation accumulator cleared by the split-K sum's launch.  Same
+    gradients BIT FOR BIT as the plain pair of calls wherever both loss passes run on the persistent kernel (and the
+    flag is a no-op elsewhere: n = 100); a call in between (the generation count moves) makes kge_amd.model's
+    _FusedCE2Sum fall back by itself."""
+    from kge_amd import model as km
+    R = 11
+    g = torch.Generator().manual_seed(n)
+    ent = (torch.randn(E, d, generator=g) * 0.3).bfloat16().to(DEV)
+    rel = (torch.randn(R, d, generator=g) * 0.3).bfloat16().to(DEV)
+    T = eng.Tables("complex", ent, rel)
+    s, p, o = (torch.randint(hi, (n,), generator=g).to(DEV) for hi in (E, R, E))
+    one = torch.ones((), device=DEV)
+    tot0, rows0, lse0 = eng.ce_sp_po_fwd_sum(T, s, p, o, 0.5)
+    ge0, gr0 = eng.ce_sp_po_bwd_accum_sum(T, s, p, o, lse0, g=one, scale=0.5)
+    tot1, rows1, lse1 = eng.ce_sp_po_fwd_sum(T, s, p, o, 0.5, keep_queries=True)
+    ge1, gr1 = eng.ce_sp_po_bwd_accum_sum(T, s, p, o, lse1, g=one, scale=0.5, keep_queries=True)
+    assert torch.equal(tot0, tot1) and torch.equal(rows0, rows1) and torch.equal(lse0, lse1)
+    # (the entity gradient is dT + float-atomic scatters of the 2n gathered rows: equal up to their order)
+    assert float((ge1 - ge0).abs().max()) <= 1e-6 * float(ge0.abs().max()) and torch.equal(gr1 == gr1, gr0 == gr0)
+    assert float((gr1 - gr0).abs().max()) <= 1e-6 * float(gr0.abs().max())
+    # model level: an unrelated loss call between forward and backward moves the generation count
+    m = km.create("complex", E, R, d, device=DEV, score_dtype=torch.bfloat16)
+    m.zero_grad()
+    a = m.loss_sp_po_sum(s, p, o, one * (1.0 / n))
+    gen = eng.ce2_generation(torch.device(DEV))
+    a.backward()
+    assert eng.ce2_generation(torch.device(DEV)) == gen + 1
+    ga = [x.grad.clone() for x in m.parameters()]
+    m.zero_grad()
+    a = m.loss_sp_po_sum(s, p, o, one * (1.0 / n))
+    with torch.no_grad():
+        m.loss_sp_po_sum(o, p, s, one)       # another batch through the same workspace: its fragments are there now
+    a.backward()
+    for x, y in zip(ga, [x.grad for x in m.parameters()]):
+        assert float((x - y).norm() / x.norm()) <= 1e-5
+
+
 @pytest.mark.parametrize("model,d,E,R,n,scale", CASES[:2] + CASES[4:6])
 def test_fused_losses_against_the_oracles_loss_restatements(eng, model, d, E, R, n, scale):
     """The three fused training losses against oracle/torch_port.kl_loss / bce_loss (pinned bit for bit to the reference's
