@@ -1267,7 +1267,22 @@ def main():
                          "us_per_batch": ms * 1e3 / Ld, "algorithmic_bytes_per_launch": abd,
                          "frac": abd / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "scored_triples_per_s": Ld * n * Ed / (ms * 1e-3)}
-            del T256, qd, outd, e256, r256, trid
+            # the parity mode of the same groups (split queries: q_hi + q_lo, twice the matrix work per score; the
+            # SPLIT instantiation of the same kernel), beside one launch per batch on the single-batch split kernel
+            Ts = engine.Tables("complex", e256, r256, flags=engine.FLAG_SPLIT_QUERY)
+            qs_ = engine.build_queries_group(Ts, "sp_", trid, n, Ld, flags=engine.FLAG_SPLIT_QUERY)
+            for _ in range(3):
+                engine.score_queries_group(Ts, qs_, outd[:, :, :Ed])
+            ms_s = event_avg_ms(lambda: engine.score_queries_group(Ts, qs_, outd[:, :, :Ed]), max(5, a.steps // 4))
+            q1 = engine.build_queries(Ts, "sp_", trid[:n, 0], trid[:n, 1], None, flags=engine.FLAG_SPLIT_QUERY)
+            for _ in range(3):
+                engine.score_queries(Ts, q1, out=outd[0, :, :Ed])
+            ms_1 = event_avg_ms(lambda: engine.score_queries(Ts, q1, out=outd[0, :, :Ed]), max(5, a.steps // 4))
+            by_d[tag]["parity"] = {"avg_launch_us": ms_s * 1e3, "us_per_batch": ms_s * 1e3 / Ld,
+                                   "frac": abd / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "scored_triples_per_s": Ld * n * Ed / (ms_s * 1e-3),
+                                   "one_launch_per_batch_us": ms_1 * 1e3}
+            del T256, qd, outd, e256, r256, trid, Ts, qs_, q1
             torch.cuda.empty_cache()
         extra["score_sp_groups_d256"] = by_d
         # float32 tables (the dtype of an unmodified LibKGE config; the reference's own precision):

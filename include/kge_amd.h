@@ -102,10 +102,8 @@ typedef enum kge_flags {
                                  f32-chain kernel instead of the bf16 MFMA kernel            */
   KGE_FLAG_NO_MFMA = 2,       /* f32 ComplEx/DistMult: VALU fmaf chain instead of the f32
                                  MFMA (same bits; used to cross-check the MFMA mapping)      */
-  KGE_FLAG_BF16_V1 = 4,       /* bf16 ComplEx/DistMult: the tile-per-workgroup kernel -- the default of
-                                 every dim % 64 == 0 outside {128, 256, 512} -- also at those dims (cross-check
-                                 of the row-persistent kernels; tolerance-level: another summation order) */
-                              /* (8: retired with the 32-target-tile kernel v2, tools/attic)            */
+                              /* (4, 8: retired with the tile-per-workgroup kernels v1 and v2 -- bf16 tables of a
+                                 dim outside {128, 256, 512} run the f32 chain; the bits are ignored)       */
   KGE_FLAG_BF16_V3 = 16,      /* bf16 ComplEx/DistMult with a workspace: the single-role
                                  kernel (v3) instead of the loader/consumer kernel (v4)      */
   KGE_FLAG_SPLIT_QUERY = 32   /* bf16 ComplEx/DistMult scoring: the query vector q = s (x) r is NOT rounded

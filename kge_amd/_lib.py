@@ -22,7 +22,7 @@ SCORERS = {"complex": COMPLEX, "distmult": DISTMULT, "transe": TRANSE, "rotate":
 F32, BF16 = 0, 1
 I32, I64 = 0, 1
 SPO, SP_, PO_ = 0, 1, 2
-FLAG_EXACT, FLAG_NO_MFMA, FLAG_BF16_V1, FLAG_BF16_V3 = 1, 2, 4, 16
+FLAG_EXACT, FLAG_NO_MFMA, FLAG_BF16_V3 = 1, 2, 16
 FLAG_SPLIT_QUERY = 32
 SP_PO = 3
 

@@ -15,10 +15,6 @@ int run_pairs_exact(int scorer, int dtype, bool use_mfma, const Operand& A, cons
                     const Operand& TG, int dir, int d, int dr, long long n, long long m,
                     float lp, float* out, long long ldo, hipStream_t st, bool round_query = true,
                     const RankArgs* rk = nullptr);
-bool pairs_bf16_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
-                          const Operand& TG);
-int run_pairs_bf16(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
-                   int d, long long n, long long m, float* out, long long ldo, hipStream_t st);
 bool pairs_bf16_v3_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R,
                              const Operand& TG);
 int run_pairs_bf16_v3(int scorer, const Operand& A, const Operand& R, const Operand& TG, int dir,
@@ -63,10 +59,6 @@ int run_pairs_bf16_v8_rank(int scorer, bool split, const Operand& TG, int d, lon
                            const CeArgs& ce, hipStream_t st, unsigned long long* dbg, int reserve_cus, bool band = false,
                            long long* band_lists = nullptr);
 int v8_launch_count(int which);
-bool pairs_bf16_v5_supported(int scorer, int dtype, int d, const Operand& A, const Operand& R, const Operand& TG);
-int run_pairs_bf16_v5(int scorer, const Operand& A, const Operand* A2, const Operand& R, const Operand& TG, int dir,
-                      int d, long long n, long long m, float* out, long long ldo, long long out2_off, hipStream_t st,
-                      unsigned long long* dbg);
 int run_embed2(const EmbedJob& a, const EmbedJob& b, int rowbytes, int esize, hipStream_t st);
 int run_ns_bce(int kind, const float* scores, long long ld, long long n, long long c, float offset, float temp,
                float* loss_rows, float* grad, long long ldg, hipStream_t st);
@@ -245,16 +237,6 @@ int check_tables(const kge_tables* t, bool need_ptrs) {
   return KGE_OK;
 }
 
-// The workgroup-local-build kernel (score_pairs_bf16_v5.hip) IN FRONT of the cooperative one (v4) instead
-// of behind it (where it takes what v4 declines): KGE_V5=1, for tests and measurements.
-constexpr bool V5_DEFAULT = false;
-bool v5_on(const kge_tables* t) {
-  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY))
-    return false;
-  const long long e = sw(SW_V5);
-  return e >= 0 ? e == 1 : V5_DEFAULT;
-}
-
 int check_index(const kge_index& ix, bool allow_null, int64_t len = 1) {
   if (!ix.ptr) return (allow_null || len == 0) ? KGE_OK : KGE_ERR_INVALID_ARG;
   if (ix.itype != KGE_I32 && ix.itype != KGE_I64) return KGE_ERR_INVALID_ARG;
@@ -317,15 +299,15 @@ static int one_call_v8(const kge_tables* t, int dir, const Operand& A, const Ope
   if (sw(SW_ONE_CALL_V8) == 0) return KGE_ERR_UNSUPPORTED;
   const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0, two = A2 != nullptr;
   const int d = (int)t->dim;
-  // d = 512, or -- single-pass queries -- d = 256 (round 6: the persistent structure's score-store epilogue)
-  if (t->dtype != KGE_BF16 || (d != 512 && !(d == 256 && !split)) || TG.idx.ptr != nullptr || ws == nullptr ||
+  // d = 512, or d = 256 (round 6: the persistent structure's score-store epilogue, ce_pairs_v8.hip)
+  if (t->dtype != KGE_BF16 || (d != 512 && d != 256) || TG.idx.ptr != nullptr || ws == nullptr ||
       n < one_call_v8_min_rows())
     return KGE_ERR_UNSUPPORTED;
   // (d = 256: the group kernel is 2 x the single-batch kernels at the FB15k-237 shape -- 5.4-7.0 against 11-14.5 us per
   // one-sided batch -- and on a par with them on a Wikidata5M shard, 291-326 against 305-339 us, where a "group" is two
   // batches of 1.2 GB each: tools/d256_store_probe.py, profiles/r6_d256_store_policies.txt)
   if (d == 256 && m > 65536) return KGE_ERR_UNSUPPORTED;
-  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
+  if (t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
   if (t->scorer != KGE_COMPLEX && t->scorer != KGE_DISTMULT) return KGE_ERR_UNSUPPORTED;
   if (!pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG) ||
       (two && !pairs_bf16_v4_supported(t->scorer, t->dtype, d, *A2, R, TG)))
@@ -343,81 +325,75 @@ static int one_call_v8(const kge_tables* t, int dir, const Operand& A, const Ope
   return rc;  // (UNSUPPORTED behind the build launch: the fragments are simply not used)
 }
 
+// ---- the bf16 matrix-core STORE path of ComplEx / DistMult: four routes, tried in this order -----------------------
+//   1  many rows against all entities: ONE persistent launch over the call's 512-row batches (one_call_v8 above:
+//      pairs_bf16_v8_kernel at d = 512, pairs_bf16_v8_ce_kernel<V3_STORE> at d = 256); the n % 512 rows left re-enter
+//   2  prepared queries: a query-build launch + the direct-store kernel (pairs_bf16_v6 / v7_kernel) -- split queries
+//      (q = q_hi + q_lo) always, single-pass queries where one_call_prepared measured the two launches ahead
+//   3  the loader/consumer kernel with its in-launch cooperative query build (pairs_bf16_v4_kernel), one- or two-sided
+//   4  one-sided calls only: the single-role kernel (pairs_bf16_v3_kernel): d = 128, no workspace, more row groups or
+//      fewer CUs than route 3 takes, KGE_FLAG_BF16_V3
+// All four score a pair with the same products in the same K order: the same bits (tests/test_gpu_parity.py,
+// test_gpu_fuzz_shapes.py, test_gpu_queries.py).  A2 != NULL: both blocks of a two-sided call (the second `b2` floats
+// into a row).  KGE_ERR_UNSUPPORTED = no route applies and nothing was launched: a one-sided caller goes on to the
+// exact f32 chain, a two-sided caller side by side.  (Until round 6 two more generations sat in this ladder: the
+// workgroup-local-build kernel "v5" behind route 3 and the tile-per-workgroup kernel "v1" for dim % 64 == 0 behind
+// route 4; what they took now runs on route 4 and on the exact chain -- DESIGN 13.)
+static int bf16_store_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand* A2, const Operand& R,
+                               const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo, int64_t b2, void* ws,
+                               int64_t ws_bytes, hipStream_t st) {
+  if (t->dtype != KGE_BF16 || (t->flags & KGE_FLAG_EXACT)) return KGE_ERR_UNSUPPORTED;
+  const int d = (int)t->dim;
+  const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0, two = A2 != nullptr;
+  const int reserve = (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255;
+  {  // route 1
+    int64_t done = 0;
+    const int rc8 = one_call_v8(t, dir, A, A2, R, TG, n, m, out, ldo, b2, ws, ws_bytes, st, &done);
+    if (rc8 != KGE_ERR_UNSUPPORTED) {
+      if (rc8 != KGE_OK || done == n) return rc8;
+      const Operand Ar = operand_from(A, done, 2), Rr = operand_from(R, done, 2);
+      const Operand A2r = two ? operand_from(*A2, done, 2) : Operand{};
+      float* const outr = out + done * ldo;
+      const int rcr = bf16_store_dispatch(t, dir, Ar, two ? &A2r : nullptr, Rr, TG, n - done, m, outr, ldo, b2, ws, ws_bytes, st);
+      if (rcr != KGE_ERR_UNSUPPORTED || !two) return rcr;
+      // two-sided rows left that no route takes as one launch: side by side, HERE (the first rows are scored already)
+      const int rc = bf16_store_dispatch(t, KGE_SP_, Ar, nullptr, Rr, TG, n - done, m, outr, ldo, 0, ws, ws_bytes, st);
+      if (rc) return rc;
+      return bf16_store_dispatch(t, KGE_PO_, A2r, nullptr, Rr, TG, n - done, m, outr + b2, ldo, 0, ws, ws_bytes, st);
+    }
+  }
+  const bool v4_ok = ws != nullptr && !(t->flags & KGE_FLAG_BF16_V3) &&
+                     pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG) &&
+                     (!two || pairs_bf16_v4_supported(t->scorer, t->dtype, d, *A2, R, TG));
+  if (v4_ok && (split || one_call_prepared(t, TG, n, m, ws_bytes, two))) {  // route 2
+    const int rcp = run_pairs_bf16_v4_prepared(t->scorer, split, A, A2, R, TG, dir, d, n, m, out, ldo, two ? b2 : 0, st,
+                                               nullptr, nullptr, ws, ws_bytes, reserve, nullptr, nullptr, nullptr, 0, nullptr);
+    if (rcp != KGE_ERR_UNSUPPORTED) return rcp;
+  }
+  // split queries stop here: f32 arithmetic on the table values, never a rounded query (the exact chain of the
+  // one-sided caller keeps the query vector in f32)
+  if (split) return KGE_ERR_UNSUPPORTED;
+  if (v4_ok) {  // route 3
+    const int rc = run_pairs_bf16_v4(t->scorer, A, A2, R, TG, dir, d, n, m, out, ldo, two ? b2 : 0, st, nullptr, ws, ws_bytes,
+                                     reserve);
+    if (rc != KGE_ERR_UNSUPPORTED) return rc;
+  }
+  if (!two && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))  // route 4
+    return run_pairs_bf16_v3(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
+  return KGE_ERR_UNSUPPORTED;
+}
+
 int pairs_dispatch(const kge_tables* t, int dir, const Operand& A, const Operand& R,
                    const Operand& TG, int64_t n, int64_t m, float* out, int64_t ldo,
                    void* ws, int64_t ws_bytes, hipStream_t st) {
-  const int d = (int)t->dim, dr = (int)t->rel_dim;
-  {  // many rows: groups of 512-row batches through the persistent kernel, the rest as a call of its own size
-    int64_t done = 0;
-    const int rc8 = one_call_v8(t, dir, A, nullptr, R, TG, n, m, out, ldo, 0, ws, ws_bytes, st, &done);
-    if (rc8 != KGE_ERR_UNSUPPORTED) {
-      if (rc8 != KGE_OK || done == n) return rc8;
-      return pairs_dispatch(t, dir, operand_from(A, done, 2), operand_from(R, done, 2), TG, n - done, m, out + done * ldo,
-                            ldo, ws, ws_bytes, st);
-    }
-  }
-  if ((t->flags & KGE_FLAG_SPLIT_QUERY) && !(t->flags & KGE_FLAG_EXACT) && t->dtype == KGE_BF16) {
-    // q = q_hi + q_lo on the matrix cores (f32-level parity on the bf16 tables); what the loader/consumer kernel
-    // does not take runs the exact f32 chain with the query vector kept in f32 (KGE_FLAG_EXACT rounds it to bf16:
-    // the bits of the single-pass semantics) -- f32 arithmetic on the table values, never a rounded query
-    if (ws != nullptr && pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
-      const int rc = run_pairs_bf16_v4_prepared(t->scorer, true, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st,
-                                                nullptr, nullptr, ws, ws_bytes,
-                                                (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr,
-                                                nullptr, 0, nullptr);
-      if (rc != KGE_ERR_UNSUPPORTED) return rc;
-    }
-    return run_pairs_exact(t->scorer, t->dtype, !(t->flags & KGE_FLAG_NO_MFMA), A, R, TG, dir, d, dr, n, m,
-                           t->l_norm, out, ldo, st, /*round_query=*/false);
-  }
-  if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, d, A, R, TG)) {
-    const int rc = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr);
-    if (rc != KGE_ERR_UNSUPPORTED) return rc;
-  }
-  if (!(t->flags & KGE_FLAG_EXACT)) {
-    const bool v1 = t->flags & KGE_FLAG_BF16_V1;
-    if (!v1 && !(t->flags & KGE_FLAG_BF16_V3) && ws != nullptr &&
-        pairs_bf16_v4_supported(t->scorer, t->dtype, d, A, R, TG)) {
-      if (one_call_prepared(t, TG, n, m, ws_bytes, false)) {
-        const int rcp = run_pairs_bf16_v4_prepared(t->scorer, false, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st,
-                                                   nullptr, nullptr, ws, ws_bytes,
-                                                   (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr,
-                                                   nullptr, 0, nullptr);
-        if (rcp != KGE_ERR_UNSUPPORTED) return rcp;
-      }
-      const int rc = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr,
-                                       ws, ws_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
-      if (rc != KGE_ERR_UNSUPPORTED) return rc;  // else: launch conditions not met, single-role kernel
-    }
-    // v4 declined (no workspace, more than 32 row groups, fewer CUs than workgroups): the kernel with
-    // the workgroup-local query build, same bits
-    if (!v1 && !(t->flags & KGE_FLAG_BF16_V3) && pairs_bf16_v5_supported(t->scorer, t->dtype, d, A, R, TG)) {
-      const int rc = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, dir, d, n, m, out, ldo, 0, st, nullptr);
-      if (rc != KGE_ERR_UNSUPPORTED) return rc;
-    }
-    if (!v1 && pairs_bf16_v3_supported(t->scorer, t->dtype, d, A, R, TG))
-      return run_pairs_bf16_v3(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st, nullptr, ws, ws_bytes);
-    // every other dim % 64 == 0 (64, 192, 320, ...): the tile-per-workgroup kernel
-    if (pairs_bf16_supported(t->scorer, t->dtype, d, A, R, TG))
-      return run_pairs_bf16(t->scorer, A, R, TG, dir, d, n, m, out, ldo, st);
-  }
-  const bool mfma = !(t->flags & KGE_FLAG_NO_MFMA);
-  return run_pairs_exact(t->scorer, t->dtype, mfma, A, R, TG, dir, d, dr, n, m, t->l_norm, out,
-                         ldo, st);
-}
-
-// KGE_FLAG_SPLIT_QUERY, both score blocks: builder launch + ONE two-sided launch of the loader/consumer kernel on
-// the q_hi / q_lo fragments.  KGE_ERR_UNSUPPORTED: the caller goes side by side through pairs_dispatch (split again,
-// or the exact f32 chain).
-int split_sp_po(const kge_tables* t, const Operand& S, const Operand& O, const Operand& P, const Operand& TG, int64_t n,
-                int64_t m, float* out, int64_t ldo, void* ws, int64_t ws_bytes, hipStream_t st, int64_t b2 = -1) {
-  if (b2 < 0) b2 = m;  // the _po block right behind the sp_ block
-  if (t->dtype != KGE_BF16 || !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) ||
-      !pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG))
-    return KGE_ERR_UNSUPPORTED;
-  return run_pairs_bf16_v4_prepared(t->scorer, true, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, b2, st, nullptr,
-                                    nullptr, ws, ws_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr,
-                                    nullptr, nullptr, 0, nullptr);
+  const int rc = bf16_store_dispatch(t, dir, A, nullptr, R, TG, n, m, out, ldo, 0, ws, ws_bytes, st);
+  if (rc != KGE_ERR_UNSUPPORTED) return rc;
+  // the exact f32 chain: float32 tables, TransE / RotatE, every other dim, KGE_FLAG_EXACT (on bf16 tables the query
+  // vector rounded to bf16: the bits of the single-pass semantics) and split queries that no matrix-core route took
+  // (the query vector kept in f32)
+  const bool keep_f32_query = (t->flags & KGE_FLAG_SPLIT_QUERY) && !(t->flags & KGE_FLAG_EXACT) && t->dtype == KGE_BF16;
+  return run_pairs_exact(t->scorer, t->dtype, !(t->flags & KGE_FLAG_NO_MFMA), A, R, TG, dir, (int)t->dim, (int)t->rel_dim, n,
+                         m, t->l_norm, out, ldo, st, /*round_query=*/!keep_f32_query);
 }
 
 int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t n,
@@ -442,9 +418,9 @@ namespace kge {
 static long long g_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 static_assert(SW_COUNT == 20, "g_switch's initialiser");
 static const char* const g_switch_name[SW_COUNT] = {
-    "V5", "ONE_CALL_PREPARED", "ONE_CALL_V8", "ONE_CALL_V8_MIN_ROWS", "V8_RANK", "RANK_FUSED_FRONT", "BWD_GEMM_LIB",
+    "ONE_CALL_PREPARED", "ONE_CALL_V8", "ONE_CALL_V8_MIN_ROWS", "V8_RANK", "RANK_FUSED_FRONT", "BWD_GEMM_LIB",
     "CE_V3", "CE_V8", "V4_OWN_BUILD", "V4_INTERLEAVE", "V4_STORE_SC1", "V6", "V7", "V7_NOSTORE", "V7_PROBE", "V8",
-    "V8_VAR", "V8R_PROBE", "TRANSE_GENERIC"};
+    "V8_VAR", "V8R_PROBE", "BWD_FORK", "TRANSE_GENERIC"};
 long long sw(Switch s) { return __atomic_load_n(&g_switch[(int)s], __ATOMIC_RELAXED); }
 static int switch_index(const char* name) {
   if (name == nullptr) return -1;
@@ -511,7 +487,7 @@ int64_t kge_score_workspace_bytes(const kge_tables* t, int64_t n) {
 // ---- prepared queries (include/kge_amd.h) -----------------------------------------------------------------------
 static bool queries_supported(const kge_tables* t) {
   return t->dtype == KGE_BF16 && (t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT) &&
-         (t->dim == 256 || t->dim == 512) && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 |
+         (t->dim == 256 || t->dim == 512) && !(t->flags & (KGE_FLAG_EXACT |
                                                            KGE_FLAG_BF16_V3));
 }
 
@@ -639,8 +615,8 @@ int kge_score_queries_multi(const kge_tables* t, int combine, const void* querie
   if ((rc = check_index(targets, true))) return rc;
   if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
   const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
-  // groups: d = 512 (pairs_bf16_v8_kernel), d = 256 with single-pass queries (its parametric sibling's store epilogue)
-  if (!queries_supported(t) || (t->dim != 512 && !(t->dim == 256 && !split)) || targets.ptr) return KGE_ERR_UNSUPPORTED;
+  // groups: d = 512 (pairs_bf16_v8_kernel), d = 256 (its parametric sibling's store epilogue)
+  if (!queries_supported(t) || (t->dim != 512 && t->dim != 256) || targets.ptr) return KGE_ERR_UNSUPPORTED;
   const int64_t per = kge_queries_bytes(t, combine, n);
   if (work && num_batches > 1 && ((queries_stride & 15) || queries_stride < per)) return KGE_ERR_INVALID_ARG;
   Operand TG = ent_op(t, targets);
@@ -697,55 +673,15 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
                     int64_t workspace_bytes, void* stream) {
   KGE_RANGE();
   if (ldo < 2 * m) return KGE_ERR_INVALID_ARG;
-  // one two-sided launch of the loader/consumer kernel when it applies: the query build, the
-  // kernel start-up and the launch overhead are paid once for both score blocks
-  if (t && workspace && n > 0 && m > 0 && out && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 |
-                                                                KGE_FLAG_BF16_V3)) &&
-      check_tables(t, true) == KGE_OK && check_index(s, false) == KGE_OK &&
+  // both score blocks from ONE launch where a route of bf16_store_dispatch takes the call two-sided: the query build,
+  // the kernel start-up and the launch overhead are paid once
+  if (t && workspace && n > 0 && m > 0 && out && check_tables(t, true) == KGE_OK && check_index(s, false) == KGE_OK &&
       check_index(p, false) == KGE_OK && check_index(o, false) == KGE_OK &&
       check_index(targets, true) == KGE_OK && (targets.ptr || m == t->num_ent)) {
-    Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, targets);
-    const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
-    {  // many rows: both blocks of 512-row batches from ONE launch of the persistent kernel (one_call_v8)
-      int64_t done = 0;
-      const int rc8 = one_call_v8(t, KGE_SP_, S, &O, P, TG, n, m, out, ldo, m, workspace, workspace_bytes,
-                                  (hipStream_t)stream, &done);
-      if (rc8 != KGE_ERR_UNSUPPORTED) {
-        if (rc8 != KGE_OK || done == n) return rc8;
-        auto from = [&](kge_index ix) {
-          ix.ptr = (const char*)ix.ptr + done * ix.stride * (ix.itype == KGE_I32 ? 4 : 8);
-          return ix;
-        };
-        return kge_score_sp_po(t, from(s), from(p), from(o), n - done, targets, m, out + done * ldo, ldo, workspace,
-                               workspace_bytes, stream);
-      }
-    }
-    if (split) {  // q_hi + q_lo: one two-sided launch behind a builder launch
-      const int rcs = split_sp_po(t, S, O, P, TG, n, m, out, ldo, workspace, workspace_bytes, (hipStream_t)stream);
-      if (rcs != KGE_ERR_UNSUPPORTED) return rcs;
-    }
-    if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
-        pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
-      const int rc5 = run_pairs_bf16_v5(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
-                                        (hipStream_t)stream, nullptr);
-      if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
-    }
-    if (!split && pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
-        pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
-      if (one_call_prepared(t, TG, n, m, workspace_bytes, true)) {
-        // two launches -- the query build, then the scoring launch on prepared queries (pairs_bf16_v7_kernel) -- beat the
-        // one launch with the in-launch cooperative build (five dependent round trips before the first score)
-        const int rcp = run_pairs_bf16_v4_prepared(t->scorer, false, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
-                                                   (hipStream_t)stream, nullptr, nullptr, workspace, workspace_bytes,
-                                                   (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr,
-                                                   nullptr, 0, nullptr);
-        if (rcp != KGE_ERR_UNSUPPORTED) return rcp;
-      }
-      const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, m,
-                                        (hipStream_t)stream, nullptr, workspace, workspace_bytes,
-                                        (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
-      if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;
-    }
+    const Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, targets);
+    const int rc2 = bf16_store_dispatch(t, KGE_SP_, S, &O, P, TG, n, m, out, ldo, m, workspace, workspace_bytes,
+                                        (hipStream_t)stream);
+    if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;
   }
   int rc = pairs_entry(t, KGE_SP_, s, p, n, targets, m, out, ldo, workspace, workspace_bytes, stream);
   if (rc) return rc;
@@ -916,30 +852,8 @@ int kge_score_emb_sp_po_blocks(const kge_tables* t, const void* s_emb, int64_t s
   const Index ident{nullptr, 1, KGE_I64};
   Operand S{s_emb, s_ld, ident}, P{p_emb, p_ld, ident}, O{o_emb, o_ld, ident}, TG{tgt_emb, tgt_ld, ident};
   hipStream_t st = (hipStream_t)stream;
-  if (n > 0 && m > 0 && v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
-      pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
-    const int rc5 = run_pairs_bf16_v5(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, b2, st, nullptr);
-    if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
-  }
-  if (workspace && n > 0 && m > 0 && (t->flags & KGE_FLAG_SPLIT_QUERY) && !(t->flags & KGE_FLAG_EXACT)) {
-    const int rcs = split_sp_po(t, S, O, P, TG, n, m, out, ldo, workspace, workspace_bytes, st, b2);
-    if (rcs != KGE_ERR_UNSUPPORTED) return rcs;
-  }
-  if (workspace && n > 0 && m > 0 &&
-      !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3 | KGE_FLAG_SPLIT_QUERY)) &&
-      pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
-      pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, O, P, TG)) {
-    if (one_call_prepared(t, TG, n, m, workspace_bytes, true)) {
-      // as in kge_score_sp_po: the query build from the dense rows as a launch of its own, then the direct-store kernel
-      // on prepared queries (the per-rank scoring launch of the sharded step at d = 512: 44 -> ~25 us)
-      const int rcp = run_pairs_bf16_v4_prepared(t->scorer, false, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, b2, st,
-                                                 nullptr, nullptr, workspace, workspace_bytes,
-                                                 (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255, nullptr, nullptr, nullptr,
-                                                 0, nullptr);
-      if (rcp != KGE_ERR_UNSUPPORTED) return rcp;
-    }
-    const int rc2 = run_pairs_bf16_v4(t->scorer, S, &O, P, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, b2, st, nullptr,
-                                      workspace, workspace_bytes, (t->flags >> KGE_FLAG_RESERVE_CUS_SHIFT) & 255);
+  if (workspace && n > 0 && m > 0) {  // as kge_score_sp_po, on dense rows (the per-rank scoring launch of the sharded step)
+    const int rc2 = bf16_store_dispatch(t, KGE_SP_, S, &O, P, TG, n, m, out, ldo, b2, workspace, workspace_bytes, st);
     if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;
   }
   rc = pairs_dispatch(t, KGE_SP_, S, P, TG, n, m, out, ldo, workspace, workspace_bytes, st);
@@ -1064,7 +978,7 @@ static int score_rank_core(const kge_tables* t, const Operand& S, const Operand&
   const bool dot = t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT;
   const bool exact_path = t->dtype == KGE_F32 || !dot || (t->flags & KGE_FLAG_EXACT);
   const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0 && !exact_path;
-  if (t->flags & (KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) return KGE_ERR_UNSUPPORTED;
+  if (t->flags & KGE_FLAG_BF16_V3) return KGE_ERR_UNSUPPORTED;
   if ((t->flags & KGE_FLAG_SPLIT_QUERY) && exact_path) return KGE_ERR_UNSUPPORTED;
   // split queries are counted by pairs_bf16_v8_rank_kernel only (their two partial scores meet in one lane there)
   const bool v8_rank = !exact_path && sw(SW_V8_RANK) != 0 && (t->dim == 256 || t->dim == 512) && TG.idx.ptr == nullptr &&
@@ -1396,7 +1310,7 @@ int kge_eval_batch_band(const kge_tables* t, kge_index s, kge_index p, kge_index
   // both the true scores and the counting launch (pairs_bf16_v8_rank_kernel), which then start on prepared queries
   const bool dot = t->scorer == KGE_COMPLEX || t->scorer == KGE_DISTMULT;
   const bool split = (t->flags & KGE_FLAG_SPLIT_QUERY) != 0;
-  bool ready = t->dtype == KGE_BF16 && dot && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V1 | KGE_FLAG_BF16_V3)) &&
+  bool ready = t->dtype == KGE_BF16 && dot && !(t->flags & (KGE_FLAG_EXACT | KGE_FLAG_BF16_V3)) &&
                (t->dim == 256 || t->dim == 512) && sw(SW_V8_RANK) != 0 && workspace && !((uintptr_t)workspace & 15) &&
                workspace_bytes >= PAIRS_WS_CTRL_BYTES + pairs_bf16_v4_query_bytes((int)t->dim, n, true, split) &&
                pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, S, P, TG) &&
@@ -2114,11 +2028,6 @@ int kge_debug_score_sp_bf16_v2(const kge_tables* t, kge_index s, kge_index p, in
                                       nullptr, nullptr, 0, nullptr);
   }
   if (ablate) return KGE_ERR_UNSUPPORTED;
-  if (v5_on(t) && pairs_bf16_v5_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {
-    const int rc5 = run_pairs_bf16_v5(t->scorer, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo, 0,
-                                      (hipStream_t)stream, stamps);
-    if (rc5 != KGE_ERR_UNSUPPORTED) return rc5;
-  }
   if (!(t->flags & KGE_FLAG_BF16_V3) && workspace != nullptr &&
       pairs_bf16_v4_supported(t->scorer, t->dtype, (int)t->dim, A, R, TG)) {
     const int rc4 = run_pairs_bf16_v4(t->scorer, A, nullptr, R, TG, KGE_SP_, (int)t->dim, n, m, out, ldo,

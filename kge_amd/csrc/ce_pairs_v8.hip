@@ -63,10 +63,16 @@ struct V8CeArgs {
 // and wrote 32 rows x 32 bytes per instruction: 9.9 us per one-sided batch at the FB15k-237 shape, of which the L2's
 // merging of partial lines was the larger part) -- and a unit is ONE 32-column sub-unit: 16 stores per burst keep the
 // count of operations in flight across two bursts inside the 6-bit vmcnt.  AUX: the stores' cache policy.
-template <int HH, int EPI, int AUX = 0>
+// SPLIT (V3_STORE only; KGE_FLAG_SPLIT_QUERY: q = q_hi + q_lo, the parity mode of the score store): the q_hi and q_lo
+// rows of 16 real rows are a wave's 32 operand rows, operand row 16 a + 8 part + j = real row 8 a + j (the arrangement of
+// pairs_bf16_v8_kernel<SPLIT>): accumulator elements r and r + 4 (r & 4 == 0) of a lane are the two partial scores of
+// one (row, column) -- one add, eight stores per sub-unit; a chunk is 128 real rows, fragment groups hold 64.
+template <int HH, int EPI, int AUX = 0, int SPLIT = 0>
 __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
   static_assert(EPI == V3_LSE || EPI == V3_DS || EPI == V3_STORE, "forward row statistics, the gradient of the scores, or the scores");
   constexpr bool ST = EPI == V3_STORE;
+  static_assert(!SPLIT || ST, "split queries: the score store only");
+  constexpr int RW = SPLIT ? 16 : 32;     // real query rows per wave
   constexpr int NT = (HH == 128 && !ST) ? 2 : 1;   // 32-row sub-units of a unit, one accumulator each
   constexpr int UT = V8C_UT * NT;         // table rows per unit: 32 / 64
   constexpr int NKB = 2 * HH / 16;        // 32 / 16 K-blocks
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
   constexpr int NP = UNITB / 1024 / 8;    // pieces per unit and wave: 4
   constexpr int PF = 4;                   // K-blocks read ahead
   constexpr int PB = NKB == 32 ? 14 : 6;  // K-block of the barrier (first half of the workgroup)
-  constexpr int NSTORE = EPI == V3_DS ? 2 * NT : (ST ? 16 * NT : 0);  // vector stores of a burst (at least)
+  constexpr int NSTORE = EPI == V3_DS ? 2 * NT : (ST ? (SPLIT ? 8 : 16) * NT : 0);  // vector stores of a burst (at least)
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
   if (a.n < 0) smem[threadIdx.x] = 0;  // (never: keeps the allocation -- only asm names the array)
 
@@ -260,11 +266,23 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
   // drops both.  gvo = the lane's byte offset ((4 fh) rows down, fi columns in); the row of element r rides on top.
   auto sc_sub = [&](const f32x16& v, long long c0u, unsigned int colb) __attribute__((always_inline)) {
     const unsigned int vo = (c0u + V8C_UT <= m || c0u + fi < m) ? gvo : 0x80000000u;
+    if constexpr (SPLIT) {
+      // element r (r & 4 == 0): real row 8 (r >> 3) + 4 fh + (r & 3) of the wave's 16; score = (sum q_hi t) + (sum q_lo t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float x = v[r];  // (a copy first: __builtin_bit_cast straight on a vector element takes element 0 every time)
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), grs,
-                                            vo + (unsigned int)(8 * (r >> 2) + (r & 3)) * gld4, colb, AUX);
+      for (int q = 0; q < 8; ++q) {
+        const int r = (q & 3) + 8 * (q >> 2);
+        const float hi = v[r], lo = v[r + 4];
+        const float x = hi + lo;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), grs,
+                                              vo + (unsigned int)(8 * (r >> 3) + (r & 3)) * gld4, colb, AUX);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float x = v[r];  // (a copy first: __builtin_bit_cast straight on a vector element takes element 0 every time)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), grs,
+                                              vo + (unsigned int)(8 * (r >> 2) + (r & 3)) * gld4, colb, AUX);
+      }
     }
   };
   // the row's results out (V3_LSE): the two lanes of a row -> one (max, sum exp) per row and column group
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
       const int lb = pair / per_b, prem = pair - lb * per_b;  // (a group of batches: V3_STORE only)
       const int side = prem / a.chunks, ch = prem - side * a.chunks;
       // ---- this lane's row of the pair
-      const long long rb = (long long)ch * 256 + 32 * wave;  // the wave's first row (of the side)
+      const long long rb = (long long)ch * (8 * RW) + RW * wave;  // the wave's first row (of the side)
       const long long lrow = rb + fi;
       const long long orow = lrow < a.n ? lrow : a.n - 1;  // padded rows repeat row n - 1 (and never write)
       const long long roff = side ? ce.side2_off : 0;
@@ -369,7 +387,7 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
       }
       if constexpr (EPI == V3_STORE) {
         // the wave's rows of the score block: rows beyond n fall outside the descriptor and are dropped by the hardware
-        const long long rows_here = rb < a.n ? (a.n - rb < 32 ? a.n - rb : 32) : 0;
+        const long long rows_here = rb < a.n ? (a.n - rb < RW ? a.n - rb : RW) : 0;
         float* const ob = a.out + (long long)lb * a.out_stride + (side ? a.out2_off : 0) + (rows_here > 0 ? rb : 0) * a.ldo;
         grs = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, (int)(rows_here * a.ldo * 4), 0x00020000);
         gvo = (unsigned int)(((long long)(4 * fh) * a.ldo + fi) * 4);
@@ -390,12 +408,26 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_ce_kernel(V8CeArgs a) {
       int grp = 2 * ch + (wave >> 2);
       if (grp >= a.rgn1) grp = a.rgn1 - 1;
       grp += side * a.rgn1;
-      const unsigned char* const fb =
-          (const unsigned char*)(a.qf + (long long)lb * a.q_stride + (long long)grp * 4 * NKB * 64) + (wave & 3) * (NKB * 1024);
-      const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, NKB * 1024, 0x00020000);
+      const unsigned char* const gbase = (const unsigned char*)(a.qf + (long long)lb * a.q_stride + (long long)grp * 4 * NKB * 64);
+      unsigned int flo;
+      const unsigned char* fb;
+      int frange;
+      if constexpr (SPLIT) {
+        // operand row fi = 16 a + 8 part + jj of wave w: real row 16 (w & 3) + 8 a + jj of the group's 64, whose q_hi
+        // sits in block (row >> 5), its q_lo in block 2 + (row >> 5) (bf16_queries.hpp)
+        const int part = (fi >> 3) & 1, rr = 16 * (wave & 3) + 8 * (fi >> 4) + (fi & 7);
+        flo = (unsigned int)((((2 * part + (rr >> 5)) * NKB) * 64 + (rr & 31) + 32 * fh) * 16);
+        fb = gbase;
+        frange = 4 * NKB * 1024;
+      } else {
+        flo = (unsigned int)(lane * 16);
+        fb = gbase + (wave & 3) * (NKB * 1024);
+        frange = NKB * 1024;
+      }
+      const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)fb, 0, frange, 0x00020000);
       v4_static_for<0, NKB>([&](auto kc) __attribute__((always_inline)) {
         constexpr int kb = decltype(kc)::value;
-        afr[kb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, (unsigned int)(lane * 16) + kb * 1024, 0, 16 /* sc1 */));
+        afr[kb] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(frs, flo + kb * 1024, 0, 16 /* sc1 */));
       });
       // fragments, row state, pieces of the ring fill, the stores of the pair before: everything of this wave has landed
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -456,9 +488,10 @@ static int v8c_cu_count() {
 // row's statistics come in (V3_LSE: the layout of CeArgs::part), 0 = not this kernel's case.  A function of the
 // shape alone (the device's CU count is clamped to 256 as in the launch below).
 static bool v8c_geometry(int d, long long n, long long m, bool two_sided, int epi, long long ld16, V8CeArgs& a,
-                         int nbatch = 1, int reserve_cus = 0) {
+                         int nbatch = 1, int reserve_cus = 0, bool split = false) {
   if ((d != 512 && d != 256) || n < 1 || m < 1) return false;
-  const long long rgn1 = (n + 127) / 128;
+  const long long rgr = split ? 64 : 128;  // real rows per fragment group (a chunk = two groups)
+  const long long rgn1 = (n + rgr - 1) / rgr;
   const long long ut = (d == 256 && epi != V3_STORE) ? 2 * V8C_UT : V8C_UT;
   const long long cols = epi == V3_DS ? ld16 : m;  // the gradient pass also writes the pad columns of the pitch
   const long long nunits = (cols + ut - 1) / ut;
@@ -525,17 +558,17 @@ int run_pairs_bf16_v8_ce(int epi, const Operand& TG, int d, long long n, long lo
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;
 }
 
-// Scores of `nbatch` prepared single-pass batches against the identity-indexed bf16 table TG at d = 256 -- what
+// Scores of `nbatch` prepared batches (single-pass or split queries) against the identity-indexed bf16 table TG at d = 256 -- what
 // run_pairs_bf16_v8 is at d = 512 (same arguments; no in-launch build of the next group: the caller launches it).
 // sc1: the stores' cache policy as there (0 plain, 1 write-through, 2 non-temporal).
-int run_pairs_bf16_v8_store256(const Operand& TG, bool two_sided, long long n, long long m, int nbatch, const void* qf,
-                               long long q_stride_bytes, float* out, long long out_stride, long long ldo,
+int run_pairs_bf16_v8_store256(const Operand& TG, bool split, bool two_sided, long long n, long long m, int nbatch,
+                               const void* qf, long long q_stride_bytes, float* out, long long out_stride, long long ldo,
                                long long out2_off, int sc1, int reserve_cus, hipStream_t st) {
   if (TG.idx.ptr != nullptr || qf == nullptr || nbatch < 1 || ((uintptr_t)qf & 15) || (q_stride_bytes & 15))
     return KGE_ERR_UNSUPPORTED;
   if (TG.ld * 2 >= (1LL << 28) || ldo >= (1LL << 24)) return KGE_ERR_UNSUPPORTED;
   V8CeArgs a{};
-  if (!v8c_geometry(256, n, m, two_sided, V3_STORE, 0, a, nbatch, reserve_cus)) return KGE_ERR_UNSUPPORTED;
+  if (!v8c_geometry(256, n, m, two_sided, V3_STORE, 0, a, nbatch, reserve_cus, split)) return KGE_ERR_UNSUPPORTED;
   a.TG = TG;
   a.qf = (const u32x4*)qf;
   a.q_stride = q_stride_bytes / 16;
@@ -544,7 +577,11 @@ int run_pairs_bf16_v8_store256(const Operand& TG, bool two_sided, long long n, l
   a.ldo = ldo;
   a.out2_off = out2_off;
   const dim3 grid(8 * a.wpx), block(512);
-  if (sc1 == 1) hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 16>), grid, block, 0, st, a);
+  if (split) {
+    if (sc1 == 1) hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 16, 1>), grid, block, 0, st, a);
+    else if (sc1 == 2) hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 2, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 0, 1>), grid, block, 0, st, a);
+  } else if (sc1 == 1) hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 16>), grid, block, 0, st, a);
   else if (sc1 == 2) hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((pairs_bf16_v8_ce_kernel<128, V3_STORE, 0>), grid, block, 0, st, a);
   return hipGetLastError() == hipSuccess ? KGE_OK : KGE_ERR_LAUNCH;

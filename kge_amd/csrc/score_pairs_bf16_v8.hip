@@ -375,8 +375,8 @@ __global__ __launch_bounds__(512, 1) void pairs_bf16_v8_kernel(V8Args a) {
 void v6_set_stamps(unsigned long long* p);
 unsigned long long* v6_get_stamps();
 
-int run_pairs_bf16_v8_store256(const Operand& TG, bool two_sided, long long n, long long m, int nbatch, const void* qf,
-                               long long q_stride_bytes, float* out, long long out_stride, long long ldo,
+int run_pairs_bf16_v8_store256(const Operand& TG, bool split, bool two_sided, long long n, long long m, int nbatch,
+                               const void* qf, long long q_stride_bytes, float* out, long long out_stride, long long ldo,
                                long long out2_off, int sc1, int reserve_cus, hipStream_t st);
 
 static int v8_cu_count() {
@@ -435,7 +435,7 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
                       int nbatch, const void* qf, long long q_stride_bytes, float* out, long long out_stride,
                       long long ldo, long long out2_off, hipStream_t st, unsigned long long* dbg, const NextQ& nx,
                       int reserve_cus) {
-  if ((d != 512 && !(d == 256 && !split)) || TG.idx.ptr != nullptr || qf == nullptr || nbatch < 1) return KGE_ERR_UNSUPPORTED;
+  if ((d != 512 && d != 256) || TG.idx.ptr != nullptr || qf == nullptr || nbatch < 1) return KGE_ERR_UNSUPPORTED;
   // A single batch stays with pairs_bf16_v7 / v6 (a workgroup of this kernel loads the fragments of 256 rows before
   // its first chain -- 9-12 k cycles against 5 k there -- and a single batch's list gives it 7 units to amortise them
   // over: FB15k-237 shape two-sided 22.0 us against 19.2, profiles/r4_v8_probe.txt); KGE_V8=1 takes it here too.
@@ -486,14 +486,14 @@ int run_pairs_bf16_v8(int scorer, bool split, const Operand& TG, bool two_sided,
   // 238 MB: 226 us with nt against 112 for the single-batch kernel's plain stores, tools/one_call_v8_probe.py).
   const int sc1 = sc1e >= 0 ? (int)sc1e : (!st_aligned ? 0 : (bytes > 160e6 ? 2 : (bytes <= 48e6 ? 1 : 0)));
   if (d == 256) {
-    // d = 256, single-pass queries: the parametric structure of ce_pairs_v8.hip with a score-store epilogue (the
+    // d = 256 (single-pass and split queries): the parametric structure of ce_pairs_v8.hip with a score-store epilogue (the
     // kernel below is scheduled by hand for d = 512's 32-slot chains).  No in-launch build of the next group there.
     if (nx.qf != nullptr) return KGE_ERR_INVALID_ARG;
     // cache policy of its stores (tools/d256_store_probe.py, profiles/r6_d256_store_policies.txt): plain write-back up to
     // ~1 GB of scores per launch (FB15k-237 shape, 8 one-sided batches = 238 MB: 5.4 us per batch against 5.9 write-
     // through and 6.1-7.0 nt), write-through beyond (a Wikidata5M shard, 2.3 GB: 291 us per batch against 315)
     const int pol = sc1e >= 0 ? (int)(sc1e & 3) : (st_aligned && bytes > 1e9 ? 1 : 0);
-    const int rc = run_pairs_bf16_v8_store256(TG, two_sided, n, m, nbatch, qf, q_stride_bytes, out, out_stride, ldo,
+    const int rc = run_pairs_bf16_v8_store256(TG, split, two_sided, n, m, nbatch, qf, q_stride_bytes, out, out_stride, ldo,
                                               out2_off, pol, reserve_cus, st);
     if (rc == KGE_OK) __atomic_fetch_add(&g_v8_launches[0], 1, __ATOMIC_RELAXED);
     return rc;

@@ -9,8 +9,7 @@
 namespace kge {
 
 enum Switch : int {
-  SW_V5 = 0,               // 1: the workgroup-local-build kernel in front of v4 (tests)
-  SW_ONE_CALL_PREPARED,    // 0 / 1: query-build launch + prepared kernel for the one-call entries
+  SW_ONE_CALL_PREPARED = 0, // 0 / 1: query-build launch + prepared kernel for the one-call entries
   SW_ONE_CALL_V8,          // 0: one-call entries with many rows do not take the persistent kernel
   SW_ONE_CALL_V8_MIN_ROWS, // threshold of that route (>= 1024)
   SW_V8_RANK,              // 0: the counting kernel declines everything (pairs_bf16_v4_kernel<V3_RANK>)
@@ -28,6 +27,7 @@ enum Switch : int {
   SW_V8,                   // 0: the persistent store kernel declines everything; 1: takes single batches too
   SW_V8_VAR,               // probe builds (-DKGE_V8_PROBES)
   SW_V8R_PROBE,            // probe builds (-DKGE_V8_PROBES)
+  SW_BWD_FORK,             // 0: the two-sided backward's dQ product + split-K sum stay on the caller's stream (no side lane)
   SW_TRANSE_GENERIC,       // 1: TransE score_sp / score_po on the generic 4 x 4 kernel (the cross-check of pairs_transe_kernel)
   SW_COUNT
 };

@@ -16,11 +16,11 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (BF16, F32, FLAG_BF16_V1, FLAG_BF16_V3, FLAG_EXACT, FLAG_NO_MFMA, FLAG_SPLIT_QUERY, I32, I64, PO_,
+from ._lib import (BF16, F32, FLAG_BF16_V3, FLAG_EXACT, FLAG_NO_MFMA, FLAG_SPLIT_QUERY, I32, I64, PO_,
                    SCORERS, SP_, SP_PO, SPO, KgeIndex, KgeNextQueries, KgeTables)
 
 __all__ = ["Tables", "score_spo", "score_sp", "score_po", "score_sp_po", "score_neg",
-           "score_emb", "embed", "shard_gather", "shard_pick", "ns_bce_loss", "rank_counts", "score_pitch", "eval_batch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V1", "FLAG_BF16_V3",
+           "score_emb", "embed", "shard_gather", "shard_pick", "ns_bce_loss", "rank_counts", "score_pitch", "eval_batch", "FLAG_EXACT", "FLAG_NO_MFMA", "FLAG_BF16_V3",
            "FLAG_SPLIT_QUERY", "reserve_cus", "Queries", "build_queries", "score_queries", "ScorePipeline"]
 
 

@@ -95,7 +95,6 @@ def test_c2_full_size_bf16(eng, model):
     _eq("no-workspace kernel == default", _np(eng.score_sp(Tn, s, p)), _np(sp))
     _eq("v3 == default", _np(eng.score_sp(T, s, p, flags=eng.FLAG_BF16_V3)), _np(sp))
     _eq("v3 == default (po)", _np(eng.score_po(T, p, o, flags=eng.FLAG_BF16_V3)), _np(po))
-    _close("v1 ~ default", _np(eng.score_sp(T, s, p, flags=eng.FLAG_BF16_V1)), _np(sp))
     _close("exact f32-chain twin ~ default", _np(eng.score_sp(T, s, p, flags=eng.FLAG_EXACT)), _np(sp))
     both = eng.score_sp_po(T, s, p, o)
     _eq("two-sided launch, sp block", _np(both[:, :E]), _np(sp))

@@ -220,10 +220,7 @@ def test_bf16_mfma_kernel_vs_oracle(eng, model, d):
     _eq("16 CUs left free == default", _np(eng.score_sp(T, ts, tp, flags=eng.reserve_cus(16))), ref_sp)
     _eq("v3 fused == v3 coop", _np(eng.score_sp(Tn, ts, tp, flags=eng.FLAG_BF16_V3)), ref_sp)
     _eq("v3 fused == v3 coop (po, subset i32)", _np(eng.score_po(Tn, tp, to, _t(sub).int(), flags=eng.FLAG_BF16_V3)), ref_po)
-    # the tile-per-workgroup kernel (v1) computes the same thing
-    _close("v1 sp_all", _np(eng.score_sp(T, ts, tp, flags=eng.FLAG_BF16_V1)), ko.score_sp(O, s, p))
-    _close("v1 po_sub", _np(eng.score_po(T, tp, to, _t(sub), flags=eng.FLAG_BF16_V1)), ko.score_po(O, p, o, sub))
-    # and its bit-exact twin computes the same semantics
+    # the order-specified f32 chain computes the same semantics
     _eq("exact twin", _np(eng.score_sp(T, ts, tp, flags=eng.FLAG_EXACT)), ko.score_sp(O, s, p))
 
 
@@ -768,34 +765,33 @@ def test_degraded_workspace_recovers(eng):
     assert seen == [2, 1, 0, 0, 0], seen
 
 
-def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch, kge_switch):
-    """score_pairs_bf16_v5.hip (every workgroup builds the query vectors of its own 64 rows: no workspace,
-    no hand-off, any n) takes the calls the cooperative kernel declines.  Forced in front of it
-    (KGE_V5=1) it must give the same bits -- all / listed targets, one- and two-sided, dense rows, d = 256
-    and 512, ragged shapes; and so must the calls it takes on its own: no scratch buffer, n > 4096."""
+def test_what_the_cooperative_kernel_declines_runs_on_the_single_role_kernel(eng, kge_switch):
+    """Route 4 of api.hip's bf16_store_dispatch: calls the loader/consumer kernel (v4) does not take -- no scratch
+    buffer, more than 32 row groups -- run on pairs_bf16_v3_kernel with the same bits.  (Until round 6 a fifth kernel
+    generation, the workgroup-local-build kernel "v5", sat between the two; it is gone.)  Ragged shapes, all / listed
+    targets, one- and two-sided, dense rows, d = 256 and 512."""
     rng = np.random.default_rng(55)
-    for it in range(14):
+    for it in range(10):
         d = int(rng.choice([256, 512]))
         E = int(rng.integers(1, 5000))
-        n = int(rng.integers(1, 1300)) if it % 4 else int(rng.integers(1, 70))
+        n = int(rng.integers(1, 1000)) if it % 4 else int(rng.integers(1, 70))
         R = 5
         model = "complex" if it % 2 else "distmult"
         ent = rng.standard_normal((E, d)).astype(np.float32)
         rel = rng.standard_normal((R, d)).astype(np.float32)
         T = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+        Tn = _gpu_tables(eng, model, ent, rel, 1.0, bf16=True)
+        Tn.use_workspace = False
         s, p, o = (_t(rng.integers(0, hi, n)) for hi in (E, R, E))
         sub = None if it % 3 else _t(rng.integers(0, E, int(rng.integers(1, E + 1))))
         want = (_np(eng.score_sp(T, s, p, sub)), _np(eng.score_po(T, p, o, sub)), _np(eng.score_sp_po(T, s, p, o, sub)))
-        kge_switch.set("V5", "1")
-        got = (_np(eng.score_sp(T, s, p, sub)), _np(eng.score_po(T, p, o, sub)), _np(eng.score_sp_po(T, s, p, o, sub)))
+        got = (_np(eng.score_sp(Tn, s, p, sub)), _np(eng.score_po(Tn, p, o, sub)), _np(eng.score_sp_po(Tn, s, p, o, sub)))
         dense = _np(eng.score_emb(model, T.ent[s.long()], T.rel[p.long()], T.ent if sub is None else T.ent[sub.long()], "sp_"))
-        kge_switch.set("V5", "0")
         tag = f"it={it} {model} d={d} n={n} E={E} sub={None if sub is None else int(sub.numel())}"
         for k, (a, b) in enumerate(zip(got, want)):
-            _eq(f"local build, call {k}, {tag}", a, b)
-        _eq(f"local build, dense rows, {tag}", dense, want[0])
-    kge_switch.unset("V5")
-    # the calls it takes on its own
+            _eq(f"no scratch buffer, call {k}, {tag}", a, b)
+        _eq(f"dense rows, {tag}", dense, want[0])
+    kge_switch.set("ONE_CALL_V8", "0")  # (n >= 1024 would leave as batches of the persistent kernel otherwise)
     E, d, n = 3000, 512, 4500
     ent = rng.standard_normal((E, d)).astype(np.float32)
     rel = rng.standard_normal((R, d)).astype(np.float32)
@@ -804,6 +800,8 @@ def test_bf16_local_build_kernel_is_bit_identical(eng, monkeypatch, kge_switch):
     Tn.use_workspace = False
     s, p = _t(rng.integers(0, E, n)), _t(rng.integers(0, R, n))
     big = _np(eng.score_sp(T, s, p))            # 36 row groups of 128: beyond the cooperative kernel
+    kge_switch.unset("ONE_CALL_V8")
+    _eq("n = 4500: the single-role kernel == the persistent kernel's batches", _np(eng.score_sp(T, s, p)), big)
     _eq("n = 4500 vs two halves", big, np.concatenate([_np(eng.score_sp(T, s[:2250], p[:2250])),
                                                        _np(eng.score_sp(T, s[2250:], p[2250:]))]))
     _eq("no scratch buffer", _np(eng.score_sp(Tn, s[:700], p[:700])), big[:700])

@@ -302,9 +302,10 @@ def test_group_launch_equals_one_launch_per_batch(eng, scorer, combine, n, L, E,
         _same(flat[l], want[l], f"contiguous {combine} batch {l}")
 
 
-@pytest.mark.parametrize("n,L", [(512, 4), (200, 3), (64, 2)])
-def test_group_launch_with_split_queries(eng, n, L, monkeypatch, kge_switch):
-    E, R, d = 14541, 7, 512
+@pytest.mark.parametrize("d", [512, 256])   # 256: pairs_bf16_v8_ce_kernel<128, V3_STORE, ., SPLIT> (configs[4] in parity mode)
+@pytest.mark.parametrize("n,L", [(512, 4), (200, 3), (64, 2), (1, 3), (130, 9)])
+def test_group_launch_with_split_queries(eng, n, L, d, monkeypatch, kge_switch):
+    E, R = 14541 if n != 130 else 2111, 7
     fl = eng.FLAG_SPLIT_QUERY
     T, _, _ = _tables(eng, "complex", E, R, d, 70 + n, flags=fl)
     trip = torch.stack(_batch(E, R, n * L, 71), dim=1).contiguous()
@@ -319,6 +320,13 @@ def test_group_launch_with_split_queries(eng, n, L, monkeypatch, kge_switch):
     for l in range(L):
         _same(out[l].reshape(n, -1), want[l], f"split n={n} batch {l}/{L}")
     assert int((~torch.isnan(big)).sum()) == L * n * 2 * E
+    # one-sided groups on contiguous rows (4-byte alignment only)
+    flat = torch.full((L, n + 2, E), float("nan"), device=DEV)
+    q1 = eng.build_queries_group(T, "_po", trip, n, L, flags=fl)
+    eng.score_queries_group(T, q1, flat[:, :n])
+    for l in range(L):
+        _same(flat[l, :n], want[l][:, E:], f"split _po n={n} batch {l}/{L}")
+    assert int((~torch.isnan(flat)).sum()) == L * n * E
 
 
 @pytest.mark.parametrize("d", [512, 256])
@@ -505,8 +513,6 @@ def test_one_call_entry_with_many_rows_takes_the_persistent_kernel(eng, scorer, 
     kge_debug_launch_count) behind one query-build launch, the n % 512 rows left as a call of their own size.
     Bit-identical to the route switched off (KGE_ONE_CALL_V8=0: single-batch kernels), both query modes, all three
     entries, an E that is not a multiple of anything, strided int32 indices, and nothing outside the block."""
-    if d == 256 and split:
-        pytest.skip("split queries at d = 256 keep the single-batch kernels (the store epilogue takes single-pass queries)")
     E, R = 3001 if n > 2048 else 14541, 17
     flags = eng.FLAG_SPLIT_QUERY if split else 0
     T, _, _ = _tables(eng, scorer, E, R, d, seed=11, flags=flags)
