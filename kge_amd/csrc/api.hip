@@ -415,12 +415,12 @@ int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
 
 // ---- measurement switches (switches.hpp, include/kge_amd_debug.h) ----
 namespace kge {
-static long long g_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-static_assert(SW_COUNT == 20, "g_switch's initialiser");
+static long long g_switch[SW_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+static_assert(SW_COUNT == 19, "g_switch's initialiser");
 static const char* const g_switch_name[SW_COUNT] = {
     "ONE_CALL_PREPARED", "ONE_CALL_V8", "ONE_CALL_V8_MIN_ROWS", "V8_RANK", "RANK_FUSED_FRONT", "BWD_GEMM_LIB",
     "CE_V3", "CE_V8", "V4_OWN_BUILD", "V4_INTERLEAVE", "V4_STORE_SC1", "V6", "V7", "V7_NOSTORE", "V7_PROBE", "V8",
-    "V8_VAR", "V8R_PROBE", "BWD_FORK", "TRANSE_GENERIC"};
+    "V8_VAR", "V8R_PROBE", "TRANSE_GENERIC"};
 long long sw(Switch s) { return __atomic_load_n(&g_switch[(int)s], __ATOMIC_RELAXED); }
 static int switch_index(const char* name) {
   if (name == nullptr) return -1;

@@ -14,49 +14,9 @@
 // partials of the dQ product.  Tolerance-level parity with the reference's autograd (summation order unspecified
 // on both sides).  No BLAS library is linked.
 #include "common.hpp"
-#include <mutex>
 
 
 namespace kge {
-
-// ---- a side lane for the two-sided backward (bwdg_products16_two) ---------------------------------------------------
-// dQ = G16 T (+ the sum of its split-K partials) and dT = G16^T Q16 read the same G16 and write different buffers (the
-// caller's split-K scratch / the table gradient): neither needs the other.  Issued on ONE stream the split-K sum --
-// 33 MB read by a launch that leaves most of every CU idle -- stands between the two products; with the first product
-// and its sum on a second stream (fork behind the launch that wrote G16, join in front of the chain-rule launch) the
-// sum runs under the other product's tiles.  Under stream capture the fork / join events become graph edges: the
-// captured training step keeps the two branches.  One lane per device, created at the first EAGER call (creating
-// streams / events is not a capturable operation: a call that is being captured before any eager call keeps the
-// single-stream order); a mutex keeps two host threads from interleaving their record / wait pairs on the shared events.
-// Switch BWD_FORK = 0: off (A/B runs: tools/train_step_prof.py).
-struct SideLane {
-  hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  std::mutex mu;
-  bool tried = false, ok = false;
-};
-static SideLane g_side[64];
-
-static SideLane* side_lane(hipStream_t st) {
-  if (sw(SW_BWD_FORK) == 0) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideLane* L = &g_side[dev];
-  std::lock_guard<std::mutex> lk(L->mu);
-  if (!L->tried) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      return nullptr;  // (not marked tried: the next eager call creates the lane)
-    }
-    L->tried = true;
-    L->ok = hipStreamCreateWithFlags(&L->s, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&L->fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&L->join, hipEventDisableTiming) == hipSuccess;
-    if (!L->ok) (void)hipGetLastError();
-  }
-  return L->ok ? L : nullptr;
-}
 
 // bwd_gemm16.hip: the hand-written bf16 contractions
 int run_gemm16_dq(int d, long long rows, long long m, const unsigned short* T, long long ldt,
@@ -426,25 +386,14 @@ static int bwdg_products16_two(const Operand& A1, const Operand& A2, const Opera
   float* lws = dq_scratch != nullptr ? dq_scratch : g_tgt;
   const size_t lws_bytes = dq_scratch != nullptr ? (size_t)dq_scratch_bytes : (size_t)m * d * sizeof(float);
   const bool clr = clear_acc_rel && acc_rel != nullptr;
-  // the caller's scratch: dQ and its split-K sum touch nothing dT touches -- on the side lane, beside dT
-  SideLane* const sl = dq_scratch != nullptr ? side_lane(st) : nullptr;
-  if (sl != nullptr) {
-    std::lock_guard<std::mutex> lk(sl->mu);
-    if (hipEventRecord(sl->fork, st) != hipSuccess || hipStreamWaitEvent(sl->s, sl->fork, 0) != hipSuccess)
-      return KGE_ERR_LAUNCH;
-    const bool okq = bwdg_dq16(d, nrows, m, T, TG.ld, G16, mp, g_a, lws, lws_bytes, sl->s, clr ? acc_rel : nullptr,
-                               clr ? acc_rel_rows * acc_rel_ld : 0LL);
-    // (join even when a product declined: a capture must not end with the side lane still forked)
-    const bool okj = hipEventRecord(sl->join, sl->s) == hipSuccess;
-    const bool okt = okq && bwdg_dt16(d, nrows, m, Q16, G16, mp, g_tgt, st);
-    if (!okj || hipStreamWaitEvent(st, sl->join, 0) != hipSuccess) return KGE_ERR_LAUNCH;
-    if (!okq || !okt) return KGE_ERR_UNSUPPORTED;
-  } else {
-    if (!bwdg_dq16(d, nrows, m, T, TG.ld, G16, mp, g_a, lws, lws_bytes, st, clr ? acc_rel : nullptr,
-                   clr ? acc_rel_rows * acc_rel_ld : 0LL))
-      return KGE_ERR_UNSUPPORTED;
-    if (!bwdg_dt16(d, nrows, m, Q16, G16, mp, g_tgt, st)) return KGE_ERR_UNSUPPORTED;
-  }
+  // [Tried in round 6 and reverted: dQ + its split-K sum on a second stream beside dT (fork behind the launch that wrote
+  // G16, join in front of the chain rule; the events become edges of the captured step).  The replayed step went from
+  // 0.1409 to 0.1432-0.1448 ms, the eager step from 0.234 to 0.255+: both products fill the chip (one 144 KB workgroup
+  // per CU), so only the 7 us sum could overlap, and the two cross-stream edges of the graph cost more than that.]
+  if (!bwdg_dq16(d, nrows, m, T, TG.ld, G16, mp, g_a, lws, lws_bytes, st, clr ? acc_rel : nullptr,
+                 clr ? acc_rel_rows * acc_rel_ld : 0LL))
+    return KGE_ERR_UNSUPPORTED;
+  if (!bwdg_dt16(d, nrows, m, Q16, G16, mp, g_tgt, st)) return KGE_ERR_UNSUPPORTED;
   // acc_rel != NULL: the row gradients go straight into the table gradients -- the entity rows
   // on top of dT in g_tgt [m, d] (all entities: row ids are table rows), the relation rows into acc_rel
   hipLaunchKernelGGL((bwdg_chain16_kernel<SCORER>), qgrid, dim3(256), 0, st, A1, R, KGE_SP_, d, n, g_a, g_p, A2, R2, n2,

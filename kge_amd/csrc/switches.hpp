@@ -27,7 +27,6 @@ enum Switch : int {
   SW_V8,                   // 0: the persistent store kernel declines everything; 1: takes single batches too
   SW_V8_VAR,               // probe builds (-DKGE_V8_PROBES)
   SW_V8R_PROBE,            // probe builds (-DKGE_V8_PROBES)
-  SW_BWD_FORK,             // 0: the two-sided backward's dQ product + split-K sum stay on the caller's stream (no side lane)
   SW_TRANSE_GENERIC,       // 1: TransE score_sp / score_po on the generic 4 x 4 kernel (the cross-check of pairs_transe_kernel)
   SW_COUNT
 };

@@ -10,7 +10,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from kge_amd import model as km, optim as kopt  # noqa: E402
+from kge_amd import model as km, optim as kopt, _lib  # noqa: E402
+
+# KGE_SWITCHES="BWD_FORK=0,CE_V8=0": the library's measurement switches (kge_amd/csrc/switches.hpp) for A/B runs
+for kv in filter(None, os.environ.get("KGE_SWITCHES", "").split(",")):
+    k, v = kv.split("=")
+    _lib.set_switch(k, int(v))
 
 E, R, D, N = 14541, 237, 512, 512
 STEPS = int(os.environ.get("STEPS", "200"))
