@@ -550,7 +550,7 @@ def main_sharded(a, world, rank, device):
         # Default: ONE batch at a time, issued call by call -- the configuration every earlier round ran.  Two lanes pay
         # only with the step captured into a hipGraph (call by call the step is bound by the host: 60 -> 84 us with
         # two lanes, 60 -> 47 us with two lanes + graph, one rank); the capture of a multi-rank RCCL all-gather has
-        # not run on this code, so N > 1 takes it only when asked (--streams 2 with KGE_SHARDED_GRAPH=1).
+        # not run on this code, so N > 1 takes it only when asked (--streams 2 with ShardedScoreLanes.GRAPH = True).
         lanes = ShardedScoreLanes(sh, 1 if big_slab else max(1, a.streams if a.streams is not None else 2))
         tri3 = torch.stack([s.long(), p.long(), o.long()], 1).contiguous()
 
@@ -775,7 +775,7 @@ def ns_step_leg(device, n, steps):
     call and as ONE hipGraph replay (kge_amd.train_graph.GraphedStep; hip_negative_sampling.graph_step).  The negatives'
     gather is the algorithmic traffic: 2 slots x n x K rows of d floats forward, the same rows read again + their
     gradient rows scattered in the backward."""
-    from kge_amd import model as km, optim as kopt
+    from kge_amd import engine, model as km, optim as kopt
     from kge_amd.train_graph import GraphedStep
     E, R, d, K = 40943, 11, DIM, 1000
     q = torch.Generator().manual_seed(5)
@@ -814,7 +814,7 @@ def ns_step_leg(device, n, steps):
            "eager": {"ms_per_step": ms, "scored_triples_per_s": 2.0 * n * (K + 1) / (ms * 1e-3)}}
     # the same eager step with the backward's scatter as one float atomic per element and occurrence
     # (kge_score_neg_bwd_accum) instead of sorted by entity (kge_score_neg_bwd_accum_sorted: the default at this shape)
-    os.environ["KGE_NEG_BWD_SORTED"] = "0"
+    engine.NEG_BWD_SORTED = False
     try:
         for _ in range(2):
             step()
@@ -825,7 +825,7 @@ def ns_step_leg(device, n, steps):
         torch.cuda.synchronize()
         out["eager_with_atomic_scatter"] = {"ms_per_step": (time.perf_counter() - t0) / steps * 1e3}
     finally:
-        os.environ.pop("KGE_NEG_BWD_SORTED", None)
+        engine.NEG_BWD_SORTED = None
     gs = GraphedStep(loss_fn, opt, warmup=1)
     for _ in range(4):
         gs(s, p, o, negs[0], negs[1])

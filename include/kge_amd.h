@@ -134,11 +134,15 @@ typedef enum kge_flags {
 #define KGE_FLAG_RESERVE_CUS(n) (((n) & 255) << KGE_FLAG_RESERVE_CUS_SHIFT)
 
 /* An index vector: element i is ptr[i*stride] of type itype.
- * ptr == NULL means the identity 0,1,2,... (used for "all entities"). */
+ * ptr == NULL means the identity 0,1,2,... (used for "all entities") -- or, as the `targets` of kge_score_sp / _po /
+ * _sp_po only, the contiguous range start, start+1, ..., start+m-1 (0 <= start, start + m <= num_ent): the entity chunk
+ * the reference's EntityRankingJob scores against, passed there as torch.arange(chunk_start, chunk_end)
+ * (kge/job/eval_entity_ranking.py:216-229) -- the kernels stream rows [start, start + m) of the table itself, no index
+ * is read.  `start` must be 0 with a non-NULL ptr and everywhere else. */
 typedef struct kge_index {
   const void* ptr;
   int32_t itype;              /* kge_itype */
-  int32_t reserved;
+  int32_t start;              /* see above; 0 otherwise (until round 6 this field was `reserved`, always 0) */
   int64_t stride;             /* in elements */
 } kge_index;
 

@@ -40,7 +40,7 @@ class KgeTables(ctypes.Structure):
 
 
 class KgeIndex(ctypes.Structure):
-    _fields_ = [("ptr", c_vp), ("itype", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    _fields_ = [("ptr", c_vp), ("itype", ctypes.c_int32), ("start", ctypes.c_int32),
                 ("stride", c_i64)]
 
 

@@ -238,6 +238,7 @@ int check_tables(const kge_tables* t, bool need_ptrs) {
 }
 
 int check_index(const kge_index& ix, bool allow_null, int64_t len = 1) {
+  if (ix.start != 0) return KGE_ERR_INVALID_ARG;  // (a range of targets: check_targets below, kge_score_sp / _po / _sp_po only)
   if (!ix.ptr) return (allow_null || len == 0) ? KGE_OK : KGE_ERR_INVALID_ARG;
   if (ix.itype != KGE_I32 && ix.itype != KGE_I64) return KGE_ERR_INVALID_ARG;
   if (ix.stride < 1) return KGE_ERR_INVALID_ARG;
@@ -246,6 +247,23 @@ int check_index(const kge_index& ix, bool allow_null, int64_t len = 1) {
 
 Operand ent_op(const kge_tables* t, const kge_index& ix) {
   return Operand{t->ent, t->ent_ld, make_index(ix)};
+}
+// The `targets` of kge_score_sp / _po / _sp_po: a listed subset, all entities (ptr == NULL, start == 0, m == num_ent) or
+// the contiguous range [start, start + m) (ptr == NULL): the reference's entity chunk, torch.arange(chunk_start,
+// chunk_end) (eval_entity_ranking.py:216-229) -- rows of the table itself, streamed without an index.
+int check_targets(const kge_tables* t, const kge_index& ix, int64_t m) {
+  if (ix.ptr) {
+    kge_index k = ix;
+    if (k.start != 0) return KGE_ERR_INVALID_ARG;
+    return check_index(k, true);
+  }
+  if (ix.start < 0 || (int64_t)ix.start + m > t->num_ent) return KGE_ERR_INVALID_ARG;
+  return KGE_OK;
+}
+Operand tgt_op(const kge_tables* t, const kge_index& ix) {
+  if (ix.ptr) return ent_op(t, ix);
+  const int64_t esize = t->dtype == KGE_BF16 ? 2 : 4;
+  return Operand{(const char*)t->ent + (int64_t)ix.start * t->ent_ld * esize, t->ent_ld, Index{nullptr, 1, KGE_I64}};
 }
 Operand rel_op(const kge_tables* t, const kge_index& ix) {
   return Operand{t->rel, t->rel_ld, make_index(ix)};
@@ -403,11 +421,9 @@ int pairs_entry(const kge_tables* t, int dir, kge_index a, kge_index p, int64_t 
   if (rc) return rc;
   if (n < 0 || m < 0 || (!out && n * m > 0) || ldo < m) return KGE_ERR_INVALID_ARG;
   if (n == 0 || m == 0) return KGE_OK;  // empty batch / empty subset: nothing to score
-  if ((rc = check_index(a, false)) || (rc = check_index(p, false)) ||
-      (rc = check_index(targets, true)))
+  if ((rc = check_index(a, false)) || (rc = check_index(p, false)) || (rc = check_targets(t, targets, m)))
     return rc;
-  if (!targets.ptr && m != t->num_ent) return KGE_ERR_INVALID_ARG;
-  return pairs_dispatch(t, dir, ent_op(t, a), rel_op(t, p), ent_op(t, targets), n, m, out, ldo,
+  return pairs_dispatch(t, dir, ent_op(t, a), rel_op(t, p), tgt_op(t, targets), n, m, out, ldo,
                         ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -677,8 +693,8 @@ int kge_score_sp_po(const kge_tables* t, kge_index s, kge_index p, kge_index o, 
   // the kernel start-up and the launch overhead are paid once
   if (t && workspace && n > 0 && m > 0 && out && check_tables(t, true) == KGE_OK && check_index(s, false) == KGE_OK &&
       check_index(p, false) == KGE_OK && check_index(o, false) == KGE_OK &&
-      check_index(targets, true) == KGE_OK && (targets.ptr || m == t->num_ent)) {
-    const Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = ent_op(t, targets);
+      check_targets(t, targets, m) == KGE_OK) {
+    const Operand S = ent_op(t, s), O = ent_op(t, o), P = rel_op(t, p), TG = tgt_op(t, targets);
     const int rc2 = bf16_store_dispatch(t, KGE_SP_, S, &O, P, TG, n, m, out, ldo, m, workspace, workspace_bytes,
                                         (hipStream_t)stream);
     if (rc2 != KGE_ERR_UNSUPPORTED) return rc2;

@@ -157,6 +157,18 @@ def _index3(triples, device, keep):
     return KgeIndex(base, it, 0, st), KgeIndex(base + st1 * w, it, 0, st), KgeIndex(base + 2 * st1 * w, it, 0, st), n
 
 
+def _targets(targets, t, keep):
+    """The `targets` operand of score_sp / score_po / score_sp_po -> (KgeIndex, m): None = all entities, a `range`
+    (step 1) = that contiguous chunk of the table -- kge_index.start, include/kge_amd.h: no index is read, the
+    all-entities kernels stream rows [start, stop) --, anything else = a listed subset."""
+    if isinstance(targets, range):
+        if targets.step != 1 or targets.start < 0 or targets.stop > t.num_ent or targets.stop < targets.start:
+            raise ValueError(f"kge_amd: a target range must be a step-1 range inside [0, {t.num_ent}); got {targets}")
+        return KgeIndex(None, I64, targets.start, 1), len(targets)
+    ti = _index(targets, t.device, keep)
+    return ti, (t.num_ent if targets is None else keep[-1].numel())
+
+
 def _same_len(ixs, what):
     """All index operands of one call must have the same length (the reference would raise a shape
     error; a shorter vector here would be an out-of-bounds read on the device)."""
@@ -276,8 +288,7 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None, padded=
     keep = []
     ai, pi = _index(a, t.device, keep), _index(p, t.device, keep)
     n = _same_len(keep[:2], "_pairs")
-    ti = _index(targets, t.device, keep)
-    m = t.num_ent if targets is None else keep[-1].numel()
+    ti, m = _targets(targets, t, keep)
     ret = None
     if out is None:
         if padded and m > 0:
@@ -303,7 +314,8 @@ def _pairs(fn_name, t: Tables, a, p, targets, flags, out=None, ldo=None, padded=
 
 
 def score_sp(t: Tables, s, p, o=None, flags=None, padded=None) -> torch.Tensor:
-    """[n, E|m] scores of (s_i, p_i, ·) against all / the listed objects.  padded=True (default: the tables'
+    """[n, E|m] scores of (s_i, p_i, ·) against all / the listed objects / the objects of a step-1 `range` (a chunk of
+    the table streamed without an index: the all-entities kernels).  padded=True (default: the tables'
     `pad_pitch`): the [:, :m] view of a matrix on the row pitch `score_pitch(m)` -- sector-aligned rows, what the store
     kernels are measured on (E = 14,541 is odd: rows of a contiguous matrix start at 4-byte granularity); the reference
     returns a contiguous tensor, so this is an option."""
@@ -329,8 +341,7 @@ def score_sp_po(t: Tables, s, p, o, entity_subset=None, flags=None) -> torch.Ten
     keep = []
     si, pi, oi = (_index(x, t.device, keep) for x in (s, p, o))
     n = _same_len(keep[:3], "score_sp_po")
-    ti = _index(entity_subset, t.device, keep)
-    m = t.num_ent if entity_subset is None else keep[-1].numel()
+    ti, m = _targets(entity_subset, t, keep)
     out = _empty((n, 2 * m), t.device)
     with _on_device(t.device):
         tc = t.c(flags)
@@ -679,14 +690,14 @@ def score_neg(t: Tables, s, p, o, slot: int, neg: torch.Tensor, flags=None) -> t
 
 # kge_score_neg_bwd_accum_sorted (occurrences sorted by corrupted entity: one gradient-row flush per run of equal ids
 # instead of one float atomic per element and occurrence) from this many occurrences on, when every entity is drawn
-# several times on average; KGE_NEG_BWD_SORTED=0 / 1 forces either.
+# several times on average; NEG_BWD_SORTED = True / False forces either (tests, bench.py's A/B leg).
 NEG_BWD_SORTED_MIN = 1 << 17
+NEG_BWD_SORTED = None
 
 
 def _neg_bwd_sorted(n, K, num_ent) -> bool:
-    want = os.environ.get("KGE_NEG_BWD_SORTED")
-    if want is not None:
-        return want == "1"
+    if NEG_BWD_SORTED is not None:
+        return bool(NEG_BWD_SORTED)
     return n * K >= NEG_BWD_SORTED_MIN and n * K >= 4 * num_ent
 
 

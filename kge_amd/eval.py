@@ -20,7 +20,6 @@ applies the filters cumulatively (:305-307), "_filt_test" filters with the union
 """
 from typing import Dict, List
 
-import os
 
 import numpy as np
 import torch
@@ -137,15 +136,26 @@ class EntityRankingEvaluator:
     # ... and, under "auto", only from this many entities on: the form costs two launches and a read of every row's q_lo
     # block per (side, chunk) -- ~14 us at the FB15k-237 shape, where the split kernel's whole second chain is 16 us
     BAND_MIN_ENTITIES = 100000
-
+    # measurement options and their defaults (constructor keywords): two_step = never count inside the scoring kernel;
+    # launch_by_launch = the fused loop as separate engine calls; reserve_cus = compute units the persistent kernels leave
+    # free; hip_graph = full batches as graph replays; lanes = captured batches in flight; fused_exact = the exact
+    # kernels' counting epilogue (None: from FUSED_EXACT_MIN_BYTES of score matrix on)
+    OPTIONS = {"two_step": False, "launch_by_launch": False, "reserve_cus": 0, "hip_graph": True, "lanes": 3,
+               "fused_exact": None}
 
     def __init__(self, model, splits: Dict[str, np.ndarray], num_entities: int, num_relations: int,
                  eval_split: str = "valid", filter_splits=("train", "valid"),
                  filter_with_test: bool = True, batch_size: int = 100, chunk_size: int = -1,
                  tie_handling: str = "rounded_mean_rank", tie_atol: float = 1e-5,
                  tie_rtol: float = 1e-4,
-                 hits_at_k_s=(1, 3, 10, 50, 100, 200, 300, 400, 500, 1000), band_rescore="auto"):
+                 hits_at_k_s=(1, 3, 10, 50, 100, 200, 300, 400, 500, 1000), band_rescore="auto", **options):
         self.model = model
+        # measurement options (OPTIONS below; keyword arguments override the class defaults -- nothing here is read
+        # from the environment: tools/ map their old KGE_EVAL_* variables onto OPTIONS themselves, tools/_eval_env.py)
+        unknown = set(options) - set(self.OPTIONS)
+        if unknown:
+            raise TypeError(f"EntityRankingEvaluator: unknown option(s) {sorted(unknown)}")
+        opt = dict(self.OPTIONS, **options)
         # split-query evaluation of bf16 ComplEx / DistMult tables through band-and-rescore: "auto" (probe the first
         # batch of every run), True (no probe; a run that dropped pairs still falls back), False (the split kernel)
         self.band_rescore = band_rescore
@@ -165,17 +175,18 @@ class EntityRankingEvaluator:
         self.tie_handling, self.tie_atol, self.tie_rtol = tie_handling, tie_atol, tie_rtol
         self.hits_at_k_s = [k for k in hits_at_k_s if k <= min(num_entities, max(hits_at_k_s))]
         # count inside the scoring kernel where the library offers it (set False to force the two-step path)
-        self._fused = os.environ.get("KGE_EVAL_TWO_STEP", "0") != "1"
+        self._fused = not opt["two_step"]
         self._declined = set()  # batch sizes kge_score_rank_sp_po declined for these tables
         self._declined_for = None
-        # KGE_EVAL_LAUNCH_BY_LAUNCH=1: the fused loop as separate engine calls (a dozen launches per batch) instead of
+        # launch_by_launch: the fused loop as separate engine calls (a dozen launches per batch) instead of
         # kge_eval_batch's four
-        self.four_launches = os.environ.get("KGE_EVAL_LAUNCH_BY_LAUNCH", "0") != "1"
-        self.reserve_cus = int(os.environ.get("KGE_EVAL_RESERVE_CUS", "0"))
-        # replay the fused loop's full batches as one hipGraph (KGE_EVAL_GRAPH=0: issue every launch from Python)
-        self.hip_graph = os.environ.get("KGE_EVAL_GRAPH", "1") != "0"
+        self.four_launches = not opt["launch_by_launch"]
+        self.reserve_cus = int(opt["reserve_cus"])
+        # replay the fused loop's full batches as one hipGraph (hip_graph=False: issue every launch from Python)
+        self.hip_graph = bool(opt["hip_graph"])
         self.graph_batches = 0  # batches that ran as graph replays (all runs)
-        self.lanes = int(os.environ.get("KGE_EVAL_LANES", "3"))  # captured batches in flight (one HIP stream each)
+        self.lanes = int(opt["lanes"])  # captured batches in flight (one HIP stream each)
+        self.fused_exact = opt["fused_exact"]  # None: by score-matrix size (FUSED_EXACT_MIN_BYTES); True / False
         self._graph = None
 
     @staticmethod
@@ -282,7 +293,7 @@ class EntityRankingEvaluator:
         gkey = ((tables.ent.data_ptr(), tables.rel.data_ptr(), tuple(tables.ent.shape), tuple(tables.rel.shape),
                  tables.ent.stride(0), tables.rel.stride(0), tables.scorer, bool(return_ranks), M, int(tables.flags),
                  bool(self._fused), bool(self.four_launches), self.tie_handling, float(self.tie_atol),
-                 float(self.tie_rtol), os.environ.get("KGE_EVAL_FUSED_EXACT"), int(self.chunk_size), int(self.reserve_cus))
+                 float(self.tie_rtol), self.fused_exact, int(self.chunk_size), int(self.reserve_cus))
                 if isinstance(tables, engine.Tables) else None)
         # ---- band-and-rescore for this run?
         chunk0 = E if self.chunk_size < 0 else self.chunk_size
@@ -324,11 +335,11 @@ class EntityRankingEvaluator:
         # the exact kernels' counting epilogue (float32 tables, TransE / RotatE) saves the [n, 2E] score matrix, not
         # time: their scoring is compute-bound and the true scores cost a launch pair of their own (C4 shape,
         # float32 DistMult: 0.35 ms per batch against 0.24 for score + scan, tools/eval_f32_probe.py) -- taken when
-        # the matrix would be large (FUSED_EXACT_MIN_BYTES) or asked for (KGE_EVAL_FUSED_EXACT=1)
+        # the matrix would be large (FUSED_EXACT_MIN_BYTES) or asked for (fused_exact=True)
         if fused and (tables.ent.dtype != torch.bfloat16 or
                       tables.scorer not in (engine.SCORERS["complex"], engine.SCORERS["distmult"])):
-            want = os.environ.get("KGE_EVAL_FUSED_EXACT")
-            fused = (want == "1") if want is not None else 8 * self.batch_size * min(chunk, E) >= self.FUSED_EXACT_MIN_BYTES
+            want = self.fused_exact
+            fused = bool(want) if want is not None else 8 * self.batch_size * min(chunk, E) >= self.FUSED_EXACT_MIN_BYTES
         if self._declined_for != gkey:  # other tables: ask again
             self._declined_for, self._declined = gkey, set()
         declined = self._declined

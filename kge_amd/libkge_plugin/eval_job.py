@@ -1,6 +1,5 @@
 """EntityRankingJob on the fused kernels (eval.type: hip_entity_ranking)."""
 import math
-import os
 import time
 
 import numpy as np
@@ -106,22 +105,29 @@ class HipEntityRankingJob(EntityRankingJob):
                 pin_memory=self.config.get("eval.pin_memory"),
             )
 
+    def _option(self, name, default):
+        """hip_entity_ranking.<name> of the job's configuration (a config written before the option existed: `default`)."""
+        try:
+            return self.config.get(f"hip_entity_ranking.{name}")
+        except KeyError:
+            return default
+
     def _eval_begin(self, M, chunk_size):
         """What one evaluation decides once: which tables the counting kernel runs on, split queries or not."""
         # A plain hip_* model (fused gather): scoring and counting in one kernel -- float32 tables of every scorer
         # (the exact kernels' counting epilogue), bf16 ComplEx / DistMult tables with dim 256 / 512 (the loader /
-        # consumer kernel's); what the library declines falls back below.  KGE_EVAL_TWO_STEP=1: never.
+        # consumer kernel's); what the library declines falls back below.  hip_entity_ranking.two_step: true = never.
         E = self.dataset.num_entities()
         fused_tables = getattr(self.model, "_rank_tables", None)
-        if os.environ.get("KGE_EVAL_TWO_STEP", "0") == "1" or M > 3 or fused_tables is None or fused_tables() is None:
+        if self._option("two_step", False) or M > 3 or fused_tables is None or fused_tables() is None:
             fused_tables = None
         # (the exact kernels' counting saves the score matrix, not time -- kge_amd.eval.EntityRankingEvaluator.run:
-        # taken from FUSED_EXACT_MIN_BYTES of score matrix on, or with KGE_EVAL_FUSED_EXACT=1)
+        # taken from FUSED_EXACT_MIN_BYTES of score matrix on, or with hip_entity_ranking.fused_exact: always)
         if fused_tables is not None and (fused_tables().ent.dtype != torch.bfloat16
                                          or self.model._scorer.name not in ("complex", "distmult")):
             from ..eval import EntityRankingEvaluator as _Ev
-            want = os.environ.get("KGE_EVAL_FUSED_EXACT")
-            if not ((want == "1") if want is not None
+            want = self._option("fused_exact", "auto")
+            if not ((want == "always") if want in ("always", "never")
                     else 8 * self.batch_size * min(chunk_size, E) >= _Ev.FUSED_EXACT_MIN_BYTES):
                 fused_tables = None
         # hip_entity_ranking.bf16_queries (hip_entity_ranking.yaml): "split" (default) scores bf16 tables with split

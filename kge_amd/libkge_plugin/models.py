@@ -166,9 +166,53 @@ class _FusedScoring:
         except KeyError:
             return False
 
+    # ---- scoring without a recorded gradient: what an UNMODIFIED EntityRankingJob (eval.type: entity_ranking) calls
+    # -- score_sp_po(s, p, o, torch.arange(chunk_start, chunk_end)) per chunk, score_sp / score_po against the batch's
+    # unique true answers (kge/job/eval_entity_ranking.py:143-229).
+    RANGE_MIN = 1024  # subsets from this length on are checked for being a contiguous range (one host read)
+
+    def _no_grad_call(self):
+        """(tables, flags) of a scoring call under torch.no_grad(), None where a gradient is recorded.  On bf16 tables
+        (ComplEx / DistMult, `score_dtype: bfloat16` or bf16 parameters) the flags carry KGE_FLAG_SPLIT_QUERY unless
+        `no_grad_queries: single`: the query vector as q_hi + q_lo -- the ranks of float32 arithmetic on those tables
+        (what `hip_entity_ranking.bf16_queries: split` counts), where a single rounded query vector moves 4 % of them."""
+        if torch.is_grad_enabled():
+            return None
+        ent, rel = self._w()
+        t = self._fwd_tables() or engine.Tables(self._scorer.name, ent.detach(), rel.detach(), self._scorer._norm)
+        flags = None
+        if t.ent.dtype == torch.bfloat16 and self._scorer.name in ("complex", "distmult"):
+            try:
+                single = self.get_option("no_grad_queries") == "single"
+            except KeyError:
+                single = False
+            if not single:
+                flags = int(t.flags) | engine.FLAG_SPLIT_QUERY
+        return t, flags
+
+    def _targets(self, subset):
+        """The reference hands an entity chunk over as torch.arange(chunk_start, chunk_end) -- also the whole table when
+        nothing is chunked.  A LISTED subset keeps the kernels that gather their target rows through the index (and, with
+        split queries, the f32 chain); recognised as a contiguous range (strictly increasing, last - first == len - 1:
+        one small reduction + one host read, in a loop that waits for the device several times per batch anyway) it is
+        scored by the all-entities kernels on rows [start, stop) of the table (kge_index.start, include/kge_amd.h)."""
+        if subset is None or not torch.is_tensor(subset) or subset.dim() != 1 or subset.numel() < self.RANGE_MIN \
+                or subset.dtype not in (torch.int32, torch.int64):
+            return subset
+        m = subset.numel()
+        ok = ((subset[-1] - subset[0]) == m - 1) & (subset[1:] > subset[:-1]).all()
+        ok, first = torch.stack((ok.to(torch.int64), subset[0].to(torch.int64))).tolist()
+        E = self._w()[0].shape[0]
+        if not ok or first < 0 or first + m > E:
+            return subset
+        return None if (first == 0 and m == E) else range(first, first + m)
+
     def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
         if not self._fused():
             return super().score_sp(s, p, o)
+        ng = self._no_grad_call()
+        if ng is not None:
+            return engine.score_sp(ng[0], s, p, self._targets(o), flags=ng[1], padded=self._padded())
         ent, rel = self._w()
         return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "sp", ent, rel, s, p, o,
                                  self._fwd_tables(), self._padded())
@@ -176,6 +220,9 @@ class _FusedScoring:
     def score_po(self, p: Tensor, o: Tensor, s: Tensor = None) -> Tensor:
         if not self._fused():
             return super().score_po(p, o, s)
+        ng = self._no_grad_call()
+        if ng is not None:
+            return engine.score_po(ng[0], p, o, self._targets(s), flags=ng[1], padded=self._padded())
         ent, rel = self._w()
         return _ScorePairs.apply(self._scorer.name, self._scorer._norm, "po", ent, rel, o, p, s,
                                  self._fwd_tables(), self._padded())
@@ -301,11 +348,9 @@ class _FusedScoring:
     def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
         if not self._fused():
             return super().score_sp_po(s, p, o, entity_subset)
-        if not torch.is_grad_enabled():
-            ent, rel = self._w()
-            t = self._fwd_tables() or engine.Tables(self._scorer.name, ent.detach(), rel.detach(),
-                                                    self._scorer._norm)
-            return engine.score_sp_po(t, s, p, o, entity_subset)
+        ng = self._no_grad_call()
+        if ng is not None:
+            return engine.score_sp_po(ng[0], s, p, o, self._targets(entity_subset), flags=ng[1])
         return torch.cat((self.score_sp(s, p, entity_subset), self.score_po(p, o, entity_subset)), dim=1)
 
 

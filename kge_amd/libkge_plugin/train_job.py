@@ -578,11 +578,13 @@ class HipTrainingJobNegativeSampling(_CudaOomText, TrainingJobNegativeSampling):
     def __init__(self, config, dataset, parent_job=None, model=None, forward_only=False):
         super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
         self.type_str = "negative_sampling"
-        # the bce family of losses on a GPU: loss + gradient of a slot's score block in one kernel (KGE_NS_FUSED_LOSS=0:
-        # the reference's loss object, untouched)
-        import os
-        if (str(self.device).startswith("cuda") and _fusable_ns_loss(self.loss)
-                and os.environ.get("KGE_NS_FUSED_LOSS", "1") != "0"):
+        # the bce family of losses on a GPU: loss + gradient of a slot's score block in one kernel
+        # (hip_negative_sampling.fused_loss: false = the reference's loss object, untouched)
+        try:
+            fused_loss = bool(config.get("hip_negative_sampling.fused_loss"))
+        except KeyError:
+            fused_loss = True
+        if str(self.device).startswith("cuda") and _fusable_ns_loss(self.loss) and fused_loss:
             self.loss = _HipNsBceLoss(self.loss)
         self._graph_step = None       # kge_amd.train_graph.GraphedStep (hip_negative_sampling.graph_step)
         self._graph_step_ok = None    # decided at the first batch

@@ -33,7 +33,6 @@ all-reduce).  Optimizer state follows the rows: every rank steps its own shard.
 """
 from typing import Optional
 
-import os
 
 import torch
 import torch.distributed as dist
@@ -365,16 +364,22 @@ class _ShardedNeg(torch.autograd.Function):
 
 
 class ShardedEntityTable:
+    # measurement / test settings, class attributes (until round 6 the environment variables
+    # KGE_SHARDED_FORCE_COLLECTIVES and KGE_EVAL_TWO_STEP): FORCE_COLLECTIVES = a one-rank process group still issues
+    # every collective; TWO_STEP = rank_batch_multi never counts inside the scoring kernel
+    FORCE_COLLECTIVES = False
+    TWO_STEP = False
+
     def __init__(self, scorer: str, ent_local: torch.Tensor, rel: torch.Tensor, num_entities: int,
                  l_norm: float = 1.0, group=None, backend=None, force_collectives: bool = False):
         self.scorer, self.l_norm = scorer, float(l_norm)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        # With one rank every exchange step is an identity and is skipped -- unless `force_collectives` (or
-        # KGE_SHARDED_FORCE_COLLECTIVES=1): then a one-rank process group still runs every all-gather /
+        # With one rank every exchange step is an identity and is skipped -- unless `force_collectives` (or the class
+        # attribute FORCE_COLLECTIVES): then a one-rank process group still runs every all-gather /
         # all-reduce, so that a single-GPU box exercises the RCCL calls of the N > 1 path (tests, bench).
-        force = force_collectives or os.environ.get("KGE_SHARDED_FORCE_COLLECTIVES") == "1"
+        force = force_collectives or self.FORCE_COLLECTIVES
         self.collectives = self.world > 1 or (force and dist.is_initialized())
         self.E = int(num_entities)
         self.shard = (self.E + self.world - 1) // self.world
@@ -391,8 +396,8 @@ class ShardedEntityTable:
         self._bufs, self._tcache = {}, {}
         self._lane = 0  # exchange buffers are per lane (ShardedScoreLanes: several batches in flight)
         # rank_batch_multi counts inside the scoring kernel where the backend offers it (no score slabs);
-        # False / KGE_EVAL_TWO_STEP=1: score slabs + rank_counts_multi
-        self.fused_rank = os.environ.get("KGE_EVAL_TWO_STEP", "0") != "1"
+        # False (TWO_STEP): score slabs + rank_counts_multi
+        self.fused_rank = not self.TWO_STEP
 
     @staticmethod
     def check_partition(num_entities: int, world: int):
@@ -727,6 +732,8 @@ class ShardedScoreLanes:
             if len(pending) == 2: lanes.join(); consume(pending); pending = []; lanes.fork()
     """
 
+    GRAPH = None  # None: the default below; True / False (tests)
+
     def __init__(self, table: ShardedEntityTable, lanes: int = 2, graph: Optional[bool] = None):
         self.table = table
         self.L = max(1, int(lanes))
@@ -736,16 +743,16 @@ class ShardedScoreLanes:
         self.k = 0
         self._out = []
         if graph is None:
-            # default: ON for a single rank, OPT-IN (KGE_SHARDED_GRAPH=1) for world > 1 -- the capture of a step that
+            # default: ON for a single rank, OPT-IN (ShardedScoreLanes.GRAPH = True) for world > 1 -- the capture of a step that
             # contains a multi-GPU RCCL all-gather has run on ONE rank only in the build loop --, OFF with
-            # KGE_SHARDED_GRAPH=0.  Either way behind a self-check in two votes (see _issue): every rank first says
+            # GRAPH = False.  Either way behind a self-check in two votes (see _issue): every rank first says
             # whether its capture went through, BEFORE anything that holds a collective is replayed; only if all did
             # is the capture replayed once and compared bit for bit with the step issued call by call, and the ranks
             # vote again.  A capture that throws, differs or is voted down anywhere turns the feature off on all ranks
             # -- loudly (warnings.warn + `graph_error`) --, the step going call by call from then on.
-            want = os.environ.get("KGE_SHARDED_GRAPH")
+            want = self.GRAPH
             multi = bool(table.collectives) and table.world > 1
-            graph = (want != "0") if want is not None else (not multi)
+            graph = bool(want) if want is not None else (not multi)
             if graph and table.collectives:
                 try:
                     graph = dist.get_backend(table.group) == "nccl"

@@ -323,7 +323,9 @@ def test_c2_fused_counting_equals_the_reference_job_on_the_same_bf16_scores(data
     state = {"_entity_embedder._embeddings.weight": torch.randn(E, d, device=DEVICE) * 0.3,
              "_relation_embedder._embeddings.weight": torch.randn(R, d, device=DEVICE) * 0.3}
     bf = {f"hip_{model}.score_dtype": "bfloat16"}
-    single = dict(bf, **{"hip_entity_ranking.bf16_queries": "single"})  # (the default, "split", is test_c3's)
+    # both jobs on single rounded query vectors (the defaults -- split queries on both sides -- are test_c3's / c4's)
+    single = dict(bf, **{"hip_entity_ranking.bf16_queries": "single"})
+    bf_single = dict(bf, **{f"hip_{model}.no_grad_queries": "single"})
     calls = {"n": 0}
     orig = engine.score_rank_sp_po
 
@@ -336,7 +338,7 @@ def test_c2_fused_counting_equals_the_reference_job_on_the_same_bf16_scores(data
     engine.score_rank_sp_po = counting
     try:
         for chunk in (-1, 5000):
-            j1, ex_1, m_1 = _eval(root, folder, f"c2_mid_{model}", "hip_" + model, "entity_ranking", state, chunk, opts=bf)
+            j1, ex_1, m_1 = _eval(root, folder, f"c2_mid_{model}", "hip_" + model, "entity_ranking", state, chunk, opts=bf_single)
             assert calls["n"] == 0
             j2, ex_2, m_2 = _eval(root, folder, f"c2_hip_{model}", "hip_" + model, "hip_entity_ranking", state, chunk,
                                   opts=single)
@@ -393,6 +395,58 @@ def test_c3_split_queries_are_the_default_of_bf16_evaluation(data, model):
             assert flips <= 0.02 * len(ex_hip) and dm <= 1e-5
     finally:
         engine.score_rank_sp_po = orig
+
+
+@pytest.mark.parametrize("model", ["complex", "distmult"])
+def test_c4_the_reference_job_over_a_hip_model_keeps_the_ranks(data, model):
+    """The drop-in a user makes first: ONLY the model's name changes (`hip_complex`, `score_dtype: bfloat16`), the job
+    stays the reference's own `eval.type: entity_ranking` (kge/job/eval_entity_ranking.py:143-229).  That job scores
+    under torch.no_grad() through score_sp_po(s, p, o, torch.arange(chunk_start, chunk_end)) and score_sp / score_po
+    against the batch's unique answers.  Round 6: (i) those calls carry split queries (`no_grad_queries: split`) -- the
+    ranks of float32 arithmetic on the bf16 tables, as `hip_entity_ranking` counts them; with `single` the same job
+    moves percent of the ranks --, (ii) the arange is recognised as a contiguous chunk of the table and scored by the
+    all-entities kernels (no listed-target launch, no f32 chain)."""
+    from kge_amd import engine
+    root, folder = data
+    torch.manual_seed(7)
+    d = 512
+    ent = (torch.randn(E, d, device=DEVICE) * 0.3).bfloat16().float()
+    rel = (torch.randn(R, d, device=DEVICE) * 0.3).bfloat16().float()
+    state = {"_entity_embedder._embeddings.weight": ent, "_relation_embedder._embeddings.weight": rel}
+    bf = {f"hip_{model}.score_dtype": "bfloat16"}
+    seen = {"targets": [], "flags": set()}
+    orig = engine.score_sp_po
+
+    def spy(t, s, p, o, entity_subset=None, flags=None):
+        seen["targets"].append(type(entity_subset).__name__ if entity_subset is not None else "all")
+        seen["flags"].add(flags)
+        return orig(t, s, p, o, entity_subset, flags=flags)
+
+    engine.score_sp_po = spy
+    try:
+        for chunk in (-1, 2000):
+            _, ex_ref, m_ref = _eval(root, folder, f"c4_ref_{model}", model, "entity_ranking", state, chunk)
+            seen["targets"], seen["flags"] = [], set()
+            _, ex_two, m_two = _eval(root, folder, f"c4_two_{model}", "hip_" + model, "entity_ranking", state, chunk, opts=bf)
+            # (a last chunk below the model's RANGE_MIN = 1,024 entities stays a listed subset)
+            want = {"all"} if chunk < 0 else {"range", "Tensor"}
+            assert seen["targets"] and set(seen["targets"]) <= want and seen["targets"][0] != "Tensor", \
+                (chunk, set(seen["targets"]))
+            assert all(f is not None and f & engine.FLAG_SPLIT_QUERY for f in seen["flags"]), seen["flags"]
+            _, ex_hip, m_hip = _eval(root, folder, f"c4_hip_{model}", "hip_" + model, "hip_entity_ranking", state, chunk, opts=bf)
+            flips_ref = sum(a != b for a, b in zip(ex_ref, ex_two))
+            flips_hip = sum(a != b for a, b in zip(ex_hip, ex_two))
+            dm = max(abs(m_ref[k] - m_two[k]) for k in m_ref if k.startswith("mean_reciprocal_rank"))
+            _, ex_one, m_one = _eval(root, folder, f"c4_one_{model}", "hip_" + model, "entity_ranking", state, chunk,
+                                     opts=dict(bf, **{f"hip_{model}.no_grad_queries": "single"}))
+            flips_one = sum(a != b for a, b in zip(ex_ref, ex_one))
+            _log(case=f"c4: eval.type entity_ranking (the reference's job) over hip_{model} bf16, chunk {chunk}",
+                 examples=len(ex_two), differing_from_reference_model=flips_ref, differing_from_hip_entity_ranking=flips_hip,
+                 differing_with_single_queries=flips_one, abs_mrr_diff=dm)
+            assert flips_hip == 0, "two-step scores and the counting kernel disagree on split queries"
+            assert flips_ref <= 0.02 * len(ex_two) and dm <= 1e-5
+    finally:
+        engine.score_sp_po = orig
 
 
 def test_d_reciprocal_relations_model_over_hip_distmult(data):
@@ -604,7 +658,7 @@ def test_i_subbatch_auto_tune_fires_on_rocm(data):
 def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case):
     """train.type: hip_sharded_* + eval.type: hip_sharded_entity_ranking through TrainingJob.create / EvaluationJob.create
     of an unmodified LibKGE on the MI355X, as ONE rank of an RCCL group (torchrun's environment for a world of one,
-    KGE_SHARDED_FORCE_COLLECTIVES=1: every all-gather / all-reduce of the N > 1 path is issued) with the engine's
+    ShardedEntityTable.FORCE_COLLECTIVES: every all-gather / all-reduce of the N > 1 path is issued) with the engine's
     kernels -- against the unsharded hip_* job of the same config.  (Two ranks: tests/test_libkge_sharded_plugin_cpu.py
     on gloo; the driver's box has one GPU.)"""
     if DEVICE == "cpu":
@@ -616,8 +670,10 @@ def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", str(port)), ("RANK", "0"), ("WORLD_SIZE", "1"),
-                 ("LOCAL_RANK", "0"), ("KGE_SHARDED_FORCE_COLLECTIVES", "1")):
+                 ("LOCAL_RANK", "0")):
         monkeypatch.setenv(k, v)
+    from kge_amd.sharded import ShardedEntityTable
+    monkeypatch.setattr(ShardedEntityTable, "FORCE_COLLECTIVES", True)
     if case == "negative_sampling":
         model, dim, plain = "hip_rotate", 128, "hip_negative_sampling"
         opts = {"negative_sampling.num_samples.s": 64, "negative_sampling.num_samples.o": 64,

@@ -171,10 +171,11 @@ def test_score_neg_blocks_is_the_composed_calls_in_one_node(name, l_norm):
 def test_score_neg_backward_sorted_by_entity(name, l_norm, d, monkeypatch):
     """kge_score_neg_bwd_accum_sorted (round 5): the occurrences sorted by the entity they corrupt, an entity's gradient
     row summed in registers over a run of equal ids and flushed once -- instead of one float atomic per element and
-    occurrence.  Forced on (KGE_NEG_BWD_SORTED=1) at shapes with many occurrences per entity, runs longer than a wave's
+    occurrence.  Forced on (engine.NEG_BWD_SORTED = True) at shapes with many occurrences per entity, runs longer than a wave's
     chunk of 32, chunks that start and end inside a run, int32 / int64 samples, both slots: both table gradients against
     torch autograd through the reference's op sequence on the expanded triples (BatchNegativeSample.score "triple",
     kge/util/sampler.py:291-306) at the bar of the atomic kernel's test, and against the atomic kernel itself."""
+    from kge_amd import engine as _engine
     E, R, n, K = 23, 3, 37, 131   # 4,847 occurrences over 23 entities: runs of ~210
     m = _model(name, E, R, d, l_norm=l_norm).train()
     ent0 = m.get_s_embedder().weight.detach().cpu().clone()
@@ -192,7 +193,7 @@ def test_score_neg_backward_sorted_by_entity(name, l_norm, d, monkeypatch):
         (ref * w).sum().backward()
         grads = {}
         for mode in ("1", "0"):
-            monkeypatch.setenv("KGE_NEG_BWD_SORTED", mode)
+            monkeypatch.setattr(_engine, "NEG_BWD_SORTED", mode == "1")
             m.zero_grad()
             got = m.score_neg(s.to(DEV), p.to(DEV), o.to(DEV), slot, neg.to(DEV).to(idt))
             (got * w.to(DEV)).sum().backward()
@@ -204,7 +205,7 @@ def test_score_neg_backward_sorted_by_entity(name, l_norm, d, monkeypatch):
         for a, b, nm in ((grads["1"][0], grads["0"][0], "entity"), (grads["1"][1], grads["0"][1], "relation")):
             scale = max(1.0, float(b.abs().max()))
             assert float((a - b).abs().max()) <= 5e-5 * scale, (name, l_norm, slot, nm)
-    monkeypatch.delenv("KGE_NEG_BWD_SORTED")
+    monkeypatch.setattr(_engine, "NEG_BWD_SORTED", None)
     from kge_amd import engine
     assert engine._neg_bwd_sorted(512, 1000, 40943) and not engine._neg_bwd_sorted(512, 100, 14541)
 

@@ -539,3 +539,38 @@ def test_one_call_entry_with_many_rows_takes_the_persistent_kernel(eng, scorer, 
     eng.score_sp_po(T, s[:1000], p[:1000], o[:1000])
     torch.cuda.synchronize()
     assert _v8_launches() == before
+
+
+@pytest.mark.parametrize("case", [
+    ("complex", 512, torch.bfloat16, 0), ("complex", 512, torch.bfloat16, "split"), ("distmult", 256, torch.bfloat16, "split"),
+    ("distmult", 256, torch.bfloat16, 0), ("complex", 128, torch.bfloat16, 0), ("complex", 64, torch.float32, 0),
+    ("transe", 100, torch.float32, 0), ("rotate", 64, torch.float32, 0)])
+@pytest.mark.parametrize("n", [37, 512, 1500])
+def test_a_range_of_targets_is_scored_on_the_table_rows_themselves(eng, case, n):
+    """`targets` = a Python range (kge_index.start, include/kge_amd.h): the entity chunk the reference's EntityRankingJob
+    hands over as torch.arange(chunk_start, chunk_end) (kge/job/eval_entity_ranking.py:216-229) -- rows [start, stop) of
+    the table streamed without an index, by the kernels an all-entities call takes (n = 1500 at d = 512 / 256: batches of
+    the persistent kernel).  Equal to the same columns of the all-entities call bit for bit and to the listed subset
+    torch.arange gives; one- and two-sided; a range that is the whole table; bad ranges are refused."""
+    scorer, d, dt, split = case
+    E, R = 3001, 9
+    g = torch.Generator().manual_seed(d + n)
+    ent = (torch.randn(E, d, generator=g) * 0.3).to(dt).to(DEV)
+    rel = (torch.randn(R, d // 2 if scorer == "rotate" else d, generator=g) * 0.3).to(dt).to(DEV)
+    fl = eng.FLAG_SPLIT_QUERY if split else 0
+    T = eng.Tables(scorer, ent, rel, 1.0, fl)
+    s, p, o = _batch(E, R, n, seed=5)
+    full_sp, full_po, full2 = eng.score_sp(T, s, p), eng.score_po(T, p, o), eng.score_sp_po(T, s, p, o)
+    for lo, hi in ((0, E), (0, 1000), (1000, 2000), (2999, 3001), (17, 2931)):
+        r = range(lo, hi)
+        _same(eng.score_sp(T, s, p, r), full_sp[:, lo:hi], f"score_sp {case} range {lo}:{hi}")
+        _same(eng.score_po(T, p, o, r), full_po[:, lo:hi], f"score_po {case} range {lo}:{hi}")
+        both = eng.score_sp_po(T, s, p, o, r)
+        _same(both[:, :hi - lo], full2[:, lo:hi], f"score_sp_po sp block {case} range {lo}:{hi}")
+        _same(both[:, hi - lo:], full2[:, E + lo:E + hi], f"score_sp_po po block {case} range {lo}:{hi}")
+    if not split:   # (a LISTED subset under split queries runs the f32 chain: float32-level, not the same bits)
+        lst = torch.arange(1000, 2000, device=DEV)
+        _same(eng.score_sp(T, s, p, lst), full_sp[:, 1000:2000], f"listed arange {case}")
+    for bad in (range(0, E + 1), range(5, 3), range(0, 10, 2)):
+        with pytest.raises(ValueError):
+            eng.score_sp(T, s, p, bad)

@@ -239,7 +239,8 @@ def test_evaluator_with_fused_counting_equals_the_two_step_evaluator(model, E, d
                        (torch.randn(R, d // 2 if model == "rotate" else d, generator=g) * 0.3).to(DEV), 1.0)
     calls = {"fused": 0}
     orig, orig_batch = eng.score_rank_sp_po, eng.eval_batch
-    monkeypatch.setenv("KGE_EVAL_FUSED_EXACT", "1")  # float32 tables: by default only from 1 GiB of score matrix on
+    # float32 tables: by default only from 1 GiB of score matrix on
+    monkeypatch.setitem(EntityRankingEvaluator.OPTIONS, "fused_exact", True)
 
     def counting(*a, **k):
         calls["fused"] += 1

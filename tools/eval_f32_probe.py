@@ -8,6 +8,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from kge_amd import engine, eval as kev
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _eval_env  # KGE_EVAL_* variables -> EntityRankingEvaluator.OPTIONS
+_eval_env.apply()
 from kge_amd.synthetic import make_splits
 dev = torch.device("cuda", 0)
 E, R, d, bs = 14541, 237, 512, 512

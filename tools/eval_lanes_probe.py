@@ -5,6 +5,7 @@ sys.path.insert(0, ".")
 import bench
 from kge_amd import engine
 for L in ("1", "2", "3"):
-    os.environ["KGE_EVAL_LANES"] = L
+    from kge_amd.eval import EntityRankingEvaluator
+    EntityRankingEvaluator.OPTIONS["lanes"] = int(L)
     r = bench.eval_leg(engine, torch.device("cuda:0"))
     print(L, {k: (round(v["ms_per_batch"], 4), v["graph_batches"], round(v["mrr_filtered"], 8)) for k, v in r.items() if isinstance(v, dict)}, flush=True)
