@@ -835,6 +835,15 @@ class ShardedScoreLanes:
 
         err = None
         g = cap = None
+        if tb.collectives:
+            # Collectives issued so far (the warm-up call above) must be complete AND seen complete by ProcessGroupNCCL's
+            # watchdog thread before the streams their end events were recorded on start capturing: HIP refuses
+            # hipEventQuery on an event "last recorded in a capturing stream" also when it was recorded BEFORE the
+            # capture began, and the watchdog's exception aborts the process (a fast box in round 6 lost that race:
+            # profiles/r6_bench_dist1rank_watchdog_abort.txt).  The watchdog polls every 100 ms; captures are rare.
+            import time
+            torch.cuda.synchronize()
+            time.sleep(0.35)
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
