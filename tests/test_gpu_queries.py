@@ -401,6 +401,8 @@ def test_persistent_kernel_on_single_batches(eng, E, n, split, monkeypatch, kge_
     ("distmult", 14541, 512, 200, False),
     ("complex", 14541, 512, 300, True),    # split queries through the same block offsets
     ("complex", 3000, 256, 130, False),    # the loader / consumer kernel
+    ("complex", 14541, 512, 1500, False),  # many dense rows: batches of the persistent kernel + the 476 rows left (round 6)
+    ("distmult", 3001, 256, 1100, True),   # ... at d = 256 with split queries
     ("distmult", 777, 128, 70, False),
     ("transe", 1000, 128, 70, False),      # float32 tables: one exact launch per direction
 ])
