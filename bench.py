@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="N = 1: do not spawn the two rocprofv3 --pmc passes that measure `roofline.traffic` live "
+                         "(report the committed passes instead; runs that are themselves under rocprofv3 skip them anyway)")
     ap.add_argument("--no-one-sided", action="store_true",
                     help="skip the reference region of one-sided launches (profiling runs: the kernel "
                          "trace then holds two-sided launches only)")
@@ -96,6 +99,86 @@ def pmc_traffic(mode, group):
         return d[mode]["hbm_bytes_per_launch"] if d.get("group") == group else None
     except Exception:
         return None
+
+
+_PMC_LIVE = {}
+
+
+def pmc_traffic_live(group, timeout_s=150):
+    """HBM bytes per GROUP launch of the dominant kernel, both query modes, from counters collected BY THIS RUN: two
+    separate `rocprofv3 --pmc <counter>` passes (FETCH_SIZE, then WRITE_SIZE; counters only, no trace domain) over
+    tools/v8_pmc_target.py -- 12 launches per query mode of exactly the launch the timed region issues -- spawned as
+    child processes on the same GPU after the timed regions.  Units and corrections as MI355X_MICROARCH.md's HBM /
+    rocprofv3 section prescribes: both counters in KiB, gfx950's FETCH_SIZE counts 128-byte requests as 64 bytes (x 2);
+    per launch = the median over the dispatches behind the first two.  {} when rocprofv3 is not on the PATH, a pass
+    fails or takes longer than `timeout_s` (the caller then reports the committed passes and says so)."""
+    if _PMC_LIVE.get("group") == group:
+        return _PMC_LIVE
+    import glob
+    import shutil
+    import sqlite3
+    import statistics
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return {}
+    res = {}
+    work = tempfile.mkdtemp(prefix="kge_pmc_", dir="/tmp")
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            env = dict(os.environ, TMPDIR="/tmp", GROUP=str(group))
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            t0 = time.time()
+            r = subprocess.run([rp, "--pmc", c, "-d", os.path.join(work, c), "-o", "v8", "--", sys.executable,
+                                os.path.join(ROOT, "tools", "v8_pmc_target.py")], cwd="/tmp", env=env, timeout=timeout_s,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            dbs = glob.glob(os.path.join(work, c, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return {}
+            per = {}
+            con = sqlite3.connect(dbs[0])
+            for name, v in con.execute("select kernel_name, value from counters_collection where counter_name=?", (c,)):
+                per.setdefault(name, []).append(v)
+            con.close()
+            res[c] = per
+            res[c + "_seconds"] = time.time() - t0
+        out = {"group": group, "seconds": res["FETCH_SIZE_seconds"] + res["WRITE_SIZE_seconds"]}
+        for mode, split in (("parity", 1), ("training", 0)):
+            vals = {}
+            for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+                ks = [k for k in res[c] if ("pairs_bf16_v8_kernel<0, %d," % split) in k.replace("(int)", "")]
+                if not ks:
+                    return {}
+                v = res[c][ks[0]]
+                vals[c] = statistics.median(v[2:] if len(v) > 4 else v) * 1024.0 * mul
+                vals[c + "_dispatches"] = len(v)
+            out[mode] = {"hbm_bytes_per_launch": vals["FETCH_SIZE"] + vals["WRITE_SIZE"],
+                         "fetch_bytes_corrected": vals["FETCH_SIZE"], "write_bytes": vals["WRITE_SIZE"],
+                         "dispatches": vals["FETCH_SIZE_dispatches"]}
+        _PMC_LIVE.clear()
+        _PMC_LIVE.update(out)
+        return out
+    except Exception:  # a counter pass must never take the bench line down
+        return {}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def traffic_of(mode, group, live):
+    """(`traffic`, `traffic_source`, detail) of the roofline object of query mode `mode`."""
+    if live and mode in live:
+        d = live[mode]
+        return d["hbm_bytes_per_launch"], (
+            "live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate child processes of this run, after the "
+            "timed regions) over tools/v8_pmc_target.py = 12 launches of this group launch per query mode; KiB, FETCH_SIZE "
+            "x 2 (gfx950), median per dispatch behind the first two"), {
+                "fetch_bytes_corrected": d["fetch_bytes_corrected"], "write_bytes": d["write_bytes"],
+                "dispatches": d["dispatches"], "passes_seconds": live.get("seconds")}
+    return pmc_traffic(mode, group), ("profiles/pmc_latest.json (COMMITTED passes of tools/gpu_r6prof.sh over the same group "
+                                      "launch on the builder's box: no live counter pass in this run -- rocprofv3 absent, "
+                                      "--no-pmc, or a pass failed)"), None
 
 
 def algorithmic_bytes(n, m, d, elt=2, sides=1):
@@ -1338,6 +1421,11 @@ def main():
 
     rp = res["parity"]
     rt = res["training"]
+    # roofline.traffic, measured by this run where it can be: two rocprofv3 --pmc child passes (pmc_traffic_live).  Not
+    # when this process is itself being profiled (its own kernel trace would then hold the children's launches too).
+    profiled = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ)
+    live = {} if (a.no_pmc or profiled) else pmc_traffic_live(L)
+    tr_par, tr_trn = traffic_of("parity", L, live), traffic_of("training", L, live)
     out = {
         "metric": "scored triples/sec (1vsAll, ComplEx d=512)",
         "value": total / rp["el"],
@@ -1382,10 +1470,9 @@ def main():
         "roofline": {**roofline_of("parity", "pairs_bf16_v8_kernel<ComplEx, SPLIT> (kge_score_queries_multi: one "
                                              "persistent launch = `group` two-sided batches, split queries: twice the "
                                              "matrix-core work per score)"),
-                     "traffic": pmc_traffic("parity", L),
+                     "traffic": tr_par[0],
                      # what in this object is measured in THIS run and what is a committed constant
-                     "traffic_source": "profiles/pmc_latest.json (committed: rocprofv3 --pmc passes of tools/gpu_r4prof.sh over "
-                                       "the same group launch on the builder's box; bench.py cannot collect counters)",
+                     "traffic_source": tr_par[1], "traffic_detail": tr_par[2],
                      "achieved_source": "live: HIP events around back-to-back group launches in this run",
                      "timed_region": {"us_per_step": rp["el"] / a.steps * 1e6,
                                       "frac": ab / (rp["el"] / a.steps) / 1e9 / HBM_PEAK_GBS}},
@@ -1399,8 +1486,7 @@ def main():
             "host_issue_ms_per_step": rt["host"] / a.steps * 1e3, "group_launches_in_flight": rt["lanes"],
             "roofline": {**roofline_of("training", "pairs_bf16_v8_kernel<ComplEx> (kge_score_queries_multi: one "
                                                    "persistent launch = `group` two-sided batches, single-pass queries)"),
-                         "traffic": pmc_traffic("training", L),
-                         "traffic_source": "profiles/pmc_latest.json (committed constant, as above)",
+                         "traffic": tr_trn[0], "traffic_source": tr_trn[1], "traffic_detail": tr_trn[2],
                          "timed_region": {"us_per_step": rt["el"] / a.steps * 1e6,
                                           "frac": ab / (rt["el"] / a.steps) / 1e9 / HBM_PEAK_GBS}}},
         **extra,

@@ -102,10 +102,11 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
 
 
-def test_bench_traffic_comes_from_the_committed_counter_passes():
-    """bench.py cannot collect PMC counters itself: `roofline.traffic` is read from profiles/pmc_latest.json, the
-    summary of the committed rocprofv3 --pmc passes over the SAME group launch (tools/gpu_r4prof.sh) -- per query mode,
-    and only for the group size the passes were taken at."""
+def test_bench_traffic_falls_back_to_the_committed_counter_passes():
+    """`roofline.traffic`: bench.py spawns two rocprofv3 --pmc passes itself (pmc_traffic_live: round 6) and says so in
+    `traffic_source`; where it cannot (no rocprofv3, --no-pmc, a failed pass) the figure is read from
+    profiles/pmc_latest.json, the summary of the committed passes over the SAME group launch -- per query mode, only
+    for the group size the passes were taken at, and labelled COMMITTED."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
@@ -121,6 +122,15 @@ def test_bench_traffic_comes_from_the_committed_counter_passes():
         assert abs(d[mode]["fetch_bytes_corrected"] + d[mode]["write_bytes"] - t) < 1.0
         assert bench.pmc_traffic(mode, g + 1) is None     # another group size: no figure rather than a wrong one
     assert os.path.exists(os.path.join(root, d["source"]))
+    # which of the two a line reports, it says
+    live = {"group": g, "seconds": 30.0, "parity": {"hbm_bytes_per_launch": 6.6e8, "fetch_bytes_corrected": 1.7e8,
+                                                     "write_bytes": 4.9e8, "dispatches": 12}}
+    t, src, detail = bench.traffic_of("parity", g, live)
+    assert t == 6.6e8 and src.startswith("live:") and detail["write_bytes"] == 4.9e8
+    t, src, detail = bench.traffic_of("training", g, live)        # a mode the live passes did not deliver
+    assert t == d["training"]["hbm_bytes_per_launch"] and "COMMITTED" in src and detail is None
+    t, src, _ = bench.traffic_of("parity", g, {})
+    assert t == d["parity"]["hbm_bytes_per_launch"] and "COMMITTED" in src
 
 
 def test_graphed_step_gate_refuses_step_count_dependent_optimizers():
