@@ -5,6 +5,7 @@ TAG=${1:-suite}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export KGE_PLUGIN_LOG=$OUT/plugin.jsonl
 timeout 3000 python -m pytest tests -m gpu -q --timeout=1200 ${2:-} > $OUT/pytest_gpu.log 2>&1
 echo "pytest gpu exit: $?" > $OUT/env.log
 tail -n 25 $OUT/pytest_gpu.log
