@@ -199,6 +199,8 @@ class _FusedScoring:
         if subset is None or not torch.is_tensor(subset) or subset.dim() != 1 or subset.numel() < self.RANGE_MIN \
                 or subset.dtype not in (torch.int32, torch.int64):
             return subset
+        if subset.is_cuda and torch.cuda.is_current_stream_capturing():
+            return subset  # (no host read inside a capture: the listed-subset kernels)
         m = subset.numel()
         ok = ((subset[-1] - subset[0]) == m - 1) & (subset[1:] > subset[:-1]).all()
         ok, first = torch.stack((ok.to(torch.int64), subset[0].to(torch.int64))).tolist()

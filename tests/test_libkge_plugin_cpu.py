@@ -439,3 +439,31 @@ def test_ns_bce_stand_in_hands_everything_it_does_not_recognise_to_the_reference
         assert torch.equal(ref(scores, idx), w(scores, idx))
     weighted = BCEWithLogitsKgeLoss(config, offset=0.0, bce_type=bce_type, pos_weight=torch.tensor(2.0), **kw)
     assert not _fusable_ns_loss(weighted)
+
+
+def test_an_arange_subset_is_recognised_as_a_range_of_the_table():
+    """_FusedScoring._targets (round 6): the reference's EntityRankingJob hands an entity chunk over as
+    torch.arange(chunk_start, chunk_end) (kge/job/eval_entity_ranking.py:216-229) -- recognised (one reduction, one host
+    read) it becomes None (the whole table) or a Python range (kge_index.start: the all-entities kernels on those rows);
+    anything else stays the listed subset it is."""
+    rh.import_reference()
+    import types
+    from kge_amd.libkge_plugin.models import _FusedScoring
+    E = 5000
+    stub = types.SimpleNamespace(RANGE_MIN=_FusedScoring.RANGE_MIN, _w=lambda: (torch.zeros(E, 4), torch.zeros(3, 4)))
+    t = lambda x: _FusedScoring._targets(stub, x)
+    assert t(None) is None
+    assert t(torch.arange(0, E)) is None
+    assert t(torch.arange(0, E, dtype=torch.int32)) is None
+    assert t(torch.arange(1000, 3000)) == range(1000, 3000)
+    assert t(torch.arange(E - 1024, E)) == range(E - 1024, E)
+    for keep in (torch.arange(10, 500),                                    # short: not worth a host read
+                 torch.arange(0, 4000, 2),                                 # a stride
+                 torch.arange(2000, 0, -1),                                # descending
+                 torch.cat((torch.arange(0, 1500), torch.arange(1501, 3002))),   # one id missing: last - first != len - 1
+                 torch.cat((torch.arange(0, 1500), torch.tensor([1499]), torch.arange(1500, 2999))),  # a duplicate
+                 torch.arange(E - 1000, E + 500),                          # beyond the table
+                 torch.arange(0, 2048).view(2, 1024)):                     # not a vector
+        assert t(keep) is keep
+    perm = torch.randperm(E)
+    assert t(perm) is perm
