@@ -176,6 +176,8 @@ def test_c5_shard_full_size(eng):
         ids = torch.arange(lo, hi, device=DEV)
         part = eng.score_sp(T, s, p, ids)
         _eq(f"columns [{lo},{hi})", _np(part), _np(slab[:, lo:hi]))
+        # the same chunk as a RANGE of the table (kge_index.start: the all-entities kernels, no index read)
+        assert torch.equal(eng.score_sp(T, s, p, range(lo, hi)), part), f"range({lo}, {hi})"
         r, t = eng.rank_counts(part, true)
         rank_sum += r
         ties_sum += t
@@ -194,3 +196,36 @@ def test_c5_shard_full_size(eng):
     close = (x == tt) | (np.abs(x - tt) <= 1e-5 + np.abs(1e-4 * tt))
     _eq("rank recount", _np(r)[rows], ((x > tt) & ~close).sum(1))
     _eq("ties recount", _np(t)[rows], close.sum(1))
+
+
+def test_c5_shard_full_size_groups_in_parity_mode(eng, kge_switch):
+    """C5 in parity mode (split queries) on the d = 256 persistent store kernel (round 6:
+    pairs_bf16_v8_ce_kernel<128, V3_STORE, ., SPLIT>): a group of two one-sided batches of 512 against the 574,311-row
+    shard -- 2 x 1.18 GB of scores from one launch -- equals one launch per batch on the single-batch split kernel bit for
+    bit; sampled elements against float32 arithmetic on the bf16 values (the oracle on the widened tables)."""
+    E, R, d, n, L = 574311, 822, 256, 512, 2
+    ent, rel, T = _tables(eng, "complex", E, R, d, dtype=torch.bfloat16)
+    fl = eng.FLAG_SPLIT_QUERY
+    Ts = eng.Tables("complex", T.ent, T.rel, flags=fl)
+    g = torch.Generator().manual_seed(77)
+    tri = torch.stack([torch.randint(hi, (n * L,), generator=g) for hi in (E, R, E)], 1).to(DEV)
+    P = eng.score_pitch(E)
+    out = torch.empty(L, n, P, device=DEV)
+    q = eng.build_queries_group(Ts, "sp_", tri, n, L, flags=fl)
+    eng.score_queries_group(Ts, q, out[:, :, :E])
+    torch.cuda.synchronize()
+    kge_switch.set("V8", "0")   # one launch per batch on the single-batch kernels
+    for l in range(L):
+        t = tri[l * n:(l + 1) * n]
+        one = eng.score_queries(Ts, eng.build_queries(Ts, "sp_", t[:, 0], t[:, 1], None, flags=fl))
+        assert torch.equal(out[l, :, :E], one), f"batch {l}"
+        del one
+    kge_switch.unset("V8")
+    Of = ko.Tables("complex", ent.float().numpy(), rel.float().numpy(), 1.0)   # the bf16 values, widened exactly
+    rows = np.array([0, 300, 511])
+    cols = np.concatenate([np.arange(0, 40), np.arange(E - 40, E), np.array([123456, 300000])])
+    t1 = tri[n:2 * n].cpu().numpy()
+    want = ko.score_sp(Of, t1[rows, 0], t1[rows, 1], cols).astype(np.float64)
+    got = out[1, :, :E].cpu().numpy()[np.ix_(rows, cols)].astype(np.float64)
+    big = max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= 4e-6 * big   # float32 summation noise, far inside one rounded query vector's 2^-9
