@@ -4,6 +4,7 @@ Usage inside an unmodified LibKGE installation (config-default.yaml:137, README.
 
     modules: [kge.job, kge.model, kge.model.embedder, kge_amd.libkge_plugin]
     model: hip_complex            # or hip_distmult / hip_transe / hip_rotate
+    #   (or model: hip_reciprocal_relations_model with hip_reciprocal_relations_model.base_model.type: hip_complex)
     # optional: eval.type: hip_entity_ranking
     # optional: train.type: hip_1vsAll / hip_KvsAll  (kl / bce loss fused into the scoring kernel)
     #           train.type: hip_negative_sampling  (negatives through the fused gather + score kernel)
@@ -29,7 +30,7 @@ except ImportError as e:  # pragma: no cover
     raise ImportError("kge_amd.libkge_plugin needs LibKGE (`kge`) to be importable") from e
 
 from .models import (HipComplEx, HipComplExScorer, HipDistMult, HipDistMultScorer,  # noqa: F401
-                     HipRotatE, HipRotatEScorer, HipTransE, HipTransEScorer)
+                     HipReciprocalRelationsModel, HipRotatE, HipRotatEScorer, HipTransE, HipTransEScorer)
 from .eval_job import HipEntityRankingJob  # noqa: F401
 from .train_job import (HipTrainingJob1vsAll, HipTrainingJobKvsAll,  # noqa: F401
                         HipTrainingJobNegativeSampling)

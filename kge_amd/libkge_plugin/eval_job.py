@@ -231,10 +231,12 @@ class HipEntityRankingJob(EntityRankingJob):
                     continue
                 # declined: the two-step path from here on (o_true / s_true stay)
                 ft = ev["fused_tables"] = fused_tables = None
-            sub = None if c == E else torch.arange(chunk_start, chunk_end, device=dev)
             if split_tables is not None:
-                scores = engine.score_sp_po(split_tables(), s, p, o, sub, flags=engine.FLAG_SPLIT_QUERY)
+                # (the chunk as a RANGE of the table -- kge_index.start --: the all-entities kernels, not a listed subset)
+                scores = engine.score_sp_po(split_tables(), s, p, o, None if c == E else range(chunk_start, chunk_end),
+                                            flags=engine.FLAG_SPLIT_QUERY)
             else:
+                sub = None if c == E else torch.arange(chunk_start, chunk_end, device=dev)
                 scores = self.model.score_sp_po(s, p, o, sub)
             scores_sp, scores_po = scores[:, :c], scores[:, c:]
             if o_true is None:

@@ -391,3 +391,82 @@ class HipRotatE(_FusedScoring, _RefRotatE):
             self.set_option("relation_embedder.dim", self.get_option("entity_embedder.dim") // 2, log=True)
         _init(self, HipRotatEScorer, config, dataset, self.configuration_key, init_for_load_only)
         self._normalize_phases = self.get_option("normalize_phases")
+
+
+from kge.model.reciprocal_relations_model import ReciprocalRelationsModel as _RefReciprocal  # noqa: E402
+
+
+class HipReciprocalRelationsModel(_RefReciprocal):
+    """`model: hip_reciprocal_relations_model` over a hip_* base model -- the reference's wrapper
+    (kge/model/reciprocal_relations_model.py: separate relation embeddings p and p + R for predicting objects and
+    subjects, used by most of LibKGE's tuned 1vsAll / KvsAll configurations) with its scoring routed to the base model's
+    fused INDEX-level calls.  The reference wrapper embeds the batch's rows and the whole entity table and calls
+    `scorer.score_emb` on the dense rows (reciprocal_relations_model.py:84-131) -- correct over a hip_* base too, through
+    the dense-row kernels and a full-table gather per call --; here
+        score_po(p, o, s)        = base.score_sp(o, p + R, s)                       (reciprocal_relations_model.py:84-91)
+        score_sp_po(s, p, o, E') = [base.score_sp(s, p, E') | base.score_sp(o, p + R, E')]          (:96-131)
+    and the fused-loss hooks of the hip_* training jobs (loss_sp / loss_po / loss_sp_po, kl_loss_*, bce_loss_*) exist with
+    the same translation: BOTH directions of a 1vsAll batch are sp_ queries of the base model -- rows (s, p | label o)
+    and (o, p + R | label s) -- so `loss_sp_po` is ONE fused one-sided launch over 2 n rows, and `train.type: hip_1vsAll`
+    (graph_step included) / `hip_KvsAll` run their fused paths on reciprocal models.  Where the base model's fused path
+    does not apply (job.device cpu, other embedders, dropout) every call is the reference wrapper's own code.
+    `eval.type: hip_entity_ranking` takes its two-step path (score_sp_po above + kge_rank_counts_multi): the counting
+    kernel's second side is a _po query of ONE relation table, which a reciprocal model does not have."""
+
+    def _R(self) -> int:
+        return self.dataset.num_relations()
+
+    def _base_fused(self) -> bool:
+        b = self._base_model
+        return isinstance(b, _FusedScoring) and b._fused()
+
+    # ---- scores
+    def score_sp(self, s: Tensor, p: Tensor, o: Tensor = None) -> Tensor:
+        if not self._base_fused():
+            return super().score_sp(s, p, o)
+        return self._base_model.score_sp(s, p, o)
+
+    def score_po(self, p: Tensor, o: Tensor, s: Tensor = None) -> Tensor:
+        if not self._base_fused():
+            return super().score_po(p, o, s)
+        return self._base_model.score_sp(o, p + self._R(), s)
+
+    def score_sp_po(self, s: Tensor, p: Tensor, o: Tensor, entity_subset: Tensor = None) -> Tensor:
+        if not self._base_fused():
+            return super().score_sp_po(s, p, o, entity_subset)
+        b = self._base_model
+        # (where no gradient is recorded: ONE range check for both calls -- a Python range passes through the base
+        # model's own check untouched)
+        sub = b._targets(entity_subset) if not torch.is_grad_enabled() else entity_subset
+        return torch.cat((b.score_sp(s, p, sub), b.score_sp(o, p + self._R(), sub)), dim=1)
+
+    # ---- the fused-loss hooks of HipTrainingJob1vsAll / HipTrainingJobKvsAll (train_job.py)
+    def _ce_tables(self):
+        f = getattr(self._base_model, "_ce_tables", None)
+        return f() if f is not None else None
+
+    def _dropout_only(self):
+        f = getattr(self._base_model, "_dropout_only", None)
+        return f() if f is not None else None
+
+    def loss_sp(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
+        return self._base_model.loss_sp(s, p, o)
+
+    def loss_po(self, p: Tensor, o: Tensor, s: Tensor) -> Tensor:
+        return self._base_model.loss_sp(o, p + self._R(), s)
+
+    def loss_sp_po(self, s: Tensor, p: Tensor, o: Tensor) -> Tensor:
+        """[2n] loss rows, the sp_ queries first: one fused launch over the 2 n sp_ queries of the base model."""
+        return self._base_model.loss_sp(torch.cat((s, o)), torch.cat((p, p + self._R())), torch.cat((o, s)))
+
+    def kl_loss_sp(self, s, p, lbl_rowptr, lbl_col, label_smoothing: float = 0.0):
+        return self._base_model.kl_loss_sp(s, p, lbl_rowptr, lbl_col, label_smoothing)
+
+    def kl_loss_po(self, p, o, lbl_rowptr, lbl_col, label_smoothing: float = 0.0):
+        return self._base_model.kl_loss_sp(o, p + self._R(), lbl_rowptr, lbl_col, label_smoothing)
+
+    def bce_loss_sp(self, s, p, lbl_rowptr, lbl_col, offset: float = 0.0, label_smoothing: float = 0.0):
+        return self._base_model.bce_loss_sp(s, p, lbl_rowptr, lbl_col, offset, label_smoothing)
+
+    def bce_loss_po(self, p, o, lbl_rowptr, lbl_col, offset: float = 0.0, label_smoothing: float = 0.0):
+        return self._base_model.bce_loss_sp(o, p + self._R(), lbl_rowptr, lbl_col, offset, label_smoothing)

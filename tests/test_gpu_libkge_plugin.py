@@ -397,6 +397,69 @@ def test_c3_split_queries_are_the_default_of_bf16_evaluation(data, model):
         engine.score_rank_sp_po = orig
 
 
+def test_d2_hip_reciprocal_relations_model_takes_the_fused_paths(data):
+    """`model: hip_reciprocal_relations_model` (round 6): the reference's reciprocal wrapper with score_po / score_sp_po
+    routed to the base model's fused index-level score_sp (relation p + R) and the fused-loss hooks of hip_1vsAll /
+    hip_KvsAll -- against `reciprocal_relations_model` over the reference's distmult: (i) float32 kernels under the
+    reference's own 1vsAll job, (ii) hip_1vsAll with bf16 scoring + HipAdagrad: ONE fused loss launch per batch over the
+    2 n sp_ queries, the step replayed as a hipGraph, (iii) hip_KvsAll (kl), (iv) both evaluation jobs on the trained
+    state; the reference wrapper's checkpoints load (same parameter names)."""
+    root, folder = data
+    rr, hrr = "reciprocal_relations_model", "hip_reciprocal_relations_model"
+    ref, l_ref, st = _train_epoch(root, folder, "d2_ref", (rr, "distmult"), dim=256)
+    hip, l_hip, _ = _train_epoch(root, folder, "d2_hip", (hrr, "hip_distmult"), dim=256, init_from=st)
+    assert type(hip.model).__name__ == "HipReciprocalRelationsModel" and type(hip.model._base_model).__name__ == "HipDistMult"
+    assert list(hip.model.state_dict().keys()) == list(ref.model.state_dict().keys())
+    d = _param_diff(hip, ref)
+    _log(case="d2: hip_reciprocal_relations_model(hip_distmult) + 1vsAll (f32 kernels) vs the reference wrapper",
+         loss_ref=l_ref, loss_hip=l_hip, rel=_rel(l_hip, l_ref), param_rel_diff=d)
+    assert _rel(l_hip, l_ref) <= 1e-4 and d <= 1e-3
+    from kge_amd import engine
+    calls = {"ce": 0}
+    orig = engine.ce_fwd
+
+    def spy(*a, **k):
+        calls["ce"] += 1
+        return orig(*a, **k)
+
+    engine.ce_fwd = spy
+    try:
+        fus, l_fus, _ = _train_epoch(
+            root, folder, "d2_fused", (hrr, "hip_distmult"), "hip_1vsAll", dim=256, init_from=st,
+            opts={"hip_distmult.score_dtype": "bfloat16", "train.optimizer.default.type": "HipAdagrad",
+                  "train.optimizer.default.args.bf16_copies": True})
+    finally:
+        engine.ce_fwd = orig
+    assert type(fus).__name__ == "HipTrainingJob1vsAll"
+    gs = fus._graph_step
+    assert calls["ce"] >= 1, "the fused loss of the base model was not reached"
+    assert gs is not None and gs.disabled_reason is None and gs.replays >= 90, vars(gs) if gs is not None else None
+    d16 = _param_diff(fus, ref)
+    _log(case="d2: ... + hip_1vsAll + bf16 scoring + HipAdagrad (one fused launch over 2n sp_ queries, graph step)",
+         loss_ref=l_ref, loss_hip=l_fus, rel=_rel(l_fus, l_ref), param_rel_diff=d16, replays=gs.replays,
+         seconds_per_epoch_reference=_second_epoch_seconds(ref), seconds_per_epoch_fused=_second_epoch_seconds(fus))
+    assert _rel(l_fus, l_ref) <= 1e-2 and d16 <= 5e-2
+    # KvsAll, kl, with label smoothing
+    kopts = {"KvsAll.label_smoothing": 0.1}
+    kref, lk_ref, _ = _train_epoch(root, folder, "d2_kref", (rr, "distmult"), "KvsAll", dim=256, init_from=st, opts=kopts)
+    khip, lk_hip, _ = _train_epoch(root, folder, "d2_khip", (hrr, "hip_distmult"), "hip_KvsAll", dim=256, init_from=st,
+                                   opts=dict(kopts, **{"hip_distmult.score_dtype": "bfloat16"}))
+    _log(case="d2: hip_KvsAll (kl, label smoothing 0.1) over the hip reciprocal wrapper vs the reference",
+         loss_ref=lk_ref, loss_hip=lk_hip, rel=_rel(lk_hip, lk_ref), param_rel_diff=_param_diff(khip, kref))
+    assert _rel(lk_hip, lk_ref) <= 1e-2
+    # evaluation on the reference's trained state: the reference job and hip_entity_ranking over the hip wrapper
+    state = {k: v.detach().clone() for k, v in ref.model.state_dict().items()}
+    _, ex_ref, m_ref = _eval(root, folder, "d2_eval_ref", (rr, "distmult"), "entity_ranking", state, dim=256)
+    key = "mean_reciprocal_rank_filtered_with_test"
+    for job_type in ("entity_ranking", "hip_entity_ranking"):
+        for chunk in (-1, 3000):
+            _, ex_hip, m_hip = _eval(root, folder, "d2_eval_hip", (hrr, "hip_distmult"), job_type, state, chunk, dim=256)
+            flips = sum(a != b for a, b in zip(ex_ref, ex_hip))
+            _log(case=f"d2: {job_type} over the hip reciprocal wrapper (f32 tables), chunk {chunk}", examples=len(ex_hip),
+                 examples_differing=flips, abs_mrr_diff=abs(m_ref[key] - m_hip[key]))
+            assert flips <= 15 and abs(m_ref[key] - m_hip[key]) <= 1e-5
+
+
 @pytest.mark.parametrize("model", ["complex", "distmult"])
 def test_c4_the_reference_job_over_a_hip_model_keeps_the_ranks(data, model):
     """The drop-in a user makes first: ONLY the model's name changes (`hip_complex`, `score_dtype: bfloat16`), the job

@@ -467,3 +467,44 @@ def test_an_arange_subset_is_recognised_as_a_range_of_the_table():
         assert t(keep) is keep
     perm = torch.randperm(E)
     assert t(perm) is perm
+
+
+def test_hip_reciprocal_wrapper_is_the_reference_wrapper_without_a_gpu():
+    """`model: hip_reciprocal_relations_model` over hip_distmult on job.device cpu: the reference wrapper's parameter names
+    (its checkpoints load), and -- without a HIP device the base model's fused path does not apply -- the reference
+    wrapper's own scores bit for bit; the fused-loss hooks answer None (the hip_* jobs then run the reference's code)."""
+    import os
+    rh.import_reference()
+    from kge import Config, Dataset
+    from kge.model import KgeModel
+    data = os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test")   # (the wrapper reads the relation ids)
+    models = {}
+    for name, base in (("reciprocal_relations_model", "distmult"), ("hip_reciprocal_relations_model", "hip_distmult")):
+        config = Config()
+        config.folder = None
+        config.set("console.quiet", True)
+        config.set("modules", ["kge.job", "kge.model", "kge.model.embedder", "kge_amd.libkge_plugin"])
+        config.set("model", name)
+        config._import(name)
+        config._import(base)
+        config.set(f"{name}.base_model.type", base)
+        config.set("dataset.name", "dataset_test")
+        config.set("job.device", "cpu")
+        config.set_all({"lookup_embedder.dim": 16})
+        torch.manual_seed(5)
+        models[name] = KgeModel.create(config, Dataset.create(config, folder=data))
+    ref, hip = models["reciprocal_relations_model"], models["hip_reciprocal_relations_model"]
+    assert type(hip).__name__ == "HipReciprocalRelationsModel" and type(hip._base_model).__name__ == "HipDistMult"
+    assert list(hip.state_dict().keys()) == list(ref.state_dict().keys())
+    hip.load_state_dict(ref.state_dict())
+    E, R = ref.dataset.num_entities(), ref.dataset.num_relations()
+    assert hip._base_model.get_p_embedder()._embeddings.weight.shape[0] == 2 * R   # p and p + R
+    g = torch.Generator().manual_seed(6)
+    s, p, o = (torch.randint(hi, (11,), generator=g) for hi in (E, R, E))
+    sub = torch.tensor([E - 1, 1, 0])   # (the reference's test dataset: 4 entities, 3 relations)
+    for call in (lambda m: m.score_sp(s, p), lambda m: m.score_po(p, o), lambda m: m.score_po(p, o, sub),
+                 lambda m: m.score_sp_po(s, p, o), lambda m: m.score_sp_po(s, p, o, sub),
+                 lambda m: m.score_spo(s, p, o, "s"), lambda m: m.score_spo(s, p, o, "o")):
+        assert torch.equal(call(hip), call(ref))
+    assert hip._ce_tables() is None and hip._dropout_only() is None
+    assert hip.loss_sp(s, p, o) is None and hip.loss_po(p, o, s) is None and hip.loss_sp_po(s, p, o) is None
