@@ -108,6 +108,13 @@ def _scorer_of(model):
 def _check_model(model, allow_dropout=True):
     """The model shapes the sharded table can stand in for (module docstring); -> (entity weight, relation weight)."""
     from kge.model import LookupEmbedder
+    from kge.model.reciprocal_relations_model import ReciprocalRelationsModel
+    if isinstance(model, ReciprocalRelationsModel):
+        # (its embedders ARE the base model's plain lookup tables, so the check below would pass -- and the job would then
+        # score the subject direction with relation p instead of p + R: a different model, silently)
+        raise ValueError("kge_amd: hip_sharded_* jobs do not take a reciprocal-relations wrapper (its subject direction "
+                         "scores with relation p + R); use train.type hip_1vsAll / hip_KvsAll with model "
+                         "hip_reciprocal_relations_model on one GPU")
     se, oe, pe = model.get_s_embedder(), model.get_o_embedder(), model.get_p_embedder()
     if se is not oe or type(se) is not LookupEmbedder or type(pe) is not LookupEmbedder:
         raise ValueError("kge_amd: hip_sharded_* jobs need plain lookup embedders, the entity embedder shared by the "

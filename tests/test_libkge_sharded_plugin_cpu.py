@@ -405,3 +405,19 @@ def test_the_plugin_imports_nothing_named_by_the_environment():
         assert sj._backend_for("cpu") is sj.SHARD_BACKEND
     finally:
         del os.environ["KGE_AMD_TEST_SHARD_BACKEND"]
+
+
+def test_sharded_jobs_refuse_the_reciprocal_wrapper(tmp_path):
+    """A reciprocal-relations wrapper's embedders ARE its base model's plain lookup tables: the sharded jobs' embedder
+    check alone would pass and the job would score the subject direction with relation p instead of p + R -- another
+    model, silently.  They refuse it by type (one GPU: hip_reciprocal_relations_model under hip_1vsAll / hip_KvsAll)."""
+    rh.import_reference()
+    from kge import Dataset
+    from kge.job import Job
+    tmp = str(tmp_path)
+    for wrapper, base in (("reciprocal_relations_model", "complex"), ("hip_reciprocal_relations_model", "hip_complex")):
+        config = _config(tmp, "recip_" + wrapper, wrapper, 16, "hip_sharded_1vsAll", "hip_sharded_entity_ranking", {})
+        config._import(base)
+        config.set(f"{wrapper}.base_model.type", base)
+        with pytest.raises(ValueError, match="reciprocal-relations wrapper"):
+            Job.create(config, Dataset.create(config, folder=_dataset_dir(tmp)))
