@@ -38,8 +38,9 @@ embedder dropout (lookup_embedder.py:64-69, 102-105) is applied in front of the 
 KvsAll; kge_amd.sharded: _dropout_loss).  Every rank starts from rank 0's parameters (one broadcast at job creation).
 
 What it declines, loudly (ValueError at job creation): embedder dropout under negative sampling,
-entity and relation embedders that are not plain LookupEmbedders shared between the s and o slot, reciprocal-relations
-wrappers, optimizer parameter groups, `train.loss` other than kl (1vsAll, KvsAll, negative sampling) or plain bce
+entity and relation embedders that are not plain LookupEmbedders shared between the s and o slot, a reciprocal-relations
+wrapper under negative sampling (1vsAll / KvsAll / evaluation take it: the table scores its subject direction as an sp_
+query with relation p + R, kge_amd.sharded: _recip), optimizer parameter groups, `train.loss` other than kl (1vsAll, KvsAll, negative sampling) or plain bce
 (KvsAll, negative sampling), s_o queries, negatives for the relation slot.
 
 CPU / gloo: the CPU test (tests/test_libkge_sharded_plugin_cpu.py) runs these jobs on two gloo ranks with the test
@@ -105,16 +106,21 @@ def _scorer_of(model):
     return name, l_norm
 
 
-def _check_model(model, allow_dropout=True):
+def _reciprocal_R(model) -> int:
+    """The number of relations R of a reciprocal-relations wrapper (kge/model/reciprocal_relations_model.py: 2 R relation
+    rows, the subject direction scores with relation p + R), 0 for any other model."""
+    from kge.model.reciprocal_relations_model import ReciprocalRelationsModel
+    return int(model.dataset.num_relations()) if isinstance(model, ReciprocalRelationsModel) else 0
+
+
+def _check_model(model, allow_dropout=True, allow_reciprocal=True):
     """The model shapes the sharded table can stand in for (module docstring); -> (entity weight, relation weight)."""
     from kge.model import LookupEmbedder
-    from kge.model.reciprocal_relations_model import ReciprocalRelationsModel
-    if isinstance(model, ReciprocalRelationsModel):
+    if _reciprocal_R(model) and not allow_reciprocal:
         # (its embedders ARE the base model's plain lookup tables, so the check below would pass -- and the job would then
         # score the subject direction with relation p instead of p + R: a different model, silently)
-        raise ValueError("kge_amd: hip_sharded_* jobs do not take a reciprocal-relations wrapper (its subject direction "
-                         "scores with relation p + R); use train.type hip_1vsAll / hip_KvsAll with model "
-                         "hip_reciprocal_relations_model on one GPU")
+        raise ValueError("kge_amd: hip_sharded_negative_sampling does not take a reciprocal-relations wrapper (its subject "
+                         "direction scores with relation p + R); hip_sharded_1vsAll / hip_sharded_KvsAll do")
     se, oe, pe = model.get_s_embedder(), model.get_o_embedder(), model.get_p_embedder()
     if se is not oe or type(se) is not LookupEmbedder or type(pe) is not LookupEmbedder:
         raise ValueError("kge_amd: hip_sharded_* jobs need plain lookup embedders, the entity embedder shared by the "
@@ -152,7 +158,7 @@ class _ShardState(_ShardedJob):
 
     def __init__(self, job, slack_rows=0):
         cfg, model = job.config, job.model
-        ent_w, rel_w = _check_model(model, allow_dropout=slack_rows <= 0)
+        ent_w, rel_w = _check_model(model, allow_dropout=slack_rows <= 0, allow_reciprocal=slack_rows <= 0)
         scorer, l_norm = _scorer_of(model)
         dev = torch.device(job.device)
         if ent_w.device != dev and not (dev.type == "cuda" and dev.index is None and ent_w.is_cuda):
@@ -184,6 +190,7 @@ class _ShardState(_ShardedJob):
         super().__init__(scorer, E, R, d, rel_dim=dr, state_dict=state, lr=lr if lr is not None else 0.0,
                          optimizer=self._opt_type, optimizer_args=args, score_dtype=sd, device=dev,
                          backend=_backend_for(dev), l_norm=l_norm, slack_rows=slack_rows, config=cfg, alias_state=True)
+        self.table.reciprocal_R = _reciprocal_R(model)  # (every "po" of the table becomes "sp" with p + R: sharded.py _recip)
         if dev.type == "cuda" and sd != torch.float32 and not ns:
             from .. import engine
             if _backend_for(dev) is None and not engine.ce_supported(self.table._tables(self.table.ent_local, "local")):
@@ -294,7 +301,15 @@ def sharded_model_penalty(model, sh, **kwargs):
     ent_pen = _lookup_penalty(se, ent_rows, sh.lo, entity_indexes, allreduce)
     if not (triples is not None and weighted):
         ent_pen = [(k, v * 2) for k, v in ent_pen]  # (kge_model.py:620-625 / 636-640: "backwards compatibility")
-    return result + ent_pen
+    result = result + ent_pen
+    # a reciprocal-relations wrapper adds the weighted term of the reciprocal relation rows p + R
+    # (reciprocal_relations_model.py:59-72), behind the base model's terms
+    R = _reciprocal_R(model)
+    if R and pe.get_option("regularize_args.weighted") and pe.regularize != "" and pe.get_option("regularize_weight") != 0.0:
+        if triples is None:
+            raise KeyError("batch")
+        result = result + _lookup_penalty(pe, rel_rows, 0, triples[:, _P] + R, None)
+    return result
 
 
 def _batch_checksum(batch) -> torch.Tensor:
@@ -633,6 +648,7 @@ class HipShardedEntityRankingJob(HipEntityRankingJob):
             lo, hi = ShardedEntityTable.partition(E, world, rank)
             tb = ShardedEntityTable(scorer, ent_w.detach()[lo:hi].to(sd).contiguous(), rel_w.detach().to(sd).contiguous(),
                                     E, l_norm=l_norm, backend=_backend_for(ent_w.device))
+            tb.reciprocal_R = _reciprocal_R(self.model)
             self._own_table = tb
         return tb
 

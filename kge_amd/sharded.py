@@ -395,6 +395,10 @@ class ShardedEntityTable:
         self.backend = backend
         self._bufs, self._tcache = {}, {}
         self._lane = 0  # exchange buffers are per lane (ShardedScoreLanes: several batches in flight)
+        # A reciprocal-relations model (kge/model/reciprocal_relations_model.py): the relation table holds 2 R rows and the
+        # subject direction is an sp_ query with relation p + R -- score_po(p, o) = score_sp(o, p + R).  0 = a plain model.
+        # Every "po" of this class is translated in ONE place (_recip); negative sampling is not offered.
+        self.reciprocal_R = 0
         # rank_batch_multi counts inside the scoring kernel where the backend offers it (no score slabs);
         # False (TWO_STEP): score slabs + rank_counts_multi
         self.fused_rank = not self.TWO_STEP
@@ -484,6 +488,12 @@ class ShardedEntityTable:
         """[n, d] rows of the GLOBAL entity table for global ids `idx`."""
         return self.exchange_rows([idx])[0].clone()
 
+    def _recip(self, direction: str, p: torch.Tensor):
+        """(direction, relation ids) as the kernels see them: a reciprocal model's "po" is "sp" with p + R."""
+        if self.reciprocal_R and direction == "po":
+            return "sp", p + self.reciprocal_R
+        return direction, p
+
     # ---- scoring: local slabs, no collective ---------------------------------------------
     def score_sp(self, s: torch.Tensor, p: torch.Tensor):
         """[n, E_g]: scores of (s_i, p_i, ·) against this rank's entities."""
@@ -491,6 +501,8 @@ class ShardedEntityTable:
         return self.backend.score_emb(self.scorer, rows, rel_rows, self.ent_local, "sp_", self.l_norm)
 
     def score_po(self, p: torch.Tensor, o: torch.Tensor):
+        if self.reciprocal_R:
+            return self.score_sp(o, p + self.reciprocal_R)
         rows, rel_rows = self.exchange_rows([o], p)
         return self.backend.score_emb(self.scorer, self.ent_local, rel_rows, rows, "_po", self.l_norm)
 
@@ -505,6 +517,9 @@ class ShardedEntityTable:
         lines) or, for slabs that outgrow the Infinity Cache, one launch per direction into matrices with
         a 128-byte-aligned row pitch."""
         n, m = s.numel(), self.hi - self.lo
+        if self.reciprocal_R:  # two sp_ launches: (s, p) and (o, p + R); the exchanged rows are copied out of the lane's
+            sp = self.score_sp(s, p)   # buffer by the first launch's consumer before the second exchange reuses it
+            return sp, self.score_sp(o, p + self.reciprocal_R)
         rows, rel_rows = self.exchange_rows([s, o], p)
         s_rows, o_rows = rows[:n], rows[n:]
         big = n * m * 4 > self.BIG_SLAB_BYTES
@@ -542,6 +557,7 @@ class ShardedEntityTable:
         rel_master = self.rel if rel_master is None else rel_master
         if dropout is not None and max(dropout) > 0.0:
             return self._dropout_loss("ce", direction, ids, p, ent_master, rel_master, (labels,), dropout, masks)
+        direction, p = self._recip(direction, p)
         return _ShardedCE.apply(self, direction, ent_master, rel_master, ids, p, labels)
 
     def kl_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, ent_master=None, rel_master=None, dropout=None,
@@ -551,6 +567,7 @@ class ShardedEntityTable:
         rel_master = self.rel if rel_master is None else rel_master
         if dropout is not None and max(dropout) > 0.0:
             return self._dropout_loss("kl", direction, ids, p, ent_master, rel_master, (lbl_rowptr, lbl_col), dropout, masks)
+        direction, p = self._recip(direction, p)
         return _ShardedKL.apply(self, direction, ent_master, rel_master, ids, p, lbl_rowptr, lbl_col)
 
     def bce_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, offset: float = 0.0, ent_master=None,
@@ -561,6 +578,7 @@ class ShardedEntityTable:
         if dropout is not None and max(dropout) > 0.0:
             return self._dropout_loss("bce", direction, ids, p, ent_master, rel_master, (lbl_rowptr, lbl_col, offset),
                                       dropout, masks)
+        direction, p = self._recip(direction, p)
         return _ShardedBCE.apply(self, direction, ent_master, rel_master, ids, p, lbl_rowptr, lbl_col, offset)
 
     def _dropout_loss(self, kind, direction, ids, p, ent_master, rel_master, extra, dropout, masks):
@@ -578,11 +596,17 @@ class ShardedEntityTable:
         def drop_all():
             return _drop(shard, p_ent, masks.get("all"), gen)
         table = drop_all() if direction == "po" else None
-        a_rows = _drop(_OwnerRows.apply(self, ent_master, ids), p_ent, masks.get("a"))
-        p_rows = _drop(_SumOverShards.apply(self, rel_master[p.reshape(-1).long()]), p_rel, masks.get("p"))
+        kdir, kp = self._recip(direction, p)
+        if self.reciprocal_R and direction == "po":
+            # the wrapper's own order (reciprocal_relations_model.py:84-91): all entities, relation rows p + R, o rows
+            p_rows = _drop(_SumOverShards.apply(self, rel_master[kp.reshape(-1).long()]), p_rel, masks.get("p"))
+            a_rows = _drop(_OwnerRows.apply(self, ent_master, ids), p_ent, masks.get("a"))
+        else:
+            a_rows = _drop(_OwnerRows.apply(self, ent_master, ids), p_ent, masks.get("a"))
+            p_rows = _drop(_SumOverShards.apply(self, rel_master[kp.reshape(-1).long()]), p_rel, masks.get("p"))
         if table is None:
             table = drop_all()
-        return _ShardedDense.apply(self, kind, direction, table, a_rows, p_rows, extra)
+        return _ShardedDense.apply(self, kind, kdir, table, a_rows, p_rows, extra)
 
     @staticmethod
     def with_slack(rows: torch.Tensor, n_max: int):
@@ -596,6 +620,8 @@ class ShardedEntityTable:
     def neg_scores(self, s, p, o, slot: int, neg, ent_master=None, rel_master=None):
         """(positives [n], scores [n, K] of the triples with `slot` replaced by neg[i, k]) -- see _ShardedNeg.  Needs
         `self.ent_ext` (with_slack) whose first rows are this table's `ent_local`."""
+        if self.reciprocal_R:
+            raise NotImplementedError("kge_amd.sharded: negative sampling over a reciprocal-relations model")
         ent_master = self.ent_local if ent_master is None else ent_master
         rel_master = self.rel if rel_master is None else rel_master
         return _ShardedNeg.apply(self, ent_master, rel_master, s, p, o, slot, neg)
@@ -647,7 +673,7 @@ class ShardedEntityTable:
         [2 (o, s), 2 (rank, ties), len(filters) + 1, n]."""
         s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
         n, K = triples.shape[0], len(filters_o)
-        if (self.fused_rank and K <= 2 and hasattr(self.backend, "score_rank_emb_sp_po")
+        if (self.fused_rank and not self.reciprocal_R and K <= 2 and hasattr(self.backend, "score_rank_emb_sp_po")
                 and hasattr(self.backend, "score_emb_sp_po")):
             counts = self._rank_batch_fused(s, p, o, filters_o, filters_s, atol, rtol)
             if counts is not None:

@@ -717,7 +717,7 @@ def test_i_subbatch_auto_tune_fires_on_rocm(data):
     assert _rel(loss, l_ref) <= 1e-5, (loss, l_ref)
 
 
-@pytest.mark.parametrize("case", ["1vsAll", "KvsAll", "negative_sampling"])
+@pytest.mark.parametrize("case", ["1vsAll", "KvsAll", "negative_sampling", "1vsAll-reciprocal"])
 def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case):
     """train.type: hip_sharded_* + eval.type: hip_sharded_entity_ranking through TrainingJob.create / EvaluationJob.create
     of an unmodified LibKGE on the MI355X, as ONE rank of an RCCL group (torchrun's environment for a world of one,
@@ -742,6 +742,12 @@ def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case
         opts = {"negative_sampling.num_samples.s": 64, "negative_sampling.num_samples.o": 64,
                 "negative_sampling.implementation": "triple"}
         bound = 1e-4
+    elif case == "1vsAll-reciprocal":
+        # the reciprocal wrapper (round 6): the sharded table scores the subject direction as an sp_ query with relation
+        # p + R (kge_amd.sharded: _recip) -- against hip_1vsAll over the same wrapper (one fused launch over 2n sp_ queries)
+        model, dim, plain = ("hip_reciprocal_relations_model", "hip_complex"), 512, "hip_1vsAll"
+        opts = {"hip_complex.score_dtype": "bfloat16"}
+        bound, case = 2e-3, "1vsAll"
     else:
         model, dim, plain = ("hip_complex", 512, "hip_1vsAll") if case == "1vsAll" else ("hip_distmult", 512, "hip_KvsAll")
         opts = {f"{model}.score_dtype": "bfloat16"}
@@ -759,15 +765,18 @@ def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case
             torch.manual_seed(v)
             np.random.seed(v % (2 ** 32))
             random.seed(v)
-        ref, l_ref, st = _train_epoch(root, folder, f"j_plain_{case}", model, plain, dim, opts, before_epoch=seed_like_sharded)
+        tagm = "recip_" if isinstance(model, tuple) else ""
+        ref, l_ref, st = _train_epoch(root, folder, f"j_plain_{tagm}{case}", model, plain, dim, opts, before_epoch=seed_like_sharded)
         sopts = dict(opts)
         sopts["eval.type"] = "hip_sharded_entity_ranking"
-        shd, l_shd, _ = _train_epoch(root, folder, f"j_sharded_{case}", model, "hip_sharded_" + case, dim, sopts, init_from=st,
+        shd, l_shd, _ = _train_epoch(root, folder, f"j_sharded_{tagm}{case}", model, "hip_sharded_" + case, dim, sopts, init_from=st,
                                      before_epoch=lambda job: setattr(job, "_seed_base", 4242))
         assert type(shd).__name__.startswith("HipShardedTrainingJob") and dist.is_initialized()
         assert dist.get_backend() == "nccl" and shd._sh.table.collectives
         d = _param_diff(shd, ref) if case != "negative_sampling" else None
-        _log(case=f"j: hip_sharded_{case} (one RCCL rank, collectives forced) vs {plain}", loss_plain=l_ref,
+        if tagm:
+            assert shd._sh.table.reciprocal_R == R
+        _log(case=f"j: hip_sharded_{case} {tagm}(one RCCL rank, collectives forced) vs {plain}", loss_plain=l_ref,
              loss_sharded=l_shd, rel=_rel(l_shd, l_ref), param_rel_diff_own_rows=d)
         assert _rel(l_shd, l_ref) <= bound, (l_shd, l_ref)
         # validation through the job's own valid_job = the sharded evaluation on the table being trained
@@ -777,7 +786,7 @@ def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case
         ref.valid_job.epoch = 1
         tr_ref = ref.valid_job.run()
         k = "mean_reciprocal_rank_filtered_with_test"
-        _log(case=f"j: validation of hip_sharded_{case} by hip_sharded_entity_ranking vs the plain job's entity_ranking",
+        _log(case=f"j: validation of hip_sharded_{case} {tagm}by hip_sharded_entity_ranking vs the plain job's entity_ranking",
              mrr_sharded=tr[k], mrr_plain=tr_ref[k])
         assert abs(tr[k] - tr_ref[k]) <= 2e-3 * max(tr_ref[k], 1e-3) + 1e-4
         # the checkpoint: the reference's layout, ONE [E, d] parameter
