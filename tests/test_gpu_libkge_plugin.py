@@ -439,6 +439,20 @@ def test_d2_hip_reciprocal_relations_model_takes_the_fused_paths(data):
          loss_ref=l_ref, loss_hip=l_fus, rel=_rel(l_fus, l_ref), param_rel_diff=d16, replays=gs.replays,
          seconds_per_epoch_reference=_second_epoch_seconds(ref), seconds_per_epoch_fused=_second_epoch_seconds(fus))
     assert _rel(l_fus, l_ref) <= 1e-2 and d16 <= 5e-2
+    # a weighted penalty (what the tuned configurations carry): the wrapper's penalty() -- the base model's terms + the
+    # reciprocal relation rows' (reciprocal_relations_model.py:59-72) -- is the reference's code next to the fused loss
+    popts = {"lookup_embedder.regularize_args.weighted": True, "distmult.entity_embedder.regularize_weight": 1e-2,
+             "distmult.relation_embedder.regularize_weight": 1e-2}
+    hpopts = {k.replace("distmult.", "hip_distmult."): v for k, v in popts.items()}
+    pref, lp_ref, _ = _train_epoch(root, folder, "d2_pref", (rr, "distmult"), dim=256, init_from=st, opts=popts)
+    phip, lp_hip, _ = _train_epoch(root, folder, "d2_phip", (hrr, "hip_distmult"), "hip_1vsAll", dim=256, init_from=st,
+                                   opts=dict(hpopts, **{"hip_distmult.score_dtype": "bfloat16"}))
+    pen_ref = pref.last_epoch_trace["avg_penalty"]
+    pen_hip = phip.last_epoch_trace["avg_penalty"]
+    _log(case="d2: hip_1vsAll over the hip reciprocal wrapper with weighted L2 penalties vs the reference", loss_ref=lp_ref,
+         loss_hip=lp_hip, rel=_rel(lp_hip, lp_ref), avg_penalty_ref=pen_ref, avg_penalty_hip=pen_hip,
+         param_rel_diff=_param_diff(phip, pref))
+    assert pen_ref > 0 and abs(pen_hip - pen_ref) <= 2e-2 * pen_ref and _rel(lp_hip, lp_ref) <= 1e-2
     # KvsAll, kl, with label smoothing
     kopts = {"KvsAll.label_smoothing": 0.1}
     kref, lk_ref, _ = _train_epoch(root, folder, "d2_kref", (rr, "distmult"), "KvsAll", dim=256, init_from=st, opts=kopts)
