@@ -41,7 +41,7 @@ What it declines, loudly (ValueError at job creation): embedder dropout under ne
 entity and relation embedders that are not plain LookupEmbedders shared between the s and o slot, a reciprocal-relations
 wrapper under negative sampling (1vsAll / KvsAll / evaluation take it: the table scores its subject direction as an sp_
 query with relation p + R, kge_amd.sharded: _recip), optimizer parameter groups, `train.loss` other than kl (1vsAll, KvsAll, negative sampling) or plain bce
-(KvsAll, negative sampling), s_o queries, negatives for the relation slot.
+(KvsAll, negative sampling), KvsAll.label_smoothing under bce (kl takes it), s_o queries, negatives for the relation slot.
 
 CPU / gloo: the CPU test (tests/test_libkge_sharded_plugin_cpu.py) runs these jobs on two gloo ranks with the test
 suite's stand-in backend handed in through `SHARD_BACKEND`; the product default is kge_amd.engine (HIP kernels, no CPU
@@ -521,9 +521,9 @@ class HipShardedTrainingJobKvsAll(_ShardedTrainMixin, TrainingJobKvsAll):
         super().__init__(config, dataset, parent_job, model=model, forward_only=forward_only)
         if self.config.get("KvsAll.query_types").get("s_o"):
             raise ValueError("kge_amd: hip_sharded_KvsAll scores sp_ and _po queries (KvsAll.query_types.s_o: false)")
-        if float(self.label_smoothing) != 0.0:
-            raise ValueError("kge_amd: hip_sharded_KvsAll does not support KvsAll.label_smoothing")
         self._bce_offset = _plain_bce(self.loss)
+        if float(self.label_smoothing) != 0.0 and self._bce_offset is not None:
+            raise ValueError("kge_amd: hip_sharded_KvsAll supports KvsAll.label_smoothing with train.loss: kl (not bce)")
         if not isinstance(self.loss, KLDivWithSoftmaxKgeLoss) and self._bce_offset is None:
             raise ValueError("kge_amd: hip_sharded_KvsAll supports train.loss: kl and plain bce")
         self._sharded_init()
@@ -550,7 +550,8 @@ class HipShardedTrainingJobKvsAll(_ShardedTrainMixin, TrainingJobKvsAll):
             direction, ids, p = ("sp", q0, q1) if query_type == "sp_" else ("po", q1, q0)
             if self._bce_offset is None:
                 rows = sh.table.kl_loss(direction, ids, p, rowptr, col, sh.ent_master, sh.rel_master,
-                                        dropout=self._dropout if self.model.training else None)
+                                        dropout=self._dropout if self.model.training else None,
+                                        label_smoothing=float(self.label_smoothing))
             else:
                 rows = sh.table.bce_loss(direction, ids, p, rowptr, col, self._bce_offset, sh.ent_master, sh.rel_master,
                                          dropout=self._dropout if self.model.training else None)

@@ -94,6 +94,37 @@ def _merge_query_grads(sh, ids, p, g_a, g_p, g_t, ent_shape, rel_shape):
     return ge.to(torch.float32).view(ent_shape), gr
 
 
+def _kl_label_terms(rowptr, eps: float, num_entities: int):
+    """Per-row constants of the KvsAll KL loss (train_KvsAll.py:244-294, loss.py:208-213) -> (k, has, w, bias, const):
+    the loss row is  lse_i - w_i sum_{labels} x_ij - bias_i sum_{all j} x_ij + const_i  on rows with `has`, 0 elsewhere.
+    Without label smoothing: w = 1 / k, bias = None, const = -log k, rows without labels contribute nothing.  With
+    smoothing eps (train_KvsAll.py:260-266: labels = (1 - eps) multi_hot + 1 / E, then normalised): the label row is a_i
+    on the k_i labels and b_i elsewhere, Z_i = (1 - eps) k_i + 1, a_i = (1 - eps + 1 / E) / Z_i, b_i = (1 / E) / Z_i:
+    w = a - b, bias = b, const = k a log a + (E - k) b log b (kge_amd.model.kl_fused has the unsharded form)."""
+    k = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+    if eps == 0.0:
+        has = k > 0
+        w = torch.where(has, 1.0 / k.clamp(min=1.0), torch.zeros_like(k))
+        return k, has, w, None, -torch.log(k.clamp(min=1.0))
+    E = float(num_entities)
+    Z = (1.0 - eps) * k + 1.0
+    a_w, b_w = (1.0 - eps + 1.0 / E) / Z, (1.0 / E) / Z
+    const = k * a_w * torch.log(a_w) + (E - k) * b_w * torch.log(b_w)
+    return k, torch.ones_like(k, dtype=torch.bool), (a_w - b_w).contiguous(), b_w.contiguous(), const
+
+
+@torch.no_grad()
+def _sum_of_shard_scores(sh, t16, direction, a_rows, p_rows):
+    """[n]: sum_j score(i, j) over THIS shard's entities j -- ComplEx and DistMult are linear in the target row, so it is
+    one score of every query against the shard's column sum (the label-smoothing term's value; its gradient is taken
+    inside the gradient kernel: label_bias)."""
+    colsum = t16.ent.float().sum(dim=0, keepdim=True)
+    a32, p32 = a_rows.float(), p_rows.float()
+    if direction == "sp":
+        return sh.backend.score_emb(sh.scorer, a32, p32, colsum, "sp_", sh.l_norm).reshape(-1).to(torch.float32)
+    return sh.backend.score_emb(sh.scorer, colsum, p32, a32, "_po", sh.l_norm).reshape(-1).to(torch.float32)
+
+
 class _ShardedKL(torch.autograd.Function):
     """Per-row KL divergence of softmax(score(i, .)) over the entities of ALL shards from the row's normalised
     multi-hot labels (TrainingJobKvsAll with train.loss: kl, kge/job/train_KvsAll.py:244-294, kge/util/loss.py:208-213):
@@ -101,17 +132,17 @@ class _ShardedKL(torch.autograd.Function):
     holds GLOBAL entity ids and is the same on every rank: each shard's kernel takes the labels it owns."""
 
     @staticmethod
-    def forward(ctx, sh, direction, ent_master, rel_master, ids, p, rowptr, col):
+    def forward(ctx, sh, direction, ent_master, rel_master, ids, p, rowptr, col, eps=0.0):
         rows, rel_rows = sh.exchange_rows([ids], p)
         rows, rel_rows = rows.clone(), rel_rows.clone()
-        k = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
-        has = k > 0
-        w = torch.where(has, 1.0 / k.clamp(min=1.0), torch.zeros_like(k))
+        k, has, w, bias, const = _kl_label_terms(rowptr, float(eps), sh.E)
         t16 = sh._tables(sh.ent_local, "local")
         loss_loc, lse_loc = sh.backend.kl_emb_fwd(t16, direction, rows, rel_rows, rowptr, col, sh.lo, w)
         # w_i * (sum of the label scores inside this shard).  A rank whose shard is EMPTY (E = 9 over 4 ranks) has
         # lse = -inf and loss = -inf: the difference would be NaN and the all-reduce below would spread it (ADVICE r4).
         lab = torch.where(torch.isfinite(lse_loc), lse_loc - loss_loc, torch.zeros_like(lse_loc))
+        if bias is not None:  # label smoothing: + bias_i x (this shard's sum of ALL scores of row i), one all-reduce for both
+            lab = lab + bias * _sum_of_shard_scores(sh, t16, direction, rows, rel_rows)
         if sh.collectives:
             allse = torch.empty(sh.world * lse_loc.numel(), dtype=lse_loc.dtype, device=lse_loc.device)
             dist.all_gather_into_tensor(allse, lse_loc.contiguous(), group=sh.group)
@@ -121,19 +152,21 @@ class _ShardedKL(torch.autograd.Function):
             lse = lse_loc
         ctx.sh, ctx.direction = sh, direction
         ctx.meta = (ids, p, rowptr, col, ent_master.shape, rel_master.shape)
-        ctx.save_for_backward(rows, rel_rows, lse, w, has)
-        return torch.where(has, lse - lab - torch.log(k.clamp(min=1.0)), torch.zeros_like(lse))
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(rows, rel_rows, lse, w, has, bias if bias is not None else w)
+        return torch.where(has, lse - lab + const, torch.zeros_like(lse))
 
     @staticmethod
     def backward(ctx, g_rows):
         sh = ctx.sh
         ids, p, rowptr, col, ent_shape, rel_shape = ctx.meta
-        rows, rel_rows, lse, w, has = ctx.saved_tensors
+        rows, rel_rows, lse, w, has, bias = ctx.saved_tensors
         g = torch.where(has, g_rows, torch.zeros_like(g_rows)).contiguous()  # rows without labels: no gradient
         t16 = sh._tables(sh.ent_local, "local")
-        g_a, g_p, g_t = sh.backend.kl_emb_bwd(t16, ctx.direction, rows, rel_rows, rowptr, col, sh.lo, w, lse, g_rows=g)
+        g_a, g_p, g_t = sh.backend.kl_emb_bwd(t16, ctx.direction, rows, rel_rows, rowptr, col, sh.lo, w, lse, g_rows=g,
+                                              label_bias=bias if ctx.has_bias else None)
         ge, gr = _merge_query_grads(sh, ids, p, g_a, g_p, g_t, ent_shape, rel_shape)
-        return None, None, ge, gr, None, None, None, None
+        return None, None, ge, gr, None, None, None, None, None
 
 
 class _ShardedBCE(torch.autograd.Function):
@@ -260,16 +293,18 @@ class _ShardedDense(torch.autograd.Function):
             return lse - true
         rowptr, col = extra[0], extra[1]
         if kind == "kl":
-            k = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
-            has = k > 0
-            w = torch.where(has, 1.0 / k.clamp(min=1.0), torch.zeros_like(k))
+            eps = float(extra[2]) if len(extra) > 2 else 0.0
+            k, has, w, bias, const = _kl_label_terms(rowptr, eps, sh.E)
             loss_loc, lse_loc = sh.backend.kl_emb_fwd(t16, direction, a16, p16, rowptr, col, sh.lo, w)
             lab = torch.where(torch.isfinite(lse_loc), lse_loc - loss_loc, torch.zeros_like(lse_loc))
+            if bias is not None:
+                lab = lab + bias * _sum_of_shard_scores(sh, t16, direction, a16, p16)
             lse = merge(lse_loc)
             sh._allreduce(lab)
             ctx.extra = (rowptr, col)
-            ctx.save_for_backward(a16, p16, lse, w, has)
-            return torch.where(has, lse - lab - torch.log(k.clamp(min=1.0)), torch.zeros_like(lse))
+            ctx.has_bias = bias is not None
+            ctx.save_for_backward(a16, p16, lse, w, has, bias if bias is not None else w)
+            return torch.where(has, lse - lab + const, torch.zeros_like(lse))
         offset = float(extra[2])
         loss = sh.backend.bce_emb_fwd(t16, direction, a16, p16, rowptr, col, sh.lo, offset)
         loss = sh._allreduce(loss.clone())
@@ -284,9 +319,10 @@ class _ShardedDense(torch.autograd.Function):
             a16, p16, lse = ctx.saved_tensors
             g_a, g_p, g_t = sh.backend.ce_emb_bwd(t16, ctx.direction, a16, p16, ctx.extra[0], lse, g_rows=g_rows.contiguous())
         elif ctx.kind == "kl":
-            a16, p16, lse, w, has = ctx.saved_tensors
+            a16, p16, lse, w, has, bias = ctx.saved_tensors
             g = torch.where(has, g_rows, torch.zeros_like(g_rows)).contiguous()
-            g_a, g_p, g_t = sh.backend.kl_emb_bwd(t16, ctx.direction, a16, p16, ctx.extra[0], ctx.extra[1], sh.lo, w, lse, g_rows=g)
+            g_a, g_p, g_t = sh.backend.kl_emb_bwd(t16, ctx.direction, a16, p16, ctx.extra[0], ctx.extra[1], sh.lo, w, lse, g_rows=g,
+                                                  label_bias=bias if ctx.has_bias else None)
         else:
             a16, p16 = ctx.saved_tensors
             g_a, g_p, g_t = sh.backend.bce_emb_bwd(t16, ctx.direction, a16, p16, ctx.extra[0], ctx.extra[1], sh.lo,
@@ -561,14 +597,19 @@ class ShardedEntityTable:
         return _ShardedCE.apply(self, direction, ent_master, rel_master, ids, p, labels)
 
     def kl_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, ent_master=None, rel_master=None, dropout=None,
-                masks=None):
-        """[n] KvsAll KL loss rows over ALL entities (see _ShardedKL); sum / batch size = the reference's loss."""
+                masks=None, label_smoothing: float = 0.0):
+        """[n] KvsAll KL loss rows over ALL entities (see _ShardedKL); sum / batch size = the reference's loss.
+        label_smoothing: KvsAll.label_smoothing (train_KvsAll.py:260-266; _kl_label_terms)."""
         ent_master = self.ent_local if ent_master is None else ent_master
         rel_master = self.rel if rel_master is None else rel_master
+        eps = float(label_smoothing)
+        if eps != 0.0 and self.scorer not in ("complex", "distmult"):
+            raise NotImplementedError("kge_amd.sharded: label smoothing needs a scorer that is linear in the target row")
         if dropout is not None and max(dropout) > 0.0:
-            return self._dropout_loss("kl", direction, ids, p, ent_master, rel_master, (lbl_rowptr, lbl_col), dropout, masks)
+            return self._dropout_loss("kl", direction, ids, p, ent_master, rel_master, (lbl_rowptr, lbl_col, eps), dropout,
+                                      masks)
         direction, p = self._recip(direction, p)
-        return _ShardedKL.apply(self, direction, ent_master, rel_master, ids, p, lbl_rowptr, lbl_col)
+        return _ShardedKL.apply(self, direction, ent_master, rel_master, ids, p, lbl_rowptr, lbl_col, eps)
 
     def bce_loss(self, direction: str, ids, p, lbl_rowptr, lbl_col, offset: float = 0.0, ent_master=None,
                  rel_master=None, dropout=None, masks=None):

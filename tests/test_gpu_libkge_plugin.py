@@ -731,7 +731,7 @@ def test_i_subbatch_auto_tune_fires_on_rocm(data):
     assert _rel(loss, l_ref) <= 1e-5, (loss, l_ref)
 
 
-@pytest.mark.parametrize("case", ["1vsAll", "KvsAll", "negative_sampling", "1vsAll-reciprocal"])
+@pytest.mark.parametrize("case", ["1vsAll", "KvsAll", "negative_sampling", "1vsAll-reciprocal", "KvsAll-smoothed"])
 def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case):
     """train.type: hip_sharded_* + eval.type: hip_sharded_entity_ranking through TrainingJob.create / EvaluationJob.create
     of an unmodified LibKGE on the MI355X, as ONE rank of an RCCL group (torchrun's environment for a world of one,
@@ -756,6 +756,12 @@ def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case
         opts = {"negative_sampling.num_samples.s": 64, "negative_sampling.num_samples.o": 64,
                 "negative_sampling.implementation": "triple"}
         bound = 1e-4
+    elif case == "KvsAll-smoothed":
+        # KvsAll.label_smoothing under kl (round 6): the uniform part of the smoothed labels as the gradient kernel's
+        # per-row bias + one score per query against the shard's column sum
+        model, dim, plain = "hip_distmult", 512, "hip_KvsAll"
+        opts = {"hip_distmult.score_dtype": "bfloat16", "KvsAll.label_smoothing": 0.1}
+        bound, case = 2e-3, "KvsAll"
     elif case == "1vsAll-reciprocal":
         # the reciprocal wrapper (round 6): the sharded table scores the subject direction as an sp_ query with relation
         # p + R (kge_amd.sharded: _recip) -- against hip_1vsAll over the same wrapper (one fused launch over 2n sp_ queries)
@@ -779,7 +785,7 @@ def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case
             torch.manual_seed(v)
             np.random.seed(v % (2 ** 32))
             random.seed(v)
-        tagm = "recip_" if isinstance(model, tuple) else ""
+        tagm = "recip_" if isinstance(model, tuple) else ("smoothed_" if "KvsAll.label_smoothing" in opts else "")
         ref, l_ref, st = _train_epoch(root, folder, f"j_plain_{tagm}{case}", model, plain, dim, opts, before_epoch=seed_like_sharded)
         sopts = dict(opts)
         sopts["eval.type"] = "hip_sharded_entity_ranking"
@@ -788,7 +794,7 @@ def test_j_sharded_jobs_behind_the_plugin_api_on_the_gpu(data, monkeypatch, case
         assert type(shd).__name__.startswith("HipShardedTrainingJob") and dist.is_initialized()
         assert dist.get_backend() == "nccl" and shd._sh.table.collectives
         d = _param_diff(shd, ref) if case != "negative_sampling" else None
-        if tagm:
+        if tagm == "recip_":
             assert shd._sh.table.reciprocal_R == R
         _log(case=f"j: hip_sharded_{case} {tagm}(one RCCL rank, collectives forced) vs {plain}", loss_plain=l_ref,
              loss_sharded=l_shd, rel=_rel(l_shd, l_ref), param_rel_diff_own_rows=d)

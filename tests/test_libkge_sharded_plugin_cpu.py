@@ -30,6 +30,11 @@ CASES = {
     "1vsAll-complex": ("hip_complex", 16, "hip_sharded_1vsAll", "hip_1vsAll", {}),
     "KvsAll-distmult-kl": ("hip_distmult", 16, "hip_sharded_KvsAll", "hip_KvsAll", {"train.loss": "kl"}),
     "KvsAll-complex-bce": ("complex", 16, "hip_sharded_KvsAll", "KvsAll", {"train.loss": "bce"}),
+    # KvsAll.label_smoothing (train_KvsAll.py:260-266) under kl, against the REFERENCE model and job: the uniform part of
+    # the smoothed labels is a per-row bias of the gradient kernel and ONE score per query against each shard's column sum
+    "KvsAll-complex-kl-smoothed": ("complex", 16, "hip_sharded_KvsAll", "KvsAll", {
+        "train.loss": "kl", "KvsAll.label_smoothing": 0.3, "lookup_embedder.initialize": "normal_",
+        "lookup_embedder.initialize_args.normal_.mean": 0.0, "lookup_embedder.initialize_args.normal_.std": 0.1}),
     "negative_sampling-transe": ("hip_transe", 16, "hip_sharded_negative_sampling", "hip_negative_sampling",
                                  {"negative_sampling.num_samples.s": 7, "negative_sampling.num_samples.o": 5,
                                   "negative_sampling.implementation": "triple", "hip_transe.l_norm": 2.0}),
@@ -314,6 +319,7 @@ def test_one_shard_job_with_embedder_dropout_equals_the_reference_job(tmp_path):
     -- `complex` + `1vsAll` / `KvsAll` with entity dropout 0.3 and relation dropout 0.2, plus a penalty term --: epoch
     losses, penalties, validation metrics, final parameters.  (Two shards draw their table masks per rank: the masks
     handed in, tests/test_sharded_gloo_cpu.py.)"""
+    rh.import_reference()
     import kge_amd.libkge_plugin.sharded_job as sj
     from test_sharded_gloo_cpu import OracleBackend
     tmp = str(tmp_path)
@@ -321,6 +327,7 @@ def test_one_shard_job_with_embedder_dropout_equals_the_reference_job(tmp_path):
              "lookup_embedder.regularize_weight": 0.01}
     for sharded_type, plain_type, more in (("hip_sharded_1vsAll", "1vsAll", {}),
                                            ("hip_sharded_KvsAll", "KvsAll", {"train.loss": "kl"}),
+                                           ("hip_sharded_KvsAll", "KvsAll", {"train.loss": "kl", "KvsAll.label_smoothing": 0.3}),
                                            ("hip_sharded_KvsAll", "KvsAll", {"train.loss": "bce"})):
         opts = dict(extra, **more)
         config = _config(tmp, "dropout_ref", "complex", 16, plain_type, "entity_ranking", opts)

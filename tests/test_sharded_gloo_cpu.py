@@ -91,7 +91,10 @@ class OracleBackend:
             sc = OracleBackend._scores(t, direction, a, pr, T)
             g = g_rows if g_rows is not None else torch.full_like(lse, g_scalar)
             y = OracleBackend._label_matrix(t, rowptr, col, col_lo)
-            G = (torch.exp(sc.detach() - lse.view(-1, 1)) - weight.view(-1, 1) * y) * g.view(-1, 1)
+            G = torch.exp(sc.detach() - lse.view(-1, 1)) - weight.view(-1, 1) * y
+            if label_bias is not None:   # label smoothing: b_i subtracted at every column (include/kge_amd.h)
+                G = G - label_bias.view(-1, 1)
+            G = G * g.view(-1, 1)
             (sc * G).sum().backward()
         return a.grad, pr.grad, T.grad
 
