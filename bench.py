@@ -104,7 +104,7 @@ def pmc_traffic(mode, group):
 _PMC_LIVE = {}
 
 
-def pmc_traffic_live(group, timeout_s=150):
+def pmc_traffic_live(group, timeout_s=90):
     """HBM bytes per GROUP launch of the dominant kernel, both query modes, from counters collected BY THIS RUN: two
     separate `rocprofv3 --pmc <counter>` passes (FETCH_SIZE, then WRITE_SIZE; counters only, no trace domain) over
     tools/v8_pmc_target.py -- 12 launches per query mode of exactly the launch the timed region issues -- spawned as
