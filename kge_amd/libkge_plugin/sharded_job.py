@@ -40,7 +40,8 @@ KvsAll; kge_amd.sharded: _dropout_loss).  Every rank starts from rank 0's parame
 What it declines, loudly (ValueError at job creation): embedder dropout under negative sampling,
 entity and relation embedders that are not plain LookupEmbedders shared between the s and o slot, a reciprocal-relations
 wrapper under negative sampling (1vsAll / KvsAll / evaluation take it: the table scores its subject direction as an sp_
-query with relation p + R, kge_amd.sharded: _recip), optimizer parameter groups, `train.loss` other than kl (1vsAll, KvsAll, negative sampling) or plain bce
+query with relation p + R, kge_amd.sharded: _recip), a second optimizer TYPE in a parameter group (groups with their own
+args are taken), `train.loss` other than kl (1vsAll, KvsAll, negative sampling) or plain bce
 (KvsAll, negative sampling), KvsAll.label_smoothing under bce (kl takes it), s_o queries, negatives for the relation slot.
 
 CPU / gloo: the CPU test (tests/test_libkge_sharded_plugin_cpu.py) runs these jobs on two gloo ranks with the test
@@ -177,10 +178,29 @@ class _ShardState(_ShardedJob):
         key = cfg.get("train.type")
         ns = slack_rows > 0
         sd = _score_dtype(cfg, key, scorer, d, dev, ns=ns)
-        opt_cfg = cfg.get("train.optimizer")
-        extra = [g for g in opt_cfg if g != "default"]
-        if extra:
-            raise ValueError(f"kge_amd: hip_sharded_* jobs support train.optimizer.default only (found groups {extra})")
+        # train.optimizer.<group> (kge/util/optimizer.py:28-95): parameters grouped by a regex over their names, a group's
+        # args on top of the default's; the groups first, in the configuration's order, then "default" -- the order torch
+        # numbers the parameters in, i.e. the checkpoint's.  Here there are two parameters to place.
+        import re
+        name_of = {id(v): k for k, v in model.named_parameters()}
+        names = {"ent": name_of[id(ent_w)], "rel": name_of[id(rel_w)]}
+        self._opt_groups, taken = [], {}
+        for gname, g in cfg.get("train.optimizer").items():
+            if gname == "default":
+                continue
+            if "type" in g:
+                raise NotImplementedError("Multiple optimizer types are not yet supported.")  # (the reference's text)
+            pat = re.compile(g["regex"])
+            members = [w for w in ("ent", "rel") if pat.match(names[w])]
+            for w in members:
+                if w in taken:
+                    raise ValueError(f"The parameters {{'{names[w]}'}}, were matched by the optimizer group {taken[w]} "
+                                     f"and ['{gname}']")
+                taken[w] = gname
+            self._opt_groups.append((gname, dict(g.get("args") or {}), members))
+        if self._opt_groups:
+            order = [w for _, _, ms in self._opt_groups for w in ms]
+            self._param_order = tuple(order + [w for w in ("ent", "rel") if w not in order])
         args = dict(cfg.get("train.optimizer.default.args"))
         lr = args.pop("lr", None)
         state = {ENT_KEY: ent_w.data, REL_KEY: rel_w.data}
@@ -201,6 +221,11 @@ class _ShardState(_ShardedJob):
 
     def _make_optimizer(self, name, lr, args):
         params = [self.ent_master, self.rel_master]
+        if getattr(self, "_opt_groups", None):
+            master = {"ent": self.ent_master, "rel": self.rel_master}
+            placed = [w for _, _, ms in self._opt_groups for w in ms]
+            params = [dict(ga, params=[master[w] for w in ms], name=gname) for gname, ga, ms in self._opt_groups]
+            params.append({"params": [master[w] for w in ("ent", "rel") if w not in placed], "name": "default"})
         kw = dict(args)
         if self._opt_lr is not None:
             kw["lr"] = self._opt_lr

@@ -151,11 +151,14 @@ class _ShardedJob:
         every per-row state tensor of the entity parameter gathered to [E, ...] (collective)."""
         sd = self.optimizer.state_dict()
         state = {}
-        for pid, prm in enumerate((self.ent_master, self.rel_master)):
+        # parameter ids in the optimizer's own order: [entities, relations] unless parameter groups (the LibKGE plugin's
+        # `train.optimizer.<group>`, sharded_job._ShardState) put them another way round
+        for pid, which in enumerate(getattr(self, "_param_order", ("ent", "rel"))):
+            prm = self.ent_master if which == "ent" else self.rel_master
             conv = {}
             for k, v in sd["state"].get(pid, {}).items():
                 if torch.is_tensor(v) and v.shape == prm.shape:
-                    conv[k] = (self._gather_rows(v) if pid == 0 else v.detach().clone()).cpu()
+                    conv[k] = (self._gather_rows(v) if which == "ent" else v.detach().clone()).cpu()
                 else:
                     conv[k] = v.detach().cpu().clone() if torch.is_tensor(v) else v
             if conv:
@@ -165,11 +168,11 @@ class _ShardedJob:
     def load_optimizer_state_dict(self, sd: dict):
         """The inverse: an unsharded optimizer state (this job's, or a reference TrainingJob's) onto this rank's rows."""
         local = {"state": {}, "param_groups": [dict(g) for g in sd["param_groups"]]}
-        for pid, prm in enumerate((self.ent_master, self.rel_master)):
+        for pid, which in enumerate(getattr(self, "_param_order", ("ent", "rel"))):
             conv = {}
             for k, v in sd["state"].get(pid, {}).items():
-                if torch.is_tensor(v) and v.dim() == 2 and v.shape[0] == (self.E if pid == 0 else self.R):
-                    conv[k] = (v[self.lo:self.hi] if pid == 0 else v).to(self.device).clone()
+                if torch.is_tensor(v) and v.dim() == 2 and v.shape[0] == (self.E if which == "ent" else self.R):
+                    conv[k] = (v[self.lo:self.hi] if which == "ent" else v).to(self.device).clone()
                 else:
                     conv[k] = v.clone() if torch.is_tensor(v) else v
             if conv:

@@ -30,6 +30,10 @@ CASES = {
     "1vsAll-complex": ("hip_complex", 16, "hip_sharded_1vsAll", "hip_1vsAll", {}),
     "KvsAll-distmult-kl": ("hip_distmult", 16, "hip_sharded_KvsAll", "hip_KvsAll", {"train.loss": "kl"}),
     "KvsAll-complex-bce": ("complex", 16, "hip_sharded_KvsAll", "KvsAll", {"train.loss": "bce"}),
+    # train.optimizer.<group> (kge/util/optimizer.py:28-95): the relation table in a group of its own (another learning
+    # rate), which also puts it FIRST in torch's parameter numbering -- the checkpoint's optimizer state must follow
+    "1vsAll-complex-optimizer-groups": ("complex", 16, "hip_sharded_1vsAll", "1vsAll", {
+        "train.optimizer.relation.regex": ".*relation_embedder.*", "train.optimizer.relation.args.lr": 0.05}),
     # KvsAll.label_smoothing (train_KvsAll.py:260-266) under kl, against the REFERENCE model and job: the uniform part of
     # the smoothed labels is a per-row bias of the gradient kernel and ONE score per query against each shard's column sum
     "KvsAll-complex-kl-smoothed": ("complex", 16, "hip_sharded_KvsAll", "KvsAll", {
