@@ -440,6 +440,28 @@ class HipReciprocalRelationsModel(_RefReciprocal):
         sub = b._targets(entity_subset) if not torch.is_grad_enabled() else entity_subset
         return torch.cat((b.score_sp(s, p, sub), b.score_sp(o, p + self._R(), sub)), dim=1)
 
+    def score_spo(self, s: Tensor, p: Tensor, o: Tensor, direction=None) -> Tensor:
+        # (reciprocal_relations_model.py:74-82: "o" scores the triple as it stands, "s" the reversed triple with p + R)
+        if not self._base_fused() or direction not in ("o", "s"):
+            return super().score_spo(s, p, o, direction)
+        if direction == "o":
+            return self._base_model.score_spo(s, p, o, "o")
+        return self._base_model.score_spo(o, p + self._R(), s, "o")
+
+    def score_neg(self, s: Tensor, p: Tensor, o: Tensor, slot: int, neg: Tensor):
+        """[n, K] scores of the positives with slot (0 = s, 2 = o) replaced by neg[i, k] -- the hook
+        HipTrainingJobNegativeSampling hands a slot's samples to (BatchNegativeSample.score, kge/util/sampler.py:263-306,
+        which asks score_spo(..., direction) of this wrapper): a corrupted SUBJECT is the corrupted object of the
+        reversed triple (o, p + R, s').  None: the sampler's own code."""
+        b = self._base_model
+        if not self._base_fused() or not hasattr(b, "score_neg"):
+            return None
+        if slot == 2:
+            return b.score_neg(s, p, o, 2, neg)
+        if slot == 0:
+            return b.score_neg(o, p + self._R(), s, 2, neg)
+        return None
+
     # ---- the fused-loss hooks of HipTrainingJob1vsAll / HipTrainingJobKvsAll (train_job.py)
     def _ce_tables(self):
         f = getattr(self._base_model, "_ce_tables", None)

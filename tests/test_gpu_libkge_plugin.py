@@ -242,6 +242,41 @@ def test_b_negative_sampling_jobs(data, model):
     assert d1 <= bound and d2 <= bound
 
 
+def test_b4_negative_sampling_over_the_hip_reciprocal_wrapper(data):
+    """Negative sampling over `hip_reciprocal_relations_model(hip_distmult)` (round 6): the wrapper's score_spo(direction)
+    and its score_neg hook -- a corrupted subject is the corrupted OBJECT of the reversed triple (o, p + R, s') -- against
+    the reference wrapper over the reference model, under the reference's job and under hip_negative_sampling (whose
+    whole-step graph capture needs score_neg_blocks, which a reciprocal model cannot offer: ONE positives vector for both
+    slots does not exist there; the fused per-slot scoring is what is taken)."""
+    root, folder = data
+    rr, hrr = "reciprocal_relations_model", "hip_reciprocal_relations_model"
+    opts = {"negative_sampling.num_samples.s": 100, "negative_sampling.num_samples.o": 100,
+            "negative_sampling.implementation": "triple"}
+    ref, l_ref, st = _train_epoch(root, folder, "b4_ref", (rr, "distmult"), "negative_sampling", 128, opts)
+    hip, l_hip, _ = _train_epoch(root, folder, "b4_hip", (hrr, "hip_distmult"), "negative_sampling", 128, opts, init_from=st)
+    from kge_amd import engine
+    calls = {"neg": 0}
+    orig = engine.score_neg
+
+    def spy(*a, **k):
+        calls["neg"] += 1
+        return orig(*a, **k)
+
+    engine.score_neg = spy
+    try:
+        fus, l_fus, _ = _train_epoch(root, folder, "b4_fus", (hrr, "hip_distmult"), "hip_negative_sampling", 128, opts,
+                                     init_from=st)
+    finally:
+        engine.score_neg = orig
+    assert type(fus).__name__ == "HipTrainingJobNegativeSampling" and calls["neg"] >= 100, calls
+    d1, d2 = _param_diff(hip, ref), _param_diff(fus, ref)
+    _log(case="b4: negative sampling over the hip reciprocal wrapper vs the reference wrapper (distmult, 2 x 100 negatives)",
+         loss_ref=l_ref, loss_hip=l_hip, loss_fused=l_fus, rel=_rel(l_hip, l_ref), rel_fused=_rel(l_fus, l_ref),
+         param_rel_diff=d1, param_rel_diff_fused=d2, score_neg_calls=calls["neg"],
+         seconds_reference=_second_epoch_seconds(ref), seconds_hip_negative_sampling=_second_epoch_seconds(fus))
+    assert _rel(l_hip, l_ref) <= 1e-4 and _rel(l_fus, l_ref) <= 1e-4 and d1 <= 1e-3 and d2 <= 1e-3
+
+
 def _eval(root, folder, tag, model, eval_type, state, chunk=-1, dim=512, opts=None):
     rh.import_reference()
     from kge import Dataset
