@@ -394,8 +394,8 @@ class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
         return self._graph_step
 
     def _fused_ok(self) -> bool:
-        if "s_o" in self.query_types:
-            return False
+        # (s_o queries -- relation targets, off by default: config-default.yaml:322-325 -- ride along: their few hundred
+        # columns go through the reference's own ops below, the entity-target queries keep the fused loss)
         if isinstance(self.loss, KLDivWithSoftmaxKgeLoss):
             return hasattr(self.model, "kl_loss_sp")
         return _plain_bce(self.loss) is not None and hasattr(self.model, "bce_loss_sp")
@@ -429,10 +429,28 @@ class HipTrainingJobKvsAll(_CudaOomText, TrainingJobKvsAll):
                 + torch.arange(total, device=cnt.device)
             per_type[query_type] = (queries[examples, 0], queries[examples, 1], rowptr, coords[idx, 1].long())
             totals[query_type] = total
+        if "s_o" in per_type:
+            # relation targets: score_so + the job's loss on the dense [n_q, R] label matrix, exactly as the reference does
+            # it (train_KvsAll.py:255-258, 279-291; label smoothing is for entity targets only there, :262-266)
+            q0, q1, rowptr, col = per_type.pop("s_o")
+            totals.pop("s_o")
+            result.forward_time -= time.time()
+            nq, R = len(q0), self.dataset.num_relations()
+            labels = torch.zeros(nq, R, device=q0.device)
+            rws = torch.repeat_interleave(torch.arange(nq, device=q0.device), rowptr[1:] - rowptr[:-1],
+                                          output_size=int(col.numel()))
+            labels[rws, col] = 1.0
+            loss_value = self.loss(self.model.score_so(q0, q1), labels) / batch_size
+            result.avg_loss += loss_value.item()
+            result.forward_time += time.time()
+            result.backward_time -= time.time()
+            if not self.is_forward_only:
+                loss_value.backward()
+            result.backward_time += time.time()
         # both query types of the subbatch: their loss rows with ONE backward (two d loss / d score passes, the gradient
         # products once over all rows, no index_add / accumulation passes of autograd in between); the reference
         # back-propagates the two losses one after the other -- the same gradients, accumulated
-        if ls == 0.0 and len(per_type) >= 1 and hasattr(self.model, "multilabel_loss_sp_po"):
+        if ls == 0.0 and len(per_type) >= 1 and hasattr(self.model, "multilabel_loss_sp_po") and "s_o" not in self.query_types:
             gs = self._graph_step_for(batch_index, batch, subbatch_slice, per_type, totals)
             if gs is not None and gs.enabled:
                 result.prepare_time -= time.time()

@@ -583,15 +583,19 @@ def test_d_reciprocal_relations_model_over_hip_distmult(data):
     assert flips <= 15 and dm <= 1e-5
 
 
-@pytest.mark.parametrize("loss,smoothing", [("kl", 0.0), ("kl", 0.1), ("bce", 0.1)])
+@pytest.mark.parametrize("loss,smoothing", [("kl", 0.0), ("kl", 0.1), ("bce", 0.1), ("kl_s_o", 0.1)])
 def test_e_kvsall_jobs_with_label_smoothing(data, loss, smoothing):
     """TrainingJobKvsAll (reference model, reference job) vs HipTrainingJobKvsAll over hip_complex with
     bf16 scoring: the fused kl / bce losses (kge_kl_fwd, kge_kl_weighted_fwd, kge_bce_fwd), with
     KvsAll.label_smoothing (train_KvsAll.py:260-266) handled by the per-row label weight plus the linear
     column-sum score (kge_amd.model.kl_fused / bce_fused)."""
     root, folder = data
-    opts = {"train.loss": loss, "KvsAll.label_smoothing": smoothing}
     tag = f"e_{loss}_{int(smoothing * 10)}"
+    s_o = loss.endswith("_s_o")   # KvsAll.query_types.s_o (round 6): relation-target queries beside the fused losses
+    loss = loss[:-4] if s_o else loss
+    opts = {"train.loss": loss, "KvsAll.label_smoothing": smoothing}
+    if s_o:
+        opts["KvsAll.query_types.s_o"] = True
     ref, l_ref, st = _train_epoch(root, folder, tag + "_ref", "complex", "KvsAll", opts=opts)
     fus, l_fus, _ = _train_epoch(
         root, folder, tag + "_fused", "hip_complex", "hip_KvsAll", init_from=st,
@@ -599,7 +603,7 @@ def test_e_kvsall_jobs_with_label_smoothing(data, loss, smoothing):
               "train.optimizer.default.args.bf16_copies": True})
     assert type(fus).__name__ == "HipTrainingJobKvsAll" and fus._fused_ok()
     d16 = _param_diff(fus, ref)
-    _log(case=f"e: hip_complex + hip_KvsAll ({loss}, label_smoothing {smoothing}) + bf16 scoring vs complex + KvsAll",
+    _log(case=f"e: hip_complex + hip_KvsAll ({loss}, label_smoothing {smoothing}{', with s_o queries' if s_o else ''}) + bf16 scoring vs complex + KvsAll",
          loss_ref=l_ref, loss_hip=l_fus, rel=_rel(l_fus, l_ref), param_rel_diff=d16,
          seconds_per_epoch_reference=_second_epoch_seconds(ref), seconds_per_epoch_fused=_second_epoch_seconds(fus))
     assert _rel(l_fus, l_ref) <= 1e-2

@@ -168,7 +168,7 @@ def _job_config(tmp, model, train_type, seed=7):
     return config
 
 
-@pytest.mark.parametrize("loss", ["kl", "bce", "kl_smoothed", "bce_smoothed"])
+@pytest.mark.parametrize("loss", ["kl", "bce", "kl_smoothed", "bce_smoothed", "kl_s_o", "bce_smoothed_s_o"])
 @pytest.mark.parametrize("ref_type,hip_type", [("1vsAll", "hip_1vsAll"), ("KvsAll", "hip_KvsAll")])
 def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type, loss):
     """Control flow of the plugin training jobs on CPU: with a model whose loss_sp / loss_po
@@ -186,6 +186,11 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type,
     data = os.path.join(str(tmp_path), "dataset_test")  # the jobs write index caches next to the data
     shutil.copytree(os.path.join(rh.REFERENCE_ROOT, "tests", "data", "dataset_test"), data)
     smoothing = 0.0
+    s_o = loss.endswith("_s_o")   # KvsAll.query_types.s_o (round 6): relation targets beside the fused entity-target losses
+    if s_o:
+        if ref_type != "KvsAll":
+            pytest.skip("query types are a KvsAll option")
+        loss = loss[:-4]
     if loss.endswith("_smoothed"):  # KvsAll.label_smoothing (train_KvsAll.py:260-266): kl_/bce_loss_*'s last argument
         if ref_type != "KvsAll":
             pytest.skip("label smoothing is a KvsAll option")
@@ -195,6 +200,8 @@ def test_fused_loss_jobs_follow_the_reference_jobs(tmp_path, ref_type, hip_type,
         config = _job_config(str(tmp_path), "complex", train_type)
         config.set("train.loss", loss)
         config.set("KvsAll.label_smoothing", smoothing)
+        if s_o:
+            config.set("KvsAll.query_types.s_o", True)
         if loss == "bce":
             config.set("train.loss_arg", -0.5)  # score offset
         torch.manual_seed(11)  # same initialisation and batch order for both jobs
